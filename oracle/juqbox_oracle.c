@@ -1,0 +1,691 @@
+/*
+ * juqbox_oracle.c -- CPU restatement (plain C, fp64, single thread) of the reference's
+ * Stormer-Verlet traceobjgrad path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is the parity oracle of the repository.  It is NOT part of the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.  The product
+ * path (juqbox.jl_amd/csrc, libjuqbox_hip.so) never links, loads or calls anything in here.
+ *
+ * Parity status: PINNED.  tests/test_oracle_golden.py checks this restatement against every
+ * Stormer-Verlet golden the reference's own test-suite holds
+ * (test/reference_solutions/{rabi,swap02,flux,cnot2,cnot2-leakieq,cnot2-jacobi,cnot3}-ref.jld2,
+ * extracted to tests/golden/ by tests/golden/make_golden.py) at the reference's own tolerance
+ * (rtol 1e-10 / atol 1e-14, test/evalGrad.jl:4-5).
+ *
+ * Each function cites the reference file:line (relative to /root/reference) it follows.
+ * All matrices are column-major Float64 like the reference's Julia arrays.
+ *
+ * "Sparse" mode mirrors the reference's use_sparse=true path (SparseMatrixCSC operators): the
+ * products only visit the entries of the sparsity pattern that KS_alloc establishes
+ * (src/evalobjgrad.jl:3072-3092), which is what makes cnot3 (Ntot=96) run in seconds.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define JQO_NEUMANN 1
+#define JQO_JACOBI 2
+
+typedef struct {
+    int n;        /* Ntot */
+    int nnz;      /* number of pattern entries */
+    int *colptr;  /* n+1 */
+    int *rowval;  /* nnz */
+} pattern_t;
+
+typedef struct {
+    /* problem (objparams fields the path needs: src/evalobjgrad.jl:53-148) */
+    int Ntot, N, Ncoupled, Nfreq, nsteps, objFuncType;
+    int solver_id, max_iter; /* linear_solver (src/linear_solvers.jl:28-65) */
+    double solver_tol;
+    double T;
+    double *Hconst;  /* Ntot*Ntot */
+    double *Hsym;    /* Ncoupled * Ntot*Ntot */
+    double *Hanti;   /* Ncoupled * Ntot*Ntot */
+    double *Uinit, *Utr, *Uti; /* Ntot*N */
+    double *wdiag;   /* Ntot: diag(wmat_real) */
+    double *Cfreq;   /* Ncoupled x Nfreq, column-major */
+    int use_sparse;
+    pattern_t patK, patS;      /* union patterns (KS_alloc :3072-3092) */
+    pattern_t *patHsym, *patHanti; /* per-operator patterns (sparse trace operator :2135-2154) */
+    /* spline parameters (bcparams, src/bsplines.jl:160-185) -- set per evaluation */
+    int D1, nCoeff;
+    double dtknot;
+    double *tcenter;
+    const double *pcof;
+} oracle_t;
+
+/* ------------------------------------------------------------------------------------------ */
+static void pattern_from_dense(pattern_t *p, int n, const double *const *mats, int nmats, int full)
+{
+    int i, j, q, cnt = 0;
+    p->n = n;
+    p->colptr = (int *)malloc((size_t)(n + 1) * sizeof(int));
+    p->rowval = (int *)malloc((size_t)n * n * sizeof(int));
+    for (j = 0; j < n; j++) {
+        p->colptr[j] = cnt;
+        for (i = 0; i < n; i++) {
+            int nz = full;
+            for (q = 0; q < nmats && !nz; q++)
+                if (mats[q][i + (size_t)j * n] != 0.0) nz = 1;
+            if (nz) p->rowval[cnt++] = i;
+        }
+    }
+    p->colptr[n] = cnt;
+    p->nnz = cnt;
+}
+
+static void pattern_free(pattern_t *p)
+{
+    free(p->colptr);
+    free(p->rowval);
+}
+
+/* Y = alpha*A*X + beta*Y over the pattern of A; A n x n, X,Y n x ncol (col-major).
+ * Stands for LinearAlgebra.mul!(Y,A,X,alpha,beta) at the call sites
+ * src/StormerVerlet.jl:264-300, 468-498 (dense dgemm) and :316-352, 514-546 (SparseArrays CSC spmm). */
+static void mul(double *Y, const double *A, const pattern_t *p, const double *X, int ncol, double alpha, double beta)
+{
+    int n = p->n, j, c, k;
+    for (c = 0; c < ncol; c++) {
+        double *y = Y + (size_t)c * n;
+        const double *x = X + (size_t)c * n;
+        if (beta == 0.0)
+            for (j = 0; j < n; j++) y[j] = 0.0;
+        else if (beta != 1.0)
+            for (j = 0; j < n; j++) y[j] *= beta;
+        for (j = 0; j < n; j++) {
+            double axj = alpha * x[j];
+            const double *a = A + (size_t)j * n;
+            for (k = p->colptr[j]; k < p->colptr[j + 1]; k++) y[p->rowval[k]] += a[p->rowval[k]] * axj;
+        }
+    }
+}
+
+static void axpy(int len, double a, const double *x, double *y)
+{
+    int i;
+    for (i = 0; i < len; i++) y[i] += a * x[i];
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* bcarrier2: src/bsplines.jl:211-304 */
+static int knot_index(const oracle_t *o, double t)
+{
+    /* k = max(3, ceil(Int64, t/dtknot + 2)); k = min(k, D1)   (bsplines.jl:224-225) -- 1-based */
+    long k = (long)ceil(t / o->dtknot + 2.0);
+    if (k < 3) k = 3;
+    if (k > o->D1) k = o->D1;
+    return (int)k;
+}
+
+static double bcarrier2(const oracle_t *o, double t, int func)
+{
+    int osc = func / 2, q_func = func % 2, freq;
+    double f = 0.0, width = 3.0 * o->dtknot;
+    int k = knot_index(o, t);
+    for (freq = 1; freq <= o->Nfreq; freq++) {
+        double fbs1 = 0.0, fbs2 = 0.0, tc, tau, b, om;
+        int offset1 = 2 * osc * o->Nfreq * o->D1 + (freq - 1) * 2 * o->D1; /* :234 */
+        int offset2 = offset1 + o->D1;                                      /* :235 */
+        /* 1st segment of nurb k (:238-241); pcof[offset+k] is 1-based -> [offset+k-1] */
+        tc = o->tcenter[k - 1];
+        tau = (t - tc) / width;
+        b = 9.0 / 8.0 + 4.5 * tau + 4.5 * tau * tau;
+        fbs1 += o->pcof[offset1 + k - 1] * b;
+        fbs2 += o->pcof[offset2 + k - 1] * b;
+        /* 2nd segment of nurb k-1 (:244-247) */
+        tc = o->tcenter[k - 2];
+        tau = (t - tc) / width;
+        b = 0.75 - 9.0 * tau * tau;
+        fbs1 += o->pcof[offset1 + k - 2] * b;
+        fbs2 += o->pcof[offset2 + k - 2] * b;
+        /* 3rd segment of nurb k-2 (:250-253) */
+        tc = o->tcenter[k - 3];
+        tau = (t - tc) / width;
+        b = 9.0 / 8.0 - 4.5 * tau + 4.5 * tau * tau;
+        fbs1 += o->pcof[offset1 + k - 3] * b;
+        fbs2 += o->pcof[offset2 + k - 3] * b;
+        om = o->Cfreq[osc + (size_t)(freq - 1) * o->Ncoupled]; /* om[osc+1,freq] */
+        if (q_func == 1)
+            f += fbs1 * sin(om * t) + fbs2 * cos(om * t); /* :258 */
+        else
+            f += fbs1 * cos(om * t) - fbs2 * sin(om * t); /* :260 */
+    }
+    return f;
+}
+
+/* gradbcarrier2!: src/bsplines.jl:321-415 */
+static void gradbcarrier2(const oracle_t *o, double t, int func, double *g)
+{
+    int osc = func / 2, q_func = func % 2, freq, seg;
+    double width = 3.0 * o->dtknot;
+    int k = knot_index(o, t);
+    memset(g, 0, (size_t)o->nCoeff * sizeof(double)); /* g .= 0.0 (:330) */
+    for (freq = 1; freq <= o->Nfreq; freq++) {
+        int offset1 = 2 * osc * o->Nfreq * o->D1 + (freq - 1) * 2 * o->D1;
+        int offset2 = offset1 + o->D1;
+        double om = o->Cfreq[osc + (size_t)(freq - 1) * o->Ncoupled];
+        double sn = sin(om * t), cs = cos(om * t);
+        for (seg = 0; seg < 3; seg++) {
+            double tc = o->tcenter[k - 1 - seg];
+            double tau = (t - tc) / width, bk;
+            if (seg == 0)
+                bk = 9.0 / 8.0 + 4.5 * tau + 4.5 * tau * tau; /* :349 */
+            else if (seg == 1)
+                bk = 0.75 - 9.0 * tau * tau; /* :361 */
+            else
+                bk = 9.0 / 8.0 - 4.5 * tau + 4.5 * tau * tau; /* :373 */
+            if (q_func == 1) {
+                g[offset1 + k - 1 - seg] = bk * sn;
+                g[offset2 + k - 1 - seg] = bk * cs;
+            } else {
+                g[offset1 + k - 1 - seg] = bk * cs;
+                g[offset2 + k - 1 - seg] = -bk * sn;
+            }
+        }
+    }
+}
+
+/* KS!: src/evalobjgrad.jl:2354-2389 (dense) / :2392-2426 (sparse); coupled controls only */
+static void KS(const oracle_t *o, double *K, double *S, double t)
+{
+    size_t nn = (size_t)o->Ntot * o->Ntot;
+    int q;
+    memcpy(K, o->Hconst, nn * sizeof(double));
+    memset(S, 0, nn * sizeof(double));
+    for (q = 0; q < o->Ncoupled; q++) {
+        double pt = bcarrier2(o, t, 2 * q);
+        double qt = bcarrier2(o, t, 2 * q + 1);
+        axpy((int)nn, pt, o->Hsym + q * nn, K);
+        axpy((int)nn, qt, o->Hanti + q * nn, S);
+    }
+}
+
+/* neumann!: src/linear_solvers.jl:81-106.  Overwrites B and uses Tm as scratch, as the reference. */
+static void neumann(const oracle_t *o, double h, const double *S, double *B, double *Tm, double *X, int nterms)
+{
+    int len = o->Ntot * o->N, j;
+    double coeff = 1.0;
+    memcpy(X, B, (size_t)len * sizeof(double));
+    memcpy(Tm, B, (size_t)len * sizeof(double));
+    for (j = 1; j <= nterms; j++) {
+        mul(Tm, S, &o->patS, B, o->N, 1.0, 0.0);
+        coeff *= (0.5 * h);
+        axpy(len, coeff, Tm, X);
+        memcpy(B, Tm, (size_t)len * sizeof(double));
+    }
+}
+
+/* jacobi!: src/linear_solvers.jl:110-153 (S is scaled by -h/2 in place and restored there; here the
+ * scaling is folded into the product).  B is left untouched, as in the reference. */
+static void jacobi(const oracle_t *o, double h, const double *S, const double *B, double *Tm, double *X, int max_iter,
+                   double tol)
+{
+    int len = o->Ntot * o->N, j, i;
+    double coeff = -0.5 * h;
+    memcpy(X, B, (size_t)len * sizeof(double));
+    for (j = 1; j <= max_iter; j++) {
+        double err = 0.0;
+        mul(Tm, S, &o->patS, X, o->N, coeff, 0.0); /* T = (coeff*S)*X */
+        for (i = 0; i < len; i++) {
+            double tnew = B[i] - Tm[i]; /* T = B - T */
+            double d = tnew - X[i];
+            err += d * d;
+            X[i] = tnew; /* X .= T */
+        }
+        if (sqrt(err) < tol) return;
+    }
+}
+
+static void solve(const oracle_t *o, double h, const double *S, double *B, double *Tm, double *X)
+{
+    if (o->solver_id == JQO_JACOBI)
+        jacobi(o, h, S, B, Tm, X, o->max_iter, o->solver_tol);
+    else
+        neumann(o, h, S, B, Tm, X, o->max_iter);
+}
+
+typedef struct {
+    double *K0, *S0, *K05, *S05, *K1, *S1;
+    double *k1, *k2, *l1, *l2, *rhs;
+} work_t;
+
+/* forward step!: src/StormerVerlet.jl:461-504 (dense) == :507-550 (sparse) */
+static double step_fwd(const oracle_t *o, work_t *w, double t, double *u, double *v, double *v05, double h)
+{
+    int len = o->Ntot * o->N, N = o->N, i;
+    mul(w->rhs, w->K05, &o->patK, u, N, 1.0, 0.0);
+    mul(w->rhs, w->S05, &o->patS, v, N, 1.0, 1.0);
+    solve(o, h, w->S05, w->rhs, v05, w->l1);
+    memcpy(v05, v, (size_t)len * sizeof(double));
+    axpy(len, 0.5 * h, w->l1, v05);
+    mul(w->k1, w->S0, &o->patS, u, N, 1.0, 0.0);
+    mul(w->k1, w->K0, &o->patK, v05, N, -1.0, 1.0);
+    mul(w->rhs, w->S1, &o->patS, u, N, 1.0, 0.0);
+    mul(w->rhs, w->S1, &o->patS, w->k1, N, 0.5 * h, 1.0);
+    mul(w->rhs, w->K1, &o->patK, v05, N, -1.0, 1.0);
+    axpy(len, 0.5 * h, w->k1, u);
+    solve(o, h, w->S1, w->rhs, w->k1, w->k2);
+    axpy(len, 0.5 * h, w->k2, u);
+    mul(w->l2, w->K05, &o->patK, u, N, 1.0, 0.0);
+    mul(w->l2, w->S05, &o->patS, v05, N, 1.0, 1.0);
+    for (i = 0; i < len; i++) v[i] = v[i] + 0.5 * h * (w->l1[i] + w->l2[i]);
+    return t + h;
+}
+
+/* adjoint step! with forcing: src/StormerVerlet.jl:255-303 == :306-356;
+ * forcing pointers may be NULL => step_no_forcing! (:365-451) */
+static double step_adj(const oracle_t *o, work_t *w, double t, double *mu, double *nu, double *X, double h,
+                       const double *uf0, const double *vf0, const double *uf1, const double *vf1)
+{
+    int len = o->Ntot * o->N, N = o->N, i;
+    mul(w->rhs, w->S0, &o->patS, mu, N, 1.0, 0.0);
+    mul(w->rhs, w->K05, &o->patK, nu, N, -1.0, 1.0);
+    if (uf0) axpy(len, 1.0, uf0, w->rhs);
+    solve(o, h, w->S0, w->rhs, w->k1, w->k2);
+    axpy(len, 0.5 * h, w->k2, mu);
+    memcpy(X, mu, (size_t)len * sizeof(double));
+    mul(w->l2, w->K0, &o->patK, X, N, 1.0, 0.0);
+    mul(w->l2, w->S05, &o->patS, nu, N, 1.0, 1.0);
+    if (vf0) axpy(len, 1.0, vf0, w->l2);
+    mul(w->rhs, w->S05, &o->patS, nu, N, 1.0, 0.0);
+    mul(w->rhs, w->S05, &o->patS, w->l2, N, 0.5 * h, 1.0);
+    mul(w->rhs, w->K1, &o->patK, X, N, 1.0, 1.0);
+    if (vf1) axpy(len, 1.0, vf1, w->rhs);
+    solve(o, h, w->S05, w->rhs, w->k2, w->l1);
+    for (i = 0; i < len; i++) nu[i] = nu[i] + (0.5 * h) * (w->l2[i] + w->l1[i]);
+    mul(w->k1, w->S1, &o->patS, X, N, 1.0, 0.0);
+    mul(w->k1, w->K05, &o->patK, nu, N, -1.0, 1.0);
+    if (uf1) axpy(len, 1.0, uf1, w->k1);
+    axpy(len, 0.5 * h, w->k1, mu);
+    return t + h;
+}
+
+/* penalf2aTrap (:2199-2208), penalf2a (:2170-2180) for Diagonal weights */
+static double penalf2aTrap(const oracle_t *o, const double *vr)
+{
+    double f = 0.0;
+    int i, j;
+    for (j = 0; j < o->N; j++)
+        for (i = 0; i < o->Ntot; i++) f += o->wdiag[i] * vr[i + (size_t)j * o->Ntot] * vr[i + (size_t)j * o->Ntot];
+    return f;
+}
+
+static double penalf2a(const oracle_t *o, const double *vr, const double *vi)
+{
+    double f = 0.0;
+    int i, j;
+    for (j = 0; j < o->N; j++)
+        for (i = 0; i < o->Ntot; i++) {
+            double a = vr[i + (size_t)j * o->Ntot], b = vi[i + (size_t)j * o->Ntot];
+            f += (a * a + 2.0 * b * b) * o->wdiag[i];
+        }
+    return f;
+}
+
+/* trace_operator(A,B,C,D) = tr(A'B + C'D): src/evalobjgrad.jl:2101-2111 */
+static double trace4(int len, const double *A, const double *B, const double *C, double csign, const double *D)
+{
+    double tr = 0.0;
+    int i;
+    for (i = 0; i < len; i++) tr += A[i] * B[i] + (csign * C[i]) * D[i];
+    return tr;
+}
+
+/* tracefidcomplex(ur, ui, vtr, vti) with ui = -vi: src/evalobjgrad.jl:2078-2084 */
+static void tracefidcomplex(const oracle_t *o, const double *ur, const double *vi, double *re, double *im)
+{
+    int len = o->Ntot * o->N;
+    /* ui = -vi:  re = tr(ur'Vtr + ui'Vti)/N ; im = tr(ur'Vti + (-ui)'Vtr)/N */
+    *re = trace4(len, ur, o->Utr, vi, -1.0, o->Uti) / o->N;
+    *im = trace4(len, ur, o->Uti, vi, 1.0, o->Utr) / o->N;
+}
+
+/* adjoint_trace_operator!(A,B,C) = tr(A' B C): src/evalobjgrad.jl:2114-2131 / :2135-2154 */
+static double adjoint_trace(const oracle_t *o, const double *A, const double *B, const pattern_t *pB, const double *C)
+{
+    int n = o->Ntot, j, c, k;
+    double tr = 0.0;
+    for (c = 0; c < o->N; c++) {
+        const double *a = A + (size_t)c * n, *cc = C + (size_t)c * n;
+        for (j = 0; j < n; j++) { /* column j of B: sum_i A[i,c] B[i,j] C[j,c] */
+            double tmp = 0.0;
+            const double *b = B + (size_t)j * n;
+            for (k = pB->colptr[j]; k < pB->colptr[j + 1]; k++) tmp += a[pB->rowval[k]] * b[pB->rowval[k]];
+            tr += tmp * cc[j];
+        }
+    }
+    return tr;
+}
+
+/* adjoint_grad_calc!: src/evalobjgrad.jl:2567-2656 (coupled controls) */
+static void adjoint_grad_calc(const oracle_t *o, const double *vr0, const double *vi05, const double *vr,
+                              const double *lr05, const double *li, const double *li0, double t0, double dt, double *gr,
+                              double *gi, double *grad_step)
+{
+    size_t nn = (size_t)o->Ntot * o->Ntot;
+    int q, nC = o->nCoeff;
+    memset(grad_step, 0, (size_t)nC * sizeof(double));
+    for (q = 0; q < o->Ncoupled; q++) {
+        const double *Hs = o->Hsym + q * nn, *Ha = o->Hanti + q * nn;
+        const pattern_t *ps = &o->patHsym[q], *pa = &o->patHanti[q];
+        int qs = 2 * q, qa = 2 * q + 1;
+        double tr;
+        gradbcarrier2(o, t0, qs, gr);
+        gradbcarrier2(o, t0, qa, gi);
+        tr = adjoint_trace(o, vr0, Ha, pa, lr05);
+        axpy(nC, -tr, gi, grad_step);
+        tr = adjoint_trace(o, vi05, Hs, ps, lr05);
+        axpy(nC, -tr, gr, grad_step);
+
+        gradbcarrier2(o, t0 + dt, qs, gr);
+        gradbcarrier2(o, t0 + dt, qa, gi);
+        axpy(nC, -tr, gr, grad_step); /* same trace as above (:2596) */
+        tr = adjoint_trace(o, vr, Ha, pa, lr05);
+        axpy(nC, -tr, gi, grad_step);
+
+        gradbcarrier2(o, t0 + 0.5 * dt, qs, gr);
+        gradbcarrier2(o, t0 + 0.5 * dt, qa, gi);
+        tr = adjoint_trace(o, vr, Hs, ps, li);
+        axpy(nC, tr, gr, grad_step);
+        tr = adjoint_trace(o, vr0, Hs, ps, li0);
+        axpy(nC, tr, gr, grad_step);
+        tr = adjoint_trace(o, vi05, Ha, pa, li);
+        axpy(nC, -tr, gi, grad_step);
+        tr = adjoint_trace(o, vi05, Ha, pa, li0);
+        axpy(nC, -tr, gi, grad_step);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+void *jqo_create(int Ntot, int N, int Ncoupled, int Nfreq, int nsteps, double T, const double *Hconst,
+                 const double *Hsym, const double *Hanti, const double *Uinit, const double *Utr, const double *Uti,
+                 const double *wdiag, const double *Cfreq, int objFuncType, int solver_id, int max_iter,
+                 double solver_tol, int use_sparse)
+{
+    oracle_t *o = (oracle_t *)calloc(1, sizeof(oracle_t));
+    size_t nn = (size_t)Ntot * Ntot, nc = (size_t)Ntot * N;
+    int q;
+    const double **mats;
+    o->Ntot = Ntot; o->N = N; o->Ncoupled = Ncoupled; o->Nfreq = Nfreq; o->nsteps = nsteps; o->T = T;
+    o->objFuncType = objFuncType; o->solver_id = solver_id; o->max_iter = max_iter; o->solver_tol = solver_tol;
+    o->use_sparse = use_sparse;
+#define DUP(dst, src, cnt) do { dst = (double *)malloc((cnt) * sizeof(double)); memcpy(dst, src, (cnt) * sizeof(double)); } while (0)
+    DUP(o->Hconst, Hconst, nn);
+    DUP(o->Hsym, Hsym, nn * Ncoupled);
+    DUP(o->Hanti, Hanti, nn * Ncoupled);
+    DUP(o->Uinit, Uinit, nc);
+    DUP(o->Utr, Utr, nc);
+    DUP(o->Uti, Uti, nc);
+    DUP(o->wdiag, wdiag, (size_t)Ntot);
+    DUP(o->Cfreq, Cfreq, (size_t)Ncoupled * Nfreq);
+#undef DUP
+    mats = (const double **)malloc((size_t)(Ncoupled + 1) * sizeof(double *));
+    mats[0] = o->Hconst;
+    for (q = 0; q < Ncoupled; q++) mats[q + 1] = o->Hsym + q * nn;
+    pattern_from_dense(&o->patK, Ntot, mats, Ncoupled + 1, !use_sparse);
+    for (q = 0; q < Ncoupled; q++) mats[q] = o->Hanti + q * nn;
+    pattern_from_dense(&o->patS, Ntot, mats, Ncoupled, !use_sparse);
+    o->patHsym = (pattern_t *)malloc((size_t)Ncoupled * sizeof(pattern_t));
+    o->patHanti = (pattern_t *)malloc((size_t)Ncoupled * sizeof(pattern_t));
+    for (q = 0; q < Ncoupled; q++) {
+        mats[0] = o->Hsym + q * nn;
+        pattern_from_dense(&o->patHsym[q], Ntot, mats, 1, !use_sparse);
+        mats[0] = o->Hanti + q * nn;
+        pattern_from_dense(&o->patHanti[q], Ntot, mats, 1, !use_sparse);
+    }
+    free(mats);
+    return o;
+}
+
+void jqo_destroy(void *h)
+{
+    oracle_t *o = (oracle_t *)h;
+    int q;
+    if (!o) return;
+    for (q = 0; q < o->Ncoupled; q++) {
+        pattern_free(&o->patHsym[q]);
+        pattern_free(&o->patHanti[q]);
+    }
+    pattern_free(&o->patK);
+    pattern_free(&o->patS);
+    free(o->patHsym); free(o->patHanti);
+    free(o->Hconst); free(o->Hsym); free(o->Hanti); free(o->Uinit); free(o->Utr); free(o->Uti);
+    free(o->wdiag); free(o->Cfreq);
+    free(o);
+}
+
+void jqo_set_max_iter(void *h, int max_iter) { ((oracle_t *)h)->max_iter = max_iter; }
+void jqo_set_target(void *h, const double *Utr, const double *Uti)
+{
+    oracle_t *o = (oracle_t *)h;
+    size_t nc = (size_t)o->Ntot * o->N;
+    memcpy(o->Utr, Utr, nc * sizeof(double));
+    memcpy(o->Uti, Uti, nc * sizeof(double));
+}
+double *jqo_hconst(void *h) { return ((oracle_t *)h)->Hconst; }
+
+/* p_k(t), q_k(t) for all coupled controls at time t -- exposes bcarrier2 for unit tests */
+int jqo_controls(void *h, const double *pcof, int ncoeff, double t, double *pq /* 2*Ncoupled */)
+{
+    oracle_t *o = (oracle_t *)h;
+    int Nsig = 2 * o->Ncoupled, k, f;
+    if (ncoeff % (Nsig * o->Nfreq) != 0) return -2;
+    o->D1 = ncoeff / (Nsig * o->Nfreq);
+    o->nCoeff = ncoeff;
+    o->dtknot = o->T / (o->D1 - 2);
+    o->tcenter = (double *)malloc((size_t)o->D1 * sizeof(double));
+    for (k = 1; k <= o->D1; k++) o->tcenter[k - 1] = o->dtknot * (k - 1.5);
+    o->pcof = pcof;
+    for (f = 0; f < Nsig; f++) pq[f] = bcarrier2(o, t, f);
+    free(o->tcenter);
+    o->tcenter = NULL;
+    return 0;
+}
+
+/* gradient of control `func` at time t -- exposes gradbcarrier2! for unit tests */
+int jqo_control_grad(void *h, int ncoeff, double t, int func, double *g)
+{
+    oracle_t *o = (oracle_t *)h;
+    int Nsig = 2 * o->Ncoupled, k;
+    if (ncoeff % (Nsig * o->Nfreq) != 0) return -2;
+    o->D1 = ncoeff / (Nsig * o->Nfreq);
+    o->nCoeff = ncoeff;
+    o->dtknot = o->T / (o->D1 - 2);
+    o->tcenter = (double *)malloc((size_t)o->D1 * sizeof(double));
+    for (k = 1; k <= o->D1; k++) o->tcenter[k - 1] = o->dtknot * (k - 1.5);
+    gradbcarrier2(o, t, func, g);
+    free(o->tcenter);
+    o->tcenter = NULL;
+    return 0;
+}
+
+/*
+ * traceobjgrad(pcof0, params, wa::Working_Arrays, verbose, evaladjoint): src/evalobjgrad.jl:504-1038
+ *
+ * out[0]=objfv out[1]=primaryobjf out[2]=secondaryobjf out[3]=traceInfidelity (:1033)
+ * totalgrad/infidelgrad/leakgrad: length ncoeff (leakgrad all-zero when objFuncType==1, where the
+ * reference returns an empty vector and infidelgrad === totalgrad, :948-952).
+ * hist_r/hist_i (optional, may be NULL): [Ntot,N,nsteps+1] state history, real part and
+ * imaginary part (usavei = -vi, :677-680, :748-752).
+ * final_state (optional): 4*Ntot*N doubles = vr,vi after the forward sweep then vr,vi after the
+ * backward sweep (reversibility diagnostics).
+ * Returns 0, or -1 for the reference's `error(...)` at :604-606, -2 for bcparams' DimensionMismatch
+ * (src/bsplines.jl:178-181).
+ */
+int jqo_traceobjgrad(void *h, const double *pcof, int ncoeff, int evaladjoint, double *out, double *totalgrad,
+                     double *infidelgrad, double *leakgrad, double *hist_r, double *hist_i, double *final_state)
+{
+    oracle_t *o = (oracle_t *)h;
+    int Ntot = o->Ntot, N = o->N, len = Ntot * N, nsteps = o->nsteps;
+    int Nsig = 2 * o->Ncoupled, k, step, i, j;
+    size_t nn = (size_t)Ntot * Ntot;
+    double T = o->T, tinv = 1.0 / T, dt = T / nsteps, t = 0.0, objfv = 0.0;
+    double primaryobjf, secondaryobjf, traceInfidelity, sre, sim;
+    work_t w;
+    double *vr, *vi, *vi05, *vr0;
+    double *buf;
+
+    /* :604-606 */
+    if (ncoeff % Nsig != 0 || ncoeff < 3 * Nsig) return -1;
+    o->D1 = ncoeff / (Nsig * o->Nfreq); /* :608 */
+    /* bcparams (bsplines.jl:173-183) */
+    if (o->Nfreq * o->D1 * Nsig != ncoeff) return -2;
+    o->nCoeff = ncoeff;
+    o->dtknot = T / (o->D1 - 2);
+    o->tcenter = (double *)malloc((size_t)o->D1 * sizeof(double));
+    for (k = 1; k <= o->D1; k++) o->tcenter[k - 1] = o->dtknot * (k - 1.5);
+    o->pcof = pcof;
+
+    buf = (double *)calloc(6 * nn + 9 * (size_t)len, sizeof(double));
+    w.K0 = buf; w.S0 = buf + nn; w.K05 = buf + 2 * nn; w.S05 = buf + 3 * nn; w.K1 = buf + 4 * nn; w.S1 = buf + 5 * nn;
+    w.k1 = buf + 6 * nn; w.k2 = w.k1 + len; w.l1 = w.k2 + len; w.l2 = w.l1 + len; w.rhs = w.l2 + len;
+    vr = w.rhs + len; vi = vr + len; vi05 = vi + len; vr0 = vi05 + len;
+
+    memcpy(vr, o->Uinit, (size_t)len * sizeof(double)); /* :651-652 */
+
+    if (hist_r) {
+        memcpy(hist_r, vr, (size_t)len * sizeof(double));
+        for (i = 0; i < len; i++) hist_i[i] = -vi[i];
+    }
+
+    /* forward time stepping loop :698-753 (order 2 => stages=1, gamma=[1.0], :507, :644) */
+    for (step = 1; step <= nsteps; step++) {
+        double forbidden0 = tinv * penalf2aTrap(o, vr), forbidden;
+        memcpy(vr0, vr, (size_t)len * sizeof(double));
+        KS(o, w.K0, w.S0, t);
+        KS(o, w.K05, w.S05, t + 0.5 * dt);
+        KS(o, w.K1, w.S1, t + dt);
+        t = step_fwd(o, &w, t, vr, vi, vi05, dt);
+        forbidden = tinv * penalf2a(o, vr, vi05);
+        /* penalf2imag == 0 for Diagonal wmat_imag (:2231-2233) */
+        objfv = objfv + dt * 0.5 * (forbidden0 + forbidden - 2.0 * 0.0);
+        if (hist_r) {
+            size_t off = (size_t)step * len;
+            memcpy(hist_r + off, vr, (size_t)len * sizeof(double));
+            for (i = 0; i < len; i++) hist_i[off + i] = -vi[i];
+        }
+    }
+
+    /* pFidType == 2 (:759): 1 - |tr(Vtg' V)/N|^2 */
+    tracefidcomplex(o, vr, vi, &sre, &sim);
+    primaryobjf = 1.0 - (sre * sre + sim * sim);
+    secondaryobjf = objfv;
+    objfv = primaryobjf + secondaryobjf;
+    traceInfidelity = 1.0 - (sre * sre + sim * sim); /* :792 */
+    out[0] = objfv; out[1] = primaryobjf; out[2] = secondaryobjf; out[3] = traceInfidelity;
+    if (final_state) {
+        memcpy(final_state, vr, (size_t)len * sizeof(double));
+        memcpy(final_state + len, vi, (size_t)len * sizeof(double));
+    }
+
+    if (evaladjoint) {
+        double *ab = (double *)calloc(14 * (size_t)len + 4 * (size_t)ncoeff, sizeof(double));
+        double *lr = ab, *lr0 = lr + len, *li = lr0 + len, *li0 = li + len, *lr05 = li0 + len;
+        double *lrn = lr05 + len, *lin = lrn + len, *li0n = lin + len, *lr05n = li0n + len;
+        double *hr0 = lr05n + len, *hi0 = hr0 + len, *hr1 = hi0 + len, *hi1 = hr1 + len;
+        double *gr = hi1 + len + len, *gi = gr + ncoeff, *gradobjfadj = gi + ncoeff, *tr_adj = gradobjfadj + ncoeff;
+        int nfrc = (o->objFuncType != 1);
+
+        t = T; /* :811 */
+        dt = -dt;
+        /* scomplex0 (:818) and init_adjoint! pFidType==2 (:2029-2042) */
+        for (j = 0; j < N; j++)
+            for (i = 0; i < Ntot; i++) {
+                size_t ix = i + (size_t)j * Ntot;
+                double rtmp = (sre * o->Utr[ix] + sim * o->Uti[ix]) / N;
+                double itmp = (sim * o->Utr[ix] - sre * o->Uti[ix]) / N;
+                lr[ix] = rtmp; lr0[ix] = rtmp; lr05[ix] = rtmp;
+                li[ix] = itmp; li0[ix] = itmp;
+            }
+        if (nfrc) { /* :848-855 */
+            memcpy(lrn, lr, (size_t)len * sizeof(double));
+            memcpy(lin, li, (size_t)len * sizeof(double));
+            memcpy(li0n, li0, (size_t)len * sizeof(double));
+            memcpy(lr05n, lr05, (size_t)len * sizeof(double));
+            memset(infidelgrad, 0, (size_t)ncoeff * sizeof(double));
+        }
+
+        /* backward time stepping loop :859-921 */
+        for (step = nsteps - 1; step >= 0; step--) {
+            double t0 = t;
+            for (j = 0; j < N; j++) /* hr0 = tinv*W*vr (:862) */
+                for (i = 0; i < Ntot; i++) hr0[i + (size_t)j * Ntot] = tinv * o->wdiag[i] * vr[i + (size_t)j * Ntot];
+            memcpy(vr0, vr, (size_t)len * sizeof(double));
+            KS(o, w.K0, w.S0, t);
+            KS(o, w.K05, w.S05, t + 0.5 * dt);
+            KS(o, w.K1, w.S1, t + dt);
+            t = step_fwd(o, &w, t, vr, vi, vi05, dt); /* :879 */
+            for (j = 0; j < N; j++)
+                for (i = 0; i < Ntot; i++) {
+                    size_t ix = i + (size_t)j * Ntot;
+                    hi0[ix] = tinv * o->wdiag[i] * vi05[ix]; /* :882 */
+                    hr1[ix] = tinv * o->wdiag[i] * vr[ix];   /* :883 (+0 from the Diagonal-zero wmat_imag, :886) */
+                    hi1[ix] = hi0[ix];                       /* :887-888 */
+                }
+            step_adj(o, &w, t0, lr, li, lr05, dt, hr0, hi0, hr1, hi1); /* :892 */
+            adjoint_grad_calc(o, vr0, vi05, vr, lr05, li, li0, t0, dt, gr, gi, tr_adj); /* :896 */
+            axpy(ncoeff, dt, tr_adj, gradobjfadj);                                      /* :898 */
+            memcpy(li0, li, (size_t)len * sizeof(double));                              /* :901-902 */
+            memcpy(lr0, lr, (size_t)len * sizeof(double));
+            if (nfrc) { /* :905-918 */
+                step_adj(o, &w, t0, lrn, lin, lr05n, dt, NULL, NULL, NULL, NULL);
+                adjoint_grad_calc(o, vr0, vi05, vr, lr05n, lin, li0n, t0, dt, gr, gi, tr_adj);
+                axpy(ncoeff, dt, tr_adj, infidelgrad);
+                memcpy(li0n, lin, (size_t)len * sizeof(double));
+            }
+        }
+        memcpy(totalgrad, gradobjfadj, (size_t)ncoeff * sizeof(double)); /* :936-937 */
+        if (nfrc) {
+            for (i = 0; i < ncoeff; i++) leakgrad[i] = totalgrad[i] - infidelgrad[i]; /* :947 */
+        } else {
+            memcpy(infidelgrad, totalgrad, (size_t)ncoeff * sizeof(double)); /* :951 */
+            memset(leakgrad, 0, (size_t)ncoeff * sizeof(double));
+        }
+        if (final_state) {
+            memcpy(final_state + 2 * len, vr, (size_t)len * sizeof(double));
+            memcpy(final_state + 3 * len, vi, (size_t)len * sizeof(double));
+        }
+        free(ab);
+    }
+    free(buf);
+    free(o->tcenter);
+    o->tcenter = NULL;
+    return 0;
+}
+
+/*
+ * eval_f_g_grad!: src/ipopt_interface.jl:24-70 -- risk-neutral quadrature loop.
+ * shift[j] (length Ntot) generalises the reference's 0.01*10^(j-2) (j>=2, 1-based; shift[0]=0):
+ * Hconst[j,j] += ep*shift[j] before, -= after each node (:41-44, :62-64).
+ * out[0]=last_infidelity out[1]=last_leak; infid_grad/leak_grad length ncoeff (zero-filled first).
+ */
+int jqo_eval_f_g_grad(void *h, const double *pcof, int ncoeff, const double *nodes, const double *weights, int nquad,
+                      const double *shift, int compute_adjoint, double *out, double *infid_grad, double *leak_grad)
+{
+    oracle_t *o = (oracle_t *)h;
+    int n = o->Ntot, i, j, rc = 0;
+    double *tg = (double *)malloc(3 * (size_t)ncoeff * sizeof(double));
+    double *ig = tg + ncoeff, *lg = ig + ncoeff, r[4];
+    out[0] = 0.0; out[1] = 0.0;
+    memset(infid_grad, 0, (size_t)ncoeff * sizeof(double));
+    memset(leak_grad, 0, (size_t)ncoeff * sizeof(double));
+    for (i = 0; i < nquad && rc == 0; i++) {
+        double ep = nodes[i];
+        for (j = 1; j < n; j++) o->Hconst[j + (size_t)j * n] += ep * shift[j];
+        rc = jqo_traceobjgrad(h, pcof, ncoeff, compute_adjoint, r, tg, ig, lg, NULL, NULL, NULL);
+        if (rc == 0) {
+            if (compute_adjoint)
+                for (j = 0; j < ncoeff; j++) {
+                    infid_grad[j] += ig[j] * weights[i];
+                    leak_grad[j] += lg[j] * weights[i];
+                }
+            out[0] += r[1] * weights[i];
+            out[1] += r[2] * weights[i];
+        }
+        for (j = 1; j < n; j++) o->Hconst[j + (size_t)j * n] -= ep * shift[j];
+    }
+    free(tg);
+    return rc;
+}
