@@ -1,0 +1,148 @@
+/*
+ * juqbox_hip.h -- C ABI of libjuqbox_hip.so: the MI355X (gfx950) replacement for Juqbox.jl's
+ * Stormer-Verlet `traceobjgrad` hot path.
+ *
+ * The reference has NO foreign-function boundary on this path (it is 100% Julia); the seam this
+ * ABI plugs into is the multiple-dispatch method
+ *     traceobjgrad(pcof0, params::objparams, wa::Working_Arrays, verbose, evaladjoint)
+ * (src/evalobjgrad.jl:504) and its ensemble caller eval_f_g_grad! (src/ipopt_interface.jl:24-70).
+ * A new working-array type whose traceobjgrad method `ccall`s the entry points below is the
+ * drop-in (INTEGRATION.md shows the Julia shim).  File:line citations are relative to the
+ * reference repository root.
+ *
+ * Conventions
+ *  - all matrices are Float64, COLUMN-MAJOR (Julia Array layout); indices in comments are 1-based
+ *    when they quote the reference.
+ *  - every pointer argument is a HOST pointer owned by the caller and only read/written during the
+ *    call; the library copies what it keeps.  The handle owns all device memory.
+ *  - every function returns 0 on success, a negative JQ_E* code otherwise; jq_last_error() gives
+ *    the message.  No C++ exception crosses this boundary.
+ *  - one handle = one in-flight call (not re-entrant), like the reference's single-threaded use.
+ *  - the handle is bound to the HIP device that was current when jq_create() ran
+ *    (jq_set_device() selects it; one process per GPU under torch.distributed / RCCL).
+ */
+#ifndef JUQBOX_HIP_H
+#define JUQBOX_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JQ_OK 0
+#define JQ_EINVAL -1      /* bad argument (the reference's @assert / error(...) sites)            */
+#define JQ_EDIM -2        /* DimensionMismatch: nCoeff != length(pcof) (src/bsplines.jl:178-181)   */
+#define JQ_EUNSUPPORTED -3/* valid for the reference but outside what the HIP path implements     */
+#define JQ_EHIP -4        /* HIP runtime failure                                                   */
+#define JQ_ENOMEM -5
+
+typedef struct jq_handle jq_handle;
+
+/*
+ * Problem description = the objparams fields the device needs (src/evalobjgrad.jl:53-148;
+ * SURVEY.md section 8 row a13).  Hard-wired in the reference and therefore not passed:
+ * use_bcarrier=true (:208), pFidType=2 (:164), sv_type=1 (:314), order=2/stages=1 (:507,:644).
+ */
+typedef struct jq_problem {
+    int32_t Ntot;          /* prod(Ne+Ng): Hilbert dimension incl. guard levels                   */
+    int32_t N;             /* prod(Ne): number of initial-condition columns                       */
+    int32_t Ncoupled;      /* number of (Hsym_ops[k], Hanti_ops[k]) control pairs                 */
+    int32_t Nfreq;         /* carrier frequencies per control = size(Cfreq,2)                     */
+    int32_t nsteps;        /* params.nsteps                                                        */
+    int32_t neumann_terms; /* params.linear_solver.max_iter (NEUMANN_SOLVER, linear_solvers.jl:37) */
+    int32_t objFuncType;   /* 1: infidelity+leak; 2/3: second, unforced adjoint gives infidelgrad  */
+    int32_t reserved;      /* must be 0                                                            */
+    double T;              /* gate duration                                                        */
+    const double *Hconst;    /* [Ntot x Ntot]                                                      */
+    const double *Hsym_ops;  /* [Ncoupled][Ntot x Ntot]                                            */
+    const double *Hanti_ops; /* [Ncoupled][Ntot x Ntot]                                            */
+    const double *Uinit;     /* [Ntot x N]                                                         */
+    const double *Utarget_r; /* [Ntot x N]  real(Utarget) (rotating frame)                         */
+    const double *Utarget_i; /* [Ntot x N]  imag(Utarget)                                          */
+    const double *wmat_real_diag; /* [Ntot] diag(params.wmat_real); Diagonal weights only          */
+    const double *Cfreq;     /* [Ncoupled x Nfreq] carrier (angular) frequencies                   */
+} jq_problem;
+
+/* Timing of the last evaluation, measured with HIP events on the library's stream. */
+typedef struct jq_timing {
+    double ms_total;        /* whole call on the device (generate + propagate + reduce)            */
+    double ms_propagate;    /* sum over launches of the forward+backward propagator kernels        */
+    double ms_generate;     /* control evaluation + K(t)/S(t) tile-stream generation               */
+    int64_t n_propagate_launches;
+    int64_t mfma_executed;  /* v_mfma_f64_16x16x4 instructions issued by the propagators (all waves)*/
+    int64_t svts;           /* state-vector-time-steps processed (columns x nsteps), SURVEY 8(d)   */
+} jq_timing;
+
+/* ---- lifetime --------------------------------------------------------------------------------*/
+int jq_device_count(void);
+int jq_set_device(int device);
+/* Replaces: objparams(...) constructor + Working_Arrays(params, nCoeff) (src/evalobjgrad.jl:152-343,
+ * :405-440): validates sizes, uploads the operators as MFMA A-fragment tile images. */
+int jq_create(const jq_problem *problem, jq_handle **out);
+void jq_destroy(jq_handle *h);
+/* Message of the last failing call on `h` (h == NULL: last jq_create failure of this thread). */
+const char *jq_last_error(const jq_handle *h);
+
+/* ---- mutations scripts apply to `params` after construction ----------------------------------*/
+/* params.linear_solver.max_iter = m (estimate_Neumann!, src/evalobjgrad.jl:2922-2925) */
+int jq_set_neumann_terms(jq_handle *h, int32_t m);
+/* change_target!(params, new_Utarget) (src/evalobjgrad.jl:1492) */
+int jq_update_target(jq_handle *h, const double *Utarget_r, const double *Utarget_i);
+/* params.Hconst is mutated freely (src/ipopt_interface.jl:41-44, run_all.jl:13-15) */
+int jq_update_hconst(jq_handle *h, const double *Hconst);
+/* params.wmat_real = orig_wmatsetup(Ne,Ng) (e.g. test/cases/cnot3-setup.jl:253) */
+int jq_update_wmat_diag(jq_handle *h, const double *wmat_real_diag);
+
+/* ---- the hot path ----------------------------------------------------------------------------*/
+/*
+ * Replaces traceobjgrad(pcof0, params, wa, false, evaladjoint) (src/evalobjgrad.jl:504-1038).
+ * out4 = { objfv, primaryobjf, secondaryobjf, traceInfidelity } (return tuple :1033/:1035; objfv
+ * excludes the Tikhonov term, which the Ipopt callbacks add: src/ipopt_interface.jl:96-98).
+ * totalgrad / infidelgrad / leakgrad: caller-allocated length ncoeff, written when evaladjoint != 0
+ * (leakgrad is zero-filled and infidelgrad == totalgrad when objFuncType == 1, where the reference
+ * returns an empty leakgrad, :948-952).  May be NULL when evaladjoint == 0.
+ * Errors: JQ_EINVAL for the reference's error at :604-606, JQ_EDIM for bcparams' DimensionMismatch.
+ */
+int jq_traceobjgrad(jq_handle *h, const double *pcof, int32_t ncoeff, int32_t evaladjoint, double *out4,
+                    double *totalgrad, double *infidelgrad, double *leakgrad);
+
+/*
+ * Replaces the verbose branch's state history (src/evalobjgrad.jl:677-680, :748-752, returned at
+ * :1031 as usaver + im*usavei): ur/ui are [Ntot x N x (nsteps+1)], ui = -vi.
+ */
+int jq_state_history(jq_handle *h, const double *pcof, int32_t ncoeff, double *ur, double *ui);
+
+/*
+ * Replaces eval_f_g_grad!(pcof, params, wa, nodes, weights, compute_adjoint)
+ * (src/ipopt_interface.jl:24-70): for each quadrature node ep_i the drift Hamiltonian is
+ * Hconst + ep_i*diag(shift) and the four weighted sums are accumulated.  All nquad evaluations run
+ * concurrently as one batch of N*nquad state columns.
+ *   shift  : [Ntot] per-level factor; NULL selects the reference's 0.01*10^(j-2), j=2..Ntot (:41-44)
+ *   out2   : { last_infidelity, last_leak } (:58-59)
+ *   infid_grad / leak_grad : [ncoeff] weighted sums of infidelgrad / leakgrad (:48-53); leak_grad is
+ *            zero-filled for objFuncType == 1.  Ignored (may be NULL) when compute_adjoint == 0.
+ * In a multi-GPU job each rank passes its shard of (nodes, weights); the caller sums the four
+ * outputs over ranks with ONE all-reduce (RCCL), see juqbox.jl_amd/ipopt_interface.py.
+ */
+int jq_eval_f_g_grad(jq_handle *h, const double *pcof, int32_t ncoeff, const double *nodes, const double *weights,
+                     int32_t nquad, const double *shift, int32_t compute_adjoint, double *out2, double *infid_grad,
+                     double *leak_grad);
+
+/*
+ * Robustness sweep (ep_plot, examples/Risk_Neutral/run_all.jl:6-32): nquad independent
+ * traceobjgrad evaluations with Hconst + ep_i*diag(shift), forward sweep only.
+ * out: [4 x nquad] column-major = { objfv, primaryobjf, secondaryobjf, traceInfidelity } per node.
+ */
+int jq_traceobj_sweep(jq_handle *h, const double *pcof, int32_t ncoeff, const double *nodes, int32_t nquad,
+                      const double *shift, double *out);
+
+/* ---- measurement -----------------------------------------------------------------------------*/
+int jq_last_timing(const jq_handle *h, jq_timing *t);
+/* Library build info: "gfx950 juqbox_hip <version>" */
+const char *jq_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JUQBOX_HIP_H */

@@ -2,5 +2,8 @@
 mirror of the reference's objparams / traceobjgrad / Ipopt-callback surface over a C-ABI library of
 hand-written gfx950 HIP kernels).  See DESIGN.md / INTEGRATION.md."""
 from . import cases, setup_utils  # noqa: F401
+from .evalobjgrad import Working_Arrays_HIP, traceobjgrad  # noqa: F401
+from .ipopt_interface import (eval_f_g_grad, eval_f_par, eval_g_par, eval_grad_f_par,  # noqa: F401
+                              eval_jac_g_par, traceobj_sweep)
 from .objparams import (JACOBI_SOLVER, NEUMANN_SOLVER, Stormer_Verlet, lsolver_object,  # noqa: F401
                         objparams)

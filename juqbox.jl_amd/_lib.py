@@ -1,0 +1,78 @@
+"""ctypes binding of libjuqbox_hip.so (C ABI: include/juqbox_hip.h).
+
+The library is the product: there is NO CPU fallback.  If the shared object is missing or a symbol
+is absent, importing/using the hot path raises immediately (build with
+`make -C juqbox.jl_amd/csrc` or `python -c "import __graft_entry__ as g; g.build()"`).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libjuqbox_hip.so")
+
+c_dp = ctypes.POINTER(ctypes.c_double)
+c_i32 = ctypes.c_int32
+
+JQ_OK, JQ_EINVAL, JQ_EDIM, JQ_EUNSUPPORTED, JQ_EHIP, JQ_ENOMEM = 0, -1, -2, -3, -4, -5
+
+
+class jq_problem(ctypes.Structure):
+    _fields_ = [("Ntot", c_i32), ("N", c_i32), ("Ncoupled", c_i32), ("Nfreq", c_i32), ("nsteps", c_i32),
+                ("neumann_terms", c_i32), ("objFuncType", c_i32), ("reserved", c_i32), ("T", ctypes.c_double),
+                ("Hconst", c_dp), ("Hsym_ops", c_dp), ("Hanti_ops", c_dp), ("Uinit", c_dp), ("Utarget_r", c_dp),
+                ("Utarget_i", c_dp), ("wmat_real_diag", c_dp), ("Cfreq", c_dp)]
+
+
+class jq_timing(ctypes.Structure):
+    _fields_ = [("ms_total", ctypes.c_double), ("ms_propagate", ctypes.c_double), ("ms_generate", ctypes.c_double),
+                ("n_propagate_launches", ctypes.c_int64), ("mfma_executed", ctypes.c_int64), ("svts", ctypes.c_int64)]
+
+
+# every symbol include/juqbox_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "jq_device_count": (ctypes.c_int, []),
+    "jq_set_device": (ctypes.c_int, [ctypes.c_int]),
+    "jq_create": (ctypes.c_int, [ctypes.POINTER(jq_problem), ctypes.POINTER(ctypes.c_void_p)]),
+    "jq_destroy": (None, [ctypes.c_void_p]),
+    "jq_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
+    "jq_set_neumann_terms": (ctypes.c_int, [ctypes.c_void_p, c_i32]),
+    "jq_update_target": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp]),
+    "jq_update_hconst": (ctypes.c_int, [ctypes.c_void_p, c_dp]),
+    "jq_update_wmat_diag": (ctypes.c_int, [ctypes.c_void_p, c_dp]),
+    "jq_traceobjgrad": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_i32, c_i32, c_dp, c_dp, c_dp, c_dp]),
+    "jq_state_history": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_i32, c_dp, c_dp]),
+    "jq_eval_f_g_grad": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_i32, c_dp, c_dp, c_i32, c_dp, c_i32, c_dp, c_dp, c_dp]),
+    "jq_traceobj_sweep": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_i32, c_dp, c_i32, c_dp, c_dp]),
+    "jq_last_timing": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(jq_timing)]),
+    "jq_version": (ctypes.c_char_p, []),
+}
+
+_lib = None
+
+
+class JuqboxHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libjuqbox_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def load():
+    """Load the C-ABI library (once) and bind every declared symbol.  Raises if anything is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libjuqbox_hip.so not built: %s is missing (run `make -C juqbox.jl_amd/csrc`); "
+                              "there is no CPU fallback for the hot path" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)          # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, handle=None):
+    if rc != JQ_OK:
+        msg = load().jq_last_error(handle)
+        raise JuqboxHipError(rc, msg.decode() if msg else "?")

@@ -1,0 +1,228 @@
+// jq_aux_kernels.h -- the small kernels around the propagators: on-device control evaluation
+// (bcarrier2), K(t)/S(t) tile-stream generation, state initialisation, fidelity + adjoint terminal
+// condition, trace reduction and gradient assembly (gradbcarrier2! as an 18-entry scatter).
+#pragma once
+#include "jq_kernels.h"
+
+struct SplineArgs {
+    const double* pcof;   // [nCoeff]
+    const double* cfreq;  // [Ncoupled x Nfreq] column-major
+    int D1, Nfreq, Ncoupled, nCoeff;
+    double dtknot;        // T/(D1-2)            (bcparams, src/bsplines.jl:174)
+};
+
+// knot index k (1-based) of bcarrier2 / gradbcarrier2! (src/bsplines.jl:224-225, :335-336)
+__device__ __forceinline__ int knot_index(double t, double dtknot, int D1)
+{
+    int k = (int)ceil(t / dtknot + 2.0);
+    k = k < 3 ? 3 : k;
+    k = k > D1 ? D1 : k;
+    return k;
+}
+
+// bcarrier2(t, params, func): src/bsplines.jl:211-304
+__device__ double bcarrier2_dev(const SplineArgs& s, double t, int func)
+{
+    const int osc = func >> 1, q_func = func & 1;
+    const double width = 3.0 * s.dtknot;
+    const int k = knot_index(t, s.dtknot, s.D1);
+    double f = 0.0;
+    for (int freq = 0; freq < s.Nfreq; ++freq) {
+        const int offset1 = 2 * osc * s.Nfreq * s.D1 + freq * 2 * s.D1;
+        const int offset2 = offset1 + s.D1;
+        double fbs1 = 0.0, fbs2 = 0.0, tc, tau, b;
+        tc = s.dtknot * ((double)k - 1.5);           // tcenter[k]   (:175, :238)
+        tau = (t - tc) / width;
+        b = 9.0 / 8.0 + 4.5 * tau + 4.5 * tau * tau;
+        fbs1 += s.pcof[offset1 + k - 1] * b;
+        fbs2 += s.pcof[offset2 + k - 1] * b;
+        tc = s.dtknot * ((double)(k - 1) - 1.5);     // tcenter[k-1] (:244)
+        tau = (t - tc) / width;
+        b = 0.75 - 9.0 * tau * tau;
+        fbs1 += s.pcof[offset1 + k - 2] * b;
+        fbs2 += s.pcof[offset2 + k - 2] * b;
+        tc = s.dtknot * ((double)(k - 2) - 1.5);     // tcenter[k-2] (:250)
+        tau = (t - tc) / width;
+        b = 9.0 / 8.0 - 4.5 * tau + 4.5 * tau * tau;
+        fbs1 += s.pcof[offset1 + k - 3] * b;
+        fbs2 += s.pcof[offset2 + k - 3] * b;
+        const double om = s.cfreq[osc + freq * s.Ncoupled];
+        double sn, cs;
+        sincos(om * t, &sn, &cs);
+        if (q_func)
+            f += fbs1 * sn + fbs2 * cs;   // :258
+        else
+            f += fbs1 * cs - fbs2 * sn;   // :260
+    }
+    return f;
+}
+
+// time of stream point j of a chunk: t_n (j even) or t_n + h/2 (j odd); t_n is read from the
+// host-accumulated table (t = t + h, src/StormerVerlet.jl:502; the backward table starts at exactly T,
+// src/evalobjgrad.jl:811) so that knot indices match the reference to the ulp.
+__device__ __forceinline__ double stream_time(const double* tt, int n0, int j, double h)
+{
+    const double t = tt[n0 + (j >> 1)];
+    return (j & 1) ? t + 0.5 * h : t;
+}
+
+// pq[j][2*Ncoupled] = (p_1, q_1, p_2, q_2, ...)(t_j)   -- KS!'s controlfunc calls (src/evalobjgrad.jl:2366-2367)
+__global__ void k_ctrl(SplineArgs s, const double* tt, int n0, int ntp, double h, double* pq)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ntp) return;
+    const double t = stream_time(tt, n0, j, h);
+    for (int f = 0; f < 2 * s.Ncoupled; ++f) pq[(size_t)j * 2 * s.Ncoupled + f] = bcarrier2_dev(s, t, f);
+}
+
+// KS!: K = Hconst + sum_q p_q Hsym_q ; S = sum_q q_q Hanti_q  (src/evalobjgrad.jl:2354-2370), evaluated
+// on the MFMA tile images.  grid = (mat_elems/256, ntp)
+__global__ void k_stream(const double* __restrict__ himg, const double* __restrict__ pq, int Ncoupled, long long mat_elems,
+                         double* __restrict__ stream)
+{
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (e >= mat_elems) return;
+    const double* c = pq + (size_t)j * 2 * Ncoupled;
+    double K = himg[e], S = 0.0;
+    for (int q = 0; q < Ncoupled; ++q) {
+        K += c[2 * q] * himg[(size_t)(1 + q) * mat_elems + e];
+        S += c[2 * q + 1] * himg[(size_t)(1 + Ncoupled + q) * mat_elems + e];
+    }
+    stream[(size_t)(2 * j) * mat_elems + e] = K;
+    stream[(size_t)(2 * j + 1) * mat_elems + e] = S;
+}
+
+// state file <- (Uinit, 0, 0, 0, extras 0); grid = nslabs, block = 64
+__global__ void k_init_state(double* state, long long stride, const double* __restrict__ uimg, int KT)
+{
+    double* st = state + (size_t)blockIdx.x * stride;
+    const int lane = threadIdx.x;
+    for (int kk = 0; kk < KT; ++kk) {
+        st[kk * 64 + lane] = uimg[kk * 64 + lane];
+        st[(KT + kk) * 64 + lane] = 0.0;
+        st[(2 * KT + kk) * 64 + lane] = 0.0;
+        st[(3 * KT + kk) * 64 + lane] = 0.0;
+    }
+    for (int r = 0; r < JQ_STATE_EXTRA; ++r) st[(JQ_STATE_ARRAYS * KT + r) * 64 + lane] = 0.0;
+}
+
+// Fidelity, leak integral and adjoint terminal condition per sample.
+//   s = tr(Vtg' V)/N with ur = vr, ui = -vi (tracefidcomplex, src/evalobjgrad.jl:2078-2084)
+//   primaryobjf = 1 - |s|^2 (:759) ; secondaryobjf = dt/2 * tinv * sum(leak partials) (:716-718)
+//   lambda(T) (init_adjoint!, :2029-2042)
+// res[sample][4] = { primaryobjf, secondaryobjf, Re s, Im s }.   grid = nslabs, block = 64
+__global__ void k_terminal(double* state, long long stride, const double* __restrict__ vtr_img,
+                           const double* __restrict__ vti_img, int KT, int N, int sps, int nsamples, double leak_scale,
+                           double* res)
+{
+    __shared__ double part[3][64];
+    double* st = state + (size_t)blockIdx.x * stride;
+    const int lane = threadIdx.x;
+    const int col = lane & 15;
+    const int sl = (col < sps * N) ? col / N : -1;
+    double re = 0.0, im = 0.0;
+    for (int kk = 0; kk < KT; ++kk) {
+        const double u = st[kk * 64 + lane], v = st[(KT + kk) * 64 + lane];
+        const double tr = vtr_img[kk * 64 + lane], ti = vti_img[kk * 64 + lane];
+        re += u * tr - v * ti;
+        im += u * ti + v * tr;
+    }
+    part[0][lane] = re;
+    part[1][lane] = im;
+    part[2][lane] = st[(JQ_STATE_ARRAYS * KT + JQ_MAXNC) * 64 + lane];
+    __syncthreads();
+    double sre = 0.0, sim = 0.0, slk = 0.0;
+    for (int l = 0; l < 64; ++l) {
+        const int c2 = l & 15;
+        const int s2 = (c2 < sps * N) ? c2 / N : -1;
+        if (s2 == sl && sl >= 0) {
+            sre += part[0][l];
+            sim += part[1][l];
+            slk += part[2][l];
+        }
+    }
+    sre /= N;
+    sim /= N;
+    for (int kk = 0; kk < KT; ++kk) {
+        const double tr = vtr_img[kk * 64 + lane], ti = vti_img[kk * 64 + lane];
+        st[(2 * KT + kk) * 64 + lane] = (sl >= 0) ? (sre * tr + sim * ti) / N : 0.0;  // lambdar
+        st[(3 * KT + kk) * 64 + lane] = (sl >= 0) ? (sim * tr - sre * ti) / N : 0.0;  // lambdai
+    }
+    const int sample = blockIdx.x * sps + sl;
+    if (sl >= 0 && (col % N) == 0 && (lane >> 4) == 0 && sample < nsamples) {
+        res[(size_t)sample * 4 + 0] = 1.0 - (sre * sre + sim * sim);
+        res[(size_t)sample * 4 + 1] = leak_scale * slk;
+        res[(size_t)sample * 4 + 2] = sre;
+        res[(size_t)sample * 4 + 3] = sim;
+    }
+}
+
+// R[m][k] = sum_slab traces[slab][m][k] in slab order (deterministic).  thread per (m,k)
+__global__ void k_trace_reduce(const double* __restrict__ traces, int nslabs, int nsteps_chunk, int ntr, double* R)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long tot = (long long)nsteps_chunk * ntr;
+    if (i >= tot) return;
+    double s = 0.0;
+    for (int sl = 0; sl < nslabs; ++sl) s += traces[(size_t)sl * tot + i];
+    R[i] = s;
+}
+
+// Gradient assembly for one chunk of backward steps: adjoint_grad_calc! + gradbcarrier2!
+// (src/evalobjgrad.jl:2581-2618, src/bsplines.jl:321-415) + gradobjfadj += dt*tr_adj (:898).
+// One thread per coefficient; each (step, time point) touches it only when its knot window covers it.
+__global__ void k_gradacc(SplineArgs s, const double* __restrict__ R, const double* __restrict__ tb, int n0,
+                          int nsteps_chunk, double h, double* grad)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= s.nCoeff) return;
+    const int per_osc = 2 * s.Nfreq * s.D1;
+    const int q = idx / per_osc;
+    const int rem = idx - q * per_osc;
+    const int freq = rem / (2 * s.D1);
+    const int rem2 = rem - freq * 2 * s.D1;
+    const int part = rem2 / s.D1;          // 0: offset1 block (alpha_1), 1: offset2 block (alpha_2)
+    const int kc = rem2 - part * s.D1 + 1; // 1-based coefficient number within the block
+    const double om = s.cfreq[q + freq * s.Ncoupled];
+    const double width = 3.0 * s.dtknot;
+    const double tc = s.dtknot * ((double)kc - 1.5);
+    const int ntr = s.Ncoupled * JQ_NTR;
+    double acc = 0.0;
+    for (int m = 0; m < nsteps_chunk; ++m) {
+        const double t0 = tb[n0 + m];
+        const double* r = R + (size_t)m * ntr + q * JQ_NTR;
+        double step_acc = 0.0;
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+            const double tau_t = (w == 0) ? t0 : (w == 1 ? t0 + h : t0 + 0.5 * h);
+            const int k = knot_index(tau_t, s.dtknot, s.D1);
+            const int jj = k - kc;
+            if (jj < 0 || jj > 2) continue;
+            double P, Q;
+            if (w == 0) {
+                P = -r[1];
+                Q = -r[0];
+            } else if (w == 1) {
+                P = -r[1];
+                Q = -r[2];
+            } else {
+                P = r[3];
+                Q = -r[4];
+            }
+            const double tau = (tau_t - tc) / width;
+            double b;
+            if (jj == 0)
+                b = 9.0 / 8.0 + 4.5 * tau + 4.5 * tau * tau;
+            else if (jj == 1)
+                b = 0.75 - 9.0 * tau * tau;
+            else
+                b = 9.0 / 8.0 - 4.5 * tau + 4.5 * tau * tau;
+            double sn, cs;
+            sincos(om * tau_t, &sn, &cs);
+            step_acc += b * (part == 0 ? (P * cs + Q * sn) : (-P * sn + Q * cs));
+        }
+        acc += h * step_acc;
+    }
+    grad[idx] += acc;
+}

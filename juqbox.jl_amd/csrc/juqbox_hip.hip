@@ -1,0 +1,653 @@
+// juqbox_hip.hip -- C ABI (include/juqbox_hip.h) and host orchestration of the gfx950 propagator.
+//
+// One evaluation = { forward sweep, terminal condition, backward sweep(s), gradient assembly } over a
+// batch of N*nsamples state columns.  Time is processed in chunks: for each chunk the controls are
+// evaluated on the device (k_ctrl), the K(t)/S(t) tile stream is generated into a reusable HBM buffer
+// (k_stream) and one persistent propagator launch consumes it (k_forward / k_backward).  Everything
+// runs in order on the handle's HIP stream; the call returns after one stream synchronisation.
+#include "../../include/juqbox_hip.h"
+#include "jq_aux_kernels.h"
+#include "jq_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define JQ_VERSION "gfx950 juqbox_hip 0.1.0"
+
+static thread_local std::string g_create_error;
+
+struct jq_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // problem
+    int Ntot = 0, N = 0, Nc = 0, Nfreq = 0, nsteps = 0, m = 0, objFuncType = 1;
+    double T = 0.0;
+    int NT = 0, KT = 0, NP = 0, sps = 0;
+    long long mat_elems = 0;
+    long long state_stride = 0;
+    std::vector<double> Hconst, Hsym, Hanti, Uinit, Utr, Uti, wd, cfreq;
+    std::vector<double> tf, tb;
+    // device buffers (owned)
+    double *d_himg = nullptr, *d_uimg = nullptr, *d_vtr = nullptr, *d_vti = nullptr, *d_tabs = nullptr;
+    double *d_tf = nullptr, *d_tb = nullptr, *d_cfreq = nullptr, *d_pcof = nullptr;
+    double *d_stream = nullptr, *d_pq = nullptr;
+    double *d_state = nullptr, *d_state_save = nullptr, *d_colinfo = nullptr, *d_traces = nullptr, *d_R = nullptr;
+    double *d_grad = nullptr, *d_res = nullptr;
+    size_t cap_pcof = 0, cap_slabs = 0, cap_traces = 0, cap_grad = 0, cap_res = 0;
+    int chunk_steps = 0;
+    std::vector<hipEvent_t> ev;
+    std::string err;
+    jq_timing timing = {};
+};
+
+#define HIPCHK(h, call)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            char buf_[512];                                                                          \
+            snprintf(buf_, sizeof buf_, "HIP error '%s' at %s:%d (%s)", hipGetErrorString(e_), __FILE__, __LINE__, #call); \
+            (h)->err = buf_;                                                                         \
+            return JQ_EHIP;                                                                          \
+        }                                                                                            \
+    } while (0)
+
+static int fail(jq_handle* h, int code, const char* msg)
+{
+    h->err = msg;
+    return code;
+}
+
+// A-fragment tile image of a column-major Ntot x Ntot matrix, walk order (kk outer, mt inner):
+// tile (mt,kk) lane l holds M[16*mt + (l&15)][4*kk + (l>>4)]; zero padded.
+static void tile_image(const double* M, int Ntot, int NT, double* img)
+{
+    const int KT = 4 * NT;
+    for (int kk = 0; kk < KT; ++kk)
+        for (int mt = 0; mt < NT; ++mt)
+            for (int l = 0; l < 64; ++l) {
+                const int row = 16 * mt + (l & 15), col = 4 * kk + (l >> 4);
+                img[((size_t)kk * NT + mt) * 64 + l] = (row < Ntot && col < Ntot) ? M[row + (size_t)Ntot * col] : 0.0;
+            }
+}
+
+// register-layout image [KT][64] of an Ntot x N array replicated over the samples of a slab
+static void slab_image(const double* A, int Ntot, int N, int sps, int KT, double* img)
+{
+    for (int kk = 0; kk < KT; ++kk)
+        for (int l = 0; l < 64; ++l) {
+            const int row = 4 * kk + (l >> 4), col = l & 15;
+            img[kk * 64 + l] = (row < Ntot && col < sps * N) ? A[row + (size_t)Ntot * (col % N)] : 0.0;
+        }
+}
+
+template <typename T>
+static int dev_alloc(jq_handle* h, T** p, size_t count)
+{
+    if (*p) {
+        hipFree(*p);
+        *p = nullptr;
+    }
+    HIPCHK(h, hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T)));
+    return JQ_OK;
+}
+
+static int upload_operators(jq_handle* h)
+{
+    const size_t nn = (size_t)h->Ntot * h->Ntot;
+    std::vector<double> img((size_t)(1 + 2 * h->Nc) * h->mat_elems, 0.0);
+    tile_image(h->Hconst.data(), h->Ntot, h->NT, img.data());
+    for (int q = 0; q < h->Nc; ++q) {
+        tile_image(h->Hsym.data() + q * nn, h->Ntot, h->NT, img.data() + (size_t)(1 + q) * h->mat_elems);
+        tile_image(h->Hanti.data() + q * nn, h->Ntot, h->NT, img.data() + (size_t)(1 + h->Nc + q) * h->mat_elems);
+    }
+    HIPCHK(h, hipMemcpy(h->d_himg, img.data(), img.size() * sizeof(double), hipMemcpyHostToDevice));
+    return JQ_OK;
+}
+
+static int upload_targets(jq_handle* h)
+{
+    std::vector<double> img((size_t)h->KT * 64);
+    slab_image(h->Utr.data(), h->Ntot, h->N, h->sps, h->KT, img.data());
+    HIPCHK(h, hipMemcpy(h->d_vtr, img.data(), img.size() * sizeof(double), hipMemcpyHostToDevice));
+    slab_image(h->Uti.data(), h->Ntot, h->N, h->sps, h->KT, img.data());
+    HIPCHK(h, hipMemcpy(h->d_vti, img.data(), img.size() * sizeof(double), hipMemcpyHostToDevice));
+    return JQ_OK;
+}
+
+extern "C" int jq_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int jq_set_device(int device) { return hipSetDevice(device) == hipSuccess ? JQ_OK : JQ_EHIP; }
+
+extern "C" const char* jq_version(void) { return JQ_VERSION; }
+
+extern "C" const char* jq_last_error(const jq_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+extern "C" void jq_destroy(jq_handle* h)
+{
+    if (!h) return;
+    hipSetDevice(h->device);
+    double** bufs[] = {&h->d_himg,  &h->d_uimg,       &h->d_vtr,     &h->d_vti,    &h->d_tabs, &h->d_tf,   &h->d_tb,
+                       &h->d_cfreq, &h->d_pcof,       &h->d_stream,  &h->d_pq,     &h->d_state, &h->d_state_save,
+                       &h->d_colinfo, &h->d_traces,   &h->d_R,       &h->d_grad,   &h->d_res};
+    for (auto b : bufs)
+        if (*b) hipFree(*b);
+    for (auto e : h->ev) hipEventDestroy(e);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+static int create_impl(const jq_problem* p, jq_handle* h)
+{
+    if (!p) return fail(h, JQ_EINVAL, "jq_create: problem is NULL");
+    if (p->Ntot < 1 || p->N < 1 || p->N > p->Ntot) return fail(h, JQ_EINVAL, "jq_create: need 1 <= N <= Ntot");
+    if (p->nsteps < 1 || !(p->T > 0.0)) return fail(h, JQ_EINVAL, "jq_create: need nsteps >= 1 and T > 0");
+    if (p->Nfreq < 1) return fail(h, JQ_EINVAL, "jq_create: need Nfreq >= 1");
+    if (p->neumann_terms < 0) return fail(h, JQ_EINVAL, "jq_create: neumann_terms must be >= 0");
+    if (p->reserved != 0) return fail(h, JQ_EINVAL, "jq_create: reserved must be 0");
+    if (!p->Hconst || !p->Hsym_ops || !p->Hanti_ops || !p->Uinit || !p->Utarget_r || !p->Utarget_i ||
+        !p->wmat_real_diag || !p->Cfreq)
+        return fail(h, JQ_EINVAL, "jq_create: NULL array in problem description");
+    if (p->Ncoupled < 1) return fail(h, JQ_EUNSUPPORTED, "jq_create: at least one coupled control pair is required");
+    if (p->Ncoupled > JQ_MAXNC) return fail(h, JQ_EUNSUPPORTED, "jq_create: Ncoupled > 4 is not supported");
+    if (p->Ntot > 96)
+        return fail(h, JQ_EUNSUPPORTED, "jq_create: Ntot > 96 does not fit the two-slot LDS operator ring");
+    if (p->N > 16) return fail(h, JQ_EUNSUPPORTED, "jq_create: N > 16 (more than one 16-column slab per sample)");
+    if (p->objFuncType < 1 || p->objFuncType > 3) return fail(h, JQ_EINVAL, "jq_create: objFuncType must be 1, 2 or 3");
+
+    HIPCHK(h, hipGetDevice(&h->device));
+    hipDeviceProp_t prop;
+    HIPCHK(h, hipGetDeviceProperties(&prop, h->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        char buf[256];
+        snprintf(buf, sizeof buf, "jq_create: device arch '%s' is not gfx950 (this library is MI355X-only)", prop.gcnArchName);
+        return fail(h, JQ_EUNSUPPORTED, buf);
+    }
+    HIPCHK(h, hipStreamCreate(&h->stream));
+
+    h->Ntot = p->Ntot; h->N = p->N; h->Nc = p->Ncoupled; h->Nfreq = p->Nfreq; h->nsteps = p->nsteps;
+    h->m = p->neumann_terms; h->objFuncType = p->objFuncType; h->T = p->T;
+    h->NT = (p->Ntot + 15) / 16;
+    h->KT = 4 * h->NT;
+    h->NP = 16 * h->NT;
+    h->sps = 16 / p->N;
+    h->mat_elems = ((256LL * h->NT * h->NT + 511) / 512) * 512;
+    h->state_stride = (long long)(JQ_STATE_ARRAYS * h->KT + JQ_STATE_EXTRA) * 64;
+    const size_t nn = (size_t)p->Ntot * p->Ntot, nc = (size_t)p->Ntot * p->N;
+    h->Hconst.assign(p->Hconst, p->Hconst + nn);
+    h->Hsym.assign(p->Hsym_ops, p->Hsym_ops + nn * p->Ncoupled);
+    h->Hanti.assign(p->Hanti_ops, p->Hanti_ops + nn * p->Ncoupled);
+    h->Uinit.assign(p->Uinit, p->Uinit + nc);
+    h->Utr.assign(p->Utarget_r, p->Utarget_r + nc);
+    h->Uti.assign(p->Utarget_i, p->Utarget_i + nc);
+    h->wd.assign(p->wmat_real_diag, p->wmat_real_diag + p->Ntot);
+    h->cfreq.assign(p->Cfreq, p->Cfreq + (size_t)p->Ncoupled * p->Nfreq);
+
+    // time tables, accumulated exactly like the reference: t = t + h (src/StormerVerlet.jl:502);
+    // the backward sweep restarts from exactly T with h = -dt (src/evalobjgrad.jl:811-812)
+    const double dt = h->T / h->nsteps;
+    h->tf.resize(h->nsteps + 1);
+    h->tb.resize(h->nsteps + 1);
+    double t = 0.0;
+    for (int n = 0; n <= h->nsteps; ++n) {
+        h->tf[n] = t;
+        t = t + dt;
+    }
+    t = h->T;
+    for (int n = 0; n <= h->nsteps; ++n) {
+        h->tb[n] = t;
+        t = t + (-dt);
+    }
+
+    int rc;
+    if ((rc = dev_alloc(h, &h->d_himg, (size_t)(1 + 2 * h->Nc) * h->mat_elems))) return rc;
+    if ((rc = dev_alloc(h, &h->d_uimg, (size_t)h->KT * 64))) return rc;
+    if ((rc = dev_alloc(h, &h->d_vtr, (size_t)h->KT * 64))) return rc;
+    if ((rc = dev_alloc(h, &h->d_vti, (size_t)h->KT * 64))) return rc;
+    if ((rc = dev_alloc(h, &h->d_tabs, (size_t)32 * h->NT))) return rc;
+    if ((rc = dev_alloc(h, &h->d_tf, (size_t)h->nsteps + 1))) return rc;
+    if ((rc = dev_alloc(h, &h->d_tb, (size_t)h->nsteps + 1))) return rc;
+    if ((rc = dev_alloc(h, &h->d_cfreq, h->cfreq.size()))) return rc;
+    HIPCHK(h, hipMemcpy(h->d_tf, h->tf.data(), h->tf.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->d_tb, h->tb.data(), h->tb.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->d_cfreq, h->cfreq.data(), h->cfreq.size() * sizeof(double), hipMemcpyHostToDevice));
+    if ((rc = upload_operators(h))) return rc;
+    if ((rc = upload_targets(h))) return rc;
+    {
+        std::vector<double> img((size_t)h->KT * 64);
+        slab_image(h->Uinit.data(), h->Ntot, h->N, h->sps, h->KT, img.data());
+        HIPCHK(h, hipMemcpy(h->d_uimg, img.data(), img.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+
+    // chunking of the time loop: the tile stream of one chunk has (2*cs+1) time points x {K,S}
+    size_t budget = (size_t)1 << 30;
+    if (const char* e = getenv("JQ_STREAM_BYTES")) {
+        const long long v = atoll(e);
+        if (v > 0) budget = (size_t)v;
+    }
+    const size_t per_tp = 2 * (size_t)h->mat_elems * sizeof(double);
+    long long cs = ((long long)(budget / per_tp) - 1) / 2;
+    cs = std::max<long long>(1, std::min<long long>(cs, h->nsteps));
+    if (const char* e = getenv("JQ_CHUNK_STEPS")) {
+        const long long v = atoll(e);
+        if (v > 0) cs = std::min<long long>(v, h->nsteps);
+    }
+    h->chunk_steps = (int)cs;
+    if ((rc = dev_alloc(h, &h->d_stream, (size_t)(2 * cs + 1) * 2 * h->mat_elems))) return rc;
+    if ((rc = dev_alloc(h, &h->d_pq, (size_t)(2 * cs + 1) * 2 * h->Nc))) return rc;
+    if ((rc = dev_alloc(h, &h->d_R, (size_t)cs * h->Nc * JQ_NTR))) return rc;
+    return JQ_OK;
+}
+
+extern "C" int jq_create(const jq_problem* problem, jq_handle** out)
+{
+    if (!out) {
+        g_create_error = "jq_create: out is NULL";
+        return JQ_EINVAL;
+    }
+    *out = nullptr;
+    jq_handle* h = new (std::nothrow) jq_handle();
+    if (!h) {
+        g_create_error = "jq_create: out of host memory";
+        return JQ_ENOMEM;
+    }
+    int rc = create_impl(problem, h);
+    if (rc != JQ_OK) {
+        g_create_error = h->err;
+        jq_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return JQ_OK;
+}
+
+extern "C" int jq_set_neumann_terms(jq_handle* h, int32_t m)
+{
+    if (!h) return JQ_EINVAL;
+    if (m < 0) return fail(h, JQ_EINVAL, "jq_set_neumann_terms: m must be >= 0");
+    h->m = m;
+    return JQ_OK;
+}
+
+extern "C" int jq_update_target(jq_handle* h, const double* Utr, const double* Uti)
+{
+    if (!h) return JQ_EINVAL;
+    if (!Utr || !Uti) return fail(h, JQ_EINVAL, "jq_update_target: NULL pointer");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t nc = (size_t)h->Ntot * h->N;
+    h->Utr.assign(Utr, Utr + nc);
+    h->Uti.assign(Uti, Uti + nc);
+    return upload_targets(h);
+}
+
+extern "C" int jq_update_hconst(jq_handle* h, const double* Hconst)
+{
+    if (!h) return JQ_EINVAL;
+    if (!Hconst) return fail(h, JQ_EINVAL, "jq_update_hconst: NULL pointer");
+    HIPCHK(h, hipSetDevice(h->device));
+    h->Hconst.assign(Hconst, Hconst + (size_t)h->Ntot * h->Ntot);
+    return upload_operators(h);
+}
+
+extern "C" int jq_update_wmat_diag(jq_handle* h, const double* w)
+{
+    if (!h) return JQ_EINVAL;
+    if (!w) return fail(h, JQ_EINVAL, "jq_update_wmat_diag: NULL pointer");
+    h->wd.assign(w, w + h->Ntot);
+    return JQ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+typedef void (*prop_kernel_t)(PropArgs);
+
+template <int NT>
+static void pick_kernels(prop_kernel_t* fwd, prop_kernel_t* bwd)
+{
+    constexpr int MINW = (NT <= 2) ? 2 : 1;
+    *fwd = k_forward<NT, MINW>;
+    *bwd = k_backward<NT, MINW>;
+}
+
+static int select_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
+{
+    switch (h->NT) {
+    case 1: pick_kernels<1>(fwd, bwd); break;
+    case 2: pick_kernels<2>(fwd, bwd); break;
+    case 3: pick_kernels<3>(fwd, bwd); break;
+    case 4: pick_kernels<4>(fwd, bwd); break;
+    case 5: pick_kernels<5>(fwd, bwd); break;
+    case 6: pick_kernels<6>(fwd, bwd); break;
+    default: return fail(h, JQ_EUNSUPPORTED, "unsupported Hilbert dimension");
+    }
+    return JQ_OK;
+}
+
+struct EvalOut {
+    std::vector<double> res;    // [nsamples][4] primary, secondary, Re s, Im s
+    std::vector<double> grad0;  // forced adjoint (total gradient), weighted sum over samples
+    std::vector<double> grad1;  // unforced adjoint (infidelity gradient), only objFuncType != 1
+};
+
+// The batched evaluation behind every hot-path entry point.
+static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, const double* eps, const double* wgt,
+                    const double* shift, bool adjoint, double* hist_r, double* hist_i, EvalOut* out)
+{
+    HIPCHK(h, hipSetDevice(h->device));
+    const int Nsig = 2 * h->Nc;
+    // src/evalobjgrad.jl:604-606
+    if (ncoeff % Nsig != 0 || ncoeff < 3 * Nsig) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "pcof must have an even number of elements >= %d, not %d", 3 * Nsig, ncoeff);
+        return fail(h, JQ_EINVAL, buf);
+    }
+    const int D1 = ncoeff / (Nsig * h->Nfreq);  // :608
+    // bcparams: nCoeff = Nfreq*D1*2*Ncoupled must equal length(pcof) (src/bsplines.jl:177-181)
+    if (h->Nfreq * D1 * Nsig != ncoeff)
+        return fail(h, JQ_EDIM, "DimensionMismatch: Inconsistent number of coefficients and size of parameter vector (nCoeff != length(pcof))");
+    if (D1 < 3) return fail(h, JQ_EINVAL, "need at least 3 B-spline coefficients per control function");
+    if (nsamples < 1) return fail(h, JQ_EINVAL, "need at least one sample");
+
+    prop_kernel_t kfwd, kbwd;
+    int rc = select_kernels(h, &kfwd, &kbwd);
+    if (rc) return rc;
+
+    const int nslabs = (nsamples + h->sps - 1) / h->sps;
+    const int nblocks = (nslabs + JQ_WAVES - 1) / JQ_WAVES;
+    const int cs = h->chunk_steps;
+    const int ntr = h->Nc * JQ_NTR;
+    const bool two_pass = adjoint && h->objFuncType != 1;
+
+    // ---- capacity ------------------------------------------------------------------------------
+    if ((size_t)ncoeff > h->cap_pcof) {
+        if ((rc = dev_alloc(h, &h->d_pcof, (size_t)ncoeff))) return rc;
+        h->cap_pcof = ncoeff;
+    }
+    if ((size_t)nslabs > h->cap_slabs) {
+        if ((rc = dev_alloc(h, &h->d_state, (size_t)nslabs * h->state_stride))) return rc;
+        if ((rc = dev_alloc(h, &h->d_state_save, (size_t)nslabs * h->state_stride))) return rc;
+        if ((rc = dev_alloc(h, &h->d_colinfo, (size_t)nslabs * 32))) return rc;
+        h->cap_slabs = nslabs;
+        h->cap_traces = 0;
+    }
+    if (adjoint && (size_t)nslabs * cs * ntr > h->cap_traces) {
+        if ((rc = dev_alloc(h, &h->d_traces, (size_t)nslabs * cs * ntr))) return rc;
+        h->cap_traces = (size_t)nslabs * cs * ntr;
+    }
+    if ((size_t)2 * ncoeff > h->cap_grad) {
+        if ((rc = dev_alloc(h, &h->d_grad, (size_t)2 * ncoeff))) return rc;
+        h->cap_grad = 2 * ncoeff;
+    }
+    if ((size_t)nsamples * 4 > h->cap_res) {
+        if ((rc = dev_alloc(h, &h->d_res, (size_t)nsamples * 4))) return rc;
+        h->cap_res = (size_t)nsamples * 4;
+    }
+
+    // ---- inputs --------------------------------------------------------------------------------
+    hipStream_t s = h->stream;
+    HIPCHK(h, hipMemcpyAsync(h->d_pcof, pcof, (size_t)ncoeff * sizeof(double), hipMemcpyHostToDevice, s));
+    bool use_shift = false;
+    std::vector<double> colinfo((size_t)nslabs * 32, 0.0);
+    for (int sl = 0; sl < nslabs; ++sl)
+        for (int c = 0; c < h->sps * h->N; ++c) {
+            const int smp = sl * h->sps + c / h->N;
+            if (smp < nsamples) {
+                colinfo[(size_t)sl * 32 + c] = eps ? eps[smp] : 0.0;
+                colinfo[(size_t)sl * 32 + 16 + c] = wgt ? wgt[smp] : 1.0;
+                if (eps && eps[smp] != 0.0) use_shift = true;
+            }
+        }
+    HIPCHK(h, hipMemcpyAsync(h->d_colinfo, colinfo.data(), colinfo.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    std::vector<double> tabs((size_t)32 * h->NT, 0.0);
+    for (int i = 0; i < h->Ntot; ++i) {
+        tabs[i] = h->wd[i];
+        // reference perturbation: Hconst[j,j] += ep*0.01*10^(j-2), j = 2..Ntot (src/ipopt_interface.jl:41-44)
+        tabs[(size_t)16 * h->NT + i] = shift ? shift[i] : (i >= 1 ? 0.01 * pow(10.0, (double)(i - 1)) : 0.0);
+    }
+    HIPCHK(h, hipMemcpyAsync(h->d_tabs, tabs.data(), tabs.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemsetAsync(h->d_grad, 0, (size_t)2 * ncoeff * sizeof(double), s));
+
+    SplineArgs sp;
+    sp.pcof = h->d_pcof; sp.cfreq = h->d_cfreq; sp.D1 = D1; sp.Nfreq = h->Nfreq; sp.Ncoupled = h->Nc; sp.nCoeff = ncoeff;
+    sp.dtknot = h->T / (D1 - 2);
+
+    const double dt = h->T / h->nsteps;
+    PropArgs a;
+    memset(&a, 0, sizeof a);
+    a.stream = h->d_stream; a.himg = h->d_himg; a.state = h->d_state; a.colinfo = h->d_colinfo; a.traces = h->d_traces;
+    a.tabs = h->d_tabs; a.mat_elems = h->mat_elems; a.rounds = (int)(h->mat_elems * 8 / 4096); a.m = h->m;
+    a.nslabs = nslabs; a.Ncoupled = h->Nc; a.Ntot = h->Ntot; a.N = h->N; a.use_shift = use_shift ? 1 : 0;
+    a.tinv = 1.0 / h->T; a.state_stride = h->state_stride;
+
+    const size_t lds_fwd = 2 * (size_t)h->mat_elems * 8 + (size_t)32 * h->NT * 8;
+    const size_t lds_bwd = lds_fwd + (size_t)JQ_MAXNC * 256 * 8;
+    HIPCHK(h, hipFuncSetAttribute((const void*)kfwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fwd));
+    HIPCHK(h, hipFuncSetAttribute((const void*)kbwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bwd));
+
+    // events: [0]=start [1]=end, then pairs around every propagator launch
+    const int nchunks = (h->nsteps + cs - 1) / cs;
+    const size_t nev = 2 + 2 * (size_t)nchunks * (1 + (adjoint ? (two_pass ? 2 : 1) : 0));
+    while (h->ev.size() < nev) {
+        hipEvent_t e;
+        HIPCHK(h, hipEventCreate(&e));
+        h->ev.push_back(e);
+    }
+    size_t evi = 2;
+    HIPCHK(h, hipEventRecord(h->ev[0], s));
+
+    hipLaunchKernelGGL(k_init_state, dim3(nslabs), dim3(64), 0, s, h->d_state, h->state_stride, h->d_uimg, h->KT);
+
+    long long mfma = 0;
+    const long long tiles = (long long)h->NT * h->KT;
+    // ---- forward sweep -------------------------------------------------------------------------
+    for (int n0 = 0; n0 < h->nsteps; n0 += cs) {
+        const int nc = std::min(cs, h->nsteps - n0);
+        const int ntp = 2 * nc + 1;
+        hipLaunchKernelGGL(k_ctrl, dim3((ntp + 127) / 128), dim3(128), 0, s, sp, h->d_tf, n0, ntp, dt, h->d_pq);
+        hipLaunchKernelGGL(k_stream, dim3((unsigned)((h->mat_elems + 255) / 256), ntp), dim3(256), 0, s, h->d_himg, h->d_pq,
+                           h->Nc, h->mat_elems, h->d_stream);
+        a.nsteps_chunk = nc; a.step0 = n0; a.first_chunk = (n0 == 0); a.h = dt; a.forced = 1;
+        a.hist_r = hist_r; a.hist_i = hist_i;
+        HIPCHK(h, hipEventRecord(h->ev[evi++], s));
+        hipLaunchKernelGGL(kfwd, dim3(nblocks), dim3(256), lds_fwd, s, a);
+        HIPCHK(h, hipEventRecord(h->ev[evi++], s));
+        mfma += (long long)nslabs * nc * (8 + 2 * h->m) * tiles;
+    }
+    HIPCHK(h, hipGetLastError());
+    const double leak_scale = 0.5 * dt * (1.0 / h->T);
+    hipLaunchKernelGGL(k_terminal, dim3(nslabs), dim3(64), 0, s, h->d_state, h->state_stride, h->d_vtr, h->d_vti, h->KT,
+                       h->N, h->sps, nsamples, leak_scale, h->d_res);
+
+    // ---- backward sweep(s) ---------------------------------------------------------------------
+    if (adjoint) {
+        if (two_pass)
+            HIPCHK(h, hipMemcpyAsync(h->d_state_save, h->d_state, (size_t)nslabs * h->state_stride * sizeof(double),
+                                     hipMemcpyDeviceToDevice, s));
+        for (int pass = 0; pass < (two_pass ? 2 : 1); ++pass) {
+            if (pass == 1)
+                HIPCHK(h, hipMemcpyAsync(h->d_state, h->d_state_save, (size_t)nslabs * h->state_stride * sizeof(double),
+                                         hipMemcpyDeviceToDevice, s));
+            for (int n0 = 0; n0 < h->nsteps; n0 += cs) {
+                const int nc = std::min(cs, h->nsteps - n0);
+                const int ntp = 2 * nc + 1;
+                hipLaunchKernelGGL(k_ctrl, dim3((ntp + 127) / 128), dim3(128), 0, s, sp, h->d_tb, n0, ntp, -dt, h->d_pq);
+                hipLaunchKernelGGL(k_stream, dim3((unsigned)((h->mat_elems + 255) / 256), ntp), dim3(256), 0, s, h->d_himg,
+                                   h->d_pq, h->Nc, h->mat_elems, h->d_stream);
+                a.nsteps_chunk = nc; a.step0 = n0; a.first_chunk = (n0 == 0); a.h = -dt; a.forced = (pass == 0);
+                a.hist_r = nullptr; a.hist_i = nullptr;
+                HIPCHK(h, hipEventRecord(h->ev[evi++], s));
+                hipLaunchKernelGGL(kbwd, dim3(nblocks), dim3(256), lds_bwd, s, a);
+                HIPCHK(h, hipEventRecord(h->ev[evi++], s));
+                hipLaunchKernelGGL(k_trace_reduce, dim3((unsigned)(((long long)nc * ntr + 255) / 256)), dim3(256), 0, s,
+                                   h->d_traces, nslabs, nc, ntr, h->d_R);
+                hipLaunchKernelGGL(k_gradacc, dim3((ncoeff + 63) / 64), dim3(64), 0, s, sp, h->d_R, h->d_tb, n0, nc, -dt,
+                                   h->d_grad + (size_t)pass * ncoeff);
+                mfma += (long long)nslabs * nc * (2 * (8 + 2 * h->m) + 4 * h->Nc) * tiles;
+                if (n0 == 0) mfma += (long long)nslabs * h->Nc * tiles;
+            }
+        }
+    }
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->ev[1], s));
+
+    // ---- outputs -------------------------------------------------------------------------------
+    out->res.resize((size_t)nsamples * 4);
+    HIPCHK(h, hipMemcpyAsync(out->res.data(), h->d_res, out->res.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (adjoint) {
+        out->grad0.resize(ncoeff);
+        HIPCHK(h, hipMemcpyAsync(out->grad0.data(), h->d_grad, (size_t)ncoeff * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (two_pass) {
+            out->grad1.resize(ncoeff);
+            HIPCHK(h, hipMemcpyAsync(out->grad1.data(), h->d_grad + ncoeff, (size_t)ncoeff * sizeof(double),
+                                     hipMemcpyDeviceToHost, s));
+        }
+    }
+    HIPCHK(h, hipStreamSynchronize(s));
+
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+    h->timing.ms_total = ms;
+    double prop = 0.0;
+    for (size_t i = 2; i + 1 < evi; i += 2) {
+        HIPCHK(h, hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
+        prop += ms;
+    }
+    h->timing.ms_propagate = prop;
+    h->timing.ms_generate = h->timing.ms_total - prop;
+    h->timing.n_propagate_launches = (long long)(evi - 2) / 2;
+    h->timing.mfma_executed = mfma;
+    h->timing.svts = (long long)nsamples * h->N * h->nsteps;
+    return JQ_OK;
+}
+
+extern "C" int jq_traceobjgrad(jq_handle* h, const double* pcof, int32_t ncoeff, int32_t evaladjoint, double* out4,
+                               double* totalgrad, double* infidelgrad, double* leakgrad)
+{
+    if (!h) return JQ_EINVAL;
+    if (!pcof || !out4) return fail(h, JQ_EINVAL, "jq_traceobjgrad: NULL pointer");
+    if (evaladjoint && (!totalgrad || !infidelgrad || !leakgrad))
+        return fail(h, JQ_EINVAL, "jq_traceobjgrad: gradient outputs are required when evaladjoint != 0");
+    EvalOut o;
+    int rc = run_eval(h, pcof, ncoeff, 1, nullptr, nullptr, nullptr, evaladjoint != 0, nullptr, nullptr, &o);
+    if (rc) return rc;
+    const double primary = o.res[0], secondary = o.res[1];
+    out4[0] = primary + secondary;  // objfv (src/evalobjgrad.jl:765-766)
+    out4[1] = primary;
+    out4[2] = secondary;
+    out4[3] = primary;              // traceInfidelity == 1 - |s|^2 for pFidType 2 (:792)
+    if (evaladjoint) {
+        for (int i = 0; i < ncoeff; ++i) totalgrad[i] = o.grad0[i];
+        if (h->objFuncType != 1) {
+            for (int i = 0; i < ncoeff; ++i) {
+                infidelgrad[i] = o.grad1[i];
+                leakgrad[i] = o.grad0[i] - o.grad1[i];  // :947
+            }
+        } else {
+            for (int i = 0; i < ncoeff; ++i) {
+                infidelgrad[i] = o.grad0[i];  // :951
+                leakgrad[i] = 0.0;
+            }
+        }
+    }
+    return JQ_OK;
+}
+
+extern "C" int jq_state_history(jq_handle* h, const double* pcof, int32_t ncoeff, double* ur, double* ui)
+{
+    if (!h) return JQ_EINVAL;
+    if (!pcof || !ur || !ui) return fail(h, JQ_EINVAL, "jq_state_history: NULL pointer");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t len = (size_t)h->Ntot * h->N * (h->nsteps + 1);
+    double *d_r = nullptr, *d_i = nullptr;
+    HIPCHK(h, hipMalloc((void**)&d_r, len * sizeof(double)));
+    if (hipMalloc((void**)&d_i, len * sizeof(double)) != hipSuccess) {
+        hipFree(d_r);
+        return fail(h, JQ_ENOMEM, "jq_state_history: out of device memory");
+    }
+    hipMemset(d_r, 0, len * sizeof(double));
+    hipMemset(d_i, 0, len * sizeof(double));
+    EvalOut o;
+    int rc = run_eval(h, pcof, ncoeff, 1, nullptr, nullptr, nullptr, false, d_r, d_i, &o);
+    if (rc == JQ_OK) {
+        if (hipMemcpy(ur, d_r, len * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(ui, d_i, len * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(h, JQ_EHIP, "jq_state_history: copy back failed");
+        // usaver[:,:,1] = Uinit ; usavei[:,:,1] = -vi = 0 (src/evalobjgrad.jl:679-680)
+        for (size_t i = 0; i < (size_t)h->Ntot * h->N && rc == JQ_OK; ++i) {
+            ur[i] = h->Uinit[i];
+            ui[i] = -0.0;
+        }
+    }
+    hipFree(d_r);
+    hipFree(d_i);
+    return rc;
+}
+
+extern "C" int jq_eval_f_g_grad(jq_handle* h, const double* pcof, int32_t ncoeff, const double* nodes, const double* weights,
+                                int32_t nquad, const double* shift, int32_t compute_adjoint, double* out2, double* infid_grad,
+                                double* leak_grad)
+{
+    if (!h) return JQ_EINVAL;
+    if (!pcof || !nodes || !weights || !out2) return fail(h, JQ_EINVAL, "jq_eval_f_g_grad: NULL pointer");
+    if (nquad < 1) return fail(h, JQ_EINVAL, "jq_eval_f_g_grad: nquad must be >= 1");
+    if (compute_adjoint && (!infid_grad || !leak_grad))
+        return fail(h, JQ_EINVAL, "jq_eval_f_g_grad: gradient outputs are required when compute_adjoint != 0");
+    EvalOut o;
+    int rc = run_eval(h, pcof, ncoeff, nquad, nodes, weights, shift, compute_adjoint != 0, nullptr, nullptr, &o);
+    if (rc) return rc;
+    double inf = 0.0, leak = 0.0;
+    for (int i = 0; i < nquad; ++i) {  // src/ipopt_interface.jl:58-59
+        inf += o.res[(size_t)i * 4 + 0] * weights[i];
+        leak += o.res[(size_t)i * 4 + 1] * weights[i];
+    }
+    out2[0] = inf;
+    out2[1] = leak;
+    if (compute_adjoint) {
+        if (h->objFuncType != 1) {
+            for (int i = 0; i < ncoeff; ++i) {
+                infid_grad[i] = o.grad1[i];
+                leak_grad[i] = o.grad0[i] - o.grad1[i];
+            }
+        } else {
+            for (int i = 0; i < ncoeff; ++i) {
+                infid_grad[i] = o.grad0[i];  // "infidelgrad stores the totalgrad" (src/evalobjgrad.jl:949-951)
+                leak_grad[i] = 0.0;
+            }
+        }
+    }
+    return JQ_OK;
+}
+
+extern "C" int jq_traceobj_sweep(jq_handle* h, const double* pcof, int32_t ncoeff, const double* nodes, int32_t nquad,
+                                 const double* shift, double* out)
+{
+    if (!h) return JQ_EINVAL;
+    if (!pcof || !nodes || !out) return fail(h, JQ_EINVAL, "jq_traceobj_sweep: NULL pointer");
+    if (nquad < 1) return fail(h, JQ_EINVAL, "jq_traceobj_sweep: nquad must be >= 1");
+    EvalOut o;
+    int rc = run_eval(h, pcof, ncoeff, nquad, nodes, nullptr, shift, false, nullptr, nullptr, &o);
+    if (rc) return rc;
+    for (int i = 0; i < nquad; ++i) {
+        const double primary = o.res[(size_t)i * 4 + 0], secondary = o.res[(size_t)i * 4 + 1];
+        out[(size_t)i * 4 + 0] = primary + secondary;
+        out[(size_t)i * 4 + 1] = primary;
+        out[(size_t)i * 4 + 2] = secondary;
+        out[(size_t)i * 4 + 3] = primary;
+    }
+    return JQ_OK;
+}
+
+extern "C" int jq_last_timing(const jq_handle* h, jq_timing* t)
+{
+    if (!h || !t) return JQ_EINVAL;
+    *t = h->timing;
+    return JQ_OK;
+}

@@ -1,0 +1,138 @@
+"""Host-side mirror of the reference's hot-path entry points over the C ABI:
+
+  Working_Arrays_HIP(params, nCoeff)    the drop-in third working-array type:
+                                        where the reference dispatches traceobjgrad on
+                                        wa::Working_Arrays (src/evalobjgrad.jl:504) this type forwards
+                                        to libjuqbox_hip.so.  Offers `wa.gr` like Working_Arrays (:400),
+                                        which eval_grad_f_par uses (src/ipopt_interface.jl:139-141).
+  traceobjgrad(pcof0, params, wa, verbose=False, evaladjoint=True)
+                                        same argument order and return tuples as
+                                        src/evalobjgrad.jl:504, :1027-1036.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .objparams import JACOBI_SOLVER, NEUMANN_SOLVER, objparams
+
+
+def _f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64).ravel(order="F"))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_lib.c_dp) if a is not None else None
+
+
+class Working_Arrays_HIP:
+    """Owns the device handle for one `objparams`.  Mutable fields of `params` that scripts change
+    after construction (Hconst, wmat_real, Utarget_r/i, linear_solver.max_iter) are re-synchronised
+    with the device at every call, so `params` stays the single source of truth like in the reference."""
+
+    def __init__(self, params: objparams, nCoeff: int):
+        L = _lib.load()
+        if params.linear_solver.solver_id != NEUMANN_SOLVER:
+            if params.linear_solver.solver_id == JACOBI_SOLVER:
+                raise NotImplementedError("JACOBI_SOLVER is not implemented by the HIP path (SURVEY.md section 8f row 4)")
+            raise ValueError("Please specify a supported linear solver")
+        self.params = params
+        self.nCoeff = int(nCoeff)
+        self.gr = np.zeros(self.nCoeff)            # Working_Arrays.gr (src/evalobjgrad.jl:400)
+        p = params
+        hs = np.concatenate([_f64(h) for h in p.Hsym_ops]) if p.Ncoupled else np.zeros(1)
+        ha = np.concatenate([_f64(h) for h in p.Hanti_ops]) if p.Ncoupled else np.zeros(1)
+        self._hconst = _f64(p.Hconst).copy()
+        self._wd = _f64(p.wmat_real).copy()
+        self._utr = _f64(p.Utarget_r).copy()
+        self._uti = _f64(p.Utarget_i).copy()
+        self._m = int(p.linear_solver.max_iter)
+        keep = [self._hconst, hs, ha, _f64(p.Uinit), self._utr, self._uti, self._wd, _f64(p.Cfreq[:p.Ncoupled, :])]
+        prob = _lib.jq_problem(p.Ntot, p.N, p.Ncoupled, p.Nfreq, p.nsteps, self._m, p.objFuncType, 0, p.T,
+                               *[_ptr(a) for a in keep])
+        h = ctypes.c_void_p()
+        rc = L.jq_create(ctypes.byref(prob), ctypes.byref(h))
+        if rc != _lib.JQ_OK:
+            msg = L.jq_last_error(None)
+            raise _lib.JuqboxHipError(rc, msg.decode() if msg else "?")
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            _lib.load().jq_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync_params(self):
+        """Push post-construction mutations of `params` to the device (only what changed)."""
+        L, p, h = _lib.load(), self.params, self.handle
+        if p.linear_solver.solver_id != NEUMANN_SOLVER:
+            raise NotImplementedError("only NEUMANN_SOLVER is implemented by the HIP path")
+        m = int(p.linear_solver.max_iter)
+        if m != self._m:
+            _lib.check(L.jq_set_neumann_terms(h, m), h)
+            self._m = m
+        hc = _f64(p.Hconst)
+        if not np.array_equal(hc, self._hconst):
+            _lib.check(L.jq_update_hconst(h, _ptr(hc)), h)
+            self._hconst = hc.copy()
+        wd = _f64(p.wmat_real)
+        if wd.size != p.Ntot:
+            raise NotImplementedError("only Diagonal wmat_real (given as its diagonal) is supported")
+        if not np.array_equal(wd, self._wd):
+            _lib.check(L.jq_update_wmat_diag(h, _ptr(wd)), h)
+            self._wd = wd.copy()
+        utr, uti = _f64(p.Utarget_r), _f64(p.Utarget_i)
+        if not (np.array_equal(utr, self._utr) and np.array_equal(uti, self._uti)):
+            _lib.check(L.jq_update_target(h, _ptr(utr), _ptr(uti)), h)
+            self._utr, self._uti = utr.copy(), uti.copy()
+
+    def last_timing(self):
+        t = _lib.jq_timing()
+        _lib.check(_lib.load().jq_last_timing(self.handle, ctypes.byref(t)), self.handle)
+        return {k: getattr(t, k) for k, _ in _lib.jq_timing._fields_}
+
+
+def traceobjgrad(pcof0, params: objparams, wa: Working_Arrays_HIP, verbose: bool = False, evaladjoint: bool = True):
+    """traceobjgrad(pcof0, params, wa, verbose, evaladjoint) -- src/evalobjgrad.jl:504-1038.
+
+    evaladjoint (not verbose): (objfv, totalgrad, primaryobjf, secondaryobjf, traceInfidelity,
+                                infidelgrad, leakgrad)                                     (:1033)
+    neither:                   (objfv, primaryobjf, secondaryobjf)                         (:1035)
+    verbose (not evaladjoint): (objfv, unitaryhistory[Ntot,N,nsteps+1] complex, fidelity)  (:1031)
+    verbose and evaladjoint (the reference's forward-sensitivity self check, :1028) is out of scope.
+    objfv excludes the Tikhonov term (added by the Ipopt callbacks, src/ipopt_interface.jl:96-98).
+    """
+    if not isinstance(wa, Working_Arrays_HIP):
+        raise TypeError("traceobjgrad: wa must be a Working_Arrays_HIP")
+    if wa.params is not params:
+        raise ValueError("traceobjgrad: wa was allocated for a different objparams")
+    if verbose and evaladjoint:
+        raise NotImplementedError("verbose && evaladjoint (forward gradient self-check) is not accelerated")
+    L, h = _lib.load(), wa.handle
+    pcof = _f64(pcof0)
+    n = pcof.size
+    wa.sync_params()
+    out4 = np.zeros(4)
+    if verbose:
+        shp = (params.Ntot, params.N, params.nsteps + 1)
+        ur = np.zeros(int(np.prod(shp)))
+        ui = np.zeros_like(ur)
+        _lib.check(L.jq_state_history(h, _ptr(pcof), n, _ptr(ur), _ptr(ui)), h)
+        hist = ur.reshape(shp, order="F") + 1j * ui.reshape(shp, order="F")
+        # objective of the same evaluation (forward sweep only)
+        _lib.check(L.jq_traceobjgrad(h, _ptr(pcof), n, 0, _ptr(out4), None, None, None), h)
+        return out4[0], hist, 1.0 - out4[3]
+    if evaladjoint:
+        tg, ig, lg = np.zeros(n), np.zeros(n), np.zeros(n)
+        _lib.check(L.jq_traceobjgrad(h, _ptr(pcof), n, 1, _ptr(out4), _ptr(tg), _ptr(ig), _ptr(lg)), h)
+        if params.objFuncType == 1:
+            lg = np.zeros(0)      # the reference returns an empty leakgrad here (:808, :948-952)
+        return out4[0], tg, out4[1], out4[2], out4[3], ig, lg
+    _lib.check(L.jq_traceobjgrad(h, _ptr(pcof), n, 0, _ptr(out4), None, None, None), h)
+    return out4[0], out4[1], out4[2]
