@@ -68,8 +68,11 @@ typedef struct jq_problem {
 typedef struct jq_timing {
     double ms_total;        /* whole call on the device (generate + propagate + reduce)            */
     double ms_propagate;    /* sum over launches of the forward+backward propagator kernels        */
-    double ms_generate;     /* control evaluation + K(t)/S(t) tile-stream generation               */
-    int64_t n_propagate_launches;
+    double ms_generate;     /* everything else: control evaluation, K(t)/S(t) tile stream, reductions*/
+    double ms_forward;      /* sum over k_forward launches                                         */
+    double ms_backward;     /* sum over k_backward launches                                        */
+    int64_t n_forward_launches;
+    int64_t n_backward_launches;
     int64_t mfma_executed;  /* v_mfma_f64_16x16x4 instructions issued by the propagators (all waves)*/
     int64_t svts;           /* state-vector-time-steps processed (columns x nsteps), SURVEY 8(d)   */
 } jq_timing;

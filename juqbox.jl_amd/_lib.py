@@ -25,7 +25,8 @@ class jq_problem(ctypes.Structure):
 
 class jq_timing(ctypes.Structure):
     _fields_ = [("ms_total", ctypes.c_double), ("ms_propagate", ctypes.c_double), ("ms_generate", ctypes.c_double),
-                ("n_propagate_launches", ctypes.c_int64), ("mfma_executed", ctypes.c_int64), ("svts", ctypes.c_int64)]
+                ("ms_forward", ctypes.c_double), ("ms_backward", ctypes.c_double),
+                ("n_forward_launches", ctypes.c_int64), ("n_backward_launches", ctypes.c_int64), ("mfma_executed", ctypes.c_int64), ("svts", ctypes.c_int64)]
 
 
 # every symbol include/juqbox_hip.h declares: name -> (restype, argtypes)

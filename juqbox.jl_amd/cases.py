@@ -351,3 +351,20 @@ BUILDERS = {
     "cnot1": cnot1,
     "swap02_rn": swap02_rn,
 }
+
+
+def cnot3_ensemble(nsamples, ep_max=2 * np.pi * 1.0e-4):
+    """Risk-neutral ensemble for the cnot3 configuration (BASELINE.json configs[3]/[4] combined: the
+    reference's own perturbation 0.01*ep*10^(j-2) (src/ipopt_interface.jl:41-44) overflows any
+    sensible scale at Ntot = 96, so the ensemble perturbs the drift Hamiltonian with a common
+    detuning of the three oscillators instead:  Hconst + ep*(Na + Nb + Nc), ep = Gauss-Legendre
+    nodes on [-ep_max, ep_max] (ep_max = 2pi x 100 kHz), weights summing to one -- the same
+    construction as examples/Risk_Neutral/swap-02-risk-neutral.jl:45-49.
+    Returns (nodes, weights, shift[Ntot])."""
+    Nt = [4, 4, 6]
+    i1 = np.tile(np.arange(Nt[0]), Nt[1] * Nt[2])
+    i2 = np.tile(np.repeat(np.arange(Nt[1]), Nt[0]), Nt[2])
+    i3 = np.repeat(np.arange(Nt[2]), Nt[0] * Nt[1])
+    shift = (i1 + i2 + i3).astype(np.float64)
+    x, w = np.polynomial.legendre.leggauss(nsamples)
+    return x * ep_max, w * 0.5, shift

@@ -515,14 +515,21 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     float ms = 0.f;
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
     h->timing.ms_total = ms;
-    double prop = 0.0;
-    for (size_t i = 2; i + 1 < evi; i += 2) {
+    double fwd = 0.0, bwd = 0.0;
+    const size_t nfwd = (size_t)nchunks;
+    for (size_t i = 2, k = 0; i + 1 < evi; i += 2, ++k) {
         HIPCHK(h, hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
-        prop += ms;
+        if (k < nfwd)
+            fwd += ms;
+        else
+            bwd += ms;
     }
-    h->timing.ms_propagate = prop;
-    h->timing.ms_generate = h->timing.ms_total - prop;
-    h->timing.n_propagate_launches = (long long)(evi - 2) / 2;
+    h->timing.ms_forward = fwd;
+    h->timing.ms_backward = bwd;
+    h->timing.ms_propagate = fwd + bwd;
+    h->timing.ms_generate = h->timing.ms_total - (fwd + bwd);
+    h->timing.n_forward_launches = (long long)nfwd;
+    h->timing.n_backward_launches = (long long)((evi - 2) / 2 - nfwd);
     h->timing.mfma_executed = mfma;
     h->timing.svts = (long long)nsamples * h->N * h->nsteps;
     return JQ_OK;

@@ -41,39 +41,45 @@ def allreduce_sum_(vec, device=None):
     return vec
 
 
+def _hip_shard_eval(pcof, params, wa, nodes, weights, shift, compute_adjoint):
+    """Evaluate one shard of the ensemble on this rank's GPU: returns the packed partial sums
+    [infidelity, leak, grad_infid(nCoeff), grad_leak(nCoeff)]."""
+    if not isinstance(wa, Working_Arrays_HIP):
+        raise TypeError("eval_f_g_grad: wa must be a Working_Arrays_HIP")
+    L, h = _lib.load(), wa.handle
+    n = pcof.size
+    wa.sync_params()
+    out2 = np.zeros(2)
+    ig, lg = np.zeros(n), np.zeros(n)
+    sh = _f64(shift) if shift is not None else None
+    _lib.check(L.jq_eval_f_g_grad(h, _ptr(pcof), n, _ptr(nodes), _ptr(weights), nodes.size, _ptr(sh),
+                                  1 if compute_adjoint else 0, _ptr(out2), _ptr(ig), _ptr(lg)), h)
+    return np.concatenate([out2, ig, lg])
+
+
 def eval_f_g_grad(pcof, params, wa, nodes=(0.0,), weights=(1.0,), compute_adjoint=True, shift=None,
-                  distributed=True):
+                  distributed=True, _shard_eval=_hip_shard_eval):
     """eval_f_g_grad!(pcof, params, wa, nodes, weights, compute_adjoint) -- src/ipopt_interface.jl:24-70.
 
     All quadrature nodes are evaluated concurrently on the GPU as one batch of N*nquad columns; with an
     initialised torch.distributed process group the nodes are block-partitioned over the ranks and the
     packed result [infidelity, leak, grad_infid(nCoeff), grad_leak(nCoeff)] is summed with ONE
-    all-reduce.  Results land in params.last_* exactly like the reference (:27-31, :48-59, :67-68)."""
-    if not isinstance(wa, Working_Arrays_HIP):
-        raise TypeError("eval_f_g_grad: wa must be a Working_Arrays_HIP")
-    L, h = _lib.load(), wa.handle
+    all-reduce.  Results land in params.last_* exactly like the reference (:27-31, :48-59, :67-68).
+    `_shard_eval` exists for the CPU (gloo) tests of the sharding logic; the product default is the
+    HIP library and there is no CPU fallback."""
     pcof = _f64(pcof)
     n = pcof.size
     nodes = _f64(nodes)
     weights = _f64(weights)
     if nodes.size != weights.size:
         raise ValueError("nodes and weights must have the same length")
-    wa.sync_params()
     dist = _dist() if distributed else None
     lo, hi = 0, nodes.size
     if dist is not None and dist.get_world_size() > 1:
         lo, hi = shard_bounds(nodes.size, dist.get_rank(), dist.get_world_size())
     packed = np.zeros(2 + 2 * n)
     if hi > lo:
-        out2 = np.zeros(2)
-        ig, lg = np.zeros(n), np.zeros(n)
-        sh = _f64(shift) if shift is not None else None
-        nd, wt = nodes[lo:hi].copy(), weights[lo:hi].copy()
-        _lib.check(L.jq_eval_f_g_grad(h, _ptr(pcof), n, _ptr(nd), _ptr(wt), hi - lo, _ptr(sh),
-                                      1 if compute_adjoint else 0, _ptr(out2), _ptr(ig), _ptr(lg)), h)
-        packed[0:2] = out2
-        packed[2:2 + n] = ig
-        packed[2 + n:] = lg
+        packed[:] = _shard_eval(pcof, params, wa, nodes[lo:hi].copy(), weights[lo:hi].copy(), shift, compute_adjoint)
     if dist is not None and dist.get_world_size() > 1:
         allreduce_sum_(packed)
     params.last_pcof = pcof.copy()
