@@ -76,21 +76,23 @@ __global__ void k_ctrl(SplineArgs s, const double* tt, int n0, int ntp, double h
 }
 
 // KS!: K = Hconst + sum_q p_q Hsym_q ; S = sum_q q_q Hanti_q  (src/evalobjgrad.jl:2354-2370), evaluated
-// on the MFMA tile images.  grid = (mat_elems/256, ntp)
+// on the MFMA tile images and stored pre-scaled for the accumulate-in-place step formulation
+// (jq_kernels.h): with c = h/2, K -> +c K at the half time points (odd j), -c K at the integer
+// time points (even j); S -> c S.   grid = (mat_elems/256, ntp)
 __global__ void k_stream(const double* __restrict__ himg, const double* __restrict__ pq, int Ncoupled, long long mat_elems,
-                         double* __restrict__ stream)
+                         double c, double* __restrict__ stream)
 {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int j = blockIdx.y;
     if (e >= mat_elems) return;
-    const double* c = pq + (size_t)j * 2 * Ncoupled;
+    const double* ctl = pq + (size_t)j * 2 * Ncoupled;
     double K = himg[e], S = 0.0;
     for (int q = 0; q < Ncoupled; ++q) {
-        K += c[2 * q] * himg[(size_t)(1 + q) * mat_elems + e];
-        S += c[2 * q + 1] * himg[(size_t)(1 + Ncoupled + q) * mat_elems + e];
+        K += ctl[2 * q] * himg[(size_t)(1 + q) * mat_elems + e];
+        S += ctl[2 * q + 1] * himg[(size_t)(1 + Ncoupled + q) * mat_elems + e];
     }
-    stream[(size_t)(2 * j) * mat_elems + e] = K;
-    stream[(size_t)(2 * j + 1) * mat_elems + e] = S;
+    stream[(size_t)(2 * j) * mat_elems + e] = ((j & 1) ? c : -c) * K;
+    stream[(size_t)(2 * j + 1) * mat_elems + e] = c * S;
 }
 
 // state file <- (Uinit, 0, 0, 0, extras 0); grid = nslabs, block = 64
@@ -147,7 +149,7 @@ __global__ void k_terminal(double* state, long long stride, const double* __rest
     for (int kk = 0; kk < KT; ++kk) {
         const double tr = vtr_img[kk * 64 + lane], ti = vti_img[kk * 64 + lane];
         st[(2 * KT + kk) * 64 + lane] = (sl >= 0) ? (sre * tr + sim * ti) / N : 0.0;  // lambdar
-        st[(3 * KT + kk) * 64 + lane] = (sl >= 0) ? (sim * tr - sre * ti) / N : 0.0;  // lambdai
+        st[(3 * KT + kk) * 64 + lane] = (sl >= 0) ? -((sim * tr - sre * ti) / N) : 0.0;  // nb = -lambdai
     }
     const int sample = blockIdx.x * sps + sl;
     if (sl >= 0 && (col % N) == 0 && (lane >> 4) == 0 && sample < nsamples) {

@@ -10,8 +10,12 @@
 //     products  Y = M * X  never move state between lanes or through memory.
 //   * the time-dependent operators K(t) = H0 + sum_k p_k(t) Hsym_k,  S(t) = sum_k q_k(t) Hanti_k are
 //     shared by every column of every sample; they are pre-assembled per time point as MFMA A-fragment
-//     tile images ("tile stream", k_stream below), and double-buffered through LDS with direct
-//     global->LDS DMA (global_load_lds_dwordx4) one matrix ahead of the MFMAs.
+//     tile images ("tile stream", k_stream), and staged through a ring of LDS slots with direct
+//     global->LDS DMA (global_load_lds_dwordx4) up to three operators ahead of the MFMAs.
+//   * block-band structure: with 16x16 blocks, block (mt,kb) of an operator is stored / multiplied
+//     only when |mt-kb| <= BW (BW = NT-1 is the dense case).  Hamiltonians of coupled oscillators in
+//     Kronecker ordering are block-banded (cnot3: block-tridiagonal, 64 of 144 tiles), and the band
+//     width is a compile-time parameter, so the MFMA loops stay branch-free and fully scheduled.
 //   * the per-sample perturbation  H0_s = H0 + eps_s diag(shift)  of the risk-neutral ensemble
 //     (src/ipopt_interface.jl:41-44) is applied in registers after each K product.
 #pragma once
@@ -25,6 +29,18 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define JQ_NTR 5              // trace scalars per control per backward step
 #define JQ_STATE_ARRAYS 4     // U, V, MU, NU
 #define JQ_STATE_EXTRA 8      // 64-double rows after the arrays: CARRY[0..3], LEAK, spare
+#define JQ_MAXSLOTS 4         // LDS ring depth (prefetch distance = slots-1 <= 3: one DMA per wave in flight)
+#define JQ_MAXSCHED 32        // max operator uses per time step (13 + 2*JQ_MAXNC = 21)
+
+// number of stored tiles of an NT x 4NT tile grid with block band width BW (host + device)
+__host__ __device__ constexpr int band_tiles(int NT, int BW)
+{
+    int n = 0;
+    for (int kb = 0; kb < NT; ++kb)
+        for (int mt = 0; mt < NT; ++mt)
+            if ((mt - kb <= BW) && (kb - mt <= BW)) n += 4;
+    return n;
+}
 
 template <int NT>
 struct Arr {
@@ -75,7 +91,7 @@ __device__ __forceinline__ void a_axpy_rows(Arr<NT>& y, double c, const double* 
 #pragma unroll
         for (int r = 0; r < 4; ++r) y.t[i][r] += (c * tab[16 * i + 4 * r + g]) * x.t[i][r];
 }
-// sum_rows tab[row] * (x^2 * cx + y^2 * cy)
+// sum_rows tab[row] * x[row]^2
 template <int NT>
 __device__ __forceinline__ double a_wsq(const double* tab, int g, const Arr<NT>& x)
 {
@@ -105,19 +121,58 @@ __device__ __forceinline__ void a_store(const Arr<NT>& a, double* __restrict__ i
         for (int r = 0; r < 4; ++r) img[(4 * i + r) * 64 + lane] = a.t[i][r];
 }
 
-// acc += M * x.  M: LDS tile image in walk order (kk outer, mt inner), 64 doubles per tile;
+// D = C + M * x over the stored (band) tiles (D may alias C; D must not alias x).
+// M: compact LDS tile image in walk order (kk outer, mt inner, band tiles only), 64 doubles per tile;
 // `mat` already carries the lane offset.  Tile (mt,kk) lane l holds M[16*mt + (l&15)][4*kk + (l>>4)].
-template <int NT>
-__device__ __forceinline__ void mm(Arr<NT>& acc, const double* mat, const Arr<NT>& x)
+// The A fragments are fetched JQ_PF tiles ahead of their MFMA through a small register FIFO: a
+// v_mfma_f64_16x16x4 occupies the matrix pipe for 64 cycles, an LDS read returns in ~100.
+#define JQ_PF 6
+template <int NT, int BW, bool ZEROC>
+__device__ __forceinline__ void mm_any(Arr<NT>& D, const Arr<NT>& C, const double* mat, const Arr<NT>& x)
 {
+    constexpr int NTILES = band_tiles(NT, BW);
+    double f[JQ_PF];
+#pragma unroll
+    for (int i = 0; i < JQ_PF; ++i)
+        if (i < NTILES) f[i] = mat[i * 64];
+    int idx = 0;
 #pragma unroll
     for (int kk = 0; kk < 4 * NT; ++kk) {
 #pragma unroll
         for (int mt = 0; mt < NT; ++mt) {
-            double a = mat[(kk * NT + mt) * 64];
-            acc.t[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, x.t[kk >> 2][kk & 3], acc.t[mt], 0, 0, 0);
+            const int kb = kk >> 2;
+            if ((mt - kb <= BW) && (kb - mt <= BW)) {
+                const double a = f[idx % JQ_PF];
+                if (idx + JQ_PF < NTILES) f[idx % JQ_PF] = mat[(idx + JQ_PF) * 64];
+                const int kb0 = (mt - BW) > 0 ? (mt - BW) : 0;   // first k-block of this tile row
+                const bool first = (kk == 4 * kb0);
+                const d4 zero = {0.0, 0.0, 0.0, 0.0};
+                const d4 cin = first ? (ZEROC ? zero : C.t[mt]) : D.t[mt];
+                D.t[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, x.t[kk >> 2][kk & 3], cin, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);   // keep the FIFO order: hipcc otherwise hoists every ds_read
+                ++idx;
+            }
         }
     }
+}
+template <int NT, int BW>
+__device__ __forceinline__ void mm_c(Arr<NT>& D, const Arr<NT>& C, const double* mat, const Arr<NT>& x)
+{
+    mm_any<NT, BW, false>(D, C, mat, x);
+}
+template <int NT, int BW>
+__device__ __forceinline__ void mm_z(Arr<NT>& D, const double* mat, const Arr<NT>& x)
+{
+    mm_any<NT, BW, true>(D, D, mat, x);
+}
+// D = M * x with an operator whose own band is either 0 (block diagonal) or the kernel's BW
+template <int NT, int BW>
+__device__ __forceinline__ void mm_z_bw(Arr<NT>& D, const double* mat, const Arr<NT>& x, int bw)
+{
+    if (BW > 0 && bw == 0)
+        mm_any<NT, 0, true>(D, D, mat, x);
+    else
+        mm_any<NT, BW, true>(D, D, mat, x);
 }
 
 __device__ __forceinline__ double wave_sum(double x)
@@ -128,63 +183,26 @@ __device__ __forceinline__ double wave_sum(double x)
 }
 
 // ---------------------------------------------------------------------------------------------
-// LDS double buffer of operator images fed by global->LDS DMA.
-struct Pipe {
-    char* smem;
-    int slot_bytes;
-    int rounds;  // slot_bytes / 4096
-    int cur;     // slot holding the matrix that is used next
-    int wave, lane;
-
-    __device__ __forceinline__ void dma(const double* src, int slot) const
-    {
-        char* dst = smem + (size_t)slot * slot_bytes;
-        for (int r = 0; r < rounds; ++r) {
-            int piece = r * JQ_WAVES + wave;  // 1 KiB per wave-instruction
-            const char* s = (const char*)src + (size_t)piece * 1024 + lane * 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
-                                             (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
-        }
-    }
-    // Barrier: the matrix in slot `cur` has landed and every wave is done with the other slot;
-    // start the DMA of `next` into the other slot; return the (lane-offset) LDS image to use now.
-    __device__ __forceinline__ const double* use_and_prefetch(const double* next)
-    {
-        __syncthreads();
-        dma(next, cur ^ 1);
-        const double* M = (const double*)(smem + (size_t)cur * slot_bytes) + lane;
-        cur ^= 1;
-        return M;
-    }
+// One entry of the per-step operator schedule: which image the next product group multiplies with.
+//   kind 0/1: K / S of the tile stream at time point 2*n + tp of the chunk;  kind 2: constant image #tp
+struct SchedEntry {
+    int kind;
+    int tp;
 };
 
-// X = sum_{j=0..m} (c S)^j B   (neumann!, src/linear_solvers.jl:81-106; c = h/2).  B is clobbered.
-template <int NT>
-__device__ __forceinline__ void neumann(Arr<NT>& X, Arr<NT>& B, const double* S, double c, int m)
-{
-    X = B;
-    double coeff = 1.0;
-    for (int j = 0; j < m; ++j) {
-        Arr<NT> T;
-        a_zero(T);
-        mm(T, S, B);
-        coeff *= c;
-        a_axpy(X, coeff, T);
-        B = T;
-    }
-}
-
 struct PropArgs {
-    const double* stream;   // chunk tile stream: time point j -> K at (2j)*mat_elems, S at (2j+1)*mat_elems
-    const double* himg;     // constant images [H0 | Hsym_0.. | Hanti_0..], mat_elems each
+    const double* stream;   // chunk tile stream: time point j -> K at (2j)*stride, S at (2j+1)*stride
+    const double* cimg;     // constant trace images [Hsym_0.. | Hanti_0..], `stride` doubles each
     double* state;          // per-slab array file
     const double* colinfo;  // per slab: eps[16], wgt[16]
     double* traces;         // backward: [nslabs][nsteps_chunk][Ncoupled*JQ_NTR]
     double* hist_r;         // forward history of sample 0 ([Ntot,N,nsteps+1]) or null
     double* hist_i;
     const double* tabs;     // wd[NP] (diag wmat_real, zero padded), ws[NP] (shift weights)
-    long long mat_elems;    // doubles per operator image (multiple of 512)
-    int rounds;             // mat_elems*8/4096
+    long long stride;       // doubles per operator image slot (multiple of 128 = 1 KiB)
+    long long state_stride; // doubles per slab in the array file
+    int pieces;             // 1 KiB DMA pieces per operator image
+    int nslots;             // LDS ring depth (2..JQ_MAXSLOTS)
     int nsteps_chunk;
     int m;                  // Neumann terms
     int nslabs;
@@ -194,81 +212,188 @@ struct PropArgs {
     int Ntot, N;
     int use_shift;
     int forced;             // backward: add the leakage forcing (0: step_no_forcing!)
+    int period;             // operator uses per time step
+    int npro;               // operator uses before the first step (backward first chunk: carry products)
+    int bw_trace[JQ_MAXNC]; // band width of the trace images per control (0 or the kernel's BW)
     double h;               // signed time step
     double tinv;            // 1/T
-    long long state_stride; // doubles per slab in the array file
+    SchedEntry pro[JQ_MAXNC];
+    SchedEntry sched[JQ_MAXSCHED];
 };
 
-__device__ __forceinline__ const double* stream_mat(const PropArgs& a, int j, int isS)
+// LDS ring of operator images fed by global->LDS DMA.  Operator use #Q lives in slot Q % nslots and is
+// fetched by wave Q % 4 alone, nslots-1 uses ahead, so a wave never has more than one DMA in flight
+// and can wait for exactly its own operator (vmcnt(0)) right before the barrier that publishes it.
+struct Ring {
+    char* smem;
+    const PropArgs* a;
+    int slot_bytes;
+    int Q;        // index of the operator use that comes next
+    int Qp;       // index of the next operator use to prefetch
+    int np, ip;   // (step, position) cursor of Qp within the schedule
+    int wave, lane;
+
+    __device__ __forceinline__ const double* src_of_cursor() const
+    {
+        SchedEntry e;
+        int n = np;
+        if (Qp < a->npro) {
+            e = a->pro[Qp];
+            n = 0;
+        } else {
+            e = a->sched[ip];
+        }
+        if (n >= a->nsteps_chunk) n = a->nsteps_chunk - 1;  // past the end: harmless re-fetch
+        if (e.kind == 2) return a->cimg + (size_t)e.tp * a->stride;
+        return a->stream + (size_t)(2 * (2 * n + e.tp) + e.kind) * a->stride;
+    }
+    __device__ __forceinline__ void advance_cursor()
+    {
+        if (Qp >= a->npro) {
+            if (++ip == a->period) {
+                ip = 0;
+                ++np;
+            }
+        }
+        ++Qp;
+    }
+    __device__ __forceinline__ void issue_prefetch()
+    {
+        if ((Qp & (JQ_WAVES - 1)) == wave) {
+            const char* src = (const char*)src_of_cursor() + lane * 16;
+            char* dst = smem + (size_t)(Qp % a->nslots) * slot_bytes;
+            for (int p = 0; p < a->pieces; ++p)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)p * 1024),
+                                                 (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
+        }
+        advance_cursor();
+    }
+    __device__ __forceinline__ void init(char* smem_, const PropArgs* a_, int wave_, int lane_)
+    {
+        smem = smem_;
+        a = a_;
+        slot_bytes = (int)(a_->stride * 8);
+        Q = 0;
+        Qp = 0;
+        np = 0;
+        ip = 0;
+        wave = wave_;
+        lane = lane_;
+        for (int i = 0; i < a->nslots - 1; ++i) issue_prefetch();
+    }
+    // Publish operator use Q (its fetching wave drains its DMA, then a workgroup barrier), start the
+    // fetch of use Q + nslots - 1 into the slot that use Q-1 just released, return the LDS image of Q.
+    __device__ __forceinline__ const double* next()
+    {
+        if ((Q & (JQ_WAVES - 1)) == wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue_prefetch();
+        const double* M = (const double*)(smem + (size_t)(Q % a->nslots) * slot_bytes) + lane;
+        ++Q;
+        return M;
+    }
+    __device__ __forceinline__ void drain()
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Scaled, signed operator stream.  With c = h/2 the tile stream holds (k_stream)
+//     Kp = +c K(t)  at the half time points (odd j),   Kn = -c K(t) at the integer time points (even j),
+//     S  =  c S(t)  everywhere,
+// so every update of the Stormer-Verlet step is of the form  D = C + M x  and lands directly in the MFMA
+// accumulator registers (no axpy passes), and the truncated Neumann series (neumann!,
+// src/linear_solvers.jl:81-106) is evaluated in Horner form with the same operator:
+//     sum_{j=0..m} S^j A  =  A + S (A + S (A + ... ))                                   (m products).
+// The adjoint variable lambda_i is carried negated (nb = -lambda_i), which makes the adjoint step!
+// (src/StormerVerlet.jl:255-303) use K05 with '+' and K0, K1 with '-' exactly like the state step.
+
+// out = base_plus_A + sum_{j=1..m} S^j A      (i.e. base + sum_{j=0..m} S^j A with base_plus_A = base + A)
+// Ya, Yb are scratch arrays.  out may alias base_plus_A; out must not alias A, Ya, Yb.
+template <int NT, int BW>
+__device__ __forceinline__ void horner_add(Arr<NT>& out, const Arr<NT>& bpa, const Arr<NT>& A, const double* S, int m,
+                                           Arr<NT>& Ya, Arr<NT>& Yb)
 {
-    return a.stream + (size_t)(2 * j + isS) * a.mat_elems;
+    if (m <= 0) {
+        out = bpa;
+        return;
+    }
+    int rem = m - 1;  // Horner updates before the final product
+    if (rem == 0) {
+        mm_c<NT, BW>(out, bpa, S, A);
+        return;
+    }
+    mm_c<NT, BW>(Ya, A, S, A);  // Y1 = A + S A
+    --rem;
+    while (rem >= 2) {
+        mm_c<NT, BW>(Yb, A, S, Ya);
+        mm_c<NT, BW>(Ya, A, S, Yb);
+        rem -= 2;
+    }
+    if (rem == 1) {
+        mm_c<NT, BW>(Yb, A, S, Ya);
+        mm_c<NT, BW>(out, bpa, S, Yb);
+    } else {
+        mm_c<NT, BW>(out, bpa, S, Ya);
+    }
 }
 
-// State (re-)integration, positions 0..5 of one Stormer-Verlet step (forward step!,
+// State (re-)integration, operator uses 0..5 of one Stormer-Verlet step (forward step!,
 // src/StormerVerlet.jl:461-504, also used with h<0 by the backward sweep, src/evalobjgrad.jl:879):
-//   in : u, v at t                 out: u = u(t+h), v unchanged, v05, l1, L2 = S05*v05 (partial l2)
-// The caller finishes with position 6:  L2 += K05*u_new ; v += c*(l1 + L2).
-// Operator order per step: K05 S05 K0 S0 K1 S1 (K05) -- `after` is prefetched while S1 is in use.
-template <int NT>
-__device__ __forceinline__ void sv_step_head(Pipe& p, const PropArgs& a, int n, const double* after, bool active,
-                                             double eps, const double* ws, int g, Arr<NT>& u, const Arr<NT>& v,
-                                             Arr<NT>& v05, Arr<NT>& l1, Arr<NT>& L2)
+//   in : u, v at t          out: unew = u(t+h), v05, vpart = v05 + S05 v05   (u, v are left untouched)
+// The caller finishes with use 6:  v(t+h) = vpart + Kp05 unew.
+// Operator order per step: Kp05 S05 Kn0 S0 Kn1 S1 (Kp05).
+template <int NT, int BW>
+__device__ __forceinline__ void sv_step_head(Ring& p, const PropArgs& a, bool active, double ceps, const double* ws, int g,
+                                             const Arr<NT>& u, const Arr<NT>& v, Arr<NT>& unew, Arr<NT>& v05, Arr<NT>& vpart)
 {
-    const double c = 0.5 * a.h;
-    const int j0 = 2 * n, j05 = 2 * n + 1, j1 = 2 * n + 2;
-    Arr<NT> A;
-    // pos 0: K05
-    const double* M = p.use_and_prefetch(stream_mat(a, j05, 1));
+    Arr<NT> A, Ya, Yb;
+    // use 0: Kp05 -- A = c K05 u
+    const double* M = p.next();
     if (active) {
-        a_zero(A);
-        mm(A, M, u);
-        if (a.use_shift) a_axpy_rows(A, eps, ws, g, u);
+        mm_z<NT, BW>(A, M, u);
+        if (a.use_shift) a_axpy_rows(A, ceps, ws, g, u);
     }
-    // pos 1: S05 -- rhs = K05 u + S05 v ; l1 = (I - c S05)^-1 rhs ; v05 = v + c l1 ; L2 = S05 v05
-    M = p.use_and_prefetch(stream_mat(a, j0, 0));
+    // use 1: S05 -- A = c (K05 u + S05 v) ; v05 = v + sum_j S^j A ; vpart = v05 + S05 v05
+    M = p.next();
     if (active) {
-        mm(A, M, v);
-        neumann(l1, A, M, c, a.m);
+        mm_c<NT, BW>(A, A, M, v);
         v05 = v;
-        a_axpy(v05, c, l1);
-        a_zero(L2);
-        mm(L2, M, v05);
+        a_add(v05, A);
+        horner_add<NT, BW>(v05, v05, A, M, a.m, Ya, Yb);
+        mm_c<NT, BW>(vpart, v05, M, v05);
     }
-    // pos 2: K0 -- A = K0 v05
-    M = p.use_and_prefetch(stream_mat(a, j0, 1));
+    // use 2: Kn0 -- unew = u - c K0 v05
+    M = p.next();
     if (active) {
-        a_zero(A);
-        mm(A, M, v05);
-        if (a.use_shift) a_axpy_rows(A, eps, ws, g, v05);
+        mm_c<NT, BW>(unew, u, M, v05);
+        if (a.use_shift) a_axpy_rows(unew, -ceps, ws, g, v05);
     }
-    // pos 3: S0 -- kappa1 = S0 u - K0 v05 ; u += c kappa1
-    M = p.use_and_prefetch(stream_mat(a, j1, 0));
+    // use 3: S0 -- unew = u + c (S0 u - K0 v05) = u + c kappa1
+    M = p.next();
+    if (active) mm_c<NT, BW>(unew, unew, M, u);
+    // use 4: Kn1 -- A = -c K1 v05
+    M = p.next();
     if (active) {
-        a_neg(A);
-        mm(A, M, u);
-        a_axpy(u, c, A);
+        mm_z<NT, BW>(A, M, v05);
+        if (a.use_shift) a_axpy_rows(A, -ceps, ws, g, v05);
     }
-    // pos 4: K1 -- A = K1 v05
-    M = p.use_and_prefetch(stream_mat(a, j1, 1));
+    // use 5: S1 -- A = c (S1 (u + c kappa1) - K1 v05) ; unew += sum_j S^j A
+    M = p.next();
     if (active) {
-        a_zero(A);
-        mm(A, M, v05);
-        if (a.use_shift) a_axpy_rows(A, eps, ws, g, v05);
-    }
-    // pos 5: S1 -- rhs = S1 (u + c kappa1) - K1 v05 ; kappa2 = (I - c S1)^-1 rhs ; u += c kappa2
-    M = p.use_and_prefetch(after);
-    if (active) {
-        Arr<NT> k2;
-        a_neg(A);
-        mm(A, M, u);
-        neumann(k2, A, M, c, a.m);
-        a_axpy(u, c, k2);
+        mm_c<NT, BW>(A, A, M, unew);
+        a_add(unew, A);
+        horner_add<NT, BW>(unew, unew, A, M, a.m, Ya, Yb);
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // Forward sweep over one chunk of time steps (src/evalobjgrad.jl:698-753).
-template <int NT, int MINW>
+// schedule (period 7): Kp05 S05 Kn0 S0 Kn1 S1 Kp05
+template <int NT, int BW, int MINW>
 __global__ __launch_bounds__(256, MINW) void k_forward(PropArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -279,46 +404,36 @@ __global__ __launch_bounds__(256, MINW) void k_forward(PropArgs a)
     const int slab = blockIdx.x * JQ_WAVES + wave;
     const bool active = slab < a.nslabs;
 
-    Pipe p;
-    p.smem = smem;
-    p.slot_bytes = (int)(a.mat_elems * 8);
-    p.rounds = a.rounds;
-    p.cur = 0;
-    p.wave = wave;
-    p.lane = lane;
-    double* tab = (double*)(smem + 2 * (size_t)p.slot_bytes);
+    double* tab = (double*)(smem + (size_t)a.nslots * a.stride * 8);
     const double* wd = tab;
     const double* ws = tab + 16 * NT;
     for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[i] = a.tabs[i];
 
     Arr<NT> u, v;
-    double leak = 0.0, eps = 0.0;
+    double leak = 0.0, ceps = 0.0;
     double* st = a.state + (size_t)(active ? slab : 0) * a.state_stride;
     if (active) {
         a_load(u, st, lane);
         a_load(v, st + KT * 64, lane);
         leak = st[(JQ_STATE_ARRAYS * KT + JQ_MAXNC) * 64 + lane];
-        eps = a.colinfo[(size_t)slab * 32 + (lane & 15)];
+        ceps = 0.5 * a.h * a.colinfo[(size_t)slab * 32 + (lane & 15)];
     } else {
         a_zero(u);
         a_zero(v);
     }
-    // first operator of the chunk: K05 of step 0
-    p.dma(stream_mat(a, 1, 0), 0);
+    Ring p;
+    p.init(smem, &a, wave, lane);
 
-    const double c = 0.5 * a.h;
     for (int n = 0; n < a.nsteps_chunk; ++n) {
-        Arr<NT> v05, l1, L2;
+        Arr<NT> unew, v05, vpart;
         if (active) leak += a_wsq(wd, g, u);  // trapezoidal part: tr(vr' W vr) at t_n (:700)
-        sv_step_head<NT>(p, a, n, stream_mat(a, 2 * n + 1, 0), active, eps, ws, g, u, v, v05, l1, L2);
-        // pos 6: K05 again -- l2 = K05 u_new + S05 v05 ; v += c (l1 + l2).  Prefetch next step's K05.
-        const int nn = (n + 1 < a.nsteps_chunk) ? n + 1 : n;
-        const double* M = p.use_and_prefetch(stream_mat(a, 2 * nn + 1, 0));
+        sv_step_head<NT, BW>(p, a, active, ceps, ws, g, u, v, unew, v05, vpart);
+        // use 6: Kp05 again -- v(t+h) = v05 + c (K05 u_new + S05 v05)
+        const double* M = p.next();
         if (active) {
-            mm(L2, M, u);
-            if (a.use_shift) a_axpy_rows(L2, eps, ws, g, u);
-            a_add(L2, l1);
-            a_axpy(v, c, L2);
+            mm_c<NT, BW>(v, vpart, M, unew);
+            if (a.use_shift) a_axpy_rows(v, ceps, ws, g, unew);
+            u = unew;
             // leak integrand: tr(vr' W vr + 2 vi05' W vi05) after the step (:716, penalf2a :2170-2180)
             leak += a_wsq(wd, g, u) + 2.0 * a_wsq(wd, g, v05);
             if (a.hist_r) {
@@ -340,7 +455,7 @@ __global__ __launch_bounds__(256, MINW) void k_forward(PropArgs a)
             }
         }
     }
-    __syncthreads();  // drain the last (unused) prefetch before the workgroup exits
+    p.drain();  // land the trailing prefetches before the workgroup exits
     if (active) {
         a_store(u, st, lane);
         a_store(v, st + KT * 64, lane);
@@ -352,7 +467,10 @@ __global__ __launch_bounds__(256, MINW) void k_forward(PropArgs a)
 // Backward sweep over one chunk (src/evalobjgrad.jl:859-921): state re-integration with h<0,
 // adjoint step! with forcing (src/StormerVerlet.jl:255-303) or step_no_forcing! (:365-451), and the
 // per-step trace scalars of adjoint_grad_calc! (src/evalobjgrad.jl:2567-2619), written to `traces`.
-template <int NT, int MINW>
+// schedule (period 13 + 2*Ncoupled):
+//   Kp05 S05 Kn0 S0 Kn1 S1 Kp05 | S0 Kn0 Kn1 S05 Kp05 S1 | Hanti_0 Hsym_0 Hanti_1 Hsym_1 ...
+// State file slot NU holds nb = -lambda_i.
+template <int NT, int BW, int MINW>
 __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -364,198 +482,167 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
     const bool active = slab < a.nslabs;
     const int Nc = a.Ncoupled;
 
-    Pipe p;
-    p.smem = smem;
-    p.slot_bytes = (int)(a.mat_elems * 8);
-    p.rounds = a.rounds;
-    p.cur = 0;
-    p.wave = wave;
-    p.lane = lane;
-    double* tab = (double*)(smem + 2 * (size_t)p.slot_bytes);
+    double* tab = (double*)(smem + (size_t)a.nslots * a.stride * 8);
     const double* wd = tab;
     const double* ws = tab + 16 * NT;
     double* carry = tab + 32 * NT;  // [JQ_MAXNC][256]
     for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[i] = a.tabs[i];
 
-    Arr<NT> u, v, mu, nu;
-    double eps = 0.0, wgt = 0.0;
+    Arr<NT> u, v, mu, nb;
+    double ceps = 0.0, wgt = 0.0;
     double* st = a.state + (size_t)(active ? slab : 0) * a.state_stride;
     if (active) {
         a_load(u, st, lane);
         a_load(v, st + KT * 64, lane);
         a_load(mu, st + 2 * KT * 64, lane);
-        a_load(nu, st + 3 * KT * 64, lane);
-        eps = a.colinfo[(size_t)slab * 32 + (lane & 15)];
+        a_load(nb, st + 3 * KT * 64, lane);
+        ceps = 0.5 * a.h * a.colinfo[(size_t)slab * 32 + (lane & 15)];
         wgt = a.colinfo[(size_t)slab * 32 + 16 + (lane & 15)];
         for (int q = 0; q < Nc; ++q) carry[q * 256 + threadIdx.x] = st[(JQ_STATE_ARRAYS * KT + q) * 64 + lane];
     } else {
         a_zero(u);
         a_zero(v);
         a_zero(mu);
-        a_zero(nu);
+        a_zero(nb);
     }
-    const double* Hs0 = a.himg + a.mat_elems;                     // Hsym_q  at Hs0 + q*mat_elems
-    const double* Ha0 = a.himg + (size_t)(1 + Nc) * a.mat_elems;  // Hanti_q at Ha0 + q*mat_elems
-    const double c = 0.5 * a.h;
-    const double fw = a.forced ? a.tinv : 0.0;  // forcing weight: hr0 = tinv*W*vr etc. (:862, :882-888)
+    // forcing weight c*tinv: c*hr0 = c*tinv*W*vr etc. (:862, :882-888); 0 for step_no_forcing!
+    const double cfw = a.forced ? 0.5 * a.h * a.tinv : 0.0;
+
+    Ring p;
+    p.init(smem, &a, wave, lane);
 
     if (a.first_chunk) {
         // carry_q = tr(vr' Hsym_q lambdai) at t = T: the "vr0/lambdai0" term of the first backward
         // step (:2609); on later steps it is the previous step's tr(vr' Hsym_q lambdai) (:901-902).
-        p.dma(Hs0, 0);
         for (int q = 0; q < Nc; ++q) {
-            const double* nxt = (q + 1 < Nc) ? Hs0 + (size_t)(q + 1) * a.mat_elems : stream_mat(a, 1, 0);
-            const double* M = p.use_and_prefetch(nxt);
+            const double* M = p.next();  // Hsym_q
             if (active) {
                 Arr<NT> T;
-                a_zero(T);
-                mm(T, M, nu);
-                carry[q * 256 + threadIdx.x] = a_dot(u, T);
+                mm_z_bw<NT, BW>(T, M, nb, a.bw_trace[q]);
+                carry[q * 256 + threadIdx.x] = -a_dot(u, T);
             }
         }
-    } else {
-        p.dma(stream_mat(a, 1, 0), 0);
     }
 
     for (int n = 0; n < a.nsteps_chunk; ++n) {
-        const int j0 = 2 * n, j05 = 2 * n + 1, j1 = 2 * n + 2;
-        Arr<NT> uold, v05, X;
+        Arr<NT> unew, v05, X, Bq;
         {
-            Arr<NT> l1, L2;
-            uold = u;
-            sv_step_head<NT>(p, a, n, stream_mat(a, j05, 0), active, eps, ws, g, u, v, v05, l1, L2);
-            // pos 6: K05 -- finish the state step; first adjoint product R = K05 nu
-            const double* M = p.use_and_prefetch(stream_mat(a, j0, 1));
-            Arr<NT> R;
-            if (active) {
-                mm(L2, M, u);
-                if (a.use_shift) a_axpy_rows(L2, eps, ws, g, u);
-                a_add(L2, l1);
-                a_axpy(v, c, L2);
-                a_zero(R);
-                mm(R, M, nu);
-                if (a.use_shift) a_axpy_rows(R, eps, ws, g, nu);
+            Arr<NT> R, Ya, Yb;
+            {
+                Arr<NT> vpart;
+                sv_step_head<NT, BW>(p, a, active, ceps, ws, g, u, v, unew, v05, vpart);
+                // use 6: Kp05 -- finish the state step; first adjoint product R = c K05 nb (= -c K05 lambda_i)
+                const double* M = p.next();
+                if (active) {
+                    mm_c<NT, BW>(v, vpart, M, unew);
+                    if (a.use_shift) a_axpy_rows(v, ceps, ws, g, unew);
+                    mm_z<NT, BW>(R, M, nb);
+                    if (a.use_shift) a_axpy_rows(R, ceps, ws, g, nb);
+                }
             }
-            // pos 7: S0 -- rhs = S0 mu - K05 nu + hr0 ; kappa2 = (I - c S0)^-1 rhs ; mu += c kappa2 ; X = mu
-            M = p.use_and_prefetch(stream_mat(a, j0, 0));
+            // use 7: S0 -- R = c (S0 mu - K05 li + hr0) ; X = mu + sum_j S^j R        (X = lambda_r^{1/2})
+            const double* M = p.next();
             if (active) {
-                Arr<NT> k2;
-                a_neg(R);
-                mm(R, M, mu);
-                a_axpy_rows(R, fw, wd, g, uold);
-                neumann(k2, R, M, c, a.m);
-                a_axpy(mu, c, k2);
+                mm_c<NT, BW>(R, R, M, mu);
+                a_axpy_rows(R, cfw, wd, g, u);  // u still holds vr before the state step (:862)
                 X = mu;
+                a_add(X, R);
+                horner_add<NT, BW>(X, X, R, M, a.m, Ya, Yb);
             }
         }
         {
-            Arr<NT> A, Bq;
-            // pos 8: K0 -- A = K0 X
-            const double* M = p.use_and_prefetch(stream_mat(a, j1, 0));
+            Arr<NT> L, Qv, Ya, Yb;
+            // use 8: Kn0 -- L = -c K0 X
+            const double* M = p.next();
             if (active) {
-                a_zero(A);
-                mm(A, M, X);
-                if (a.use_shift) a_axpy_rows(A, eps, ws, g, X);
+                mm_z<NT, BW>(L, M, X);
+                if (a.use_shift) a_axpy_rows(L, -ceps, ws, g, X);
             }
-            // pos 9: K1 -- Bq = K1 X
-            M = p.use_and_prefetch(stream_mat(a, j05, 1));
+            // use 9: Kn1 -- Qv = -c K1 X
+            M = p.next();
             if (active) {
-                a_zero(Bq);
-                mm(Bq, M, X);
-                if (a.use_shift) a_axpy_rows(Bq, eps, ws, g, X);
+                mm_z<NT, BW>(Qv, M, X);
+                if (a.use_shift) a_axpy_rows(Qv, -ceps, ws, g, X);
             }
-            // pos 10: S05 -- l2 = K0 X + S05 nu + hi0 ; rhs = S05 (nu + c l2) + K1 X + hi1 ;
-            //                l1 = (I - c S05)^-1 rhs ; nu += c (l2 + l1)
-            M = p.use_and_prefetch(stream_mat(a, j05, 0));
+            // use 10: S05 -- L = -c l2 = -c (K0 X + S05 li + hi0) ; Qv = -c (S05 (li + c l2) + K1 X + hi1) ;
+            //               nb_new = nb + L + sum_j S^j Qv          (li_new = li + c (l2 + l1))
+            M = p.next();
             if (active) {
-                Arr<NT> P, l1;
-                a_zero(P);
-                mm(P, M, nu);
-                a_add(A, P);
-                a_axpy_rows(A, fw, wd, g, v05);  // A = l2
                 {
-                    Arr<NT> Q;
-                    a_zero(Q);
-                    mm(Q, M, A);
-                    a_add(Bq, P);
-                    a_axpy(Bq, c, Q);
+                    Arr<NT> P;
+                    mm_z<NT, BW>(P, M, nb);
+                    a_axpy_rows(P, -cfw, wd, g, v05);  // P = c (-S05 li - hi0)
+                    a_add(L, P);
+                    a_add(Qv, P);
                 }
-                a_axpy_rows(Bq, fw, wd, g, v05);  // Bq = rhs
-                neumann(l1, Bq, M, c, a.m);
-                a_add(A, l1);
-                // keep lambdai0 + lambdai for the last trace: P = nu_old + nu_new
-                P = nu;
-                a_axpy(nu, c, A);
-                a_add(P, nu);
-                Bq = P;  // Bq now holds (nu_old + nu_new)
+                mm_c<NT, BW>(Qv, Qv, M, L);
+                Bq = nb;          // nb_old, becomes nb_old + nb_new below
+                a_add(L, nb);
+                a_add(L, Qv);     // L = nb + L + Qv
+                horner_add<NT, BW>(nb, L, Qv, M, a.m, Ya, Yb);
+                a_add(Bq, nb);
             }
-            // pos 11: K05 -- R = K05 nu_new
-            M = p.use_and_prefetch(stream_mat(a, j1, 1));
+            // use 11: Kp05 -- L = X + c K05 nb_new (= lambda_r^{1/2} - c K05 li_new)
+            M = p.next();
             if (active) {
-                a_zero(A);
-                mm(A, M, nu);
-                if (a.use_shift) a_axpy_rows(A, eps, ws, g, nu);
+                mm_c<NT, BW>(L, X, M, nb);
+                if (a.use_shift) a_axpy_rows(L, ceps, ws, g, nb);
             }
-            // pos 12: S1 -- kappa1 = S1 X - K05 nu + hr1 ; mu += c kappa1
-            M = p.use_and_prefetch(Ha0);
+            // use 12: S1 -- mu_new = X + c (S1 X - K05 li_new + hr1)
+            M = p.next();
             if (active) {
-                a_neg(A);
-                mm(A, M, X);
-                a_axpy_rows(A, fw, wd, g, u);
-                a_axpy(mu, c, A);
+                mm_c<NT, BW>(mu, L, M, X);
+                a_axpy_rows(mu, cfw, wd, g, unew);
             }
-            // traces (adjoint_grad_calc!, :2581-2618), per control q, weighted by the sample weight:
-            //   tr1 = tr(vr0' Hanti X)  tr3 = tr(vr' Hanti X)  tr5 = tr(vi05' Hanti (li0+li))
-            //   tr2 = tr(vi05' Hsym X)  tr4 = tr(vr' Hsym li) + tr(vr0' Hsym li0)
-            for (int q = 0; q < Nc; ++q) {
-                double t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
-                M = p.use_and_prefetch(Hs0 + (size_t)q * a.mat_elems);  // now: Hanti_q
-                if (active) {
-                    Arr<NT> T;
-                    a_zero(T);
-                    mm(T, M, X);
-                    t1 = a_dot(uold, T);
-                    t3 = a_dot(u, T);
-                    a_zero(T);
-                    mm(T, M, Bq);
-                    t5 = a_dot(v05, T);
-                }
-                const int nn = (n + 1 < a.nsteps_chunk) ? n + 1 : n;
-                const double* nxt = (q + 1 < Nc) ? Ha0 + (size_t)(q + 1) * a.mat_elems : stream_mat(a, 2 * nn + 1, 0);
-                M = p.use_and_prefetch(nxt);  // now: Hsym_q
-                if (active) {
-                    Arr<NT> T;
-                    a_zero(T);
-                    mm(T, M, X);
-                    t2 = a_dot(v05, T);
-                    a_zero(T);
-                    mm(T, M, nu);
-                    const double p4 = a_dot(u, T);
-                    t4 = p4 + carry[q * 256 + threadIdx.x];
-                    carry[q * 256 + threadIdx.x] = p4;
-                    t1 = wave_sum(t1 * wgt);
-                    t2 = wave_sum(t2 * wgt);
-                    t3 = wave_sum(t3 * wgt);
-                    t4 = wave_sum(t4 * wgt);
-                    t5 = wave_sum(t5 * wgt);
-                    if (lane == 0) {
-                        double* tr = a.traces + ((size_t)slab * a.nsteps_chunk + n) * (Nc * JQ_NTR) + q * JQ_NTR;
-                        tr[0] = t1;
-                        tr[1] = t2;
-                        tr[2] = t3;
-                        tr[3] = t4;
-                        tr[4] = t5;
-                    }
+        }
+        // traces (adjoint_grad_calc!, :2581-2618), per control q, weighted by the sample weight:
+        //   tr1 = tr(vr0' Hanti X)  tr3 = tr(vr' Hanti X)  tr5 = tr(vi05' Hanti (li0+li))
+        //   tr2 = tr(vi05' Hsym X)  tr4 = tr(vr' Hsym li) + tr(vr0' Hsym li0)
+        // (u = vr0 before the state step, unew = vr after it; Bq = -(li0 + li), nb = -li)
+        for (int q = 0; q < Nc; ++q) {
+            double t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
+            const int bwq = a.bw_trace[q];
+            const double* M = p.next();  // Hanti_q
+            if (active) {
+                Arr<NT> T;
+                mm_z_bw<NT, BW>(T, M, X, bwq);
+                t1 = a_dot(u, T);
+                t3 = a_dot(unew, T);
+                mm_z_bw<NT, BW>(T, M, Bq, bwq);
+                t5 = -a_dot(v05, T);
+            }
+            M = p.next();  // Hsym_q
+            if (active) {
+                Arr<NT> T;
+                mm_z_bw<NT, BW>(T, M, X, bwq);
+                t2 = a_dot(v05, T);
+                mm_z_bw<NT, BW>(T, M, nb, bwq);
+                const double p4 = -a_dot(unew, T);
+                t4 = p4 + carry[q * 256 + threadIdx.x];
+                carry[q * 256 + threadIdx.x] = p4;
+                t1 = wave_sum(t1 * wgt);
+                t2 = wave_sum(t2 * wgt);
+                t3 = wave_sum(t3 * wgt);
+                t4 = wave_sum(t4 * wgt);
+                t5 = wave_sum(t5 * wgt);
+                if (lane == 0) {
+                    double* tr = a.traces + ((size_t)slab * a.nsteps_chunk + n) * (Nc * JQ_NTR) + q * JQ_NTR;
+                    tr[0] = t1;
+                    tr[1] = t2;
+                    tr[2] = t3;
+                    tr[3] = t4;
+                    tr[4] = t5;
                 }
             }
         }
+        if (active) u = unew;
     }
-    __syncthreads();
+    p.drain();
     if (active) {
         a_store(u, st, lane);
         a_store(v, st + KT * 64, lane);
         a_store(mu, st + 2 * KT * 64, lane);
-        a_store(nu, st + 3 * KT * 64, lane);
+        a_store(nb, st + 3 * KT * 64, lane);
         for (int q = 0; q < Nc; ++q) st[(JQ_STATE_ARRAYS * KT + q) * 64 + lane] = carry[q * 256 + threadIdx.x];
     }
 }

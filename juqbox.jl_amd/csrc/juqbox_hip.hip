@@ -28,11 +28,15 @@ struct jq_handle {
     int Ntot = 0, N = 0, Nc = 0, Nfreq = 0, nsteps = 0, m = 0, objFuncType = 1;
     double T = 0.0;
     int NT = 0, KT = 0, NP = 0, sps = 0;
-    long long mat_elems = 0;
+    int BW = 0;                 // block band width the kernels are instantiated for
+    int bw_trace[JQ_MAXNC] = {0, 0, 0, 0};
+    long long mat_elems = 0;    // doubles per operator image slot ("stride"): band tiles, padded to 1 KiB
     long long state_stride = 0;
+    int nslots = 2;
     std::vector<double> Hconst, Hsym, Hanti, Uinit, Utr, Uti, wd, cfreq;
     std::vector<double> tf, tb;
     // device buffers (owned)
+    double *d_cimg = nullptr;
     double *d_himg = nullptr, *d_uimg = nullptr, *d_vtr = nullptr, *d_vti = nullptr, *d_tabs = nullptr;
     double *d_tf = nullptr, *d_tb = nullptr, *d_cfreq = nullptr, *d_pcof = nullptr;
     double *d_stream = nullptr, *d_pq = nullptr;
@@ -62,17 +66,33 @@ static int fail(jq_handle* h, int code, const char* msg)
     return code;
 }
 
-// A-fragment tile image of a column-major Ntot x Ntot matrix, walk order (kk outer, mt inner):
-// tile (mt,kk) lane l holds M[16*mt + (l&15)][4*kk + (l>>4)]; zero padded.
-static void tile_image(const double* M, int Ntot, int NT, double* img)
+// A-fragment tile image of a column-major Ntot x Ntot matrix: only the tiles of the block band
+// |mt - kk/4| <= BW are stored, in walk order (kk outer, mt inner); tile (mt,kk) lane l holds
+// M[16*mt + (l&15)][4*kk + (l>>4)]; zero padded.
+static void tile_image(const double* M, int Ntot, int NT, int BW, double* img)
 {
     const int KT = 4 * NT;
+    size_t idx = 0;
     for (int kk = 0; kk < KT; ++kk)
-        for (int mt = 0; mt < NT; ++mt)
+        for (int mt = 0; mt < NT; ++mt) {
+            const int kb = kk >> 2;
+            if (mt - kb > BW || kb - mt > BW) continue;
             for (int l = 0; l < 64; ++l) {
                 const int row = 16 * mt + (l & 15), col = 4 * kk + (l >> 4);
-                img[((size_t)kk * NT + mt) * 64 + l] = (row < Ntot && col < Ntot) ? M[row + (size_t)Ntot * col] : 0.0;
+                img[idx * 64 + l] = (row < Ntot && col < Ntot) ? M[row + (size_t)Ntot * col] : 0.0;
             }
+            ++idx;
+        }
+}
+
+// smallest block band width that contains every nonzero of M
+static int block_band(const double* M, int Ntot)
+{
+    int bw = 0;
+    for (int col = 0; col < Ntot; ++col)
+        for (int row = 0; row < Ntot; ++row)
+            if (M[row + (size_t)Ntot * col] != 0.0) bw = std::max(bw, std::abs(row / 16 - col / 16));
+    return bw;
 }
 
 // register-layout image [KT][64] of an Ntot x N array replicated over the samples of a slab
@@ -99,13 +119,21 @@ static int dev_alloc(jq_handle* h, T** p, size_t count)
 static int upload_operators(jq_handle* h)
 {
     const size_t nn = (size_t)h->Ntot * h->Ntot;
+    // images the tile stream is generated from: [H0 | Hsym_q | Hanti_q] in the kernels' band layout
     std::vector<double> img((size_t)(1 + 2 * h->Nc) * h->mat_elems, 0.0);
-    tile_image(h->Hconst.data(), h->Ntot, h->NT, img.data());
+    tile_image(h->Hconst.data(), h->Ntot, h->NT, h->BW, img.data());
     for (int q = 0; q < h->Nc; ++q) {
-        tile_image(h->Hsym.data() + q * nn, h->Ntot, h->NT, img.data() + (size_t)(1 + q) * h->mat_elems);
-        tile_image(h->Hanti.data() + q * nn, h->Ntot, h->NT, img.data() + (size_t)(1 + h->Nc + q) * h->mat_elems);
+        tile_image(h->Hsym.data() + q * nn, h->Ntot, h->NT, h->BW, img.data() + (size_t)(1 + q) * h->mat_elems);
+        tile_image(h->Hanti.data() + q * nn, h->Ntot, h->NT, h->BW, img.data() + (size_t)(1 + h->Nc + q) * h->mat_elems);
     }
     HIPCHK(h, hipMemcpy(h->d_himg, img.data(), img.size() * sizeof(double), hipMemcpyHostToDevice));
+    // images of the trace products: [Hsym_q | Hanti_q], each pair in its own band (0 or BW)
+    std::vector<double> cimg((size_t)(2 * h->Nc) * h->mat_elems, 0.0);
+    for (int q = 0; q < h->Nc; ++q) {
+        tile_image(h->Hsym.data() + q * nn, h->Ntot, h->NT, h->bw_trace[q], cimg.data() + (size_t)q * h->mat_elems);
+        tile_image(h->Hanti.data() + q * nn, h->Ntot, h->NT, h->bw_trace[q], cimg.data() + (size_t)(h->Nc + q) * h->mat_elems);
+    }
+    HIPCHK(h, hipMemcpy(h->d_cimg, cimg.data(), cimg.size() * sizeof(double), hipMemcpyHostToDevice));
     return JQ_OK;
 }
 
@@ -136,7 +164,7 @@ extern "C" void jq_destroy(jq_handle* h)
 {
     if (!h) return;
     hipSetDevice(h->device);
-    double** bufs[] = {&h->d_himg,  &h->d_uimg,       &h->d_vtr,     &h->d_vti,    &h->d_tabs, &h->d_tf,   &h->d_tb,
+    double** bufs[] = {&h->d_cimg, &h->d_himg,  &h->d_uimg,       &h->d_vtr,     &h->d_vti,    &h->d_tabs, &h->d_tf,   &h->d_tb,
                        &h->d_cfreq, &h->d_pcof,       &h->d_stream,  &h->d_pq,     &h->d_state, &h->d_state_save,
                        &h->d_colinfo, &h->d_traces,   &h->d_R,       &h->d_grad,   &h->d_res};
     for (auto b : bufs)
@@ -180,7 +208,6 @@ static int create_impl(const jq_problem* p, jq_handle* h)
     h->KT = 4 * h->NT;
     h->NP = 16 * h->NT;
     h->sps = 16 / p->N;
-    h->mat_elems = ((256LL * h->NT * h->NT + 511) / 512) * 512;
     h->state_stride = (long long)(JQ_STATE_ARRAYS * h->KT + JQ_STATE_EXTRA) * 64;
     const size_t nn = (size_t)p->Ntot * p->Ntot, nc = (size_t)p->Ntot * p->N;
     h->Hconst.assign(p->Hconst, p->Hconst + nn);
@@ -191,6 +218,29 @@ static int create_impl(const jq_problem* p, jq_handle* h)
     h->Uti.assign(p->Utarget_i, p->Utarget_i + nc);
     h->wd.assign(p->wmat_real_diag, p->wmat_real_diag + p->Ntot);
     h->cfreq.assign(p->Cfreq, p->Cfreq + (size_t)p->Ncoupled * p->Nfreq);
+
+    // block-band structure (16x16 blocks) of the operators: kernels exist for BW in {0,1,2,NT-1}
+    {
+        int bw = block_band(h->Hconst.data(), h->Ntot);
+        for (int q = 0; q < h->Nc; ++q) {
+            const int bq = std::max(block_band(h->Hsym.data() + q * nn, h->Ntot), block_band(h->Hanti.data() + q * nn, h->Ntot));
+            h->bw_trace[q] = bq;
+            bw = std::max(bw, bq);
+        }
+        if (const char* e = getenv("JQ_FORCE_DENSE"))
+            if (atoi(e) != 0) bw = h->NT - 1;
+        h->BW = (bw <= 2 && bw < h->NT - 1) ? bw : h->NT - 1;
+        for (int q = 0; q < h->Nc; ++q) h->bw_trace[q] = (h->bw_trace[q] == 0) ? 0 : h->BW;
+        h->mat_elems = ((64LL * band_tiles(h->NT, h->BW) + 127) / 128) * 128;
+        const long long lds_fixed = (long long)32 * h->NT * 8 + (long long)JQ_MAXNC * 256 * 8;
+        long long ns = (163840 - lds_fixed) / (h->mat_elems * 8);
+        if (ns < 2) return fail(h, JQ_EUNSUPPORTED, "jq_create: operator images do not fit the LDS ring");
+        h->nslots = (int)std::min<long long>(ns, JQ_MAXSLOTS);
+        if (const char* e = getenv("JQ_NSLOTS")) {
+            const int v = atoi(e);
+            if (v >= 2 && v <= h->nslots) h->nslots = v;
+        }
+    }
 
     // time tables, accumulated exactly like the reference: t = t + h (src/StormerVerlet.jl:502);
     // the backward sweep restarts from exactly T with h = -dt (src/evalobjgrad.jl:811-812)
@@ -210,6 +260,7 @@ static int create_impl(const jq_problem* p, jq_handle* h)
 
     int rc;
     if ((rc = dev_alloc(h, &h->d_himg, (size_t)(1 + 2 * h->Nc) * h->mat_elems))) return rc;
+    if ((rc = dev_alloc(h, &h->d_cimg, (size_t)(2 * h->Nc) * h->mat_elems))) return rc;
     if ((rc = dev_alloc(h, &h->d_uimg, (size_t)h->KT * 64))) return rc;
     if ((rc = dev_alloc(h, &h->d_vtr, (size_t)h->KT * 64))) return rc;
     if ((rc = dev_alloc(h, &h->d_vti, (size_t)h->KT * 64))) return rc;
@@ -309,26 +360,29 @@ extern "C" int jq_update_wmat_diag(jq_handle* h, const double* w)
 // ---------------------------------------------------------------------------------------------
 typedef void (*prop_kernel_t)(PropArgs);
 
-template <int NT>
+template <int NT, int BW>
 static void pick_kernels(prop_kernel_t* fwd, prop_kernel_t* bwd)
 {
     constexpr int MINW = (NT <= 2) ? 2 : 1;
-    *fwd = k_forward<NT, MINW>;
-    *bwd = k_backward<NT, MINW>;
+    *fwd = k_forward<NT, BW, MINW>;
+    *bwd = k_backward<NT, BW, MINW>;
 }
 
 static int select_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
 {
-    switch (h->NT) {
-    case 1: pick_kernels<1>(fwd, bwd); break;
-    case 2: pick_kernels<2>(fwd, bwd); break;
-    case 3: pick_kernels<3>(fwd, bwd); break;
-    case 4: pick_kernels<4>(fwd, bwd); break;
-    case 5: pick_kernels<5>(fwd, bwd); break;
-    case 6: pick_kernels<6>(fwd, bwd); break;
-    default: return fail(h, JQ_EUNSUPPORTED, "unsupported Hilbert dimension");
+#define JQ_PICK(nt, bw)                        \
+    if (h->NT == nt && h->BW == bw) {          \
+        pick_kernels<nt, bw>(fwd, bwd);        \
+        return JQ_OK;                          \
     }
-    return JQ_OK;
+    JQ_PICK(1, 0)
+    JQ_PICK(2, 0) JQ_PICK(2, 1)
+    JQ_PICK(3, 0) JQ_PICK(3, 1) JQ_PICK(3, 2)
+    JQ_PICK(4, 0) JQ_PICK(4, 1) JQ_PICK(4, 2) JQ_PICK(4, 3)
+    JQ_PICK(5, 0) JQ_PICK(5, 1) JQ_PICK(5, 2) JQ_PICK(5, 4)
+    JQ_PICK(6, 0) JQ_PICK(6, 1) JQ_PICK(6, 2) JQ_PICK(6, 5)
+#undef JQ_PICK
+    return fail(h, JQ_EUNSUPPORTED, "unsupported Hilbert dimension / band width");
 }
 
 struct EvalOut {
@@ -422,12 +476,17 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     const double dt = h->T / h->nsteps;
     PropArgs a;
     memset(&a, 0, sizeof a);
-    a.stream = h->d_stream; a.himg = h->d_himg; a.state = h->d_state; a.colinfo = h->d_colinfo; a.traces = h->d_traces;
-    a.tabs = h->d_tabs; a.mat_elems = h->mat_elems; a.rounds = (int)(h->mat_elems * 8 / 4096); a.m = h->m;
+    a.stream = h->d_stream; a.cimg = h->d_cimg; a.state = h->d_state; a.colinfo = h->d_colinfo; a.traces = h->d_traces;
+    a.tabs = h->d_tabs; a.stride = h->mat_elems; a.pieces = (int)(h->mat_elems * 8 / 1024); a.nslots = h->nslots; a.m = h->m;
     a.nslabs = nslabs; a.Ncoupled = h->Nc; a.Ntot = h->Ntot; a.N = h->N; a.use_shift = use_shift ? 1 : 0;
     a.tinv = 1.0 / h->T; a.state_stride = h->state_stride;
+    for (int q = 0; q < JQ_MAXNC; ++q) a.bw_trace[q] = h->bw_trace[q];
+    // operator schedules: {kind (0 K, 1 S, 2 constant image), time point offset / image index}
+    const SchedEntry K0e = {0, 0}, S0e = {1, 0}, K05e = {0, 1}, S05e = {1, 1}, K1e = {0, 2}, S1e = {1, 2};
+    const SchedEntry fwd_sched[7] = {K05e, S05e, K0e, S0e, K1e, S1e, K05e};
+    const SchedEntry adj_sched[6] = {S0e, K0e, K1e, S05e, K05e, S1e};
 
-    const size_t lds_fwd = 2 * (size_t)h->mat_elems * 8 + (size_t)32 * h->NT * 8;
+    const size_t lds_fwd = (size_t)h->nslots * h->mat_elems * 8 + (size_t)32 * h->NT * 8;
     const size_t lds_bwd = lds_fwd + (size_t)JQ_MAXNC * 256 * 8;
     HIPCHK(h, hipFuncSetAttribute((const void*)kfwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fwd));
     HIPCHK(h, hipFuncSetAttribute((const void*)kbwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bwd));
@@ -446,16 +505,20 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     hipLaunchKernelGGL(k_init_state, dim3(nslabs), dim3(64), 0, s, h->d_state, h->state_stride, h->d_uimg, h->KT);
 
     long long mfma = 0;
-    const long long tiles = (long long)h->NT * h->KT;
+    const long long tiles = band_tiles(h->NT, h->BW);
+    long long trace_tiles = 0;
+    for (int q = 0; q < h->Nc; ++q) trace_tiles += band_tiles(h->NT, h->bw_trace[q]);
     // ---- forward sweep -------------------------------------------------------------------------
     for (int n0 = 0; n0 < h->nsteps; n0 += cs) {
         const int nc = std::min(cs, h->nsteps - n0);
         const int ntp = 2 * nc + 1;
         hipLaunchKernelGGL(k_ctrl, dim3((ntp + 127) / 128), dim3(128), 0, s, sp, h->d_tf, n0, ntp, dt, h->d_pq);
         hipLaunchKernelGGL(k_stream, dim3((unsigned)((h->mat_elems + 255) / 256), ntp), dim3(256), 0, s, h->d_himg, h->d_pq,
-                           h->Nc, h->mat_elems, h->d_stream);
+                           h->Nc, h->mat_elems, 0.5 * dt, h->d_stream);
         a.nsteps_chunk = nc; a.step0 = n0; a.first_chunk = (n0 == 0); a.h = dt; a.forced = 1;
         a.hist_r = hist_r; a.hist_i = hist_i;
+        a.period = 7; a.npro = 0;
+        for (int i = 0; i < 7; ++i) a.sched[i] = fwd_sched[i];
         HIPCHK(h, hipEventRecord(h->ev[evi++], s));
         hipLaunchKernelGGL(kfwd, dim3(nblocks), dim3(256), lds_fwd, s, a);
         HIPCHK(h, hipEventRecord(h->ev[evi++], s));
@@ -480,9 +543,17 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
                 const int ntp = 2 * nc + 1;
                 hipLaunchKernelGGL(k_ctrl, dim3((ntp + 127) / 128), dim3(128), 0, s, sp, h->d_tb, n0, ntp, -dt, h->d_pq);
                 hipLaunchKernelGGL(k_stream, dim3((unsigned)((h->mat_elems + 255) / 256), ntp), dim3(256), 0, s, h->d_himg,
-                                   h->d_pq, h->Nc, h->mat_elems, h->d_stream);
+                                   h->d_pq, h->Nc, h->mat_elems, -0.5 * dt, h->d_stream);
                 a.nsteps_chunk = nc; a.step0 = n0; a.first_chunk = (n0 == 0); a.h = -dt; a.forced = (pass == 0);
                 a.hist_r = nullptr; a.hist_i = nullptr;
+                a.period = 13 + 2 * h->Nc; a.npro = (n0 == 0) ? h->Nc : 0;
+                for (int i = 0; i < 7; ++i) a.sched[i] = fwd_sched[i];
+                for (int i = 0; i < 6; ++i) a.sched[7 + i] = adj_sched[i];
+                for (int q = 0; q < h->Nc; ++q) {
+                    a.sched[13 + 2 * q] = SchedEntry{2, h->Nc + q};   // Hanti_q
+                    a.sched[13 + 2 * q + 1] = SchedEntry{2, q};       // Hsym_q
+                    a.pro[q] = SchedEntry{2, q};                      // first chunk: carry products with Hsym_q
+                }
                 HIPCHK(h, hipEventRecord(h->ev[evi++], s));
                 hipLaunchKernelGGL(kbwd, dim3(nblocks), dim3(256), lds_bwd, s, a);
                 HIPCHK(h, hipEventRecord(h->ev[evi++], s));
@@ -490,8 +561,8 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
                                    h->d_traces, nslabs, nc, ntr, h->d_R);
                 hipLaunchKernelGGL(k_gradacc, dim3((ncoeff + 63) / 64), dim3(64), 0, s, sp, h->d_R, h->d_tb, n0, nc, -dt,
                                    h->d_grad + (size_t)pass * ncoeff);
-                mfma += (long long)nslabs * nc * (2 * (8 + 2 * h->m) + 4 * h->Nc) * tiles;
-                if (n0 == 0) mfma += (long long)nslabs * h->Nc * tiles;
+                mfma += (long long)nslabs * nc * (2 * (8 + 2 * h->m) * tiles + 4 * trace_tiles);
+                if (n0 == 0) mfma += (long long)nslabs * trace_tiles;
             }
         }
     }
