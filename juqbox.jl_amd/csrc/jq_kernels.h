@@ -30,7 +30,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define JQ_STATE_ARRAYS 4     // U, V, MU, NU
 #define JQ_STATE_EXTRA 8      // 64-double rows after the arrays: CARRY[0..3], LEAK, spare
 #define JQ_MAXSLOTS 4         // LDS ring depth (prefetch distance = slots-1 <= 3: one DMA per wave in flight)
-#define JQ_MAXSCHED 32        // max operator uses per time step (13 + 2*JQ_MAXNC = 21)
+#define JQ_MAXSCHED 32        // max operator uses per time step (13 + 3*JQ_MAXNC = 25)
 
 // number of stored tiles of an NT x 4NT tile grid with block band width BW (host + device)
 __host__ __device__ constexpr int band_tiles(int NT, int BW)
@@ -126,7 +126,7 @@ __device__ __forceinline__ void a_store(const Arr<NT>& a, double* __restrict__ i
 // `mat` already carries the lane offset.  Tile (mt,kk) lane l holds M[16*mt + (l&15)][4*kk + (l>>4)].
 // The A fragments are fetched JQ_PF tiles ahead of their MFMA through a small register FIFO: a
 // v_mfma_f64_16x16x4 occupies the matrix pipe for 64 cycles, an LDS read returns in ~100.
-#define JQ_PF 6
+#define JQ_PF 4
 template <int NT, int BW, bool ZEROC>
 __device__ __forceinline__ void mm_any(Arr<NT>& D, const Arr<NT>& C, const double* mat, const Arr<NT>& x)
 {
@@ -199,6 +199,7 @@ struct PropArgs {
     double* hist_r;         // forward history of sample 0 ([Ntot,N,nsteps+1]) or null
     double* hist_i;
     const double* tabs;     // wd[NP] (diag wmat_real, zero padded), ws[NP] (shift weights)
+    double* park;           // HBM parking images [nslabs][2][4*NT*64] (slot 0: G1; slot 1: P0 when park_lds == 0)
     long long stride;       // doubles per operator image slot (multiple of 128 = 1 KiB)
     long long state_stride; // doubles per slab in the array file
     int pieces;             // 1 KiB DMA pieces per operator image
@@ -212,6 +213,7 @@ struct PropArgs {
     int Ntot, N;
     int use_shift;
     int forced;             // backward: add the leakage forcing (0: step_no_forcing!)
+    int park_lds;           // 1: the backward kernel parks its dormant array in LDS, 0: in `park`
     int period;             // operator uses per time step
     int npro;               // operator uses before the first step (backward first chunk: carry products)
     int bw_trace[JQ_MAXNC]; // band width of the trace images per control (0 or the kernel's BW)
@@ -220,6 +222,27 @@ struct PropArgs {
     SchedEntry pro[JQ_MAXNC];
     SchedEntry sched[JQ_MAXSCHED];
 };
+
+// usaver[:,:,step+1] = vr ; usavei = -vi (src/evalobjgrad.jl:748-752); only sample 0 (slab 0, columns < N)
+template <int NT>
+__device__ __forceinline__ void hist_store(const PropArgs& a, int slab, int lane, int g, int n, const Arr<NT>& u,
+                                           const Arr<NT>& v)
+{
+    const int col = lane & 15;
+    if (slab == 0 && col < a.N) {
+        const size_t off = (size_t)(a.step0 + n + 1) * a.Ntot * a.N + (size_t)col * a.Ntot;
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * i + 4 * r + g;
+                if (row < a.Ntot) {
+                    a.hist_r[off + row] = u.t[i][r];
+                    a.hist_i[off + row] = -v.t[i][r];
+                }
+            }
+    }
+}
 
 // LDS ring of operator images fed by global->LDS DMA.  Operator use #Q lives in slot Q % nslots and is
 // fetched by wave Q % 4 alone, nslots-1 uses ahead, so a wave never has more than one DMA in flight
@@ -231,6 +254,8 @@ struct Ring {
     int Q;        // index of the operator use that comes next
     int Qp;       // index of the next operator use to prefetch
     int np, ip;   // (step, position) cursor of Qp within the schedule
+    int qslot;    // slot of operator use Q
+    int pslot;    // slot of operator use Qp
     int wave, lane;
 
     __device__ __forceinline__ const double* src_of_cursor() const
@@ -260,12 +285,17 @@ struct Ring {
     __device__ __forceinline__ void issue_prefetch()
     {
         if ((Qp & (JQ_WAVES - 1)) == wave) {
-            const char* src = (const char*)src_of_cursor() + lane * 16;
-            char* dst = smem + (size_t)(Qp % a->nslots) * slot_bytes;
+            // lane byte offset recomputed here (2 VALU ops) so that no long-lived VGPR has to survive
+            // (hipcc otherwise spills it and reloads it with a full vmcnt(0) wait in front of every DMA)
+            unsigned lo;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lo));
+            const char* src = (const char*)src_of_cursor() + lo * 16u;
+            char* dst = smem + (size_t)pslot * slot_bytes;
             for (int p = 0; p < a->pieces; ++p)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)p * 1024),
                                                  (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
         }
+        if (++pslot == a->nslots) pslot = 0;
         advance_cursor();
     }
     __device__ __forceinline__ void init(char* smem_, const PropArgs* a_, int wave_, int lane_)
@@ -277,6 +307,8 @@ struct Ring {
         Qp = 0;
         np = 0;
         ip = 0;
+        qslot = 0;
+        pslot = 0;
         wave = wave_;
         lane = lane_;
         for (int i = 0; i < a->nslots - 1; ++i) issue_prefetch();
@@ -289,7 +321,8 @@ struct Ring {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         issue_prefetch();
-        const double* M = (const double*)(smem + (size_t)(Q % a->nslots) * slot_bytes) + lane;
+        const double* M = (const double*)(smem + (size_t)qslot * slot_bytes) + lane;
+        if (++qslot == a->nslots) qslot = 0;
         ++Q;
         return M;
     }
@@ -341,36 +374,54 @@ __device__ __forceinline__ void horner_add(Arr<NT>& out, const Arr<NT>& bpa, con
     }
 }
 
-// State (re-)integration, operator uses 0..5 of one Stormer-Verlet step (forward step!,
-// src/StormerVerlet.jl:461-504, also used with h<0 by the backward sweep, src/evalobjgrad.jl:879):
-//   in : u, v at t          out: unew = u(t+h), v05, vpart = v05 + S05 v05   (u, v are left untouched)
-// The caller finishes with use 6:  v(t+h) = vpart + Kp05 unew.
-// Operator order per step: Kp05 S05 Kn0 S0 Kn1 S1 (Kp05).
-template <int NT, int BW>
-__device__ __forceinline__ void sv_step_head(Ring& p, const PropArgs& a, bool active, double ceps, const double* ws, int g,
-                                             const Arr<NT>& u, const Arr<NT>& v, Arr<NT>& unew, Arr<NT>& v05, Arr<NT>& vpart)
+// LDS / global parking of a dormant state array (one [4*NT][64] image per wave)
+template <int NT>
+__device__ __forceinline__ void a_park(const Arr<NT>& a, double* park)
 {
-    Arr<NT> A, Ya, Yb;
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) park[(4 * i + r) * 64] = a.t[i][r];
+}
+template <int NT>
+__device__ __forceinline__ void a_unpark(Arr<NT>& a, const double* park)
+{
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a.t[i][r] = park[(4 * i + r) * 64];
+}
+
+// State (re-)integration, operator uses 0..5 of one Stormer-Verlet step (forward step!,
+// src/StormerVerlet.jl:461-504, also used with h<0 by the backward sweep, src/evalobjgrad.jl:879).
+//   in : u (preserved), v (CONSUMED: overwritten in place by v05 = v(t+h/2))
+//   out: unew = u(t+h), vN = v05 + S05 v05 (the caller finishes v(t+h) = vN + Kp05 unew with use 6)
+//   A, Ya, Yb: scratch arrays.          Operator order per step: Kp05 S05 Kn0 S0 Kn1 S1 (Kp05).
+// At most 8 arrays are live here (u, v/v05, unew, vN, A, Ya, Yb + one of the caller's).
+template <int NT, int BW>
+__device__ __forceinline__ void sv_state(Ring& p, const PropArgs& a, bool active, double ceps, const double* ws, int g,
+                                         const Arr<NT>& u, Arr<NT>& v, Arr<NT>& unew, Arr<NT>& vN, Arr<NT>& A, Arr<NT>& Ya,
+                                         Arr<NT>& Yb)
+{
     // use 0: Kp05 -- A = c K05 u
     const double* M = p.next();
     if (active) {
         mm_z<NT, BW>(A, M, u);
         if (a.use_shift) a_axpy_rows(A, ceps, ws, g, u);
     }
-    // use 1: S05 -- A = c (K05 u + S05 v) ; v05 = v + sum_j S^j A ; vpart = v05 + S05 v05
+    // use 1: S05 -- A = c (K05 u + S05 v) ; v05 = v + sum_j S^j A (in place) ; vN = v05 + S05 v05
     M = p.next();
     if (active) {
         mm_c<NT, BW>(A, A, M, v);
-        v05 = v;
-        a_add(v05, A);
-        horner_add<NT, BW>(v05, v05, A, M, a.m, Ya, Yb);
-        mm_c<NT, BW>(vpart, v05, M, v05);
+        a_add(v, A);
+        horner_add<NT, BW>(v, v, A, M, a.m, Ya, Yb);
+        mm_c<NT, BW>(vN, v, M, v);
     }
     // use 2: Kn0 -- unew = u - c K0 v05
     M = p.next();
     if (active) {
-        mm_c<NT, BW>(unew, u, M, v05);
-        if (a.use_shift) a_axpy_rows(unew, -ceps, ws, g, v05);
+        mm_c<NT, BW>(unew, u, M, v);
+        if (a.use_shift) a_axpy_rows(unew, -ceps, ws, g, v);
     }
     // use 3: S0 -- unew = u + c (S0 u - K0 v05) = u + c kappa1
     M = p.next();
@@ -378,8 +429,8 @@ __device__ __forceinline__ void sv_step_head(Ring& p, const PropArgs& a, bool ac
     // use 4: Kn1 -- A = -c K1 v05
     M = p.next();
     if (active) {
-        mm_z<NT, BW>(A, M, v05);
-        if (a.use_shift) a_axpy_rows(A, -ceps, ws, g, v05);
+        mm_z<NT, BW>(A, M, v);
+        if (a.use_shift) a_axpy_rows(A, -ceps, ws, g, v);
     }
     // use 5: S1 -- A = c (S1 (u + c kappa1) - K1 v05) ; unew += sum_j S^j A
     M = p.next();
@@ -409,56 +460,54 @@ __global__ __launch_bounds__(256, MINW) void k_forward(PropArgs a)
     const double* ws = tab + 16 * NT;
     for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[i] = a.tabs[i];
 
-    Arr<NT> u, v;
+    Arr<NT> ua, va, ub, vb, A, Ya, Yb;
     double leak = 0.0, ceps = 0.0;
     double* st = a.state + (size_t)(active ? slab : 0) * a.state_stride;
     if (active) {
-        a_load(u, st, lane);
-        a_load(v, st + KT * 64, lane);
+        a_load(ua, st, lane);
+        a_load(va, st + KT * 64, lane);
         leak = st[(JQ_STATE_ARRAYS * KT + JQ_MAXNC) * 64 + lane];
         ceps = 0.5 * a.h * a.colinfo[(size_t)slab * 32 + (lane & 15)];
     } else {
-        a_zero(u);
-        a_zero(v);
+        a_zero(ua);
+        a_zero(va);
     }
     Ring p;
     p.init(smem, &a, wave, lane);
 
-    for (int n = 0; n < a.nsteps_chunk; ++n) {
-        Arr<NT> unew, v05, vpart;
-        if (active) leak += a_wsq(wd, g, u);  // trapezoidal part: tr(vr' W vr) at t_n (:700)
-        sv_step_head<NT, BW>(p, a, active, ceps, ws, g, u, v, unew, v05, vpart);
-        // use 6: Kp05 again -- v(t+h) = v05 + c (K05 u_new + S05 v05)
-        const double* M = p.next();
+    // one time step: (u, v) -> (unew, vN); v is consumed (becomes v05).  The two array pairs swap
+    // roles every step, so the loop body is written for two steps and nothing is ever copied.
+#define JQ_FWD_STEP(U, V, UN, VN, NSTEP)                                                                         \
+    {                                                                                                            \
+        if (active) leak += a_wsq(wd, g, U); /* trapezoidal part: tr(vr' W vr) at t_n (:700) */                  \
+        sv_state<NT, BW>(p, a, active, ceps, ws, g, U, V, UN, VN, A, Ya, Yb);                                    \
+        /* use 6: Kp05 again -- v(t+h) = v05 + c (K05 u_new + S05 v05) */                                        \
+        const double* M6 = p.next();                                                                             \
+        if (active) {                                                                                            \
+            mm_c<NT, BW>(VN, VN, M6, UN);                                                                        \
+            if (a.use_shift) a_axpy_rows(VN, ceps, ws, g, UN);                                                   \
+            /* leak integrand: tr(vr' W vr + 2 vi05' W vi05) after the step (:716, penalf2a :2170-2180) */       \
+            leak += a_wsq(wd, g, UN) + 2.0 * a_wsq(wd, g, V);                                                    \
+            if (a.hist_r) hist_store<NT>(a, slab, lane, g, NSTEP, UN, VN);                                       \
+        }                                                                                                        \
+    }
+    int n = 0;
+    for (; n + 1 < a.nsteps_chunk; n += 2) {
+        JQ_FWD_STEP(ua, va, ub, vb, n)
+        JQ_FWD_STEP(ub, vb, ua, va, n + 1)
+    }
+    if (n < a.nsteps_chunk) {
+        JQ_FWD_STEP(ua, va, ub, vb, n)
         if (active) {
-            mm_c<NT, BW>(v, vpart, M, unew);
-            if (a.use_shift) a_axpy_rows(v, ceps, ws, g, unew);
-            u = unew;
-            // leak integrand: tr(vr' W vr + 2 vi05' W vi05) after the step (:716, penalf2a :2170-2180)
-            leak += a_wsq(wd, g, u) + 2.0 * a_wsq(wd, g, v05);
-            if (a.hist_r) {
-                // usaver[:,:,step+1] = vr ; usavei = -vi (:748-752); only sample 0 (slab 0, columns < N)
-                const int col = lane & 15;
-                if (slab == 0 && col < a.N) {
-                    const size_t off = (size_t)(a.step0 + n + 1) * a.Ntot * a.N + (size_t)col * a.Ntot;
-#pragma unroll
-                    for (int i = 0; i < NT; ++i)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int row = 16 * i + 4 * r + g;
-                            if (row < a.Ntot) {
-                                a.hist_r[off + row] = u.t[i][r];
-                                a.hist_i[off + row] = -v.t[i][r];
-                            }
-                        }
-                }
-            }
+            ua = ub;
+            va = vb;
         }
     }
+#undef JQ_FWD_STEP
     p.drain();  // land the trailing prefetches before the workgroup exits
     if (active) {
-        a_store(u, st, lane);
-        a_store(v, st + KT * 64, lane);
+        a_store(ua, st, lane);
+        a_store(va, st + KT * 64, lane);
         st[(JQ_STATE_ARRAYS * KT + JQ_MAXNC) * 64 + lane] = leak;
     }
 }
@@ -467,9 +516,12 @@ __global__ __launch_bounds__(256, MINW) void k_forward(PropArgs a)
 // Backward sweep over one chunk (src/evalobjgrad.jl:859-921): state re-integration with h<0,
 // adjoint step! with forcing (src/StormerVerlet.jl:255-303) or step_no_forcing! (:365-451), and the
 // per-step trace scalars of adjoint_grad_calc! (src/evalobjgrad.jl:2567-2619), written to `traces`.
-// schedule (period 13 + 2*Ncoupled):
-//   Kp05 S05 Kn0 S0 Kn1 S1 Kp05 | S0 Kn0 Kn1 S05 Kp05 S1 | Hanti_0 Hsym_0 Hanti_1 Hsym_1 ...
+// schedule (period 13 + 3*Ncoupled):
+//   Kp05 S05 Kn0 S0 Kn1 S1 Kp05 | S0 | Hanti_0 .. | Kn0 Kn1 S05 Kp05 S1 | Hanti_0 Hsym_0 Hanti_1 Hsym_1 ...
 // State file slot NU holds nb = -lambda_i.
+// Register budget (512 per lane, 8 per array element pair): at most 9 state-sized arrays are live at
+// any point (8 since vr0 dies after the early traces); the one array that is dormant in each phase (lambda_r during the state step, v during the
+// adjoint step and the traces) is parked in the wave's LDS (or global) parking image.
 template <int NT, int BW, int MINW>
 __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
 {
@@ -487,10 +539,23 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
     const double* ws = tab + 16 * NT;
     double* carry = tab + 32 * NT;  // [JQ_MAXNC][256]
     for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[i] = a.tabs[i];
-
-    Arr<NT> u, v, mu, nb;
-    double ceps = 0.0, wgt = 0.0;
     double* st = a.state + (size_t)(active ? slab : 0) * a.state_stride;
+    // parking images of this wave: P0 in LDS when it fits (else HBM), G1 always in HBM
+    double* P0 = a.park_lds ? (carry + JQ_MAXNC * 256 + (size_t)wave * KT * 64 + lane)
+                            : (a.park + ((size_t)(active ? slab : 0) * 2 + 1) * KT * 64 + lane);
+    double* G1 = a.park + ((size_t)(active ? slab : 0) * 2) * KT * 64 + lane;
+
+    // array roles (register arrays are renamed, never copied, except at the end of a step):
+    //   u  : vr before the state step (vr0)      un : vr after it
+    //   v  : vi -> vi05 (in place)               vN : vi after the step / scratch Q, G
+    //   mu : lambda_r -> X = lambda_r^{1/2} (in place)
+    //   nb : -lambda_i (old) -> -(li0 + li)      L  : scratch -> -lambda_i (new)
+    //   Ya, Yb: Horner scratch (also trace products)
+    // Parking schedule (keeps <= 7 arrays live, the most hipcc allocates without scratch spills):
+    //   state step : mu -> P0, nb -> G1            uses 7..early traces : vN -> P0, v -> G1
+    //   use 10     : vN(P0), un -> G1             end of step          : v <- P0
+    Arr<NT> u, v, mu, nb, un, vN, L, Ya, Yb;
+    double ceps = 0.0, wgt = 0.0;
     if (active) {
         a_load(u, st, lane);
         a_load(v, st + KT * 64, lane);
@@ -517,125 +582,133 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
         for (int q = 0; q < Nc; ++q) {
             const double* M = p.next();  // Hsym_q
             if (active) {
-                Arr<NT> T;
-                mm_z_bw<NT, BW>(T, M, nb, a.bw_trace[q]);
-                carry[q * 256 + threadIdx.x] = -a_dot(u, T);
+                mm_z_bw<NT, BW>(Ya, M, nb, a.bw_trace[q]);
+                carry[q * 256 + threadIdx.x] = -a_dot(u, Ya);
             }
         }
     }
 
     for (int n = 0; n < a.nsteps_chunk; ++n) {
-        Arr<NT> unew, v05, X, Bq;
-        {
-            Arr<NT> R, Ya, Yb;
-            {
-                Arr<NT> vpart;
-                sv_step_head<NT, BW>(p, a, active, ceps, ws, g, u, v, unew, v05, vpart);
-                // use 6: Kp05 -- finish the state step; first adjoint product R = c K05 nb (= -c K05 lambda_i)
-                const double* M = p.next();
-                if (active) {
-                    mm_c<NT, BW>(v, vpart, M, unew);
-                    if (a.use_shift) a_axpy_rows(v, ceps, ws, g, unew);
-                    mm_z<NT, BW>(R, M, nb);
-                    if (a.use_shift) a_axpy_rows(R, ceps, ws, g, nb);
-                }
-            }
-            // use 7: S0 -- R = c (S0 mu - K05 li + hr0) ; X = mu + sum_j S^j R        (X = lambda_r^{1/2})
-            const double* M = p.next();
-            if (active) {
-                mm_c<NT, BW>(R, R, M, mu);
-                a_axpy_rows(R, cfw, wd, g, u);  // u still holds vr before the state step (:862)
-                X = mu;
-                a_add(X, R);
-                horner_add<NT, BW>(X, X, R, M, a.m, Ya, Yb);
-            }
+        // ---- state step (lambda_r and -lambda_i parked) -----------------------------------------
+        if (active) {
+            a_park(mu, P0);
+            a_park(nb, G1);
         }
-        {
-            Arr<NT> L, Qv, Ya, Yb;
-            // use 8: Kn0 -- L = -c K0 X
-            const double* M = p.next();
-            if (active) {
-                mm_z<NT, BW>(L, M, X);
-                if (a.use_shift) a_axpy_rows(L, -ceps, ws, g, X);
-            }
-            // use 9: Kn1 -- Qv = -c K1 X
-            M = p.next();
-            if (active) {
-                mm_z<NT, BW>(Qv, M, X);
-                if (a.use_shift) a_axpy_rows(Qv, -ceps, ws, g, X);
-            }
-            // use 10: S05 -- L = -c l2 = -c (K0 X + S05 li + hi0) ; Qv = -c (S05 (li + c l2) + K1 X + hi1) ;
-            //               nb_new = nb + L + sum_j S^j Qv          (li_new = li + c (l2 + l1))
-            M = p.next();
-            if (active) {
-                {
-                    Arr<NT> P;
-                    mm_z<NT, BW>(P, M, nb);
-                    a_axpy_rows(P, -cfw, wd, g, v05);  // P = c (-S05 li - hi0)
-                    a_add(L, P);
-                    a_add(Qv, P);
-                }
-                mm_c<NT, BW>(Qv, Qv, M, L);
-                Bq = nb;          // nb_old, becomes nb_old + nb_new below
-                a_add(L, nb);
-                a_add(L, Qv);     // L = nb + L + Qv
-                horner_add<NT, BW>(nb, L, Qv, M, a.m, Ya, Yb);
-                a_add(Bq, nb);
-            }
-            // use 11: Kp05 -- L = X + c K05 nb_new (= lambda_r^{1/2} - c K05 li_new)
-            M = p.next();
-            if (active) {
-                mm_c<NT, BW>(L, X, M, nb);
-                if (a.use_shift) a_axpy_rows(L, ceps, ws, g, nb);
-            }
-            // use 12: S1 -- mu_new = X + c (S1 X - K05 li_new + hr1)
-            M = p.next();
-            if (active) {
-                mm_c<NT, BW>(mu, L, M, X);
-                a_axpy_rows(mu, cfw, wd, g, unew);
-            }
+        // mu's registers serve as the scratch array A of the state step
+        sv_state<NT, BW>(p, a, active, ceps, ws, g, u, v, un, vN, mu, Ya, Yb);
+        // use 6: Kp05 -- finish the state step; first adjoint product L = c K05 nb (= -c K05 lambda_i)
+        const double* M = p.next();
+        if (active) {
+            a_unpark(nb, G1);   // lands while the first product below runs
+            mm_c<NT, BW>(vN, vN, M, un);
+            if (a.use_shift) a_axpy_rows(vN, ceps, ws, g, un);
+            mm_z<NT, BW>(L, M, nb);
+            if (a.use_shift) a_axpy_rows(L, ceps, ws, g, nb);
+            a_unpark(mu, P0);
+            a_park(vN, P0);     // vi(t_n) sleeps until the end of the step
+            a_park(v, G1);      // vi05 sleeps until use 10
         }
-        // traces (adjoint_grad_calc!, :2581-2618), per control q, weighted by the sample weight:
-        //   tr1 = tr(vr0' Hanti X)  tr3 = tr(vr' Hanti X)  tr5 = tr(vi05' Hanti (li0+li))
-        //   tr2 = tr(vi05' Hsym X)  tr4 = tr(vr' Hsym li) + tr(vr0' Hsym li0)
-        // (u = vr0 before the state step, unew = vr after it; Bq = -(li0 + li), nb = -li)
+        // ---- adjoint step ----------------------------------------------------------------------
+        // use 7: S0 -- L = c (S0 mu - K05 li + hr0) ; X = mu + sum_j S^j L   (in place: mu becomes X)
+        M = p.next();
+        if (active) {
+            mm_c<NT, BW>(L, L, M, mu);
+            a_axpy_rows(L, cfw, wd, g, u);  // u holds vr before the state step (:862)
+            a_add(mu, L);
+            horner_add<NT, BW>(mu, mu, L, M, a.m, Ya, Yb);
+        }
+        // early traces with X (lets vr0 = u die here): tr1 = tr(vr0' Hanti_q X), tr3 = tr(vr' Hanti_q X)
         for (int q = 0; q < Nc; ++q) {
-            double t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
-            const int bwq = a.bw_trace[q];
-            const double* M = p.next();  // Hanti_q
+            M = p.next();  // Hanti_q
             if (active) {
-                Arr<NT> T;
-                mm_z_bw<NT, BW>(T, M, X, bwq);
-                t1 = a_dot(u, T);
-                t3 = a_dot(unew, T);
-                mm_z_bw<NT, BW>(T, M, Bq, bwq);
-                t5 = -a_dot(v05, T);
+                mm_z_bw<NT, BW>(Ya, M, mu, a.bw_trace[q]);
+                const double t1 = wave_sum(a_dot(u, Ya) * wgt);
+                const double t3 = wave_sum(a_dot(un, Ya) * wgt);
+                if (lane == 0) {
+                    double* tr = a.traces + ((size_t)slab * a.nsteps_chunk + n) * (Nc * JQ_NTR) + q * JQ_NTR;
+                    tr[0] = t1;
+                    tr[2] = t3;
+                }
+            }
+        }
+        // use 8: Kn0 -- L = -c K0 X
+        M = p.next();
+        if (active) {
+            a_unpark(v, G1);    // vi05 back (needed at use 10); vr(t_n) takes its place
+            mm_z<NT, BW>(L, M, mu);
+            if (a.use_shift) a_axpy_rows(L, -ceps, ws, g, mu);
+        }
+        // use 9: Kn1 -- vN(scratch Q) = -c K1 X
+        M = p.next();
+        if (active) {
+            mm_z<NT, BW>(vN, M, mu);
+            if (a.use_shift) a_axpy_rows(vN, -ceps, ws, g, mu);
+            a_park(un, G1);
+        }
+        // use 10: S05 -- L = -c l2 = -c (K0 X + S05 li + hi0) ; Q = -c (S05 (li + c l2) + K1 X + hi1) ;
+        //               nb_new = nb + L + sum_j S^j Q          (li_new = li + c (l2 + l1))
+        M = p.next();
+        if (active) {
+            mm_z<NT, BW>(Ya, M, nb);
+            a_axpy_rows(Ya, -cfw, wd, g, v);  // v holds vi05;  Ya = c (-S05 li - hi0)
+            a_add(L, Ya);
+            a_add(vN, Ya);
+            mm_c<NT, BW>(vN, vN, M, L);       // vN = Q
+            a_add(L, nb);
+            a_add(L, vN);                     // L = nb + L + Q
+            horner_add<NT, BW>(L, L, vN, M, a.m, Ya, Yb);  // L = nb_new
+            a_add(nb, L);                     // nb = nb_old + nb_new = -(li0 + li)
+        }
+        // use 11: Kp05 -- vN(scratch G) = X + c K05 nb_new (= lambda_r^{1/2} - c K05 li_new)
+        M = p.next();
+        if (active) {
+            a_unpark(un, G1);
+            mm_c<NT, BW>(vN, mu, M, L);
+            if (a.use_shift) a_axpy_rows(vN, ceps, ws, g, L);
+        }
+        // use 12: S1 -- lambda_r_new = X + c (S1 X - K05 li_new + hr1)
+        M = p.next();
+        if (active) {
+            mm_c<NT, BW>(vN, vN, M, mu);
+            a_axpy_rows(vN, cfw, wd, g, un);
+        }
+        // ---- late traces (adjoint_grad_calc!, :2581-2618), per control q, weighted by the sample weight:
+        //   tr5 = tr(vi05' Hanti (li0+li))   tr2 = tr(vi05' Hsym X)   tr4 = tr(vr' Hsym li) + tr(vr0' Hsym li0)
+        // here: un = vr, v = vi05, mu = X, nb = -(li0+li), L = -li
+        for (int q = 0; q < Nc; ++q) {
+            double t2 = 0, t4 = 0, t5 = 0;
+            const int bwq = a.bw_trace[q];
+            M = p.next();  // Hanti_q
+            if (active) {
+                mm_z_bw<NT, BW>(Ya, M, nb, bwq);
+                t5 = -a_dot(v, Ya);
             }
             M = p.next();  // Hsym_q
             if (active) {
-                Arr<NT> T;
-                mm_z_bw<NT, BW>(T, M, X, bwq);
-                t2 = a_dot(v05, T);
-                mm_z_bw<NT, BW>(T, M, nb, bwq);
-                const double p4 = -a_dot(unew, T);
+                mm_z_bw<NT, BW>(Ya, M, mu, bwq);
+                t2 = a_dot(v, Ya);
+                mm_z_bw<NT, BW>(Ya, M, L, bwq);
+                const double p4 = -a_dot(un, Ya);
                 t4 = p4 + carry[q * 256 + threadIdx.x];
                 carry[q * 256 + threadIdx.x] = p4;
-                t1 = wave_sum(t1 * wgt);
                 t2 = wave_sum(t2 * wgt);
-                t3 = wave_sum(t3 * wgt);
                 t4 = wave_sum(t4 * wgt);
                 t5 = wave_sum(t5 * wgt);
                 if (lane == 0) {
                     double* tr = a.traces + ((size_t)slab * a.nsteps_chunk + n) * (Nc * JQ_NTR) + q * JQ_NTR;
-                    tr[0] = t1;
                     tr[1] = t2;
-                    tr[2] = t3;
                     tr[3] = t4;
                     tr[4] = t5;
                 }
             }
         }
-        if (active) u = unew;
+        // ---- roles for the next step: u <- un, mu <- vN(new lambda_r), nb <- L, v <- parked vi(t_n)
+        if (active) {
+            u = un;
+            mu = vN;
+            nb = L;
+            a_unpark(v, P0);
+        }
     }
     p.drain();
     if (active) {

@@ -32,11 +32,13 @@ struct jq_handle {
     int bw_trace[JQ_MAXNC] = {0, 0, 0, 0};
     long long mat_elems = 0;    // doubles per operator image slot ("stride"): band tiles, padded to 1 KiB
     long long state_stride = 0;
-    int nslots = 2;
+    int nslots = 2;             // LDS ring depth of the forward kernel
+    int nslots_bwd = 2;         // ... of the backward kernel (shares LDS with carry + parking images)
+    int park_lds = 0;           // backward kernel parks its dormant array in LDS (1) or HBM (0)
     std::vector<double> Hconst, Hsym, Hanti, Uinit, Utr, Uti, wd, cfreq;
     std::vector<double> tf, tb;
     // device buffers (owned)
-    double *d_cimg = nullptr;
+    double *d_cimg = nullptr, *d_park = nullptr;
     double *d_himg = nullptr, *d_uimg = nullptr, *d_vtr = nullptr, *d_vti = nullptr, *d_tabs = nullptr;
     double *d_tf = nullptr, *d_tb = nullptr, *d_cfreq = nullptr, *d_pcof = nullptr;
     double *d_stream = nullptr, *d_pq = nullptr;
@@ -109,7 +111,7 @@ template <typename T>
 static int dev_alloc(jq_handle* h, T** p, size_t count)
 {
     if (*p) {
-        hipFree(*p);
+        (void)hipFree(*p);
         *p = nullptr;
     }
     HIPCHK(h, hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T)));
@@ -163,14 +165,14 @@ extern "C" const char* jq_last_error(const jq_handle* h) { return h ? h->err.c_s
 extern "C" void jq_destroy(jq_handle* h)
 {
     if (!h) return;
-    hipSetDevice(h->device);
-    double** bufs[] = {&h->d_cimg, &h->d_himg,  &h->d_uimg,       &h->d_vtr,     &h->d_vti,    &h->d_tabs, &h->d_tf,   &h->d_tb,
+    (void)hipSetDevice(h->device);
+    double** bufs[] = {&h->d_park, &h->d_cimg, &h->d_himg,  &h->d_uimg,       &h->d_vtr,     &h->d_vti,    &h->d_tabs, &h->d_tf,   &h->d_tb,
                        &h->d_cfreq, &h->d_pcof,       &h->d_stream,  &h->d_pq,     &h->d_state, &h->d_state_save,
                        &h->d_colinfo, &h->d_traces,   &h->d_R,       &h->d_grad,   &h->d_res};
     for (auto b : bufs)
-        if (*b) hipFree(*b);
-    for (auto e : h->ev) hipEventDestroy(e);
-    if (h->stream) hipStreamDestroy(h->stream);
+        if (*b) (void)hipFree(*b);
+    for (auto e : h->ev) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
 
@@ -232,13 +234,26 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         h->BW = (bw <= 2 && bw < h->NT - 1) ? bw : h->NT - 1;
         for (int q = 0; q < h->Nc; ++q) h->bw_trace[q] = (h->bw_trace[q] == 0) ? 0 : h->BW;
         h->mat_elems = ((64LL * band_tiles(h->NT, h->BW) + 127) / 128) * 128;
-        const long long lds_fixed = (long long)32 * h->NT * 8 + (long long)JQ_MAXNC * 256 * 8;
-        long long ns = (163840 - lds_fixed) / (h->mat_elems * 8);
-        if (ns < 2) return fail(h, JQ_EUNSUPPORTED, "jq_create: operator images do not fit the LDS ring");
-        h->nslots = (int)std::min<long long>(ns, JQ_MAXSLOTS);
+        const long long slot = h->mat_elems * 8;
+        const long long lds_fwd_fixed = (long long)32 * h->NT * 8;
+        const long long lds_bwd_fixed = lds_fwd_fixed + (long long)JQ_MAXNC * 256 * 8;
+        const long long park_bytes = (long long)JQ_WAVES * h->KT * 64 * 8;
+        long long nf = (163840 - lds_fwd_fixed) / slot;
+        if (nf < 2) return fail(h, JQ_EUNSUPPORTED, "jq_create: operator images do not fit the LDS ring");
+        h->nslots = (int)std::min<long long>(nf, JQ_MAXSLOTS);
+        long long nb = (163840 - lds_bwd_fixed - park_bytes) / slot;
+        if (nb >= 2) {
+            h->park_lds = 1;
+        } else {
+            h->park_lds = 0;
+            nb = (163840 - lds_bwd_fixed) / slot;
+            if (nb < 2) return fail(h, JQ_EUNSUPPORTED, "jq_create: operator images do not fit the LDS ring");
+        }
+        h->nslots_bwd = (int)std::min<long long>(nb, JQ_MAXSLOTS);
         if (const char* e = getenv("JQ_NSLOTS")) {
             const int v = atoi(e);
             if (v >= 2 && v <= h->nslots) h->nslots = v;
+            if (v >= 2 && v <= h->nslots_bwd) h->nslots_bwd = v;
         }
     }
 
@@ -360,27 +375,26 @@ extern "C" int jq_update_wmat_diag(jq_handle* h, const double* w)
 // ---------------------------------------------------------------------------------------------
 typedef void (*prop_kernel_t)(PropArgs);
 
-template <int NT, int BW>
-static void pick_kernels(prop_kernel_t* fwd, prop_kernel_t* bwd)
-{
-    constexpr int MINW = (NT <= 2) ? 2 : 1;
-    *fwd = k_forward<NT, BW, MINW>;
-    *bwd = k_backward<NT, BW, MINW>;
-}
+// The (NT, BW) instantiations are compiled in their own translation units (jq_kernel_inst.hip).
+#define JQ_FOR_EACH_INST(X)                                                                       \
+    X(1, 0) X(2, 0) X(2, 1) X(3, 0) X(3, 1) X(3, 2) X(4, 0) X(4, 1) X(4, 2) X(4, 3) X(5, 0) X(5, 1) \
+    X(5, 2) X(5, 4) X(6, 0) X(6, 1) X(6, 2) X(6, 5)
+#define JQ_MINW_OF(nt) (((nt) <= 2) ? 2 : 1)
+#define JQ_DECL(nt, bw)                                                               \
+    extern template __global__ void k_forward<nt, bw, JQ_MINW_OF(nt)>(PropArgs);      \
+    extern template __global__ void k_backward<nt, bw, JQ_MINW_OF(nt)>(PropArgs);
+JQ_FOR_EACH_INST(JQ_DECL)
+#undef JQ_DECL
 
 static int select_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
 {
-#define JQ_PICK(nt, bw)                        \
-    if (h->NT == nt && h->BW == bw) {          \
-        pick_kernels<nt, bw>(fwd, bwd);        \
-        return JQ_OK;                          \
+#define JQ_PICK(nt, bw)                                   \
+    if (h->NT == nt && h->BW == bw) {                     \
+        *fwd = k_forward<nt, bw, JQ_MINW_OF(nt)>;         \
+        *bwd = k_backward<nt, bw, JQ_MINW_OF(nt)>;        \
+        return JQ_OK;                                     \
     }
-    JQ_PICK(1, 0)
-    JQ_PICK(2, 0) JQ_PICK(2, 1)
-    JQ_PICK(3, 0) JQ_PICK(3, 1) JQ_PICK(3, 2)
-    JQ_PICK(4, 0) JQ_PICK(4, 1) JQ_PICK(4, 2) JQ_PICK(4, 3)
-    JQ_PICK(5, 0) JQ_PICK(5, 1) JQ_PICK(5, 2) JQ_PICK(5, 4)
-    JQ_PICK(6, 0) JQ_PICK(6, 1) JQ_PICK(6, 2) JQ_PICK(6, 5)
+    JQ_FOR_EACH_INST(JQ_PICK)
 #undef JQ_PICK
     return fail(h, JQ_EUNSUPPORTED, "unsupported Hilbert dimension / band width");
 }
@@ -429,6 +443,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
         if ((rc = dev_alloc(h, &h->d_state, (size_t)nslabs * h->state_stride))) return rc;
         if ((rc = dev_alloc(h, &h->d_state_save, (size_t)nslabs * h->state_stride))) return rc;
         if ((rc = dev_alloc(h, &h->d_colinfo, (size_t)nslabs * 32))) return rc;
+        if ((rc = dev_alloc(h, &h->d_park, (size_t)nslabs * 2 * h->KT * 64))) return rc;
         h->cap_slabs = nslabs;
         h->cap_traces = 0;
     }
@@ -487,7 +502,9 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     const SchedEntry adj_sched[6] = {S0e, K0e, K1e, S05e, K05e, S1e};
 
     const size_t lds_fwd = (size_t)h->nslots * h->mat_elems * 8 + (size_t)32 * h->NT * 8;
-    const size_t lds_bwd = lds_fwd + (size_t)JQ_MAXNC * 256 * 8;
+    const size_t lds_bwd = (size_t)h->nslots_bwd * h->mat_elems * 8 + (size_t)32 * h->NT * 8 + (size_t)JQ_MAXNC * 256 * 8 +
+                           (h->park_lds ? (size_t)JQ_WAVES * h->KT * 64 * 8 : 0);
+    a.park = h->d_park; a.park_lds = h->park_lds;
     HIPCHK(h, hipFuncSetAttribute((const void*)kfwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fwd));
     HIPCHK(h, hipFuncSetAttribute((const void*)kbwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bwd));
 
@@ -517,7 +534,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
                            h->Nc, h->mat_elems, 0.5 * dt, h->d_stream);
         a.nsteps_chunk = nc; a.step0 = n0; a.first_chunk = (n0 == 0); a.h = dt; a.forced = 1;
         a.hist_r = hist_r; a.hist_i = hist_i;
-        a.period = 7; a.npro = 0;
+        a.period = 7; a.npro = 0; a.nslots = h->nslots;
         for (int i = 0; i < 7; ++i) a.sched[i] = fwd_sched[i];
         HIPCHK(h, hipEventRecord(h->ev[evi++], s));
         hipLaunchKernelGGL(kfwd, dim3(nblocks), dim3(256), lds_fwd, s, a);
@@ -546,13 +563,18 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
                                    h->d_pq, h->Nc, h->mat_elems, -0.5 * dt, h->d_stream);
                 a.nsteps_chunk = nc; a.step0 = n0; a.first_chunk = (n0 == 0); a.h = -dt; a.forced = (pass == 0);
                 a.hist_r = nullptr; a.hist_i = nullptr;
-                a.period = 13 + 2 * h->Nc; a.npro = (n0 == 0) ? h->Nc : 0;
-                for (int i = 0; i < 7; ++i) a.sched[i] = fwd_sched[i];
-                for (int i = 0; i < 6; ++i) a.sched[7 + i] = adj_sched[i];
-                for (int q = 0; q < h->Nc; ++q) {
-                    a.sched[13 + 2 * q] = SchedEntry{2, h->Nc + q};   // Hanti_q
-                    a.sched[13 + 2 * q + 1] = SchedEntry{2, q};       // Hsym_q
-                    a.pro[q] = SchedEntry{2, q};                      // first chunk: carry products with Hsym_q
+                a.period = 13 + 3 * h->Nc; a.npro = (n0 == 0) ? h->Nc : 0; a.nslots = h->nslots_bwd;
+                {
+                    int k = 0;
+                    for (int i = 0; i < 7; ++i) a.sched[k++] = fwd_sched[i];
+                    a.sched[k++] = adj_sched[0];                                              // S0
+                    for (int q = 0; q < h->Nc; ++q) a.sched[k++] = SchedEntry{2, h->Nc + q};  // early traces: Hanti_q
+                    for (int i = 1; i < 6; ++i) a.sched[k++] = adj_sched[i];                  // Kn0 Kn1 S05 Kp05 S1
+                    for (int q = 0; q < h->Nc; ++q) {
+                        a.sched[k++] = SchedEntry{2, h->Nc + q};                              // late traces: Hanti_q
+                        a.sched[k++] = SchedEntry{2, q};                                      //              Hsym_q
+                        a.pro[q] = SchedEntry{2, q};                  // first chunk: carry products with Hsym_q
+                    }
                 }
                 HIPCHK(h, hipEventRecord(h->ev[evi++], s));
                 hipLaunchKernelGGL(kbwd, dim3(nblocks), dim3(256), lds_bwd, s, a);
@@ -647,11 +669,11 @@ extern "C" int jq_state_history(jq_handle* h, const double* pcof, int32_t ncoeff
     double *d_r = nullptr, *d_i = nullptr;
     HIPCHK(h, hipMalloc((void**)&d_r, len * sizeof(double)));
     if (hipMalloc((void**)&d_i, len * sizeof(double)) != hipSuccess) {
-        hipFree(d_r);
+        (void)hipFree(d_r);
         return fail(h, JQ_ENOMEM, "jq_state_history: out of device memory");
     }
-    hipMemset(d_r, 0, len * sizeof(double));
-    hipMemset(d_i, 0, len * sizeof(double));
+    (void)hipMemset(d_r, 0, len * sizeof(double));
+    (void)hipMemset(d_i, 0, len * sizeof(double));
     EvalOut o;
     int rc = run_eval(h, pcof, ncoeff, 1, nullptr, nullptr, nullptr, false, d_r, d_i, &o);
     if (rc == JQ_OK) {
@@ -664,8 +686,8 @@ extern "C" int jq_state_history(jq_handle* h, const double* pcof, int32_t ncoeff
             ui[i] = -0.0;
         }
     }
-    hipFree(d_r);
-    hipFree(d_i);
+    (void)hipFree(d_r);
+    (void)hipFree(d_i);
     return rc;
 }
 
