@@ -29,7 +29,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define JQ_NTR 5              // trace scalars per control per backward step
 #define JQ_STATE_ARRAYS 4     // U, V, MU, NU
 #define JQ_STATE_EXTRA 8      // 64-double rows after the arrays: CARRY[0..3], LEAK, spare
-#define JQ_MAXSLOTS 4         // LDS ring depth (prefetch distance = slots-1 <= 3: one DMA per wave in flight)
+#define JQ_MAXSLOTS 2         // LDS operator slots (double buffer)
 #define JQ_MAXSCHED 32        // max operator uses per time step (13 + 3*JQ_MAXNC = 25)
 
 // number of stored tiles of an NT x 4NT tile grid with block band width BW (host + device)
@@ -199,7 +199,7 @@ struct PropArgs {
     double* hist_r;         // forward history of sample 0 ([Ntot,N,nsteps+1]) or null
     double* hist_i;
     const double* tabs;     // wd[NP] (diag wmat_real, zero padded), ws[NP] (shift weights)
-    double* park;           // HBM parking images [nslabs][2][4*NT*64] (slot 0: G1; slot 1: P0 when park_lds == 0)
+    double* park;           // HBM parking images [nslabs][4*NT*64] (used when park_lds == 0)
     long long stride;       // doubles per operator image slot (multiple of 128 = 1 KiB)
     long long state_stride; // doubles per slab in the array file
     int pieces;             // 1 KiB DMA pieces per operator image
@@ -244,9 +244,11 @@ __device__ __forceinline__ void hist_store(const PropArgs& a, int slab, int lane
     }
 }
 
-// LDS ring of operator images fed by global->LDS DMA.  Operator use #Q lives in slot Q % nslots and is
-// fetched by wave Q % 4 alone, nslots-1 uses ahead, so a wave never has more than one DMA in flight
-// and can wait for exactly its own operator (vmcnt(0)) right before the barrier that publishes it.
+// LDS double buffer of operator images fed by global->LDS DMA.  Operator use #Q lives in slot Q & 1; while
+// the MFMAs of use Q run, the image of use Q+1 streams into the other slot (every wave issues a quarter
+// of the 1 KiB pieces).  One workgroup barrier per operator switch; each wave drains its own DMA
+// (vmcnt(0)) right before the barrier that publishes the image.  (Deeper rings were measured to make no
+// difference: one product takes >= 4096 cycles, the 32 KiB image lands in a fraction of that.)
 struct Ring {
     char* smem;
     const PropArgs* a;
@@ -254,8 +256,6 @@ struct Ring {
     int Q;        // index of the operator use that comes next
     int Qp;       // index of the next operator use to prefetch
     int np, ip;   // (step, position) cursor of Qp within the schedule
-    int qslot;    // slot of operator use Q
-    int pslot;    // slot of operator use Qp
     int wave, lane;
 
     __device__ __forceinline__ const double* src_of_cursor() const
@@ -284,18 +284,14 @@ struct Ring {
     }
     __device__ __forceinline__ void issue_prefetch()
     {
-        if ((Qp & (JQ_WAVES - 1)) == wave) {
-            // lane byte offset recomputed here (2 VALU ops) so that no long-lived VGPR has to survive
-            // (hipcc otherwise spills it and reloads it with a full vmcnt(0) wait in front of every DMA)
-            unsigned lo;
-            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lo));
-            const char* src = (const char*)src_of_cursor() + lo * 16u;
-            char* dst = smem + (size_t)pslot * slot_bytes;
-            for (int p = 0; p < a->pieces; ++p)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)p * 1024),
-                                                 (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
-        }
-        if (++pslot == a->nslots) pslot = 0;
+        // lane byte offset recomputed here (2 VALU ops) so that no long-lived VGPR has to survive
+        unsigned lo;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lo));
+        const char* src = (const char*)src_of_cursor() + lo * 16u;
+        char* dst = smem + (size_t)(Qp & 1) * slot_bytes;
+        for (int p = wave; p < a->pieces; p += JQ_WAVES)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)p * 1024),
+                                             (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
         advance_cursor();
     }
     __device__ __forceinline__ void init(char* smem_, const PropArgs* a_, int wave_, int lane_)
@@ -307,22 +303,19 @@ struct Ring {
         Qp = 0;
         np = 0;
         ip = 0;
-        qslot = 0;
-        pslot = 0;
         wave = wave_;
         lane = lane_;
-        for (int i = 0; i < a->nslots - 1; ++i) issue_prefetch();
+        issue_prefetch();
     }
-    // Publish operator use Q (its fetching wave drains its DMA, then a workgroup barrier), start the
-    // fetch of use Q + nslots - 1 into the slot that use Q-1 just released, return the LDS image of Q.
+    // Publish operator use Q (every wave drains its DMA pieces, then a workgroup barrier), start the
+    // fetch of use Q+1 into the slot that use Q-1 just released, return the LDS image of Q.
     __device__ __forceinline__ const double* next()
     {
-        if ((Q & (JQ_WAVES - 1)) == wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         issue_prefetch();
-        const double* M = (const double*)(smem + (size_t)qslot * slot_bytes) + lane;
-        if (++qslot == a->nslots) qslot = 0;
+        const double* M = (const double*)(smem + (size_t)(Q & 1) * slot_bytes) + lane;
         ++Q;
         return M;
     }
@@ -540,10 +533,9 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
     double* carry = tab + 32 * NT;  // [JQ_MAXNC][256]
     for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[i] = a.tabs[i];
     double* st = a.state + (size_t)(active ? slab : 0) * a.state_stride;
-    // parking images of this wave: P0 in LDS when it fits (else HBM), G1 always in HBM
+    // parking image of this wave: in LDS when it fits, else in HBM
     double* P0 = a.park_lds ? (carry + JQ_MAXNC * 256 + (size_t)wave * KT * 64 + lane)
-                            : (a.park + ((size_t)(active ? slab : 0) * 2 + 1) * KT * 64 + lane);
-    double* G1 = a.park + ((size_t)(active ? slab : 0) * 2) * KT * 64 + lane;
+                            : (a.park + (size_t)(active ? slab : 0) * KT * 64 + lane);
 
     // array roles (register arrays are renamed, never copied, except at the end of a step):
     //   u  : vr before the state step (vr0)      un : vr after it
@@ -551,9 +543,7 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
     //   mu : lambda_r -> X = lambda_r^{1/2} (in place)
     //   nb : -lambda_i (old) -> -(li0 + li)      L  : scratch -> -lambda_i (new)
     //   Ya, Yb: Horner scratch (also trace products)
-    // Parking schedule (keeps <= 7 arrays live, the most hipcc allocates without scratch spills):
-    //   state step : mu -> P0, nb -> G1            uses 7..early traces : vN -> P0, v -> G1
-    //   use 10     : vN(P0), un -> G1             end of step          : v <- P0
+    // Parking (P0): lambda_r sleeps during the state step, vi(t_n) from use 6 to the end of the step.
     Arr<NT> u, v, mu, nb, un, vN, L, Ya, Yb;
     double ceps = 0.0, wgt = 0.0;
     if (active) {
@@ -589,24 +579,19 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
     }
 
     for (int n = 0; n < a.nsteps_chunk; ++n) {
-        // ---- state step (lambda_r and -lambda_i parked) -----------------------------------------
-        if (active) {
-            a_park(mu, P0);
-            a_park(nb, G1);
-        }
+        // ---- state step (lambda_r parked) ------------------------------------------------------
+        if (active) a_park(mu, P0);
         // mu's registers serve as the scratch array A of the state step
         sv_state<NT, BW>(p, a, active, ceps, ws, g, u, v, un, vN, mu, Ya, Yb);
         // use 6: Kp05 -- finish the state step; first adjoint product L = c K05 nb (= -c K05 lambda_i)
         const double* M = p.next();
         if (active) {
-            a_unpark(nb, G1);   // lands while the first product below runs
             mm_c<NT, BW>(vN, vN, M, un);
             if (a.use_shift) a_axpy_rows(vN, ceps, ws, g, un);
             mm_z<NT, BW>(L, M, nb);
             if (a.use_shift) a_axpy_rows(L, ceps, ws, g, nb);
             a_unpark(mu, P0);
             a_park(vN, P0);     // vi(t_n) sleeps until the end of the step
-            a_park(v, G1);      // vi05 sleeps until use 10
         }
         // ---- adjoint step ----------------------------------------------------------------------
         // use 7: S0 -- L = c (S0 mu - K05 li + hr0) ; X = mu + sum_j S^j L   (in place: mu becomes X)
@@ -634,7 +619,6 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
         // use 8: Kn0 -- L = -c K0 X
         M = p.next();
         if (active) {
-            a_unpark(v, G1);    // vi05 back (needed at use 10); vr(t_n) takes its place
             mm_z<NT, BW>(L, M, mu);
             if (a.use_shift) a_axpy_rows(L, -ceps, ws, g, mu);
         }
@@ -643,7 +627,6 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
         if (active) {
             mm_z<NT, BW>(vN, M, mu);
             if (a.use_shift) a_axpy_rows(vN, -ceps, ws, g, mu);
-            a_park(un, G1);
         }
         // use 10: S05 -- L = -c l2 = -c (K0 X + S05 li + hi0) ; Q = -c (S05 (li + c l2) + K1 X + hi1) ;
         //               nb_new = nb + L + sum_j S^j Q          (li_new = li + c (l2 + l1))
@@ -662,7 +645,6 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
         // use 11: Kp05 -- vN(scratch G) = X + c K05 nb_new (= lambda_r^{1/2} - c K05 li_new)
         M = p.next();
         if (active) {
-            a_unpark(un, G1);
             mm_c<NT, BW>(vN, mu, M, L);
             if (a.use_shift) a_axpy_rows(vN, ceps, ws, g, L);
         }

@@ -443,7 +443,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
         if ((rc = dev_alloc(h, &h->d_state, (size_t)nslabs * h->state_stride))) return rc;
         if ((rc = dev_alloc(h, &h->d_state_save, (size_t)nslabs * h->state_stride))) return rc;
         if ((rc = dev_alloc(h, &h->d_colinfo, (size_t)nslabs * 32))) return rc;
-        if ((rc = dev_alloc(h, &h->d_park, (size_t)nslabs * 2 * h->KT * 64))) return rc;
+        if ((rc = dev_alloc(h, &h->d_park, (size_t)nslabs * h->KT * 64))) return rc;
         h->cap_slabs = nslabs;
         h->cap_traces = 0;
     }
