@@ -101,8 +101,18 @@ def main():
         flops_per_launch = f_bwd * svts_rank / max(nb, 1)
         avg_launch_s = bwd_ms * 1e-3 / max(nb, 1)
         achieved = flops_per_launch / avg_launch_s / 1e12
-        roofline = {"bound": "mfma", "kernel": "k_backward<NT=6>", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+        # HBM bytes per k_backward launch from the PMC passes kept under profiles/ (FETCH_SIZE x2 gfx950 correction
+        # + WRITE_SIZE, separate rocprofv3 --pmc runs of this same command; null if not measured for this build)
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
+            traffic = tj["kernels"]["k_backward<6, 1, 1>"]["hbm_bytes_per_launch"]
+        except Exception:
+            pass
+        roofline = {"bound": "mfma", "kernel": "k_backward<NT=6,BW=1>", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                    "traffic_unit": "HBM bytes per launch (PMC)",
+                    "mfma_pipe_util": mfma * 2048.0 / (prop_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                     "launches": int(nb), "avg_launch_ms": avg_launch_s * 1e3,
                     "all_propagators_tflops": (f_bwd + f_fwd) * svts_rank / (prop_ms * 1e-3) / 1e12,
                     "executed_mfma_tflops": mfma * 2048.0 / (prop_ms * 1e-3) / 1e12,

@@ -175,11 +175,39 @@ __device__ __forceinline__ void mm_z_bw(Arr<NT>& D, const double* mat, const Arr
         mm_any<NT, BW, true>(D, D, mat, x);
 }
 
+// x + (x rotated right by N lanes within each row of 16 lanes), via DPP (no LDS crossbar traffic)
+template <int N>
+__device__ __forceinline__ double row_ror_add(double x)
+{
+    union {
+        double d;
+        int i[2];
+    } a, b;
+    a.d = x;
+    b.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], 0x120 + N, 0xf, 0xf, false);
+    b.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], 0x120 + N, 0xf, 0xf, false);
+    return x + b.d;
+}
+__device__ __forceinline__ double lane_bcast(double x, int l)
+{
+    union {
+        double d;
+        int i[2];
+    } a, b;
+    a.d = x;
+    b.i[0] = __builtin_amdgcn_readlane(a.i[0], l);
+    b.i[1] = __builtin_amdgcn_readlane(a.i[1], l);
+    return b.d;
+}
+// sum over the 64 lanes of the wave (valid in every lane): 4 DPP rotate-adds inside the rows of 16,
+// then the four row sums are combined through scalar broadcasts
 __device__ __forceinline__ double wave_sum(double x)
 {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
-    return x;
+    x = row_ror_add<8>(x);
+    x = row_ror_add<4>(x);
+    x = row_ror_add<2>(x);
+    x = row_ror_add<1>(x);
+    return (lane_bcast(x, 0) + lane_bcast(x, 16)) + (lane_bcast(x, 32) + lane_bcast(x, 48));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -213,6 +241,7 @@ struct PropArgs {
     int Ntot, N;
     int use_shift;
     int forced;             // backward: add the leakage forcing (0: step_no_forcing!)
+    int debug;              // profiling experiments only (JQ_DEBUG): 1 skip trace reductions, 2 skip forcing/shift rows, 4 skip parking
     int park_lds;           // 1: the backward kernel parks its dormant array in LDS, 0: in `park`
     int period;             // operator uses per time step
     int npro;               // operator uses before the first step (backward first chunk: carry products)
@@ -311,10 +340,12 @@ struct Ring {
     // fetch of use Q+1 into the slot that use Q-1 just released, return the LDS image of Q.
     __device__ __forceinline__ const double* next()
     {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        issue_prefetch();
+        if (!(a->debug & 8)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            issue_prefetch();
+        }
         const double* M = (const double*)(smem + (size_t)(Q & 1) * slot_bytes) + lane;
         ++Q;
         return M;
@@ -607,8 +638,8 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
             M = p.next();  // Hanti_q
             if (active) {
                 mm_z_bw<NT, BW>(Ya, M, mu, a.bw_trace[q]);
-                const double t1 = wave_sum(a_dot(u, Ya) * wgt);
-                const double t3 = wave_sum(a_dot(un, Ya) * wgt);
+                const double t1 = (a.debug & 1) ? a_dot(u, Ya) : wave_sum(a_dot(u, Ya) * wgt);
+                const double t3 = (a.debug & 1) ? a_dot(un, Ya) : wave_sum(a_dot(un, Ya) * wgt);
                 if (lane == 0) {
                     double* tr = a.traces + ((size_t)slab * a.nsteps_chunk + n) * (Nc * JQ_NTR) + q * JQ_NTR;
                     tr[0] = t1;
@@ -673,9 +704,11 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
                 const double p4 = -a_dot(un, Ya);
                 t4 = p4 + carry[q * 256 + threadIdx.x];
                 carry[q * 256 + threadIdx.x] = p4;
-                t2 = wave_sum(t2 * wgt);
-                t4 = wave_sum(t4 * wgt);
-                t5 = wave_sum(t5 * wgt);
+                if (!(a.debug & 1)) {
+                    t2 = wave_sum(t2 * wgt);
+                    t4 = wave_sum(t4 * wgt);
+                    t5 = wave_sum(t5 * wgt);
+                }
                 if (lane == 0) {
                     double* tr = a.traces + ((size_t)slab * a.nsteps_chunk + n) * (Nc * JQ_NTR) + q * JQ_NTR;
                     tr[1] = t2;

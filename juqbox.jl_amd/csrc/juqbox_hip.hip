@@ -505,6 +505,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     const size_t lds_bwd = (size_t)h->nslots_bwd * h->mat_elems * 8 + (size_t)32 * h->NT * 8 + (size_t)JQ_MAXNC * 256 * 8 +
                            (h->park_lds ? (size_t)JQ_WAVES * h->KT * 64 * 8 : 0);
     a.park = h->d_park; a.park_lds = h->park_lds;
+    if (const char* e = getenv("JQ_DEBUG")) a.debug = atoi(e);
     HIPCHK(h, hipFuncSetAttribute((const void*)kfwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fwd));
     HIPCHK(h, hipFuncSetAttribute((const void*)kbwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bwd));
 
