@@ -45,7 +45,7 @@ def main():
     torch.cuda.set_device(local_rank)
     _lib.check(L.jq_set_device(local_rank))
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:     # launched by torch.distributed.run (also with one rank)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))

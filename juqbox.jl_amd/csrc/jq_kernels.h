@@ -243,6 +243,8 @@ struct PropArgs {
     int forced;             // backward: add the leakage forcing (0: step_no_forcing!)
     int debug;              // profiling experiments only (JQ_DEBUG): 1 skip trace reductions, 2 skip forcing/shift rows, 4 skip parking
     int park_lds;           // 1: the backward kernel parks its dormant array in LDS, 0: in `park`
+    int batch;              // 0: one LDS slot per operator use; B > 0: K/S images of B time steps per DMA batch
+    int lds_tab_off;        // byte offset of the tables (wd, ws[, carry, park]) in dynamic LDS
     int period;             // operator uses per time step
     int npro;               // operator uses before the first step (backward first chunk: carry products)
     int bw_trace[JQ_MAXNC]; // band width of the trace images per control (0 or the kernel's BW)
@@ -273,80 +275,131 @@ __device__ __forceinline__ void hist_store(const PropArgs& a, int slab, int lane
     }
 }
 
-// LDS double buffer of operator images fed by global->LDS DMA.  Operator use #Q lives in slot Q & 1; while
-// the MFMAs of use Q run, the image of use Q+1 streams into the other slot (every wave issues a quarter
-// of the 1 KiB pieces).  One workgroup barrier per operator switch; each wave drains its own DMA
-// (vmcnt(0)) right before the barrier that publishes the image.  (Deeper rings were measured to make no
-// difference: one product takes >= 4096 cycles, the 32 KiB image lands in a fraction of that.)
+// LDS staging of the operator images, fed by global->LDS DMA (global_load_lds_dwordx4).
+//
+// per-operator mode (large images, batch == 0): operator use #Q lives in slot Q & 1; while the MFMAs of
+//   use Q run, the image of use Q+1 streams into the other slot (every wave issues a quarter of the 1 KiB
+//   pieces).  One workgroup barrier per operator switch; each wave drains its own DMA (vmcnt(0)) right
+//   before the barrier that publishes the image.  (Deeper rings were measured to make no difference: one
+//   product takes >= 4096 cycles, the 32 KiB image lands in a fraction of that.)
+// batched mode (small images, batch = B > 0): the K/S images of B consecutive time steps (2B+1 time
+//   points, contiguous in the tile stream) are fetched with one DMA burst into one of two batch buffers
+//   and the constant trace images stay resident, so there is ONE barrier per B steps instead of one per
+//   operator use -- for Ntot <= 32 a product is only 4..32 MFMAs and the barrier + DMA latency would
+//   otherwise dominate.
 struct Ring {
     char* smem;
     const PropArgs* a;
-    int slot_bytes;
-    int Q;        // index of the operator use that comes next
-    int Qp;       // index of the next operator use to prefetch
-    int np, ip;   // (step, position) cursor of Qp within the schedule
+    int slot_bytes;   // bytes of one slot (per-operator mode) or of one batch buffer (batched mode)
+    int Q;            // index of the operator use that comes next
+    int Qp;           // per-operator mode: index of the next operator use to prefetch
+    int np, ip;       // (step, position) cursor: of Qp (per-operator mode) or of Q (batched mode)
     int wave, lane;
 
-    __device__ __forceinline__ const double* src_of_cursor() const
-    {
-        SchedEntry e;
-        int n = np;
-        if (Qp < a->npro) {
-            e = a->pro[Qp];
-            n = 0;
-        } else {
-            e = a->sched[ip];
-        }
-        if (n >= a->nsteps_chunk) n = a->nsteps_chunk - 1;  // past the end: harmless re-fetch
-        if (e.kind == 2) return a->cimg + (size_t)e.tp * a->stride;
-        return a->stream + (size_t)(2 * (2 * n + e.tp) + e.kind) * a->stride;
-    }
-    __device__ __forceinline__ void advance_cursor()
-    {
-        if (Qp >= a->npro) {
-            if (++ip == a->period) {
-                ip = 0;
-                ++np;
-            }
-        }
-        ++Qp;
-    }
-    __device__ __forceinline__ void issue_prefetch()
+    __device__ __forceinline__ unsigned lane_off16() const
     {
         // lane byte offset recomputed here (2 VALU ops) so that no long-lived VGPR has to survive
         unsigned lo;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lo));
-        const char* src = (const char*)src_of_cursor() + lo * 16u;
-        char* dst = smem + (size_t)(Qp & 1) * slot_bytes;
-        for (int p = wave; p < a->pieces; p += JQ_WAVES)
+        return lo * 16u;
+    }
+    __device__ __forceinline__ void dma(const double* gsrc, char* dst, int pieces) const
+    {
+        const char* src = (const char*)gsrc + lane_off16();
+        for (int p = wave; p < pieces; p += JQ_WAVES)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)p * 1024),
                                              (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
-        advance_cursor();
+    }
+    __device__ __forceinline__ SchedEntry entry_at(int q, int i) const { return (q < a->npro) ? a->pro[q] : a->sched[i]; }
+    __device__ __forceinline__ void advance(int& q, int& n, int& i) const
+    {
+        if (q >= a->npro) {
+            if (++i == a->period) {
+                i = 0;
+                ++n;
+            }
+        }
+        ++q;
+    }
+    // ---- per-operator mode -------------------------------------------------------------------
+    __device__ __forceinline__ void issue_prefetch()
+    {
+        const SchedEntry e = entry_at(Qp, ip);
+        int n = (Qp < a->npro) ? 0 : np;
+        if (n >= a->nsteps_chunk) n = a->nsteps_chunk - 1;  // past the end: harmless re-fetch
+        const double* src = (e.kind == 2) ? a->cimg + (size_t)e.tp * a->stride
+                                          : a->stream + (size_t)(2 * (2 * n + e.tp) + e.kind) * a->stride;
+        dma(src, smem + (size_t)(Qp & 1) * slot_bytes, a->pieces);
+        advance(Qp, np, ip);
+    }
+    // ---- batched mode ------------------------------------------------------------------------
+    __device__ __forceinline__ void issue_batch(int b)
+    {
+        const int first = b * a->batch;
+        if (first >= a->nsteps_chunk) return;
+        int steps = a->nsteps_chunk - first;
+        if (steps > a->batch) steps = a->batch;
+        const int npts = 2 * steps + 1;
+        dma(a->stream + (size_t)(4 * first) * a->stride, smem + (size_t)(b & 1) * slot_bytes, npts * 2 * a->pieces);
+    }
+    // call at the top of every time step n (of the chunk)
+    __device__ __forceinline__ void begin_step(int n)
+    {
+        if (a->batch > 0 && (n % a->batch) == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            issue_batch(n / a->batch + 1);
+        }
     }
     __device__ __forceinline__ void init(char* smem_, const PropArgs* a_, int wave_, int lane_)
     {
         smem = smem_;
         a = a_;
-        slot_bytes = (int)(a_->stride * 8);
         Q = 0;
         Qp = 0;
         np = 0;
         ip = 0;
         wave = wave_;
         lane = lane_;
-        issue_prefetch();
+        if (a->batch > 0) {
+            slot_bytes = (int)((2 * a->batch + 1) * 2 * a->stride * 8);
+            // resident constant images behind the two batch buffers
+            dma(a->cimg, smem + 2 * (size_t)slot_bytes, 2 * a->Ncoupled * a->pieces);
+            issue_batch(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // constants are used before the first begin_step
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        } else {
+            slot_bytes = (int)(a_->stride * 8);
+            issue_prefetch();
+        }
     }
-    // Publish operator use Q (every wave drains its DMA pieces, then a workgroup barrier), start the
-    // fetch of use Q+1 into the slot that use Q-1 just released, return the LDS image of Q.
+    // LDS image (lane offset applied) of the next operator use
     __device__ __forceinline__ const double* next()
     {
+        const double* M;
+        if (a->batch > 0) {
+            const SchedEntry e = entry_at(Q, ip);
+            const int n = (Q < a->npro) ? 0 : np;
+            if (e.kind == 2) {
+                M = (const double*)(smem + 2 * (size_t)slot_bytes) + (size_t)e.tp * a->stride;
+            } else {
+                const int b = n / a->batch, nl = n - b * a->batch;
+                M = (const double*)(smem + (size_t)(b & 1) * slot_bytes) + (size_t)(2 * (2 * nl + e.tp) + e.kind) * a->stride;
+            }
+            advance(Q, np, ip);
+            return M + lane;
+        }
+        // Publish operator use Q (every wave drains its DMA pieces, then a workgroup barrier), start the
+        // fetch of use Q+1 into the slot that use Q-1 just released.
         if (!(a->debug & 8)) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             issue_prefetch();
         }
-        const double* M = (const double*)(smem + (size_t)(Q & 1) * slot_bytes) + lane;
+        M = (const double*)(smem + (size_t)(Q & 1) * slot_bytes) + lane;
         ++Q;
         return M;
     }
@@ -479,7 +532,7 @@ __global__ __launch_bounds__(256, MINW) void k_forward(PropArgs a)
     const int slab = blockIdx.x * JQ_WAVES + wave;
     const bool active = slab < a.nslabs;
 
-    double* tab = (double*)(smem + (size_t)a.nslots * a.stride * 8);
+    double* tab = (double*)(smem + a.lds_tab_off);
     const double* wd = tab;
     const double* ws = tab + 16 * NT;
     for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[i] = a.tabs[i];
@@ -503,6 +556,7 @@ __global__ __launch_bounds__(256, MINW) void k_forward(PropArgs a)
     // roles every step, so the loop body is written for two steps and nothing is ever copied.
 #define JQ_FWD_STEP(U, V, UN, VN, NSTEP)                                                                         \
     {                                                                                                            \
+        p.begin_step(NSTEP);                                                                                     \
         if (active) leak += a_wsq(wd, g, U); /* trapezoidal part: tr(vr' W vr) at t_n (:700) */                  \
         sv_state<NT, BW>(p, a, active, ceps, ws, g, U, V, UN, VN, A, Ya, Yb);                                    \
         /* use 6: Kp05 again -- v(t+h) = v05 + c (K05 u_new + S05 v05) */                                        \
@@ -558,7 +612,7 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
     const bool active = slab < a.nslabs;
     const int Nc = a.Ncoupled;
 
-    double* tab = (double*)(smem + (size_t)a.nslots * a.stride * 8);
+    double* tab = (double*)(smem + a.lds_tab_off);
     const double* wd = tab;
     const double* ws = tab + 16 * NT;
     double* carry = tab + 32 * NT;  // [JQ_MAXNC][256]
@@ -610,6 +664,7 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
     }
 
     for (int n = 0; n < a.nsteps_chunk; ++n) {
+        p.begin_step(n);
         // ---- state step (lambda_r parked) ------------------------------------------------------
         if (active) a_park(mu, P0);
         // mu's registers serve as the scratch array A of the state step

@@ -35,6 +35,7 @@ struct jq_handle {
     int nslots = 2;             // LDS ring depth of the forward kernel
     int nslots_bwd = 2;         // ... of the backward kernel (shares LDS with carry + parking images)
     int park_lds = 0;           // backward kernel parks its dormant array in LDS (1) or HBM (0)
+    int batch = 0;              // > 0: batched staging (K/S images of `batch` time steps per DMA burst)
     std::vector<double> Hconst, Hsym, Hanti, Uinit, Utr, Uti, wd, cfreq;
     std::vector<double> tf, tb;
     // device buffers (owned)
@@ -238,22 +239,28 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         const long long lds_fwd_fixed = (long long)32 * h->NT * 8;
         const long long lds_bwd_fixed = lds_fwd_fixed + (long long)JQ_MAXNC * 256 * 8;
         const long long park_bytes = (long long)JQ_WAVES * h->KT * 64 * 8;
-        long long nf = (163840 - lds_fwd_fixed) / slot;
-        if (nf < 2) return fail(h, JQ_EUNSUPPORTED, "jq_create: operator images do not fit the LDS ring");
-        h->nslots = (int)std::min<long long>(nf, JQ_MAXSLOTS);
-        long long nb = (163840 - lds_bwd_fixed - park_bytes) / slot;
-        if (nb >= 2) {
-            h->park_lds = 1;
-        } else {
-            h->park_lds = 0;
-            nb = (163840 - lds_bwd_fixed) / slot;
-            if (nb < 2) return fail(h, JQ_EUNSUPPORTED, "jq_create: operator images do not fit the LDS ring");
-        }
-        h->nslots_bwd = (int)std::min<long long>(nb, JQ_MAXSLOTS);
-        if (const char* e = getenv("JQ_NSLOTS")) {
+        if (2 * slot + lds_fwd_fixed > 163840)
+            return fail(h, JQ_EUNSUPPORTED, "jq_create: operator images do not fit the LDS double buffer");
+        h->nslots = 2;
+        h->nslots_bwd = 2;
+        h->park_lds = (2 * slot + lds_bwd_fixed + park_bytes <= 163840) ? 1 : 0;
+        // Batched staging (K/S images of B time steps per DMA burst, constants resident in LDS) exists for
+        // small images but is OFF by default: measured on MI355X it does not help (swap02/cnot2: the
+        // ~600-cycle dependent-product latency dominates, not the per-operator barrier) and its 150 KB of
+        // LDS allow only one workgroup per CU.  JQ_BATCH=<B> enables it for experiments.
+        h->batch = 0;
+        if (const char* e = getenv("JQ_BATCH")) {
             const int v = atoi(e);
-            if (v >= 2 && v <= h->nslots) h->nslots = v;
-            if (v >= 2 && v <= h->nslots_bwd) h->nslots_bwd = v;
+            if (v >= 2 && slot <= 8192) {
+                const long long fixed = lds_bwd_fixed + park_bytes + 2LL * h->Nc * slot;
+                const long long per_buf = (163840 - fixed) / 2;
+                long long B = (per_buf / (2 * slot) - 1) / 2;
+                if (B > v) B = v;
+                if (B >= 2) {
+                    h->batch = (int)B;
+                    h->park_lds = 1;
+                }
+            }
         }
     }
 
@@ -501,9 +508,12 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     const SchedEntry fwd_sched[7] = {K05e, S05e, K0e, S0e, K1e, S1e, K05e};
     const SchedEntry adj_sched[6] = {S0e, K0e, K1e, S05e, K05e, S1e};
 
-    const size_t lds_fwd = (size_t)h->nslots * h->mat_elems * 8 + (size_t)32 * h->NT * 8;
-    const size_t lds_bwd = (size_t)h->nslots_bwd * h->mat_elems * 8 + (size_t)32 * h->NT * 8 + (size_t)JQ_MAXNC * 256 * 8 +
-                           (h->park_lds ? (size_t)JQ_WAVES * h->KT * 64 * 8 : 0);
+    // dynamic LDS layout: [operator staging | tables wd, ws | (backward: carry, parking images)]
+    const size_t lds_stage = h->batch > 0 ? (size_t)2 * (2 * h->batch + 1) * 2 * h->mat_elems * 8 + (size_t)2 * h->Nc * h->mat_elems * 8
+                                          : (size_t)2 * h->mat_elems * 8;
+    const size_t lds_fwd = lds_stage + (size_t)32 * h->NT * 8;
+    const size_t lds_bwd = lds_fwd + (size_t)JQ_MAXNC * 256 * 8 + (h->park_lds ? (size_t)JQ_WAVES * h->KT * 64 * 8 : 0);
+    a.batch = h->batch; a.lds_tab_off = (int)lds_stage;
     a.park = h->d_park; a.park_lds = h->park_lds;
     if (const char* e = getenv("JQ_DEBUG")) a.debug = atoi(e);
     HIPCHK(h, hipFuncSetAttribute((const void*)kfwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fwd));
