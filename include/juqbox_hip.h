@@ -90,6 +90,10 @@ const char *jq_last_error(const jq_handle *h);
 /* ---- mutations scripts apply to `params` after construction ----------------------------------*/
 /* params.linear_solver.max_iter = m (estimate_Neumann!, src/evalobjgrad.jl:2922-2925) */
 int jq_set_neumann_terms(jq_handle *h, int32_t m);
+/* params.linear_solver = lsolver_object(solver=..., max_iter=..., tol=...) (src/linear_solvers.jl:28-78):
+ * solver_id 1 = NEUMANN_SOLVER (neumann!, :81-106; tol ignored), 2 = JACOBI_SOLVER (jacobi!, :110-153; `tol` is
+ * the already nrhs-scaled tolerance, :40).  Other ids: JQ_EUNSUPPORTED. */
+int jq_set_linear_solver(jq_handle *h, int32_t solver_id, int32_t max_iter, double tol);
 /* change_target!(params, new_Utarget) (src/evalobjgrad.jl:1492) */
 int jq_update_target(jq_handle *h, const double *Utarget_r, const double *Utarget_i);
 /* params.Hconst is mutated freely (src/ipopt_interface.jl:41-44, run_all.jl:13-15) */

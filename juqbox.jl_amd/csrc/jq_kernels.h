@@ -250,8 +250,8 @@ struct PropArgs {
     int bw_trace[JQ_MAXNC]; // band width of the trace images per control (0 or the kernel's BW)
     double h;               // signed time step
     double tinv;            // 1/T
-    SchedEntry pro[JQ_MAXNC];
-    SchedEntry sched[JQ_MAXSCHED];
+    double jacobi_tol2;     // JAC kernels (JACOBI_SOLVER): squared tolerance, max_iter = m
+    const SchedEntry* sched_tab;  // device memory: [pro: JQ_MAXNC entries | sched: JQ_MAXSCHED entries]
 };
 
 // usaver[:,:,step+1] = vr ; usavei = -vi (src/evalobjgrad.jl:748-752); only sample 0 (slab 0, columns < N)
@@ -289,7 +289,13 @@ __device__ __forceinline__ void hist_store(const PropArgs& a, int slab, int lane
 //   otherwise dominate.
 struct Ring {
     char* smem;
-    const PropArgs* a;
+    // copies of the launch parameters the staging needs (kept in SGPRs; taking the address of the kernel
+    // argument struct would make hipcc spill all of it to scratch)
+    const double* stream;
+    const double* cimg;
+    const SchedEntry* tab;
+    long long stride;
+    int pieces, nsteps_chunk, period, npro, batch, ncoupled, debug;
     int slot_bytes;   // bytes of one slot (per-operator mode) or of one batch buffer (batched mode)
     int Q;            // index of the operator use that comes next
     int Qp;           // per-operator mode: index of the next operator use to prefetch
@@ -310,11 +316,17 @@ struct Ring {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)p * 1024),
                                              (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
     }
-    __device__ __forceinline__ SchedEntry entry_at(int q, int i) const { return (q < a->npro) ? a->pro[q] : a->sched[i]; }
+    // schedule entry of operator use q (cursor position i within the step); scalar loads, no struct copies
+    __device__ __forceinline__ void entry_at(int q, int i, int& kind, int& tp) const
+    {
+        const SchedEntry* e = (q < npro) ? tab + q : tab + JQ_MAXNC + i;
+        kind = e->kind;
+        tp = e->tp;
+    }
     __device__ __forceinline__ void advance(int& q, int& n, int& i) const
     {
-        if (q >= a->npro) {
-            if (++i == a->period) {
+        if (q >= npro) {
+            if (++i == period) {
                 i = 0;
                 ++n;
             }
@@ -324,54 +336,65 @@ struct Ring {
     // ---- per-operator mode -------------------------------------------------------------------
     __device__ __forceinline__ void issue_prefetch()
     {
-        const SchedEntry e = entry_at(Qp, ip);
-        int n = (Qp < a->npro) ? 0 : np;
-        if (n >= a->nsteps_chunk) n = a->nsteps_chunk - 1;  // past the end: harmless re-fetch
-        const double* src = (e.kind == 2) ? a->cimg + (size_t)e.tp * a->stride
-                                          : a->stream + (size_t)(2 * (2 * n + e.tp) + e.kind) * a->stride;
-        dma(src, smem + (size_t)(Qp & 1) * slot_bytes, a->pieces);
+        int kind, tp;
+        entry_at(Qp, ip, kind, tp);
+        int n = (Qp < npro) ? 0 : np;
+        if (n >= nsteps_chunk) n = nsteps_chunk - 1;  // past the end: harmless re-fetch
+        const double* src = (kind == 2) ? cimg + (size_t)tp * stride
+                                        : stream + (size_t)(2 * (2 * n + tp) + kind) * stride;
+        dma(src, smem + (size_t)(Qp & 1) * slot_bytes, pieces);
         advance(Qp, np, ip);
     }
     // ---- batched mode ------------------------------------------------------------------------
     __device__ __forceinline__ void issue_batch(int b)
     {
-        const int first = b * a->batch;
-        if (first >= a->nsteps_chunk) return;
-        int steps = a->nsteps_chunk - first;
-        if (steps > a->batch) steps = a->batch;
+        const int first = b * batch;
+        if (first >= nsteps_chunk) return;
+        int steps = nsteps_chunk - first;
+        if (steps > batch) steps = batch;
         const int npts = 2 * steps + 1;
-        dma(a->stream + (size_t)(4 * first) * a->stride, smem + (size_t)(b & 1) * slot_bytes, npts * 2 * a->pieces);
+        dma(stream + (size_t)(4 * first) * stride, smem + (size_t)(b & 1) * slot_bytes, npts * 2 * pieces);
     }
     // call at the top of every time step n (of the chunk)
     __device__ __forceinline__ void begin_step(int n)
     {
-        if (a->batch > 0 && (n % a->batch) == 0) {
+        if (batch > 0 && (n % batch) == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            issue_batch(n / a->batch + 1);
+            issue_batch(n / batch + 1);
         }
     }
-    __device__ __forceinline__ void init(char* smem_, const PropArgs* a_, int wave_, int lane_)
+    __device__ __forceinline__ void init(char* smem_, const PropArgs& a, int wave_, int lane_)
     {
         smem = smem_;
-        a = a_;
+        stream = a.stream;
+        cimg = a.cimg;
+        tab = a.sched_tab;
+        stride = a.stride;
+        pieces = a.pieces;
+        nsteps_chunk = a.nsteps_chunk;
+        period = a.period;
+        npro = a.npro;
+        batch = a.batch;
+        ncoupled = a.Ncoupled;
+        debug = a.debug;
         Q = 0;
         Qp = 0;
         np = 0;
         ip = 0;
         wave = wave_;
         lane = lane_;
-        if (a->batch > 0) {
-            slot_bytes = (int)((2 * a->batch + 1) * 2 * a->stride * 8);
+        if (batch > 0) {
+            slot_bytes = (int)((2 * batch + 1) * 2 * stride * 8);
             // resident constant images behind the two batch buffers
-            dma(a->cimg, smem + 2 * (size_t)slot_bytes, 2 * a->Ncoupled * a->pieces);
+            dma(cimg, smem + 2 * (size_t)slot_bytes, 2 * ncoupled * pieces);
             issue_batch(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // constants are used before the first begin_step
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         } else {
-            slot_bytes = (int)(a_->stride * 8);
+            slot_bytes = (int)(stride * 8);
             issue_prefetch();
         }
     }
@@ -379,21 +402,22 @@ struct Ring {
     __device__ __forceinline__ const double* next()
     {
         const double* M;
-        if (a->batch > 0) {
-            const SchedEntry e = entry_at(Q, ip);
-            const int n = (Q < a->npro) ? 0 : np;
-            if (e.kind == 2) {
-                M = (const double*)(smem + 2 * (size_t)slot_bytes) + (size_t)e.tp * a->stride;
+        if (batch > 0) {
+            int kind, tp;
+            entry_at(Q, ip, kind, tp);
+            const int n = (Q < npro) ? 0 : np;
+            if (kind == 2) {
+                M = (const double*)(smem + 2 * (size_t)slot_bytes) + (size_t)tp * stride;
             } else {
-                const int b = n / a->batch, nl = n - b * a->batch;
-                M = (const double*)(smem + (size_t)(b & 1) * slot_bytes) + (size_t)(2 * (2 * nl + e.tp) + e.kind) * a->stride;
+                const int b = n / batch, nl = n - b * batch;
+                M = (const double*)(smem + (size_t)(b & 1) * slot_bytes) + (size_t)(2 * (2 * nl + tp) + kind) * stride;
             }
             advance(Q, np, ip);
             return M + lane;
         }
         // Publish operator use Q (every wave drains its DMA pieces, then a workgroup barrier), start the
         // fetch of use Q+1 into the slot that use Q-1 just released.
-        if (!(a->debug & 8)) {
+        if (!(debug & 8)) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -423,10 +447,59 @@ struct Ring {
 
 // out = base_plus_A + sum_{j=1..m} S^j A      (i.e. base + sum_{j=0..m} S^j A with base_plus_A = base + A)
 // Ya, Yb are scratch arrays.  out may alias base_plus_A; out must not alias A, Ya, Yb.
-template <int NT, int BW>
-__device__ __forceinline__ void horner_add(Arr<NT>& out, const Arr<NT>& bpa, const Arr<NT>& A, const double* S, int m,
-                                           Arr<NT>& Ya, Arr<NT>& Yb)
+// sum over the lane's elements of (x - y)^2
+template <int NT>
+__device__ __forceinline__ double a_diff2(const Arr<NT>& x, const Arr<NT>& y)
 {
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const d4 d = x.t[i] - y.t[i];
+        const d4 p = d * d;
+        s += (p[0] + p[1]) + (p[2] + p[3]);
+    }
+    return s;
+}
+
+// JACOBI_SOLVER (jacobi!, src/linear_solvers.jl:110-153): X_j = A + S X_{j-1}, X_0 = A, stop at the first
+// j with ||X_j - X_{j-1}||_F < tol or at j = max_iter.  It is the same fixed-point iteration as the Horner
+// form above, plus the convergence test.  The reference tests each sample's Ntot x N block on its own; here
+// the test is on the whole 16-column slab (a wave-uniform decision), i.e. never earlier than the
+// reference, so the two results differ by less than tol.
+template <int NT, int BW>
+__device__ __forceinline__ void jacobi_add(Arr<NT>& out, const Arr<NT>& bpa, const Arr<NT>& A, const double* S, int max_iter,
+                                           double tol2, Arr<NT>& Ya, Arr<NT>& Yb)
+{
+    // out = bpa - A + X_j
+    if (max_iter <= 0) {
+        out = bpa;
+        return;
+    }
+    mm_c<NT, BW>(Ya, A, S, A);  // X_1
+    bool in_a = true;
+    double err2 = wave_sum(a_diff2(Ya, A));
+    for (int j = 2; j <= max_iter && !(err2 < tol2); ++j) {
+        if (in_a) {
+            mm_c<NT, BW>(Yb, A, S, Ya);
+            err2 = wave_sum(a_diff2(Yb, Ya));
+        } else {
+            mm_c<NT, BW>(Ya, A, S, Yb);
+            err2 = wave_sum(a_diff2(Ya, Yb));
+        }
+        in_a = !in_a;
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) out.t[i] = (bpa.t[i] - A.t[i]) + (in_a ? Ya.t[i] : Yb.t[i]);
+}
+
+template <int NT, int BW, bool JAC>
+__device__ __forceinline__ void horner_add(Arr<NT>& out, const Arr<NT>& bpa, const Arr<NT>& A, const double* S, int m,
+                                           Arr<NT>& Ya, Arr<NT>& Yb, double jacobi_tol2)
+{
+    if (JAC) {
+        jacobi_add<NT, BW>(out, bpa, A, S, m, jacobi_tol2, Ya, Yb);
+        return;
+    }
     if (m <= 0) {
         out = bpa;
         return;
@@ -475,7 +548,7 @@ __device__ __forceinline__ void a_unpark(Arr<NT>& a, const double* park)
 //   out: unew = u(t+h), vN = v05 + S05 v05 (the caller finishes v(t+h) = vN + Kp05 unew with use 6)
 //   A, Ya, Yb: scratch arrays.          Operator order per step: Kp05 S05 Kn0 S0 Kn1 S1 (Kp05).
 // At most 8 arrays are live here (u, v/v05, unew, vN, A, Ya, Yb + one of the caller's).
-template <int NT, int BW>
+template <int NT, int BW, bool JAC>
 __device__ __forceinline__ void sv_state(Ring& p, const PropArgs& a, bool active, double ceps, const double* ws, int g,
                                          const Arr<NT>& u, Arr<NT>& v, Arr<NT>& unew, Arr<NT>& vN, Arr<NT>& A, Arr<NT>& Ya,
                                          Arr<NT>& Yb)
@@ -491,7 +564,7 @@ __device__ __forceinline__ void sv_state(Ring& p, const PropArgs& a, bool active
     if (active) {
         mm_c<NT, BW>(A, A, M, v);
         a_add(v, A);
-        horner_add<NT, BW>(v, v, A, M, a.m, Ya, Yb);
+        horner_add<NT, BW, JAC>(v, v, A, M, a.m, Ya, Yb, a.jacobi_tol2);
         mm_c<NT, BW>(vN, v, M, v);
     }
     // use 2: Kn0 -- unew = u - c K0 v05
@@ -514,14 +587,14 @@ __device__ __forceinline__ void sv_state(Ring& p, const PropArgs& a, bool active
     if (active) {
         mm_c<NT, BW>(A, A, M, unew);
         a_add(unew, A);
-        horner_add<NT, BW>(unew, unew, A, M, a.m, Ya, Yb);
+        horner_add<NT, BW, JAC>(unew, unew, A, M, a.m, Ya, Yb, a.jacobi_tol2);
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // Forward sweep over one chunk of time steps (src/evalobjgrad.jl:698-753).
 // schedule (period 7): Kp05 S05 Kn0 S0 Kn1 S1 Kp05
-template <int NT, int BW, int MINW>
+template <int NT, int BW, int MINW, bool JAC>
 __global__ __launch_bounds__(256, MINW) void k_forward(PropArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -550,7 +623,7 @@ __global__ __launch_bounds__(256, MINW) void k_forward(PropArgs a)
         a_zero(va);
     }
     Ring p;
-    p.init(smem, &a, wave, lane);
+    p.init(smem, a, wave, lane);
 
     // one time step: (u, v) -> (unew, vN); v is consumed (becomes v05).  The two array pairs swap
     // roles every step, so the loop body is written for two steps and nothing is ever copied.
@@ -558,7 +631,7 @@ __global__ __launch_bounds__(256, MINW) void k_forward(PropArgs a)
     {                                                                                                            \
         p.begin_step(NSTEP);                                                                                     \
         if (active) leak += a_wsq(wd, g, U); /* trapezoidal part: tr(vr' W vr) at t_n (:700) */                  \
-        sv_state<NT, BW>(p, a, active, ceps, ws, g, U, V, UN, VN, A, Ya, Yb);                                    \
+        sv_state<NT, BW, JAC>(p, a, active, ceps, ws, g, U, V, UN, VN, A, Ya, Yb);                                    \
         /* use 6: Kp05 again -- v(t+h) = v05 + c (K05 u_new + S05 v05) */                                        \
         const double* M6 = p.next();                                                                             \
         if (active) {                                                                                            \
@@ -600,7 +673,7 @@ __global__ __launch_bounds__(256, MINW) void k_forward(PropArgs a)
 // Register budget (512 per lane, 8 per array element pair): at most 9 state-sized arrays are live at
 // any point (8 since vr0 dies after the early traces); the one array that is dormant in each phase (lambda_r during the state step, v during the
 // adjoint step and the traces) is parked in the wave's LDS (or global) parking image.
-template <int NT, int BW, int MINW>
+template <int NT, int BW, int MINW, bool JAC>
 __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -649,7 +722,7 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
     const double cfw = a.forced ? 0.5 * a.h * a.tinv : 0.0;
 
     Ring p;
-    p.init(smem, &a, wave, lane);
+    p.init(smem, a, wave, lane);
 
     if (a.first_chunk) {
         // carry_q = tr(vr' Hsym_q lambdai) at t = T: the "vr0/lambdai0" term of the first backward
@@ -668,7 +741,7 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
         // ---- state step (lambda_r parked) ------------------------------------------------------
         if (active) a_park(mu, P0);
         // mu's registers serve as the scratch array A of the state step
-        sv_state<NT, BW>(p, a, active, ceps, ws, g, u, v, un, vN, mu, Ya, Yb);
+        sv_state<NT, BW, JAC>(p, a, active, ceps, ws, g, u, v, un, vN, mu, Ya, Yb);
         // use 6: Kp05 -- finish the state step; first adjoint product L = c K05 nb (= -c K05 lambda_i)
         const double* M = p.next();
         if (active) {
@@ -686,7 +759,7 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
             mm_c<NT, BW>(L, L, M, mu);
             a_axpy_rows(L, cfw, wd, g, u);  // u holds vr before the state step (:862)
             a_add(mu, L);
-            horner_add<NT, BW>(mu, mu, L, M, a.m, Ya, Yb);
+            horner_add<NT, BW, JAC>(mu, mu, L, M, a.m, Ya, Yb, a.jacobi_tol2);
         }
         // early traces with X (lets vr0 = u die here): tr1 = tr(vr0' Hanti_q X), tr3 = tr(vr' Hanti_q X)
         for (int q = 0; q < Nc; ++q) {
@@ -725,7 +798,7 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
             mm_c<NT, BW>(vN, vN, M, L);       // vN = Q
             a_add(L, nb);
             a_add(L, vN);                     // L = nb + L + Q
-            horner_add<NT, BW>(L, L, vN, M, a.m, Ya, Yb);  // L = nb_new
+            horner_add<NT, BW, JAC>(L, L, vN, M, a.m, Ya, Yb, a.jacobi_tol2);  // L = nb_new
             a_add(nb, L);                     // nb = nb_old + nb_new = -(li0 + li)
         }
         // use 11: Kp05 -- vN(scratch G) = X + c K05 nb_new (= lambda_r^{1/2} - c K05 li_new)

@@ -26,6 +26,8 @@ struct jq_handle {
     hipStream_t stream = nullptr;
     // problem
     int Ntot = 0, N = 0, Nc = 0, Nfreq = 0, nsteps = 0, m = 0, objFuncType = 1;
+    int solver_id = 1;          // 1 NEUMANN_SOLVER, 2 JACOBI_SOLVER
+    double solver_tol = 0.0;
     double T = 0.0;
     int NT = 0, KT = 0, NP = 0, sps = 0;
     int BW = 0;                 // block band width the kernels are instantiated for
@@ -40,6 +42,7 @@ struct jq_handle {
     std::vector<double> tf, tb;
     // device buffers (owned)
     double *d_cimg = nullptr, *d_park = nullptr;
+    SchedEntry* d_sched = nullptr;   // 3 schedule tables: forward, backward first chunk, backward later chunks
     double *d_himg = nullptr, *d_uimg = nullptr, *d_vtr = nullptr, *d_vti = nullptr, *d_tabs = nullptr;
     double *d_tf = nullptr, *d_tb = nullptr, *d_cfreq = nullptr, *d_pcof = nullptr;
     double *d_stream = nullptr, *d_pq = nullptr;
@@ -172,6 +175,7 @@ extern "C" void jq_destroy(jq_handle* h)
                        &h->d_colinfo, &h->d_traces,   &h->d_R,       &h->d_grad,   &h->d_res};
     for (auto b : bufs)
         if (*b) (void)hipFree(*b);
+    if (h->d_sched) (void)hipFree(h->d_sched);
     for (auto e : h->ev) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -283,6 +287,31 @@ static int create_impl(const jq_problem* p, jq_handle* h)
     int rc;
     if ((rc = dev_alloc(h, &h->d_himg, (size_t)(1 + 2 * h->Nc) * h->mat_elems))) return rc;
     if ((rc = dev_alloc(h, &h->d_cimg, (size_t)(2 * h->Nc) * h->mat_elems))) return rc;
+    if ((rc = dev_alloc(h, &h->d_sched, (size_t)3 * (JQ_MAXNC + JQ_MAXSCHED)))) return rc;
+    {
+        // operator schedules: {kind (0 K, 1 S, 2 constant image), time point offset / image index}
+        const int TS = JQ_MAXNC + JQ_MAXSCHED;
+        std::vector<SchedEntry> tab((size_t)3 * TS, SchedEntry{0, 0});
+        const SchedEntry K0e = {0, 0}, S0e = {1, 0}, K05e = {0, 1}, S05e = {1, 1}, K1e = {0, 2}, S1e = {1, 2};
+        const SchedEntry fwd_sched[7] = {K05e, S05e, K0e, S0e, K1e, S1e, K05e};
+        const SchedEntry adj_sched[6] = {S0e, K0e, K1e, S05e, K05e, S1e};
+        for (int i = 0; i < 7; ++i) tab[JQ_MAXNC + i] = fwd_sched[i];
+        for (int t = 1; t <= 2; ++t) {
+            SchedEntry* pro = tab.data() + (size_t)t * TS;
+            SchedEntry* sc = pro + JQ_MAXNC;
+            int k = 0;
+            for (int i = 0; i < 7; ++i) sc[k++] = fwd_sched[i];
+            sc[k++] = adj_sched[0];                                              // S0
+            for (int q = 0; q < h->Nc; ++q) sc[k++] = SchedEntry{2, h->Nc + q};  // early traces: Hanti_q
+            for (int i = 1; i < 6; ++i) sc[k++] = adj_sched[i];                  // Kn0 Kn1 S05 Kp05 S1
+            for (int q = 0; q < h->Nc; ++q) {
+                sc[k++] = SchedEntry{2, h->Nc + q};                              // late traces: Hanti_q
+                sc[k++] = SchedEntry{2, q};                                      //              Hsym_q
+                pro[q] = SchedEntry{2, q};                 // first chunk: carry products with Hsym_q
+            }
+        }
+        HIPCHK(h, hipMemcpy(h->d_sched, tab.data(), tab.size() * sizeof(SchedEntry), hipMemcpyHostToDevice));
+    }
     if ((rc = dev_alloc(h, &h->d_uimg, (size_t)h->KT * 64))) return rc;
     if ((rc = dev_alloc(h, &h->d_vtr, (size_t)h->KT * 64))) return rc;
     if ((rc = dev_alloc(h, &h->d_vti, (size_t)h->KT * 64))) return rc;
@@ -351,6 +380,21 @@ extern "C" int jq_set_neumann_terms(jq_handle* h, int32_t m)
     return JQ_OK;
 }
 
+extern "C" int jq_set_linear_solver(jq_handle* h, int32_t solver_id, int32_t max_iter, double tol)
+{
+    if (!h) return JQ_EINVAL;
+    if (max_iter < 0) return fail(h, JQ_EINVAL, "jq_set_linear_solver: max_iter must be >= 0");
+    if (solver_id == 2) {
+        if (!(tol > 0.0)) return fail(h, JQ_EINVAL, "jq_set_linear_solver: JACOBI_SOLVER needs tol > 0");
+    } else if (solver_id != 1) {
+        return fail(h, JQ_EUNSUPPORTED, "jq_set_linear_solver: only NEUMANN_SOLVER (1) and JACOBI_SOLVER (2) are implemented");
+    }
+    h->solver_id = solver_id;
+    h->m = max_iter;
+    h->solver_tol = tol;
+    return JQ_OK;
+}
+
 extern "C" int jq_update_target(jq_handle* h, const double* Utr, const double* Uti)
 {
     if (!h) return JQ_EINVAL;
@@ -387,19 +431,22 @@ typedef void (*prop_kernel_t)(PropArgs);
     X(1, 0) X(2, 0) X(2, 1) X(3, 0) X(3, 1) X(3, 2) X(4, 0) X(4, 1) X(4, 2) X(4, 3) X(5, 0) X(5, 1) \
     X(5, 2) X(5, 4) X(6, 0) X(6, 1) X(6, 2) X(6, 5)
 #define JQ_MINW_OF(nt) (((nt) <= 2) ? 2 : 1)
-#define JQ_DECL(nt, bw)                                                               \
-    extern template __global__ void k_forward<nt, bw, JQ_MINW_OF(nt)>(PropArgs);      \
-    extern template __global__ void k_backward<nt, bw, JQ_MINW_OF(nt)>(PropArgs);
+#define JQ_DECL(nt, bw)                                                                      \
+    extern template __global__ void k_forward<nt, bw, JQ_MINW_OF(nt), false>(PropArgs);      \
+    extern template __global__ void k_backward<nt, bw, JQ_MINW_OF(nt), false>(PropArgs);     \
+    extern template __global__ void k_forward<nt, bw, JQ_MINW_OF(nt), true>(PropArgs);       \
+    extern template __global__ void k_backward<nt, bw, JQ_MINW_OF(nt), true>(PropArgs);
 JQ_FOR_EACH_INST(JQ_DECL)
 #undef JQ_DECL
 
 static int select_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
 {
-#define JQ_PICK(nt, bw)                                   \
-    if (h->NT == nt && h->BW == bw) {                     \
-        *fwd = k_forward<nt, bw, JQ_MINW_OF(nt)>;         \
-        *bwd = k_backward<nt, bw, JQ_MINW_OF(nt)>;        \
-        return JQ_OK;                                     \
+    const bool jac = (h->solver_id == 2);
+#define JQ_PICK(nt, bw)                                                                                  \
+    if (h->NT == nt && h->BW == bw) {                                                                    \
+        *fwd = jac ? k_forward<nt, bw, JQ_MINW_OF(nt), true> : k_forward<nt, bw, JQ_MINW_OF(nt), false>; \
+        *bwd = jac ? k_backward<nt, bw, JQ_MINW_OF(nt), true> : k_backward<nt, bw, JQ_MINW_OF(nt), false>; \
+        return JQ_OK;                                                                                    \
     }
     JQ_FOR_EACH_INST(JQ_PICK)
 #undef JQ_PICK
@@ -502,12 +549,8 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     a.tabs = h->d_tabs; a.stride = h->mat_elems; a.pieces = (int)(h->mat_elems * 8 / 1024); a.nslots = h->nslots; a.m = h->m;
     a.nslabs = nslabs; a.Ncoupled = h->Nc; a.Ntot = h->Ntot; a.N = h->N; a.use_shift = use_shift ? 1 : 0;
     a.tinv = 1.0 / h->T; a.state_stride = h->state_stride;
+    a.jacobi_tol2 = (h->solver_id == 2) ? h->solver_tol * h->solver_tol : 0.0;
     for (int q = 0; q < JQ_MAXNC; ++q) a.bw_trace[q] = h->bw_trace[q];
-    // operator schedules: {kind (0 K, 1 S, 2 constant image), time point offset / image index}
-    const SchedEntry K0e = {0, 0}, S0e = {1, 0}, K05e = {0, 1}, S05e = {1, 1}, K1e = {0, 2}, S1e = {1, 2};
-    const SchedEntry fwd_sched[7] = {K05e, S05e, K0e, S0e, K1e, S1e, K05e};
-    const SchedEntry adj_sched[6] = {S0e, K0e, K1e, S05e, K05e, S1e};
-
     // dynamic LDS layout: [operator staging | tables wd, ws | (backward: carry, parking images)]
     const size_t lds_stage = h->batch > 0 ? (size_t)2 * (2 * h->batch + 1) * 2 * h->mat_elems * 8 + (size_t)2 * h->Nc * h->mat_elems * 8
                                           : (size_t)2 * h->mat_elems * 8;
@@ -545,8 +588,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
                            h->Nc, h->mat_elems, 0.5 * dt, h->d_stream);
         a.nsteps_chunk = nc; a.step0 = n0; a.first_chunk = (n0 == 0); a.h = dt; a.forced = 1;
         a.hist_r = hist_r; a.hist_i = hist_i;
-        a.period = 7; a.npro = 0; a.nslots = h->nslots;
-        for (int i = 0; i < 7; ++i) a.sched[i] = fwd_sched[i];
+        a.period = 7; a.npro = 0; a.nslots = h->nslots; a.sched_tab = h->d_sched;
         HIPCHK(h, hipEventRecord(h->ev[evi++], s));
         hipLaunchKernelGGL(kfwd, dim3(nblocks), dim3(256), lds_fwd, s, a);
         HIPCHK(h, hipEventRecord(h->ev[evi++], s));
@@ -575,18 +617,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
                 a.nsteps_chunk = nc; a.step0 = n0; a.first_chunk = (n0 == 0); a.h = -dt; a.forced = (pass == 0);
                 a.hist_r = nullptr; a.hist_i = nullptr;
                 a.period = 13 + 3 * h->Nc; a.npro = (n0 == 0) ? h->Nc : 0; a.nslots = h->nslots_bwd;
-                {
-                    int k = 0;
-                    for (int i = 0; i < 7; ++i) a.sched[k++] = fwd_sched[i];
-                    a.sched[k++] = adj_sched[0];                                              // S0
-                    for (int q = 0; q < h->Nc; ++q) a.sched[k++] = SchedEntry{2, h->Nc + q};  // early traces: Hanti_q
-                    for (int i = 1; i < 6; ++i) a.sched[k++] = adj_sched[i];                  // Kn0 Kn1 S05 Kp05 S1
-                    for (int q = 0; q < h->Nc; ++q) {
-                        a.sched[k++] = SchedEntry{2, h->Nc + q};                              // late traces: Hanti_q
-                        a.sched[k++] = SchedEntry{2, q};                                      //              Hsym_q
-                        a.pro[q] = SchedEntry{2, q};                  // first chunk: carry products with Hsym_q
-                    }
-                }
+                a.sched_tab = h->d_sched + (size_t)((n0 == 0) ? 1 : 2) * (JQ_MAXNC + JQ_MAXSCHED);
                 HIPCHK(h, hipEventRecord(h->ev[evi++], s));
                 hipLaunchKernelGGL(kbwd, dim3(nblocks), dim3(256), lds_bwd, s, a);
                 HIPCHK(h, hipEventRecord(h->ev[evi++], s));

@@ -32,9 +32,7 @@ class Working_Arrays_HIP:
 
     def __init__(self, params: objparams, nCoeff: int):
         L = _lib.load()
-        if params.linear_solver.solver_id != NEUMANN_SOLVER:
-            if params.linear_solver.solver_id == JACOBI_SOLVER:
-                raise NotImplementedError("JACOBI_SOLVER is not implemented by the HIP path (SURVEY.md section 8f row 4)")
+        if params.linear_solver.solver_id not in (NEUMANN_SOLVER, JACOBI_SOLVER):
             raise ValueError("Please specify a supported linear solver")
         self.params = params
         self.nCoeff = int(nCoeff)
@@ -47,6 +45,7 @@ class Working_Arrays_HIP:
         self._utr = _f64(p.Utarget_r).copy()
         self._uti = _f64(p.Utarget_i).copy()
         self._m = int(p.linear_solver.max_iter)
+        self._solver = None
         keep = [self._hconst, hs, ha, _f64(p.Uinit), self._utr, self._uti, self._wd, _f64(p.Cfreq[:p.Ncoupled, :])]
         prob = _lib.jq_problem(p.Ntot, p.N, p.Ncoupled, p.Nfreq, p.nsteps, self._m, p.objFuncType, 0, p.T,
                                *[_ptr(a) for a in keep])
@@ -71,12 +70,14 @@ class Working_Arrays_HIP:
     def sync_params(self):
         """Push post-construction mutations of `params` to the device (only what changed)."""
         L, p, h = _lib.load(), self.params, self.handle
-        if p.linear_solver.solver_id != NEUMANN_SOLVER:
-            raise NotImplementedError("only NEUMANN_SOLVER is implemented by the HIP path")
-        m = int(p.linear_solver.max_iter)
-        if m != self._m:
-            _lib.check(L.jq_set_neumann_terms(h, m), h)
-            self._m = m
+        ls = p.linear_solver
+        if ls.solver_id not in (NEUMANN_SOLVER, JACOBI_SOLVER):
+            raise ValueError("Please specify a supported linear solver")
+        key = (int(ls.solver_id), int(ls.max_iter), float(ls.tol))
+        if key != self._solver:
+            _lib.check(L.jq_set_linear_solver(h, key[0], key[1], key[2]), h)
+            self._solver = key
+            self._m = key[1]
         hc = _f64(p.Hconst)
         if not np.array_equal(hc, self._hconst):
             _lib.check(L.jq_update_hconst(h, _ptr(hc)), h)

@@ -39,7 +39,7 @@ def gpu_eval_like_evalGrad(jq, params, wa, pcof):
     return np.array([objv]), grad
 
 
-@pytest.mark.parametrize("case", ["rabi", "swap02", "flux", "cnot2", "cnot2-leakieq", "cnot3"])
+@pytest.mark.parametrize("case", ["rabi", "swap02", "flux", "cnot2", "cnot2-leakieq", "cnot2-jacobi", "cnot3"])
 def test_reference_golden_through_the_callbacks(hip, case):
     jq = hip
     params, info, pcof, golden = case_inputs(case)
@@ -171,9 +171,28 @@ def test_error_paths(hip):
         jq.traceobjgrad(np.concatenate([pcof, pcof[:2]]), params, wa)
     assert e.value.code == _lib.JQ_EDIM
     wa.close()
-    p2, _, _, _ = case_inputs("cnot2-jacobi")
-    with pytest.raises(NotImplementedError):
-        jq.Working_Arrays_HIP(p2, 80)
+
+
+def test_jacobi_solver_matches_oracle_and_switches_at_run_time(hip):
+    """JACOBI_SOLVER (src/linear_solvers.jl:110-153) incl. its early exit, and switching the solver of an
+    existing params object (scripts replace params.linear_solver after construction)."""
+    from oracle.oracle import Oracle
+    jq = hip
+    params, info, pcof, _ = case_inputs("cnot2-jacobi")
+    wa = jq.Working_Arrays_HIP(params, pcof.size)
+    for max_iter, tol in ((5, 2e-15), (50, 1e-9), (3, 1e-30)):
+        params.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER, max_iter=max_iter, tol=tol, nrhs=1)
+        r = Oracle(params).traceobjgrad(pcof)
+        objfv, tg, prim, sec, tinf, ig, lg = jq.traceobjgrad(pcof, params, wa, False, True)
+        # the device tests convergence per 16-column slab instead of per sample: agreement to O(tol)
+        bound = max(TOL, 100 * tol)
+        assert abs(objfv - r["objfv"]) <= bound * abs(r["objfv"])
+        assert rel(tg, r["totalgrad"]) < bound
+    params.linear_solver = jq.lsolver_object(solver=jq.NEUMANN_SOLVER, max_iter=5)
+    r = Oracle(params).traceobjgrad(pcof)
+    objfv, tg, *_ = jq.traceobjgrad(pcof, params, wa, False, True)
+    assert abs(objfv - r["objfv"]) <= TOL * abs(r["objfv"]) and rel(tg, r["totalgrad"]) < TOL
+    wa.close()
 
 
 def test_cnot3_full_size_properties(hip):
