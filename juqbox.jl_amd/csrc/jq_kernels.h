@@ -30,16 +30,29 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define JQ_STATE_ARRAYS 4     // U, V, MU, NU
 #define JQ_STATE_EXTRA 8      // 64-double rows after the arrays: CARRY[0..3], LEAK, spare
 #define JQ_MAXSLOTS 2         // LDS operator slots (double buffer)
-#define JQ_MAXSCHED 32        // max operator uses per time step (13 + 3*JQ_MAXNC = 25)
+#define JQ_MAXSCHED 30        // max operator uses per time step (13 + 3*JQ_MAXNC = 25)
 
-// number of stored tiles of an NT x 4NT tile grid with block band width BW (host + device)
-__host__ __device__ constexpr int band_tiles(int NT, int BW)
+// Stored tiles of an NT x 4NT tile grid: block (mt,kb) is kept when |mt-kb| <= BW and, for SD ("skip
+// diagonal": operators like a3 +- a3' of the slowest subsystem, whose diagonal blocks vanish), mt != kb.
+__host__ __device__ constexpr bool block_on(int BW, bool SD, int mt, int kb)
+{
+    return (mt - kb <= BW) && (kb - mt <= BW) && !(SD && mt == kb);
+}
+// number of stored tiles (host + device)
+__host__ __device__ constexpr int band_tiles(int NT, int BW, bool SD = false)
 {
     int n = 0;
     for (int kb = 0; kb < NT; ++kb)
         for (int mt = 0; mt < NT; ++mt)
-            if ((mt - kb <= BW) && (kb - mt <= BW)) n += 4;
+            if (block_on(BW, SD, mt, kb)) n += 4;
     return n;
+}
+// first stored k-block of tile row mt (NT if the row is empty)
+__host__ __device__ constexpr int first_kb(int NT, int BW, bool SD, int mt)
+{
+    for (int kb = 0; kb < NT; ++kb)
+        if (block_on(BW, SD, mt, kb)) return kb;
+    return NT;
 }
 
 template <int NT>
@@ -127,10 +140,10 @@ __device__ __forceinline__ void a_store(const Arr<NT>& a, double* __restrict__ i
 // The A fragments are fetched JQ_PF tiles ahead of their MFMA through a small register FIFO: a
 // v_mfma_f64_16x16x4 occupies the matrix pipe for 64 cycles, an LDS read returns in ~100.
 #define JQ_PF 4
-template <int NT, int BW, bool ZEROC>
+template <int NT, int BW, bool ZEROC, bool SD = false>
 __device__ __forceinline__ void mm_any(Arr<NT>& D, const Arr<NT>& C, const double* mat, const Arr<NT>& x)
 {
-    constexpr int NTILES = band_tiles(NT, BW);
+    constexpr int NTILES = band_tiles(NT, BW, SD);
     double f[JQ_PF];
 #pragma unroll
     for (int i = 0; i < JQ_PF; ++i)
@@ -140,12 +153,10 @@ __device__ __forceinline__ void mm_any(Arr<NT>& D, const Arr<NT>& C, const doubl
     for (int kk = 0; kk < 4 * NT; ++kk) {
 #pragma unroll
         for (int mt = 0; mt < NT; ++mt) {
-            const int kb = kk >> 2;
-            if ((mt - kb <= BW) && (kb - mt <= BW)) {
+            if (block_on(BW, SD, mt, kk >> 2)) {
                 const double a = f[idx % JQ_PF];
                 if (idx + JQ_PF < NTILES) f[idx % JQ_PF] = mat[(idx + JQ_PF) * 64];
-                const int kb0 = (mt - BW) > 0 ? (mt - BW) : 0;   // first k-block of this tile row
-                const bool first = (kk == 4 * kb0);
+                const bool first = (kk == 4 * first_kb(NT, BW, SD, mt));
                 const d4 zero = {0.0, 0.0, 0.0, 0.0};
                 const d4 cin = first ? (ZEROC ? zero : C.t[mt]) : D.t[mt];
                 D.t[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, x.t[kk >> 2][kk & 3], cin, 0, 0, 0);
@@ -153,6 +164,12 @@ __device__ __forceinline__ void mm_any(Arr<NT>& D, const Arr<NT>& C, const doubl
                 ++idx;
             }
         }
+    }
+    if (ZEROC) {
+        // tile rows without any stored tile (cannot happen for BW >= 0 without SD; with SD only if NT == 1)
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt)
+            if (first_kb(NT, BW, SD, mt) >= NT) D.t[mt] = (d4){0.0, 0.0, 0.0, 0.0};
     }
 }
 template <int NT, int BW>
@@ -165,12 +182,15 @@ __device__ __forceinline__ void mm_z(Arr<NT>& D, const double* mat, const Arr<NT
 {
     mm_any<NT, BW, true>(D, D, mat, x);
 }
-// D = M * x with an operator whose own band is either 0 (block diagonal) or the kernel's BW
+// D = M * x with a constant (trace) operator stored in its own layout:
+//   mode 0: block diagonal (band 0)   mode 1: the kernel's band BW   mode 2: band BW without the diagonal blocks
 template <int NT, int BW>
-__device__ __forceinline__ void mm_z_bw(Arr<NT>& D, const double* mat, const Arr<NT>& x, int bw)
+__device__ __forceinline__ void mm_z_bw(Arr<NT>& D, const double* mat, const Arr<NT>& x, int mode)
 {
-    if (BW > 0 && bw == 0)
+    if (BW > 0 && mode == 0)
         mm_any<NT, 0, true>(D, D, mat, x);
+    else if (BW > 0 && NT > 1 && mode == 2)
+        mm_any<NT, BW, true, true>(D, D, mat, x);
     else
         mm_any<NT, BW, true>(D, D, mat, x);
 }
@@ -247,12 +267,19 @@ struct PropArgs {
     int lds_tab_off;        // byte offset of the tables (wd, ws[, carry, park]) in dynamic LDS
     int period;             // operator uses per time step
     int npro;               // operator uses before the first step (backward first chunk: carry products)
-    int bw_trace[JQ_MAXNC]; // band width of the trace images per control (0 or the kernel's BW)
+    int bw_trace[JQ_MAXNC]; // layout of the trace images per control: 0 block diagonal, 1 band BW, 2 band BW w/o diagonal
     double h;               // signed time step
     double tinv;            // 1/T
     double jacobi_tol2;     // JAC kernels (JACOBI_SOLVER): squared tolerance, max_iter = m
-    const SchedEntry* sched_tab;  // device memory: [pro: JQ_MAXNC entries | sched: JQ_MAXSCHED entries]
+    // operator schedule, 6 bits per entry (kind | tp << 2), 10 entries per 64-bit word: decoded with
+    // scalar ALU ops only (a table in memory costs a dependent scalar load in front of every DMA issue)
+    unsigned long long sched_bits[3];  // entries 0..29 of the per-step schedule
+    unsigned long long pro_bits;       // entries of the prologue (backward first chunk)
 };
+__host__ __device__ inline void sched_pack(unsigned long long* words, int i, int kind, int tp)
+{
+    words[i / 10] |= (unsigned long long)((kind & 3) | ((tp & 15) << 2)) << (6 * (i % 10));
+}
 
 // usaver[:,:,step+1] = vr ; usavei = -vi (src/evalobjgrad.jl:748-752); only sample 0 (slab 0, columns < N)
 template <int NT>
@@ -293,7 +320,7 @@ struct Ring {
     // argument struct would make hipcc spill all of it to scratch)
     const double* stream;
     const double* cimg;
-    const SchedEntry* tab;
+    unsigned long long sb0, sb1, sb2, pb;
     long long stride;
     int pieces, nsteps_chunk, period, npro, batch, ncoupled, debug;
     int slot_bytes;   // bytes of one slot (per-operator mode) or of one batch buffer (batched mode)
@@ -319,9 +346,23 @@ struct Ring {
     // schedule entry of operator use q (cursor position i within the step); scalar loads, no struct copies
     __device__ __forceinline__ void entry_at(int q, int i, int& kind, int& tp) const
     {
-        const SchedEntry* e = (q < npro) ? tab + q : tab + JQ_MAXNC + i;
-        kind = e->kind;
-        tp = e->tp;
+        unsigned long long w;
+        int k = i;
+        if (q < npro) {
+            w = pb;
+            k = q;
+        } else if (i < 10) {
+            w = sb0;
+        } else if (i < 20) {
+            w = sb1;
+            k = i - 10;
+        } else {
+            w = sb2;
+            k = i - 20;
+        }
+        const unsigned e = (unsigned)(w >> (6 * k)) & 63u;
+        kind = (int)(e & 3u);
+        tp = (int)(e >> 2);
     }
     __device__ __forceinline__ void advance(int& q, int& n, int& i) const
     {
@@ -370,7 +411,10 @@ struct Ring {
         smem = smem_;
         stream = a.stream;
         cimg = a.cimg;
-        tab = a.sched_tab;
+        sb0 = a.sched_bits[0];
+        sb1 = a.sched_bits[1];
+        sb2 = a.sched_bits[2];
+        pb = a.pro_bits;
         stride = a.stride;
         pieces = a.pieces;
         nsteps_chunk = a.nsteps_chunk;

@@ -42,7 +42,6 @@ struct jq_handle {
     std::vector<double> tf, tb;
     // device buffers (owned)
     double *d_cimg = nullptr, *d_park = nullptr;
-    SchedEntry* d_sched = nullptr;   // 3 schedule tables: forward, backward first chunk, backward later chunks
     double *d_himg = nullptr, *d_uimg = nullptr, *d_vtr = nullptr, *d_vti = nullptr, *d_tabs = nullptr;
     double *d_tf = nullptr, *d_tb = nullptr, *d_cfreq = nullptr, *d_pcof = nullptr;
     double *d_stream = nullptr, *d_pq = nullptr;
@@ -75,20 +74,29 @@ static int fail(jq_handle* h, int code, const char* msg)
 // A-fragment tile image of a column-major Ntot x Ntot matrix: only the tiles of the block band
 // |mt - kk/4| <= BW are stored, in walk order (kk outer, mt inner); tile (mt,kk) lane l holds
 // M[16*mt + (l&15)][4*kk + (l>>4)]; zero padded.
-static void tile_image(const double* M, int Ntot, int NT, int BW, double* img)
+static void tile_image(const double* M, int Ntot, int NT, int BW, double* img, bool SD = false)
 {
     const int KT = 4 * NT;
     size_t idx = 0;
     for (int kk = 0; kk < KT; ++kk)
         for (int mt = 0; mt < NT; ++mt) {
             const int kb = kk >> 2;
-            if (mt - kb > BW || kb - mt > BW) continue;
+            if (!block_on(BW, SD, mt, kb)) continue;
             for (int l = 0; l < 64; ++l) {
                 const int row = 16 * mt + (l & 15), col = 4 * kk + (l >> 4);
                 img[idx * 64 + l] = (row < Ntot && col < Ntot) ? M[row + (size_t)Ntot * col] : 0.0;
             }
             ++idx;
         }
+}
+
+// true if every diagonal 16x16 block of M is zero
+static bool diag_blocks_zero(const double* M, int Ntot)
+{
+    for (int col = 0; col < Ntot; ++col)
+        for (int row = 0; row < Ntot; ++row)
+            if (row / 16 == col / 16 && M[row + (size_t)Ntot * col] != 0.0) return false;
+    return true;
 }
 
 // smallest block band width that contains every nonzero of M
@@ -136,8 +144,10 @@ static int upload_operators(jq_handle* h)
     // images of the trace products: [Hsym_q | Hanti_q], each pair in its own band (0 or BW)
     std::vector<double> cimg((size_t)(2 * h->Nc) * h->mat_elems, 0.0);
     for (int q = 0; q < h->Nc; ++q) {
-        tile_image(h->Hsym.data() + q * nn, h->Ntot, h->NT, h->bw_trace[q], cimg.data() + (size_t)q * h->mat_elems);
-        tile_image(h->Hanti.data() + q * nn, h->Ntot, h->NT, h->bw_trace[q], cimg.data() + (size_t)(h->Nc + q) * h->mat_elems);
+        const int bwq = (h->bw_trace[q] == 0) ? 0 : h->BW;
+        const bool sd = (h->bw_trace[q] == 2);
+        tile_image(h->Hsym.data() + q * nn, h->Ntot, h->NT, bwq, cimg.data() + (size_t)q * h->mat_elems, sd);
+        tile_image(h->Hanti.data() + q * nn, h->Ntot, h->NT, bwq, cimg.data() + (size_t)(h->Nc + q) * h->mat_elems, sd);
     }
     HIPCHK(h, hipMemcpy(h->d_cimg, cimg.data(), cimg.size() * sizeof(double), hipMemcpyHostToDevice));
     return JQ_OK;
@@ -175,7 +185,6 @@ extern "C" void jq_destroy(jq_handle* h)
                        &h->d_colinfo, &h->d_traces,   &h->d_R,       &h->d_grad,   &h->d_res};
     for (auto b : bufs)
         if (*b) (void)hipFree(*b);
-    if (h->d_sched) (void)hipFree(h->d_sched);
     for (auto e : h->ev) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -237,7 +246,14 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         if (const char* e = getenv("JQ_FORCE_DENSE"))
             if (atoi(e) != 0) bw = h->NT - 1;
         h->BW = (bw <= 2 && bw < h->NT - 1) ? bw : h->NT - 1;
-        for (int q = 0; q < h->Nc; ++q) h->bw_trace[q] = (h->bw_trace[q] == 0) ? 0 : h->BW;
+        // trace image layout per control: 0 block diagonal, 1 band BW, 2 band BW without the diagonal blocks
+        for (int q = 0; q < h->Nc; ++q) {
+            if (h->bw_trace[q] == 0 || h->BW == 0)
+                h->bw_trace[q] = (h->BW == 0) ? 1 : 0;
+            else
+                h->bw_trace[q] = (h->NT > 1 && diag_blocks_zero(h->Hsym.data() + q * nn, h->Ntot) &&
+                                  diag_blocks_zero(h->Hanti.data() + q * nn, h->Ntot)) ? 2 : 1;
+        }
         h->mat_elems = ((64LL * band_tiles(h->NT, h->BW) + 127) / 128) * 128;
         const long long slot = h->mat_elems * 8;
         const long long lds_fwd_fixed = (long long)32 * h->NT * 8;
@@ -287,31 +303,6 @@ static int create_impl(const jq_problem* p, jq_handle* h)
     int rc;
     if ((rc = dev_alloc(h, &h->d_himg, (size_t)(1 + 2 * h->Nc) * h->mat_elems))) return rc;
     if ((rc = dev_alloc(h, &h->d_cimg, (size_t)(2 * h->Nc) * h->mat_elems))) return rc;
-    if ((rc = dev_alloc(h, &h->d_sched, (size_t)3 * (JQ_MAXNC + JQ_MAXSCHED)))) return rc;
-    {
-        // operator schedules: {kind (0 K, 1 S, 2 constant image), time point offset / image index}
-        const int TS = JQ_MAXNC + JQ_MAXSCHED;
-        std::vector<SchedEntry> tab((size_t)3 * TS, SchedEntry{0, 0});
-        const SchedEntry K0e = {0, 0}, S0e = {1, 0}, K05e = {0, 1}, S05e = {1, 1}, K1e = {0, 2}, S1e = {1, 2};
-        const SchedEntry fwd_sched[7] = {K05e, S05e, K0e, S0e, K1e, S1e, K05e};
-        const SchedEntry adj_sched[6] = {S0e, K0e, K1e, S05e, K05e, S1e};
-        for (int i = 0; i < 7; ++i) tab[JQ_MAXNC + i] = fwd_sched[i];
-        for (int t = 1; t <= 2; ++t) {
-            SchedEntry* pro = tab.data() + (size_t)t * TS;
-            SchedEntry* sc = pro + JQ_MAXNC;
-            int k = 0;
-            for (int i = 0; i < 7; ++i) sc[k++] = fwd_sched[i];
-            sc[k++] = adj_sched[0];                                              // S0
-            for (int q = 0; q < h->Nc; ++q) sc[k++] = SchedEntry{2, h->Nc + q};  // early traces: Hanti_q
-            for (int i = 1; i < 6; ++i) sc[k++] = adj_sched[i];                  // Kn0 Kn1 S05 Kp05 S1
-            for (int q = 0; q < h->Nc; ++q) {
-                sc[k++] = SchedEntry{2, h->Nc + q};                              // late traces: Hanti_q
-                sc[k++] = SchedEntry{2, q};                                      //              Hsym_q
-                pro[q] = SchedEntry{2, q};                 // first chunk: carry products with Hsym_q
-            }
-        }
-        HIPCHK(h, hipMemcpy(h->d_sched, tab.data(), tab.size() * sizeof(SchedEntry), hipMemcpyHostToDevice));
-    }
     if ((rc = dev_alloc(h, &h->d_uimg, (size_t)h->KT * 64))) return rc;
     if ((rc = dev_alloc(h, &h->d_vtr, (size_t)h->KT * 64))) return rc;
     if ((rc = dev_alloc(h, &h->d_vti, (size_t)h->KT * 64))) return rc;
@@ -411,6 +402,9 @@ extern "C" int jq_update_hconst(jq_handle* h, const double* Hconst)
     if (!h) return JQ_EINVAL;
     if (!Hconst) return fail(h, JQ_EINVAL, "jq_update_hconst: NULL pointer");
     HIPCHK(h, hipSetDevice(h->device));
+    if (block_band(Hconst, h->Ntot) > h->BW)
+        return fail(h, JQ_EUNSUPPORTED, "jq_update_hconst: new Hconst has entries outside the block band the kernels were "
+                                        "selected for; create a new handle");
     h->Hconst.assign(Hconst, Hconst + (size_t)h->Ntot * h->Ntot);
     return upload_operators(h);
 }
@@ -578,7 +572,8 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     long long mfma = 0;
     const long long tiles = band_tiles(h->NT, h->BW);
     long long trace_tiles = 0;
-    for (int q = 0; q < h->Nc; ++q) trace_tiles += band_tiles(h->NT, h->bw_trace[q]);
+    for (int q = 0; q < h->Nc; ++q)
+        trace_tiles += band_tiles(h->NT, h->bw_trace[q] == 0 ? 0 : h->BW, h->bw_trace[q] == 2);
     // ---- forward sweep -------------------------------------------------------------------------
     for (int n0 = 0; n0 < h->nsteps; n0 += cs) {
         const int nc = std::min(cs, h->nsteps - n0);
@@ -588,7 +583,12 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
                            h->Nc, h->mat_elems, 0.5 * dt, h->d_stream);
         a.nsteps_chunk = nc; a.step0 = n0; a.first_chunk = (n0 == 0); a.h = dt; a.forced = 1;
         a.hist_r = hist_r; a.hist_i = hist_i;
-        a.period = 7; a.npro = 0; a.nslots = h->nslots; a.sched_tab = h->d_sched;
+        a.period = 7; a.npro = 0; a.nslots = h->nslots;
+        {   // Kp05 S05 Kn0 S0 Kn1 S1 Kp05     {kind (0 K, 1 S, 2 constant image), time point offset / image index}
+            const int kinds[7] = {0, 1, 0, 1, 0, 1, 0}, tps[7] = {1, 1, 0, 0, 2, 2, 1};
+            a.sched_bits[0] = a.sched_bits[1] = a.sched_bits[2] = a.pro_bits = 0;
+            for (int i = 0; i < 7; ++i) sched_pack(a.sched_bits, i, kinds[i], tps[i]);
+        }
         HIPCHK(h, hipEventRecord(h->ev[evi++], s));
         hipLaunchKernelGGL(kfwd, dim3(nblocks), dim3(256), lds_fwd, s, a);
         HIPCHK(h, hipEventRecord(h->ev[evi++], s));
@@ -617,7 +617,20 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
                 a.nsteps_chunk = nc; a.step0 = n0; a.first_chunk = (n0 == 0); a.h = -dt; a.forced = (pass == 0);
                 a.hist_r = nullptr; a.hist_i = nullptr;
                 a.period = 13 + 3 * h->Nc; a.npro = (n0 == 0) ? h->Nc : 0; a.nslots = h->nslots_bwd;
-                a.sched_tab = h->d_sched + (size_t)((n0 == 0) ? 1 : 2) * (JQ_MAXNC + JQ_MAXSCHED);
+                {   // Kp05 S05 Kn0 S0 Kn1 S1 Kp05 | S0 | Hanti_q.. | Kn0 Kn1 S05 Kp05 S1 | (Hanti_q Hsym_q)..
+                    const int kinds[8] = {0, 1, 0, 1, 0, 1, 0, 1}, tps[8] = {1, 1, 0, 0, 2, 2, 1, 0};
+                    const int kinds2[5] = {0, 0, 1, 0, 1}, tps2[5] = {0, 2, 1, 1, 2};
+                    a.sched_bits[0] = a.sched_bits[1] = a.sched_bits[2] = a.pro_bits = 0;
+                    int k = 0;
+                    for (int i = 0; i < 8; ++i) sched_pack(a.sched_bits, k++, kinds[i], tps[i]);
+                    for (int q = 0; q < h->Nc; ++q) sched_pack(a.sched_bits, k++, 2, h->Nc + q);   // early traces: Hanti_q
+                    for (int i = 0; i < 5; ++i) sched_pack(a.sched_bits, k++, kinds2[i], tps2[i]);
+                    for (int q = 0; q < h->Nc; ++q) {
+                        sched_pack(a.sched_bits, k++, 2, h->Nc + q);                               // late traces: Hanti_q
+                        sched_pack(a.sched_bits, k++, 2, q);                                       //              Hsym_q
+                        sched_pack(&a.pro_bits, q, 2, q);          // first chunk: carry products with Hsym_q
+                    }
+                }
                 HIPCHK(h, hipEventRecord(h->ev[evi++], s));
                 hipLaunchKernelGGL(kbwd, dim3(nblocks), dim3(256), lds_bwd, s, a);
                 HIPCHK(h, hipEventRecord(h->ev[evi++], s));
