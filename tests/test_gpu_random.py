@@ -1,0 +1,105 @@
+"""GPU (-m gpu): randomized problems vs the CPU oracle -- sizes, paddings and code paths the reference's
+own cases do not reach: dense (non-banded) Hamiltonians, every tile count NT = 1..6, Hilbert dimensions
+that are not multiples of 16, N = 1..16 columns per sample (ragged slabs), 1..4 controls, 1..3 carrier
+frequencies, Neumann terms 0..7, objFuncType 1/2/3, time loops split into several chunks of odd length
+(JQ_CHUNK_STEPS), ensembles that do not fill their last slab / workgroup."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9   # random problems are less well conditioned than the reference cases; observed ~1e-13
+
+
+def random_problem(jq, rng, Ntot, N, Nc, Nfreq, nsteps, m, objFuncType, banded):
+    T = 1.0 + rng.random()
+    if banded:      # nearest-level couplings like a ladder operator: block band 0 or 1
+        def sym():
+            a = np.zeros((Ntot, Ntot))
+            for i in range(Ntot - 1):
+                a[i, i + 1] = rng.standard_normal()
+            return a
+        Hs = [(lambda a: a + a.T)(sym()) for _ in range(Nc)]
+        Ha = [(lambda a: a - a.T)(sym()) for _ in range(Nc)]
+        H0 = np.diag(rng.standard_normal(Ntot))
+    else:
+        Hs = [(lambda a: a + a.T)(rng.standard_normal((Ntot, Ntot))) for _ in range(Nc)]
+        Ha = [(lambda a: a - a.T)(rng.standard_normal((Ntot, Ntot))) for _ in range(Nc)]
+        H0 = (lambda a: a + a.T)(rng.standard_normal((Ntot, Ntot)))
+    scale = 2.0 / max(1.0, max(np.abs(np.linalg.eigvalsh(h)).max() for h in Hs + [H0]))
+    H0 *= scale
+    Hs = [h * scale for h in Hs]
+    Ha = [h * scale for h in Ha]
+    Ne, Ng = [N], [Ntot - N]
+    U0 = np.linalg.qr(rng.standard_normal((Ntot, N)))[0]
+    Ut = np.linalg.qr(rng.standard_normal((Ntot, N)) + 1j * rng.standard_normal((Ntot, N)))[0]
+    Cfreq = rng.standard_normal((Nc, Nfreq))
+    p = jq.objparams(Ne, Ng, T, nsteps, Uinit=U0, Utarget=Ut, Cfreq=Cfreq, Rfreq=np.zeros(Nc), Hconst=H0,
+                     Hsym_ops=Hs, Hanti_ops=Ha, objFuncType=objFuncType,
+                     linear_solver=jq.lsolver_object(max_iter=m))
+    p.wmat_real = rng.random(Ntot) * (np.arange(Ntot) >= N)
+    D1 = int(rng.integers(3, 7))
+    pcof = 0.3 * rng.standard_normal(2 * Nc * Nfreq * D1)
+    return p, pcof
+
+
+CASES = [
+    # Ntot, N, Nc, Nfreq, nsteps, m, objFuncType, banded, chunk_steps
+    (2, 1, 1, 1, 5, 0, 1, False, 0),
+    (3, 3, 1, 2, 17, 2, 1, False, 4),
+    (7, 2, 2, 1, 33, 3, 3, False, 7),
+    (16, 16, 1, 1, 9, 1, 1, False, 0),
+    (17, 5, 2, 2, 21, 4, 2, False, 5),
+    (30, 4, 3, 1, 12, 3, 1, True, 0),
+    (33, 7, 1, 3, 11, 5, 3, True, 3),
+    (47, 3, 4, 1, 8, 2, 1, False, 0),
+    (50, 8, 2, 1, 7, 7, 1, True, 2),
+    (64, 4, 3, 2, 6, 3, 3, False, 0),
+    (80, 2, 1, 1, 5, 2, 1, True, 0),
+    (81, 9, 2, 1, 5, 1, 2, False, 2),
+    (96, 4, 3, 1, 6, 6, 1, False, 4),
+    (95, 6, 2, 2, 4, 3, 3, True, 0),
+]
+
+
+@pytest.mark.parametrize("cfg", CASES, ids=lambda c: "Ntot%d_N%d_Nc%d_f%d_m%d_o%d_%s_c%d" % (c[0], c[1], c[2], c[3], c[5], c[6], "band" if c[7] else "dense", c[8]))
+def test_random_problem_matches_oracle(jq, cfg):
+    from oracle.oracle import Oracle
+    Ntot, N, Nc, Nfreq, nsteps, m, oft, banded, chunk = cfg
+    rng = np.random.default_rng(1000 + Ntot * 31 + N)
+    p, pcof = random_problem(jq, rng, Ntot, N, Nc, Nfreq, nsteps, m, oft, banded)
+    if chunk:
+        os.environ["JQ_CHUNK_STEPS"] = str(chunk)
+    try:
+        wa = jq.Working_Arrays_HIP(p, pcof.size)
+    finally:
+        os.environ.pop("JQ_CHUNK_STEPS", None)
+    r = Oracle(p, use_sparse=False).traceobjgrad(pcof, history=True)
+    objfv, tg, prim, sec, tinf, ig, lg = jq.traceobjgrad(pcof, p, wa, False, True)
+    gn = np.linalg.norm(r["totalgrad"])
+    assert abs(prim - r["primaryobjf"]) <= TOL
+    assert abs(sec - r["secondaryobjf"]) <= TOL * max(abs(r["secondaryobjf"]), 1e-3)
+    assert np.linalg.norm(tg - r["totalgrad"]) <= TOL * gn
+    assert np.linalg.norm(ig - r["infidelgrad"]) <= TOL * gn
+    if oft != 1:
+        assert np.linalg.norm(lg - r["leakgrad"]) <= TOL * gn
+    # per-step states
+    _, hist, _ = jq.traceobjgrad(pcof, p, wa, True, False)
+    assert np.max(np.abs(hist - r["history"])) < 1e-10
+    # ragged ensemble: sample counts that leave slabs / workgroups partly empty
+    sps = 16 // N
+    for nq in sorted({1, sps + 1, 4 * sps + 1}):
+        nodes = 0.1 * rng.standard_normal(nq)
+        weights = rng.random(nq)
+        shift = rng.standard_normal(Ntot) * 0.05
+        shift[0] = 0.0
+        ref = Oracle(p, use_sparse=False).eval_f_g_grad(pcof, nodes, weights, shift)
+        jq.eval_f_g_grad(pcof, p, wa, nodes, weights, True, shift=shift)
+        gref = ref["last_infidelity_grad"]
+        assert abs(p.last_infidelity - ref["last_infidelity"]) <= TOL * abs(ref["last_infidelity"])
+        assert abs(p.last_leak - ref["last_leak"]) <= TOL * max(abs(ref["last_leak"]), 1e-3)
+        assert np.linalg.norm(p.last_infidelity_grad - gref) <= TOL * np.linalg.norm(gref)
+        if oft != 1:
+            assert np.linalg.norm(p.last_leak_grad - ref["last_leak_grad"]) <= TOL * np.linalg.norm(gref)
+    wa.close()
