@@ -1,0 +1,413 @@
+// jq_coop_kernels.h -- "cooperative" (row-split) variants of the propagators for SMALL batches.
+//
+// The slab kernels of jq_kernels.h give one wave a whole 16-column slab: maximal MFMA efficiency, but one
+// evaluation is a chain of 72 * nsteps dependent products of NT*KT-band MFMAs each, and the time of an
+// ensemble evaluation is flat (cnot3: 4.9 s) until every wave of the chip has its own slab.  When there are
+// fewer slabs than that, these kernels split ONE slab over the NT waves of a workgroup instead: wave `mt`
+// owns tile row mt (16 rows) of every state array (a single d4 = 8 registers per array), computes its
+// rows of each product  D[mt] = C[mt] + sum_kb M[mt,kb] x[kb]  and publishes them to an LDS exchange buffer
+// from which all waves read the next product's B operands.  A product is then 4*NB MFMAs per wave
+// (NB = min(2*BW+1, NT) k-blocks; cnot3: 12 instead of 64) plus one workgroup barrier.
+//
+// Operator image layout ("row-window"): for tile row mt the NB k-blocks kb0(mt) .. kb0(mt)+NB-1,
+// kb0 = min(max(mt-BW, 0), NT-NB), 4 tiles each, rows consecutively.  Blocks inside the window but outside
+// the band are simply stored (they are zero).  Same math, schedule bit-fields, state file, tile stream
+// generator and reductions as the slab kernels.
+#pragma once
+#include "jq_kernels.h"
+
+__host__ __device__ constexpr int coop_nb(int NT, int BW) { return (2 * BW + 1 < NT) ? 2 * BW + 1 : NT; }
+__host__ __device__ constexpr int coop_kb0(int NT, int BW, int mt)
+{
+    const int nb = coop_nb(NT, BW);
+    int k = mt - BW;
+    if (k < 0) k = 0;
+    if (k > NT - nb) k = NT - nb;
+    return k;
+}
+__host__ __device__ constexpr int coop_tiles(int NT, int BW) { return NT * 4 * coop_nb(NT, BW); }
+
+// D = C + M[mt, window] * x[window]  (ZEROC: C = 0).  Mrow: my row's tiles in LDS (lane offset applied);
+// x: exchange buffer [4*NT][64] (lane offset applied), kb0 = first k-block of my window.
+template <int NT, int BW, bool ZEROC>
+__device__ __forceinline__ d4 cmm(const d4& C, const double* Mrow, const double* x, int kb0)
+{
+    constexpr int NTL = 4 * coop_nb(NT, BW);
+    const double* xs = x + (size_t)kb0 * 4 * 64;
+    double fa[JQ_PF], fb[JQ_PF];
+#pragma unroll
+    for (int i = 0; i < JQ_PF; ++i)
+        if (i < NTL) {
+            fa[i] = Mrow[i * 64];
+            fb[i] = xs[i * 64];
+        }
+    d4 acc = ZEROC ? (d4){0.0, 0.0, 0.0, 0.0} : C;
+#pragma unroll
+    for (int i = 0; i < NTL; ++i) {
+        const double a = fa[i % JQ_PF], b = fb[i % JQ_PF];
+        if (i + JQ_PF < NTL) {
+            fa[i % JQ_PF] = Mrow[(i + JQ_PF) * 64];
+            fb[i % JQ_PF] = xs[(i + JQ_PF) * 64];
+        }
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return acc;
+}
+
+// per-wave context of a cooperative workgroup
+template <int NT, int BW>
+struct Coop {
+    Ring ring;
+    double* xbuf;       // LDS exchange buffers [2][4*NT][64], lane offset applied
+    const double* M;    // current operator: my row's tiles (lane offset applied)
+    int xcur;           // buffer that holds the published x
+    int mt;             // my tile row
+    int kb0;
+    int row_off;        // doubles from the start of an operator image to my row's tiles
+
+    // write my rows of Z into the other exchange buffer (visible after the next barrier)
+    __device__ __forceinline__ void stage(const d4& Z)
+    {
+        double* w = xbuf + (size_t)(xcur ^ 1) * (4 * NT * 64) + (size_t)(4 * mt) * 64;
+        w[0] = Z[0];
+        w[64] = Z[1];
+        w[128] = Z[2];
+        w[192] = Z[3];
+    }
+    // publish the staged x for a product with the operator that is already resident
+    __device__ __forceinline__ void publish()
+    {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my ds_writes are done
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        xcur ^= 1;
+    }
+    // publish the staged x AND switch to the next operator use (one barrier for both)
+    __device__ __forceinline__ void publish_next_op()
+    {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        M = ring.next() + row_off;   // vmcnt(0) + barrier + prefetch inside
+        xcur ^= 1;
+    }
+    __device__ __forceinline__ void next_op() { M = ring.next() + row_off; }
+    __device__ __forceinline__ const double* x() const { return xbuf + (size_t)xcur * (4 * NT * 64); }
+    __device__ __forceinline__ d4 mm_z() const { return cmm<NT, BW, true>((d4){0, 0, 0, 0}, M, x(), kb0); }
+    __device__ __forceinline__ d4 mm_c(const d4& C) const { return cmm<NT, BW, false>(C, M, x(), kb0); }
+};
+
+// dst[lane] (+)= sum over the NT waves of val, summed in wave order by wave 0 (deterministic).
+// scratch: LDS [NT][64] doubles (lane offset NOT applied).  Contains workgroup barriers.
+template <int NT>
+__device__ __forceinline__ void wg_sum_store(double val, double* scratch, double* dst, int wave, int lane, bool accumulate)
+{
+    __syncthreads();
+    scratch[wave * 64 + lane] = val;
+    __syncthreads();
+    if (wave == 0) {
+        double s = accumulate ? dst[lane] : 0.0;
+        for (int w = 0; w < NT; ++w) s += scratch[w * 64 + lane];
+        dst[lane] = s;
+    }
+}
+
+// rows of this wave/lane: 16*mt + 4*r + g
+__device__ __forceinline__ d4 rows4(const double* tab, int mt, int g)
+{
+    return (d4){tab[16 * mt + g], tab[16 * mt + 4 + g], tab[16 * mt + 8 + g], tab[16 * mt + 12 + g]};
+}
+__device__ __forceinline__ double dot4(const d4& a, const d4& b)
+{
+    const d4 p = a * b;
+    return (p[0] + p[1]) + (p[2] + p[3]);
+}
+
+// out = bpa + sum_{j=1..m} S^j A with the resident operator S (Horner form, see jq_kernels.h); on entry
+// NOTHING needs to be published; on exit the exchange buffer holds an intermediate iterate.
+template <int NT, int BW>
+__device__ __forceinline__ d4 coop_horner(Coop<NT, BW>& c, const d4& bpa, const d4& A, int m)
+{
+    if (m <= 0) return bpa;
+    d4 Y = A;
+    for (int j = 1; j < m; ++j) {
+        c.stage(Y);
+        c.publish();
+        Y = c.mm_c(A);
+    }
+    c.stage(Y);
+    c.publish();
+    return c.mm_c(bpa);
+}
+
+// State (re-)integration: uses 0..5 of a step in the cooperative schedule Kp05 S05 Kn0 Kn1 S0 S1 (Kp05).
+//   in: u, v (my rows)   out: un = u(t+h), v05, vN = v05 + S05 v05 (caller adds Kp05 un with use 6)
+template <int NT, int BW>
+__device__ __forceinline__ void coop_state(Coop<NT, BW>& c, const PropArgs& a, double ceps, const d4& wsr, const d4& u,
+                                           const d4& v, d4& un, d4& v05, d4& vN)
+{
+    // use 0: Kp05 -- A = c K05 u
+    c.stage(u);
+    c.publish_next_op();
+    d4 A = c.mm_z();
+    if (a.use_shift) A += (ceps * wsr) * u;
+    // use 1: S05 -- A = c (K05 u + S05 v) ; v05 = v + sum_j S^j A ; vN = v05 + S05 v05
+    c.stage(v);
+    c.publish_next_op();
+    A = c.mm_c(A);
+    v05 = coop_horner<NT, BW>(c, v + A, A, a.m);
+    c.stage(v05);
+    c.publish();
+    vN = c.mm_c(v05);
+    // use 2: Kn0 -- un = u - c K0 v05      (x = v05 stays published)
+    c.next_op();
+    un = c.mm_c(u);
+    if (a.use_shift) un -= (ceps * wsr) * v05;
+    // use 3: Kn1 -- A = -c K1 v05
+    c.next_op();
+    A = c.mm_z();
+    if (a.use_shift) A -= (ceps * wsr) * v05;
+    // use 4: S0 -- un = u + c (S0 u - K0 v05)
+    c.stage(u);
+    c.publish_next_op();
+    un = c.mm_c(un);
+    // use 5: S1 -- A = c (S1 un - K1 v05) ; un += sum_j S^j A
+    c.stage(un);
+    c.publish_next_op();
+    A = c.mm_c(A);
+    un = coop_horner<NT, BW>(c, un + A, A, a.m);
+}
+
+template <int NT, int BW>
+__device__ __forceinline__ void coop_setup(Coop<NT, BW>& c, char* smem, const PropArgs& a, int wave, int lane)
+{
+    c.ring.init(smem, a, wave, lane, NT);
+    c.xbuf = (double*)(smem + a.lds_tab_off) + 32 * NT + lane;
+    c.xcur = 0;
+    c.mt = wave;
+    c.kb0 = coop_kb0(NT, BW, 0);
+    // kb0 and the row offset depend on the (wave-uniform) tile row
+    int k = wave - BW;
+    if (k < 0) k = 0;
+    if (k > NT - coop_nb(NT, BW)) k = NT - coop_nb(NT, BW);
+    c.kb0 = k;
+    c.row_off = wave * 4 * coop_nb(NT, BW) * 64;
+    c.M = nullptr;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Forward sweep, one slab per workgroup of NT waves.
+template <int NT, int BW>
+__global__ __launch_bounds__(64 * NT) void k_forward_coop(PropArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KT = 4 * NT;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4;
+    const int slab = blockIdx.x;
+
+    double* tab = (double*)(smem + a.lds_tab_off);
+    for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[i] = a.tabs[i];
+    Coop<NT, BW> c;
+    coop_setup(c, smem, a, wave, lane);
+    __syncthreads();
+    const d4 wdr = rows4(tab, wave, g), wsr = rows4(tab + 16 * NT, wave, g);
+
+    double* st = a.state + (size_t)slab * a.state_stride;
+    d4 u, v;
+    for (int r = 0; r < 4; ++r) {
+        u[r] = st[(4 * wave + r) * 64 + lane];
+        v[r] = st[(KT + 4 * wave + r) * 64 + lane];
+    }
+    // leak partials: one value per (wave, lane); the state file row holds 64 per slab, so the waves'
+    // partials are combined (in wave order) at the end of the chunk
+    double leak = 0.0;
+    const double ceps = 0.5 * a.h * a.colinfo[(size_t)slab * 32 + (lane & 15)];
+
+    for (int n = 0; n < a.nsteps_chunk; ++n) {
+        d4 un, v05, vN;
+        leak += dot4(wdr, u * u);  // trapezoidal part at t_n (src/evalobjgrad.jl:700)
+        coop_state<NT, BW>(c, a, ceps, wsr, u, v, un, v05, vN);
+        // use 6: Kp05 -- v(t+h) = v05 + c (K05 u_new + S05 v05)
+        c.stage(un);
+        c.publish_next_op();
+        v = c.mm_c(vN);
+        if (a.use_shift) v += (ceps * wsr) * un;
+        u = un;
+        leak += dot4(wdr, u * u) + 2.0 * dot4(wdr, v05 * v05);  // (:716, penalf2a :2170-2180)
+        if (a.hist_r) {
+            const int col = lane & 15;
+            if (slab == 0 && col < a.N) {
+                const size_t off = (size_t)(a.step0 + n + 1) * a.Ntot * a.N + (size_t)col * a.Ntot;
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * wave + 4 * r + g;
+                    if (row < a.Ntot) {
+                        a.hist_r[off + row] = u[r];
+                        a.hist_i[off + row] = -v[r];
+                    }
+                }
+            }
+        }
+    }
+    c.ring.drain();
+    for (int r = 0; r < 4; ++r) {
+        st[(4 * wave + r) * 64 + lane] = u[r];
+        st[(KT + 4 * wave + r) * 64 + lane] = v[r];
+    }
+    wg_sum_store<NT>(leak, tab + 32 * NT, &st[(JQ_STATE_ARRAYS * KT + JQ_MAXNC) * 64], wave, lane, true);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward sweep, one slab per workgroup of NT waves.  Cooperative schedule (period 13 + 3*Ncoupled):
+//   Kp05 S05 Kn0 Kn1 S0 S1 Kp05 | S0 | Hanti_q.. | Kn0 Kn1 S05 Kp05 S1 | (Hanti_q Hsym_q)..
+// Trace scalars are written per wave: traces[(slab*NT + wave)][step][Ncoupled*JQ_NTR] (k_trace_reduce sums).
+template <int NT, int BW>
+__global__ __launch_bounds__(64 * NT) void k_backward_coop(PropArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KT = 4 * NT;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4;
+    const int slab = blockIdx.x;
+    const int Nc = a.Ncoupled;
+
+    double* tab = (double*)(smem + a.lds_tab_off);
+    for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[i] = a.tabs[i];
+    Coop<NT, BW> c;
+    coop_setup(c, smem, a, wave, lane);
+    __syncthreads();
+    const d4 wdr = rows4(tab, wave, g), wsr = rows4(tab + 16 * NT, wave, g);
+
+    double* st = a.state + (size_t)slab * a.state_stride;
+    d4 u, v, mu, nb;
+    for (int r = 0; r < 4; ++r) {
+        u[r] = st[(4 * wave + r) * 64 + lane];
+        v[r] = st[(KT + 4 * wave + r) * 64 + lane];
+        mu[r] = st[(2 * KT + 4 * wave + r) * 64 + lane];
+        nb[r] = st[(3 * KT + 4 * wave + r) * 64 + lane];
+    }
+    const double ceps = 0.5 * a.h * a.colinfo[(size_t)slab * 32 + (lane & 15)];
+    const double wgt = a.colinfo[(size_t)slab * 32 + 16 + (lane & 15)];
+    const double cfw = a.forced ? 0.5 * a.h * a.tinv : 0.0;
+    // one file row of 64 per control holds the slab total of the trace carry; each wave keeps its own partial
+    // in a register (total/NT at load; the waves' partials are summed in wave order at the end of the chunk)
+    double carry[JQ_MAXNC];
+    for (int q = 0; q < JQ_MAXNC; ++q) carry[q] = (q < Nc) ? st[(JQ_STATE_ARRAYS * KT + q) * 64 + lane] / NT : 0.0;
+    double* trw = a.traces + ((size_t)(slab * NT + wave) * a.nsteps_chunk) * (Nc * JQ_NTR);
+
+    if (a.first_chunk) {
+        // carry_q = tr(vr' Hsym_q lambdai) at t = T (see k_backward)
+        c.stage(nb);
+        for (int q = 0; q < JQ_MAXNC; ++q) {
+            if (q < Nc) {
+                if (q == 0)
+                    c.publish_next_op();
+                else
+                    c.next_op();
+                carry[q] = -dot4(u, c.mm_z());   // nb = -lambda_i
+            }
+        }
+    }
+
+    for (int n = 0; n < a.nsteps_chunk; ++n) {
+        d4 un, v05, vN;
+        coop_state<NT, BW>(c, a, ceps, wsr, u, v, un, v05, vN);
+        // use 6: Kp05 -- finish the state step; R = c K05 nb
+        c.stage(un);
+        c.publish_next_op();
+        vN = c.mm_c(vN);
+        if (a.use_shift) vN += (ceps * wsr) * un;
+        c.stage(nb);
+        c.publish();
+        d4 R = c.mm_z();
+        if (a.use_shift) R += (ceps * wsr) * nb;
+        // use 7: S0 -- R = c (S0 mu - K05 li + hr0) ; X = mu + sum_j S^j R
+        c.stage(mu);
+        c.publish_next_op();
+        R = c.mm_c(R);
+        R += (cfw * wdr) * u;
+        const d4 X = coop_horner<NT, BW>(c, mu + R, R, a.m);
+        // early traces with X: tr1 = tr(vr0' Hanti_q X), tr3 = tr(vr' Hanti_q X)
+        c.stage(X);
+        for (int q = 0; q < JQ_MAXNC; ++q) {
+            if (q < Nc) {
+                if (q == 0)
+                    c.publish_next_op();
+                else
+                    c.next_op();
+                const d4 Tq = c.mm_z();
+                const double t1 = wave_sum(dot4(u, Tq) * wgt), t3 = wave_sum(dot4(un, Tq) * wgt);
+                if (lane == 0) {
+                    trw[(size_t)n * (Nc * JQ_NTR) + q * JQ_NTR + 0] = t1;
+                    trw[(size_t)n * (Nc * JQ_NTR) + q * JQ_NTR + 2] = t3;
+                }
+            }
+        }
+        // use 8: Kn0 -- L = -c K0 X ; use 9: Kn1 -- Q = -c K1 X       (x = X stays published)
+        c.next_op();
+        d4 L = c.mm_z();
+        if (a.use_shift) L -= (ceps * wsr) * X;
+        c.next_op();
+        d4 Qv = c.mm_z();
+        if (a.use_shift) Qv -= (ceps * wsr) * X;
+        // use 10: S05 -- L = -c l2 ; Q = -c (...) ; nb_new = nb + L + sum_j S^j Q
+        c.stage(nb);
+        c.publish_next_op();
+        {
+            d4 P = c.mm_z();
+            P -= (cfw * wdr) * v05;
+            L += P;
+            Qv += P;
+        }
+        c.stage(L);
+        c.publish();
+        Qv = c.mm_c(Qv);
+        const d4 nbn = coop_horner<NT, BW>(c, (nb + L) + Qv, Qv, a.m);
+        const d4 Bq = nb + nbn;   // -(li0 + li)
+        // use 11: Kp05 -- G = X + c K05 nb_new
+        c.stage(nbn);
+        c.publish_next_op();
+        d4 G = c.mm_c(X);
+        if (a.use_shift) G += (ceps * wsr) * nbn;
+        // use 12: S1 -- lambda_r_new = X + c (S1 X - K05 li_new + hr1)
+        c.stage(X);
+        c.publish_next_op();
+        G = c.mm_c(G);
+        G += (cfw * wdr) * un;
+        // late traces: tr5 = tr(vi05' Hanti (li0+li)), tr2 = tr(vi05' Hsym X), tr4 = tr(vr' Hsym li) + carry
+        for (int q = 0; q < JQ_MAXNC; ++q) {
+            if (q < Nc) {
+                c.stage(Bq);
+                c.publish_next_op();   // Hanti_q
+                const double t5 = wave_sum(-dot4(v05, c.mm_z()) * wgt);
+                c.stage(X);
+                c.publish_next_op();   // Hsym_q
+                const double t2 = wave_sum(dot4(v05, c.mm_z()) * wgt);
+                c.stage(nbn);
+                c.publish();
+                const double p4 = -dot4(un, c.mm_z());
+                const double t4 = wave_sum((p4 + carry[q]) * wgt);
+                carry[q] = p4;
+                if (lane == 0) {
+                    trw[(size_t)n * (Nc * JQ_NTR) + q * JQ_NTR + 1] = t2;
+                    trw[(size_t)n * (Nc * JQ_NTR) + q * JQ_NTR + 3] = t4;
+                    trw[(size_t)n * (Nc * JQ_NTR) + q * JQ_NTR + 4] = t5;
+                }
+            }
+        }
+        u = un;
+        v = vN;
+        mu = G;
+        nb = nbn;
+    }
+    c.ring.drain();
+    for (int r = 0; r < 4; ++r) {
+        st[(4 * wave + r) * 64 + lane] = u[r];
+        st[(KT + 4 * wave + r) * 64 + lane] = v[r];
+        st[(2 * KT + 4 * wave + r) * 64 + lane] = mu[r];
+        st[(3 * KT + 4 * wave + r) * 64 + lane] = nb[r];
+    }
+    for (int q = 0; q < JQ_MAXNC; ++q)
+        if (q < Nc) wg_sum_store<NT>(carry[q], tab + 32 * NT, &st[(JQ_STATE_ARRAYS * KT + q) * 64], wave, lane, false);
+}

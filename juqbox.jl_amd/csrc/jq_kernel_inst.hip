@@ -1,9 +1,16 @@
-// One translation unit per (NT, BW, solver) instantiation of the propagator kernels (parallel builds, and
+// One translation unit per (NT, BW, variant) instantiation of the propagator kernels (parallel builds, and
 // the MFMA register form can be chosen per instantiation -- see Makefile).
-#include "jq_kernels.h"
-#if !defined(JQ_NT) || !defined(JQ_BW) || !defined(JQ_JAC)
-#error "compile with -DJQ_NT=<tiles> -DJQ_BW=<band> -DJQ_JAC=<0|1>"
+//   JQ_VARIANT 0: slab kernels, Neumann   1: slab kernels, Jacobi   2: cooperative (row-split) kernels
+#if !defined(JQ_NT) || !defined(JQ_BW) || !defined(JQ_VARIANT)
+#error "compile with -DJQ_NT=<tiles> -DJQ_BW=<band> -DJQ_VARIANT=<0|1|2>"
 #endif
+#if JQ_VARIANT == 2
+#include "jq_coop_kernels.h"
+template __global__ void k_forward_coop<JQ_NT, JQ_BW>(PropArgs);
+template __global__ void k_backward_coop<JQ_NT, JQ_BW>(PropArgs);
+#else
+#include "jq_kernels.h"
 #define JQ_MINW ((JQ_NT <= 2) ? 2 : 1)
-template __global__ void k_forward<JQ_NT, JQ_BW, JQ_MINW, (JQ_JAC != 0)>(PropArgs);
-template __global__ void k_backward<JQ_NT, JQ_BW, JQ_MINW, (JQ_JAC != 0)>(PropArgs);
+template __global__ void k_forward<JQ_NT, JQ_BW, JQ_MINW, (JQ_VARIANT == 1)>(PropArgs);
+template __global__ void k_backward<JQ_NT, JQ_BW, JQ_MINW, (JQ_VARIANT == 1)>(PropArgs);
+#endif

@@ -327,7 +327,7 @@ struct Ring {
     int Q;            // index of the operator use that comes next
     int Qp;           // per-operator mode: index of the next operator use to prefetch
     int np, ip;       // (step, position) cursor: of Qp (per-operator mode) or of Q (batched mode)
-    int wave, lane;
+    int wave, lane, nwaves;
 
     __device__ __forceinline__ unsigned lane_off16() const
     {
@@ -339,7 +339,7 @@ struct Ring {
     __device__ __forceinline__ void dma(const double* gsrc, char* dst, int pieces) const
     {
         const char* src = (const char*)gsrc + lane_off16();
-        for (int p = wave; p < pieces; p += JQ_WAVES)
+        for (int p = wave; p < pieces; p += nwaves)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)p * 1024),
                                              (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
     }
@@ -406,9 +406,10 @@ struct Ring {
             issue_batch(n / batch + 1);
         }
     }
-    __device__ __forceinline__ void init(char* smem_, const PropArgs& a, int wave_, int lane_)
+    __device__ __forceinline__ void init(char* smem_, const PropArgs& a, int wave_, int lane_, int nwaves_ = JQ_WAVES)
     {
         smem = smem_;
+        nwaves = nwaves_;
         stream = a.stream;
         cimg = a.cimg;
         sb0 = a.sched_bits[0];

@@ -7,6 +7,7 @@
 // runs in order on the handle's HIP stream; the call returns after one stream synchronisation.
 #include "../../include/juqbox_hip.h"
 #include "jq_aux_kernels.h"
+#include "jq_coop_kernels.h"
 #include "jq_kernels.h"
 
 #include <algorithm>
@@ -33,6 +34,8 @@ struct jq_handle {
     int BW = 0;                 // block band width the kernels are instantiated for
     int bw_trace[JQ_MAXNC] = {0, 0, 0, 0};
     long long mat_elems = 0;    // doubles per operator image slot ("stride"): band tiles, padded to 1 KiB
+    long long mat_elems_c = 0;  // ... in the row-window layout of the cooperative kernels (0: not available)
+    int coop_max_slabs = 256;   // batches with at most this many slabs (= CUs: one workgroup each) use the cooperative kernels
     long long state_stride = 0;
     int nslots = 2;             // LDS ring depth of the forward kernel
     int nslots_bwd = 2;         // ... of the backward kernel (shares LDS with carry + parking images)
@@ -42,6 +45,7 @@ struct jq_handle {
     std::vector<double> tf, tb;
     // device buffers (owned)
     double *d_cimg = nullptr, *d_park = nullptr;
+    double *d_himg_c = nullptr, *d_cimg_c = nullptr;   // operator images in the cooperative layout
     double *d_himg = nullptr, *d_uimg = nullptr, *d_vtr = nullptr, *d_vti = nullptr, *d_tabs = nullptr;
     double *d_tf = nullptr, *d_tb = nullptr, *d_cfreq = nullptr, *d_pcof = nullptr;
     double *d_stream = nullptr, *d_pq = nullptr;
@@ -88,6 +92,26 @@ static void tile_image(const double* M, int Ntot, int NT, int BW, double* img, b
             }
             ++idx;
         }
+}
+
+// Row-window layout of the cooperative kernels (jq_coop_kernels.h): for tile row mt the NB k-blocks
+// kb0(mt)..kb0(mt)+NB-1, 4 tiles each, rows consecutively.
+static void tile_image_coop(const double* M, int Ntot, int NT, int BW, double* img)
+{
+    const int NB = coop_nb(NT, BW);
+    size_t idx = 0;
+    for (int mt = 0; mt < NT; ++mt) {
+        const int kb0 = coop_kb0(NT, BW, mt);
+        for (int j = 0; j < NB; ++j)
+            for (int r = 0; r < 4; ++r) {
+                const int kk = 4 * (kb0 + j) + r;
+                for (int l = 0; l < 64; ++l) {
+                    const int row = 16 * mt + (l & 15), col = 4 * kk + (l >> 4);
+                    img[idx * 64 + l] = (row < Ntot && col < Ntot) ? M[row + (size_t)Ntot * col] : 0.0;
+                }
+                ++idx;
+            }
+    }
 }
 
 // true if every diagonal 16x16 block of M is zero
@@ -150,6 +174,18 @@ static int upload_operators(jq_handle* h)
         tile_image(h->Hanti.data() + q * nn, h->Ntot, h->NT, bwq, cimg.data() + (size_t)(h->Nc + q) * h->mat_elems, sd);
     }
     HIPCHK(h, hipMemcpy(h->d_cimg, cimg.data(), cimg.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (h->mat_elems_c > 0) {
+        std::vector<double> ic((size_t)(1 + 2 * h->Nc) * h->mat_elems_c, 0.0);
+        tile_image_coop(h->Hconst.data(), h->Ntot, h->NT, h->BW, ic.data());
+        for (int q = 0; q < h->Nc; ++q) {
+            tile_image_coop(h->Hsym.data() + q * nn, h->Ntot, h->NT, h->BW, ic.data() + (size_t)(1 + q) * h->mat_elems_c);
+            tile_image_coop(h->Hanti.data() + q * nn, h->Ntot, h->NT, h->BW, ic.data() + (size_t)(1 + h->Nc + q) * h->mat_elems_c);
+        }
+        HIPCHK(h, hipMemcpy(h->d_himg_c, ic.data(), ic.size() * sizeof(double), hipMemcpyHostToDevice));
+        // trace images [Hsym_q | Hanti_q] = images 1.. of the same array
+        HIPCHK(h, hipMemcpy(h->d_cimg_c, ic.data() + h->mat_elems_c, (size_t)2 * h->Nc * h->mat_elems_c * sizeof(double),
+                            hipMemcpyHostToDevice));
+    }
     return JQ_OK;
 }
 
@@ -180,7 +216,7 @@ extern "C" void jq_destroy(jq_handle* h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    double** bufs[] = {&h->d_park, &h->d_cimg, &h->d_himg,  &h->d_uimg,       &h->d_vtr,     &h->d_vti,    &h->d_tabs, &h->d_tf,   &h->d_tb,
+    double** bufs[] = {&h->d_himg_c, &h->d_cimg_c, &h->d_park, &h->d_cimg, &h->d_himg,  &h->d_uimg,       &h->d_vtr,     &h->d_vti,    &h->d_tabs, &h->d_tf,   &h->d_tb,
                        &h->d_cfreq, &h->d_pcof,       &h->d_stream,  &h->d_pq,     &h->d_state, &h->d_state_save,
                        &h->d_colinfo, &h->d_traces,   &h->d_R,       &h->d_grad,   &h->d_res};
     for (auto b : bufs)
@@ -264,6 +300,15 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         h->nslots = 2;
         h->nslots_bwd = 2;
         h->park_lds = (2 * slot + lds_bwd_fixed + park_bytes <= 163840) ? 1 : 0;
+        // cooperative (row-split) kernels for small batches: NT waves per slab, needs NT >= 2
+        h->mat_elems_c = 0;
+        if (h->NT >= 2) {
+            const long long ec = ((64LL * coop_tiles(h->NT, h->BW) + 127) / 128) * 128;
+            const long long lds_c = 2 * ec * 8 + lds_fwd_fixed + 2LL * h->KT * 64 * 8;
+            if (lds_c <= 163840) h->mat_elems_c = ec;
+        }
+        h->coop_max_slabs = prop.multiProcessorCount;   // one cooperative workgroup per CU = one round
+        if (const char* e = getenv("JQ_COOP_MAX")) h->coop_max_slabs = atoi(e);
         // Batched staging (K/S images of B time steps per DMA burst, constants resident in LDS) exists for
         // small images but is OFF by default: measured on MI355X it does not help (swap02/cnot2: the
         // ~600-cycle dependent-product latency dominates, not the per-operator barrier) and its 150 KB of
@@ -303,6 +348,10 @@ static int create_impl(const jq_problem* p, jq_handle* h)
     int rc;
     if ((rc = dev_alloc(h, &h->d_himg, (size_t)(1 + 2 * h->Nc) * h->mat_elems))) return rc;
     if ((rc = dev_alloc(h, &h->d_cimg, (size_t)(2 * h->Nc) * h->mat_elems))) return rc;
+    if (h->mat_elems_c > 0) {
+        if ((rc = dev_alloc(h, &h->d_himg_c, (size_t)(1 + 2 * h->Nc) * h->mat_elems_c))) return rc;
+        if ((rc = dev_alloc(h, &h->d_cimg_c, (size_t)(2 * h->Nc) * h->mat_elems_c))) return rc;
+    }
     if ((rc = dev_alloc(h, &h->d_uimg, (size_t)h->KT * 64))) return rc;
     if ((rc = dev_alloc(h, &h->d_vtr, (size_t)h->KT * 64))) return rc;
     if ((rc = dev_alloc(h, &h->d_vti, (size_t)h->KT * 64))) return rc;
@@ -327,7 +376,7 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         const long long v = atoll(e);
         if (v > 0) budget = (size_t)v;
     }
-    const size_t per_tp = 2 * (size_t)h->mat_elems * sizeof(double);
+    const size_t per_tp = 2 * (size_t)std::max(h->mat_elems, h->mat_elems_c) * sizeof(double);
     long long cs = ((long long)(budget / per_tp) - 1) / 2;
     cs = std::max<long long>(1, std::min<long long>(cs, h->nsteps));
     if (const char* e = getenv("JQ_CHUNK_STEPS")) {
@@ -335,7 +384,7 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         if (v > 0) cs = std::min<long long>(v, h->nsteps);
     }
     h->chunk_steps = (int)cs;
-    if ((rc = dev_alloc(h, &h->d_stream, (size_t)(2 * cs + 1) * 2 * h->mat_elems))) return rc;
+    if ((rc = dev_alloc(h, &h->d_stream, (size_t)(2 * cs + 1) * 2 * std::max(h->mat_elems, h->mat_elems_c)))) return rc;
     if ((rc = dev_alloc(h, &h->d_pq, (size_t)(2 * cs + 1) * 2 * h->Nc))) return rc;
     if ((rc = dev_alloc(h, &h->d_R, (size_t)cs * h->Nc * JQ_NTR))) return rc;
     return JQ_OK;
@@ -447,6 +496,28 @@ static int select_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
     return fail(h, JQ_EUNSUPPORTED, "unsupported Hilbert dimension / band width");
 }
 
+#define JQ_DECLC(nt, bw)                                                   \
+    extern template __global__ void k_forward_coop<nt, bw>(PropArgs);       \
+    extern template __global__ void k_backward_coop<nt, bw>(PropArgs);
+#define JQ_FOR_EACH_COOP(X)                                                                               \
+    X(2, 0) X(2, 1) X(3, 0) X(3, 1) X(3, 2) X(4, 0) X(4, 1) X(4, 2) X(4, 3) X(5, 0) X(5, 1) X(5, 2) X(5, 4) \
+    X(6, 0) X(6, 1) X(6, 2) X(6, 5)
+JQ_FOR_EACH_COOP(JQ_DECLC)
+#undef JQ_DECLC
+
+static int select_coop_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
+{
+#define JQ_PICKC(nt, bw)                      \
+    if (h->NT == nt && h->BW == bw) {         \
+        *fwd = k_forward_coop<nt, bw>;        \
+        *bwd = k_backward_coop<nt, bw>;       \
+        return JQ_OK;                         \
+    }
+    JQ_FOR_EACH_COOP(JQ_PICKC)
+#undef JQ_PICKC
+    return fail(h, JQ_EUNSUPPORTED, "no cooperative kernel for this Hilbert dimension / band width");
+}
+
 struct EvalOut {
     std::vector<double> res;    // [nsamples][4] primary, secondary, Re s, Im s
     std::vector<double> grad0;  // forced adjoint (total gradient), weighted sum over samples
@@ -472,12 +543,18 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     if (D1 < 3) return fail(h, JQ_EINVAL, "need at least 3 B-spline coefficients per control function");
     if (nsamples < 1) return fail(h, JQ_EINVAL, "need at least one sample");
 
-    prop_kernel_t kfwd, kbwd;
-    int rc = select_kernels(h, &kfwd, &kbwd);
-    if (rc) return rc;
-
     const int nslabs = (nsamples + h->sps - 1) / h->sps;
-    const int nblocks = (nslabs + JQ_WAVES - 1) / JQ_WAVES;
+    // small batches: cooperative (row-split) kernels, one workgroup of NT waves per slab; large batches: slab
+    // kernels, one wave per slab (jq_coop_kernels.h explains the trade-off)
+    const bool coop = h->mat_elems_c > 0 && h->solver_id == 1 && nslabs <= h->coop_max_slabs;
+    prop_kernel_t kfwd, kbwd;
+    int rc = coop ? select_coop_kernels(h, &kfwd, &kbwd) : select_kernels(h, &kfwd, &kbwd);
+    if (rc) return rc;
+    const int nblocks = coop ? nslabs : (nslabs + JQ_WAVES - 1) / JQ_WAVES;
+    const int nthreads = coop ? 64 * h->NT : 256;
+    const int trace_rows = coop ? nslabs * h->NT : nslabs;   // per-step trace records: one per wave
+    const long long stride = coop ? h->mat_elems_c : h->mat_elems;
+    const double* himg = coop ? h->d_himg_c : h->d_himg;
     const int cs = h->chunk_steps;
     const int ntr = h->Nc * JQ_NTR;
     const bool two_pass = adjoint && h->objFuncType != 1;
@@ -495,9 +572,9 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
         h->cap_slabs = nslabs;
         h->cap_traces = 0;
     }
-    if (adjoint && (size_t)nslabs * cs * ntr > h->cap_traces) {
-        if ((rc = dev_alloc(h, &h->d_traces, (size_t)nslabs * cs * ntr))) return rc;
-        h->cap_traces = (size_t)nslabs * cs * ntr;
+    if (adjoint && (size_t)trace_rows * cs * ntr > h->cap_traces) {
+        if ((rc = dev_alloc(h, &h->d_traces, (size_t)trace_rows * cs * ntr))) return rc;
+        h->cap_traces = (size_t)trace_rows * cs * ntr;
     }
     if ((size_t)2 * ncoeff > h->cap_grad) {
         if ((rc = dev_alloc(h, &h->d_grad, (size_t)2 * ncoeff))) return rc;
@@ -539,18 +616,22 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     const double dt = h->T / h->nsteps;
     PropArgs a;
     memset(&a, 0, sizeof a);
-    a.stream = h->d_stream; a.cimg = h->d_cimg; a.state = h->d_state; a.colinfo = h->d_colinfo; a.traces = h->d_traces;
-    a.tabs = h->d_tabs; a.stride = h->mat_elems; a.pieces = (int)(h->mat_elems * 8 / 1024); a.nslots = h->nslots; a.m = h->m;
+    a.stream = h->d_stream; a.cimg = coop ? h->d_cimg_c : h->d_cimg; a.state = h->d_state; a.colinfo = h->d_colinfo;
+    a.traces = h->d_traces;
+    a.tabs = h->d_tabs; a.stride = stride; a.pieces = (int)(stride * 8 / 1024); a.nslots = h->nslots; a.m = h->m;
     a.nslabs = nslabs; a.Ncoupled = h->Nc; a.Ntot = h->Ntot; a.N = h->N; a.use_shift = use_shift ? 1 : 0;
     a.tinv = 1.0 / h->T; a.state_stride = h->state_stride;
     a.jacobi_tol2 = (h->solver_id == 2) ? h->solver_tol * h->solver_tol : 0.0;
     for (int q = 0; q < JQ_MAXNC; ++q) a.bw_trace[q] = h->bw_trace[q];
     // dynamic LDS layout: [operator staging | tables wd, ws | (backward: carry, parking images)]
-    const size_t lds_stage = h->batch > 0 ? (size_t)2 * (2 * h->batch + 1) * 2 * h->mat_elems * 8 + (size_t)2 * h->Nc * h->mat_elems * 8
-                                          : (size_t)2 * h->mat_elems * 8;
-    const size_t lds_fwd = lds_stage + (size_t)32 * h->NT * 8;
-    const size_t lds_bwd = lds_fwd + (size_t)JQ_MAXNC * 256 * 8 + (h->park_lds ? (size_t)JQ_WAVES * h->KT * 64 * 8 : 0);
-    a.batch = h->batch; a.lds_tab_off = (int)lds_stage;
+    // cooperative kernels: [two operator slots | tables wd, ws | two x exchange buffers]
+    const int batch = coop ? 0 : h->batch;
+    const size_t lds_stage = batch > 0 ? (size_t)2 * (2 * batch + 1) * 2 * stride * 8 + (size_t)2 * h->Nc * stride * 8
+                                       : (size_t)2 * stride * 8;
+    const size_t lds_fwd = lds_stage + (size_t)32 * h->NT * 8 + (coop ? (size_t)2 * h->KT * 64 * 8 : 0);
+    const size_t lds_bwd = coop ? lds_fwd
+                                : lds_fwd + (size_t)JQ_MAXNC * 256 * 8 + (h->park_lds ? (size_t)JQ_WAVES * h->KT * 64 * 8 : 0);
+    a.batch = batch; a.lds_tab_off = (int)lds_stage;
     a.park = h->d_park; a.park_lds = h->park_lds;
     if (const char* e = getenv("JQ_DEBUG")) a.debug = atoi(e);
     HIPCHK(h, hipFuncSetAttribute((const void*)kfwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fwd));
@@ -570,27 +651,31 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     hipLaunchKernelGGL(k_init_state, dim3(nslabs), dim3(64), 0, s, h->d_state, h->state_stride, h->d_uimg, h->KT);
 
     long long mfma = 0;
-    const long long tiles = band_tiles(h->NT, h->BW);
+    const long long tiles = coop ? coop_tiles(h->NT, h->BW) : band_tiles(h->NT, h->BW);
     long long trace_tiles = 0;
     for (int q = 0; q < h->Nc; ++q)
-        trace_tiles += band_tiles(h->NT, h->bw_trace[q] == 0 ? 0 : h->BW, h->bw_trace[q] == 2);
+        trace_tiles += coop ? coop_tiles(h->NT, h->BW) : band_tiles(h->NT, h->bw_trace[q] == 0 ? 0 : h->BW, h->bw_trace[q] == 2);
     // ---- forward sweep -------------------------------------------------------------------------
     for (int n0 = 0; n0 < h->nsteps; n0 += cs) {
         const int nc = std::min(cs, h->nsteps - n0);
         const int ntp = 2 * nc + 1;
         hipLaunchKernelGGL(k_ctrl, dim3((ntp + 127) / 128), dim3(128), 0, s, sp, h->d_tf, n0, ntp, dt, h->d_pq);
-        hipLaunchKernelGGL(k_stream, dim3((unsigned)((h->mat_elems + 255) / 256), ntp), dim3(256), 0, s, h->d_himg, h->d_pq,
-                           h->Nc, h->mat_elems, 0.5 * dt, h->d_stream);
+        hipLaunchKernelGGL(k_stream, dim3((unsigned)((stride + 255) / 256), ntp), dim3(256), 0, s, himg, h->d_pq,
+                           h->Nc, stride, 0.5 * dt, h->d_stream);
         a.nsteps_chunk = nc; a.step0 = n0; a.first_chunk = (n0 == 0); a.h = dt; a.forced = 1;
         a.hist_r = hist_r; a.hist_i = hist_i;
         a.period = 7; a.npro = 0; a.nslots = h->nslots;
-        {   // Kp05 S05 Kn0 S0 Kn1 S1 Kp05     {kind (0 K, 1 S, 2 constant image), time point offset / image index}
-            const int kinds[7] = {0, 1, 0, 1, 0, 1, 0}, tps[7] = {1, 1, 0, 0, 2, 2, 1};
+        {   // slab kernels: Kp05 S05 Kn0 S0 Kn1 S1 Kp05 ; cooperative kernels: Kp05 S05 Kn0 Kn1 S0 S1 Kp05
+            // {kind (0 K, 1 S, 2 constant image), time point offset / image index}
+            const int kinds_s[7] = {0, 1, 0, 1, 0, 1, 0}, tps_s[7] = {1, 1, 0, 0, 2, 2, 1};
+            const int kinds_c[7] = {0, 1, 0, 0, 1, 1, 0}, tps_c[7] = {1, 1, 0, 2, 0, 2, 1};
+            const int* kinds = coop ? kinds_c : kinds_s;
+            const int* tps = coop ? tps_c : tps_s;
             a.sched_bits[0] = a.sched_bits[1] = a.sched_bits[2] = a.pro_bits = 0;
             for (int i = 0; i < 7; ++i) sched_pack(a.sched_bits, i, kinds[i], tps[i]);
         }
         HIPCHK(h, hipEventRecord(h->ev[evi++], s));
-        hipLaunchKernelGGL(kfwd, dim3(nblocks), dim3(256), lds_fwd, s, a);
+        hipLaunchKernelGGL(kfwd, dim3(nblocks), dim3(nthreads), lds_fwd, s, a);
         HIPCHK(h, hipEventRecord(h->ev[evi++], s));
         mfma += (long long)nslabs * nc * (8 + 2 * h->m) * tiles;
     }
@@ -612,13 +697,16 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
                 const int nc = std::min(cs, h->nsteps - n0);
                 const int ntp = 2 * nc + 1;
                 hipLaunchKernelGGL(k_ctrl, dim3((ntp + 127) / 128), dim3(128), 0, s, sp, h->d_tb, n0, ntp, -dt, h->d_pq);
-                hipLaunchKernelGGL(k_stream, dim3((unsigned)((h->mat_elems + 255) / 256), ntp), dim3(256), 0, s, h->d_himg,
-                                   h->d_pq, h->Nc, h->mat_elems, -0.5 * dt, h->d_stream);
+                hipLaunchKernelGGL(k_stream, dim3((unsigned)((stride + 255) / 256), ntp), dim3(256), 0, s, himg,
+                                   h->d_pq, h->Nc, stride, -0.5 * dt, h->d_stream);
                 a.nsteps_chunk = nc; a.step0 = n0; a.first_chunk = (n0 == 0); a.h = -dt; a.forced = (pass == 0);
                 a.hist_r = nullptr; a.hist_i = nullptr;
                 a.period = 13 + 3 * h->Nc; a.npro = (n0 == 0) ? h->Nc : 0; a.nslots = h->nslots_bwd;
                 {   // Kp05 S05 Kn0 S0 Kn1 S1 Kp05 | S0 | Hanti_q.. | Kn0 Kn1 S05 Kp05 S1 | (Hanti_q Hsym_q)..
-                    const int kinds[8] = {0, 1, 0, 1, 0, 1, 0, 1}, tps[8] = {1, 1, 0, 0, 2, 2, 1, 0};
+                    const int kinds_s[8] = {0, 1, 0, 1, 0, 1, 0, 1}, tps_s[8] = {1, 1, 0, 0, 2, 2, 1, 0};
+                    const int kinds_c[8] = {0, 1, 0, 0, 1, 1, 0, 1}, tps_c[8] = {1, 1, 0, 2, 0, 2, 1, 0};
+                    const int* kinds = coop ? kinds_c : kinds_s;
+                    const int* tps = coop ? tps_c : tps_s;
                     const int kinds2[5] = {0, 0, 1, 0, 1}, tps2[5] = {0, 2, 1, 1, 2};
                     a.sched_bits[0] = a.sched_bits[1] = a.sched_bits[2] = a.pro_bits = 0;
                     int k = 0;
@@ -632,10 +720,10 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
                     }
                 }
                 HIPCHK(h, hipEventRecord(h->ev[evi++], s));
-                hipLaunchKernelGGL(kbwd, dim3(nblocks), dim3(256), lds_bwd, s, a);
+                hipLaunchKernelGGL(kbwd, dim3(nblocks), dim3(nthreads), lds_bwd, s, a);
                 HIPCHK(h, hipEventRecord(h->ev[evi++], s));
                 hipLaunchKernelGGL(k_trace_reduce, dim3((unsigned)(((long long)nc * ntr + 255) / 256)), dim3(256), 0, s,
-                                   h->d_traces, nslabs, nc, ntr, h->d_R);
+                                   h->d_traces, trace_rows, nc, ntr, h->d_R);
                 hipLaunchKernelGGL(k_gradacc, dim3((ncoeff + 63) / 64), dim3(64), 0, s, sp, h->d_R, h->d_tb, n0, nc, -dt,
                                    h->d_grad + (size_t)pass * ncoeff);
                 mfma += (long long)nslabs * nc * (2 * (8 + 2 * h->m) * tiles + 4 * trace_tiles);

@@ -39,11 +39,20 @@ def gpu_eval_like_evalGrad(jq, params, wa, pcof):
     return np.array([objv]), grad
 
 
-@pytest.mark.parametrize("case", ["rabi", "swap02", "flux", "cnot2", "cnot2-leakieq", "cnot2-jacobi", "cnot3"])
+@pytest.mark.parametrize("case", ["rabi", "swap02", "flux", "cnot2", "cnot2-leakieq", "cnot2-jacobi", "cnot3", "cnot3:slab"])
 def test_reference_golden_through_the_callbacks(hip, case):
+    """All seven Stormer-Verlet goldens of the reference (test/runtests.jl:30).  cnot3 runs twice: on the
+    cooperative kernels (default for a single sample) and, with JQ_COOP_MAX=0, on the slab kernels."""
+    import os
     jq = hip
+    case, _, mode = case.partition(":")
     params, info, pcof, golden = case_inputs(case)
-    wa = jq.Working_Arrays_HIP(params, pcof.size)
+    if mode == "slab":
+        os.environ["JQ_COOP_MAX"] = "0"
+    try:
+        wa = jq.Working_Arrays_HIP(params, pcof.size)
+    finally:
+        os.environ.pop("JQ_COOP_MAX", None)
     obj, grad = gpu_eval_like_evalGrad(jq, params, wa, pcof)
     assert reference_pass(obj, golden["obj0"]), (obj, golden["obj0"])
     assert reference_pass(grad, golden["grad0"])

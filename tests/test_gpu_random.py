@@ -63,18 +63,24 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("mode", ["auto", "slab"])
 @pytest.mark.parametrize("cfg", CASES, ids=lambda c: "Ntot%d_N%d_Nc%d_f%d_m%d_o%d_%s_c%d" % (c[0], c[1], c[2], c[3], c[5], c[6], "band" if c[7] else "dense", c[8]))
-def test_random_problem_matches_oracle(jq, cfg):
+def test_random_problem_matches_oracle(jq, cfg, mode):
+    """mode 'auto': small batches run on the cooperative (row-split) kernels when Ntot > 16;
+    mode 'slab': JQ_COOP_MAX=0 forces the one-wave-per-slab kernels that large ensembles use."""
     from oracle.oracle import Oracle
     Ntot, N, Nc, Nfreq, nsteps, m, oft, banded, chunk = cfg
     rng = np.random.default_rng(1000 + Ntot * 31 + N)
     p, pcof = random_problem(jq, rng, Ntot, N, Nc, Nfreq, nsteps, m, oft, banded)
     if chunk:
         os.environ["JQ_CHUNK_STEPS"] = str(chunk)
+    if mode == "slab":
+        os.environ["JQ_COOP_MAX"] = "0"
     try:
         wa = jq.Working_Arrays_HIP(p, pcof.size)
     finally:
         os.environ.pop("JQ_CHUNK_STEPS", None)
+        os.environ.pop("JQ_COOP_MAX", None)
     r = Oracle(p, use_sparse=False).traceobjgrad(pcof, history=True)
     objfv, tg, prim, sec, tinf, ig, lg = jq.traceobjgrad(pcof, p, wa, False, True)
     gn = np.linalg.norm(r["totalgrad"])
