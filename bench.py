@@ -106,7 +106,7 @@ def main():
         traffic = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
-            traffic = tj["kernels"]["k_backward<6, 1, 1>"]["hbm_bytes_per_launch"]
+            traffic = tj["kernels"]["k_backward<6, 1, 1, false>"]["hbm_bytes_per_launch"]
         except Exception:
             pass
         roofline = {"bound": "mfma", "kernel": "k_backward<NT=6,BW=1>", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
