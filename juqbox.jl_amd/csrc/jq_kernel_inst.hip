@@ -1,10 +1,17 @@
 // One translation unit per (NT, BW, variant) instantiation of the propagator kernels (parallel builds, and
 // the MFMA register form can be chosen per instantiation -- see Makefile).
 //   JQ_VARIANT 0: slab kernels, Neumann   1: slab kernels, Jacobi   2: cooperative (row-split) kernels
+//              3: lane kernels (one lane per column; JQ_NT = padded Hilbert dimension NP, JQ_BW unused)
 #if !defined(JQ_NT) || !defined(JQ_BW) || !defined(JQ_VARIANT)
-#error "compile with -DJQ_NT=<tiles> -DJQ_BW=<band> -DJQ_VARIANT=<0|1|2>"
+#error "compile with -DJQ_NT=<tiles> -DJQ_BW=<band> -DJQ_VARIANT=<0|1|2|3>"
 #endif
-#if JQ_VARIANT == 2
+#if JQ_VARIANT == 3
+#include "jq_lane_kernels.h"
+template __global__ void k_forward_lane<JQ_NT>(PropArgs);
+template __global__ void k_backward_lane<JQ_NT>(PropArgs);
+template __global__ void k_init_state_lane<JQ_NT>(double*, long long, const double*, int, long long);
+template __global__ void k_terminal_lane<JQ_NT>(double*, long long, const double*, const double*, int, int, double, double*);
+#elif JQ_VARIANT == 2
 #include "jq_coop_kernels.h"
 template __global__ void k_forward_coop<JQ_NT, JQ_BW>(PropArgs);
 template __global__ void k_backward_coop<JQ_NT, JQ_BW>(PropArgs);

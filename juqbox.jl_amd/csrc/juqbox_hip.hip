@@ -9,6 +9,7 @@
 #include "jq_aux_kernels.h"
 #include "jq_coop_kernels.h"
 #include "jq_kernels.h"
+#include "jq_lane_kernels.h"
 
 #include <algorithm>
 #include <cmath>
@@ -41,17 +42,21 @@ struct jq_handle {
     int nslots_bwd = 2;         // ... of the backward kernel (shares LDS with carry + parking images)
     int park_lds = 0;           // backward kernel parks its dormant array in LDS (1) or HBM (0)
     int batch = 0;              // > 0: batched staging (K/S images of `batch` time steps per DMA burst)
+    int lane_np = 0;            // > 0: lane kernels available (Ntot <= 12), padded Hilbert dimension NP
+    long long lane_stride = 0;  // doubles per plain NP x NP operator image (padded to 64 B)
+    int lane_min_cols = 0, lane_max_cols = 0;   // column counts (samples x N) routed to the lane kernels
     std::vector<double> Hconst, Hsym, Hanti, Uinit, Utr, Uti, wd, cfreq;
     std::vector<double> tf, tb;
     // device buffers (owned)
     double *d_cimg = nullptr, *d_park = nullptr;
     double *d_himg_c = nullptr, *d_cimg_c = nullptr;   // operator images in the cooperative layout
+    double *d_himg_l = nullptr, *d_uinit_l = nullptr, *d_vtr_l = nullptr, *d_vti_l = nullptr;   // lane kernels
     double *d_himg = nullptr, *d_uimg = nullptr, *d_vtr = nullptr, *d_vti = nullptr, *d_tabs = nullptr;
     double *d_tf = nullptr, *d_tb = nullptr, *d_cfreq = nullptr, *d_pcof = nullptr;
     double *d_stream = nullptr, *d_pq = nullptr;
     double *d_state = nullptr, *d_state_save = nullptr, *d_colinfo = nullptr, *d_traces = nullptr, *d_R = nullptr;
     double *d_grad = nullptr, *d_res = nullptr;
-    size_t cap_pcof = 0, cap_slabs = 0, cap_traces = 0, cap_grad = 0, cap_res = 0;
+    size_t cap_pcof = 0, cap_slabs = 0, cap_traces = 0, cap_grad = 0, cap_res = 0, cap_state = 0, cap_colinfo = 0;
     int chunk_steps = 0;
     std::vector<hipEvent_t> ev;
     std::string err;
@@ -143,6 +148,20 @@ static void slab_image(const double* A, int Ntot, int N, int sps, int KT, double
         }
 }
 
+// plain row-major NP x NP image of a column-major Ntot x Ntot matrix (lane kernels), zero padded
+static void plain_image(const double* M, int Ntot, int NP, double* img)
+{
+    for (int i = 0; i < Ntot; ++i)
+        for (int j = 0; j < Ntot; ++j) img[(size_t)i * NP + j] = M[i + (size_t)Ntot * j];
+}
+
+// [N][NP] image of an Ntot x N array (lane kernels)
+static void column_image(const double* A, int Ntot, int N, int NP, double* img)
+{
+    for (int c = 0; c < N; ++c)
+        for (int r = 0; r < Ntot; ++r) img[(size_t)c * NP + r] = A[r + (size_t)Ntot * c];
+}
+
 template <typename T>
 static int dev_alloc(jq_handle* h, T** p, size_t count)
 {
@@ -186,6 +205,15 @@ static int upload_operators(jq_handle* h)
         HIPCHK(h, hipMemcpy(h->d_cimg_c, ic.data() + h->mat_elems_c, (size_t)2 * h->Nc * h->mat_elems_c * sizeof(double),
                             hipMemcpyHostToDevice));
     }
+    if (h->lane_np > 0) {
+        std::vector<double> il((size_t)(1 + 2 * h->Nc) * h->lane_stride, 0.0);
+        plain_image(h->Hconst.data(), h->Ntot, h->lane_np, il.data());
+        for (int q = 0; q < h->Nc; ++q) {
+            plain_image(h->Hsym.data() + q * nn, h->Ntot, h->lane_np, il.data() + (size_t)(1 + q) * h->lane_stride);
+            plain_image(h->Hanti.data() + q * nn, h->Ntot, h->lane_np, il.data() + (size_t)(1 + h->Nc + q) * h->lane_stride);
+        }
+        HIPCHK(h, hipMemcpy(h->d_himg_l, il.data(), il.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     return JQ_OK;
 }
 
@@ -196,6 +224,14 @@ static int upload_targets(jq_handle* h)
     HIPCHK(h, hipMemcpy(h->d_vtr, img.data(), img.size() * sizeof(double), hipMemcpyHostToDevice));
     slab_image(h->Uti.data(), h->Ntot, h->N, h->sps, h->KT, img.data());
     HIPCHK(h, hipMemcpy(h->d_vti, img.data(), img.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (h->lane_np > 0) {
+        std::vector<double> cl((size_t)h->N * h->lane_np, 0.0);
+        column_image(h->Utr.data(), h->Ntot, h->N, h->lane_np, cl.data());
+        HIPCHK(h, hipMemcpy(h->d_vtr_l, cl.data(), cl.size() * sizeof(double), hipMemcpyHostToDevice));
+        std::fill(cl.begin(), cl.end(), 0.0);
+        column_image(h->Uti.data(), h->Ntot, h->N, h->lane_np, cl.data());
+        HIPCHK(h, hipMemcpy(h->d_vti_l, cl.data(), cl.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     return JQ_OK;
 }
 
@@ -216,7 +252,7 @@ extern "C" void jq_destroy(jq_handle* h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    double** bufs[] = {&h->d_himg_c, &h->d_cimg_c, &h->d_park, &h->d_cimg, &h->d_himg,  &h->d_uimg,       &h->d_vtr,     &h->d_vti,    &h->d_tabs, &h->d_tf,   &h->d_tb,
+    double** bufs[] = {&h->d_himg_l, &h->d_uinit_l, &h->d_vtr_l, &h->d_vti_l, &h->d_himg_c, &h->d_cimg_c, &h->d_park, &h->d_cimg, &h->d_himg,  &h->d_uimg,       &h->d_vtr,     &h->d_vti,    &h->d_tabs, &h->d_tf,   &h->d_tb,
                        &h->d_cfreq, &h->d_pcof,       &h->d_stream,  &h->d_pq,     &h->d_state, &h->d_state_save,
                        &h->d_colinfo, &h->d_traces,   &h->d_R,       &h->d_grad,   &h->d_res};
     for (auto b : bufs)
@@ -329,6 +365,29 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         }
     }
 
+    // Lane kernels (jq_lane_kernels.h) for small Hilbert spaces: one lane per state column, operators through
+    // scalar loads.  Instantiated for NP in {2,4,6,8,12}.  JQ_LANE=0 disables them, JQ_LANE_MIN / JQ_LANE_MAX
+    // bound the column counts (samples x N) they are used for.
+    h->lane_np = 0;
+    {
+        static const int nps[] = {2, 4, 6, 8, 12};
+        for (int v : nps)
+            if (h->Ntot <= v) {
+                h->lane_np = v;
+                break;
+            }
+        int mode = 1;   // JQ_LANE: 0 never, 1 where measured faster than the MFMA kernels (default), 2 always
+        if (const char* e = getenv("JQ_LANE")) mode = atoi(e);
+        if (mode == 0) h->lane_np = 0;
+        h->lane_stride = ((long long)h->lane_np * h->lane_np + 7) / 8 * 8;
+        // measured on MI355X (scripts/time_cases.py): NP <= 4 always faster; NP 6..8 from ~16k columns;
+        // NP = 12 slower than the MFMA slab kernels at every ensemble size tried
+        h->lane_min_cols = (mode == 2 || h->lane_np <= 4) ? 1 : (h->lane_np <= 8 ? 16384 : (1 << 30));
+        h->lane_max_cols = 1 << 30;
+        if (const char* e = getenv("JQ_LANE_MIN")) h->lane_min_cols = atoi(e);
+        if (const char* e = getenv("JQ_LANE_MAX")) h->lane_max_cols = atoi(e);
+    }
+
     // time tables, accumulated exactly like the reference: t = t + h (src/StormerVerlet.jl:502);
     // the backward sweep restarts from exactly T with h = -dt (src/evalobjgrad.jl:811-812)
     const double dt = h->T / h->nsteps;
@@ -351,6 +410,15 @@ static int create_impl(const jq_problem* p, jq_handle* h)
     if (h->mat_elems_c > 0) {
         if ((rc = dev_alloc(h, &h->d_himg_c, (size_t)(1 + 2 * h->Nc) * h->mat_elems_c))) return rc;
         if ((rc = dev_alloc(h, &h->d_cimg_c, (size_t)(2 * h->Nc) * h->mat_elems_c))) return rc;
+    }
+    if (h->lane_np > 0) {
+        if ((rc = dev_alloc(h, &h->d_himg_l, (size_t)(1 + 2 * h->Nc) * h->lane_stride))) return rc;
+        if ((rc = dev_alloc(h, &h->d_uinit_l, (size_t)h->N * h->lane_np))) return rc;
+        if ((rc = dev_alloc(h, &h->d_vtr_l, (size_t)h->N * h->lane_np))) return rc;
+        if ((rc = dev_alloc(h, &h->d_vti_l, (size_t)h->N * h->lane_np))) return rc;
+        std::vector<double> cl((size_t)h->N * h->lane_np, 0.0);
+        column_image(h->Uinit.data(), h->Ntot, h->N, h->lane_np, cl.data());
+        HIPCHK(h, hipMemcpy(h->d_uinit_l, cl.data(), cl.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     if ((rc = dev_alloc(h, &h->d_uimg, (size_t)h->KT * 64))) return rc;
     if ((rc = dev_alloc(h, &h->d_vtr, (size_t)h->KT * 64))) return rc;
@@ -518,6 +586,33 @@ static int select_coop_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* 
     return fail(h, JQ_EUNSUPPORTED, "no cooperative kernel for this Hilbert dimension / band width");
 }
 
+// lane kernels (one lane per column), NP = padded Hilbert dimension
+typedef void (*lane_init_t)(double*, long long, const double*, int, long long);
+typedef void (*lane_term_t)(double*, long long, const double*, const double*, int, int, double, double*);
+#define JQ_FOR_EACH_LANE(X) X(2) X(4) X(6) X(8) X(12)
+#define JQ_DECLL(np)                                                                                  \
+    extern template __global__ void k_forward_lane<np>(PropArgs);                                     \
+    extern template __global__ void k_backward_lane<np>(PropArgs);                                    \
+    extern template __global__ void k_init_state_lane<np>(double*, long long, const double*, int, long long); \
+    extern template __global__ void k_terminal_lane<np>(double*, long long, const double*, const double*, int, int, double, double*);
+JQ_FOR_EACH_LANE(JQ_DECLL)
+#undef JQ_DECLL
+
+static int select_lane_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd, lane_init_t* init, lane_term_t* term)
+{
+#define JQ_PICKL(np)                     \
+    if (h->lane_np == np) {              \
+        *fwd = k_forward_lane<np>;       \
+        *bwd = k_backward_lane<np>;      \
+        *init = k_init_state_lane<np>;   \
+        *term = k_terminal_lane<np>;     \
+        return JQ_OK;                    \
+    }
+    JQ_FOR_EACH_LANE(JQ_PICKL)
+#undef JQ_PICKL
+    return fail(h, JQ_EUNSUPPORTED, "no lane kernel for this Hilbert dimension");
+}
+
 struct EvalOut {
     std::vector<double> res;    // [nsamples][4] primary, secondary, Re s, Im s
     std::vector<double> grad0;  // forced adjoint (total gradient), weighted sum over samples
@@ -546,15 +641,24 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     const int nslabs = (nsamples + h->sps - 1) / h->sps;
     // small batches: cooperative (row-split) kernels, one workgroup of NT waves per slab; large batches: slab
     // kernels, one wave per slab (jq_coop_kernels.h explains the trade-off)
-    const bool coop = h->mat_elems_c > 0 && h->solver_id == 1 && nslabs <= h->coop_max_slabs;
+    // small Hilbert spaces: lane kernels, one lane per column (jq_lane_kernels.h)
+    const long long ncols_used = (long long)nsamples * h->N;
+    const bool lane = h->lane_np > 0 && h->solver_id == 1 && ncols_used >= h->lane_min_cols && ncols_used <= h->lane_max_cols;
+    const long long ncols = (ncols_used + 63) / 64 * 64;
+    const bool coop = !lane && h->mat_elems_c > 0 && h->solver_id == 1 && nslabs <= h->coop_max_slabs;
     prop_kernel_t kfwd, kbwd;
-    int rc = coop ? select_coop_kernels(h, &kfwd, &kbwd) : select_kernels(h, &kfwd, &kbwd);
+    lane_init_t klinit = nullptr;
+    lane_term_t klterm = nullptr;
+    int rc = lane ? select_lane_kernels(h, &kfwd, &kbwd, &klinit, &klterm)
+                  : coop ? select_coop_kernels(h, &kfwd, &kbwd) : select_kernels(h, &kfwd, &kbwd);
     if (rc) return rc;
-    const int nblocks = coop ? nslabs : (nslabs + JQ_WAVES - 1) / JQ_WAVES;
-    const int nthreads = coop ? 64 * h->NT : 256;
-    const int trace_rows = coop ? nslabs * h->NT : nslabs;   // per-step trace records: one per wave
-    const long long stride = coop ? h->mat_elems_c : h->mat_elems;
-    const double* himg = coop ? h->d_himg_c : h->d_himg;
+    const int nblocks = lane ? (int)(ncols / 64) : coop ? nslabs : (nslabs + JQ_WAVES - 1) / JQ_WAVES;
+    const int nthreads = lane ? 64 : coop ? 64 * h->NT : 256;
+    const int trace_rows = lane ? nblocks : coop ? nslabs * h->NT : nslabs;   // per-step trace records: one per wave
+    const long long stride = lane ? h->lane_stride : coop ? h->mat_elems_c : h->mat_elems;
+    const double* himg = lane ? h->d_himg_l : coop ? h->d_himg_c : h->d_himg;
+    const size_t state_doubles = lane ? (size_t)JQ_LANE_ROWS(h->lane_np) * ncols : (size_t)nslabs * h->state_stride;
+    const size_t colinfo_doubles = lane ? (size_t)2 * ncols : (size_t)nslabs * 32;
     const int cs = h->chunk_steps;
     const int ntr = h->Nc * JQ_NTR;
     const bool two_pass = adjoint && h->objFuncType != 1;
@@ -564,13 +668,18 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
         if ((rc = dev_alloc(h, &h->d_pcof, (size_t)ncoeff))) return rc;
         h->cap_pcof = ncoeff;
     }
-    if ((size_t)nslabs > h->cap_slabs) {
-        if ((rc = dev_alloc(h, &h->d_state, (size_t)nslabs * h->state_stride))) return rc;
-        if ((rc = dev_alloc(h, &h->d_state_save, (size_t)nslabs * h->state_stride))) return rc;
-        if ((rc = dev_alloc(h, &h->d_colinfo, (size_t)nslabs * 32))) return rc;
+    if (state_doubles > h->cap_state) {
+        if ((rc = dev_alloc(h, &h->d_state, state_doubles))) return rc;
+        if ((rc = dev_alloc(h, &h->d_state_save, state_doubles))) return rc;
+        h->cap_state = state_doubles;
+    }
+    if (colinfo_doubles > h->cap_colinfo) {
+        if ((rc = dev_alloc(h, &h->d_colinfo, colinfo_doubles))) return rc;
+        h->cap_colinfo = colinfo_doubles;
+    }
+    if (!lane && (size_t)nslabs > h->cap_slabs) {
         if ((rc = dev_alloc(h, &h->d_park, (size_t)nslabs * h->KT * 64))) return rc;
         h->cap_slabs = nslabs;
-        h->cap_traces = 0;
     }
     if (adjoint && (size_t)trace_rows * cs * ntr > h->cap_traces) {
         if ((rc = dev_alloc(h, &h->d_traces, (size_t)trace_rows * cs * ntr))) return rc;
@@ -589,22 +698,32 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     hipStream_t s = h->stream;
     HIPCHK(h, hipMemcpyAsync(h->d_pcof, pcof, (size_t)ncoeff * sizeof(double), hipMemcpyHostToDevice, s));
     bool use_shift = false;
-    std::vector<double> colinfo((size_t)nslabs * 32, 0.0);
-    for (int sl = 0; sl < nslabs; ++sl)
-        for (int c = 0; c < h->sps * h->N; ++c) {
-            const int smp = sl * h->sps + c / h->N;
-            if (smp < nsamples) {
-                colinfo[(size_t)sl * 32 + c] = eps ? eps[smp] : 0.0;
-                colinfo[(size_t)sl * 32 + 16 + c] = wgt ? wgt[smp] : 1.0;
-                if (eps && eps[smp] != 0.0) use_shift = true;
-            }
+    std::vector<double> colinfo(colinfo_doubles, 0.0);
+    if (lane) {   // [eps per column | weight per column]
+        for (long long c = 0; c < ncols_used; ++c) {
+            const int smp = (int)(c / h->N);
+            colinfo[c] = eps ? eps[smp] : 0.0;
+            colinfo[ncols + c] = wgt ? wgt[smp] : 1.0;
+            if (eps && eps[smp] != 0.0) use_shift = true;
         }
+    } else {
+        for (int sl = 0; sl < nslabs; ++sl)
+            for (int c = 0; c < h->sps * h->N; ++c) {
+                const int smp = sl * h->sps + c / h->N;
+                if (smp < nsamples) {
+                    colinfo[(size_t)sl * 32 + c] = eps ? eps[smp] : 0.0;
+                    colinfo[(size_t)sl * 32 + 16 + c] = wgt ? wgt[smp] : 1.0;
+                    if (eps && eps[smp] != 0.0) use_shift = true;
+                }
+            }
+    }
     HIPCHK(h, hipMemcpyAsync(h->d_colinfo, colinfo.data(), colinfo.size() * sizeof(double), hipMemcpyHostToDevice, s));
     std::vector<double> tabs((size_t)32 * h->NT, 0.0);
+    const size_t ws_off = lane ? (size_t)h->lane_np : (size_t)16 * h->NT;   // tables: [wd | ws]
     for (int i = 0; i < h->Ntot; ++i) {
         tabs[i] = h->wd[i];
         // reference perturbation: Hconst[j,j] += ep*0.01*10^(j-2), j = 2..Ntot (src/ipopt_interface.jl:41-44)
-        tabs[(size_t)16 * h->NT + i] = shift ? shift[i] : (i >= 1 ? 0.01 * pow(10.0, (double)(i - 1)) : 0.0);
+        tabs[ws_off + i] = shift ? shift[i] : (i >= 1 ? 0.01 * pow(10.0, (double)(i - 1)) : 0.0);
     }
     HIPCHK(h, hipMemcpyAsync(h->d_tabs, tabs.data(), tabs.size() * sizeof(double), hipMemcpyHostToDevice, s));
     HIPCHK(h, hipMemsetAsync(h->d_grad, 0, (size_t)2 * ncoeff * sizeof(double), s));
@@ -616,10 +735,10 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     const double dt = h->T / h->nsteps;
     PropArgs a;
     memset(&a, 0, sizeof a);
-    a.stream = h->d_stream; a.cimg = coop ? h->d_cimg_c : h->d_cimg; a.state = h->d_state; a.colinfo = h->d_colinfo;
+    a.stream = h->d_stream; a.cimg = lane ? h->d_himg_l + h->lane_stride : coop ? h->d_cimg_c : h->d_cimg; a.state = h->d_state; a.colinfo = h->d_colinfo;
     a.traces = h->d_traces;
     a.tabs = h->d_tabs; a.stride = stride; a.pieces = (int)(stride * 8 / 1024); a.nslots = h->nslots; a.m = h->m;
-    a.nslabs = nslabs; a.Ncoupled = h->Nc; a.Ntot = h->Ntot; a.N = h->N; a.use_shift = use_shift ? 1 : 0;
+    a.nslabs = lane ? (int)ncols : nslabs; a.Ncoupled = h->Nc; a.Ntot = h->Ntot; a.N = h->N; a.use_shift = use_shift ? 1 : 0;
     a.tinv = 1.0 / h->T; a.state_stride = h->state_stride;
     a.jacobi_tol2 = (h->solver_id == 2) ? h->solver_tol * h->solver_tol : 0.0;
     for (int q = 0; q < JQ_MAXNC; ++q) a.bw_trace[q] = h->bw_trace[q];
@@ -628,14 +747,16 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     const int batch = coop ? 0 : h->batch;
     const size_t lds_stage = batch > 0 ? (size_t)2 * (2 * batch + 1) * 2 * stride * 8 + (size_t)2 * h->Nc * stride * 8
                                        : (size_t)2 * stride * 8;
-    const size_t lds_fwd = lds_stage + (size_t)32 * h->NT * 8 + (coop ? (size_t)2 * h->KT * 64 * 8 : 0);
-    const size_t lds_bwd = coop ? lds_fwd
+    const size_t lds_fwd = lane ? 0 : lds_stage + (size_t)32 * h->NT * 8 + (coop ? (size_t)2 * h->KT * 64 * 8 : 0);
+    const size_t lds_bwd = lane ? 0 : coop ? lds_fwd
                                 : lds_fwd + (size_t)JQ_MAXNC * 256 * 8 + (h->park_lds ? (size_t)JQ_WAVES * h->KT * 64 * 8 : 0);
     a.batch = batch; a.lds_tab_off = (int)lds_stage;
     a.park = h->d_park; a.park_lds = h->park_lds;
     if (const char* e = getenv("JQ_DEBUG")) a.debug = atoi(e);
-    HIPCHK(h, hipFuncSetAttribute((const void*)kfwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fwd));
-    HIPCHK(h, hipFuncSetAttribute((const void*)kbwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bwd));
+    if (!lane) {
+        HIPCHK(h, hipFuncSetAttribute((const void*)kfwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fwd));
+        HIPCHK(h, hipFuncSetAttribute((const void*)kbwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bwd));
+    }
 
     // events: [0]=start [1]=end, then pairs around every propagator launch
     const int nchunks = (h->nsteps + cs - 1) / cs;
@@ -648,12 +769,15 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     size_t evi = 2;
     HIPCHK(h, hipEventRecord(h->ev[0], s));
 
-    hipLaunchKernelGGL(k_init_state, dim3(nslabs), dim3(64), 0, s, h->d_state, h->state_stride, h->d_uimg, h->KT);
+    if (lane)
+        hipLaunchKernelGGL(klinit, dim3((unsigned)(ncols / 64)), dim3(64), 0, s, h->d_state, ncols, h->d_uinit_l, h->N, ncols_used);
+    else
+        hipLaunchKernelGGL(k_init_state, dim3(nslabs), dim3(64), 0, s, h->d_state, h->state_stride, h->d_uimg, h->KT);
 
     long long mfma = 0;
-    const long long tiles = coop ? coop_tiles(h->NT, h->BW) : band_tiles(h->NT, h->BW);
+    const long long tiles = lane ? 0 : coop ? coop_tiles(h->NT, h->BW) : band_tiles(h->NT, h->BW);
     long long trace_tiles = 0;
-    for (int q = 0; q < h->Nc; ++q)
+    for (int q = 0; q < h->Nc && !lane; ++q)
         trace_tiles += coop ? coop_tiles(h->NT, h->BW) : band_tiles(h->NT, h->bw_trace[q] == 0 ? 0 : h->BW, h->bw_trace[q] == 2);
     // ---- forward sweep -------------------------------------------------------------------------
     for (int n0 = 0; n0 < h->nsteps; n0 += cs) {
@@ -681,17 +805,21 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     }
     HIPCHK(h, hipGetLastError());
     const double leak_scale = 0.5 * dt * (1.0 / h->T);
-    hipLaunchKernelGGL(k_terminal, dim3(nslabs), dim3(64), 0, s, h->d_state, h->state_stride, h->d_vtr, h->d_vti, h->KT,
-                       h->N, h->sps, nsamples, leak_scale, h->d_res);
+    if (lane)
+        hipLaunchKernelGGL(klterm, dim3((nsamples + 63) / 64), dim3(64), 0, s, h->d_state, ncols, h->d_vtr_l, h->d_vti_l, h->N,
+                           nsamples, leak_scale, h->d_res);
+    else
+        hipLaunchKernelGGL(k_terminal, dim3(nslabs), dim3(64), 0, s, h->d_state, h->state_stride, h->d_vtr, h->d_vti, h->KT,
+                           h->N, h->sps, nsamples, leak_scale, h->d_res);
 
     // ---- backward sweep(s) ---------------------------------------------------------------------
     if (adjoint) {
         if (two_pass)
-            HIPCHK(h, hipMemcpyAsync(h->d_state_save, h->d_state, (size_t)nslabs * h->state_stride * sizeof(double),
+            HIPCHK(h, hipMemcpyAsync(h->d_state_save, h->d_state, state_doubles * sizeof(double),
                                      hipMemcpyDeviceToDevice, s));
         for (int pass = 0; pass < (two_pass ? 2 : 1); ++pass) {
             if (pass == 1)
-                HIPCHK(h, hipMemcpyAsync(h->d_state, h->d_state_save, (size_t)nslabs * h->state_stride * sizeof(double),
+                HIPCHK(h, hipMemcpyAsync(h->d_state, h->d_state_save, state_doubles * sizeof(double),
                                          hipMemcpyDeviceToDevice, s));
             for (int n0 = 0; n0 < h->nsteps; n0 += cs) {
                 const int nc = std::min(cs, h->nsteps - n0);
