@@ -1,39 +1,61 @@
-// jq_lane_kernels.h -- propagators for SMALL Hilbert spaces (Ntot <= 12): one LANE per state column.
+// jq_lane_kernels.h -- propagators for SMALL Hilbert spaces (Ntot <= 8): one LANE per state column.
 //
 // For Ntot <= 16 an MFMA tile is mostly padding (SWAP-02: 4 of 16 rows and 4 of 16 k) and every product is a
 // ~600-cycle dependent chain (LDS round trip + 4 dependent 64-cycle MFMAs).  Here each lane owns one column
-// (ensemble sample x initial condition): its state vectors are NP doubles in registers, the operators are
-// uniform across the wave and are read with SCALAR loads (s_load through the scalar cache) straight into
-// the SGPR operand of v_fma_f64, so a product is NP*NP FMAs and nothing else -- no LDS, no barriers, no
-// cross-lane traffic except the per-step trace reduction.  Same math (scaled/signed operator stream,
-// Horner-form Neumann series, negated lambda_i, 4 trace products per control), same schedule of time
-// points, same trace/gradient pipeline as the MFMA kernels.
+// (ensemble sample x initial condition): its state vectors are NP doubles in registers and a product
+// y = M x is NP*NP v_fmac_f64 and nothing else.
 //
-// Layouts:  operators: plain row-major NP x NP images (zero padded), stream point j -> K at (2j)*NP*NP,
-//           S at (2j+1)*NP*NP;  state file: [array][row][column] with the column index fastest.
+// Operand delivery: the operators are uniform across the wave.  An NP x NP image lives in ceil(NP*NP/16)
+// VGPR pairs: lane l holds elements (l & 15) + 16 r, identically in each of the four 16-lane rows, and every
+// FMA reads "its" element with the DP-ALU DPP control row_newbcast:k (gfx90a+: broadcast lane k of each row
+// to the row), which costs nothing -- measured on MI355X (probes/dpp_fmac_probe.hip): 36.0 TFLOP/s for
+// v_fmac_f64_dpp vs 41.0 for plain v_fma_f64 at one wave per SIMD, inside a loop that is 20 % other work.
+// So there is no LDS, no scalar-cache latency in the product chain and no barrier; the images of the NEXT
+// time step (4 new ones: K, S at t+3h/2 and t+2h) are fetched with ordinary per-lane global loads one step
+// ahead, and the compiler's own vmcnt bookkeeping covers them.
+// (History: a first version fed the FMAs from SGPRs via s_load; SMEM returns out of order, so every 8..16
+// doubles cost a full ~150-cycle lgkmcnt(0) round trip and the wave ran 4x below the FMA rate.)
+//
+// The DPP FMA is inline asm (this clang has no 64-bit update_dpp builtin; the llvm.amdgcn.update.dpp.i64
+// intrinsic yields v_mov_b64_dpp + v_fma, twice the VALU work).  gfx950 requires 2 wait states between a
+// VALU write of a VGPR and a DPP read of it and does NOT interlock (probe: stale data); the hazard recognizer
+// cannot see into inline asm, so (1) every product starts with s_nop 1 and (2) scripts/check_dpp_hazard.py
+// verifies the final ISA of every lane kernel at build time (make fails on a violation).
+//
+// Same math as the MFMA kernels (scaled/signed operator stream, Horner-form Neumann series, negated
+// lambda_i, 4 trace products per control), same time-point schedule, same trace/gradient pipeline.
+//
+// Layouts:  operator images: row-major NP x NP, zero padded to a multiple of 16 doubles (a.stride);
+//           stream point j -> K at (2j)*stride, S at (2j+1)*stride;
+//           state file: [array][row][column] with the column index fastest.
 #pragma once
 #include "jq_kernels.h"
+#include <utility>
 
-// Operator/table pointers in the CONSTANT address space: the images are written by earlier kernels
-// (k_stream) and never by the propagators, and a uniform load from address space 4 is always selected
-// as s_load (a plain global pointer is not: the kernel also stores to global memory, so the compiler
-// cannot prove the operator bytes unclobbered and falls back to per-lane global_load into VGPRs).
+// Operator images are written by earlier kernels (k_stream), never by the propagators: reading them through
+// the constant address space lets the loads move freely across the kernels' own global stores.
 typedef const __attribute__((address_space(4))) double* cmat_t;
 __device__ __forceinline__ cmat_t as_const(const double* p) { return (cmat_t)(unsigned long long)p; }
-
-// Opaque copy of a table pointer: keeps the compiler from hoisting the (loop invariant) table loads out
-// of the time loop, where 2*NP doubles of wd/ws would permanently occupy up to 48 of the ~100 SGPRs.
-__device__ __forceinline__ cmat_t launder(cmat_t p)
-{
-    unsigned long long v = (unsigned long long)p;
-    asm volatile("" : "+s"(v));
-    return (cmat_t)v;
-}
 
 template <int NP>
 struct Vec {
     double e[NP];
 };
+// operator image in registers: element e of the row-major image sits in r[e / 16], lane (e % 16) of each row
+template <int NP>
+struct Mat {
+    static constexpr int NR = (NP * NP + 15) / 16;
+    double r[NR];
+};
+
+template <int NP>
+__device__ __forceinline__ Mat<NP> mat_load(cmat_t p, int l16)
+{
+    Mat<NP> m;
+#pragma unroll
+    for (int k = 0; k < Mat<NP>::NR; ++k) m.r[k] = p[16 * k + l16];
+    return m;
+}
 
 template <int NP>
 __device__ __forceinline__ Vec<NP> v_add(const Vec<NP>& a, const Vec<NP>& b)
@@ -51,91 +73,59 @@ __device__ __forceinline__ double v_dot(const Vec<NP>& a, const Vec<NP>& b)
     for (int i = 0; i < NP; ++i) s += a.e[i] * b.e[i];
     return s;
 }
-// Scalar-load pipeline of one operator image.  The image is read as a flat stream of CH-double chunks
-// (s_load_dwordx16 / x8) into SGPR tuples that feed v_fma_f64 directly; chunk c+1 is in flight while the
-// FMAs of chunk c run.  Inline asm because hipcc, left alone, hoists every load of a matrix (and of the
-// next matrices) to the top of the block and then spills hundreds of SGPRs lane by lane into VGPRs.
-// SMEM returns out of order, so the only usable wait is lgkmcnt(0); the wait takes the landed tuple as
-// an in/out operand so that no consumer can be scheduled above it.
-typedef double sd8 __attribute__((ext_vector_type(8)));
-typedef double sd4 __attribute__((ext_vector_type(4)));
-template <int CH> struct SChunk;
-template <> struct SChunk<8> {
-    typedef sd8 type;
-    template <int OFF>
-    static __device__ __forceinline__ void load(sd8& r, cmat_t p) { asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(r) : "s"(p), "i"(OFF)); }
-};
-template <> struct SChunk<4> {
-    typedef sd4 type;
-    template <int OFF>
-    static __device__ __forceinline__ void load(sd4& r, cmat_t p) { asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(r) : "s"(p), "i"(OFF)); }
-};
-template <typename T>
-__device__ __forceinline__ void s_landed(T& r)
+
+// y += m[lane K of the row] * x
+template <int K>
+__device__ __forceinline__ void fma_bcast(double& y, double m, double x)
 {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r));
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(y) : "v"(m), "v"(x), "n"(K));
 }
-
-// chunk C of the image: wait for it, issue chunk C+1 (byte offset as an instruction immediate: no pointer
-// arithmetic for the compiler to keep alive), run its CH FMAs, recurse with the buffers swapped
-template <int NP, int CH, int C, int NCH>
-struct MvStep {
-    typedef typename SChunk<CH>::type chunk_t;
-    static __device__ __forceinline__ void run(Vec<NP>& y, cmat_t M, const Vec<NP>& x, chunk_t& cur, chunk_t& nxt)
-    {
-        s_landed(cur);
-        if constexpr (C + 1 < NCH) SChunk<CH>::template load<(C + 1) * CH * 8>(nxt, M);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < CH; ++k) {
-            const int e = C * CH + k;
-            y.e[e / NP] = fma(cur[k], x.e[e % NP], y.e[e / NP]);
-        }
-        __builtin_amdgcn_sched_barrier(0);   // the tuple dies here, its SGPRs are reused by chunk C+2
-        if constexpr (C + 1 < NCH) MvStep<NP, CH, C + 1, NCH>::run(y, M, x, nxt, cur);
-    }
-};
-
-// y = c + M x   (M uniform, row-major NP x NP; y may alias c, not x)
-template <int NP, bool ZEROC>
-__device__ __forceinline__ Vec<NP> mv(const Vec<NP>& c, cmat_t M, const Vec<NP>& x)
+template <int NP, int... E>
+__device__ __forceinline__ void mv_fold(Vec<NP>& y, const Mat<NP>& M, const Vec<NP>& x, std::integer_sequence<int, E...>)
 {
-    constexpr int CH = (NP * NP % 8 == 0) ? 8 : 4;
-    constexpr int NCH = NP * NP / CH;
-    static_assert(NP * NP % CH == 0, "NP*NP must be a multiple of 4");
-    typedef typename SChunk<CH>::type chunk_t;
+    (fma_bcast<E % 16>(y.e[E / NP], M.r[E / 16], x.e[E % NP]), ...);
+}
+// y = c + M x   (y may alias c, not x)
+template <int NP, bool ZEROC>
+__device__ __forceinline__ Vec<NP> mv(const Vec<NP>& c, const Mat<NP>& M, const Vec<NP>& x)
+{
     Vec<NP> y;
 #pragma unroll
     for (int i = 0; i < NP; ++i) y.e[i] = ZEROC ? 0.0 : c.e[i];
-    chunk_t b0, b1;
-    SChunk<CH>::template load<0>(b0, M);
-    MvStep<NP, CH, 0, NCH>::run(y, M, x, b0, b1);
-    // pin the result here: otherwise LLVM sinks the FMAs of a product whose result is only needed in a
-    // later basic block below the (volatile) loads and keeps every loaded tuple alive by spilling it
-#pragma unroll
-    for (int i = 0; i < NP; ++i) asm volatile("" : "+v"(y.e[i]));
+    // DPP read-after-VALU-write hazard (see header): nothing the register allocator places in front of the
+    // product (copies, AGPR reloads of M) may sit closer than 2 wait states to the first FMA
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 1");
+    __builtin_amdgcn_sched_barrier(0);   // (the non-volatile FMAs may otherwise move above the s_nop)
+    mv_fold<NP>(y, M, x, std::make_integer_sequence<int, NP * NP>{});
     return y;
 }
-// y += (s * tab) .* x     (tab uniform)
+// y += s * tab .* x     (per-lane tables)
 template <int NP>
-__device__ __forceinline__ void v_axpy_rows(Vec<NP>& y, double s, cmat_t tab0, const Vec<NP>& x)
+__device__ __forceinline__ void v_axpy_rows(Vec<NP>& y, double s, const Vec<NP>& tab, const Vec<NP>& x)
 {
-    cmat_t tab = launder(tab0);
 #pragma unroll
-    for (int i = 0; i < NP; ++i) y.e[i] = fma(s * tab[i], x.e[i], y.e[i]);
+    for (int i = 0; i < NP; ++i) y.e[i] = fma(s * tab.e[i], x.e[i], y.e[i]);
 }
 template <int NP>
-__device__ __forceinline__ double v_wsq(cmat_t tab0, const Vec<NP>& x)
+__device__ __forceinline__ double v_wsq(const Vec<NP>& tab, const Vec<NP>& x)
 {
-    cmat_t tab = launder(tab0);
     double s = 0.0;
 #pragma unroll
-    for (int i = 0; i < NP; ++i) s = fma(tab[i], x.e[i] * x.e[i], s);
+    for (int i = 0; i < NP; ++i) s = fma(tab.e[i], x.e[i] * x.e[i], s);
     return s;
+}
+template <int NP>
+__device__ __forceinline__ Vec<NP> tab_load(const double* t)
+{
+    Vec<NP> r;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) r.e[i] = t[i];
+    return r;
 }
 // bpa + sum_{j=1..m} S^j A  (Horner form, see jq_kernels.h)
 template <int NP>
-__device__ __forceinline__ Vec<NP> lane_horner(const Vec<NP>& bpa, const Vec<NP>& A, cmat_t S, int m)
+__device__ __forceinline__ Vec<NP> lane_horner(const Vec<NP>& bpa, const Vec<NP>& A, const Mat<NP>& S, int m)
 {
     if (m <= 0) return bpa;
     Vec<NP> Y = A;
@@ -143,41 +133,61 @@ __device__ __forceinline__ Vec<NP> lane_horner(const Vec<NP>& bpa, const Vec<NP>
     return mv<NP, false>(bpa, S, Y);
 }
 
+// the six operator images of one time step: K, S at t (0), t + h/2 (05), t + h (1); scaled and signed by
+// k_stream (Kp = +cK at half points, Kn = -cK at integer points, S = cS, c = h/2)
+template <int NP>
 struct LaneOps {
-    cmat_t Kp05, S05, Kn0, S0, Kn1, S1;
+    Mat<NP> Kn0, S0, Kp05, S05, Kn1, S1;
 };
-__device__ __forceinline__ LaneOps lane_ops(const PropArgs& a, int n, int nn)
+template <int NP>
+__device__ __forceinline__ void ops_load_half(LaneOps<NP>& o, const PropArgs& a, int n, int l16)
 {
-    LaneOps o;
+    cmat_t s = as_const(a.stream) + (size_t)(2 * (2 * n + 1)) * a.stride;
+    o.Kp05 = mat_load<NP>(s, l16);
+    o.S05 = mat_load<NP>(s + a.stride, l16);
+    o.Kn1 = mat_load<NP>(s + 2 * a.stride, l16);
+    o.S1 = mat_load<NP>(s + 3 * a.stride, l16);
+}
+template <int NP>
+__device__ __forceinline__ void ops_load_first(LaneOps<NP>& o, const PropArgs& a, int l16)
+{
     cmat_t s = as_const(a.stream);
-    o.Kn0 = s + (size_t)(2 * (2 * n)) * nn;
-    o.S0 = o.Kn0 + nn;
-    o.Kp05 = s + (size_t)(2 * (2 * n + 1)) * nn;
-    o.S05 = o.Kp05 + nn;
-    o.Kn1 = s + (size_t)(2 * (2 * n + 2)) * nn;
-    o.S1 = o.Kn1 + nn;
-    return o;
+    o.Kn0 = mat_load<NP>(s, l16);
+    o.S0 = mat_load<NP>(s + a.stride, l16);
+    ops_load_half(o, a, 0, l16);
+}
+// roles for the next step: (K,S)(t+h) become (K,S)(t); the four images fetched one step ahead move in
+template <int NP>
+__device__ __forceinline__ void ops_advance(LaneOps<NP>& o, const LaneOps<NP>& nxt)
+{
+    o.Kn0 = o.Kn1;
+    o.S0 = o.S1;
+    o.Kp05 = nxt.Kp05;
+    o.S05 = nxt.S05;
+    o.Kn1 = nxt.Kn1;
+    o.S1 = nxt.S1;
 }
 
-// one Stormer-Verlet state step (forward step!, src/StormerVerlet.jl:461-504) in the accumulate form
+// One Stormer-Verlet state step (forward step!, src/StormerVerlet.jl:461-504) in the accumulate form.
+// sw = eps * c * ws per lane (reference perturbation of diag(Hconst), src/ipopt_interface.jl:41-44).
 template <int NP>
-__device__ __forceinline__ void lane_state(const PropArgs& a, const LaneOps& o, double ceps, cmat_t ws,
-                                           const Vec<NP>& u, const Vec<NP>& v, Vec<NP>& un, Vec<NP>& v05, Vec<NP>& vnew)
+__device__ __forceinline__ void lane_state(const PropArgs& a, const LaneOps<NP>& o, const Vec<NP>& sw, const Vec<NP>& u,
+                                           const Vec<NP>& v, Vec<NP>& un, Vec<NP>& v05, Vec<NP>& vnew)
 {
     Vec<NP> A = mv<NP, true>(u, o.Kp05, u);
-    if (a.use_shift) v_axpy_rows(A, ceps, ws, u);
+    if (a.use_shift) v_axpy_rows(A, 1.0, sw, u);
     A = mv<NP, false>(A, o.S05, v);
     v05 = lane_horner<NP>(v_add(v, A), A, o.S05, a.m);
-    Vec<NP> vN = mv<NP, false>(v05, o.S05, v05);
+    const Vec<NP> vN = mv<NP, false>(v05, o.S05, v05);
     un = mv<NP, false>(u, o.Kn0, v05);
-    if (a.use_shift) v_axpy_rows(un, -ceps, ws, v05);
+    if (a.use_shift) v_axpy_rows(un, -1.0, sw, v05);
     un = mv<NP, false>(un, o.S0, u);
     A = mv<NP, true>(u, o.Kn1, v05);
-    if (a.use_shift) v_axpy_rows(A, -ceps, ws, v05);
+    if (a.use_shift) v_axpy_rows(A, -1.0, sw, v05);
     A = mv<NP, false>(A, o.S1, un);
     un = lane_horner<NP>(v_add(un, A), A, o.S1, a.m);
     vnew = mv<NP, false>(vN, o.Kp05, un);
-    if (a.use_shift) v_axpy_rows(vnew, ceps, ws, un);
+    if (a.use_shift) v_axpy_rows(vnew, 1.0, sw, un);
 }
 
 // state file access: [array][row][column]
@@ -205,16 +215,21 @@ __global__ __launch_bounds__(64) void k_forward_lane(PropArgs a)
 {
     const long long col = (long long)blockIdx.x * 64 + threadIdx.x;
     const long long ncols = a.nslabs;
-    cmat_t wd = as_const(a.tabs);
-    cmat_t ws = wd + NP;
+    const int l16 = threadIdx.x & 15;
+    const Vec<NP> wd = tab_load<NP>(a.tabs);
+    Vec<NP> sw = tab_load<NP>(a.tabs + NP);
     Vec<NP> u = lane_load<NP>(a.state, 0, ncols, col), v = lane_load<NP>(a.state, 1, ncols, col);
     double leak = a.state[((size_t)JQ_LANE_ARRAYS * NP + JQ_MAXNC) * ncols + col];
     const double ceps = 0.5 * a.h * a.colinfo[col];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) sw.e[i] *= ceps;
+    LaneOps<NP> o, nxt;
+    ops_load_first(o, a, l16);
     for (int n = 0; n < a.nsteps_chunk; ++n) {
-        const LaneOps o = lane_ops(a, n, (int)a.stride);
+        ops_load_half(nxt, a, min(n + 1, a.nsteps_chunk - 1), l16);   // lands during this step
         Vec<NP> un, v05, vnew;
         leak += v_wsq<NP>(wd, u);
-        lane_state<NP>(a, o, ceps, ws, u, v, un, v05, vnew);
+        lane_state<NP>(a, o, sw, u, v, un, v05, vnew);
         u = un;
         v = vnew;
         leak += v_wsq<NP>(wd, u) + 2.0 * v_wsq<NP>(wd, v05);
@@ -227,6 +242,7 @@ __global__ __launch_bounds__(64) void k_forward_lane(PropArgs a)
                     a.hist_i[off + i] = -v.e[i];
                 }
         }
+        ops_advance(o, nxt);
     }
     lane_store<NP>(a.state, 0, ncols, col, u);
     lane_store<NP>(a.state, 1, ncols, col, v);
@@ -234,48 +250,61 @@ __global__ __launch_bounds__(64) void k_forward_lane(PropArgs a)
 }
 
 // Backward sweep of one chunk (state re-integration, adjoint step, trace scalars per wave and step).
-// a.cimg: constant images [Hsym_q | Hanti_q], NP*NP each.
+// a.cimg: constant images [Hsym_q | Hanti_q], resident in registers for the whole sweep.
 template <int NP>
 __global__ __launch_bounds__(64) void k_backward_lane(PropArgs a)
 {
     const long long col = (long long)blockIdx.x * 64 + threadIdx.x;
     const long long ncols = a.nslabs;
     const int lane = threadIdx.x;
+    const int l16 = lane & 15;
     const int Nc = a.Ncoupled;
-    const int NN = (int)a.stride;   // doubles per operator image (NP*NP padded to 64 B)
-    cmat_t cimg = as_const(a.cimg);
-    cmat_t wd = as_const(a.tabs);
-    cmat_t ws = wd + NP;
+    const Vec<NP> wd = tab_load<NP>(a.tabs);
+    Vec<NP> sw = tab_load<NP>(a.tabs + NP);
     Vec<NP> u = lane_load<NP>(a.state, 0, ncols, col), v = lane_load<NP>(a.state, 1, ncols, col);
     Vec<NP> mu = lane_load<NP>(a.state, 2, ncols, col), nb = lane_load<NP>(a.state, 3, ncols, col);
     const double ceps = 0.5 * a.h * a.colinfo[col];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) sw.e[i] *= ceps;
     const double wgt = a.colinfo[ncols + col];
     const double cfw = a.forced ? 0.5 * a.h * a.tinv : 0.0;
     double carry[JQ_MAXNC];
+    // constant images: resident in registers for NP <= 6; for NP = 8 (32 more VGPR pairs at 4 controls) they
+    // are re-fetched every step so that nothing spills to AGPRs
+    constexpr bool RESIDENT = (NP <= 6);
+    Mat<NP> Hs[JQ_MAXNC], Ha[JQ_MAXNC];
 #pragma unroll
-    for (int q = 0; q < JQ_MAXNC; ++q) carry[q] = (q < Nc) ? a.state[((size_t)JQ_LANE_ARRAYS * NP + q) * ncols + col] : 0.0;
+    for (int q = 0; q < JQ_MAXNC; ++q) {
+        const int qq = min(q, Nc - 1);
+        carry[q] = (q < Nc) ? a.state[((size_t)JQ_LANE_ARRAYS * NP + q) * ncols + col] : 0.0;
+        if (RESIDENT || a.first_chunk) Hs[q] = mat_load<NP>(as_const(a.cimg) + (size_t)qq * a.stride, l16);
+        if (RESIDENT) Ha[q] = mat_load<NP>(as_const(a.cimg) + (size_t)(Nc + qq) * a.stride, l16);
+    }
     double* trw = a.traces + ((size_t)blockIdx.x * a.nsteps_chunk) * (Nc * JQ_NTR);
 
     if (a.first_chunk) {
+        // carry_q = tr(vr' Hsym_q lambdai) at t = T (see k_backward)
 #pragma unroll
         for (int q = 0; q < JQ_MAXNC; ++q)
-            if (q < Nc) carry[q] = -v_dot(u, mv<NP, true>(u, cimg + (size_t)q * NN, nb));
+            if (q < Nc) carry[q] = -v_dot(u, mv<NP, true>(u, Hs[q], nb));
     }
 
+    LaneOps<NP> o, nxt;
+    ops_load_first(o, a, l16);
     for (int n = 0; n < a.nsteps_chunk; ++n) {
-        const LaneOps o = lane_ops(a, n, NN);
+        ops_load_half(nxt, a, min(n + 1, a.nsteps_chunk - 1), l16);   // lands during this step
         Vec<NP> un, v05, vnew;
-        lane_state<NP>(a, o, ceps, ws, u, v, un, v05, vnew);
+        lane_state<NP>(a, o, sw, u, v, un, v05, vnew);
         // adjoint step! (src/StormerVerlet.jl:255-303) with nb = -lambda_i, see k_backward
         Vec<NP> R = mv<NP, true>(u, o.Kp05, nb);
-        if (a.use_shift) v_axpy_rows(R, ceps, ws, nb);
+        if (a.use_shift) v_axpy_rows(R, 1.0, sw, nb);
         R = mv<NP, false>(R, o.S0, mu);
         v_axpy_rows(R, cfw, wd, u);
         const Vec<NP> X = lane_horner<NP>(v_add(mu, R), R, o.S0, a.m);
         Vec<NP> L = mv<NP, true>(u, o.Kn0, X);
-        if (a.use_shift) v_axpy_rows(L, -ceps, ws, X);
+        if (a.use_shift) v_axpy_rows(L, -1.0, sw, X);
         Vec<NP> Qv = mv<NP, true>(u, o.Kn1, X);
-        if (a.use_shift) v_axpy_rows(Qv, -ceps, ws, X);
+        if (a.use_shift) v_axpy_rows(Qv, -1.0, sw, X);
         {
             Vec<NP> P = mv<NP, true>(u, o.S05, nb);
             v_axpy_rows(P, -cfw, wd, v05);
@@ -286,21 +315,23 @@ __global__ __launch_bounds__(64) void k_backward_lane(PropArgs a)
         const Vec<NP> nbn = lane_horner<NP>(v_add(v_add(nb, L), Qv), Qv, o.S05, a.m);
         const Vec<NP> Bq = v_add(nb, nbn);
         Vec<NP> G = mv<NP, false>(X, o.Kp05, nbn);
-        if (a.use_shift) v_axpy_rows(G, ceps, ws, nbn);
+        if (a.use_shift) v_axpy_rows(G, 1.0, sw, nbn);
         G = mv<NP, false>(G, o.S1, X);
         v_axpy_rows(G, cfw, wd, un);
         // traces (adjoint_grad_calc!, src/evalobjgrad.jl:2581-2618), weighted and summed over the wave
 #pragma unroll
         for (int q = 0; q < JQ_MAXNC; ++q) {
             if (q < Nc) {
-                cmat_t Hs = cimg + (size_t)q * NN;
-                cmat_t Ha = cimg + (size_t)(Nc + q) * NN;
-                const Vec<NP> HaX = mv<NP, true>(u, Ha, X);
+                if (!RESIDENT) {
+                    Hs[q] = mat_load<NP>(as_const(a.cimg) + (size_t)q * a.stride, l16);
+                    Ha[q] = mat_load<NP>(as_const(a.cimg) + (size_t)(Nc + q) * a.stride, l16);
+                }
+                const Vec<NP> HaX = mv<NP, true>(u, Ha[q], X);
                 const double t1 = wave_sum(v_dot(u, HaX) * wgt);
                 const double t3 = wave_sum(v_dot(un, HaX) * wgt);
-                const double t5 = wave_sum(-v_dot(v05, mv<NP, true>(u, Ha, Bq)) * wgt);
-                const double t2 = wave_sum(v_dot(v05, mv<NP, true>(u, Hs, X)) * wgt);
-                const double p4 = -v_dot(un, mv<NP, true>(u, Hs, nbn));
+                const double t5 = wave_sum(-v_dot(v05, mv<NP, true>(u, Ha[q], Bq)) * wgt);
+                const double t2 = wave_sum(v_dot(v05, mv<NP, true>(u, Hs[q], X)) * wgt);
+                const double p4 = -v_dot(un, mv<NP, true>(u, Hs[q], nbn));
                 const double t4 = wave_sum((p4 + carry[q]) * wgt);
                 carry[q] = p4;
                 if (lane == 0) {
@@ -317,6 +348,7 @@ __global__ __launch_bounds__(64) void k_backward_lane(PropArgs a)
         v = vnew;
         mu = G;
         nb = nbn;
+        ops_advance(o, nxt);
     }
     lane_store<NP>(a.state, 0, ncols, col, u);
     lane_store<NP>(a.state, 1, ncols, col, v);

@@ -365,24 +365,21 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         }
     }
 
-    // Lane kernels (jq_lane_kernels.h) for small Hilbert spaces: one lane per state column, operators through
-    // scalar loads.  Instantiated for NP in {2,4,6,8,12}.  JQ_LANE=0 disables them, JQ_LANE_MIN / JQ_LANE_MAX
-    // bound the column counts (samples x N) they are used for.
+    // Lane kernels (jq_lane_kernels.h) for small Hilbert spaces: one lane per state column, operator images in
+    // VGPRs read through DPP row broadcasts.  Instantiated for NP in {2,4,6,8}.  JQ_LANE=0 disables them,
+    // JQ_LANE_MIN / JQ_LANE_MAX bound the column counts (samples x N) they are used for.
     h->lane_np = 0;
     {
-        static const int nps[] = {2, 4, 6, 8, 12};
+        static const int nps[] = {2, 4, 6, 8};
         for (int v : nps)
             if (h->Ntot <= v) {
                 h->lane_np = v;
                 break;
             }
-        int mode = 1;   // JQ_LANE: 0 never, 1 where measured faster than the MFMA kernels (default), 2 always
-        if (const char* e = getenv("JQ_LANE")) mode = atoi(e);
-        if (mode == 0) h->lane_np = 0;
-        h->lane_stride = ((long long)h->lane_np * h->lane_np + 7) / 8 * 8;
-        // measured on MI355X (scripts/time_cases.py): NP <= 4 always faster; NP 6..8 from ~16k columns;
-        // NP = 12 slower than the MFMA slab kernels at every ensemble size tried
-        h->lane_min_cols = (mode == 2 || h->lane_np <= 4) ? 1 : (h->lane_np <= 8 ? 16384 : (1 << 30));
+        if (const char* e = getenv("JQ_LANE"))
+            if (atoi(e) == 0) h->lane_np = 0;
+        h->lane_stride = ((long long)h->lane_np * h->lane_np + 15) / 16 * 16;
+        h->lane_min_cols = 1;
         h->lane_max_cols = 1 << 30;
         if (const char* e = getenv("JQ_LANE_MIN")) h->lane_min_cols = atoi(e);
         if (const char* e = getenv("JQ_LANE_MAX")) h->lane_max_cols = atoi(e);
@@ -589,7 +586,7 @@ static int select_coop_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* 
 // lane kernels (one lane per column), NP = padded Hilbert dimension
 typedef void (*lane_init_t)(double*, long long, const double*, int, long long);
 typedef void (*lane_term_t)(double*, long long, const double*, const double*, int, int, double, double*);
-#define JQ_FOR_EACH_LANE(X) X(2) X(4) X(6) X(8) X(12)
+#define JQ_FOR_EACH_LANE(X) X(2) X(4) X(6) X(8)
 #define JQ_DECLL(np)                                                                                  \
     extern template __global__ void k_forward_lane<np>(PropArgs);                                     \
     extern template __global__ void k_backward_lane<np>(PropArgs);                                    \
@@ -852,7 +849,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
                 HIPCHK(h, hipEventRecord(h->ev[evi++], s));
                 hipLaunchKernelGGL(k_trace_reduce, dim3((unsigned)(((long long)nc * ntr + 255) / 256)), dim3(256), 0, s,
                                    h->d_traces, trace_rows, nc, ntr, h->d_R);
-                hipLaunchKernelGGL(k_gradacc, dim3((ncoeff + 63) / 64), dim3(64), 0, s, sp, h->d_R, h->d_tb, n0, nc, -dt,
+                hipLaunchKernelGGL(k_gradacc, dim3(ncoeff), dim3(JQ_GRADACC_THREADS), 0, s, sp, h->d_R, h->d_tb, n0, nc, -dt,
                                    h->d_grad + (size_t)pass * ncoeff);
                 mfma += (long long)nslabs * nc * (2 * (8 + 2 * h->m) * tiles + 4 * trace_tiles);
                 if (n0 == 0) mfma += (long long)nslabs * trace_tiles;

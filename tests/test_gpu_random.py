@@ -48,7 +48,10 @@ CASES = [
     # Ntot, N, Nc, Nfreq, nsteps, m, objFuncType, banded, chunk_steps
     (2, 1, 1, 1, 5, 0, 1, False, 0),
     (3, 3, 1, 2, 17, 2, 1, False, 4),
+    (4, 2, 4, 1, 11, 1, 3, False, 0),
+    (5, 4, 2, 1, 13, 3, 2, False, 3),
     (7, 2, 2, 1, 33, 3, 3, False, 7),
+    (8, 3, 3, 2, 9, 2, 1, False, 0),
     (16, 16, 1, 1, 9, 1, 1, False, 0),
     (17, 5, 2, 2, 21, 4, 2, False, 5),
     (30, 4, 3, 1, 12, 3, 1, True, 0),
@@ -63,24 +66,30 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("mode", ["auto", "slab"])
+@pytest.mark.parametrize("mode", ["auto", "slab", "nolane"])
 @pytest.mark.parametrize("cfg", CASES, ids=lambda c: "Ntot%d_N%d_Nc%d_f%d_m%d_o%d_%s_c%d" % (c[0], c[1], c[2], c[3], c[5], c[6], "band" if c[7] else "dense", c[8]))
 def test_random_problem_matches_oracle(jq, cfg, mode):
-    """mode 'auto': small batches run on the cooperative (row-split) kernels when Ntot > 16;
-    mode 'slab': JQ_COOP_MAX=0 forces the one-wave-per-slab kernels that large ensembles use."""
+    """mode 'auto': Ntot <= 8 runs on the lane kernels (one lane per column), Ntot > 16 with small batches on
+    the cooperative (row-split) kernels; mode 'slab': JQ_COOP_MAX=0 forces the one-wave-per-slab kernels
+    that large ensembles use; mode 'nolane': JQ_LANE=0 keeps the MFMA kernels covered for Ntot <= 8."""
     from oracle.oracle import Oracle
     Ntot, N, Nc, Nfreq, nsteps, m, oft, banded, chunk = cfg
+    if mode == "nolane" and Ntot > 8:
+        pytest.skip("lane kernels only exist for Ntot <= 8")
     rng = np.random.default_rng(1000 + Ntot * 31 + N)
     p, pcof = random_problem(jq, rng, Ntot, N, Nc, Nfreq, nsteps, m, oft, banded)
     if chunk:
         os.environ["JQ_CHUNK_STEPS"] = str(chunk)
     if mode == "slab":
         os.environ["JQ_COOP_MAX"] = "0"
+    if mode == "nolane":
+        os.environ["JQ_LANE"] = "0"
     try:
         wa = jq.Working_Arrays_HIP(p, pcof.size)
     finally:
         os.environ.pop("JQ_CHUNK_STEPS", None)
         os.environ.pop("JQ_COOP_MAX", None)
+        os.environ.pop("JQ_LANE", None)
     r = Oracle(p, use_sparse=False).traceobjgrad(pcof, history=True)
     objfv, tg, prim, sec, tinf, ig, lg = jq.traceobjgrad(pcof, p, wa, False, True)
     gn = np.linalg.norm(r["totalgrad"])
@@ -95,7 +104,8 @@ def test_random_problem_matches_oracle(jq, cfg, mode):
     assert np.max(np.abs(hist - r["history"])) < 1e-10
     # ragged ensemble: sample counts that leave slabs / workgroups partly empty
     sps = 16 // N
-    for nq in sorted({1, sps + 1, 4 * sps + 1}):
+    # (Ntot <= 8: also more columns than one 64-lane wave of the lane kernels holds)
+    for nq in sorted({1, sps + 1, 4 * sps + 1} | ({150 // N} if Ntot <= 8 else set())):
         nodes = 0.1 * rng.standard_normal(nq)
         weights = rng.random(nq)
         shift = rng.standard_normal(Ntot) * 0.05
