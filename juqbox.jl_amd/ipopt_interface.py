@@ -154,3 +154,147 @@ def traceobj_sweep(pcof, params, wa, ep_vals, shift=None):
     sh = _f64(shift) if shift is not None else None
     _lib.check(L.jq_traceobj_sweep(h, _ptr(pcof), pcof.size, _ptr(ep), ep.size, _ptr(sh), _ptr(out)), h)
     return out.reshape((ep.size, 4))
+
+
+# ---------------------------------------------------------------------------------------------
+# Optimiser loop on top of the callbacks.  The reference hands the callbacks to
+# Ipopt (L-BFGS Hessian approximation, bound constraints, optionally the leakage as one inequality
+# constraint); Ipopt is not available in this image, so run_optimizer drives the SAME callbacks with
+# scipy's bound-constrained quasi-Newton methods.  Names, arguments, memoisation, convergence history and
+# the early-stop thresholds follow src/ipopt_interface.jl:205-437; the iterates differ from Ipopt's
+# (different line search / barrier), the objective and gradient they see do not.
+def intermediate_par(alg_mod, iter_count, obj_value, inf_pr, inf_du, mu, d_norm, regularization_size,
+                     alpha_du, alpha_pr, ls_trials, params):
+    """src/ipopt_interface.jl:205-236: record the convergence history, stop on the thresholds."""
+    if params.saveConvHist:
+        params.objHist.append(obj_value)
+        params.dualInfidelityHist.append(inf_du)
+        params.primaryHist.append(params.lastTraceInfidelity)
+        params.secondaryHist.append(params.lastLeakIntegral)
+    if obj_value < params.objThreshold:
+        if not params.quiet:
+            print("Stopping because objective value = ", obj_value, " < threshold = ", params.objThreshold)
+        return False
+    if params.lastTraceInfidelity < params.traceInfidelityThreshold:
+        if not params.quiet:
+            print("Stopping because trace infidelity = ", params.lastTraceInfidelity, " < threshold = ",
+                  params.traceInfidelityThreshold)
+        return False
+    return True
+
+
+class OptimProblem:
+    """What setup_ipopt_problem returns: callbacks + options (the fields an IpoptProblem carries)."""
+
+    def __init__(self):
+        self.x = None
+        self.obj_val = None
+        self.status = None
+        self.n_iter = 0
+
+
+def setup_ipopt_problem(params, wa, nCoeff, minCoeff, maxCoeff, maxIter=50, lbfgsMax=10, startFromScratch=True,
+                        ipTol=1.0e-5, acceptTol=1.0e-5, acceptIter=15, nodes=(0.0,), weights=(1.0,),
+                        jacob_approx="exact"):
+    """src/ipopt_interface.jl:262-415."""
+    minCoeff = np.asarray(minCoeff, dtype=np.float64)
+    maxCoeff = np.asarray(maxCoeff, dtype=np.float64)
+    if minCoeff.size != nCoeff or maxCoeff.size != nCoeff:
+        raise ValueError("minCoeff and maxCoeff must have nCoeff elements")
+    rng = np.random.default_rng()
+    params.last_pcof = 1e9 * rng.random(nCoeff)              # :277-281: force the first evaluation
+    params.last_infidelity_grad = 1e9 * rng.random(nCoeff)
+    if params.objFuncType != 1:
+        params.last_leak_grad = 1e9 * rng.random(nCoeff)
+    nodes = np.asarray(nodes, dtype=np.float64)
+    weights = np.asarray(weights, dtype=np.float64)
+
+    prob = OptimProblem()
+    prob.params, prob.wa, prob.nCoeff = params, wa, int(nCoeff)
+    prob.x_L, prob.x_U = minCoeff, maxCoeff
+    prob.eval_f = lambda pcof: eval_f_par(pcof, params, wa, nodes, weights)
+
+    def _grad(pcof):
+        g = np.zeros(nCoeff)
+        eval_grad_f_par(pcof, g, params, wa, nodes, weights)
+        return g
+    prob.eval_grad_f = _grad
+    if params.objFuncType == 3:                               # :299-306: leakage as an inequality constraint
+        prob.m = 1
+        prob.g_L, prob.g_U = np.array([-2e19]), np.array([params.leak_ubound])
+    else:
+        prob.m = 0
+        prob.g_L, prob.g_U = np.zeros(0), np.zeros(0)
+
+    def _g(pcof):
+        g = np.zeros(1)
+        eval_g_par(pcof, g, params, wa, nodes, weights)
+        return g
+
+    def _jac_g(pcof):
+        jac = np.zeros(nCoeff)
+        if _stale(pcof, params):     # the reference's callback returns unfilled in this case (:169-173); Ipopt
+            eval_f_g_grad(pcof, params, wa, nodes, weights, True)   # always calls eval_g first -- here we recompute
+        eval_jac_g_par(pcof, [], [], jac, params, wa, nodes, weights)
+        return jac
+    prob.eval_g, prob.eval_jac_g = _g, _jac_g
+    prob.intermediate = lambda it, obj, inf_du: intermediate_par(0, it, obj, 0.0, inf_du, 0.0, 0.0, 0.0, 0.0, 0.0, 0,
+                                                                 params)
+    prob.options = dict(max_iter=int(maxIter), limited_memory_max_history=int(lbfgsMax), tol=float(ipTol),
+                        acceptable_tol=float(acceptTol), acceptable_iter=int(acceptIter),
+                        warm_start=not startFromScratch, jacobian_approximation=jacob_approx)
+    if not params.quiet:
+        print("Optimizer parameters: max # iterations = ", maxIter)
+        print("Optimizer parameters: max history L-BFGS = ", lbfgsMax)
+        print("Optimizer parameters: tol = ", ipTol)
+    return prob
+
+
+class _Stop(Exception):
+    pass
+
+
+def run_optimizer(prob, pcof0, baseName=""):
+    """src/ipopt_interface.jl:417-437: optimise the control vector, optionally save it as <baseName>.jld2."""
+    from scipy import optimize
+    from .pcof_io import save_pcof
+    params = prob.params
+    x0 = np.clip(np.array(pcof0, dtype=np.float64), prob.x_L, prob.x_U)     # copy: pcof0 is not overwritten
+    opt = prob.options
+    bounds = optimize.Bounds(prob.x_L, prob.x_U)
+    state = {"it": 0, "x": x0.copy()}
+
+    def callback(xk, *_):
+        state["it"] += 1
+        state["x"] = np.array(xk, dtype=np.float64)
+        obj = prob.eval_f(xk)                      # memoised: no extra propagation for an accepted iterate
+        g = prob.eval_grad_f(xk)
+        # projected-gradient norm as the dual infeasibility measure of the bound-constrained problem
+        pg = np.where((xk <= prob.x_L) & (g > 0) | (xk >= prob.x_U) & (g < 0), 0.0, g)
+        if not prob.intermediate(state["it"], obj, float(np.max(np.abs(pg))) if pg.size else 0.0):
+            raise _Stop()
+
+    if not params.quiet:
+        print("*** Starting the optimization ***")
+    try:
+        if prob.m == 0:
+            res = optimize.minimize(prob.eval_f, x0, jac=prob.eval_grad_f, method="L-BFGS-B", bounds=bounds,
+                                    callback=callback,
+                                    options=dict(maxiter=opt["max_iter"], maxcor=opt["limited_memory_max_history"],
+                                                 ftol=0.0, gtol=opt["tol"]))
+        else:
+            cons = [dict(type="ineq", fun=lambda x: prob.g_U - prob.eval_g(x), jac=lambda x: -prob.eval_jac_g(x)[None, :])]
+            res = optimize.minimize(prob.eval_f, x0, jac=prob.eval_grad_f, method="SLSQP", bounds=bounds,
+                                    constraints=cons, callback=callback,
+                                    options=dict(maxiter=opt["max_iter"], ftol=opt["tol"] * 1e-3))
+        x, prob.status = np.array(res.x), str(res.message)
+    except _Stop:
+        x, prob.status = state["x"], "stopped by intermediate callback (threshold reached)"
+    prob.x = x
+    prob.obj_val = prob.eval_f(x)
+    prob.n_iter = state["it"]
+    if len(baseName) > 0:
+        save_pcof(baseName + ".jld2", x)
+        if not params.quiet:
+            print("Saved B-spline parameters on binary jld2-file '%s.jld2'" % baseName)
+    return x
