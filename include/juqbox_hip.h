@@ -121,6 +121,21 @@ int jq_traceobjgrad(jq_handle *h, const double *pcof, int32_t ncoeff, int32_t ev
 int jq_state_history(jq_handle *h, const double *pcof, int32_t ncoeff, double *ur, double *ui);
 
 /*
+ * Device-side consumers of the state history, so that the [Ntot x N x (nsteps+1)] arrays (199 MB at cnot3)
+ * never leave the GPU.  Replaces what the reference derives from usaver/usavei on the host:
+ *   pop    : [ngroups x N x nout] (column-major) level populations  sum_{rows r in group g} |psi[r,q,k*every]|^2
+ *            for the sampled steps k*every, k = 0..nout-1, nout = nsteps/every + 1.  With group_of_row == NULL
+ *            (ngroups == Ntot) these are the curves of plotunitary / plotspecified (src/plotstatectrl.jl);
+ *            with group_of_row[r] = third-subsystem index they are marginalize3 (src/plotstatectrl.jl:405-423).
+ *            Rows with group_of_row[r] < 0 are skipped.  May be NULL (then ngroups/every/nout are ignored).
+ *   maxpop : [Ntot] max over columns and ALL time steps of |psi[r,q,:]|^2 -- the forbidden-level maxima of the
+ *            verbose branch (src/evalobjgrad.jl:1004-1018).  May be NULL.
+ * Errors: JQ_EINVAL for NULL/size errors (nout must equal nsteps/every + 1, group indices < ngroups).
+ */
+int jq_state_populations(jq_handle *h, const double *pcof, int32_t ncoeff, const int32_t *group_of_row, int32_t ngroups,
+                         int32_t every, int32_t nout, double *pop, double *maxpop);
+
+/*
  * Replaces eval_f_g_grad!(pcof, params, wa, nodes, weights, compute_adjoint)
  * (src/ipopt_interface.jl:24-70): for each quadrature node ep_i the drift Hamiltonian is
  * Hconst + ep_i*diag(shift) and the four weighted sums are accumulated.  All nquad evaluations run

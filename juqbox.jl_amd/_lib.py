@@ -43,6 +43,8 @@ SYMBOLS = {
     "jq_update_wmat_diag": (ctypes.c_int, [ctypes.c_void_p, c_dp]),
     "jq_traceobjgrad": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_i32, c_i32, c_dp, c_dp, c_dp, c_dp]),
     "jq_state_history": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_i32, c_dp, c_dp]),
+    "jq_state_populations": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_i32, ctypes.POINTER(ctypes.c_int32), c_i32, c_i32, c_i32,
+                                            c_dp, c_dp]),
     "jq_eval_f_g_grad": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_i32, c_dp, c_dp, c_i32, c_dp, c_i32, c_dp, c_dp, c_dp]),
     "jq_traceobj_sweep": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_i32, c_dp, c_i32, c_dp, c_dp]),
     "jq_last_timing": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(jq_timing)]),

@@ -239,3 +239,45 @@ __global__ __launch_bounds__(JQ_GRADACC_THREADS) void k_gradacc(SplineArgs s, co
     }
     if (threadIdx.x == 0) grad[idx] += red[0];
 }
+
+// ---------------------------------------------------------------------------------------------
+// Consumers of the state history on the device (jq_state_populations).  hist_r/hist_i: [Ntot][N][nsteps+1]
+// column-major (row fastest).
+// pop[g + ngroups*(q + N*k)] = sum_{rows r: group(r) == g} |psi[r, q, k*every]|^2.   thread per (q, k)
+__global__ void k_pop_groups(const double* __restrict__ hr, const double* __restrict__ hi, int Ntot, int N, int every,
+                             int nout, const int* __restrict__ group_of_row, int ngroups, double* __restrict__ pop)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)N * nout) return;
+    const int q = (int)(i % N);
+    const long long k = i / N;
+    const size_t src = ((size_t)k * every * N + q) * Ntot;
+    double* out = pop + (size_t)ngroups * i;
+    for (int g = 0; g < ngroups; ++g) out[g] = 0.0;
+    for (int r = 0; r < Ntot; ++r) {
+        const int g = group_of_row ? group_of_row[r] : r;
+        if (g < 0) continue;
+        const double a = hr[src + r], b = hi[src + r];
+        out[g] += a * a + b * b;       // rows of a group are summed in increasing row order, like the reference
+    }
+}
+
+// maxpop[r] = max_{q, step} |psi[r, q, step]|^2.   block per row
+__global__ __launch_bounds__(256) void k_pop_max(const double* __restrict__ hr, const double* __restrict__ hi, int Ntot,
+                                                 long long ncolsteps, double* __restrict__ maxpop)
+{
+    __shared__ double red[256];
+    const int r = blockIdx.x;
+    double m = 0.0;
+    for (long long j = threadIdx.x; j < ncolsteps; j += 256) {
+        const double a = hr[(size_t)j * Ntot + r], b = hi[(size_t)j * Ntot + r];
+        m = fmax(m, a * a + b * b);
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + w]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) maxpop[r] = red[0];
+}

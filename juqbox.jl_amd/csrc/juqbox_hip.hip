@@ -959,6 +959,62 @@ extern "C" int jq_state_history(jq_handle* h, const double* pcof, int32_t ncoeff
     return rc;
 }
 
+extern "C" int jq_state_populations(jq_handle* h, const double* pcof, int32_t ncoeff, const int32_t* group_of_row,
+                                    int32_t ngroups, int32_t every, int32_t nout, double* pop, double* maxpop)
+{
+    if (!h) return JQ_EINVAL;
+    if (!pcof) return fail(h, JQ_EINVAL, "jq_state_populations: NULL pointer");
+    if (!pop && !maxpop) return fail(h, JQ_EINVAL, "jq_state_populations: pop and maxpop are both NULL");
+    if (pop) {
+        if (every < 1 || nout != h->nsteps / every + 1)
+            return fail(h, JQ_EINVAL, "jq_state_populations: need every >= 1 and nout == nsteps/every + 1");
+        if (ngroups < 1 || (!group_of_row && ngroups != h->Ntot))
+            return fail(h, JQ_EINVAL, "jq_state_populations: ngroups must be Ntot when group_of_row is NULL");
+        if (group_of_row)
+            for (int r = 0; r < h->Ntot; ++r)
+                if (group_of_row[r] >= ngroups) return fail(h, JQ_EINVAL, "jq_state_populations: group index >= ngroups");
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t len = (size_t)h->Ntot * h->N * (h->nsteps + 1);
+    const size_t npop = pop ? (size_t)ngroups * h->N * nout : 0;
+    double *d_r = nullptr, *d_i = nullptr, *d_pop = nullptr, *d_max = nullptr;
+    int* d_grp = nullptr;
+    int rc = JQ_OK;
+    auto cleanup = [&]() {
+        (void)hipFree(d_r); (void)hipFree(d_i); (void)hipFree(d_pop); (void)hipFree(d_max); (void)hipFree(d_grp);
+    };
+    if (hipMalloc((void**)&d_r, len * sizeof(double)) != hipSuccess || hipMalloc((void**)&d_i, len * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&d_pop, std::max<size_t>(npop, 1) * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&d_max, (size_t)h->Ntot * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&d_grp, (size_t)h->Ntot * sizeof(int)) != hipSuccess) {
+        cleanup();
+        return fail(h, JQ_ENOMEM, "jq_state_populations: out of device memory");
+    }
+    (void)hipMemset(d_r, 0, len * sizeof(double));
+    (void)hipMemset(d_i, 0, len * sizeof(double));
+    EvalOut o;
+    rc = run_eval(h, pcof, ncoeff, 1, nullptr, nullptr, nullptr, false, d_r, d_i, &o);
+    if (rc == JQ_OK) {
+        // usaver[:,:,1] = Uinit ; usavei[:,:,1] = 0 (src/evalobjgrad.jl:679-680)
+        bool ok = hipMemcpy(d_r, h->Uinit.data(), (size_t)h->Ntot * h->N * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+        if (pop && ok) {
+            if (group_of_row) ok = hipMemcpy(d_grp, group_of_row, (size_t)h->Ntot * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
+            const long long nthr = (long long)h->N * nout;
+            hipLaunchKernelGGL(k_pop_groups, dim3((unsigned)((nthr + 127) / 128)), dim3(128), 0, h->stream, d_r, d_i, h->Ntot, h->N,
+                               every, nout, group_of_row ? d_grp : nullptr, ngroups, d_pop);
+        }
+        if (maxpop && ok)
+            hipLaunchKernelGGL(k_pop_max, dim3(h->Ntot), dim3(256), 0, h->stream, d_r, d_i, h->Ntot,
+                               (long long)h->N * (h->nsteps + 1), d_max);
+        ok = ok && hipStreamSynchronize(h->stream) == hipSuccess && hipGetLastError() == hipSuccess;
+        if (pop && ok) ok = hipMemcpy(pop, d_pop, npop * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
+        if (maxpop && ok) ok = hipMemcpy(maxpop, d_max, (size_t)h->Ntot * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
+        if (!ok) rc = fail(h, JQ_EHIP, "jq_state_populations: device reduction or copy failed");
+    }
+    cleanup();
+    return rc;
+}
+
 extern "C" int jq_eval_f_g_grad(jq_handle* h, const double* pcof, int32_t ncoeff, const double* nodes, const double* weights,
                                 int32_t nquad, const double* shift, int32_t compute_adjoint, double* out2, double* infid_grad,
                                 double* leak_grad)
