@@ -3,6 +3,7 @@
 // condition, trace reduction and gradient assembly (gradbcarrier2! as an 18-entry scatter).
 #pragma once
 #include "jq_kernels.h"
+#include "jq_rowlane_kernels.h"
 
 struct SplineArgs {
     const double* pcof;   // [nCoeff]
@@ -280,4 +281,54 @@ __global__ __launch_bounds__(256) void k_pop_max(const double* __restrict__ hr, 
         __syncthreads();
     }
     if (threadIdx.x == 0) maxpop[r] = red[0];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row-lane kernels (jq_rowlane_kernels.h): initial state and terminal condition in their state-file layout
+// state file <- (Uinit, 0, ...).  uinit: [N][16] (column ic of Uinit, zero padded).  grid = waves, block = 64
+__global__ void k_init_state_rowlane(double* state, long long nw, const double* __restrict__ uinit, int N, long long ncols_used)
+{
+    const int lane = threadIdx.x;
+    const long long w = blockIdx.x;
+    const long long col = 4 * w + (lane >> 4);
+    for (int r = 0; r < JQ_ROWLANE_ROWS; ++r) {
+        double val = 0.0;
+        if (r == 0 && col < ncols_used) val = uinit[(col % N) * 16 + (lane & 15)];
+        state[((size_t)r * nw + w) * 64 + lane] = val;
+    }
+}
+
+// fidelity, leak and adjoint terminal condition per sample (thread per sample; see k_terminal)
+__global__ void k_terminal_rowlane(double* state, long long nw, const double* __restrict__ vtr, const double* __restrict__ vti,
+                                   int N, int nsamples, double leak_scale, double* res)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsamples) return;
+    double re = 0.0, im = 0.0, lk = 0.0;
+    for (int ic = 0; ic < N; ++ic) {
+        const long long col = (long long)s * N + ic;
+        const size_t base = (size_t)(col >> 2) * 64 + (size_t)(col & 3) * 16;
+        for (int r = 0; r < 16; ++r) {
+            const double u = state[base + r], v = state[(size_t)nw * 64 + base + r];
+            const double tr = vtr[ic * 16 + r], ti = vti[ic * 16 + r];
+            re += u * tr - v * ti;
+            im += u * ti + v * tr;
+            lk += state[(size_t)(JQ_ROWLANE_ARRAYS + JQ_MAXNC) * nw * 64 + base + r];
+        }
+    }
+    re /= N;
+    im /= N;
+    for (int ic = 0; ic < N; ++ic) {
+        const long long col = (long long)s * N + ic;
+        const size_t base = (size_t)(col >> 2) * 64 + (size_t)(col & 3) * 16;
+        for (int r = 0; r < 16; ++r) {
+            const double tr = vtr[ic * 16 + r], ti = vti[ic * 16 + r];
+            state[(size_t)2 * nw * 64 + base + r] = (re * tr + im * ti) / N;       // lambda_r
+            state[(size_t)3 * nw * 64 + base + r] = -((im * tr - re * ti) / N);    // nb = -lambda_i
+        }
+    }
+    res[(size_t)s * 4 + 0] = 1.0 - (re * re + im * im);
+    res[(size_t)s * 4 + 1] = leak_scale * lk;
+    res[(size_t)s * 4 + 2] = re;
+    res[(size_t)s * 4 + 3] = im;
 }

@@ -1,0 +1,283 @@
+// jq_rowlane_kernels.h -- latency-optimised propagators for SMALL Hilbert spaces and SMALL batches:
+// one lane per (row, column), four state columns per wave.
+//
+// The lane kernels (jq_lane_kernels.h) give a lane a whole column: NP*NP dependent-ish FMAs per product, which
+// is the right shape for throughput (64 columns per wave) but leaves the latency of one evaluation at
+// NP*NP*4 cycles per product.  Ensembles of the sizes Juqbox runs (1 ... a few thousand samples) do not fill
+// the chip, so what the user waits for is exactly that latency.  Here the product is spread over the lanes:
+//
+//   lane = 16*c + i  holds element i of column c (c = 0..3: the four 16-lane DPP rows of the wave),
+//   an operator row i lives in the lane's registers (M.r[j] = M[i][j]),
+//   y_i = c_i + sum_j M[i][j] * x_j   is   NP x  v_fmac_f64_dpp  y, x, M.r[j]  row_newbcast:j
+//
+// i.e. the DPP operand is now the STATE vector (lane j of the row broadcast to the row) and the matrix
+// element is the ordinary per-lane operand: NP FMAs per product instead of NP*NP, a state vector is ONE
+// register pair.  The DPP operand is always freshly written by VALU instructions, so the 2-wait-state
+// hazard (jq_lane_kernels.h) is systematic here: every product starts with s_nop 1 behind a scheduling
+// barrier, and scripts/check_dpp_hazard.py verifies the final ISA.
+//
+// Throughput per column is 16/NP x 1..1.5 lower than the lane kernels (idle lanes for NP < 16, two accumulator
+// chains), so the host uses these kernels only while the batch is small (run_eval, juqbox_hip.hip).
+//
+// Layouts:  operator images: [16 rows][NPJ] row-major, zero padded (stride = 16*NPJ doubles = a.stride);
+//           stream point j -> K at (2j)*stride, S at (2j+1)*stride;   constants a.cimg: [Hsym_q | Hanti_q];
+//           state file: [array][wave][64 lanes];   a.colinfo: [eps per column | weight per column], 4 per wave.
+#pragma once
+#include "jq_lane_kernels.h"
+
+template <int NPJ>
+struct RowMat {
+    double r[NPJ];
+};
+
+template <int NPJ>
+__device__ __forceinline__ RowMat<NPJ> row_load(cmat_t img, int row)
+{
+    RowMat<NPJ> m;
+    cmat_t p = img + row * NPJ;
+#pragma unroll
+    for (int j = 0; j < NPJ; ++j) m.r[j] = p[j];
+    return m;
+}
+
+// the same from an LDS copy of the image (constant images of the backward sweep when NPJ > 8)
+template <int NPJ>
+__device__ __forceinline__ RowMat<NPJ> row_load_lds(const double* img, int row)
+{
+    RowMat<NPJ> m;
+    const double* p = img + row * NPJ;
+#pragma unroll
+    for (int j = 0; j < NPJ; ++j) m.r[j] = p[j];
+    return m;
+}
+
+// y += x[lane J of the row] * m
+template <int J>
+__device__ __forceinline__ void fma_xbcast(double& y, double x, double m)
+{
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(y) : "v"(x), "v"(m), "n"(J));
+}
+template <int NPJ, int... J>
+__device__ __forceinline__ void rmv_fold(double& ya, double& yb, double x, const RowMat<NPJ>& M, std::integer_sequence<int, J...>)
+{
+    (fma_xbcast<J>((J & 1) ? yb : ya, x, M.r[J]), ...);
+}
+// y = c + M x : two accumulator chains (even / odd j)
+template <int NPJ, bool ZEROC>
+__device__ __forceinline__ double rmv(double c, const RowMat<NPJ>& M, double x)
+{
+    double ya = ZEROC ? 0.0 : c, yb = 0.0;
+    // x was (almost always) just written by VALU instructions: DPP read-after-write hazard, 2 wait states
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 1");
+    __builtin_amdgcn_sched_barrier(0);
+    rmv_fold<NPJ>(ya, yb, x, M, std::make_integer_sequence<int, NPJ>{});
+    return ya + yb;
+}
+// bpa + sum_{j=1..m} S^j A  (Horner form)
+template <int NPJ>
+__device__ __forceinline__ double row_horner(double bpa, double A, const RowMat<NPJ>& S, int m)
+{
+    if (m <= 0) return bpa;
+    double Y = A;
+    for (int j = 1; j < m; ++j) Y = rmv<NPJ, false>(A, S, Y);
+    return rmv<NPJ, false>(bpa, S, Y);
+}
+
+template <int NPJ>
+struct RowOps {
+    RowMat<NPJ> Kn0, S0, Kp05, S05, Kn1, S1;
+};
+template <int NPJ>
+__device__ __forceinline__ void rops_load_half(RowOps<NPJ>& o, const PropArgs& a, int n, int row)
+{
+    cmat_t s = as_const(a.stream) + (size_t)(2 * (2 * n + 1)) * a.stride;
+    o.Kp05 = row_load<NPJ>(s, row);
+    o.S05 = row_load<NPJ>(s + a.stride, row);
+    o.Kn1 = row_load<NPJ>(s + 2 * a.stride, row);
+    o.S1 = row_load<NPJ>(s + 3 * a.stride, row);
+}
+template <int NPJ>
+__device__ __forceinline__ void rops_advance(RowOps<NPJ>& o, const RowOps<NPJ>& nxt)
+{
+    o.Kn0 = o.Kn1;
+    o.S0 = o.S1;
+    o.Kp05 = nxt.Kp05;
+    o.S05 = nxt.S05;
+    o.Kn1 = nxt.Kn1;
+    o.S1 = nxt.S1;
+}
+
+// One Stormer-Verlet state step (forward step!, src/StormerVerlet.jl:461-504), accumulate form; sw = eps*c*ws_i
+template <int NPJ>
+__device__ __forceinline__ void row_state(const PropArgs& a, const RowOps<NPJ>& o, double sw, double u, double v, double& un,
+                                          double& v05, double& vnew)
+{
+    double A = rmv<NPJ, true>(0.0, o.Kp05, u);
+    if (a.use_shift) A = fma(sw, u, A);
+    A = rmv<NPJ, false>(A, o.S05, v);
+    v05 = row_horner<NPJ>(v + A, A, o.S05, a.m);
+    const double vN = rmv<NPJ, false>(v05, o.S05, v05);
+    un = rmv<NPJ, false>(u, o.Kn0, v05);
+    if (a.use_shift) un = fma(-sw, v05, un);
+    un = rmv<NPJ, false>(un, o.S0, u);
+    A = rmv<NPJ, true>(0.0, o.Kn1, v05);
+    if (a.use_shift) A = fma(-sw, v05, A);
+    A = rmv<NPJ, false>(A, o.S1, un);
+    un = row_horner<NPJ>(un + A, A, o.S1, a.m);
+    vnew = rmv<NPJ, false>(vN, o.Kp05, un);
+    if (a.use_shift) vnew = fma(sw, un, vnew);
+}
+
+#define JQ_ROWLANE_ARRAYS 4                                   // U, V, MU, NB
+#define JQ_ROWLANE_ROWS (JQ_ROWLANE_ARRAYS + JQ_MAXNC + 1)    // + carry rows + leak row
+
+// Forward sweep of one chunk; a.nslabs = number of waves (4 columns each), grid = a.nslabs, block = 64.
+template <int NPJ>
+__global__ __launch_bounds__(64) void k_forward_rowlane(PropArgs a)
+{
+    const int lane = threadIdx.x;
+    const int row = lane & 15;
+    const long long w = blockIdx.x, nw = a.nslabs;
+    const long long col = 4 * w + (lane >> 4);
+    const double wd = a.tabs[row];
+    double* st = a.state + w * 64 + lane;
+    double u = st[0], v = st[nw * 64];
+    double leak = st[(size_t)(JQ_ROWLANE_ARRAYS + JQ_MAXNC) * nw * 64];
+    const double sw = 0.5 * a.h * a.colinfo[col] * a.tabs[16 + row];
+    RowOps<NPJ> o, nxt;
+    o.Kn0 = row_load<NPJ>(as_const(a.stream), row);
+    o.S0 = row_load<NPJ>(as_const(a.stream) + a.stride, row);
+    rops_load_half(o, a, 0, row);
+    for (int n = 0; n < a.nsteps_chunk; ++n) {
+        rops_load_half(nxt, a, min(n + 1, a.nsteps_chunk - 1), row);   // lands during this step
+        double un, v05, vnew;
+        leak = fma(wd, u * u, leak);
+        row_state<NPJ>(a, o, sw, u, v, un, v05, vnew);
+        u = un;
+        v = vnew;
+        leak = fma(wd, u * u + 2.0 * v05 * v05, leak);
+        if (a.hist_r && col < a.N && row < a.Ntot) {
+            const size_t off = (size_t)(a.step0 + n + 1) * a.Ntot * a.N + (size_t)col * a.Ntot + row;
+            a.hist_r[off] = u;
+            a.hist_i[off] = -v;
+        }
+        rops_advance(o, nxt);
+    }
+    st[0] = u;
+    st[nw * 64] = v;
+    st[(size_t)(JQ_ROWLANE_ARRAYS + JQ_MAXNC) * nw * 64] = leak;
+}
+
+// Backward sweep of one chunk (state re-integration, adjoint step, trace scalars per wave and step).
+template <int NPJ>
+__global__ __launch_bounds__(64) void k_backward_rowlane(PropArgs a)
+{
+    const int lane = threadIdx.x;
+    const int row = lane & 15;
+    const long long w = blockIdx.x, nw = a.nslabs;
+    const long long col = 4 * w + (lane >> 4);
+    const int Nc = a.Ncoupled;
+    const double wd = a.tabs[row];
+    double* st = a.state + w * 64 + lane;
+    double u = st[0], v = st[nw * 64], mu = st[2 * nw * 64], nb = st[3 * nw * 64];
+    const double sw = 0.5 * a.h * a.colinfo[col] * a.tabs[16 + row];
+    const double wgt = a.colinfo[4 * nw + col];
+    const double cfw = (a.forced ? 0.5 * a.h * a.tinv : 0.0) * wd;
+    double carry[JQ_MAXNC];
+    // constant images: register resident for NPJ <= 8; for NPJ = 12, 16 (24..32 registers per image row) they
+    // live in LDS (2*Nc*stride doubles, copied once) and a row is read right before its two products
+    constexpr bool RESIDENT = (NPJ <= 8);
+    extern __shared__ double lds_c[];
+    if (!RESIDENT) {
+        for (int i = lane; i < 2 * Nc * (int)a.stride; i += 64) lds_c[i] = a.cimg[i];
+        __syncthreads();
+    }
+    RowMat<NPJ> Hs[JQ_MAXNC], Ha[JQ_MAXNC];
+#pragma unroll
+    for (int q = 0; q < JQ_MAXNC; ++q) {
+        const int qq = min(q, Nc - 1);
+        carry[q] = (q < Nc) ? st[(size_t)(JQ_ROWLANE_ARRAYS + q) * nw * 64] : 0.0;
+        if (RESIDENT || a.first_chunk) Hs[q] = row_load<NPJ>(as_const(a.cimg) + (size_t)qq * a.stride, row);
+        if (RESIDENT) Ha[q] = row_load<NPJ>(as_const(a.cimg) + (size_t)(Nc + qq) * a.stride, row);
+    }
+    double* trw = a.traces + ((size_t)w * a.nsteps_chunk) * (Nc * JQ_NTR);
+
+    if (a.first_chunk) {
+        // per-lane part of carry_q = tr(vr' Hsym_q lambdai) at t = T (see k_backward); summed with the traces
+#pragma unroll
+        for (int q = 0; q < JQ_MAXNC; ++q)
+            if (q < Nc) carry[q] = -u * rmv<NPJ, true>(0.0, Hs[q], nb);
+    }
+
+    RowOps<NPJ> o, nxt;
+    o.Kn0 = row_load<NPJ>(as_const(a.stream), row);
+    o.S0 = row_load<NPJ>(as_const(a.stream) + a.stride, row);
+    rops_load_half(o, a, 0, row);
+    for (int n = 0; n < a.nsteps_chunk; ++n) {
+        rops_load_half(nxt, a, min(n + 1, a.nsteps_chunk - 1), row);   // lands during this step
+        double un, v05, vnew;
+        row_state<NPJ>(a, o, sw, u, v, un, v05, vnew);
+        // adjoint step! (src/StormerVerlet.jl:255-303) with nb = -lambda_i, see k_backward
+        double R = rmv<NPJ, true>(0.0, o.Kp05, nb);
+        if (a.use_shift) R = fma(sw, nb, R);
+        R = rmv<NPJ, false>(R, o.S0, mu);
+        R = fma(cfw, u, R);
+        const double X = row_horner<NPJ>(mu + R, R, o.S0, a.m);
+        double L = rmv<NPJ, true>(0.0, o.Kn0, X);
+        if (a.use_shift) L = fma(-sw, X, L);
+        double Qv = rmv<NPJ, true>(0.0, o.Kn1, X);
+        if (a.use_shift) Qv = fma(-sw, X, Qv);
+        {
+            double P = rmv<NPJ, true>(0.0, o.S05, nb);
+            P = fma(-cfw, v05, P);
+            L += P;
+            Qv += P;
+        }
+        Qv = rmv<NPJ, false>(Qv, o.S05, L);
+        const double nbn = row_horner<NPJ>((nb + L) + Qv, Qv, o.S05, a.m);
+        const double Bq = nb + nbn;
+        double G = rmv<NPJ, false>(X, o.Kp05, nbn);
+        if (a.use_shift) G = fma(sw, nbn, G);
+        G = rmv<NPJ, false>(G, o.S1, X);
+        G = fma(cfw, un, G);
+        // traces (adjoint_grad_calc!, src/evalobjgrad.jl:2581-2618), weighted and summed over the wave
+#pragma unroll
+        for (int q = 0; q < JQ_MAXNC; ++q) {
+            if (q < Nc) {
+                if (!RESIDENT) {
+                    Ha[q] = row_load_lds<NPJ>(lds_c + (size_t)(Nc + q) * a.stride, row);
+                    Hs[q] = row_load_lds<NPJ>(lds_c + (size_t)q * a.stride, row);
+                }
+                const double HaX = rmv<NPJ, true>(0.0, Ha[q], X);
+                const double t1 = wave_sum(u * HaX * wgt);
+                const double t3 = wave_sum(un * HaX * wgt);
+                const double t5 = wave_sum(-v05 * rmv<NPJ, true>(0.0, Ha[q], Bq) * wgt);
+                const double t2 = wave_sum(v05 * rmv<NPJ, true>(0.0, Hs[q], X) * wgt);
+                const double p4 = -un * rmv<NPJ, true>(0.0, Hs[q], nbn);
+                const double t4 = wave_sum((p4 + carry[q]) * wgt);
+                carry[q] = p4;
+                if (lane == 0) {
+                    double* tr = trw + (size_t)n * (Nc * JQ_NTR) + q * JQ_NTR;
+                    tr[0] = t1;
+                    tr[1] = t2;
+                    tr[2] = t3;
+                    tr[3] = t4;
+                    tr[4] = t5;
+                }
+            }
+        }
+        u = un;
+        v = vnew;
+        mu = G;
+        nb = nbn;
+        rops_advance(o, nxt);
+    }
+    st[0] = u;
+    st[nw * 64] = v;
+    st[2 * nw * 64] = mu;
+    st[3 * nw * 64] = nb;
+#pragma unroll
+    for (int q = 0; q < JQ_MAXNC; ++q)
+        if (q < Nc) st[(size_t)(JQ_ROWLANE_ARRAYS + q) * nw * 64] = carry[q];
+}

@@ -10,6 +10,7 @@
 #include "jq_coop_kernels.h"
 #include "jq_kernels.h"
 #include "jq_lane_kernels.h"
+#include "jq_rowlane_kernels.h"
 
 #include <algorithm>
 #include <cmath>
@@ -45,12 +46,16 @@ struct jq_handle {
     int lane_np = 0;            // > 0: lane kernels available (Ntot <= 12), padded Hilbert dimension NP
     long long lane_stride = 0;  // doubles per plain NP x NP operator image (padded to 64 B)
     int lane_min_cols = 0, lane_max_cols = 0;   // column counts (samples x N) routed to the lane kernels
+    int rl_npj = 0;             // > 0: row-lane kernels available (Ntot <= 16), padded row length NPJ
+    long long rl_stride = 0;    // doubles per [16][NPJ] operator image
+    int rl_max_cols = 0;        // batches of at most this many columns use the row-lane kernels (latency regime)
     std::vector<double> Hconst, Hsym, Hanti, Uinit, Utr, Uti, wd, cfreq;
     std::vector<double> tf, tb;
     // device buffers (owned)
     double *d_cimg = nullptr, *d_park = nullptr;
     double *d_himg_c = nullptr, *d_cimg_c = nullptr;   // operator images in the cooperative layout
     double *d_himg_l = nullptr, *d_uinit_l = nullptr, *d_vtr_l = nullptr, *d_vti_l = nullptr;   // lane kernels
+    double *d_himg_r = nullptr, *d_uinit_r = nullptr, *d_vtr_r = nullptr, *d_vti_r = nullptr;   // row-lane kernels
     double *d_himg = nullptr, *d_uimg = nullptr, *d_vtr = nullptr, *d_vti = nullptr, *d_tabs = nullptr;
     double *d_tf = nullptr, *d_tb = nullptr, *d_cfreq = nullptr, *d_pcof = nullptr;
     double *d_stream = nullptr, *d_pq = nullptr;
@@ -162,6 +167,13 @@ static void column_image(const double* A, int Ntot, int N, int NP, double* img)
         for (int r = 0; r < Ntot; ++r) img[(size_t)c * NP + r] = A[r + (size_t)Ntot * c];
 }
 
+// [16][NPJ] row-major image of a column-major Ntot x Ntot matrix (row-lane kernels), zero padded
+static void rowlane_image(const double* M, int Ntot, int NPJ, double* img)
+{
+    for (int i = 0; i < Ntot; ++i)
+        for (int j = 0; j < Ntot; ++j) img[(size_t)i * NPJ + j] = M[i + (size_t)Ntot * j];
+}
+
 template <typename T>
 static int dev_alloc(jq_handle* h, T** p, size_t count)
 {
@@ -214,6 +226,15 @@ static int upload_operators(jq_handle* h)
         }
         HIPCHK(h, hipMemcpy(h->d_himg_l, il.data(), il.size() * sizeof(double), hipMemcpyHostToDevice));
     }
+    if (h->rl_npj > 0) {
+        std::vector<double> ir((size_t)(1 + 2 * h->Nc) * h->rl_stride, 0.0);
+        rowlane_image(h->Hconst.data(), h->Ntot, h->rl_npj, ir.data());
+        for (int q = 0; q < h->Nc; ++q) {
+            rowlane_image(h->Hsym.data() + q * nn, h->Ntot, h->rl_npj, ir.data() + (size_t)(1 + q) * h->rl_stride);
+            rowlane_image(h->Hanti.data() + q * nn, h->Ntot, h->rl_npj, ir.data() + (size_t)(1 + h->Nc + q) * h->rl_stride);
+        }
+        HIPCHK(h, hipMemcpy(h->d_himg_r, ir.data(), ir.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     return JQ_OK;
 }
 
@@ -231,6 +252,14 @@ static int upload_targets(jq_handle* h)
         std::fill(cl.begin(), cl.end(), 0.0);
         column_image(h->Uti.data(), h->Ntot, h->N, h->lane_np, cl.data());
         HIPCHK(h, hipMemcpy(h->d_vti_l, cl.data(), cl.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (h->rl_npj > 0) {
+        std::vector<double> cl((size_t)h->N * 16, 0.0);
+        column_image(h->Utr.data(), h->Ntot, h->N, 16, cl.data());
+        HIPCHK(h, hipMemcpy(h->d_vtr_r, cl.data(), cl.size() * sizeof(double), hipMemcpyHostToDevice));
+        std::fill(cl.begin(), cl.end(), 0.0);
+        column_image(h->Uti.data(), h->Ntot, h->N, 16, cl.data());
+        HIPCHK(h, hipMemcpy(h->d_vti_r, cl.data(), cl.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     return JQ_OK;
 }
@@ -252,7 +281,7 @@ extern "C" void jq_destroy(jq_handle* h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    double** bufs[] = {&h->d_himg_l, &h->d_uinit_l, &h->d_vtr_l, &h->d_vti_l, &h->d_himg_c, &h->d_cimg_c, &h->d_park, &h->d_cimg, &h->d_himg,  &h->d_uimg,       &h->d_vtr,     &h->d_vti,    &h->d_tabs, &h->d_tf,   &h->d_tb,
+    double** bufs[] = {&h->d_himg_r, &h->d_uinit_r, &h->d_vtr_r, &h->d_vti_r, &h->d_himg_l, &h->d_uinit_l, &h->d_vtr_l, &h->d_vti_l, &h->d_himg_c, &h->d_cimg_c, &h->d_park, &h->d_cimg, &h->d_himg,  &h->d_uimg,       &h->d_vtr,     &h->d_vti,    &h->d_tabs, &h->d_tf,   &h->d_tb,
                        &h->d_cfreq, &h->d_pcof,       &h->d_stream,  &h->d_pq,     &h->d_state, &h->d_state_save,
                        &h->d_colinfo, &h->d_traces,   &h->d_R,       &h->d_grad,   &h->d_res};
     for (auto b : bufs)
@@ -381,6 +410,17 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         h->lane_stride = ((long long)h->lane_np * h->lane_np + 15) / 16 * 16;
         h->lane_min_cols = 1;
         h->lane_max_cols = 1 << 30;
+        // row-lane kernels (jq_rowlane_kernels.h): same sizes, one lane per (row, column), 4 columns per wave;
+        // used while the batch is small enough that the evaluation is bound by the latency of one wave
+        // (measured cross-over with the lane kernels, scripts/time_cases.py).  JQ_ROWLANE_MAX overrides.
+        h->rl_npj = h->Ntot <= 8 ? (h->Ntot + 1) / 2 * 2 : (h->Ntot <= 12 ? 12 : (h->Ntot <= 16 ? 16 : 0));
+        if (const char* e = getenv("JQ_LANE"))
+            if (atoi(e) == 0) h->rl_npj = 0;
+        h->rl_stride = 16LL * h->rl_npj;
+        // cross-over measured with scripts/time_cases.py: ~2 waves per SIMD against the lane kernels (Ntot <= 8),
+        // ~4 against the MFMA slab kernels (Ntot 9..16)
+        h->rl_max_cols = (h->rl_npj > 8 ? 4 : 2) * 4 * 4 * prop.multiProcessorCount;
+        if (const char* e = getenv("JQ_ROWLANE_MAX")) h->rl_max_cols = atoi(e);
         if (const char* e = getenv("JQ_LANE_MIN")) h->lane_min_cols = atoi(e);
         if (const char* e = getenv("JQ_LANE_MAX")) h->lane_max_cols = atoi(e);
     }
@@ -416,6 +456,15 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         std::vector<double> cl((size_t)h->N * h->lane_np, 0.0);
         column_image(h->Uinit.data(), h->Ntot, h->N, h->lane_np, cl.data());
         HIPCHK(h, hipMemcpy(h->d_uinit_l, cl.data(), cl.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (h->rl_npj > 0) {
+        if ((rc = dev_alloc(h, &h->d_himg_r, (size_t)(1 + 2 * h->Nc) * h->rl_stride))) return rc;
+        if ((rc = dev_alloc(h, &h->d_uinit_r, (size_t)h->N * 16))) return rc;
+        if ((rc = dev_alloc(h, &h->d_vtr_r, (size_t)h->N * 16))) return rc;
+        if ((rc = dev_alloc(h, &h->d_vti_r, (size_t)h->N * 16))) return rc;
+        std::vector<double> cl((size_t)h->N * 16, 0.0);
+        column_image(h->Uinit.data(), h->Ntot, h->N, 16, cl.data());
+        HIPCHK(h, hipMemcpy(h->d_uinit_r, cl.data(), cl.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     if ((rc = dev_alloc(h, &h->d_uimg, (size_t)h->KT * 64))) return rc;
     if ((rc = dev_alloc(h, &h->d_vtr, (size_t)h->KT * 64))) return rc;
@@ -610,6 +659,27 @@ static int select_lane_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* 
     return fail(h, JQ_EUNSUPPORTED, "no lane kernel for this Hilbert dimension");
 }
 
+// row-lane kernels (one lane per (row, column)), NPJ = padded row length
+#define JQ_FOR_EACH_ROWLANE(X) X(2) X(4) X(6) X(8) X(12) X(16)
+#define JQ_DECLR(npj)                                                     \
+    extern template __global__ void k_forward_rowlane<npj>(PropArgs);     \
+    extern template __global__ void k_backward_rowlane<npj>(PropArgs);
+JQ_FOR_EACH_ROWLANE(JQ_DECLR)
+#undef JQ_DECLR
+
+static int select_rowlane_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
+{
+#define JQ_PICKR(npj)                     \
+    if (h->rl_npj == npj) {               \
+        *fwd = k_forward_rowlane<npj>;    \
+        *bwd = k_backward_rowlane<npj>;   \
+        return JQ_OK;                     \
+    }
+    JQ_FOR_EACH_ROWLANE(JQ_PICKR)
+#undef JQ_PICKR
+    return fail(h, JQ_EUNSUPPORTED, "no row-lane kernel for this Hilbert dimension");
+}
+
 struct EvalOut {
     std::vector<double> res;    // [nsamples][4] primary, secondary, Re s, Im s
     std::vector<double> grad0;  // forced adjoint (total gradient), weighted sum over samples
@@ -640,22 +710,26 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     // kernels, one wave per slab (jq_coop_kernels.h explains the trade-off)
     // small Hilbert spaces: lane kernels, one lane per column (jq_lane_kernels.h)
     const long long ncols_used = (long long)nsamples * h->N;
-    const bool lane = h->lane_np > 0 && h->solver_id == 1 && ncols_used >= h->lane_min_cols && ncols_used <= h->lane_max_cols;
-    const long long ncols = (ncols_used + 63) / 64 * 64;
-    const bool coop = !lane && h->mat_elems_c > 0 && h->solver_id == 1 && nslabs <= h->coop_max_slabs;
+    const bool rl = h->rl_npj > 0 && h->solver_id == 1 && ncols_used <= h->rl_max_cols;
+    const bool lane = !rl && h->lane_np > 0 && h->solver_id == 1 && ncols_used >= h->lane_min_cols && ncols_used <= h->lane_max_cols;
+    const long long ncols = rl ? (ncols_used + 3) / 4 * 4 : (ncols_used + 63) / 64 * 64;
+    const long long nwaves_rl = ncols / 4;
+    const bool coop = !lane && !rl && h->mat_elems_c > 0 && h->solver_id == 1 && nslabs <= h->coop_max_slabs;
     prop_kernel_t kfwd, kbwd;
     lane_init_t klinit = nullptr;
     lane_term_t klterm = nullptr;
-    int rc = lane ? select_lane_kernels(h, &kfwd, &kbwd, &klinit, &klterm)
+    int rc = rl ? select_rowlane_kernels(h, &kfwd, &kbwd)
+             : lane ? select_lane_kernels(h, &kfwd, &kbwd, &klinit, &klterm)
                   : coop ? select_coop_kernels(h, &kfwd, &kbwd) : select_kernels(h, &kfwd, &kbwd);
     if (rc) return rc;
-    const int nblocks = lane ? (int)(ncols / 64) : coop ? nslabs : (nslabs + JQ_WAVES - 1) / JQ_WAVES;
-    const int nthreads = lane ? 64 : coop ? 64 * h->NT : 256;
-    const int trace_rows = lane ? nblocks : coop ? nslabs * h->NT : nslabs;   // per-step trace records: one per wave
-    const long long stride = lane ? h->lane_stride : coop ? h->mat_elems_c : h->mat_elems;
-    const double* himg = lane ? h->d_himg_l : coop ? h->d_himg_c : h->d_himg;
-    const size_t state_doubles = lane ? (size_t)JQ_LANE_ROWS(h->lane_np) * ncols : (size_t)nslabs * h->state_stride;
-    const size_t colinfo_doubles = lane ? (size_t)2 * ncols : (size_t)nslabs * 32;
+    const int nblocks = rl ? (int)nwaves_rl : lane ? (int)(ncols / 64) : coop ? nslabs : (nslabs + JQ_WAVES - 1) / JQ_WAVES;
+    const int nthreads = (lane || rl) ? 64 : coop ? 64 * h->NT : 256;
+    const int trace_rows = (lane || rl) ? nblocks : coop ? nslabs * h->NT : nslabs;   // per-step trace records: one per wave
+    const long long stride = rl ? h->rl_stride : lane ? h->lane_stride : coop ? h->mat_elems_c : h->mat_elems;
+    const double* himg = rl ? h->d_himg_r : lane ? h->d_himg_l : coop ? h->d_himg_c : h->d_himg;
+    const size_t state_doubles = rl ? (size_t)JQ_ROWLANE_ROWS * nwaves_rl * 64
+                                    : lane ? (size_t)JQ_LANE_ROWS(h->lane_np) * ncols : (size_t)nslabs * h->state_stride;
+    const size_t colinfo_doubles = (lane || rl) ? (size_t)2 * ncols : (size_t)nslabs * 32;
     const int cs = h->chunk_steps;
     const int ntr = h->Nc * JQ_NTR;
     const bool two_pass = adjoint && h->objFuncType != 1;
@@ -674,7 +748,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
         if ((rc = dev_alloc(h, &h->d_colinfo, colinfo_doubles))) return rc;
         h->cap_colinfo = colinfo_doubles;
     }
-    if (!lane && (size_t)nslabs > h->cap_slabs) {
+    if (!lane && !rl && (size_t)nslabs > h->cap_slabs) {
         if ((rc = dev_alloc(h, &h->d_park, (size_t)nslabs * h->KT * 64))) return rc;
         h->cap_slabs = nslabs;
     }
@@ -696,7 +770,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     HIPCHK(h, hipMemcpyAsync(h->d_pcof, pcof, (size_t)ncoeff * sizeof(double), hipMemcpyHostToDevice, s));
     bool use_shift = false;
     std::vector<double> colinfo(colinfo_doubles, 0.0);
-    if (lane) {   // [eps per column | weight per column]
+    if (lane || rl) {   // [eps per column | weight per column]
         for (long long c = 0; c < ncols_used; ++c) {
             const int smp = (int)(c / h->N);
             colinfo[c] = eps ? eps[smp] : 0.0;
@@ -716,7 +790,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     }
     HIPCHK(h, hipMemcpyAsync(h->d_colinfo, colinfo.data(), colinfo.size() * sizeof(double), hipMemcpyHostToDevice, s));
     std::vector<double> tabs((size_t)32 * h->NT, 0.0);
-    const size_t ws_off = lane ? (size_t)h->lane_np : (size_t)16 * h->NT;   // tables: [wd | ws]
+    const size_t ws_off = rl ? 16 : lane ? (size_t)h->lane_np : (size_t)16 * h->NT;   // tables: [wd | ws]
     for (int i = 0; i < h->Ntot; ++i) {
         tabs[i] = h->wd[i];
         // reference perturbation: Hconst[j,j] += ep*0.01*10^(j-2), j = 2..Ntot (src/ipopt_interface.jl:41-44)
@@ -732,10 +806,10 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     const double dt = h->T / h->nsteps;
     PropArgs a;
     memset(&a, 0, sizeof a);
-    a.stream = h->d_stream; a.cimg = lane ? h->d_himg_l + h->lane_stride : coop ? h->d_cimg_c : h->d_cimg; a.state = h->d_state; a.colinfo = h->d_colinfo;
+    a.stream = h->d_stream; a.cimg = rl ? h->d_himg_r + h->rl_stride : lane ? h->d_himg_l + h->lane_stride : coop ? h->d_cimg_c : h->d_cimg; a.state = h->d_state; a.colinfo = h->d_colinfo;
     a.traces = h->d_traces;
     a.tabs = h->d_tabs; a.stride = stride; a.pieces = (int)(stride * 8 / 1024); a.nslots = h->nslots; a.m = h->m;
-    a.nslabs = lane ? (int)ncols : nslabs; a.Ncoupled = h->Nc; a.Ntot = h->Ntot; a.N = h->N; a.use_shift = use_shift ? 1 : 0;
+    a.nslabs = rl ? (int)nwaves_rl : lane ? (int)ncols : nslabs; a.Ncoupled = h->Nc; a.Ntot = h->Ntot; a.N = h->N; a.use_shift = use_shift ? 1 : 0;
     a.tinv = 1.0 / h->T; a.state_stride = h->state_stride;
     a.jacobi_tol2 = (h->solver_id == 2) ? h->solver_tol * h->solver_tol : 0.0;
     for (int q = 0; q < JQ_MAXNC; ++q) a.bw_trace[q] = h->bw_trace[q];
@@ -744,13 +818,13 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     const int batch = coop ? 0 : h->batch;
     const size_t lds_stage = batch > 0 ? (size_t)2 * (2 * batch + 1) * 2 * stride * 8 + (size_t)2 * h->Nc * stride * 8
                                        : (size_t)2 * stride * 8;
-    const size_t lds_fwd = lane ? 0 : lds_stage + (size_t)32 * h->NT * 8 + (coop ? (size_t)2 * h->KT * 64 * 8 : 0);
-    const size_t lds_bwd = lane ? 0 : coop ? lds_fwd
+    const size_t lds_fwd = (lane || rl) ? 0 : lds_stage + (size_t)32 * h->NT * 8 + (coop ? (size_t)2 * h->KT * 64 * 8 : 0);
+    const size_t lds_bwd = rl ? (h->rl_npj > 8 ? (size_t)2 * h->Nc * h->rl_stride * 8 : 0) : lane ? 0 : coop ? lds_fwd
                                 : lds_fwd + (size_t)JQ_MAXNC * 256 * 8 + (h->park_lds ? (size_t)JQ_WAVES * h->KT * 64 * 8 : 0);
     a.batch = batch; a.lds_tab_off = (int)lds_stage;
     a.park = h->d_park; a.park_lds = h->park_lds;
     if (const char* e = getenv("JQ_DEBUG")) a.debug = atoi(e);
-    if (!lane) {
+    if (!lane && !rl) {
         HIPCHK(h, hipFuncSetAttribute((const void*)kfwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fwd));
         HIPCHK(h, hipFuncSetAttribute((const void*)kbwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bwd));
     }
@@ -766,15 +840,18 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     size_t evi = 2;
     HIPCHK(h, hipEventRecord(h->ev[0], s));
 
-    if (lane)
+    if (rl)
+        hipLaunchKernelGGL(k_init_state_rowlane, dim3((unsigned)nwaves_rl), dim3(64), 0, s, h->d_state, nwaves_rl, h->d_uinit_r, h->N,
+                           ncols_used);
+    else if (lane)
         hipLaunchKernelGGL(klinit, dim3((unsigned)(ncols / 64)), dim3(64), 0, s, h->d_state, ncols, h->d_uinit_l, h->N, ncols_used);
     else
         hipLaunchKernelGGL(k_init_state, dim3(nslabs), dim3(64), 0, s, h->d_state, h->state_stride, h->d_uimg, h->KT);
 
     long long mfma = 0;
-    const long long tiles = lane ? 0 : coop ? coop_tiles(h->NT, h->BW) : band_tiles(h->NT, h->BW);
+    const long long tiles = (lane || rl) ? 0 : coop ? coop_tiles(h->NT, h->BW) : band_tiles(h->NT, h->BW);
     long long trace_tiles = 0;
-    for (int q = 0; q < h->Nc && !lane; ++q)
+    for (int q = 0; q < h->Nc && !lane && !rl; ++q)
         trace_tiles += coop ? coop_tiles(h->NT, h->BW) : band_tiles(h->NT, h->bw_trace[q] == 0 ? 0 : h->BW, h->bw_trace[q] == 2);
     // ---- forward sweep -------------------------------------------------------------------------
     for (int n0 = 0; n0 < h->nsteps; n0 += cs) {
@@ -802,7 +879,10 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     }
     HIPCHK(h, hipGetLastError());
     const double leak_scale = 0.5 * dt * (1.0 / h->T);
-    if (lane)
+    if (rl)
+        hipLaunchKernelGGL(k_terminal_rowlane, dim3((nsamples + 63) / 64), dim3(64), 0, s, h->d_state, nwaves_rl, h->d_vtr_r,
+                           h->d_vti_r, h->N, nsamples, leak_scale, h->d_res);
+    else if (lane)
         hipLaunchKernelGGL(klterm, dim3((nsamples + 63) / 64), dim3(64), 0, s, h->d_state, ncols, h->d_vtr_l, h->d_vti_l, h->N,
                            nsamples, leak_scale, h->d_res);
     else

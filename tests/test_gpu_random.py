@@ -52,6 +52,8 @@ CASES = [
     (5, 4, 2, 1, 13, 3, 2, False, 3),
     (7, 2, 2, 1, 33, 3, 3, False, 7),
     (8, 3, 3, 2, 9, 2, 1, False, 0),
+    (10, 3, 2, 2, 15, 3, 3, False, 4),
+    (12, 4, 2, 2, 14, 5, 1, False, 0),
     (16, 16, 1, 1, 9, 1, 1, False, 0),
     (17, 5, 2, 2, 21, 4, 2, False, 5),
     (30, 4, 3, 1, 12, 3, 1, True, 0),
@@ -66,16 +68,18 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("mode", ["auto", "slab", "nolane"])
+@pytest.mark.parametrize("mode", ["auto", "slab", "lane", "nolane"])
 @pytest.mark.parametrize("cfg", CASES, ids=lambda c: "Ntot%d_N%d_Nc%d_f%d_m%d_o%d_%s_c%d" % (c[0], c[1], c[2], c[3], c[5], c[6], "band" if c[7] else "dense", c[8]))
 def test_random_problem_matches_oracle(jq, cfg, mode):
-    """mode 'auto': Ntot <= 8 runs on the lane kernels (one lane per column), Ntot > 16 with small batches on
-    the cooperative (row-split) kernels; mode 'slab': JQ_COOP_MAX=0 forces the one-wave-per-slab kernels
-    that large ensembles use; mode 'nolane': JQ_LANE=0 keeps the MFMA kernels covered for Ntot <= 8."""
+    """mode 'auto': Ntot <= 16 runs on the row-lane kernels (one lane per (row, column); small batches), Ntot > 16
+    with small batches on the cooperative (row-split) kernels; mode 'slab': JQ_COOP_MAX=0 forces the
+    one-wave-per-slab kernels that large ensembles use; mode 'lane': JQ_ROWLANE_MAX=0 forces the lane kernels
+    (one lane per column) that large ensembles of small systems use; mode 'nolane': JQ_LANE=0 keeps the MFMA
+    kernels covered for Ntot <= 16."""
     from oracle.oracle import Oracle
     Ntot, N, Nc, Nfreq, nsteps, m, oft, banded, chunk = cfg
-    if mode == "nolane" and Ntot > 8:
-        pytest.skip("lane kernels only exist for Ntot <= 8")
+    if (mode == "lane" and Ntot > 8) or (mode == "nolane" and Ntot > 16):
+        pytest.skip("lane kernels only exist for Ntot <= 8, row-lane kernels for Ntot <= 16")
     rng = np.random.default_rng(1000 + Ntot * 31 + N)
     p, pcof = random_problem(jq, rng, Ntot, N, Nc, Nfreq, nsteps, m, oft, banded)
     if chunk:
@@ -84,12 +88,15 @@ def test_random_problem_matches_oracle(jq, cfg, mode):
         os.environ["JQ_COOP_MAX"] = "0"
     if mode == "nolane":
         os.environ["JQ_LANE"] = "0"
+    if mode == "lane":
+        os.environ["JQ_ROWLANE_MAX"] = "0"
     try:
         wa = jq.Working_Arrays_HIP(p, pcof.size)
     finally:
         os.environ.pop("JQ_CHUNK_STEPS", None)
         os.environ.pop("JQ_COOP_MAX", None)
         os.environ.pop("JQ_LANE", None)
+        os.environ.pop("JQ_ROWLANE_MAX", None)
     r = Oracle(p, use_sparse=False).traceobjgrad(pcof, history=True)
     objfv, tg, prim, sec, tinf, ig, lg = jq.traceobjgrad(pcof, p, wa, False, True)
     gn = np.linalg.norm(r["totalgrad"])
@@ -105,7 +112,7 @@ def test_random_problem_matches_oracle(jq, cfg, mode):
     # ragged ensemble: sample counts that leave slabs / workgroups partly empty
     sps = 16 // N
     # (Ntot <= 8: also more columns than one 64-lane wave of the lane kernels holds)
-    for nq in sorted({1, sps + 1, 4 * sps + 1} | ({150 // N} if Ntot <= 8 else set())):
+    for nq in sorted({1, sps + 1, 4 * sps + 1} | ({150 // N} if Ntot <= 16 else set())):
         nodes = 0.1 * rng.standard_normal(nq)
         weights = rng.random(nq)
         shift = rng.standard_normal(Ntot) * 0.05
