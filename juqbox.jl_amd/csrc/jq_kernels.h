@@ -32,11 +32,18 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define JQ_MAXSLOTS 2         // LDS operator slots (double buffer)
 #define JQ_MAXSCHED 30        // max operator uses per time step (13 + 3*JQ_MAXNC = 25)
 
+// BW == JQ_BW_OD: block band 1 whose off-diagonal 16x16 blocks are DIAGONAL matrices (an operator of the
+// slowest subsystem of a Kronecker-ordered Hilbert space, (c +- c') x I_16: cnot3).  Only the diagonal blocks
+// are MFMA tiles; the off-diagonal blocks are 16 coefficients each, applied with 4 v_fma_f64 per block in the
+// shadow of the MFMAs (mm_od) -- 24 MFMAs + 40 FMAs per product at Ntot = 96 instead of 64 MFMAs.
+#define JQ_BW_OD 9
+#define JQ_OD_COEFS(NT) (32 * (NT))   // doubles after the tiles: [mt][dir: below, above][g = lane>>4][r]
+
 // Stored tiles of an NT x 4NT tile grid: block (mt,kb) is kept when |mt-kb| <= BW and, for SD ("skip
 // diagonal": operators like a3 +- a3' of the slowest subsystem, whose diagonal blocks vanish), mt != kb.
 __host__ __device__ constexpr bool block_on(int BW, bool SD, int mt, int kb)
 {
-    return (mt - kb <= BW) && (kb - mt <= BW) && !(SD && mt == kb);
+    return (BW == JQ_BW_OD) ? (mt == kb && !SD) : ((mt - kb <= BW) && (kb - mt <= BW) && !(SD && mt == kb));
 }
 // number of stored tiles (host + device)
 __host__ __device__ constexpr int band_tiles(int NT, int BW, bool SD = false)
@@ -140,9 +147,119 @@ __device__ __forceinline__ void a_store(const Arr<NT>& a, double* __restrict__ i
 // The A fragments are fetched JQ_PF tiles ahead of their MFMA through a small register FIFO: a
 // v_mfma_f64_16x16x4 occupies the matrix pipe for 64 cycles, an LDS read returns in ~100.
 #define JQ_PF 4
+
+// BW == JQ_BW_OD:  D = C + blockdiag(M) x (MFMA)  +  diagonal off-diagonal blocks (VALU).
+// Row mt's accumulator input  C[mt] + d_below[mt] .* x[mt-1] + d_above[mt] .* x[mt+1]  is computed right after
+// the first MFMA of row mt-1 has been issued (it runs in that MFMA's 64-cycle shadow); its coefficients were
+// read from LDS one row earlier.  SD: the operator has no diagonal blocks at all -> no MFMA.
+template <int NT, bool ZEROC, bool SD>
+__device__ __forceinline__ void mm_od(Arr<NT>& D, const Arr<NT>& C, const double* mat, const Arr<NT>& x)
+{
+    // Alias-safe: D may be the same array as C and/or x (every x row is copied to a d4 before D's row is
+    // written; in SSA form these are renames, not moves) -- the Horner recurrence Y <- A + S Y runs in place.
+    constexpr int NTILES = SD ? 0 : 4 * NT;
+    const int lane = threadIdx.x & 63;
+    const double* cf = mat - lane + NTILES * 64 + (lane >> 4) * 4;
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    d4 ca = *(const d4*)(cf), cb = *(const d4*)(cf + 16);        // row 0: below (unused), above
+    if constexpr (SD) {
+        d4 x_prev = zero, x_cur = x.t[0];
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) {
+            const d4 x_next = (mt + 1 < NT) ? x.t[mt + 1] : zero;
+            d4 acc = ZEROC ? zero : C.t[mt];
+            if (mt > 0) acc += ca * x_prev;
+            if (mt + 1 < NT) acc += cb * x_next;
+            if (mt + 1 < NT) {
+                ca = *(const d4*)(cf + ((mt + 1) * 2 + 0) * 16);
+                cb = *(const d4*)(cf + ((mt + 1) * 2 + 1) * 16);
+            }
+            D.t[mt] = acc;
+            x_prev = x_cur;
+            x_cur = x_next;
+        }
+        return;
+    } else {
+        // Rows are processed in pairs so that consecutive MFMAs alternate between two independent accumulators
+        // (the four k-steps of one row form a dependent chain).  Tile order in the image: (mt, k) row-major.
+        double f[JQ_PF];
+#pragma unroll
+        for (int i = 0; i < JQ_PF; ++i)
+            if (i < NTILES) f[i] = mat[(((i & 1) ? 4 : 0) + (i >> 1)) * 64];   // pair 0: tiles 0,4,1,5,...
+        auto init_row = [&](int mt, const d4& xm1, const d4& xp1, const d4& cbelow, const d4& cabove) -> d4 {
+            d4 acc = ZEROC ? zero : C.t[mt];
+            if (mt > 0) acc += cbelow * xm1;
+            if (mt + 1 < NT) acc += cabove * xp1;
+            return acc;
+        };
+        auto coef = [&](int mt, int dir) -> d4 { return *(const d4*)(cf + (mt * 2 + dir) * 16); };
+        constexpr int NPAIR = (NT + 1) / 2;
+        // accumulator inputs of the first pair
+        d4 xa = x.t[0], xb = (NT > 1) ? x.t[1] : zero;            // old x of the pair's rows
+        d4 x_before = zero;                                       // old x of the row above the pair
+        d4 acc0 = init_row(0, zero, xb, ca, cb);
+        d4 acc1 = zero;
+        if (NT > 1) acc1 = init_row(1, xa, (NT > 2) ? x.t[2] : zero, coef(1, 0), coef(1, 1));
+        int idx = 0;
+#pragma unroll
+        for (int pr = 0; pr < NPAIR; ++pr) {
+            const int m0 = 2 * pr, m1 = 2 * pr + 1;
+            const bool two = (m1 < NT);
+            // old x of the next pair (read before this pair's results can overwrite an aliased array)
+            const d4 xna = (m0 + 2 < NT) ? x.t[m0 + 2] : zero;
+            const d4 xnb = (m0 + 3 < NT) ? x.t[m0 + 3] : zero;
+            const d4 xnc = (m0 + 4 < NT) ? x.t[m0 + 4] : zero;
+            d4 nacc0 = zero, nacc1 = zero;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (h == 1 && !two) continue;
+                    const double a = f[idx % JQ_PF];
+                    {   // prefetch the tile JQ_PF MFMAs ahead (same pair-interleaved walk)
+                        const int j = idx + JQ_PF;
+                        if (j < NTILES) {
+                            // walk position j -> (pair, k, h): full pairs hold 8 tiles, a trailing single row 4
+                            const int jp = j / 8, jr = j % 8;
+                            const bool jtwo = (2 * jp + 1 < NT);
+                            const int jm = jtwo ? (2 * jp + (jr & 1)) : (2 * jp);
+                            const int jk = jtwo ? (jr >> 1) : jr;
+                            f[idx % JQ_PF] = mat[(4 * jm + jk) * 64];
+                        }
+                    }
+                    if (h == 0)
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xa[k], acc0, 0, 0, 0);
+                    else
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xb[k], acc1, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ++idx;
+                    if (k == 0 && h == (two ? 1 : 0) && m0 + 2 < NT) {
+                        // accumulator inputs of the next pair, in the shadow of the MFMAs just issued
+                        nacc0 = init_row(m0 + 2, two ? xb : xa, xnb, coef(m0 + 2, 0), coef(m0 + 2, 1));
+                        if (m0 + 3 < NT) nacc1 = init_row(m0 + 3, xna, xnc, coef(m0 + 3, 0), coef(m0 + 3, 1));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            D.t[m0] = acc0;
+            if (two) D.t[m1] = acc1;
+            acc0 = nacc0;
+            acc1 = nacc1;
+            x_before = two ? xb : xa;
+            xa = xna;
+            xb = xnb;
+        }
+        (void)x_before;
+    }
+}
+
 template <int NT, int BW, bool ZEROC, bool SD = false>
 __device__ __forceinline__ void mm_any(Arr<NT>& D, const Arr<NT>& C, const double* mat, const Arr<NT>& x)
 {
+    if constexpr (BW == JQ_BW_OD) {
+        mm_od<NT, ZEROC, SD>(D, C, mat, x);
+        return;
+    }
     constexpr int NTILES = band_tiles(NT, BW, SD);
     double f[JQ_PF];
 #pragma unroll
@@ -556,6 +673,12 @@ __device__ __forceinline__ void horner_add(Arr<NT>& out, const Arr<NT>& bpa, con
     }
     mm_c<NT, BW>(Ya, A, S, A);  // Y1 = A + S A
     --rem;
+    if constexpr (BW == JQ_BW_OD) {
+        // mm_od is alias-safe: the recurrence runs in place and Yb is never touched (48 registers less)
+        for (; rem > 0; --rem) mm_c<NT, BW>(Ya, A, S, Ya);
+        mm_c<NT, BW>(out, bpa, S, Ya);
+        return;
+    }
     while (rem >= 2) {
         mm_c<NT, BW>(Yb, A, S, Ya);
         mm_c<NT, BW>(Ya, A, S, Yb);

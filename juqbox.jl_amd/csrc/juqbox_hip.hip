@@ -33,7 +33,8 @@ struct jq_handle {
     double solver_tol = 0.0;
     double T = 0.0;
     int NT = 0, KT = 0, NP = 0, sps = 0;
-    int BW = 0;                 // block band width the kernels are instantiated for
+    int BW = 0;                 // block band width the kernels are instantiated for (JQ_BW_OD: see jq_kernels.h)
+    int BWc = 0;                // ... of the cooperative kernels (plain band)
     int bw_trace[JQ_MAXNC] = {0, 0, 0, 0};
     long long mat_elems = 0;    // doubles per operator image slot ("stride"): band tiles, padded to 1 KiB
     long long mat_elems_c = 0;  // ... in the row-window layout of the cooperative kernels (0: not available)
@@ -102,6 +103,33 @@ static void tile_image(const double* M, int Ntot, int NT, int BW, double* img, b
             }
             ++idx;
         }
+    if (BW == JQ_BW_OD) {
+        // diagonals of the first off-diagonal blocks: [mt][dir: block mt-1, block mt+1][g][r] <-> row 16mt + 4r + g
+        double* cf = img + idx * 64;
+        for (int mt = 0; mt < NT; ++mt)
+            for (int dir = 0; dir < 2; ++dir) {
+                const int nb = mt + (dir ? 1 : -1);
+                for (int g = 0; g < 4; ++g)
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * mt + 4 * r + g, col = 16 * nb + 4 * r + g;
+                        cf[((mt * 2 + dir) * 4 + g) * 4 + r] =
+                            (nb >= 0 && nb < NT && row < Ntot && col < Ntot) ? M[row + (size_t)Ntot * col] : 0.0;
+                    }
+            }
+    }
+}
+
+// true if M is block tridiagonal (16x16 blocks) and every off-diagonal block is a diagonal matrix
+static bool offdiag_blocks_diagonal(const double* M, int Ntot)
+{
+    for (int col = 0; col < Ntot; ++col)
+        for (int row = 0; row < Ntot; ++row) {
+            if (M[row + (size_t)Ntot * col] == 0.0) continue;
+            const int d = row / 16 - col / 16;
+            if (d == 0) continue;
+            if (std::abs(d) > 1 || row % 16 != col % 16) return false;
+        }
+    return true;
 }
 
 // Row-window layout of the cooperative kernels (jq_coop_kernels.h): for tile row mt the NB k-blocks
@@ -207,10 +235,10 @@ static int upload_operators(jq_handle* h)
     HIPCHK(h, hipMemcpy(h->d_cimg, cimg.data(), cimg.size() * sizeof(double), hipMemcpyHostToDevice));
     if (h->mat_elems_c > 0) {
         std::vector<double> ic((size_t)(1 + 2 * h->Nc) * h->mat_elems_c, 0.0);
-        tile_image_coop(h->Hconst.data(), h->Ntot, h->NT, h->BW, ic.data());
+        tile_image_coop(h->Hconst.data(), h->Ntot, h->NT, h->BWc, ic.data());
         for (int q = 0; q < h->Nc; ++q) {
-            tile_image_coop(h->Hsym.data() + q * nn, h->Ntot, h->NT, h->BW, ic.data() + (size_t)(1 + q) * h->mat_elems_c);
-            tile_image_coop(h->Hanti.data() + q * nn, h->Ntot, h->NT, h->BW, ic.data() + (size_t)(1 + h->Nc + q) * h->mat_elems_c);
+            tile_image_coop(h->Hsym.data() + q * nn, h->Ntot, h->NT, h->BWc, ic.data() + (size_t)(1 + q) * h->mat_elems_c);
+            tile_image_coop(h->Hanti.data() + q * nn, h->Ntot, h->NT, h->BWc, ic.data() + (size_t)(1 + h->Nc + q) * h->mat_elems_c);
         }
         HIPCHK(h, hipMemcpy(h->d_himg_c, ic.data(), ic.size() * sizeof(double), hipMemcpyHostToDevice));
         // trace images [Hsym_q | Hanti_q] = images 1.. of the same array
@@ -347,6 +375,17 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         if (const char* e = getenv("JQ_FORCE_DENSE"))
             if (atoi(e) != 0) bw = h->NT - 1;
         h->BW = (bw <= 2 && bw < h->NT - 1) ? bw : h->NT - 1;
+        h->BWc = h->BW;
+        // block tridiagonal with DIAGONAL off-diagonal blocks (operators of the slowest subsystem, cnot3):
+        // MFMA only for the diagonal blocks, 16 coefficients per off-diagonal block (JQ_OD=0 disables)
+        bool od = (bw == 1 && h->NT >= 2 && offdiag_blocks_diagonal(h->Hconst.data(), h->Ntot));
+        for (int q = 0; q < h->Nc && od; ++q)
+            od = offdiag_blocks_diagonal(h->Hsym.data() + q * nn, h->Ntot) && offdiag_blocks_diagonal(h->Hanti.data() + q * nn, h->Ntot);
+        if (const char* e = getenv("JQ_OD"))
+            if (atoi(e) == 0) od = false;
+        if (const char* e = getenv("JQ_FORCE_DENSE"))
+            if (atoi(e) != 0) od = false;
+        if (od) h->BW = JQ_BW_OD;
         // trace image layout per control: 0 block diagonal, 1 band BW, 2 band BW without the diagonal blocks
         for (int q = 0; q < h->Nc; ++q) {
             if (h->bw_trace[q] == 0 || h->BW == 0)
@@ -355,7 +394,7 @@ static int create_impl(const jq_problem* p, jq_handle* h)
                 h->bw_trace[q] = (h->NT > 1 && diag_blocks_zero(h->Hsym.data() + q * nn, h->Ntot) &&
                                   diag_blocks_zero(h->Hanti.data() + q * nn, h->Ntot)) ? 2 : 1;
         }
-        h->mat_elems = ((64LL * band_tiles(h->NT, h->BW) + 127) / 128) * 128;
+        h->mat_elems = ((64LL * band_tiles(h->NT, h->BW) + (h->BW == JQ_BW_OD ? JQ_OD_COEFS(h->NT) : 0) + 127) / 128) * 128;
         const long long slot = h->mat_elems * 8;
         const long long lds_fwd_fixed = (long long)32 * h->NT * 8;
         const long long lds_bwd_fixed = lds_fwd_fixed + (long long)JQ_MAXNC * 256 * 8;
@@ -368,7 +407,7 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         // cooperative (row-split) kernels for small batches: NT waves per slab, needs NT >= 2
         h->mat_elems_c = 0;
         if (h->NT >= 2) {
-            const long long ec = ((64LL * coop_tiles(h->NT, h->BW) + 127) / 128) * 128;
+            const long long ec = ((64LL * coop_tiles(h->NT, h->BWc) + 127) / 128) * 128;
             const long long lds_c = 2 * ec * 8 + lds_fwd_fixed + 2LL * h->KT * 64 * 8;
             if (lds_c <= 163840) h->mat_elems_c = ec;
         }
@@ -565,7 +604,7 @@ extern "C" int jq_update_hconst(jq_handle* h, const double* Hconst)
     if (!h) return JQ_EINVAL;
     if (!Hconst) return fail(h, JQ_EINVAL, "jq_update_hconst: NULL pointer");
     HIPCHK(h, hipSetDevice(h->device));
-    if (block_band(Hconst, h->Ntot) > h->BW)
+    if (block_band(Hconst, h->Ntot) > h->BWc || (h->BW == JQ_BW_OD && !offdiag_blocks_diagonal(Hconst, h->Ntot)))
         return fail(h, JQ_EUNSUPPORTED, "jq_update_hconst: new Hconst has entries outside the block band the kernels were "
                                         "selected for; create a new handle");
     h->Hconst.assign(Hconst, Hconst + (size_t)h->Ntot * h->Ntot);
@@ -586,7 +625,7 @@ typedef void (*prop_kernel_t)(PropArgs);
 // The (NT, BW) instantiations are compiled in their own translation units (jq_kernel_inst.hip).
 #define JQ_FOR_EACH_INST(X)                                                                       \
     X(1, 0) X(2, 0) X(2, 1) X(3, 0) X(3, 1) X(3, 2) X(4, 0) X(4, 1) X(4, 2) X(4, 3) X(5, 0) X(5, 1) \
-    X(5, 2) X(5, 4) X(6, 0) X(6, 1) X(6, 2) X(6, 5)
+    X(5, 2) X(5, 4) X(6, 0) X(6, 1) X(6, 2) X(6, 5) X(2, 9) X(3, 9) X(4, 9) X(5, 9) X(6, 9)
 #define JQ_MINW_OF(nt) (((nt) <= 2) ? 2 : 1)
 #define JQ_DECL(nt, bw)                                                                      \
     extern template __global__ void k_forward<nt, bw, JQ_MINW_OF(nt), false>(PropArgs);      \
@@ -622,7 +661,7 @@ JQ_FOR_EACH_COOP(JQ_DECLC)
 static int select_coop_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
 {
 #define JQ_PICKC(nt, bw)                      \
-    if (h->NT == nt && h->BW == bw) {         \
+    if (h->NT == nt && h->BWc == bw) {        \
         *fwd = k_forward_coop<nt, bw>;        \
         *bwd = k_backward_coop<nt, bw>;       \
         return JQ_OK;                         \
@@ -849,10 +888,10 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
         hipLaunchKernelGGL(k_init_state, dim3(nslabs), dim3(64), 0, s, h->d_state, h->state_stride, h->d_uimg, h->KT);
 
     long long mfma = 0;
-    const long long tiles = (lane || rl) ? 0 : coop ? coop_tiles(h->NT, h->BW) : band_tiles(h->NT, h->BW);
+    const long long tiles = (lane || rl) ? 0 : coop ? coop_tiles(h->NT, h->BWc) : band_tiles(h->NT, h->BW);
     long long trace_tiles = 0;
     for (int q = 0; q < h->Nc && !lane && !rl; ++q)
-        trace_tiles += coop ? coop_tiles(h->NT, h->BW) : band_tiles(h->NT, h->bw_trace[q] == 0 ? 0 : h->BW, h->bw_trace[q] == 2);
+        trace_tiles += coop ? coop_tiles(h->NT, h->BWc) : band_tiles(h->NT, h->bw_trace[q] == 0 ? 0 : h->BW, h->bw_trace[q] == 2);
     // ---- forward sweep -------------------------------------------------------------------------
     for (int n0 = 0; n0 < h->nsteps; n0 += cs) {
         const int nc = std::min(cs, h->nsteps - n0);

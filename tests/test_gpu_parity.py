@@ -39,20 +39,25 @@ def gpu_eval_like_evalGrad(jq, params, wa, pcof):
     return np.array([objv]), grad
 
 
-@pytest.mark.parametrize("case", ["rabi", "swap02", "flux", "cnot2", "cnot2-leakieq", "cnot2-jacobi", "cnot3", "cnot3:slab"])
+@pytest.mark.parametrize("case", ["rabi", "swap02", "flux", "cnot2", "cnot2-leakieq", "cnot2-jacobi", "cnot3", "cnot3:slab", "cnot3:slab-band"])
 def test_reference_golden_through_the_callbacks(hip, case):
-    """All seven Stormer-Verlet goldens of the reference (test/runtests.jl:30).  cnot3 runs twice: on the
-    cooperative kernels (default for a single sample) and, with JQ_COOP_MAX=0, on the slab kernels."""
+    """All seven Stormer-Verlet goldens of the reference (test/runtests.jl:30).  cnot3 runs three times: on the
+    cooperative kernels (default for a single sample), with JQ_COOP_MAX=0 on the slab kernels (JQ_BW_OD variant:
+    MFMA for the diagonal blocks, VALU for the diagonal off-diagonal blocks) and with JQ_OD=0 on the plain
+    block-band slab kernels."""
     import os
     jq = hip
     case, _, mode = case.partition(":")
     params, info, pcof, golden = case_inputs(case)
-    if mode == "slab":
+    if mode.startswith("slab"):
         os.environ["JQ_COOP_MAX"] = "0"
+    if mode == "slab-band":
+        os.environ["JQ_OD"] = "0"
     try:
         wa = jq.Working_Arrays_HIP(params, pcof.size)
     finally:
         os.environ.pop("JQ_COOP_MAX", None)
+        os.environ.pop("JQ_OD", None)
     obj, grad = gpu_eval_like_evalGrad(jq, params, wa, pcof)
     assert reference_pass(obj, golden["obj0"]), (obj, golden["obj0"])
     assert reference_pass(grad, golden["grad0"])

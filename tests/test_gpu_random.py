@@ -14,7 +14,28 @@ TOL = 1e-9   # random problems are less well conditioned than the reference case
 
 def random_problem(jq, rng, Ntot, N, Nc, Nfreq, nsteps, m, objFuncType, banded):
     T = 1.0 + rng.random()
-    if banded:      # nearest-level couplings like a ladder operator: block band 0 or 1
+    if banded == "od":   # Kronecker structure (slowest subsystem x 16 fast levels): dense 16x16 diagonal blocks,
+        # DIAGONAL first off-diagonal blocks -> the JQ_BW_OD kernels (MFMA for the diagonal blocks only)
+        def kron(anti):
+            a = np.zeros((Ntot, Ntot))
+            for b in range(0, Ntot, 16):
+                e = min(b + 16, Ntot)
+                blk = rng.standard_normal((e - b, e - b))
+                a[b:e, b:e] = blk - blk.T if anti else blk + blk.T
+            for i in range(Ntot - 16):
+                a[i, i + 16] = rng.standard_normal()
+                a[i + 16, i] = -a[i, i + 16] if anti else a[i, i + 16]
+            return a
+        Hs = [kron(False) for _ in range(Nc)]
+        if Nc > 1:                           # one control of the slowest subsystem only: no diagonal blocks at all
+            for b in range(0, Ntot, 16):
+                Hs[-1][b:b + 16, b:b + 16] = 0.0
+        Ha = [kron(True) for _ in range(Nc)]
+        if Nc > 1:
+            for b in range(0, Ntot, 16):
+                Ha[-1][b:b + 16, b:b + 16] = 0.0
+        H0 = kron(False)
+    elif banded:      # nearest-level couplings like a ladder operator: block band 0 or 1
         def sym():
             a = np.zeros((Ntot, Ntot))
             for i in range(Ntot - 1):
@@ -65,11 +86,15 @@ CASES = [
     (81, 9, 2, 1, 5, 1, 2, False, 2),
     (96, 4, 3, 1, 6, 6, 1, False, 4),
     (95, 6, 2, 2, 4, 3, 3, True, 0),
+    (32, 4, 1, 1, 9, 2, 1, "od", 0),
+    (40, 3, 2, 2, 7, 3, 3, "od", 3),
+    (80, 5, 3, 1, 6, 4, 2, "od", 0),
+    (96, 4, 3, 2, 5, 6, 1, "od", 2),
 ]
 
 
 @pytest.mark.parametrize("mode", ["auto", "slab", "lane", "nolane"])
-@pytest.mark.parametrize("cfg", CASES, ids=lambda c: "Ntot%d_N%d_Nc%d_f%d_m%d_o%d_%s_c%d" % (c[0], c[1], c[2], c[3], c[5], c[6], "band" if c[7] else "dense", c[8]))
+@pytest.mark.parametrize("cfg", CASES, ids=lambda c: "Ntot%d_N%d_Nc%d_f%d_m%d_o%d_%s_c%d" % (c[0], c[1], c[2], c[3], c[5], c[6], c[7] if isinstance(c[7], str) else ("band" if c[7] else "dense"), c[8]))
 def test_random_problem_matches_oracle(jq, cfg, mode):
     """mode 'auto': Ntot <= 16 runs on the row-lane kernels (one lane per (row, column); small batches), Ntot > 16
     with small batches on the cooperative (row-split) kernels; mode 'slab': JQ_COOP_MAX=0 forces the
