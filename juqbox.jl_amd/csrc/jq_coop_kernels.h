@@ -114,7 +114,7 @@ __device__ __forceinline__ void wg_sum_store(double val, double* scratch, double
 // rows of this wave/lane: 16*mt + 4*r + g
 __device__ __forceinline__ d4 rows4(const double* tab, int mt, int g)
 {
-    return (d4){tab[16 * mt + g], tab[16 * mt + 4 + g], tab[16 * mt + 8 + g], tab[16 * mt + 12 + g]};
+    return *(const d4*)(tab + 16 * mt + 4 * g);   // tables are stored [block][g][r]
 }
 __device__ __forceinline__ double dot4(const d4& a, const d4& b)
 {
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(64 * NT) void k_forward_coop(PropArgs a)
     const int slab = blockIdx.x;
 
     double* tab = (double*)(smem + a.lds_tab_off);
-    for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[i] = a.tabs[i];
+    for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[(i & ~15) + 4 * (i & 3) + ((i >> 2) & 3)] = a.tabs[i];   // [block][g][r]
     Coop<NT, BW> c;
     coop_setup(c, smem, a, wave, lane);
     __syncthreads();
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(64 * NT) void k_backward_coop(PropArgs a)
     const int Nc = a.Ncoupled;
 
     double* tab = (double*)(smem + a.lds_tab_off);
-    for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[i] = a.tabs[i];
+    for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[(i & ~15) + 4 * (i & 3) + ((i >> 2) & 3)] = a.tabs[i];   // [block][g][r]
     Coop<NT, BW> c;
     coop_setup(c, smem, a, wave, lane);
     __syncthreads();

@@ -102,14 +102,14 @@ __device__ __forceinline__ double a_dot(const Arr<NT>& x, const Arr<NT>& y)
     }
     return s;
 }
-// y += c * tab .* x   (tab: per-row table in LDS, padded to 16*NT rows; g = lane>>4)
+// y += c * tab .* x   (tab: per-row table in LDS, padded to 16*NT rows, stored [block][g][r] so that the four
+// values of a lane are one 32-byte read; g = lane>>4).
 template <int NT>
 __device__ __forceinline__ void a_axpy_rows(Arr<NT>& y, double c, const double* tab, int g, const Arr<NT>& x)
 {
+    const d4* t4 = (const d4*)(tab + 4 * g);
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) y.t[i][r] += (c * tab[16 * i + 4 * r + g]) * x.t[i][r];
+    for (int i = 0; i < NT; ++i) y.t[i] += (c * t4[4 * i]) * x.t[i];
 }
 // sum_rows tab[row] * x[row]^2
 template <int NT>
@@ -119,7 +119,7 @@ __device__ __forceinline__ double a_wsq(const double* tab, int g, const Arr<NT>&
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s += tab[16 * i + 4 * r + g] * (x.t[i][r] * x.t[i][r]);
+        for (int r = 0; r < 4; ++r) s += tab[16 * i + 4 * g + r] * (x.t[i][r] * x.t[i][r]);
     return s;
 }
 
@@ -180,76 +180,45 @@ __device__ __forceinline__ void mm_od(Arr<NT>& D, const Arr<NT>& C, const double
         }
         return;
     } else {
-        // Rows are processed in pairs so that consecutive MFMAs alternate between two independent accumulators
-        // (the four k-steps of one row form a dependent chain).  Tile order in the image: (mt, k) row-major.
+        // (Interleaving the MFMAs of two rows -- two independent accumulator chains -- was measured to make no
+        // difference and costs registers: the matrix pipe is not the bottleneck of this variant, DESIGN.md.)
         double f[JQ_PF];
 #pragma unroll
         for (int i = 0; i < JQ_PF; ++i)
-            if (i < NTILES) f[i] = mat[(((i & 1) ? 4 : 0) + (i >> 1)) * 64];   // pair 0: tiles 0,4,1,5,...
-        auto init_row = [&](int mt, const d4& xm1, const d4& xp1, const d4& cbelow, const d4& cabove) -> d4 {
-            d4 acc = ZEROC ? zero : C.t[mt];
-            if (mt > 0) acc += cbelow * xm1;
-            if (mt + 1 < NT) acc += cabove * xp1;
-            return acc;
-        };
-        auto coef = [&](int mt, int dir) -> d4 { return *(const d4*)(cf + (mt * 2 + dir) * 16); };
-        constexpr int NPAIR = (NT + 1) / 2;
-        // accumulator inputs of the first pair
-        d4 xa = x.t[0], xb = (NT > 1) ? x.t[1] : zero;            // old x of the pair's rows
-        d4 x_before = zero;                                       // old x of the row above the pair
-        d4 acc0 = init_row(0, zero, xb, ca, cb);
-        d4 acc1 = zero;
-        if (NT > 1) acc1 = init_row(1, xa, (NT > 2) ? x.t[2] : zero, coef(1, 0), coef(1, 1));
-        int idx = 0;
+            if (i < NTILES) f[i] = mat[i * 64];
+        d4 x_cur = x.t[0];
+        d4 nxt = ZEROC ? zero : C.t[0];
+        if (NT > 1) nxt += cb * x.t[1];
+        if (NT > 1) {
+            ca = *(const d4*)(cf + 2 * 16);
+            cb = *(const d4*)(cf + 3 * 16);
+        }
 #pragma unroll
-        for (int pr = 0; pr < NPAIR; ++pr) {
-            const int m0 = 2 * pr, m1 = 2 * pr + 1;
-            const bool two = (m1 < NT);
-            // old x of the next pair (read before this pair's results can overwrite an aliased array)
-            const d4 xna = (m0 + 2 < NT) ? x.t[m0 + 2] : zero;
-            const d4 xnb = (m0 + 3 < NT) ? x.t[m0 + 3] : zero;
-            const d4 xnc = (m0 + 4 < NT) ? x.t[m0 + 4] : zero;
-            d4 nacc0 = zero, nacc1 = zero;
+        for (int mt = 0; mt < NT; ++mt) {
+            const d4 x_next = (mt + 1 < NT) ? x.t[mt + 1] : zero;
+            d4 acc = nxt;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    if (h == 1 && !two) continue;
-                    const double a = f[idx % JQ_PF];
-                    {   // prefetch the tile JQ_PF MFMAs ahead (same pair-interleaved walk)
-                        const int j = idx + JQ_PF;
-                        if (j < NTILES) {
-                            // walk position j -> (pair, k, h): full pairs hold 8 tiles, a trailing single row 4
-                            const int jp = j / 8, jr = j % 8;
-                            const bool jtwo = (2 * jp + 1 < NT);
-                            const int jm = jtwo ? (2 * jp + (jr & 1)) : (2 * jp);
-                            const int jk = jtwo ? (jr >> 1) : jr;
-                            f[idx % JQ_PF] = mat[(4 * jm + jk) * 64];
-                        }
+                const int kk = 4 * mt + k;
+                const double a = f[kk % JQ_PF];
+                if (kk + JQ_PF < NTILES) f[kk % JQ_PF] = mat[(kk + JQ_PF) * 64];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, x_cur[k], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (k == 0 && mt + 1 < NT) {
+                    // accumulator input of the next row, in the shadow of the MFMA just issued
+                    nxt = ZEROC ? zero : C.t[mt + 1];
+                    nxt += ca * x_cur;
+                    if (mt + 2 < NT) nxt += cb * x.t[mt + 2];
+                    if (mt + 2 < NT) {
+                        ca = *(const d4*)(cf + ((mt + 2) * 2 + 0) * 16);
+                        cb = *(const d4*)(cf + ((mt + 2) * 2 + 1) * 16);
                     }
-                    if (h == 0)
-                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xa[k], acc0, 0, 0, 0);
-                    else
-                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xb[k], acc1, 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    ++idx;
-                    if (k == 0 && h == (two ? 1 : 0) && m0 + 2 < NT) {
-                        // accumulator inputs of the next pair, in the shadow of the MFMAs just issued
-                        nacc0 = init_row(m0 + 2, two ? xb : xa, xnb, coef(m0 + 2, 0), coef(m0 + 2, 1));
-                        if (m0 + 3 < NT) nacc1 = init_row(m0 + 3, xna, xnc, coef(m0 + 3, 0), coef(m0 + 3, 1));
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
                 }
             }
-            D.t[m0] = acc0;
-            if (two) D.t[m1] = acc1;
-            acc0 = nacc0;
-            acc1 = nacc1;
-            x_before = two ? xb : xa;
-            xa = xna;
-            xb = xnb;
+            D.t[mt] = acc;
+            x_cur = x_next;
         }
-        (void)x_before;
     }
 }
 
@@ -776,7 +745,7 @@ __global__ __launch_bounds__(256, MINW) void k_forward(PropArgs a)
     double* tab = (double*)(smem + a.lds_tab_off);
     const double* wd = tab;
     const double* ws = tab + 16 * NT;
-    for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[i] = a.tabs[i];
+    for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[(i & ~15) + 4 * (i & 3) + ((i >> 2) & 3)] = a.tabs[i];   // [block][g][r]
 
     Arr<NT> ua, va, ub, vb, A, Ya, Yb;
     double leak = 0.0, ceps = 0.0;
@@ -857,7 +826,7 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
     const double* wd = tab;
     const double* ws = tab + 16 * NT;
     double* carry = tab + 32 * NT;  // [JQ_MAXNC][256]
-    for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[i] = a.tabs[i];
+    for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[(i & ~15) + 4 * (i & 3) + ((i >> 2) & 3)] = a.tabs[i];   // [block][g][r]
     double* st = a.state + (size_t)(active ? slab : 0) * a.state_stride;
     // parking image of this wave: in LDS when it fits, else in HBM
     double* P0 = a.park_lds ? (carry + JQ_MAXNC * 256 + (size_t)wave * KT * 64 + lane)
