@@ -16,9 +16,13 @@
 #pragma once
 #include "jq_kernels.h"
 
-__host__ __device__ constexpr int coop_nb(int NT, int BW) { return (2 * BW + 1 < NT) ? 2 * BW + 1 : NT; }
+// BW == JQ_BW_OD (jq_kernels.h): the window is the row's own diagonal block (4 MFMA tiles); the two neighbouring
+// blocks are diagonal matrices, stored as 2 x 16 coefficients behind the tiles and applied with 8 FMAs.
+__host__ __device__ constexpr int coop_nb(int NT, int BW) { return (BW == JQ_BW_OD) ? 1 : ((2 * BW + 1 < NT) ? 2 * BW + 1 : NT); }
+__host__ __device__ constexpr int coop_row_elems(int NT, int BW) { return 4 * coop_nb(NT, BW) * 64 + (BW == JQ_BW_OD ? 32 : 0); }
 __host__ __device__ constexpr int coop_kb0(int NT, int BW, int mt)
 {
+    if (BW == JQ_BW_OD) return mt;
     const int nb = coop_nb(NT, BW);
     int k = mt - BW;
     if (k < 0) k = 0;
@@ -55,6 +59,30 @@ __device__ __forceinline__ d4 cmm(const d4& C, const double* Mrow, const double*
     return acc;
 }
 
+// JQ_BW_OD:  D = C + Mdiag[mt] x[mt] (4 MFMAs, B operand = the wave's own rows, still in registers)
+//                 + d_below .* x[mt-1] + d_above .* x[mt+1]  (neighbour rows from the exchange buffer; the
+//                 coefficients of a missing neighbour are zero, its index is clamped)
+template <int NT, bool ZEROC>
+__device__ __forceinline__ d4 cmm_od(const d4& C, const double* Mrow, const double* x, const d4& xown, int mt)
+{
+    const int lane = threadIdx.x & 63;
+    const double* cf = Mrow - lane + 4 * 64 + (lane >> 4) * 4;     // [dir][g][r]
+    const int mb = mt > 0 ? mt - 1 : 0, ma = mt + 1 < NT ? mt + 1 : NT - 1;
+    const double* xb = x + (size_t)(4 * mb) * 64;
+    const double* xa = x + (size_t)(4 * ma) * 64;
+    const double a0 = Mrow[0], a1 = Mrow[64], a2 = Mrow[128], a3 = Mrow[192];
+    const d4 cb = *(const d4*)(cf), ca = *(const d4*)(cf + 16);
+    const d4 vb = {xb[0], xb[64], xb[128], xb[192]}, va = {xa[0], xa[64], xa[128], xa[192]};
+    d4 acc = ZEROC ? (d4){0.0, 0.0, 0.0, 0.0} : C;
+    acc += cb * vb;
+    acc += ca * va;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, xown[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, xown[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, xown[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, xown[3], acc, 0, 0, 0);
+    return acc;
+}
+
 // per-wave context of a cooperative workgroup
 template <int NT, int BW>
 struct Coop {
@@ -65,11 +93,13 @@ struct Coop {
     int mt;             // my tile row
     int kb0;
     int row_off;        // doubles from the start of an operator image to my row's tiles
+    d4 xown;            // my rows of the staged / published x (JQ_BW_OD: B operand of the diagonal block)
 
     // write my rows of Z into the other exchange buffer (visible after the next barrier)
     __device__ __forceinline__ void stage(const d4& Z)
     {
         double* w = xbuf + (size_t)(xcur ^ 1) * (4 * NT * 64) + (size_t)(4 * mt) * 64;
+        xown = Z;
         w[0] = Z[0];
         w[64] = Z[1];
         w[128] = Z[2];
@@ -92,8 +122,16 @@ struct Coop {
     }
     __device__ __forceinline__ void next_op() { M = ring.next() + row_off; }
     __device__ __forceinline__ const double* x() const { return xbuf + (size_t)xcur * (4 * NT * 64); }
-    __device__ __forceinline__ d4 mm_z() const { return cmm<NT, BW, true>((d4){0, 0, 0, 0}, M, x(), kb0); }
-    __device__ __forceinline__ d4 mm_c(const d4& C) const { return cmm<NT, BW, false>(C, M, x(), kb0); }
+    __device__ __forceinline__ d4 mm_z() const
+    {
+        if constexpr (BW == JQ_BW_OD) return cmm_od<NT, true>((d4){0, 0, 0, 0}, M, x(), xown, mt);
+        else return cmm<NT, BW, true>((d4){0, 0, 0, 0}, M, x(), kb0);
+    }
+    __device__ __forceinline__ d4 mm_c(const d4& C) const
+    {
+        if constexpr (BW == JQ_BW_OD) return cmm_od<NT, false>(C, M, x(), xown, mt);
+        else return cmm<NT, BW, false>(C, M, x(), kb0);
+    }
 };
 
 // dst[lane] (+)= sum over the NT waves of val, summed in wave order by wave 0 (deterministic).
@@ -186,11 +224,12 @@ __device__ __forceinline__ void coop_setup(Coop<NT, BW>& c, char* smem, const Pr
     c.mt = wave;
     c.kb0 = coop_kb0(NT, BW, 0);
     // kb0 and the row offset depend on the (wave-uniform) tile row
-    int k = wave - BW;
+    int k = (BW == JQ_BW_OD) ? wave : wave - BW;
     if (k < 0) k = 0;
     if (k > NT - coop_nb(NT, BW)) k = NT - coop_nb(NT, BW);
     c.kb0 = k;
-    c.row_off = wave * 4 * coop_nb(NT, BW) * 64;
+    c.row_off = wave * coop_row_elems(NT, BW);
+    c.xown = (d4){0.0, 0.0, 0.0, 0.0};
     c.M = nullptr;
 }
 

@@ -137,6 +137,26 @@ static bool offdiag_blocks_diagonal(const double* M, int Ntot)
 static void tile_image_coop(const double* M, int Ntot, int NT, int BW, double* img)
 {
     const int NB = coop_nb(NT, BW);
+    if (BW == JQ_BW_OD) {
+        // per tile row: the 4 tiles of the diagonal block, then [dir: block mt-1, mt+1][g][r] <-> row 16mt + 4r + g
+        for (int mt = 0; mt < NT; ++mt) {
+            double* row = img + (size_t)mt * coop_row_elems(NT, BW);
+            for (int r4 = 0; r4 < 4; ++r4)
+                for (int l = 0; l < 64; ++l) {
+                    const int rr = 16 * mt + (l & 15), col = 4 * (4 * mt + r4) + (l >> 4);
+                    row[r4 * 64 + l] = (rr < Ntot && col < Ntot) ? M[rr + (size_t)Ntot * col] : 0.0;
+                }
+            for (int dir = 0; dir < 2; ++dir) {
+                const int nb = mt + (dir ? 1 : -1);
+                for (int g = 0; g < 4; ++g)
+                    for (int r = 0; r < 4; ++r) {
+                        const int rr = 16 * mt + 4 * r + g, col = 16 * nb + 4 * r + g;
+                        row[256 + (dir * 4 + g) * 4 + r] = (nb >= 0 && nb < NT && rr < Ntot && col < Ntot) ? M[rr + (size_t)Ntot * col] : 0.0;
+                    }
+            }
+        }
+        return;
+    }
     size_t idx = 0;
     for (int mt = 0; mt < NT; ++mt) {
         const int kb0 = coop_kb0(NT, BW, mt);
@@ -385,7 +405,7 @@ static int create_impl(const jq_problem* p, jq_handle* h)
             if (atoi(e) == 0) od = false;
         if (const char* e = getenv("JQ_FORCE_DENSE"))
             if (atoi(e) != 0) od = false;
-        if (od) h->BW = JQ_BW_OD;
+        if (od) h->BW = h->BWc = JQ_BW_OD;
         // trace image layout per control: 0 block diagonal, 1 band BW, 2 band BW without the diagonal blocks
         for (int q = 0; q < h->Nc; ++q) {
             if (h->bw_trace[q] == 0 || h->BW == 0)
@@ -407,7 +427,7 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         // cooperative (row-split) kernels for small batches: NT waves per slab, needs NT >= 2
         h->mat_elems_c = 0;
         if (h->NT >= 2) {
-            const long long ec = ((64LL * coop_tiles(h->NT, h->BWc) + 127) / 128) * 128;
+            const long long ec = (((long long)h->NT * coop_row_elems(h->NT, h->BWc) + 127) / 128) * 128;
             const long long lds_c = 2 * ec * 8 + lds_fwd_fixed + 2LL * h->KT * 64 * 8;
             if (lds_c <= 163840) h->mat_elems_c = ec;
         }
@@ -604,7 +624,7 @@ extern "C" int jq_update_hconst(jq_handle* h, const double* Hconst)
     if (!h) return JQ_EINVAL;
     if (!Hconst) return fail(h, JQ_EINVAL, "jq_update_hconst: NULL pointer");
     HIPCHK(h, hipSetDevice(h->device));
-    if (block_band(Hconst, h->Ntot) > h->BWc || (h->BW == JQ_BW_OD && !offdiag_blocks_diagonal(Hconst, h->Ntot)))
+    if ((h->BW == JQ_BW_OD) ? !offdiag_blocks_diagonal(Hconst, h->Ntot) : block_band(Hconst, h->Ntot) > h->BW)
         return fail(h, JQ_EUNSUPPORTED, "jq_update_hconst: new Hconst has entries outside the block band the kernels were "
                                         "selected for; create a new handle");
     h->Hconst.assign(Hconst, Hconst + (size_t)h->Ntot * h->Ntot);
@@ -654,7 +674,7 @@ static int select_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
     extern template __global__ void k_backward_coop<nt, bw>(PropArgs);
 #define JQ_FOR_EACH_COOP(X)                                                                               \
     X(2, 0) X(2, 1) X(3, 0) X(3, 1) X(3, 2) X(4, 0) X(4, 1) X(4, 2) X(4, 3) X(5, 0) X(5, 1) X(5, 2) X(5, 4) \
-    X(6, 0) X(6, 1) X(6, 2) X(6, 5)
+    X(6, 0) X(6, 1) X(6, 2) X(6, 5) X(2, 9) X(3, 9) X(4, 9) X(5, 9) X(6, 9)
 JQ_FOR_EACH_COOP(JQ_DECLC)
 #undef JQ_DECLC
 
