@@ -72,6 +72,7 @@ def main():
     prop_ms = bwd_ms = fwd_ms = 0.0
     nb = nf = 0
     mfma = 0
+    tm = {}
     for _ in range(args.steps):
         step()
         tm = wa.last_timing()
@@ -103,13 +104,18 @@ def main():
         achieved = flops_per_launch / avg_launch_s / 1e12
         # HBM bytes per k_backward launch from the PMC passes kept under profiles/ (FETCH_SIZE x2 gfx950 correction
         # + WRITE_SIZE, separate rocprofv3 --pmc runs of this same command; null if not measured for this build)
+        # the library reports which propagator family / instantiation ran (jq_timing.kernel_*)
+        fam = {0: "k_backward", 1: "k_backward_coop", 2: "k_backward_lane", 3: "k_backward_rowlane"}.get(tm.get("kernel_family", 0))
+        kname = "%s<%d, %d>" % (fam, tm.get("kernel_size", 0), tm.get("kernel_band", 0))
         traffic = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
-            traffic = tj["kernels"]["k_backward<6, 1, 1, false>"]["hbm_bytes_per_launch"]
+            traffic = tj["kernels"][kname]["hbm_bytes_per_launch"]
         except Exception:
             pass
-        roofline = {"bound": "mfma", "kernel": "k_backward<NT=6,BW=1>", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
+        roofline = {"bound": "mfma", "kernel": kname + (" (band 9 = block tridiagonal with diagonal off-diagonal blocks)"
+                                                         if tm.get("kernel_band") == 9 else ""),
+                    "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                     "traffic_unit": "HBM bytes per launch (PMC)",
                     "mfma_pipe_util": mfma * 2048.0 / (prop_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,

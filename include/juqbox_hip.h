@@ -75,6 +75,11 @@ typedef struct jq_timing {
     int64_t n_backward_launches;
     int64_t mfma_executed;  /* v_mfma_f64_16x16x4 instructions issued by the propagators (all waves)*/
     int64_t svts;           /* state-vector-time-steps processed (columns x nsteps), SURVEY 8(d)   */
+    int32_t kernel_family;  /* propagators used: 0 slab (MFMA, wave per slab), 1 cooperative (MFMA, row split),
+                               2 lane (VALU, lane per column), 3 row-lane (VALU, lane per (row, column))  */
+    int32_t kernel_size;    /* template size parameter: NT (16-row tiles) for 0/1, NP for 2, NPJ for 3       */
+    int32_t kernel_band;    /* block band of the MFMA families (9 = JQ_BW_OD: diagonal off-diagonal blocks)  */
+    int32_t reserved;
 } jq_timing;
 
 /* ---- lifetime --------------------------------------------------------------------------------*/

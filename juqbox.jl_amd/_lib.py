@@ -26,7 +26,9 @@ class jq_problem(ctypes.Structure):
 class jq_timing(ctypes.Structure):
     _fields_ = [("ms_total", ctypes.c_double), ("ms_propagate", ctypes.c_double), ("ms_generate", ctypes.c_double),
                 ("ms_forward", ctypes.c_double), ("ms_backward", ctypes.c_double),
-                ("n_forward_launches", ctypes.c_int64), ("n_backward_launches", ctypes.c_int64), ("mfma_executed", ctypes.c_int64), ("svts", ctypes.c_int64)]
+                ("n_forward_launches", ctypes.c_int64), ("n_backward_launches", ctypes.c_int64), ("mfma_executed", ctypes.c_int64), ("svts", ctypes.c_int64),
+                ("kernel_family", ctypes.c_int32), ("kernel_size", ctypes.c_int32), ("kernel_band", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
 
 
 # every symbol include/juqbox_hip.h declares: name -> (restype, argtypes)

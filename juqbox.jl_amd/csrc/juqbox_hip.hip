@@ -1032,6 +1032,10 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     h->timing.n_backward_launches = (long long)((evi - 2) / 2 - nfwd);
     h->timing.mfma_executed = mfma;
     h->timing.svts = (long long)nsamples * h->N * h->nsteps;
+    h->timing.kernel_family = rl ? 3 : lane ? 2 : coop ? 1 : 0;
+    h->timing.kernel_size = rl ? h->rl_npj : lane ? h->lane_np : h->NT;
+    h->timing.kernel_band = (rl || lane) ? 0 : coop ? h->BWc : h->BW;
+    h->timing.reserved = 0;
     return JQ_OK;
 }
 
