@@ -465,6 +465,9 @@ void jqo_set_target(void *h, const double *Utr, const double *Uti)
     memcpy(o->Uti, Uti, nc * sizeof(double));
 }
 double *jqo_hconst(void *h) { return ((oracle_t *)h)->Hconst; }
+/* leakage weights: the Stormer-Verlet path reads params.wmat_real (src/evalobjgrad.jl:583), the implicit-midpoint
+ * path params.wmat (:1147); the test setups overwrite only the former (e.g. test/cases/cnot2-setup.jl) */
+void jqo_set_wdiag(void *h, const double *w) { memcpy(((oracle_t *)h)->wdiag, w, (size_t)((oracle_t *)h)->Ntot * sizeof(double)); }
 
 /* p_k(t), q_k(t) for all coupled controls at time t -- exposes bcarrier2 for unit tests */
 int jqo_controls(void *h, const double *pcof, int ncoeff, double t, double *pq /* 2*Ncoupled */)
@@ -646,6 +649,231 @@ int jqo_traceobjgrad(void *h, const double *pcof, int ncoeff, int evaladjoint, d
         if (final_state) {
             memcpy(final_state + 2 * len, vr, (size_t)len * sizeof(double));
             memcpy(final_state + 3 * len, vi, (size_t)len * sizeof(double));
+        }
+        free(ab);
+    }
+    free(buf);
+    free(o->tcenter);
+    o->tcenter = NULL;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Implicit-midpoint path: traceobjgrad(pcof0, params, wa::Working_Arrays_M, ...), src/evalobjgrad.jl:1042-1481.
+ * Parity status: PINNED by test/reference_solutions/<case>-ref-imr.jld2 (tests/test_oracle_golden.py).        */
+
+/* jacobi_midpoint: src/linear_solvers.jl:156-215 (sparse) / :218-270 (dense).  On exit x0_u, x0_v hold the
+ * solution of (I - h/2 [S -K; K S]) x = rhs.  The caller copies them into u, v (ImplicitMidpoint.jl:142-143). */
+static void jacobi_midpoint(const oracle_t *o, double h, const double *rhs_u, const double *rhs_v, const double *S,
+                            const double *K, double *u_init, double *v_init, double *x0_u, double *x0_v, double *nu_,
+                            double *nv_, int max_iter, double tol)
+{
+    int len = o->Ntot * o->N, N = o->N, it, i;
+    memcpy(x0_u, u_init, (size_t)len * sizeof(double));
+    memcpy(x0_v, v_init, (size_t)len * sizeof(double));
+    for (it = 0; it < max_iter; it++) {
+        double nru = 0.0, nrv = 0.0;
+        mul(u_init, S, &o->patS, x0_u, N, 0.5 * h, 0.0);
+        axpy(len, 1.0, rhs_u, u_init);
+        mul(u_init, K, &o->patK, x0_v, N, -0.5 * h, 1.0);
+        mul(v_init, K, &o->patK, x0_u, N, 0.5 * h, 0.0);
+        axpy(len, 1.0, rhs_v, v_init);
+        mul(v_init, S, &o->patS, x0_v, N, 0.5 * h, 1.0);
+        memcpy(x0_u, u_init, (size_t)len * sizeof(double));
+        memcpy(x0_v, v_init, (size_t)len * sizeof(double));
+        mul(nu_, K, &o->patK, x0_v, N, 0.5 * h, 0.0);
+        mul(nu_, S, &o->patS, x0_u, N, -0.5 * h, 1.0);
+        axpy(len, 1.0, x0_u, nu_);
+        axpy(len, -1.0, rhs_u, nu_);
+        mul(nv_, S, &o->patS, x0_v, N, -0.5 * h, 0.0);
+        mul(nv_, K, &o->patK, x0_u, N, -0.5 * h, 1.0);
+        axpy(len, 1.0, x0_v, nv_);
+        axpy(len, -1.0, rhs_v, nv_);
+        for (i = 0; i < len; i++) {
+            nru += nu_[i] * nu_[i];
+            nrv += nv_[i] * nv_[i];
+        }
+        if (sqrt(nru) < tol && sqrt(nrv) < tol) break;
+    }
+}
+
+typedef struct {
+    double *K05, *S05, *rhs_u, *rhs_v, *x0_u, *x0_v, *nu_, *nv_;
+} workm_t;
+
+/* m_step_no_forcing! (uf == NULL) / m_step! : src/ImplicitMidpoint.jl:120-175 / :178-227 */
+static double m_step(const oracle_t *o, workm_t *w, double t, double *u, double *v, double h, const double *uf,
+                     const double *vf, int max_iter, double tol)
+{
+    int len = o->Ntot * o->N, N = o->N;
+    mul(w->rhs_u, w->S05, &o->patS, u, N, 0.5 * h, 0.0);
+    axpy(len, 1.0, u, w->rhs_u);
+    mul(w->rhs_u, w->K05, &o->patK, v, N, -0.5 * h, 1.0);
+    if (uf) axpy(len, h, uf, w->rhs_u);
+    mul(w->rhs_v, w->S05, &o->patS, v, N, 0.5 * h, 0.0);
+    axpy(len, 1.0, v, w->rhs_v);
+    mul(w->rhs_v, w->K05, &o->patK, u, N, 0.5 * h, 1.0);
+    if (vf) axpy(len, h, vf, w->rhs_v);
+    jacobi_midpoint(o, h, w->rhs_u, w->rhs_v, w->S05, w->K05, u, v, w->x0_u, w->x0_v, w->nu_, w->nv_, max_iter, tol);
+    memcpy(u, w->x0_u, (size_t)len * sizeof(double));
+    memcpy(v, w->x0_v, (size_t)len * sizeof(double));
+    return t + h;
+}
+
+/* penal_m: src/evalobjgrad.jl:2158-2166 */
+static double penal_m(const oracle_t *o, const double *v, const double *vn)
+{
+    int i, j;
+    double g = 0.0;
+    for (i = 0; i < o->Ntot; i++)
+        for (j = 0; j < o->N; j++) {
+            double s = v[i + (size_t)j * o->Ntot] + vn[i + (size_t)j * o->Ntot];
+            g += s * s * o->wdiag[i];
+        }
+    return g;
+}
+
+/* adjoint_grad_calc_m: src/evalobjgrad.jl:2660-2702; grad is OVERWRITTEN (:2665). */
+static void adjoint_grad_calc_m(const oracle_t *o, double t, double dt, const double *Un, const double *Un1,
+                                const double *Vn, const double *Vn1, const double *Mun, const double *Mun1,
+                                const double *Nun, const double *Nun1, double *sum_mu, double *sum_v, double *sum_nu,
+                                double *sum_u, double *gr, double *gi, double *grad)
+{
+    int len = o->Ntot * o->N, i, q;
+    size_t nn = (size_t)o->Ntot * o->Ntot;
+    memset(grad, 0, (size_t)o->nCoeff * sizeof(double));
+    for (i = 0; i < len; i++) {
+        sum_mu[i] = Mun[i] + Mun1[i];
+        sum_v[i] = Vn[i] + Vn1[i];
+        sum_nu[i] = Nun[i] + Nun1[i];
+        sum_u[i] = Un[i] + Un1[i];
+    }
+    for (q = 0; q < o->Ncoupled; q++) {
+        const double *Hs = o->Hsym + q * nn, *Ha = o->Hanti + q * nn;
+        double A, B, C, D;
+        gradbcarrier2(o, t + dt / 2, 2 * q, gr);
+        gradbcarrier2(o, t + dt / 2, 2 * q + 1, gi);
+        B = -adjoint_trace(o, sum_mu, Hs, &o->patHsym[q], sum_v);
+        axpy(o->nCoeff, B, gr, grad);
+        C = adjoint_trace(o, sum_nu, Hs, &o->patHsym[q], sum_u);
+        axpy(o->nCoeff, C, gr, grad);
+        A = adjoint_trace(o, sum_mu, Ha, &o->patHanti[q], sum_u);
+        axpy(o->nCoeff, A, gi, grad);
+        D = adjoint_trace(o, sum_nu, Ha, &o->patHanti[q], sum_v);
+        axpy(o->nCoeff, D, gi, grad);
+    }
+}
+
+/* out[0..3] = objfv, primaryobjf, secondaryobjf, traceInfidelity.  max_iter / tol: the JACOBI_SOLVER_M settings
+ * (src/linear_solvers.jl:52-55; the tolerance is NOT scaled by sqrt(nrhs) for this solver, :38-41). */
+int jqo_traceobjgrad_imr(void *h, const double *pcof, int ncoeff, int evaladjoint, int max_iter, double tol, double *out,
+                         double *totalgrad, double *infidelgrad, double *leakgrad, double *hist_r, double *hist_i)
+{
+    oracle_t *o = (oracle_t *)h;
+    int Ntot = o->Ntot, N = o->N, len = Ntot * N, nsteps = o->nsteps;
+    int Nsig = 2 * o->Ncoupled, k, step, i, j;
+    size_t nn = (size_t)Ntot * Ntot;
+    double T = o->T, tinv = 1.0 / T, dt = T / nsteps, t = 0.0, objfv = 0.0;
+    double primaryobjf, secondaryobjf, sre, sim;
+    workm_t w;
+    double *buf, *vr, *vi, *vr_s, *vi_s;
+
+    if (ncoeff % Nsig != 0 || ncoeff < 3 * Nsig) return -1;      /* :1131-1133 */
+    o->D1 = ncoeff / (Nsig * o->Nfreq);
+    if (o->Nfreq * o->D1 * Nsig != ncoeff) return -2;
+    o->nCoeff = ncoeff;
+    o->dtknot = T / (o->D1 - 2);
+    o->tcenter = (double *)malloc((size_t)o->D1 * sizeof(double));
+    for (k = 1; k <= o->D1; k++) o->tcenter[k - 1] = o->dtknot * (k - 1.5);
+    o->pcof = pcof;
+
+    buf = (double *)calloc(2 * nn + 10 * (size_t)len, sizeof(double));
+    w.K05 = buf; w.S05 = buf + nn;
+    w.rhs_u = buf + 2 * nn; w.rhs_v = w.rhs_u + len; w.x0_u = w.rhs_v + len; w.x0_v = w.x0_u + len;
+    w.nu_ = w.x0_v + len; w.nv_ = w.nu_ + len;
+    vr = w.nv_ + len; vi = vr + len; vr_s = vi + len; vi_s = vr_s + len;
+    memcpy(vr, o->Uinit, (size_t)len * sizeof(double));          /* :1172-1173 */
+    if (hist_r) {
+        memcpy(hist_r, vr, (size_t)len * sizeof(double));
+        for (i = 0; i < len; i++) hist_i[i] = -vi[i];
+    }
+    /* forward loop :1204-1219 */
+    for (step = 1; step <= nsteps; step++) {
+        KS(o, w.K05, w.S05, t + 0.5 * dt);
+        memcpy(vr_s, vr, (size_t)len * sizeof(double));
+        memcpy(vi_s, vi, (size_t)len * sizeof(double));
+        t = m_step(o, &w, t, vr, vi, dt, NULL, NULL, max_iter, tol);
+        objfv += penal_m(o, vr_s, vr) + penal_m(o, vi_s, vi);
+        if (hist_r) {
+            size_t off = (size_t)step * len;
+            memcpy(hist_r + off, vr, (size_t)len * sizeof(double));
+            for (i = 0; i < len; i++) hist_i[off + i] = -vi[i];
+        }
+    }
+    objfv = dt * objfv * tinv / 4;                               /* :1221 */
+    tracefidcomplex(o, vr, vi, &sre, &sim);                       /* pFidType == 2, :1228 */
+    primaryobjf = 1.0 - (sre * sre + sim * sim);
+    secondaryobjf = objfv;
+    out[0] = primaryobjf + secondaryobjf; out[1] = primaryobjf; out[2] = secondaryobjf; out[3] = primaryobjf;
+
+    if (evaladjoint) {
+        double *ab = (double *)calloc(14 * (size_t)len + 4 * (size_t)ncoeff, sizeof(double));
+        double *lr = ab, *li = lr + len, *lr_s = li + len, *li_s = lr_s + len;
+        double *lrn = li_s + len, *lin = lrn + len, *lrn_s = lin + len, *lin_s = lrn_s + len;
+        double *hr = lin_s + len, *hi = hr + len;
+        double *sum_mu = hi + len, *sum_v = sum_mu + len, *sum_nu = sum_v + len, *sum_u = sum_nu + len;
+        double *gr = sum_u + len, *gi = gr + ncoeff, *gradobjfadj = gi + ncoeff, *tr_adj = gradobjfadj + ncoeff;
+        int nfrc = (o->objFuncType != 1);
+        double s1 = 0.0, s2 = 0.0;
+        t = T;                                                   /* :1264-1265 */
+        dt = -dt;
+        for (i = 0; i < len; i++) {                              /* :1268-1271 */
+            s1 += vr[i] * o->Utr[i] - vi[i] * o->Uti[i];
+            s2 += vr[i] * o->Uti[i] + vi[i] * o->Utr[i];
+        }
+        for (i = 0; i < len; i++) {
+            lr[i] = -2.0 / ((double)N * N) * (s1 * o->Utr[i] + s2 * o->Uti[i]);
+            li[i] = -2.0 / ((double)N * N) * (-s1 * o->Uti[i] + s2 * o->Utr[i]);
+        }
+        if (nfrc) {                                              /* :1273-1281 */
+            memcpy(lrn, lr, (size_t)len * sizeof(double));
+            memcpy(lin, li, (size_t)len * sizeof(double));
+            memset(infidelgrad, 0, (size_t)ncoeff * sizeof(double));
+        }
+        for (step = 1; step <= nsteps; step++) {                 /* :1290-1336 */
+            double t0 = t;
+            KS(o, w.K05, w.S05, t + 0.5 * dt);
+            memcpy(vi_s, vi, (size_t)len * sizeof(double));
+            memcpy(vr_s, vr, (size_t)len * sizeof(double));
+            memcpy(lr_s, lr, (size_t)len * sizeof(double));
+            memcpy(li_s, li, (size_t)len * sizeof(double));
+            t = m_step(o, &w, t, vr, vi, dt, NULL, NULL, max_iter, tol);
+            for (j = 0; j < N; j++)                              /* hr = -tinv W (vr + vr_s), hi likewise :1308-1312 */
+                for (i = 0; i < Ntot; i++) {
+                    size_t ix = i + (size_t)j * Ntot;
+                    hr[ix] = -tinv * o->wdiag[i] * vr[ix] + -tinv * o->wdiag[i] * vr_s[ix];
+                    hi[ix] = -tinv * o->wdiag[i] * vi[ix] + -tinv * o->wdiag[i] * vi_s[ix];
+                }
+            m_step(o, &w, t0, lr, li, dt, hr, hi, max_iter, tol);
+            adjoint_grad_calc_m(o, t0, dt, vr, vr_s, vi, vi_s, lr, lr_s, li, li_s, sum_mu, sum_v, sum_nu, sum_u, gr, gi, tr_adj);
+            axpy(ncoeff, 1.0, tr_adj, gradobjfadj);
+            if (nfrc) {
+                memcpy(lrn_s, lrn, (size_t)len * sizeof(double));
+                memcpy(lin_s, lin, (size_t)len * sizeof(double));
+                m_step(o, &w, t0, lrn, lin, dt, NULL, NULL, max_iter, tol);
+                adjoint_grad_calc_m(o, t0, dt, vr, vr_s, vi, vi_s, lrn, lrn_s, lin, lin_s, sum_mu, sum_v, sum_nu, sum_u, gr, gi, tr_adj);
+                axpy(ncoeff, 1.0, tr_adj, infidelgrad);
+            }
+        }
+        for (i = 0; i < ncoeff; i++) totalgrad[i] = -gradobjfadj[i] * dt / 4;      /* :1338, :1355-1356 */
+        if (nfrc) {
+            for (i = 0; i < ncoeff; i++) {
+                infidelgrad[i] = -infidelgrad[i] * dt / 4;                          /* :1339 */
+                leakgrad[i] = totalgrad[i] - infidelgrad[i];                        /* :1365 */
+            }
+        } else {
+            memcpy(infidelgrad, totalgrad, (size_t)ncoeff * sizeof(double));        /* :1367 */
+            memset(leakgrad, 0, (size_t)ncoeff * sizeof(double));
         }
         free(ab);
     }

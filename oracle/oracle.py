@@ -32,11 +32,13 @@ def lib():
         L.jqo_destroy.argtypes = [ctypes.c_void_p]
         L.jqo_set_max_iter.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.jqo_set_target.argtypes = [ctypes.c_void_p, c_dp, c_dp]
+        L.jqo_set_wdiag.argtypes = [ctypes.c_void_p, c_dp]
         L.jqo_hconst.restype = c_dp
         L.jqo_hconst.argtypes = [ctypes.c_void_p]
         L.jqo_controls.argtypes = [ctypes.c_void_p, c_dp, ctypes.c_int, ctypes.c_double, c_dp]
         L.jqo_control_grad.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_int, c_dp]
         L.jqo_traceobjgrad.argtypes = [ctypes.c_void_p, c_dp, ctypes.c_int, ctypes.c_int] + [c_dp] * 7
+        L.jqo_traceobjgrad_imr.argtypes = [ctypes.c_void_p, c_dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double] + [c_dp] * 6
         L.jqo_eval_f_g_grad.argtypes = [ctypes.c_void_p, c_dp, ctypes.c_int, c_dp, c_dp, ctypes.c_int, c_dp,
                                         ctypes.c_int, c_dp, c_dp, c_dp]
         _LIB = L
@@ -63,6 +65,7 @@ class Oracle:
         sparse = p.use_sparse if use_sparse is None else use_sparse
         self._keep = [_f(p.Hconst), hs, ha, _f(p.Uinit), _f(p.Utarget_r), _f(p.Utarget_i),
                       _f(p.wmat_real), _f(p.Cfreq[:p.Ncoupled, :])]
+        self._wmat_real, self._wmat = _f(p.wmat_real), _f(getattr(p, "wmat", p.wmat_real))
         self.h = lib().jqo_create(p.Ntot, p.N, p.Ncoupled, p.Nfreq, p.nsteps, p.T,
                                   *[_p(a) for a in self._keep], p.objFuncType,
                                   p.linear_solver.solver_id, p.linear_solver.max_iter, p.linear_solver.tol,
@@ -116,6 +119,32 @@ class Oracle:
             res["history"] = hr.reshape(shp, order="F") + 1j * hi.reshape(shp, order="F")
         if final_state:
             res["final_state"] = fs.reshape((self.Ntot, self.N, 4), order="F")
+        return res
+
+    def traceobjgrad_imr(self, pcof, max_iter=100, tol=1e-12, evaladjoint=True, history=False):
+        """Implicit-midpoint path (src/evalobjgrad.jl:1042-1481) with the JACOBI_SOLVER_M fixed-point solver."""
+        pcof = _f(pcof)
+        n = pcof.size
+        out = np.zeros(4)
+        tg, ig, lg = np.zeros(n), np.zeros(n), np.zeros(n)
+        hr = hi = None
+        if history:
+            hr = np.zeros(self.Ntot * self.N * (self.nsteps + 1))
+            hi = np.zeros_like(hr)
+        lib().jqo_set_wdiag(self.h, _p(self._wmat))         # this path weights with params.wmat (src/evalobjgrad.jl:1147)
+        try:
+            rc = lib().jqo_traceobjgrad_imr(self.h, _p(pcof), n, 1 if evaladjoint else 0, int(max_iter), float(tol), _p(out),
+                                            _p(tg), _p(ig), _p(lg), _p(hr), _p(hi))
+        finally:
+            lib().jqo_set_wdiag(self.h, _p(self._wmat_real))
+        if rc != 0:
+            raise ValueError("invalid pcof length (rc %d)" % rc)
+        res = dict(objfv=out[0], primaryobjf=out[1], secondaryobjf=out[2], traceInfidelity=out[3])
+        if evaladjoint:
+            res.update(totalgrad=tg, infidelgrad=ig, leakgrad=lg)
+        if history:
+            shp = (self.Ntot, self.N, self.nsteps + 1)
+            res["history"] = hr.reshape(shp, order="F") + 1j * hi.reshape(shp, order="F")
         return res
 
     def eval_f_g_grad(self, pcof, nodes, weights, shift, compute_adjoint=True):

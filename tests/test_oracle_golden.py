@@ -29,6 +29,19 @@ def test_oracle_reproduces_reference_golden(jq, case):
     assert reference_pass(grad, golden["grad0"])
 
 
+@pytest.mark.parametrize("case", SV_CASES)
+def test_oracle_reproduces_reference_golden_implicit_midpoint(jq, case):
+    """The second loop of test/runtests.jl:60-80: the same seven set-ups with params.Integrator_id = 2 and
+    lsolver_object(solver=JACOBI_SOLVER_M, max_iter=100, tol=1e-12), against <case>-ref-imr.jld2
+    (tests/golden/<case>-imr.json, tests/golden/make_golden_imr.py)."""
+    params, info, pcof, _ = case_inputs(case)
+    golden = load_golden(case + "-imr")
+    r = Oracle(params).traceobjgrad_imr(pcof, golden["solver"]["max_iter"], golden["solver"]["tol"])
+    obj, grad = eval_like_evalGrad(jq, params, pcof, r)
+    assert reference_pass(obj, golden["obj0"]), (obj, golden["obj0"])
+    assert reference_pass(grad, golden["grad0"])
+
+
 def test_cnot3_decomposition_matches_survey(jq):
     """SURVEY.md section 8c records the decomposition of the cnot3 golden objective."""
     params, info, pcof, golden = case_inputs("cnot3")
