@@ -40,6 +40,7 @@ SYMBOLS = {
     "jq_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
     "jq_set_neumann_terms": (ctypes.c_int, [ctypes.c_void_p, c_i32]),
     "jq_set_linear_solver": (ctypes.c_int, [ctypes.c_void_p, c_i32, c_i32, ctypes.c_double]),
+    "jq_set_integrator": (ctypes.c_int, [ctypes.c_void_p, c_i32, c_i32, ctypes.c_double]),
     "jq_update_target": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp]),
     "jq_update_hconst": (ctypes.c_int, [ctypes.c_void_p, c_dp]),
     "jq_update_wmat_diag": (ctypes.c_int, [ctypes.c_void_p, c_dp]),

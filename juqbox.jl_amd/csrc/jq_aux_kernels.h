@@ -286,14 +286,17 @@ __global__ __launch_bounds__(256) void k_pop_max(const double* __restrict__ hr, 
 // ---------------------------------------------------------------------------------------------
 // Row-lane kernels (jq_rowlane_kernels.h): initial state and terminal condition in their state-file layout
 // state file <- (Uinit, 0, ...).  uinit: [N][16] (column ic of Uinit, zero padded).  grid = waves, block = 64
-__global__ void k_init_state_rowlane(double* state, long long nw, const double* __restrict__ uinit, int N, long long ncols_used)
+// cpw: columns per wave (4, or N*floor(4/N) in the sample-aligned packing of the implicit-midpoint kernels)
+__global__ void k_init_state_rowlane(double* state, long long nw, const double* __restrict__ uinit, int N, long long ncols_used,
+                                     int cpw)
 {
     const int lane = threadIdx.x;
     const long long w = blockIdx.x;
-    const long long col = 4 * w + (lane >> 4);
+    const int c = lane >> 4;
+    const long long col = w * cpw + c;
     for (int r = 0; r < JQ_ROWLANE_ROWS; ++r) {
         double val = 0.0;
-        if (r == 0 && col < ncols_used) val = uinit[(col % N) * 16 + (lane & 15)];
+        if (r == 0 && c < cpw && col < ncols_used) val = uinit[(col % N) * 16 + (lane & 15)];
         state[((size_t)r * nw + w) * 64 + lane] = val;
     }
 }
@@ -332,3 +335,40 @@ __global__ void k_terminal_rowlane(double* state, long long nw, const double* __
     res[(size_t)s * 4 + 2] = re;
     res[(size_t)s * 4 + 3] = im;
 }
+
+// implicit-midpoint variant (src/evalobjgrad.jl:1221-1271): secondaryobjf = dt * tinv / 4 * sum(penal_m) (leak_scale),
+// lambda(T) = -2/N^2 (s1 Vtr + s2 Vti),  -2/N^2 (-s1 Vti + s2 Vtr)  with s1 + i s2 = N s  (true lambda_i, not negated)
+__global__ void k_terminal_rowlane_imr(double* state, long long nw, const double* __restrict__ vtr, const double* __restrict__ vti,
+                                       int N, int nsamples, double leak_scale, double* res, int cpw)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsamples) return;
+    double re = 0.0, im = 0.0, lk = 0.0;
+    for (int ic = 0; ic < N; ++ic) {
+        const long long col = (long long)s * N + ic;
+        const size_t base = (size_t)(col / cpw) * 64 + (size_t)(col % cpw) * 16;
+        for (int r = 0; r < 16; ++r) {
+            const double u = state[base + r], v = state[(size_t)nw * 64 + base + r];
+            const double tr = vtr[ic * 16 + r], ti = vti[ic * 16 + r];
+            re += u * tr - v * ti;
+            im += u * ti + v * tr;
+            lk += state[(size_t)(JQ_ROWLANE_ARRAYS + JQ_MAXNC) * nw * 64 + base + r];
+        }
+    }
+    re /= N;
+    im /= N;
+    for (int ic = 0; ic < N; ++ic) {
+        const long long col = (long long)s * N + ic;
+        const size_t base = (size_t)(col / cpw) * 64 + (size_t)(col % cpw) * 16;
+        for (int r = 0; r < 16; ++r) {
+            const double tr = vtr[ic * 16 + r], ti = vti[ic * 16 + r];
+            state[(size_t)2 * nw * 64 + base + r] = -2.0 / N * (re * tr + im * ti);
+            state[(size_t)3 * nw * 64 + base + r] = -2.0 / N * (-re * ti + im * tr);
+        }
+    }
+    res[(size_t)s * 4 + 0] = 1.0 - (re * re + im * im);
+    res[(size_t)s * 4 + 1] = leak_scale * lk;
+    res[(size_t)s * 4 + 2] = re;
+    res[(size_t)s * 4 + 3] = im;
+}
+

@@ -11,6 +11,7 @@
 #include "jq_kernels.h"
 #include "jq_lane_kernels.h"
 #include "jq_rowlane_kernels.h"
+#include "jq_rowlane_imr_kernels.h"
 
 #include <algorithm>
 #include <cmath>
@@ -29,6 +30,9 @@ struct jq_handle {
     hipStream_t stream = nullptr;
     // problem
     int Ntot = 0, N = 0, Nc = 0, Nfreq = 0, nsteps = 0, m = 0, objFuncType = 1;
+    int integrator = 1;         // 1 Stormer-Verlet, 2 implicit midpoint (JACOBI_SOLVER_M fixed-point solver)
+    int imr_max_iter = 100;
+    double imr_tol = 1e-12;
     int solver_id = 1;          // 1 NEUMANN_SOLVER, 2 JACOBI_SOLVER
     double solver_tol = 0.0;
     double T = 0.0;
@@ -608,6 +612,23 @@ extern "C" int jq_set_linear_solver(jq_handle* h, int32_t solver_id, int32_t max
     return JQ_OK;
 }
 
+extern "C" int jq_set_integrator(jq_handle* h, int32_t integrator_id, int32_t max_iter, double tol)
+{
+    if (!h) return JQ_EINVAL;
+    if (integrator_id == 1) {
+        h->integrator = 1;
+        return JQ_OK;
+    }
+    if (integrator_id != 2) return fail(h, JQ_EUNSUPPORTED, "jq_set_integrator: 1 = Stormer-Verlet, 2 = implicit midpoint");
+    if (max_iter < 1 || !(tol > 0.0)) return fail(h, JQ_EINVAL, "jq_set_integrator: implicit midpoint needs max_iter >= 1 and tol > 0");
+    if (h->rl_npj == 0)
+        return fail(h, JQ_EUNSUPPORTED, "jq_set_integrator: the implicit-midpoint path is implemented for Ntot <= 16 (row-lane kernels)");
+    h->integrator = 2;
+    h->imr_max_iter = max_iter;
+    h->imr_tol = tol;
+    return JQ_OK;
+}
+
 extern "C" int jq_update_target(jq_handle* h, const double* Utr, const double* Uti)
 {
     if (!h) return JQ_EINVAL;
@@ -739,6 +760,25 @@ static int select_rowlane_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_
     return fail(h, JQ_EUNSUPPORTED, "no row-lane kernel for this Hilbert dimension");
 }
 
+#define JQ_DECLM(npj)                                                        \
+    extern template __global__ void k_forward_rowlane_imr<npj>(PropArgs);    \
+    extern template __global__ void k_backward_rowlane_imr<npj>(PropArgs);
+JQ_FOR_EACH_ROWLANE(JQ_DECLM)
+#undef JQ_DECLM
+
+static int select_rowlane_imr_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
+{
+#define JQ_PICKM(npj)                         \
+    if (h->rl_npj == npj) {                   \
+        *fwd = k_forward_rowlane_imr<npj>;    \
+        *bwd = k_backward_rowlane_imr<npj>;   \
+        return JQ_OK;                         \
+    }
+    JQ_FOR_EACH_ROWLANE(JQ_PICKM)
+#undef JQ_PICKM
+    return fail(h, JQ_EUNSUPPORTED, "no implicit-midpoint kernel for this Hilbert dimension");
+}
+
 struct EvalOut {
     std::vector<double> res;    // [nsamples][4] primary, secondary, Re s, Im s
     std::vector<double> grad0;  // forced adjoint (total gradient), weighted sum over samples
@@ -769,15 +809,21 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     // kernels, one wave per slab (jq_coop_kernels.h explains the trade-off)
     // small Hilbert spaces: lane kernels, one lane per column (jq_lane_kernels.h)
     const long long ncols_used = (long long)nsamples * h->N;
-    const bool rl = h->rl_npj > 0 && h->solver_id == 1 && ncols_used <= h->rl_max_cols;
+    const bool imr = (h->integrator == 2);
+    if (imr && (h->rl_npj == 0 || h->N > 4))
+        return fail(h, JQ_EUNSUPPORTED, "implicit midpoint: implemented for Ntot <= 16 and N <= 4 (the columns of an "
+                                        "evaluation share one wave for the solver's per-evaluation convergence test)");
+    const int cpw = imr ? imr_cols_per_wave(h->N) : 4;      // columns per wave of the row-lane kernels
+    const bool rl = imr || (h->rl_npj > 0 && h->solver_id == 1 && ncols_used <= h->rl_max_cols);
     const bool lane = !rl && h->lane_np > 0 && h->solver_id == 1 && ncols_used >= h->lane_min_cols && ncols_used <= h->lane_max_cols;
-    const long long ncols = rl ? (ncols_used + 3) / 4 * 4 : (ncols_used + 63) / 64 * 64;
-    const long long nwaves_rl = ncols / 4;
+    const long long nwaves_rl = (ncols_used + cpw - 1) / cpw;
+    const long long ncols = rl ? 4 * nwaves_rl : (ncols_used + 63) / 64 * 64;      // row-lane: column SLOTS (4 per wave)
     const bool coop = !lane && !rl && h->mat_elems_c > 0 && h->solver_id == 1 && nslabs <= h->coop_max_slabs;
     prop_kernel_t kfwd, kbwd;
     lane_init_t klinit = nullptr;
     lane_term_t klterm = nullptr;
-    int rc = rl ? select_rowlane_kernels(h, &kfwd, &kbwd)
+    int rc = imr ? select_rowlane_imr_kernels(h, &kfwd, &kbwd)
+             : rl ? select_rowlane_kernels(h, &kfwd, &kbwd)
              : lane ? select_lane_kernels(h, &kfwd, &kbwd, &klinit, &klterm)
                   : coop ? select_coop_kernels(h, &kfwd, &kbwd) : select_kernels(h, &kfwd, &kbwd);
     if (rc) return rc;
@@ -829,11 +875,12 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     HIPCHK(h, hipMemcpyAsync(h->d_pcof, pcof, (size_t)ncoeff * sizeof(double), hipMemcpyHostToDevice, s));
     bool use_shift = false;
     std::vector<double> colinfo(colinfo_doubles, 0.0);
-    if (lane || rl) {   // [eps per column | weight per column]
+    if (lane || rl) {   // [eps per column slot | weight per column slot]
         for (long long c = 0; c < ncols_used; ++c) {
             const int smp = (int)(c / h->N);
-            colinfo[c] = eps ? eps[smp] : 0.0;
-            colinfo[ncols + c] = wgt ? wgt[smp] : 1.0;
+            const long long slot = rl ? (c / cpw) * 4 + (c % cpw) : c;
+            colinfo[slot] = eps ? eps[smp] : 0.0;
+            colinfo[ncols + slot] = wgt ? wgt[smp] : 1.0;
             if (eps && eps[smp] != 0.0) use_shift = true;
         }
     } else {
@@ -871,6 +918,10 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     a.nslabs = rl ? (int)nwaves_rl : lane ? (int)ncols : nslabs; a.Ncoupled = h->Nc; a.Ntot = h->Ntot; a.N = h->N; a.use_shift = use_shift ? 1 : 0;
     a.tinv = 1.0 / h->T; a.state_stride = h->state_stride;
     a.jacobi_tol2 = (h->solver_id == 2) ? h->solver_tol * h->solver_tol : 0.0;
+    if (imr) {   // fixed-point solver of the implicit-midpoint step: iteration cap and per-lane threshold (jq_rowlane_imr_kernels.h)
+        a.m = h->imr_max_iter;
+        a.jacobi_tol2 = h->imr_tol * h->imr_tol;
+    }
     for (int q = 0; q < JQ_MAXNC; ++q) a.bw_trace[q] = h->bw_trace[q];
     // dynamic LDS layout: [operator staging | tables wd, ws | (backward: carry, parking images)]
     // cooperative kernels: [two operator slots | tables wd, ws | two x exchange buffers]
@@ -901,7 +952,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
 
     if (rl)
         hipLaunchKernelGGL(k_init_state_rowlane, dim3((unsigned)nwaves_rl), dim3(64), 0, s, h->d_state, nwaves_rl, h->d_uinit_r, h->N,
-                           ncols_used);
+                           ncols_used, cpw);
     else if (lane)
         hipLaunchKernelGGL(klinit, dim3((unsigned)(ncols / 64)), dim3(64), 0, s, h->d_state, ncols, h->d_uinit_l, h->N, ncols_used);
     else
@@ -937,8 +988,11 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
         mfma += (long long)nslabs * nc * (8 + 2 * h->m) * tiles;
     }
     HIPCHK(h, hipGetLastError());
-    const double leak_scale = 0.5 * dt * (1.0 / h->T);
-    if (rl)
+    const double leak_scale = imr ? 0.25 * dt * (1.0 / h->T) : 0.5 * dt * (1.0 / h->T);
+    if (imr)
+        hipLaunchKernelGGL(k_terminal_rowlane_imr, dim3((nsamples + 63) / 64), dim3(64), 0, s, h->d_state, nwaves_rl, h->d_vtr_r,
+                           h->d_vti_r, h->N, nsamples, leak_scale, h->d_res, cpw);
+    else if (rl)
         hipLaunchKernelGGL(k_terminal_rowlane, dim3((nsamples + 63) / 64), dim3(64), 0, s, h->d_state, nwaves_rl, h->d_vtr_r,
                            h->d_vti_r, h->N, nsamples, leak_scale, h->d_res);
     else if (lane)
@@ -1032,7 +1086,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     h->timing.n_backward_launches = (long long)((evi - 2) / 2 - nfwd);
     h->timing.mfma_executed = mfma;
     h->timing.svts = (long long)nsamples * h->N * h->nsteps;
-    h->timing.kernel_family = rl ? 3 : lane ? 2 : coop ? 1 : 0;
+    h->timing.kernel_family = imr ? 4 : rl ? 3 : lane ? 2 : coop ? 1 : 0;
     h->timing.kernel_size = rl ? h->rl_npj : lane ? h->lane_np : h->NT;
     h->timing.kernel_band = (rl || lane) ? 0 : coop ? h->BWc : h->BW;
     h->timing.reserved = 0;

@@ -14,7 +14,8 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from .objparams import JACOBI_SOLVER, NEUMANN_SOLVER, objparams
+from .objparams import (JACOBI_SOLVER, JACOBI_SOLVER_M, NEUMANN_SOLVER, Implicit_Midpoint, Stormer_Verlet,
+                        objparams)
 
 
 def _f64(a):
@@ -30,9 +31,16 @@ class Working_Arrays_HIP:
     after construction (Hconst, wmat_real, Utarget_r/i, linear_solver.max_iter) are re-synchronised
     with the device at every call, so `params` stays the single source of truth like in the reference."""
 
+    INTEGRATOR = Stormer_Verlet
+    SOLVERS = (NEUMANN_SOLVER, JACOBI_SOLVER)
+
+    def _weights(self, p):
+        """leakage weights of this path: params.wmat_real (src/evalobjgrad.jl:583)"""
+        return _f64(p.wmat_real)
+
     def __init__(self, params: objparams, nCoeff: int):
         L = _lib.load()
-        if params.linear_solver.solver_id not in (NEUMANN_SOLVER, JACOBI_SOLVER):
+        if params.linear_solver.solver_id not in self.SOLVERS:
             raise ValueError("Please specify a supported linear solver")
         self.params = params
         self.nCoeff = int(nCoeff)
@@ -41,10 +49,10 @@ class Working_Arrays_HIP:
         hs = np.concatenate([_f64(h) for h in p.Hsym_ops]) if p.Ncoupled else np.zeros(1)
         ha = np.concatenate([_f64(h) for h in p.Hanti_ops]) if p.Ncoupled else np.zeros(1)
         self._hconst = _f64(p.Hconst).copy()
-        self._wd = _f64(p.wmat_real).copy()
+        self._wd = self._weights(p).copy()
         self._utr = _f64(p.Utarget_r).copy()
         self._uti = _f64(p.Utarget_i).copy()
-        self._m = int(p.linear_solver.max_iter)
+        self._m = int(p.linear_solver.max_iter) if self.INTEGRATOR == Stormer_Verlet else 0
         self._solver = None
         keep = [self._hconst, hs, ha, _f64(p.Uinit), self._utr, self._uti, self._wd, _f64(p.Cfreq[:p.Ncoupled, :])]
         prob = _lib.jq_problem(p.Ntot, p.N, p.Ncoupled, p.Nfreq, p.nsteps, self._m, p.objFuncType, 0, p.T,
@@ -71,20 +79,23 @@ class Working_Arrays_HIP:
         """Push post-construction mutations of `params` to the device (only what changed)."""
         L, p, h = _lib.load(), self.params, self.handle
         ls = p.linear_solver
-        if ls.solver_id not in (NEUMANN_SOLVER, JACOBI_SOLVER):
+        if ls.solver_id not in self.SOLVERS:
             raise ValueError("Please specify a supported linear solver")
         key = (int(ls.solver_id), int(ls.max_iter), float(ls.tol))
         if key != self._solver:
-            _lib.check(L.jq_set_linear_solver(h, key[0], key[1], key[2]), h)
+            if self.INTEGRATOR == Stormer_Verlet:
+                _lib.check(L.jq_set_linear_solver(h, key[0], key[1], key[2]), h)
+                self._m = key[1]
+            else:
+                _lib.check(L.jq_set_integrator(h, Implicit_Midpoint, key[1], key[2]), h)
             self._solver = key
-            self._m = key[1]
         hc = _f64(p.Hconst)
         if not np.array_equal(hc, self._hconst):
             _lib.check(L.jq_update_hconst(h, _ptr(hc)), h)
             self._hconst = hc.copy()
-        wd = _f64(p.wmat_real)
+        wd = self._weights(p)
         if wd.size != p.Ntot:
-            raise NotImplementedError("only Diagonal wmat_real (given as its diagonal) is supported")
+            raise NotImplementedError("only Diagonal weight matrices (given as their diagonal) are supported")
         if not np.array_equal(wd, self._wd):
             _lib.check(L.jq_update_wmat_diag(h, _ptr(wd)), h)
             self._wd = wd.copy()
@@ -97,6 +108,18 @@ class Working_Arrays_HIP:
         t = _lib.jq_timing()
         _lib.check(_lib.load().jq_last_timing(self.handle, ctypes.byref(t)), self.handle)
         return {k: getattr(t, k) for k, _ in _lib.jq_timing._fields_}
+
+
+class Working_Arrays_M_HIP(Working_Arrays_HIP):
+    """Working_Arrays_M (src/evalobjgrad.jl:445-500): selects the IMPLICIT-MIDPOINT method of traceobjgrad
+    (:1042-1481) the way the reference does, by the type of `wa`.  `params.linear_solver` must be
+    lsolver_object(solver=JACOBI_SOLVER_M, max_iter=..., tol=...) (test/runtests.jl:70); the leakage weights of this
+    path are params.wmat (:1147), not params.wmat_real.  Device support: Ntot <= 16."""
+    INTEGRATOR = Implicit_Midpoint
+    SOLVERS = (JACOBI_SOLVER_M,)
+
+    def _weights(self, p):
+        return _f64(p.wmat)
 
 
 def traceobjgrad(pcof0, params: objparams, wa: Working_Arrays_HIP, verbose: bool = False, evaladjoint: bool = True):

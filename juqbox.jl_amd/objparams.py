@@ -11,10 +11,11 @@ import numpy as np
 from . import setup_utils
 
 Stormer_Verlet = 1      # src/evalobjgrad.jl:1
-Implicit_Midpoint = 2   # src/evalobjgrad.jl:2 (not accelerated: out of scope)
+Implicit_Midpoint = 2   # src/evalobjgrad.jl:2 (accelerated for Ntot <= 16: Working_Arrays_M_HIP)
 
 NEUMANN_SOLVER = 1      # src/linear_solvers.jl:5
 JACOBI_SOLVER = 2       # src/linear_solvers.jl:6
+JACOBI_SOLVER_M = 4     # src/linear_solvers.jl:8 (fixed-point solver of the implicit-midpoint step)
 
 
 class lsolver_object:
@@ -26,8 +27,10 @@ class lsolver_object:
             self.solver_name = "Jacobi"
         elif solver == NEUMANN_SOLVER:
             self.solver_name = "Neumann"
+        elif solver == JACOBI_SOLVER_M:
+            self.solver_name = "Jacobi from Implicit Midpoint"            # :52-55 (tol is NOT scaled by sqrt(nrhs))
         else:
-            # GAUSSIAN_ELIM_SOLVER / JACOBI_SOLVER_M belong to paths that are out of scope here
+            # GAUSSIAN_ELIM_SOLVER belongs to a path that is out of scope here
             raise ValueError("Please specify a supported linear solver")   # :59
         self.tol = float(tol)
         self.max_iter = int(max_iter)
@@ -122,8 +125,8 @@ class objparams:
         self.save_pcof_hist = False
         self.pcof_hist = []
         self.sv_type = 1
-        if Integrator != Stormer_Verlet:
-            raise NotImplementedError("only the Stormer-Verlet integrator is accelerated")
+        if Integrator not in (Stormer_Verlet, Implicit_Midpoint):
+            raise NotImplementedError("Integrator must be Stormer_Verlet (1) or Implicit_Midpoint (2)")
         self.Integrator_id = Integrator
 
         if linear_solver is None:

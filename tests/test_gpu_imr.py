@@ -1,0 +1,136 @@
+"""GPU (-m gpu): the implicit-midpoint path (traceobjgrad for Working_Arrays_M,
+src/evalobjgrad.jl:1042-1481) through the C ABI (jq_set_integrator) and the mirrored callbacks."""
+import json
+import os
+
+import numpy as np
+import pytest
+from conftest import case_inputs, load_golden, reference_pass
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def _imr_params(jq, case):
+    params, info, pcof, _ = case_inputs(case)
+    params.Integrator_id = jq.Implicit_Midpoint                                    # test/runtests.jl:69-70
+    params.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER_M, max_iter=100, tol=1e-12, nrhs=params.N)
+    return params, pcof
+
+
+@pytest.mark.parametrize("case", ["rabi", "swap02", "flux", "cnot2", "cnot2-leakieq", "cnot2-jacobi"])
+def test_reference_imr_golden_through_the_callbacks(jq, case):
+    """The implicit-midpoint goldens of the reference (second loop of test/runtests.jl) whose Hilbert space fits the
+    row-lane kernels (Ntot <= 16); cnot3-imr (Ntot = 96) is pinned for the CPU oracle only."""
+    params, pcof = _imr_params(jq, case)
+    golden = load_golden(case + "-imr")
+    wa = jq.Working_Arrays_M_HIP(params, pcof.size)
+    n = pcof.size
+    if params.objFuncType == 3:                      # test/evalGrad.jl:14-25
+        obj = np.array([jq.eval_f_par(pcof, params, wa), 0.0])
+        g = np.zeros(1)
+        jq.eval_g_par(pcof, g, params, wa)
+        obj[1] = g[0]
+        gf, jac = np.zeros(n), np.zeros(n)
+        jq.eval_grad_f_par(pcof, gf, params, wa)
+        jq.eval_jac_g_par(pcof, [], [], jac, params, wa)
+        grad = np.concatenate([gf, jac])
+    else:
+        obj = np.array([jq.eval_f_par(pcof, params, wa)])
+        grad = np.zeros(n)
+        jq.eval_grad_f_par(pcof, grad, params, wa)
+    assert reference_pass(obj, golden["obj0"]), (obj, golden["obj0"])
+    assert reference_pass(grad, golden["grad0"])
+    assert wa.last_timing()["kernel_family"] == 4
+    wa.close()
+
+
+@pytest.mark.parametrize("case", ["swap02", "cnot1", "cnot2-leakieq"])
+def test_imr_matches_oracle_including_history_and_ensemble(jq, case):
+    from oracle.oracle import Oracle
+    params, pcof = _imr_params(jq, case)
+    orc = Oracle(params)
+    r = orc.traceobjgrad_imr(pcof, 100, 1e-12, history=True)
+    wa = jq.Working_Arrays_M_HIP(params, pcof.size)
+    objfv, tg, prim, sec, tinf, ig, lg = jq.traceobjgrad(pcof, params, wa, False, True)
+    gn = np.linalg.norm(r["totalgrad"])
+    assert abs(prim - r["primaryobjf"]) <= max(TOL * abs(r["primaryobjf"]), 1e-14)
+    assert abs(sec - r["secondaryobjf"]) <= max(TOL * abs(r["secondaryobjf"]), 1e-18)
+    assert np.linalg.norm(tg - r["totalgrad"]) <= TOL * gn
+    assert np.linalg.norm(ig - r["infidelgrad"]) <= TOL * gn
+    if params.objFuncType != 1:
+        assert np.linalg.norm(lg - r["leakgrad"]) <= TOL * gn
+    _, hist, _ = jq.traceobjgrad(pcof, params, wa, True, False)
+    assert np.max(np.abs(hist - r["history"])) < 1e-10
+    # weighted ensemble with a diagonal perturbation = weighted sum of single evaluations of the oracle
+    rng = np.random.default_rng(3)
+    nodes, weights = 0.02 * rng.standard_normal(5), rng.random(5)
+    shift = 0.05 * rng.standard_normal(params.Ntot)
+    shift[0] = 0.0
+    jq.eval_f_g_grad(pcof, params, wa, nodes, weights, True, shift=shift)
+    inf = leak = 0.0
+    g = np.zeros(pcof.size)
+    H0 = params.Hconst.copy()
+    for ep, wq in zip(nodes, weights):
+        params.Hconst = H0 + np.diag(ep * shift)
+        rr = Oracle(params).traceobjgrad_imr(pcof, 100, 1e-12)
+        inf += wq * rr["primaryobjf"]
+        leak += wq * rr["secondaryobjf"]
+        g += wq * rr["infidelgrad"]
+    params.Hconst = H0
+    assert abs(params.last_infidelity - inf) <= TOL * abs(inf)
+    assert abs(params.last_leak - leak) <= max(TOL * abs(leak), 1e-18)
+    assert np.linalg.norm(params.last_infidelity_grad - g) <= TOL * np.linalg.norm(g)
+    wa.close()
+
+
+def test_imr_is_refused_beyond_the_row_lane_sizes(jq):
+    params, pcof = _imr_params(jq, "cnot3")
+    wa = jq.Working_Arrays_M_HIP(params, pcof.size)
+    with pytest.raises(RuntimeError) as e:
+        jq.traceobjgrad(pcof, params, wa)
+    assert "Ntot <= 16" in str(e.value)
+    wa.close()
+
+
+@pytest.mark.parametrize("cfg", [(2, 1, 1, 1, 9, 1), (5, 3, 2, 2, 14, 3), (9, 2, 3, 1, 11, 2), (12, 4, 2, 2, 8, 1), (16, 4, 4, 1, 6, 3)],
+                         ids=lambda c: "Ntot%d_N%d_Nc%d_f%d_o%d" % (c[0], c[1], c[2], c[3], c[5]))
+def test_imr_random_problems_match_oracle(jq, cfg):
+    """Sizes and paddings the reference cases do not reach: every row-lane instantiation (NPJ 2..16), N = 1..4 columns
+    (one, two or four evaluations per wave; an idle row for N = 3), 1..4 controls, objFuncType 1/2/3, several chunks,
+    ensembles with ragged last waves."""
+    from oracle.oracle import Oracle
+    from test_gpu_random import random_problem
+    Ntot, N, Nc, Nfreq, nsteps, oft = cfg
+    rng = np.random.default_rng(77 + Ntot)
+    p, pcof = random_problem(jq, rng, Ntot, N, Nc, Nfreq, nsteps, 3, oft, False)
+    p.Integrator_id = jq.Implicit_Midpoint
+    p.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER_M, max_iter=60, tol=1e-11, nrhs=N)
+    p.wmat = p.wmat_real.copy()
+    os.environ["JQ_CHUNK_STEPS"] = "5"
+    try:
+        wa = jq.Working_Arrays_M_HIP(p, pcof.size)
+    finally:
+        os.environ.pop("JQ_CHUNK_STEPS", None)
+    r = Oracle(p, use_sparse=False).traceobjgrad_imr(pcof, 60, 1e-11, history=True)
+    objfv, tg, prim, sec, tinf, ig, lg = jq.traceobjgrad(pcof, p, wa, False, True)
+    gn = np.linalg.norm(r["totalgrad"])
+    assert abs(prim - r["primaryobjf"]) <= 1e-9 and abs(sec - r["secondaryobjf"]) <= 1e-9 * max(abs(r["secondaryobjf"]), 1e-3)
+    assert np.linalg.norm(tg - r["totalgrad"]) <= 1e-9 * gn and np.linalg.norm(ig - r["infidelgrad"]) <= 1e-9 * gn
+    _, hist, _ = jq.traceobjgrad(pcof, p, wa, True, False)
+    assert np.max(np.abs(hist - r["history"])) < 1e-10
+    for nq in (1, 3, 7):
+        nodes, weights = 0.05 * rng.standard_normal(nq), rng.random(nq)
+        shift = 0.05 * rng.standard_normal(Ntot)
+        shift[0] = 0.0
+        jq.eval_f_g_grad(pcof, p, wa, nodes, weights, True, shift=shift)
+        inf, g, H0 = 0.0, np.zeros(pcof.size), p.Hconst.copy()
+        for ep, wq in zip(nodes, weights):
+            p.Hconst = H0 + np.diag(ep * shift)
+            rr = Oracle(p, use_sparse=False).traceobjgrad_imr(pcof, 60, 1e-11)
+            inf += wq * rr["primaryobjf"]
+            g += wq * rr["infidelgrad"]
+        p.Hconst = H0
+        assert abs(p.last_infidelity - inf) <= 1e-9 * abs(inf)
+        assert np.linalg.norm(p.last_infidelity_grad - g) <= 1e-9 * np.linalg.norm(g)
+    wa.close()
