@@ -161,6 +161,59 @@ __global__ void k_terminal(double* state, long long stride, const double* __rest
     }
 }
 
+// Implicit-midpoint variant of k_terminal (src/evalobjgrad.jl:1221-1271): lambda(T) = -2/N (re Vtr + im Vti),
+// -2/N (-re Vti + im Vtr) with the true lambda_i in slot NU; secondaryobjf = dt*tinv/4 * sum(penal_m) (leak_scale).
+// Fidelity, leak integral and adjoint terminal condition per sample.
+//   s = tr(Vtg' V)/N with ur = vr, ui = -vi (tracefidcomplex, src/evalobjgrad.jl:2078-2084)
+//   primaryobjf = 1 - |s|^2 (:759) ; secondaryobjf = dt/2 * tinv * sum(leak partials) (:716-718)
+//   lambda(T) (init_adjoint!, :2029-2042)
+// res[sample][4] = { primaryobjf, secondaryobjf, Re s, Im s }.   grid = nslabs, block = 64
+__global__ void k_terminal_imr(double* state, long long stride, const double* __restrict__ vtr_img,
+                           const double* __restrict__ vti_img, int KT, int N, int sps, int nsamples, double leak_scale,
+                           double* res)
+{
+    __shared__ double part[3][64];
+    double* st = state + (size_t)blockIdx.x * stride;
+    const int lane = threadIdx.x;
+    const int col = lane & 15;
+    const int sl = (col < sps * N) ? col / N : -1;
+    double re = 0.0, im = 0.0;
+    for (int kk = 0; kk < KT; ++kk) {
+        const double u = st[kk * 64 + lane], v = st[(KT + kk) * 64 + lane];
+        const double tr = vtr_img[kk * 64 + lane], ti = vti_img[kk * 64 + lane];
+        re += u * tr - v * ti;
+        im += u * ti + v * tr;
+    }
+    part[0][lane] = re;
+    part[1][lane] = im;
+    part[2][lane] = st[(JQ_STATE_ARRAYS * KT + JQ_MAXNC) * 64 + lane];
+    __syncthreads();
+    double sre = 0.0, sim = 0.0, slk = 0.0;
+    for (int l = 0; l < 64; ++l) {
+        const int c2 = l & 15;
+        const int s2 = (c2 < sps * N) ? c2 / N : -1;
+        if (s2 == sl && sl >= 0) {
+            sre += part[0][l];
+            sim += part[1][l];
+            slk += part[2][l];
+        }
+    }
+    sre /= N;
+    sim /= N;
+    for (int kk = 0; kk < KT; ++kk) {
+        const double tr = vtr_img[kk * 64 + lane], ti = vti_img[kk * 64 + lane];
+        st[(2 * KT + kk) * 64 + lane] = (sl >= 0) ? -2.0 / N * (sre * tr + sim * ti) : 0.0;   // lambdar
+        st[(3 * KT + kk) * 64 + lane] = (sl >= 0) ? -2.0 / N * (-sre * ti + sim * tr) : 0.0;  // lambdai
+    }
+    const int sample = blockIdx.x * sps + sl;
+    if (sl >= 0 && (col % N) == 0 && (lane >> 4) == 0 && sample < nsamples) {
+        res[(size_t)sample * 4 + 0] = 1.0 - (sre * sre + sim * sim);
+        res[(size_t)sample * 4 + 1] = leak_scale * slk;
+        res[(size_t)sample * 4 + 2] = sre;
+        res[(size_t)sample * 4 + 3] = sim;
+    }
+}
+
 // R[m][k] = sum_slab traces[slab][m][k] in slab order (deterministic).  thread per (m,k)
 __global__ void k_trace_reduce(const double* __restrict__ traces, int nslabs, int nsteps_chunk, int ntr, double* R)
 {

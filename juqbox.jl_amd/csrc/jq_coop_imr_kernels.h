@@ -1,0 +1,279 @@
+// jq_coop_imr_kernels.h -- IMPLICIT MIDPOINT propagators for Ntot > 16 (MFMA), small batches: the row-split
+// ("cooperative") mapping of jq_coop_kernels.h -- one slab of 16 columns per workgroup of NT waves, wave mt owns tile
+// row mt of every array -- applied to traceobjgrad for Working_Arrays_M (src/evalobjgrad.jl:1042-1481; m_step!,
+// src/ImplicitMidpoint.jl:120-227; jacobi_midpoint, src/linear_solvers.jl:156-270).  The algorithm and the exact
+// reproduction of the reference's stopping rule are described in jq_rowlane_imr_kernels.h.
+//
+// The row split is what makes this integrator fit: a step keeps rhs, the current and the next iterate (6 arrays) on top
+// of the state, the adjoint and their step sums; per wave an array is ONE d4 (8 registers).
+//
+// LDS: [K(t+h/2) image | S(t+h/2) image | tables wd, ws | two x exchange buffers | norm partials 2 x NT x 64].
+// Both operator images of a step stay resident for all products of its fixed-point iterations (they are fetched once
+// per step; the two slots are re-used for the (Hsym_q, Hanti_q) pair of every control after the adjoint solve).
+// Per-evaluation convergence: every wave writes its rows' partial sums of squares per lane, and after one barrier
+// every lane adds up the NT x 4 x N entries of its own evaluation -- all waves reach the same decision.
+#pragma once
+#include "jq_coop_kernels.h"
+
+template <int NT, int BW>
+struct CoopImr {
+    Coop<NT, BW> c;          // exchange buffers + product (c.M is pointed at the wanted image by hand; its ring is unused)
+    char* smem;
+    const double* stream;
+    const double* cimg;
+    long long stride;
+    int pieces, wave, lane;
+    double* normbuf;         // [2][NT][64]
+    const double* Kimg;      // my row's tiles of the two resident images (lane offset applied)
+    const double* Simg;
+
+    __device__ __forceinline__ void setup(char* smem_, const PropArgs& a, int wave_, int lane_)
+    {
+        smem = smem_;
+        stream = a.stream;
+        cimg = a.cimg;
+        stride = a.stride;
+        pieces = a.pieces;
+        wave = wave_;
+        lane = lane_;
+        double* tab = (double*)(smem + a.lds_tab_off);
+        c.xbuf = tab + 32 * NT + lane;
+        c.xcur = 0;
+        c.mt = wave;
+        int k = (BW == JQ_BW_OD) ? wave : wave - BW;
+        if (k < 0) k = 0;
+        if (k > NT - coop_nb(NT, BW)) k = NT - coop_nb(NT, BW);
+        c.kb0 = k;
+        c.row_off = wave * coop_row_elems(NT, BW);
+        c.xown = (d4){0.0, 0.0, 0.0, 0.0};
+        c.M = nullptr;
+        normbuf = tab + 32 * NT + 2 * (4 * NT * 64);
+        Kimg = (const double*)smem + c.row_off + lane;
+        Simg = Kimg + stride;
+    }
+    // fetch two consecutive images (2*pieces KiB) into the two slots; all waves take part; ends with a barrier
+    __device__ __forceinline__ void load_pair(const double* src)
+    {
+        __syncthreads();                                   // every wave is done with the previous pair
+        unsigned lo;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lo));
+        const char* s = (const char*)src + lo * 16u;
+        for (int p = wave; p < 2 * pieces; p += NT)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s + (size_t)p * 1024),
+                                             (__attribute__((address_space(3))) void*)(smem + p * 1024), 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    // M * (published x) with the K / S image
+    __device__ __forceinline__ d4 mulK()
+    {
+        c.M = Kimg;
+        return c.mm_z();
+    }
+    __device__ __forceinline__ d4 mulS()
+    {
+        c.M = Simg;
+        return c.mm_z();
+    }
+    __device__ __forceinline__ void pub(const d4& x)
+    {
+        c.stage(x);
+        c.publish();
+    }
+    // (S pu - K pv - sw.*pv,  K pu + S pv + sw.*pu): the action of h/2 [S -K; K S] (+ the sample's diagonal shift)
+    __device__ __forceinline__ void applyB(const PropArgs& a, const d4& sw, const d4& pu, const d4& pv, d4& bu, d4& bv)
+    {
+        pub(pu);
+        bu = mulS();
+        bv = mulK();
+        pub(pv);
+        bu -= mulK();
+        bv += mulS();
+        if (a.use_shift) {
+            bu -= sw * pv;
+            bv += sw * pu;
+        }
+    }
+    // per-evaluation sums of squares (u and v parts) of d over the NT waves; result valid in every lane of every wave
+    __device__ __forceinline__ void sample_norms(const d4& du, const d4& dv, bool mask, int N, double& ru, double& rv)
+    {
+        const d4 pu = du * du, pv = dv * dv;
+        normbuf[wave * 64 + lane] = mask ? 0.0 : (pu[0] + pu[1]) + (pu[2] + pu[3]);
+        normbuf[(NT + wave) * 64 + lane] = mask ? 0.0 : (pv[0] + pv[1]) + (pv[2] + pv[3]);
+        __syncthreads();
+        const int c0 = min(((lane & 15) / N) * N, 16 - N);  // first column of my evaluation (idle columns: clamped)
+        ru = 0.0;
+        rv = 0.0;
+        for (int w = 0; w < NT; ++w)
+            for (int g = 0; g < 4; ++g)
+                for (int cc = 0; cc < N; ++cc) {
+                    ru += normbuf[w * 64 + g * 16 + c0 + cc];
+                    rv += normbuf[(NT + w) * 64 + g * 16 + c0 + cc];
+                }
+        __syncthreads();                                   // normbuf may be rewritten
+    }
+    // one implicit-midpoint step of (u, v); fu, fv: forcing already multiplied by h; valid: my column holds an evaluation
+    __device__ __forceinline__ void step(const PropArgs& a, const d4& sw, d4& u, d4& v, const d4& fu, const d4& fv, bool valid)
+    {
+        d4 bu, bv;
+        applyB(a, sw, u, v, bu, bv);
+        const d4 rhs_u = (u + fu) + bu, rhs_v = (v + fv) + bv;
+        d4 cu = rhs_u + bu, cv = rhs_v + bv;               // x_1 = rhs + B x_0
+        bool done = !valid;
+        for (int it = 1; it <= a.m; ++it) {
+            applyB(a, sw, cu, cv, bu, bv);
+            const d4 nu = rhs_u + bu, nv = rhs_v + bv;      // x_{it+1}; residual at x_it = x_it - x_{it+1}
+            double ru, rv;
+            sample_norms(cu - nu, cv - nv, done, a.N, ru, rv);
+            const bool conv = (ru < a.jacobi_tol2) && (rv < a.jacobi_tol2);
+            if (!done && !conv && it < a.m) {
+                cu = nu;
+                cv = nv;
+            } else {
+                done = true;
+            }
+            // every wave sees the same per-evaluation sums, so this exit is uniform over the workgroup
+            if (__ballot(!done) == 0ull) break;
+        }
+        u = cu;
+        v = cv;
+    }
+};
+
+// dynamic LDS of the cooperative implicit-midpoint kernels (bytes)
+__host__ __device__ inline size_t coop_imr_lds_bytes(int NT, long long stride)
+{
+    return (size_t)2 * stride * 8 + (size_t)32 * NT * 8 + (size_t)2 * (4 * NT * 64) * 8 + (size_t)2 * NT * 64 * 8;
+}
+
+template <int NT, int BW>
+__global__ __launch_bounds__(64 * NT) void k_forward_coop_imr(PropArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KT = 4 * NT;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4;
+    const int slab = blockIdx.x;
+    double* tab = (double*)(smem + a.lds_tab_off);
+    for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[(i & ~15) + 4 * (i & 3) + ((i >> 2) & 3)] = a.tabs[i];   // [block][g][r]
+    CoopImr<NT, BW> m;
+    m.setup(smem, a, wave, lane);
+    __syncthreads();
+    const d4 wdr = rows4(tab, wave, g), wsr = rows4(tab + 16 * NT, wave, g);
+    double* st = a.state + (size_t)slab * a.state_stride;
+    d4 u, v;
+    for (int r = 0; r < 4; ++r) {
+        u[r] = st[(4 * wave + r) * 64 + lane];
+        v[r] = st[(KT + 4 * wave + r) * 64 + lane];
+    }
+    double leak = 0.0;
+    const d4 sw = (0.5 * a.h * a.colinfo[(size_t)slab * 32 + (lane & 15)]) * wsr;
+    const bool valid = (lane & 15) < (16 / a.N) * a.N;
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    for (int n = 0; n < a.nsteps_chunk; ++n) {
+        m.load_pair(a.stream + (size_t)(2 * (2 * n + 1)) * a.stride);
+        const d4 us = u, vs = v;
+        m.step(a, sw, u, v, zero, zero, valid);
+        leak += dot4(wdr, (us + u) * (us + u) + (vs + v) * (vs + v));   // penal_m (src/evalobjgrad.jl:1214, :2158-2166)
+        if (a.hist_r) {
+            const int col = lane & 15;
+            if (slab == 0 && col < a.N) {
+                const size_t off = (size_t)(a.step0 + n + 1) * a.Ntot * a.N + (size_t)col * a.Ntot;
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * wave + 4 * r + g;
+                    if (row < a.Ntot) {
+                        a.hist_r[off + row] = u[r];
+                        a.hist_i[off + row] = -v[r];
+                    }
+                }
+            }
+        }
+    }
+    for (int r = 0; r < 4; ++r) {
+        st[(4 * wave + r) * 64 + lane] = u[r];
+        st[(KT + 4 * wave + r) * 64 + lane] = v[r];
+    }
+    wg_sum_store<NT>(leak, m.normbuf, &st[(JQ_STATE_ARRAYS * KT + JQ_MAXNC) * 64], wave, lane, true);
+}
+
+// Backward sweep (src/evalobjgrad.jl:1290-1336); trace records per wave as in k_backward_coop, in the slots of the
+// midpoint weights of k_gradacc (jq_rowlane_imr_kernels.h): tr[3] = -(B + C)/4, tr[4] = (A + D)/4.
+template <int NT, int BW>
+__global__ __launch_bounds__(64 * NT) void k_backward_coop_imr(PropArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KT = 4 * NT;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4;
+    const int slab = blockIdx.x;
+    const int Nc = a.Ncoupled;
+    double* tab = (double*)(smem + a.lds_tab_off);
+    for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[(i & ~15) + 4 * (i & 3) + ((i >> 2) & 3)] = a.tabs[i];   // [block][g][r]
+    CoopImr<NT, BW> m;
+    m.setup(smem, a, wave, lane);
+    __syncthreads();
+    const d4 wdr = rows4(tab, wave, g), wsr = rows4(tab + 16 * NT, wave, g);
+    double* st = a.state + (size_t)slab * a.state_stride;
+    d4 u, v, lr, li;
+    for (int r = 0; r < 4; ++r) {
+        u[r] = st[(4 * wave + r) * 64 + lane];
+        v[r] = st[(KT + 4 * wave + r) * 64 + lane];
+        lr[r] = st[(2 * KT + 4 * wave + r) * 64 + lane];
+        li[r] = st[(3 * KT + 4 * wave + r) * 64 + lane];
+    }
+    const d4 sw = (0.5 * a.h * a.colinfo[(size_t)slab * 32 + (lane & 15)]) * wsr;
+    const double wgt = a.colinfo[(size_t)slab * 32 + 16 + (lane & 15)];
+    const d4 cfw = (a.forced ? -a.h * a.tinv : 0.0) * wdr;            // h * (-tinv * W)
+    const bool valid = (lane & 15) < (16 / a.N) * a.N;
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    double* trw = a.traces + ((size_t)(slab * NT + wave) * a.nsteps_chunk) * (Nc * JQ_NTR);
+    for (int n = 0; n < a.nsteps_chunk; ++n) {
+        m.load_pair(a.stream + (size_t)(2 * (2 * n + 1)) * a.stride);
+        const d4 us = u, vs = v, lrs = lr, lis = li;
+        m.step(a, sw, u, v, zero, zero, valid);
+        const d4 su = u + us, sv = v + vs;
+        m.step(a, sw, lr, li, cfw * su, cfw * sv, valid);
+        const d4 smu = lr + lrs, snu = li + lis;
+        for (int q = 0; q < Nc; ++q) {
+            // the two slots now take (Hsym_q, Hanti_q): a.cimg = [Hsym_0.. | Hanti_0..] -> two separate fetches
+            __syncthreads();
+            {
+                unsigned lo;
+                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lo));
+                const char* s0 = (const char*)(a.cimg + (size_t)q * a.stride) + lo * 16u;
+                const char* s1 = (const char*)(a.cimg + (size_t)(Nc + q) * a.stride) + lo * 16u;
+                for (int p = wave; p < a.pieces; p += NT) {
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s0 + (size_t)p * 1024),
+                                                     (__attribute__((address_space(3))) void*)(smem + p * 1024), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s1 + (size_t)p * 1024),
+                                                     (__attribute__((address_space(3))) void*)(smem + a.stride * 8 + p * 1024), 16, 0, 0);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+            m.pub(sv);
+            const double B = -dot4(smu, m.mulK());       // slot 0 holds Hsym_q
+            const double D = dot4(snu, m.mulS());        // slot 1 holds Hanti_q
+            m.pub(su);
+            const double C = dot4(snu, m.mulK());
+            const double A = dot4(smu, m.mulS());
+            const double P = wave_sum((B + C) * wgt), Q = wave_sum((A + D) * wgt);
+            if (lane == 0) {
+                double* tr = trw + (size_t)n * (Nc * JQ_NTR) + q * JQ_NTR;
+                tr[0] = 0.0;
+                tr[1] = 0.0;
+                tr[2] = 0.0;
+                tr[3] = -0.25 * P;
+                tr[4] = 0.25 * Q;
+            }
+        }
+    }
+    for (int r = 0; r < 4; ++r) {
+        st[(4 * wave + r) * 64 + lane] = u[r];
+        st[(KT + 4 * wave + r) * 64 + lane] = v[r];
+        st[(2 * KT + 4 * wave + r) * 64 + lane] = lr[r];
+        st[(3 * KT + 4 * wave + r) * 64 + lane] = li[r];
+    }
+}

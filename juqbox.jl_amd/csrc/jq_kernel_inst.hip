@@ -2,12 +2,17 @@
 // the MFMA register form can be chosen per instantiation -- see Makefile).
 //   JQ_VARIANT 0: slab kernels, Neumann   1: slab kernels, Jacobi   2: cooperative (row-split) kernels
 //              3: lane kernels (one lane per column; JQ_NT = padded Hilbert dimension NP, JQ_BW unused)
+//              6: cooperative kernels of the implicit-midpoint integrator
 //              5: row-lane kernels of the implicit-midpoint integrator (JQ_NT = NPJ)
 //              4: row-lane kernels (one lane per (row, column); JQ_NT = padded row length NPJ, JQ_BW unused)
 #if !defined(JQ_NT) || !defined(JQ_BW) || !defined(JQ_VARIANT)
-#error "compile with -DJQ_NT=<tiles> -DJQ_BW=<band> -DJQ_VARIANT=<0..5>"
+#error "compile with -DJQ_NT=<tiles> -DJQ_BW=<band> -DJQ_VARIANT=<0..6>"
 #endif
-#if JQ_VARIANT == 5
+#if JQ_VARIANT == 6
+#include "jq_coop_imr_kernels.h"
+template __global__ void k_forward_coop_imr<JQ_NT, JQ_BW>(PropArgs);
+template __global__ void k_backward_coop_imr<JQ_NT, JQ_BW>(PropArgs);
+#elif JQ_VARIANT == 5
 #include "jq_rowlane_imr_kernels.h"
 template __global__ void k_forward_rowlane_imr<JQ_NT>(PropArgs);
 template __global__ void k_backward_rowlane_imr<JQ_NT>(PropArgs);

@@ -12,6 +12,7 @@
 #include "jq_lane_kernels.h"
 #include "jq_rowlane_kernels.h"
 #include "jq_rowlane_imr_kernels.h"
+#include "jq_coop_imr_kernels.h"
 
 #include <algorithm>
 #include <cmath>
@@ -621,8 +622,9 @@ extern "C" int jq_set_integrator(jq_handle* h, int32_t integrator_id, int32_t ma
     }
     if (integrator_id != 2) return fail(h, JQ_EUNSUPPORTED, "jq_set_integrator: 1 = Stormer-Verlet, 2 = implicit midpoint");
     if (max_iter < 1 || !(tol > 0.0)) return fail(h, JQ_EINVAL, "jq_set_integrator: implicit midpoint needs max_iter >= 1 and tol > 0");
-    if (h->rl_npj == 0)
-        return fail(h, JQ_EUNSUPPORTED, "jq_set_integrator: the implicit-midpoint path is implemented for Ntot <= 16 (row-lane kernels)");
+    if (!(h->rl_npj > 0 && h->N <= 4) && h->mat_elems_c == 0)
+        return fail(h, JQ_EUNSUPPORTED, "jq_set_integrator: the implicit-midpoint path needs Ntot <= 16 with N <= 4 (row-lane "
+                                        "kernels) or Ntot > 16 (cooperative kernels)");
     h->integrator = 2;
     h->imr_max_iter = max_iter;
     h->imr_tol = tol;
@@ -779,6 +781,25 @@ static int select_rowlane_imr_kernels(jq_handle* h, prop_kernel_t* fwd, prop_ker
     return fail(h, JQ_EUNSUPPORTED, "no implicit-midpoint kernel for this Hilbert dimension");
 }
 
+#define JQ_DECLCI(nt, bw)                                                    \
+    extern template __global__ void k_forward_coop_imr<nt, bw>(PropArgs);     \
+    extern template __global__ void k_backward_coop_imr<nt, bw>(PropArgs);
+JQ_FOR_EACH_COOP(JQ_DECLCI)
+#undef JQ_DECLCI
+
+static int select_coop_imr_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
+{
+#define JQ_PICKCI(nt, bw)                      \
+    if (h->NT == nt && h->BWc == bw) {         \
+        *fwd = k_forward_coop_imr<nt, bw>;     \
+        *bwd = k_backward_coop_imr<nt, bw>;    \
+        return JQ_OK;                          \
+    }
+    JQ_FOR_EACH_COOP(JQ_PICKCI)
+#undef JQ_PICKCI
+    return fail(h, JQ_EUNSUPPORTED, "no cooperative implicit-midpoint kernel for this Hilbert dimension / band width");
+}
+
 struct EvalOut {
     std::vector<double> res;    // [nsamples][4] primary, secondary, Re s, Im s
     std::vector<double> grad0;  // forced adjoint (total gradient), weighted sum over samples
@@ -809,20 +830,27 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     // kernels, one wave per slab (jq_coop_kernels.h explains the trade-off)
     // small Hilbert spaces: lane kernels, one lane per column (jq_lane_kernels.h)
     const long long ncols_used = (long long)nsamples * h->N;
+    // implicit midpoint: row-lane kernels for Ntot <= 16 with N <= 4 (the columns of an evaluation share one wave for the
+    // solver's per-evaluation convergence test), cooperative MFMA kernels (one slab per workgroup) otherwise
     const bool imr = (h->integrator == 2);
-    if (imr && (h->rl_npj == 0 || h->N > 4))
-        return fail(h, JQ_EUNSUPPORTED, "implicit midpoint: implemented for Ntot <= 16 and N <= 4 (the columns of an "
-                                        "evaluation share one wave for the solver's per-evaluation convergence test)");
-    const int cpw = imr ? imr_cols_per_wave(h->N) : 4;      // columns per wave of the row-lane kernels
-    const bool rl = imr || (h->rl_npj > 0 && h->solver_id == 1 && ncols_used <= h->rl_max_cols);
+    const bool imr_rl = imr && h->rl_npj > 0 && h->N <= 4;
+    const bool imr_coop = imr && !imr_rl;
+    if (imr_coop && (h->mat_elems_c == 0 || coop_imr_lds_bytes(h->NT, h->mat_elems_c) > 163840))
+        return fail(h, JQ_EUNSUPPORTED, "implicit midpoint: needs Ntot <= 16 with N <= 4, or 16 < Ntot <= 96");
+    if (imr_coop && nslabs > 4 * h->coop_max_slabs)
+        return fail(h, JQ_EUNSUPPORTED, "implicit midpoint for Ntot > 16 is implemented for small batches only (cooperative "
+                                        "kernels, at most four workgroups per CU)");
+    const int cpw = imr_rl ? imr_cols_per_wave(h->N) : 4;   // columns per wave of the row-lane kernels
+    const bool rl = imr_rl || (!imr && h->rl_npj > 0 && h->solver_id == 1 && ncols_used <= h->rl_max_cols);
     const bool lane = !rl && h->lane_np > 0 && h->solver_id == 1 && ncols_used >= h->lane_min_cols && ncols_used <= h->lane_max_cols;
     const long long nwaves_rl = (ncols_used + cpw - 1) / cpw;
     const long long ncols = rl ? 4 * nwaves_rl : (ncols_used + 63) / 64 * 64;      // row-lane: column SLOTS (4 per wave)
-    const bool coop = !lane && !rl && h->mat_elems_c > 0 && h->solver_id == 1 && nslabs <= h->coop_max_slabs;
+    const bool coop = imr_coop || (!lane && !rl && h->mat_elems_c > 0 && h->solver_id == 1 && nslabs <= h->coop_max_slabs);
     prop_kernel_t kfwd, kbwd;
     lane_init_t klinit = nullptr;
     lane_term_t klterm = nullptr;
-    int rc = imr ? select_rowlane_imr_kernels(h, &kfwd, &kbwd)
+    int rc = imr_coop ? select_coop_imr_kernels(h, &kfwd, &kbwd)
+             : imr_rl ? select_rowlane_imr_kernels(h, &kfwd, &kbwd)
              : rl ? select_rowlane_kernels(h, &kfwd, &kbwd)
              : lane ? select_lane_kernels(h, &kfwd, &kbwd, &klinit, &klterm)
                   : coop ? select_coop_kernels(h, &kfwd, &kbwd) : select_kernels(h, &kfwd, &kbwd);
@@ -928,7 +956,8 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     const int batch = coop ? 0 : h->batch;
     const size_t lds_stage = batch > 0 ? (size_t)2 * (2 * batch + 1) * 2 * stride * 8 + (size_t)2 * h->Nc * stride * 8
                                        : (size_t)2 * stride * 8;
-    const size_t lds_fwd = (lane || rl) ? 0 : lds_stage + (size_t)32 * h->NT * 8 + (coop ? (size_t)2 * h->KT * 64 * 8 : 0);
+    const size_t lds_fwd = (lane || rl) ? 0 : imr_coop ? coop_imr_lds_bytes(h->NT, stride)
+                                           : lds_stage + (size_t)32 * h->NT * 8 + (coop ? (size_t)2 * h->KT * 64 * 8 : 0);
     const size_t lds_bwd = rl ? (h->rl_npj > 8 ? (size_t)2 * h->Nc * h->rl_stride * 8 : 0) : lane ? 0 : coop ? lds_fwd
                                 : lds_fwd + (size_t)JQ_MAXNC * 256 * 8 + (h->park_lds ? (size_t)JQ_WAVES * h->KT * 64 * 8 : 0);
     a.batch = batch; a.lds_tab_off = (int)lds_stage;
@@ -989,7 +1018,10 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     }
     HIPCHK(h, hipGetLastError());
     const double leak_scale = imr ? 0.25 * dt * (1.0 / h->T) : 0.5 * dt * (1.0 / h->T);
-    if (imr)
+    if (imr_coop)
+        hipLaunchKernelGGL(k_terminal_imr, dim3(nslabs), dim3(64), 0, s, h->d_state, h->state_stride, h->d_vtr, h->d_vti, h->KT,
+                           h->N, h->sps, nsamples, leak_scale, h->d_res);
+    else if (imr)
         hipLaunchKernelGGL(k_terminal_rowlane_imr, dim3((nsamples + 63) / 64), dim3(64), 0, s, h->d_state, nwaves_rl, h->d_vtr_r,
                            h->d_vti_r, h->N, nsamples, leak_scale, h->d_res, cpw);
     else if (rl)
@@ -1084,9 +1116,9 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     h->timing.ms_generate = h->timing.ms_total - (fwd + bwd);
     h->timing.n_forward_launches = (long long)nfwd;
     h->timing.n_backward_launches = (long long)((evi - 2) / 2 - nfwd);
-    h->timing.mfma_executed = mfma;
+    h->timing.mfma_executed = imr ? 0 : mfma;   // (the iteration counts of the implicit-midpoint solver are data dependent)
     h->timing.svts = (long long)nsamples * h->N * h->nsteps;
-    h->timing.kernel_family = imr ? 4 : rl ? 3 : lane ? 2 : coop ? 1 : 0;
+    h->timing.kernel_family = imr_coop ? 5 : imr ? 4 : rl ? 3 : lane ? 2 : coop ? 1 : 0;
     h->timing.kernel_size = rl ? h->rl_npj : lane ? h->lane_np : h->NT;
     h->timing.kernel_band = (rl || lane) ? 0 : coop ? h->BWc : h->BW;
     h->timing.reserved = 0;

@@ -18,10 +18,10 @@ def _imr_params(jq, case):
     return params, pcof
 
 
-@pytest.mark.parametrize("case", ["rabi", "swap02", "flux", "cnot2", "cnot2-leakieq", "cnot2-jacobi"])
+@pytest.mark.parametrize("case", ["rabi", "swap02", "flux", "cnot2", "cnot2-leakieq", "cnot2-jacobi", "cnot3"])
 def test_reference_imr_golden_through_the_callbacks(jq, case):
-    """The implicit-midpoint goldens of the reference (second loop of test/runtests.jl) whose Hilbert space fits the
-    row-lane kernels (Ntot <= 16); cnot3-imr (Ntot = 96) is pinned for the CPU oracle only."""
+    """All seven implicit-midpoint goldens of the reference (second loop of test/runtests.jl:60-80): Ntot <= 16 on the
+    row-lane kernels (family 4), cnot3 (Ntot = 96) on the cooperative MFMA kernels (family 5)."""
     params, pcof = _imr_params(jq, case)
     golden = load_golden(case + "-imr")
     wa = jq.Working_Arrays_M_HIP(params, pcof.size)
@@ -41,7 +41,7 @@ def test_reference_imr_golden_through_the_callbacks(jq, case):
         jq.eval_grad_f_par(pcof, grad, params, wa)
     assert reference_pass(obj, golden["obj0"]), (obj, golden["obj0"])
     assert reference_pass(grad, golden["grad0"])
-    assert wa.last_timing()["kernel_family"] == 4
+    assert wa.last_timing()["kernel_family"] == (5 if params.Ntot > 16 else 4)
     wa.close()
 
 
@@ -84,17 +84,24 @@ def test_imr_matches_oracle_including_history_and_ensemble(jq, case):
     wa.close()
 
 
-def test_imr_is_refused_beyond_the_row_lane_sizes(jq):
-    params, pcof = _imr_params(jq, "cnot3")
-    wa = jq.Working_Arrays_M_HIP(params, pcof.size)
+def test_imr_is_refused_where_it_is_not_implemented(jq):
+    """Ntot <= 16 with more than 4 columns per evaluation has neither a row-lane nor a cooperative kernel."""
+    from test_gpu_random import random_problem
+    p, pcof = random_problem(jq, np.random.default_rng(1), 16, 16, 1, 1, 5, 1, 1, False)
+    p.Integrator_id = jq.Implicit_Midpoint
+    p.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER_M, max_iter=50, tol=1e-11, nrhs=16)
+    p.wmat = p.wmat_real.copy()
+    wa = jq.Working_Arrays_M_HIP(p, pcof.size)
     with pytest.raises(RuntimeError) as e:
-        jq.traceobjgrad(pcof, params, wa)
-    assert "Ntot <= 16" in str(e.value)
+        jq.traceobjgrad(pcof, p, wa)
+    assert "implicit" in str(e.value).lower()
     wa.close()
 
 
-@pytest.mark.parametrize("cfg", [(2, 1, 1, 1, 9, 1), (5, 3, 2, 2, 14, 3), (9, 2, 3, 1, 11, 2), (12, 4, 2, 2, 8, 1), (16, 4, 4, 1, 6, 3)],
-                         ids=lambda c: "Ntot%d_N%d_Nc%d_f%d_o%d" % (c[0], c[1], c[2], c[3], c[5]))
+@pytest.mark.parametrize("cfg", [(2, 1, 1, 1, 9, 1), (5, 3, 2, 2, 14, 3), (9, 2, 3, 1, 11, 2), (12, 4, 2, 2, 8, 1), (16, 4, 4, 1, 6, 3),
+                                 (17, 5, 2, 1, 7, 3), (33, 3, 1, 2, 6, 1), (48, 4, 3, 1, 5, 2), (80, 16, 2, 1, 4, 1), (95, 2, 2, 1, 4, "band"),
+                                 (48, 4, 2, 1, 5, "od"), (96, 4, 3, 1, 4, "od")],
+                         ids=lambda c: "Ntot%d_N%d_Nc%d_f%d_o%s" % (c[0], c[1], c[2], c[3], c[5]))
 def test_imr_random_problems_match_oracle(jq, cfg):
     """Sizes and paddings the reference cases do not reach: every row-lane instantiation (NPJ 2..16), N = 1..4 columns
     (one, two or four evaluations per wave; an idle row for N = 3), 1..4 controls, objFuncType 1/2/3, several chunks,
@@ -103,7 +110,12 @@ def test_imr_random_problems_match_oracle(jq, cfg):
     from test_gpu_random import random_problem
     Ntot, N, Nc, Nfreq, nsteps, oft = cfg
     rng = np.random.default_rng(77 + Ntot)
-    p, pcof = random_problem(jq, rng, Ntot, N, Nc, Nfreq, nsteps, 3, oft, False)
+    structure = False
+    if oft == "od":          # Kronecker structure -> the JQ_BW_OD variant of the cooperative kernels
+        structure, oft = "od", 1
+    if oft == "band":        # ladder-operator couplings: block band 1 (dense 96 x 96 images do not fit two LDS slots)
+        structure, oft = True, 3
+    p, pcof = random_problem(jq, rng, Ntot, N, Nc, Nfreq, nsteps, 3, oft, structure)
     p.Integrator_id = jq.Implicit_Midpoint
     p.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER_M, max_iter=60, tol=1e-11, nrhs=N)
     p.wmat = p.wmat_real.copy()
