@@ -1,0 +1,88 @@
+"""Randomised GPU-vs-oracle stress (development aid, not part of the test-suite): draws problem sizes, structures,
+kernel-family overrides, chunkings and ensemble sizes and compares objective / gradient with the CPU oracle.
+usage: fuzz_gpu.py [n_cases] [seed]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import juqbox_jl_amd as jq
+from oracle.oracle import Oracle
+from test_gpu_random import random_problem
+
+
+
+def run(n_cases=50, seed=1, verbose=True):
+    """Returns (worst relative error, number of evaluated cases)."""
+    nonlocal_print = print if verbose else (lambda *a, **k: None)
+    rng = np.random.default_rng(seed)
+    worst = 0.0
+    t0 = time.time()
+    for case in range(n_cases):
+        Ntot = int(rng.choice([2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 14, 16, 17, 20, 31, 32, 33, 40, 48, 50, 63, 64, 65, 80, 81, 95, 96]))
+        N = int(rng.integers(1, min(Ntot, 16) + 1))
+        Nc = int(rng.integers(1, 5))
+        Nfreq = int(rng.integers(1, 4))
+        nsteps = int(rng.integers(3, 24))
+        m = int(rng.integers(0, 8))
+        oft = int(rng.integers(1, 4))
+        structure = rng.choice([False, True, "od"]) if Ntot > 16 else rng.choice([False, True])
+        structure = structure if isinstance(structure, str) else bool(structure)
+        imr = bool(rng.random() < 0.3) and ((Ntot <= 16 and N <= 4) or (Ntot > 16 and structure is not False))
+        env = {}
+        if rng.random() < 0.5:
+            env["JQ_CHUNK_STEPS"] = str(int(rng.integers(1, nsteps + 1)))
+        mode = rng.choice(["auto", "JQ_COOP_MAX=0", "JQ_LANE=0", "JQ_ROWLANE_MAX=0", "JQ_OD=0"])
+        if imr and mode == "JQ_COOP_MAX=0":
+            mode = "auto"           # (the cooperative kernels are the only implicit-midpoint path for Ntot > 16)
+        if mode != "auto":
+            k, v = mode.split("=")
+            env[k] = v
+        p, pcof = random_problem(jq, rng, Ntot, N, Nc, Nfreq, nsteps, m, oft, structure)
+        if imr:
+            p.Integrator_id = jq.Implicit_Midpoint
+            p.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER_M, max_iter=80, tol=1e-11, nrhs=N)
+            p.wmat = p.wmat_real.copy()
+        os.environ.update(env)
+        try:
+            wa = (jq.Working_Arrays_M_HIP if imr else jq.Working_Arrays_HIP)(p, pcof.size)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        nq = int(rng.choice([1, 2, 5, 17, 70]))
+        nodes, weights = 0.05 * rng.standard_normal(nq), rng.random(nq)
+        shift = 0.05 * rng.standard_normal(Ntot); shift[0] = 0.0
+        orc = Oracle(p, use_sparse=False)
+        inf = leak = 0.0
+        gi, gl = np.zeros(pcof.size), np.zeros(pcof.size)
+        H0 = p.Hconst.copy()
+        for ep, wq in zip(nodes, weights):
+            p.Hconst = H0 + np.diag(ep * shift)
+            o2 = Oracle(p, use_sparse=False)
+            r = o2.traceobjgrad_imr(pcof, 80, 1e-11) if imr else o2.traceobjgrad(pcof)
+            inf += wq * r["primaryobjf"]; leak += wq * r["secondaryobjf"]; gi += wq * r["infidelgrad"]; gl += wq * r["leakgrad"]
+        p.Hconst = H0
+        try:
+            jq.eval_f_g_grad(pcof, p, wa, nodes, weights, True, shift=shift)
+        except RuntimeError as e:
+            if "error -3" in str(e):     # JQ_EUNSUPPORTED: a combination (usually forced by the env override) without kernels
+                nonlocal_print("%3d Ntot=%2d N=%2d %s %-18s unsupported: %s" % (case, Ntot, N, "IMR" if imr else "SV ", mode, str(e)[-70:]), flush=True)
+                wa.close()
+                continue
+            raise
+        fam = wa.last_timing()["kernel_family"]
+        e1 = abs(p.last_infidelity - inf) / max(abs(inf), 1e-300)
+        e2 = abs(p.last_leak - leak) / max(abs(leak), 1e-3)
+        e3 = np.linalg.norm(p.last_infidelity_grad - gi) / max(np.linalg.norm(gi), 1e-300)
+        e4 = np.linalg.norm(p.last_leak_grad - gl) / max(np.linalg.norm(gi), 1e-300) if oft != 1 else 0.0
+        err = max(e1, e2, e3, e4)
+        worst = max(worst, err)
+        flag = "" if err < 1e-8 else "   <<<<<< MISMATCH"
+        nonlocal_print("%3d Ntot=%2d N=%2d Nc=%d Nf=%d steps=%2d m=%d oft=%d %-5s %s nq=%2d fam=%d %-18s env=%s err=%.1e%s" % (
+            case, Ntot, N, Nc, Nfreq, nsteps, m, oft, structure, "IMR" if imr else "SV ", nq, fam, mode, env.get("JQ_CHUNK_STEPS", "-"), err, flag), flush=True)
+        wa.close()
+    nonlocal_print("worst relative error %.2e over %d cases in %.0f s" % (worst, n_cases, time.time() - t0))
+
+    return worst, n_cases
+
+
+if __name__ == "__main__":
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 50, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
