@@ -39,11 +39,26 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define JQ_BW_OD 9
 #define JQ_OD_COEFS(NT) (32 * (NT))   // doubles after the tiles: [mt][dir: below, above][g = lane>>4][r]
 
+// BW == JQ_BW_T4: the JQ_BW_OD structure one level finer -- also inside every 16x16 diagonal block the off-diagonal
+// 4x4 blocks are DIAGONAL matrices and couple only neighbouring 4-row groups (a Kronecker-ordered Hilbert space whose
+// fastest subsystem has 4 levels and whose operators are sums of single-subsystem terms and diagonal couplings:
+// cnot3 = 4 x 4 x 6).  A register of a state array (4 rows x 16 columns, row = lane>>4, column = lane&15) is exactly
+// the B and the C/D operand of v_mfma_f64_4x4x4_4b_f64 (four 4x4x4 blocks in 16 cycles, profiles/
+// r01_mfma_f64_4x4x4_layout.txt), so the product needs ONE such MFMA per 4-row group for its dense 4x4 diagonal block
+// (24 x 16 = 384 cycles at Ntot = 96 instead of 24 x 64) and at most four v_fma_f64 per group for the couplings to the
+// groups rho-1, rho+1 (same 16-row block) and rho-4, rho+4 (neighbouring blocks), mm_t4.
+#define JQ_BW_T4 8
+#define JQ_T4_COEFS(NT) (64 * (NT))   // doubles after the 4NT A-operand tiles: [mt][g = lane>>4][r][term: r-1, r+1, mt-1, mt+1]
+// trace-image modes of this variant (a.bw_trace[q]): bit 0 diagonal 4x4 blocks present, bit 1 r+-1 terms, bit 2 mt+-1 terms
+#define JQ_T4_DIAG 1
+#define JQ_T4_RTERMS 2
+#define JQ_T4_MTERMS 4
+
 // Stored tiles of an NT x 4NT tile grid: block (mt,kb) is kept when |mt-kb| <= BW and, for SD ("skip
 // diagonal": operators like a3 +- a3' of the slowest subsystem, whose diagonal blocks vanish), mt != kb.
 __host__ __device__ constexpr bool block_on(int BW, bool SD, int mt, int kb)
 {
-    return (BW == JQ_BW_OD) ? (mt == kb && !SD) : ((mt - kb <= BW) && (kb - mt <= BW) && !(SD && mt == kb));
+    return (BW == JQ_BW_OD || BW == JQ_BW_T4) ? (mt == kb && !SD) : ((mt - kb <= BW) && (kb - mt <= BW) && !(SD && mt == kb));
 }
 // number of stored tiles (host + device)
 __host__ __device__ constexpr int band_tiles(int NT, int BW, bool SD = false)
@@ -62,9 +77,35 @@ __host__ __device__ constexpr int first_kb(int NT, int BW, bool SD, int mt)
     return NT;
 }
 
+// Four doubles WITHOUT the register-tuple constraint of d4 (the 16x16x4 MFMA wants its C/D operand in 8 consecutive
+// VGPRs; v_mfma_f64_4x4x4 works on single doubles and the in-place products of JQ_BW_T4 then cost v_mov copies).
+struct s4 {
+    double e[4];
+    __device__ __forceinline__ s4() = default;
+    __device__ __forceinline__ s4(d4 v) : e{v[0], v[1], v[2], v[3]} {}
+    __device__ __forceinline__ double& operator[](int i) { return e[i]; }
+    __device__ __forceinline__ double operator[](int i) const { return e[i]; }
+    __device__ __forceinline__ s4& operator+=(const s4& o)
+    {
+        e[0] += o.e[0], e[1] += o.e[1], e[2] += o.e[2], e[3] += o.e[3];
+        return *this;
+    }
+};
+__device__ __forceinline__ s4 operator+(const s4& a, const s4& b) { return s4((d4){a.e[0] + b.e[0], a.e[1] + b.e[1], a.e[2] + b.e[2], a.e[3] + b.e[3]}); }
+__device__ __forceinline__ s4 operator-(const s4& a, const s4& b) { return s4((d4){a.e[0] - b.e[0], a.e[1] - b.e[1], a.e[2] - b.e[2], a.e[3] - b.e[3]}); }
+__device__ __forceinline__ s4 operator*(const s4& a, const s4& b) { return s4((d4){a.e[0] * b.e[0], a.e[1] * b.e[1], a.e[2] * b.e[2], a.e[3] * b.e[3]}); }
+__device__ __forceinline__ s4 operator*(double c, const s4& b) { return s4((d4){c * b.e[0], c * b.e[1], c * b.e[2], c * b.e[3]}); }
+__device__ __forceinline__ s4 operator-(const s4& a) { return s4((d4){-a.e[0], -a.e[1], -a.e[2], -a.e[3]}); }
+// row type of the state arrays of this translation unit (one (NT, BW) instantiation per unit, jq_kernel_inst.hip)
+#if defined(JQ_BW) && JQ_BW == 8 && !defined(JQ_ROW_D4)
+typedef s4 jq_row;
+#else
+typedef d4 jq_row;
+#endif
+
 template <int NT>
 struct Arr {
-    d4 t[NT];
+    jq_row t[NT];
 };
 
 template <int NT>
@@ -97,7 +138,7 @@ __device__ __forceinline__ double a_dot(const Arr<NT>& x, const Arr<NT>& y)
     double s = 0.0;
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-        d4 p = x.t[i] * y.t[i];
+        const auto p = x.t[i] * y.t[i];
         s += (p[0] + p[1]) + (p[2] + p[3]);
     }
     return s;
@@ -109,7 +150,7 @@ __device__ __forceinline__ void a_axpy_rows(Arr<NT>& y, double c, const double* 
 {
     const d4* t4 = (const d4*)(tab + 4 * g);
 #pragma unroll
-    for (int i = 0; i < NT; ++i) y.t[i] += (c * t4[4 * i]) * x.t[i];
+    for (int i = 0; i < NT; ++i) y.t[i] += jq_row(c * t4[4 * i]) * x.t[i];
 }
 // sum_rows tab[row] * x[row]^2
 template <int NT>
@@ -222,13 +263,140 @@ __device__ __forceinline__ void mm_od(Arr<NT>& D, const Arr<NT>& C, const double
     }
 }
 
+// y += c[lane K of this lane's 16-lane row] * x   (v_fmac_f64_dpp: DPP costs nothing extra, probes/dpp_fmac_probe.hip).
+// GUARD wait states in front (inside the asm statement, where nothing can be scheduled in between):
+//  2: gfx950 does not interlock a VALU write of the DPP operand c with this read, and the register allocator may reload c
+//     (v_accvgpr_read, v_mov) right in front of a group's first FMA;
+//  6: y is the result of a v_mfma_f64_4x4x4 -- a software hazard (6 wait states before a VALU read) that the compiler's
+//     hazard recognizer does not apply to inline asm.
+template <int K, int GUARD>
+__device__ __forceinline__ void fma_rowbcast(double& y, double c, double x)
+{
+    static_assert(GUARD == 0 || GUARD == 2 || GUARD == 6, "");
+    if constexpr (GUARD == 6)
+        asm("s_nop 5\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(y) : "v"(c), "v"(x), "n"(K));
+    else if constexpr (GUARD == 2)
+        asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(y) : "v"(c), "v"(x), "n"(K));
+    else
+        asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(y) : "v"(c), "v"(x), "n"(K));
+}
+
+// coupling terms of 4-row group R of a 16-row block: coefficient lane 4R + term of this lane's row of c.
+// LO / HI: the block has a neighbour block below / above.  G: guard of the group's first FMA.
+template <int R, bool RT, bool MTM, bool LO, bool HI, int G>
+__device__ __forceinline__ void t4_couple(double& acc, double c, double xrm, double xrp, double xmm, double xmp)
+{
+    constexpr bool t0 = RT && R > 0, t1 = RT && R < 3, t2 = MTM && LO, t3 = MTM && HI;
+    if constexpr (t0) fma_rowbcast<4 * R + 0, G>(acc, c, xrm);
+    if constexpr (t1) fma_rowbcast<4 * R + 1, t0 ? 0 : G>(acc, c, xrp);
+    if constexpr (t2) fma_rowbcast<4 * R + 2, (t0 || t1) ? 0 : G>(acc, c, xmm);
+    if constexpr (t3) fma_rowbcast<4 * R + 3, (t0 || t1 || t2) ? 0 : G>(acc, c, xmp);
+}
+template <int R, bool RT, bool MTM, int G>
+__device__ __forceinline__ void t4_couple(double& acc, double c, double xrm, double xrp, double xmm, double xmp, bool lo, bool hi)
+{
+    if (lo && hi) t4_couple<R, RT, MTM, true, true, G>(acc, c, xrm, xrp, xmm, xmp);
+    else if (lo) t4_couple<R, RT, MTM, true, false, G>(acc, c, xrm, xrp, xmm, xmp);
+    else if (hi) t4_couple<R, RT, MTM, false, true, G>(acc, c, xrm, xrp, xmm, xmp);
+    else t4_couple<R, RT, MTM, false, false, G>(acc, c, xrm, xrp, xmm, xmp);
+}
+
+// BW == JQ_BW_T4 (see the definition above).  Alias-safe (D may be C and/or x): the old values of the last four
+// 4-row groups are kept in a rolling window.  MODE: which parts of the image are non-zero (JQ_T4_* bits).
+// The 16 coupling coefficients of a 16-row block and a lane row g = lane>>4 (4 groups x 4 terms) sit in the 16 lanes of
+// that row of ONE register (one ds_read_b64 per block; the first version read a d4 per group and lane and was bound by
+// the LDS port, 20 of 38 cycles per group and wave); the FMAs pick theirs with a DPP row broadcast (2-wait-state
+// hazard on the DPP operand: first FMA of every group guarded, scripts/check_dpp_hazard.py checks the final ISA).
+template <int NT, bool ZEROC, int MODE>
+__device__ __forceinline__ void mm_t4(Arr<NT>& D, const Arr<NT>& C, const double* mat, const Arr<NT>& x)
+{
+    constexpr int NR = 4 * NT;
+    constexpr bool diag = MODE & JQ_T4_DIAG, rt = MODE & JQ_T4_RTERMS, mtm = MODE & JQ_T4_MTERMS;
+    const double* cf = mat + NR * 64;
+    double f[JQ_PF];
+    double cq[2];
+    if constexpr (diag) {
+#pragma unroll
+        for (int i = 0; i < JQ_PF; ++i)
+            if (i < NR) f[i] = mat[i * 64];
+    }
+    if constexpr (rt || mtm) {
+        cq[0] = cf[0];
+        if (NT > 1) cq[1] = cf[64];
+    }
+    // MFMA first (three-operand: the C element is read in place, no copy), then the tied DPP FMAs on its result.  The
+    // MFMAs run two groups ahead: an MFMA result needs 6 wait states before a VALU read, a software hazard the compiler
+    // does not apply to inline asm -- here the FMAs of the group before, two MFMAs and the guard of the first FMA are
+    // in between (group 0: longer guard).  scripts/check_dpp_hazard.py verifies the final ISA.
+    double xo[4] = {0.0, 0.0, 0.0, 0.0};
+    double pend[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        if (i < NR) {
+            pend[i] = ZEROC ? 0.0 : C.t[i >> 2][i & 3];
+            if constexpr (diag) {
+                pend[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(f[i % JQ_PF], x.t[i >> 2][i & 3], pend[i], 0, 0, 0);
+                if (i + JQ_PF < NR) f[i % JQ_PF] = mat[(i + JQ_PF) * 64];
+            }
+        }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) {
+        double c = 0.0;
+        if constexpr (rt || mtm) {
+            c = cq[mt & 1];
+            if (mt + 2 < NT) cq[mt & 1] = cf[(mt + 2) * 64];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rho = 4 * mt + r, nx = rho + 2;
+            double cur = pend[rho & 1];
+            if (nx < NR) {
+                double nxt = ZEROC ? 0.0 : C.t[nx >> 2][nx & 3];
+                if constexpr (diag) {
+                    nxt = __builtin_amdgcn_mfma_f64_4x4x4f64(f[nx % JQ_PF], x.t[nx >> 2][nx & 3], nxt, 0, 0, 0);
+                    if (nx + JQ_PF < NR) f[nx % JQ_PF] = mat[(nx + JQ_PF) * 64];
+                }
+                pend[rho & 1] = nxt;
+            }
+            const double xc = x.t[mt][r];
+            if constexpr (rt || mtm) {
+                const double xrm = xo[(rho + 3) & 3], xmm = xo[rho & 3];           // old x of the groups rho-1, rho-4
+                const double xrp = (r < 3) ? x.t[mt][(r + 1) & 3] : 0.0;
+                const double xmp = (mt + 1 < NT) ? x.t[(mt + 1 < NT) ? mt + 1 : mt][r] : 0.0;
+                constexpr int G = diag ? 6 : 2;
+                if (rho == 0)
+                    t4_couple<0, rt, mtm, G>(cur, c, xrm, xrp, xmm, xmp, false, mt + 1 < NT);
+                else
+                    switch (r) {
+                    case 0: t4_couple<0, rt, mtm, 2>(cur, c, xrm, xrp, xmm, xmp, mt > 0, mt + 1 < NT); break;
+                    case 1: t4_couple<1, rt, mtm, 2>(cur, c, xrm, xrp, xmm, xmp, mt > 0, mt + 1 < NT); break;
+                    case 2: t4_couple<2, rt, mtm, 2>(cur, c, xrm, xrp, xmm, xmp, mt > 0, mt + 1 < NT); break;
+                    default: t4_couple<3, rt, mtm, 2>(cur, c, xrm, xrp, xmm, xmp, mt > 0, mt + 1 < NT); break;
+                    }
+            }
+            D.t[mt][r] = cur;
+            xo[rho & 3] = xc;
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch FIFOs in order (hipcc otherwise hoists every load -> spills)
+        }
+    }
+}
+
+template <int NT, int BW, bool ZEROC, bool SD = false>
+__device__ __forceinline__ void mm_band(Arr<NT>& D, const Arr<NT>& C, const double* mat, const Arr<NT>& x);
 template <int NT, int BW, bool ZEROC, bool SD = false>
 __device__ __forceinline__ void mm_any(Arr<NT>& D, const Arr<NT>& C, const double* mat, const Arr<NT>& x)
 {
-    if constexpr (BW == JQ_BW_OD) {
+    if constexpr (BW == JQ_BW_T4)
+        mm_t4<NT, ZEROC, JQ_T4_DIAG | JQ_T4_RTERMS | JQ_T4_MTERMS>(D, C, mat, x);
+    else if constexpr (BW == JQ_BW_OD)
         mm_od<NT, ZEROC, SD>(D, C, mat, x);
-        return;
-    }
+    else
+        mm_band<NT, BW, ZEROC, SD>(D, C, mat, x);
+}
+template <int NT, int BW, bool ZEROC, bool SD>
+__device__ __forceinline__ void mm_band(Arr<NT>& D, const Arr<NT>& C, const double* mat, const Arr<NT>& x)
+{
     constexpr int NTILES = band_tiles(NT, BW, SD);
     double f[JQ_PF];
 #pragma unroll
@@ -273,12 +441,23 @@ __device__ __forceinline__ void mm_z(Arr<NT>& D, const double* mat, const Arr<NT
 template <int NT, int BW>
 __device__ __forceinline__ void mm_z_bw(Arr<NT>& D, const double* mat, const Arr<NT>& x, int mode)
 {
-    if (BW > 0 && mode == 0)
-        mm_any<NT, 0, true>(D, D, mat, x);
-    else if (BW > 0 && NT > 1 && mode == 2)
-        mm_any<NT, BW, true, true>(D, D, mat, x);
-    else
-        mm_any<NT, BW, true>(D, D, mat, x);
+    if constexpr (BW == JQ_BW_T4) {
+        // single-subsystem control operators touch exactly one part of the image; anything else takes the full product
+        // (always correct: the absent parts are stored as zeros)
+        switch (mode) {
+        case JQ_T4_DIAG: mm_t4<NT, true, JQ_T4_DIAG>(D, D, mat, x); break;
+        case JQ_T4_RTERMS: mm_t4<NT, true, JQ_T4_RTERMS>(D, D, mat, x); break;
+        case JQ_T4_MTERMS: mm_t4<NT, true, JQ_T4_MTERMS>(D, D, mat, x); break;
+        default: mm_t4<NT, true, JQ_T4_DIAG | JQ_T4_RTERMS | JQ_T4_MTERMS>(D, D, mat, x); break;
+        }
+    } else {
+        if (BW > 0 && mode == 0)
+            mm_any<NT, 0, true>(D, D, mat, x);
+        else if (BW > 0 && NT > 1 && mode == 2)
+            mm_any<NT, BW, true, true>(D, D, mat, x);
+        else
+            mm_any<NT, BW, true>(D, D, mat, x);
+    }
 }
 
 // x + (x rotated right by N lanes within each row of 16 lanes), via DPP (no LDS crossbar traffic)
@@ -585,8 +764,8 @@ __device__ __forceinline__ double a_diff2(const Arr<NT>& x, const Arr<NT>& y)
     double s = 0.0;
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-        const d4 d = x.t[i] - y.t[i];
-        const d4 p = d * d;
+        const auto d = x.t[i] - y.t[i];
+        const auto p = d * d;
         s += (p[0] + p[1]) + (p[2] + p[3]);
     }
     return s;
@@ -642,8 +821,8 @@ __device__ __forceinline__ void horner_add(Arr<NT>& out, const Arr<NT>& bpa, con
     }
     mm_c<NT, BW>(Ya, A, S, A);  // Y1 = A + S A
     --rem;
-    if constexpr (BW == JQ_BW_OD) {
-        // mm_od is alias-safe: the recurrence runs in place and Yb is never touched (48 registers less)
+    if constexpr (BW == JQ_BW_OD || BW == JQ_BW_T4) {
+        // mm_od / mm_t4 are alias-safe: the recurrence runs in place and Yb is never touched (48 registers less)
         for (; rem > 0; --rem) mm_c<NT, BW>(Ya, A, S, Ya);
         mm_c<NT, BW>(out, bpa, S, Ya);
         return;

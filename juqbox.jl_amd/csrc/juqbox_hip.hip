@@ -108,6 +108,32 @@ static void tile_image(const double* M, int Ntot, int NT, int BW, double* img, b
             }
             ++idx;
         }
+    if (BW == JQ_BW_T4) {
+        // A operands of v_mfma_f64_4x4x4_4b: tile rho, lane l holds M[4 rho + (l & 3)][4 rho + (l >> 4)] (the 4x4 diagonal
+        // block, the same in all four 16-column... 4-column blocks of the instruction); then the coupling coefficients
+        // [mt][g][r][term: group rho-1, rho+1 (same 16-row block), rho-4, rho+4] <-> row 4 rho + g, rho = 4 mt + r
+        const int NR = 4 * NT;
+        idx = 0;
+        if (!SD)
+            for (int rho = 0; rho < NR; ++rho, ++idx)
+                for (int l = 0; l < 64; ++l) {
+                    const int row = 4 * rho + (l & 3), col = 4 * rho + (l >> 4);
+                    img[idx * 64 + l] = (row < Ntot && col < Ntot) ? M[row + (size_t)Ntot * col] : 0.0;
+                }
+        double* cf = img + (size_t)NR * 64;          // fixed position (the device code does not know SD here)
+        if (SD)
+            for (size_t i = 0; i < (size_t)NR * 64; ++i) img[i] = 0.0;
+        for (int rho = 0; rho < NR; ++rho)
+            for (int g = 0; g < 4; ++g) {
+                const int row = 4 * rho + g, r = rho & 3;
+                const int nbr[4] = {r > 0 ? row - 4 : -1, r < 3 ? row + 4 : -1, row - 16, row + 16};
+                for (int t = 0; t < 4; ++t) {
+                    const int col = nbr[t];
+                    cf[(rho >> 2) * 64 + g * 16 + r * 4 + t] = (col >= 0 && col < Ntot && row < Ntot) ? M[row + (size_t)Ntot * col] : 0.0;
+                }
+            }
+        return;
+    }
     if (BW == JQ_BW_OD) {
         // diagonals of the first off-diagonal blocks: [mt][dir: block mt-1, block mt+1][g][r] <-> row 16mt + 4r + g
         double* cf = img + idx * 64;
@@ -122,6 +148,32 @@ static void tile_image(const double* M, int Ntot, int NT, int BW, double* img, b
                     }
             }
     }
+}
+
+// JQ_BW_T4 structure: entries outside the 4x4 diagonal blocks only at (i, i +- 4) inside one 16-row block or at (i, i +- 16)
+static bool t4_structure(const double* M, int Ntot)
+{
+    for (int col = 0; col < Ntot; ++col)
+        for (int row = 0; row < Ntot; ++row) {
+            if (M[row + (size_t)Ntot * col] == 0.0 || row / 4 == col / 4) continue;
+            const int d = row - col;
+            const bool same16 = (row / 16 == col / 16);
+            if (!((same16 && (d == 4 || d == -4)) || d == 16 || d == -16)) return false;
+        }
+    return true;
+}
+// parts of the T4 image of M that are non-zero: JQ_T4_DIAG | JQ_T4_RTERMS | JQ_T4_MTERMS
+static int t4_mode(const double* M, int Ntot)
+{
+    int mode = 0;
+    for (int col = 0; col < Ntot; ++col)
+        for (int row = 0; row < Ntot; ++row) {
+            if (M[row + (size_t)Ntot * col] == 0.0) continue;
+            if (row / 4 == col / 4) mode |= JQ_T4_DIAG;
+            else if (row - col == 4 || col - row == 4) mode |= JQ_T4_RTERMS;
+            else mode |= JQ_T4_MTERMS;
+        }
+    return mode;
 }
 
 // true if M is block tridiagonal (16x16 blocks) and every off-diagonal block is a diagonal matrix
@@ -252,8 +304,8 @@ static int upload_operators(jq_handle* h)
     // images of the trace products: [Hsym_q | Hanti_q], each pair in its own band (0 or BW)
     std::vector<double> cimg((size_t)(2 * h->Nc) * h->mat_elems, 0.0);
     for (int q = 0; q < h->Nc; ++q) {
-        const int bwq = (h->bw_trace[q] == 0) ? 0 : h->BW;
-        const bool sd = (h->bw_trace[q] == 2);
+        const int bwq = (h->BW == JQ_BW_T4) ? JQ_BW_T4 : (h->bw_trace[q] == 0) ? 0 : h->BW;
+        const bool sd = (h->BW == JQ_BW_T4) ? false : (h->bw_trace[q] == 2);
         tile_image(h->Hsym.data() + q * nn, h->Ntot, h->NT, bwq, cimg.data() + (size_t)q * h->mat_elems, sd);
         tile_image(h->Hanti.data() + q * nn, h->Ntot, h->NT, bwq, cimg.data() + (size_t)(h->Nc + q) * h->mat_elems, sd);
     }
@@ -411,15 +463,30 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         if (const char* e = getenv("JQ_FORCE_DENSE"))
             if (atoi(e) != 0) od = false;
         if (od) h->BW = h->BWc = JQ_BW_OD;
+        // ... and, one level finer, 4x4 diagonal blocks + diagonal couplings of neighbouring 4-row groups: the slab kernels
+        // use v_mfma_f64_4x4x4 (JQ_BW_T4; JQ_T4=0 disables); the cooperative kernels stay on the JQ_BW_OD variant
+        bool t4 = (bw <= 1) && t4_structure(h->Hconst.data(), h->Ntot);
+        for (int q = 0; q < h->Nc && t4; ++q)
+            t4 = t4_structure(h->Hsym.data() + q * nn, h->Ntot) && t4_structure(h->Hanti.data() + q * nn, h->Ntot);
+        if (const char* e = getenv("JQ_T4"))
+            if (atoi(e) == 0) t4 = false;
+        if (const char* e = getenv("JQ_OD"))
+            if (atoi(e) == 0) t4 = false;
+        if (const char* e = getenv("JQ_FORCE_DENSE"))
+            if (atoi(e) != 0) t4 = false;
+        if (t4) h->BW = JQ_BW_T4;
         // trace image layout per control: 0 block diagonal, 1 band BW, 2 band BW without the diagonal blocks
-        for (int q = 0; q < h->Nc; ++q) {
+        for (int q = 0; q < h->Nc && h->BW == JQ_BW_T4; ++q)
+            h->bw_trace[q] = t4_mode(h->Hsym.data() + q * nn, h->Ntot) | t4_mode(h->Hanti.data() + q * nn, h->Ntot);
+        for (int q = 0; q < h->Nc && h->BW != JQ_BW_T4; ++q) {
             if (h->bw_trace[q] == 0 || h->BW == 0)
                 h->bw_trace[q] = (h->BW == 0) ? 1 : 0;
             else
                 h->bw_trace[q] = (h->NT > 1 && diag_blocks_zero(h->Hsym.data() + q * nn, h->Ntot) &&
                                   diag_blocks_zero(h->Hanti.data() + q * nn, h->Ntot)) ? 2 : 1;
         }
-        h->mat_elems = ((64LL * band_tiles(h->NT, h->BW) + (h->BW == JQ_BW_OD ? JQ_OD_COEFS(h->NT) : 0) + 127) / 128) * 128;
+        h->mat_elems = ((64LL * band_tiles(h->NT, h->BW) + (h->BW == JQ_BW_OD ? JQ_OD_COEFS(h->NT) : 0) +
+                         (h->BW == JQ_BW_T4 ? JQ_T4_COEFS(h->NT) : 0) + 127) / 128) * 128;
         const long long slot = h->mat_elems * 8;
         const long long lds_fwd_fixed = (long long)32 * h->NT * 8;
         const long long lds_bwd_fixed = lds_fwd_fixed + (long long)JQ_MAXNC * 256 * 8;
@@ -647,7 +714,8 @@ extern "C" int jq_update_hconst(jq_handle* h, const double* Hconst)
     if (!h) return JQ_EINVAL;
     if (!Hconst) return fail(h, JQ_EINVAL, "jq_update_hconst: NULL pointer");
     HIPCHK(h, hipSetDevice(h->device));
-    if ((h->BW == JQ_BW_OD) ? !offdiag_blocks_diagonal(Hconst, h->Ntot) : block_band(Hconst, h->Ntot) > h->BW)
+    if ((h->BW == JQ_BW_T4) ? !t4_structure(Hconst, h->Ntot)
+        : (h->BW == JQ_BW_OD) ? !offdiag_blocks_diagonal(Hconst, h->Ntot) : block_band(Hconst, h->Ntot) > h->BW)
         return fail(h, JQ_EUNSUPPORTED, "jq_update_hconst: new Hconst has entries outside the block band the kernels were "
                                         "selected for; create a new handle");
     h->Hconst.assign(Hconst, Hconst + (size_t)h->Ntot * h->Ntot);
@@ -668,7 +736,8 @@ typedef void (*prop_kernel_t)(PropArgs);
 // The (NT, BW) instantiations are compiled in their own translation units (jq_kernel_inst.hip).
 #define JQ_FOR_EACH_INST(X)                                                                       \
     X(1, 0) X(2, 0) X(2, 1) X(3, 0) X(3, 1) X(3, 2) X(4, 0) X(4, 1) X(4, 2) X(4, 3) X(5, 0) X(5, 1) \
-    X(5, 2) X(5, 4) X(6, 0) X(6, 1) X(6, 2) X(6, 5) X(2, 9) X(3, 9) X(4, 9) X(5, 9) X(6, 9)
+    X(5, 2) X(5, 4) X(6, 0) X(6, 1) X(6, 2) X(6, 5) X(2, 9) X(3, 9) X(4, 9) X(5, 9) X(6, 9) X(1, 8) X(2, 8) X(3, 8)       \
+    X(4, 8) X(5, 8) X(6, 8)
 #define JQ_MINW_OF(nt) (((nt) <= 2) ? 2 : 1)
 #define JQ_DECL(nt, bw)                                                                      \
     extern template __global__ void k_forward<nt, bw, JQ_MINW_OF(nt), false>(PropArgs);      \
@@ -991,7 +1060,9 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     const long long tiles = (lane || rl) ? 0 : coop ? coop_tiles(h->NT, h->BWc) : band_tiles(h->NT, h->BW);
     long long trace_tiles = 0;
     for (int q = 0; q < h->Nc && !lane && !rl; ++q)
-        trace_tiles += coop ? coop_tiles(h->NT, h->BWc) : band_tiles(h->NT, h->bw_trace[q] == 0 ? 0 : h->BW, h->bw_trace[q] == 2);
+        trace_tiles += coop ? coop_tiles(h->NT, h->BWc)
+                            : (h->BW == JQ_BW_T4) ? ((h->bw_trace[q] & JQ_T4_DIAG) ? 4 * h->NT : 0)
+                                                  : band_tiles(h->NT, h->bw_trace[q] == 0 ? 0 : h->BW, h->bw_trace[q] == 2);
     // ---- forward sweep -------------------------------------------------------------------------
     for (int n0 = 0; n0 < h->nsteps; n0 += cs) {
         const int nc = std::min(cs, h->nsteps - n0);
@@ -1116,7 +1187,8 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     h->timing.ms_generate = h->timing.ms_total - (fwd + bwd);
     h->timing.n_forward_launches = (long long)nfwd;
     h->timing.n_backward_launches = (long long)((evi - 2) / 2 - nfwd);
-    h->timing.mfma_executed = imr ? 0 : mfma;   // (the iteration counts of the implicit-midpoint solver are data dependent)
+    // (JQ_BW_T4: one v_mfma_f64_4x4x4_4b is 512 FLOP, a quarter of the 16x16x4 instruction this counter is quoted in)
+    h->timing.mfma_executed = imr ? 0 : (!coop && !lane && !rl && h->BW == JQ_BW_T4) ? mfma / 4 : mfma;   // (the iteration counts of the implicit-midpoint solver are data dependent)
     h->timing.svts = (long long)nsamples * h->N * h->nsteps;
     h->timing.kernel_family = imr_coop ? 5 : imr ? 4 : rl ? 3 : lane ? 2 : coop ? 1 : 0;
     h->timing.kernel_size = rl ? h->rl_npj : lane ? h->lane_np : h->NT;

@@ -38,6 +38,7 @@ def check(path):
     bad = 0
     ndpp = 0
     window = []          # (wait_states, written_regs | None for label)
+    mwindow = []         # the same with a third field: wait states an MFMA result needs before a VALU read
     func = "?"
     for ln, raw in enumerate(open(path), 1):
         line = raw.split(";")[0].strip()
@@ -47,8 +48,10 @@ def check(path):
             if not line.startswith(".L"):
                 func = line[:-1]
                 window = []
+                mwindow = []
             else:
                 window.append((0, None))
+                mwindow.append((0, None, 0))
             continue
         parts = line.split(None, 1)
         op = parts[0]
@@ -71,6 +74,32 @@ def check(path):
                         bad += 1
                         break
                     ws += w
+                # second hazard the compiler cannot see through inline asm: a double-precision MFMA result read (or, for
+                # the tied accumulator, overwritten) by this VALU instruction needs 6 (4x4x4) / 11 (16x16x4) wait states
+                # (LLVM GCNHazardRecognizer: DMFMA4x4/16x16WriteVgprVALUReadWaitStates) -- used by mm_t4 (jq_kernels.h)
+                used = set()
+                for a in args:
+                    used |= regs(a.split()[0])
+                ws = 0
+                for w, written, mfma_need in reversed(mwindow):
+                    if written is None:
+                        break                     # label: the MFMA products never end a basic block right behind an MFMA
+                    if mfma_need and (written & used) and ws < mfma_need:
+                        print("%s:%d: %s: MFMA result read by inline-asm VALU %d wait state(s) later (needs %d): %s" % (path, ln, func, ws, mfma_need, line))
+                        bad += 1
+                        break
+                    ws += w
+                    if ws >= 11:
+                        break
+        mneed = 6 if op.startswith("v_mfma_f64_4x4x4") else 11 if op.startswith("v_mfma_f64_16x16x4") else 0
+        if line.endswith(":"):
+            pass
+        elif op == "s_nop":
+            mwindow.append((int(args[0], 0) + 1, set(), 0))
+        else:
+            mwindow.append((1, valu_writes(op, args), mneed))
+        if len(mwindow) > 16:
+            mwindow = mwindow[-16:]
         if op == "s_nop":
             window.append((int(args[0], 0) + 1, set()))
         else:
