@@ -263,22 +263,37 @@ __device__ __forceinline__ void mm_od(Arr<NT>& D, const Arr<NT>& C, const double
     }
 }
 
-// y += c[lane K of this lane's 16-lane row] * x   (v_fmac_f64_dpp: DPP costs nothing extra, probes/dpp_fmac_probe.hip).
-// GUARD wait states in front (inside the asm statement, where nothing can be scheduled in between):
+// y += sum_k c[lane K_k of this lane's 16-lane row] * x_k  (v_fmac_f64_dpp: DPP costs nothing extra, probes/dpp_fmac_probe.hip)
+// as ONE asm statement (between separate statements hipcc puts an s_nop each) with GUARD wait states in front, where
+// nothing can be scheduled in between:
 //  2: gfx950 does not interlock a VALU write of the DPP operand c with this read, and the register allocator may reload c
 //     (v_accvgpr_read, v_mov) right in front of a group's first FMA;
 //  6: y is the result of a v_mfma_f64_4x4x4 -- a software hazard (6 wait states before a VALU read) that the compiler's
 //     hazard recognizer does not apply to inline asm.
-template <int K, int GUARD>
-__device__ __forceinline__ void fma_rowbcast(double& y, double c, double x)
+#define JQ_DPPF(y, c, x, k) "v_fmac_f64_dpp " y ", " c ", " x " row_newbcast:" k " row_mask:0xf bank_mask:0xf\n\t"
+template <int GUARD, int K0>
+__device__ __forceinline__ void fma_rowbcast(double& y, double c, double x0)
 {
-    static_assert(GUARD == 0 || GUARD == 2 || GUARD == 6, "");
-    if constexpr (GUARD == 6)
-        asm("s_nop 5\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(y) : "v"(c), "v"(x), "n"(K));
-    else if constexpr (GUARD == 2)
-        asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(y) : "v"(c), "v"(x), "n"(K));
-    else
-        asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(y) : "v"(c), "v"(x), "n"(K));
+    asm("s_nop %3\n\t" JQ_DPPF("%0", "%1", "%2", "%4") : "+v"(y) : "v"(c), "v"(x0), "n"(GUARD - 1), "n"(K0));
+}
+template <int GUARD, int K0, int K1>
+__device__ __forceinline__ void fma_rowbcast(double& y, double c, double x0, double x1)
+{
+    asm("s_nop %4\n\t" JQ_DPPF("%0", "%1", "%2", "%5") JQ_DPPF("%0", "%1", "%3", "%6")
+        : "+v"(y) : "v"(c), "v"(x0), "v"(x1), "n"(GUARD - 1), "n"(K0), "n"(K1));
+}
+template <int GUARD, int K0, int K1, int K2>
+__device__ __forceinline__ void fma_rowbcast(double& y, double c, double x0, double x1, double x2)
+{
+    asm("s_nop %5\n\t" JQ_DPPF("%0", "%1", "%2", "%6") JQ_DPPF("%0", "%1", "%3", "%7") JQ_DPPF("%0", "%1", "%4", "%8")
+        : "+v"(y) : "v"(c), "v"(x0), "v"(x1), "v"(x2), "n"(GUARD - 1), "n"(K0), "n"(K1), "n"(K2));
+}
+template <int GUARD, int K0, int K1, int K2, int K3>
+__device__ __forceinline__ void fma_rowbcast(double& y, double c, double x0, double x1, double x2, double x3)
+{
+    asm("s_nop %6\n\t" JQ_DPPF("%0", "%1", "%2", "%7") JQ_DPPF("%0", "%1", "%3", "%8") JQ_DPPF("%0", "%1", "%4", "%9")
+        JQ_DPPF("%0", "%1", "%5", "%10")
+        : "+v"(y) : "v"(c), "v"(x0), "v"(x1), "v"(x2), "v"(x3), "n"(GUARD - 1), "n"(K0), "n"(K1), "n"(K2), "n"(K3));
 }
 
 // coupling terms of 4-row group R of a 16-row block: coefficient lane 4R + term of this lane's row of c.
@@ -286,11 +301,24 @@ __device__ __forceinline__ void fma_rowbcast(double& y, double c, double x)
 template <int R, bool RT, bool MTM, bool LO, bool HI, int G>
 __device__ __forceinline__ void t4_couple(double& acc, double c, double xrm, double xrp, double xmm, double xmp)
 {
-    constexpr bool t0 = RT && R > 0, t1 = RT && R < 3, t2 = MTM && LO, t3 = MTM && HI;
-    if constexpr (t0) fma_rowbcast<4 * R + 0, G>(acc, c, xrm);
-    if constexpr (t1) fma_rowbcast<4 * R + 1, t0 ? 0 : G>(acc, c, xrp);
-    if constexpr (t2) fma_rowbcast<4 * R + 2, (t0 || t1) ? 0 : G>(acc, c, xmm);
-    if constexpr (t3) fma_rowbcast<4 * R + 3, (t0 || t1 || t2) ? 0 : G>(acc, c, xmp);
+    constexpr bool on[4] = {RT && R > 0, RT && R < 3, MTM && LO, MTM && HI};
+    constexpr int n = on[0] + on[1] + on[2] + on[3];
+    // k-th active term
+    constexpr auto act = [](int k) constexpr {
+        const bool o[4] = {RT && R > 0, RT && R < 3, MTM && LO, MTM && HI};
+        for (int t = 0; t < 4; ++t)
+            if (o[t] && k-- == 0) return t;
+        return 0;
+    };
+    const double xv[4] = {xrm, xrp, xmm, xmp};
+    if constexpr (n == 1)
+        fma_rowbcast<G, 4 * R + act(0)>(acc, c, xv[act(0)]);
+    else if constexpr (n == 2)
+        fma_rowbcast<G, 4 * R + act(0), 4 * R + act(1)>(acc, c, xv[act(0)], xv[act(1)]);
+    else if constexpr (n == 3)
+        fma_rowbcast<G, 4 * R + act(0), 4 * R + act(1), 4 * R + act(2)>(acc, c, xv[act(0)], xv[act(1)], xv[act(2)]);
+    else if constexpr (n == 4)
+        fma_rowbcast<G, 4 * R + 0, 4 * R + 1, 4 * R + 2, 4 * R + 3>(acc, c, xrm, xrp, xmm, xmp);
 }
 template <int R, bool RT, bool MTM, int G>
 __device__ __forceinline__ void t4_couple(double& acc, double c, double xrm, double xrp, double xmm, double xmp, bool lo, bool hi)

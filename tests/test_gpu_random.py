@@ -14,7 +14,31 @@ TOL = 1e-9   # random problems are less well conditioned than the reference case
 
 def random_problem(jq, rng, Ntot, N, Nc, Nfreq, nsteps, m, objFuncType, banded):
     T = 1.0 + rng.random()
-    if banded == "od":   # Kronecker structure (slowest subsystem x 16 fast levels): dense 16x16 diagonal blocks,
+    if banded == "t4":   # Kronecker structure one level finer (fastest subsystem 4 levels, next one 4, slowest Ntot/16):
+        # dense 4x4 diagonal blocks, DIAGONAL couplings (i, i+-4) inside a 16-row block and (i, i+-16) between blocks
+        # -> the JQ_BW_T4 slab kernels (v_mfma_f64_4x4x4 + DPP FMAs).  Controls 2, 3, 4 (if present) act on ONE
+        # subsystem each, i.e. touch one part of the image only (the trace products then skip the other parts).
+        def kron(anti, parts=7):
+            a = np.zeros((Ntot, Ntot))
+            if parts & 1:
+                for b in range(0, Ntot, 4):
+                    e = min(b + 4, Ntot)
+                    blk = rng.standard_normal((e - b, e - b))
+                    a[b:e, b:e] = blk - blk.T if anti else blk + blk.T
+            for d, bit in ((4, 2), (16, 4)):
+                if not parts & bit:
+                    continue
+                for i in range(Ntot - d):
+                    if d == 4 and (i // 16 != (i + 4) // 16):
+                        continue
+                    a[i, i + d] = rng.standard_normal()
+                    a[i + d, i] = -a[i, i + d] if anti else a[i, i + d]
+            return a
+        parts = [7, 1, 2, 4]
+        Hs = [kron(False, parts[q % 4]) for q in range(Nc)]
+        Ha = [kron(True, parts[q % 4]) for q in range(Nc)]
+        H0 = kron(False)
+    elif banded == "od":   # Kronecker structure (slowest subsystem x 16 fast levels): dense 16x16 diagonal blocks,
         # DIAGONAL first off-diagonal blocks -> the JQ_BW_OD kernels (MFMA for the diagonal blocks only)
         def kron(anti):
             a = np.zeros((Ntot, Ntot))
@@ -90,10 +114,17 @@ CASES = [
     (40, 3, 2, 2, 7, 3, 3, "od", 3),
     (80, 5, 3, 1, 6, 4, 2, "od", 0),
     (96, 4, 3, 2, 5, 6, 1, "od", 2),
+    (16, 4, 2, 1, 9, 3, 1, "t4", 0),
+    (24, 3, 4, 1, 8, 2, 3, "t4", 3),
+    (36, 5, 3, 2, 7, 4, 2, "t4", 0),
+    (48, 4, 4, 1, 6, 3, 1, "t4", 2),
+    (62, 2, 2, 1, 7, 5, 3, "t4", 0),
+    (80, 8, 4, 1, 5, 4, 1, "t4", 0),
+    (96, 4, 4, 2, 5, 6, 2, "t4", 2),
 ]
 
 
-@pytest.mark.parametrize("mode", ["auto", "slab", "lane", "nolane"])
+@pytest.mark.parametrize("mode", ["auto", "slab", "slab-od", "lane", "nolane"])
 @pytest.mark.parametrize("cfg", CASES, ids=lambda c: "Ntot%d_N%d_Nc%d_f%d_m%d_o%d_%s_c%d" % (c[0], c[1], c[2], c[3], c[5], c[6], c[7] if isinstance(c[7], str) else ("band" if c[7] else "dense"), c[8]))
 def test_random_problem_matches_oracle(jq, cfg, mode):
     """mode 'auto': Ntot <= 16 runs on the row-lane kernels (one lane per (row, column); small batches), Ntot > 16
@@ -105,12 +136,17 @@ def test_random_problem_matches_oracle(jq, cfg, mode):
     Ntot, N, Nc, Nfreq, nsteps, m, oft, banded, chunk = cfg
     if (mode == "lane" and Ntot > 8) or (mode == "nolane" and Ntot > 16):
         pytest.skip("lane kernels only exist for Ntot <= 8, row-lane kernels for Ntot <= 16")
+    if mode == "slab-od" and banded != "t4":
+        pytest.skip("slab-od: the JQ_BW_T4 problems once more on the JQ_BW_OD / band kernels (JQ_T4=0)")
     rng = np.random.default_rng(1000 + Ntot * 31 + N)
     p, pcof = random_problem(jq, rng, Ntot, N, Nc, Nfreq, nsteps, m, oft, banded)
     if chunk:
         os.environ["JQ_CHUNK_STEPS"] = str(chunk)
-    if mode == "slab":
+    if mode in ("slab", "slab-od"):
         os.environ["JQ_COOP_MAX"] = "0"
+        os.environ["JQ_LANE"] = "0"
+    if mode == "slab-od":
+        os.environ["JQ_T4"] = "0"
     if mode == "nolane":
         os.environ["JQ_LANE"] = "0"
     if mode == "lane":
@@ -122,6 +158,7 @@ def test_random_problem_matches_oracle(jq, cfg, mode):
         os.environ.pop("JQ_COOP_MAX", None)
         os.environ.pop("JQ_LANE", None)
         os.environ.pop("JQ_ROWLANE_MAX", None)
+        os.environ.pop("JQ_T4", None)
     r = Oracle(p, use_sparse=False).traceobjgrad(pcof, history=True)
     objfv, tg, prim, sec, tinf, ig, lg = jq.traceobjgrad(pcof, p, wa, False, True)
     gn = np.linalg.norm(r["totalgrad"])
@@ -131,6 +168,9 @@ def test_random_problem_matches_oracle(jq, cfg, mode):
     assert np.linalg.norm(ig - r["infidelgrad"]) <= TOL * gn
     if oft != 1:
         assert np.linalg.norm(lg - r["leakgrad"]) <= TOL * gn
+    if banded == "t4" and mode in ("slab", "slab-od"):      # the kernel variant under test really ran
+        t = wa.last_timing()
+        assert t["kernel_family"] == 0 and (t["kernel_band"] == 8) == (mode == "slab")
     # per-step states
     _, hist, _ = jq.traceobjgrad(pcof, p, wa, True, False)
     assert np.max(np.abs(hist - r["history"])) < 1e-10
