@@ -48,7 +48,10 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // (24 x 16 = 384 cycles at Ntot = 96 instead of 24 x 64) and at most four v_fma_f64 per group for the couplings to the
 // groups rho-1, rho+1 (same 16-row block) and rho-4, rho+4 (neighbouring blocks), mm_t4.
 #define JQ_BW_T4 8
-#define JQ_T4_COEFS(NT) (64 * (NT))   // doubles after the 4NT A-operand tiles: [mt][g = lane>>4][r][term: r-1, r+1, mt-1, mt+1]
+#define JQ_T4_TILE 16                  // doubles per 4-row group in the image: the 4x4 diagonal block [k][i] (the MFMA's A operand
+                                      // repeats it in its four column blocks: lane 16k+4b+i reads element 4k+i, an LDS broadcast)
+#define JQ_T4_COEFS(NT) (64 * (NT))   // doubles after the 4NT blocks: [mt][g = lane>>4][r][term: r-1, r+1, mt-1, mt+1]
+#define JQ_T4_ELEMS(NT) (4 * (NT) * JQ_T4_TILE + JQ_T4_COEFS(NT))
 // trace-image modes of this variant (a.bw_trace[q]): bit 0 diagonal 4x4 blocks present, bit 1 r+-1 terms, bit 2 mt+-1 terms
 #define JQ_T4_DIAG 1
 #define JQ_T4_RTERMS 2
@@ -340,13 +343,15 @@ __device__ __forceinline__ void mm_t4(Arr<NT>& D, const Arr<NT>& C, const double
 {
     constexpr int NR = 4 * NT;
     constexpr bool diag = MODE & JQ_T4_DIAG, rt = MODE & JQ_T4_RTERMS, mtm = MODE & JQ_T4_MTERMS;
-    const double* cf = mat + NR * 64;
+    const int lane = threadIdx.x & 63;
+    const double* cf = mat + NR * JQ_T4_TILE;
+    const double* ma = mat - lane + ((lane >> 4) * 4 + (lane & 3));   // this lane's element of every 4x4 block
     double f[JQ_PF];
     double cq[2];
     if constexpr (diag) {
 #pragma unroll
         for (int i = 0; i < JQ_PF; ++i)
-            if (i < NR) f[i] = mat[i * 64];
+            if (i < NR) f[i] = ma[i * JQ_T4_TILE];
     }
     if constexpr (rt || mtm) {
         cq[0] = cf[0];
@@ -364,7 +369,7 @@ __device__ __forceinline__ void mm_t4(Arr<NT>& D, const Arr<NT>& C, const double
             pend[i] = ZEROC ? 0.0 : C.t[i >> 2][i & 3];
             if constexpr (diag) {
                 pend[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(f[i % JQ_PF], x.t[i >> 2][i & 3], pend[i], 0, 0, 0);
-                if (i + JQ_PF < NR) f[i % JQ_PF] = mat[(i + JQ_PF) * 64];
+                if (i + JQ_PF < NR) f[i % JQ_PF] = ma[(i + JQ_PF) * JQ_T4_TILE];
             }
         }
     __builtin_amdgcn_sched_barrier(0);
@@ -383,7 +388,7 @@ __device__ __forceinline__ void mm_t4(Arr<NT>& D, const Arr<NT>& C, const double
                 double nxt = ZEROC ? 0.0 : C.t[nx >> 2][nx & 3];
                 if constexpr (diag) {
                     nxt = __builtin_amdgcn_mfma_f64_4x4x4f64(f[nx % JQ_PF], x.t[nx >> 2][nx & 3], nxt, 0, 0, 0);
-                    if (nx + JQ_PF < NR) f[nx % JQ_PF] = mat[(nx + JQ_PF) * 64];
+                    if (nx + JQ_PF < NR) f[nx % JQ_PF] = ma[(nx + JQ_PF) * JQ_T4_TILE];
                 }
                 pend[rho & 1] = nxt;
             }

@@ -96,6 +96,31 @@ static int fail(jq_handle* h, int code, const char* msg)
 // M[16*mt + (l&15)][4*kk + (l>>4)]; zero padded.
 static void tile_image(const double* M, int Ntot, int NT, int BW, double* img, bool SD = false)
 {
+    if (BW == JQ_BW_T4) {
+        // compact image (JQ_T4_ELEMS doubles): per 4-row group rho its 4x4 diagonal block as [k][i] = M[4 rho + i][4 rho + k]
+        // (lane 16k+4b+i of the MFMA's A operand reads element 4k+i), then the coupling coefficients
+        // [mt][g][r][term: group rho-1, rho+1 (same 16-row block), rho-4, rho+4] <-> row 4 rho + g, rho = 4 mt + r
+        const int NR = 4 * NT;
+        for (size_t i = 0; i < (size_t)JQ_T4_ELEMS(NT); ++i) img[i] = 0.0;
+        if (!SD)
+            for (int rho = 0; rho < NR; ++rho)
+                for (int k = 0; k < 4; ++k)
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = 4 * rho + i, col = 4 * rho + k;
+                        img[rho * JQ_T4_TILE + 4 * k + i] = (row < Ntot && col < Ntot) ? M[row + (size_t)Ntot * col] : 0.0;
+                    }
+        double* cf = img + (size_t)NR * JQ_T4_TILE;
+        for (int rho = 0; rho < NR; ++rho)
+            for (int g = 0; g < 4; ++g) {
+                const int row = 4 * rho + g, r = rho & 3;
+                const int nbr[4] = {r > 0 ? row - 4 : -1, r < 3 ? row + 4 : -1, row - 16, row + 16};
+                for (int t = 0; t < 4; ++t) {
+                    const int col = nbr[t];
+                    cf[(rho >> 2) * 64 + g * 16 + r * 4 + t] = (col >= 0 && col < Ntot && row < Ntot) ? M[row + (size_t)Ntot * col] : 0.0;
+                }
+            }
+        return;
+    }
     const int KT = 4 * NT;
     size_t idx = 0;
     for (int kk = 0; kk < KT; ++kk)
@@ -108,32 +133,6 @@ static void tile_image(const double* M, int Ntot, int NT, int BW, double* img, b
             }
             ++idx;
         }
-    if (BW == JQ_BW_T4) {
-        // A operands of v_mfma_f64_4x4x4_4b: tile rho, lane l holds M[4 rho + (l & 3)][4 rho + (l >> 4)] (the 4x4 diagonal
-        // block, the same in all four 16-column... 4-column blocks of the instruction); then the coupling coefficients
-        // [mt][g][r][term: group rho-1, rho+1 (same 16-row block), rho-4, rho+4] <-> row 4 rho + g, rho = 4 mt + r
-        const int NR = 4 * NT;
-        idx = 0;
-        if (!SD)
-            for (int rho = 0; rho < NR; ++rho, ++idx)
-                for (int l = 0; l < 64; ++l) {
-                    const int row = 4 * rho + (l & 3), col = 4 * rho + (l >> 4);
-                    img[idx * 64 + l] = (row < Ntot && col < Ntot) ? M[row + (size_t)Ntot * col] : 0.0;
-                }
-        double* cf = img + (size_t)NR * 64;          // fixed position (the device code does not know SD here)
-        if (SD)
-            for (size_t i = 0; i < (size_t)NR * 64; ++i) img[i] = 0.0;
-        for (int rho = 0; rho < NR; ++rho)
-            for (int g = 0; g < 4; ++g) {
-                const int row = 4 * rho + g, r = rho & 3;
-                const int nbr[4] = {r > 0 ? row - 4 : -1, r < 3 ? row + 4 : -1, row - 16, row + 16};
-                for (int t = 0; t < 4; ++t) {
-                    const int col = nbr[t];
-                    cf[(rho >> 2) * 64 + g * 16 + r * 4 + t] = (col >= 0 && col < Ntot && row < Ntot) ? M[row + (size_t)Ntot * col] : 0.0;
-                }
-            }
-        return;
-    }
     if (BW == JQ_BW_OD) {
         // diagonals of the first off-diagonal blocks: [mt][dir: block mt-1, block mt+1][g][r] <-> row 16mt + 4r + g
         double* cf = img + idx * 64;
@@ -485,8 +484,8 @@ static int create_impl(const jq_problem* p, jq_handle* h)
                 h->bw_trace[q] = (h->NT > 1 && diag_blocks_zero(h->Hsym.data() + q * nn, h->Ntot) &&
                                   diag_blocks_zero(h->Hanti.data() + q * nn, h->Ntot)) ? 2 : 1;
         }
-        h->mat_elems = ((64LL * band_tiles(h->NT, h->BW) + (h->BW == JQ_BW_OD ? JQ_OD_COEFS(h->NT) : 0) +
-                         (h->BW == JQ_BW_T4 ? JQ_T4_COEFS(h->NT) : 0) + 127) / 128) * 128;
+        h->mat_elems = (((h->BW == JQ_BW_T4 ? (long long)JQ_T4_ELEMS(h->NT)
+                                             : 64LL * band_tiles(h->NT, h->BW) + (h->BW == JQ_BW_OD ? JQ_OD_COEFS(h->NT) : 0)) + 127) / 128) * 128;
         const long long slot = h->mat_elems * 8;
         const long long lds_fwd_fixed = (long long)32 * h->NT * 8;
         const long long lds_bwd_fixed = lds_fwd_fixed + (long long)JQ_MAXNC * 256 * 8;
@@ -621,7 +620,9 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         const long long v = atoll(e);
         if (v > 0) budget = (size_t)v;
     }
-    const size_t per_tp = 2 * (size_t)std::max(h->mat_elems, h->mat_elems_c) * sizeof(double);
+    // largest operator image of any kernel family the handle may use (slab, cooperative, lane, row-lane)
+    const long long img_elems = std::max(std::max(h->mat_elems, h->mat_elems_c), std::max(h->lane_stride, h->rl_stride));
+    const size_t per_tp = 2 * (size_t)img_elems * sizeof(double);
     long long cs = ((long long)(budget / per_tp) - 1) / 2;
     cs = std::max<long long>(1, std::min<long long>(cs, h->nsteps));
     if (const char* e = getenv("JQ_CHUNK_STEPS")) {
@@ -629,7 +630,7 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         if (v > 0) cs = std::min<long long>(v, h->nsteps);
     }
     h->chunk_steps = (int)cs;
-    if ((rc = dev_alloc(h, &h->d_stream, (size_t)(2 * cs + 1) * 2 * std::max(h->mat_elems, h->mat_elems_c)))) return rc;
+    if ((rc = dev_alloc(h, &h->d_stream, (size_t)(2 * cs + 1) * 2 * img_elems))) return rc;
     if ((rc = dev_alloc(h, &h->d_pq, (size_t)(2 * cs + 1) * 2 * h->Nc))) return rc;
     if ((rc = dev_alloc(h, &h->d_R, (size_t)cs * h->Nc * JQ_NTR))) return rc;
     return JQ_OK;
