@@ -612,6 +612,12 @@ __device__ __forceinline__ void hist_store(const PropArgs& a, int slab, int lane
 //   and the constant trace images stay resident, so there is ONE barrier per B steps instead of one per
 //   operator use -- for Ntot <= 32 a product is only 4..32 MFMAs and the barrier + DMA latency would
 //   otherwise dominate.
+// window mode (batch < 0; images small enough that everything below fits the LDS -- the compact JQ_BW_T4 images):
+//   a ring of JQ_WIN_TPS = 5 time points (K and S image each) and the constant trace images are RESIDENT: step n works
+//   on the time points 2n, 2n+1, 2n+2 while 2n+3 and 2n+4 stream in, every image is fetched once instead of once per
+//   use (backward: 4 image fetches per step instead of 13 + 3 Ncoupled), and there is ONE workgroup barrier per time step
+//   instead of one per operator use (measured: the per-use wait + barrier + DMA issue was 15% of the cnot3 evaluation).
+#define JQ_WIN_TPS 5
 struct Ring {
     char* smem;
     // copies of the launch parameters the staging needs (kept in SGPRs; taking the address of the kernel
@@ -626,6 +632,15 @@ struct Ring {
     int Qp;           // per-operator mode: index of the next operator use to prefetch
     int np, ip;       // (step, position) cursor: of Qp (per-operator mode) or of Q (batched mode)
     int wave, lane, nwaves;
+    // per-operator mode, prefetch cursor in incremental form (no multiplications by the step number, no schedule word
+    // selection, no reloads of kernel arguments in front of every DMA issue -- that code was 10% of the backward step):
+    unsigned long long pword;      // schedule entries not yet consumed of the current word (6 bits each)
+    const char* pbase;             // stream + images of time point 2 * np (bytes)
+    unsigned stride_b;             // bytes per image slot
+    // window mode: cursor of the next operator use
+    unsigned long long qword;      // its schedule entries not yet consumed
+    int iq;                        // its position in the step
+    int s0;                        // ring slot of time point 2n of the current step
 
     __device__ __forceinline__ unsigned lane_off16() const
     {
@@ -675,14 +690,24 @@ struct Ring {
     // ---- per-operator mode -------------------------------------------------------------------
     __device__ __forceinline__ void issue_prefetch()
     {
-        int kind, tp;
-        entry_at(Qp, ip, kind, tp);
-        int n = (Qp < npro) ? 0 : np;
-        if (n >= nsteps_chunk) n = nsteps_chunk - 1;  // past the end: harmless re-fetch
-        const double* src = (kind == 2) ? cimg + (size_t)tp * stride
-                                        : stream + (size_t)(2 * (2 * n + tp) + kind) * stride;
-        dma(src, smem + (size_t)(Qp & 1) * slot_bytes, pieces);
-        advance(Qp, np, ip);
+        const unsigned e = (unsigned)pword & 63u, kind = e & 3u, tp = e >> 2;
+        // image #tp of the constants, or K (kind 0) / S (kind 1) of time point 2 * np + tp of the chunk
+        const char* src = (kind == 2) ? (const char*)cimg + tp * stride_b : pbase + (2 * tp + kind) * stride_b;
+        dma((const double*)src, smem + (size_t)(Qp & 1) * slot_bytes, pieces);
+        pword >>= 6;
+        if (Qp >= npro) {
+            ++ip;
+            if (ip == 10) pword = sb1;
+            if (ip == 20) pword = sb2;
+            if (ip == period) {
+                ip = 0;
+                pword = sb0;
+                if (++np < nsteps_chunk) pbase += 4 * (size_t)stride_b;   // (past the end: harmless re-fetch of the last step)
+            }
+        } else if (Qp + 1 == npro) {
+            pword = sb0;
+        }
+        ++Qp;
     }
     // ---- batched mode ------------------------------------------------------------------------
     __device__ __forceinline__ void issue_batch(int b)
@@ -695,8 +720,27 @@ struct Ring {
         dma(stream + (size_t)(4 * first) * stride, smem + (size_t)(b & 1) * slot_bytes, npts * 2 * pieces);
     }
     // call at the top of every time step n (of the chunk)
+    __device__ __forceinline__ void issue_tp(int j)   // window mode: K and S of time point j of the chunk -> its ring slot
+    {
+        if (j > 2 * nsteps_chunk) return;
+        dma((const double*)((const char*)stream + (size_t)j * 2 * stride_b), smem + (size_t)(j % JQ_WIN_TPS) * 2 * stride_b, 2 * pieces);
+    }
     __device__ __forceinline__ void begin_step(int n)
     {
+        if (batch < 0) {
+            if (n > 0) {
+                // every wave has finished step n-1 behind this barrier: its time points 2n-2, 2n-1 make room for 2n+3, 2n+4;
+                // the images of this step (issued one step ago) have landed
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                issue_tp(2 * n + 3);
+                issue_tp(2 * n + 4);
+                s0 += 2;
+                if (s0 >= JQ_WIN_TPS) s0 -= JQ_WIN_TPS;
+            }
+            return;
+        }
         if (batch > 0 && (n % batch) == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -728,7 +772,19 @@ struct Ring {
         ip = 0;
         wave = wave_;
         lane = lane_;
-        if (batch > 0) {
+        if (batch < 0) {
+            stride_b = (unsigned)(stride * 8);
+            slot_bytes = (int)(2 * stride_b);
+            // resident constant images behind the ring of time points
+            dma(cimg, smem + (size_t)JQ_WIN_TPS * slot_bytes, 2 * ncoupled * pieces);
+            for (int j = 0; j < JQ_WIN_TPS; ++j) issue_tp(j);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            qword = npro > 0 ? pb : sb0;
+            iq = 0;
+            s0 = 0;
+        } else if (batch > 0) {
             slot_bytes = (int)((2 * batch + 1) * 2 * stride * 8);
             // resident constant images behind the two batch buffers
             dma(cimg, smem + 2 * (size_t)slot_bytes, 2 * ncoupled * pieces);
@@ -738,6 +794,11 @@ struct Ring {
             asm volatile("" ::: "memory");
         } else {
             slot_bytes = (int)(stride * 8);
+            stride_b = (unsigned)(stride * 8);
+            pbase = (const char*)stream;
+            pword = npro > 0 ? pb : sb0;
+            // (opaque copies: otherwise hipcc re-reads these kernel arguments from memory in front of every DMA issue)
+            asm volatile("" : "+s"(cimg), "+s"(pbase));
             issue_prefetch();
         }
     }
@@ -745,6 +806,31 @@ struct Ring {
     __device__ __forceinline__ const double* next()
     {
         const double* M;
+        if (batch < 0) {
+            const unsigned e = (unsigned)qword & 63u, kind = e & 3u, tp = e >> 2;
+            unsigned off;
+            if (kind == 2) {
+                off = (unsigned)(JQ_WIN_TPS * slot_bytes) + tp * stride_b;
+            } else {
+                unsigned sl = (unsigned)s0 + tp;
+                if (sl >= JQ_WIN_TPS) sl -= JQ_WIN_TPS;
+                off = sl * (unsigned)slot_bytes + kind * stride_b;
+            }
+            qword >>= 6;
+            if (Q >= npro) {
+                ++iq;
+                if (iq == 10) qword = sb1;
+                if (iq == 20) qword = sb2;
+                if (iq == period) {
+                    iq = 0;
+                    qword = sb0;
+                }
+            } else if (Q + 1 == npro) {
+                qword = sb0;
+            }
+            ++Q;
+            return (const double*)(smem + off) + lane;
+        }
         if (batch > 0) {
             int kind, tp;
             entry_at(Q, ip, kind, tp);

@@ -509,6 +509,20 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         // ~600-cycle dependent-product latency dominates, not the per-operator barrier) and its 150 KB of
         // LDS allow only one workgroup per CU.  JQ_BATCH=<B> enables it for experiments.
         h->batch = 0;
+        // Window staging (jq_kernels.h Ring, batch < 0): five time points (K and S image each) and the constant trace images
+        // resident in LDS, one workgroup barrier per time step.  Used whenever it fits next to the backward kernel's carry
+        // and parking images (kernels compiled for two workgroups per CU: in half of the LDS); JQ_WINDOW=0 disables it.
+        {
+            const long long win = (2LL * JQ_WIN_TPS + 2LL * h->Nc) * slot;
+            const long long budget = (h->NT <= 2) ? 81920 : 163840;
+            bool w = win + lds_bwd_fixed + park_bytes <= budget;
+            if (const char* e = getenv("JQ_WINDOW"))
+                if (atoi(e) == 0) w = false;
+            if (w) {
+                h->batch = -1;
+                h->park_lds = 1;
+            }
+        }
         if (const char* e = getenv("JQ_BATCH")) {
             const int v = atoi(e);
             if (v >= 2 && slot <= 8192) {
@@ -1024,8 +1038,9 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     // dynamic LDS layout: [operator staging | tables wd, ws | (backward: carry, parking images)]
     // cooperative kernels: [two operator slots | tables wd, ws | two x exchange buffers]
     const int batch = coop ? 0 : h->batch;
-    const size_t lds_stage = batch > 0 ? (size_t)2 * (2 * batch + 1) * 2 * stride * 8 + (size_t)2 * h->Nc * stride * 8
-                                       : (size_t)2 * stride * 8;
+    const size_t lds_stage = batch > 0   ? (size_t)2 * (2 * batch + 1) * 2 * stride * 8 + (size_t)2 * h->Nc * stride * 8
+                             : batch < 0 ? (size_t)(2 * JQ_WIN_TPS + 2 * h->Nc) * stride * 8
+                                         : (size_t)2 * stride * 8;
     const size_t lds_fwd = (lane || rl) ? 0 : imr_coop ? coop_imr_lds_bytes(h->NT, stride)
                                            : lds_stage + (size_t)32 * h->NT * 8 + (coop ? (size_t)2 * h->KT * 64 * 8 : 0);
     const size_t lds_bwd = rl ? (h->rl_npj > 8 ? (size_t)2 * h->Nc * h->rl_stride * 8 : 0) : lane ? 0 : coop ? lds_fwd
