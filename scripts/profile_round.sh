@@ -1,0 +1,21 @@
+#!/bin/bash
+# Everything the judged profile files come from, in one GPU call (run through gpurun):
+#   1. the default bench.py line                                   -> gpurun_out/bench_<tag>.log
+#   2. rocprofv3 --kernel-trace --stats of one bench step           -> gpurun_out/stats_<tag>.txt
+#   3. rocprofv3 --pmc passes of the same command (HBM bytes; SQ)   -> gpurun_out/traffic_<tag>.json
+# usage: scripts/profile_round.sh <tag>          (copy the three files into profiles/ afterwards)
+tag=$1
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+(cd $R && python3 bench.py) > $R/gpurun_out/bench_${tag}.log 2>&1
+tail -1 $R/gpurun_out/bench_${tag}.log | cut -c1-600
+CMD="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline"
+(cd $R && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${tag}/stats -o res -- $CMD) > $R/gpurun_out/prof_${tag}_stats.log 2>&1
+(cd $R && python3 scripts/rocpd_summary.py $(find gpurun_out/prof_${tag}/stats -name "*.db" | head -1) gpurun_out/stats_${tag}.txt; head -6 gpurun_out/stats_${tag}.txt)
+i=0
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+           "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"; do
+  i=$((i+1))
+  (cd $R && rocprofv3 --pmc $grp --kernel-trace -d $R/gpurun_out/prof_${tag}/pmc$i -o res -- $CMD) > $R/gpurun_out/prof_${tag}_pmc$i.log 2>&1
+done
+cd $R && python3 scripts/make_traffic_json.py gpurun_out/traffic_${tag}.json $(find gpurun_out/prof_${tag}/pmc* -name "*.db") && head -30 gpurun_out/traffic_${tag}.json
