@@ -274,62 +274,84 @@ __device__ __forceinline__ void mm_od(Arr<NT>& D, const Arr<NT>& C, const double
 //  6: y is the result of a v_mfma_f64_4x4x4 -- a software hazard (6 wait states before a VALU read) that the compiler's
 //     hazard recognizer does not apply to inline asm.
 #define JQ_DPPF(y, c, x, k) "v_fmac_f64_dpp " y ", " c ", " x " row_newbcast:" k " row_mask:0xf bank_mask:0xf\n\t"
-template <int GUARD, int K0>
-__device__ __forceinline__ void fma_rowbcast(double& y, double c, double x0)
+// The same for the groups A, B of a pair with their FMA chains interleaved (A0 B0 A1 B1 ...): a dependent v_fma_f64 chain
+// issues at 4.7 ns per instruction, two independent ones at 3.4 (probes/t4_group_probe.hip).  NA, NB terms; unused x operands
+// are passed as copies of c.
+#define JQ_PAIR_OPS : "+v"(yA), "+v"(yB) : "v"(c), "v"(xa0), "v"(xa1), "v"(xa2), "v"(xa3), "v"(xb0), "v"(xb1), "v"(xb2), "v"(xb3), \
+                      "n"(GUARD - 1), "n"(KA0), "n"(KA1), "n"(KA2), "n"(KA3), "n"(KB0), "n"(KB1), "n"(KB2), "n"(KB3)
+template <int GUARD, int NA, int NB, int KA0, int KA1, int KA2, int KA3, int KB0, int KB1, int KB2, int KB3>
+__device__ __forceinline__ void fma_rowbcast_pair(double& yA, double& yB, double c, double xa0, double xa1, double xa2, double xa3,
+                                                  double xb0, double xb1, double xb2, double xb3)
 {
-    asm("s_nop %3\n\t" JQ_DPPF("%0", "%1", "%2", "%4") : "+v"(y) : "v"(c), "v"(x0), "n"(GUARD - 1), "n"(K0));
-}
-template <int GUARD, int K0, int K1>
-__device__ __forceinline__ void fma_rowbcast(double& y, double c, double x0, double x1)
-{
-    asm("s_nop %4\n\t" JQ_DPPF("%0", "%1", "%2", "%5") JQ_DPPF("%0", "%1", "%3", "%6")
-        : "+v"(y) : "v"(c), "v"(x0), "v"(x1), "n"(GUARD - 1), "n"(K0), "n"(K1));
-}
-template <int GUARD, int K0, int K1, int K2>
-__device__ __forceinline__ void fma_rowbcast(double& y, double c, double x0, double x1, double x2)
-{
-    asm("s_nop %5\n\t" JQ_DPPF("%0", "%1", "%2", "%6") JQ_DPPF("%0", "%1", "%3", "%7") JQ_DPPF("%0", "%1", "%4", "%8")
-        : "+v"(y) : "v"(c), "v"(x0), "v"(x1), "v"(x2), "n"(GUARD - 1), "n"(K0), "n"(K1), "n"(K2));
-}
-template <int GUARD, int K0, int K1, int K2, int K3>
-__device__ __forceinline__ void fma_rowbcast(double& y, double c, double x0, double x1, double x2, double x3)
-{
-    asm("s_nop %6\n\t" JQ_DPPF("%0", "%1", "%2", "%7") JQ_DPPF("%0", "%1", "%3", "%8") JQ_DPPF("%0", "%1", "%4", "%9")
-        JQ_DPPF("%0", "%1", "%5", "%10")
-        : "+v"(y) : "v"(c), "v"(x0), "v"(x1), "v"(x2), "v"(x3), "n"(GUARD - 1), "n"(K0), "n"(K1), "n"(K2), "n"(K3));
+    static_assert(NA >= 1 && NA <= 4 && NB >= 1 && NB <= 4, "");
+    if constexpr (NA == 1 && NB == 1)
+        asm("s_nop %11\n\t" JQ_DPPF("%0", "%2", "%3", "%12") JQ_DPPF("%1", "%2", "%7", "%16") JQ_PAIR_OPS);
+    else if constexpr (NA == 1 && NB == 2)
+        asm("s_nop %11\n\t" JQ_DPPF("%0", "%2", "%3", "%12") JQ_DPPF("%1", "%2", "%7", "%16") JQ_DPPF("%1", "%2", "%8", "%17") JQ_PAIR_OPS);
+    else if constexpr (NA == 1 && NB == 3)
+        asm("s_nop %11\n\t" JQ_DPPF("%0", "%2", "%3", "%12") JQ_DPPF("%1", "%2", "%7", "%16") JQ_DPPF("%1", "%2", "%8", "%17") JQ_DPPF("%1", "%2", "%9", "%18") JQ_PAIR_OPS);
+    else if constexpr (NA == 1 && NB == 4)
+        asm("s_nop %11\n\t" JQ_DPPF("%0", "%2", "%3", "%12") JQ_DPPF("%1", "%2", "%7", "%16") JQ_DPPF("%1", "%2", "%8", "%17") JQ_DPPF("%1", "%2", "%9", "%18") JQ_DPPF("%1", "%2", "%10", "%19") JQ_PAIR_OPS);
+    else if constexpr (NA == 2 && NB == 1)
+        asm("s_nop %11\n\t" JQ_DPPF("%0", "%2", "%3", "%12") JQ_DPPF("%1", "%2", "%7", "%16") JQ_DPPF("%0", "%2", "%4", "%13") JQ_PAIR_OPS);
+    else if constexpr (NA == 2 && NB == 2)
+        asm("s_nop %11\n\t" JQ_DPPF("%0", "%2", "%3", "%12") JQ_DPPF("%1", "%2", "%7", "%16") JQ_DPPF("%0", "%2", "%4", "%13") JQ_DPPF("%1", "%2", "%8", "%17") JQ_PAIR_OPS);
+    else if constexpr (NA == 2 && NB == 3)
+        asm("s_nop %11\n\t" JQ_DPPF("%0", "%2", "%3", "%12") JQ_DPPF("%1", "%2", "%7", "%16") JQ_DPPF("%0", "%2", "%4", "%13") JQ_DPPF("%1", "%2", "%8", "%17") JQ_DPPF("%1", "%2", "%9", "%18") JQ_PAIR_OPS);
+    else if constexpr (NA == 2 && NB == 4)
+        asm("s_nop %11\n\t" JQ_DPPF("%0", "%2", "%3", "%12") JQ_DPPF("%1", "%2", "%7", "%16") JQ_DPPF("%0", "%2", "%4", "%13") JQ_DPPF("%1", "%2", "%8", "%17") JQ_DPPF("%1", "%2", "%9", "%18") JQ_DPPF("%1", "%2", "%10", "%19") JQ_PAIR_OPS);
+    else if constexpr (NA == 3 && NB == 1)
+        asm("s_nop %11\n\t" JQ_DPPF("%0", "%2", "%3", "%12") JQ_DPPF("%1", "%2", "%7", "%16") JQ_DPPF("%0", "%2", "%4", "%13") JQ_DPPF("%0", "%2", "%5", "%14") JQ_PAIR_OPS);
+    else if constexpr (NA == 3 && NB == 2)
+        asm("s_nop %11\n\t" JQ_DPPF("%0", "%2", "%3", "%12") JQ_DPPF("%1", "%2", "%7", "%16") JQ_DPPF("%0", "%2", "%4", "%13") JQ_DPPF("%1", "%2", "%8", "%17") JQ_DPPF("%0", "%2", "%5", "%14") JQ_PAIR_OPS);
+    else if constexpr (NA == 3 && NB == 3)
+        asm("s_nop %11\n\t" JQ_DPPF("%0", "%2", "%3", "%12") JQ_DPPF("%1", "%2", "%7", "%16") JQ_DPPF("%0", "%2", "%4", "%13") JQ_DPPF("%1", "%2", "%8", "%17") JQ_DPPF("%0", "%2", "%5", "%14") JQ_DPPF("%1", "%2", "%9", "%18") JQ_PAIR_OPS);
+    else if constexpr (NA == 3 && NB == 4)
+        asm("s_nop %11\n\t" JQ_DPPF("%0", "%2", "%3", "%12") JQ_DPPF("%1", "%2", "%7", "%16") JQ_DPPF("%0", "%2", "%4", "%13") JQ_DPPF("%1", "%2", "%8", "%17") JQ_DPPF("%0", "%2", "%5", "%14") JQ_DPPF("%1", "%2", "%9", "%18") JQ_DPPF("%1", "%2", "%10", "%19") JQ_PAIR_OPS);
+    else if constexpr (NA == 4 && NB == 1)
+        asm("s_nop %11\n\t" JQ_DPPF("%0", "%2", "%3", "%12") JQ_DPPF("%1", "%2", "%7", "%16") JQ_DPPF("%0", "%2", "%4", "%13") JQ_DPPF("%0", "%2", "%5", "%14") JQ_DPPF("%0", "%2", "%6", "%15") JQ_PAIR_OPS);
+    else if constexpr (NA == 4 && NB == 2)
+        asm("s_nop %11\n\t" JQ_DPPF("%0", "%2", "%3", "%12") JQ_DPPF("%1", "%2", "%7", "%16") JQ_DPPF("%0", "%2", "%4", "%13") JQ_DPPF("%1", "%2", "%8", "%17") JQ_DPPF("%0", "%2", "%5", "%14") JQ_DPPF("%0", "%2", "%6", "%15") JQ_PAIR_OPS);
+    else if constexpr (NA == 4 && NB == 3)
+        asm("s_nop %11\n\t" JQ_DPPF("%0", "%2", "%3", "%12") JQ_DPPF("%1", "%2", "%7", "%16") JQ_DPPF("%0", "%2", "%4", "%13") JQ_DPPF("%1", "%2", "%8", "%17") JQ_DPPF("%0", "%2", "%5", "%14") JQ_DPPF("%1", "%2", "%9", "%18") JQ_DPPF("%0", "%2", "%6", "%15") JQ_PAIR_OPS);
+    else if constexpr (NA == 4 && NB == 4)
+        asm("s_nop %11\n\t" JQ_DPPF("%0", "%2", "%3", "%12") JQ_DPPF("%1", "%2", "%7", "%16") JQ_DPPF("%0", "%2", "%4", "%13") JQ_DPPF("%1", "%2", "%8", "%17") JQ_DPPF("%0", "%2", "%5", "%14") JQ_DPPF("%1", "%2", "%9", "%18") JQ_DPPF("%0", "%2", "%6", "%15") JQ_DPPF("%1", "%2", "%10", "%19") JQ_PAIR_OPS);
 }
 
-// coupling terms of 4-row group R of a 16-row block: coefficient lane 4R + term of this lane's row of c.
-// LO / HI: the block has a neighbour block below / above.  G: guard of the group's first FMA.
+// coupling terms of the 4-row groups R (even) and R+1 of a 16-row block: coefficient lane 4 R + term of this lane's row of c.
+// xa / xb: {x of the group below in the block, above in the block, of the block below, of the block above} for A / B.
+// LO / HI: the block has a neighbour block below / above.  G: guard of the first FMA.
 template <int R, bool RT, bool MTM, bool LO, bool HI, int G>
-__device__ __forceinline__ void t4_couple(double& acc, double c, double xrm, double xrp, double xmm, double xmp)
+__device__ __forceinline__ void t4_couple_pair(double& accA, double& accB, double c, const double (&xa)[4], const double (&xb)[4])
 {
-    constexpr bool on[4] = {RT && R > 0, RT && R < 3, MTM && LO, MTM && HI};
-    constexpr int n = on[0] + on[1] + on[2] + on[3];
-    // k-th active term
-    constexpr auto act = [](int k) constexpr {
-        const bool o[4] = {RT && R > 0, RT && R < 3, MTM && LO, MTM && HI};
+    constexpr auto on = [](int r, int t) constexpr { return t == 0 ? (RT && r > 0) : t == 1 ? (RT && r < 3) : t == 2 ? (MTM && LO) : (MTM && HI); };
+    constexpr auto cnt = [on](int r) constexpr { return on(r, 0) + on(r, 1) + on(r, 2) + on(r, 3); };
+    // k-th active term of group r (past the end: term 0, unused)
+    constexpr auto act = [on](int r, int k) constexpr {
         for (int t = 0; t < 4; ++t)
-            if (o[t] && k-- == 0) return t;
+            if (on(r, t) && k-- == 0) return t;
         return 0;
     };
-    const double xv[4] = {xrm, xrp, xmm, xmp};
-    if constexpr (n == 1)
-        fma_rowbcast<G, 4 * R + act(0)>(acc, c, xv[act(0)]);
-    else if constexpr (n == 2)
-        fma_rowbcast<G, 4 * R + act(0), 4 * R + act(1)>(acc, c, xv[act(0)], xv[act(1)]);
-    else if constexpr (n == 3)
-        fma_rowbcast<G, 4 * R + act(0), 4 * R + act(1), 4 * R + act(2)>(acc, c, xv[act(0)], xv[act(1)], xv[act(2)]);
-    else if constexpr (n == 4)
-        fma_rowbcast<G, 4 * R + 0, 4 * R + 1, 4 * R + 2, 4 * R + 3>(acc, c, xrm, xrp, xmm, xmp);
+    constexpr int NA = cnt(R), NB = cnt(R + 1);
+    static_assert((NA == 0) == (NB == 0), "");
+    if constexpr (NA > 0) {
+#define JQ_XA(k) (k < NA ? xa[act(R, k)] : c)
+#define JQ_XB(k) (k < NB ? xb[act(R + 1, k)] : c)
+        fma_rowbcast_pair<G, NA, NB, 4 * R + act(R, 0), 4 * R + act(R, 1), 4 * R + act(R, 2), 4 * R + act(R, 3), 4 * R + 4 + act(R + 1, 0),
+                          4 * R + 4 + act(R + 1, 1), 4 * R + 4 + act(R + 1, 2), 4 * R + 4 + act(R + 1, 3)>(
+            accA, accB, c, JQ_XA(0), JQ_XA(1), JQ_XA(2), JQ_XA(3), JQ_XB(0), JQ_XB(1), JQ_XB(2), JQ_XB(3));
+#undef JQ_XA
+#undef JQ_XB
+    }
 }
 template <int R, bool RT, bool MTM, int G>
-__device__ __forceinline__ void t4_couple(double& acc, double c, double xrm, double xrp, double xmm, double xmp, bool lo, bool hi)
+__device__ __forceinline__ void t4_couple_pair(double& accA, double& accB, double c, const double (&xa)[4], const double (&xb)[4], bool lo,
+                                               bool hi)
 {
-    if (lo && hi) t4_couple<R, RT, MTM, true, true, G>(acc, c, xrm, xrp, xmm, xmp);
-    else if (lo) t4_couple<R, RT, MTM, true, false, G>(acc, c, xrm, xrp, xmm, xmp);
-    else if (hi) t4_couple<R, RT, MTM, false, true, G>(acc, c, xrm, xrp, xmm, xmp);
-    else t4_couple<R, RT, MTM, false, false, G>(acc, c, xrm, xrp, xmm, xmp);
+    if (lo && hi) t4_couple_pair<R, RT, MTM, true, true, G>(accA, accB, c, xa, xb);
+    else if (lo) t4_couple_pair<R, RT, MTM, true, false, G>(accA, accB, c, xa, xb);
+    else if (hi) t4_couple_pair<R, RT, MTM, false, true, G>(accA, accB, c, xa, xb);
+    else t4_couple_pair<R, RT, MTM, false, false, G>(accA, accB, c, xa, xb);
 }
 
 // BW == JQ_BW_T4 (see the definition above).  Alias-safe (D may be C and/or x): the old values of the last four
@@ -357,21 +379,21 @@ __device__ __forceinline__ void mm_t4(Arr<NT>& D, const Arr<NT>& C, const double
         cq[0] = cf[0];
         if (NT > 1) cq[1] = cf[64];
     }
-    // MFMA first (three-operand: the C element is read in place, no copy), then the tied DPP FMAs on its result.  The
-    // MFMAs run two groups ahead: an MFMA result needs 6 wait states before a VALU read, a software hazard the compiler
-    // does not apply to inline asm -- here the FMAs of the group before, two MFMAs and the guard of the first FMA are
-    // in between (group 0: longer guard).  scripts/check_dpp_hazard.py verifies the final ISA.
+    // MFMA first (three-operand: the C element is read in place, no copy), then the tied DPP FMAs on its result, two
+    // groups at a time with their chains interleaved.  The MFMAs run one pair ahead: an MFMA result needs 6 wait states
+    // before a VALU read, a software hazard the compiler does not apply to inline asm -- here the FMAs of the pair before,
+    // two MFMAs and the guard of the first FMA are in between (first pair: longer guard).  scripts/check_dpp_hazard.py
+    // verifies the final ISA.
     double xo[4] = {0.0, 0.0, 0.0, 0.0};
     double pend[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-        if (i < NR) {
-            pend[i] = ZEROC ? 0.0 : C.t[i >> 2][i & 3];
-            if constexpr (diag) {
-                pend[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(f[i % JQ_PF], x.t[i >> 2][i & 3], pend[i], 0, 0, 0);
-                if (i + JQ_PF < NR) f[i % JQ_PF] = ma[(i + JQ_PF) * JQ_T4_TILE];
-            }
+    for (int i = 0; i < 2; ++i) {
+        pend[i] = ZEROC ? 0.0 : C.t[0][i];
+        if constexpr (diag) {
+            pend[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(f[i % JQ_PF], x.t[0][i], pend[i], 0, 0, 0);
+            if (i + JQ_PF < NR) f[i % JQ_PF] = ma[(i + JQ_PF) * JQ_T4_TILE];
         }
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt) {
@@ -381,35 +403,42 @@ __device__ __forceinline__ void mm_t4(Arr<NT>& D, const Arr<NT>& C, const double
             if (mt + 2 < NT) cq[mt & 1] = cf[(mt + 2) * 64];
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int rho = 4 * mt + r, nx = rho + 2;
-            double cur = pend[rho & 1];
-            if (nx < NR) {
-                double nxt = ZEROC ? 0.0 : C.t[nx >> 2][nx & 3];
-                if constexpr (diag) {
-                    nxt = __builtin_amdgcn_mfma_f64_4x4x4f64(f[nx % JQ_PF], x.t[nx >> 2][nx & 3], nxt, 0, 0, 0);
-                    if (nx + JQ_PF < NR) f[nx % JQ_PF] = ma[(nx + JQ_PF) * JQ_T4_TILE];
+        for (int pr = 0; pr < 2; ++pr) {
+            const int r = 2 * pr, rho = 4 * mt + r;
+            double curA = pend[0], curB = pend[1];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int nx = rho + 2 + i;
+                if (nx < NR) {
+                    double nxt = ZEROC ? 0.0 : C.t[nx >> 2][nx & 3];
+                    if constexpr (diag) {
+                        nxt = __builtin_amdgcn_mfma_f64_4x4x4f64(f[nx % JQ_PF], x.t[nx >> 2][nx & 3], nxt, 0, 0, 0);
+                        if (nx + JQ_PF < NR) f[nx % JQ_PF] = ma[(nx + JQ_PF) * JQ_T4_TILE];
+                    }
+                    pend[i] = nxt;
                 }
-                pend[rho & 1] = nxt;
             }
-            const double xc = x.t[mt][r];
+            __builtin_amdgcn_sched_barrier(0);   // both MFMAs of the next pair are issued before this pair's FMAs
+            const double xA = x.t[mt][r], xB = x.t[mt][r + 1];
             if constexpr (rt || mtm) {
-                const double xrm = xo[(rho + 3) & 3], xmm = xo[rho & 3];           // old x of the groups rho-1, rho-4
-                const double xrp = (r < 3) ? x.t[mt][(r + 1) & 3] : 0.0;
-                const double xmp = (mt + 1 < NT) ? x.t[(mt + 1 < NT) ? mt + 1 : mt][r] : 0.0;
+                const bool hi = mt + 1 < NT;
+                const int mu = hi ? mt + 1 : mt;
+                // {group below in the block, above in the block, same group of the block below, of the block above}; "below" values
+                // are the OLD ones (the product may run in place)
+                const double xa[4] = {xo[(rho + 3) & 3], xB, xo[rho & 3], hi ? x.t[mu][r] : 0.0};
+                const double xb[4] = {xA, r + 2 < 4 ? x.t[mt][(r + 2) & 3] : 0.0, xo[(rho + 1) & 3], hi ? x.t[mu][r + 1] : 0.0};
                 constexpr int G = diag ? 6 : 2;
                 if (rho == 0)
-                    t4_couple<0, rt, mtm, G>(cur, c, xrm, xrp, xmm, xmp, false, mt + 1 < NT);
+                    t4_couple_pair<0, rt, mtm, G>(curA, curB, c, xa, xb, false, hi);
+                else if (pr == 0)
+                    t4_couple_pair<0, rt, mtm, 2>(curA, curB, c, xa, xb, mt > 0, hi);
                 else
-                    switch (r) {
-                    case 0: t4_couple<0, rt, mtm, 2>(cur, c, xrm, xrp, xmm, xmp, mt > 0, mt + 1 < NT); break;
-                    case 1: t4_couple<1, rt, mtm, 2>(cur, c, xrm, xrp, xmm, xmp, mt > 0, mt + 1 < NT); break;
-                    case 2: t4_couple<2, rt, mtm, 2>(cur, c, xrm, xrp, xmm, xmp, mt > 0, mt + 1 < NT); break;
-                    default: t4_couple<3, rt, mtm, 2>(cur, c, xrm, xrp, xmm, xmp, mt > 0, mt + 1 < NT); break;
-                    }
+                    t4_couple_pair<2, rt, mtm, 2>(curA, curB, c, xa, xb, mt > 0, hi);
             }
-            D.t[mt][r] = cur;
-            xo[rho & 3] = xc;
+            D.t[mt][r] = curA;
+            D.t[mt][r + 1] = curB;
+            xo[rho & 3] = xA;
+            xo[(rho + 1) & 3] = xB;
             __builtin_amdgcn_sched_barrier(0);   // keep the prefetch FIFOs in order (hipcc otherwise hoists every load -> spills)
         }
     }
