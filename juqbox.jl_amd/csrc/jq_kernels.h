@@ -48,6 +48,16 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // (24 x 16 = 384 cycles at Ntot = 96 instead of 24 x 64) and at most four v_fma_f64 per group for the couplings to the
 // groups rho-1, rho+1 (same 16-row block) and rho-4, rho+4 (neighbouring blocks), mm_t4.
 #define JQ_BW_T4 8
+// BW == JQ_BW_T4Q: the same operators, images and staging as JQ_BW_T4 in the QUAD layout for small batches: one wave carries
+// four state columns, a register of a state array is a whole 16-row block (lane 16 i + 4 b + j <-> row 16 mt + 4 b + i,
+// column j), an Ntot = 96 array is 6 registers (everything stays in VGPRs), ONE v_mfma_f64_4x4x4_4b does the four 4x4
+// diagonal blocks of a 16-row block, the couplings (i, i+-4) read the same register shifted by 4 lanes inside each 16-lane
+// row (2 x v_mov_b32_dpp row_shr/row_shl -- 64-bit DPP only has row_newbcast) and the couplings (i, i+-16) the
+// neighbouring register.  A product takes 209 ns per wave (probes/t4q_probe.hip) where the cooperative kernels need 656
+// (one barrier + LDS exchange per product); per column it is slower than JQ_BW_T4 (590 vs 486 ns per 16 columns), so
+// large batches stay there.  The four waves of a workgroup share ONE slab of the JQ_BW_T4 state file (wave q = columns
+// 4q .. 4q+3): array file, initial / terminal kernels, column tables and operator images are those of the slab kernels.
+#define JQ_BW_T4Q 7
 #define JQ_T4_TILE 16                  // doubles per 4-row group in the image: the 4x4 diagonal block [k][i] (the MFMA's A operand
                                       // repeats it in its four column blocks: lane 16k+4b+i reads element 4k+i, an LDS broadcast)
 #define JQ_T4_COEFS(NT) (64 * (NT))   // doubles after the 4NT blocks: [mt][g = lane>>4][r][term: r-1, r+1, mt-1, mt+1]
@@ -61,7 +71,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // diagonal": operators like a3 +- a3' of the slowest subsystem, whose diagonal blocks vanish), mt != kb.
 __host__ __device__ constexpr bool block_on(int BW, bool SD, int mt, int kb)
 {
-    return (BW == JQ_BW_OD || BW == JQ_BW_T4) ? (mt == kb && !SD) : ((mt - kb <= BW) && (kb - mt <= BW) && !(SD && mt == kb));
+    return (BW == JQ_BW_OD || BW == JQ_BW_T4 || BW == JQ_BW_T4Q) ? (mt == kb && !SD) : ((mt - kb <= BW) && (kb - mt <= BW) && !(SD && mt == kb));
 }
 // number of stored tiles (host + device)
 __host__ __device__ constexpr int band_tiles(int NT, int BW, bool SD = false)
@@ -99,11 +109,38 @@ __device__ __forceinline__ s4 operator-(const s4& a, const s4& b) { return s4((d
 __device__ __forceinline__ s4 operator*(const s4& a, const s4& b) { return s4((d4){a.e[0] * b.e[0], a.e[1] * b.e[1], a.e[2] * b.e[2], a.e[3] * b.e[3]}); }
 __device__ __forceinline__ s4 operator*(double c, const s4& b) { return s4((d4){c * b.e[0], c * b.e[1], c * b.e[2], c * b.e[3]}); }
 __device__ __forceinline__ s4 operator-(const s4& a) { return s4((d4){-a.e[0], -a.e[1], -a.e[2], -a.e[3]}); }
+// One double per 16-row block: the JQ_BW_T4Q ("quad") kernels, whose lanes are (row in group, group, column of a quad).
+struct s1 {
+    double e[1];
+    __device__ __forceinline__ s1() = default;
+    __device__ __forceinline__ s1(d4 v) : e{v[0]} {}
+    __device__ __forceinline__ explicit s1(double v) : e{v} {}
+    __device__ __forceinline__ double& operator[](int i) { return e[0]; }
+    __device__ __forceinline__ double operator[](int i) const { return e[0]; }
+    __device__ __forceinline__ s1& operator+=(const s1& o)
+    {
+        e[0] += o.e[0];
+        return *this;
+    }
+};
+__device__ __forceinline__ s1 operator+(const s1& a, const s1& b) { return s1(a.e[0] + b.e[0]); }
+__device__ __forceinline__ s1 operator-(const s1& a, const s1& b) { return s1(a.e[0] - b.e[0]); }
+__device__ __forceinline__ s1 operator*(const s1& a, const s1& b) { return s1(a.e[0] * b.e[0]); }
+__device__ __forceinline__ s1 operator*(double c, const s1& b) { return s1(c * b.e[0]); }
+__device__ __forceinline__ s1 operator-(const s1& a) { return s1(-a.e[0]); }
+__device__ __forceinline__ double row_sum(const d4& p) { return (p[0] + p[1]) + (p[2] + p[3]); }
+__device__ __forceinline__ double row_sum(const s4& p) { return (p[0] + p[1]) + (p[2] + p[3]); }
+__device__ __forceinline__ double row_sum(const s1& p) { return p[0]; }
 // row type of the state arrays of this translation unit (one (NT, BW) instantiation per unit, jq_kernel_inst.hip)
-#if defined(JQ_BW) && JQ_BW == 8 && !defined(JQ_ROW_D4)
+#if defined(JQ_BW) && JQ_BW == 7
+typedef s1 jq_row;
+#define JQ_RL 1               // doubles per row element of an array
+#elif defined(JQ_BW) && JQ_BW == 8 && !defined(JQ_ROW_D4)
 typedef s4 jq_row;
+#define JQ_RL 4
 #else
 typedef d4 jq_row;
+#define JQ_RL 4
 #endif
 
 template <int NT>
@@ -141,19 +178,24 @@ __device__ __forceinline__ double a_dot(const Arr<NT>& x, const Arr<NT>& y)
     double s = 0.0;
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-        const auto p = x.t[i] * y.t[i];
-        s += (p[0] + p[1]) + (p[2] + p[3]);
+        s += row_sum(x.t[i] * y.t[i]);
     }
     return s;
 }
 // y += c * tab .* x   (tab: per-row table in LDS, padded to 16*NT rows, stored [block][g][r] so that the four
-// values of a lane are one 32-byte read; g = lane>>4).
+// values of a lane are one 32-byte read; g = lane>>4).  Quad layout (JQ_RL == 1): g = this lane's offset in a block of the
+// table, 4 * (lane >> 4) + ((lane >> 2) & 3).
 template <int NT>
 __device__ __forceinline__ void a_axpy_rows(Arr<NT>& y, double c, const double* tab, int g, const Arr<NT>& x)
 {
+#if JQ_RL == 1
+#pragma unroll
+    for (int i = 0; i < NT; ++i) y.t[i][0] = fma(c * tab[16 * i + g], x.t[i][0], y.t[i][0]);
+#else
     const d4* t4 = (const d4*)(tab + 4 * g);
 #pragma unroll
     for (int i = 0; i < NT; ++i) y.t[i] += jq_row(c * t4[4 * i]) * x.t[i];
+#endif
 }
 // sum_rows tab[row] * x[row]^2
 template <int NT>
@@ -163,18 +205,19 @@ __device__ __forceinline__ double a_wsq(const double* tab, int g, const Arr<NT>&
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s += tab[16 * i + 4 * g + r] * (x.t[i][r] * x.t[i][r]);
+        for (int r = 0; r < JQ_RL; ++r) s += tab[16 * i + (JQ_RL == 1 ? g : 4 * g + r)] * (x.t[i][r] * x.t[i][r]);
     return s;
 }
 
-// image <-> registers: array image = [4*NT][64] doubles, element kk*64 + lane
+// image <-> registers: array image = [4*NT][64] doubles, element kk*64 + lane  (quad layout: `lane` is this lane's offset
+// in a block of the slab image, ((lane >> 2) & 3) * 64 + 16 * (lane >> 4) + first column of the quad + (lane & 3))
 template <int NT>
 __device__ __forceinline__ void a_load(Arr<NT>& a, const double* __restrict__ img, int lane)
 {
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a.t[i][r] = img[(4 * i + r) * 64 + lane];
+        for (int r = 0; r < JQ_RL; ++r) a.t[i][r] = img[(4 * i + r) * 64 + lane];
 }
 template <int NT>
 __device__ __forceinline__ void a_store(const Arr<NT>& a, double* __restrict__ img, int lane)
@@ -182,7 +225,7 @@ __device__ __forceinline__ void a_store(const Arr<NT>& a, double* __restrict__ i
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) img[(4 * i + r) * 64 + lane] = a.t[i][r];
+        for (int r = 0; r < JQ_RL; ++r) img[(4 * i + r) * 64 + lane] = a.t[i][r];
 }
 
 // D = C + M * x over the stored (band) tiles (D may alias C; D must not alias x).
@@ -444,6 +487,58 @@ __device__ __forceinline__ void mm_t4(Arr<NT>& D, const Arr<NT>& C, const double
     }
 }
 
+// x shifted by 4 lanes inside each row of 16 lanes (CTRL 0x114: lane n <- n - 4, 0x104: lane n <- n + 4; zeros shifted in)
+template <int CTRL>
+__device__ __forceinline__ double row_shift4(double x)
+{
+    union {
+        double d;
+        int i[2];
+    } a, b;
+    a.d = x;
+    b.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], CTRL, 0xf, 0xf, true);
+    b.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], CTRL, 0xf, 0xf, true);
+    return b.d;
+}
+// BW == JQ_BW_T4Q (see the definition above): D = C + M x on the JQ_BW_T4 image.  Alias-safe (D may be C and/or x).
+template <int NT, bool ZEROC, int MODE>
+__device__ __forceinline__ void mm_t4q(Arr<NT>& D, const Arr<NT>& C, const double* mat, const Arr<NT>& x)
+{
+    constexpr bool diag = MODE & JQ_T4_DIAG, rt = MODE & JQ_T4_RTERMS, mtm = MODE & JQ_T4_MTERMS;
+    const int lane = threadIdx.x & 63;
+    // A operand: lane 16 k + 4 b + i holds B_{4 mt + b}[i][k] = element 16 b + 4 k + i of the block's 64 doubles;
+    // coefficients [mt][g = row in group][r = group][term] of this lane's row: four consecutive doubles
+    const double* ma = mat - lane + (((lane >> 2) & 3) * 16 + (lane >> 4) * 4 + (lane & 3));
+    const d4* cf = (const d4*)(mat - lane + 4 * NT * JQ_T4_TILE + (lane >> 4) * 16 + ((lane >> 2) & 3) * 4);
+    double a_cur = 0.0;
+    d4 c_cur = {0.0, 0.0, 0.0, 0.0};
+    if constexpr (diag) a_cur = ma[0];
+    if constexpr (rt || mtm) c_cur = cf[0];
+    double xold = 0.0;
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) {
+        const double a = a_cur;
+        const d4 c = c_cur;
+        if (mt + 1 < NT) {
+            if constexpr (diag) a_cur = ma[(mt + 1) * 64];
+            if constexpr (rt || mtm) c_cur = cf[(mt + 1) * 16];
+        }
+        const double xc = x.t[mt][0];
+        double acc = ZEROC ? 0.0 : C.t[mt][0];
+        if constexpr (diag) acc = __builtin_amdgcn_mfma_f64_4x4x4f64(a, xc, acc, 0, 0, 0);
+        if constexpr (rt) {
+            acc = fma(c[0], row_shift4<0x114>(xc), acc);
+            acc = fma(c[1], row_shift4<0x104>(xc), acc);
+        }
+        if constexpr (mtm) {
+            if (mt > 0) acc = fma(c[2], xold, acc);
+            if (mt + 1 < NT) acc = fma(c[3], x.t[mt + 1 < NT ? mt + 1 : mt][0], acc);
+        }
+        xold = xc;
+        D.t[mt][0] = acc;
+    }
+}
+
 template <int NT, int BW, bool ZEROC, bool SD = false>
 __device__ __forceinline__ void mm_band(Arr<NT>& D, const Arr<NT>& C, const double* mat, const Arr<NT>& x);
 template <int NT, int BW, bool ZEROC, bool SD = false>
@@ -451,6 +546,8 @@ __device__ __forceinline__ void mm_any(Arr<NT>& D, const Arr<NT>& C, const doubl
 {
     if constexpr (BW == JQ_BW_T4)
         mm_t4<NT, ZEROC, JQ_T4_DIAG | JQ_T4_RTERMS | JQ_T4_MTERMS>(D, C, mat, x);
+    else if constexpr (BW == JQ_BW_T4Q)
+        mm_t4q<NT, ZEROC, JQ_T4_DIAG | JQ_T4_RTERMS | JQ_T4_MTERMS>(D, C, mat, x);
     else if constexpr (BW == JQ_BW_OD)
         mm_od<NT, ZEROC, SD>(D, C, mat, x);
     else
@@ -511,6 +608,13 @@ __device__ __forceinline__ void mm_z_bw(Arr<NT>& D, const double* mat, const Arr
         case JQ_T4_RTERMS: mm_t4<NT, true, JQ_T4_RTERMS>(D, D, mat, x); break;
         case JQ_T4_MTERMS: mm_t4<NT, true, JQ_T4_MTERMS>(D, D, mat, x); break;
         default: mm_t4<NT, true, JQ_T4_DIAG | JQ_T4_RTERMS | JQ_T4_MTERMS>(D, D, mat, x); break;
+        }
+    } else if constexpr (BW == JQ_BW_T4Q) {
+        switch (mode) {
+        case JQ_T4_DIAG: mm_t4q<NT, true, JQ_T4_DIAG>(D, D, mat, x); break;
+        case JQ_T4_RTERMS: mm_t4q<NT, true, JQ_T4_RTERMS>(D, D, mat, x); break;
+        case JQ_T4_MTERMS: mm_t4q<NT, true, JQ_T4_MTERMS>(D, D, mat, x); break;
+        default: mm_t4q<NT, true, JQ_T4_DIAG | JQ_T4_RTERMS | JQ_T4_MTERMS>(D, D, mat, x); break;
         }
     } else {
         if (BW > 0 && mode == 0)
@@ -609,18 +713,18 @@ __host__ __device__ inline void sched_pack(unsigned long long* words, int i, int
 }
 
 // usaver[:,:,step+1] = vr ; usavei = -vi (src/evalobjgrad.jl:748-752); only sample 0 (slab 0, columns < N)
+// (col: state column of this lane; g: its row in a 4-row group -- quad layout: its row in a 16-row block)
 template <int NT>
-__device__ __forceinline__ void hist_store(const PropArgs& a, int slab, int lane, int g, int n, const Arr<NT>& u,
+__device__ __forceinline__ void hist_store(const PropArgs& a, int slab, int col, int g, int n, const Arr<NT>& u,
                                            const Arr<NT>& v)
 {
-    const int col = lane & 15;
     if (slab == 0 && col < a.N) {
         const size_t off = (size_t)(a.step0 + n + 1) * a.Ntot * a.N + (size_t)col * a.Ntot;
 #pragma unroll
         for (int i = 0; i < NT; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * i + 4 * r + g;
+            for (int r = 0; r < JQ_RL; ++r) {
+                const int row = 16 * i + (JQ_RL == 1 ? 0 : 4 * r) + g;
                 if (row < a.Ntot) {
                     a.hist_r[off + row] = u.t[i][r];
                     a.hist_i[off + row] = -v.t[i][r];
@@ -913,8 +1017,7 @@ __device__ __forceinline__ double a_diff2(const Arr<NT>& x, const Arr<NT>& y)
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         const auto d = x.t[i] - y.t[i];
-        const auto p = d * d;
-        s += (p[0] + p[1]) + (p[2] + p[3]);
+        s += row_sum(d * d);
     }
     return s;
 }
@@ -969,7 +1072,7 @@ __device__ __forceinline__ void horner_add(Arr<NT>& out, const Arr<NT>& bpa, con
     }
     mm_c<NT, BW>(Ya, A, S, A);  // Y1 = A + S A
     --rem;
-    if constexpr (BW == JQ_BW_OD || BW == JQ_BW_T4) {
+    if constexpr (BW == JQ_BW_OD || BW == JQ_BW_T4 || BW == JQ_BW_T4Q) {
         // mm_od / mm_t4 are alias-safe: the recurrence runs in place and Yb is never touched (48 registers less)
         for (; rem > 0; --rem) mm_c<NT, BW>(Ya, A, S, Ya);
         mm_c<NT, BW>(out, bpa, S, Ya);
@@ -995,7 +1098,7 @@ __device__ __forceinline__ void a_park(const Arr<NT>& a, double* park)
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) park[(4 * i + r) * 64] = a.t[i][r];
+        for (int r = 0; r < JQ_RL; ++r) park[(4 * i + r) * 64] = a.t[i][r];
 }
 template <int NT>
 __device__ __forceinline__ void a_unpark(Arr<NT>& a, const double* park)
@@ -1003,7 +1106,7 @@ __device__ __forceinline__ void a_unpark(Arr<NT>& a, const double* park)
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a.t[i][r] = park[(4 * i + r) * 64];
+        for (int r = 0; r < JQ_RL; ++r) a.t[i][r] = park[(4 * i + r) * 64];
 }
 
 // State (re-)integration, operator uses 0..5 of one Stormer-Verlet step (forward step!,
@@ -1063,10 +1166,16 @@ __global__ __launch_bounds__(256, MINW) void k_forward(PropArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KT = 4 * NT;
-    const int lane = threadIdx.x & 63;
+    const int lane_ = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int g = lane >> 4;
-    const int slab = blockIdx.x * JQ_WAVES + wave;
+    // slab layout: one slab per wave, lane = 16 g + column.  Quad layout (JQ_BW_T4Q): the workgroup's four waves share one
+    // slab, wave q carries its columns 4q .. 4q+3; `lane` / `g` are then this lane's offsets in a block of the slab image / of
+    // the row tables (a_load, a_axpy_rows) and `col` its state column
+    constexpr bool QUAD = (BW == JQ_BW_T4Q);
+    const int col = QUAD ? 4 * wave + (lane_ & 3) : (lane_ & 15);
+    const int lane = QUAD ? ((lane_ >> 2) & 3) * 64 + 16 * (lane_ >> 4) + col : lane_;
+    const int g = QUAD ? 4 * (lane_ >> 4) + ((lane_ >> 2) & 3) : lane_ >> 4;
+    const int slab = QUAD ? (int)blockIdx.x : blockIdx.x * JQ_WAVES + wave;
     const bool active = slab < a.nslabs;
 
     double* tab = (double*)(smem + a.lds_tab_off);
@@ -1080,14 +1189,16 @@ __global__ __launch_bounds__(256, MINW) void k_forward(PropArgs a)
     if (active) {
         a_load(ua, st, lane);
         a_load(va, st + KT * 64, lane);
-        leak = st[(JQ_STATE_ARRAYS * KT + JQ_MAXNC) * 64 + lane];
-        ceps = 0.5 * a.h * a.colinfo[(size_t)slab * 32 + (lane & 15)];
+        // per-lane partial of the leak integral: the slab image has one slot per (row in group, column); in the quad layout the
+        // lanes of group 0 carry it between chunks
+        leak = (!QUAD || ((lane_ >> 2) & 3) == 0) ? st[(JQ_STATE_ARRAYS * KT + JQ_MAXNC) * 64 + (QUAD ? 16 * (lane_ >> 4) + col : lane)] : 0.0;
+        ceps = 0.5 * a.h * a.colinfo[(size_t)slab * 32 + col];
     } else {
         a_zero(ua);
         a_zero(va);
     }
     Ring p;
-    p.init(smem, a, wave, lane);
+    p.init(smem, a, wave, lane_);
 
     // one time step: (u, v) -> (unew, vN); v is consumed (becomes v05).  The two array pairs swap
     // roles every step, so the loop body is written for two steps and nothing is ever copied.
@@ -1103,7 +1214,7 @@ __global__ __launch_bounds__(256, MINW) void k_forward(PropArgs a)
             if (a.use_shift) a_axpy_rows(VN, ceps, ws, g, UN);                                                   \
             /* leak integrand: tr(vr' W vr + 2 vi05' W vi05) after the step (:716, penalf2a :2170-2180) */       \
             leak += a_wsq(wd, g, UN) + 2.0 * a_wsq(wd, g, V);                                                    \
-            if (a.hist_r) hist_store<NT>(a, slab, lane, g, NSTEP, UN, VN);                                       \
+            if (a.hist_r) hist_store<NT>(a, slab, col, QUAD ? 4 * ((lane_ >> 2) & 3) + (lane_ >> 4) : g, NSTEP, UN, VN); \
         }                                                                                                        \
     }
     int n = 0;
@@ -1123,7 +1234,12 @@ __global__ __launch_bounds__(256, MINW) void k_forward(PropArgs a)
     if (active) {
         a_store(ua, st, lane);
         a_store(va, st + KT * 64, lane);
-        st[(JQ_STATE_ARRAYS * KT + JQ_MAXNC) * 64 + lane] = leak;
+        if constexpr (QUAD) {
+            leak = row_ror_add<8>(row_ror_add<4>(leak));   // sum over the four groups of a block (lanes 4 b + j of a row)
+            if (((lane_ >> 2) & 3) == 0) st[(JQ_STATE_ARRAYS * KT + JQ_MAXNC) * 64 + 16 * (lane_ >> 4) + col] = leak;
+        } else {
+            st[(JQ_STATE_ARRAYS * KT + JQ_MAXNC) * 64 + lane] = leak;
+        }
     }
 }
 
@@ -1142,12 +1258,20 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KT = 4 * NT;
-    const int lane = threadIdx.x & 63;
+    const int lane_ = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int g = lane >> 4;
-    const int slab = blockIdx.x * JQ_WAVES + wave;
+    // (slab / quad layout: see k_forward)
+    constexpr bool QUAD = (BW == JQ_BW_T4Q);
+    const int col = QUAD ? 4 * wave + (lane_ & 3) : (lane_ & 15);
+    const int lane = QUAD ? ((lane_ >> 2) & 3) * 64 + 16 * (lane_ >> 4) + col : lane_;
+    const int g = QUAD ? 4 * (lane_ >> 4) + ((lane_ >> 2) & 3) : lane_ >> 4;
+    const int slab = QUAD ? (int)blockIdx.x : blockIdx.x * JQ_WAVES + wave;
+    const int trow = QUAD ? slab * JQ_WAVES + wave : slab;   // row of this wave in the per-step trace records
     const bool active = slab < a.nslabs;
     const int Nc = a.Ncoupled;
+    // per-lane trace carries in the array file: like the leak partial of k_forward
+    const bool cslot = !QUAD || ((lane_ >> 2) & 3) == 0;
+    const int clane = QUAD ? 16 * (lane_ >> 4) + col : lane_;
 
     double* tab = (double*)(smem + a.lds_tab_off);
     const double* wd = tab;
@@ -1156,7 +1280,7 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
     for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[(i & ~15) + 4 * (i & 3) + ((i >> 2) & 3)] = a.tabs[i];   // [block][g][r]
     double* st = a.state + (size_t)(active ? slab : 0) * a.state_stride;
     // parking image of this wave: in LDS when it fits, else in HBM
-    double* P0 = a.park_lds ? (carry + JQ_MAXNC * 256 + (size_t)wave * KT * 64 + lane)
+    double* P0 = a.park_lds ? (carry + JQ_MAXNC * 256 + (size_t)wave * KT * 64 + lane_)
                             : (a.park + (size_t)(active ? slab : 0) * KT * 64 + lane);
 
     // array roles (register arrays are renamed, never copied, except at the end of a step):
@@ -1173,9 +1297,9 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
         a_load(v, st + KT * 64, lane);
         a_load(mu, st + 2 * KT * 64, lane);
         a_load(nb, st + 3 * KT * 64, lane);
-        ceps = 0.5 * a.h * a.colinfo[(size_t)slab * 32 + (lane & 15)];
-        wgt = a.colinfo[(size_t)slab * 32 + 16 + (lane & 15)];
-        for (int q = 0; q < Nc; ++q) carry[q * 256 + threadIdx.x] = st[(JQ_STATE_ARRAYS * KT + q) * 64 + lane];
+        ceps = 0.5 * a.h * a.colinfo[(size_t)slab * 32 + col];
+        wgt = a.colinfo[(size_t)slab * 32 + 16 + col];
+        for (int q = 0; q < Nc; ++q) carry[q * 256 + threadIdx.x] = cslot ? st[(JQ_STATE_ARRAYS * KT + q) * 64 + clane] : 0.0;
     } else {
         a_zero(u);
         a_zero(v);
@@ -1186,7 +1310,7 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
     const double cfw = a.forced ? 0.5 * a.h * a.tinv : 0.0;
 
     Ring p;
-    p.init(smem, a, wave, lane);
+    p.init(smem, a, wave, lane_);
 
     if (a.first_chunk) {
         // carry_q = tr(vr' Hsym_q lambdai) at t = T: the "vr0/lambdai0" term of the first backward
@@ -1232,8 +1356,8 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
                 mm_z_bw<NT, BW>(Ya, M, mu, a.bw_trace[q]);
                 const double t1 = (a.debug & 1) ? a_dot(u, Ya) : wave_sum(a_dot(u, Ya) * wgt);
                 const double t3 = (a.debug & 1) ? a_dot(un, Ya) : wave_sum(a_dot(un, Ya) * wgt);
-                if (lane == 0) {
-                    double* tr = a.traces + ((size_t)slab * a.nsteps_chunk + n) * (Nc * JQ_NTR) + q * JQ_NTR;
+                if (lane_ == 0) {
+                    double* tr = a.traces + ((size_t)trow * a.nsteps_chunk + n) * (Nc * JQ_NTR) + q * JQ_NTR;
                     tr[0] = t1;
                     tr[2] = t3;
                 }
@@ -1301,8 +1425,8 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
                     t4 = wave_sum(t4 * wgt);
                     t5 = wave_sum(t5 * wgt);
                 }
-                if (lane == 0) {
-                    double* tr = a.traces + ((size_t)slab * a.nsteps_chunk + n) * (Nc * JQ_NTR) + q * JQ_NTR;
+                if (lane_ == 0) {
+                    double* tr = a.traces + ((size_t)trow * a.nsteps_chunk + n) * (Nc * JQ_NTR) + q * JQ_NTR;
                     tr[1] = t2;
                     tr[3] = t4;
                     tr[4] = t5;
@@ -1323,6 +1447,10 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
         a_store(v, st + KT * 64, lane);
         a_store(mu, st + 2 * KT * 64, lane);
         a_store(nb, st + 3 * KT * 64, lane);
-        for (int q = 0; q < Nc; ++q) st[(JQ_STATE_ARRAYS * KT + q) * 64 + lane] = carry[q * 256 + threadIdx.x];
+        for (int q = 0; q < Nc; ++q) {
+            double cv = carry[q * 256 + threadIdx.x];
+            if constexpr (QUAD) cv = row_ror_add<8>(row_ror_add<4>(cv));   // only ever used summed over the rows of a column
+            if (cslot) st[(JQ_STATE_ARRAYS * KT + q) * 64 + clane] = cv;
+        }
     }
 }

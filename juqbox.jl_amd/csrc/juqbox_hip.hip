@@ -776,6 +776,25 @@ static int select_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
     return fail(h, JQ_EUNSUPPORTED, "unsupported Hilbert dimension / band width");
 }
 
+// quad-layout kernels of the JQ_BW_T4 structure (jq_kernels.h JQ_BW_T4Q): small batches, Neumann solver
+#define JQ_DECLQ(nt)                                                                               \
+    extern template __global__ void k_forward<nt, JQ_BW_T4Q, JQ_MINW_OF(nt), false>(PropArgs);      \
+    extern template __global__ void k_backward<nt, JQ_BW_T4Q, JQ_MINW_OF(nt), false>(PropArgs);
+JQ_DECLQ(1) JQ_DECLQ(2) JQ_DECLQ(3) JQ_DECLQ(4) JQ_DECLQ(5) JQ_DECLQ(6)
+#undef JQ_DECLQ
+static int select_quad_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
+{
+#define JQ_PICKQ(nt)                                                       \
+    if (h->NT == nt) {                                                     \
+        *fwd = k_forward<nt, JQ_BW_T4Q, JQ_MINW_OF(nt), false>;            \
+        *bwd = k_backward<nt, JQ_BW_T4Q, JQ_MINW_OF(nt), false>;           \
+        return JQ_OK;                                                      \
+    }
+    JQ_PICKQ(1) JQ_PICKQ(2) JQ_PICKQ(3) JQ_PICKQ(4) JQ_PICKQ(5) JQ_PICKQ(6)
+#undef JQ_PICKQ
+    return fail(h, JQ_EUNSUPPORTED, "unsupported Hilbert dimension");
+}
+
 #define JQ_DECLC(nt, bw)                                                   \
     extern template __global__ void k_forward_coop<nt, bw>(PropArgs);       \
     extern template __global__ void k_backward_coop<nt, bw>(PropArgs);
@@ -929,7 +948,12 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     const bool lane = !rl && h->lane_np > 0 && h->solver_id == 1 && ncols_used >= h->lane_min_cols && ncols_used <= h->lane_max_cols;
     const long long nwaves_rl = (ncols_used + cpw - 1) / cpw;
     const long long ncols = rl ? 4 * nwaves_rl : (ncols_used + 63) / 64 * 64;      // row-lane: column SLOTS (4 per wave)
-    const bool coop = imr_coop || (!lane && !rl && h->mat_elems_c > 0 && h->solver_id == 1 && nslabs <= h->coop_max_slabs);
+    // JQ_BW_T4 structure, small batches: the quad-layout kernels (one workgroup per slab, its four waves carry four columns
+    // each; 3 x shorter dependent chain than the cooperative kernels).  JQ_QUAD=0 disables them.
+    bool quad = !imr && !lane && !rl && h->BW == JQ_BW_T4 && h->batch < 0 && h->solver_id == 1 && nslabs <= h->coop_max_slabs;
+    if (const char* e = getenv("JQ_QUAD"))
+        if (atoi(e) == 0) quad = false;
+    const bool coop = imr_coop || (!quad && !lane && !rl && h->mat_elems_c > 0 && h->solver_id == 1 && nslabs <= h->coop_max_slabs);
     prop_kernel_t kfwd, kbwd;
     lane_init_t klinit = nullptr;
     lane_term_t klterm = nullptr;
@@ -937,11 +961,11 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
              : imr_rl ? select_rowlane_imr_kernels(h, &kfwd, &kbwd)
              : rl ? select_rowlane_kernels(h, &kfwd, &kbwd)
              : lane ? select_lane_kernels(h, &kfwd, &kbwd, &klinit, &klterm)
-                  : coop ? select_coop_kernels(h, &kfwd, &kbwd) : select_kernels(h, &kfwd, &kbwd);
+                  : coop ? select_coop_kernels(h, &kfwd, &kbwd) : quad ? select_quad_kernels(h, &kfwd, &kbwd) : select_kernels(h, &kfwd, &kbwd);
     if (rc) return rc;
-    const int nblocks = rl ? (int)nwaves_rl : lane ? (int)(ncols / 64) : coop ? nslabs : (nslabs + JQ_WAVES - 1) / JQ_WAVES;
+    const int nblocks = rl ? (int)nwaves_rl : lane ? (int)(ncols / 64) : (coop || quad) ? nslabs : (nslabs + JQ_WAVES - 1) / JQ_WAVES;
     const int nthreads = (lane || rl) ? 64 : coop ? 64 * h->NT : 256;
-    const int trace_rows = (lane || rl) ? nblocks : coop ? nslabs * h->NT : nslabs;   // per-step trace records: one per wave
+    const int trace_rows = (lane || rl) ? nblocks : coop ? nslabs * h->NT : quad ? nslabs * JQ_WAVES : nslabs;   // per-step trace records: one per wave
     const long long stride = rl ? h->rl_stride : lane ? h->lane_stride : coop ? h->mat_elems_c : h->mat_elems;
     const double* himg = rl ? h->d_himg_r : lane ? h->d_himg_l : coop ? h->d_himg_c : h->d_himg;
     const size_t state_doubles = rl ? (size_t)JQ_ROWLANE_ROWS * nwaves_rl * 64
@@ -1206,9 +1230,9 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     // (JQ_BW_T4: one v_mfma_f64_4x4x4_4b is 512 FLOP, a quarter of the 16x16x4 instruction this counter is quoted in)
     h->timing.mfma_executed = imr ? 0 : (!coop && !lane && !rl && h->BW == JQ_BW_T4) ? mfma / 4 : mfma;   // (the iteration counts of the implicit-midpoint solver are data dependent)
     h->timing.svts = (long long)nsamples * h->N * h->nsteps;
-    h->timing.kernel_family = imr_coop ? 5 : imr ? 4 : rl ? 3 : lane ? 2 : coop ? 1 : 0;
+    h->timing.kernel_family = imr_coop ? 5 : imr ? 4 : rl ? 3 : lane ? 2 : coop ? 1 : quad ? 6 : 0;
     h->timing.kernel_size = rl ? h->rl_npj : lane ? h->lane_np : h->NT;
-    h->timing.kernel_band = (rl || lane) ? 0 : coop ? h->BWc : h->BW;
+    h->timing.kernel_band = (rl || lane) ? 0 : coop ? h->BWc : quad ? JQ_BW_T4Q : h->BW;
     h->timing.reserved = 0;
     return JQ_OK;
 }
