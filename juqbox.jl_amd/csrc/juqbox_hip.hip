@@ -48,7 +48,8 @@ struct jq_handle {
     int nslots = 2;             // LDS ring depth of the forward kernel
     int nslots_bwd = 2;         // ... of the backward kernel (shares LDS with carry + parking images)
     int park_lds = 0;           // backward kernel parks its dormant array in LDS (1) or HBM (0)
-    int batch = 0;              // > 0: batched staging (K/S images of `batch` time steps per DMA burst)
+    int batch = 0;              // > 0: batched staging (K/S images of `batch` time steps per DMA burst); < 0: window staging
+    int quad_max_slabs = 0;     // JQ_BW_T4 structure: batches of at most this many slabs use the quad-layout kernels (0: never)
     int lane_np = 0;            // > 0: lane kernels available (Ntot <= 12), padded Hilbert dimension NP
     long long lane_stride = 0;  // doubles per plain NP x NP operator image (padded to 64 B)
     int lane_min_cols = 0, lane_max_cols = 0;   // column counts (samples x N) routed to the lane kernels
@@ -523,6 +524,12 @@ static int create_impl(const jq_problem* p, jq_handle* h)
                 h->park_lds = 1;
             }
         }
+        // Quad-layout kernels (jq_kernels.h JQ_BW_T4Q) for small batches of this structure: one workgroup per slab and one
+        // workgroup per CU (LDS), i.e. rounds of #CU slabs at 0.37 of the slab kernels' time for 4 #CU slabs -> up to two
+        // rounds.  JQ_QUAD=0 disables them, JQ_QUAD=<n> sets the limit.
+        h->quad_max_slabs = (h->BW == JQ_BW_T4 && h->batch < 0) ? 2 * prop.multiProcessorCount : 0;
+        if (const char* e = getenv("JQ_QUAD"))
+            if (h->quad_max_slabs > 0) h->quad_max_slabs = atoi(e);
         if (const char* e = getenv("JQ_BATCH")) {
             const int v = atoi(e);
             if (v >= 2 && slot <= 8192) {
@@ -950,9 +957,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     const long long ncols = rl ? 4 * nwaves_rl : (ncols_used + 63) / 64 * 64;      // row-lane: column SLOTS (4 per wave)
     // JQ_BW_T4 structure, small batches: the quad-layout kernels (one workgroup per slab, its four waves carry four columns
     // each; 3 x shorter dependent chain than the cooperative kernels).  JQ_QUAD=0 disables them.
-    bool quad = !imr && !lane && !rl && h->BW == JQ_BW_T4 && h->batch < 0 && h->solver_id == 1 && nslabs <= h->coop_max_slabs;
-    if (const char* e = getenv("JQ_QUAD"))
-        if (atoi(e) == 0) quad = false;
+    const bool quad = !imr && !lane && !rl && h->solver_id == 1 && nslabs <= h->quad_max_slabs;
     const bool coop = imr_coop || (!quad && !lane && !rl && h->mat_elems_c > 0 && h->solver_id == 1 && nslabs <= h->coop_max_slabs);
     prop_kernel_t kfwd, kbwd;
     lane_init_t klinit = nullptr;

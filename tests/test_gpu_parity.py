@@ -39,16 +39,18 @@ def gpu_eval_like_evalGrad(jq, params, wa, pcof):
     return np.array([objv]), grad
 
 
-@pytest.mark.parametrize("case", ["rabi", "swap02", "flux", "cnot2", "cnot2-leakieq", "cnot2-jacobi", "cnot3", "cnot3:slab", "cnot3:slab-band"])
+@pytest.mark.parametrize("case", ["rabi", "swap02", "flux", "cnot2", "cnot2-leakieq", "cnot2-jacobi", "cnot3", "cnot3:coop", "cnot3:slab", "cnot3:slab-band"])
 def test_reference_golden_through_the_callbacks(hip, case):
-    """All seven Stormer-Verlet goldens of the reference (test/runtests.jl:30).  cnot3 runs three times: on the
-    cooperative kernels (default for a single sample), with JQ_COOP_MAX=0 on the slab kernels (JQ_BW_OD variant:
-    MFMA for the diagonal blocks, VALU for the diagonal off-diagonal blocks) and with JQ_OD=0 on the plain
-    block-band slab kernels."""
+    """All seven Stormer-Verlet goldens of the reference (test/runtests.jl:30).  cnot3 runs four times: on the quad-layout
+    kernels (default for a small batch of this structure), with JQ_QUAD=0 on the cooperative kernels, with JQ_COOP_MAX=0 (and
+    JQ_QUAD=0) on the slab kernels (JQ_BW_T4 variant: v_mfma_f64_4x4x4 for the 4x4 diagonal blocks, DPP FMAs for the diagonal
+    couplings) and with JQ_OD=0 on the plain block-band slab kernels."""
     import os
     jq = hip
     case, _, mode = case.partition(":")
     params, info, pcof, golden = case_inputs(case)
+    if mode:
+        os.environ["JQ_QUAD"] = "0"
     if mode.startswith("slab"):
         os.environ["JQ_COOP_MAX"] = "0"
     if mode == "slab-band":
@@ -58,6 +60,7 @@ def test_reference_golden_through_the_callbacks(hip, case):
     finally:
         os.environ.pop("JQ_COOP_MAX", None)
         os.environ.pop("JQ_OD", None)
+        os.environ.pop("JQ_QUAD", None)
     obj, grad = gpu_eval_like_evalGrad(jq, params, wa, pcof)
     assert reference_pass(obj, golden["obj0"]), (obj, golden["obj0"])
     assert reference_pass(grad, golden["grad0"])

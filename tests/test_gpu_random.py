@@ -124,7 +124,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("mode", ["auto", "slab", "slab-od", "lane", "nolane"])
+@pytest.mark.parametrize("mode", ["auto", "coop", "slab", "slab-od", "lane", "nolane"])
 @pytest.mark.parametrize("cfg", CASES, ids=lambda c: "Ntot%d_N%d_Nc%d_f%d_m%d_o%d_%s_c%d" % (c[0], c[1], c[2], c[3], c[5], c[6], c[7] if isinstance(c[7], str) else ("band" if c[7] else "dense"), c[8]))
 def test_random_problem_matches_oracle(jq, cfg, mode):
     """mode 'auto': Ntot <= 16 runs on the row-lane kernels (one lane per (row, column); small batches), Ntot > 16
@@ -136,6 +136,8 @@ def test_random_problem_matches_oracle(jq, cfg, mode):
     Ntot, N, Nc, Nfreq, nsteps, m, oft, banded, chunk = cfg
     if (mode == "lane" and Ntot > 8) or (mode == "nolane" and Ntot > 16):
         pytest.skip("lane kernels only exist for Ntot <= 8, row-lane kernels for Ntot <= 16")
+    if mode == "coop" and (banded != "t4" or Ntot <= 16):
+        pytest.skip("coop: the JQ_BW_T4 problems (auto: quad-layout kernels) once more on the cooperative kernels (JQ_QUAD=0)")
     if mode == "slab-od" and banded != "t4":
         pytest.skip("slab-od: the JQ_BW_T4 problems once more on the JQ_BW_OD / band kernels (JQ_T4=0)")
     rng = np.random.default_rng(1000 + Ntot * 31 + N)
@@ -145,6 +147,8 @@ def test_random_problem_matches_oracle(jq, cfg, mode):
     if mode in ("slab", "slab-od"):
         os.environ["JQ_COOP_MAX"] = "0"
         os.environ["JQ_LANE"] = "0"
+    if mode in ("slab", "slab-od", "coop"):
+        os.environ["JQ_QUAD"] = "0"
     if mode == "slab-od":
         os.environ["JQ_T4"] = "0"
     if mode == "nolane":
@@ -159,6 +163,7 @@ def test_random_problem_matches_oracle(jq, cfg, mode):
         os.environ.pop("JQ_LANE", None)
         os.environ.pop("JQ_ROWLANE_MAX", None)
         os.environ.pop("JQ_T4", None)
+        os.environ.pop("JQ_QUAD", None)
     r = Oracle(p, use_sparse=False).traceobjgrad(pcof, history=True)
     objfv, tg, prim, sec, tinf, ig, lg = jq.traceobjgrad(pcof, p, wa, False, True)
     gn = np.linalg.norm(r["totalgrad"])
@@ -171,6 +176,10 @@ def test_random_problem_matches_oracle(jq, cfg, mode):
     if banded == "t4" and mode in ("slab", "slab-od"):      # the kernel variant under test really ran
         t = wa.last_timing()
         assert t["kernel_family"] == 0 and (t["kernel_band"] == 8) == (mode == "slab")
+    if banded == "t4" and Ntot > 16 and mode in ("auto", "coop"):
+        # (quad-layout kernels need the window staging: five time points + 2 Nc constant images in LDS; not at Ntot = 96, Nc = 4)
+        fam = wa.last_timing()["kernel_family"]
+        assert fam == (6 if mode == "auto" and (Ntot < 96 or Nc < 4) else 1)
     # per-step states
     _, hist, _ = jq.traceobjgrad(pcof, p, wa, True, False)
     assert np.max(np.abs(hist - r["history"])) < 1e-10
