@@ -24,13 +24,17 @@ def run(n_cases=50, seed=1, verbose=True):
         nsteps = int(rng.integers(3, 24))
         m = int(rng.integers(0, 8))
         oft = int(rng.integers(1, 4))
-        structure = rng.choice([False, True, "od"]) if Ntot > 16 else rng.choice([False, True])
+        structure = rng.choice([False, True, "od", "t4", "t4"]) if Ntot > 16 else rng.choice([False, True, "t4"])
         structure = structure if isinstance(structure, str) else bool(structure)
         imr = bool(rng.random() < 0.3) and ((Ntot <= 16 and N <= 4) or (Ntot > 16 and structure is not False))
         env = {}
         if rng.random() < 0.5:
             env["JQ_CHUNK_STEPS"] = str(int(rng.integers(1, nsteps + 1)))
-        mode = rng.choice(["auto", "JQ_COOP_MAX=0", "JQ_LANE=0", "JQ_ROWLANE_MAX=0", "JQ_OD=0"])
+        mode = rng.choice(["auto", "JQ_COOP_MAX=0", "JQ_LANE=0", "JQ_ROWLANE_MAX=0", "JQ_OD=0", "JQ_QUAD=0", "JQ_WINDOW=0", "JQ_T4=0"])
+        if structure == "t4" and rng.random() < 0.5:      # the JQ_BW_T4 slab kernels instead of the quad-layout / cooperative ones
+            env["JQ_QUAD"] = "0"
+            env["JQ_COOP_MAX"] = "0"
+            env["JQ_LANE"] = "0"
         if imr and mode == "JQ_COOP_MAX=0":
             mode = "auto"           # (the cooperative kernels are the only implicit-midpoint path for Ntot > 16)
         if mode != "auto":

@@ -1,14 +1,12 @@
 #!/bin/bash
 # Everything the judged profile files come from, in one GPU call (run through gpurun):
-#   1. the default bench.py line                                   -> gpurun_out/bench_<tag>.log
-#   2. rocprofv3 --kernel-trace --stats of one bench step           -> gpurun_out/stats_<tag>.txt
-#   3. rocprofv3 --pmc passes of the same command (HBM bytes; SQ)   -> gpurun_out/traffic_<tag>.json
+#   1. rocprofv3 --kernel-trace --stats of one bench step           -> gpurun_out/stats_<tag>.txt
+#   2. rocprofv3 --pmc passes of the same command (HBM bytes; SQ)   -> gpurun_out/traffic_<tag>.json
+#   3. the default bench.py line (quotes 2.)                       -> gpurun_out/bench_<tag>.log
 # usage: scripts/profile_round.sh <tag>          (copy the three files into profiles/ afterwards)
 tag=$1
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-(cd $R && python3 bench.py) > $R/gpurun_out/bench_${tag}.log 2>&1
-tail -1 $R/gpurun_out/bench_${tag}.log | cut -c1-600
 CMD="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline"
 (cd $R && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${tag}/stats -o res -- $CMD) > $R/gpurun_out/prof_${tag}_stats.log 2>&1
 (cd $R && python3 scripts/rocpd_summary.py $(find gpurun_out/prof_${tag}/stats -name "*.db" | head -1) gpurun_out/stats_${tag}.txt; head -6 gpurun_out/stats_${tag}.txt)
@@ -18,4 +16,8 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VAL
   i=$((i+1))
   (cd $R && rocprofv3 --pmc $grp --kernel-trace -d $R/gpurun_out/prof_${tag}/pmc$i -o res -- $CMD) > $R/gpurun_out/prof_${tag}_pmc$i.log 2>&1
 done
-cd $R && python3 scripts/make_traffic_json.py gpurun_out/traffic_${tag}.json $(find gpurun_out/prof_${tag}/pmc* -name "*.db") && head -30 gpurun_out/traffic_${tag}.json
+cd $R && python3 scripts/make_traffic_json.py gpurun_out/traffic_${tag}.json $(find gpurun_out/prof_${tag}/pmc* -name "*.db") && head -12 gpurun_out/traffic_${tag}.json
+# the bench line last: it quotes the HBM bytes per launch from the PMC passes of THIS build
+cp gpurun_out/traffic_${tag}.json profiles/r01_hbm_traffic.json
+python3 bench.py > gpurun_out/bench_${tag}.log 2>&1
+tail -1 gpurun_out/bench_${tag}.log | cut -c1-600
