@@ -501,19 +501,52 @@ __device__ __forceinline__ double row_shift4(double x)
     return b.d;
 }
 // BW == JQ_BW_T4Q (see the definition above): D = C + M x on the JQ_BW_T4 image.  Alias-safe (D may be C and/or x).
+// This lane's share of an operator: A operand (lane 16 k + 4 b + i holds B_{4 mt + b}[i][k] = element 16 b + 4 k + i of the
+// block's 64 doubles) and the coefficients [mt][g = row in group][r = group][term] of its row (four consecutive doubles).
+template <int NT>
+struct OpQ {
+    double a[NT];
+    d4 c[NT];
+};
+__device__ __forceinline__ const double* t4q_a(const double* mat, int lane)
+{
+    return mat - lane + (((lane >> 2) & 3) * 16 + (lane >> 4) * 4 + (lane & 3));
+}
+template <int NT>
+__device__ __forceinline__ const d4* t4q_c(const double* mat, int lane)
+{
+    return (const d4*)(mat - lane + 4 * NT * JQ_T4_TILE + (lane >> 4) * 16 + ((lane >> 2) & 3) * 4);
+}
+// one 16-row block
+template <int NT, bool ZEROC, int MODE>
+__device__ __forceinline__ void t4q_block(Arr<NT>& D, const Arr<NT>& C, const Arr<NT>& x, int mt, double a, const d4& c, double& xold)
+{
+    constexpr bool diag = MODE & JQ_T4_DIAG, rt = MODE & JQ_T4_RTERMS, mtm = MODE & JQ_T4_MTERMS;
+    const double xc = x.t[mt][0];
+    double acc = ZEROC ? 0.0 : C.t[mt][0];
+    if constexpr (diag) acc = __builtin_amdgcn_mfma_f64_4x4x4f64(a, xc, acc, 0, 0, 0);
+    if constexpr (rt) {
+        acc = fma(c[0], row_shift4<0x114>(xc), acc);
+        acc = fma(c[1], row_shift4<0x104>(xc), acc);
+    }
+    if constexpr (mtm) {
+        if (mt > 0) acc = fma(c[2], xold, acc);
+        if (mt + 1 < NT) acc = fma(c[3], x.t[mt + 1 < NT ? mt + 1 : mt][0], acc);
+    }
+    xold = xc;
+    D.t[mt][0] = acc;
+}
 template <int NT, bool ZEROC, int MODE>
 __device__ __forceinline__ void mm_t4q(Arr<NT>& D, const Arr<NT>& C, const double* mat, const Arr<NT>& x)
 {
-    constexpr bool diag = MODE & JQ_T4_DIAG, rt = MODE & JQ_T4_RTERMS, mtm = MODE & JQ_T4_MTERMS;
+    constexpr bool diag = MODE & JQ_T4_DIAG, coef = (MODE & (JQ_T4_RTERMS | JQ_T4_MTERMS)) != 0;
     const int lane = threadIdx.x & 63;
-    // A operand: lane 16 k + 4 b + i holds B_{4 mt + b}[i][k] = element 16 b + 4 k + i of the block's 64 doubles;
-    // coefficients [mt][g = row in group][r = group][term] of this lane's row: four consecutive doubles
-    const double* ma = mat - lane + (((lane >> 2) & 3) * 16 + (lane >> 4) * 4 + (lane & 3));
-    const d4* cf = (const d4*)(mat - lane + 4 * NT * JQ_T4_TILE + (lane >> 4) * 16 + ((lane >> 2) & 3) * 4);
+    const double* ma = t4q_a(mat, lane);
+    const d4* cf = t4q_c<NT>(mat, lane);
     double a_cur = 0.0;
     d4 c_cur = {0.0, 0.0, 0.0, 0.0};
     if constexpr (diag) a_cur = ma[0];
-    if constexpr (rt || mtm) c_cur = cf[0];
+    if constexpr (coef) c_cur = cf[0];
     double xold = 0.0;
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt) {
@@ -521,22 +554,30 @@ __device__ __forceinline__ void mm_t4q(Arr<NT>& D, const Arr<NT>& C, const doubl
         const d4 c = c_cur;
         if (mt + 1 < NT) {
             if constexpr (diag) a_cur = ma[(mt + 1) * 64];
-            if constexpr (rt || mtm) c_cur = cf[(mt + 1) * 16];
+            if constexpr (coef) c_cur = cf[(mt + 1) * 16];
         }
-        const double xc = x.t[mt][0];
-        double acc = ZEROC ? 0.0 : C.t[mt][0];
-        if constexpr (diag) acc = __builtin_amdgcn_mfma_f64_4x4x4f64(a, xc, acc, 0, 0, 0);
-        if constexpr (rt) {
-            acc = fma(c[0], row_shift4<0x114>(xc), acc);
-            acc = fma(c[1], row_shift4<0x104>(xc), acc);
-        }
-        if constexpr (mtm) {
-            if (mt > 0) acc = fma(c[2], xold, acc);
-            if (mt + 1 < NT) acc = fma(c[3], x.t[mt + 1 < NT ? mt + 1 : mt][0], acc);
-        }
-        xold = xc;
-        D.t[mt][0] = acc;
+        t4q_block<NT, ZEROC, MODE>(D, C, x, mt, a, c, xold);
     }
+}
+// the same with the operator in registers (the m + 1 products of a Horner chain share it: no LDS latency at their heads)
+template <int NT>
+__device__ __forceinline__ void t4q_load(OpQ<NT>& op, const double* mat)
+{
+    const int lane = threadIdx.x & 63;
+    const double* ma = t4q_a(mat, lane);
+    const d4* cf = t4q_c<NT>(mat, lane);
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) {
+        op.a[mt] = ma[mt * 64];
+        op.c[mt] = cf[mt * 16];
+    }
+}
+template <int NT>
+__device__ __forceinline__ void mm_t4q_regs(Arr<NT>& D, const Arr<NT>& C, const OpQ<NT>& op, const Arr<NT>& x)
+{
+    double xold = 0.0;
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) t4q_block<NT, false, JQ_T4_DIAG | JQ_T4_RTERMS | JQ_T4_MTERMS>(D, C, x, mt, op.a[mt], op.c[mt], xold);
 }
 
 template <int NT, int BW, bool ZEROC, bool SD = false>
@@ -774,6 +815,7 @@ struct Ring {
     unsigned long long qword;      // its schedule entries not yet consumed
     int iq;                        // its position in the step
     int s0;                        // ring slot of time point 2n of the current step
+    unsigned wb0, wb1, wb2;        // byte offsets of the K image of the time points 2n, 2n+1, 2n+2
 
     __device__ __forceinline__ unsigned lane_off16() const
     {
@@ -853,6 +895,11 @@ struct Ring {
         dma(stream + (size_t)(4 * first) * stride, smem + (size_t)(b & 1) * slot_bytes, npts * 2 * pieces);
     }
     // call at the top of every time step n (of the chunk)
+    __device__ __forceinline__ void set_window()
+    {
+        const int s1 = s0 + 1 >= JQ_WIN_TPS ? s0 + 1 - JQ_WIN_TPS : s0 + 1, s2 = s0 + 2 >= JQ_WIN_TPS ? s0 + 2 - JQ_WIN_TPS : s0 + 2;
+        wb0 = (unsigned)(s0 * slot_bytes), wb1 = (unsigned)(s1 * slot_bytes), wb2 = (unsigned)(s2 * slot_bytes);
+    }
     __device__ __forceinline__ void issue_tp(int j)   // window mode: K and S of time point j of the chunk -> its ring slot
     {
         if (j > 2 * nsteps_chunk) return;
@@ -871,6 +918,7 @@ struct Ring {
                 issue_tp(2 * n + 4);
                 s0 += 2;
                 if (s0 >= JQ_WIN_TPS) s0 -= JQ_WIN_TPS;
+                set_window();
             }
             return;
         }
@@ -917,6 +965,7 @@ struct Ring {
             qword = npro > 0 ? pb : sb0;
             iq = 0;
             s0 = 0;
+            set_window();
         } else if (batch > 0) {
             slot_bytes = (int)((2 * batch + 1) * 2 * stride * 8);
             // resident constant images behind the two batch buffers
@@ -988,6 +1037,20 @@ struct Ring {
         M = (const double*)(smem + (size_t)(Q & 1) * slot_bytes) + lane;
         ++Q;
         return M;
+    }
+    // The slab kernels know at every call site which image comes next (the schedule is theirs): K (KIND 0) / S (KIND 1) of
+    // time point 2n + TP, or constant image #idx.  In window mode that is two scalar instructions instead of the generic
+    // cursor (which was 10 % of a quad-layout step); the other modes ignore the hint.
+    template <int KIND, int TP>
+    __device__ __forceinline__ const double* next_ks()
+    {
+        if (batch < 0) return (const double*)(smem + ((TP == 0 ? wb0 : TP == 1 ? wb1 : wb2) + KIND * stride_b)) + lane;
+        return next();
+    }
+    __device__ __forceinline__ const double* next_c(int idx)
+    {
+        if (batch < 0) return (const double*)(smem + ((unsigned)(JQ_WIN_TPS * slot_bytes) + (unsigned)idx * stride_b)) + lane;
+        return next();
     }
     __device__ __forceinline__ void drain()
     {
@@ -1070,9 +1133,17 @@ __device__ __forceinline__ void horner_add(Arr<NT>& out, const Arr<NT>& bpa, con
         mm_c<NT, BW>(out, bpa, S, A);
         return;
     }
+    if constexpr (BW == JQ_BW_T4Q) {
+        OpQ<NT> op;
+        t4q_load(op, S);
+        mm_t4q_regs(Ya, A, op, A);
+        for (--rem; rem > 0; --rem) mm_t4q_regs(Ya, A, op, Ya);
+        mm_t4q_regs(out, bpa, op, Ya);
+        return;
+    }
     mm_c<NT, BW>(Ya, A, S, A);  // Y1 = A + S A
     --rem;
-    if constexpr (BW == JQ_BW_OD || BW == JQ_BW_T4 || BW == JQ_BW_T4Q) {
+    if constexpr (BW == JQ_BW_OD || BW == JQ_BW_T4) {
         // mm_od / mm_t4 are alias-safe: the recurrence runs in place and Yb is never touched (48 registers less)
         for (; rem > 0; --rem) mm_c<NT, BW>(Ya, A, S, Ya);
         mm_c<NT, BW>(out, bpa, S, Ya);
@@ -1121,13 +1192,13 @@ __device__ __forceinline__ void sv_state(Ring& p, const PropArgs& a, bool active
                                          Arr<NT>& Yb)
 {
     // use 0: Kp05 -- A = c K05 u
-    const double* M = p.next();
+    const double* M = p.next_ks<0, 1>();
     if (active) {
         mm_z<NT, BW>(A, M, u);
         if (a.use_shift) a_axpy_rows(A, ceps, ws, g, u);
     }
     // use 1: S05 -- A = c (K05 u + S05 v) ; v05 = v + sum_j S^j A (in place) ; vN = v05 + S05 v05
-    M = p.next();
+    M = p.next_ks<1, 1>();
     if (active) {
         mm_c<NT, BW>(A, A, M, v);
         a_add(v, A);
@@ -1135,22 +1206,22 @@ __device__ __forceinline__ void sv_state(Ring& p, const PropArgs& a, bool active
         mm_c<NT, BW>(vN, v, M, v);
     }
     // use 2: Kn0 -- unew = u - c K0 v05
-    M = p.next();
+    M = p.next_ks<0, 0>();
     if (active) {
         mm_c<NT, BW>(unew, u, M, v);
         if (a.use_shift) a_axpy_rows(unew, -ceps, ws, g, v);
     }
     // use 3: S0 -- unew = u + c (S0 u - K0 v05) = u + c kappa1
-    M = p.next();
+    M = p.next_ks<1, 0>();
     if (active) mm_c<NT, BW>(unew, unew, M, u);
     // use 4: Kn1 -- A = -c K1 v05
-    M = p.next();
+    M = p.next_ks<0, 2>();
     if (active) {
         mm_z<NT, BW>(A, M, v);
         if (a.use_shift) a_axpy_rows(A, -ceps, ws, g, v);
     }
     // use 5: S1 -- A = c (S1 (u + c kappa1) - K1 v05) ; unew += sum_j S^j A
-    M = p.next();
+    M = p.next_ks<1, 2>();
     if (active) {
         mm_c<NT, BW>(A, A, M, unew);
         a_add(unew, A);
@@ -1208,7 +1279,7 @@ __global__ __launch_bounds__(256, MINW) void k_forward(PropArgs a)
         if (active) leak += a_wsq(wd, g, U); /* trapezoidal part: tr(vr' W vr) at t_n (:700) */                  \
         sv_state<NT, BW, JAC>(p, a, active, ceps, ws, g, U, V, UN, VN, A, Ya, Yb);                                    \
         /* use 6: Kp05 again -- v(t+h) = v05 + c (K05 u_new + S05 v05) */                                        \
-        const double* M6 = p.next();                                                                             \
+        const double* M6 = p.next_ks<0, 1>();                                                                             \
         if (active) {                                                                                            \
             mm_c<NT, BW>(VN, VN, M6, UN);                                                                        \
             if (a.use_shift) a_axpy_rows(VN, ceps, ws, g, UN);                                                   \
@@ -1316,7 +1387,7 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
         // carry_q = tr(vr' Hsym_q lambdai) at t = T: the "vr0/lambdai0" term of the first backward
         // step (:2609); on later steps it is the previous step's tr(vr' Hsym_q lambdai) (:901-902).
         for (int q = 0; q < Nc; ++q) {
-            const double* M = p.next();  // Hsym_q
+            const double* M = p.next_c(q);  // Hsym_q
             if (active) {
                 mm_z_bw<NT, BW>(Ya, M, nb, a.bw_trace[q]);
                 carry[q * 256 + threadIdx.x] = -a_dot(u, Ya);
@@ -1331,7 +1402,7 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
         // mu's registers serve as the scratch array A of the state step
         sv_state<NT, BW, JAC>(p, a, active, ceps, ws, g, u, v, un, vN, mu, Ya, Yb);
         // use 6: Kp05 -- finish the state step; first adjoint product L = c K05 nb (= -c K05 lambda_i)
-        const double* M = p.next();
+        const double* M = p.next_ks<0, 1>();
         if (active) {
             mm_c<NT, BW>(vN, vN, M, un);
             if (a.use_shift) a_axpy_rows(vN, ceps, ws, g, un);
@@ -1342,7 +1413,7 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
         }
         // ---- adjoint step ----------------------------------------------------------------------
         // use 7: S0 -- L = c (S0 mu - K05 li + hr0) ; X = mu + sum_j S^j L   (in place: mu becomes X)
-        M = p.next();
+        M = p.next_ks<1, 0>();
         if (active) {
             mm_c<NT, BW>(L, L, M, mu);
             a_axpy_rows(L, cfw, wd, g, u);  // u holds vr before the state step (:862)
@@ -1351,7 +1422,7 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
         }
         // early traces with X (lets vr0 = u die here): tr1 = tr(vr0' Hanti_q X), tr3 = tr(vr' Hanti_q X)
         for (int q = 0; q < Nc; ++q) {
-            M = p.next();  // Hanti_q
+            M = p.next_c(Nc + q);  // Hanti_q
             if (active) {
                 mm_z_bw<NT, BW>(Ya, M, mu, a.bw_trace[q]);
                 const double t1 = (a.debug & 1) ? a_dot(u, Ya) : wave_sum(a_dot(u, Ya) * wgt);
@@ -1364,20 +1435,20 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
             }
         }
         // use 8: Kn0 -- L = -c K0 X
-        M = p.next();
+        M = p.next_ks<0, 0>();
         if (active) {
             mm_z<NT, BW>(L, M, mu);
             if (a.use_shift) a_axpy_rows(L, -ceps, ws, g, mu);
         }
         // use 9: Kn1 -- vN(scratch Q) = -c K1 X
-        M = p.next();
+        M = p.next_ks<0, 2>();
         if (active) {
             mm_z<NT, BW>(vN, M, mu);
             if (a.use_shift) a_axpy_rows(vN, -ceps, ws, g, mu);
         }
         // use 10: S05 -- L = -c l2 = -c (K0 X + S05 li + hi0) ; Q = -c (S05 (li + c l2) + K1 X + hi1) ;
         //               nb_new = nb + L + sum_j S^j Q          (li_new = li + c (l2 + l1))
-        M = p.next();
+        M = p.next_ks<1, 1>();
         if (active) {
             mm_z<NT, BW>(Ya, M, nb);
             a_axpy_rows(Ya, -cfw, wd, g, v);  // v holds vi05;  Ya = c (-S05 li - hi0)
@@ -1390,13 +1461,13 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
             a_add(nb, L);                     // nb = nb_old + nb_new = -(li0 + li)
         }
         // use 11: Kp05 -- vN(scratch G) = X + c K05 nb_new (= lambda_r^{1/2} - c K05 li_new)
-        M = p.next();
+        M = p.next_ks<0, 1>();
         if (active) {
             mm_c<NT, BW>(vN, mu, M, L);
             if (a.use_shift) a_axpy_rows(vN, ceps, ws, g, L);
         }
         // use 12: S1 -- lambda_r_new = X + c (S1 X - K05 li_new + hr1)
-        M = p.next();
+        M = p.next_ks<1, 2>();
         if (active) {
             mm_c<NT, BW>(vN, vN, M, mu);
             a_axpy_rows(vN, cfw, wd, g, un);
@@ -1407,12 +1478,12 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
         for (int q = 0; q < Nc; ++q) {
             double t2 = 0, t4 = 0, t5 = 0;
             const int bwq = a.bw_trace[q];
-            M = p.next();  // Hanti_q
+            M = p.next_c(Nc + q);  // Hanti_q
             if (active) {
                 mm_z_bw<NT, BW>(Ya, M, nb, bwq);
                 t5 = -a_dot(v, Ya);
             }
-            M = p.next();  // Hsym_q
+            M = p.next_c(q);  // Hsym_q
             if (active) {
                 mm_z_bw<NT, BW>(Ya, M, mu, bwq);
                 t2 = a_dot(v, Ya);
