@@ -148,6 +148,15 @@ def main():
                "svts_per_s": nsamples_total * N * nsteps * args.steps / elapsed,
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
+            # outside the timed region: the latency of ONE evaluation (what an Ipopt iteration of the reference waits for;
+            # quad-layout kernels) next to the CPU figure below -- not part of `value`
+            jq.traceobjgrad(pcof, params, wa, False, True)
+            t1 = time.perf_counter()
+            jq.traceobjgrad(pcof, params, wa, False, True)
+            torch.cuda.synchronize()
+            ts = wa.last_timing()
+            out["single_evaluation"] = {"seconds": time.perf_counter() - t1, "ms_propagate": ts["ms_propagate"],
+                                        "kernel_family": ts["kernel_family"], "kernel_band": ts["kernel_band"]}
             from oracle.oracle import Oracle
             orc = Oracle(params)                      # sparse products like the reference's use_sparse=true
             nrep = 2

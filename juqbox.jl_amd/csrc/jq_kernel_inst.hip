@@ -3,12 +3,17 @@
 //   JQ_VARIANT 0: slab kernels, Neumann   1: slab kernels, Jacobi   2: cooperative (row-split) kernels
 //              3: lane kernels (one lane per column; JQ_NT = padded Hilbert dimension NP, JQ_BW unused)
 //              6: cooperative kernels of the implicit-midpoint integrator
+//              7: quad-layout kernels of the implicit-midpoint integrator (JQ_BW = 7)
 //              5: row-lane kernels of the implicit-midpoint integrator (JQ_NT = NPJ)
 //              4: row-lane kernels (one lane per (row, column); JQ_NT = padded row length NPJ, JQ_BW unused)
 #if !defined(JQ_NT) || !defined(JQ_BW) || !defined(JQ_VARIANT)
-#error "compile with -DJQ_NT=<tiles> -DJQ_BW=<band> -DJQ_VARIANT=<0..6>"
+#error "compile with -DJQ_NT=<tiles> -DJQ_BW=<band> -DJQ_VARIANT=<0..7>"
 #endif
-#if JQ_VARIANT == 6
+#if JQ_VARIANT == 7
+#include "jq_quad_imr_kernels.h"
+template __global__ void k_forward_quad_imr<JQ_NT>(PropArgs);
+template __global__ void k_backward_quad_imr<JQ_NT>(PropArgs);
+#elif JQ_VARIANT == 6
 #include "jq_coop_imr_kernels.h"
 template __global__ void k_forward_coop_imr<JQ_NT, JQ_BW>(PropArgs);
 template __global__ void k_backward_coop_imr<JQ_NT, JQ_BW>(PropArgs);

@@ -789,6 +789,25 @@ static int select_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
     extern template __global__ void k_backward<nt, JQ_BW_T4Q, JQ_MINW_OF(nt), false>(PropArgs);
 JQ_DECLQ(1) JQ_DECLQ(2) JQ_DECLQ(3) JQ_DECLQ(4) JQ_DECLQ(5) JQ_DECLQ(6)
 #undef JQ_DECLQ
+template <int NT> __global__ void k_forward_quad_imr(PropArgs);      // jq_quad_imr_kernels.h (own translation units)
+template <int NT> __global__ void k_backward_quad_imr(PropArgs);
+#define JQ_DECLQI(nt)                                                      \
+    extern template __global__ void k_forward_quad_imr<nt>(PropArgs);      \
+    extern template __global__ void k_backward_quad_imr<nt>(PropArgs);
+JQ_DECLQI(1) JQ_DECLQI(2) JQ_DECLQI(3) JQ_DECLQI(4) JQ_DECLQI(5) JQ_DECLQI(6)
+#undef JQ_DECLQI
+static int select_quad_imr_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
+{
+#define JQ_PICKQI(nt)                              \
+    if (h->NT == nt) {                             \
+        *fwd = k_forward_quad_imr<nt>;             \
+        *bwd = k_backward_quad_imr<nt>;            \
+        return JQ_OK;                              \
+    }
+    JQ_PICKQI(1) JQ_PICKQI(2) JQ_PICKQI(3) JQ_PICKQI(4) JQ_PICKQI(5) JQ_PICKQI(6)
+#undef JQ_PICKQI
+    return fail(h, JQ_EUNSUPPORTED, "unsupported Hilbert dimension");
+}
 static int select_quad_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
 {
 #define JQ_PICKQ(nt)                                                       \
@@ -944,7 +963,9 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     // solver's per-evaluation convergence test), cooperative MFMA kernels (one slab per workgroup) otherwise
     const bool imr = (h->integrator == 2);
     const bool imr_rl = imr && h->rl_npj > 0 && h->N <= 4;
-    const bool imr_coop = imr && !imr_rl;
+    // JQ_BW_T4 structure with an evaluation's columns inside one quad: quad-layout kernels (jq_quad_imr_kernels.h)
+    const bool imr_quad = imr && !imr_rl && h->quad_max_slabs > 0 && (h->N == 1 || h->N == 2 || h->N == 4) && nslabs <= 4 * h->coop_max_slabs;
+    const bool imr_coop = imr && !imr_rl && !imr_quad;
     if (imr_coop && (h->mat_elems_c == 0 || coop_imr_lds_bytes(h->NT, h->mat_elems_c) > 163840))
         return fail(h, JQ_EUNSUPPORTED, "implicit midpoint: needs Ntot <= 16 with N <= 4, or 16 < Ntot <= 96");
     if (imr_coop && nslabs > 4 * h->coop_max_slabs)
@@ -957,12 +978,13 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     const long long ncols = rl ? 4 * nwaves_rl : (ncols_used + 63) / 64 * 64;      // row-lane: column SLOTS (4 per wave)
     // JQ_BW_T4 structure, small batches: the quad-layout kernels (one workgroup per slab, its four waves carry four columns
     // each; 3 x shorter dependent chain than the cooperative kernels).  JQ_QUAD=0 disables them.
-    const bool quad = !imr && !lane && !rl && h->solver_id == 1 && nslabs <= h->quad_max_slabs;
+    const bool quad = imr_quad || (!imr && !lane && !rl && h->solver_id == 1 && nslabs <= h->quad_max_slabs);
     const bool coop = imr_coop || (!quad && !lane && !rl && h->mat_elems_c > 0 && h->solver_id == 1 && nslabs <= h->coop_max_slabs);
     prop_kernel_t kfwd, kbwd;
     lane_init_t klinit = nullptr;
     lane_term_t klterm = nullptr;
-    int rc = imr_coop ? select_coop_imr_kernels(h, &kfwd, &kbwd)
+    int rc = imr_quad ? select_quad_imr_kernels(h, &kfwd, &kbwd)
+             : imr_coop ? select_coop_imr_kernels(h, &kfwd, &kbwd)
              : imr_rl ? select_rowlane_imr_kernels(h, &kfwd, &kbwd)
              : rl ? select_rowlane_kernels(h, &kfwd, &kbwd)
              : lane ? select_lane_kernels(h, &kfwd, &kbwd, &klinit, &klterm)
@@ -1134,7 +1156,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     }
     HIPCHK(h, hipGetLastError());
     const double leak_scale = imr ? 0.25 * dt * (1.0 / h->T) : 0.5 * dt * (1.0 / h->T);
-    if (imr_coop)
+    if (imr_coop || imr_quad)
         hipLaunchKernelGGL(k_terminal_imr, dim3(nslabs), dim3(64), 0, s, h->d_state, h->state_stride, h->d_vtr, h->d_vti, h->KT,
                            h->N, h->sps, nsamples, leak_scale, h->d_res);
     else if (imr)
@@ -1235,7 +1257,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     // (JQ_BW_T4: one v_mfma_f64_4x4x4_4b is 512 FLOP, a quarter of the 16x16x4 instruction this counter is quoted in)
     h->timing.mfma_executed = imr ? 0 : (!coop && !lane && !rl && h->BW == JQ_BW_T4) ? mfma / 4 : mfma;   // (the iteration counts of the implicit-midpoint solver are data dependent)
     h->timing.svts = (long long)nsamples * h->N * h->nsteps;
-    h->timing.kernel_family = imr_coop ? 5 : imr ? 4 : rl ? 3 : lane ? 2 : coop ? 1 : quad ? 6 : 0;
+    h->timing.kernel_family = imr_quad ? 7 : imr_coop ? 5 : imr ? 4 : rl ? 3 : lane ? 2 : coop ? 1 : quad ? 6 : 0;
     h->timing.kernel_size = rl ? h->rl_npj : lane ? h->lane_np : h->NT;
     h->timing.kernel_band = (rl || lane) ? 0 : coop ? h->BWc : quad ? JQ_BW_T4Q : h->BW;
     h->timing.reserved = 0;

@@ -18,13 +18,20 @@ def _imr_params(jq, case):
     return params, pcof
 
 
-@pytest.mark.parametrize("case", ["rabi", "swap02", "flux", "cnot2", "cnot2-leakieq", "cnot2-jacobi", "cnot3"])
+@pytest.mark.parametrize("case", ["rabi", "swap02", "flux", "cnot2", "cnot2-leakieq", "cnot2-jacobi", "cnot3", "cnot3:coop"])
 def test_reference_imr_golden_through_the_callbacks(jq, case):
     """All seven implicit-midpoint goldens of the reference (second loop of test/runtests.jl:60-80): Ntot <= 16 on the
-    row-lane kernels (family 4), cnot3 (Ntot = 96) on the cooperative MFMA kernels (family 5)."""
+    row-lane kernels (family 4), cnot3 (Ntot = 96 = 4 x 4 x 6) on the quad-layout kernels (family 7) and, with JQ_QUAD=0,
+    on the cooperative MFMA kernels (family 5)."""
+    case, _, mode = case.partition(":")
     params, pcof = _imr_params(jq, case)
     golden = load_golden(case + "-imr")
-    wa = jq.Working_Arrays_M_HIP(params, pcof.size)
+    if mode == "coop":
+        os.environ["JQ_QUAD"] = "0"
+    try:
+        wa = jq.Working_Arrays_M_HIP(params, pcof.size)
+    finally:
+        os.environ.pop("JQ_QUAD", None)
     n = pcof.size
     if params.objFuncType == 3:                      # test/evalGrad.jl:14-25
         obj = np.array([jq.eval_f_par(pcof, params, wa), 0.0])
@@ -41,7 +48,7 @@ def test_reference_imr_golden_through_the_callbacks(jq, case):
         jq.eval_grad_f_par(pcof, grad, params, wa)
     assert reference_pass(obj, golden["obj0"]), (obj, golden["obj0"])
     assert reference_pass(grad, golden["grad0"])
-    assert wa.last_timing()["kernel_family"] == (5 if params.Ntot > 16 else 4)
+    assert wa.last_timing()["kernel_family"] == ((5 if mode == "coop" else 7) if params.Ntot > 16 else 4)
     wa.close()
 
 
@@ -100,7 +107,8 @@ def test_imr_is_refused_where_it_is_not_implemented(jq):
 
 @pytest.mark.parametrize("cfg", [(2, 1, 1, 1, 9, 1), (5, 3, 2, 2, 14, 3), (9, 2, 3, 1, 11, 2), (12, 4, 2, 2, 8, 1), (16, 4, 4, 1, 6, 3),
                                  (17, 5, 2, 1, 7, 3), (33, 3, 1, 2, 6, 1), (48, 4, 3, 1, 5, 2), (80, 16, 2, 1, 4, 1), (95, 2, 2, 1, 4, "band"),
-                                 (48, 4, 2, 1, 5, "od"), (96, 4, 3, 1, 4, "od")],
+                                 (48, 4, 2, 1, 5, "od"), (96, 4, 3, 1, 4, "od"), (32, 1, 2, 1, 6, "t4"), (48, 2, 3, 2, 5, "t4"),
+                                 (64, 4, 3, 1, 5, "t4"), (96, 4, 3, 1, 4, "t4"), (80, 3, 2, 1, 4, "t4")],
                          ids=lambda c: "Ntot%d_N%d_Nc%d_f%d_o%s" % (c[0], c[1], c[2], c[3], c[5]))
 def test_imr_random_problems_match_oracle(jq, cfg):
     """Sizes and paddings the reference cases do not reach: every row-lane instantiation (NPJ 2..16), N = 1..4 columns
@@ -113,6 +121,8 @@ def test_imr_random_problems_match_oracle(jq, cfg):
     structure = False
     if oft == "od":          # Kronecker structure -> the JQ_BW_OD variant of the cooperative kernels
         structure, oft = "od", 1
+    if oft == "t4":          # 4 x 4 x n Kronecker structure -> the quad-layout kernels for N = 1, 2, 4 (N = 3: cooperative kernels)
+        structure, oft = "t4", 2
     if oft == "band":        # ladder-operator couplings: block band 1 (dense 96 x 96 images do not fit two LDS slots)
         structure, oft = True, 3
     p, pcof = random_problem(jq, rng, Ntot, N, Nc, Nfreq, nsteps, 3, oft, structure)
@@ -129,6 +139,8 @@ def test_imr_random_problems_match_oracle(jq, cfg):
     gn = np.linalg.norm(r["totalgrad"])
     assert abs(prim - r["primaryobjf"]) <= 1e-9 and abs(sec - r["secondaryobjf"]) <= 1e-9 * max(abs(r["secondaryobjf"]), 1e-3)
     assert np.linalg.norm(tg - r["totalgrad"]) <= 1e-9 * gn and np.linalg.norm(ig - r["infidelgrad"]) <= 1e-9 * gn
+    if structure == "t4":
+        assert wa.last_timing()["kernel_family"] == (7 if N in (1, 2, 4) else 5)
     _, hist, _ = jq.traceobjgrad(pcof, p, wa, True, False)
     assert np.max(np.abs(hist - r["history"])) < 1e-10
     for nq in (1, 3, 7):
