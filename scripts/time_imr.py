@@ -4,7 +4,8 @@ import numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import juqbox_jl_amd as jq
 from oracle.oracle import Oracle
-for case in ["swap02", "flux", "cnot1", "cnot2"]:
+cases = sys.argv[1:] or ["swap02", "flux", "cnot1", "cnot2"]     # (cnot3: the CPU oracle takes ~18 s)
+for case in cases:
     p, info = jq.cases.BUILDERS[case]()
     g = json.load(open("tests/golden/%s.json" % info["golden"])) if info.get("golden") else None
     pcof = np.array(g["pcof0"]) if g and "pcof0" in g else info["pcof0"]
