@@ -964,7 +964,8 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     const bool imr = (h->integrator == 2);
     const bool imr_rl = imr && h->rl_npj > 0 && h->N <= 4;
     // JQ_BW_T4 structure with an evaluation's columns inside one quad: quad-layout kernels (jq_quad_imr_kernels.h)
-    const bool imr_quad = imr && !imr_rl && h->quad_max_slabs > 0 && (h->N == 1 || h->N == 2 || h->N == 4) && nslabs <= 4 * h->coop_max_slabs;
+    // (any batch size: one workgroup per slab, rounds of one workgroup per CU)
+    const bool imr_quad = imr && !imr_rl && h->quad_max_slabs > 0 && (h->N == 1 || h->N == 2 || h->N == 4);
     const bool imr_coop = imr && !imr_rl && !imr_quad;
     if (imr_coop && (h->mat_elems_c == 0 || coop_imr_lds_bytes(h->NT, h->mat_elems_c) > 163840))
         return fail(h, JQ_EUNSUPPORTED, "implicit midpoint: needs Ntot <= 16 with N <= 4, or 16 < Ntot <= 96");
