@@ -19,7 +19,7 @@ __device__ __forceinline__ double row_shift(double x)
     return b.d;
 }
 // image per block: [A tile 64][c_dn 64][c_up 64][c_lo 64][c_hi 64]
-template <int NT, bool REGS>
+template <int NT, bool REGS, bool SPLIT = false>
 __global__ __launch_bounds__(256) void k_probe(const double* img, double* out, int reps)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -44,10 +44,18 @@ __global__ __launch_bounds__(256) void k_probe(const double* img, double* out, i
             double acc = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x, A[mt], 0, 0, 0);
             const double xdn = row_shift<0x114>(x);   // row_shr:4  (lane n <- n-4)
             const double xup = row_shift<0x104>(x);   // row_shl:4  (lane n <- n+4)
-            acc = fma(cdn, xdn, acc);
-            acc = fma(cup, xup, acc);
-            if (mt > 0) acc = fma(clo, xold, acc);
-            if (mt + 1 < NT) acc = fma(chi, Y[mt + 1], acc);
+            if (SPLIT) {                              // the coupling chain runs beside the MFMA, one add at the end
+                double z = cdn * xdn;
+                z = fma(cup, xup, z);
+                if (mt > 0) z = fma(clo, xold, z);
+                if (mt + 1 < NT) z = fma(chi, Y[mt + 1], z);
+                acc += z;
+            } else {
+                acc = fma(cdn, xdn, acc);
+                acc = fma(cup, xup, acc);
+                if (mt > 0) acc = fma(clo, xold, acc);
+                if (mt + 1 < NT) acc = fma(chi, Y[mt + 1], acc);
+            }
             xold = x;
             Y[mt] = acc;
         }
@@ -56,7 +64,7 @@ __global__ __launch_bounds__(256) void k_probe(const double* img, double* out, i
     for (int i = 0; i < NT; ++i) s += Y[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
-template <int NT, bool REGS>
+template <int NT, bool REGS, bool SPLIT = false>
 int run(const double* dimg, double* dout, int wgs_per_cu)
 {
     const size_t lds = NT * 320 * 8;
@@ -64,14 +72,14 @@ int run(const double* dimg, double* dout, int wgs_per_cu)
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    hipLaunchKernelGGL((k_probe<NT, REGS>), dim3(256 * wgs_per_cu), dim3(256), lds, 0, dimg, dout, 10);
+    hipLaunchKernelGGL((k_probe<NT, REGS, SPLIT>), dim3(256 * wgs_per_cu), dim3(256), lds, 0, dimg, dout, 10);
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL((k_probe<NT, REGS>), dim3(256 * wgs_per_cu), dim3(256), lds, 0, dimg, dout, reps);
+    hipLaunchKernelGGL((k_probe<NT, REGS, SPLIT>), dim3(256 * wgs_per_cu), dim3(256), lds, 0, dimg, dout, reps);
     CK(hipEventRecord(e1));
     CK(hipDeviceSynchronize());
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
-    printf("NT=%d coefficients in %s, %d wave(s)/SIMD: %7.1f ns per product and wave -> %7.1f ns per 16 columns\n", NT, REGS ? "registers" : "LDS      ",
+    printf("NT=%d %s coefficients in %s, %d wave(s)/SIMD: %7.1f ns per product and wave -> %7.1f ns per 16 columns\n", NT, SPLIT ? "split" : "chain", REGS ? "registers" : "LDS      ",
            wgs_per_cu, ms * 1e6 / reps, ms * 1e6 / reps * 4 / wgs_per_cu);
     return 0;
 }
@@ -83,9 +91,10 @@ int main()
     CK(hipMalloc(&dimg, img.size() * 8));
     CK(hipMalloc(&dout, 256 * 8 * 256 * 8));
     CK(hipMemcpy(dimg, img.data(), img.size() * 8, hipMemcpyHostToDevice));
-    for (int w : {1, 2, 4, 8}) {
+    for (int w : {1, 2}) {
         run<NT, false>(dimg, dout, w);
         run<NT, true>(dimg, dout, w);
+        run<NT, false, true>(dimg, dout, w);
     }
     return 0;
 }
