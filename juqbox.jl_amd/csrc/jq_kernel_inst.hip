@@ -38,6 +38,15 @@ template __global__ void k_backward_coop<JQ_NT, JQ_BW>(PropArgs);
 #else
 #include "jq_kernels.h"
 #define JQ_MINW ((JQ_NT <= 2) ? 2 : 1)
+#if JQ_BW == 7     // quad layout: workgroups of four waves (one slab) and of eight waves (two slabs, two waves per SIMD)
+template __global__ void k_forward<JQ_NT, JQ_BW, 1, false>(PropArgs);
+template __global__ void k_backward<JQ_NT, JQ_BW, 1, false>(PropArgs);
+template __global__ void k_forward<JQ_NT, JQ_BW, 2, false>(PropArgs);
+template __global__ void k_backward<JQ_NT, JQ_BW, 2, false>(PropArgs);
+template __global__ void k_forward<JQ_NT, JQ_BW, 3, false>(PropArgs);
+template __global__ void k_backward<JQ_NT, JQ_BW, 3, false>(PropArgs);
+#else
 template __global__ void k_forward<JQ_NT, JQ_BW, JQ_MINW, (JQ_VARIANT == 1)>(PropArgs);
 template __global__ void k_backward<JQ_NT, JQ_BW, JQ_MINW, (JQ_VARIANT == 1)>(PropArgs);
+#endif
 #endif

@@ -1169,7 +1169,7 @@ __device__ __forceinline__ void a_park(const Arr<NT>& a, double* park)
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int r = 0; r < JQ_RL; ++r) park[(4 * i + r) * 64] = a.t[i][r];
+        for (int r = 0; r < JQ_RL; ++r) park[(JQ_RL * i + r) * 64] = a.t[i][r];
 }
 template <int NT>
 __device__ __forceinline__ void a_unpark(Arr<NT>& a, const double* park)
@@ -1177,7 +1177,7 @@ __device__ __forceinline__ void a_unpark(Arr<NT>& a, const double* park)
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int r = 0; r < JQ_RL; ++r) a.t[i][r] = park[(4 * i + r) * 64];
+        for (int r = 0; r < JQ_RL; ++r) a.t[i][r] = park[(JQ_RL * i + r) * 64];
 }
 
 // State (re-)integration, operator uses 0..5 of one Stormer-Verlet step (forward step!,
@@ -1233,7 +1233,7 @@ __device__ __forceinline__ void sv_state(Ring& p, const PropArgs& a, bool active
 // Forward sweep over one chunk of time steps (src/evalobjgrad.jl:698-753).
 // schedule (period 7): Kp05 S05 Kn0 S0 Kn1 S1 Kp05
 template <int NT, int BW, int MINW, bool JAC>
-__global__ __launch_bounds__(256, MINW) void k_forward(PropArgs a)
+__global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_T4Q) ? 1 : MINW) void k_forward(PropArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KT = 4 * NT;
@@ -1242,11 +1242,13 @@ __global__ __launch_bounds__(256, MINW) void k_forward(PropArgs a)
     // slab layout: one slab per wave, lane = 16 g + column.  Quad layout (JQ_BW_T4Q): the workgroup's four waves share one
     // slab, wave q carries its columns 4q .. 4q+3; `lane` / `g` are then this lane's offsets in a block of the slab image / of
     // the row tables (a_load, a_axpy_rows) and `col` its state column
+    // (quad layout with MINW == 2: workgroups of eight waves = two slabs, two waves per SIMD)
     constexpr bool QUAD = (BW == JQ_BW_T4Q);
-    const int col = QUAD ? 4 * wave + (lane_ & 3) : (lane_ & 15);
+    constexpr int NWAVES = QUAD ? JQ_WAVES * MINW : JQ_WAVES;
+    const int col = QUAD ? 4 * (wave & 3) + (lane_ & 3) : (lane_ & 15);
     const int lane = QUAD ? ((lane_ >> 2) & 3) * 64 + 16 * (lane_ >> 4) + col : lane_;
     const int g = QUAD ? 4 * (lane_ >> 4) + ((lane_ >> 2) & 3) : lane_ >> 4;
-    const int slab = QUAD ? (int)blockIdx.x : blockIdx.x * JQ_WAVES + wave;
+    const int slab = QUAD ? (int)blockIdx.x * (NWAVES / 4) + (wave >> 2) : blockIdx.x * JQ_WAVES + wave;
     const bool active = slab < a.nslabs;
 
     double* tab = (double*)(smem + a.lds_tab_off);
@@ -1269,7 +1271,7 @@ __global__ __launch_bounds__(256, MINW) void k_forward(PropArgs a)
         a_zero(va);
     }
     Ring p;
-    p.init(smem, a, wave, lane_);
+    p.init(smem, a, wave, lane_, NWAVES);
 
     // one time step: (u, v) -> (unew, vN); v is consumed (becomes v05).  The two array pairs swap
     // roles every step, so the loop body is written for two steps and nothing is ever copied.
@@ -1325,7 +1327,7 @@ __global__ __launch_bounds__(256, MINW) void k_forward(PropArgs a)
 // any point (8 since vr0 dies after the early traces); the one array that is dormant in each phase (lambda_r during the state step, v during the
 // adjoint step and the traces) is parked in the wave's LDS (or global) parking image.
 template <int NT, int BW, int MINW, bool JAC>
-__global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
+__global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_T4Q) ? 1 : MINW) void k_backward(PropArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KT = 4 * NT;
@@ -1333,11 +1335,13 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // (slab / quad layout: see k_forward)
     constexpr bool QUAD = (BW == JQ_BW_T4Q);
-    const int col = QUAD ? 4 * wave + (lane_ & 3) : (lane_ & 15);
+    constexpr int NWAVES = QUAD ? JQ_WAVES * MINW : JQ_WAVES;
+    constexpr int NTHREADS = 64 * NWAVES;
+    const int col = QUAD ? 4 * (wave & 3) + (lane_ & 3) : (lane_ & 15);
     const int lane = QUAD ? ((lane_ >> 2) & 3) * 64 + 16 * (lane_ >> 4) + col : lane_;
     const int g = QUAD ? 4 * (lane_ >> 4) + ((lane_ >> 2) & 3) : lane_ >> 4;
-    const int slab = QUAD ? (int)blockIdx.x : blockIdx.x * JQ_WAVES + wave;
-    const int trow = QUAD ? slab * JQ_WAVES + wave : slab;   // row of this wave in the per-step trace records
+    const int slab = QUAD ? (int)blockIdx.x * (NWAVES / 4) + (wave >> 2) : blockIdx.x * JQ_WAVES + wave;
+    const int trow = QUAD ? slab * JQ_WAVES + (wave & 3) : slab;   // row of this wave in the per-step trace records
     const bool active = slab < a.nslabs;
     const int Nc = a.Ncoupled;
     // per-lane trace carries in the array file: like the leak partial of k_forward
@@ -1347,11 +1351,11 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
     double* tab = (double*)(smem + a.lds_tab_off);
     const double* wd = tab;
     const double* ws = tab + 16 * NT;
-    double* carry = tab + 32 * NT;  // [JQ_MAXNC][256]
+    double* carry = tab + 32 * NT;  // [JQ_MAXNC][threads of the workgroup]
     for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[(i & ~15) + 4 * (i & 3) + ((i >> 2) & 3)] = a.tabs[i];   // [block][g][r]
     double* st = a.state + (size_t)(active ? slab : 0) * a.state_stride;
     // parking image of this wave: in LDS when it fits, else in HBM
-    double* P0 = a.park_lds ? (carry + JQ_MAXNC * 256 + (size_t)wave * KT * 64 + lane_)
+    double* P0 = a.park_lds ? (carry + JQ_MAXNC * NTHREADS + (size_t)wave * (JQ_RL * NT) * 64 + lane_)
                             : (a.park + (size_t)(active ? slab : 0) * KT * 64 + lane);
 
     // array roles (register arrays are renamed, never copied, except at the end of a step):
@@ -1370,7 +1374,7 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
         a_load(nb, st + 3 * KT * 64, lane);
         ceps = 0.5 * a.h * a.colinfo[(size_t)slab * 32 + col];
         wgt = a.colinfo[(size_t)slab * 32 + 16 + col];
-        for (int q = 0; q < Nc; ++q) carry[q * 256 + threadIdx.x] = cslot ? st[(JQ_STATE_ARRAYS * KT + q) * 64 + clane] : 0.0;
+        for (int q = 0; q < Nc; ++q) carry[q * NTHREADS + threadIdx.x] = cslot ? st[(JQ_STATE_ARRAYS * KT + q) * 64 + clane] : 0.0;
     } else {
         a_zero(u);
         a_zero(v);
@@ -1381,7 +1385,7 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
     const double cfw = a.forced ? 0.5 * a.h * a.tinv : 0.0;
 
     Ring p;
-    p.init(smem, a, wave, lane_);
+    p.init(smem, a, wave, lane_, NWAVES);
 
     if (a.first_chunk) {
         // carry_q = tr(vr' Hsym_q lambdai) at t = T: the "vr0/lambdai0" term of the first backward
@@ -1390,7 +1394,7 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
             const double* M = p.next_c(q);  // Hsym_q
             if (active) {
                 mm_z_bw<NT, BW>(Ya, M, nb, a.bw_trace[q]);
-                carry[q * 256 + threadIdx.x] = -a_dot(u, Ya);
+                carry[q * NTHREADS + threadIdx.x] = -a_dot(u, Ya);
             }
         }
     }
@@ -1489,8 +1493,8 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
                 t2 = a_dot(v, Ya);
                 mm_z_bw<NT, BW>(Ya, M, L, bwq);
                 const double p4 = -a_dot(un, Ya);
-                t4 = p4 + carry[q * 256 + threadIdx.x];
-                carry[q * 256 + threadIdx.x] = p4;
+                t4 = p4 + carry[q * NTHREADS + threadIdx.x];
+                carry[q * NTHREADS + threadIdx.x] = p4;
                 if (!(a.debug & 1)) {
                     t2 = wave_sum(t2 * wgt);
                     t4 = wave_sum(t4 * wgt);
@@ -1519,7 +1523,7 @@ __global__ __launch_bounds__(256, MINW) void k_backward(PropArgs a)
         a_store(mu, st + 2 * KT * 64, lane);
         a_store(nb, st + 3 * KT * 64, lane);
         for (int q = 0; q < Nc; ++q) {
-            double cv = carry[q * 256 + threadIdx.x];
+            double cv = carry[q * NTHREADS + threadIdx.x];
             if constexpr (QUAD) cv = row_ror_add<8>(row_ror_add<4>(cv));   // only ever used summed over the rows of a column
             if (cslot) st[(JQ_STATE_ARRAYS * KT + q) * 64 + clane] = cv;
         }

@@ -49,7 +49,8 @@ struct jq_handle {
     int nslots_bwd = 2;         // ... of the backward kernel (shares LDS with carry + parking images)
     int park_lds = 0;           // backward kernel parks its dormant array in LDS (1) or HBM (0)
     int batch = 0;              // > 0: batched staging (K/S images of `batch` time steps per DMA burst); < 0: window staging
-    int quad_max_slabs = 0;     // JQ_BW_T4 structure: batches of at most this many slabs use the quad-layout kernels (0: never)
+    int quad_max_slabs = 0;     // JQ_BW_T4 structure: batches of at most this many slabs may use the quad-layout kernels (0: never)
+    int num_cu = 256;
     int lane_np = 0;            // > 0: lane kernels available (Ntot <= 12), padded Hilbert dimension NP
     long long lane_stride = 0;  // doubles per plain NP x NP operator image (padded to 64 B)
     int lane_min_cols = 0, lane_max_cols = 0;   // column counts (samples x N) routed to the lane kernels
@@ -524,10 +525,12 @@ static int create_impl(const jq_problem* p, jq_handle* h)
                 h->park_lds = 1;
             }
         }
-        // Quad-layout kernels (jq_kernels.h JQ_BW_T4Q) for small batches of this structure: one workgroup per slab and one
-        // workgroup per CU (LDS), i.e. rounds of #CU slabs at 0.37 of the slab kernels' time for 4 #CU slabs -> up to two
-        // rounds.  JQ_QUAD=0 disables them, JQ_QUAD=<n> sets the limit.
-        h->quad_max_slabs = (h->BW == JQ_BW_T4 && h->batch < 0) ? 2 * prop.multiProcessorCount : 0;
+        // Quad-layout kernels (jq_kernels.h JQ_BW_T4Q) for this structure: workgroups of 4, 8 or 12 waves carry 1, 2 or 3 slabs
+        // (1, 2, 3 waves per SIMD; one workgroup per CU because of the LDS).  run_eval picks the variant -- or the slab
+        // kernels -- by the number of rounds the batch needs (quad_plan).  JQ_QUAD=0 disables them, JQ_QUAD=<n> limits them to
+        // batches of at most n slabs.
+        h->quad_max_slabs = (h->BW == JQ_BW_T4 && h->batch < 0) ? (1 << 30) : 0;
+        h->num_cu = prop.multiProcessorCount;
         if (const char* e = getenv("JQ_QUAD"))
             if (h->quad_max_slabs > 0) h->quad_max_slabs = atoi(e);
         if (const char* e = getenv("JQ_BATCH")) {
@@ -784,9 +787,13 @@ static int select_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
 }
 
 // quad-layout kernels of the JQ_BW_T4 structure (jq_kernels.h JQ_BW_T4Q): small batches, Neumann solver
-#define JQ_DECLQ(nt)                                                                               \
-    extern template __global__ void k_forward<nt, JQ_BW_T4Q, JQ_MINW_OF(nt), false>(PropArgs);      \
-    extern template __global__ void k_backward<nt, JQ_BW_T4Q, JQ_MINW_OF(nt), false>(PropArgs);
+#define JQ_DECLQ(nt)                                                            \
+    extern template __global__ void k_forward<nt, JQ_BW_T4Q, 1, false>(PropArgs);    \
+    extern template __global__ void k_backward<nt, JQ_BW_T4Q, 1, false>(PropArgs);   \
+    extern template __global__ void k_forward<nt, JQ_BW_T4Q, 2, false>(PropArgs);    \
+    extern template __global__ void k_backward<nt, JQ_BW_T4Q, 2, false>(PropArgs);   \
+    extern template __global__ void k_forward<nt, JQ_BW_T4Q, 3, false>(PropArgs);    \
+    extern template __global__ void k_backward<nt, JQ_BW_T4Q, 3, false>(PropArgs);
 JQ_DECLQ(1) JQ_DECLQ(2) JQ_DECLQ(3) JQ_DECLQ(4) JQ_DECLQ(5) JQ_DECLQ(6)
 #undef JQ_DECLQ
 template <int NT> __global__ void k_forward_quad_imr(PropArgs);      // jq_quad_imr_kernels.h (own translation units)
@@ -808,13 +815,14 @@ static int select_quad_imr_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel
 #undef JQ_PICKQI
     return fail(h, JQ_EUNSUPPORTED, "unsupported Hilbert dimension");
 }
-static int select_quad_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
+// (spw: slabs per workgroup = waves per SIMD: workgroups of 4 spw waves)
+static int select_quad_kernels(jq_handle* h, int spw, prop_kernel_t* fwd, prop_kernel_t* bwd)
 {
-#define JQ_PICKQ(nt)                                                       \
-    if (h->NT == nt) {                                                     \
-        *fwd = k_forward<nt, JQ_BW_T4Q, JQ_MINW_OF(nt), false>;            \
-        *bwd = k_backward<nt, JQ_BW_T4Q, JQ_MINW_OF(nt), false>;           \
-        return JQ_OK;                                                      \
+#define JQ_PICKQ(nt)                                                                                                                             \
+    if (h->NT == nt) {                                                                                                                           \
+        *fwd = spw == 3 ? k_forward<nt, JQ_BW_T4Q, 3, false> : spw == 2 ? k_forward<nt, JQ_BW_T4Q, 2, false> : k_forward<nt, JQ_BW_T4Q, 1, false>;     \
+        *bwd = spw == 3 ? k_backward<nt, JQ_BW_T4Q, 3, false> : spw == 2 ? k_backward<nt, JQ_BW_T4Q, 2, false> : k_backward<nt, JQ_BW_T4Q, 1, false>;  \
+        return JQ_OK;                                                                                                                            \
     }
     JQ_PICKQ(1) JQ_PICKQ(2) JQ_PICKQ(3) JQ_PICKQ(4) JQ_PICKQ(5) JQ_PICKQ(6)
 #undef JQ_PICKQ
@@ -979,7 +987,28 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     const long long ncols = rl ? 4 * nwaves_rl : (ncols_used + 63) / 64 * 64;      // row-lane: column SLOTS (4 per wave)
     // JQ_BW_T4 structure, small batches: the quad-layout kernels (one workgroup per slab, its four waves carry four columns
     // each; 3 x shorter dependent chain than the cooperative kernels).  JQ_QUAD=0 disables them.
-    const bool quad = imr_quad || (!imr && !lane && !rl && h->solver_id == 1 && nslabs <= h->quad_max_slabs);
+    // Which kernels for nslabs slabs of this structure?  Time of one round relative to the slab kernels' round of 4 #CU slabs
+    // (measured at cnot3): quad layout with 1 / 2 / 3 slabs per workgroup 0.34 / 0.50 / 0.68 for #CU / 2 #CU /
+    // 3 #CU slabs.  Fewest "round units" wins; spw = 0: slab kernels.
+    int spw = 0;
+    if (!imr && !lane && !rl && h->solver_id == 1 && nslabs <= h->quad_max_slabs) {
+        const double rel[4] = {1.0, 0.34, 0.50, 0.68};
+        const size_t quad_lds3 = (size_t)(2 * JQ_WIN_TPS + 2 * h->Nc) * h->mat_elems * 8 + (size_t)32 * h->NT * 8 +
+                                 (size_t)JQ_MAXNC * 768 * 8 + (size_t)12 * h->NT * 64 * 8;
+        double best = rel[0] * ((nslabs + 4 * h->num_cu - 1) / (4 * h->num_cu));
+        for (int k = 1; k <= 3; ++k) {
+            if (k == 3 && quad_lds3 > 163840) continue;
+            const double c = rel[k] * ((nslabs + k * h->num_cu - 1) / (k * h->num_cu));
+            if (c < best - 1e-9) {
+                best = c;
+                spw = k;
+            }
+        }
+        if (const char* e = getenv("JQ_QUAD8")) spw = std::max(1, std::min(3, atoi(e) + 1));      // experiments: force 4 / 8 / 12 waves
+    }
+    if (imr_quad) spw = 1;
+    const bool quad = spw > 0;
+    const bool quad8 = spw > 1;
     const bool coop = imr_coop || (!quad && !lane && !rl && h->mat_elems_c > 0 && h->solver_id == 1 && nslabs <= h->coop_max_slabs);
     prop_kernel_t kfwd, kbwd;
     lane_init_t klinit = nullptr;
@@ -989,10 +1018,10 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
              : imr_rl ? select_rowlane_imr_kernels(h, &kfwd, &kbwd)
              : rl ? select_rowlane_kernels(h, &kfwd, &kbwd)
              : lane ? select_lane_kernels(h, &kfwd, &kbwd, &klinit, &klterm)
-                  : coop ? select_coop_kernels(h, &kfwd, &kbwd) : quad ? select_quad_kernels(h, &kfwd, &kbwd) : select_kernels(h, &kfwd, &kbwd);
+                  : coop ? select_coop_kernels(h, &kfwd, &kbwd) : quad ? select_quad_kernels(h, spw, &kfwd, &kbwd) : select_kernels(h, &kfwd, &kbwd);
     if (rc) return rc;
-    const int nblocks = rl ? (int)nwaves_rl : lane ? (int)(ncols / 64) : (coop || quad) ? nslabs : (nslabs + JQ_WAVES - 1) / JQ_WAVES;
-    const int nthreads = (lane || rl) ? 64 : coop ? 64 * h->NT : 256;
+    const int nblocks = rl ? (int)nwaves_rl : lane ? (int)(ncols / 64) : quad8 ? (nslabs + spw - 1) / spw : (coop || quad) ? nslabs : (nslabs + JQ_WAVES - 1) / JQ_WAVES;
+    const int nthreads = (lane || rl) ? 64 : coop ? 64 * h->NT : quad8 ? 256 * spw : 256;
     const int trace_rows = (lane || rl) ? nblocks : coop ? nslabs * h->NT : quad ? nslabs * JQ_WAVES : nslabs;   // per-step trace records: one per wave
     const long long stride = rl ? h->rl_stride : lane ? h->lane_stride : coop ? h->mat_elems_c : h->mat_elems;
     const double* himg = rl ? h->d_himg_r : lane ? h->d_himg_l : coop ? h->d_himg_c : h->d_himg;
@@ -1096,6 +1125,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     const size_t lds_fwd = (lane || rl) ? 0 : imr_coop ? coop_imr_lds_bytes(h->NT, stride)
                                            : lds_stage + (size_t)32 * h->NT * 8 + (coop ? (size_t)2 * h->KT * 64 * 8 : 0);
     const size_t lds_bwd = rl ? (h->rl_npj > 8 ? (size_t)2 * h->Nc * h->rl_stride * 8 : 0) : lane ? 0 : coop ? lds_fwd
+                                : quad ? lds_fwd + (size_t)JQ_MAXNC * nthreads * 8 + (size_t)(nthreads / 64) * h->NT * 64 * 8   // (a 16-row block per register)
                                 : lds_fwd + (size_t)JQ_MAXNC * 256 * 8 + (h->park_lds ? (size_t)JQ_WAVES * h->KT * 64 * 8 : 0);
     a.batch = batch; a.lds_tab_off = (int)lds_stage;
     a.park = h->d_park; a.park_lds = h->park_lds;

@@ -9,6 +9,12 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _clean_env():
+    yield
+    os.environ.pop("JQ_QUAD8", None)
 TOL = 1e-9   # random problems are less well conditioned than the reference cases; observed ~1e-13
 
 
@@ -124,7 +130,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("mode", ["auto", "coop", "slab", "slab-od", "lane", "nolane"])
+@pytest.mark.parametrize("mode", ["auto", "quad8", "quad12", "coop", "slab", "slab-od", "lane", "nolane"])
 @pytest.mark.parametrize("cfg", CASES, ids=lambda c: "Ntot%d_N%d_Nc%d_f%d_m%d_o%d_%s_c%d" % (c[0], c[1], c[2], c[3], c[5], c[6], c[7] if isinstance(c[7], str) else ("band" if c[7] else "dense"), c[8]))
 def test_random_problem_matches_oracle(jq, cfg, mode):
     """mode 'auto': Ntot <= 16 runs on the row-lane kernels (one lane per (row, column); small batches), Ntot > 16
@@ -136,6 +142,8 @@ def test_random_problem_matches_oracle(jq, cfg, mode):
     Ntot, N, Nc, Nfreq, nsteps, m, oft, banded, chunk = cfg
     if (mode == "lane" and Ntot > 8) or (mode == "nolane" and Ntot > 16):
         pytest.skip("lane kernels only exist for Ntot <= 8, row-lane kernels for Ntot <= 16")
+    if mode in ("quad8", "quad12") and (banded != "t4" or Ntot <= 16 or (Ntot == 96 and Nc == 4)):
+        pytest.skip("quad8 / quad12: the JQ_BW_T4 problems on the quad-layout kernels with two / three slabs per workgroup (JQ_QUAD8)")
     if mode == "coop" and (banded != "t4" or Ntot <= 16):
         pytest.skip("coop: the JQ_BW_T4 problems (auto: quad-layout kernels) once more on the cooperative kernels (JQ_QUAD=0)")
     if mode == "slab-od" and banded != "t4":
@@ -144,6 +152,8 @@ def test_random_problem_matches_oracle(jq, cfg, mode):
     p, pcof = random_problem(jq, rng, Ntot, N, Nc, Nfreq, nsteps, m, oft, banded)
     if chunk:
         os.environ["JQ_CHUNK_STEPS"] = str(chunk)
+    if mode in ("quad8", "quad12"):          # (read per evaluation: stays set for the whole test)
+        os.environ["JQ_QUAD8"] = "1" if mode == "quad8" else "2"
     if mode in ("slab", "slab-od"):
         os.environ["JQ_COOP_MAX"] = "0"
         os.environ["JQ_LANE"] = "0"
@@ -176,6 +186,8 @@ def test_random_problem_matches_oracle(jq, cfg, mode):
     if banded == "t4" and mode in ("slab", "slab-od"):      # the kernel variant under test really ran
         t = wa.last_timing()
         assert t["kernel_family"] == 0 and (t["kernel_band"] == 8) == (mode == "slab")
+    if mode in ("quad8", "quad12"):
+        assert wa.last_timing()["kernel_family"] == 6
     if banded == "t4" and Ntot > 16 and mode in ("auto", "coop"):
         # (quad-layout kernels need the window staging: five time points + 2 Nc constant images in LDS; not at Ntot = 96, Nc = 4)
         fam = wa.last_timing()["kernel_family"]
@@ -200,3 +212,4 @@ def test_random_problem_matches_oracle(jq, cfg, mode):
         if oft != 1:
             assert np.linalg.norm(p.last_leak_grad - ref["last_leak_grad"]) <= TOL * np.linalg.norm(gref)
     wa.close()
+    os.environ.pop("JQ_QUAD8", None)
