@@ -28,7 +28,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--samples-per-gpu", type=int, default=int(os.environ.get("JQ_BENCH_SAMPLES", "4096")))
+    # 3072 samples = 768 slabs of 16 columns = three slabs on each of the 256 CUs: one round of the kernels that are fastest
+    # for large ensembles (quad layout, 12 waves per workgroup).  Other sizes run too (4096 = one round of the slab kernels,
+    # reported below as `other_batch_sizes`); the library picks the kernels per batch size.
+    ap.add_argument("--samples-per-gpu", type=int, default=int(os.environ.get("JQ_BENCH_SAMPLES", "3072")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -105,7 +108,7 @@ def main():
         # HBM bytes per k_backward launch from the PMC passes kept under profiles/ (FETCH_SIZE x2 gfx950 correction
         # + WRITE_SIZE, separate rocprofv3 --pmc runs of this same command; null if not measured for this build)
         # the library reports which propagator family / instantiation ran (jq_timing.kernel_*)
-        fam = {0: "k_backward", 1: "k_backward_coop", 2: "k_backward_lane", 3: "k_backward_rowlane"}.get(tm.get("kernel_family", 0))
+        fam = {0: "k_backward", 1: "k_backward_coop", 2: "k_backward_lane", 3: "k_backward_rowlane", 6: "k_backward"}.get(tm.get("kernel_family", 0))
         kname = "%s<%d, %d>" % (fam, tm.get("kernel_size", 0), tm.get("kernel_band", 0))
         traffic = None
         try:
@@ -115,13 +118,16 @@ def main():
             pass
         band = tm.get("kernel_band")
         band_note = {9: " (band 9 = block tridiagonal with diagonal off-diagonal blocks)",
-                     8: " (band 8 = 4x4 diagonal blocks on v_mfma_f64_4x4x4 + diagonal couplings on DPP FMAs)"}.get(band, "")
+                     8: " (band 8 = 4x4 diagonal blocks on v_mfma_f64_4x4x4 + diagonal couplings on DPP FMAs)",
+                     7: " (band 7 = the band-8 product in the quad layout: four columns per wave, a 16-row block per register; "
+                        "%d waves per workgroup)" % (4 * max(1, round(args.samples_per_gpu * N / 16 / 256)) if args.samples_per_gpu * N / 16 <= 768 else 12)}.get(band, "")
         # arithmetic the kernels really execute (they skip the structural zeros the dense count includes): matrix pipe
         # from the library's MFMA count; for band 8 also the coupling FMAs of the products (6 NT + 8 (NT - 1) v_fma_f64
         # of 64 lanes per product, one product per 4 NT of the 512-FLOP MFMAs)
         NT = (Ntot + 15) // 16
         executed_mfma = mfma * 2048.0
-        executed_fma = (mfma * 4.0 / (4 * NT)) * (6 * NT + 8 * (NT - 1)) * 128.0 if band == 8 else 0.0
+        fma_per_product = (6 * NT + 8 * (NT - 1)) if band == 8 else 4 * (4 * NT - 2) if band == 7 else 0     # per slab of 16 columns
+        executed_fma = (mfma * 4.0 / (4 * NT)) * fma_per_product * 128.0
         roofline = {"bound": "mfma", "kernel": kname + band_note,
                     "achieved_definition": "dense-contraction FLOPs of SURVEY.md 8(d) (2 Ntot^2 per product and column: what a dense "
                                            "formulation computes) / HIP-event time of the kernel; the kernels skip the structural zeros "
@@ -157,6 +163,16 @@ def main():
             ts = wa.last_timing()
             out["single_evaluation"] = {"seconds": time.perf_counter() - t1, "ms_propagate": ts["ms_propagate"],
                                         "kernel_family": ts["kernel_family"], "kernel_band": ts["kernel_band"]}
+            other = {}
+            for ns in (4096, 6144):
+                if ns == args.samples_per_gpu:
+                    continue
+                n2, w2, s2 = jq.cases.cnot3_ensemble(ns)
+                jq.eval_f_g_grad(pcof, params, wa, n2, w2, True, shift=s2)
+                t2 = wa.last_timing()
+                other[str(ns)] = {"evals_per_s": ns / (t2["ms_total"] * 1e-3), "ms": t2["ms_total"], "kernel_family": t2["kernel_family"],
+                                  "kernel_band": t2["kernel_band"]}
+            out["other_batch_sizes"] = other
             from oracle.oracle import Oracle
             orc = Oracle(params)                      # sparse products like the reference's use_sparse=true
             nrep = 2
