@@ -234,3 +234,31 @@ def test_cnot3_full_size_properties(hip):
     fd = (op - om) / (2 * hfd)
     assert abs(fd - np.dot(g, d)) < 1e-5 * np.linalg.norm(g)
     wa.close()
+
+
+@pytest.mark.parametrize("nsamples", [700, 1500, 3072, 5000])
+def test_planned_kernels_match_the_slab_kernels_on_large_ensembles(hip, nsamples):
+    """jq_eval_f_g_grad picks the kernel variant by batch size (quad layout with 1 / 2 / 3 slabs per workgroup, several
+    rounds, or the slab kernels); whatever it picks must agree with the slab kernels (JQ_QUAD=0 JQ_COOP_MAX=0), which the
+    goldens and the oracle pin, to rounding (cnot3 shortened to 200 steps)."""
+    import os
+    jq = hip
+    params, info, pcof, _ = case_inputs("cnot3")
+    params.nsteps = 200
+    params.T = params.T * 200 / 32386
+    nodes, weights, shift = jq.cases.cnot3_ensemble(nsamples)
+    out = {}
+    for tag, env in (("plan", {}), ("slab", {"JQ_QUAD": "0", "JQ_COOP_MAX": "0"})):
+        os.environ.update(env)
+        try:
+            wa = jq.Working_Arrays_HIP(params, pcof.size)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        jq.eval_f_g_grad(pcof, params, wa, nodes, weights, True, shift=shift)
+        out[tag] = (params.last_infidelity, params.last_leak, params.last_infidelity_grad.copy(), wa.last_timing()["kernel_family"])
+        wa.close()
+    a, b = out["plan"], out["slab"]
+    assert b[3] == 0 and a[3] == 6
+    assert abs(a[0] - b[0]) <= 1e-13 * abs(b[0]) and abs(a[1] - b[1]) <= 1e-12 * abs(b[1])
+    assert np.linalg.norm(a[2] - b[2]) <= 1e-12 * np.linalg.norm(b[2])
