@@ -262,3 +262,26 @@ def test_planned_kernels_match_the_slab_kernels_on_large_ensembles(hip, nsamples
     assert b[3] == 0 and a[3] == 6
     assert abs(a[0] - b[0]) <= 1e-13 * abs(b[0]) and abs(a[1] - b[1]) <= 1e-12 * abs(b[1])
     assert np.linalg.norm(a[2] - b[2]) <= 1e-12 * np.linalg.norm(b[2])
+
+
+def test_bench_workload_kernels_reproduce_the_cnot3_golden_at_full_size(hip):
+    """The kernels bench.py times (3072 samples per GPU: quad layout, three slabs per workgroup) at BASELINE's full size
+    (Ntot = 96, 32386 steps, forward + adjoint): with every node unperturbed and weights summing to one the ensemble IS the
+    reference's golden evaluation -- infidelity / leak decomposition and gradient (golden minus its
+    Tikhonov part) at the reference's tolerance."""
+    jq = hip
+    params, info, pcof, golden = case_inputs("cnot3")
+    wa = jq.Working_Arrays_HIP(params, pcof.size)
+    ns = 3072
+    rng = np.random.default_rng(5)
+    w = rng.random(ns)
+    w /= w.sum()
+    jq.eval_f_g_grad(pcof, params, wa, np.zeros(ns), w, True)
+    t = wa.last_timing()
+    assert t["kernel_family"] == 6 and t["kernel_band"] == 7
+    assert abs(params.last_infidelity - 0.9181500713381303) < 1e-12
+    assert abs(params.last_leak - 2.8775930168455916e-05) < 1e-15
+    g = np.array(golden["grad0"]) - jq.setup_utils.tikhonov_grad(pcof, params.tik0)
+    gt = params.last_infidelity_grad + (params.last_leak_grad if params.objFuncType != 1 else 0.0)
+    assert reference_pass(gt, g)
+    wa.close()
