@@ -58,9 +58,18 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // large batches stay there.  The four waves of a workgroup share ONE slab of the JQ_BW_T4 state file (wave q = columns
 // 4q .. 4q+3): array file, initial / terminal kernels, column tables and operator images are those of the slab kernels.
 #define JQ_BW_T4Q 7
-#define JQ_T4_TILE 16                  // doubles per 4-row group in the image: the 4x4 diagonal block [k][i] (the MFMA's A operand
+#define JQ_T4_AIDX(rho, k, i) (((rho) >> 2) * 64 + 16 * (k) + 4 * ((rho) & 3) + (i))   // element of B_rho[i][k] in the image: per 16-row block the 64
+                                      // doubles in the lane order of the quad-layout MFMA (lane 16 k + 4 b + i; a [b][k][i] order gave those reads
+                                      // LDS bank conflicts worth 5 % of an evaluation); the slab kernels read elements 16 k + i of a group's slice
+#define JQ_T4_TILE 16                  // doubles per 4-row group in the image: the 4x4 diagonal block (the MFMA's A operand
                                       // repeats it in its four column blocks: lane 16k+4b+i reads element 4k+i, an LDS broadcast)
-#define JQ_T4_COEFS(NT) (64 * (NT))   // doubles after the 4NT blocks: [mt][g = lane>>4][r][term: r-1, r+1, mt-1, mt+1]
+#define JQ_T4_COEFS(NT) (64 * (NT))   // doubles after the 4NT blocks: per 16-row block [term pair][g = row in group][r = group][term & 1],
+                                      // terms: couplings to the groups r-1, r+1 (same block), to the blocks mt-1, mt+1
+// element of (g, r, term) in a block's 64 coefficients.  Both readers are free of LDS bank conflicts with it: the slab kernels
+// read one double per lane (lane 16 g + p holds position p = JQ_T4_CPOS(r, term) of row g: 64 distinct doubles), the quad-layout
+// kernels two 16-byte pairs per lane (16 distinct consecutive pairs each; a 32-byte [g][r][4] record per lane conflicted 4-fold)
+#define JQ_T4_CIDX(g, r, t) (((t) >> 1) * 32 + ((g) * 4 + (r)) * 2 + ((t) & 1))
+#define JQ_T4_CPOS(r, t) (8 * ((t) >> 1) + 2 * (r) + ((t) & 1))
 #define JQ_T4_ELEMS(NT) (4 * (NT) * JQ_T4_TILE + JQ_T4_COEFS(NT))
 // trace-image modes of this variant (a.bw_trace[q]): bit 0 diagonal 4x4 blocks present, bit 1 r+-1 terms, bit 2 mt+-1 terms
 #define JQ_T4_DIAG 1
@@ -380,8 +389,9 @@ __device__ __forceinline__ void t4_couple_pair(double& accA, double& accB, doubl
     if constexpr (NA > 0) {
 #define JQ_XA(k) (k < NA ? xa[act(R, k)] : c)
 #define JQ_XB(k) (k < NB ? xb[act(R + 1, k)] : c)
-        fma_rowbcast_pair<G, NA, NB, 4 * R + act(R, 0), 4 * R + act(R, 1), 4 * R + act(R, 2), 4 * R + act(R, 3), 4 * R + 4 + act(R + 1, 0),
-                          4 * R + 4 + act(R + 1, 1), 4 * R + 4 + act(R + 1, 2), 4 * R + 4 + act(R + 1, 3)>(
+        fma_rowbcast_pair<G, NA, NB, JQ_T4_CPOS(R, act(R, 0)), JQ_T4_CPOS(R, act(R, 1)), JQ_T4_CPOS(R, act(R, 2)), JQ_T4_CPOS(R, act(R, 3)),
+                          JQ_T4_CPOS(R + 1, act(R + 1, 0)), JQ_T4_CPOS(R + 1, act(R + 1, 1)), JQ_T4_CPOS(R + 1, act(R + 1, 2)),
+                          JQ_T4_CPOS(R + 1, act(R + 1, 3))>(
             accA, accB, c, JQ_XA(0), JQ_XA(1), JQ_XA(2), JQ_XA(3), JQ_XB(0), JQ_XB(1), JQ_XB(2), JQ_XB(3));
 #undef JQ_XA
 #undef JQ_XB
@@ -409,14 +419,14 @@ __device__ __forceinline__ void mm_t4(Arr<NT>& D, const Arr<NT>& C, const double
     constexpr int NR = 4 * NT;
     constexpr bool diag = MODE & JQ_T4_DIAG, rt = MODE & JQ_T4_RTERMS, mtm = MODE & JQ_T4_MTERMS;
     const int lane = threadIdx.x & 63;
-    const double* cf = mat + NR * JQ_T4_TILE;
-    const double* ma = mat - lane + ((lane >> 4) * 4 + (lane & 3));   // this lane's element of every 4x4 block
+    const double* cf = mat - lane + NR * JQ_T4_TILE + (((lane >> 3) & 1) * 32 + (lane >> 4) * 8 + (lane & 7));   // position lane & 15 of row lane >> 4
+    const double* ma = mat - lane + ((lane >> 4) * 16 + (lane & 3));  // this lane's element (k = lane >> 4, i = lane & 3) of every 4x4 block
     double f[JQ_PF];
     double cq[2];
     if constexpr (diag) {
 #pragma unroll
         for (int i = 0; i < JQ_PF; ++i)
-            if (i < NR) f[i] = ma[i * JQ_T4_TILE];
+            if (i < NR) f[i] = ma[JQ_T4_AIDX(i, 0, 0)];
     }
     if constexpr (rt || mtm) {
         cq[0] = cf[0];
@@ -434,7 +444,7 @@ __device__ __forceinline__ void mm_t4(Arr<NT>& D, const Arr<NT>& C, const double
         pend[i] = ZEROC ? 0.0 : C.t[0][i];
         if constexpr (diag) {
             pend[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(f[i % JQ_PF], x.t[0][i], pend[i], 0, 0, 0);
-            if (i + JQ_PF < NR) f[i % JQ_PF] = ma[(i + JQ_PF) * JQ_T4_TILE];
+            if (i + JQ_PF < NR) f[i % JQ_PF] = ma[JQ_T4_AIDX(i + JQ_PF, 0, 0)];
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -456,7 +466,7 @@ __device__ __forceinline__ void mm_t4(Arr<NT>& D, const Arr<NT>& C, const double
                     double nxt = ZEROC ? 0.0 : C.t[nx >> 2][nx & 3];
                     if constexpr (diag) {
                         nxt = __builtin_amdgcn_mfma_f64_4x4x4f64(f[nx % JQ_PF], x.t[nx >> 2][nx & 3], nxt, 0, 0, 0);
-                        if (nx + JQ_PF < NR) f[nx % JQ_PF] = ma[(nx + JQ_PF) * JQ_T4_TILE];
+                        if (nx + JQ_PF < NR) f[nx % JQ_PF] = ma[JQ_T4_AIDX(nx + JQ_PF, 0, 0)];
                     }
                     pend[i] = nxt;
                 }
@@ -503,6 +513,7 @@ __device__ __forceinline__ double row_shift4(double x)
 // BW == JQ_BW_T4Q (see the definition above): D = C + M x on the JQ_BW_T4 image.  Alias-safe (D may be C and/or x).
 // This lane's share of an operator: A operand (lane 16 k + 4 b + i holds B_{4 mt + b}[i][k] = element 16 b + 4 k + i of the
 // block's 64 doubles) and the coefficients [mt][g = row in group][r = group][term] of its row (four consecutive doubles).
+typedef double d2 __attribute__((ext_vector_type(2)));
 template <int NT>
 struct OpQ {
     double a[NT];
@@ -510,12 +521,18 @@ struct OpQ {
 };
 __device__ __forceinline__ const double* t4q_a(const double* mat, int lane)
 {
-    return mat - lane + (((lane >> 2) & 3) * 16 + (lane >> 4) * 4 + (lane & 3));
+    return mat;      // (lane 16 k + 4 b + i reads element 16 k + 4 b + i of the block: JQ_T4_AIDX)
 }
+// (this lane's row: g = lane >> 4, r = (lane >> 2) & 3; its terms 0, 1 and, 32 doubles on, its terms 2, 3)
 template <int NT>
-__device__ __forceinline__ const d4* t4q_c(const double* mat, int lane)
+__device__ __forceinline__ const d2* t4q_c(const double* mat, int lane)
 {
-    return (const d4*)(mat - lane + 4 * NT * JQ_T4_TILE + (lane >> 4) * 16 + ((lane >> 2) & 3) * 4);
+    return (const d2*)(mat - lane + 4 * NT * JQ_T4_TILE + ((lane >> 4) * 4 + ((lane >> 2) & 3)) * 2);
+}
+__device__ __forceinline__ d4 t4q_cload(const d2* cf, int mt)
+{
+    const d2 lo = cf[mt * 32], hi = cf[mt * 32 + 16];
+    return (d4){lo[0], lo[1], hi[0], hi[1]};
 }
 // one 16-row block
 template <int NT, bool ZEROC, int MODE>
@@ -542,11 +559,11 @@ __device__ __forceinline__ void mm_t4q(Arr<NT>& D, const Arr<NT>& C, const doubl
     constexpr bool diag = MODE & JQ_T4_DIAG, coef = (MODE & (JQ_T4_RTERMS | JQ_T4_MTERMS)) != 0;
     const int lane = threadIdx.x & 63;
     const double* ma = t4q_a(mat, lane);
-    const d4* cf = t4q_c<NT>(mat, lane);
+    const d2* cf = t4q_c<NT>(mat, lane);
     double a_cur = 0.0;
     d4 c_cur = {0.0, 0.0, 0.0, 0.0};
     if constexpr (diag) a_cur = ma[0];
-    if constexpr (coef) c_cur = cf[0];
+    if constexpr (coef) c_cur = t4q_cload(cf, 0);
     double xold = 0.0;
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt) {
@@ -554,7 +571,7 @@ __device__ __forceinline__ void mm_t4q(Arr<NT>& D, const Arr<NT>& C, const doubl
         const d4 c = c_cur;
         if (mt + 1 < NT) {
             if constexpr (diag) a_cur = ma[(mt + 1) * 64];
-            if constexpr (coef) c_cur = cf[(mt + 1) * 16];
+            if constexpr (coef) c_cur = t4q_cload(cf, mt + 1);
         }
         t4q_block<NT, ZEROC, MODE>(D, C, x, mt, a, c, xold);
     }
@@ -565,11 +582,11 @@ __device__ __forceinline__ void t4q_load(OpQ<NT>& op, const double* mat)
 {
     const int lane = threadIdx.x & 63;
     const double* ma = t4q_a(mat, lane);
-    const d4* cf = t4q_c<NT>(mat, lane);
+    const d2* cf = t4q_c<NT>(mat, lane);
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt) {
         op.a[mt] = ma[mt * 64];
-        op.c[mt] = cf[mt * 16];
+        op.c[mt] = t4q_cload(cf, mt);
     }
 }
 template <int NT>

@@ -99,9 +99,10 @@ static int fail(jq_handle* h, int code, const char* msg)
 static void tile_image(const double* M, int Ntot, int NT, int BW, double* img, bool SD = false)
 {
     if (BW == JQ_BW_T4) {
-        // compact image (JQ_T4_ELEMS doubles): per 4-row group rho its 4x4 diagonal block as [k][i] = M[4 rho + i][4 rho + k]
-        // (lane 16k+4b+i of the MFMA's A operand reads element 4k+i), then the coupling coefficients
-        // [mt][g][r][term: group rho-1, rho+1 (same 16-row block), rho-4, rho+4] <-> row 4 rho + g, rho = 4 mt + r
+        // compact image (JQ_T4_ELEMS doubles): per 16-row block the 4x4 diagonal blocks of its four 4-row groups rho = 4 mt + b,
+        // element JQ_T4_AIDX(rho, k, i) = M[4 rho + i][4 rho + k] (= lane 16 k + 4 b + i of the quad-layout MFMA's A operand), then the
+        // coupling coefficients
+        // per block mt: JQ_T4_CIDX(g, r, term: group rho-1, rho+1 (same 16-row block), rho-4, rho+4) <-> row 4 rho + g, rho = 4 mt + r
         const int NR = 4 * NT;
         for (size_t i = 0; i < (size_t)JQ_T4_ELEMS(NT); ++i) img[i] = 0.0;
         if (!SD)
@@ -109,7 +110,7 @@ static void tile_image(const double* M, int Ntot, int NT, int BW, double* img, b
                 for (int k = 0; k < 4; ++k)
                     for (int i = 0; i < 4; ++i) {
                         const int row = 4 * rho + i, col = 4 * rho + k;
-                        img[rho * JQ_T4_TILE + 4 * k + i] = (row < Ntot && col < Ntot) ? M[row + (size_t)Ntot * col] : 0.0;
+                        img[JQ_T4_AIDX(rho, k, i)] = (row < Ntot && col < Ntot) ? M[row + (size_t)Ntot * col] : 0.0;
                     }
         double* cf = img + (size_t)NR * JQ_T4_TILE;
         for (int rho = 0; rho < NR; ++rho)
@@ -118,7 +119,7 @@ static void tile_image(const double* M, int Ntot, int NT, int BW, double* img, b
                 const int nbr[4] = {r > 0 ? row - 4 : -1, r < 3 ? row + 4 : -1, row - 16, row + 16};
                 for (int t = 0; t < 4; ++t) {
                     const int col = nbr[t];
-                    cf[(rho >> 2) * 64 + g * 16 + r * 4 + t] = (col >= 0 && col < Ntot && row < Ntot) ? M[row + (size_t)Ntot * col] : 0.0;
+                    cf[(rho >> 2) * 64 + JQ_T4_CIDX(g, r, t)] = (col >= 0 && col < Ntot && row < Ntot) ? M[row + (size_t)Ntot * col] : 0.0;
                 }
             }
         return;
