@@ -63,13 +63,13 @@ typedef double d4 __attribute__((ext_vector_type(4)));
                                       // LDS bank conflicts worth 5 % of an evaluation); the slab kernels read elements 16 k + i of a group's slice
 #define JQ_T4_TILE 16                  // doubles per 4-row group in the image: the 4x4 diagonal block (the MFMA's A operand
                                       // repeats it in its four column blocks: lane 16k+4b+i reads element 4k+i, an LDS broadcast)
-#define JQ_T4_COEFS(NT) (64 * (NT))   // doubles after the 4NT blocks: per 16-row block [term pair][g = row in group][r = group][term & 1],
-                                      // terms: couplings to the groups r-1, r+1 (same block), to the blocks mt-1, mt+1
-// element of (g, r, term) in a block's 64 coefficients.  Both readers are free of LDS bank conflicts with it: the slab kernels
-// read one double per lane (lane 16 g + p holds position p = JQ_T4_CPOS(r, term) of row g: 64 distinct doubles), the quad-layout
-// kernels two 16-byte pairs per lane (16 distinct consecutive pairs each; a 32-byte [g][r][4] record per lane conflicted 4-fold)
-#define JQ_T4_CIDX(g, r, t) (((t) >> 1) * 32 + ((g) * 4 + (r)) * 2 + ((t) & 1))
-#define JQ_T4_CPOS(r, t) (8 * ((t) >> 1) + 2 * (r) + ((t) & 1))
+#define JQ_T4_COEFS(NT) (64 * (NT))   // doubles after the 4NT blocks: per 16-row block [g = row in group][r = group][term], terms: couplings
+                                      // to the groups r-1, r+1 (same block), to the blocks mt-1, mt+1.  The slab kernels read one double per
+                                      // lane (lane 16 g + p holds position p = JQ_T4_CPOS(r, term) of row g), the quad-layout kernels the
+                                      // 32-byte record of their row; neither read has LDS bank conflicts (PMC; a [term pair][g][r][2]
+                                      // order was tried for the quad reads: no difference there, 2-way conflicts in the slab reads)
+#define JQ_T4_CIDX(g, r, t) ((g) * 16 + (r) * 4 + (t))
+#define JQ_T4_CPOS(r, t) (4 * (r) + (t))
 #define JQ_T4_ELEMS(NT) (4 * (NT) * JQ_T4_TILE + JQ_T4_COEFS(NT))
 // trace-image modes of this variant (a.bw_trace[q]): bit 0 diagonal 4x4 blocks present, bit 1 r+-1 terms, bit 2 mt+-1 terms
 #define JQ_T4_DIAG 1
@@ -419,7 +419,7 @@ __device__ __forceinline__ void mm_t4(Arr<NT>& D, const Arr<NT>& C, const double
     constexpr int NR = 4 * NT;
     constexpr bool diag = MODE & JQ_T4_DIAG, rt = MODE & JQ_T4_RTERMS, mtm = MODE & JQ_T4_MTERMS;
     const int lane = threadIdx.x & 63;
-    const double* cf = mat - lane + NR * JQ_T4_TILE + (((lane >> 3) & 1) * 32 + (lane >> 4) * 8 + (lane & 7));   // position lane & 15 of row lane >> 4
+    const double* cf = mat + NR * JQ_T4_TILE;     // (lane 16 g + p: position p of row g)
     const double* ma = mat - lane + ((lane >> 4) * 16 + (lane & 3));  // this lane's element (k = lane >> 4, i = lane & 3) of every 4x4 block
     double f[JQ_PF];
     double cq[2];
@@ -523,17 +523,13 @@ __device__ __forceinline__ const double* t4q_a(const double* mat, int lane)
 {
     return mat;      // (lane 16 k + 4 b + i reads element 16 k + 4 b + i of the block: JQ_T4_AIDX)
 }
-// (this lane's row: g = lane >> 4, r = (lane >> 2) & 3; its terms 0, 1 and, 32 doubles on, its terms 2, 3)
+// (this lane's row: g = lane >> 4, r = (lane >> 2) & 3: the record of its four terms)
 template <int NT>
-__device__ __forceinline__ const d2* t4q_c(const double* mat, int lane)
+__device__ __forceinline__ const d4* t4q_c(const double* mat, int lane)
 {
-    return (const d2*)(mat - lane + 4 * NT * JQ_T4_TILE + ((lane >> 4) * 4 + ((lane >> 2) & 3)) * 2);
+    return (const d4*)(mat - lane + 4 * NT * JQ_T4_TILE + JQ_T4_CIDX(lane >> 4, (lane >> 2) & 3, 0));
 }
-__device__ __forceinline__ d4 t4q_cload(const d2* cf, int mt)
-{
-    const d2 lo = cf[mt * 32], hi = cf[mt * 32 + 16];
-    return (d4){lo[0], lo[1], hi[0], hi[1]};
-}
+__device__ __forceinline__ d4 t4q_cload(const d4* cf, int mt) { return cf[mt * 16]; }
 // one 16-row block
 template <int NT, bool ZEROC, int MODE>
 __device__ __forceinline__ void t4q_block(Arr<NT>& D, const Arr<NT>& C, const Arr<NT>& x, int mt, double a, const d4& c, double& xold)
@@ -559,7 +555,7 @@ __device__ __forceinline__ void mm_t4q(Arr<NT>& D, const Arr<NT>& C, const doubl
     constexpr bool diag = MODE & JQ_T4_DIAG, coef = (MODE & (JQ_T4_RTERMS | JQ_T4_MTERMS)) != 0;
     const int lane = threadIdx.x & 63;
     const double* ma = t4q_a(mat, lane);
-    const d2* cf = t4q_c<NT>(mat, lane);
+    const d4* cf = t4q_c<NT>(mat, lane);
     double a_cur = 0.0;
     d4 c_cur = {0.0, 0.0, 0.0, 0.0};
     if constexpr (diag) a_cur = ma[0];
@@ -582,7 +578,7 @@ __device__ __forceinline__ void t4q_load(OpQ<NT>& op, const double* mat)
 {
     const int lane = threadIdx.x & 63;
     const double* ma = t4q_a(mat, lane);
-    const d2* cf = t4q_c<NT>(mat, lane);
+    const d4* cf = t4q_c<NT>(mat, lane);
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt) {
         op.a[mt] = ma[mt * 64];
