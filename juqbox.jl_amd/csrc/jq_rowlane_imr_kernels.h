@@ -152,7 +152,12 @@ __global__ __launch_bounds__(64) void k_backward_rowlane_imr(PropArgs a)
     extern __shared__ double lds_c[];
     constexpr bool RESIDENT = (NPJ <= 8);
     if (!RESIDENT) {
-        for (int i = lane; i < 2 * Nc * (int)a.stride; i += 64) lds_c[i] = a.cimg[i];
+        // transposed copy [image][column j][row]: the 16 lanes of an LDS pass read 16 consecutive doubles (the [row][j] order of the
+        // global image gave these reads 4-way bank conflicts at NPJ = 12: 75 % of the LDS cycles)
+        for (int i = lane; i < 2 * Nc * (int)a.stride; i += 64) {
+            const int im = i / (int)a.stride, e = i - im * (int)a.stride;
+            lds_c[im * (int)a.stride + (e % NPJ) * 16 + e / NPJ] = a.cimg[i];
+        }
         __syncthreads();
     }
     RowMat<NPJ> Hs[JQ_MAXNC], Ha[JQ_MAXNC];

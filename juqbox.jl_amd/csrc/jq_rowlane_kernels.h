@@ -45,9 +45,9 @@ template <int NPJ>
 __device__ __forceinline__ RowMat<NPJ> row_load_lds(const double* img, int row)
 {
     RowMat<NPJ> m;
-    const double* p = img + row * NPJ;
+    const double* p = img + row;       // [column j][row] (see the copy loops)
 #pragma unroll
-    for (int j = 0; j < NPJ; ++j) m.r[j] = p[j];
+    for (int j = 0; j < NPJ; ++j) m.r[j] = p[j * 16];
     return m;
 }
 
@@ -190,7 +190,12 @@ __global__ __launch_bounds__(64) void k_backward_rowlane(PropArgs a)
     constexpr bool RESIDENT = (NPJ <= 8);
     extern __shared__ double lds_c[];
     if (!RESIDENT) {
-        for (int i = lane; i < 2 * Nc * (int)a.stride; i += 64) lds_c[i] = a.cimg[i];
+        // transposed copy [image][column j][row]: the 16 lanes of an LDS pass read 16 consecutive doubles (the [row][j] order of the
+        // global image gave these reads 4-way bank conflicts at NPJ = 12: 75 % of the LDS cycles)
+        for (int i = lane; i < 2 * Nc * (int)a.stride; i += 64) {
+            const int im = i / (int)a.stride, e = i - im * (int)a.stride;
+            lds_c[im * (int)a.stride + (e % NPJ) * 16 + e / NPJ] = a.cimg[i];
+        }
         __syncthreads();
     }
     RowMat<NPJ> Hs[JQ_MAXNC], Ha[JQ_MAXNC];
