@@ -4,10 +4,11 @@
 //              3: lane kernels (one lane per column; JQ_NT = padded Hilbert dimension NP, JQ_BW unused)
 //              6: cooperative kernels of the implicit-midpoint integrator
 //              7: quad-layout kernels of the implicit-midpoint integrator (JQ_BW = 7)
+//              8: quad-layout slab kernels with 1 and 2 slabs per workgroup (JQ_BW = 7; variant 0 holds the 3-slab ones)
 //              5: row-lane kernels of the implicit-midpoint integrator (JQ_NT = NPJ)
 //              4: row-lane kernels (one lane per (row, column); JQ_NT = padded row length NPJ, JQ_BW unused)
 #if !defined(JQ_NT) || !defined(JQ_BW) || !defined(JQ_VARIANT)
-#error "compile with -DJQ_NT=<tiles> -DJQ_BW=<band> -DJQ_VARIANT=<0..7>"
+#error "compile with -DJQ_NT=<tiles> -DJQ_BW=<band> -DJQ_VARIANT=<0..8>"
 #endif
 #if JQ_VARIANT == 7
 #include "jq_quad_imr_kernels.h"
@@ -38,11 +39,12 @@ template __global__ void k_backward_coop<JQ_NT, JQ_BW>(PropArgs);
 #else
 #include "jq_kernels.h"
 #define JQ_MINW ((JQ_NT <= 2) ? 2 : 1)
-#if JQ_BW == 7     // quad layout: workgroups of four waves (one slab) and of eight waves (two slabs, two waves per SIMD)
+#if JQ_BW == 7 && JQ_VARIANT == 8   // quad layout, workgroups of 4 / 8 waves (1 / 2 slabs): built with the max-ILP scheduler (Makefile)
 template __global__ void k_forward<JQ_NT, JQ_BW, 1, false>(PropArgs);
 template __global__ void k_backward<JQ_NT, JQ_BW, 1, false>(PropArgs);
 template __global__ void k_forward<JQ_NT, JQ_BW, 2, false>(PropArgs);
 template __global__ void k_backward<JQ_NT, JQ_BW, 2, false>(PropArgs);
+#elif JQ_BW == 7                    // quad layout, workgroups of 12 waves (3 slabs, 168 registers per wave): default scheduler
 template __global__ void k_forward<JQ_NT, JQ_BW, 3, false>(PropArgs);
 template __global__ void k_backward<JQ_NT, JQ_BW, 3, false>(PropArgs);
 #else
