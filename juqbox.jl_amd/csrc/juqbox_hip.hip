@@ -530,7 +530,16 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         // (1, 2, 3 waves per SIMD; one workgroup per CU because of the LDS).  run_eval picks the variant -- or the slab
         // kernels -- by the number of rounds the batch needs (quad_plan).  JQ_QUAD=0 disables them, JQ_QUAD=<n> limits them to
         // batches of at most n slabs.
-        h->quad_max_slabs = (h->BW == JQ_BW_T4 && h->batch < 0) ? (1 << 30) : 0;
+        // (they always use the window staging and need less LDS next to it than the slab kernels -- a register per 16-row block
+        // to park -- so they are also available when the slab kernels have to fall back to the per-operator ring: Ntot > 80, Nc = 4)
+        {
+            const long long win = (2LL * JQ_WIN_TPS + 2LL * h->Nc) * slot;
+            const long long quad_fixed = lds_fwd_fixed + (long long)JQ_MAXNC * 256 * 8 + (long long)JQ_WAVES * h->NT * 64 * 8;
+            bool w = h->BW == JQ_BW_T4 && win + quad_fixed <= 163840;
+            if (const char* e = getenv("JQ_WINDOW"))
+                if (atoi(e) == 0) w = false;
+            h->quad_max_slabs = w ? (1 << 30) : 0;
+        }
         h->num_cu = prop.multiProcessorCount;
         if (const char* e = getenv("JQ_QUAD"))
             if (h->quad_max_slabs > 0) h->quad_max_slabs = atoi(e);
@@ -994,18 +1003,23 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     int spw = 0;
     if (!imr && !lane && !rl && h->solver_id == 1 && nslabs <= h->quad_max_slabs) {
         const double rel[4] = {1.0, 0.34, 0.50, 0.68};
-        const size_t quad_lds3 = (size_t)(2 * JQ_WIN_TPS + 2 * h->Nc) * h->mat_elems * 8 + (size_t)32 * h->NT * 8 +
-                                 (size_t)JQ_MAXNC * 768 * 8 + (size_t)12 * h->NT * 64 * 8;
+        auto quad_lds = [&](int k) {    // backward kernel, k slabs per workgroup
+            return (size_t)(2 * JQ_WIN_TPS + 2 * h->Nc) * h->mat_elems * 8 + (size_t)32 * h->NT * 8 + (size_t)JQ_MAXNC * 256 * k * 8 +
+                   (size_t)4 * k * h->NT * 64 * 8;
+        };
         double best = rel[0] * ((nslabs + 4 * h->num_cu - 1) / (4 * h->num_cu));
         for (int k = 1; k <= 3; ++k) {
-            if (k == 3 && quad_lds3 > 163840) continue;
+            if (quad_lds(k) > 163840) continue;
             const double c = rel[k] * ((nslabs + k * h->num_cu - 1) / (k * h->num_cu));
             if (c < best - 1e-9) {
                 best = c;
                 spw = k;
             }
         }
-        if (const char* e = getenv("JQ_QUAD8")) spw = std::max(1, std::min(3, atoi(e) + 1));      // experiments: force 4 / 8 / 12 waves
+        if (const char* e = getenv("JQ_QUAD8")) {      // experiments / tests: force 4 / 8 / 12 waves (as far as the LDS allows)
+            spw = std::max(1, std::min(3, atoi(e) + 1));
+            while (spw > 1 && quad_lds(spw) > 163840) --spw;
+        }
     }
     if (imr_quad) spw = 1;
     const bool quad = spw > 0;
@@ -1119,7 +1133,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     for (int q = 0; q < JQ_MAXNC; ++q) a.bw_trace[q] = h->bw_trace[q];
     // dynamic LDS layout: [operator staging | tables wd, ws | (backward: carry, parking images)]
     // cooperative kernels: [two operator slots | tables wd, ws | two x exchange buffers]
-    const int batch = coop ? 0 : h->batch;
+    const int batch = coop ? 0 : quad ? -1 : h->batch;
     const size_t lds_stage = batch > 0   ? (size_t)2 * (2 * batch + 1) * 2 * stride * 8 + (size_t)2 * h->Nc * stride * 8
                              : batch < 0 ? (size_t)(2 * JQ_WIN_TPS + 2 * h->Nc) * stride * 8
                                          : (size_t)2 * stride * 8;
@@ -1129,7 +1143,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
                                 : quad ? lds_fwd + (size_t)JQ_MAXNC * nthreads * 8 + (size_t)(nthreads / 64) * h->NT * 64 * 8   // (a 16-row block per register)
                                 : lds_fwd + (size_t)JQ_MAXNC * 256 * 8 + (h->park_lds ? (size_t)JQ_WAVES * h->KT * 64 * 8 : 0);
     a.batch = batch; a.lds_tab_off = (int)lds_stage;
-    a.park = h->d_park; a.park_lds = h->park_lds;
+    a.park = h->d_park; a.park_lds = quad ? 1 : h->park_lds;
     if (const char* e = getenv("JQ_DEBUG")) a.debug = atoi(e);
     if (!lane && !rl) {
         HIPCHK(h, hipFuncSetAttribute((const void*)kfwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fwd));

@@ -142,7 +142,7 @@ def test_random_problem_matches_oracle(jq, cfg, mode):
     Ntot, N, Nc, Nfreq, nsteps, m, oft, banded, chunk = cfg
     if (mode == "lane" and Ntot > 8) or (mode == "nolane" and Ntot > 16):
         pytest.skip("lane kernels only exist for Ntot <= 8, row-lane kernels for Ntot <= 16")
-    if mode in ("quad8", "quad12") and (banded != "t4" or Ntot <= 16 or (Ntot == 96 and Nc == 4)):
+    if mode in ("quad8", "quad12") and (banded != "t4" or Ntot <= 16):
         pytest.skip("quad8 / quad12: the JQ_BW_T4 problems on the quad-layout kernels with two / three slabs per workgroup (JQ_QUAD8)")
     if mode == "coop" and (banded != "t4" or Ntot <= 16):
         pytest.skip("coop: the JQ_BW_T4 problems (auto: quad-layout kernels) once more on the cooperative kernels (JQ_QUAD=0)")
@@ -189,9 +189,7 @@ def test_random_problem_matches_oracle(jq, cfg, mode):
     if mode in ("quad8", "quad12"):
         assert wa.last_timing()["kernel_family"] == 6
     if banded == "t4" and Ntot > 16 and mode in ("auto", "coop"):
-        # (quad-layout kernels need the window staging: five time points + 2 Nc constant images in LDS; not at Ntot = 96, Nc = 4)
-        fam = wa.last_timing()["kernel_family"]
-        assert fam == (6 if mode == "auto" and (Ntot < 96 or Nc < 4) else 1)
+        assert wa.last_timing()["kernel_family"] == (6 if mode == "auto" else 1)
     # per-step states
     _, hist, _ = jq.traceobjgrad(pcof, p, wa, True, False)
     assert np.max(np.abs(hist - r["history"])) < 1e-10
