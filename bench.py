@@ -1,161 +1,279 @@
 #!/usr/bin/env python3
 """bench.py -- traceobjgrad evals/sec (forward + discrete adjoint) at the cnot3 Hilbert dimension.
 
-One "step" = one eval_f_g_grad pass of the hot path over the rank's batch of ensemble samples
-(every sample is one full traceobjgrad evaluation of test/cases/cnot3-setup.jl: Ntot=96, N=4,
-32 386 Stormer-Verlet steps, 6 Neumann terms, golden pcof).  Inputs (operators, pcof, ensemble
-nodes) are resident in HBM when the timed region starts.  Weak scaling: every rank (GPU) gets
---samples-per-gpu samples; the four weighted sums are combined with ONE all-reduce (RCCL).
+One "step" = one eval_f_g_grad pass of the hot path over the job's batch of ensemble samples (every sample is one
+full traceobjgrad evaluation of test/cases/cnot3-setup.jl: Ntot=96, N=4, 32 386 Stormer-Verlet steps, 6 Neumann
+terms, golden pcof).  Inputs (operators, pcof, ensemble nodes) are resident in HBM when the timed region starts.
+
+Launch modes
+  python bench.py --gpus 1                       one process, one GPU
+  python bench.py --gpus N        (N > 1)        this process starts N ranks FIRST (torch.distributed.run, one process
+                                                 per GPU, RCCL) -- before it touches any GPU -- and relays their line
+  python -m torch.distributed.run ... bench.py --gpus N     the driver's form: RANK/WORLD_SIZE come from the environment
+                                                 and must agree with --gpus
+  python bench.py --gpus N --single-process      ONE process drives N GPUs through a multi-device library handle
+                                                 (jq_create_multi: RCCL all-reduce inside libjuqbox_hip.so)
+`value` is weak scaling (--samples-per-gpu samples on every GPU, ONE all-reduce of the packed sums per step); the
+strong-scaling figure on a fixed 24 576-sample ensemble is reported beside it (`strong_scaling`).
 
 Prints ONE JSON line on rank 0 (see the contract in the repository brief)."""
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak: 256 CU x 4 SIMD x 32 FLOP/clk x 2.4 GHz
                                # (v_mfma_f64_16x16x4_f64 issues every 64 clk; measured 75.4 TF, probes/)
+STRONG_TOTAL_SAMPLES = 24576   # fixed ensemble of the strong-scaling run = 8 GPUs x one full round (3072 samples) each
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     # 3072 samples = 768 slabs of 16 columns = three slabs on each of the 256 CUs: one round of the kernels that are fastest
-    # for large ensembles (quad layout, 12 waves per workgroup).  Other sizes run too (4096 = one round of the slab kernels,
-    # reported below as `other_batch_sizes`); the library picks the kernels per batch size.
+    # for large ensembles (quad layout, 12 waves per workgroup).  Other sizes run too (reported as `other_batch_sizes`).
     ap.add_argument("--samples-per-gpu", type=int, default=int(os.environ.get("JQ_BENCH_SAMPLES", "3072")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-extras", action="store_true", help="skip everything outside the timed region (profiling runs)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="one process, --gpus devices behind one multi-device handle (RCCL inside the library)")
+    ap.add_argument("--strong-samples", type=int, default=STRONG_TOTAL_SAMPLES)
+    return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """--gpus N > 1 without a launcher: start N ranks (one process per GPU) before this process touches a GPU, relay
+    the children's output and return their exit code."""
+    import torch                                   # (counting devices does not initialise the GPU)
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d requested but only %d GPU(s) are visible -- refusing to report a %d-GPU "
+                         "number from fewer devices\n" % (args.gpus, ndev, args.gpus))
+        return 2
+    port = 29500 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def cpu_baseline(params, pcof, nrep=2):
+    """The oracle (C restatement of the reference's sparse Stormer-Verlet path, golden-validated) timed on this box's
+    host cores: one core like the reference's serial loop, and all cores over independent samples."""
+    from oracle.oracle import Oracle
+    orc = Oracle(params)                      # sparse products like the reference's use_sparse=true
+    t1 = time.perf_counter()
+    for _ in range(nrep):
+        orc.traceobjgrad(pcof)
+    tc = (time.perf_counter() - t1) / nrep
+    out = {"value": 1.0 / tc, "unit": "evals/s", "cores": 1, "kind": "port",
+           "sample": "%d x one cnot3 traceobjgrad (1 sample = 4 columns x 32386 steps), C restatement of the reference's "
+                     "sparse Stormer-Verlet path, single thread like the reference" % nrep,
+           "seconds_per_eval": tc, "host_cores_available": os.cpu_count()}
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    try:      # all cores: one independent evaluation per core (fresh processes: nothing here forks a GPU process)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_ensemble.py"), "--procs", str(ncores)],
+                           capture_output=True, text=True, timeout=300)
+        j = json.loads(r.stdout.strip().splitlines()[-1])
+        out["all_cores"] = {"value": j["evals_per_s"], "unit": "evals/s", "cores": j["procs"],
+                            "sample": "%d concurrent processes x one cnot3 traceobjgrad each (independent ensemble samples)"
+                                      % j["procs"], "seconds": j["seconds"]}
+    except Exception as e:  # noqa: BLE001 -- a reported baseline must not take the bench down
+        out["all_cores"] = {"error": str(e)[:200]}
+    return out
+
+
+def main():
+    args = parse_args()
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched and not args.single_process:
+        sys.exit(spawn_ranks(args))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if launched and world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d does not match WORLD_SIZE=%d of the launcher\n" % (args.gpus, world))
+        sys.exit(2)
+    if args.single_process and launched and world > 1:
+        sys.stderr.write("bench.py: --single-process cannot run under a multi-rank launcher\n")
+        sys.exit(2)
 
+    import numpy as np
     import torch
     import juqbox_jl_amd as jq
     from juqbox_jl_amd import _lib
     from juqbox_jl_amd.ipopt_interface import shard_bounds
 
     L = _lib.load()
+    ndev_visible = L.jq_device_count()
+    ngpus = args.gpus                                  # GPUs of the whole job
+    if args.single_process:
+        if ndev_visible < ngpus:
+            sys.stderr.write("bench.py: --gpus %d requested but only %d GPU(s) are visible\n" % (ngpus, ndev_visible))
+            sys.exit(2)
+    elif ndev_visible <= local_rank:
+        sys.stderr.write("bench.py: rank %d has no GPU (%d visible)\n" % (rank, ndev_visible))
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     _lib.check(L.jq_set_device(local_rank))
     dist = None
-    if world > 1 or "RANK" in os.environ:     # launched by torch.distributed.run (also with one rank)
+    if launched:                                       # launched by torch.distributed.run (also with one rank)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     params, info = jq.cases.cnot3()
     pcof = np.array(json.load(open(os.path.join(ROOT, "tests", "golden", "cnot3.json")))["pcof0"])
-    nsamples_total = args.samples_per_gpu * world
+    nsamples_total = args.samples_per_gpu * ngpus
     nodes, weights, shift = jq.cases.cnot3_ensemble(nsamples_total)
-    wa = jq.Working_Arrays_HIP(params, pcof.size)
+    wa = jq.Working_Arrays_HIP(params, pcof.size, devices=ngpus if args.single_process else None)
 
     def step():
         jq.eval_f_g_grad(pcof, params, wa, nodes, weights, True, shift=shift)
 
+    def sync_all():
+        for d in range(ngpus if args.single_process else 1):
+            torch.cuda.synchronize(d if args.single_process else local_rank)
+
     def fence():
-        torch.cuda.synchronize()
+        sync_all()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync_all()
+
+    def timed(fn, nsteps):
+        """barrier + synchronize, nsteps x fn, barrier + synchronize; MAX over ranks of the elapsed time"""
+        fence()
+        t0 = time.perf_counter()
+        acc = []
+        for _ in range(nsteps):
+            fn()
+            acc.append(wa.last_timing())
+        fence()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, acc
 
     for _ in range(args.warmup):
         step()
-    fence()
-    t0 = time.perf_counter()
-    prop_ms = bwd_ms = fwd_ms = 0.0
-    nb = nf = 0
-    mfma = 0
-    tm = {}
-    for _ in range(args.steps):
-        step()
-        tm = wa.last_timing()
-        prop_ms += tm["ms_propagate"]
-        bwd_ms += tm["ms_backward"]
-        fwd_ms += tm["ms_forward"]
-        nb += tm["n_backward_launches"]
-        nf += tm["n_forward_launches"]
-        mfma += tm["mfma_executed"]
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, tms = timed(step, args.steps)
+    prop_ms = sum(t["ms_propagate"] for t in tms)
+    bwd_ms = sum(t["ms_backward"] for t in tms)
+    fwd_ms = sum(t["ms_forward"] for t in tms)
+    nb = sum(t["n_backward_launches"] for t in tms)
+    mfma = sum(t["mfma_executed"] for t in tms)
+    mfma_bwd = sum(t["mfma_backward"] for t in tms)
+    tm = tms[-1]
+    infid_weak = params.last_infidelity
+
+    # ---- strong scaling: a FIXED ensemble split over the job's GPUs (outside the timed region of `value`) ------------
+    strong = None
+    if not args.no_extras:
+        ns = args.strong_samples
+        n2, w2, s2 = jq.cases.cnot3_ensemble(ns)
+
+        def strong_step():
+            jq.eval_f_g_grad(pcof, params, wa, n2, w2, True, shift=s2)
+        strong_step()                                   # (buffers grow to the shard size here)
+        el2, tms2 = timed(strong_step, 1)
+        strong = {"total_samples": ns, "samples_per_gpu": ns // ngpus, "seconds": el2, "evals_per_s": ns / el2,
+                  "note": "fixed ensemble, block-partitioned over the GPUs, one all-reduce; compare evals_per_s across n_gpus"}
 
     if rank == 0:
         evals = nsamples_total * args.steps
         value = evals / elapsed
         Ntot, N, Nc, m, nsteps = params.Ntot, params.N, params.Ncoupled, params.linear_solver.max_iter, params.nsteps
-        lo, hi = shard_bounds(nsamples_total, 0, world)
-        svts_rank = (hi - lo) * N * nsteps * args.steps
-        f_bwd = 2.0 * Ntot * Ntot * (2 * (9 + 2 * m) + 7 * Nc)                 # algorithmic dense FLOP / SVTS, backward sweep
+        lo, hi = shard_bounds(nsamples_total, 0, ngpus)
+        svts_rank = (hi - lo) * N * nsteps * args.steps                      # SURVEY.md section 8(d), one GPU's share
+        f_bwd = 2.0 * Ntot * Ntot * (2 * (9 + 2 * m) + 7 * Nc)                 # dense-contraction FLOP / SVTS, backward sweep
         f_fwd = 2.0 * Ntot * Ntot * (9 + 2 * m)
-        # dominant kernel = k_backward<6>: algorithmic FLOPs per launch / average launch duration (HIP events
-        # recorded on the library's stream around every launch, jq_last_timing)
-        flops_per_launch = f_bwd * svts_rank / max(nb, 1)
         avg_launch_s = bwd_ms * 1e-3 / max(nb, 1)
-        achieved = flops_per_launch / avg_launch_s / 1e12
-        # HBM bytes per k_backward launch from the PMC passes kept under profiles/ (FETCH_SIZE x2 gfx950 correction
-        # + WRITE_SIZE, separate rocprofv3 --pmc runs of this same command; null if not measured for this build)
-        # the library reports which propagator family / instantiation ran (jq_timing.kernel_*)
         fam = {0: "k_backward", 1: "k_backward_coop", 2: "k_backward_lane", 3: "k_backward_rowlane", 6: "k_backward"}.get(tm.get("kernel_family", 0))
         kname = "%s<%d, %d>" % (fam, tm.get("kernel_size", 0), tm.get("kernel_band", 0))
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
-            traffic = tj["kernels"][kname]["hbm_bytes_per_launch"]
-        except Exception:
-            pass
         band = tm.get("kernel_band")
         band_note = {9: " (band 9 = block tridiagonal with diagonal off-diagonal blocks)",
                      8: " (band 8 = 4x4 diagonal blocks on v_mfma_f64_4x4x4 + diagonal couplings on DPP FMAs)",
                      7: " (band 7 = the band-8 product in the quad layout: four columns per wave, a 16-row block per register; "
                         "%d waves per workgroup)" % (4 * max(1, round(args.samples_per_gpu * N / 16 / 256)) if args.samples_per_gpu * N / 16 <= 768 else 12)}.get(band, "")
-        # arithmetic the kernels really execute (they skip the structural zeros the dense count includes): matrix pipe
-        # from the library's MFMA count; for band 8 also the coupling FMAs of the products (6 NT + 8 (NT - 1) v_fma_f64
-        # of 64 lanes per product, one product per 4 NT of the 512-FLOP MFMAs)
+        # ---- roofline of the dominant kernel (k_backward): EXECUTED fp64 matrix FLOP / HIP-event time / matrix peak.
+        # The kernels skip the structural zeros of the operators, so the executed arithmetic -- not the dense-contraction
+        # count of SURVEY.md 8(d), which would exceed the peak -- is what the fraction is made of.  MFMA instruction
+        # count: rocprofv3 PMC (SQ_INSTS_MFMA) of this build when profiles/ holds one, else the library's analytic count.
         NT = (Ntot + 15) // 16
-        executed_mfma = mfma * 2048.0
-        fma_per_product = (6 * NT + 8 * (NT - 1)) if band == 8 else 4 * (4 * NT - 2) if band == 7 else 0     # per slab of 16 columns
-        executed_fma = (mfma * 4.0 / (4 * NT)) * fma_per_product * 128.0
+        flop_per_mfma = 2048.0                          # jq_timing counts in units of one v_mfma_f64_16x16x4 (4 x v_mfma_f64_4x4x4_4b)
+        mfma_src = "analytic (library count)"
+        pmc = {}
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
+            pk = pj["kernels"].get(kname)
+            if pk and pj.get("library_version") == L.jq_version().decode() and pk.get("samples_per_gpu") == args.samples_per_gpu:
+                pmc = pk
+        except Exception:  # noqa: BLE001
+            pass
+        mfma_bwd_per_launch = mfma_bwd / max(nb, 1)
+        if pmc.get("mfma_16x16x4_equiv_per_launch"):
+            mfma_bwd_per_launch = pmc["mfma_16x16x4_equiv_per_launch"]
+            mfma_src = "rocprofv3 PMC SQ_INSTS_MFMA (profiles/r02_pmc.json)"
+        achieved = mfma_bwd_per_launch * flop_per_mfma / avg_launch_s / 1e12
+        # coupling FMAs of the products (v_fma_f64 of 64 lanes): 6 NT + 8 (NT - 1) per product and slab in the slab layout,
+        # 4 (4 NT - 2) in the quad layout; one product per 4 NT of the 512-FLOP MFMAs
+        fma_per_product = (6 * NT + 8 * (NT - 1)) if band == 8 else 4 * (4 * NT - 2) if band == 7 else 0
+        executed_fma_bwd = (mfma_bwd_per_launch * 4.0 / (4 * NT)) * fma_per_product * 128.0
+        frac = achieved / FP64_MFMA_PEAK_TFLOPS
+        assert frac <= 1.0, "roofline fraction above 1: the MFMA count or the peak is wrong"
         roofline = {"bound": "mfma", "kernel": kname + band_note,
-                    "achieved_definition": "dense-contraction FLOPs of SURVEY.md 8(d) (2 Ntot^2 per product and column: what a dense "
-                                           "formulation computes) / HIP-event time of the kernel; the kernels skip the structural zeros "
-                                           "of the operators, so this exceeds the matrix peak (frac > 1) -- executed_* is the arithmetic "
-                                           "really issued",
-                    "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                    "traffic_unit": "HBM bytes per launch (PMC)",
-                    "mfma_pipe_util": mfma * 2048.0 / (prop_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                    "achieved_definition": "EXECUTED fp64 MFMA FLOP of one k_backward launch (v_mfma_f64_4x4x4_4b x 512 FLOP; "
+                                           "structural zeros are skipped, not counted) / average HIP-event duration of the launch",
+                    "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": frac,
+                    "mfma_count_source": mfma_src,
+                    "traffic": pmc.get("hbm_bytes_per_launch"), "traffic_unit": "HBM bytes per launch (PMC)",
+                    "valu_per_mfma": pmc.get("valu_per_mfma"), "wait_frac": pmc.get("wait_frac"),
+                    "wait_inst_frac": pmc.get("wait_inst_frac"),
                     "launches": int(nb), "avg_launch_ms": avg_launch_s * 1e3,
-                    "all_propagators_tflops": (f_bwd + f_fwd) * svts_rank / (prop_ms * 1e-3) / 1e12,
-                    "executed_mfma_tflops": executed_mfma / (prop_ms * 1e-3) / 1e12,
-                    "executed_valu_fma_tflops": executed_fma / (prop_ms * 1e-3) / 1e12,
-                    "executed_frac_of_fp64_peak": (executed_mfma + executed_fma) / (prop_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                    "frac_incl_coupling_fma": (achieved + executed_fma_bwd / avg_launch_s / 1e12) / FP64_MFMA_PEAK_TFLOPS,
+                    "dense_equivalent_tflops": f_bwd * svts_rank / max(nb, 1) / avg_launch_s / 1e12,
+                    "dense_equivalent_note": "2 Ntot^2 FLOP per product and column (SURVEY.md 8(d)): what a dense formulation "
+                                             "would have to execute for the same result; not a hardware utilisation",
+                    "all_propagators_mfma_frac": mfma * flop_per_mfma / (prop_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                     "forward_ms": fwd_ms, "backward_ms": bwd_ms}
         out = {"metric": "traceobjgrad evals/sec (fwd+adjoint), cnot3 Hilbert dim", "value": value,
-               "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "unit": "evals/s", "n_gpus": ngpus, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": "cnot3 (test/cases/cnot3-setup.jl: Ntot=96, N=4, nsteps=32386, 6 Neumann terms, "
                                       "golden pcof) x risk-neutral ensemble of %d samples per GPU" % args.samples_per_gpu,
                           "samples_per_gpu": args.samples_per_gpu, "columns_per_gpu": args.samples_per_gpu * N,
-                          "svts_per_step_all_gpus": nsamples_total * N * nsteps, "parallelism": "ensemble-dp%d" % world},
+                          "svts_per_step_all_gpus": nsamples_total * N * nsteps, "parallelism": "ensemble-dp%d" % ngpus,
+                          "launcher": ("one process, %d devices behind one jq_create_multi handle (RCCL all-reduce inside the "
+                                       "library)" % wa.num_devices) if args.single_process else
+                                      ("torch.distributed: %d rank(s), one process per GPU, backend %s"
+                                       % (dist.get_world_size(), dist.get_backend()) if dist is not None else "one process, one GPU"),
+                          "ranks": world, "rccl_world_size": dist.get_world_size() if dist is not None else
+                                      (wa.num_devices if args.single_process else 1)},
                "svts_per_s": nsamples_total * N * nsteps * args.steps / elapsed,
+               "ensemble_infidelity": infid_weak,
                "roofline": roofline}
-        if world == 1 and not args.no_cpu_baseline:
-            # outside the timed region: the latency of ONE evaluation (what an Ipopt iteration of the reference waits for;
-            # quad-layout kernels) next to the CPU figure below -- not part of `value`
+        if strong is not None:
+            out["strong_scaling"] = strong
+        if ngpus == 1 and not args.no_extras:
+            # outside the timed region: the latency of ONE evaluation and of the reference's 9-node ensemble
+            # (examples/Risk_Neutral/run_all.jl:134) -- what an Ipopt iteration of the reference waits for -- next to the
+            # CPU figures below; not part of `value`
             jq.traceobjgrad(pcof, params, wa, False, True)
             t1 = time.perf_counter()
             jq.traceobjgrad(pcof, params, wa, False, True)
@@ -163,6 +281,12 @@ def main():
             ts = wa.last_timing()
             out["single_evaluation"] = {"seconds": time.perf_counter() - t1, "ms_propagate": ts["ms_propagate"],
                                         "kernel_family": ts["kernel_family"], "kernel_band": ts["kernel_band"]}
+            n9, w9, s9 = jq.cases.cnot3_ensemble(9)
+            jq.eval_f_g_grad(pcof, params, wa, n9, w9, True, shift=s9)
+            t1 = time.perf_counter()
+            jq.eval_f_g_grad(pcof, params, wa, n9, w9, True, shift=s9)
+            out["nine_node_ensemble"] = {"seconds": time.perf_counter() - t1, "evals_per_s": 9 / (time.perf_counter() - t1),
+                                         "kernel_family": wa.last_timing()["kernel_family"]}
             other = {}
             for ns in (4096, 6144):
                 if ns == args.samples_per_gpu:
@@ -173,17 +297,8 @@ def main():
                 other[str(ns)] = {"evals_per_s": ns / (t2["ms_total"] * 1e-3), "ms": t2["ms_total"], "kernel_family": t2["kernel_family"],
                                   "kernel_band": t2["kernel_band"]}
             out["other_batch_sizes"] = other
-            from oracle.oracle import Oracle
-            orc = Oracle(params)                      # sparse products like the reference's use_sparse=true
-            nrep = 2
-            t1 = time.perf_counter()
-            for _ in range(nrep):
-                orc.traceobjgrad(pcof)
-            tc = (time.perf_counter() - t1) / nrep
-            out["cpu_baseline"] = {"value": 1.0 / tc, "unit": "evals/s", "cores": 1, "kind": "port",
-                                   "sample": "%d x one cnot3 traceobjgrad (1 sample = 4 columns x 32386 steps), C restatement "
-                                             "of the reference's sparse Stormer-Verlet path, single thread like the reference" % nrep,
-                                   "seconds_per_eval": tc, "host_cores_available": os.cpu_count()}
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(params, pcof)
         print(json.dumps(out), flush=True)
     wa.close()
     if dist is not None:

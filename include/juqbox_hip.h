@@ -19,7 +19,8 @@
  *    the message.  No C++ exception crosses this boundary.
  *  - one handle = one in-flight call (not re-entrant), like the reference's single-threaded use.
  *  - the handle is bound to the HIP device that was current when jq_create() ran
- *    (jq_set_device() selects it; one process per GPU under torch.distributed / RCCL).
+ *    (jq_set_device() selects it; one process per GPU under torch.distributed / RCCL), or to the
+ *    devices given to jq_create_multi() (one process, several GPUs, RCCL inside the library).
  */
 #ifndef JUQBOX_HIP_H
 #define JUQBOX_HIP_H
@@ -83,6 +84,7 @@ typedef struct jq_timing {
     int32_t kernel_band;    /* block band of the MFMA families (9 = JQ_BW_OD: diagonal off-diagonal blocks,
                                8 = JQ_BW_T4: 4x4 diagonal blocks + diagonal couplings, 7 = the same, quad layout) */
     int32_t reserved;
+    int64_t mfma_backward;  /* the part of mfma_executed issued by the k_backward launches                  */
 } jq_timing;
 
 /* ---- lifetime --------------------------------------------------------------------------------*/
@@ -94,6 +96,28 @@ int jq_create(const jq_problem *problem, jq_handle **out);
 void jq_destroy(jq_handle *h);
 /* Message of the last failing call on `h` (h == NULL: last jq_create failure of this thread). */
 const char *jq_last_error(const jq_handle *h);
+
+/*
+ * Multi-device handle: ONE process drives `ndev` GPUs of a node -- what the single-threaded Julia caller of
+ * eval_f_g_grad! (src/ipopt_interface.jl:38-65: a serial loop over the quadrature nodes) needs to use 8 GPUs without
+ * MPI.  devices: `ndev` distinct HIP device ids, or NULL for 0..ndev-1.  Every entry point below accepts such a handle:
+ *   jq_eval_f_g_grad   block-partitions the nquad nodes over the devices (jq_shard_bounds), evaluates the shards
+ *                      concurrently and sums the packed results with ONE ncclAllReduce (RCCL over xGMI, sum, fp64);
+ *   jq_traceobj_sweep  partitions the nodes the same way (independent outputs: no collective);
+ *   jq_traceobjgrad / jq_state_history / jq_state_populations (ONE evaluation: not shardable) run on the first device;
+ *   jq_set_* / jq_update_* apply to every device.
+ * librccl.so is loaded at run time by this call (JQ_EUNSUPPORTED if it cannot be found); single-device users never
+ * need it.  Errors: JQ_EINVAL if ndev < 1, ndev > jq_device_count() or a device id repeats.
+ */
+int jq_create_multi(const jq_problem *problem, const int32_t *devices, int32_t ndev, jq_handle **out);
+/* number of GPUs behind a handle (1 for jq_create handles) */
+int jq_num_devices(const jq_handle *h);
+/*
+ * The contiguous block partition of `nquad` ensemble samples over `world` shards (devices of a multi-device handle, or
+ * the ranks of a torch.distributed / MPI job with one process per GPU): shard `rank` owns samples [*lo, *hi); the first
+ * nquad % world shards get one sample more.  Pure host arithmetic (no GPU needed).
+ */
+int jq_shard_bounds(int32_t nquad, int32_t rank, int32_t world, int32_t *lo, int32_t *hi);
 
 /* ---- mutations scripts apply to `params` after construction ----------------------------------*/
 /* params.linear_solver.max_iter = m (estimate_Neumann!, src/evalobjgrad.jl:2922-2925) */
@@ -135,6 +159,12 @@ int jq_traceobjgrad(jq_handle *h, const double *pcof, int32_t ncoeff, int32_t ev
  * :1031 as usaver + im*usavei): ur/ui are [Ntot x N x (nsteps+1)], ui = -vi.
  */
 int jq_state_history(jq_handle *h, const double *pcof, int32_t ncoeff, double *ur, double *ui);
+/*
+ * The whole verbose, evaladjoint = false call traceobjgrad(pcof0, params, wa, true, false) (return tuple
+ * src/evalobjgrad.jl:1031) from ONE forward sweep: the history as above plus out4 = { objfv, primaryobjf,
+ * secondaryobjf, traceInfidelity } of the same sweep (out4 may be NULL).
+ */
+int jq_traceobj_verbose(jq_handle *h, const double *pcof, int32_t ncoeff, double *out4, double *ur, double *ui);
 
 /*
  * Device-side consumers of the state history, so that the [Ntot x N x (nsteps+1)] arrays (199 MB at cnot3)
@@ -160,12 +190,24 @@ int jq_state_populations(jq_handle *h, const double *pcof, int32_t ncoeff, const
  *   out2   : { last_infidelity, last_leak } (:58-59)
  *   infid_grad / leak_grad : [ncoeff] weighted sums of infidelgrad / leakgrad (:48-53); leak_grad is
  *            zero-filled for objFuncType == 1.  Ignored (may be NULL) when compute_adjoint == 0.
- * In a multi-GPU job each rank passes its shard of (nodes, weights); the caller sums the four
- * outputs over ranks with ONE all-reduce (RCCL), see juqbox.jl_amd/ipopt_interface.py.
+ * Multi-GPU: a jq_create_multi handle shards the nodes over its devices and all-reduces inside this call; with one
+ * process per GPU each rank passes its shard of (nodes, weights) (jq_shard_bounds) to jq_eval_f_g_grad_dev and the
+ * caller sums the packed vector over the ranks with ONE all-reduce (RCCL), see juqbox.jl_amd/ipopt_interface.py.
  */
 int jq_eval_f_g_grad(jq_handle *h, const double *pcof, int32_t ncoeff, const double *nodes, const double *weights,
                      int32_t nquad, const double *shift, int32_t compute_adjoint, double *out2, double *infid_grad,
                      double *leak_grad);
+
+/*
+ * The same evaluation with the result left ON THE DEVICE for a caller that runs its own collective (one process per GPU:
+ * torch.distributed / RCCL, MPI.jl): d_packed is a DEVICE pointer on the handle's GPU to 2 + 2*ncoeff doubles
+ *   { sum_i w_i*infidelity_i, sum_i w_i*leak_i, infid_grad[ncoeff], leak_grad[ncoeff] }
+ * -- exactly the vector that ONE all-reduce (sum) over the ranks turns into the results of eval_f_g_grad!.  The call
+ * returns after the handle's stream has been synchronised.  nquad == 0 (a rank without a shard) writes zeros.
+ * Single-device handles only.
+ */
+int jq_eval_f_g_grad_dev(jq_handle *h, const double *pcof, int32_t ncoeff, const double *nodes, const double *weights,
+                         int32_t nquad, const double *shift, int32_t compute_adjoint, void *d_packed);
 
 /*
  * Robustness sweep (ep_plot, examples/Risk_Neutral/run_all.jl:6-32): nquad independent

@@ -28,7 +28,7 @@ class jq_timing(ctypes.Structure):
                 ("ms_forward", ctypes.c_double), ("ms_backward", ctypes.c_double),
                 ("n_forward_launches", ctypes.c_int64), ("n_backward_launches", ctypes.c_int64), ("mfma_executed", ctypes.c_int64), ("svts", ctypes.c_int64),
                 ("kernel_family", ctypes.c_int32), ("kernel_size", ctypes.c_int32), ("kernel_band", ctypes.c_int32),
-                ("reserved", ctypes.c_int32)]
+                ("reserved", ctypes.c_int32), ("mfma_backward", ctypes.c_int64)]
 
 
 # every symbol include/juqbox_hip.h declares: name -> (restype, argtypes)
@@ -46,9 +46,15 @@ SYMBOLS = {
     "jq_update_wmat_diag": (ctypes.c_int, [ctypes.c_void_p, c_dp]),
     "jq_traceobjgrad": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_i32, c_i32, c_dp, c_dp, c_dp, c_dp]),
     "jq_state_history": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_i32, c_dp, c_dp]),
+    "jq_traceobj_verbose": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_i32, c_dp, c_dp, c_dp]),
     "jq_state_populations": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_i32, ctypes.POINTER(ctypes.c_int32), c_i32, c_i32, c_i32,
                                             c_dp, c_dp]),
     "jq_eval_f_g_grad": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_i32, c_dp, c_dp, c_i32, c_dp, c_i32, c_dp, c_dp, c_dp]),
+    "jq_eval_f_g_grad_dev": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_i32, c_dp, c_dp, c_i32, c_dp, c_i32, ctypes.c_void_p]),
+    "jq_create_multi": (ctypes.c_int, [ctypes.POINTER(jq_problem), ctypes.POINTER(ctypes.c_int32), c_i32,
+                                       ctypes.POINTER(ctypes.c_void_p)]),
+    "jq_num_devices": (ctypes.c_int, [ctypes.c_void_p]),
+    "jq_shard_bounds": (ctypes.c_int, [c_i32, c_i32, c_i32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "jq_traceobj_sweep": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_i32, c_dp, c_i32, c_dp, c_dp]),
     "jq_last_timing": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(jq_timing)]),
     "jq_version": (ctypes.c_char_p, []),

@@ -294,6 +294,45 @@ __global__ __launch_bounds__(JQ_GRADACC_THREADS) void k_gradacc(SplineArgs s, co
     if (threadIdx.x == 0) grad[idx] += red[0];
 }
 
+// Packed result of an ensemble evaluation, left on the device for the collective that sums it over GPUs (one all-reduce):
+//   out = [ sum_i w_i primaryobjf_i, sum_i w_i secondaryobjf_i, infidelity gradient [ncoeff], leak gradient [ncoeff] ]
+// (src/ipopt_interface.jl:48-59; grad = the weighted gradient sums of the forced [0] and unforced [1] backward sweeps:
+// objFuncType == 1: infidelgrad = totalgrad, no leak gradient; else leakgrad = totalgrad - infidelgrad, src/evalobjgrad.jl:947).
+// One workgroup, fixed summation order (deterministic).  wq == nullptr: unit weights.
+__global__ __launch_bounds__(256) void k_pack(const double* __restrict__ res, const double* __restrict__ wq, int nsamples,
+                                              const double* __restrict__ grad, int ncoeff, int adjoint, int two_pass,
+                                              double* __restrict__ out)
+{
+    __shared__ double r0[256], r1[256];
+    const int t = threadIdx.x;
+    double s0 = 0.0, s1 = 0.0;
+    for (int i = t; i < nsamples; i += 256) {
+        const double w = wq ? wq[i] : 1.0;
+        s0 += w * res[(size_t)i * 4 + 0];
+        s1 += w * res[(size_t)i * 4 + 1];
+    }
+    r0[t] = s0;
+    r1[t] = s1;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) {
+            r0[t] += r0[t + w];
+            r1[t] += r1[t + w];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        out[0] = r0[0];
+        out[1] = r1[0];
+    }
+    for (int i = t; i < ncoeff; i += 256) {
+        const double g0 = adjoint ? grad[i] : 0.0;
+        const double g1 = (adjoint && two_pass) ? grad[(size_t)ncoeff + i] : 0.0;
+        out[2 + i] = two_pass ? g1 : g0;
+        out[2 + (size_t)ncoeff + i] = two_pass ? g0 - g1 : 0.0;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Consumers of the state history on the device (jq_state_populations).  hist_r/hist_i: [Ntot][N][nsteps+1]
 // column-major (row fastest).

@@ -728,7 +728,7 @@ struct PropArgs {
     const double* cimg;     // constant trace images [Hsym_0.. | Hanti_0..], `stride` doubles each
     double* state;          // per-slab array file
     const double* colinfo;  // per slab: eps[16], wgt[16]
-    double* traces;         // backward: [nslabs][nsteps_chunk][Ncoupled*JQ_NTR]
+    double* traces;         // backward: [workgroups][nsteps_chunk][Ncoupled*JQ_NTR] (slab / quad kernels: summed over the workgroup's waves)
     double* hist_r;         // forward history of sample 0 ([Ntot,N,nsteps+1]) or null
     double* hist_i;
     const double* tabs;     // wd[NP] (diag wmat_real, zero padded), ws[NP] (shift weights)
@@ -924,7 +924,7 @@ struct Ring {
             if (n > 0) {
                 // every wave has finished step n-1 behind this barrier: its time points 2n-2, 2n-1 make room for 2n+3, 2n+4;
                 // the images of this step (issued one step ago) have landed
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 issue_tp(2 * n + 3);
@@ -936,7 +936,7 @@ struct Ring {
             return;
         }
         if (batch > 0 && (n % batch) == 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             issue_batch(n / batch + 1);
@@ -1042,7 +1042,7 @@ struct Ring {
         // Publish operator use Q (every wave drains its DMA pieces, then a workgroup barrier), start the
         // fetch of use Q+1 into the slot that use Q-1 just released.
         if (!(debug & 8)) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             issue_prefetch();
@@ -1067,8 +1067,9 @@ struct Ring {
     }
     __device__ __forceinline__ void drain()
     {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     }
 };
 
@@ -1354,7 +1355,6 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
     const int lane = QUAD ? ((lane_ >> 2) & 3) * 64 + 16 * (lane_ >> 4) + col : lane_;
     const int g = QUAD ? 4 * (lane_ >> 4) + ((lane_ >> 2) & 3) : lane_ >> 4;
     const int slab = QUAD ? (int)blockIdx.x * (NWAVES / 4) + (wave >> 2) : blockIdx.x * JQ_WAVES + wave;
-    const int trow = QUAD ? slab * JQ_WAVES + (wave & 3) : slab;   // row of this wave in the per-step trace records
     const bool active = slab < a.nslabs;
     const int Nc = a.Ncoupled;
     // per-lane trace carries in the array file: like the leak partial of k_forward
@@ -1364,12 +1364,33 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
     double* tab = (double*)(smem + a.lds_tab_off);
     const double* wd = tab;
     const double* ws = tab + 16 * NT;
-    double* carry = tab + 32 * NT;  // [JQ_MAXNC][threads of the workgroup]
+    double* carry = tab + 32 * NT;  // [Ncoupled][threads of the workgroup]
     for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[(i & ~15) + 4 * (i & 3) + ((i >> 2) & 3)] = a.tabs[i];   // [block][g][r]
     double* st = a.state + (size_t)(active ? slab : 0) * a.state_stride;
     // parking image of this wave: in LDS when it fits, else in HBM
-    double* P0 = a.park_lds ? (carry + JQ_MAXNC * NTHREADS + (size_t)wave * (JQ_RL * NT) * 64 + lane_)
+    double* P0 = a.park_lds ? (carry + Nc * NTHREADS + (size_t)wave * (JQ_RL * NT) * 64 + lane_)
                             : (a.park + (size_t)(active ? slab : 0) * KT * 64 + lane);
+    // Per-step trace scalars: every wave leaves its Ncoupled * JQ_NTR wave sums of step n in the LDS record
+    // rec[n & 1][wave][.]; once the whole workgroup has passed a barrier behind step n, wave 0 adds the waves' records in
+    // wave order and writes ONE record per workgroup and step to HBM (a.traces) -- the records of a launch are
+    // [workgroups][steps][ntr] instead of [waves][steps][ntr] (12 x less traffic with three slabs per workgroup).
+    const int ntr = Nc * JQ_NTR;
+    double* rec = carry + Nc * NTHREADS + (a.park_lds ? (size_t)NWAVES * (JQ_RL * NT) * 64 : 0);
+    for (int i = threadIdx.x; i < 2 * NWAVES * ntr; i += blockDim.x) rec[i] = 0.0;   // (inactive waves never write theirs)
+    auto flush_traces = [&](int k) {
+        if (a.batch > 0) {   // batched staging has no workgroup barrier in every step
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        if (wave == 0 && lane_ < ntr) {
+            const double* r = rec + (size_t)(k & 1) * NWAVES * ntr + lane_;
+            double s = r[0];
+#pragma unroll
+            for (int w = 1; w < NWAVES; ++w) s += r[w * ntr];
+            a.traces[((size_t)blockIdx.x * a.nsteps_chunk + k) * ntr + lane_] = s;
+        }
+    };
 
     // array roles (register arrays are renamed, never copied, except at the end of a step):
     //   u  : vr before the state step (vr0)      un : vr after it
@@ -1418,6 +1439,9 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
         if (active) a_park(mu, P0);
         // mu's registers serve as the scratch array A of the state step
         sv_state<NT, BW, JAC>(p, a, active, ceps, ws, g, u, v, un, vN, mu, Ya, Yb);
+        // (every wave has passed a workgroup barrier since it finished step n-1: begin_step in window mode, the operator
+        // switches of sv_state otherwise)
+        if (n > 0) flush_traces(n - 1);
         // use 6: Kp05 -- finish the state step; first adjoint product L = c K05 nb (= -c K05 lambda_i)
         const double* M = p.next_ks<0, 1>();
         if (active) {
@@ -1445,7 +1469,7 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
                 const double t1 = (a.debug & 1) ? a_dot(u, Ya) : wave_sum(a_dot(u, Ya) * wgt);
                 const double t3 = (a.debug & 1) ? a_dot(un, Ya) : wave_sum(a_dot(un, Ya) * wgt);
                 if (lane_ == 0) {
-                    double* tr = a.traces + ((size_t)trow * a.nsteps_chunk + n) * (Nc * JQ_NTR) + q * JQ_NTR;
+                    double* tr = rec + ((size_t)(n & 1) * NWAVES + wave) * ntr + q * JQ_NTR;
                     tr[0] = t1;
                     tr[2] = t3;
                 }
@@ -1514,7 +1538,7 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
                     t5 = wave_sum(t5 * wgt);
                 }
                 if (lane_ == 0) {
-                    double* tr = a.traces + ((size_t)trow * a.nsteps_chunk + n) * (Nc * JQ_NTR) + q * JQ_NTR;
+                    double* tr = rec + ((size_t)(n & 1) * NWAVES + wave) * ntr + q * JQ_NTR;
                     tr[1] = t2;
                     tr[3] = t4;
                     tr[4] = t5;
@@ -1530,6 +1554,7 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
         }
     }
     p.drain();
+    flush_traces(a.nsteps_chunk - 1);
     if (active) {
         a_store(u, st, lane);
         a_store(v, st + KT * 64, lane);

@@ -14,15 +14,20 @@
 #include "jq_rowlane_imr_kernels.h"
 #include "jq_coop_imr_kernels.h"
 
+#include <rccl/rccl.h>   // types and prototypes only: librccl is loaded at run time by jq_create_multi (load_rccl)
+
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
-#define JQ_VERSION "gfx950 juqbox_hip 0.1.0"
+#define JQ_VERSION "gfx950 juqbox_hip 0.2.0"
 
 static thread_local std::string g_create_error;
 
@@ -69,8 +74,13 @@ struct jq_handle {
     double *d_stream = nullptr, *d_pq = nullptr;
     double *d_state = nullptr, *d_state_save = nullptr, *d_colinfo = nullptr, *d_traces = nullptr, *d_R = nullptr;
     double *d_grad = nullptr, *d_res = nullptr;
-    size_t cap_pcof = 0, cap_slabs = 0, cap_traces = 0, cap_grad = 0, cap_res = 0, cap_state = 0, cap_colinfo = 0;
+    double *d_wq = nullptr, *d_pack = nullptr;   // ensemble weights per sample; packed result [2 + 2 nCoeff] (multi-device all-reduce)
+    size_t cap_pcof = 0, cap_slabs = 0, cap_traces = 0, cap_grad = 0, cap_res = 0, cap_state = 0, cap_colinfo = 0, cap_wq = 0, cap_pack = 0;
     int chunk_steps = 0;
+    // multi-device handle (jq_create_multi): one single-device handle per GPU and one RCCL communicator each; such a
+    // handle owns no device memory itself
+    std::vector<jq_handle*> subs;
+    std::vector<ncclComm_t> comms;
     std::vector<hipEvent_t> ev;
     std::string err;
     jq_timing timing = {};
@@ -384,11 +394,17 @@ extern "C" const char* jq_version(void) { return JQ_VERSION; }
 
 extern "C" const char* jq_last_error(const jq_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
+static void destroy_multi(jq_handle* h);
+
 extern "C" void jq_destroy(jq_handle* h)
 {
     if (!h) return;
+    if (!h->subs.empty()) {
+        destroy_multi(h);
+        return;
+    }
     (void)hipSetDevice(h->device);
-    double** bufs[] = {&h->d_himg_r, &h->d_uinit_r, &h->d_vtr_r, &h->d_vti_r, &h->d_himg_l, &h->d_uinit_l, &h->d_vtr_l, &h->d_vti_l, &h->d_himg_c, &h->d_cimg_c, &h->d_park, &h->d_cimg, &h->d_himg,  &h->d_uimg,       &h->d_vtr,     &h->d_vti,    &h->d_tabs, &h->d_tf,   &h->d_tb,
+    double** bufs[] = {&h->d_wq, &h->d_pack, &h->d_himg_r, &h->d_uinit_r, &h->d_vtr_r, &h->d_vti_r, &h->d_himg_l, &h->d_uinit_l, &h->d_vtr_l, &h->d_vti_l, &h->d_himg_c, &h->d_cimg_c, &h->d_park, &h->d_cimg, &h->d_himg,  &h->d_uimg,       &h->d_vtr,     &h->d_vti,    &h->d_tabs, &h->d_tf,   &h->d_tb,
                        &h->d_cfreq, &h->d_pcof,       &h->d_stream,  &h->d_pq,     &h->d_state, &h->d_state_save,
                        &h->d_colinfo, &h->d_traces,   &h->d_R,       &h->d_grad,   &h->d_res};
     for (auto b : bufs)
@@ -396,6 +412,14 @@ extern "C" void jq_destroy(jq_handle* h)
     for (auto e : h->ev) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
+}
+
+// LDS bytes of the backward slab / quad kernels (jq_kernels.h k_backward) behind the operator staging: the tables wd, ws,
+// the per-thread trace carries [Nc][threads], the parking images (park_doubles per wave; 0: parked in HBM) and the
+// double-buffered per-step trace records [2][waves][Nc * JQ_NTR]
+static long long bwd_lds_tail(int NT, int Nc, int nwaves, long long park_doubles)
+{
+    return 32LL * NT * 8 + (long long)Nc * 64 * nwaves * 8 + (long long)nwaves * park_doubles * 8 + 2LL * nwaves * Nc * JQ_NTR * 8;
 }
 
 static int create_impl(const jq_problem* p, jq_handle* h)
@@ -491,7 +515,7 @@ static int create_impl(const jq_problem* p, jq_handle* h)
                                              : 64LL * band_tiles(h->NT, h->BW) + (h->BW == JQ_BW_OD ? JQ_OD_COEFS(h->NT) : 0)) + 127) / 128) * 128;
         const long long slot = h->mat_elems * 8;
         const long long lds_fwd_fixed = (long long)32 * h->NT * 8;
-        const long long lds_bwd_fixed = lds_fwd_fixed + (long long)JQ_MAXNC * 256 * 8;
+        const long long lds_bwd_fixed = bwd_lds_tail(h->NT, h->Nc, JQ_WAVES, 0);
         const long long park_bytes = (long long)JQ_WAVES * h->KT * 64 * 8;
         if (2 * slot + lds_fwd_fixed > 163840)
             return fail(h, JQ_EUNSUPPORTED, "jq_create: operator images do not fit the LDS double buffer");
@@ -534,7 +558,7 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         // to park -- so they are also available when the slab kernels have to fall back to the per-operator ring: Ntot > 80, Nc = 4)
         {
             const long long win = (2LL * JQ_WIN_TPS + 2LL * h->Nc) * slot;
-            const long long quad_fixed = lds_fwd_fixed + (long long)JQ_MAXNC * 256 * 8 + (long long)JQ_WAVES * h->NT * 64 * 8;
+            const long long quad_fixed = bwd_lds_tail(h->NT, h->Nc, JQ_WAVES, (long long)h->NT * 64);
             bool w = h->BW == JQ_BW_T4 && win + quad_fixed <= 163840;
             if (const char* e = getenv("JQ_WINDOW"))
                 if (atoi(e) == 0) w = false;
@@ -663,6 +687,8 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         const long long v = atoll(e);
         if (v > 0) cs = std::min<long long>(v, h->nsteps);
     }
+    // k_ctrl / k_stream put the 2 cs + 1 time points of a chunk into gridDim.y (limit 65535)
+    cs = std::min<long long>(cs, 32767);
     h->chunk_steps = (int)cs;
     if ((rc = dev_alloc(h, &h->d_stream, (size_t)(2 * cs + 1) * 2 * img_elems))) return rc;
     if ((rc = dev_alloc(h, &h->d_pq, (size_t)(2 * cs + 1) * 2 * h->Nc))) return rc;
@@ -692,9 +718,26 @@ extern "C" int jq_create(const jq_problem* problem, jq_handle** out)
     return JQ_OK;
 }
 
+template <typename F>
+static int multi_forall(jq_handle* h, F f);
+static int multi_eval_f_g_grad(jq_handle* h, const double* pcof, int ncoeff, const double* nodes, const double* weights, int nquad,
+                               const double* shift, bool adjoint, double* out2, double* infid_grad, double* leak_grad);
+static int multi_traceobj_sweep(jq_handle* h, const double* pcof, int ncoeff, const double* nodes, int nquad, const double* shift,
+                                double* out);
+// a single evaluation cannot be sharded: multi-device handles run it on their first device
+#define JQ_ON_FIRST(h, call)                         \
+    if (!(h)->subs.empty()) {                        \
+        jq_handle* s0_ = (h)->subs[0];               \
+        const int rc_ = (call);                      \
+        if (rc_ != JQ_OK) (h)->err = s0_->err;       \
+        (h)->timing = s0_->timing;                   \
+        return rc_;                                  \
+    }
+
 extern "C" int jq_set_neumann_terms(jq_handle* h, int32_t m)
 {
     if (!h) return JQ_EINVAL;
+    if (!h->subs.empty()) return multi_forall(h, [&](jq_handle* sub) { return jq_set_neumann_terms(sub, m); });
     if (m < 0) return fail(h, JQ_EINVAL, "jq_set_neumann_terms: m must be >= 0");
     h->m = m;
     return JQ_OK;
@@ -703,6 +746,7 @@ extern "C" int jq_set_neumann_terms(jq_handle* h, int32_t m)
 extern "C" int jq_set_linear_solver(jq_handle* h, int32_t solver_id, int32_t max_iter, double tol)
 {
     if (!h) return JQ_EINVAL;
+    if (!h->subs.empty()) return multi_forall(h, [&](jq_handle* sub) { return jq_set_linear_solver(sub, solver_id, max_iter, tol); });
     if (max_iter < 0) return fail(h, JQ_EINVAL, "jq_set_linear_solver: max_iter must be >= 0");
     if (solver_id == 2) {
         if (!(tol > 0.0)) return fail(h, JQ_EINVAL, "jq_set_linear_solver: JACOBI_SOLVER needs tol > 0");
@@ -718,6 +762,7 @@ extern "C" int jq_set_linear_solver(jq_handle* h, int32_t solver_id, int32_t max
 extern "C" int jq_set_integrator(jq_handle* h, int32_t integrator_id, int32_t max_iter, double tol)
 {
     if (!h) return JQ_EINVAL;
+    if (!h->subs.empty()) return multi_forall(h, [&](jq_handle* sub) { return jq_set_integrator(sub, integrator_id, max_iter, tol); });
     if (integrator_id == 1) {
         h->integrator = 1;
         return JQ_OK;
@@ -737,6 +782,7 @@ extern "C" int jq_update_target(jq_handle* h, const double* Utr, const double* U
 {
     if (!h) return JQ_EINVAL;
     if (!Utr || !Uti) return fail(h, JQ_EINVAL, "jq_update_target: NULL pointer");
+    if (!h->subs.empty()) return multi_forall(h, [&](jq_handle* sub) { return jq_update_target(sub, Utr, Uti); });
     HIPCHK(h, hipSetDevice(h->device));
     const size_t nc = (size_t)h->Ntot * h->N;
     h->Utr.assign(Utr, Utr + nc);
@@ -748,6 +794,7 @@ extern "C" int jq_update_hconst(jq_handle* h, const double* Hconst)
 {
     if (!h) return JQ_EINVAL;
     if (!Hconst) return fail(h, JQ_EINVAL, "jq_update_hconst: NULL pointer");
+    if (!h->subs.empty()) return multi_forall(h, [&](jq_handle* sub) { return jq_update_hconst(sub, Hconst); });
     HIPCHK(h, hipSetDevice(h->device));
     if ((h->BW == JQ_BW_T4) ? !t4_structure(Hconst, h->Ntot)
         : (h->BW == JQ_BW_OD) ? !offdiag_blocks_diagonal(Hconst, h->Ntot) : block_band(Hconst, h->Ntot) > h->BW)
@@ -761,6 +808,7 @@ extern "C" int jq_update_wmat_diag(jq_handle* h, const double* w)
 {
     if (!h) return JQ_EINVAL;
     if (!w) return fail(h, JQ_EINVAL, "jq_update_wmat_diag: NULL pointer");
+    if (!h->subs.empty()) return multi_forall(h, [&](jq_handle* sub) { return jq_update_wmat_diag(sub, w); });
     h->wd.assign(w, w + h->Ntot);
     return JQ_OK;
 }
@@ -954,8 +1002,9 @@ struct EvalOut {
 };
 
 // The batched evaluation behind every hot-path entry point.
+// d_packed != nullptr: the packed ensemble result (k_pack) is also left at this DEVICE address of h's GPU.
 static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, const double* eps, const double* wgt,
-                    const double* shift, bool adjoint, double* hist_r, double* hist_i, EvalOut* out)
+                    const double* shift, bool adjoint, double* hist_r, double* hist_i, EvalOut* out, double* d_packed = nullptr)
 {
     HIPCHK(h, hipSetDevice(h->device));
     const int Nsig = 2 * h->Nc;
@@ -1004,8 +1053,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     if (!imr && !lane && !rl && h->solver_id == 1 && nslabs <= h->quad_max_slabs) {
         const double rel[4] = {1.0, 0.34, 0.50, 0.68};
         auto quad_lds = [&](int k) {    // backward kernel, k slabs per workgroup
-            return (size_t)(2 * JQ_WIN_TPS + 2 * h->Nc) * h->mat_elems * 8 + (size_t)32 * h->NT * 8 + (size_t)JQ_MAXNC * 256 * k * 8 +
-                   (size_t)4 * k * h->NT * 64 * 8;
+            return (size_t)(2 * JQ_WIN_TPS + 2 * h->Nc) * h->mat_elems * 8 + (size_t)bwd_lds_tail(h->NT, h->Nc, 4 * k, (long long)h->NT * 64);
         };
         double best = rel[0] * ((nslabs + 4 * h->num_cu - 1) / (4 * h->num_cu));
         for (int k = 1; k <= 3; ++k) {
@@ -1037,15 +1085,29 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     if (rc) return rc;
     const int nblocks = rl ? (int)nwaves_rl : lane ? (int)(ncols / 64) : quad8 ? (nslabs + spw - 1) / spw : (coop || quad) ? nslabs : (nslabs + JQ_WAVES - 1) / JQ_WAVES;
     const int nthreads = (lane || rl) ? 64 : coop ? 64 * h->NT : quad8 ? 256 * spw : 256;
-    const int trace_rows = (lane || rl) ? nblocks : coop ? nslabs * h->NT : quad ? nslabs * JQ_WAVES : nslabs;   // per-step trace records: one per wave
+    // per-step trace records: one per wave (cooperative, lane, row-lane, implicit-midpoint kernels) or one per workgroup
+    // (slab / quad kernels: summed over the workgroup's waves in LDS)
+    const int trace_rows = (lane || rl) ? nblocks : coop ? nslabs * h->NT : imr_quad ? nslabs * JQ_WAVES : nblocks;
     const long long stride = rl ? h->rl_stride : lane ? h->lane_stride : coop ? h->mat_elems_c : h->mat_elems;
     const double* himg = rl ? h->d_himg_r : lane ? h->d_himg_l : coop ? h->d_himg_c : h->d_himg;
     const size_t state_doubles = rl ? (size_t)JQ_ROWLANE_ROWS * nwaves_rl * 64
                                     : lane ? (size_t)JQ_LANE_ROWS(h->lane_np) * ncols : (size_t)nslabs * h->state_stride;
     const size_t colinfo_doubles = (lane || rl) ? (size_t)2 * ncols : (size_t)nslabs * 32;
-    const int cs = h->chunk_steps;
     const int ntr = h->Nc * JQ_NTR;
     const bool two_pass = adjoint && h->objFuncType != 1;
+    // chunk length: the tile stream of h->chunk_steps steps fits its buffer; the per-step trace records of a backward chunk
+    // ([trace_rows][cs][ntr] doubles) are bounded by JQ_TRACE_BYTES (default 4 GiB) so that large ensembles take more,
+    // shorter chunks instead of an allocation that grows with batch size x gate length
+    int cs = h->chunk_steps;
+    if (adjoint) {
+        size_t tbudget = (size_t)4 << 30;
+        if (const char* e = getenv("JQ_TRACE_BYTES")) {
+            const long long v = atoll(e);
+            if (v > 0) tbudget = (size_t)v;
+        }
+        const long long cst = (long long)(tbudget / ((size_t)trace_rows * ntr * sizeof(double)));
+        cs = (int)std::max<long long>(1, std::min<long long>(cs, cst));
+    }
 
     // ---- capacity ------------------------------------------------------------------------------
     if ((size_t)ncoeff > h->cap_pcof) {
@@ -1140,8 +1202,9 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     const size_t lds_fwd = (lane || rl) ? 0 : imr_coop ? coop_imr_lds_bytes(h->NT, stride)
                                            : lds_stage + (size_t)32 * h->NT * 8 + (coop ? (size_t)2 * h->KT * 64 * 8 : 0);
     const size_t lds_bwd = rl ? (h->rl_npj > 8 ? (size_t)2 * h->Nc * h->rl_stride * 8 : 0) : lane ? 0 : coop ? lds_fwd
-                                : quad ? lds_fwd + (size_t)JQ_MAXNC * nthreads * 8 + (size_t)(nthreads / 64) * h->NT * 64 * 8   // (a 16-row block per register)
-                                : lds_fwd + (size_t)JQ_MAXNC * 256 * 8 + (h->park_lds ? (size_t)JQ_WAVES * h->KT * 64 * 8 : 0);
+                                : imr_quad ? lds_fwd + (size_t)JQ_MAXNC * nthreads * 8 + (size_t)(nthreads / 64) * h->NT * 64 * 8
+                                : quad ? lds_stage + (size_t)bwd_lds_tail(h->NT, h->Nc, nthreads / 64, (long long)h->NT * 64)   // (a 16-row block per register)
+                                : lds_stage + (size_t)bwd_lds_tail(h->NT, h->Nc, JQ_WAVES, h->park_lds ? (long long)h->KT * 64 : 0);
     a.batch = batch; a.lds_tab_off = (int)lds_stage;
     a.park = h->d_park; a.park_lds = quad ? 1 : h->park_lds;
     if (const char* e = getenv("JQ_DEBUG")) a.debug = atoi(e);
@@ -1169,7 +1232,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     else
         hipLaunchKernelGGL(k_init_state, dim3(nslabs), dim3(64), 0, s, h->d_state, h->state_stride, h->d_uimg, h->KT);
 
-    long long mfma = 0;
+    long long mfma = 0, mfma_fwd = 0;
     const long long tiles = (lane || rl) ? 0 : coop ? coop_tiles(h->NT, h->BWc) : band_tiles(h->NT, h->BW);
     long long trace_tiles = 0;
     for (int q = 0; q < h->Nc && !lane && !rl; ++q)
@@ -1201,6 +1264,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
         mfma += (long long)nslabs * nc * (8 + 2 * h->m) * tiles;
     }
     HIPCHK(h, hipGetLastError());
+    mfma_fwd = mfma;
     const double leak_scale = imr ? 0.25 * dt * (1.0 / h->T) : 0.5 * dt * (1.0 / h->T);
     if (imr_coop || imr_quad)
         hipLaunchKernelGGL(k_terminal_imr, dim3(nslabs), dim3(64), 0, s, h->d_state, h->state_stride, h->d_vtr, h->d_vti, h->KT,
@@ -1266,6 +1330,18 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
         }
     }
     HIPCHK(h, hipGetLastError());
+    if (d_packed) {
+        if (wgt) {
+            if ((size_t)nsamples > h->cap_wq) {
+                if ((rc = dev_alloc(h, &h->d_wq, (size_t)nsamples))) return rc;
+                h->cap_wq = nsamples;
+            }
+            HIPCHK(h, hipMemcpyAsync(h->d_wq, wgt, (size_t)nsamples * sizeof(double), hipMemcpyHostToDevice, s));
+        }
+        hipLaunchKernelGGL(k_pack, dim3(1), dim3(256), 0, s, h->d_res, wgt ? h->d_wq : nullptr, nsamples, h->d_grad, ncoeff,
+                           adjoint ? 1 : 0, two_pass ? 1 : 0, d_packed);
+        HIPCHK(h, hipGetLastError());
+    }
     HIPCHK(h, hipEventRecord(h->ev[1], s));
 
     // ---- outputs -------------------------------------------------------------------------------
@@ -1302,6 +1378,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     h->timing.n_backward_launches = (long long)((evi - 2) / 2 - nfwd);
     // (JQ_BW_T4: one v_mfma_f64_4x4x4_4b is 512 FLOP, a quarter of the 16x16x4 instruction this counter is quoted in)
     h->timing.mfma_executed = imr ? 0 : (!coop && !lane && !rl && h->BW == JQ_BW_T4) ? mfma / 4 : mfma;   // (the iteration counts of the implicit-midpoint solver are data dependent)
+    h->timing.mfma_backward = h->timing.mfma_executed == 0 ? 0 : (h->timing.mfma_executed == mfma ? mfma - mfma_fwd : (mfma - mfma_fwd) / 4);
     h->timing.svts = (long long)nsamples * h->N * h->nsteps;
     h->timing.kernel_family = imr_quad ? 7 : imr_coop ? 5 : imr ? 4 : rl ? 3 : lane ? 2 : coop ? 1 : quad ? 6 : 0;
     h->timing.kernel_size = rl ? h->rl_npj : lane ? h->lane_np : h->NT;
@@ -1317,6 +1394,7 @@ extern "C" int jq_traceobjgrad(jq_handle* h, const double* pcof, int32_t ncoeff,
     if (!pcof || !out4) return fail(h, JQ_EINVAL, "jq_traceobjgrad: NULL pointer");
     if (evaladjoint && (!totalgrad || !infidelgrad || !leakgrad))
         return fail(h, JQ_EINVAL, "jq_traceobjgrad: gradient outputs are required when evaladjoint != 0");
+    JQ_ON_FIRST(h, jq_traceobjgrad(s0_, pcof, ncoeff, evaladjoint, out4, totalgrad, infidelgrad, leakgrad))
     EvalOut o;
     int rc = run_eval(h, pcof, ncoeff, 1, nullptr, nullptr, nullptr, evaladjoint != 0, nullptr, nullptr, &o);
     if (rc) return rc;
@@ -1344,8 +1422,14 @@ extern "C" int jq_traceobjgrad(jq_handle* h, const double* pcof, int32_t ncoeff,
 
 extern "C" int jq_state_history(jq_handle* h, const double* pcof, int32_t ncoeff, double* ur, double* ui)
 {
+    return jq_traceobj_verbose(h, pcof, ncoeff, nullptr, ur, ui);
+}
+
+extern "C" int jq_traceobj_verbose(jq_handle* h, const double* pcof, int32_t ncoeff, double* out4, double* ur, double* ui)
+{
     if (!h) return JQ_EINVAL;
     if (!pcof || !ur || !ui) return fail(h, JQ_EINVAL, "jq_state_history: NULL pointer");
+    JQ_ON_FIRST(h, jq_traceobj_verbose(s0_, pcof, ncoeff, out4, ur, ui))
     HIPCHK(h, hipSetDevice(h->device));
     const size_t len = (size_t)h->Ntot * h->N * (h->nsteps + 1);
     double *d_r = nullptr, *d_i = nullptr;
@@ -1367,6 +1451,12 @@ extern "C" int jq_state_history(jq_handle* h, const double* pcof, int32_t ncoeff
             ur[i] = h->Uinit[i];
             ui[i] = -0.0;
         }
+        if (out4 && rc == JQ_OK) {   // the objective of the same forward sweep (src/evalobjgrad.jl:759-792)
+            out4[0] = o.res[0] + o.res[1];
+            out4[1] = o.res[0];
+            out4[2] = o.res[1];
+            out4[3] = o.res[0];
+        }
     }
     (void)hipFree(d_r);
     (void)hipFree(d_i);
@@ -1379,6 +1469,7 @@ extern "C" int jq_state_populations(jq_handle* h, const double* pcof, int32_t nc
     if (!h) return JQ_EINVAL;
     if (!pcof) return fail(h, JQ_EINVAL, "jq_state_populations: NULL pointer");
     if (!pop && !maxpop) return fail(h, JQ_EINVAL, "jq_state_populations: pop and maxpop are both NULL");
+    JQ_ON_FIRST(h, jq_state_populations(s0_, pcof, ncoeff, group_of_row, ngroups, every, nout, pop, maxpop))
     if (pop) {
         if (every < 1 || nout != h->nsteps / every + 1)
             return fail(h, JQ_EINVAL, "jq_state_populations: need every >= 1 and nout == nsteps/every + 1");
@@ -1438,6 +1529,8 @@ extern "C" int jq_eval_f_g_grad(jq_handle* h, const double* pcof, int32_t ncoeff
     if (nquad < 1) return fail(h, JQ_EINVAL, "jq_eval_f_g_grad: nquad must be >= 1");
     if (compute_adjoint && (!infid_grad || !leak_grad))
         return fail(h, JQ_EINVAL, "jq_eval_f_g_grad: gradient outputs are required when compute_adjoint != 0");
+    if (!h->subs.empty())
+        return multi_eval_f_g_grad(h, pcof, ncoeff, nodes, weights, nquad, shift, compute_adjoint != 0, out2, infid_grad, leak_grad);
     EvalOut o;
     int rc = run_eval(h, pcof, ncoeff, nquad, nodes, weights, shift, compute_adjoint != 0, nullptr, nullptr, &o);
     if (rc) return rc;
@@ -1464,12 +1557,32 @@ extern "C" int jq_eval_f_g_grad(jq_handle* h, const double* pcof, int32_t ncoeff
     return JQ_OK;
 }
 
+extern "C" int jq_eval_f_g_grad_dev(jq_handle* h, const double* pcof, int32_t ncoeff, const double* nodes, const double* weights,
+                                    int32_t nquad, const double* shift, int32_t compute_adjoint, void* d_packed)
+{
+    if (!h) return JQ_EINVAL;
+    if (!pcof || !nodes || !weights || !d_packed) return fail(h, JQ_EINVAL, "jq_eval_f_g_grad_dev: NULL pointer");
+    if (nquad < 0) return fail(h, JQ_EINVAL, "jq_eval_f_g_grad_dev: nquad must be >= 0");
+    if (!h->subs.empty())
+        return fail(h, JQ_EINVAL, "jq_eval_f_g_grad_dev: multi-device handles reduce inside jq_eval_f_g_grad; use that entry");
+    if (nquad == 0) {     // a rank without a shard contributes zeros to the all-reduce
+        HIPCHK(h, hipSetDevice(h->device));
+        HIPCHK(h, hipMemsetAsync(d_packed, 0, (2 + 2 * (size_t)ncoeff) * sizeof(double), h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->timing = jq_timing{};
+        return JQ_OK;
+    }
+    EvalOut o;
+    return run_eval(h, pcof, ncoeff, nquad, nodes, weights, shift, compute_adjoint != 0, nullptr, nullptr, &o, (double*)d_packed);
+}
+
 extern "C" int jq_traceobj_sweep(jq_handle* h, const double* pcof, int32_t ncoeff, const double* nodes, int32_t nquad,
                                  const double* shift, double* out)
 {
     if (!h) return JQ_EINVAL;
     if (!pcof || !nodes || !out) return fail(h, JQ_EINVAL, "jq_traceobj_sweep: NULL pointer");
     if (nquad < 1) return fail(h, JQ_EINVAL, "jq_traceobj_sweep: nquad must be >= 1");
+    if (!h->subs.empty()) return multi_traceobj_sweep(h, pcof, ncoeff, nodes, nquad, shift, out);
     EvalOut o;
     int rc = run_eval(h, pcof, ncoeff, nquad, nodes, nullptr, shift, false, nullptr, nullptr, &o);
     if (rc) return rc;
@@ -1480,6 +1593,280 @@ extern "C" int jq_traceobj_sweep(jq_handle* h, const double* pcof, int32_t ncoef
         out[(size_t)i * 4 + 2] = secondary;
         out[(size_t)i * 4 + 3] = primary;
     }
+    return JQ_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Multi-device handle: ONE process (the single-threaded Julia caller of src/ipopt_interface.jl:38-65) drives ndev GPUs.
+// The quadrature nodes of eval_f_g_grad! are block-partitioned over the devices (jq_shard_bounds), every device evaluates
+// its shard concurrently (one host thread per device, each on its device's own stream) and the packed results
+// [infidelity, leak, grad_infid(nCoeff), grad_leak(nCoeff)] are summed with ONE ncclAllReduce (RCCL over xGMI).
+// librccl is loaded at run time (only multi-device callers need it); a library already mapped into the process -- e.g.
+// the one PyTorch ships -- is reused.
+struct RcclApi {
+    void* lib = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+static RcclApi g_rccl;
+
+static int load_rccl(std::string* err)
+{
+    if (g_rccl.lib) return JQ_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* lib = nullptr;
+    for (const char* n : names)
+        if ((lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+    for (const char* n : names) {
+        if (lib) break;
+        lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    }
+    if (!lib) {
+        *err = std::string("jq_create_multi: cannot load librccl (") + (dlerror() ? dlerror() : "?") + ")";
+        return JQ_EUNSUPPORTED;
+    }
+    RcclApi a;
+    a.lib = lib;
+    a.CommInitAll = (decltype(a.CommInitAll))dlsym(lib, "ncclCommInitAll");
+    a.CommDestroy = (decltype(a.CommDestroy))dlsym(lib, "ncclCommDestroy");
+    a.AllReduce = (decltype(a.AllReduce))dlsym(lib, "ncclAllReduce");
+    a.GroupStart = (decltype(a.GroupStart))dlsym(lib, "ncclGroupStart");
+    a.GroupEnd = (decltype(a.GroupEnd))dlsym(lib, "ncclGroupEnd");
+    a.GetErrorString = (decltype(a.GetErrorString))dlsym(lib, "ncclGetErrorString");
+    if (!a.CommInitAll || !a.CommDestroy || !a.AllReduce || !a.GroupStart || !a.GroupEnd || !a.GetErrorString) {
+        *err = "jq_create_multi: librccl lacks a required symbol";
+        return JQ_EUNSUPPORTED;
+    }
+    g_rccl = a;
+    return JQ_OK;
+}
+
+#define NCCLCHK(h, call)                                                                                      \
+    do {                                                                                                      \
+        ncclResult_t r_ = (call);                                                                             \
+        if (r_ != ncclSuccess) {                                                                              \
+            char buf_[512];                                                                                   \
+            snprintf(buf_, sizeof buf_, "RCCL error '%s' at %s:%d (%s)", g_rccl.GetErrorString(r_), __FILE__, __LINE__, #call); \
+            (h)->err = buf_;                                                                                  \
+            return JQ_EHIP;                                                                                   \
+        }                                                                                                     \
+    } while (0)
+
+extern "C" int jq_shard_bounds(int32_t nquad, int32_t rank, int32_t world, int32_t* lo, int32_t* hi)
+{
+    if (!lo || !hi || nquad < 0 || world < 1 || rank < 0 || rank >= world) return JQ_EINVAL;
+    const int base = nquad / world, rem = nquad % world;
+    *lo = rank * base + std::min(rank, rem);
+    *hi = *lo + base + (rank < rem ? 1 : 0);
+    return JQ_OK;
+}
+
+extern "C" int jq_num_devices(const jq_handle* h) { return !h ? 0 : h->subs.empty() ? 1 : (int)h->subs.size(); }
+
+static void destroy_multi(jq_handle* h)
+{
+    for (size_t d = 0; d < h->comms.size(); ++d)
+        if (h->comms[d] && g_rccl.CommDestroy) {
+            (void)hipSetDevice(h->subs[d]->device);
+            (void)g_rccl.CommDestroy(h->comms[d]);
+        }
+    for (jq_handle* sub : h->subs) jq_destroy(sub);
+    delete h;
+}
+
+extern "C" int jq_create_multi(const jq_problem* problem, const int32_t* devices, int32_t ndev, jq_handle** out)
+{
+    if (!out) {
+        g_create_error = "jq_create_multi: out is NULL";
+        return JQ_EINVAL;
+    }
+    *out = nullptr;
+    int avail = 0;
+    if (hipGetDeviceCount(&avail) != hipSuccess) avail = 0;
+    if (ndev < 1 || ndev > avail) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "jq_create_multi: ndev = %d but %d HIP device(s) are visible", ndev, avail);
+        g_create_error = buf;
+        return JQ_EINVAL;
+    }
+    std::vector<int> devs(ndev);
+    for (int d = 0; d < ndev; ++d) {
+        devs[d] = devices ? devices[d] : d;
+        if (devs[d] < 0 || devs[d] >= avail || std::count(devs.begin(), devs.begin() + d, devs[d])) {
+            g_create_error = "jq_create_multi: device ids must be distinct and < jq_device_count()";
+            return JQ_EINVAL;
+        }
+    }
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    jq_handle* h = new (std::nothrow) jq_handle();
+    if (!h) {
+        g_create_error = "jq_create_multi: out of host memory";
+        return JQ_ENOMEM;
+    }
+    int rc = JQ_OK;
+    for (int d = 0; d < ndev && rc == JQ_OK; ++d) {
+        if (hipSetDevice(devs[d]) != hipSuccess) {
+            g_create_error = "jq_create_multi: hipSetDevice failed";
+            rc = JQ_EHIP;
+            break;
+        }
+        jq_handle* sub = nullptr;
+        rc = jq_create(problem, &sub);      // (sets g_create_error on failure)
+        if (rc == JQ_OK) h->subs.push_back(sub);
+    }
+    if (rc == JQ_OK) {
+        std::string err;
+        rc = load_rccl(&err);
+        if (rc != JQ_OK) g_create_error = err;
+    }
+    if (rc == JQ_OK) {
+        h->comms.assign(ndev, nullptr);
+        const ncclResult_t r = g_rccl.CommInitAll(h->comms.data(), ndev, devs.data());
+        if (r != ncclSuccess) {
+            g_create_error = std::string("jq_create_multi: ncclCommInitAll failed: ") + g_rccl.GetErrorString(r);
+            h->comms.clear();
+            rc = JQ_EHIP;
+        }
+    }
+    (void)hipSetDevice(prev);
+    if (rc != JQ_OK) {
+        if (h->subs.empty()) delete h; else destroy_multi(h);
+        return rc;
+    }
+    const jq_handle* s0 = h->subs[0];
+    h->device = s0->device;
+    h->Ntot = s0->Ntot; h->N = s0->N; h->Nc = s0->Nc; h->Nfreq = s0->Nfreq; h->nsteps = s0->nsteps; h->objFuncType = s0->objFuncType;
+    h->T = s0->T;
+    *out = h;
+    return JQ_OK;
+}
+
+// apply f to every device handle; the first failure is reported on the multi handle
+template <typename F>
+static int multi_forall(jq_handle* h, F f)
+{
+    for (jq_handle* sub : h->subs) {
+        const int rc = f(sub);
+        if (rc != JQ_OK) {
+            h->err = sub->err;
+            return rc;
+        }
+    }
+    return JQ_OK;
+}
+
+// timing of a multi-device call: the slowest device's times, work summed over the devices
+static void multi_timing(jq_handle* h)
+{
+    jq_timing t = {};
+    bool first = true;
+    for (const jq_handle* sub : h->subs) {
+        const jq_timing& u = sub->timing;
+        if (u.svts == 0) continue;     // device without a shard in the last call
+        if (first || u.ms_total > t.ms_total) {
+            const long long mf = t.mfma_executed, mb = t.mfma_backward, sv = t.svts;
+            t = u;
+            t.mfma_executed = mf;
+            t.mfma_backward = mb;
+            t.svts = sv;
+        }
+        t.mfma_executed += u.mfma_executed;
+        t.mfma_backward += u.mfma_backward;
+        t.svts += u.svts;
+        first = false;
+    }
+    h->timing = t;
+}
+
+static int multi_eval_f_g_grad(jq_handle* h, const double* pcof, int ncoeff, const double* nodes, const double* weights, int nquad,
+                               const double* shift, bool adjoint, double* out2, double* infid_grad, double* leak_grad)
+{
+    const int nd = (int)h->subs.size();
+    const size_t npk = 2 + 2 * (size_t)ncoeff;
+    std::vector<int> rcs(nd, JQ_OK);
+    std::vector<std::thread> th;
+    for (int d = 0; d < nd; ++d)
+        th.emplace_back([&, d]() {
+            jq_handle* sub = h->subs[d];
+            int lo = 0, hi = 0;
+            jq_shard_bounds(nquad, d, nd, &lo, &hi);
+            sub->timing = jq_timing{};
+            auto body = [&]() -> int {
+                HIPCHK(sub, hipSetDevice(sub->device));
+                if (npk > sub->cap_pack) {
+                    int rc = dev_alloc(sub, &sub->d_pack, npk);
+                    if (rc) return rc;
+                    sub->cap_pack = npk;
+                }
+                if (hi > lo) {
+                    EvalOut o;
+                    return run_eval(sub, pcof, ncoeff, hi - lo, nodes + lo, weights + lo, shift, adjoint, nullptr, nullptr, &o, sub->d_pack);
+                }
+                HIPCHK(sub, hipMemsetAsync(sub->d_pack, 0, npk * sizeof(double), sub->stream));   // no shard: contributes zeros
+                HIPCHK(sub, hipStreamSynchronize(sub->stream));
+                return JQ_OK;
+            };
+            rcs[d] = body();
+        });
+    for (auto& t : th) t.join();
+    for (int d = 0; d < nd; ++d)
+        if (rcs[d] != JQ_OK) {
+            h->err = h->subs[d]->err;
+            return rcs[d];
+        }
+    // ONE all-reduce (sum, fp64) of the packed vector over the devices
+    NCCLCHK(h, g_rccl.GroupStart());
+    for (int d = 0; d < nd; ++d) {
+        jq_handle* sub = h->subs[d];
+        HIPCHK(h, hipSetDevice(sub->device));
+        NCCLCHK(h, g_rccl.AllReduce(sub->d_pack, sub->d_pack, npk, ncclDouble, ncclSum, h->comms[d], sub->stream));
+    }
+    NCCLCHK(h, g_rccl.GroupEnd());
+    std::vector<double> packed(npk);
+    for (int d = nd - 1; d >= 0; --d) {
+        jq_handle* sub = h->subs[d];
+        HIPCHK(h, hipSetDevice(sub->device));
+        if (d == 0) HIPCHK(h, hipMemcpyAsync(packed.data(), sub->d_pack, npk * sizeof(double), hipMemcpyDeviceToHost, sub->stream));
+        HIPCHK(h, hipStreamSynchronize(sub->stream));
+    }
+    out2[0] = packed[0];
+    out2[1] = packed[1];
+    if (adjoint)
+        for (int i = 0; i < ncoeff; ++i) {
+            infid_grad[i] = packed[2 + i];
+            leak_grad[i] = packed[2 + (size_t)ncoeff + i];
+        }
+    multi_timing(h);
+    return JQ_OK;
+}
+
+static int multi_traceobj_sweep(jq_handle* h, const double* pcof, int ncoeff, const double* nodes, int nquad, const double* shift,
+                                double* out)
+{
+    const int nd = (int)h->subs.size();
+    std::vector<int> rcs(nd, JQ_OK);
+    std::vector<std::thread> th;
+    for (int d = 0; d < nd; ++d)
+        th.emplace_back([&, d]() {
+            jq_handle* sub = h->subs[d];
+            int lo = 0, hi = 0;
+            jq_shard_bounds(nquad, d, nd, &lo, &hi);
+            sub->timing = jq_timing{};
+            if (hi > lo) rcs[d] = jq_traceobj_sweep(sub, pcof, ncoeff, nodes + lo, hi - lo, shift, out + (size_t)4 * lo);
+        });
+    for (auto& t : th) t.join();
+    for (int d = 0; d < nd; ++d)
+        if (rcs[d] != JQ_OK) {
+            h->err = h->subs[d]->err;
+            return rcs[d];
+        }
+    multi_timing(h);
     return JQ_OK;
 }
 

@@ -38,7 +38,10 @@ class Working_Arrays_HIP:
         """leakage weights of this path: params.wmat_real (src/evalobjgrad.jl:583)"""
         return _f64(p.wmat_real)
 
-    def __init__(self, params: objparams, nCoeff: int):
+    def __init__(self, params: objparams, nCoeff: int, devices=None):
+        """devices: None = the current HIP device (one process per GPU); an int n or a list of device ids = ONE process
+        driving several GPUs (jq_create_multi: the ensemble of eval_f_g_grad is sharded over them and summed with one
+        RCCL all-reduce inside the library)."""
         L = _lib.load()
         if params.linear_solver.solver_id not in self.SOLVERS:
             raise ValueError("Please specify a supported linear solver")
@@ -58,11 +61,17 @@ class Working_Arrays_HIP:
         prob = _lib.jq_problem(p.Ntot, p.N, p.Ncoupled, p.Nfreq, p.nsteps, self._m, p.objFuncType, 0, p.T,
                                *[_ptr(a) for a in keep])
         h = ctypes.c_void_p()
-        rc = L.jq_create(ctypes.byref(prob), ctypes.byref(h))
+        if devices is None:
+            rc = L.jq_create(ctypes.byref(prob), ctypes.byref(h))
+        else:
+            devs = list(range(devices)) if isinstance(devices, int) else [int(d) for d in devices]
+            arr = (ctypes.c_int32 * len(devs))(*devs)
+            rc = L.jq_create_multi(ctypes.byref(prob), arr, len(devs), ctypes.byref(h))
         if rc != _lib.JQ_OK:
             msg = L.jq_last_error(None)
             raise _lib.JuqboxHipError(rc, msg.decode() if msg else "?")
         self.handle = h
+        self.num_devices = L.jq_num_devices(h)
 
     def close(self):
         if getattr(self, "handle", None):
@@ -147,10 +156,9 @@ def traceobjgrad(pcof0, params: objparams, wa: Working_Arrays_HIP, verbose: bool
         shp = (params.Ntot, params.N, params.nsteps + 1)
         ur = np.zeros(int(np.prod(shp)))
         ui = np.zeros_like(ur)
-        _lib.check(L.jq_state_history(h, _ptr(pcof), n, _ptr(ur), _ptr(ui)), h)
+        # history and objective from ONE forward sweep, like the reference's single pass
+        _lib.check(L.jq_traceobj_verbose(h, _ptr(pcof), n, _ptr(out4), _ptr(ur), _ptr(ui)), h)
         hist = ur.reshape(shp, order="F") + 1j * ui.reshape(shp, order="F")
-        # objective of the same evaluation (forward sweep only)
-        _lib.check(L.jq_traceobjgrad(h, _ptr(pcof), n, 0, _ptr(out4), None, None, None), h)
         return out4[0], hist, 1.0 - out4[3]
     if evaladjoint:
         tg, ig, lg = np.zeros(n), np.zeros(n), np.zeros(n)

@@ -20,24 +20,23 @@ def _dist():
 
 
 def shard_bounds(nquad, rank, world):
-    """Contiguous block partition of the nquad ensemble samples over `world` ranks."""
-    base, rem = divmod(nquad, world)
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
+    """Contiguous block partition of the nquad ensemble samples over `world` ranks: the library's own
+    jq_shard_bounds (the partition a multi-device handle uses for its GPUs), so ranks and devices shard alike."""
+    import ctypes
+    lo, hi = ctypes.c_int32(), ctypes.c_int32()
+    _lib.check(_lib.load().jq_shard_bounds(int(nquad), int(rank), int(world), ctypes.byref(lo), ctypes.byref(hi)))
+    return lo.value, hi.value
 
 
-def allreduce_sum_(vec, device=None):
-    """ONE all-reduce (sum, fp64) of the packed result vector over all ranks (RCCL when the process
-    group's backend is nccl; gloo in the CPU tests).  No-op without an initialised process group."""
+def allreduce_sum_(vec):
+    """ONE all-reduce (sum, fp64) of a packed host vector over all ranks (the gloo path of the CPU tests; the RCCL path
+    keeps the vector on the device, _hip_shard_eval_dev).  No-op without an initialised process group."""
     dist = _dist()
     if dist is None or dist.get_world_size() == 1:
         return vec
     import torch
     t = torch.from_numpy(vec)
-    if dist.get_backend() == "nccl":
-        t = t.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    vec[:] = t.cpu().numpy()
     return vec
 
 
@@ -55,6 +54,24 @@ def _hip_shard_eval(pcof, params, wa, nodes, weights, shift, compute_adjoint):
     _lib.check(L.jq_eval_f_g_grad(h, _ptr(pcof), n, _ptr(nodes), _ptr(weights), nodes.size, _ptr(sh),
                                   1 if compute_adjoint else 0, _ptr(out2), _ptr(ig), _ptr(lg)), h)
     return np.concatenate([out2, ig, lg])
+
+
+def _hip_shard_eval_dev(pcof, params, wa, nodes, weights, shift, compute_adjoint):
+    """The same evaluation for a job with one process per GPU over RCCL: the library leaves the packed partial sums
+    on the device (jq_eval_f_g_grad_dev), torch.distributed all-reduces them in place, ONE copy brings the result back.
+    A rank without a shard contributes zeros."""
+    import torch
+    dist = _dist()
+    L, h = _lib.load(), wa.handle
+    n = pcof.size
+    wa.sync_params()
+    t = torch.empty(2 + 2 * n, dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
+    sh = _f64(shift) if shift is not None else None
+    import ctypes
+    _lib.check(L.jq_eval_f_g_grad_dev(h, _ptr(pcof), n, _ptr(nodes), _ptr(weights), nodes.size, _ptr(sh),
+                                      1 if compute_adjoint else 0, ctypes.c_void_p(t.data_ptr())), h)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy()
 
 
 def eval_f_g_grad(pcof, params, wa, nodes=(0.0,), weights=(1.0,), compute_adjoint=True, shift=None,
@@ -77,11 +94,19 @@ def eval_f_g_grad(pcof, params, wa, nodes=(0.0,), weights=(1.0,), compute_adjoin
     lo, hi = 0, nodes.size
     if dist is not None and dist.get_world_size() > 1:
         lo, hi = shard_bounds(nodes.size, dist.get_rank(), dist.get_world_size())
+    # reset the memoised gradients like the reference (src/ipopt_interface.jl:27-31): a call with compute_adjoint = false
+    # must not leave the gradients of an older pcof behind the new last_pcof
+    params.last_infidelity_grad = np.zeros(n)
+    params.last_leak_grad = np.zeros(n) if params.objFuncType != 1 else np.zeros(0)
     packed = np.zeros(2 + 2 * n)
-    if hi > lo:
-        packed[:] = _shard_eval(pcof, params, wa, nodes[lo:hi].copy(), weights[lo:hi].copy(), shift, compute_adjoint)
-    if dist is not None and dist.get_world_size() > 1:
-        allreduce_sum_(packed)
+    if dist is not None and dist.get_backend() == "nccl" and _shard_eval is _hip_shard_eval:
+        # one process per GPU (also with a single rank): partial sums stay on the device for the RCCL all-reduce
+        packed[:] = _hip_shard_eval_dev(pcof, params, wa, nodes[lo:hi].copy(), weights[lo:hi].copy(), shift, compute_adjoint)
+    else:
+        if hi > lo:
+            packed[:] = _shard_eval(pcof, params, wa, nodes[lo:hi].copy(), weights[lo:hi].copy(), shift, compute_adjoint)
+        if dist is not None and dist.get_world_size() > 1:
+            allreduce_sum_(packed)
     params.last_pcof = pcof.copy()
     params.last_infidelity = float(packed[0])
     params.last_leak = float(packed[1])

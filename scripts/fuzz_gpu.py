@@ -11,10 +11,12 @@ from test_gpu_random import random_problem
 
 
 def run(n_cases=50, seed=1, verbose=True):
-    """Returns (worst relative error, number of evaluated cases)."""
+    """Returns (worst relative error, number of cases really compared with the oracle -- combinations without kernels
+    (JQ_EUNSUPPORTED) are skipped and NOT counted)."""
     nonlocal_print = print if verbose else (lambda *a, **k: None)
     rng = np.random.default_rng(seed)
     worst = 0.0
+    compared = 0
     t0 = time.time()
     for case in range(n_cases):
         Ntot = int(rng.choice([2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 14, 16, 17, 20, 31, 32, 33, 40, 48, 50, 63, 64, 65, 80, 81, 95, 96]))
@@ -79,13 +81,14 @@ def run(n_cases=50, seed=1, verbose=True):
         e4 = np.linalg.norm(p.last_leak_grad - gl) / max(np.linalg.norm(gi), 1e-300) if oft != 1 else 0.0
         err = max(e1, e2, e3, e4)
         worst = max(worst, err)
+        compared += 1
         flag = "" if err < 1e-8 else "   <<<<<< MISMATCH"
         nonlocal_print("%3d Ntot=%2d N=%2d Nc=%d Nf=%d steps=%2d m=%d oft=%d %-5s %s nq=%2d fam=%d %-18s env=%s err=%.1e%s" % (
             case, Ntot, N, Nc, Nfreq, nsteps, m, oft, structure, "IMR" if imr else "SV ", nq, fam, mode, env.get("JQ_CHUNK_STEPS", "-"), err, flag), flush=True)
         wa.close()
-    nonlocal_print("worst relative error %.2e over %d cases in %.0f s" % (worst, n_cases, time.time() - t0))
+    nonlocal_print("worst relative error %.2e over %d compared cases (of %d drawn) in %.0f s" % (worst, compared, n_cases, time.time() - t0))
 
-    return worst, n_cases
+    return worst, compared
 
 
 if __name__ == "__main__":

@@ -77,3 +77,53 @@ def test_product_never_imports_the_oracle():
             if fn.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
                 txt = open(os.path.join(dirpath, fn)).read()
                 assert not bad.search(txt), fn
+
+
+def test_shard_bounds_is_a_contiguous_balanced_partition():
+    """jq_shard_bounds: the ONE partition rule of the ensemble -- devices of a multi-device handle and ranks of a
+    torch.distributed job (juqbox.jl_amd/ipopt_interface.py::shard_bounds calls it) shard alike.  Pure host arithmetic."""
+    from juqbox_jl_amd import _lib
+    from juqbox_jl_amd.ipopt_interface import shard_bounds
+    L = _lib.load()
+    for nquad in (0, 1, 7, 9, 512, 513, 24576):
+        for world in (1, 2, 3, 4, 8):
+            b = [shard_bounds(nquad, r, world) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == nquad
+            assert all(b[r][1] == b[r + 1][0] for r in range(world - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    lo, hi = ctypes.c_int32(), ctypes.c_int32()
+    assert L.jq_shard_bounds(8, 2, 2, ctypes.byref(lo), ctypes.byref(hi)) == _lib.JQ_EINVAL
+    assert L.jq_shard_bounds(8, 0, 0, ctypes.byref(lo), ctypes.byref(hi)) == _lib.JQ_EINVAL
+    assert L.jq_shard_bounds(8, 0, 2, None, None) == _lib.JQ_EINVAL
+
+
+def test_multi_device_create_fails_loudly_without_enough_gpus():
+    from juqbox_jl_amd import _lib
+    L = _lib.load()
+    n = L.jq_device_count()
+    params, info, pcof, _ = case_inputs("swap02")
+    prob, keep = _problem(None, params)
+    h = ctypes.c_void_p()
+    assert L.jq_create_multi(ctypes.byref(prob), None, n + 1, ctypes.byref(h)) == _lib.JQ_EINVAL
+    assert h.value is None and b"visible" in L.jq_last_error(None)
+    assert L.jq_create_multi(ctypes.byref(prob), None, 0, ctypes.byref(h)) == _lib.JQ_EINVAL
+    assert L.jq_num_devices(None) == 0
+
+
+def test_bench_refuses_a_gpu_count_it_cannot_see():
+    """`python bench.py --gpus N` must never print an n_gpus line from fewer devices (round-1 verdict): without a launcher
+    it starts the N ranks itself, and refuses before that when fewer than N GPUs are visible."""
+    import subprocess
+    import sys
+    from juqbox_jl_amd import _lib
+    n = _lib.load().jq_device_count()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 2)], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode != 0 and "GPU(s) are visible" in r.stderr
+    assert not any(ln.startswith("{") for ln in r.stdout.splitlines())
+    # under a launcher whose WORLD_SIZE disagrees with --gpus
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode != 0 and "does not match WORLD_SIZE" in r.stderr

@@ -1,0 +1,257 @@
+"""GPU (-m gpu): the parity gaps of the round-1 verdict and the multi-GPU entry points.
+
+ (1) the EXACT path bench.py times -- cnot3 at full length (32 386 steps), 3 072 PERTURBED samples (use_shift = 1),
+     quad-layout kernels with three slabs per workgroup -- against the CPU oracle: one-hot ensemble weights select
+     single samples, whose infidelity / leak / gradient are compared with oracle evaluations of the same perturbed
+     Hamiltonian; the forward-only sweep entry gives the per-sample objectives of ALL samples;
+ (2) SWAP-02 risk-neutral at BASELINE's 512 nodes against the oracle's serial ensemble loop;
+ (3) the cnot3 state history against the oracle at sampled steps;
+ (4) chunking rules (trace-record budget, gridDim.y cap at nsteps > 32 767);
+ (5) multi-GPU: a one-device multi-device handle (RCCL inside the library), a one-rank nccl process group through
+     torch.distributed (the device-resident packed result), bench.py's launcher.
+Tolerance: 1e-10 relative (north_star: "within a stated fp64 tolerance"; the reference's own rtol, test/evalGrad.jl:4)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+from conftest import ROOT, case_inputs
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-10
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def hip(jq):
+    from juqbox_jl_amd import _lib
+    assert _lib.load().jq_device_count() >= 1, "no HIP device: the hot path has no CPU fallback"
+    return jq
+
+
+def oracle_sample(params, pcof, ep, shift, **kw):
+    """oracle evaluation of ONE ensemble sample: Hconst + ep * diag(shift) (src/ipopt_interface.jl:41-44)"""
+    from oracle.oracle import Oracle
+    H0 = params.Hconst.copy()
+    params.Hconst = H0 + np.diag(ep * shift)
+    try:
+        return Oracle(params).traceobjgrad(pcof, **kw)
+    finally:
+        params.Hconst = H0
+
+
+def test_bench_path_full_length_perturbed_samples_match_the_oracle(hip):
+    jq = hip
+    params, info, pcof, _ = case_inputs("cnot3")
+    ns = 3072
+    nodes, weights, shift = jq.cases.cnot3_ensemble(ns)          # bench.py's ensemble: nonzero nodes
+    wa = jq.Working_Arrays_HIP(params, pcof.size)
+    picks = [0, 1537, 3071]          # first / middle / last sample: different slabs, waves and workgroups
+    refs = {i: oracle_sample(params, pcof, nodes[i], shift) for i in picks}
+    for i in picks:
+        w = np.zeros(ns)
+        w[i] = 1.0
+        jq.eval_f_g_grad(pcof, params, wa, nodes, w, True, shift=shift)
+        t = wa.last_timing()
+        assert t["kernel_family"] == 6 and t["kernel_band"] == 7 and t["kernel_size"] == 6      # bench.py's kernels
+        r = refs[i]
+        assert abs(params.last_infidelity - r["primaryobjf"]) <= TOL * abs(r["primaryobjf"]), i
+        assert abs(params.last_leak - r["secondaryobjf"]) <= TOL * abs(r["secondaryobjf"]), i
+        assert rel(params.last_infidelity_grad, r["totalgrad"]) < TOL, i
+    # the perturbation matters at this tolerance (the test would not notice a dropped shift otherwise)
+    assert abs(refs[0]["primaryobjf"] - refs[1537]["primaryobjf"]) > 1e-7 * abs(refs[1537]["primaryobjf"])
+    # per-sample objectives of the whole ensemble from the forward-only sweep entry
+    sw = jq.traceobj_sweep(pcof, params, wa, nodes, shift)
+    for i in picks:
+        assert abs(sw[i, 1] - refs[i]["primaryobjf"]) <= TOL * abs(refs[i]["primaryobjf"])
+        assert abs(sw[i, 2] - refs[i]["secondaryobjf"]) <= TOL * abs(refs[i]["secondaryobjf"])
+    # the quadrature nodes are symmetric and the detuning enters the objective smoothly: the sweep is a smooth curve
+    assert np.all(np.isfinite(sw)) and np.max(np.abs(np.diff(sw[:, 1]))) < 1e-3
+    # the full weighted ensemble equals the weighted sum of the sweep (linearity of eval_f_g_grad! in the weights)
+    jq.eval_f_g_grad(pcof, params, wa, nodes, weights, True, shift=shift)
+    assert abs(params.last_infidelity - np.dot(weights, sw[:, 1])) <= 1e-12
+    assert abs(params.last_leak - np.dot(weights, sw[:, 2])) <= 1e-15
+    wa.close()
+
+
+def test_swap02_risk_neutral_512_nodes_matches_the_oracle_loop(hip):
+    """BASELINE configs[4]: examples/Risk_Neutral/swap-02-risk-neutral.jl with 512 Gauss-Legendre nodes and the reference's
+    own perturbation 0.01 ep 10^(j-2)."""
+    from oracle.oracle import Oracle
+    jq = hip
+    params, info, pcof, _ = case_inputs("swap02_rn")
+    nodes, weights = info["nodes"], info["weights"]
+    assert nodes.size == 512
+    ref = Oracle(params).eval_f_g_grad(pcof, nodes, weights, params.shift_weights_reference())
+    wa = jq.Working_Arrays_HIP(params, pcof.size)
+    jq.eval_f_g_grad(pcof, params, wa, nodes, weights, True)
+    assert abs(params.last_infidelity - ref["last_infidelity"]) <= TOL * abs(ref["last_infidelity"])
+    assert abs(params.last_leak - ref["last_leak"]) <= TOL * abs(ref["last_leak"])
+    assert rel(params.last_infidelity_grad, ref["last_infidelity_grad"]) < TOL
+    wa.close()
+
+
+def test_cnot3_state_history_matches_the_oracle_at_sampled_steps(hip):
+    from oracle.oracle import Oracle
+    jq = hip
+    params, info, pcof, _ = case_inputs("cnot3")
+    r = Oracle(params).traceobjgrad(pcof, evaladjoint=False, history=True)
+    wa = jq.Working_Arrays_HIP(params, pcof.size)
+    objfv, hist, fid = jq.traceobjgrad(pcof, params, wa, True, False)      # ONE forward sweep: history + objective
+    steps = np.unique(np.concatenate([np.arange(0, params.nsteps + 1, 97), [1, 2, params.nsteps - 1, params.nsteps]]))
+    assert steps.size > 300
+    assert np.max(np.abs(hist[:, :, steps] - r["history"][:, :, steps])) < 1e-11
+    assert abs(objfv - r["objfv"]) <= TOL * abs(r["objfv"])
+    # the device-side consumers (jq_state_populations) against numpy on the ORACLE's history: level populations at every
+    # 500th step, third-subsystem marginals, maxima over all columns and steps
+    p2 = np.abs(r["history"]) ** 2
+    pop, maxpop = jq.state_populations(pcof, params, wa, every=500)
+    assert np.max(np.abs(pop - p2[:, :, ::500])) < 1e-11
+    assert np.max(np.abs(maxpop - p2.max(axis=(1, 2)))) < 1e-11
+    m3 = jq.marginalize3_device(pcof, params, wa, every=500)
+    grp = jq.plotstatectrl._subsystem_indices(params)[2]
+    ref3 = np.zeros_like(m3)
+    for row in range(params.Ntot):
+        ref3[grp[row]] += p2[row, :, ::500]
+    assert np.max(np.abs(m3 - ref3)) < 1e-11
+    wa.close()
+
+
+def test_trace_record_budget_only_changes_the_chunking(hip):
+    """JQ_TRACE_BYTES bounds the per-step trace records of a backward chunk: a tiny budget forces many short chunks and
+    must give the same result (cnot3 shortened to 240 steps, 40 perturbed samples)."""
+    jq = hip
+    params, info, pcof, _ = case_inputs("cnot3")
+    params.nsteps = 240
+    params.T = params.T * 240 / 32386
+    nodes, weights, shift = jq.cases.cnot3_ensemble(40)
+    res = []
+    for budget in (None, "20000"):
+        if budget:
+            os.environ["JQ_TRACE_BYTES"] = budget
+        try:
+            wa = jq.Working_Arrays_HIP(params, pcof.size)
+            jq.eval_f_g_grad(pcof, params, wa, nodes, weights, True, shift=shift)
+        finally:
+            os.environ.pop("JQ_TRACE_BYTES", None)
+        res.append((params.last_infidelity, params.last_leak, params.last_infidelity_grad.copy(),
+                    wa.last_timing()["n_backward_launches"]))
+        wa.close()
+    assert res[1][3] > res[0][3]
+    assert abs(res[0][0] - res[1][0]) <= 1e-13 and abs(res[0][1] - res[1][1]) <= 1e-16
+    assert rel(res[1][2], res[0][2]) < 1e-12
+
+
+def test_more_than_32767_steps_per_evaluation(hip):
+    """k_ctrl / k_stream index the time points of a chunk with gridDim.y: chunks are capped at 32 767 steps, so longer
+    gates take more than one chunk (rabi with 40 000 steps vs the oracle)."""
+    from oracle.oracle import Oracle
+    jq = hip
+    params, info, pcof, _ = case_inputs("rabi")
+    params.nsteps = 40000
+    r = Oracle(params).traceobjgrad(pcof)
+    wa = jq.Working_Arrays_HIP(params, pcof.size)
+    objfv, tg, *_ = jq.traceobjgrad(pcof, params, wa, False, True)
+    assert wa.last_timing()["n_forward_launches"] >= 2
+    assert abs(objfv - r["objfv"]) <= max(TOL * abs(r["objfv"]), 1e-14)
+    assert np.linalg.norm(tg - r["totalgrad"]) <= max(TOL * np.linalg.norm(r["totalgrad"]), 1e-14)
+    wa.close()
+
+
+# ---- multi-GPU entry points ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case,nquad", [("swap02_rn", 64), ("cnot2-leakieq", 5)])
+def test_multi_device_handle_with_one_device_matches_the_single_device_handle(hip, case, nquad):
+    """jq_create_multi on the one GPU of this box: sharding, per-device packing and the ncclAllReduce (1-rank communicator
+    from ncclCommInitAll) run for real; results must equal the single-device handle's, which the oracle pins."""
+    jq = hip
+    params, info, pcof, _ = case_inputs(case)
+    x, w = np.polynomial.legendre.leggauss(nquad)
+    nodes, weights = x * 0.5 * (2 * np.pi * 2e-2), w * 0.5
+    shift = None if params.Ntot <= 4 else 0.05 * np.arange(params.Ntot)
+    wa1 = jq.Working_Arrays_HIP(params, pcof.size)
+    jq.eval_f_g_grad(pcof, params, wa1, nodes, weights, True, shift=shift)
+    a = (params.last_infidelity, params.last_leak, params.last_infidelity_grad.copy(), params.last_leak_grad.copy())
+    sw1 = jq.traceobj_sweep(pcof, params, wa1, nodes, shift)
+    t1 = jq.traceobjgrad(pcof, params, wa1, False, True)
+    wa1.close()
+    wam = jq.Working_Arrays_HIP(params, pcof.size, devices=[0])
+    assert wam.num_devices == 1
+    jq.eval_f_g_grad(pcof, params, wam, nodes, weights, True, shift=shift)
+    assert abs(params.last_infidelity - a[0]) <= 1e-13 * abs(a[0]) and abs(params.last_leak - a[1]) <= 1e-13 * abs(a[1])
+    assert rel(params.last_infidelity_grad, a[2]) < 1e-13
+    if params.objFuncType != 1:
+        assert np.linalg.norm(params.last_leak_grad - a[3]) <= 1e-13 * np.linalg.norm(a[2])
+    assert wam.last_timing()["svts"] == nquad * params.N * params.nsteps
+    assert np.array_equal(jq.traceobj_sweep(pcof, params, wam, nodes, shift), sw1)
+    tm = jq.traceobjgrad(pcof, params, wam, False, True)
+    assert tm[0] == t1[0] and np.array_equal(tm[1], t1[1])
+    params.linear_solver.max_iter += 1                           # mutations reach every device handle
+    jq.eval_f_g_grad(pcof, params, wam, nodes, weights, True, shift=shift)
+    assert params.last_infidelity != a[0]
+    wam.close()
+
+
+def test_multi_device_handle_rejects_more_devices_than_visible(hip):
+    from juqbox_jl_amd import _lib
+    jq = hip
+    params, info, pcof, _ = case_inputs("swap02")
+    n = _lib.load().jq_device_count()
+    with pytest.raises(_lib.JuqboxHipError) as e:
+        jq.Working_Arrays_HIP(params, pcof.size, devices=n + 1)
+    assert e.value.code == _lib.JQ_EINVAL
+    with pytest.raises(_lib.JuqboxHipError):
+        jq.Working_Arrays_HIP(params, pcof.size, devices=[0, 0])
+
+
+_NCCL_WORKER = r"""
+import json, os, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import torch, torch.distributed as dist
+import juqbox_jl_amd as jq
+from conftest import case_inputs
+torch.cuda.set_device(0)
+params, info, pcof, _ = case_inputs("swap02_rn")
+nodes, weights = info["nodes"][:96], info["weights"][:96]
+wa = jq.Working_Arrays_HIP(params, pcof.size)
+jq.eval_f_g_grad(pcof, params, wa, nodes, weights, True)                       # no process group: host path
+a = [params.last_infidelity, params.last_leak] + params.last_infidelity_grad.tolist()
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+jq.eval_f_g_grad(pcof, params, wa, nodes, weights, True)                       # device-resident packed result + all_reduce
+b = [params.last_infidelity, params.last_leak] + params.last_infidelity_grad.tolist()
+jq.eval_f_g_grad(pcof, params, wa, nodes, weights, False)
+c = [params.last_infidelity, params.last_leak, float(np.abs(params.last_infidelity_grad).max())]
+dist.barrier(); dist.destroy_process_group(); wa.close()
+print("RESULT " + json.dumps(dict(a=a, b=b, c=c, backend="nccl")))
+"""
+
+
+def test_one_rank_nccl_process_group_uses_the_device_resident_result(hip):
+    """eval_f_g_grad under an initialised nccl (= RCCL) process group with ONE rank: jq_eval_f_g_grad_dev leaves the packed
+    sums on the GPU, torch.distributed all-reduces them there.  Fresh process: the group must not leak into other tests."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _NCCL_WORKER.format(root=ROOT)], capture_output=True, text=True, env=env,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    a, b, c = np.array(res["a"]), np.array(res["b"]), res["c"]
+    assert abs(a[0] - b[0]) <= 1e-13 * abs(a[0]) and abs(a[1] - b[1]) <= 1e-13 * abs(a[1])
+    assert rel(b[2:], a[2:]) < 1e-13
+    assert abs(c[0] - a[0]) <= 1e-13 * abs(a[0]) and c[2] == 0.0      # compute_adjoint = false: gradients reset to zero
+
+
+def test_bench_refuses_more_gpus_than_visible(hip):
+    from juqbox_jl_amd import _lib
+    n = _lib.load().jq_device_count()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1)], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode != 0 and "GPU(s) are visible" in r.stderr
+    assert not any(ln.startswith("{") for ln in r.stdout.splitlines())       # and no JSON line that could be mistaken for a result

@@ -114,3 +114,22 @@ def test_callbacks_memoise_and_add_tikhonov(jq):
     rows, cols = np.zeros(pcof.size, dtype=np.int32), np.zeros(pcof.size, dtype=np.int32)
     ii.eval_jac_g_par(pcof, rows, cols, None, params, wa)
     assert rows[0] == 1 and cols[-1] == pcof.size
+
+
+def test_eval_f_g_grad_resets_the_memoised_gradients_like_the_reference():
+    """src/ipopt_interface.jl:23-27: every call zeroes last_infidelity_grad / last_leak_grad first, so a forward-only call
+    (compute_adjoint = false) cannot leave the gradient of an OLDER pcof behind the new last_pcof."""
+    import juqbox_jl_amd as jq
+    from juqbox_jl_amd import ipopt_interface as ii
+    from conftest import case_inputs
+    params, info, pcof, _ = case_inputs("cnot2-leakieq")
+    n = pcof.size
+
+    def fake(pcof, params, wa, nodes, weights, shift, adj):
+        return np.concatenate([[0.25, 0.5], np.full(n, 3.0) if adj else np.zeros(n), np.full(n, 7.0) if adj else np.zeros(n)])
+    ii.eval_f_g_grad(pcof, params, None, [0.0], [1.0], True, _shard_eval=fake)
+    assert np.all(params.last_infidelity_grad == 3.0) and np.all(params.last_leak_grad == 7.0)
+    ii.eval_f_g_grad(pcof + 1e-3, params, None, [0.0], [1.0], False, _shard_eval=fake)
+    assert params.last_infidelity == 0.25 and params.last_leak == 0.5
+    assert np.all(params.last_infidelity_grad == 0.0) and np.all(params.last_leak_grad == 0.0)
+    assert np.array_equal(params.last_pcof, pcof + 1e-3)

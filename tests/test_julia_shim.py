@@ -1,0 +1,104 @@
+"""CPU: julia/hip_backend.jl (the binding a Juqbox.jl maintainer includes; Julia is not in the image) against
+include/juqbox_hip.h -- struct layouts (field order, names, types) and the return / argument types of EVERY ccall."""
+import os
+import re
+
+from conftest import ROOT
+
+CTYPE = {  # C type -> the Julia types a ccall may use for it
+    "int": {"Cint", "Int32"}, "int32_t": {"Int32", "Cint"}, "int64_t": {"Int64"}, "double": {"Float64", "Cdouble"},
+    "void": {"Cvoid"},
+    "const double *": {"Ptr{Float64}"}, "double *": {"Ptr{Float64}"},
+    "const int32_t *": {"Ptr{Int32}"}, "int32_t *": {"Ref{Int32}", "Ptr{Int32}"},
+    "jq_handle *": {"Ptr{Cvoid}"}, "const jq_handle *": {"Ptr{Cvoid}"}, "jq_handle **": {"Ref{Ptr{Cvoid}}"},
+    "const jq_problem *": {"Ref{JQProblem}"}, "jq_timing *": {"Ref{JQTiming}"},
+    "const char *": {"Cstring"}, "void *": {"Ptr{Cvoid}"},
+}
+
+
+def _norm(t):
+    t = re.sub(r"\s+", " ", t.strip())
+    return re.sub(r"\s*\*", " *", t).replace("* *", "**")
+
+
+def header():
+    txt = open(os.path.join(ROOT, "include", "juqbox_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    structs = {}
+    for name in ("jq_problem", "jq_timing"):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), txt, flags=re.S).group(1)
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if decl:
+                m = re.match(r"(.*?)(\w+)$", decl)
+                fields.append((m.group(2), _norm(m.group(1))))
+        structs[name] = fields
+    protos = {}
+    for m in re.finditer(r"^([\w ]+?\*?)\s*(jq_\w+)\s*\(([^;]*?)\);", txt, flags=re.M | re.S):
+        ret, name, args = _norm(m.group(1)), m.group(2), m.group(3)
+        argt = []
+        if args.strip() != "void":
+            for a in args.split(","):
+                mm = re.match(r"(.*?)(\w+)$", a.strip())
+                argt.append(_norm(mm.group(1)))
+        protos[name] = (ret, argt)
+    return structs, protos
+
+
+def julia():
+    txt = open(os.path.join(ROOT, "julia", "hip_backend.jl")).read()
+    txt = re.sub(r"#.*", "", txt)
+    structs = {}
+    for name in ("JQProblem", "JQTiming"):
+        body = re.search(r"struct %s\s*\n(.*?)\nend" % name, txt, flags=re.S).group(1)
+        structs[name] = [tuple(x.strip() for x in ln.split("::")) for ln in body.splitlines() if "::" in ln]
+    calls = []
+    for m in re.finditer(r"ccall\(\(:(\w+),\s*libjq\),\s*(\w+),\s*\(", txt):
+        i, depth = m.end(), 1
+        while depth:                       # the argument-type tuple, with nested braces / parentheses
+            depth += {"(": 1, ")": -1}.get(txt[i], 0)
+            i += 1
+        tup = txt[m.end():i - 1]
+        parts, cur, d = [], "", 0
+        for ch in tup:
+            d += {"{": 1, "}": -1}.get(ch, 0)
+            if ch == "," and d == 0:
+                parts.append(cur.strip())
+                cur = ""
+            else:
+                cur += ch
+        if cur.strip():
+            parts.append(cur.strip())
+        calls.append((m.group(1), m.group(2), parts))
+    return structs, calls
+
+
+def test_struct_layouts_match_the_header():
+    hs, _ = header()
+    js, _ = julia()
+    for cname, jname in (("jq_problem", "JQProblem"), ("jq_timing", "JQTiming")):
+        cf, jf = hs[cname], js[jname]
+        assert [n for n, _ in cf] == [n for n, _ in jf], (cname, "field names / order")
+        for (n, ct), (_, jt) in zip(cf, jf):
+            assert jt in CTYPE[ct], (cname, n, ct, jt)
+
+
+def test_every_ccall_matches_its_prototype():
+    _, protos = header()
+    _, calls = julia()
+    assert len(calls) >= 20
+    for name, ret, args in calls:
+        assert name in protos, "ccall of an undeclared symbol: " + name
+        cret, cargs = protos[name]
+        assert ret in CTYPE[cret], (name, "return", cret, ret)
+        assert len(args) == len(cargs), (name, "argument count", cargs, args)
+        for k, (ct, jt) in enumerate(zip(cargs, args)):
+            assert jt in CTYPE[ct], (name, k, ct, jt)
+
+
+def test_the_shim_binds_every_hot_path_entry_point():
+    _, protos = header()
+    _, calls = julia()
+    bound = {c[0] for c in calls}
+    assert set(protos) - bound == set(), "header entry points the Julia shim does not bind: %s" % sorted(set(protos) - bound)
