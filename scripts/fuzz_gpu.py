@@ -18,7 +18,9 @@ def run(n_cases=50, seed=1, verbose=True):
     worst = 0.0
     compared = 0
     t0 = time.time()
-    for case in range(n_cases):
+    case = -1
+    while compared < n_cases and case + 1 < 2 * n_cases:     # draws without kernels (JQ_EUNSUPPORTED) are replaced, not counted
+        case += 1
         Ntot = int(rng.choice([2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 14, 16, 17, 20, 31, 32, 33, 40, 48, 50, 63, 64, 65, 80, 81, 95, 96]))
         N = int(rng.integers(1, min(Ntot, 16) + 1))
         Nc = int(rng.integers(1, 5))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""profiles/r01_hbm_traffic.json from rocprofv3 PMC passes (rocpd sqlite files).
+"""profiles/r02_pmc.json (round 1: r01_hbm_traffic.json) from rocprofv3 PMC passes (rocpd sqlite files).
 
-usage: make_traffic_json.py out.json <db> [<db> ...]
+usage: make_traffic_json.py out.json [--version "<jq_version>"] [--samples N] <db> [<db> ...]
 Every db is one `rocprofv3 --pmc <counters> --kernel-trace` pass of the same command.  FETCH_SIZE / WRITE_SIZE
 are in KiB; per MI355X_MICROARCH.md (HBM section) FETCH_SIZE under-reports wide (16 B/lane) coalesced reads by
 exactly 2x on gfx950, so fetch bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE is taken as is.  SQ_* counters are
@@ -27,7 +27,15 @@ def short(name):
 
 
 def main():
-    out_path, dbs = sys.argv[1], sys.argv[2:]
+    out_path, rest = sys.argv[1], sys.argv[2:]
+    version, samples = None, None
+    while rest and rest[0].startswith("--"):
+        if rest[0] == "--version":
+            version = rest[1]
+        elif rest[0] == "--samples":
+            samples = int(rest[1])
+        rest = rest[2:]
+    dbs = rest
     acc = defaultdict(lambda: defaultdict(float))
     launches = defaultdict(int)
     for path in dbs:
@@ -57,8 +65,24 @@ def main():
             if "SQ_VALU_MFMA_BUSY_CYCLES" in sq and "SQ_WAVE_CYCLES" in sq and "k_" in k:
                 # one wave per SIMD in the MFMA kernels: MFMA busy cycles (per SIMD) / 4 / wave cycles
                 e["mfma_busy_frac_of_wave_cycles"] = sq["SQ_VALU_MFMA_BUSY_CYCLES"] / 4.0 / sq["SQ_WAVE_CYCLES"]
+            # what bench.py's roofline block quotes (per launch): MFMA instructions in units of one v_mfma_f64_16x16x4
+            # (2048 FLOP; the quad / JQ_BW_T4 kernels issue v_mfma_f64_4x4x4_4b = 512 FLOP, a quarter), instruction mix, stalls
+            if sq.get("SQ_INSTS_MFMA"):
+                quarter = k.endswith(", 7>") or k.endswith(", 8>")
+                e["mfma_insts_per_launch"] = sq["SQ_INSTS_MFMA"] / n
+                e["mfma_flop_per_inst"] = 512 if quarter else 2048
+                e["mfma_16x16x4_equiv_per_launch"] = sq["SQ_INSTS_MFMA"] / n / (4.0 if quarter else 1.0)
+                if "SQ_INSTS_VALU" in sq:
+                    e["valu_per_mfma"] = (sq["SQ_INSTS_VALU"] - sq["SQ_INSTS_MFMA"]) / sq["SQ_INSTS_MFMA"]     # (SQ_INSTS_VALU includes the MFMAs)
+            if sq.get("SQ_WAVE_CYCLES"):
+                if "SQ_WAIT_ANY" in sq:
+                    e["wait_frac"] = sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"]
+                if "SQ_WAIT_INST_ANY" in sq:
+                    e["wait_inst_frac"] = sq["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"]
+        if samples is not None:
+            e["samples_per_gpu"] = samples
         kernels[k] = e
-    json.dump({"note": __doc__.split("usage:")[1].strip(), "kernels": kernels}, open(out_path, "w"), indent=1)
+    json.dump({"note": __doc__.split("usage:")[1].strip(), "library_version": version, "kernels": kernels}, open(out_path, "w"), indent=1)
     print("wrote", out_path, "kernels:", ", ".join(sorted(kernels)))
 
 

@@ -13,4 +13,4 @@ def test_fixed_seed_fuzz_matches_oracle():
     import fuzz_gpu
     worst, n = fuzz_gpu.run(60, 11, verbose=False)
     # n = cases really compared with the oracle (drawn combinations without kernels are skipped, not counted)
-    assert n >= 55 and worst < 1e-9, (n, worst)
+    assert n == 60 and worst < 1e-9, (n, worst)
