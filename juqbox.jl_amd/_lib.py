@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libjuqbox_hip.so")
+# JQ_LIB: another build of the SAME library (kernel experiments, scripts/exp_variants.sh); never a different backend
+LIB_PATH = os.environ.get("JQ_LIB") or os.path.join(_HERE, "libjuqbox_hip.so")
 
 c_dp = ctypes.POINTER(ctypes.c_double)
 c_i32 = ctypes.c_int32

@@ -187,7 +187,11 @@ __device__ __forceinline__ double a_dot(const Arr<NT>& x, const Arr<NT>& y)
     double s = 0.0;
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
+#if JQ_RL == 1 && defined(JQ_EXP_DOTFMA)
+        s = fma(x.t[i][0], y.t[i][0], s);
+#else
         s += row_sum(x.t[i] * y.t[i]);
+#endif
     }
     return s;
 }
@@ -506,6 +510,9 @@ __device__ __forceinline__ double row_shift4(double x)
         int i[2];
     } a, b;
     a.d = x;
+#ifdef JQ_EXP_NOSHIFT      // timing experiment only (wrong results): what the lane shifts cost
+    return x;
+#endif
     b.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], CTRL, 0xf, 0xf, true);
     b.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], CTRL, 0xf, 0xf, true);
     return b.d;
@@ -715,6 +722,43 @@ __device__ __forceinline__ double wave_sum(double x)
     return (lane_bcast(x, 0) + lane_bcast(x, 16)) + (lane_bcast(x, 32) + lane_bcast(x, 48));
 }
 
+// Wave sums of FOUR values at a time (gfx950 row-swap instructions): v_permlane32_swap exchanges the rows 2, 3 of one
+// register with the rows 0, 1 of another, so ONE add halves two values at once (rows: a0+a2, a1+a3, b0+b2, b1+b3);
+// v_permlane16_swap (odd rows of the first <-> even rows of the second) does the same for the next level and leaves the
+// 16 column partials of a, c, b, d in the rows 0, 1, 2, 3; four DPP rotate-adds finish all four.  21 VALU instructions
+// for four sums instead of 4 x 23 (wave_sum); the sum of a / c / b / d is valid in every lane of row 0 / 1 / 2 / 3.
+typedef unsigned jq_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void row_swap32(double& a, double& b)
+{
+    union { double d; unsigned u[2]; } x, y;
+    x.d = a, y.d = b;
+    const jq_u2 lo = __builtin_amdgcn_permlane32_swap(x.u[0], y.u[0], false, false);
+    const jq_u2 hi = __builtin_amdgcn_permlane32_swap(x.u[1], y.u[1], false, false);
+    x.u[0] = lo[0], y.u[0] = lo[1], x.u[1] = hi[0], y.u[1] = hi[1];
+    a = x.d, b = y.d;
+}
+__device__ __forceinline__ void row_swap16(double& a, double& b)
+{
+    union { double d; unsigned u[2]; } x, y;
+    x.d = a, y.d = b;
+    const jq_u2 lo = __builtin_amdgcn_permlane16_swap(x.u[0], y.u[0], false, false);
+    const jq_u2 hi = __builtin_amdgcn_permlane16_swap(x.u[1], y.u[1], false, false);
+    x.u[0] = lo[0], y.u[0] = lo[1], x.u[1] = hi[0], y.u[1] = hi[1];
+    a = x.d, b = y.d;
+}
+__device__ __forceinline__ double wave_sum4(double a, double b, double c, double d)
+{
+    row_swap32(a, b);
+    double p = a + b;
+    row_swap32(c, d);
+    double q = c + d;
+    row_swap16(p, q);
+    double r = p + q;
+    r = row_ror_add<8>(r);
+    r = row_ror_add<4>(r);
+    r = row_ror_add<2>(r);
+    return row_ror_add<1>(r);
+}
 // ---------------------------------------------------------------------------------------------
 // One entry of the per-step operator schedule: which image the next product group multiplies with.
 //   kind 0/1: K / S of the tile stream at time point 2*n + tp of the chunk;  kind 2: constant image #tp
@@ -1147,7 +1191,11 @@ __device__ __forceinline__ void horner_add(Arr<NT>& out, const Arr<NT>& bpa, con
         mm_c<NT, BW>(out, bpa, S, A);
         return;
     }
+#ifdef JQ_EXP_NOOPQ
+    if constexpr (false) {
+#else
     if constexpr (BW == JQ_BW_T4Q) {
+#endif
         OpQ<NT> op;
         t4q_load(op, S);
         mm_t4q_regs(Ya, A, op, A);
@@ -1157,7 +1205,7 @@ __device__ __forceinline__ void horner_add(Arr<NT>& out, const Arr<NT>& bpa, con
     }
     mm_c<NT, BW>(Ya, A, S, A);  // Y1 = A + S A
     --rem;
-    if constexpr (BW == JQ_BW_OD || BW == JQ_BW_T4) {
+    if constexpr (BW == JQ_BW_OD || BW == JQ_BW_T4 || BW == JQ_BW_T4Q) {
         // mm_od / mm_t4 are alias-safe: the recurrence runs in place and Yb is never touched (48 registers less)
         for (; rem > 0; --rem) mm_c<NT, BW>(Ya, A, S, Ya);
         mm_c<NT, BW>(out, bpa, S, Ya);
@@ -1371,12 +1419,14 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
     double* P0 = a.park_lds ? (carry + Nc * NTHREADS + (size_t)wave * (JQ_RL * NT) * 64 + lane_)
                             : (a.park + (size_t)(active ? slab : 0) * KT * 64 + lane);
     // Per-step trace scalars: every wave leaves its Ncoupled * JQ_NTR wave sums of step n in the LDS record
-    // rec[n & 1][wave][.]; once the whole workgroup has passed a barrier behind step n, wave 0 adds the waves' records in
+    // rec[n & 1][wave][8 Ncoupled] (one wave_sum4 group of four slots per control for the early values t1, t3 and one for
+    // the late values t2, t4, t5; a group's values a, b, c sit in the rows = slots 0, 2, 1); once the whole workgroup has passed a barrier behind step n, wave 0 adds the waves' records in
     // wave order and writes ONE record per workgroup and step to HBM (a.traces) -- the records of a launch are
     // [workgroups][steps][ntr] instead of [waves][steps][ntr] (12 x less traffic with three slabs per workgroup).
     const int ntr = Nc * JQ_NTR;
     double* rec = carry + Nc * NTHREADS + (a.park_lds ? (size_t)NWAVES * (JQ_RL * NT) * 64 : 0);
-    for (int i = threadIdx.x; i < 2 * NWAVES * ntr; i += blockDim.x) rec[i] = 0.0;   // (inactive waves never write theirs)
+    const int rslots = 8 * Nc;
+    for (int i = threadIdx.x; i < 2 * NWAVES * rslots; i += blockDim.x) rec[i] = 0.0;   // (inactive waves never write theirs)
     auto flush_traces = [&](int k) {
         if (a.batch > 0) {   // batched staging has no workgroup barrier in every step
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1384,10 +1434,14 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
             asm volatile("" ::: "memory");
         }
         if (wave == 0 && lane_ < ntr) {
-            const double* r = rec + (size_t)(k & 1) * NWAVES * ntr + lane_;
+            // trace kk of control q: t1, t3 (kk = 0, 2) are the values a, b of the control's early group, t2, t4, t5
+            // (kk = 1, 3, 4) the values a, b, c of its late group
+            const int q = lane_ / JQ_NTR, kk = lane_ - q * JQ_NTR;
+            const int slot = (kk == 0 ? 0 : kk == 2 ? 2 : 4 * Nc + (kk == 1 ? 0 : kk == 3 ? 2 : 1)) + 4 * q;
+            const double* r = rec + (size_t)(k & 1) * NWAVES * rslots + slot;
             double s = r[0];
 #pragma unroll
-            for (int w = 1; w < NWAVES; ++w) s += r[w * ntr];
+            for (int w = 1; w < NWAVES; ++w) s += r[w * rslots];
             a.traces[((size_t)blockIdx.x * a.nsteps_chunk + k) * ntr + lane_] = s;
         }
     };
@@ -1466,13 +1520,8 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
             M = p.next_c(Nc + q);  // Hanti_q
             if (active) {
                 mm_z_bw<NT, BW>(Ya, M, mu, a.bw_trace[q]);
-                const double t1 = (a.debug & 1) ? a_dot(u, Ya) : wave_sum(a_dot(u, Ya) * wgt);
-                const double t3 = (a.debug & 1) ? a_dot(un, Ya) : wave_sum(a_dot(un, Ya) * wgt);
-                if (lane_ == 0) {
-                    double* tr = rec + ((size_t)(n & 1) * NWAVES + wave) * ntr + q * JQ_NTR;
-                    tr[0] = t1;
-                    tr[2] = t3;
-                }
+                const double ts = wave_sum4(a_dot(u, Ya) * wgt, a_dot(un, Ya) * wgt, 0.0, 0.0);   // rows 0, 2: t1, t3
+                if ((lane_ & 15) == 0) rec[((size_t)(n & 1) * NWAVES + wave) * rslots + 4 * q + (lane_ >> 4)] = ts;
             }
         }
         // use 8: Kn0 -- L = -c K0 X
@@ -1532,17 +1581,8 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
                 const double p4 = -a_dot(un, Ya);
                 t4 = p4 + carry[q * NTHREADS + threadIdx.x];
                 carry[q * NTHREADS + threadIdx.x] = p4;
-                if (!(a.debug & 1)) {
-                    t2 = wave_sum(t2 * wgt);
-                    t4 = wave_sum(t4 * wgt);
-                    t5 = wave_sum(t5 * wgt);
-                }
-                if (lane_ == 0) {
-                    double* tr = rec + ((size_t)(n & 1) * NWAVES + wave) * ntr + q * JQ_NTR;
-                    tr[1] = t2;
-                    tr[3] = t4;
-                    tr[4] = t5;
-                }
+                const double ts = wave_sum4(t2 * wgt, t4 * wgt, t5 * wgt, 0.0);                     // rows 0, 2, 1: t2, t4, t5
+                if ((lane_ & 15) == 0) rec[((size_t)(n & 1) * NWAVES + wave) * rslots + 4 * (Nc + q) + (lane_ >> 4)] = ts;
             }
         }
         // ---- roles for the next step: u <- un, mu <- vN(new lambda_r), nb <- L, v <- parked vi(t_n)

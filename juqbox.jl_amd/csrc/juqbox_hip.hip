@@ -416,10 +416,10 @@ extern "C" void jq_destroy(jq_handle* h)
 
 // LDS bytes of the backward slab / quad kernels (jq_kernels.h k_backward) behind the operator staging: the tables wd, ws,
 // the per-thread trace carries [Nc][threads], the parking images (park_doubles per wave; 0: parked in HBM) and the
-// double-buffered per-step trace records [2][waves][Nc * JQ_NTR]
+// double-buffered per-step trace records [2][waves][8 Nc]
 static long long bwd_lds_tail(int NT, int Nc, int nwaves, long long park_doubles)
 {
-    return 32LL * NT * 8 + (long long)Nc * 64 * nwaves * 8 + (long long)nwaves * park_doubles * 8 + 2LL * nwaves * Nc * JQ_NTR * 8;
+    return 32LL * NT * 8 + (long long)Nc * 64 * nwaves * 8 + (long long)nwaves * park_doubles * 8 + 2LL * nwaves * 8 * Nc * 8;
 }
 
 static int create_impl(const jq_problem* p, jq_handle* h)

@@ -160,8 +160,9 @@ def test_more_than_32767_steps_per_evaluation(hip):
     wa = jq.Working_Arrays_HIP(params, pcof.size)
     objfv, tg, *_ = jq.traceobjgrad(pcof, params, wa, False, True)
     assert wa.last_timing()["n_forward_launches"] >= 2
-    assert abs(objfv - r["objfv"]) <= max(TOL * abs(r["objfv"]), 1e-14)
-    assert np.linalg.norm(tg - r["totalgrad"]) <= max(TOL * np.linalg.norm(r["totalgrad"]), 1e-14)
+    # (rabi's objective is the cancellation 1 - |s|^2 + leak ~ 1e-13 at this step size: absolute floor = rounding of 40 000 steps)
+    assert abs(objfv - r["objfv"]) <= max(TOL * abs(r["objfv"]), 1e-12)
+    assert np.linalg.norm(tg - r["totalgrad"]) <= max(TOL * np.linalg.norm(r["totalgrad"]), 1e-12)
     wa.close()
 
 
