@@ -53,7 +53,7 @@ typedef struct jq_problem {
     int32_t nsteps;        /* params.nsteps                                                        */
     int32_t neumann_terms; /* params.linear_solver.max_iter (NEUMANN_SOLVER, linear_solvers.jl:37) */
     int32_t objFuncType;   /* 1: infidelity+leak; 2/3: second, unforced adjoint gives infidelgrad  */
-    int32_t reserved;      /* must be 0                                                            */
+    int32_t Nunc;          /* number of uncoupled controls Hunc_ops (0, or > 0 with Ncoupled == 0: src/evalobjgrad.jl:176) */
     double T;              /* gate duration                                                        */
     const double *Hconst;    /* [Ntot x Ntot]                                                      */
     const double *Hsym_ops;  /* [Ncoupled][Ntot x Ntot]                                            */
@@ -62,7 +62,16 @@ typedef struct jq_problem {
     const double *Utarget_r; /* [Ntot x N]  real(Utarget) (rotating frame)                         */
     const double *Utarget_i; /* [Ntot x N]  imag(Utarget)                                          */
     const double *wmat_real_diag; /* [Ntot] diag(params.wmat_real); Diagonal weights only          */
-    const double *Cfreq;     /* [Ncoupled x Nfreq] carrier (angular) frequencies                   */
+    const double *Cfreq;     /* [(Ncoupled + Nunc) x Nfreq] carrier (angular) frequencies          */
+    /* Uncoupled controls (the lab-frame evaluation of a pulse, e.g. examples/cnot2-lab.jl): KS! adds
+     * 2 (p_q(t) cos(2 pi Rfreq[q] t) - q_q(t) sin(2 pi Rfreq[q] t)) * Hunc_ops[q] to K when Hunc_ops[q] is symmetric,
+     * to S when it is antisymmetric (src/evalobjgrad.jl:2373-2387; anything else is the reference's ArgumentError,
+     * :186-196 -> JQ_EINVAL).  FORWARD evaluations only (objective, state history, populations, sweeps): the reference's
+     * adjoint for this branch cannot run -- gradSize = (2 Ncoupled + Nunc) Nfreq D1 (:801) differs from length(pcof) =
+     * 2 (Ncoupled + Nunc) Nfreq D1, so adjoint_grad_calc!'s axpy! (:2620-2656) throws -- and gradient calls return
+     * JQ_EUNSUPPORTED.  Parity-unpinned in the reference (no golden): checked against the CPU oracle. */
+    const double *Hunc_ops;  /* [Nunc][Ntot x Ntot], NULL when Nunc == 0                           */
+    const double *Rfreq;     /* [Nunc] rotation frequencies params.Rfreq, NULL when Nunc == 0      */
 } jq_problem;
 
 /* Timing of the last evaluation, measured with HIP events on the library's stream. */

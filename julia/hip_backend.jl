@@ -23,7 +23,7 @@ struct JQProblem                          # == jq_problem
     nsteps::Int32
     neumann_terms::Int32
     objFuncType::Int32
-    reserved::Int32
+    Nunc::Int32
     T::Float64
     Hconst::Ptr{Float64}
     Hsym_ops::Ptr{Float64}
@@ -33,6 +33,8 @@ struct JQProblem                          # == jq_problem
     Utarget_i::Ptr{Float64}
     wmat_real_diag::Ptr{Float64}
     Cfreq::Ptr{Float64}
+    Hunc_ops::Ptr{Float64}
+    Rfreq::Ptr{Float64}
 end
 
 struct JQTiming                           # == jq_timing
@@ -74,17 +76,20 @@ leak_weights(::Working_Arrays_M_HIP, params) = Vector{Float64}(diag(params.wmat)
 function jq_new_handle(params, devices)
     Ntot = params.N + params.Nguard
     Hc   = Matrix{Float64}(params.Hconst)                          # dense, column-major (also for use_sparse)
-    Hs   = reduce(hcat, [vec(Matrix{Float64}(h)) for h in params.Hsym_ops])
-    Ha   = reduce(hcat, [vec(Matrix{Float64}(h)) for h in params.Hanti_ops])
+    Hs   = params.Ncoupled > 0 ? reduce(hcat, [vec(Matrix{Float64}(h)) for h in params.Hsym_ops]) : zeros(1, 1)
+    Ha   = params.Ncoupled > 0 ? reduce(hcat, [vec(Matrix{Float64}(h)) for h in params.Hanti_ops]) : zeros(1, 1)
+    Hu   = params.Nunc > 0 ? reduce(hcat, [vec(Matrix{Float64}(h)) for h in params.Hunc_ops]) : zeros(1, 1)   # lab-frame evaluation
+    Rf   = Vector{Float64}(params.Rfreq)
     wd   = Vector{Float64}(diag(params.wmat_real))                 # Diagonal weights only
-    Cf   = Matrix{Float64}(params.Cfreq[1:params.Ncoupled, :])
+    Cf   = Matrix{Float64}(params.Cfreq[1:params.Ncoupled+params.Nunc, :])
     Ui   = Matrix{Float64}(params.Uinit)
     h    = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve Hc Hs Ha wd Cf Ui params begin
+    GC.@preserve Hc Hs Ha Hu Rf wd Cf Ui params begin
         prob = JQProblem(Ntot, params.N, params.Ncoupled, params.Nfreq, params.nsteps,
-                         params.linear_solver.max_iter, params.objFuncType, 0, params.T,
+                         params.linear_solver.max_iter, params.objFuncType, params.Nunc, params.T,
                          pointer(Hc), pointer(Hs), pointer(Ha), pointer(Ui),
-                         pointer(params.Utarget_r), pointer(params.Utarget_i), pointer(wd), pointer(Cf))
+                         pointer(params.Utarget_r), pointer(params.Utarget_i), pointer(wd), pointer(Cf),
+                         params.Nunc > 0 ? pointer(Hu) : Ptr{Float64}(C_NULL), params.Nunc > 0 ? pointer(Rf) : Ptr{Float64}(C_NULL))
         if devices === nothing
             rc = ccall((:jq_create, libjq), Cint, (Ref{JQProblem}, Ref{Ptr{Cvoid}}), prob, h)
         else

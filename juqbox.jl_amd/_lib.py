@@ -19,9 +19,9 @@ JQ_OK, JQ_EINVAL, JQ_EDIM, JQ_EUNSUPPORTED, JQ_EHIP, JQ_ENOMEM = 0, -1, -2, -3, 
 
 class jq_problem(ctypes.Structure):
     _fields_ = [("Ntot", c_i32), ("N", c_i32), ("Ncoupled", c_i32), ("Nfreq", c_i32), ("nsteps", c_i32),
-                ("neumann_terms", c_i32), ("objFuncType", c_i32), ("reserved", c_i32), ("T", ctypes.c_double),
+                ("neumann_terms", c_i32), ("objFuncType", c_i32), ("Nunc", c_i32), ("T", ctypes.c_double),
                 ("Hconst", c_dp), ("Hsym_ops", c_dp), ("Hanti_ops", c_dp), ("Uinit", c_dp), ("Utarget_r", c_dp),
-                ("Utarget_i", c_dp), ("wmat_real_diag", c_dp), ("Cfreq", c_dp)]
+                ("Utarget_i", c_dp), ("wmat_real_diag", c_dp), ("Cfreq", c_dp), ("Hunc_ops", c_dp), ("Rfreq", c_dp)]
 
 
 class jq_timing(ctypes.Structure):

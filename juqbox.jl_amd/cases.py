@@ -340,6 +340,51 @@ def swap02_rn(nquad=512, seed=2456, ep_max=2 * np.pi * 2e-2):
                         golden=None)
 
 
+def cnot2_lab(Pmin=200, pcof_file=None):
+    """examples/cnot2-lab.jl: LAB-frame evaluation of a CNOT pulse on two coupled qubits (Ne = [2,2], Ng = [1,1], Ntot = 9,
+    N = 4, T = 50, Nfreq = 2) with UNCOUPLED controls Hunc_ops = [a + a', b + b'] (:124) -- the forward-only branch of KS!
+    (src/evalobjgrad.jl:2373-2387).  H0 keeps the qubit frequencies (:121), Rfreq = rot_freq (:73); the time step resolves
+    them: nsteps = ceil(T max|eig(H0 + sum maxpar Hunc)| Pmin / 2 pi) (:133, Pmin = 200).  The example starts from
+    drives/cnot2-pcof-opt-t50.jld2 (:208; tests/golden/jld2 holds that data file) -- pass its path as pcof_file; default:
+    own seeded coefficients."""
+    Ne, Ng = [2, 2], [1, 1]
+    Nt1, Nt2 = 3, 3
+    Tmax = 50.0
+    fa, fb = 4.10595, 4.81526
+    x1, x2, x12 = 2 * 0.1099, 2 * 0.1126, 0.1
+    a1, a2 = _lowering(Nt1), _lowering(Nt2)
+    I1, I2 = np.eye(Nt1), np.eye(Nt2)
+    amat = np.kron(I2, a1)
+    bmat = np.kron(a2, I1)
+    N1 = np.kron(I2, np.diag(np.arange(Nt1, dtype=np.float64)))
+    N2 = np.kron(np.diag(np.arange(Nt2, dtype=np.float64)), I1)
+    H0 = 2 * np.pi * (fa * N1 + fb * N2 - x1 / 2 * (N1 @ N1 - N1) - x2 / 2 * (N2 @ N2 - N2) - x12 * (N1 @ N2))
+    Hunc_ops = [amat + amat.T, bmat + bmat.T]
+    maxpar = [0.014, 0.020]
+    K1 = H0 + maxpar[0] * Hunc_ops[0] + maxpar[1] * Hunc_ops[1]
+    nsteps = _nsteps_from_eig(K1, Tmax, Pmin)
+    Nfreq = 2
+    om = np.zeros((2, Nfreq))
+    om[:, 1] = -2.0 * np.pi * x12
+    Ntot, N = 9, 4
+    utarget = np.zeros((Ntot, N), dtype=np.complex128)
+    utarget[0, 0] = 1.0      # Ng1 == 1 branch (:163-167)
+    utarget[1, 1] = 1.0
+    utarget[3, 3] = 1.0
+    utarget[4, 2] = 1.0
+    U0 = su.initial_cond(Ne, Ng)
+    params = objparams(Ne, Ng, Tmax, nsteps, Uinit=U0, Utarget=utarget, Cfreq=om, Rfreq=[fa, fb], Hconst=H0,
+                       Hunc_ops=Hunc_ops, use_sparse=False)
+    params.quiet = True
+    if pcof_file is not None:
+        from .pcof_io import read_pcof
+        pcof0 = read_pcof(pcof_file)
+    else:
+        pcof0 = (np.random.default_rng(2456).random(2 * 2 * Nfreq * 10) - 0.5) * 0.02
+    return params, dict(maxpar=maxpar, D1=pcof0.size // (2 * 2 * Nfreq), nCoeff=pcof0.size, pcof0=pcof0, golden=None,
+                        rot_freq=[fa, fb])
+
+
 BUILDERS = {
     "rabi": rabi,
     "swap02": swap02,
@@ -350,6 +395,7 @@ BUILDERS = {
     "cnot3": cnot3,
     "cnot1": cnot1,
     "swap02_rn": swap02_rn,
+    "cnot2_lab": lambda: cnot2_lab(Pmin=40),
 }
 
 

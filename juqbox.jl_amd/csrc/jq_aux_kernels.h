@@ -10,6 +10,7 @@ struct SplineArgs {
     const double* cfreq;  // [Ncoupled x Nfreq] column-major
     int D1, Nfreq, Ncoupled, nCoeff;
     double dtknot;        // T/(D1-2)            (bcparams, src/bsplines.jl:174)
+    const double* rfreq;  // uncoupled controls: params.Rfreq [Ncoupled] (Ncoupled then counts them); nullptr otherwise
 };
 
 // knot index k (1-based) of bcarrier2 / gradbcarrier2! (src/bsplines.jl:224-225, :335-336)
@@ -73,6 +74,17 @@ __global__ void k_ctrl(SplineArgs s, const double* tt, int n0, int ntp, double h
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= ntp) return;
     const double t = stream_time(tt, n0, j, h);
+    if (s.rfreq) {
+        // uncoupled controls (src/evalobjgrad.jl:2373-2387): ft = 2 (p cos(2 pi Rfreq t) - q sin(2 pi Rfreq t)) multiplies
+        // Hunc_ops[q], which sits in the symmetric OR the antisymmetric slot of pair q (the other slot is zero)
+        for (int q = 0; q < s.Ncoupled; ++q) {
+            const double pt = bcarrier2_dev(s, t, 2 * q), qt = bcarrier2_dev(s, t, 2 * q + 1);
+            const double ft = 2.0 * (pt * cos(2.0 * M_PI * s.rfreq[q] * t) - qt * sin(2.0 * M_PI * s.rfreq[q] * t));
+            pq[(size_t)j * 2 * s.Ncoupled + 2 * q] = ft;
+            pq[(size_t)j * 2 * s.Ncoupled + 2 * q + 1] = ft;
+        }
+        return;
+    }
     for (int f = 0; f < 2 * s.Ncoupled; ++f) pq[(size_t)j * 2 * s.Ncoupled + f] = bcarrier2_dev(s, t, f);
 }
 

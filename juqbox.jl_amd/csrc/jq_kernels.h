@@ -513,6 +513,22 @@ __device__ __forceinline__ double row_shift4(double x)
 #ifdef JQ_EXP_NOSHIFT      // timing experiment only (wrong results): what the lane shifts cost
     return x;
 #endif
+#ifdef JQ_EXP_BPERM        // one shift direction through the LDS crossbar (ds_bpermute_b32) instead of the VALU
+    if (CTRL == 0x114) {
+        const int addr = (((int)(threadIdx.x & 63) - 4) & 63) * 4;
+        b.i[0] = __builtin_amdgcn_ds_bpermute(addr, a.i[0]);
+        b.i[1] = __builtin_amdgcn_ds_bpermute(addr, a.i[1]);
+        return b.d;
+    }
+#endif
+#ifdef JQ_EXP_BPERM2       // both directions
+    {
+        const int addr = (((int)(threadIdx.x & 63) + (CTRL == 0x114 ? -4 : 4)) & 63) * 4;
+        b.i[0] = __builtin_amdgcn_ds_bpermute(addr, a.i[0]);
+        b.i[1] = __builtin_amdgcn_ds_bpermute(addr, a.i[1]);
+        return b.d;
+    }
+#endif
     b.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], CTRL, 0xf, 0xf, true);
     b.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], CTRL, 0xf, 0xf, true);
     return b.d;

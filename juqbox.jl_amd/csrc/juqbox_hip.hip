@@ -63,6 +63,8 @@ struct jq_handle {
     long long rl_stride = 0;    // doubles per [16][NPJ] operator image
     int rl_max_cols = 0;        // batches of at most this many columns use the row-lane kernels (latency regime)
     std::vector<double> Hconst, Hsym, Hanti, Uinit, Utr, Uti, wd, cfreq;
+    std::vector<double> rfreq;  // uncoupled controls (Nunc > 0): params.Rfreq; empty otherwise
+    double* d_rfreq = nullptr;
     std::vector<double> tf, tb;
     // device buffers (owned)
     double *d_cimg = nullptr, *d_park = nullptr;
@@ -404,7 +406,7 @@ extern "C" void jq_destroy(jq_handle* h)
         return;
     }
     (void)hipSetDevice(h->device);
-    double** bufs[] = {&h->d_wq, &h->d_pack, &h->d_himg_r, &h->d_uinit_r, &h->d_vtr_r, &h->d_vti_r, &h->d_himg_l, &h->d_uinit_l, &h->d_vtr_l, &h->d_vti_l, &h->d_himg_c, &h->d_cimg_c, &h->d_park, &h->d_cimg, &h->d_himg,  &h->d_uimg,       &h->d_vtr,     &h->d_vti,    &h->d_tabs, &h->d_tf,   &h->d_tb,
+    double** bufs[] = {&h->d_rfreq, &h->d_wq, &h->d_pack, &h->d_himg_r, &h->d_uinit_r, &h->d_vtr_r, &h->d_vti_r, &h->d_himg_l, &h->d_uinit_l, &h->d_vtr_l, &h->d_vti_l, &h->d_himg_c, &h->d_cimg_c, &h->d_park, &h->d_cimg, &h->d_himg,  &h->d_uimg,       &h->d_vtr,     &h->d_vti,    &h->d_tabs, &h->d_tf,   &h->d_tb,
                        &h->d_cfreq, &h->d_pcof,       &h->d_stream,  &h->d_pq,     &h->d_state, &h->d_state_save,
                        &h->d_colinfo, &h->d_traces,   &h->d_R,       &h->d_grad,   &h->d_res};
     for (auto b : bufs)
@@ -429,12 +431,15 @@ static int create_impl(const jq_problem* p, jq_handle* h)
     if (p->nsteps < 1 || !(p->T > 0.0)) return fail(h, JQ_EINVAL, "jq_create: need nsteps >= 1 and T > 0");
     if (p->Nfreq < 1) return fail(h, JQ_EINVAL, "jq_create: need Nfreq >= 1");
     if (p->neumann_terms < 0) return fail(h, JQ_EINVAL, "jq_create: neumann_terms must be >= 0");
-    if (p->reserved != 0) return fail(h, JQ_EINVAL, "jq_create: reserved must be 0");
-    if (!p->Hconst || !p->Hsym_ops || !p->Hanti_ops || !p->Uinit || !p->Utarget_r || !p->Utarget_i ||
-        !p->wmat_real_diag || !p->Cfreq)
+    if (p->Nunc < 0) return fail(h, JQ_EINVAL, "jq_create: Nunc must be >= 0");
+    if (p->Nunc > 0 && p->Ncoupled != 0)      // @assert(Ncoupled==0 || Nunc==0), src/evalobjgrad.jl:176
+        return fail(h, JQ_EINVAL, "jq_create: coupled and uncoupled controls cannot be combined (Ncoupled == 0 || Nunc == 0)");
+    if (!p->Hconst || !p->Uinit || !p->Utarget_r || !p->Utarget_i || !p->wmat_real_diag || !p->Cfreq ||
+        (p->Nunc == 0 && (!p->Hsym_ops || !p->Hanti_ops)) || (p->Nunc > 0 && (!p->Hunc_ops || !p->Rfreq)))
         return fail(h, JQ_EINVAL, "jq_create: NULL array in problem description");
-    if (p->Ncoupled < 1) return fail(h, JQ_EUNSUPPORTED, "jq_create: at least one coupled control pair is required");
-    if (p->Ncoupled > JQ_MAXNC) return fail(h, JQ_EUNSUPPORTED, "jq_create: Ncoupled > 4 is not supported");
+    const int nctrl = p->Nunc > 0 ? p->Nunc : p->Ncoupled;     // control pairs the kernels see
+    if (nctrl < 1) return fail(h, JQ_EUNSUPPORTED, "jq_create: at least one control Hamiltonian is required");
+    if (nctrl > JQ_MAXNC) return fail(h, JQ_EUNSUPPORTED, "jq_create: more than 4 control Hamiltonians are not supported");
     if (p->Ntot > 96)
         return fail(h, JQ_EUNSUPPORTED, "jq_create: Ntot > 96 does not fit the two-slot LDS operator ring");
     if (p->N > 16) return fail(h, JQ_EUNSUPPORTED, "jq_create: N > 16 (more than one 16-column slab per sample)");
@@ -450,7 +455,7 @@ static int create_impl(const jq_problem* p, jq_handle* h)
     }
     HIPCHK(h, hipStreamCreate(&h->stream));
 
-    h->Ntot = p->Ntot; h->N = p->N; h->Nc = p->Ncoupled; h->Nfreq = p->Nfreq; h->nsteps = p->nsteps;
+    h->Ntot = p->Ntot; h->N = p->N; h->Nc = nctrl; h->Nfreq = p->Nfreq; h->nsteps = p->nsteps;
     h->m = p->neumann_terms; h->objFuncType = p->objFuncType; h->T = p->T;
     h->NT = (p->Ntot + 15) / 16;
     h->KT = 4 * h->NT;
@@ -459,13 +464,37 @@ static int create_impl(const jq_problem* p, jq_handle* h)
     h->state_stride = (long long)(JQ_STATE_ARRAYS * h->KT + JQ_STATE_EXTRA) * 64;
     const size_t nn = (size_t)p->Ntot * p->Ntot, nc = (size_t)p->Ntot * p->N;
     h->Hconst.assign(p->Hconst, p->Hconst + nn);
-    h->Hsym.assign(p->Hsym_ops, p->Hsym_ops + nn * p->Ncoupled);
-    h->Hanti.assign(p->Hanti_ops, p->Hanti_ops + nn * p->Ncoupled);
+    if (p->Nunc > 0) {
+        // Uncoupled controls (src/evalobjgrad.jl:2373-2387): Hunc_ops[q] takes the symmetric slot of control pair q when it
+        // is symmetric (its term goes to K), the antisymmetric slot when it is antisymmetric (-> S); the other slot is
+        // zero and k_ctrl feeds both with ft_q(t) = 2 (p cos(2 pi Rfreq t) - q sin(2 pi Rfreq t)).  isSymm: :186-196.
+        h->Hsym.assign(nn * nctrl, 0.0);
+        h->Hanti.assign(nn * nctrl, 0.0);
+        h->rfreq.assign(p->Rfreq, p->Rfreq + nctrl);
+        for (int q = 0; q < nctrl; ++q) {
+            const double* M = p->Hunc_ops + nn * q;
+            bool sym = true;
+            double nrm2 = 0.0;
+            for (int c = 0; c < p->Ntot; ++c)
+                for (int r = 0; r < p->Ntot; ++r) {
+                    const double a = M[r + (size_t)p->Ntot * c], b = M[c + (size_t)p->Ntot * r];
+                    if (a != b) sym = false;
+                    nrm2 += (a + b) * (a + b);
+                }
+            if (!sym && !(std::sqrt(nrm2) < 1e-15))
+                return fail(h, JQ_EINVAL, "jq_create: Uncoupled Hamiltonian is not symmetric or anti-symmetric. This functionality is "
+                                          "not currently supported.");
+            std::copy(M, M + nn, (sym ? h->Hsym.begin() : h->Hanti.begin()) + nn * q);
+        }
+    } else {
+        h->Hsym.assign(p->Hsym_ops, p->Hsym_ops + nn * p->Ncoupled);
+        h->Hanti.assign(p->Hanti_ops, p->Hanti_ops + nn * p->Ncoupled);
+    }
     h->Uinit.assign(p->Uinit, p->Uinit + nc);
     h->Utr.assign(p->Utarget_r, p->Utarget_r + nc);
     h->Uti.assign(p->Utarget_i, p->Utarget_i + nc);
     h->wd.assign(p->wmat_real_diag, p->wmat_real_diag + p->Ntot);
-    h->cfreq.assign(p->Cfreq, p->Cfreq + (size_t)p->Ncoupled * p->Nfreq);
+    h->cfreq.assign(p->Cfreq, p->Cfreq + (size_t)nctrl * p->Nfreq);
 
     // block-band structure (16x16 blocks) of the operators: kernels exist for BW in {0,1,2,NT-1}
     {
@@ -664,6 +693,10 @@ static int create_impl(const jq_problem* p, jq_handle* h)
     HIPCHK(h, hipMemcpy(h->d_tf, h->tf.data(), h->tf.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->d_tb, h->tb.data(), h->tb.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->d_cfreq, h->cfreq.data(), h->cfreq.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (!h->rfreq.empty()) {
+        if ((rc = dev_alloc(h, &h->d_rfreq, h->rfreq.size()))) return rc;
+        HIPCHK(h, hipMemcpy(h->d_rfreq, h->rfreq.data(), h->rfreq.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     if ((rc = upload_operators(h))) return rc;
     if ((rc = upload_targets(h))) return rc;
     {
@@ -1020,6 +1053,10 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
         return fail(h, JQ_EDIM, "DimensionMismatch: Inconsistent number of coefficients and size of parameter vector (nCoeff != length(pcof))");
     if (D1 < 3) return fail(h, JQ_EINVAL, "need at least 3 B-spline coefficients per control function");
     if (nsamples < 1) return fail(h, JQ_EINVAL, "need at least one sample");
+    if (adjoint && !h->rfreq.empty())
+        return fail(h, JQ_EUNSUPPORTED, "uncoupled controls (Hunc_ops): forward evaluations only -- the reference's adjoint for this "
+                                        "branch cannot run (gradSize = (2 Ncoupled + Nunc) Nfreq D1, src/evalobjgrad.jl:801, is not "
+                                        "length(pcof); adjoint_grad_calc!'s axpy!, :2620-2656, throws DimensionMismatch)");
 
     const int nslabs = (nsamples + h->sps - 1) / h->sps;
     // small batches: cooperative (row-split) kernels, one workgroup of NT waves per slab; large batches: slab
@@ -1178,6 +1215,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     SplineArgs sp;
     sp.pcof = h->d_pcof; sp.cfreq = h->d_cfreq; sp.D1 = D1; sp.Nfreq = h->Nfreq; sp.Ncoupled = h->Nc; sp.nCoeff = ncoeff;
     sp.dtknot = h->T / (D1 - 2);
+    sp.rfreq = h->rfreq.empty() ? nullptr : h->d_rfreq;
 
     const double dt = h->T / h->nsteps;
     PropArgs a;

@@ -57,8 +57,11 @@ class Working_Arrays_HIP:
         self._uti = _f64(p.Utarget_i).copy()
         self._m = int(p.linear_solver.max_iter) if self.INTEGRATOR == Stormer_Verlet else 0
         self._solver = None
-        keep = [self._hconst, hs, ha, _f64(p.Uinit), self._utr, self._uti, self._wd, _f64(p.Cfreq[:p.Ncoupled, :])]
-        prob = _lib.jq_problem(p.Ntot, p.N, p.Ncoupled, p.Nfreq, p.nsteps, self._m, p.objFuncType, 0, p.T,
+        nunc = getattr(p, "Nunc", 0)
+        hu = np.concatenate([_f64(h) for h in p.Hunc_ops]) if nunc else None
+        rf = _f64(p.Rfreq[:nunc]) if nunc else None
+        keep = [self._hconst, hs, ha, _f64(p.Uinit), self._utr, self._uti, self._wd, _f64(p.Cfreq[:p.Ncoupled + nunc, :]), hu, rf]
+        prob = _lib.jq_problem(p.Ntot, p.N, p.Ncoupled, p.Nfreq, p.nsteps, self._m, p.objFuncType, nunc, p.T,
                                *[_ptr(a) for a in keep])
         h = ctypes.c_void_p()
         if devices is None:

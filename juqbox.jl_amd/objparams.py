@@ -66,17 +66,27 @@ class objparams:
         self.Ncoupled = len(Hsym_ops)
         Nanti = len(Hanti_ops)
         self.Nunc = len(Hunc_ops)
-        if self.Nunc != 0:
-            # KS! :2373-2387 / adjoint_grad_calc! :2621-2654 -- parity-unpinned branch
-            raise NotImplementedError("uncoupled controls (Hunc_ops) are not supported by the HIP path")
+        assert self.Ncoupled == 0 or self.Nunc == 0                               # :176
         assert len(self.Rfreq) >= self.Ncoupled + self.Nunc                      # :177
+        # uncoupled controls (lab-frame evaluation of a pulse: KS! :2373-2387): every operator must be symmetric (-> K) or
+        # antisymmetric (-> S), :186-196.  Parity-unpinned branch of the reference.
+        self.Hunc_ops = [np.asfortranarray(np.asarray(h, dtype=np.float64)).copy(order="F") for h in Hunc_ops]
+        self.isSymm = []
+        for h in self.Hunc_ops:
+            if np.array_equal(h, h.T):
+                self.isSymm.append(True)
+            elif np.linalg.norm(h + h.T) < 1e-15:
+                self.isSymm.append(False)
+            else:
+                raise ValueError("Uncoupled Hamiltonian is not symmetric or anti-symmetric. This functionality is not "
+                                 "currently supported.")                           # ArgumentError, :195
         tz = (self.Ntot, self.N)
         Uinit = np.asarray(Uinit, dtype=np.float64)
         Utarget = np.asarray(Utarget, dtype=np.complex128)
         assert Uinit.shape == tz, "size(Uinit) must be (Ntot, N)"                 # :181
         assert Utarget.shape == tz, "size(Utarget) must be (Ntot, N)"             # :182
         assert self.Ncoupled == Nanti, "Ncoupled == Nanti"                        # :243
-        if Cfreq.shape[0] < self.Ncoupled:
+        if Cfreq.shape[0] < self.Ncoupled + self.Nunc:
             raise ValueError("Cfreq needs one row per control Hamiltonian")
 
         self.Uinit = np.asfortranarray(Uinit)

@@ -19,6 +19,9 @@
  * products only visit the entries of the sparsity pattern that KS_alloc establishes
  * (src/evalobjgrad.jl:3072-3092), which is what makes cnot3 (Ntot=96) run in seconds.
  */
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -45,6 +48,11 @@ typedef struct {
     double *Uinit, *Utr, *Uti; /* Ntot*N */
     double *wdiag;   /* Ntot: diag(wmat_real) */
     double *Cfreq;   /* Ncoupled x Nfreq, column-major */
+    /* uncoupled controls (lab-frame evaluation; src/evalobjgrad.jl:2373-2387): nunc > 0 replaces the coupled pairs -- the
+     * reference asserts Ncoupled == 0 || Nunc == 0 (:176).  Hsym[q] holds Hunc_ops[q] when it is symmetric (else zeros),
+     * Hanti[q] when it is antisymmetric (else zeros); Ncoupled then counts the uncoupled controls. */
+    int nunc;
+    double *Rfreq;   /* nunc */
     int use_sparse;
     pattern_t patK, patS;      /* union patterns (KS_alloc :3072-3092) */
     pattern_t *patHsym, *patHanti; /* per-operator patterns (sparse trace operator :2135-2154) */
@@ -194,6 +202,18 @@ static void KS(const oracle_t *o, double *K, double *S, double t)
     int q;
     memcpy(K, o->Hconst, nn * sizeof(double));
     memset(S, 0, nn * sizeof(double));
+    if (o->nunc > 0) {
+        /* :2373-2387 with offset = 2*Ncoupled = 0: ft = 2 (p cos(2 pi Rfreq t) - q sin(2 pi Rfreq t)) goes to K for a
+         * symmetric Hunc_ops[q], to S for an antisymmetric one (the other image is all zeros here) */
+        for (q = 0; q < o->nunc; q++) {
+            double pt = bcarrier2(o, t, 2 * q);
+            double qt = bcarrier2(o, t, 2 * q + 1);
+            double ft = 2.0 * (pt * cos(2.0 * M_PI * o->Rfreq[q] * t) - qt * sin(2.0 * M_PI * o->Rfreq[q] * t));
+            axpy((int)nn, ft, o->Hsym + q * nn, K);
+            axpy((int)nn, ft, o->Hanti + q * nn, S);
+        }
+        return;
+    }
     for (q = 0; q < o->Ncoupled; q++) {
         double pt = bcarrier2(o, t, 2 * q);
         double qt = bcarrier2(o, t, 2 * q + 1);
@@ -439,6 +459,16 @@ void *jqo_create(int Ntot, int N, int Ncoupled, int Nfreq, int nsteps, double T,
     return o;
 }
 
+/* switch the instance to uncoupled controls (see oracle_t.nunc); rfreq: [Ncoupled] = params.Rfreq */
+void jqo_set_uncoupled(void *h, const double *rfreq)
+{
+    oracle_t *o = (oracle_t *)h;
+    int q;
+    o->nunc = o->Ncoupled;
+    o->Rfreq = (double *)malloc((size_t)o->Ncoupled * sizeof(double));
+    for (q = 0; q < o->Ncoupled; q++) o->Rfreq[q] = rfreq[q];
+}
+
 void jqo_destroy(void *h)
 {
     oracle_t *o = (oracle_t *)h;
@@ -452,7 +482,7 @@ void jqo_destroy(void *h)
     pattern_free(&o->patS);
     free(o->patHsym); free(o->patHanti);
     free(o->Hconst); free(o->Hsym); free(o->Hanti); free(o->Uinit); free(o->Utr); free(o->Uti);
-    free(o->wdiag); free(o->Cfreq);
+    free(o->wdiag); free(o->Cfreq); free(o->Rfreq);
     free(o);
 }
 
@@ -529,6 +559,10 @@ int jqo_traceobjgrad(void *h, const double *pcof, int ncoeff, int evaladjoint, d
     work_t w;
     double *vr, *vi, *vi05, *vr0;
     double *buf;
+
+    /* the reference's adjoint for uncoupled controls cannot run: gradSize = (2 Ncoupled + Nunc) Nfreq D1 (:801) is not the
+     * length of pcof / wa.gr, so adjoint_grad_calc!'s axpy!(-tmp, gr, grad_step) (:2620-2656) throws DimensionMismatch */
+    if (o->nunc > 0 && evaladjoint) return -3;
 
     /* :604-606 */
     if (ncoeff % Nsig != 0 || ncoeff < 3 * Nsig) return -1;

@@ -31,6 +31,7 @@ def lib():
             [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int]
         L.jqo_destroy.argtypes = [ctypes.c_void_p]
         L.jqo_set_max_iter.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.jqo_set_uncoupled.argtypes = [ctypes.c_void_p, c_dp]
         L.jqo_set_target.argtypes = [ctypes.c_void_p, c_dp, c_dp]
         L.jqo_set_wdiag.argtypes = [ctypes.c_void_p, c_dp]
         L.jqo_hconst.restype = c_dp
@@ -60,16 +61,30 @@ class Oracle:
         p = params
         self.Ntot, self.N, self.nsteps = p.Ntot, p.N, p.nsteps
         self.Ncoupled, self.Nfreq = p.Ncoupled, p.Nfreq
-        hs = np.concatenate([_f(h) for h in p.Hsym_ops]) if p.Ncoupled else np.zeros(0)
-        ha = np.concatenate([_f(h) for h in p.Hanti_ops]) if p.Ncoupled else np.zeros(0)
+        nunc = getattr(p, "Nunc", 0)
+        nctrl = p.Ncoupled
+        if nunc:
+            # uncoupled controls (src/evalobjgrad.jl:2373-2387; Ncoupled == 0, :176): Hunc_ops[q] goes to the symmetric slot
+            # when it is symmetric, to the antisymmetric one otherwise (isSymm, :186-196); see jqo_set_uncoupled
+            nctrl = nunc
+            z = np.zeros(p.Ntot * p.Ntot)
+            hs = np.concatenate([_f(h) if sym else z for h, sym in zip(p.Hunc_ops, p.isSymm)])
+            ha = np.concatenate([z if sym else _f(h) for h, sym in zip(p.Hunc_ops, p.isSymm)])
+        else:
+            hs = np.concatenate([_f(h) for h in p.Hsym_ops]) if p.Ncoupled else np.zeros(0)
+            ha = np.concatenate([_f(h) for h in p.Hanti_ops]) if p.Ncoupled else np.zeros(0)
+        self.Ncoupled = nctrl
         sparse = p.use_sparse if use_sparse is None else use_sparse
         self._keep = [_f(p.Hconst), hs, ha, _f(p.Uinit), _f(p.Utarget_r), _f(p.Utarget_i),
-                      _f(p.wmat_real), _f(p.Cfreq[:p.Ncoupled, :])]
+                      _f(p.wmat_real), _f(p.Cfreq[:nctrl, :])]
         self._wmat_real, self._wmat = _f(p.wmat_real), _f(getattr(p, "wmat", p.wmat_real))
-        self.h = lib().jqo_create(p.Ntot, p.N, p.Ncoupled, p.Nfreq, p.nsteps, p.T,
+        self.h = lib().jqo_create(p.Ntot, p.N, nctrl, p.Nfreq, p.nsteps, p.T,
                                   *[_p(a) for a in self._keep], p.objFuncType,
                                   p.linear_solver.solver_id, p.linear_solver.max_iter, p.linear_solver.tol,
                                   1 if sparse else 0)
+        if nunc:
+            self._rfreq = _f(p.Rfreq[:nunc])
+            lib().jqo_set_uncoupled(self.h, _p(self._rfreq))
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -111,6 +126,8 @@ class Oracle:
             raise ValueError("pcof must have an even number of elements >= 3*Nsig")
         if rc == -2:
             raise ValueError("DimensionMismatch: Inconsistent number of coefficients and size of parameter vector")
+        if rc == -3:
+            raise ValueError("DimensionMismatch: the reference's adjoint for uncoupled controls cannot run (gradSize != length(pcof))")
         res = dict(objfv=out[0], primaryobjf=out[1], secondaryobjf=out[2], traceInfidelity=out[3])
         if evaladjoint:
             res.update(totalgrad=tg, infidelgrad=ig, leakgrad=lg)

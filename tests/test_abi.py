@@ -33,16 +33,16 @@ def _problem(jq, params, **over):
             np.concatenate([f(h) for h in params.Hanti_ops]), f(params.Uinit), f(params.Utarget_r),
             f(params.Utarget_i), f(params.wmat_real), f(params.Cfreq)]
     vals = dict(Ntot=params.Ntot, N=params.N, Ncoupled=params.Ncoupled, Nfreq=params.Nfreq, nsteps=params.nsteps,
-                neumann_terms=params.linear_solver.max_iter, objFuncType=params.objFuncType, reserved=0, T=params.T)
+                neumann_terms=params.linear_solver.max_iter, objFuncType=params.objFuncType, Nunc=0, T=params.T)
     vals.update(over)
     prob = _lib.jq_problem(vals["Ntot"], vals["N"], vals["Ncoupled"], vals["Nfreq"], vals["nsteps"],
-                           vals["neumann_terms"], vals["objFuncType"], vals["reserved"], vals["T"],
-                           *[a.ctypes.data_as(_lib.c_dp) for a in keep])
+                           vals["neumann_terms"], vals["objFuncType"], vals["Nunc"], vals["T"],
+                           *[a.ctypes.data_as(_lib.c_dp) for a in keep], None, None)
     return prob, keep
 
 
 @pytest.mark.parametrize("over,code", [
-    (dict(nsteps=0), -1), (dict(T=0.0), -1), (dict(N=0), -1), (dict(reserved=7), -1), (dict(objFuncType=9), -1),
+    (dict(nsteps=0), -1), (dict(T=0.0), -1), (dict(N=0), -1), (dict(Nunc=-1), -1), (dict(Nunc=1), -1), (dict(objFuncType=9), -1),
     (dict(neumann_terms=-1), -1), (dict(Ntot=97), -3), (dict(Ncoupled=0), -3), (dict(Ncoupled=5), -3),
 ])
 def test_create_validates_before_touching_the_device(jq, over, code):
