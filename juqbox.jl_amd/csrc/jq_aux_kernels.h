@@ -108,11 +108,12 @@ __global__ void k_stream(const double* __restrict__ himg, const double* __restri
     stream[(size_t)(2 * j + 1) * mat_elems + e] = c * S;
 }
 
-// state file <- (Uinit, 0, 0, 0, extras 0); grid = nslabs, block = 64
-__global__ void k_init_state(double* state, long long stride, const double* __restrict__ uimg, int KT)
+// state file <- (Uinit, 0, 0, 0, extras 0); grid = nslabs, block = 64  (N > 16: slab sl holds part sl % parts of its sample)
+__global__ void k_init_state(double* state, long long stride, const double* __restrict__ uimg, int KT, int parts)
 {
     double* st = state + (size_t)blockIdx.x * stride;
     const int lane = threadIdx.x;
+    uimg += (size_t)(blockIdx.x % parts) * KT * 64;
     for (int kk = 0; kk < KT; ++kk) {
         st[kk * 64 + lane] = uimg[kk * 64 + lane];
         st[(KT + kk) * 64 + lane] = 0.0;
@@ -170,6 +171,53 @@ __global__ void k_terminal(double* state, long long stride, const double* __rest
         res[(size_t)sample * 4 + 1] = leak_scale * slk;
         res[(size_t)sample * 4 + 2] = sre;
         res[(size_t)sample * 4 + 3] = sim;
+    }
+}
+
+// k_terminal for N > 16: the columns of a sample are spread over `parts` consecutive slabs (16 columns each); the trace
+// fidelity couples them (the only cross-column coupling of an evaluation, src/evalobjgrad.jl:818, :2029-2041).
+// grid = nsamples, block = 64; sums over lanes and parts in a fixed order.
+__global__ void k_terminal_parts(double* state, long long stride, const double* __restrict__ vtr_img,
+                                 const double* __restrict__ vti_img, int KT, int N, int parts, double leak_scale, double* res)
+{
+    __shared__ double part[3][64];
+    const int lane = threadIdx.x;
+    double re = 0.0, im = 0.0, lk = 0.0;
+    for (int p = 0; p < parts; ++p) {
+        const double* st = state + ((size_t)blockIdx.x * parts + p) * stride;
+        const double *tr = vtr_img + (size_t)p * KT * 64, *ti = vti_img + (size_t)p * KT * 64;
+        for (int kk = 0; kk < KT; ++kk) {           // (columns beyond N hold zeros in state and target images)
+            const double u = st[kk * 64 + lane], v = st[(KT + kk) * 64 + lane];
+            re += u * tr[kk * 64 + lane] - v * ti[kk * 64 + lane];
+            im += u * ti[kk * 64 + lane] + v * tr[kk * 64 + lane];
+        }
+        lk += st[(JQ_STATE_ARRAYS * KT + JQ_MAXNC) * 64 + lane];
+    }
+    part[0][lane] = re;
+    part[1][lane] = im;
+    part[2][lane] = lk;
+    __syncthreads();
+    double sre = 0.0, sim = 0.0, slk = 0.0;
+    for (int l = 0; l < 64; ++l) {
+        sre += part[0][l];
+        sim += part[1][l];
+        slk += part[2][l];
+    }
+    sre /= N;
+    sim /= N;
+    for (int p = 0; p < parts; ++p) {
+        double* st = state + ((size_t)blockIdx.x * parts + p) * stride;
+        const double *tr = vtr_img + (size_t)p * KT * 64, *ti = vti_img + (size_t)p * KT * 64;
+        for (int kk = 0; kk < KT; ++kk) {
+            st[(2 * KT + kk) * 64 + lane] = (sre * tr[kk * 64 + lane] + sim * ti[kk * 64 + lane]) / N;        // lambdar
+            st[(3 * KT + kk) * 64 + lane] = -((sim * tr[kk * 64 + lane] - sre * ti[kk * 64 + lane]) / N);   // nb = -lambdai
+        }
+    }
+    if (lane == 0) {
+        res[(size_t)blockIdx.x * 4 + 0] = 1.0 - (sre * sre + sim * sim);
+        res[(size_t)blockIdx.x * 4 + 1] = leak_scale * slk;
+        res[(size_t)blockIdx.x * 4 + 2] = sre;
+        res[(size_t)blockIdx.x * 4 + 3] = sim;
     }
 }
 

@@ -15,6 +15,7 @@
 // generator and reductions as the slab kernels.
 #pragma once
 #include "jq_kernels.h"
+#include <type_traits>
 
 // BW == JQ_BW_OD (jq_kernels.h): the window is the row's own diagonal block (4 MFMA tiles); the two neighbouring
 // blocks are diagonal matrices, stored as 2 x 16 coefficients behind the tiles and applied with 8 FMAs.
@@ -33,14 +34,16 @@ __host__ __device__ constexpr int coop_tiles(int NT, int BW) { return NT * 4 * c
 
 // D = C + M[mt, window] * x[window]  (ZEROC: C = 0).  Mrow: my row's tiles in LDS (lane offset applied);
 // x: exchange buffer [4*NT][64] (lane offset applied), kb0 = first k-block of my window.
-template <int NT, int BW, bool ZEROC>
-__device__ __forceinline__ d4 cmm(const d4& C, const double* Mrow, const double* x, int kb0)
+// PF: tiles in flight ahead of their MFMA (LDS operands: JQ_PF; operands read straight from HBM / L2 -- the BIG variants
+// below -- need a deeper FIFO for the longer latency)
+template <int NT, int BW, bool ZEROC, int PF = JQ_PF>
+__device__ __forceinline__ d4 cmm(const d4& C, const double* __restrict__ Mrow, const double* x, int kb0)
 {
     constexpr int NTL = 4 * coop_nb(NT, BW);
     const double* xs = x + (size_t)kb0 * 4 * 64;
-    double fa[JQ_PF], fb[JQ_PF];
+    double fa[PF], fb[PF];
 #pragma unroll
-    for (int i = 0; i < JQ_PF; ++i)
+    for (int i = 0; i < PF; ++i)
         if (i < NTL) {
             fa[i] = Mrow[i * 64];
             fb[i] = xs[i * 64];
@@ -48,16 +51,62 @@ __device__ __forceinline__ d4 cmm(const d4& C, const double* Mrow, const double*
     d4 acc = ZEROC ? (d4){0.0, 0.0, 0.0, 0.0} : C;
 #pragma unroll
     for (int i = 0; i < NTL; ++i) {
-        const double a = fa[i % JQ_PF], b = fb[i % JQ_PF];
-        if (i + JQ_PF < NTL) {
-            fa[i % JQ_PF] = Mrow[(i + JQ_PF) * 64];
-            fb[i % JQ_PF] = xs[(i + JQ_PF) * 64];
+        const double a = fa[i % PF], b = fb[i % PF];
+        if (i + PF < NTL) {
+            fa[i % PF] = Mrow[(i + PF) * 64];
+            fb[i % PF] = xs[(i + PF) * 64];
         }
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
     return acc;
 }
+
+// Operator sequencing of the BIG variants (Ntot > 96: NT = 7 .. 16 waves per slab): the images do not go through LDS at all
+// -- a wave only ever reads ITS OWN tile row of an operator, so it loads those tiles from the tile stream in HBM (shared by
+// all workgroups through L2) straight into the MFMA's A registers.  Same schedule words as Ring, no DMA, no barrier.
+struct OpCursor {
+    const double* stream;
+    const double* cimg;
+    unsigned long long sb0, sb1, sb2, pb;
+    long long stride;
+    int period, npro, Q, np, ip;
+    __device__ __forceinline__ void init(char*, const PropArgs& a, int, int, int)
+    {
+        stream = a.stream, cimg = a.cimg;
+        sb0 = a.sched_bits[0], sb1 = a.sched_bits[1], sb2 = a.sched_bits[2], pb = a.pro_bits;
+        stride = a.stride, period = a.period, npro = a.npro;
+        Q = 0, np = 0, ip = 0;
+    }
+    __device__ __forceinline__ const double* next()
+    {
+        unsigned long long w;
+        int k = ip;
+        if (Q < npro) {
+            w = pb;
+            k = Q;
+        } else if (ip < 10) {
+            w = sb0;
+        } else if (ip < 20) {
+            w = sb1;
+            k = ip - 10;
+        } else {
+            w = sb2;
+            k = ip - 20;
+        }
+        const unsigned e = (unsigned)(w >> (6 * k)) & 63u, kind = e & 3u, tp = e >> 2;
+        const double* M = (kind == 2) ? cimg + (size_t)tp * stride : stream + ((size_t)(2 * (2 * np + tp)) + kind) * stride;
+        if (Q >= npro) {
+            if (++ip == period) {
+                ip = 0;
+                ++np;
+            }
+        }
+        ++Q;
+        return M + (threadIdx.x & 63);
+    }
+    __device__ __forceinline__ void drain() {}
+};
 
 // JQ_BW_OD:  D = C + Mdiag[mt] x[mt] (4 MFMAs, B operand = the wave's own rows, still in registers)
 //                 + d_below .* x[mt-1] + d_above .* x[mt+1]  (neighbour rows from the exchange buffer; the
@@ -83,10 +132,10 @@ __device__ __forceinline__ d4 cmm_od(const d4& C, const double* Mrow, const doub
     return acc;
 }
 
-// per-wave context of a cooperative workgroup
-template <int NT, int BW>
+// per-wave context of a cooperative workgroup (BIG: operators from HBM, see OpCursor)
+template <int NT, int BW, bool BIG = (NT > 6)>
 struct Coop {
-    Ring ring;
+    typename std::conditional<BIG, OpCursor, Ring>::type ring;
     double* xbuf;       // LDS exchange buffers [2][4*NT][64], lane offset applied
     const double* M;    // current operator: my row's tiles (lane offset applied)
     int xcur;           // buffer that holds the published x
@@ -117,7 +166,11 @@ struct Coop {
     __device__ __forceinline__ void publish_next_op()
     {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        M = ring.next() + row_off;   // vmcnt(0) + barrier + prefetch inside
+        if constexpr (BIG) {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        M = ring.next() + row_off;   // (Ring: vmcnt(0) + barrier + prefetch inside)
         xcur ^= 1;
     }
     __device__ __forceinline__ void next_op() { M = ring.next() + row_off; }
@@ -125,12 +178,12 @@ struct Coop {
     __device__ __forceinline__ d4 mm_z() const
     {
         if constexpr (BW == JQ_BW_OD) return cmm_od<NT, true>((d4){0, 0, 0, 0}, M, x(), xown, mt);
-        else return cmm<NT, BW, true>((d4){0, 0, 0, 0}, M, x(), kb0);
+        else return cmm<NT, BW, true, BIG ? 12 : JQ_PF>((d4){0, 0, 0, 0}, M, x(), kb0);
     }
     __device__ __forceinline__ d4 mm_c(const d4& C) const
     {
         if constexpr (BW == JQ_BW_OD) return cmm_od<NT, false>(C, M, x(), xown, mt);
-        else return cmm<NT, BW, false>(C, M, x(), kb0);
+        else return cmm<NT, BW, false, BIG ? 12 : JQ_PF>(C, M, x(), kb0);
     }
 };
 
@@ -275,8 +328,8 @@ __global__ __launch_bounds__(64 * NT) void k_forward_coop(PropArgs a)
         u = un;
         leak += dot4(wdr, u * u) + 2.0 * dot4(wdr, v05 * v05);  // (:716, penalf2a :2170-2180)
         if (a.hist_r) {
-            const int col = lane & 15;
-            if (slab == 0 && col < a.N) {
+            const int col = a.parts > 1 ? 16 * slab + (lane & 15) : (lane & 15);      // column of sample 0
+            if (slab < a.parts && col < a.N) {
                 const size_t off = (size_t)(a.step0 + n + 1) * a.Ntot * a.N + (size_t)col * a.Ntot;
                 for (int r = 0; r < 4; ++r) {
                     const int row = 16 * wave + 4 * r + g;

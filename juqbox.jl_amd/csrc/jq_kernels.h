@@ -804,6 +804,7 @@ struct PropArgs {
     int step0;              // global index of the first step of this chunk
     int first_chunk;
     int Ntot, N;
+    int parts;              // N > 16: slabs per sample (slab sl = part sl % parts, columns 16 part ..), else 1
     int use_shift;
     int forced;             // backward: add the leakage forcing (0: step_no_forcing!)
     int debug;              // profiling experiments only (JQ_DEBUG): 1 skip trace reductions, 2 skip forcing/shift rows, 4 skip parking
@@ -832,8 +833,9 @@ template <int NT>
 __device__ __forceinline__ void hist_store(const PropArgs& a, int slab, int col, int g, int n, const Arr<NT>& u,
                                            const Arr<NT>& v)
 {
-    if (slab == 0 && col < a.N) {
-        const size_t off = (size_t)(a.step0 + n + 1) * a.Ntot * a.N + (size_t)col * a.Ntot;
+    const int scol = a.parts > 1 ? 16 * slab + col : col;      // column of sample 0
+    if (slab < a.parts && scol < a.N) {
+        const size_t off = (size_t)(a.step0 + n + 1) * a.Ntot * a.N + (size_t)scol * a.Ntot;
 #pragma unroll
         for (int i = 0; i < NT; ++i)
 #pragma unroll

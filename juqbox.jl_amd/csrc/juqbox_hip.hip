@@ -43,6 +43,7 @@ struct jq_handle {
     double solver_tol = 0.0;
     double T = 0.0;
     int NT = 0, KT = 0, NP = 0, sps = 0;
+    int parts = 1;              // N > 16: a sample's columns take `parts` = ceil(N / 16) consecutive slabs (sps = 1)
     int BW = 0;                 // block band width the kernels are instantiated for (JQ_BW_OD: see jq_kernels.h)
     int BWc = 0;                // ... of the cooperative kernels (plain band)
     int bw_trace[JQ_MAXNC] = {0, 0, 0, 0};
@@ -54,6 +55,8 @@ struct jq_handle {
     int nslots_bwd = 2;         // ... of the backward kernel (shares LDS with carry + parking images)
     int park_lds = 0;           // backward kernel parks its dormant array in LDS (1) or HBM (0)
     int batch = 0;              // > 0: batched staging (K/S images of `batch` time steps per DMA burst); < 0: window staging
+    bool big = false;           // Ntot > 96 (NT = 7 .. 16): only the cooperative kernels with operators read from HBM (jq_coop_kernels.h
+                                // OpCursor) exist -- Stormer-Verlet, Neumann solver, any batch size
     int quad_max_slabs = 0;     // JQ_BW_T4 structure: batches of at most this many slabs may use the quad-layout kernels (0: never)
     int num_cu = 256;
     int lane_np = 0;            // > 0: lane kernels available (Ntot <= 12), padded Hilbert dimension NP
@@ -262,14 +265,18 @@ static int block_band(const double* M, int Ntot)
     return bw;
 }
 
-// register-layout image [KT][64] of an Ntot x N array replicated over the samples of a slab
-static void slab_image(const double* A, int Ntot, int N, int sps, int KT, double* img)
+// register-layout images [parts][KT][64] of an Ntot x N array: N <= 16: one image, the N columns replicated over the sps
+// samples of a slab; N > 16: part p holds the columns 16 p .. 16 p + 15
+static void slab_image(const double* A, int Ntot, int N, int sps, int KT, double* img, int parts = 1)
 {
-    for (int kk = 0; kk < KT; ++kk)
-        for (int l = 0; l < 64; ++l) {
-            const int row = 4 * kk + (l >> 4), col = l & 15;
-            img[kk * 64 + l] = (row < Ntot && col < sps * N) ? A[row + (size_t)Ntot * (col % N)] : 0.0;
-        }
+    for (int p = 0; p < parts; ++p)
+        for (int kk = 0; kk < KT; ++kk)
+            for (int l = 0; l < 64; ++l) {
+                const int row = 4 * kk + (l >> 4), col = l & 15;
+                const int scol = parts > 1 ? 16 * p + col : col % N;
+                const bool on = parts > 1 ? scol < N : col < sps * N;
+                img[((size_t)p * KT + kk) * 64 + l] = (row < Ntot && on) ? A[row + (size_t)Ntot * scol] : 0.0;
+            }
 }
 
 // plain row-major NP x NP image of a column-major Ntot x Ntot matrix (lane kernels), zero padded
@@ -308,16 +315,19 @@ static int upload_operators(jq_handle* h)
 {
     const size_t nn = (size_t)h->Ntot * h->Ntot;
     // images the tile stream is generated from: [H0 | Hsym_q | Hanti_q] in the kernels' band layout
+    // (Ntot > 96: no slab-kernel images, only the cooperative layout below)
     std::vector<double> img((size_t)(1 + 2 * h->Nc) * h->mat_elems, 0.0);
-    tile_image(h->Hconst.data(), h->Ntot, h->NT, h->BW, img.data());
-    for (int q = 0; q < h->Nc; ++q) {
-        tile_image(h->Hsym.data() + q * nn, h->Ntot, h->NT, h->BW, img.data() + (size_t)(1 + q) * h->mat_elems);
-        tile_image(h->Hanti.data() + q * nn, h->Ntot, h->NT, h->BW, img.data() + (size_t)(1 + h->Nc + q) * h->mat_elems);
+    if (!h->big) {
+        tile_image(h->Hconst.data(), h->Ntot, h->NT, h->BW, img.data());
+        for (int q = 0; q < h->Nc; ++q) {
+            tile_image(h->Hsym.data() + q * nn, h->Ntot, h->NT, h->BW, img.data() + (size_t)(1 + q) * h->mat_elems);
+            tile_image(h->Hanti.data() + q * nn, h->Ntot, h->NT, h->BW, img.data() + (size_t)(1 + h->Nc + q) * h->mat_elems);
+        }
     }
     HIPCHK(h, hipMemcpy(h->d_himg, img.data(), img.size() * sizeof(double), hipMemcpyHostToDevice));
     // images of the trace products: [Hsym_q | Hanti_q], each pair in its own band (0 or BW)
     std::vector<double> cimg((size_t)(2 * h->Nc) * h->mat_elems, 0.0);
-    for (int q = 0; q < h->Nc; ++q) {
+    for (int q = 0; q < h->Nc && !h->big; ++q) {
         const int bwq = (h->BW == JQ_BW_T4) ? JQ_BW_T4 : (h->bw_trace[q] == 0) ? 0 : h->BW;
         const bool sd = (h->BW == JQ_BW_T4) ? false : (h->bw_trace[q] == 2);
         tile_image(h->Hsym.data() + q * nn, h->Ntot, h->NT, bwq, cimg.data() + (size_t)q * h->mat_elems, sd);
@@ -359,10 +369,10 @@ static int upload_operators(jq_handle* h)
 
 static int upload_targets(jq_handle* h)
 {
-    std::vector<double> img((size_t)h->KT * 64);
-    slab_image(h->Utr.data(), h->Ntot, h->N, h->sps, h->KT, img.data());
+    std::vector<double> img((size_t)h->parts * h->KT * 64);
+    slab_image(h->Utr.data(), h->Ntot, h->N, h->sps, h->KT, img.data(), h->parts);
     HIPCHK(h, hipMemcpy(h->d_vtr, img.data(), img.size() * sizeof(double), hipMemcpyHostToDevice));
-    slab_image(h->Uti.data(), h->Ntot, h->N, h->sps, h->KT, img.data());
+    slab_image(h->Uti.data(), h->Ntot, h->N, h->sps, h->KT, img.data(), h->parts);
     HIPCHK(h, hipMemcpy(h->d_vti, img.data(), img.size() * sizeof(double), hipMemcpyHostToDevice));
     if (h->lane_np > 0) {
         std::vector<double> cl((size_t)h->N * h->lane_np, 0.0);
@@ -440,9 +450,8 @@ static int create_impl(const jq_problem* p, jq_handle* h)
     const int nctrl = p->Nunc > 0 ? p->Nunc : p->Ncoupled;     // control pairs the kernels see
     if (nctrl < 1) return fail(h, JQ_EUNSUPPORTED, "jq_create: at least one control Hamiltonian is required");
     if (nctrl > JQ_MAXNC) return fail(h, JQ_EUNSUPPORTED, "jq_create: more than 4 control Hamiltonians are not supported");
-    if (p->Ntot > 96)
-        return fail(h, JQ_EUNSUPPORTED, "jq_create: Ntot > 96 does not fit the two-slot LDS operator ring");
-    if (p->N > 16) return fail(h, JQ_EUNSUPPORTED, "jq_create: N > 16 (more than one 16-column slab per sample)");
+    if (p->Ntot > 256)
+        return fail(h, JQ_EUNSUPPORTED, "jq_create: Ntot > 256 (more than 16 tile rows = waves per 16-column slab)");
     if (p->objFuncType < 1 || p->objFuncType > 3) return fail(h, JQ_EINVAL, "jq_create: objFuncType must be 1, 2 or 3");
 
     HIPCHK(h, hipGetDevice(&h->device));
@@ -458,9 +467,11 @@ static int create_impl(const jq_problem* p, jq_handle* h)
     h->Ntot = p->Ntot; h->N = p->N; h->Nc = nctrl; h->Nfreq = p->Nfreq; h->nsteps = p->nsteps;
     h->m = p->neumann_terms; h->objFuncType = p->objFuncType; h->T = p->T;
     h->NT = (p->Ntot + 15) / 16;
+    h->big = h->NT > 6;
     h->KT = 4 * h->NT;
     h->NP = 16 * h->NT;
-    h->sps = 16 / p->N;
+    h->parts = p->N > 16 ? (p->N + 15) / 16 : 1;
+    h->sps = p->N > 16 ? 1 : 16 / p->N;
     h->state_stride = (long long)(JQ_STATE_ARRAYS * h->KT + JQ_STATE_EXTRA) * 64;
     const size_t nn = (size_t)p->Ntot * p->Ntot, nc = (size_t)p->Ntot * p->N;
     h->Hconst.assign(p->Hconst, p->Hconst + nn);
@@ -507,10 +518,11 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         if (const char* e = getenv("JQ_FORCE_DENSE"))
             if (atoi(e) != 0) bw = h->NT - 1;
         h->BW = (bw <= 2 && bw < h->NT - 1) ? bw : h->NT - 1;
+        if (h->big && h->BW == 0) h->BW = 1;      // (the big variants are instantiated for block bands 1, 2 and dense)
         h->BWc = h->BW;
         // block tridiagonal with DIAGONAL off-diagonal blocks (operators of the slowest subsystem, cnot3):
         // MFMA only for the diagonal blocks, 16 coefficients per off-diagonal block (JQ_OD=0 disables)
-        bool od = (bw == 1 && h->NT >= 2 && offdiag_blocks_diagonal(h->Hconst.data(), h->Ntot));
+        bool od = (!h->big && bw == 1 && h->NT >= 2 && offdiag_blocks_diagonal(h->Hconst.data(), h->Ntot));
         for (int q = 0; q < h->Nc && od; ++q)
             od = offdiag_blocks_diagonal(h->Hsym.data() + q * nn, h->Ntot) && offdiag_blocks_diagonal(h->Hanti.data() + q * nn, h->Ntot);
         if (const char* e = getenv("JQ_OD"))
@@ -520,7 +532,7 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         if (od) h->BW = h->BWc = JQ_BW_OD;
         // ... and, one level finer, 4x4 diagonal blocks + diagonal couplings of neighbouring 4-row groups: the slab kernels
         // use v_mfma_f64_4x4x4 (JQ_BW_T4; JQ_T4=0 disables); the cooperative kernels stay on the JQ_BW_OD variant
-        bool t4 = (bw <= 1) && t4_structure(h->Hconst.data(), h->Ntot);
+        bool t4 = !h->big && (bw <= 1) && t4_structure(h->Hconst.data(), h->Ntot);
         for (int q = 0; q < h->Nc && t4; ++q)
             t4 = t4_structure(h->Hsym.data() + q * nn, h->Ntot) && t4_structure(h->Hanti.data() + q * nn, h->Ntot);
         if (const char* e = getenv("JQ_T4"))
@@ -546,7 +558,9 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         const long long lds_fwd_fixed = (long long)32 * h->NT * 8;
         const long long lds_bwd_fixed = bwd_lds_tail(h->NT, h->Nc, JQ_WAVES, 0);
         const long long park_bytes = (long long)JQ_WAVES * h->KT * 64 * 8;
-        if (2 * slot + lds_fwd_fixed > 163840)
+        if (h->big) {
+            h->mat_elems = 128;       // (no slab-kernel images: placeholders)
+        } else if (2 * slot + lds_fwd_fixed > 163840)
             return fail(h, JQ_EUNSUPPORTED, "jq_create: operator images do not fit the LDS double buffer");
         h->nslots = 2;
         h->nslots_bwd = 2;
@@ -555,11 +569,12 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         h->mat_elems_c = 0;
         if (h->NT >= 2) {
             const long long ec = (((long long)h->NT * coop_row_elems(h->NT, h->BWc) + 127) / 128) * 128;
-            const long long lds_c = 2 * ec * 8 + lds_fwd_fixed + 2LL * h->KT * 64 * 8;
+            const long long lds_c = (h->big ? 0 : 2 * ec * 8) + lds_fwd_fixed + 2LL * h->KT * 64 * 8;
             if (lds_c <= 163840) h->mat_elems_c = ec;
         }
         h->coop_max_slabs = prop.multiProcessorCount;   // one cooperative workgroup per CU = one round
         if (const char* e = getenv("JQ_COOP_MAX")) h->coop_max_slabs = atoi(e);
+        if (h->big) h->coop_max_slabs = 1 << 30;        // the only kernel family at this size
         // Batched staging (K/S images of B time steps per DMA burst, constants resident in LDS) exists for
         // small images but is OFF by default: measured on MI355X it does not help (swap02/cnot2: the
         // ~600-cycle dependent-product latency dominates, not the per-operator barrier) and its 150 KB of
@@ -571,7 +586,7 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         {
             const long long win = (2LL * JQ_WIN_TPS + 2LL * h->Nc) * slot;
             const long long budget = (h->NT <= 2) ? 81920 : 163840;
-            bool w = win + lds_bwd_fixed + park_bytes <= budget;
+            bool w = !h->big && win + lds_bwd_fixed + park_bytes <= budget;
             if (const char* e = getenv("JQ_WINDOW"))
                 if (atoi(e) == 0) w = false;
             if (w) {
@@ -683,9 +698,9 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         column_image(h->Uinit.data(), h->Ntot, h->N, 16, cl.data());
         HIPCHK(h, hipMemcpy(h->d_uinit_r, cl.data(), cl.size() * sizeof(double), hipMemcpyHostToDevice));
     }
-    if ((rc = dev_alloc(h, &h->d_uimg, (size_t)h->KT * 64))) return rc;
-    if ((rc = dev_alloc(h, &h->d_vtr, (size_t)h->KT * 64))) return rc;
-    if ((rc = dev_alloc(h, &h->d_vti, (size_t)h->KT * 64))) return rc;
+    if ((rc = dev_alloc(h, &h->d_uimg, (size_t)h->parts * h->KT * 64))) return rc;
+    if ((rc = dev_alloc(h, &h->d_vtr, (size_t)h->parts * h->KT * 64))) return rc;
+    if ((rc = dev_alloc(h, &h->d_vti, (size_t)h->parts * h->KT * 64))) return rc;
     if ((rc = dev_alloc(h, &h->d_tabs, (size_t)32 * h->NT))) return rc;
     if ((rc = dev_alloc(h, &h->d_tf, (size_t)h->nsteps + 1))) return rc;
     if ((rc = dev_alloc(h, &h->d_tb, (size_t)h->nsteps + 1))) return rc;
@@ -700,8 +715,8 @@ static int create_impl(const jq_problem* p, jq_handle* h)
     if ((rc = upload_operators(h))) return rc;
     if ((rc = upload_targets(h))) return rc;
     {
-        std::vector<double> img((size_t)h->KT * 64);
-        slab_image(h->Uinit.data(), h->Ntot, h->N, h->sps, h->KT, img.data());
+        std::vector<double> img((size_t)h->parts * h->KT * 64);
+        slab_image(h->Uinit.data(), h->Ntot, h->N, h->sps, h->KT, img.data(), h->parts);
         HIPCHK(h, hipMemcpy(h->d_uimg, img.data(), img.size() * sizeof(double), hipMemcpyHostToDevice));
     }
 
@@ -786,6 +801,8 @@ extern "C" int jq_set_linear_solver(jq_handle* h, int32_t solver_id, int32_t max
     } else if (solver_id != 1) {
         return fail(h, JQ_EUNSUPPORTED, "jq_set_linear_solver: only NEUMANN_SOLVER (1) and JACOBI_SOLVER (2) are implemented");
     }
+    if (solver_id == 2 && h->big)
+        return fail(h, JQ_EUNSUPPORTED, "jq_set_linear_solver: JACOBI_SOLVER is implemented for Ntot <= 96 (slab kernels)");
     h->solver_id = solver_id;
     h->m = max_iter;
     h->solver_tol = tol;
@@ -802,6 +819,10 @@ extern "C" int jq_set_integrator(jq_handle* h, int32_t integrator_id, int32_t ma
     }
     if (integrator_id != 2) return fail(h, JQ_EUNSUPPORTED, "jq_set_integrator: 1 = Stormer-Verlet, 2 = implicit midpoint");
     if (max_iter < 1 || !(tol > 0.0)) return fail(h, JQ_EINVAL, "jq_set_integrator: implicit midpoint needs max_iter >= 1 and tol > 0");
+    if (h->big) return fail(h, JQ_EUNSUPPORTED, "jq_set_integrator: the implicit-midpoint path is implemented for Ntot <= 96");
+    if (h->parts > 1)
+        return fail(h, JQ_EUNSUPPORTED, "jq_set_integrator: the implicit-midpoint path is implemented for N <= 16 (its solver's "
+                                        "per-evaluation convergence test needs all columns of a sample in one workgroup)");
     if (!(h->rl_npj > 0 && h->N <= 4) && h->mat_elems_c == 0)
         return fail(h, JQ_EUNSUPPORTED, "jq_set_integrator: the implicit-midpoint path needs Ntot <= 16 with N <= 4 (row-lane "
                                         "kernels) or Ntot > 16 (cooperative kernels)");
@@ -927,6 +948,12 @@ static int select_quad_kernels(jq_handle* h, int spw, prop_kernel_t* fwd, prop_k
     X(2, 0) X(2, 1) X(3, 0) X(3, 1) X(3, 2) X(4, 0) X(4, 1) X(4, 2) X(4, 3) X(5, 0) X(5, 1) X(5, 2) X(5, 4) \
     X(6, 0) X(6, 1) X(6, 2) X(6, 5) X(2, 9) X(3, 9) X(4, 9) X(5, 9) X(6, 9)
 JQ_FOR_EACH_COOP(JQ_DECLC)
+// Ntot > 96 (NT = 7 .. 16): block band 1, 2 or dense; operators read from HBM (jq_coop_kernels.h OpCursor)
+#define JQ_FOR_EACH_BIG(X)                                                                                   \
+    X(7, 1) X(7, 2) X(7, 6) X(8, 1) X(8, 2) X(8, 7) X(9, 1) X(9, 2) X(9, 8) X(10, 1) X(10, 2) X(10, 9)      \
+    X(11, 1) X(11, 2) X(11, 10) X(12, 1) X(12, 2) X(12, 11) X(13, 1) X(13, 2) X(13, 12) X(14, 1) X(14, 2)   \
+    X(14, 13) X(15, 1) X(15, 2) X(15, 14) X(16, 1) X(16, 2) X(16, 15)
+JQ_FOR_EACH_BIG(JQ_DECLC)
 #undef JQ_DECLC
 
 static int select_coop_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
@@ -938,6 +965,7 @@ static int select_coop_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* 
         return JQ_OK;                         \
     }
     JQ_FOR_EACH_COOP(JQ_PICKC)
+    JQ_FOR_EACH_BIG(JQ_PICKC)
 #undef JQ_PICKC
     return fail(h, JQ_EUNSUPPORTED, "no cooperative kernel for this Hilbert dimension / band width");
 }
@@ -1058,7 +1086,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
                                         "branch cannot run (gradSize = (2 Ncoupled + Nunc) Nfreq D1, src/evalobjgrad.jl:801, is not "
                                         "length(pcof); adjoint_grad_calc!'s axpy!, :2620-2656, throws DimensionMismatch)");
 
-    const int nslabs = (nsamples + h->sps - 1) / h->sps;
+    const int nslabs = h->parts > 1 ? nsamples * h->parts : (nsamples + h->sps - 1) / h->sps;
     // small batches: cooperative (row-split) kernels, one workgroup of NT waves per slab; large batches: slab
     // kernels, one wave per slab (jq_coop_kernels.h explains the trade-off)
     // small Hilbert spaces: lane kernels, one lane per column (jq_lane_kernels.h)
@@ -1192,9 +1220,9 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
         }
     } else {
         for (int sl = 0; sl < nslabs; ++sl)
-            for (int c = 0; c < h->sps * h->N; ++c) {
-                const int smp = sl * h->sps + c / h->N;
-                if (smp < nsamples) {
+            for (int c = 0; c < (h->parts > 1 ? 16 : h->sps * h->N); ++c) {
+                const int smp = h->parts > 1 ? sl / h->parts : sl * h->sps + c / h->N;
+                if (smp < nsamples && (h->parts == 1 || 16 * (sl % h->parts) + c < h->N)) {
                     colinfo[(size_t)sl * 32 + c] = eps ? eps[smp] : 0.0;
                     colinfo[(size_t)sl * 32 + 16 + c] = wgt ? wgt[smp] : 1.0;
                     if (eps && eps[smp] != 0.0) use_shift = true;
@@ -1224,7 +1252,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     a.traces = h->d_traces;
     a.tabs = h->d_tabs; a.stride = stride; a.pieces = (int)(stride * 8 / 1024); a.nslots = h->nslots; a.m = h->m;
     a.nslabs = rl ? (int)nwaves_rl : lane ? (int)ncols : nslabs; a.Ncoupled = h->Nc; a.Ntot = h->Ntot; a.N = h->N; a.use_shift = use_shift ? 1 : 0;
-    a.tinv = 1.0 / h->T; a.state_stride = h->state_stride;
+    a.tinv = 1.0 / h->T; a.state_stride = h->state_stride; a.parts = h->parts;
     a.jacobi_tol2 = (h->solver_id == 2) ? h->solver_tol * h->solver_tol : 0.0;
     if (imr) {   // fixed-point solver of the implicit-midpoint step: iteration cap and per-lane threshold (jq_rowlane_imr_kernels.h)
         a.m = h->imr_max_iter;
@@ -1234,7 +1262,8 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     // dynamic LDS layout: [operator staging | tables wd, ws | (backward: carry, parking images)]
     // cooperative kernels: [two operator slots | tables wd, ws | two x exchange buffers]
     const int batch = coop ? 0 : quad ? -1 : h->batch;
-    const size_t lds_stage = batch > 0   ? (size_t)2 * (2 * batch + 1) * 2 * stride * 8 + (size_t)2 * h->Nc * stride * 8
+    const size_t lds_stage = (coop && h->big) ? 0      // operators are read from HBM, no LDS staging
+                             : batch > 0   ? (size_t)2 * (2 * batch + 1) * 2 * stride * 8 + (size_t)2 * h->Nc * stride * 8
                              : batch < 0 ? (size_t)(2 * JQ_WIN_TPS + 2 * h->Nc) * stride * 8
                                          : (size_t)2 * stride * 8;
     const size_t lds_fwd = (lane || rl) ? 0 : imr_coop ? coop_imr_lds_bytes(h->NT, stride)
@@ -1268,7 +1297,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     else if (lane)
         hipLaunchKernelGGL(klinit, dim3((unsigned)(ncols / 64)), dim3(64), 0, s, h->d_state, ncols, h->d_uinit_l, h->N, ncols_used);
     else
-        hipLaunchKernelGGL(k_init_state, dim3(nslabs), dim3(64), 0, s, h->d_state, h->state_stride, h->d_uimg, h->KT);
+        hipLaunchKernelGGL(k_init_state, dim3(nslabs), dim3(64), 0, s, h->d_state, h->state_stride, h->d_uimg, h->KT, h->parts);
 
     long long mfma = 0, mfma_fwd = 0;
     const long long tiles = (lane || rl) ? 0 : coop ? coop_tiles(h->NT, h->BWc) : band_tiles(h->NT, h->BW);
@@ -1316,6 +1345,9 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     else if (lane)
         hipLaunchKernelGGL(klterm, dim3((nsamples + 63) / 64), dim3(64), 0, s, h->d_state, ncols, h->d_vtr_l, h->d_vti_l, h->N,
                            nsamples, leak_scale, h->d_res);
+    else if (h->parts > 1)
+        hipLaunchKernelGGL(k_terminal_parts, dim3(nsamples), dim3(64), 0, s, h->d_state, h->state_stride, h->d_vtr, h->d_vti, h->KT,
+                           h->N, h->parts, leak_scale, h->d_res);
     else
         hipLaunchKernelGGL(k_terminal, dim3(nslabs), dim3(64), 0, s, h->d_state, h->state_stride, h->d_vtr, h->d_vti, h->KT,
                            h->N, h->sps, nsamples, leak_scale, h->d_res);

@@ -256,3 +256,49 @@ def test_bench_refuses_more_gpus_than_visible(hip):
                        text=True, timeout=600)
     assert r.returncode != 0 and "GPU(s) are visible" in r.stderr
     assert not any(ln.startswith("{") for ln in r.stdout.splitlines())       # and no JSON line that could be mistaken for a result
+
+
+# ---- sizes beyond the round-1 kernel limits (Ntot <= 96, N <= 16) --------------------------------------------------------
+@pytest.mark.parametrize("Ntot,N,Nc,nsteps,m,oft,structure,nq", [
+    (112, 4, 2, 9, 3, 1, False, 1),          # NT = 7, dense
+    (128, 16, 1, 7, 2, 3, False, 3),         # NT = 8, dense, full slab, objFuncType 3 (two backward passes), ensemble
+    (160, 5, 3, 6, 4, 1, True, 2),           # NT = 10, nearest-level couplings: block band 1
+    (200, 3, 2, 5, 1, 2, False, 1),          # NT = 13 (Ntot not a multiple of 16), dense
+    (256, 8, 1, 4, 2, 1, True, 1),           # NT = 16: 1024-thread workgroups
+    (40, 24, 2, 11, 3, 1, False, 2),         # N > 16: two slabs per sample, slab kernels (NT = 3)
+    (20, 20, 1, 9, 2, 3, False, 3),          # N = Ntot (no guard levels), 3 samples
+    (96, 40, 2, 6, 2, 1, "t4", 1),           # N > 16 on the quad-layout / JQ_BW_T4 kernels
+    (130, 33, 1, 5, 2, 1, True, 2),          # both: big cooperative kernels with three slabs per sample
+])
+def test_sizes_beyond_the_round1_limits_match_the_oracle(hip, Ntot, N, Nc, nsteps, m, oft, structure, nq):
+    """Ntot up to 256 (cooperative kernels with 7..16 waves per slab, operator tiles read from HBM) and N up to Ntot
+    (a sample's columns spread over ceil(N/16) slabs; the trace fidelity couples them in k_terminal_parts): objective,
+    gradients, ensemble sums and the state history against the oracle."""
+    from oracle.oracle import Oracle
+    from test_gpu_random import random_problem
+    jq = hip
+    rng = np.random.default_rng(1000 + Ntot + N)
+    p, pcof = random_problem(jq, rng, Ntot, N, Nc, 2, nsteps, m, oft, structure)
+    nodes, weights = 0.05 * rng.standard_normal(nq), rng.random(nq)
+    shift = 0.05 * rng.standard_normal(Ntot)
+    inf = leak = 0.0
+    gi, gl = np.zeros(pcof.size), np.zeros(pcof.size)
+    for ep, wq in zip(nodes, weights):
+        r = oracle_sample(p, pcof, ep, shift)
+        inf += wq * r["primaryobjf"]
+        leak += wq * r["secondaryobjf"]
+        gi += wq * r["infidelgrad"]
+        gl += wq * r["leakgrad"]
+    wa = jq.Working_Arrays_HIP(p, pcof.size)
+    jq.eval_f_g_grad(pcof, p, wa, nodes, weights, True, shift=shift)
+    assert abs(p.last_infidelity - inf) <= 1e-9 * abs(inf)
+    assert abs(p.last_leak - leak) <= 1e-9 * abs(leak)
+    assert rel(p.last_infidelity_grad, gi) < 1e-9
+    if oft != 1:
+        assert np.linalg.norm(p.last_leak_grad - gl) <= 1e-9 * np.linalg.norm(gi)
+    r0 = Oracle(p, use_sparse=False).traceobjgrad(pcof, evaladjoint=False, history=True)
+    objfv, hist, fid = jq.traceobjgrad(pcof, p, wa, True, False)
+    assert hist.shape == (Ntot, N, nsteps + 1)
+    assert np.max(np.abs(hist - r0["history"])) < 1e-11
+    assert abs(objfv - r0["objfv"]) <= 1e-9 * abs(r0["objfv"])
+    wa.close()
