@@ -82,6 +82,13 @@ struct jq_handle {
     double *d_wq = nullptr, *d_pack = nullptr;   // ensemble weights per sample; packed result [2 + 2 nCoeff] (multi-device all-reduce)
     size_t cap_pcof = 0, cap_slabs = 0, cap_traces = 0, cap_grad = 0, cap_res = 0, cap_state = 0, cap_colinfo = 0, cap_wq = 0, cap_pack = 0;
     int chunk_steps = 0;
+    // Structure embedding (try_embed): a second handle of the SAME problem with its two fastest Kronecker factors zero-padded
+    // to 4 levels each (row i1 + d1 i2 + d1 d2 i3 -> i1 + 4 i2 + 16 i3), under which the operators have the JQ_BW_T4 structure;
+    // batches that would otherwise run on the dense / band MFMA kernels go there (quad-layout / JQ_BW_T4 slab kernels).
+    jq_handle* emb = nullptr;
+    std::vector<int> emb_row;   // user row -> row of the embedded problem
+    int emb_mode = 1;           // JQ_EMBED: 0 never, 1 for batches of the MFMA families (default), 2 whenever possible (tests)
+    bool is_emb = false;        // this handle IS an embedded twin: no lane / row-lane / cooperative families, no further embedding
     // multi-device handle (jq_create_multi): one single-device handle per GPU and one RCCL communicator each; such a
     // handle owns no device memory itself
     std::vector<jq_handle*> subs;
@@ -416,6 +423,7 @@ extern "C" void jq_destroy(jq_handle* h)
         return;
     }
     (void)hipSetDevice(h->device);
+    if (h->emb) jq_destroy(h->emb);
     double** bufs[] = {&h->d_rfreq, &h->d_wq, &h->d_pack, &h->d_himg_r, &h->d_uinit_r, &h->d_vtr_r, &h->d_vti_r, &h->d_himg_l, &h->d_uinit_l, &h->d_vtr_l, &h->d_vti_l, &h->d_himg_c, &h->d_cimg_c, &h->d_park, &h->d_cimg, &h->d_himg,  &h->d_uimg,       &h->d_vtr,     &h->d_vti,    &h->d_tabs, &h->d_tf,   &h->d_tb,
                        &h->d_cfreq, &h->d_pcof,       &h->d_stream,  &h->d_pq,     &h->d_state, &h->d_state_save,
                        &h->d_colinfo, &h->d_traces,   &h->d_R,       &h->d_grad,   &h->d_res};
@@ -648,6 +656,7 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         h->rl_npj = h->Ntot <= 8 ? (h->Ntot + 1) / 2 * 2 : (h->Ntot <= 12 ? 12 : (h->Ntot <= 16 ? 16 : 0));
         if (const char* e = getenv("JQ_LANE"))
             if (atoi(e) == 0) h->rl_npj = 0;
+        if (h->is_emb) h->rl_npj = 0, h->lane_np = 0;      // an embedded twin only serves the JQ_BW_T4 / quad-layout families
         h->rl_stride = 16LL * h->rl_npj;
         // cross-over measured with scripts/time_cases.py: ~2 waves per SIMD against the lane kernels (Ntot <= 8),
         // ~4 against the MFMA slab kernels (Ntot 9..16)
@@ -744,6 +753,102 @@ static int create_impl(const jq_problem* p, jq_handle* h)
     return JQ_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Structure embedding.  The JQ_BW_T4 / quad-layout kernels need operators that are sums of 4x4 diagonal blocks and diagonal
+// couplings at the strides 4 (inside a 16-row block) and 16 -- a Kronecker-ordered Hilbert space 4 x 4 x n.  A space
+// d1 x d2 x d3 with d1, d2 <= 4 (cnot2: 3 x 4) gets there by zero-padding its two fastest factors to 4 levels: rows and
+// columns of the padded levels are zero in every operator, in the initial condition, the target and the leakage weights,
+// so those levels stay exactly empty and every result (objective, gradients) is unchanged.  The factorisation is found from
+// the operators themselves (the C ABI carries no Ne / Ng): the first (d1, d2) with the fewest 16-row blocks under which
+// H0, Hsym_q, Hanti_q all pass t4_structure.
+static void embed_matrix(const double* M, int Ntot, const std::vector<int>& row, int NtotE, double* out)
+{
+    std::fill(out, out + (size_t)NtotE * NtotE, 0.0);
+    for (int c = 0; c < Ntot; ++c)
+        for (int r = 0; r < Ntot; ++r) out[row[r] + (size_t)NtotE * row[c]] = M[r + (size_t)Ntot * c];
+}
+static void embed_rows(const double* A, int Ntot, int ncol, const std::vector<int>& row, int NtotE, double* out)
+{
+    std::fill(out, out + (size_t)NtotE * ncol, 0.0);
+    for (int c = 0; c < ncol; ++c)
+        for (int r = 0; r < Ntot; ++r) out[row[r] + (size_t)NtotE * c] = A[r + (size_t)Ntot * c];
+}
+
+static int try_embed(jq_handle* h, const jq_problem* p)
+{
+    if (const char* e = getenv("JQ_EMBED")) h->emb_mode = atoi(e);
+    if (h->is_emb || h->emb_mode == 0 || h->BW == JQ_BW_T4 || h->big || h->Ntot > 96) return JQ_OK;
+    if (const char* e = getenv("JQ_T4"))
+        if (atoi(e) == 0) return JQ_OK;
+    if (const char* e = getenv("JQ_OD"))
+        if (atoi(e) == 0) return JQ_OK;
+    if (const char* e = getenv("JQ_FORCE_DENSE"))
+        if (atoi(e) != 0) return JQ_OK;
+    const int Ntot = h->Ntot, Nc = h->Nc;
+    const size_t nn = (size_t)Ntot * Ntot;
+    int best_d1 = 0, best_d2 = 0, best_d3 = 1 << 30;
+    std::vector<int> row(Ntot);
+    std::vector<double> E;
+    for (int d1 = 1; d1 <= 4; ++d1)
+        for (int d2 = 1; d2 <= 4; ++d2) {
+            if (Ntot % (d1 * d2) != 0) continue;
+            const int d3 = Ntot / (d1 * d2);
+            if (d3 > 6 || d3 >= best_d3) continue;
+            for (int r = 0; r < Ntot; ++r) row[r] = (r % d1) + 4 * ((r / d1) % d2) + 16 * (r / (d1 * d2));
+            const int NE = 16 * d3;
+            E.assign((size_t)NE * NE, 0.0);
+            bool ok = true;
+            auto test = [&](const double* M) {
+                embed_matrix(M, Ntot, row, NE, E.data());
+                return t4_structure(E.data(), NE);
+            };
+            ok = test(h->Hconst.data());
+            for (int q = 0; q < Nc && ok; ++q) ok = test(h->Hsym.data() + q * nn) && test(h->Hanti.data() + q * nn);
+            if (ok) best_d1 = d1, best_d2 = d2, best_d3 = d3;
+        }
+    if (best_d1 == 0) return JQ_OK;
+    const int d1 = best_d1, d2 = best_d2, NE = 16 * best_d3;
+    h->emb_row.resize(Ntot);
+    for (int r = 0; r < Ntot; ++r) h->emb_row[r] = (r % d1) + 4 * ((r / d1) % d2) + 16 * (r / (d1 * d2));
+    // the embedded twin of the problem (coupled controls: Hunc problems were turned into pairs by create_impl already)
+    std::vector<double> H0((size_t)NE * NE), Hs((size_t)Nc * NE * NE), Ha((size_t)Nc * NE * NE), U0((size_t)NE * h->N),
+        Vr((size_t)NE * h->N), Vi((size_t)NE * h->N), wd(NE);
+    embed_matrix(h->Hconst.data(), Ntot, h->emb_row, NE, H0.data());
+    for (int q = 0; q < Nc; ++q) {
+        embed_matrix(h->Hsym.data() + q * nn, Ntot, h->emb_row, NE, Hs.data() + (size_t)q * NE * NE);
+        embed_matrix(h->Hanti.data() + q * nn, Ntot, h->emb_row, NE, Ha.data() + (size_t)q * NE * NE);
+    }
+    embed_rows(h->Uinit.data(), Ntot, h->N, h->emb_row, NE, U0.data());
+    embed_rows(h->Utr.data(), Ntot, h->N, h->emb_row, NE, Vr.data());
+    embed_rows(h->Uti.data(), Ntot, h->N, h->emb_row, NE, Vi.data());
+    embed_rows(h->wd.data(), Ntot, 1, h->emb_row, NE, wd.data());
+    jq_problem q = *p;
+    q.Ntot = NE;
+    q.Ncoupled = Nc;
+    q.Nunc = 0;
+    q.Hconst = H0.data(); q.Hsym_ops = Hs.data(); q.Hanti_ops = Ha.data(); q.Uinit = U0.data();
+    q.Utarget_r = Vr.data(); q.Utarget_i = Vi.data(); q.wmat_real_diag = wd.data(); q.Cfreq = h->cfreq.data();
+    q.Hunc_ops = nullptr; q.Rfreq = nullptr;
+    jq_handle* e = new (std::nothrow) jq_handle();
+    if (!e) return fail(h, JQ_ENOMEM, "jq_create: out of host memory");
+    e->is_emb = true;
+    int rc = create_impl(&q, e);
+    if (rc == JQ_OK && e->BW != JQ_BW_T4) rc = JQ_EUNSUPPORTED;      // (cannot happen: the structure test above passed)
+    if (rc != JQ_OK) {      // the embedding is an optimisation: without it the handle works as before
+        jq_destroy(e);
+        h->emb_row.clear();
+        return JQ_OK;
+    }
+    e->rfreq = h->rfreq;      // uncoupled controls: the same ft(t) of k_ctrl
+    if (!e->rfreq.empty()) {
+        if ((rc = dev_alloc(e, &e->d_rfreq, e->rfreq.size()))) { jq_destroy(e); return rc; }
+        HIPCHK(h, hipMemcpy(e->d_rfreq, e->rfreq.data(), e->rfreq.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    h->emb = e;
+    return JQ_OK;
+}
+
 extern "C" int jq_create(const jq_problem* problem, jq_handle** out)
 {
     if (!out) {
@@ -757,6 +862,7 @@ extern "C" int jq_create(const jq_problem* problem, jq_handle** out)
         return JQ_ENOMEM;
     }
     int rc = create_impl(problem, h);
+    if (rc == JQ_OK) rc = try_embed(h, problem);
     if (rc != JQ_OK) {
         g_create_error = h->err;
         jq_destroy(h);
@@ -788,6 +894,7 @@ extern "C" int jq_set_neumann_terms(jq_handle* h, int32_t m)
     if (!h->subs.empty()) return multi_forall(h, [&](jq_handle* sub) { return jq_set_neumann_terms(sub, m); });
     if (m < 0) return fail(h, JQ_EINVAL, "jq_set_neumann_terms: m must be >= 0");
     h->m = m;
+    if (h->emb) h->emb->m = m;
     return JQ_OK;
 }
 
@@ -806,6 +913,7 @@ extern "C" int jq_set_linear_solver(jq_handle* h, int32_t solver_id, int32_t max
     h->solver_id = solver_id;
     h->m = max_iter;
     h->solver_tol = tol;
+    if (h->emb) h->emb->solver_id = solver_id, h->emb->m = max_iter, h->emb->solver_tol = tol;
     return JQ_OK;
 }
 
@@ -841,6 +949,16 @@ extern "C" int jq_update_target(jq_handle* h, const double* Utr, const double* U
     const size_t nc = (size_t)h->Ntot * h->N;
     h->Utr.assign(Utr, Utr + nc);
     h->Uti.assign(Uti, Uti + nc);
+    if (h->emb) {
+        jq_handle* e = h->emb;
+        embed_rows(Utr, h->Ntot, h->N, h->emb_row, e->Ntot, e->Utr.data());
+        embed_rows(Uti, h->Ntot, h->N, h->emb_row, e->Ntot, e->Uti.data());
+        const int rc = upload_targets(e);
+        if (rc != JQ_OK) {
+            h->err = e->err;
+            return rc;
+        }
+    }
     return upload_targets(h);
 }
 
@@ -855,6 +973,14 @@ extern "C" int jq_update_hconst(jq_handle* h, const double* Hconst)
         return fail(h, JQ_EUNSUPPORTED, "jq_update_hconst: new Hconst has entries outside the block band the kernels were "
                                         "selected for; create a new handle");
     h->Hconst.assign(Hconst, Hconst + (size_t)h->Ntot * h->Ntot);
+    if (h->emb) {
+        jq_handle* e = h->emb;
+        embed_matrix(Hconst, h->Ntot, h->emb_row, e->Ntot, e->Hconst.data());
+        if (!t4_structure(e->Hconst.data(), e->Ntot) || upload_operators(e) != JQ_OK) {   // the new drift breaks the structure:
+            jq_destroy(e);                                                                // work without the embedded twin
+            h->emb = nullptr;
+        }
+    }
     return upload_operators(h);
 }
 
@@ -864,6 +990,7 @@ extern "C" int jq_update_wmat_diag(jq_handle* h, const double* w)
     if (!w) return fail(h, JQ_EINVAL, "jq_update_wmat_diag: NULL pointer");
     if (!h->subs.empty()) return multi_forall(h, [&](jq_handle* sub) { return jq_update_wmat_diag(sub, w); });
     h->wd.assign(w, w + h->Ntot);
+    if (h->emb) embed_rows(w, h->Ntot, 1, h->emb_row, h->emb->Ntot, h->emb->wd.data());
     return JQ_OK;
 }
 
@@ -1081,6 +1208,24 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
         return fail(h, JQ_EDIM, "DimensionMismatch: Inconsistent number of coefficients and size of parameter vector (nCoeff != length(pcof))");
     if (D1 < 3) return fail(h, JQ_EINVAL, "need at least 3 B-spline coefficients per control function");
     if (nsamples < 1) return fail(h, JQ_EINVAL, "need at least one sample");
+    // Structure embedding (try_embed): batches that would run on the dense / band MFMA families go to the embedded twin,
+    // whose operators have the JQ_BW_T4 structure (quad-layout / JQ_BW_T4 slab kernels).  State histories stay here (their
+    // rows are the user's), the implicit-midpoint path too.
+    if (h->emb && !hist_r && h->integrator == 1) {
+        const long long nc_used = (long long)nsamples * h->N;
+        const bool small_family = h->solver_id == 1 && ((h->rl_npj > 0 && nc_used <= h->rl_max_cols) ||
+                                                        (h->lane_np > 0 && nc_used >= h->lane_min_cols && nc_used <= h->lane_max_cols));
+        if (h->emb_mode == 2 || !small_family) {
+            jq_handle* e = h->emb;
+            std::vector<double> sh(e->Ntot, 0.0);
+            for (int i = 0; i < h->Ntot; ++i)   // (default: the reference's 0.01 * 10^(j-2) by the USER's level index, src/ipopt_interface.jl:41-44)
+                sh[h->emb_row[i]] = shift ? shift[i] : (i >= 1 ? 0.01 * pow(10.0, (double)(i - 1)) : 0.0);
+            const int rc = run_eval(e, pcof, ncoeff, nsamples, eps, wgt, sh.data(), adjoint, nullptr, nullptr, out, d_packed);
+            if (rc != JQ_OK) h->err = e->err;
+            h->timing = e->timing;
+            return rc;
+        }
+    }
     if (adjoint && !h->rfreq.empty())
         return fail(h, JQ_EUNSUPPORTED, "uncoupled controls (Hunc_ops): forward evaluations only -- the reference's adjoint for this "
                                         "branch cannot run (gradSize = (2 Ncoupled + Nunc) Nfreq D1, src/evalobjgrad.jl:801, is not "
@@ -1129,6 +1274,10 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
                 spw = k;
             }
         }
+        // One or two 16-row blocks (cnot2 embedded: NT = 1): a state array of the slab kernels is only 4 NT registers, nothing
+        // spills and two workgroups share a CU -- measured 3.5e9 vs 2.2e9 SVTS/s for cnot2 x 65 536 samples.  The quad
+        // layout keeps the latency regime (at most one slab per CU).
+        if (h->NT <= 2 && nslabs > h->num_cu) spw = 0;
         if (const char* e = getenv("JQ_QUAD8")) {      // experiments / tests: force 4 / 8 / 12 waves (as far as the LDS allows)
             spw = std::max(1, std::min(3, atoi(e) + 1));
             while (spw > 1 && quad_lds(spw) > 163840) --spw;

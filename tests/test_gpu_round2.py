@@ -302,3 +302,101 @@ def test_sizes_beyond_the_round1_limits_match_the_oracle(hip, Ntot, N, Nc, nstep
     assert np.max(np.abs(hist - r0["history"])) < 1e-11
     assert abs(objfv - r0["objfv"]) <= 1e-9 * abs(r0["objfv"])
     wa.close()
+
+
+# ---- structure embedding: d1 x d2 x d3 Hilbert spaces on the 4 x 4 x n (JQ_BW_T4 / quad-layout) kernels --------------------
+@pytest.mark.parametrize("case", ["cnot2", "cnot2-leakieq"])
+def test_cnot2_goldens_on_the_quad_layout_kernels_through_the_embedding(hip, case):
+    """cnot2 is 3 x 4 levels: padded to 4 x 4 it is ONE 16-row block of the JQ_BW_T4 structure.  JQ_EMBED=2 sends every batch to
+    the embedded twin: the reference's goldens must come out of the quad-layout kernels (kernel family 6)."""
+    from test_gpu_parity import gpu_eval_like_evalGrad
+    from conftest import reference_pass
+    jq = hip
+    params, info, pcof, golden = case_inputs(case)
+    os.environ["JQ_EMBED"] = "2"
+    try:
+        wa = jq.Working_Arrays_HIP(params, pcof.size)
+    finally:
+        os.environ.pop("JQ_EMBED", None)
+    obj, grad = gpu_eval_like_evalGrad(jq, params, wa, pcof)
+    t = wa.last_timing()
+    assert (t["kernel_family"], t["kernel_band"], t["kernel_size"]) == (6, 7, 1)
+    assert reference_pass(obj, golden["obj0"]), (obj, golden["obj0"])
+    assert reference_pass(grad, golden["grad0"])
+    # mutations reach the twin: target, weights, Neumann terms, drift
+    from oracle.oracle import Oracle
+    params.linear_solver.max_iter = 3
+    params.wmat_real = jq.setup_utils.wmatsetup(params.Ne, params.Ng)
+    params.Utarget_r, params.Utarget_i = params.Utarget_i.copy(), -params.Utarget_r.copy()
+    params.Hconst[np.diag_indices(params.Ntot)] += 1e-3 * np.arange(params.Ntot)
+    r = Oracle(params).traceobjgrad(pcof)
+    objfv, tg, *_ = jq.traceobjgrad(pcof, params, wa, False, True)
+    assert wa.last_timing()["kernel_family"] == 6
+    assert abs(objfv - r["objfv"]) <= TOL * abs(r["objfv"]) and rel(tg, r["totalgrad"]) < TOL
+    wa.close()
+
+
+@pytest.mark.parametrize("dims,N,nq", [((3, 4, 1), 4, 700), ((2, 2, 3), 3, 5), ((3, 3, 5), 4, 40), ((4, 2, 6), 2, 9), ((2, 4, 2), 16, 3)])
+def test_random_kronecker_problems_take_the_embedded_kernels(hip, dims, N, nq):
+    """Random d1 x d2 x d3 problems (dense blocks on the fastest factor, diagonal couplings of the other two): large batches
+    go to the embedded twin by default (family 6 or 0 with band 7 / 8), results against the oracle; with JQ_EMBED=0 the same
+    problem runs on the generic kernels and must agree."""
+    jq = hip
+    d1, d2, d3 = dims
+    Ntot = d1 * d2 * d3
+    rng = np.random.default_rng(77 + Ntot)
+    def op(anti, parts):
+        a = np.zeros((Ntot, Ntot))
+        if parts & 1:       # fastest factor: dense d1 x d1 blocks (different per block)
+            for b in range(0, Ntot, d1):
+                blk = rng.standard_normal((d1, d1))
+                a[b:b + d1, b:b + d1] = blk - blk.T if anti else blk + blk.T
+        for stride, bit, period in ((d1, 2, d1 * d2), (d1 * d2, 4, Ntot)):
+            if parts & bit:
+                for i in range(Ntot - stride):
+                    if i // period != (i + stride) // period:
+                        continue
+                    a[i, i + stride] = rng.standard_normal()
+                    a[i + stride, i] = -a[i, i + stride] if anti else a[i, i + stride]
+        return a
+    Nc = 3
+    Hs = [op(False, (7, 2, 4)[q]) for q in range(Nc)]
+    Ha = [op(True, (7, 2, 4)[q]) for q in range(Nc)]
+    H0 = op(False, 7)
+    scale = 2.0 / max(1.0, max(np.abs(np.linalg.eigvalsh(h)).max() for h in Hs + [H0]))
+    nsteps, m = 14, 3
+    U0 = np.linalg.qr(rng.standard_normal((Ntot, N)))[0]
+    Ut = np.linalg.qr(rng.standard_normal((Ntot, N)) + 1j * rng.standard_normal((Ntot, N)))[0]
+    p = jq.objparams([N], [Ntot - N], 1.3, nsteps, Uinit=U0, Utarget=Ut, Cfreq=rng.standard_normal((Nc, 2)), Rfreq=np.zeros(Nc),
+                     Hconst=H0 * scale, Hsym_ops=[h * scale for h in Hs], Hanti_ops=[h * scale for h in Ha], objFuncType=3,
+                     linear_solver=jq.lsolver_object(max_iter=m))
+    p.wmat_real = rng.random(Ntot) * (np.arange(Ntot) >= N)
+    pcof = 0.3 * rng.standard_normal(2 * Nc * 2 * 4)
+    nodes, weights = 0.05 * rng.standard_normal(nq), rng.random(nq)
+    shift = 0.05 * rng.standard_normal(Ntot)
+    out = {}
+    for mode in ("2", "0"):
+        os.environ["JQ_EMBED"] = mode
+        if mode == "2":
+            os.environ["JQ_LANE"] = "0"      # (a space that has the structure natively, 2 x 2 x 3, must use it too: no lane kernels)
+        try:
+            wa = jq.Working_Arrays_HIP(p, pcof.size)
+        finally:
+            os.environ.pop("JQ_EMBED", None)
+            os.environ.pop("JQ_LANE", None)
+        jq.eval_f_g_grad(pcof, p, wa, nodes, weights, True, shift=shift)
+        t = wa.last_timing()
+        out[mode] = (p.last_infidelity, p.last_leak, p.last_infidelity_grad.copy(), p.last_leak_grad.copy(), t["kernel_family"], t["kernel_band"])
+        wa.close()
+    a, b = out["2"], out["0"]
+    assert a[5] in (7, 8) and (b[5] not in (7, 8) or dims == (2, 2, 3))
+    assert abs(a[0] - b[0]) <= 1e-12 * abs(b[0]) and abs(a[1] - b[1]) <= 1e-11 * abs(b[1])
+    assert rel(a[2], b[2]) < 1e-11 and np.linalg.norm(a[3] - b[3]) <= 1e-11 * np.linalg.norm(b[2])
+    # and against the oracle (small ensembles only: CPU time)
+    if nq <= 40:
+        inf = leak = 0.0
+        gi = np.zeros(pcof.size)
+        for ep, wq in zip(nodes, weights):
+            r = oracle_sample(p, pcof, ep, shift)
+            inf += wq * r["primaryobjf"]; leak += wq * r["secondaryobjf"]; gi += wq * r["infidelgrad"]
+        assert abs(a[0] - inf) <= 1e-9 * abs(inf) and abs(a[1] - leak) <= 1e-9 * abs(leak) and rel(a[2], gi) < 1e-9

@@ -64,9 +64,13 @@ def test_objparams_validation(jq):
         jq.objparams([3], [1], 10.0, 10, Uinit=np.eye(4, 3), Utarget=np.eye(4, 3, dtype=complex),
                      Cfreq=np.zeros((1, 1)), Rfreq=[0.0], Hconst=np.zeros((4, 4)),
                      Hsym_ops=[np.zeros((4, 4))], Hanti_ops=[])
-    with pytest.raises(NotImplementedError):     # uncoupled controls: parity-unpinned branch
+    with pytest.raises(AssertionError):          # @assert(Ncoupled==0 || Nunc==0) (:176)
         jq.objparams([3], [1], 10.0, 10, Uinit=np.eye(4, 3), Utarget=np.eye(4, 3, dtype=complex),
-                     Cfreq=np.zeros((1, 1)), Rfreq=[0.0], Hconst=np.zeros((4, 4)), Hunc_ops=[np.zeros((4, 4))])
+                     Cfreq=np.zeros((2, 1)), Rfreq=[0.0, 0.0], Hconst=np.zeros((4, 4)),
+                     Hsym_ops=[np.zeros((4, 4))], Hanti_ops=[np.zeros((4, 4))], Hunc_ops=[np.zeros((4, 4))])
+    unc = jq.objparams([3], [1], 10.0, 10, Uinit=np.eye(4, 3), Utarget=np.eye(4, 3, dtype=complex),        # uncoupled controls
+                       Cfreq=np.zeros((1, 1)), Rfreq=[0.0], Hconst=np.zeros((4, 4)), Hunc_ops=[np.eye(4)])
+    assert unc.Nunc == 1 and unc.Ncoupled == 0 and unc.isSymm == [True]
     assert np.allclose(params.shift_weights_reference(), [0.0, 0.01, 0.1, 1.0])
 
 
