@@ -38,7 +38,10 @@ template __global__ void k_forward_coop<JQ_NT, JQ_BW>(PropArgs);
 template __global__ void k_backward_coop<JQ_NT, JQ_BW>(PropArgs);
 #else
 #include "jq_kernels.h"
-#define JQ_MINW ((JQ_NT <= 2) ? 2 : 1)
+#ifndef JQ_MINW_MAXNT
+#define JQ_MINW_MAXNT 2      // tile counts up to which two workgroups share a CU (slab kernels)
+#endif
+#define JQ_MINW ((JQ_NT <= JQ_MINW_MAXNT) ? 2 : 1)
 #if JQ_BW == 7 && JQ_VARIANT == 8   // quad layout, workgroups of 4 / 8 waves (1 / 2 slabs): built with the max-ILP scheduler (Makefile)
 template __global__ void k_forward<JQ_NT, JQ_BW, 1, false>(PropArgs);
 template __global__ void k_backward<JQ_NT, JQ_BW, 1, false>(PropArgs);

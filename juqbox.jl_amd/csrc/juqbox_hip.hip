@@ -28,6 +28,9 @@
 #include <vector>
 
 #define JQ_VERSION "gfx950 juqbox_hip 0.2.0"
+#ifndef JQ_MINW_MAXNT
+#define JQ_MINW_MAXNT 2      // tile counts up to which two workgroups share a CU (slab kernels; jq_kernel_inst.hip)
+#endif
 
 static thread_local std::string g_create_error;
 
@@ -593,7 +596,7 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         // and parking images (kernels compiled for two workgroups per CU: in half of the LDS); JQ_WINDOW=0 disables it.
         {
             const long long win = (2LL * JQ_WIN_TPS + 2LL * h->Nc) * slot;
-            const long long budget = (h->NT <= 2) ? 81920 : 163840;
+            const long long budget = (h->NT <= JQ_MINW_MAXNT) ? 81920 : 163840;
             bool w = !h->big && win + lds_bwd_fixed + park_bytes <= budget;
             if (const char* e = getenv("JQ_WINDOW"))
                 if (atoi(e) == 0) w = false;
@@ -1002,7 +1005,7 @@ typedef void (*prop_kernel_t)(PropArgs);
     X(1, 0) X(2, 0) X(2, 1) X(3, 0) X(3, 1) X(3, 2) X(4, 0) X(4, 1) X(4, 2) X(4, 3) X(5, 0) X(5, 1) \
     X(5, 2) X(5, 4) X(6, 0) X(6, 1) X(6, 2) X(6, 5) X(2, 9) X(3, 9) X(4, 9) X(5, 9) X(6, 9) X(1, 8) X(2, 8) X(3, 8)       \
     X(4, 8) X(5, 8) X(6, 8)
-#define JQ_MINW_OF(nt) (((nt) <= 2) ? 2 : 1)
+#define JQ_MINW_OF(nt) (((nt) <= JQ_MINW_MAXNT) ? 2 : 1)
 #define JQ_DECL(nt, bw)                                                                      \
     extern template __global__ void k_forward<nt, bw, JQ_MINW_OF(nt), false>(PropArgs);      \
     extern template __global__ void k_backward<nt, bw, JQ_MINW_OF(nt), false>(PropArgs);     \
