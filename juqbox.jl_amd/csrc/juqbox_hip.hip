@@ -1585,8 +1585,10 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     h->timing.ms_total = ms;
     double fwd = 0.0, bwd = 0.0;
     const size_t nfwd = (size_t)nchunks;
+    const bool show = getenv("JQ_DEBUG_TIMING") != nullptr;      // development aid: every propagator launch on stderr
     for (size_t i = 2, k = 0; i + 1 < evi; i += 2, ++k) {
         HIPCHK(h, hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
+        if (show) fprintf(stderr, "jq launch %zu (%s): %.3f ms\n", k, k < (size_t)nchunks ? "forward" : "backward", ms);
         if (k < nfwd)
             fwd += ms;
         else
