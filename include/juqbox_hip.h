@@ -88,7 +88,8 @@ typedef struct jq_timing {
     int32_t kernel_family;  /* propagators used: 0 slab (MFMA, wave per slab), 1 cooperative (MFMA, row split),
                                2 lane (VALU, lane per column), 3 row-lane (VALU, lane per (row, column)),
                                4 row-lane, implicit midpoint, 5 cooperative, implicit midpoint,
-                               6 quad layout (MFMA 4x4x4, four columns per wave; small batches, JQ_BW_T4)  */
+                               6 quad layout (MFMA 4x4x4, four columns per wave; JQ_BW_T4), 7 the same, implicit midpoint,
+                               8 cooperative quad (one 16-row block per wave: single evaluations / small ensembles)  */
     int32_t kernel_size;    /* template size parameter: NT (16-row tiles) for 0/1, NP for 2, NPJ for 3       */
     int32_t kernel_band;    /* block band of the MFMA families (9 = JQ_BW_OD: diagonal off-diagonal blocks,
                                8 = JQ_BW_T4: 4x4 diagonal blocks + diagonal couplings, 7 = the same, quad layout) */

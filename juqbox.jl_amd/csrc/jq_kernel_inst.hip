@@ -6,11 +6,16 @@
 //              7: quad-layout kernels of the implicit-midpoint integrator (JQ_BW = 7)
 //              8: quad-layout slab kernels with 1 and 2 slabs per workgroup (JQ_BW = 7; variant 0 holds the 3-slab ones)
 //              5: row-lane kernels of the implicit-midpoint integrator (JQ_NT = NPJ)
+//              9: cooperative-quad kernels (one 16-row block per wave; single evaluations / small ensembles; JQ_BW = 7)
 //              4: row-lane kernels (one lane per (row, column); JQ_NT = padded row length NPJ, JQ_BW unused)
 #if !defined(JQ_NT) || !defined(JQ_BW) || !defined(JQ_VARIANT)
-#error "compile with -DJQ_NT=<tiles> -DJQ_BW=<band> -DJQ_VARIANT=<0..8>"
+#error "compile with -DJQ_NT=<tiles> -DJQ_BW=<band> -DJQ_VARIANT=<0..9>"
 #endif
-#if JQ_VARIANT == 7
+#if JQ_VARIANT == 9     // cooperative-quad (latency) kernels of the JQ_BW_T4 structure (JQ_BW = 7)
+#include "jq_cq_kernels.h"
+template __global__ void k_forward_cq<JQ_NT>(PropArgs);
+template __global__ void k_backward_cq<JQ_NT>(PropArgs);
+#elif JQ_VARIANT == 7
 #include "jq_quad_imr_kernels.h"
 template __global__ void k_forward_quad_imr<JQ_NT>(PropArgs);
 template __global__ void k_backward_quad_imr<JQ_NT>(PropArgs);

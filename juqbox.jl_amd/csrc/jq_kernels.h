@@ -805,6 +805,8 @@ struct PropArgs {
     int first_chunk;
     int Ntot, N;
     int parts;              // N > 16: slabs per sample (slab sl = part sl % parts, columns 16 part ..), else 1
+    int nsamples, sps;      // evaluations of the batch, samples per slab (cooperative-quad kernels: which column quads are in use)
+    int qps;                // ... column quads of a full slab = trace-record rows per slab of those kernels
     int use_shift;
     int forced;             // backward: add the leakage forcing (0: step_no_forcing!)
     int debug;              // profiling experiments only (JQ_DEBUG): 1 skip trace reductions, 2 skip forcing/shift rows, 4 skip parking

@@ -60,6 +60,8 @@ struct jq_handle {
     int batch = 0;              // > 0: batched staging (K/S images of `batch` time steps per DMA burst); < 0: window staging
     bool big = false;           // Ntot > 96 (NT = 7 .. 16): only the cooperative kernels with operators read from HBM (jq_coop_kernels.h
                                 // OpCursor) exist -- Stormer-Verlet, Neumann solver, any batch size
+    int cq_max_quads = 0;       // JQ_BW_T4 structure: batches of at most this many column quads (4 columns) run on the cooperative-quad
+                                // (latency) kernels, one workgroup of NT waves per quad (0: never)
     int quad_max_slabs = 0;     // JQ_BW_T4 structure: batches of at most this many slabs may use the quad-layout kernels (0: never)
     int num_cu = 256;
     int lane_np = 0;            // > 0: lane kernels available (Ntot <= 12), padded Hilbert dimension NP
@@ -622,6 +624,16 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         h->num_cu = prop.multiProcessorCount;
         if (const char* e = getenv("JQ_QUAD"))
             if (h->quad_max_slabs > 0) h->quad_max_slabs = atoi(e);
+        // Cooperative-quad kernels (jq_cq_kernels.h): the latency path -- one workgroup of NT waves per column quad while every
+        // quad still gets a CU of its own (LDS: the window staging, one workgroup per CU).  NT >= 2 (a single block has no
+        // neighbour to split the work with).  JQ_CQ=0 disables them, JQ_CQ=<n> bounds the number of quads.
+        {
+            const long long win = (2LL * JQ_WIN_TPS + 2LL * h->Nc) * slot;
+            const long long tail = 32LL * h->NT * 8 + 3LL * h->NT * 64 * 8 + 2LL * h->NT * 8 * h->Nc * 8;
+            h->cq_max_quads = (h->BW == JQ_BW_T4 && h->NT >= 2 && h->quad_max_slabs > 0 && win + tail <= 163840) ? prop.multiProcessorCount : 0;
+            if (const char* e = getenv("JQ_CQ"))
+                if (h->cq_max_quads > 0) h->cq_max_quads = atoi(e);
+        }
         if (const char* e = getenv("JQ_BATCH")) {
             const int v = atoi(e);
             if (v >= 2 && slot <= 8192) {
@@ -1038,6 +1050,25 @@ static int select_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
     extern template __global__ void k_backward<nt, JQ_BW_T4Q, 3, false>(PropArgs);
 JQ_DECLQ(1) JQ_DECLQ(2) JQ_DECLQ(3) JQ_DECLQ(4) JQ_DECLQ(5) JQ_DECLQ(6)
 #undef JQ_DECLQ
+template <int NT> __global__ void k_forward_cq(PropArgs);            // jq_cq_kernels.h (own translation units)
+template <int NT> __global__ void k_backward_cq(PropArgs);
+#define JQ_DECLCQ(nt)                                               \
+    extern template __global__ void k_forward_cq<nt>(PropArgs);     \
+    extern template __global__ void k_backward_cq<nt>(PropArgs);
+JQ_DECLCQ(1) JQ_DECLCQ(2) JQ_DECLCQ(3) JQ_DECLCQ(4) JQ_DECLCQ(5) JQ_DECLCQ(6)
+#undef JQ_DECLCQ
+static int select_cq_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
+{
+#define JQ_PICKCQ(nt)                       \
+    if (h->NT == nt) {                      \
+        *fwd = k_forward_cq<nt>;            \
+        *bwd = k_backward_cq<nt>;           \
+        return JQ_OK;                       \
+    }
+    JQ_PICKCQ(1) JQ_PICKCQ(2) JQ_PICKCQ(3) JQ_PICKCQ(4) JQ_PICKCQ(5) JQ_PICKCQ(6)
+#undef JQ_PICKCQ
+    return fail(h, JQ_EUNSUPPORTED, "unsupported Hilbert dimension");
+}
 template <int NT> __global__ void k_forward_quad_imr(PropArgs);      // jq_quad_imr_kernels.h (own translation units)
 template <int NT> __global__ void k_backward_quad_imr(PropArgs);
 #define JQ_DECLQI(nt)                                                      \
@@ -1287,9 +1318,15 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
         }
     }
     if (imr_quad) spw = 1;
+    // latency regime of the JQ_BW_T4 structure: one workgroup of NT waves per column quad (jq_cq_kernels.h)
+    const long long nquads_used = (ncols_used + 3) / 4;
+    const bool cq = !imr && !lane && !rl && h->solver_id == 1 && h->cq_max_quads > 0 && nquads_used <= h->cq_max_quads &&
+                    !getenv("JQ_QUAD8");      // (JQ_QUAD8 asks for a quad-layout variant explicitly)
+    const int qps = h->parts > 1 ? 4 : (h->sps * h->N + 3) / 4;      // column quads of a full slab
+    if (cq) spw = 0;
     const bool quad = spw > 0;
     const bool quad8 = spw > 1;
-    const bool coop = imr_coop || (!quad && !lane && !rl && h->mat_elems_c > 0 && h->solver_id == 1 && nslabs <= h->coop_max_slabs);
+    const bool coop = imr_coop || (!cq && !quad && !lane && !rl && h->mat_elems_c > 0 && h->solver_id == 1 && nslabs <= h->coop_max_slabs);
     prop_kernel_t kfwd, kbwd;
     lane_init_t klinit = nullptr;
     lane_term_t klterm = nullptr;
@@ -1298,13 +1335,14 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
              : imr_rl ? select_rowlane_imr_kernels(h, &kfwd, &kbwd)
              : rl ? select_rowlane_kernels(h, &kfwd, &kbwd)
              : lane ? select_lane_kernels(h, &kfwd, &kbwd, &klinit, &klterm)
+                  : cq ? select_cq_kernels(h, &kfwd, &kbwd)
                   : coop ? select_coop_kernels(h, &kfwd, &kbwd) : quad ? select_quad_kernels(h, spw, &kfwd, &kbwd) : select_kernels(h, &kfwd, &kbwd);
     if (rc) return rc;
-    const int nblocks = rl ? (int)nwaves_rl : lane ? (int)(ncols / 64) : quad8 ? (nslabs + spw - 1) / spw : (coop || quad) ? nslabs : (nslabs + JQ_WAVES - 1) / JQ_WAVES;
-    const int nthreads = (lane || rl) ? 64 : coop ? 64 * h->NT : quad8 ? 256 * spw : 256;
+    const int nblocks = cq ? 4 * nslabs : rl ? (int)nwaves_rl : lane ? (int)(ncols / 64) : quad8 ? (nslabs + spw - 1) / spw : (coop || quad) ? nslabs : (nslabs + JQ_WAVES - 1) / JQ_WAVES;
+    const int nthreads = (lane || rl) ? 64 : (coop || cq) ? 64 * h->NT : quad8 ? 256 * spw : 256;
     // per-step trace records: one per wave (cooperative, lane, row-lane, implicit-midpoint kernels) or one per workgroup
     // (slab / quad kernels: summed over the workgroup's waves in LDS)
-    const int trace_rows = (lane || rl) ? nblocks : coop ? nslabs * h->NT : imr_quad ? nslabs * JQ_WAVES : nblocks;
+    const int trace_rows = cq ? nslabs * qps : (lane || rl) ? nblocks : coop ? nslabs * h->NT : imr_quad ? nslabs * JQ_WAVES : nblocks;
     const long long stride = rl ? h->rl_stride : lane ? h->lane_stride : coop ? h->mat_elems_c : h->mat_elems;
     const double* himg = rl ? h->d_himg_r : lane ? h->d_himg_l : coop ? h->d_himg_c : h->d_himg;
     const size_t state_doubles = rl ? (size_t)JQ_ROWLANE_ROWS * nwaves_rl * 64
@@ -1404,7 +1442,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     a.traces = h->d_traces;
     a.tabs = h->d_tabs; a.stride = stride; a.pieces = (int)(stride * 8 / 1024); a.nslots = h->nslots; a.m = h->m;
     a.nslabs = rl ? (int)nwaves_rl : lane ? (int)ncols : nslabs; a.Ncoupled = h->Nc; a.Ntot = h->Ntot; a.N = h->N; a.use_shift = use_shift ? 1 : 0;
-    a.tinv = 1.0 / h->T; a.state_stride = h->state_stride; a.parts = h->parts;
+    a.tinv = 1.0 / h->T; a.state_stride = h->state_stride; a.parts = h->parts; a.nsamples = nsamples; a.sps = h->sps; a.qps = qps;
     a.jacobi_tol2 = (h->solver_id == 2) ? h->solver_tol * h->solver_tol : 0.0;
     if (imr) {   // fixed-point solver of the implicit-midpoint step: iteration cap and per-lane threshold (jq_rowlane_imr_kernels.h)
         a.m = h->imr_max_iter;
@@ -1413,19 +1451,21 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     for (int q = 0; q < JQ_MAXNC; ++q) a.bw_trace[q] = h->bw_trace[q];
     // dynamic LDS layout: [operator staging | tables wd, ws | (backward: carry, parking images)]
     // cooperative kernels: [two operator slots | tables wd, ws | two x exchange buffers]
-    const int batch = coop ? 0 : quad ? -1 : h->batch;
+    const int batch = coop ? 0 : (quad || cq) ? -1 : h->batch;
     const size_t lds_stage = (coop && h->big) ? 0      // operators are read from HBM, no LDS staging
                              : batch > 0   ? (size_t)2 * (2 * batch + 1) * 2 * stride * 8 + (size_t)2 * h->Nc * stride * 8
                              : batch < 0 ? (size_t)(2 * JQ_WIN_TPS + 2 * h->Nc) * stride * 8
                                          : (size_t)2 * stride * 8;
-    const size_t lds_fwd = (lane || rl) ? 0 : imr_coop ? coop_imr_lds_bytes(h->NT, stride)
+    const size_t lds_cq = lds_stage + (size_t)32 * h->NT * 8 + (size_t)3 * h->NT * 64 * 8 + (size_t)2 * h->NT * 8 * h->Nc * 8;
+    const size_t lds_fwd = (lane || rl) ? 0 : cq ? lds_cq : imr_coop ? coop_imr_lds_bytes(h->NT, stride)
                                            : lds_stage + (size_t)32 * h->NT * 8 + (coop ? (size_t)2 * h->KT * 64 * 8 : 0);
-    const size_t lds_bwd = rl ? (h->rl_npj > 8 ? (size_t)2 * h->Nc * h->rl_stride * 8 : 0) : lane ? 0 : coop ? lds_fwd
+    const size_t lds_bwd = rl ? (h->rl_npj > 8 ? (size_t)2 * h->Nc * h->rl_stride * 8 : 0) : lane ? 0 : (coop || cq) ? lds_fwd
                                 : imr_quad ? lds_fwd + (size_t)JQ_MAXNC * nthreads * 8 + (size_t)(nthreads / 64) * h->NT * 64 * 8
                                 : quad ? lds_stage + (size_t)bwd_lds_tail(h->NT, h->Nc, nthreads / 64, (long long)h->NT * 64)   // (a 16-row block per register)
                                 : lds_stage + (size_t)bwd_lds_tail(h->NT, h->Nc, JQ_WAVES, h->park_lds ? (long long)h->KT * 64 : 0);
     a.batch = batch; a.lds_tab_off = (int)lds_stage;
     a.park = h->d_park; a.park_lds = quad ? 1 : h->park_lds;
+    if (cq) a.nslots = 0;
     if (const char* e = getenv("JQ_DEBUG")) a.debug = atoi(e);
     if (!lane && !rl) {
         HIPCHK(h, hipFuncSetAttribute((const void*)kfwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fwd));
@@ -1604,9 +1644,9 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     h->timing.mfma_executed = imr ? 0 : (!coop && !lane && !rl && h->BW == JQ_BW_T4) ? mfma / 4 : mfma;   // (the iteration counts of the implicit-midpoint solver are data dependent)
     h->timing.mfma_backward = h->timing.mfma_executed == 0 ? 0 : (h->timing.mfma_executed == mfma ? mfma - mfma_fwd : (mfma - mfma_fwd) / 4);
     h->timing.svts = (long long)nsamples * h->N * h->nsteps;
-    h->timing.kernel_family = imr_quad ? 7 : imr_coop ? 5 : imr ? 4 : rl ? 3 : lane ? 2 : coop ? 1 : quad ? 6 : 0;
+    h->timing.kernel_family = cq ? 8 : imr_quad ? 7 : imr_coop ? 5 : imr ? 4 : rl ? 3 : lane ? 2 : coop ? 1 : quad ? 6 : 0;
     h->timing.kernel_size = rl ? h->rl_npj : lane ? h->lane_np : h->NT;
-    h->timing.kernel_band = (rl || lane) ? 0 : coop ? h->BWc : quad ? JQ_BW_T4Q : h->BW;
+    h->timing.kernel_band = (rl || lane) ? 0 : coop ? h->BWc : (quad || cq) ? JQ_BW_T4Q : h->BW;
     h->timing.reserved = 0;
     return JQ_OK;
 }

@@ -130,7 +130,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("mode", ["auto", "quad8", "quad12", "coop", "slab", "slab-od", "lane", "nolane"])
+@pytest.mark.parametrize("mode", ["auto", "quad4", "quad8", "quad12", "coop", "slab", "slab-od", "lane", "nolane"])
 @pytest.mark.parametrize("cfg", CASES, ids=lambda c: "Ntot%d_N%d_Nc%d_f%d_m%d_o%d_%s_c%d" % (c[0], c[1], c[2], c[3], c[5], c[6], c[7] if isinstance(c[7], str) else ("band" if c[7] else "dense"), c[8]))
 def test_random_problem_matches_oracle(jq, cfg, mode):
     """mode 'auto': Ntot <= 16 runs on the row-lane kernels (one lane per (row, column); small batches), Ntot > 16
@@ -142,8 +142,9 @@ def test_random_problem_matches_oracle(jq, cfg, mode):
     Ntot, N, Nc, Nfreq, nsteps, m, oft, banded, chunk = cfg
     if (mode == "lane" and Ntot > 8) or (mode == "nolane" and Ntot > 16):
         pytest.skip("lane kernels only exist for Ntot <= 8, row-lane kernels for Ntot <= 16")
-    if mode in ("quad8", "quad12") and (banded != "t4" or Ntot <= 16):
-        pytest.skip("quad8 / quad12: the JQ_BW_T4 problems on the quad-layout kernels with two / three slabs per workgroup (JQ_QUAD8)")
+    if mode in ("quad4", "quad8", "quad12") and (banded != "t4" or Ntot <= 16):
+        pytest.skip("quad4 / quad8 / quad12: the JQ_BW_T4 problems (auto: cooperative-quad kernels) on the quad-layout kernels with "
+                    "one (JQ_CQ=0) / two / three (JQ_QUAD8) slabs per workgroup")
     if mode == "coop" and (banded != "t4" or Ntot <= 16):
         pytest.skip("coop: the JQ_BW_T4 problems (auto: quad-layout kernels) once more on the cooperative kernels (JQ_QUAD=0)")
     if mode == "slab-od" and banded != "t4":
@@ -161,6 +162,8 @@ def test_random_problem_matches_oracle(jq, cfg, mode):
         os.environ["JQ_QUAD"] = "0"
     if mode == "slab-od":
         os.environ["JQ_T4"] = "0"
+    if mode == "quad4":
+        os.environ["JQ_CQ"] = "0"
     if mode == "nolane":
         os.environ["JQ_LANE"] = "0"
     if mode == "lane":
@@ -174,6 +177,7 @@ def test_random_problem_matches_oracle(jq, cfg, mode):
         os.environ.pop("JQ_ROWLANE_MAX", None)
         os.environ.pop("JQ_T4", None)
         os.environ.pop("JQ_QUAD", None)
+        os.environ.pop("JQ_CQ", None)
     r = Oracle(p, use_sparse=False).traceobjgrad(pcof, history=True)
     objfv, tg, prim, sec, tinf, ig, lg = jq.traceobjgrad(pcof, p, wa, False, True)
     gn = np.linalg.norm(r["totalgrad"])
@@ -186,10 +190,10 @@ def test_random_problem_matches_oracle(jq, cfg, mode):
     if banded == "t4" and mode in ("slab", "slab-od"):      # the kernel variant under test really ran
         t = wa.last_timing()
         assert t["kernel_family"] == 0 and (t["kernel_band"] == 8) == (mode == "slab")
-    if mode in ("quad8", "quad12"):
+    if mode in ("quad4", "quad8", "quad12"):
         assert wa.last_timing()["kernel_family"] == 6
-    if banded == "t4" and Ntot > 16 and mode in ("auto", "coop"):
-        assert wa.last_timing()["kernel_family"] == (6 if mode == "auto" else 1)
+    if banded == "t4" and Ntot > 16 and mode in ("auto", "coop"):      # auto: the cooperative-quad (latency) kernels
+        assert wa.last_timing()["kernel_family"] == (8 if mode == "auto" else 1)
     # per-step states
     _, hist, _ = jq.traceobjgrad(pcof, p, wa, True, False)
     assert np.max(np.abs(hist - r["history"])) < 1e-10
