@@ -8,29 +8,57 @@
 // plus the exchange of x with the two neighbouring waves through a double-buffered LDS image (one ds_write, one workgroup
 // barrier, two ds_reads that fly while the wave's own block is multiplied).  Because the barrier is what a product costs
 // here, the step is regrouped so that every published x serves all the products that need it (K05 u and S0 u; S05 v05,
-// K0 v05 and K1 v05; the five products with X, ...): 17 publications per forward step (20 products), 36 per backward
-// step (52 products) at m = 6 Neumann terms.  Same operators, images, window staging (Ring, batch < 0), state file,
+// K0 v05 and K1 v05; the five products with X, ...), and the backward sweep runs its two chains -- state re-integration and
+// adjoint step -- side by side with ONE barrier per pair of publications: 17 barriers per forward step (20 products), 18
+// per backward step (52 products) at m = 6 Neumann terms.  Same operators, images, window staging (Ring, batch < 0), state file,
 // trace records and reductions as the quad-layout kernels; the regrouping only reorders floating-point additions.
 #pragma once
 #include "jq_kernels.h"
 
+// Exchange image in LDS: [2 parities][2 channels][NT + 2 blocks][64] doubles -- a zero block in front of and behind the NT
+// blocks of a channel, so that the neighbours of the edge blocks need no clamping and every access is ONE base register
+// (this wave's block of channel 0 in the current parity) plus a compile-time offset.
+typedef __attribute__((address_space(3))) double jq_lds_double;
 template <int NT>
 struct CoopQ {
+    static constexpr int CHS = (NT + 2) * 64;       // doubles per channel
+    static constexpr int PAR = 2 * CHS;              // doubles per parity
     Ring ring;
-    double* xbuf;       // LDS [2][NT][64]
-    int cur;            // buffer that holds the published x
+    jq_lds_double* xp;  // my block of channel 0 in the parity that holds the published vectors
+    int delta;          // doubles from that parity to the other one (+-PAR)
     int mt;             // my block
     int lane;
-    double xown;        // my block of the published x
+    double xown;        // my block of the published x (channel 0)
+    double xown1;       // ... of channel 1 (publish2: the backward sweep publishes one vector of each of its two chains per barrier)
 
-    __device__ __forceinline__ void publish(double x)
+    __device__ __forceinline__ void setup(double* xbuf, int wave, int lane_)
     {
-        xbuf[((cur ^ 1) * NT + mt) * 64 + lane] = x;
-        xown = x;
+        mt = wave, lane = lane_, xown = 0.0, xown1 = 0.0;
+        for (int i = threadIdx.x; i < 2 * PAR; i += blockDim.x) xbuf[i] = 0.0;      // (the pads stay zero)
+        xp = (jq_lds_double*)(xbuf + (1 + wave) * 64 + lane_);
+        delta = PAR;
+    }
+    __device__ __forceinline__ void flip()
+    {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        cur ^= 1;
+        xp += delta;
+        delta = -delta;
+    }
+    __device__ __forceinline__ void publish(double x)
+    {
+        xp[delta] = x;
+        xown = x;
+        flip();
+    }
+    __device__ __forceinline__ void publish2(double x0, double x1)
+    {
+        xp[delta] = x0;
+        xp[delta + CHS] = x1;
+        xown = x0;
+        xown1 = x1;
+        flip();
     }
     // my block of an operator image (LDS, lane offset applied): A operand of the MFMA + the four coupling coefficients of my row.
     // Loaded BEFORE the publication whose products use it: behind the barrier only the neighbours' x is still in flight.
@@ -45,35 +73,37 @@ struct CoopQ {
         o.c = t4q_cload(t4q_c<NT>(M, lane), mt);
         return o;
     }
-    template <bool ZEROC>
+    template <bool ZEROC, int CH = 0>
     __device__ __forceinline__ double mm(double C, const Op& o) const
     {
-        const double xb = xbuf[(cur * NT + (mt > 0 ? mt - 1 : 0)) * 64 + lane];
-        const double xa = xbuf[(cur * NT + (mt + 1 < NT ? mt + 1 : mt)) * 64 + lane];
+        const double xo = CH ? xown1 : xown;
+        const double xb = xp[CH * CHS - 64];
+        const double xa = xp[CH * CHS + 64];
         double acc = ZEROC ? 0.0 : C;
-        acc = __builtin_amdgcn_mfma_f64_4x4x4f64(o.a, xown, acc, 0, 0, 0);
-        acc = fma(o.c[0], row_shift4<0x114>(xown), acc);
-        acc = fma(o.c[1], row_shift4<0x104>(xown), acc);
+        acc = __builtin_amdgcn_mfma_f64_4x4x4f64(o.a, xo, acc, 0, 0, 0);
+        acc = fma(o.c[0], row_shift4<0x114>(xo), acc);
+        acc = fma(o.c[1], row_shift4<0x104>(xo), acc);
         acc = fma(o.c[2], xb, acc);      // (the coefficients of a missing neighbour are zero)
         return fma(o.c[3], xa, acc);
     }
     // C + M x  for the published x (M: LDS image with the lane offset applied; MODE: JQ_T4_* parts that are non-zero)
-    template <bool ZEROC, int MODE = JQ_T4_DIAG | JQ_T4_RTERMS | JQ_T4_MTERMS>
+    template <bool ZEROC, int MODE = JQ_T4_DIAG | JQ_T4_RTERMS | JQ_T4_MTERMS, int CH = 0>
     __device__ __forceinline__ double mm(double C, const double* M) const
     {
         constexpr bool diag = MODE & JQ_T4_DIAG, rt = MODE & JQ_T4_RTERMS, mtm = MODE & JQ_T4_MTERMS;
+        const double xo = CH ? xown1 : xown;
         double xb = 0.0, xa = 0.0;
         if constexpr (mtm) {      // neighbour blocks first: their LDS latency hides behind this block's own work
-            xb = xbuf[(cur * NT + (mt > 0 ? mt - 1 : 0)) * 64 + lane];
-            xa = xbuf[(cur * NT + (mt + 1 < NT ? mt + 1 : mt)) * 64 + lane];
+            xb = xp[CH * CHS - 64];
+            xa = xp[CH * CHS + 64];
         }
         double acc = ZEROC ? 0.0 : C;
         d4 c = {0.0, 0.0, 0.0, 0.0};
         if constexpr (rt || mtm) c = t4q_cload(t4q_c<NT>(M, lane), mt);
-        if constexpr (diag) acc = __builtin_amdgcn_mfma_f64_4x4x4f64(M[mt * 64], xown, acc, 0, 0, 0);
+        if constexpr (diag) acc = __builtin_amdgcn_mfma_f64_4x4x4f64(M[mt * 64], xo, acc, 0, 0, 0);
         if constexpr (rt) {
-            acc = fma(c[0], row_shift4<0x114>(xown), acc);
-            acc = fma(c[1], row_shift4<0x104>(xown), acc);
+            acc = fma(c[0], row_shift4<0x114>(xo), acc);
+            acc = fma(c[1], row_shift4<0x104>(xo), acc);
         }
         if constexpr (mtm) {      // (the coefficients of a missing neighbour are zero)
             acc = fma(c[2], xb, acc);
@@ -82,14 +112,33 @@ struct CoopQ {
         return acc;
     }
     // trace operators touch one part of the image only (a.bw_trace: JQ_T4_* bits); anything else takes the full product
+    template <int CH = 0>
     __device__ __forceinline__ double mm_z_mode(const double* M, int mode) const
     {
         switch (mode) {
-        case JQ_T4_DIAG: return mm<true, JQ_T4_DIAG>(0.0, M);
-        case JQ_T4_RTERMS: return mm<true, JQ_T4_RTERMS>(0.0, M);
-        case JQ_T4_MTERMS: return mm<true, JQ_T4_MTERMS>(0.0, M);
-        default: return mm<true>(0.0, M);
+        case JQ_T4_DIAG: return mm<true, JQ_T4_DIAG, CH>(0.0, M);
+        case JQ_T4_RTERMS: return mm<true, JQ_T4_RTERMS, CH>(0.0, M);
+        case JQ_T4_MTERMS: return mm<true, JQ_T4_MTERMS, CH>(0.0, M);
+        default: return mm<true, JQ_T4_DIAG | JQ_T4_RTERMS | JQ_T4_MTERMS, CH>(0.0, M);
         }
+    }
+    // two Horner chains side by side (channel 0: base0 + sum_j S0^j A0, channel 1 likewise): ONE barrier per pair of products
+    __device__ __forceinline__ void horner2(double base0, double A0, const Op& S0, double base1, double A1, const Op& S1, int m, double& out0,
+                                            double& out1)
+    {
+        if (m <= 0) {
+            out0 = base0, out1 = base1;
+            return;
+        }
+        double Y0 = A0, Y1 = A1;
+        for (int j = 1; j < m; ++j) {
+            publish2(Y0, Y1);
+            Y0 = mm<false, 0>(A0, S0);
+            Y1 = mm<false, 1>(A1, S1);
+        }
+        publish2(Y0, Y1);
+        out0 = mm<false, 0>(base0, S0);
+        out1 = mm<false, 1>(base1, S1);
     }
     // base + sum_{j=1..m} S^j A  (Horner form, jq_kernels.h): m publications
     __device__ __forceinline__ double horner(double base, double A, const Op& S, int m)
@@ -211,9 +260,8 @@ __global__ __launch_bounds__(64 * NT) void k_forward_cq(PropArgs a)
     double* tab = (double*)(smem + a.lds_tab_off);
     for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[(i & ~15) + 4 * (i & 3) + ((i >> 2) & 3)] = a.tabs[i];   // [block][g][r]
     CoopQ<NT> c;
-    c.xbuf = tab + 32 * NT;
-    double* scratch = c.xbuf + 2 * NT * 64;
-    c.cur = 0, c.mt = wave, c.lane = lane_, c.xown = 0.0;
+    double* scratch = tab + 32 * NT + 2 * CoopQ<NT>::PAR;
+    c.setup(tab + 32 * NT, wave, lane_);
     c.ring.init(smem, a, wave, lane_, NT);      // (window mode: barrier inside)
     const double wdr = tab[16 * wave + s.g], wsr = tab[16 * NT + 16 * wave + s.g];
 
@@ -273,13 +321,12 @@ __global__ __launch_bounds__(64 * NT) void k_backward_cq(PropArgs a)
     double* tab = (double*)(smem + a.lds_tab_off);
     for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[(i & ~15) + 4 * (i & 3) + ((i >> 2) & 3)] = a.tabs[i];   // [block][g][r]
     CoopQ<NT> c;
-    c.xbuf = tab + 32 * NT;
-    double* scratch = c.xbuf + 2 * NT * 64;
+    double* scratch = tab + 32 * NT + 2 * CoopQ<NT>::PAR;
     // per-step trace records rec[n & 1][wave][8 Nc] (see k_backward)
     const int ntr = Nc * JQ_NTR, rslots = 8 * Nc;
     double* rec = scratch + NT * 64;
     for (int i = threadIdx.x; i < 2 * NT * rslots; i += blockDim.x) rec[i] = 0.0;
-    c.cur = 0, c.mt = wave, c.lane = lane_, c.xown = 0.0;
+    c.setup(tab + 32 * NT, wave, lane_);
     c.ring.init(smem, a, wave, lane_, NT);
     const double wdr = tab[16 * wave + s.g], wsr = tab[16 * NT + 16 * wave + s.g];
 
@@ -314,75 +361,98 @@ __global__ __launch_bounds__(64 * NT) void k_backward_cq(PropArgs a)
             if (q < Nc) carry[q] = -(u * c.mm_z_mode(c.ring.next_c(q), a.bw_trace[q]));
     }
 
+    // One backward step = the state re-integration (chain 0, channel 0) and the adjoint step (chain 1, channel 1) side by side:
+    // the adjoint products depend on the state step of the SAME step only through dot products and forcing terms
+    // (un in tr3, tr4 and hr1; v05 in hi0), which are applied once those vectors exist -- so the two chains publish one vector
+    // each per barrier: 6 + 2 m = 18 barriers per step (m = 6) instead of 17 + 19.
     for (int n = 0; n < a.nsteps_chunk; ++n) {
         c.ring.begin_step(n);
         if (n > 0) flush_traces(n - 1);      // (every wave has passed the barrier of begin_step since it finished step n-1)
-        double un, v05, vN;
         const CqOps<NT> o = cq_load_ops<NT>(c);
-        cq_state<NT>(c, a, o, cw, u, v, un, v05, vN);
-        // x = un: finish the state step
-        c.publish(un);
-        vN = c.template mm<false>(vN, o.Kp05);
-        if (a.use_shift) vN = fma(cw, un, vN);
-        // x = nb (-lambda_i): L = c K05 nb ; T = c S05 nb (for the second half of the adjoint step)
-        c.publish(nb);
-        double L = c.template mm<true>(0.0, o.Kp05);
-        if (a.use_shift) L = fma(cw, nb, L);
-        const double Tn = c.template mm<true>(0.0, o.S05);
-        // x = mu: L = c (S0 mu - K05 li + hr0) ; X = mu + sum_j S^j L
-        c.publish(mu);
-        L = c.template mm<false>(L, o.S0);
-        L = fma(cfw, u, L);      // u holds vr before the state step (:862)
-        const double X = c.horner(mu + L, L, o.S0, a.m);
-        // x = X: early traces tr1 = tr(vr0' Hanti_q X), tr3 = tr(vr' Hanti_q X); Lk = -c K0 X ; Q = -c K1 X ; SX = c S1 X ;
-        //        HsX_q = Hsym_q X (for tr2 below)
-        c.publish(X);
-        double HsX[JQ_MAXNC];
-#pragma unroll
-        for (int q = 0; q < JQ_MAXNC; ++q) {
-            HsX[q] = 0.0;
-            if (q < Nc) {
-                const double Tq = c.mm_z_mode(c.ring.next_c(Nc + q), a.bw_trace[q]);
-                const double ts = wave_sum4(u * Tq * wgt, un * Tq * wgt, 0.0, 0.0);      // rows 0, 2: t1, t3
-                if ((lane_ & 15) == 0) rec[((size_t)(n & 1) * NT + wave) * rslots + 4 * q + (lane_ >> 4)] = ts;
-                HsX[q] = c.mm_z_mode(c.ring.next_c(q), a.bw_trace[q]);
-            }
-        }
-        double Lk = c.template mm<true>(0.0, o.Kn0);
-        double Q = c.template mm<true>(0.0, o.Kn1);
-        const double SX = c.template mm<true>(0.0, o.S1);
+        // (u | nb): A = c K05 u, P = u + c S0 u  |  L = c K05 nb, Tn = c S05 nb
+        c.publish2(u, nb);
+        double A = c.template mm<true, 0>(0.0, o.Kp05);
+        const double P = c.template mm<false, 0>(u, o.S0);
+        double L = c.template mm<true, 1>(0.0, o.Kp05);
+        const double Tn = c.template mm<true, 1>(0.0, o.S05);
         if (a.use_shift) {
+            A = fma(cw, u, A);
+            L = fma(cw, nb, L);
+        }
+        // (v | mu): A = c (K05 u + S05 v)  |  L = c (S0 mu - K05 li + hr0)
+        c.publish2(v, mu);
+        A = c.template mm<false, 0>(A, o.S05);
+        L = c.template mm<false, 1>(L, o.S0);
+        L = fma(cfw, u, L);      // u holds vr before the state step (:862)
+        // Neumann series: v05 = v + sum_j S05^j A  |  X = mu + sum_j S0^j L
+        double v05, X;
+        c.horner2(v + A, A, o.S05, mu + L, L, o.S0, a.m, v05, X);
+        // (v05 | X): vN = v05 + c S05 v05, un = u + c (S0 u - K0 v05), A = -c K1 v05  |  Hanti_q X (tr1, tr3), Hsym_q X (tr2),
+        //            Lk = -c K0 X, Q = -c K1 X, SX = c S1 X
+        c.publish2(v05, X);
+        double vN = c.template mm<false, 0>(v05, o.S05);
+        double un = c.template mm<false, 0>(P, o.Kn0);
+        A = c.template mm<true, 0>(0.0, o.Kn1);
+        double Lk = c.template mm<true, 1>(0.0, o.Kn0);
+        double Q = c.template mm<true, 1>(0.0, o.Kn1);
+        const double SX = c.template mm<true, 1>(0.0, o.S1);
+        if (a.use_shift) {
+            un = fma(-cw, v05, un);
+            A = fma(-cw, v05, A);
             Lk = fma(-cw, X, Lk);
             Q = fma(-cw, X, Q);
         }
-        // Lk = -c l2 = -c (K0 X + S05 li + hi0) ; Q = -c (S05 (li + c l2) + K1 X + hi1) ; nb_new = nb + Lk + sum_j S^j Q
+        double Tq[JQ_MAXNC], t2[JQ_MAXNC];
+#pragma unroll
+        for (int q = 0; q < JQ_MAXNC; ++q) {
+            Tq[q] = t2[q] = 0.0;
+            if (q < Nc) {
+                Tq[q] = c.template mm_z_mode<1>(c.ring.next_c(Nc + q), a.bw_trace[q]);
+                t2[q] = v05 * c.template mm_z_mode<1>(c.ring.next_c(q), a.bw_trace[q]);
+            }
+        }
+        // Lk = -c l2 = -c (K0 X + S05 li + hi0) ; Q = -c (S05 (li + c l2) + K1 X + hi1)
         {
             const double Pn = fma(-cfw, v05, Tn);
             Lk += Pn;
             Q += Pn;
         }
-        c.publish(Lk);
-        Q = c.template mm<false>(Q, o.S05);
-        const double nbn = c.horner((nb + Lk) + Q, Q, o.S05, a.m);
+        // (un | Lk): A = c (S1 un - K1 v05)  |  Q += c S05 Lk
+        c.publish2(un, Lk);
+        A = c.template mm<false, 0>(A, o.S1);
+        Q = c.template mm<false, 1>(Q, o.S05);
+        // Neumann series: un += sum_j S1^j A  |  nb_new = nb + Lk + sum_j S05^j Q
+        double nbn;
+        c.horner2(un + A, A, o.S1, (nb + Lk) + Q, Q, o.S05, a.m, un, nbn);
         const double Bq = nb + nbn;      // -(li0 + li)
-        // x = nb_new: lambda_r_new = X + c (S1 X - K05 li_new + hr1) ; late trace tr4 = tr(vr' Hsym li) + carry
-        c.publish(nbn);
-        double G = c.template mm<false>(X, o.Kp05);
-        if (a.use_shift) G = fma(cw, nbn, G);
+        // early traces now that vr(t_n) exists: tr1 = tr(vr0' Hanti_q X), tr3 = tr(vr' Hanti_q X)
+#pragma unroll
+        for (int q = 0; q < JQ_MAXNC; ++q)
+            if (q < Nc) {
+                const double ts = wave_sum4(u * Tq[q] * wgt, un * Tq[q] * wgt, 0.0, 0.0);      // rows 0, 2: t1, t3
+                if ((lane_ & 15) == 0) rec[((size_t)(n & 1) * NT + wave) * rslots + 4 * q + (lane_ >> 4)] = ts;
+            }
+        // (un | nb_new): vN = v05 + c (K05 un + S05 v05)  |  lambda_r_new = X + c (S1 X - K05 li_new + hr1), Hsym_q li_new (tr4)
+        c.publish2(un, nbn);
+        vN = c.template mm<false, 0>(vN, o.Kp05);
+        double G = c.template mm<false, 1>(X, o.Kp05);
+        if (a.use_shift) {
+            vN = fma(cw, un, vN);
+            G = fma(cw, nbn, G);
+        }
         G = (G + SX) + cfw * un;
         double p4[JQ_MAXNC];
 #pragma unroll
-        for (int q = 0; q < JQ_MAXNC; ++q) p4[q] = (q < Nc) ? -(un * c.mm_z_mode(c.ring.next_c(q), a.bw_trace[q])) : 0.0;
-        // x = -(li0 + li): late trace tr5 = tr(vi05' Hanti (li0+li)) ; tr2 = tr(vi05' Hsym X)
+        for (int q = 0; q < JQ_MAXNC; ++q) p4[q] = (q < Nc) ? -(un * c.template mm_z_mode<1>(c.ring.next_c(q), a.bw_trace[q])) : 0.0;
+        // (-(li0 + li)): tr5 = tr(vi05' Hanti (li0+li))
         c.publish(Bq);
 #pragma unroll
         for (int q = 0; q < JQ_MAXNC; ++q)
             if (q < Nc) {
-                const double t5 = -(v05 * c.mm_z_mode(c.ring.next_c(Nc + q), a.bw_trace[q]));
-                const double t2 = v05 * HsX[q];
+                const double t5 = -(v05 * c.template mm_z_mode<0>(c.ring.next_c(Nc + q), a.bw_trace[q]));
                 const double t4 = p4[q] + carry[q];
                 carry[q] = p4[q];
-                const double ts = wave_sum4(t2 * wgt, t4 * wgt, t5 * wgt, 0.0);      // rows 0, 2, 1: t2, t4, t5
+                const double ts = wave_sum4(t2[q] * wgt, t4 * wgt, t5 * wgt, 0.0);      // rows 0, 2, 1: t2, t4, t5
                 if ((lane_ & 15) == 0) rec[((size_t)(n & 1) * NT + wave) * rslots + 4 * (Nc + q) + (lane_ >> 4)] = ts;
             }
         u = un;
