@@ -24,22 +24,29 @@
 // blocks of a channel, so that the neighbours of the edge blocks need no clamping and every access is ONE base register
 // (this wave's block of ITS channel in the current parity) plus a compile-time offset.  Channel 0: forward sweep / state
 // chain of the backward sweep; channel 1: adjoint chain.
-// Window staging (jq_kernels.h, Ring with batch < 0) without the code of the other staging modes: a ring of JQ_WIN_TPS time points
-// (K and S image each) and the constant trace images are resident in LDS; step n works on the time points 2n, 2n+1, 2n+2 while
-// 2n+3 and 2n+4 stream in (global -> LDS DMA, the pieces of an image pair spread over the waves); ONE barrier per time step.
-// These kernels run one wave per SIMD or little more: every instruction of the loop -- scalar ones and taken branches
-// included -- is on the critical path, so the cursor is incremental (no multiplications, no modulo, no mode branches).
+// Window staging (jq_kernels.h, Ring with batch < 0) re-timed for these kernels: a ring of JQ_WIN_TPS = 5 time points (K and S
+// image each) and the constant trace images are resident in LDS, the time points stream in by global -> LDS DMA (the 1 KiB
+// pieces of an image pair spread over the waves).  A wave keeps the six operator blocks of its time step in REGISTERS:
+// K0, S0 of step n are K1, S1 of step n-1 (same time point), so a step reads only the time points 2n+1, 2n+2 -- and it reads
+// them during the last publication interval of step n-1.  That removes the staging barrier of the slab kernels altogether:
+//   * behind the FIRST publication barrier of step n every wave has loaded the operators of step n, i.e. all time points
+//     <= 2n+2 are dead: the DMA of the time points 2n+5, 2n+6 (operators of step n+2) is issued there, into their slots;
+//   * in front of the barrier of the second-to-last publication every wave drains its DMA (vmcnt(0): issued almost a whole
+//     step earlier), so behind it the time points 2n+3, 2n+4 have landed for everybody and the operators of step n+1 are
+//     loaded while the last interval's arithmetic runs.
+// These kernels run one to three waves per SIMD on a latency-bound chain: every instruction of the loop -- scalar ones and
+// taken branches included -- is on the critical path, so the cursor is incremental (no multiplications, no modulo).
 struct WinRing {
     char* smem;
     const char* gnext;      // global address of the next time point to fetch
     unsigned stride_b;      // bytes per image
     unsigned slot_bytes;    // bytes per time point (K and S image)
-    unsigned cbase;         // byte offset of the constant images
+    unsigned cbase;         // byte offset of the constant images (= end of the ring)
     int pieces2;            // 1 KiB pieces of a time point
     int jnext, jlast;       // next time point to fetch, last one of the chunk
     unsigned snext;         // byte offset of its ring slot
     int wave, nwaves, lane;
-    unsigned wb0, wb1, wb2; // byte offsets of the time points 2n, 2n+1, 2n+2 of the current step
+    unsigned wb1, wb2;      // byte offsets of the time points 2n+1, 2n+2 of the step whose operators are loaded next
 
     __device__ __forceinline__ void dma(const char* gsrc, char* dst, int pieces) const
     {
@@ -57,8 +64,9 @@ struct WinRing {
         gnext += slot_bytes;
         ++jnext;
         snext += slot_bytes;
-        if (snext == JQ_WIN_TPS * slot_bytes) snext = 0;
+        if (snext == cbase) snext = 0;
     }
+    // time points 0 .. 4 and the constants; wb1, wb2 = time points 1, 2 (step 0); time point 0 is at offset 0
     __device__ __forceinline__ void init(char* smem_, const PropArgs& a, int wave_, int lane_, int nwaves_)
     {
         smem = smem_, wave = wave_, lane = lane_, nwaves = nwaves_;
@@ -73,40 +81,43 @@ struct WinRing {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        wb0 = 0, wb1 = slot_bytes, wb2 = 2 * slot_bytes;
+        wb1 = slot_bytes, wb2 = 2 * slot_bytes;
     }
-    __device__ __forceinline__ void begin_step(int n)
+    // the window of the next step (call once its operators are about to be loaded)
+    __device__ __forceinline__ void advance()
     {
-        if (n == 0) return;
-        // every wave has finished step n-1 behind this barrier: its time points 2n-2, 2n-1 make room for 2n+3, 2n+4; the images
-        // of this step (issued one step ago) have landed
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        issue_next();
-        issue_next();
-        wb0 = wb2;
-        wb1 = wb0 + slot_bytes;
+        wb1 = wb2 + slot_bytes;
         if (wb1 == cbase) wb1 = 0;
         wb2 = wb1 + slot_bytes;
         if (wb2 == cbase) wb2 = 0;
     }
-    // LDS image (lane offset applied) of K (KIND 0) / S (KIND 1) at time point 2n + TP, of constant image #idx
+    // LDS image (lane offset applied) of K (KIND 0) / S (KIND 1) at time point 2n + TP (TP = 1, 2), of constant image #idx
     template <int KIND, int TP>
-    __device__ __forceinline__ const double* next_ks() const
+    __device__ __forceinline__ const double* ks() const
     {
-        return (const double*)(smem + ((TP == 0 ? wb0 : TP == 1 ? wb1 : wb2) + KIND * stride_b)) + lane;
+        return (const double*)(smem + ((TP == 1 ? wb1 : wb2) + KIND * stride_b)) + lane;
     }
-    __device__ __forceinline__ const double* next_c(int idx) const { return (const double*)(smem + (cbase + (unsigned)idx * stride_b)) + lane; }
-    __device__ __forceinline__ void drain()
-    {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    }
+    __device__ __forceinline__ const double* cimg(int idx) const { return (const double*)(smem + (cbase + (unsigned)idx * stride_b)) + lane; }
 };
 
+#ifdef JQ_CQ_TIMING     // experiment: cycle counter at the marks of one time step, printed by every wave at the end of the kernel
+#define JQ_TS_DECL unsigned long long jq_ts[28]; int jq_nts = 0; for (int i_ = 0; i_ < 28; ++i_) jq_ts[i_] = 0;
+#define JQ_TS(n) if ((n) == 500 && jq_nts < 28) jq_ts[jq_nts++] = __builtin_readcyclecounter();
+#define JQ_TS_PRINT(w) if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) { int d_[27]; for (int i_ = 0; i_ < 27; ++i_) d_[i_] = i_ + 1 < jq_nts ? (int)(jq_ts[i_ + 1] - jq_ts[i_]) : -1; printf("wave %2d: %5d %5d %5d %5d %5d %5d %5d %5d %5d %5d %5d %5d %5d %5d %5d %5d %5d %5d %5d %5d %5d %5d %5d %5d total %d\n", (w), d_[0], d_[1], d_[2], d_[3], d_[4], d_[5], d_[6], d_[7], d_[8], d_[9], d_[10], d_[11], d_[12], d_[13], d_[14], d_[15], d_[16], d_[17], d_[18], d_[19], d_[20], d_[21], d_[22], d_[23], (int)(jq_ts[jq_nts - 1] - jq_ts[0])); }
+#else
+#define JQ_TS_DECL
+#define JQ_TS(n)
+#define JQ_TS_PRINT(w)
+#endif
 typedef __attribute__((address_space(3))) double jq_lds_double;
+// Exchange image in LDS: [2 parities][2 channels][NT + 2 blocks][64] doubles -- a zero block in front of and behind the NT
+// blocks of a channel, so that the neighbours of the edge blocks need no clamping and every access is ONE base register
+// (this wave's block of ITS channel in the current parity) plus a compile-time offset.  Channel 0: forward sweep / state
+// chain of the backward sweep; channel 1: adjoint chain.
+//
+// A publication has two phases: post(x) writes the wave's block, sync() waits for everybody's; the part of the products that
+// needs only the wave's own block (MFMA, lane shifts, (i, i+-4) terms: own()) runs BETWEEN them, under the latency of the LDS
+// write and the barrier, the two (i, i+-16) terms that need the neighbours' blocks (nbr()) behind the barrier.
 template <int NT>
 struct CoopQ {
     static constexpr int CHS = (NT + 2) * 64;       // doubles per channel
@@ -116,37 +127,28 @@ struct CoopQ {
     int delta;          // doubles from that parity to the other one (+-PAR)
     int mt;             // my block
     int lane;
-    double xown;        // my block of the published x
 
     __device__ __forceinline__ void setup(double* xbuf, int blk, int lane_, int ch = 0)
     {
-        mt = blk, lane = lane_, xown = 0.0;
+        mt = blk, lane = lane_;
         for (int i = threadIdx.x; i < 2 * PAR; i += blockDim.x) xbuf[i] = 0.0;      // (the pads stay zero)
         xp = (jq_lds_double*)(xbuf + ch * CHS + (1 + blk) * 64 + lane_);
         delta = PAR;
     }
-    __device__ __forceinline__ void flip()
+    __device__ __forceinline__ void post(double x) { xp[delta] = x; }
+    template <bool DMA = false>
+    __device__ __forceinline__ void sync()
     {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (DMA)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         xp += delta;
         delta = -delta;
     }
-    __device__ __forceinline__ void publish(double x)
-    {
-        xp[delta] = x;
-        xown = x;
-        flip();
-    }
-    // my block of the vector that the OTHER chain published at the last barrier (OFF = +-CHS: where its channel is)
-    template <int OFF>
-    __device__ __forceinline__ double other() const
-    {
-        return xp[OFF];
-    }
-    // my block of an operator image (LDS, lane offset applied): A operand of the MFMA + the four coupling coefficients of my row.
-    // Loaded BEFORE the publication whose products use it: behind the barrier only the neighbours' x is still in flight.
+    // my block of an operator image (LDS, lane offset applied): A operand of the MFMA + the four coupling coefficients of my row
     struct Op {
         double a;
         d4 c;
@@ -158,57 +160,44 @@ struct CoopQ {
         o.c = t4q_cload(t4q_c<NT>(M, lane), mt);
         return o;
     }
-    template <bool ZEROC>
-    __device__ __forceinline__ double mm(double C, const Op& o) const
+    // my block of a vector with its two lane shifts (shared by all products with that vector)
+    struct Sh {
+        double x, dn, up;
+    };
+    __device__ __forceinline__ Sh sh(double x) const
     {
-        const double xb = xp[-64];
-        const double xa = xp[64];
-        double acc = ZEROC ? 0.0 : C;
-        acc = __builtin_amdgcn_mfma_f64_4x4x4f64(o.a, xown, acc, 0, 0, 0);
-        acc = fma(o.c[0], row_shift4<0x114>(xown), acc);
-        acc = fma(o.c[1], row_shift4<0x104>(xown), acc);
-        acc = fma(o.c[2], xb, acc);      // (the coefficients of a missing neighbour are zero)
-        return fma(o.c[3], xa, acc);
+        Sh s;
+        s.x = x, s.dn = row_shift4<0x114>(x), s.up = row_shift4<0x104>(x);
+        return s;
     }
-    // C + M x  for the published x (M: LDS image with the lane offset applied; MODE: JQ_T4_* parts that are non-zero)
-    template <bool ZEROC, int MODE = JQ_T4_DIAG | JQ_T4_RTERMS | JQ_T4_MTERMS>
-    __device__ __forceinline__ double mm(double C, const double* M) const
+    // C + (my block's own part of M x)
+    __device__ __forceinline__ double own(double C, const Op& o, const Sh& s) const
     {
-        constexpr bool diag = MODE & JQ_T4_DIAG, rt = MODE & JQ_T4_RTERMS, mtm = MODE & JQ_T4_MTERMS;
-        double xb = 0.0, xa = 0.0;
-        if constexpr (mtm) {      // neighbour blocks first: their LDS latency hides behind this block's own work
-            xb = xp[-64];
-            xa = xp[64];
-        }
-        double acc = ZEROC ? 0.0 : C;
-        d4 c = {0.0, 0.0, 0.0, 0.0};
-        if constexpr (rt || mtm) c = t4q_cload(t4q_c<NT>(M, lane), mt);
-        if constexpr (diag) acc = __builtin_amdgcn_mfma_f64_4x4x4f64(M[mt * 64], xown, acc, 0, 0, 0);
-        if constexpr (rt) {
-            acc = fma(c[0], row_shift4<0x114>(xown), acc);
-            acc = fma(c[1], row_shift4<0x104>(xown), acc);
-        }
-        if constexpr (mtm) {      // (the coefficients of a missing neighbour are zero)
-            acc = fma(c[2], xb, acc);
-            acc = fma(c[3], xa, acc);
-        }
-        return acc;
+        double acc = __builtin_amdgcn_mfma_f64_4x4x4f64(o.a, s.x, C, 0, 0, 0);
+        acc = fma(o.c[0], s.dn, acc);
+        return fma(o.c[1], s.up, acc);
     }
-    // trace operators touch one part of the image only (a.bw_trace: JQ_T4_* bits); anything else takes the full product
-    __device__ __forceinline__ double mm_z_mode(const double* M, int mode) const
+    // the neighbours' blocks of the published vector (OFF = 0: my channel, +-CHS: the other chain's)
+    struct Nb {
+        double b, a;
+    };
+    template <int OFF = 0>
+    __device__ __forceinline__ Nb nbs() const
     {
-#ifdef JQ_CQ_NOTRACE       // timing experiment only (wrong gradients): what the trace products cost
-        return xown;
-#endif
-#ifdef JQ_CQ_FULLTRACE     // branch-free: the absent parts of an image are stored as zeros
-        return mm<true>(0.0, M);
-#endif
-        switch (mode) {
-        case JQ_T4_DIAG: return mm<true, JQ_T4_DIAG>(0.0, M);
-        case JQ_T4_RTERMS: return mm<true, JQ_T4_RTERMS>(0.0, M);
-        case JQ_T4_MTERMS: return mm<true, JQ_T4_MTERMS>(0.0, M);
-        default: return mm<true>(0.0, M);
-        }
+        Nb n;
+        n.b = xp[OFF - 64], n.a = xp[OFF + 64];
+        return n;
+    }
+    __device__ __forceinline__ double nbr(double acc, const Op& o, const Nb& n) const
+    {
+        acc = fma(o.c[2], n.b, acc);      // (the coefficients of a missing neighbour are zero)
+        return fma(o.c[3], n.a, acc);
+    }
+    // my block of the vector that the OTHER chain published at the last barrier (OFF = +-CHS: where its channel is)
+    template <int OFF>
+    __device__ __forceinline__ double other() const
+    {
+        return xp[OFF];
     }
     // base + sum_{j=1..m} S^j A  (Horner form, jq_kernels.h): m publications
     __device__ __forceinline__ double horner(double base, double A, const Op& S, int m)
@@ -216,11 +205,15 @@ struct CoopQ {
         if (m <= 0) return base;
         double Y = A;
         for (int j = 1; j < m; ++j) {
-            publish(Y);
-            Y = mm<false>(A, S);
+            post(Y);
+            const double t = own(A, S, sh(Y));
+            sync();
+            Y = nbr(t, S, nbs());
         }
-        publish(Y);
-        return mm<false>(base, S);
+        post(Y);
+        const double t = own(base, S, sh(Y));
+        sync();
+        return nbr(t, S, nbs());
     }
 };
 
@@ -238,50 +231,101 @@ __device__ __forceinline__ double cq_wg_sum(double val, double* scratch, int wav
     return s;
 }
 
+// First three stages of wave_sum4 (jq_kernels.h): the 16 column partials of a, c, b, d end up in the rows 0, 1, 2, 3 of ONE
+// register (9 instructions for four values).  The cooperative-quad backward sweep leaves the rest of the reduction -- the sum
+// over the NT blocks and the four rotate-adds inside the rows -- to one wave per group of four values, one barrier later.
+__device__ __forceinline__ double cq_part4(double a, double b, double c, double d)
+{
+    row_swap32(a, b);
+    double p = a + b;
+    row_swap32(c, d);
+    double q = c + d;
+    row_swap16(p, q);
+    return p + q;
+}
+
 // the six operator blocks of a time step (this wave's share of K, S at the time points 2n, 2n+1, 2n+2 of the chunk)
 template <int NT>
 struct CqOps {
     typename CoopQ<NT>::Op Kp05, S05, Kn0, S0, Kn1, S1;
 };
+// step 0: time point 0 sits at the start of the ring
 template <int NT>
-__device__ __forceinline__ CqOps<NT> cq_load_ops(CoopQ<NT>& c)
+__device__ __forceinline__ CqOps<NT> cq_first_ops(const CoopQ<NT>& c)
 {
     CqOps<NT> o;
-    o.Kp05 = c.load(c.ring.template next_ks<0, 1>());
-    o.S05 = c.load(c.ring.template next_ks<1, 1>());
-    o.Kn0 = c.load(c.ring.template next_ks<0, 0>());
-    o.S0 = c.load(c.ring.template next_ks<1, 0>());
-    o.Kn1 = c.load(c.ring.template next_ks<0, 2>());
-    o.S1 = c.load(c.ring.template next_ks<1, 2>());
+    o.Kn0 = c.load((const double*)c.ring.smem + c.ring.lane);
+    o.S0 = c.load((const double*)(c.ring.smem + c.ring.stride_b) + c.ring.lane);
+    o.Kp05 = c.load(c.ring.template ks<0, 1>());
+    o.S05 = c.load(c.ring.template ks<1, 1>());
+    o.Kn1 = c.load(c.ring.template ks<0, 2>());
+    o.S1 = c.load(c.ring.template ks<1, 2>());
     return o;
 }
+// the next step: K0, S0 are this step's K1, S1; the time points 2n+3, 2n+4 have landed (see WinRing)
+template <int NT>
+__device__ __forceinline__ void cq_next_ops(CoopQ<NT>& c, CqOps<NT>& o)
+{
+    c.ring.advance();
+    o.Kn0 = o.Kn1;
+    o.S0 = o.S1;
+    o.Kp05 = c.load(c.ring.template ks<0, 1>());
+    o.S05 = c.load(c.ring.template ks<1, 1>());
+    o.Kn1 = c.load(c.ring.template ks<0, 2>());
+    o.S1 = c.load(c.ring.template ks<1, 2>());
+}
 
-// state step: in u, v; out un = u(t+h), v05, vN = v05 + S05 v05 (the caller adds Kp05 un)
+// state step up to its second-to-last publication: in u, v; out un = u(t+h), v05, vN = v05 + S05 v05 (the caller publishes un
+// once more and adds Kp05 un).  Issues the DMA of the step behind the first barrier.
 template <int NT>
 __device__ __forceinline__ void cq_state(CoopQ<NT>& c, const PropArgs& a, const CqOps<NT>& o, double cw, double u, double v, double& un,
                                          double& v05, double& vN)
 {
+    typedef typename CoopQ<NT>::Sh Sh;
+    typedef typename CoopQ<NT>::Nb Nb;
     // x = u: A = c K05 u ; P = u + c S0 u
-    c.publish(u);
-    double A = c.template mm<true>(0.0, o.Kp05);
-    const double P = c.template mm<false>(u, o.S0);
-    if (a.use_shift) A = fma(cw, u, A);
+    c.post(u);
+    double A, P;
+    {
+        const Sh s = c.sh(u);
+        A = c.own(0.0, o.Kp05, s);
+        P = c.own(u, o.S0, s);
+        if (a.use_shift) A = fma(cw, u, A);
+        c.sync();
+        c.ring.issue_next();
+        c.ring.issue_next();
+        const Nb n = c.nbs();
+        A = c.nbr(A, o.Kp05, n);
+        P = c.nbr(P, o.S0, n);
+    }
     // x = v: A = c (K05 u + S05 v) ; v05 = v + sum_j S^j A
-    c.publish(v);
-    A = c.template mm<false>(A, o.S05);
+    c.post(v);
+    A = c.own(A, o.S05, c.sh(v));
+    c.sync();
+    A = c.nbr(A, o.S05, c.nbs());
     v05 = c.horner(v + A, A, o.S05, a.m);
     // x = v05: vN = v05 + c S05 v05 ; un = u + c (S0 u - K0 v05) ; A = -c K1 v05
-    c.publish(v05);
-    vN = c.template mm<false>(v05, o.S05);
-    un = c.template mm<false>(P, o.Kn0);
-    A = c.template mm<true>(0.0, o.Kn1);
-    if (a.use_shift) {
-        un = fma(-cw, v05, un);
-        A = fma(-cw, v05, A);
+    c.post(v05);
+    {
+        const Sh s = c.sh(v05);
+        vN = c.own(v05, o.S05, s);
+        un = c.own(P, o.Kn0, s);
+        A = c.own(0.0, o.Kn1, s);
+        if (a.use_shift) {
+            un = fma(-cw, v05, un);
+            A = fma(-cw, v05, A);
+        }
+        c.sync();
+        const Nb n = c.nbs();
+        vN = c.nbr(vN, o.S05, n);
+        un = c.nbr(un, o.Kn0, n);
+        A = c.nbr(A, o.Kn1, n);
     }
     // x = un: A = c (S1 un - K1 v05) ; un += sum_j S^j A
-    c.publish(un);
-    A = c.template mm<false>(A, o.S1);
+    c.post(un);
+    A = c.own(A, o.S1, c.sh(un));
+    c.sync();
+    A = c.nbr(A, o.S1, c.nbs());
     un = c.horner(un + A, A, o.S1, a.m);
 }
 
@@ -319,7 +363,7 @@ __device__ __forceinline__ CqSetup<NT> cq_setup(const PropArgs& a)
 }
 
 // ---------------------------------------------------------------------------------------------
-// grid = 4 * nslabs (workgroup = quad qd of slab blockIdx.x / 4), block = 64 * NT
+// grid = 4 * nslabs (workgroup = quad qd of slab blockIdx.x / 4), block = 64 * NT; 5 + 2 m barriers per time step
 template <int NT>
 __global__ __launch_bounds__(64 * NT) void k_forward_cq(PropArgs a)
 {
@@ -333,7 +377,7 @@ __global__ __launch_bounds__(64 * NT) void k_forward_cq(PropArgs a)
     CoopQ<NT> c;
     double* scratch = tab + 32 * NT + 2 * CoopQ<NT>::PAR;
     c.setup(tab + 32 * NT, wave, lane_);
-    c.ring.init(smem, a, wave, lane_, NT);      // (window mode: barrier inside)
+    c.ring.init(smem, a, wave, lane_, NT);      // (barrier inside)
     const double wdr = tab[16 * wave + s.g], wsr = tab[16 * NT + 16 * wave + s.g];
 
     double* st = a.state + (size_t)s.slab * a.state_stride;
@@ -342,17 +386,19 @@ __global__ __launch_bounds__(64 * NT) void k_forward_cq(PropArgs a)
     const size_t cslot = 16 * (lane_ >> 4) + s.col;
     double leak = slot0 ? st[(size_t)(JQ_STATE_ARRAYS * KT + JQ_MAXNC) * 64 + cslot] : 0.0;
     const double cw = 0.5 * a.h * a.colinfo[(size_t)s.slab * 32 + s.col] * wsr;      // h/2 eps ws[row]
+    CqOps<NT> o = cq_first_ops<NT>(c);
 
     for (int n = 0; n < a.nsteps_chunk; ++n) {
-        c.ring.begin_step(n);
         leak = fma(wdr, u * u, leak);      // trapezoidal part at t_n (src/evalobjgrad.jl:700)
         double un, v05, vN;
-        const CqOps<NT> o = cq_load_ops<NT>(c);
         cq_state<NT>(c, a, o, cw, u, v, un, v05, vN);
         // Kp05 again: v(t+h) = v05 + c (K05 u_new + S05 v05)
-        c.publish(un);
-        v = c.template mm<false>(vN, o.Kp05);
+        c.post(un);
+        v = c.own(vN, o.Kp05, c.sh(un));
         if (a.use_shift) v = fma(cw, un, v);
+        c.template sync<true>();
+        v = c.nbr(v, o.Kp05, c.nbs());
+        cq_next_ops<NT>(c, o);
         u = un;
         leak += wdr * (u * u) + 2.0 * (wdr * (v05 * v05));      // (:716, penalf2a :2170-2180)
         if (a.hist_r) {
@@ -365,7 +411,7 @@ __global__ __launch_bounds__(64 * NT) void k_forward_cq(PropArgs a)
             }
         }
     }
-    c.ring.drain();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (nothing is in flight: every fetched time point was waited for)
     st[s.foff] = u;
     st[(size_t)KT * 64 + s.foff] = v;
     const double tot = cq_wg_sum(leak, scratch, wave, lane_, NT);
@@ -374,14 +420,23 @@ __global__ __launch_bounds__(64 * NT) void k_forward_cq(PropArgs a)
 
 // ---------------------------------------------------------------------------------------------
 // grid = 4 * nslabs, block = 128 * NT: waves 0 .. NT-1 re-integrate the state (channel 0), waves NT .. 2 NT-1 run the adjoint
-// step and the traces (channel 1).  Both sets pass the same barriers: begin_step, then 6 + 2 m publications per time step
+// step (channel 1); the trace products of adjoint_grad_calc! are shared between them (the state waves take the two traces
+// with vi05).  Both sets pass the same 6 + 2 m barriers per time step:
 //   (u | nb)  (v | mu)  m x Neumann  (v05 | X)  (un' | Lk)  m x Neumann  (un | nb_new)  (- | -(li0 + li))
+// Trace scalars: a wave reduces its per-lane values four at a time to 16 column partials per value (cq_part4) and leaves that
+// register in LDS, red[group][block][64]; behind the first barrier of the NEXT step wave g adds the NT blocks of group g,
+// finishes the four sums with rotate-adds inside the rows and writes them to the trace record of the step.
+//   group q < Nc (adjoint wave):  rows 0, 1, 2 = t1, t4, t3 of control q
+//   group Nc + j (state wave):    rows 0, 1 = t2, t5 of control 2 j, rows 2, 3 = t2, t5 of control 2 j + 1
 template <int NT>
 __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KT = 4 * NT;
     constexpr int CH = CoopQ<NT>::CHS;
+    typedef typename CoopQ<NT>::Sh Sh;
+    typedef typename CoopQ<NT>::Nb Nb;
+    typedef typename CoopQ<NT>::Op Op;
     const CqSetup<NT> s = cq_setup<NT>(a);
     const int Nc = a.Ncoupled;
     // trace records: row slab * qps + qd (qps: quads of a full slab); a quad without columns inside that range (last slab)
@@ -397,62 +452,164 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
     for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[(i & ~15) + 4 * (i & 3) + ((i >> 2) & 3)] = a.tabs[i];   // [block][g][r]
     CoopQ<NT> c;
     double* scratch = tab + 32 * NT + 2 * CoopQ<NT>::PAR;      // [2 NT][64]
-    // per-step trace records rec[n & 1][block][8 Nc] of the adjoint waves (see k_backward)
-    const int ntr = Nc * JQ_NTR, rslots = 8 * Nc;
-    double* rec = scratch + 2 * NT * 64;
-    for (int i = threadIdx.x; i < 2 * NT * rslots; i += blockDim.x) rec[i] = 0.0;
+    const int ntr = Nc * JQ_NTR, ngroups = Nc + (Nc + 1) / 2;
+    double* red = scratch + 2 * NT * 64;                        // [ngroups][NT][64]
     c.setup(tab + 32 * NT, wave, lane_, s.chain);
     c.ring.init(smem, a, wave_all, lane_, 2 * NT);
     const double wdr = tab[16 * wave + s.g], wsr = tab[16 * NT + 16 * wave + s.g];
     double* st = a.state + (size_t)s.slab * a.state_stride;
     const double cw = 0.5 * a.h * a.colinfo[(size_t)s.slab * 32 + s.col] * wsr;      // h/2 eps ws[row]
+    const double wgt = a.colinfo[(size_t)s.slab * 32 + 16 + s.col];
     const size_t cslot = 16 * (lane_ >> 4) + s.col;
     double carry[JQ_MAXNC];
 #pragma unroll
     for (int q = 0; q < JQ_MAXNC; ++q) carry[q] = 0.0;
-
-    if (s.chain == 0) {
-        // ---- state re-integration (src/evalobjgrad.jl:879), channel 0 ------------------------------------------------
-        double u = st[s.foff], v = st[(size_t)KT * 64 + s.foff];
-        if (a.first_chunk) c.publish(u);      // (vr(T) for the carry products of the adjoint waves)
-        for (int n = 0; n < a.nsteps_chunk; ++n) {
-            c.ring.begin_step(n);
-            // (every wave has passed the barrier of begin_step since it finished step n-1)
-            if (n > 0 && wave == 0 && lane_ < ntr) {
-                const int k = n - 1, q = lane_ / JQ_NTR, kk = lane_ - q * JQ_NTR;
-                const int slot = (kk == 0 ? 0 : kk == 2 ? 2 : 4 * Nc + (kk == 1 ? 0 : kk == 3 ? 2 : 1)) + 4 * q;
-                const double* r = rec + (size_t)(k & 1) * NT * rslots + slot;
-                double sum = r[0];
-#pragma unroll
-                for (int w = 1; w < NT; ++w) sum += r[w * rslots];
-                a.traces[(trow * a.nsteps_chunk + k) * ntr + lane_] = sum;
-            }
-            double un, v05, vN;
-            const CqOps<NT> o = cq_load_ops<NT>(c);
-            cq_state<NT>(c, a, o, cw, u, v, un, v05, vN);
-            // x = un: v(t_n) = v05 + c (K05 un + S05 v05)
-            c.publish(un);
-            v = c.template mm<false>(vN, o.Kp05);
-            if (a.use_shift) v = fma(cw, un, v);
-            u = un;
-            c.flip();      // (the adjoint waves' last publication of the step)
-        }
-        c.ring.drain();
-        if (wave == 0 && lane_ < ntr) {
-            const int k = a.nsteps_chunk - 1, q = lane_ / JQ_NTR, kk = lane_ - q * JQ_NTR;
-            const int slot = (kk == 0 ? 0 : kk == 2 ? 2 : 4 * Nc + (kk == 1 ? 0 : kk == 3 ? 2 : 1)) + 4 * q;
-            const double* r = rec + (size_t)(k & 1) * NT * rslots + slot;
+    // my blocks of the constant trace images (Hsym_q: image q, Hanti_q: image Nc + q) are loaded where they are used; the absent
+    // parts of a single-subsystem operator are stored as zeros, so the trace products are branch-free
+    CqOps<NT> o = cq_first_ops<NT>(c);
+    double* redw = red + (size_t)wave * 64 + lane_;      // my block's slot of group 0
+    // the trace scalars of step k (all waves; call behind a barrier that follows the step's last hand-off)
+    auto finish_traces = [&](int k) {
+        for (int g = wave_all; g < ngroups; g += 2 * NT) {
+            const double* r = red + (size_t)g * NT * 64 + lane_;
             double sum = r[0];
 #pragma unroll
-            for (int w = 1; w < NT; ++w) sum += r[w * rslots];
-            a.traces[(trow * a.nsteps_chunk + k) * ntr + lane_] = sum;
+            for (int w = 1; w < NT; ++w) sum += r[w * 64];
+            sum = row_ror_add<8>(sum);
+            sum = row_ror_add<4>(sum);
+            sum = row_ror_add<2>(sum);
+            sum = row_ror_add<1>(sum);
+            const int row = lane_ >> 4;
+            int q, kk;
+            if (g < Nc)
+                q = g, kk = row == 0 ? 0 : row == 1 ? 3 : row == 2 ? 2 : -1;
+            else
+                q = 2 * (g - Nc) + (row >> 1), kk = (row & 1) ? 4 : 1;
+            if ((lane_ & 15) == 0 && kk >= 0 && q < Nc) a.traces[(trow * a.nsteps_chunk + k) * ntr + q * JQ_NTR + kk] = sum;
         }
+    };
+
+    if (s.chain == 0) {
+        // ---- state re-integration (src/evalobjgrad.jl:879), channel 0; traces t2 = tr(vi05' Hsym_q X), t5 = tr(vi05' Hanti_q (li0+li))
+        double u = st[s.foff], v = st[(size_t)KT * 64 + s.foff];
+        if (a.first_chunk) {      // (vr(T) for the carry products of the adjoint waves)
+            c.post(u);
+            c.sync();
+        }
+        JQ_TS_DECL
+        for (int n = 0; n < a.nsteps_chunk; ++n) {
+            JQ_TS(n)
+            double un, v05, vN, t2[JQ_MAXNC];
+            // x = u: A = c K05 u ; P = u + c S0 u
+            c.post(u);
+            double A, P;
+            {
+                const Sh sx = c.sh(u);
+                A = c.own(0.0, o.Kp05, sx);
+                P = c.own(u, o.S0, sx);
+                if (a.use_shift) A = fma(cw, u, A);
+                JQ_TS(n)
+                c.sync();
+                JQ_TS(n)
+                c.ring.issue_next();
+                c.ring.issue_next();
+                const Nb nn = c.nbs();
+                A = c.nbr(A, o.Kp05, nn);
+                P = c.nbr(P, o.S0, nn);
+            }
+            if (n > 0) finish_traces(n - 1);
+            // x = v: A = c (K05 u + S05 v) ; v05 = v + sum_j S^j A
+            c.post(v);
+            A = c.own(A, o.S05, c.sh(v));
+            JQ_TS(n)
+            c.sync();
+            JQ_TS(n)
+            A = c.nbr(A, o.S05, c.nbs());
+            v05 = c.horner(v + A, A, o.S05, a.m);
+            JQ_TS(n)
+            // x = v05: vN = v05 + c S05 v05 ; un = u + c (S0 u - K0 v05) ; A = -c K1 v05
+            c.post(v05);
+            {
+                const Sh sx = c.sh(v05);
+                vN = c.own(v05, o.S05, sx);
+                un = c.own(P, o.Kn0, sx);
+                A = c.own(0.0, o.Kn1, sx);
+                if (a.use_shift) {
+                    un = fma(-cw, v05, un);
+                    A = fma(-cw, v05, A);
+                }
+                JQ_TS(n)
+                c.sync();
+                JQ_TS(n)
+                const Nb nn = c.nbs();
+                vN = c.nbr(vN, o.S05, nn);
+                un = c.nbr(un, o.Kn0, nn);
+                A = c.nbr(A, o.Kn1, nn);
+            }
+            const double v05w = v05 * wgt;
+            // x = un: A = c (S1 un - K1 v05)
+            c.post(un);
+            A = c.own(A, o.S1, c.sh(un));
+            // (under the barrier: the adjoint chain's X of the last publication)
+            {
+                const Sh sx = c.sh(c.template other<CH>());
+                const Nb nx = c.template nbs<CH>();
+#pragma unroll
+                for (int q = 0; q < JQ_MAXNC; ++q) {
+                    t2[q] = 0.0;
+                    if (q < Nc) {
+                        const Op Hs = c.load(c.ring.cimg(q));
+                        t2[q] = v05w * c.nbr(c.own(0.0, Hs, sx), Hs, nx);
+                    }
+                }
+            }
+            JQ_TS(n)
+            c.sync();
+            JQ_TS(n)
+            A = c.nbr(A, o.S1, c.nbs());
+            un = c.horner(un + A, A, o.S1, a.m);
+            JQ_TS(n)
+            // x = un: v(t_n) = v05 + c (K05 un + S05 v05)
+            c.post(un);
+            v = c.own(vN, o.Kp05, c.sh(un));
+            if (a.use_shift) v = fma(cw, un, v);
+            JQ_TS(n)
+            c.template sync<true>();
+            JQ_TS(n)
+            v = c.nbr(v, o.Kp05, c.nbs());
+            cq_next_ops<NT>(c, o);
+            u = un;
+            // (- | -(li0 + li)): t5
+            JQ_TS(n)
+            c.sync();
+            JQ_TS(n)
+            {
+                const Sh sx = c.sh(c.template other<CH>());
+                const Nb nx = c.template nbs<CH>();
+                double t5[JQ_MAXNC];
+#pragma unroll
+                for (int q = 0; q < JQ_MAXNC; ++q) {
+                    t5[q] = 0.0;
+                    if (q < Nc) {
+                        const Op Ha = c.load(c.ring.cimg(Nc + q));
+                        t5[q] = -(v05w * c.nbr(c.own(0.0, Ha, sx), Ha, nx));
+                    }
+                }
+                redw[(size_t)Nc * NT * 64] = cq_part4(t2[0], t2[1], t5[0], t5[1]);
+                if (Nc > 2) redw[(size_t)(Nc + 1) * NT * 64] = cq_part4(t2[2], t2[3], t5[2], t5[3]);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();      // (the last hand-off)
+        asm volatile("" ::: "memory");
+        finish_traces(a.nsteps_chunk - 1);
         st[s.foff] = u;
         st[(size_t)KT * 64 + s.foff] = v;
+        JQ_TS_PRINT(wave_all)
     } else {
-        // ---- adjoint step! with forcing (src/StormerVerlet.jl:255-303) and the traces of adjoint_grad_calc!, channel 1 ----
+        // ---- adjoint step! with forcing (src/StormerVerlet.jl:255-303), channel 1; traces t1 = tr(vr0' Hanti_q X),
+        //      t3 = tr(vr' Hanti_q X), t4 = tr(vr' Hsym_q li) + tr(vr0' Hsym_q li0)
         double mu = st[(size_t)2 * KT * 64 + s.foff], nb = st[(size_t)3 * KT * 64 + s.foff];
-        const double wgt = a.colinfo[(size_t)s.slab * 32 + 16 + s.col];
         const double cfw = (a.forced ? 0.5 * a.h * a.tinv : 0.0) * wdr;      // forcing weight c tinv wd[row]; 0 for step_no_forcing!
         const bool slot0 = wave == 0 && ((lane_ >> 2) & 3) == 0;      // the lanes that carry per-column partials between chunks
 #pragma unroll
@@ -460,88 +617,137 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
             if (q < Nc && slot0) carry[q] = st[(size_t)(JQ_STATE_ARRAYS * KT + q) * 64 + cslot];
         if (a.first_chunk) {
             // carry_q = tr(vr' Hsym_q lambdai) at t = T (see k_backward)
-            c.publish(nb);
+            c.post(nb);
+            const Sh sx = c.sh(nb);
+            c.sync();
             const double u0 = c.template other<-CH>();
+            const Nb nn = c.nbs();
 #pragma unroll
             for (int q = 0; q < JQ_MAXNC; ++q)
-                if (q < Nc) carry[q] = -(u0 * c.mm_z_mode(c.ring.next_c(q), a.bw_trace[q]));
-        }
-        for (int n = 0; n < a.nsteps_chunk; ++n) {
-            c.ring.begin_step(n);
-            const CqOps<NT> o = cq_load_ops<NT>(c);
-            // x = nb (-lambda_i): L = c K05 nb, Tn = c S05 nb (for the second half of the step)
-            c.publish(nb);
-            const double u = c.template other<-CH>();      // vr before the state step (:862)
-            double L = c.template mm<true>(0.0, o.Kp05);
-            const double Tn = c.template mm<true>(0.0, o.S05);
-            if (a.use_shift) L = fma(cw, nb, L);
-            // x = mu: L = c (S0 mu - K05 li + hr0) ; X = mu + sum_j S0^j L
-            c.publish(mu);
-            L = c.template mm<false>(L, o.S0);
-            L = fma(cfw, u, L);
-            const double X = c.horner(mu + L, L, o.S0, a.m);
-            // x = X: Lk = -c K0 X, Q = -c K1 X, SX = c S1 X, Hanti_q X (tr1, tr3), Hsym_q X (tr2)
-            c.publish(X);
-            const double v05 = c.template other<-CH>();
-            double Lk = c.template mm<true>(0.0, o.Kn0);
-            double Q = c.template mm<true>(0.0, o.Kn1);
-            const double SX = c.template mm<true>(0.0, o.S1);
-            if (a.use_shift) {
-                Lk = fma(-cw, X, Lk);
-                Q = fma(-cw, X, Q);
-            }
-            double Tq[JQ_MAXNC], t2[JQ_MAXNC];
-#pragma unroll
-            for (int q = 0; q < JQ_MAXNC; ++q) {
-                Tq[q] = t2[q] = 0.0;
                 if (q < Nc) {
-                    Tq[q] = c.mm_z_mode(c.ring.next_c(Nc + q), a.bw_trace[q]);
-                    t2[q] = v05 * c.mm_z_mode(c.ring.next_c(q), a.bw_trace[q]);
+                    const Op Hs = c.load(c.ring.cimg(q));
+                    carry[q] = -(u0 * c.nbr(c.own(0.0, Hs, sx), Hs, nn));
+                }
+        }
+        JQ_TS_DECL
+        for (int n = 0; n < a.nsteps_chunk; ++n) {
+            JQ_TS(n)
+            // x = nb (-lambda_i): L = c K05 nb, Tn = c S05 nb (for the second half of the step)
+            c.post(nb);
+            double L, Tn;
+            {
+                const Sh sx = c.sh(nb);
+                L = c.own(0.0, o.Kp05, sx);
+                Tn = c.own(0.0, o.S05, sx);
+                if (a.use_shift) L = fma(cw, nb, L);
+                JQ_TS(n)
+                c.sync();
+                JQ_TS(n)
+                c.ring.issue_next();
+                c.ring.issue_next();
+                const Nb nn = c.nbs();
+                L = c.nbr(L, o.Kp05, nn);
+                Tn = c.nbr(Tn, o.S05, nn);
+            }
+            const double u = c.template other<-CH>();      // vr before the state step (:862)
+            if (n > 0) finish_traces(n - 1);
+            // x = mu: L = c (S0 mu - K05 li + hr0) ; X = mu + sum_j S0^j L
+            c.post(mu);
+            L = c.own(L, o.S0, c.sh(mu));
+            L = fma(cfw, u, L);
+            JQ_TS(n)
+            c.sync();
+            JQ_TS(n)
+            L = c.nbr(L, o.S0, c.nbs());
+            const double X = c.horner(mu + L, L, o.S0, a.m);
+            JQ_TS(n)
+            // x = X: Lk = -c K0 X, Q = -c K1 X, SX = c S1 X, Hanti_q X (tr1, tr3)
+            c.post(X);
+            double Lk, Q, SX, Tq[JQ_MAXNC];
+            {
+                const Sh sx = c.sh(X);
+                Lk = c.own(0.0, o.Kn0, sx);
+                Q = c.own(0.0, o.Kn1, sx);
+                SX = c.own(0.0, o.S1, sx);
+                if (a.use_shift) {
+                    Lk = fma(-cw, X, Lk);
+                    Q = fma(-cw, X, Q);
+                }
+                JQ_TS(n)
+                c.sync();
+                JQ_TS(n)
+                const Nb nn = c.nbs();
+                Lk = c.nbr(Lk, o.Kn0, nn);
+                Q = c.nbr(Q, o.Kn1, nn);
+                SX = c.nbr(SX, o.S1, nn);
+#pragma unroll
+                for (int q = 0; q < JQ_MAXNC; ++q) {
+                    Tq[q] = 0.0;
+                    if (q < Nc) {
+                        const Op Ha = c.load(c.ring.cimg(Nc + q));
+                        Tq[q] = c.nbr(c.own(0.0, Ha, sx), Ha, nn);
+                    }
                 }
             }
             // Lk = -c l2 = -c (K0 X + S05 li + hi0) ; Q = -c (S05 (li + c l2) + K1 X + hi1)
             {
+                const double v05 = c.template other<-CH>();
                 const double Pn = fma(-cfw, v05, Tn);
                 Lk += Pn;
                 Q += Pn;
             }
             // x = Lk: Q += c S05 Lk ; nb_new = nb + Lk + sum_j S05^j Q
-            c.publish(Lk);
-            Q = c.template mm<false>(Q, o.S05);
+            c.post(Lk);
+            Q = c.own(Q, o.S05, c.sh(Lk));
+            JQ_TS(n)
+            c.sync();
+            JQ_TS(n)
+            Q = c.nbr(Q, o.S05, c.nbs());
             const double nbn = c.horner((nb + Lk) + Q, Q, o.S05, a.m);
+            JQ_TS(n)
             const double Bq = nb + nbn;      // -(li0 + li)
-            // x = nb_new: lambda_r_new = X + c (S1 X - K05 li_new + hr1), Hsym_q li_new (tr4); vr(t_n) exists now: tr1, tr3
-            c.publish(nbn);
-            const double un = c.template other<-CH>();
-            double G = c.template mm<false>(X, o.Kp05);
-            if (a.use_shift) G = fma(cw, nbn, G);
-            G = (G + SX) + cfw * un;
+            // x = nb_new: lambda_r_new = X + c (S1 X - K05 li_new + hr1), Hsym_q li_new (tr4); vr(t_n) exists behind the barrier
+            c.post(nbn);
+            double G;
+            {
+                const Sh sx = c.sh(nbn);
+                G = c.own(X, o.Kp05, sx);
+                if (a.use_shift) G = fma(cw, nbn, G);
+                G += SX;
+                JQ_TS(n)
+                c.template sync<true>();
+                JQ_TS(n)
+                const Nb nn = c.nbs();
+                const double un = c.template other<-CH>();
+                G = c.nbr(G, o.Kp05, nn);
+                G = fma(cfw, un, G);
+                cq_next_ops<NT>(c, o);
+                // x = -(li0 + li) for the state waves' tr5
+                c.post(Bq);
+                const double uw = u * wgt, unw = un * wgt;
 #pragma unroll
-            for (int q = 0; q < JQ_MAXNC; ++q)
-                if (q < Nc) {
-                    const double ts = wave_sum4(u * Tq[q] * wgt, un * Tq[q] * wgt, 0.0, 0.0);      // rows 0, 2: t1 = tr(vr0' Hanti_q X), t3 = tr(vr' Hanti_q X)
-                    if ((lane_ & 15) == 0) rec[((size_t)(n & 1) * NT + wave) * rslots + 4 * q + (lane_ >> 4)] = ts;
-                }
-            double p4[JQ_MAXNC];
-#pragma unroll
-            for (int q = 0; q < JQ_MAXNC; ++q) p4[q] = (q < Nc) ? -(un * c.mm_z_mode(c.ring.next_c(q), a.bw_trace[q])) : 0.0;
-            // x = -(li0 + li): tr5 = tr(vi05' Hanti (li0+li))
-            c.publish(Bq);
-#pragma unroll
-            for (int q = 0; q < JQ_MAXNC; ++q)
-                if (q < Nc) {
-                    const double t5 = -(v05 * c.mm_z_mode(c.ring.next_c(Nc + q), a.bw_trace[q]));
-                    const double t4 = p4[q] + carry[q];
-                    carry[q] = p4[q];
-                    const double ts = wave_sum4(t2[q] * wgt, t4 * wgt, t5 * wgt, 0.0);      // rows 0, 2, 1: t2, t4, t5
-                    if ((lane_ & 15) == 0) rec[((size_t)(n & 1) * NT + wave) * rslots + 4 * (Nc + q) + (lane_ >> 4)] = ts;
-                }
+                for (int q = 0; q < JQ_MAXNC; ++q)
+                    if (q < Nc) {
+                        const Op Hs = c.load(c.ring.cimg(q));
+                        const double pq = -(un * c.nbr(c.own(0.0, Hs, sx), Hs, nn));
+                        const double t4 = (pq + carry[q]) * wgt;
+                        carry[q] = pq;
+                        redw[(size_t)q * NT * 64] = cq_part4(uw * Tq[q], unw * Tq[q], t4, 0.0);      // rows 0, 2, 1: t1, t3, t4
+                    }
+                JQ_TS(n)
+                c.sync();
+                JQ_TS(n)
+            }
             mu = G;
             nb = nbn;
         }
-        c.ring.drain();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();      // (the last hand-off)
+        asm volatile("" ::: "memory");
+        finish_traces(a.nsteps_chunk - 1);
         st[(size_t)2 * KT * 64 + s.foff] = mu;
         st[(size_t)3 * KT * 64 + s.foff] = nb;
+        JQ_TS_PRINT(wave_all)
     }
 #pragma unroll
     for (int q = 0; q < JQ_MAXNC; ++q)
