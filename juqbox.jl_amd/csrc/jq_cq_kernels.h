@@ -46,7 +46,7 @@ struct WinRing {
     int jnext, jlast;       // next time point to fetch, last one of the chunk
     unsigned snext;         // byte offset of its ring slot
     int wave, nwaves, lane;
-    unsigned wb1, wb2;      // byte offsets of the time points 2n+1, 2n+2 of the step whose operators are loaded next
+    unsigned wb0, wb1, wb2; // byte offsets of the time points 2n, 2n+1, 2n+2 of the step whose operators are loaded next
 
     __device__ __forceinline__ void dma(const char* gsrc, char* dst, int pieces) const
     {
@@ -67,7 +67,9 @@ struct WinRing {
         if (snext == cbase) snext = 0;
     }
     // time points 0 .. 4 and the constants; wb1, wb2 = time points 1, 2 (step 0); time point 0 is at offset 0
-    __device__ __forceinline__ void init(char* smem_, const PropArgs& a, int wave_, int lane_, int nwaves_)
+    // (ahead: time points fetched before the first step -- JQ_WIN_TPS: the DMA runs two steps ahead and a step's operators must be
+    // loaded before its first barrier; 3: one step ahead, the time points 2n .. 2n+2 stay resident during step n)
+    __device__ __forceinline__ void init(char* smem_, const PropArgs& a, int wave_, int lane_, int nwaves_, int ahead = JQ_WIN_TPS)
     {
         smem = smem_, wave = wave_, lane = lane_, nwaves = nwaves_;
         stride_b = (unsigned)(a.stride * 8);
@@ -77,25 +79,26 @@ struct WinRing {
         gnext = (const char*)a.stream;
         jnext = 0, jlast = 2 * a.nsteps_chunk, snext = 0;
         dma((const char*)a.cimg, smem + cbase, 2 * a.Ncoupled * a.pieces);
-        for (int j = 0; j < JQ_WIN_TPS; ++j) issue_next();
+        for (int j = 0; j < ahead; ++j) issue_next();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        wb1 = slot_bytes, wb2 = 2 * slot_bytes;
+        wb0 = 0, wb1 = slot_bytes, wb2 = 2 * slot_bytes;
     }
     // the window of the next step (call once its operators are about to be loaded)
     __device__ __forceinline__ void advance()
     {
+        wb0 = wb2;
         wb1 = wb2 + slot_bytes;
         if (wb1 == cbase) wb1 = 0;
         wb2 = wb1 + slot_bytes;
         if (wb2 == cbase) wb2 = 0;
     }
-    // LDS image (lane offset applied) of K (KIND 0) / S (KIND 1) at time point 2n + TP (TP = 1, 2), of constant image #idx
+    // LDS image (lane offset applied) of K (KIND 0) / S (KIND 1) at time point 2n + TP, of constant image #idx
     template <int KIND, int TP>
     __device__ __forceinline__ const double* ks() const
     {
-        return (const double*)(smem + ((TP == 1 ? wb1 : wb2) + KIND * stride_b)) + lane;
+        return (const double*)(smem + ((TP == 0 ? wb0 : TP == 1 ? wb1 : wb2) + KIND * stride_b)) + lane;
     }
     __device__ __forceinline__ const double* cimg(int idx) const { return (const double*)(smem + (cbase + (unsigned)idx * stride_b)) + lane; }
 };
@@ -200,9 +203,14 @@ struct CoopQ {
         return xp[OFF];
     }
     // base + sum_{j=1..m} S^j A  (Horner form, jq_kernels.h): m publications
-    __device__ __forceinline__ double horner(double base, double A, const Op& S, int m)
+    // (pre: issues the loads of the operators that the publication AFTER the series needs, one interval ahead)
+    template <typename F>
+    __device__ __forceinline__ double horner(double base, double A, const Op& S, int m, F pre)
     {
-        if (m <= 0) return base;
+        if (m <= 0) {
+            pre();
+            return base;
+        }
         double Y = A;
         for (int j = 1; j < m; ++j) {
             post(Y);
@@ -210,10 +218,15 @@ struct CoopQ {
             sync();
             Y = nbr(t, S, nbs());
         }
+        pre();
         post(Y);
         const double t = own(base, S, sh(Y));
         sync();
         return nbr(t, S, nbs());
+    }
+    __device__ __forceinline__ double horner(double base, double A, const Op& S, int m)
+    {
+        return horner(base, A, S, m, [] {});
     }
 };
 
@@ -455,7 +468,7 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
     const int ntr = Nc * JQ_NTR, ngroups = Nc + (Nc + 1) / 2;
     double* red = scratch + 2 * NT * 64;                        // [ngroups][NT][64]
     c.setup(tab + 32 * NT, wave, lane_, s.chain);
-    c.ring.init(smem, a, wave_all, lane_, 2 * NT);
+    c.ring.init(smem, a, wave_all, lane_, 2 * NT, 3);      // (the time points of a step stay resident: operators are loaded one interval ahead of their use)
     const double wdr = tab[16 * wave + s.g], wsr = tab[16 * NT + 16 * wave + s.g];
     double* st = a.state + (size_t)s.slab * a.state_stride;
     const double cw = 0.5 * a.h * a.colinfo[(size_t)s.slab * 32 + s.col] * wsr;      // h/2 eps ws[row]
@@ -466,7 +479,6 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
     for (int q = 0; q < JQ_MAXNC; ++q) carry[q] = 0.0;
     // my blocks of the constant trace images (Hsym_q: image q, Hanti_q: image Nc + q) are loaded where they are used; the absent
     // parts of a single-subsystem operator are stored as zeros, so the trace products are branch-free
-    CqOps<NT> o = cq_first_ops<NT>(c);
     double* redw = red + (size_t)wave * 64 + lane_;      // my block's slot of group 0
     // the trace scalars of step k (all waves; call behind a barrier that follows the step's last hand-off)
     auto finish_traces = [&](int k) {
@@ -492,6 +504,7 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
     if (s.chain == 0) {
         // ---- state re-integration (src/evalobjgrad.jl:879), channel 0; traces t2 = tr(vi05' Hsym_q X), t5 = tr(vi05' Hanti_q (li0+li))
         double u = st[s.foff], v = st[(size_t)KT * 64 + s.foff];
+        Op Kp05 = c.load(c.ring.template ks<0, 1>()), S0 = c.load(c.ring.template ks<1, 0>());
         if (a.first_chunk) {      // (vr(T) for the carry products of the adjoint waves)
             c.post(u);
             c.sync();
@@ -502,11 +515,12 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
             double un, v05, vN, t2[JQ_MAXNC];
             // x = u: A = c K05 u ; P = u + c S0 u
             c.post(u);
+            const Op S05 = c.load(c.ring.template ks<1, 1>());
             double A, P;
             {
                 const Sh sx = c.sh(u);
-                A = c.own(0.0, o.Kp05, sx);
-                P = c.own(u, o.S0, sx);
+                A = c.own(0.0, Kp05, sx);
+                P = c.own(u, S0, sx);
                 if (a.use_shift) A = fma(cw, u, A);
                 JQ_TS(n)
                 c.sync();
@@ -514,26 +528,31 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
                 c.ring.issue_next();
                 c.ring.issue_next();
                 const Nb nn = c.nbs();
-                A = c.nbr(A, o.Kp05, nn);
-                P = c.nbr(P, o.S0, nn);
+                A = c.nbr(A, Kp05, nn);
+                P = c.nbr(P, S0, nn);
             }
             if (n > 0) finish_traces(n - 1);
             // x = v: A = c (K05 u + S05 v) ; v05 = v + sum_j S^j A
             c.post(v);
-            A = c.own(A, o.S05, c.sh(v));
+            A = c.own(A, S05, c.sh(v));
             JQ_TS(n)
             c.sync();
             JQ_TS(n)
-            A = c.nbr(A, o.S05, c.nbs());
-            v05 = c.horner(v + A, A, o.S05, a.m);
+            A = c.nbr(A, S05, c.nbs());
+            Op Kn0, Kn1;
+            v05 = c.horner(v + A, A, S05, a.m, [&] {
+                Kn0 = c.load(c.ring.template ks<0, 0>());
+                Kn1 = c.load(c.ring.template ks<0, 2>());
+            });
             JQ_TS(n)
             // x = v05: vN = v05 + c S05 v05 ; un = u + c (S0 u - K0 v05) ; A = -c K1 v05
             c.post(v05);
+            const Op S1 = c.load(c.ring.template ks<1, 2>());
             {
                 const Sh sx = c.sh(v05);
-                vN = c.own(v05, o.S05, sx);
-                un = c.own(P, o.Kn0, sx);
-                A = c.own(0.0, o.Kn1, sx);
+                vN = c.own(v05, S05, sx);
+                un = c.own(P, Kn0, sx);
+                A = c.own(0.0, Kn1, sx);
                 if (a.use_shift) {
                     un = fma(-cw, v05, un);
                     A = fma(-cw, v05, A);
@@ -542,14 +561,14 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
                 c.sync();
                 JQ_TS(n)
                 const Nb nn = c.nbs();
-                vN = c.nbr(vN, o.S05, nn);
-                un = c.nbr(un, o.Kn0, nn);
-                A = c.nbr(A, o.Kn1, nn);
+                vN = c.nbr(vN, S05, nn);
+                un = c.nbr(un, Kn0, nn);
+                A = c.nbr(A, Kn1, nn);
             }
             const double v05w = v05 * wgt;
             // x = un: A = c (S1 un - K1 v05)
             c.post(un);
-            A = c.own(A, o.S1, c.sh(un));
+            A = c.own(A, S1, c.sh(un));
             // (under the barrier: the adjoint chain's X of the last publication)
             {
                 const Sh sx = c.sh(c.template other<CH>());
@@ -566,18 +585,21 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
             JQ_TS(n)
             c.sync();
             JQ_TS(n)
-            A = c.nbr(A, o.S1, c.nbs());
-            un = c.horner(un + A, A, o.S1, a.m);
+            A = c.nbr(A, S1, c.nbs());
+            un = c.horner(un + A, A, S1, a.m, [&] { Kp05 = c.load(c.ring.template ks<0, 1>()); });
             JQ_TS(n)
             // x = un: v(t_n) = v05 + c (K05 un + S05 v05)
             c.post(un);
-            v = c.own(vN, o.Kp05, c.sh(un));
+            v = c.own(vN, Kp05, c.sh(un));
             if (a.use_shift) v = fma(cw, un, v);
             JQ_TS(n)
             c.template sync<true>();
             JQ_TS(n)
-            v = c.nbr(v, o.Kp05, c.nbs());
-            cq_next_ops<NT>(c, o);
+            v = c.nbr(v, Kp05, c.nbs());
+            // (the time points of the next step have landed)
+            c.ring.advance();
+            Kp05 = c.load(c.ring.template ks<0, 1>());
+            S0 = c.load(c.ring.template ks<1, 0>());
             u = un;
             // (- | -(li0 + li)): t5
             JQ_TS(n)
@@ -610,6 +632,7 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
         // ---- adjoint step! with forcing (src/StormerVerlet.jl:255-303), channel 1; traces t1 = tr(vr0' Hanti_q X),
         //      t3 = tr(vr' Hanti_q X), t4 = tr(vr' Hsym_q li) + tr(vr0' Hsym_q li0)
         double mu = st[(size_t)2 * KT * 64 + s.foff], nb = st[(size_t)3 * KT * 64 + s.foff];
+        Op Kp05 = c.load(c.ring.template ks<0, 1>()), S05 = c.load(c.ring.template ks<1, 1>());
         const double cfw = (a.forced ? 0.5 * a.h * a.tinv : 0.0) * wdr;      // forcing weight c tinv wd[row]; 0 for step_no_forcing!
         const bool slot0 = wave == 0 && ((lane_ >> 2) & 3) == 0;      // the lanes that carry per-column partials between chunks
 #pragma unroll
@@ -634,11 +657,12 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
             JQ_TS(n)
             // x = nb (-lambda_i): L = c K05 nb, Tn = c S05 nb (for the second half of the step)
             c.post(nb);
+            const Op S0 = c.load(c.ring.template ks<1, 0>());
             double L, Tn;
             {
                 const Sh sx = c.sh(nb);
-                L = c.own(0.0, o.Kp05, sx);
-                Tn = c.own(0.0, o.S05, sx);
+                L = c.own(0.0, Kp05, sx);
+                Tn = c.own(0.0, S05, sx);
                 if (a.use_shift) L = fma(cw, nb, L);
                 JQ_TS(n)
                 c.sync();
@@ -646,29 +670,34 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
                 c.ring.issue_next();
                 c.ring.issue_next();
                 const Nb nn = c.nbs();
-                L = c.nbr(L, o.Kp05, nn);
-                Tn = c.nbr(Tn, o.S05, nn);
+                L = c.nbr(L, Kp05, nn);
+                Tn = c.nbr(Tn, S05, nn);
             }
             const double u = c.template other<-CH>();      // vr before the state step (:862)
             if (n > 0) finish_traces(n - 1);
             // x = mu: L = c (S0 mu - K05 li + hr0) ; X = mu + sum_j S0^j L
             c.post(mu);
-            L = c.own(L, o.S0, c.sh(mu));
+            L = c.own(L, S0, c.sh(mu));
             L = fma(cfw, u, L);
             JQ_TS(n)
             c.sync();
             JQ_TS(n)
-            L = c.nbr(L, o.S0, c.nbs());
-            const double X = c.horner(mu + L, L, o.S0, a.m);
+            L = c.nbr(L, S0, c.nbs());
+            Op Kn0, Kn1, S1;
+            const double X = c.horner(mu + L, L, S0, a.m, [&] {
+                Kn0 = c.load(c.ring.template ks<0, 0>());
+                Kn1 = c.load(c.ring.template ks<0, 2>());
+                S1 = c.load(c.ring.template ks<1, 2>());
+            });
             JQ_TS(n)
             // x = X: Lk = -c K0 X, Q = -c K1 X, SX = c S1 X, Hanti_q X (tr1, tr3)
             c.post(X);
             double Lk, Q, SX, Tq[JQ_MAXNC];
             {
                 const Sh sx = c.sh(X);
-                Lk = c.own(0.0, o.Kn0, sx);
-                Q = c.own(0.0, o.Kn1, sx);
-                SX = c.own(0.0, o.S1, sx);
+                Lk = c.own(0.0, Kn0, sx);
+                Q = c.own(0.0, Kn1, sx);
+                SX = c.own(0.0, S1, sx);
                 if (a.use_shift) {
                     Lk = fma(-cw, X, Lk);
                     Q = fma(-cw, X, Q);
@@ -677,9 +706,9 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
                 c.sync();
                 JQ_TS(n)
                 const Nb nn = c.nbs();
-                Lk = c.nbr(Lk, o.Kn0, nn);
-                Q = c.nbr(Q, o.Kn1, nn);
-                SX = c.nbr(SX, o.S1, nn);
+                Lk = c.nbr(Lk, Kn0, nn);
+                Q = c.nbr(Q, Kn1, nn);
+                SX = c.nbr(SX, S1, nn);
 #pragma unroll
                 for (int q = 0; q < JQ_MAXNC; ++q) {
                     Tq[q] = 0.0;
@@ -698,12 +727,12 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
             }
             // x = Lk: Q += c S05 Lk ; nb_new = nb + Lk + sum_j S05^j Q
             c.post(Lk);
-            Q = c.own(Q, o.S05, c.sh(Lk));
+            Q = c.own(Q, S05, c.sh(Lk));
             JQ_TS(n)
             c.sync();
             JQ_TS(n)
-            Q = c.nbr(Q, o.S05, c.nbs());
-            const double nbn = c.horner((nb + Lk) + Q, Q, o.S05, a.m);
+            Q = c.nbr(Q, S05, c.nbs());
+            const double nbn = c.horner((nb + Lk) + Q, Q, S05, a.m);
             JQ_TS(n)
             const double Bq = nb + nbn;      // -(li0 + li)
             // x = nb_new: lambda_r_new = X + c (S1 X - K05 li_new + hr1), Hsym_q li_new (tr4); vr(t_n) exists behind the barrier
@@ -711,7 +740,7 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
             double G;
             {
                 const Sh sx = c.sh(nbn);
-                G = c.own(X, o.Kp05, sx);
+                G = c.own(X, Kp05, sx);
                 if (a.use_shift) G = fma(cw, nbn, G);
                 G += SX;
                 JQ_TS(n)
@@ -719,9 +748,12 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
                 JQ_TS(n)
                 const Nb nn = c.nbs();
                 const double un = c.template other<-CH>();
-                G = c.nbr(G, o.Kp05, nn);
+                G = c.nbr(G, Kp05, nn);
                 G = fma(cfw, un, G);
-                cq_next_ops<NT>(c, o);
+                // (the time points of the next step have landed)
+                c.ring.advance();
+                Kp05 = c.load(c.ring.template ks<0, 1>());
+                S05 = c.load(c.ring.template ks<1, 1>());
                 // x = -(li0 + li) for the state waves' tr5
                 c.post(Bq);
                 const double uw = u * wgt, unw = un * wgt;
