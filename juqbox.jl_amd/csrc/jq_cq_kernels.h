@@ -59,6 +59,9 @@ struct WinRing {
     }
     __device__ __forceinline__ void issue_next()
     {
+#ifdef JQ_CQ_NODMA      // timing experiment only (wrong results): what the DMA issue costs
+        if (jnext > 4) return;
+#endif
         if (jnext > jlast) return;
         dma(gnext, smem + snext, pieces2);
         gnext += slot_bytes;
@@ -124,7 +127,7 @@ typedef __attribute__((address_space(3))) double jq_lds_double;
 template <int NT>
 struct CoopQ {
     static constexpr int CHS = (NT + 2) * 64;       // doubles per channel
-    static constexpr int PAR = 2 * CHS;              // doubles per parity
+    static constexpr int PAR = 3 * CHS;              // doubles per parity (channel 2: the adjoint chain's second vector of its last publication)
     WinRing ring;
     jq_lds_double* xp;  // my block of my channel in the parity that holds the published vectors
     int delta;          // doubles from that parity to the other one (+-PAR)
@@ -139,6 +142,8 @@ struct CoopQ {
         delta = PAR;
     }
     __device__ __forceinline__ void post(double x) { xp[delta] = x; }
+    template <int OFF>
+    __device__ __forceinline__ void post_at(double x) { xp[delta + OFF] = x; }
     template <bool DMA = false>
     __device__ __forceinline__ void sync()
     {
@@ -289,7 +294,7 @@ __device__ __forceinline__ void cq_next_ops(CoopQ<NT>& c, CqOps<NT>& o)
 }
 
 // state step up to its second-to-last publication: in u, v; out un = u(t+h), v05, vN = v05 + S05 v05 (the caller publishes un
-// once more and adds Kp05 un).  Issues the DMA of the step behind the first barrier.
+// once more and adds Kp05 un).
 template <int NT>
 __device__ __forceinline__ void cq_state(CoopQ<NT>& c, const PropArgs& a, const CqOps<NT>& o, double cw, double u, double v, double& un,
                                          double& v05, double& vN)
@@ -305,8 +310,6 @@ __device__ __forceinline__ void cq_state(CoopQ<NT>& c, const PropArgs& a, const 
         P = c.own(u, o.S0, s);
         if (a.use_shift) A = fma(cw, u, A);
         c.sync();
-        c.ring.issue_next();
-        c.ring.issue_next();
         const Nb n = c.nbs();
         A = c.nbr(A, o.Kp05, n);
         P = c.nbr(P, o.S0, n);
@@ -376,9 +379,12 @@ __device__ __forceinline__ CqSetup<NT> cq_setup(const PropArgs& a)
 }
 
 // ---------------------------------------------------------------------------------------------
-// grid = 4 * nslabs (workgroup = quad qd of slab blockIdx.x / 4), block = 64 * NT; 5 + 2 m barriers per time step
+// grid = 4 * nslabs (workgroup = quad qd of slab blockIdx.x / 4), block = 64 * (NT + 2); 5 + 2 m barriers per time step.
+// The two extra waves only stage: they pass the barriers and, behind the last one of step n, issue the DMA of the time points
+// 2n+5, 2n+6 into the slots of 2n, 2n+1 (whose operators everybody has loaded) -- ~25 instructions per step that would
+// otherwise sit on the critical path of the six propagating waves (a wave issues one instruction every ~10 cycles).
 template <int NT>
-__global__ __launch_bounds__(64 * NT) void k_forward_cq(PropArgs a)
+__global__ __launch_bounds__(64 * NT + 128) void k_forward_cq(PropArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KT = 4 * NT;
@@ -389,8 +395,23 @@ __global__ __launch_bounds__(64 * NT) void k_forward_cq(PropArgs a)
     for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[(i & ~15) + 4 * (i & 3) + ((i >> 2) & 3)] = a.tabs[i];   // [block][g][r]
     CoopQ<NT> c;
     double* scratch = tab + 32 * NT + 2 * CoopQ<NT>::PAR;
-    c.setup(tab + 32 * NT, wave, lane_);
-    c.ring.init(smem, a, wave, lane_, NT);      // (barrier inside)
+    c.setup(tab + 32 * NT, s.chain ? 0 : wave, lane_);
+    c.ring.init(smem, a, wave + NT * s.chain, lane_, NT + 2);      // (barrier inside)
+    if (s.chain) {      // staging waves
+        c.ring.wave = wave, c.ring.nwaves = 2;
+        const int nb = 4 + 2 * (a.m > 0 ? a.m : 0);
+        for (int n = 0; n < a.nsteps_chunk; ++n) {
+            for (int k = 0; k < nb; ++k) __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (my pieces of the time points 2n+3, 2n+4)
+            __builtin_amdgcn_s_barrier();
+            c.ring.issue_next();
+            c.ring.issue_next();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();      // (cq_wg_sum of the propagating waves)
+        __syncthreads();
+        return;
+    }
     const double wdr = tab[16 * wave + s.g], wsr = tab[16 * NT + 16 * wave + s.g];
 
     double* st = a.state + (size_t)s.slab * a.state_stride;
@@ -409,9 +430,9 @@ __global__ __launch_bounds__(64 * NT) void k_forward_cq(PropArgs a)
         c.post(un);
         v = c.own(vN, o.Kp05, c.sh(un));
         if (a.use_shift) v = fma(cw, un, v);
-        c.template sync<true>();
+        c.sync();
         v = c.nbr(v, o.Kp05, c.nbs());
-        cq_next_ops<NT>(c, o);
+        cq_next_ops<NT>(c, o);      // (the staging waves drained the DMA of its time points in front of this barrier)
         u = un;
         leak += wdr * (u * u) + 2.0 * (wdr * (v05 * v05));      // (:716, penalf2a :2170-2180)
         if (a.hist_r) {
@@ -434,10 +455,12 @@ __global__ __launch_bounds__(64 * NT) void k_forward_cq(PropArgs a)
 // ---------------------------------------------------------------------------------------------
 // grid = 4 * nslabs, block = 128 * NT: waves 0 .. NT-1 re-integrate the state (channel 0), waves NT .. 2 NT-1 run the adjoint
 // step (channel 1); the trace products of adjoint_grad_calc! are shared between them (the state waves take the two traces
-// with vi05).  Both sets pass the same 6 + 2 m barriers per time step:
-//   (u | nb)  (v | mu)  m x Neumann  (v05 | X)  (un' | Lk)  m x Neumann  (un | nb_new)  (- | -(li0 + li))
+// with vi05).  Both sets pass the same 5 + 2 m barriers per time step:
+//   (u | nb)  (v | mu)  m x Neumann  (v05 | X)  (un' | Lk)  m x Neumann  (un | nb_new, -(li0 + li))
+// Staging (WinRing): behind the last barrier of step n the state waves -- which wait for the adjoint waves there -- issue the
+// DMA of the time points 2n+5, 2n+6 and drain it in front of the last barrier of step n+1.
 // Trace scalars: a wave reduces its per-lane values four at a time to 16 column partials per value (cq_part4) and leaves that
-// register in LDS, red[group][block][64]; behind the first barrier of the NEXT step wave g adds the NT blocks of group g,
+// register in LDS, red[group][block][64]; behind the first barrier of the NEXT step adjoint wave g adds the NT blocks of group g,
 // finishes the four sums with rotate-adds inside the rows and writes them to the trace record of the step.
 //   group q < Nc (adjoint wave):  rows 0, 1, 2 = t1, t4, t3 of control q
 //   group Nc + j (state wave):    rows 0, 1 = t2, t5 of control 2 j, rows 2, 3 = t2, t5 of control 2 j + 1
@@ -468,7 +491,8 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
     const int ntr = Nc * JQ_NTR, ngroups = Nc + (Nc + 1) / 2;
     double* red = scratch + 2 * NT * 64;                        // [ngroups][NT][64]
     c.setup(tab + 32 * NT, wave, lane_, s.chain);
-    c.ring.init(smem, a, wave_all, lane_, 2 * NT, 3);      // (the time points of a step stay resident: operators are loaded one interval ahead of their use)
+    c.ring.init(smem, a, wave_all, lane_, 2 * NT);
+    c.ring.wave = wave, c.ring.nwaves = NT;      // (from here on the state waves stage)
     const double wdr = tab[16 * wave + s.g], wsr = tab[16 * NT + 16 * wave + s.g];
     double* st = a.state + (size_t)s.slab * a.state_stride;
     const double cw = 0.5 * a.h * a.colinfo[(size_t)s.slab * 32 + s.col] * wsr;      // h/2 eps ws[row]
@@ -480,9 +504,12 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
     // my blocks of the constant trace images (Hsym_q: image q, Hanti_q: image Nc + q) are loaded where they are used; the absent
     // parts of a single-subsystem operator are stored as zeros, so the trace products are branch-free
     double* redw = red + (size_t)wave * 64 + lane_;      // my block's slot of group 0
-    // the trace scalars of step k (all waves; call behind a barrier that follows the step's last hand-off)
+    // the trace scalars of step k (adjoint waves; call behind a barrier that follows the step's last hand-off)
     auto finish_traces = [&](int k) {
-        for (int g = wave_all; g < ngroups; g += 2 * NT) {
+#ifdef JQ_CQ_NOFINISH   // timing experiment only (wrong gradients)
+        return;
+#endif
+        for (int g = wave; g < ngroups; g += NT) {
             const double* r = red + (size_t)g * NT * 64 + lane_;
             double sum = r[0];
 #pragma unroll
@@ -525,13 +552,10 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
                 JQ_TS(n)
                 c.sync();
                 JQ_TS(n)
-                c.ring.issue_next();
-                c.ring.issue_next();
                 const Nb nn = c.nbs();
                 A = c.nbr(A, Kp05, nn);
                 P = c.nbr(P, S0, nn);
             }
-            if (n > 0) finish_traces(n - 1);
             // x = v: A = c (K05 u + S05 v) ; v05 = v + sum_j S^j A
             c.post(v);
             A = c.own(A, S05, c.sh(v));
@@ -596,18 +620,17 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
             c.template sync<true>();
             JQ_TS(n)
             v = c.nbr(v, Kp05, c.nbs());
-            // (the time points of the next step have landed)
+            // (the time points of the next step have landed; those of this step are dead)
             c.ring.advance();
             Kp05 = c.load(c.ring.template ks<0, 1>());
             S0 = c.load(c.ring.template ks<1, 0>());
+            c.ring.issue_next();
+            c.ring.issue_next();
             u = un;
-            // (- | -(li0 + li)): t5
-            JQ_TS(n)
-            c.sync();
-            JQ_TS(n)
+            // the adjoint chain's -(li0 + li) (channel 2 of the last publication): t5
             {
-                const Sh sx = c.sh(c.template other<CH>());
-                const Nb nx = c.template nbs<CH>();
+                const Sh sx = c.sh(c.template other<2 * CH>());
+                const Nb nx = c.template nbs<2 * CH>();
                 double t5[JQ_MAXNC];
 #pragma unroll
                 for (int q = 0; q < JQ_MAXNC; ++q) {
@@ -624,7 +647,6 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();      // (the last hand-off)
         asm volatile("" ::: "memory");
-        finish_traces(a.nsteps_chunk - 1);
         st[s.foff] = u;
         st[(size_t)KT * 64 + s.foff] = v;
         JQ_TS_PRINT(wave_all)
@@ -667,8 +689,6 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
                 JQ_TS(n)
                 c.sync();
                 JQ_TS(n)
-                c.ring.issue_next();
-                c.ring.issue_next();
                 const Nb nn = c.nbs();
                 L = c.nbr(L, Kp05, nn);
                 Tn = c.nbr(Tn, S05, nn);
@@ -737,6 +757,7 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
             const double Bq = nb + nbn;      // -(li0 + li)
             // x = nb_new: lambda_r_new = X + c (S1 X - K05 li_new + hr1), Hsym_q li_new (tr4); vr(t_n) exists behind the barrier
             c.post(nbn);
+            c.template post_at<CH>(Bq);      // (channel 2: for the state waves' tr5)
             double G;
             {
                 const Sh sx = c.sh(nbn);
@@ -744,7 +765,7 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
                 if (a.use_shift) G = fma(cw, nbn, G);
                 G += SX;
                 JQ_TS(n)
-                c.template sync<true>();
+                c.sync();
                 JQ_TS(n)
                 const Nb nn = c.nbs();
                 const double un = c.template other<-CH>();
@@ -754,8 +775,6 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
                 c.ring.advance();
                 Kp05 = c.load(c.ring.template ks<0, 1>());
                 S05 = c.load(c.ring.template ks<1, 1>());
-                // x = -(li0 + li) for the state waves' tr5
-                c.post(Bq);
                 const double uw = u * wgt, unw = un * wgt;
 #pragma unroll
                 for (int q = 0; q < JQ_MAXNC; ++q)
@@ -766,9 +785,6 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
                         carry[q] = pq;
                         redw[(size_t)q * NT * 64] = cq_part4(uw * Tq[q], unw * Tq[q], t4, 0.0);      // rows 0, 2, 1: t1, t3, t4
                     }
-                JQ_TS(n)
-                c.sync();
-                JQ_TS(n)
             }
             mu = G;
             nb = nbn;

@@ -629,7 +629,7 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         // neighbour to split the work with).  JQ_CQ=0 disables them, JQ_CQ=<n> bounds the number of quads.
         {
             const long long win = (2LL * JQ_WIN_TPS + 2LL * h->Nc) * slot;
-            const long long tail = 32LL * h->NT * 8 + (4LL * (h->NT + 2) + 2 * h->NT) * 64 * 8 + (long long)(h->Nc + (h->Nc + 1) / 2) * h->NT * 64 * 8;
+            const long long tail = 32LL * h->NT * 8 + (6LL * (h->NT + 2) + 2 * h->NT) * 64 * 8 + (long long)(h->Nc + (h->Nc + 1) / 2) * h->NT * 64 * 8;
             h->cq_max_quads = (h->BW == JQ_BW_T4 && h->NT >= 2 && h->quad_max_slabs > 0 && win + tail <= 163840) ? prop.multiProcessorCount : 0;
             if (const char* e = getenv("JQ_CQ"))
                 if (h->cq_max_quads > 0) h->cq_max_quads = atoi(e);
@@ -1456,7 +1456,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
                              : batch > 0   ? (size_t)2 * (2 * batch + 1) * 2 * stride * 8 + (size_t)2 * h->Nc * stride * 8
                              : batch < 0 ? (size_t)(2 * JQ_WIN_TPS + 2 * h->Nc) * stride * 8
                                          : (size_t)2 * stride * 8;
-    const size_t lds_cq = lds_stage + (size_t)32 * h->NT * 8 + (size_t)(4 * (h->NT + 2) + 2 * h->NT) * 64 * 8 + (size_t)(h->Nc + (h->Nc + 1) / 2) * h->NT * 64 * 8;      // tables, x exchange, wg-sum scratch, trace hand-off
+    const size_t lds_cq = lds_stage + (size_t)32 * h->NT * 8 + (size_t)(6 * (h->NT + 2) + 2 * h->NT) * 64 * 8 + (size_t)(h->Nc + (h->Nc + 1) / 2) * h->NT * 64 * 8;      // tables, x exchange, wg-sum scratch, trace hand-off
     const size_t lds_fwd = (lane || rl) ? 0 : cq ? lds_cq : imr_coop ? coop_imr_lds_bytes(h->NT, stride)
                                            : lds_stage + (size_t)32 * h->NT * 8 + (coop ? (size_t)2 * h->KT * 64 * 8 : 0);
     const size_t lds_bwd = rl ? (h->rl_npj > 8 ? (size_t)2 * h->Nc * h->rl_stride * 8 : 0) : lane ? 0 : (coop || cq) ? lds_fwd
@@ -1518,7 +1518,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
             for (int i = 0; i < 7; ++i) sched_pack(a.sched_bits, i, kinds[i], tps[i]);
         }
         HIPCHK(h, hipEventRecord(h->ev[evi++], s));
-        hipLaunchKernelGGL(kfwd, dim3(nblocks), dim3(nthreads), lds_fwd, s, a);
+        hipLaunchKernelGGL(kfwd, dim3(nblocks), dim3(cq ? nthreads + 128 : nthreads), lds_fwd, s, a);      // (cooperative quad: two staging waves)
         HIPCHK(h, hipEventRecord(h->ev[evi++], s));
         mfma += (long long)nslabs * nc * (8 + 2 * h->m) * tiles;
     }
