@@ -50,12 +50,16 @@ struct WinRing {
 
     __device__ __forceinline__ void dma(const char* gsrc, char* dst, int pieces) const
     {
+        // (inline asm instead of __builtin_amdgcn_global_load_lds: hipcc puts an s_waitcnt vmcnt(0) in front of the next LDS read
+        //  that may alias the destination -- here the operator loads at the top of the step, i.e. it waited for the DMA right
+        //  after issuing it (~850 cycles per step on the critical path).  The explicit drains in sync<true>() are what orders
+        //  the DMA with its readers.)
         unsigned lo;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lo));
         const char* src = gsrc + lo * 16u;
+        const unsigned ldst = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)dst;
         for (int p = wave; p < pieces; p += nwaves)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)p * 1024),
-                                             (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(ldst + (unsigned)p * 1024u), "v"(src + (size_t)p * 1024) : "memory");
     }
     __device__ __forceinline__ void issue_next()
     {
@@ -147,7 +151,11 @@ struct CoopQ {
     template <bool DMA = false>
     __device__ __forceinline__ void sync()
     {
+#ifdef JQ_CQ_NOVMWAIT   // timing experiment only (unsafe): what the DMA drain costs
+        if (false)
+#else
         if (DMA)
+#endif
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         else
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -626,6 +634,11 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
             S0 = c.load(c.ring.template ks<1, 0>());
             c.ring.issue_next();
             c.ring.issue_next();
+#ifdef JQ_CQ_DMALAT     // experiment: latency of the DMA just issued
+            JQ_TS(n)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            JQ_TS(n)
+#endif
             u = un;
             // the adjoint chain's -(li0 + li) (channel 2 of the last publication): t5
             {
