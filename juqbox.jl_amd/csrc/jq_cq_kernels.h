@@ -6,36 +6,30 @@
 // wave `mt` owns block mt of every array (ONE register per array), a product costs one block's work per wave
 //     D[mt] = C[mt] + B_mt x[mt] (one v_mfma_f64_4x4x4_4b) + c0 shr4(x[mt]) + c1 shl4(x[mt]) + c2 x[mt-1] + c3 x[mt+1]
 // plus the exchange of x with the two neighbouring waves through a double-buffered LDS image (one ds_write, one workgroup
-// barrier, two ds_reads that fly while the wave's own block is multiplied).  Because the barrier is what a product costs
-// here, the step is regrouped so that every published x serves all the products that need it (K05 u and S0 u; S05 v05,
-// K0 v05 and K1 v05; the five products with X, ...): 17 publications per forward step (20 products) at m = 6 Neumann terms.
-// The backward sweep runs its two chains -- state re-integration and adjoint step -- on TWO SETS of NT waves (2 NT waves
-// per workgroup): the adjoint products depend on the state step of the SAME time step only through dot products and forcing
-// terms (u, v05, un of the wave's own block), which the adjoint wave reads from the state wave's publications; both chains
-// publish at the same barriers: 6 + 2 m = 18 per backward step (52 products).  A wave alone on its SIMD issues one VALU
-// instruction every ~10 cycles (probes/dp_rate_probe.hip), so the split halves the critical path: each wave executes one
-// chain's instructions, and the SIMDs interleave the two sets.
-// Same operators, images, window staging (Ring, batch < 0), state file, trace records and reductions as the quad-layout
-// kernels; the regrouping only reorders floating-point additions.
+// barrier, two ds_reads).  What such a kernel pays for (measured, scripts/time_cq_intervals.py, JQ_CQ_TIMING):
+//   * a publication interval costs ~230 cycles even when it holds a single product (LDS write -> barrier -> LDS read -> two
+//     dependent FMAs), so the step is regrouped around PUBLICATIONS: every published x serves all the products that need it
+//     (K05 u and S0 u; S05 v05, K0 v05 and K1 v05; the products with X, ...): 5 + 2 m publications per forward step (20
+//     products at m = 6 Neumann terms), and the part of a product that needs only the wave's own block runs under the barrier;
+//   * a wave that is (almost) alone on its SIMD issues ONE instruction every 10 .. 12 cycles, whatever its kind
+//     (probes/dp_rate_probe.hip): scalar bookkeeping, branches, staging and reductions are as expensive as arithmetic.  The
+//     backward sweep therefore runs its two chains -- state re-integration and adjoint step -- on TWO SETS of NT waves (the
+//     adjoint products depend on the state step of the SAME time step only through u, v05, un of the wave's own block, read from
+//     the state wave's publications), both sets pass the same 5 + 2 m barriers per step (52 products), the trace products are
+//     shared between the sets, their reductions handed to one wave per group of four values, and the staging is done by the
+//     waves that would otherwise wait (two extra waves in the forward sweep).
+// Same operators, images, state file and trace records as the quad-layout kernels; the regrouping only reorders floating-point
+// additions.  One cnot3 evaluation: 0.54 s on the quad-layout kernels, 0.21 s here.
 #pragma once
 #include "jq_kernels.h"
 
-// Exchange image in LDS: [2 parities][2 channels][NT + 2 blocks][64] doubles -- a zero block in front of and behind the NT
-// blocks of a channel, so that the neighbours of the edge blocks need no clamping and every access is ONE base register
-// (this wave's block of ITS channel in the current parity) plus a compile-time offset.  Channel 0: forward sweep / state
-// chain of the backward sweep; channel 1: adjoint chain.
 // Window staging (jq_kernels.h, Ring with batch < 0) re-timed for these kernels: a ring of JQ_WIN_TPS = 5 time points (K and S
 // image each) and the constant trace images are resident in LDS, the time points stream in by global -> LDS DMA (the 1 KiB
-// pieces of an image pair spread over the waves).  A wave keeps the six operator blocks of its time step in REGISTERS:
-// K0, S0 of step n are K1, S1 of step n-1 (same time point), so a step reads only the time points 2n+1, 2n+2 -- and it reads
-// them during the last publication interval of step n-1.  That removes the staging barrier of the slab kernels altogether:
-//   * behind the FIRST publication barrier of step n every wave has loaded the operators of step n, i.e. all time points
-//     <= 2n+2 are dead: the DMA of the time points 2n+5, 2n+6 (operators of step n+2) is issued there, into their slots;
-//   * in front of the barrier of the second-to-last publication every wave drains its DMA (vmcnt(0): issued almost a whole
-//     step earlier), so behind it the time points 2n+3, 2n+4 have landed for everybody and the operators of step n+1 are
-//     loaded while the last interval's arithmetic runs.
-// These kernels run one to three waves per SIMD on a latency-bound chain: every instruction of the loop -- scalar ones and
-// taken branches included -- is on the critical path, so the cursor is incremental (no multiplications, no modulo).
+// pieces of an image pair spread over the staging waves).  There is no staging barrier: behind the LAST publication barrier of
+// step n every wave has loaded its operator blocks of step n into registers, so the time points 2n, 2n+1 are dead and the DMA
+// of 2n+5, 2n+6 (operators of step n+2) is issued into their slots; the issuing waves drain it (vmcnt(0)) in front of the last
+// barrier of step n+1, behind which the operators of step n+2 start to be loaded.  The cursor is incremental (no
+// multiplications, no modulo, no mode branches).
 struct WinRing {
     char* smem;
     const char* gnext;      // global address of the next time point to fetch
@@ -63,9 +57,6 @@ struct WinRing {
     }
     __device__ __forceinline__ void issue_next()
     {
-#ifdef JQ_CQ_NODMA      // timing experiment only (wrong results): what the DMA issue costs
-        if (jnext > 4) return;
-#endif
         if (jnext > jlast) return;
         dma(gnext, smem + snext, pieces2);
         gnext += slot_bytes;
@@ -120,10 +111,10 @@ struct WinRing {
 #define JQ_TS_PRINT(w)
 #endif
 typedef __attribute__((address_space(3))) double jq_lds_double;
-// Exchange image in LDS: [2 parities][2 channels][NT + 2 blocks][64] doubles -- a zero block in front of and behind the NT
+// Exchange image in LDS: [2 parities][3 channels][NT + 2 blocks][64] doubles -- a zero block in front of and behind the NT
 // blocks of a channel, so that the neighbours of the edge blocks need no clamping and every access is ONE base register
 // (this wave's block of ITS channel in the current parity) plus a compile-time offset.  Channel 0: forward sweep / state
-// chain of the backward sweep; channel 1: adjoint chain.
+// chain of the backward sweep; channel 1: adjoint chain; channel 2: its second vector of the last publication of a step.
 //
 // A publication has two phases: post(x) writes the wave's block, sync() waits for everybody's; the part of the products that
 // needs only the wave's own block (MFMA, lane shifts, (i, i+-4) terms: own()) runs BETWEEN them, under the latency of the LDS
@@ -151,11 +142,7 @@ struct CoopQ {
     template <bool DMA = false>
     __device__ __forceinline__ void sync()
     {
-#ifdef JQ_CQ_NOVMWAIT   // timing experiment only (unsafe): what the DMA drain costs
-        if (false)
-#else
         if (DMA)
-#endif
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         else
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -514,9 +501,6 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
     double* redw = red + (size_t)wave * 64 + lane_;      // my block's slot of group 0
     // the trace scalars of step k (adjoint waves; call behind a barrier that follows the step's last hand-off)
     auto finish_traces = [&](int k) {
-#ifdef JQ_CQ_NOFINISH   // timing experiment only (wrong gradients)
-        return;
-#endif
         for (int g = wave; g < ngroups; g += NT) {
             const double* r = red + (size_t)g * NT * 64 + lane_;
             double sum = r[0];
