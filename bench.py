@@ -98,6 +98,40 @@ def cpu_baseline(params, pcof, nrep=2):
     return out
 
 
+def issue_bound(launch_s, steps_per_launch, products_per_step, waves_per_simd):
+    """What the quad-layout formulation itself allows: probes/t4q_issue_probe times the bare product -- per
+    wave 6 v_mfma_f64_4x4x4, 22 v_fma_f64, 24 v_mov_b32_dpp, operators in registers, nothing else -- at 1 .. 4 waves per SIMD.  The
+    kernel's cycles per product and wave (its whole time step: products, dot products, reductions, updates, staging) over the
+    probe's is the fraction of the issue-bound rate it reaches.  Both are converted with the same nominal clock, so the ratio does
+    not depend on it.  The probe runs live when its binary is in the tree (build()), else the figures recorded in profiles/ serve."""
+    import re
+    import subprocess
+    txt, src = None, None
+    exe = os.path.join(ROOT, "probes", "t4q_issue_probe")
+    if os.access(exe, os.X_OK):
+        try:
+            txt = subprocess.run([exe], capture_output=True, text=True, timeout=60).stdout
+            src = "probes/t4q_issue_probe, run by this bench"
+        except Exception:  # noqa: BLE001
+            txt = None
+    if not txt or "mode 15" not in txt:
+        try:
+            txt = open(os.path.join(ROOT, "profiles", "r02_issue_probes.txt")).read()
+            src = "profiles/r02_issue_probes.txt (recorded run of probes/t4q_issue_probe)"
+        except OSError:
+            return None
+    mm = re.search(r"mode 15 .*? %d wave\(s\)/SIMD:.*?per wave\s+(\d+) clk" % waves_per_simd, txt)
+    if not mm:
+        return None
+    probe_clk = float(mm.group(1))
+    kernel_clk = launch_s / steps_per_launch / products_per_step * 2.4e9 / waves_per_simd
+    return {"bare_product_clk_per_wave": probe_clk, "kernel_clk_per_product_and_wave": kernel_clk,
+            "frac_of_formulation_bound": probe_clk / kernel_clk, "waves_per_simd": waves_per_simd,
+            "products_per_backward_step": products_per_step, "nominal_issue_model_clk": 280, "source": src,
+            "note": "fp64 VALU instructions cost 6-7 cycles on gfx950, not 4 (probes/dp_rate_probe.hip): the bare product takes "
+                    "1.3 x its nominal issue count; the kernel as a whole runs within ~10 % of the bare product"}
+
+
 def main():
     args = parse_args()
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
@@ -255,6 +289,9 @@ def main():
                                              "would have to execute for the same result; not a hardware utilisation",
                     "all_propagators_mfma_frac": mfma * flop_per_mfma / (prop_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                     "forward_ms": fwd_ms, "backward_ms": bwd_ms}
+        if band == 7 and not args.no_extras:
+            roofline["issue_bound"] = issue_bound(avg_launch_s, nsteps * args.steps / max(nb, 1), 2 * (8 + 2 * m) + 4 * Nc,
+                                                  min(3, max(1, round(args.samples_per_gpu * N / 16 / 256))))
         out = {"metric": "traceobjgrad evals/sec (fwd+adjoint), cnot3 Hilbert dim", "value": value,
                "unit": "evals/s", "n_gpus": ngpus, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
