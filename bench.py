@@ -289,7 +289,7 @@ def main():
                                              "would have to execute for the same result; not a hardware utilisation",
                     "all_propagators_mfma_frac": mfma * flop_per_mfma / (prop_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                     "forward_ms": fwd_ms, "backward_ms": bwd_ms}
-        if band == 7 and not args.no_extras:
+        if band == 7 and ngpus == 1 and not args.no_extras:
             roofline["issue_bound"] = issue_bound(avg_launch_s, nsteps * args.steps / max(nb, 1), 2 * (8 + 2 * m) + 4 * Nc,
                                                   min(3, max(1, round(args.samples_per_gpu * N / 16 / 256))))
         out = {"metric": "traceobjgrad evals/sec (fwd+adjoint), cnot3 Hilbert dim", "value": value,
