@@ -127,6 +127,12 @@ CASES = [
     (62, 2, 2, 1, 7, 5, 3, "t4", 0),
     (80, 8, 4, 1, 5, 4, 1, "t4", 0),
     (96, 4, 4, 2, 5, 6, 2, "t4", 2),
+    # edge cases of the cooperative-quad kernels (mode auto) and their siblings: no / one Neumann term (publication counts),
+    # one column, one control, one / two / three time steps (staging ring shorter than its depth), chunks of one step
+    (32, 1, 1, 1, 3, 0, 1, "t4", 0),
+    (48, 3, 2, 1, 2, 1, 3, "t4", 1),
+    (64, 6, 3, 1, 1, 3, 1, "t4", 0),
+    (96, 2, 1, 2, 4, 7, 2, "t4", 3),
 ]
 
 
