@@ -65,9 +65,8 @@ struct WinRing {
         if (snext == cbase) snext = 0;
     }
     // time points 0 .. 4 and the constants; wb1, wb2 = time points 1, 2 (step 0); time point 0 is at offset 0
-    // (ahead: time points fetched before the first step -- JQ_WIN_TPS: the DMA runs two steps ahead and a step's operators must be
-    // loaded before its first barrier; 3: one step ahead, the time points 2n .. 2n+2 stay resident during step n)
-    __device__ __forceinline__ void init(char* smem_, const PropArgs& a, int wave_, int lane_, int nwaves_, int ahead = JQ_WIN_TPS)
+    // (all JQ_WIN_TPS time points are fetched before the first step)
+    __device__ __forceinline__ void init(char* smem_, const PropArgs& a, int wave_, int lane_, int nwaves_)
     {
         smem = smem_, wave = wave_, lane = lane_, nwaves = nwaves_;
         stride_b = (unsigned)(a.stride * 8);
@@ -77,7 +76,7 @@ struct WinRing {
         gnext = (const char*)a.stream;
         jnext = 0, jlast = 2 * a.nsteps_chunk, snext = 0;
         dma((const char*)a.cimg, smem + cbase, 2 * a.Ncoupled * a.pieces);
-        for (int j = 0; j < ahead; ++j) issue_next();
+        for (int j = 0; j < JQ_WIN_TPS; ++j) issue_next();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
