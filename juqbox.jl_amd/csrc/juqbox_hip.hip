@@ -60,6 +60,9 @@ struct jq_handle {
     int batch = 0;              // > 0: batched staging (K/S images of `batch` time steps per DMA burst); < 0: window staging
     bool big = false;           // Ntot > 96 (NT = 7 .. 16): only the cooperative kernels with operators read from HBM (jq_coop_kernels.h
                                 // OpCursor) exist -- Stormer-Verlet, Neumann solver, any batch size
+    bool in_split = false;      // run_eval is evaluating one part of a split batch
+    double* d_pk2 = nullptr;    // packed result of the first part of a split batch
+    size_t cap_pk2 = 0;
     int cq_max_quads = 0;       // JQ_BW_T4 structure: batches of at most this many column quads (4 columns) run on the cooperative-quad
                                 // (latency) kernels, one workgroup of NT waves per quad (0: never)
     int quad_max_slabs = 0;     // JQ_BW_T4 structure: batches of at most this many slabs may use the quad-layout kernels (0: never)
@@ -429,7 +432,7 @@ extern "C" void jq_destroy(jq_handle* h)
     }
     (void)hipSetDevice(h->device);
     if (h->emb) jq_destroy(h->emb);
-    double** bufs[] = {&h->d_rfreq, &h->d_wq, &h->d_pack, &h->d_himg_r, &h->d_uinit_r, &h->d_vtr_r, &h->d_vti_r, &h->d_himg_l, &h->d_uinit_l, &h->d_vtr_l, &h->d_vti_l, &h->d_himg_c, &h->d_cimg_c, &h->d_park, &h->d_cimg, &h->d_himg,  &h->d_uimg,       &h->d_vtr,     &h->d_vti,    &h->d_tabs, &h->d_tf,   &h->d_tb,
+    double** bufs[] = {&h->d_rfreq, &h->d_wq, &h->d_pk2, &h->d_pack, &h->d_himg_r, &h->d_uinit_r, &h->d_vtr_r, &h->d_vti_r, &h->d_himg_l, &h->d_uinit_l, &h->d_vtr_l, &h->d_vti_l, &h->d_himg_c, &h->d_cimg_c, &h->d_park, &h->d_cimg, &h->d_himg,  &h->d_uimg,       &h->d_vtr,     &h->d_vti,    &h->d_tabs, &h->d_tf,   &h->d_tb,
                        &h->d_cfreq, &h->d_pcof,       &h->d_stream,  &h->d_pq,     &h->d_state, &h->d_state_save,
                        &h->d_colinfo, &h->d_traces,   &h->d_R,       &h->d_grad,   &h->d_res};
     for (auto b : bufs)
@@ -1223,12 +1226,80 @@ struct EvalOut {
     std::vector<double> grad1;  // unforced adjoint (infidelity gradient), only objFuncType != 1
 };
 
+// JQ_BW_T4 structure, Stormer-Verlet / Neumann: estimated time of one batch in units of a slab-kernel round (4 #CU slabs), by the
+// plan run_eval would choose -- cooperative-quad kernels (<= cq_max_quads column quads: 0.207 s per round of #CU quads against
+// 1.917 s at cnot3), quad-layout kernels with 1 / 2 / 3 slabs per workgroup, slab kernels.  (The same figures as in run_eval.)
+static double t4_plan_cost(const jq_handle* h, long long nsamples)
+{
+    const long long nslabs = h->parts > 1 ? nsamples * h->parts : (nsamples + h->sps - 1) / h->sps;
+    const long long nquads = (nsamples * h->N + 3) / 4;
+    if (h->cq_max_quads > 0 && nquads <= h->cq_max_quads) return 0.108 * (double)((nquads + h->num_cu - 1) / h->num_cu);
+    const double rel[4] = {1.0, 0.29, 0.47, 0.615};
+    double best = rel[0] * (double)((nslabs + 4 * h->num_cu - 1) / (4 * h->num_cu));
+    if (nslabs <= h->quad_max_slabs)
+        for (int k = 1; k <= 3; ++k) {
+            if ((size_t)(2 * JQ_WIN_TPS + 2 * h->Nc) * h->mat_elems * 8 + (size_t)bwd_lds_tail(h->NT, h->Nc, 4 * k, (long long)h->NT * 64) > 163840) continue;
+            if (h->NT <= 2 && nslabs > h->num_cu) continue;
+            best = std::min(best, rel[k] * (double)((nslabs + k * h->num_cu - 1) / (k * h->num_cu)));
+        }
+    return best;
+}
+
+__global__ void k_add_to(double* __restrict__ y, const double* __restrict__ x, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] += x[i];
+}
+
 // The batched evaluation behind every hot-path entry point.
 // d_packed != nullptr: the packed ensemble result (k_pack) is also left at this DEVICE address of h's GPU.
 static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, const double* eps, const double* wgt,
                     const double* shift, bool adjoint, double* hist_r, double* hist_i, EvalOut* out, double* d_packed = nullptr)
 {
     HIPCHK(h, hipSetDevice(h->device));
+    // Ensembles that do not fill their last round: the time of a batch is a staircase in its size (every workgroup runs the
+    // whole sequential time loop; cnot3: 3 072 samples = one round of the three-slab quad-layout kernels 1.18 s, 3 200 samples =
+    // two rounds 2.35 s).  A batch of q full rounds + a remainder is evaluated as two batches when the plan says that is
+    // faster -- the remainder on whatever suits ITS size (3 200 samples: 1.18 + 0.21 s on the cooperative-quad kernels).
+    // Samples are independent and the results are sums over samples, so only the order of those sums changes.
+    if (!h->in_split && h->quad_max_slabs > 0 && h->integrator == 1 && h->solver_id == 1 && !hist_r && eps && nsamples > 1 && !getenv("JQ_NOSPLIT")) {
+        const long long per_round = 3LL * h->num_cu * (h->parts > 1 ? 1 : h->sps) / (h->parts > 1 ? h->parts : 1);      // samples of a full three-slab round
+        const long long n_main = per_round > 0 ? (long long)nsamples / per_round * per_round : 0;
+        if (n_main > 0 && n_main < nsamples &&
+            t4_plan_cost(h, n_main) + t4_plan_cost(h, nsamples - n_main) < t4_plan_cost(h, nsamples) - 1e-9) {
+            h->in_split = true;
+            EvalOut o2;
+            const int n1 = (int)n_main, n2 = nsamples - n1;
+            int rc = run_eval(h, pcof, ncoeff, n1, eps, wgt, shift, adjoint, nullptr, nullptr, out, d_packed);
+            const jq_timing t1 = h->timing;
+            const size_t npk = (size_t)2 + 2 * (size_t)ncoeff;
+            if (rc == JQ_OK && d_packed) {
+                if (npk > h->cap_pk2) {
+                    if ((rc = dev_alloc(h, &h->d_pk2, npk)) == JQ_OK) h->cap_pk2 = npk;
+                }
+                if (rc == JQ_OK && hipMemcpyAsync(h->d_pk2, d_packed, npk * sizeof(double), hipMemcpyDeviceToDevice, h->stream) != hipSuccess)
+                    rc = fail(h, JQ_EHIP, "hipMemcpyAsync (packed result of the first part of a split batch)");
+            }
+            if (rc == JQ_OK) rc = run_eval(h, pcof, ncoeff, n2, eps + n1, wgt ? wgt + n1 : nullptr, shift, adjoint, nullptr, nullptr, &o2, d_packed);
+            h->in_split = false;
+            if (rc != JQ_OK) return rc;
+            if (d_packed) {
+                hipLaunchKernelGGL(k_add_to, dim3((unsigned)((npk + 255) / 256)), dim3(256), 0, h->stream, d_packed, h->d_pk2, (int)npk);
+                HIPCHK(h, hipGetLastError());
+                HIPCHK(h, hipStreamSynchronize(h->stream));
+            }
+            out->res.insert(out->res.end(), o2.res.begin(), o2.res.end());
+            for (size_t i = 0; i < out->grad0.size() && i < o2.grad0.size(); ++i) out->grad0[i] += o2.grad0[i];
+            for (size_t i = 0; i < out->grad1.size() && i < o2.grad1.size(); ++i) out->grad1[i] += o2.grad1[i];
+            // timing: sums; the kernel family / size / band reported are those of the first (larger) part
+            h->timing.ms_total += t1.ms_total, h->timing.ms_propagate += t1.ms_propagate, h->timing.ms_generate += t1.ms_generate;
+            h->timing.ms_forward += t1.ms_forward, h->timing.ms_backward += t1.ms_backward;
+            h->timing.n_forward_launches += t1.n_forward_launches, h->timing.n_backward_launches += t1.n_backward_launches;
+            h->timing.mfma_executed += t1.mfma_executed, h->timing.mfma_backward += t1.mfma_backward, h->timing.svts += t1.svts;
+            h->timing.kernel_family = t1.kernel_family, h->timing.kernel_size = t1.kernel_size, h->timing.kernel_band = t1.kernel_band;
+            return JQ_OK;
+        }
+    }
     const int Nsig = 2 * h->Nc;
     // src/evalobjgrad.jl:604-606
     if (ncoeff % Nsig != 0 || ncoeff < 3 * Nsig) {
@@ -1291,11 +1362,11 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     // JQ_BW_T4 structure, small batches: the quad-layout kernels (one workgroup per slab, its four waves carry four columns
     // each; 3 x shorter dependent chain than the cooperative kernels).  JQ_QUAD=0 disables them.
     // Which kernels for nslabs slabs of this structure?  Time of one round relative to the slab kernels' round of 4 #CU slabs
-    // (measured at cnot3): quad layout with 1 / 2 / 3 slabs per workgroup 0.34 / 0.50 / 0.68 for #CU / 2 #CU /
+    // (measured at cnot3): quad layout with 1 / 2 / 3 slabs per workgroup 0.29 / 0.47 / 0.615 for #CU / 2 #CU /
     // 3 #CU slabs.  Fewest "round units" wins; spw = 0: slab kernels.
     int spw = 0;
     if (!imr && !lane && !rl && h->solver_id == 1 && nslabs <= h->quad_max_slabs) {
-        const double rel[4] = {1.0, 0.34, 0.50, 0.68};
+        const double rel[4] = {1.0, 0.29, 0.47, 0.615};      // (round 2: 0.553 / 0.90 / 1.177 s against 1.917 s)
         auto quad_lds = [&](int k) {    // backward kernel, k slabs per workgroup
             return (size_t)(2 * JQ_WIN_TPS + 2 * h->Nc) * h->mat_elems * 8 + (size_t)bwd_lds_tail(h->NT, h->Nc, 4 * k, (long long)h->NT * 64);
         };

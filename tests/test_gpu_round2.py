@@ -400,3 +400,58 @@ def test_random_kronecker_problems_take_the_embedded_kernels(hip, dims, N, nq):
             r = oracle_sample(p, pcof, ep, shift)
             inf += wq * r["primaryobjf"]; leak += wq * r["secondaryobjf"]; gi += wq * r["infidelgrad"]
         assert abs(a[0] - inf) <= 1e-9 * abs(inf) and abs(a[1] - leak) <= 1e-9 * abs(leak) and rel(a[2], gi) < 1e-9
+
+
+# ---- split batches (ensembles that do not fill their last round of the three-slab quad-layout kernels) -------------------
+def test_split_batches_give_the_results_of_the_unsplit_batch(hip):
+    """3 x #CU x 4 + 131 cnot3 samples (60 time steps): run_eval evaluates the full round(s) on the three-slab quad-layout
+    kernels and the remainder on the cooperative-quad kernels (two batches); JQ_NOSPLIT=1 evaluates one batch.  Same ensemble
+    sums (host outputs and the device-resident packed vector), same per-sample objectives, and the remainder's samples
+    against the oracle."""
+    import ctypes
+    from juqbox_jl_amd import _lib
+    from juqbox_jl_amd.evalobjgrad import _f64, _ptr
+    jq = hip
+    params, info = jq.cases.cnot3()
+    params.nsteps = 60
+    params.T = params.T * 60 / 32386
+    pcof = np.array(json.load(open(os.path.join(ROOT, "tests", "golden", "cnot3.json")))["pcof0"])
+    wa = jq.Working_Arrays_HIP(params, pcof.size)
+    L = _lib.load()
+    hiprt = ctypes.CDLL("libamdhip64.so")      # (device memory for the packed result without pulling torch into this process)
+    npk = 2 + 2 * pcof.size
+    d_packed = ctypes.c_void_p()
+    assert hiprt.hipMalloc(ctypes.byref(d_packed), ctypes.c_size_t(8 * npk)) == 0
+    ncu = 256                                   # MI355X; the launch-count assertion below fails loudly on another CU count
+    ns = 3 * ncu * 4 + 131
+    nodes, weights, shift = jq.cases.cnot3_ensemble(ns)
+    weights = weights * (1.0 + 0.3 * np.cos(np.arange(ns)))      # (not uniform: a mix-up of the two parts' weights would show)
+    res = {}
+    for tag in ("split", "nosplit"):
+        if tag == "nosplit":
+            os.environ["JQ_NOSPLIT"] = "1"
+        try:
+            jq.eval_f_g_grad(pcof, params, wa, nodes, weights, True, shift=shift)
+            t = wa.last_timing()
+            _lib.check(L.jq_eval_f_g_grad_dev(wa.handle, _ptr(_f64(pcof)), pcof.size, _ptr(_f64(nodes)), _ptr(_f64(weights)), ns,
+                                              _ptr(_f64(shift)), 1, d_packed), wa.handle)
+            packed = np.zeros(npk)
+            assert hiprt.hipMemcpy(packed.ctypes.data_as(ctypes.c_void_p), d_packed, ctypes.c_size_t(8 * npk), 2) == 0      # DeviceToHost
+            sweep = jq.traceobj_sweep(pcof, params, wa, nodes, shift=shift)
+        finally:
+            os.environ.pop("JQ_NOSPLIT", None)
+        res[tag] = (params.last_infidelity, params.last_leak, params.last_infidelity_grad.copy(), packed, np.asarray(sweep),
+                    t["n_forward_launches"], t["svts"])
+    a, b = res["split"], res["nosplit"]
+    assert a[5] == 2 * b[5] and a[6] == b[6] == ns * 4 * 60       # two batches, every column counted once
+    assert abs(a[0] - b[0]) <= 1e-13 * abs(b[0]) and abs(a[1] - b[1]) <= 1e-13 * abs(b[1])
+    assert rel(a[2], b[2]) < 1e-12
+    assert rel(a[3], b[3]) < 1e-12
+    assert abs(a[3][0] - a[0]) <= 1e-13 * abs(a[0]) and rel(a[3][2:2 + pcof.size], a[2]) < 1e-12
+    assert np.max(np.abs(a[4] - b[4])) < 1e-12
+    # the first and the last sample of the remainder against the oracle
+    for j in (ns - 131, ns - 1):
+        r = oracle_sample(params, pcof, nodes[j], shift, evaladjoint=False)
+        assert abs(a[4][j, 0] - r["objfv"]) <= 1e-10 * abs(r["objfv"])
+    hiprt.hipFree(d_packed)
+    wa.close()
