@@ -1263,10 +1263,17 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     // faster -- the remainder on whatever suits ITS size (3 200 samples: 1.18 + 0.21 s on the cooperative-quad kernels).
     // Samples are independent and the results are sums over samples, so only the order of those sums changes.
     if (!h->in_split && h->quad_max_slabs > 0 && h->integrator == 1 && h->solver_id == 1 && !hist_r && eps && nsamples > 1 && !getenv("JQ_NOSPLIT")) {
-        const long long per_round = 3LL * h->num_cu * (h->parts > 1 ? 1 : h->sps) / (h->parts > 1 ? h->parts : 1);      // samples of a full three-slab round
-        const long long n_main = per_round > 0 ? (long long)nsamples / per_round * per_round : 0;
-        if (n_main > 0 && n_main < nsamples &&
-            t4_plan_cost(h, n_main) + t4_plan_cost(h, nsamples - n_main) < t4_plan_cost(h, nsamples) - 1e-9) {
+        // candidates: the largest number of FULL rounds of the quad-layout kernels with 1, 2 or 3 slabs per workgroup
+        long long n_main = 0;
+        double best = t4_plan_cost(h, nsamples) - 1e-9;
+        for (int k = 1; k <= 3; ++k) {
+            const long long per_round = (long long)k * h->num_cu * (h->parts > 1 ? 1 : h->sps) / (h->parts > 1 ? h->parts : 1);      // samples of a full round
+            const long long nm = per_round > 0 ? (long long)nsamples / per_round * per_round : 0;
+            if (nm <= 0 || nm >= nsamples) continue;
+            const double c = t4_plan_cost(h, nm) + t4_plan_cost(h, nsamples - nm);
+            if (c < best) best = c, n_main = nm;
+        }
+        if (n_main > 0) {
             h->in_split = true;
             EvalOut o2;
             const int n1 = (int)n_main, n2 = nsamples - n1;

@@ -6,7 +6,7 @@ import juqbox_jl_amd as jq
 params, info = jq.cases.cnot3()
 pcof = np.array(json.load(open("tests/golden/cnot3.json"))["pcof0"])
 wa = jq.Working_Arrays_HIP(params, pcof.size)
-for ns in (3100, 3200, 3500, 4096, 5000, 6400):
+for ns in (300, 600, 1100, 1500, 2200, 2600, 3200, 4096, 5000):
     n2, w2, s2 = jq.cases.cnot3_ensemble(ns)
     line = "%5d samples:" % ns
     ref = None
