@@ -338,6 +338,33 @@ def main():
                 other[str(ns)] = {"evals_per_s": ns / (t2["ms_total"] * 1e-3), "ms": t2["ms_total"], "kernel_family": t2["kernel_family"],
                                   "kernel_band": t2["kernel_band"]}
             out["other_batch_sizes"] = other
+            # the other BASELINE.json configurations (parity-test cases, not bench lines): time of one evaluation on this GPU --
+            # single samples and, for the risk-neutral SWAP-02 case, its 512-node ensemble; Ntot <= 16: VALU row-lane kernels,
+            # no MFMA percentage is quoted
+            try:
+                cfgs = {}
+                for cname, nq in (("cnot1", 1), ("cnot2", 1), ("swap02_rn", 512)):
+                    pc, ic = jq.cases.BUILDERS[cname]()
+                    if ic.get("golden"):
+                        gj = json.load(open(os.path.join(ROOT, "tests", "golden", "%s.json" % ic["golden"])))
+                        pcf = np.array(gj["pcof0"]) if "pcof0" in gj else ic["pcof0"]
+                    else:
+                        pcf = ic["pcof0"]
+                    wc = jq.Working_Arrays_HIP(pc, pcf.size)
+                    if nq == 1:
+                        nd, wq, shc = np.zeros(1), np.ones(1), None
+                    else:
+                        xq, wq = np.polynomial.legendre.leggauss(nq)
+                        nd, wq, shc = xq * 0.5 * 2 * np.pi * 2e-2, wq * 0.5, pc.shift_weights_reference()
+                    for _ in range(2):
+                        jq.eval_f_g_grad(pcf, pc, wc, nd, wq, True, shift=shc)
+                    tc = wc.last_timing()
+                    cfgs[cname] = {"Ntot": int(pc.Ntot), "nsteps": int(pc.nsteps), "samples": nq, "ms_per_evaluation": tc["ms_total"],
+                                   "svts_per_s": tc["svts"] / (tc["ms_total"] * 1e-3), "kernel_family": tc["kernel_family"]}
+                    wc.close()
+                out["baseline_configs"] = cfgs
+            except Exception as e:  # noqa: BLE001  (never let a side measurement take the bench line down)
+                out["baseline_configs"] = {"error": repr(e)}
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(params, pcof)
         print(json.dumps(out), flush=True)
