@@ -127,3 +127,27 @@ def test_bench_refuses_a_gpu_count_it_cannot_see():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                        timeout=600, env=env)
     assert r.returncode != 0 and "does not match WORLD_SIZE" in r.stderr
+
+
+def build_c_demo(tmp_path):
+    """examples/c_abi_demo.c against include/juqbox_hip.h and the in-tree library (gcc: the ABI is plain C)."""
+    import subprocess
+    exe = os.path.join(str(tmp_path), "c_abi_demo")
+    lib_dir = os.path.join(ROOT, "juqbox.jl_amd")
+    r = subprocess.run(["gcc", "-O2", "-Wall", "-Werror", "-std=c99", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "c_abi_demo.c"), "-o", exe, "-L" + lib_dir, "-ljuqbox_hip", "-lm",
+                        "-Wl,-rpath," + lib_dir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_the_header_is_plain_c_and_a_c_program_links_against_the_library(tmp_path):
+    """The boundary is a C ABI: a C99 program includes the header, links against libjuqbox_hip.so and -- on a machine
+    without a gfx950 device -- is refused with a message instead of being served by some fallback."""
+    import subprocess
+    from juqbox_jl_amd import _lib
+    exe = build_c_demo(tmp_path)
+    if _lib.load().jq_device_count() >= 1:
+        pytest.skip("a HIP device is visible: tests/test_gpu_parity.py runs the program")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 3 and "no HIP device" in r.stderr and r.stdout == ""

@@ -285,3 +285,26 @@ def test_bench_workload_kernels_reproduce_the_cnot3_golden_at_full_size(hip):
     gt = params.last_infidelity_grad + (params.last_leak_grad if params.objFuncType != 1 else 0.0)
     assert reference_pass(gt, g)
     wa.close()
+
+
+def test_plain_c_caller_gets_the_numbers_of_the_python_mirror(hip, tmp_path):
+    """examples/c_abi_demo.c (rabi case built by hand in C, no Python in the call path) against the Python mirror on the
+    same inputs; the odd-length call returns the code of the reference's error (src/evalobjgrad.jl:604-606)."""
+    import subprocess
+    from test_abi import build_c_demo
+    jq = hip
+    exe = build_c_demo(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.split("\n")
+    objfv_c = float(lines[0].split()[1])
+    grad_c = np.array([float(ln.split()[2]) for ln in lines if ln.startswith("grad ")])
+    assert "wrong_length_rc -1" in r.stdout          # JQ_EINVAL
+    params, info = jq.cases.rabi()
+    assert params.nsteps == 57 and params.linear_solver.max_iter == 10      # (what the C program hard-codes)
+    pcof = info["pcof0"]
+    wa = jq.Working_Arrays_HIP(params, pcof.size)
+    objfv, tg, *_ = jq.traceobjgrad(pcof, params, wa, False, True)
+    assert abs(objfv_c - objfv) <= 1e-13 * max(abs(objfv), 1e-3)
+    assert np.max(np.abs(grad_c - tg)) <= 1e-13
+    wa.close()
