@@ -1944,8 +1944,7 @@ extern "C" int jq_traceobj_sweep(jq_handle* h, const double* pcof, int32_t ncoef
 // The quadrature nodes of eval_f_g_grad! are block-partitioned over the devices (jq_shard_bounds), every device evaluates
 // its shard concurrently (one host thread per device, each on its device's own stream) and the packed results
 // [infidelity, leak, grad_infid(nCoeff), grad_leak(nCoeff)] are summed with ONE ncclAllReduce (RCCL over xGMI).
-// librccl is loaded at run time (only multi-device callers need it); a library already mapped into the process -- e.g.
-// the one PyTorch ships -- is reused.
+// librccl is loaded at run time (only multi-device callers need it): the copy that belongs to the HIP runtime in use (load_rccl).
 struct RcclApi {
     void* lib = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
@@ -1960,10 +1959,29 @@ static RcclApi g_rccl;
 static int load_rccl(std::string* err)
 {
     if (g_rccl.lib) return JQ_OK;
+    // RCCL must sit on the SAME HIP / HSA runtime as this library.  A process may carry two ROCm copies -- PyTorch ships
+    // libamdhip64, libhsa-runtime64 and librccl side by side, and `import torch` maps them without initialising them -- and an
+    // RCCL on the other copy finds an uninitialised HSA runtime ("no ROCm-capable device is detected").  So the librccl NEXT TO
+    // the HIP runtime this library is bound to comes first (whether or not it is mapped already), then any librccl that is
+    // mapped, then the loader's search path.
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void* lib = nullptr;
-    for (const char* n : names)
-        if ((lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+    {
+        Dl_info di;
+        if (dladdr((void*)&hipGetDeviceCount, &di) && di.dli_fname) {
+            std::string dir(di.dli_fname);
+            const size_t sl = dir.rfind('/');
+            if (sl != std::string::npos) {
+                dir.resize(sl + 1);
+                for (const char* n : {"librccl.so.1", "librccl.so"})
+                    if ((lib = dlopen((dir + n).c_str(), RTLD_NOW | RTLD_LOCAL))) break;
+            }
+        }
+    }
+    for (const char* n : names) {
+        if (lib) break;
+        lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+    }
     for (const char* n : names) {
         if (lib) break;
         lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);

@@ -418,9 +418,11 @@ def test_split_batches_give_the_results_of_the_unsplit_batch(hip):
     pcof = np.array(json.load(open(os.path.join(ROOT, "tests", "golden", "cnot3.json")))["pcof0"])
     wa = jq.Working_Arrays_HIP(params, pcof.size)
     L = _lib.load()
-    hiprt = ctypes.CDLL("libamdhip64.so")      # (device memory for the packed result without pulling torch into this process)
+    hiprt = L      # (device memory for the packed result from the HIP runtime the library itself is bound to: dlsym on its handle
+                   #  searches its dependencies -- a second copy of the runtime, e.g. PyTorch's, may not see the device here)
     npk = 2 + 2 * pcof.size
     d_packed = ctypes.c_void_p()
+    hiprt.hipMalloc.restype = hiprt.hipMemcpy.restype = hiprt.hipFree.restype = ctypes.c_int
     assert hiprt.hipMalloc(ctypes.byref(d_packed), ctypes.c_size_t(8 * npk)) == 0
     ncu = 256                                   # MI355X; the launch-count assertion below fails loudly on another CU count
     ns = 3 * ncu * 4 + 131
