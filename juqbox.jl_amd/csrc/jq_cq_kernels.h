@@ -111,33 +111,40 @@ struct WinRing {
 #endif
 typedef __attribute__((address_space(3))) double jq_lds_double;
 // Exchange image in LDS: [2 parities][3 channels][NT + 2 blocks][64] doubles -- a zero block in front of and behind the NT
-// blocks of a channel, so that the neighbours of the edge blocks need no clamping and every access is ONE base register
-// (this wave's block of ITS channel in the current parity) plus a compile-time offset.  Channel 0: forward sweep / state
-// chain of the backward sweep; channel 1: adjoint chain; channel 2: its second vector of the last publication of a step.
+// blocks of a channel, so that the neighbours of the edge blocks need no clamping.  Channel 0: forward sweep / state chain of
+// the backward sweep; channel 1: adjoint chain; channel 2: its second vector of the last publication of a step.
+// Every access is ONE base register -- block mt-1 of channel 0 in parity 0, this lane -- plus a COMPILE-TIME offset: the parity
+// P and the channel C of every publication are template arguments.  (A run-time parity cost three instructions per publication
+// -- address add, sign flip, neighbour address -- of the ~20 a Neumann publication consists of.)  Publication k of a chunk goes
+// to parity k & 1; a time step has an odd number of publications, 5 + 2 m, so the time loop is written for two steps (start
+// parity 0, then 1) and the kernels are instantiated for even and odd m (MODD).
 //
-// A publication has two phases: post(x) writes the wave's block, sync() waits for everybody's; the part of the products that
-// needs only the wave's own block (MFMA, lane shifts, (i, i+-4) terms: own()) runs BETWEEN them, under the latency of the LDS
-// write and the barrier, the two (i, i+-16) terms that need the neighbours' blocks (nbr()) behind the barrier.
+// A publication has two phases: post(x) writes the wave's block, sync() waits for everybody's.  The products are split into the
+// part that needs only the wave's own block (MFMA, lane shifts, (i, i+-4) terms: own()) and the two (i, i+-16) terms with the
+// neighbours' blocks (nbr()); own() is written between post() and sync(), and hipcc is left free to place it: it keeps the MFMA
+// under the latency of the LDS write and moves the shifts and FMAs BEHIND the barrier, where they run while the neighbours'
+// blocks are being read.  (Pinning all of own() in front of the barrier was measured 13 % slower per Neumann publication: an
+// instruction in front of the barrier delays everybody's arrival, one behind it hides in the read latency.)
 template <int NT>
 struct CoopQ {
     static constexpr int CHS = (NT + 2) * 64;       // doubles per channel
-    static constexpr int PAR = 3 * CHS;              // doubles per parity (channel 2: the adjoint chain's second vector of its last publication)
+    static constexpr int PAR = 3 * CHS;              // doubles per parity
     WinRing ring;
-    jq_lds_double* xp;  // my block of my channel in the parity that holds the published vectors
-    int delta;          // doubles from that parity to the other one (+-PAR)
+    jq_lds_double* xb;  // block mt-1 (pad block for mt = 0) of channel 0 in parity 0, this lane
     int mt;             // my block
     int lane;
 
-    __device__ __forceinline__ void setup(double* xbuf, int blk, int lane_, int ch = 0)
+    __device__ __forceinline__ void setup(double* xbuf, int blk, int lane_)
     {
         mt = blk, lane = lane_;
         for (int i = threadIdx.x; i < 2 * PAR; i += blockDim.x) xbuf[i] = 0.0;      // (the pads stay zero)
-        xp = (jq_lds_double*)(xbuf + ch * CHS + (1 + blk) * 64 + lane_);
-        delta = PAR;
+        xb = (jq_lds_double*)(xbuf + blk * 64 + lane_);
     }
-    __device__ __forceinline__ void post(double x) { xp[delta] = x; }
-    template <int OFF>
-    __device__ __forceinline__ void post_at(double x) { xp[delta + OFF] = x; }
+    // my block of channel C, parity P
+    template <int P, int C>
+    __device__ __forceinline__ void post(double x) { xb[P * PAR + C * CHS + 64] = x; }
+    template <int P, int C>
+    __device__ __forceinline__ double block() const { return xb[P * PAR + C * CHS + 64]; }
     template <bool DMA = false>
     __device__ __forceinline__ void sync()
     {
@@ -147,8 +154,6 @@ struct CoopQ {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        xp += delta;
-        delta = -delta;
     }
     // my block of an operator image (LDS, lane offset applied): A operand of the MFMA + the four coupling coefficients of my row
     struct Op {
@@ -179,15 +184,15 @@ struct CoopQ {
         acc = fma(o.c[0], s.dn, acc);
         return fma(o.c[1], s.up, acc);
     }
-    // the neighbours' blocks of the published vector (OFF = 0: my channel, +-CHS: the other chain's)
+    // the neighbours' blocks of the vector published in channel C, parity P
     struct Nb {
         double b, a;
     };
-    template <int OFF = 0>
+    template <int P, int C>
     __device__ __forceinline__ Nb nbs() const
     {
         Nb n;
-        n.b = xp[OFF - 64], n.a = xp[OFF + 64];
+        n.b = xb[P * PAR + C * CHS], n.a = xb[P * PAR + C * CHS + 128];
         return n;
     }
     __device__ __forceinline__ double nbr(double acc, const Op& o, const Nb& n) const
@@ -195,15 +200,19 @@ struct CoopQ {
         acc = fma(o.c[2], n.b, acc);      // (the coefficients of a missing neighbour are zero)
         return fma(o.c[3], n.a, acc);
     }
-    // my block of the vector that the OTHER chain published at the last barrier (OFF = +-CHS: where its channel is)
-    template <int OFF>
-    __device__ __forceinline__ double other() const
+    // one publication of a Neumann series: Y <- C + S Y
+    template <int P, int C>
+    __device__ __forceinline__ double hstep(double Cv, double Y, const Op& S)
     {
-        return xp[OFF];
+        post<P, C>(Y);
+        const double t = own(Cv, S, sh(Y));
+        sync();
+        return nbr(t, S, nbs<P, C>());
     }
-    // base + sum_{j=1..m} S^j A  (Horner form, jq_kernels.h): m publications
+    // base + sum_{j=1..m} S^j A  (Horner form, jq_kernels.h): m publications in channel C, the first one in parity PS; m is odd iff
+    // MODD.  The inner m - 1 publications run in pairs (static parities); the next publication after the series has parity PS ^ MODD.
     // (pre: issues the loads of the operators that the publication AFTER the series needs, one interval ahead)
-    template <typename F>
+    template <int PS, int C, bool MODD, typename F>
     __device__ __forceinline__ double horner(double base, double A, const Op& S, int m, F pre)
     {
         if (m <= 0) {
@@ -211,21 +220,23 @@ struct CoopQ {
             return base;
         }
         double Y = A;
-        for (int j = 1; j < m; ++j) {
-            post(Y);
-            const double t = own(A, S, sh(Y));
-            sync();
-            Y = nbr(t, S, nbs());
+        int q = m - 1;      // inner publications; odd iff m is even
+        constexpr int PA = MODD ? PS : (PS ^ 1);      // parity of the first publication of the pairs
+        if constexpr (!MODD) {
+            Y = hstep<PS, C>(A, Y, S);
+            --q;
+        }
+        for (; q > 0; q -= 2) {
+            Y = hstep<PA, C>(A, Y, S);
+            Y = hstep<PA ^ 1, C>(A, Y, S);
         }
         pre();
-        post(Y);
-        const double t = own(base, S, sh(Y));
-        sync();
-        return nbr(t, S, nbs());
+        return hstep<PA, C>(base, Y, S);      // (the final publication: parity PS ^ ((m - 1) & 1) = PA)
     }
+    template <int PS, int C, bool MODD>
     __device__ __forceinline__ double horner(double base, double A, const Op& S, int m)
     {
-        return horner(base, A, S, m, [] {});
+        return horner<PS, C, MODD>(base, A, S, m, [] {});
     }
 };
 
@@ -266,8 +277,8 @@ template <int NT>
 __device__ __forceinline__ CqOps<NT> cq_first_ops(const CoopQ<NT>& c)
 {
     CqOps<NT> o;
-    o.Kn0 = c.load((const double*)c.ring.smem + c.ring.lane);
-    o.S0 = c.load((const double*)(c.ring.smem + c.ring.stride_b) + c.ring.lane);
+    o.Kn0 = c.load(c.ring.template ks<0, 0>());
+    o.S0 = c.load(c.ring.template ks<1, 0>());
     o.Kp05 = c.load(c.ring.template ks<0, 1>());
     o.S05 = c.load(c.ring.template ks<1, 1>());
     o.Kn1 = c.load(c.ring.template ks<0, 2>());
@@ -287,16 +298,19 @@ __device__ __forceinline__ void cq_next_ops(CoopQ<NT>& c, CqOps<NT>& o)
     o.S1 = c.load(c.ring.template ks<1, 2>());
 }
 
-// state step up to its second-to-last publication: in u, v; out un = u(t+h), v05, vN = v05 + S05 v05 (the caller publishes un
+// Parities of the publications of a time step that starts with parity P0 (both sweeps, both chains):
+//   I1: P0   I2: P0^1   first Neumann series: from P0   I3: P0^M   I4: P0^M^1   second series: from P0^M   I5: P0      (M = m & 1)
+// State step up to its second-to-last publication: in u, v; out un = u(t+h), v05, vN = v05 + S05 v05 (the caller publishes un
 // once more and adds Kp05 un).
-template <int NT>
+template <int NT, int P0, bool MODD>
 __device__ __forceinline__ void cq_state(CoopQ<NT>& c, const PropArgs& a, const CqOps<NT>& o, double cw, double u, double v, double& un,
                                          double& v05, double& vN)
 {
     typedef typename CoopQ<NT>::Sh Sh;
     typedef typename CoopQ<NT>::Nb Nb;
+    constexpr int M = MODD ? 1 : 0;
     // x = u: A = c K05 u ; P = u + c S0 u
-    c.post(u);
+    c.template post<P0, 0>(u);
     double A, P;
     {
         const Sh s = c.sh(u);
@@ -304,18 +318,18 @@ __device__ __forceinline__ void cq_state(CoopQ<NT>& c, const PropArgs& a, const 
         P = c.own(u, o.S0, s);
         if (a.use_shift) A = fma(cw, u, A);
         c.sync();
-        const Nb n = c.nbs();
+        const Nb n = c.template nbs<P0, 0>();
         A = c.nbr(A, o.Kp05, n);
         P = c.nbr(P, o.S0, n);
     }
     // x = v: A = c (K05 u + S05 v) ; v05 = v + sum_j S^j A
-    c.post(v);
+    c.template post<P0 ^ 1, 0>(v);
     A = c.own(A, o.S05, c.sh(v));
     c.sync();
-    A = c.nbr(A, o.S05, c.nbs());
-    v05 = c.horner(v + A, A, o.S05, a.m);
+    A = c.nbr(A, o.S05, c.template nbs<P0 ^ 1, 0>());
+    v05 = c.template horner<P0, 0, MODD>(v + A, A, o.S05, a.m);
     // x = v05: vN = v05 + c S05 v05 ; un = u + c (S0 u - K0 v05) ; A = -c K1 v05
-    c.post(v05);
+    c.template post<P0 ^ M, 0>(v05);
     {
         const Sh s = c.sh(v05);
         vN = c.own(v05, o.S05, s);
@@ -326,17 +340,17 @@ __device__ __forceinline__ void cq_state(CoopQ<NT>& c, const PropArgs& a, const 
             A = fma(-cw, v05, A);
         }
         c.sync();
-        const Nb n = c.nbs();
+        const Nb n = c.template nbs<P0 ^ M, 0>();
         vN = c.nbr(vN, o.S05, n);
         un = c.nbr(un, o.Kn0, n);
         A = c.nbr(A, o.Kn1, n);
     }
     // x = un: A = c (S1 un - K1 v05) ; un += sum_j S^j A
-    c.post(un);
+    c.template post<P0 ^ M ^ 1, 0>(un);
     A = c.own(A, o.S1, c.sh(un));
     c.sync();
-    A = c.nbr(A, o.S1, c.nbs());
-    un = c.horner(un + A, A, o.S1, a.m);
+    A = c.nbr(A, o.S1, c.template nbs<P0 ^ M ^ 1, 0>());
+    un = c.template horner<P0 ^ M, 0, MODD>(un + A, A, o.S1, a.m);
 }
 
 template <int NT>
@@ -377,7 +391,7 @@ __device__ __forceinline__ CqSetup<NT> cq_setup(const PropArgs& a)
 // The two extra waves only stage: they pass the barriers and, behind the last one of step n, issue the DMA of the time points
 // 2n+5, 2n+6 into the slots of 2n, 2n+1 (whose operators everybody has loaded) -- ~25 instructions per step that would
 // otherwise sit on the critical path of the six propagating waves (a wave issues one instruction every ~10 cycles).
-template <int NT>
+template <int NT, bool MODD>
 __global__ __launch_bounds__(64 * NT + 128) void k_forward_cq(PropArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -416,16 +430,18 @@ __global__ __launch_bounds__(64 * NT + 128) void k_forward_cq(PropArgs a)
     const double cw = 0.5 * a.h * a.colinfo[(size_t)s.slab * 32 + s.col] * wsr;      // h/2 eps ws[row]
     CqOps<NT> o = cq_first_ops<NT>(c);
 
-    for (int n = 0; n < a.nsteps_chunk; ++n) {
+    // one time step whose first publication has parity P0 (the next step's has P0 ^ 1: 5 + 2 m publications)
+    auto step = [&](auto P0c, int n) {
+        constexpr int P0 = decltype(P0c)::value;
         leak = fma(wdr, u * u, leak);      // trapezoidal part at t_n (src/evalobjgrad.jl:700)
         double un, v05, vN;
-        cq_state<NT>(c, a, o, cw, u, v, un, v05, vN);
+        cq_state<NT, P0, MODD>(c, a, o, cw, u, v, un, v05, vN);
         // Kp05 again: v(t+h) = v05 + c (K05 u_new + S05 v05)
-        c.post(un);
+        c.template post<P0, 0>(un);
         v = c.own(vN, o.Kp05, c.sh(un));
         if (a.use_shift) v = fma(cw, un, v);
         c.sync();
-        v = c.nbr(v, o.Kp05, c.nbs());
+        v = c.nbr(v, o.Kp05, c.template nbs<P0, 0>());
         cq_next_ops<NT>(c, o);      // (the staging waves drained the DMA of its time points in front of this barrier)
         u = un;
         leak += wdr * (u * u) + 2.0 * (wdr * (v05 * v05));      // (:716, penalf2a :2170-2180)
@@ -438,8 +454,14 @@ __global__ __launch_bounds__(64 * NT + 128) void k_forward_cq(PropArgs a)
                 a.hist_i[off] = -v;
             }
         }
+    };
+    int n = 0;
+    for (; n + 1 < a.nsteps_chunk; n += 2) {
+        step(std::integral_constant<int, 0>{}, n);
+        step(std::integral_constant<int, 1>{}, n + 1);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (nothing is in flight: every fetched time point was waited for)
+    if (n < a.nsteps_chunk) step(std::integral_constant<int, 0>{}, n);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     st[s.foff] = u;
     st[(size_t)KT * 64 + s.foff] = v;
     const double tot = cq_wg_sum(leak, scratch, wave, lane_, NT);
@@ -458,12 +480,12 @@ __global__ __launch_bounds__(64 * NT + 128) void k_forward_cq(PropArgs a)
 // finishes the four sums with rotate-adds inside the rows and writes them to the trace record of the step.
 //   group q < Nc (adjoint wave):  rows 0, 1, 2 = t1, t4, t3 of control q
 //   group Nc + j (state wave):    rows 0, 1 = t2, t5 of control 2 j, rows 2, 3 = t2, t5 of control 2 j + 1
-template <int NT>
+template <int NT, bool MODD>
 __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KT = 4 * NT;
-    constexpr int CH = CoopQ<NT>::CHS;
+    constexpr int M = MODD ? 1 : 0;
     typedef typename CoopQ<NT>::Sh Sh;
     typedef typename CoopQ<NT>::Nb Nb;
     typedef typename CoopQ<NT>::Op Op;
@@ -484,7 +506,7 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
     double* scratch = tab + 32 * NT + 2 * CoopQ<NT>::PAR;      // [2 NT][64]
     const int ntr = Nc * JQ_NTR, ngroups = Nc + (Nc + 1) / 2;
     double* red = scratch + 2 * NT * 64;                        // [ngroups][NT][64]
-    c.setup(tab + 32 * NT, wave, lane_, s.chain);
+    c.setup(tab + 32 * NT, wave, lane_);
     c.ring.init(smem, a, wave_all, lane_, 2 * NT);
     c.ring.wave = wave, c.ring.nwaves = NT;      // (from here on the state waves stage)
     const double wdr = tab[16 * wave + s.g], wsr = tab[16 * NT + 16 * wave + s.g];
@@ -523,16 +545,17 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
         // ---- state re-integration (src/evalobjgrad.jl:879), channel 0; traces t2 = tr(vi05' Hsym_q X), t5 = tr(vi05' Hanti_q (li0+li))
         double u = st[s.foff], v = st[(size_t)KT * 64 + s.foff];
         Op Kp05 = c.load(c.ring.template ks<0, 1>()), S0 = c.load(c.ring.template ks<1, 0>());
-        if (a.first_chunk) {      // (vr(T) for the carry products of the adjoint waves)
-            c.post(u);
+        if (a.first_chunk) {      // (vr(T) for the carry products of the adjoint waves; parity 1: the first step starts with 0)
+            c.template post<1, 0>(u);
             c.sync();
         }
         JQ_TS_DECL
-        for (int n = 0; n < a.nsteps_chunk; ++n) {
+        auto step = [&](auto P0c, int n) {
+            constexpr int P0 = decltype(P0c)::value;
             JQ_TS(n)
             double un, v05, vN, t2[JQ_MAXNC];
             // x = u: A = c K05 u ; P = u + c S0 u
-            c.post(u);
+            c.template post<P0, 0>(u);
             const Op S05 = c.load(c.ring.template ks<1, 1>());
             double A, P;
             {
@@ -543,25 +566,25 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
                 JQ_TS(n)
                 c.sync();
                 JQ_TS(n)
-                const Nb nn = c.nbs();
+                const Nb nn = c.template nbs<P0, 0>();
                 A = c.nbr(A, Kp05, nn);
                 P = c.nbr(P, S0, nn);
             }
             // x = v: A = c (K05 u + S05 v) ; v05 = v + sum_j S^j A
-            c.post(v);
+            c.template post<P0 ^ 1, 0>(v);
             A = c.own(A, S05, c.sh(v));
             JQ_TS(n)
             c.sync();
             JQ_TS(n)
-            A = c.nbr(A, S05, c.nbs());
+            A = c.nbr(A, S05, c.template nbs<P0 ^ 1, 0>());
             Op Kn0, Kn1;
-            v05 = c.horner(v + A, A, S05, a.m, [&] {
+            v05 = c.template horner<P0, 0, MODD>(v + A, A, S05, a.m, [&] {
                 Kn0 = c.load(c.ring.template ks<0, 0>());
                 Kn1 = c.load(c.ring.template ks<0, 2>());
             });
             JQ_TS(n)
             // x = v05: vN = v05 + c S05 v05 ; un = u + c (S0 u - K0 v05) ; A = -c K1 v05
-            c.post(v05);
+            c.template post<P0 ^ M, 0>(v05);
             const Op S1 = c.load(c.ring.template ks<1, 2>());
             {
                 const Sh sx = c.sh(v05);
@@ -575,19 +598,19 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
                 JQ_TS(n)
                 c.sync();
                 JQ_TS(n)
-                const Nb nn = c.nbs();
+                const Nb nn = c.template nbs<P0 ^ M, 0>();
                 vN = c.nbr(vN, S05, nn);
                 un = c.nbr(un, Kn0, nn);
                 A = c.nbr(A, Kn1, nn);
             }
             const double v05w = v05 * wgt;
             // x = un: A = c (S1 un - K1 v05)
-            c.post(un);
+            c.template post<P0 ^ M ^ 1, 0>(un);
             A = c.own(A, S1, c.sh(un));
             // (under the barrier: the adjoint chain's X of the last publication)
             {
-                const Sh sx = c.sh(c.template other<CH>());
-                const Nb nx = c.template nbs<CH>();
+                const Sh sx = c.sh(c.template block<P0 ^ M, 1>());
+                const Nb nx = c.template nbs<P0 ^ M, 1>();
 #pragma unroll
                 for (int q = 0; q < JQ_MAXNC; ++q) {
                     t2[q] = 0.0;
@@ -600,17 +623,17 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
             JQ_TS(n)
             c.sync();
             JQ_TS(n)
-            A = c.nbr(A, S1, c.nbs());
-            un = c.horner(un + A, A, S1, a.m, [&] { Kp05 = c.load(c.ring.template ks<0, 1>()); });
+            A = c.nbr(A, S1, c.template nbs<P0 ^ M ^ 1, 0>());
+            un = c.template horner<P0 ^ M, 0, MODD>(un + A, A, S1, a.m, [&] { Kp05 = c.load(c.ring.template ks<0, 1>()); });
             JQ_TS(n)
             // x = un: v(t_n) = v05 + c (K05 un + S05 v05)
-            c.post(un);
+            c.template post<P0, 0>(un);
             v = c.own(vN, Kp05, c.sh(un));
             if (a.use_shift) v = fma(cw, un, v);
             JQ_TS(n)
             c.template sync<true>();
             JQ_TS(n)
-            v = c.nbr(v, Kp05, c.nbs());
+            v = c.nbr(v, Kp05, c.template nbs<P0, 0>());
             // (the time points of the next step have landed; those of this step are dead)
             c.ring.advance();
             Kp05 = c.load(c.ring.template ks<0, 1>());
@@ -625,8 +648,8 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
             u = un;
             // the adjoint chain's -(li0 + li) (channel 2 of the last publication): t5
             {
-                const Sh sx = c.sh(c.template other<2 * CH>());
-                const Nb nx = c.template nbs<2 * CH>();
+                const Sh sx = c.sh(c.template block<P0, 2>());
+                const Nb nx = c.template nbs<P0, 2>();
                 double t5[JQ_MAXNC];
 #pragma unroll
                 for (int q = 0; q < JQ_MAXNC; ++q) {
@@ -639,7 +662,13 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
                 redw[(size_t)Nc * NT * 64] = cq_part4(t2[0], t2[1], t5[0], t5[1]);
                 if (Nc > 2) redw[(size_t)(Nc + 1) * NT * 64] = cq_part4(t2[2], t2[3], t5[2], t5[3]);
             }
+        };
+        int n = 0;
+        for (; n + 1 < a.nsteps_chunk; n += 2) {
+            step(std::integral_constant<int, 0>{}, n);
+            step(std::integral_constant<int, 1>{}, n + 1);
         }
+        if (n < a.nsteps_chunk) step(std::integral_constant<int, 0>{}, n);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();      // (the last hand-off)
         asm volatile("" ::: "memory");
@@ -658,11 +687,11 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
             if (q < Nc && slot0) carry[q] = st[(size_t)(JQ_STATE_ARRAYS * KT + q) * 64 + cslot];
         if (a.first_chunk) {
             // carry_q = tr(vr' Hsym_q lambdai) at t = T (see k_backward)
-            c.post(nb);
+            c.template post<1, 1>(nb);
             const Sh sx = c.sh(nb);
             c.sync();
-            const double u0 = c.template other<-CH>();
-            const Nb nn = c.nbs();
+            const double u0 = c.template block<1, 0>();
+            const Nb nn = c.template nbs<1, 1>();
 #pragma unroll
             for (int q = 0; q < JQ_MAXNC; ++q)
                 if (q < Nc) {
@@ -671,10 +700,11 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
                 }
         }
         JQ_TS_DECL
-        for (int n = 0; n < a.nsteps_chunk; ++n) {
+        auto step = [&](auto P0c, int n) {
+            constexpr int P0 = decltype(P0c)::value;
             JQ_TS(n)
             // x = nb (-lambda_i): L = c K05 nb, Tn = c S05 nb (for the second half of the step)
-            c.post(nb);
+            c.template post<P0, 1>(nb);
             const Op S0 = c.load(c.ring.template ks<1, 0>());
             double L, Tn;
             {
@@ -685,29 +715,29 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
                 JQ_TS(n)
                 c.sync();
                 JQ_TS(n)
-                const Nb nn = c.nbs();
+                const Nb nn = c.template nbs<P0, 1>();
                 L = c.nbr(L, Kp05, nn);
                 Tn = c.nbr(Tn, S05, nn);
             }
-            const double u = c.template other<-CH>();      // vr before the state step (:862)
+            const double u = c.template block<P0, 0>();      // vr before the state step (:862)
             if (n > 0) finish_traces(n - 1);
             // x = mu: L = c (S0 mu - K05 li + hr0) ; X = mu + sum_j S0^j L
-            c.post(mu);
+            c.template post<P0 ^ 1, 1>(mu);
             L = c.own(L, S0, c.sh(mu));
             L = fma(cfw, u, L);
             JQ_TS(n)
             c.sync();
             JQ_TS(n)
-            L = c.nbr(L, S0, c.nbs());
+            L = c.nbr(L, S0, c.template nbs<P0 ^ 1, 1>());
             Op Kn0, Kn1, S1;
-            const double X = c.horner(mu + L, L, S0, a.m, [&] {
+            const double X = c.template horner<P0, 1, MODD>(mu + L, L, S0, a.m, [&] {
                 Kn0 = c.load(c.ring.template ks<0, 0>());
                 Kn1 = c.load(c.ring.template ks<0, 2>());
                 S1 = c.load(c.ring.template ks<1, 2>());
             });
             JQ_TS(n)
             // x = X: Lk = -c K0 X, Q = -c K1 X, SX = c S1 X, Hanti_q X (tr1, tr3)
-            c.post(X);
+            c.template post<P0 ^ M, 1>(X);
             double Lk, Q, SX, Tq[JQ_MAXNC];
             {
                 const Sh sx = c.sh(X);
@@ -721,7 +751,7 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
                 JQ_TS(n)
                 c.sync();
                 JQ_TS(n)
-                const Nb nn = c.nbs();
+                const Nb nn = c.template nbs<P0 ^ M, 1>();
                 Lk = c.nbr(Lk, Kn0, nn);
                 Q = c.nbr(Q, Kn1, nn);
                 SX = c.nbr(SX, S1, nn);
@@ -736,24 +766,24 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
             }
             // Lk = -c l2 = -c (K0 X + S05 li + hi0) ; Q = -c (S05 (li + c l2) + K1 X + hi1)
             {
-                const double v05 = c.template other<-CH>();
+                const double v05 = c.template block<P0 ^ M, 0>();
                 const double Pn = fma(-cfw, v05, Tn);
                 Lk += Pn;
                 Q += Pn;
             }
             // x = Lk: Q += c S05 Lk ; nb_new = nb + Lk + sum_j S05^j Q
-            c.post(Lk);
+            c.template post<P0 ^ M ^ 1, 1>(Lk);
             Q = c.own(Q, S05, c.sh(Lk));
             JQ_TS(n)
             c.sync();
             JQ_TS(n)
-            Q = c.nbr(Q, S05, c.nbs());
-            const double nbn = c.horner((nb + Lk) + Q, Q, S05, a.m);
+            Q = c.nbr(Q, S05, c.template nbs<P0 ^ M ^ 1, 1>());
+            const double nbn = c.template horner<P0 ^ M, 1, MODD>((nb + Lk) + Q, Q, S05, a.m);
             JQ_TS(n)
             const double Bq = nb + nbn;      // -(li0 + li)
             // x = nb_new: lambda_r_new = X + c (S1 X - K05 li_new + hr1), Hsym_q li_new (tr4); vr(t_n) exists behind the barrier
-            c.post(nbn);
-            c.template post_at<CH>(Bq);      // (channel 2: for the state waves' tr5)
+            c.template post<P0, 1>(nbn);
+            c.template post<P0, 2>(Bq);      // (channel 2: for the state waves' tr5)
             double G;
             {
                 const Sh sx = c.sh(nbn);
@@ -763,8 +793,8 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
                 JQ_TS(n)
                 c.sync();
                 JQ_TS(n)
-                const Nb nn = c.nbs();
-                const double un = c.template other<-CH>();
+                const Nb nn = c.template nbs<P0, 1>();
+                const double un = c.template block<P0, 0>();
                 G = c.nbr(G, Kp05, nn);
                 G = fma(cfw, un, G);
                 // (the time points of the next step have landed)
@@ -784,7 +814,13 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
             }
             mu = G;
             nb = nbn;
+        };
+        int n = 0;
+        for (; n + 1 < a.nsteps_chunk; n += 2) {
+            step(std::integral_constant<int, 0>{}, n);
+            step(std::integral_constant<int, 1>{}, n + 1);
         }
+        if (n < a.nsteps_chunk) step(std::integral_constant<int, 0>{}, n);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();      // (the last hand-off)
         asm volatile("" ::: "memory");

@@ -13,8 +13,10 @@
 #endif
 #if JQ_VARIANT == 9     // cooperative-quad (latency) kernels of the JQ_BW_T4 structure (JQ_BW = 7)
 #include "jq_cq_kernels.h"
-template __global__ void k_forward_cq<JQ_NT>(PropArgs);
-template __global__ void k_backward_cq<JQ_NT>(PropArgs);
+template __global__ void k_forward_cq<JQ_NT, false>(PropArgs);
+template __global__ void k_backward_cq<JQ_NT, false>(PropArgs);
+template __global__ void k_forward_cq<JQ_NT, true>(PropArgs);      // (odd number of Neumann terms)
+template __global__ void k_backward_cq<JQ_NT, true>(PropArgs);
 #elif JQ_VARIANT == 7
 #include "jq_quad_imr_kernels.h"
 template __global__ void k_forward_quad_imr<JQ_NT>(PropArgs);
