@@ -19,7 +19,7 @@
 //     shared between the sets, their reductions handed to one wave per group of four values, and the staging is done by the
 //     waves that would otherwise wait (two extra waves in the forward sweep).
 // Same operators, images, state file and trace records as the quad-layout kernels; the regrouping only reorders floating-point
-// additions.  One cnot3 evaluation: 0.54 s on the quad-layout kernels, 0.21 s here.
+// additions.  One cnot3 evaluation: 0.54 s on the quad-layout kernels, 0.20 s here.
 #pragma once
 #include "jq_kernels.h"
 

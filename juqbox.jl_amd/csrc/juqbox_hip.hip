@@ -633,7 +633,7 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         {
             const long long win = (2LL * JQ_WIN_TPS + 2LL * h->Nc) * slot;
             const long long tail = 32LL * h->NT * 8 + (6LL * (h->NT + 2) + 2 * h->NT) * 64 * 8 + (long long)(h->Nc + (h->Nc + 1) / 2) * h->NT * 64 * 8;
-            h->cq_max_quads = (h->BW == JQ_BW_T4 && h->NT >= 2 && h->quad_max_slabs > 0 && win + tail <= 163840) ? 2 * prop.multiProcessorCount : 0;      // (two rounds of them, 2 x 0.21 s at cnot3, still beat one round of the quad-layout kernels, 0.55 s)
+            h->cq_max_quads = (h->BW == JQ_BW_T4 && h->NT >= 2 && h->quad_max_slabs > 0 && win + tail <= 163840) ? 2 * prop.multiProcessorCount : 0;      // (two rounds of them, 2 x 0.20 s at cnot3, still beat one round of the quad-layout kernels, 0.55 s)
             if (const char* e = getenv("JQ_CQ"))
                 if (h->cq_max_quads > 0) h->cq_max_quads = atoi(e);
         }
@@ -1231,13 +1231,13 @@ struct EvalOut {
 };
 
 // JQ_BW_T4 structure, Stormer-Verlet / Neumann: estimated time of one batch in units of a slab-kernel round (4 #CU slabs), by the
-// plan run_eval would choose -- cooperative-quad kernels (<= cq_max_quads column quads: 0.207 s per round of #CU quads against
+// plan run_eval would choose -- cooperative-quad kernels (<= cq_max_quads column quads: 0.196 s per round of #CU quads against
 // 1.917 s at cnot3), quad-layout kernels with 1 / 2 / 3 slabs per workgroup, slab kernels.  (The same figures as in run_eval.)
 static double t4_plan_cost(const jq_handle* h, long long nsamples)
 {
     const long long nslabs = h->parts > 1 ? nsamples * h->parts : (nsamples + h->sps - 1) / h->sps;
     const long long nquads = (nsamples * h->N + 3) / 4;
-    if (h->cq_max_quads > 0 && nquads <= h->cq_max_quads) return 0.108 * (double)((nquads + h->num_cu - 1) / h->num_cu);
+    if (h->cq_max_quads > 0 && nquads <= h->cq_max_quads) return 0.102 * (double)((nquads + h->num_cu - 1) / h->num_cu);
     const double rel[4] = {1.0, 0.29, 0.47, 0.615};
     double best = rel[0] * (double)((nslabs + 4 * h->num_cu - 1) / (4 * h->num_cu));
     if (nslabs <= h->quad_max_slabs)
@@ -1264,7 +1264,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     // Ensembles that do not fill their last round: the time of a batch is a staircase in its size (every workgroup runs the
     // whole sequential time loop; cnot3: 3 072 samples = one round of the three-slab quad-layout kernels 1.18 s, 3 200 samples =
     // two rounds 2.35 s).  A batch of q full rounds + a remainder is evaluated as two batches when the plan says that is
-    // faster -- the remainder on whatever suits ITS size (3 200 samples: 1.18 + 0.21 s on the cooperative-quad kernels).
+    // faster -- the remainder on whatever suits ITS size (3 200 samples: 1.18 + 0.20 s on the cooperative-quad kernels).
     // Samples are independent and the results are sums over samples, so only the order of those sums changes.
     if (!h->in_split && h->quad_max_slabs > 0 && h->integrator == 1 && h->solver_id == 1 && !hist_r && eps && nsamples > 1 && !getenv("JQ_NOSPLIT")) {
         // candidates: the largest number of FULL rounds of the quad-layout kernels with 1, 2 or 3 slabs per workgroup
