@@ -66,10 +66,13 @@ typedef struct jq_problem {
     /* Uncoupled controls (the lab-frame evaluation of a pulse, e.g. examples/cnot2-lab.jl): KS! adds
      * 2 (p_q(t) cos(2 pi Rfreq[q] t) - q_q(t) sin(2 pi Rfreq[q] t)) * Hunc_ops[q] to K when Hunc_ops[q] is symmetric,
      * to S when it is antisymmetric (src/evalobjgrad.jl:2373-2387; anything else is the reference's ArgumentError,
-     * :186-196 -> JQ_EINVAL).  FORWARD evaluations only (objective, state history, populations, sweeps): the reference's
-     * adjoint for this branch cannot run -- gradSize = (2 Ncoupled + Nunc) Nfreq D1 (:801) differs from length(pcof) =
-     * 2 (Ncoupled + Nunc) Nfreq D1, so adjoint_grad_calc!'s axpy! (:2620-2656) throws -- and gradient calls return
-     * JQ_EUNSUPPORTED.  Parity-unpinned in the reference (no golden): checked against the CPU oracle. */
+     * :186-196 -> JQ_EINVAL).  Parity-unpinned in the reference (no golden): checked against the CPU oracle.
+     * Gradients (Stormer-Verlet integrator): the exact gradient of the discrete objective, the traces of Hunc_ops[q] weighted
+     * with grad ft = 2 cos(.) grad p_q - 2 sin(.) grad q_q.  The reference's own code for this (adjoint_grad_calc!, :2620-2656)
+     * is not a usable reference -- it differentiates control functions of an older numbering (func = 2 Ncoupled - 1 + q, no
+     * rotation factor), i.e. not what KS! applies, and throws for objFuncType != 1 (gradSize, :801) -- so this gradient is
+     * pinned by finite differences of the objective (tests/test_uncoupled.py).  Implicit midpoint: JQ_EUNSUPPORTED (the
+     * reference's adjoint_grad_calc_m has no term for uncoupled controls). */
     const double *Hunc_ops;  /* [Nunc][Ntot x Ntot], NULL when Nunc == 0                           */
     const double *Rfreq;     /* [Nunc] rotation frequencies params.Rfreq, NULL when Nunc == 0      */
 } jq_problem;

@@ -331,6 +331,15 @@ __global__ __launch_bounds__(JQ_GRADACC_THREADS) void k_gradacc(SplineArgs s, co
                 P = r[3];
                 Q = -r[4];
             }
+            if (s.rfreq) {
+                // uncoupled control: Hunc_ops[q] sits in ONE slot of pair q (the other image is zero, its traces too) and is
+                // applied with ft = 2 (p cos(2 pi Rfreq t) - q sin(2 pi Rfreq t)): grad ft = 2 cos(.) grad p - 2 sin(.) grad q
+                const double B = P + Q;
+                double sr, cr;
+                sincos(2.0 * M_PI * s.rfreq[q] * tau_t, &sr, &cr);
+                P = 2.0 * cr * B;
+                Q = -2.0 * sr * B;
+            }
             const double tau = (tau_t - tc) / width;
             double b;
             if (jj == 0)

@@ -1342,10 +1342,9 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
             return rc;
         }
     }
-    if (adjoint && !h->rfreq.empty())
-        return fail(h, JQ_EUNSUPPORTED, "uncoupled controls (Hunc_ops): forward evaluations only -- the reference's adjoint for this "
-                                        "branch cannot run (gradSize = (2 Ncoupled + Nunc) Nfreq D1, src/evalobjgrad.jl:801, is not "
-                                        "length(pcof); adjoint_grad_calc!'s axpy!, :2620-2656, throws DimensionMismatch)");
+    if (adjoint && !h->rfreq.empty() && h->integrator != 1)
+        return fail(h, JQ_EUNSUPPORTED, "uncoupled controls (Hunc_ops): gradients with the Stormer-Verlet integrator only (the reference's "
+                                        "implicit-midpoint adjoint has no term for them, src/evalobjgrad.jl:1347)");
 
     const int nslabs = h->parts > 1 ? nsamples * h->parts : (nsamples + h->sps - 1) / h->sps;
     // small batches: cooperative (row-split) kernels, one workgroup of NT waves per slab; large batches: slab

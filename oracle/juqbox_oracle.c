@@ -379,7 +379,24 @@ static double adjoint_trace(const oracle_t *o, const double *A, const double *B,
     return tr;
 }
 
-/* adjoint_grad_calc!: src/evalobjgrad.jl:2567-2656 (coupled controls) */
+/* Uncoupled controls: Hunc_ops[q] is applied with ft(t) = 2 (p_q(t) cos(2 pi Rfreq_q t) - q_q(t) sin(2 pi Rfreq_q t))
+ * (KS!, src/evalobjgrad.jl:2373-2387), so the factor of its traces is grad ft = 2 cos(.) grad p_q - 2 sin(.) grad q_q:
+ * both gradient vectors are replaced by it.  NOT a restatement of the reference here: its adjoint_grad_calc! (:2620-2656)
+ * still differentiates the control functions of an older numbering (func = 2 Ncoupled - 1 + q, no rotation factor), i.e.
+ * something else than KS! applies, and for objFuncType != 1 it throws (gradSize, :801).  This is the gradient of the
+ * discrete objective that the forward sweep above computes; tests pin it by finite differences of that objective. */
+static void unc_combine(const oracle_t *o, int q, double tau, double *gr, double *gi)
+{
+    const double c = 2.0 * cos(2.0 * M_PI * o->Rfreq[q] * tau), s = 2.0 * sin(2.0 * M_PI * o->Rfreq[q] * tau);
+    int i;
+    for (i = 0; i < o->nCoeff; i++) {
+        const double g = c * gr[i] - s * gi[i];
+        gr[i] = g;
+        gi[i] = g;
+    }
+}
+
+/* adjoint_grad_calc!: src/evalobjgrad.jl:2567-2656 (coupled controls; uncoupled ones: see unc_combine) */
 static void adjoint_grad_calc(const oracle_t *o, const double *vr0, const double *vi05, const double *vr,
                               const double *lr05, const double *li, const double *li0, double t0, double dt, double *gr,
                               double *gi, double *grad_step)
@@ -394,6 +411,7 @@ static void adjoint_grad_calc(const oracle_t *o, const double *vr0, const double
         double tr;
         gradbcarrier2(o, t0, qs, gr);
         gradbcarrier2(o, t0, qa, gi);
+        if (o->nunc > 0) unc_combine(o, q, t0, gr, gi);
         tr = adjoint_trace(o, vr0, Ha, pa, lr05);
         axpy(nC, -tr, gi, grad_step);
         tr = adjoint_trace(o, vi05, Hs, ps, lr05);
@@ -401,12 +419,14 @@ static void adjoint_grad_calc(const oracle_t *o, const double *vr0, const double
 
         gradbcarrier2(o, t0 + dt, qs, gr);
         gradbcarrier2(o, t0 + dt, qa, gi);
+        if (o->nunc > 0) unc_combine(o, q, t0 + dt, gr, gi);
         axpy(nC, -tr, gr, grad_step); /* same trace as above (:2596) */
         tr = adjoint_trace(o, vr, Ha, pa, lr05);
         axpy(nC, -tr, gi, grad_step);
 
         gradbcarrier2(o, t0 + 0.5 * dt, qs, gr);
         gradbcarrier2(o, t0 + 0.5 * dt, qa, gi);
+        if (o->nunc > 0) unc_combine(o, q, t0 + 0.5 * dt, gr, gi);
         tr = adjoint_trace(o, vr, Hs, ps, li);
         axpy(nC, tr, gr, grad_step);
         tr = adjoint_trace(o, vr0, Hs, ps, li0);
@@ -559,10 +579,6 @@ int jqo_traceobjgrad(void *h, const double *pcof, int ncoeff, int evaladjoint, d
     work_t w;
     double *vr, *vi, *vi05, *vr0;
     double *buf;
-
-    /* the reference's adjoint for uncoupled controls cannot run: gradSize = (2 Ncoupled + Nunc) Nfreq D1 (:801) is not the
-     * length of pcof / wa.gr, so adjoint_grad_calc!'s axpy!(-tmp, gr, grad_step) (:2620-2656) throws DimensionMismatch */
-    if (o->nunc > 0 && evaladjoint) return -3;
 
     /* :604-606 */
     if (ncoeff % Nsig != 0 || ncoeff < 3 * Nsig) return -1;

@@ -126,8 +126,6 @@ class Oracle:
             raise ValueError("pcof must have an even number of elements >= 3*Nsig")
         if rc == -2:
             raise ValueError("DimensionMismatch: Inconsistent number of coefficients and size of parameter vector")
-        if rc == -3:
-            raise ValueError("DimensionMismatch: the reference's adjoint for uncoupled controls cannot run (gradSize != length(pcof))")
         res = dict(objfv=out[0], primaryobjf=out[1], secondaryobjf=out[2], traceInfidelity=out[3])
         if evaladjoint:
             res.update(totalgrad=tg, infidelgrad=ig, leakgrad=lg)

@@ -1,10 +1,13 @@
 """Uncoupled controls Hunc_ops = the LAB-frame evaluation of a pulse (KS!, src/evalobjgrad.jl:2373-2387; SURVEY.md section 8
-rows a6 / f4).  The reference holds no golden for this branch (parity unpinned) and its adjoint for it cannot run
-(gradSize, :801, is not length(pcof)), so the branch is forward-only here and pinned twice:
- CPU  the oracle's restatement against PHYSICS: the same optimised pulse (examples/drives/cnot2-pcof-opt-t50.jld2) evaluated in
-      the rotating frame (coupled controls, rotated target) and in the lab frame (uncoupled controls, unrotated target,
-      ft = 2 (p cos(2 pi f t) - q sin(2 pi f t))) must give the same gate infidelity up to the rotating-wave error;
- GPU  the HIP path against the oracle (objective, per-step states) at 1e-10."""
+rows a6 / f4).  The reference holds no golden for this branch (parity unpinned).  Pinned here:
+ CPU  the oracle's forward restatement against PHYSICS: the same optimised pulse (examples/drives/cnot2-pcof-opt-t50.jld2)
+      evaluated in the rotating frame (coupled controls, rotated target) and in the lab frame (uncoupled controls, unrotated
+      target, ft = 2 (p cos(2 pi f t) - q sin(2 pi f t))) must give the same gate infidelity up to the rotating-wave error;
+ CPU  the oracle's adjoint gradient against central finite differences of its own objective.  The reference's adjoint for this
+      branch is not a usable reference: adjoint_grad_calc! (:2620-2656) differentiates control functions of an older numbering
+      (func = 2 Ncoupled - 1 + q, no rotation factor) -- not what KS! applies -- and throws for objFuncType != 1 (gradSize,
+      :801); the oracle and the device compute the gradient of the objective that the forward sweep evaluates;
+ GPU  the HIP path against the oracle (objective, per-step states, gradient) at 1e-10."""
 import os
 
 import numpy as np
@@ -47,11 +50,34 @@ def test_oracle_lab_frame_agrees_with_the_rotating_frame_up_to_the_rotating_wave
     assert Oracle(lab).traceobjgrad(pcof, evaladjoint=False)["traceInfidelity"] > 0.3
 
 
-def test_oracle_refuses_the_adjoint_for_uncoupled_controls_like_the_reference_would_throw(jq):
+def lab_problem(jq, Pmin, anti, oft=1):
+    lab, info = jq.cases.cnot2_lab(Pmin=Pmin)
+    if anti:      # the second control antisymmetric: its term goes to S (the Neumann solves see it)
+        b = lab.Hunc_ops[1]
+        lab.Hunc_ops[1] = np.triu(b) - np.triu(b).T
+        lab.isSymm[1] = False
+        lab.linear_solver.max_iter = 4
+    lab.objFuncType = oft
+    return lab, info["pcof0"]
+
+
+@pytest.mark.parametrize("anti", [False, True])
+def test_oracle_gradient_for_uncoupled_controls_is_the_derivative_of_its_objective(jq, anti):
+    """central finite differences of the discrete objective in six coefficient directions (cos and sin blocks of both
+    controls) -- the adjoint gradient is exact for the discrete scheme, so the agreement is limited by the differences"""
     from oracle.oracle import Oracle
-    lab, info = jq.cases.cnot2_lab(Pmin=5)
-    with pytest.raises(ValueError, match="DimensionMismatch"):
-        Oracle(lab).traceobjgrad(info["pcof0"], evaladjoint=True)
+    lab, pcof = lab_problem(jq, 5, anti)
+    rng = np.random.default_rng(5)
+    pcof = pcof + 1e-3 * rng.standard_normal(pcof.size)
+    o = Oracle(lab)
+    g = o.traceobjgrad(pcof, evaladjoint=True)["totalgrad"]
+    assert np.linalg.norm(g) > 1e-6
+    eps = 1e-6
+    for i in rng.choice(pcof.size, 6, replace=False):
+        d = np.zeros(pcof.size)
+        d[i] = eps
+        fd = (o.traceobjgrad(pcof + d, evaladjoint=False)["objfv"] - o.traceobjgrad(pcof - d, evaladjoint=False)["objfv"]) / (2 * eps)
+        assert abs(fd - g[i]) <= 1e-6 * np.linalg.norm(g, np.inf) + 1e-9, (i, fd, g[i])
 
 
 def test_operators_that_are_neither_symmetric_nor_antisymmetric_are_the_references_argument_error(jq):
@@ -87,8 +113,43 @@ def test_gpu_lab_frame_evaluation_matches_the_oracle(jq, anti):
     # ensembles / sweeps are forward evaluations too
     sw = jq.traceobj_sweep(pcof, lab, wa, np.array([0.0, 1e-3]), np.arange(lab.Ntot) * 1.0)
     assert abs(sw[0, 0] - objfv) <= 1e-12
-    # gradients: refused, with the reason
+    # gradient (Stormer-Verlet): against the oracle's, which finite differences pin above
+    g = Oracle(lab).traceobjgrad(pcof, evaladjoint=True)
+    objfv2, tg, prim2, sec2, tinf, ig, lg = jq.traceobjgrad(pcof, lab, wa, False, True)
+    assert abs(objfv2 - g["objfv"]) <= 1e-10 * abs(g["objfv"])
+    assert np.linalg.norm(tg - g["totalgrad"]) <= 1e-9 * np.linalg.norm(g["totalgrad"])
+    # an ensemble with the gradient (two nodes)
+    nodes, weights, shift = np.array([-1e-3, 2e-3]), np.array([0.4, 0.6]), np.arange(lab.Ntot) * 1.0
+    ref = Oracle(lab).eval_f_g_grad(pcof, nodes, weights, shift)
+    jq.eval_f_g_grad(pcof, lab, wa, nodes, weights, True, shift=shift)
+    assert abs(lab.last_infidelity - ref["last_infidelity"]) <= 1e-10 * abs(ref["last_infidelity"])
+    assert np.linalg.norm(lab.last_infidelity_grad - ref["last_infidelity_grad"]) <= 1e-9 * np.linalg.norm(ref["last_infidelity_grad"])
+    wa.close()
+
+
+@pytest.mark.gpu
+def test_gpu_gradient_for_uncoupled_controls_with_the_leak_constraint_split(jq):
+    """objFuncType = 3 (forced and unforced backward sweep): infidelity and leak gradients against the oracle (the reference
+    throws here, gradSize :801)"""
+    from oracle.oracle import Oracle
+    lab, pcof = lab_problem(jq, 10, True, oft=3)
+    g = Oracle(lab).traceobjgrad(pcof, evaladjoint=True)
+    wa = jq.Working_Arrays_HIP(lab, pcof.size)
+    objfv, tg, prim, sec, tinf, ig, lg = jq.traceobjgrad(pcof, lab, wa, False, True)
+    gn = np.linalg.norm(g["totalgrad"])
+    assert np.linalg.norm(tg - g["totalgrad"]) <= 1e-9 * gn
+    assert np.linalg.norm(ig - g["infidelgrad"]) <= 1e-9 * gn
+    assert np.linalg.norm(lg - g["leakgrad"]) <= 1e-9 * gn
+    wa.close()
+
+
+@pytest.mark.gpu
+def test_gpu_implicit_midpoint_gradient_for_uncoupled_controls_is_refused(jq):
+    from juqbox_jl_amd import _lib
+    lab, pcof = lab_problem(jq, 5, False)
+    lab.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER_M, max_iter=100, tol=1e-12, nrhs=lab.N)
+    wa = jq.Working_Arrays_M_HIP(lab, pcof.size)
     with pytest.raises(_lib.JuqboxHipError) as e:
         jq.traceobjgrad(pcof, lab, wa, False, True)
-    assert e.value.code == _lib.JQ_EUNSUPPORTED and "gradSize" in str(e.value)
+    assert e.value.code == _lib.JQ_EUNSUPPORTED and "implicit-midpoint" in str(e.value)
     wa.close()
