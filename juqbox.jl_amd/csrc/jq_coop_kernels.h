@@ -143,6 +143,7 @@ struct Coop {
     int kb0;
     int row_off;        // doubles from the start of an operator image to my row's tiles
     d4 xown;            // my rows of the staged / published x (JQ_BW_OD: B operand of the diagonal block)
+    double* nrm;        // LDS [NT]: the waves' partial residual norms of the Jacobi solver
 
     // write my rows of Z into the other exchange buffer (visible after the next barrier)
     __device__ __forceinline__ void stage(const d4& Z)
@@ -215,10 +216,32 @@ __device__ __forceinline__ double dot4(const d4& a, const d4& b)
 
 // out = bpa + sum_{j=1..m} S^j A with the resident operator S (Horner form, see jq_kernels.h); on entry
 // NOTHING needs to be published; on exit the exchange buffer holds an intermediate iterate.
+// tol2 > 0: JACOBI_SOLVER instead (jacobi!, src/linear_solvers.jl:110-153; jq_kernels.h jacobi_add): X_j = A + S X_{j-1}, X_0 = A,
+// stop at the first j with ||X_j - X_{j-1}||_F^2 < tol2 (over the slab, like the slab kernels) or at j = m; the waves' partial
+// norms meet in LDS (one more barrier per iteration; the publication barrier of the next iteration protects their reuse).
 template <int NT, int BW>
-__device__ __forceinline__ d4 coop_horner(Coop<NT, BW>& c, const d4& bpa, const d4& A, int m)
+__device__ __forceinline__ d4 coop_horner(Coop<NT, BW>& c, const d4& bpa, const d4& A, int m, double tol2 = 0.0)
 {
     if (m <= 0) return bpa;
+    if (tol2 > 0.0) {
+        d4 X = A;
+        for (int j = 1; j <= m; ++j) {
+            c.stage(X);
+            c.publish();
+            const d4 Xn = c.mm_c(A);
+            const d4 d = Xn - X;
+            const double e = wave_sum(dot4(d, d));
+            if ((threadIdx.x & 63) == 0) c.nrm[c.mt] = e;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            double err2 = 0.0;
+            for (int w = 0; w < NT; ++w) err2 += c.nrm[w];
+            X = Xn;
+            if (err2 < tol2) break;
+        }
+        return (bpa - A) + X;
+    }
     d4 Y = A;
     for (int j = 1; j < m; ++j) {
         c.stage(Y);
@@ -245,7 +268,7 @@ __device__ __forceinline__ void coop_state(Coop<NT, BW>& c, const PropArgs& a, d
     c.stage(v);
     c.publish_next_op();
     A = c.mm_c(A);
-    v05 = coop_horner<NT, BW>(c, v + A, A, a.m);
+    v05 = coop_horner<NT, BW>(c, v + A, A, a.m, a.jacobi_tol2);
     c.stage(v05);
     c.publish();
     vN = c.mm_c(v05);
@@ -265,7 +288,7 @@ __device__ __forceinline__ void coop_state(Coop<NT, BW>& c, const PropArgs& a, d
     c.stage(un);
     c.publish_next_op();
     A = c.mm_c(A);
-    un = coop_horner<NT, BW>(c, un + A, A, a.m);
+    un = coop_horner<NT, BW>(c, un + A, A, a.m, a.jacobi_tol2);
 }
 
 template <int NT, int BW>
@@ -273,6 +296,7 @@ __device__ __forceinline__ void coop_setup(Coop<NT, BW>& c, char* smem, const Pr
 {
     c.ring.init(smem, a, wave, lane, NT);
     c.xbuf = (double*)(smem + a.lds_tab_off) + 32 * NT + lane;
+    c.nrm = (double*)(smem + a.lds_tab_off) + 32 * NT + 2 * 4 * NT * 64;      // (behind the exchange buffers)
     c.xcur = 0;
     c.mt = wave;
     c.kb0 = coop_kb0(NT, BW, 0);
@@ -419,7 +443,7 @@ __global__ __launch_bounds__(64 * NT) void k_backward_coop(PropArgs a)
         c.publish_next_op();
         R = c.mm_c(R);
         R += (cfw * wdr) * u;
-        const d4 X = coop_horner<NT, BW>(c, mu + R, R, a.m);
+        const d4 X = coop_horner<NT, BW>(c, mu + R, R, a.m, a.jacobi_tol2);
         // early traces with X: tr1 = tr(vr0' Hanti_q X), tr3 = tr(vr' Hanti_q X)
         c.stage(X);
         for (int q = 0; q < JQ_MAXNC; ++q) {
@@ -455,7 +479,7 @@ __global__ __launch_bounds__(64 * NT) void k_backward_coop(PropArgs a)
         c.stage(L);
         c.publish();
         Qv = c.mm_c(Qv);
-        const d4 nbn = coop_horner<NT, BW>(c, (nb + L) + Qv, Qv, a.m);
+        const d4 nbn = coop_horner<NT, BW>(c, (nb + L) + Qv, Qv, a.m, a.jacobi_tol2);
         const d4 Bq = nb + nbn;   // -(li0 + li)
         // use 11: Kp05 -- G = X + c K05 nb_new
         c.stage(nbn);

@@ -926,8 +926,6 @@ extern "C" int jq_set_linear_solver(jq_handle* h, int32_t solver_id, int32_t max
     } else if (solver_id != 1) {
         return fail(h, JQ_EUNSUPPORTED, "jq_set_linear_solver: only NEUMANN_SOLVER (1) and JACOBI_SOLVER (2) are implemented");
     }
-    if (solver_id == 2 && h->big)
-        return fail(h, JQ_EUNSUPPORTED, "jq_set_linear_solver: JACOBI_SOLVER is implemented for Ntot <= 96 (slab kernels)");
     h->solver_id = solver_id;
     h->m = max_iter;
     h->solver_tol = tol;
@@ -1407,7 +1405,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     if (cq) spw = 0;
     const bool quad = spw > 0;
     const bool quad8 = spw > 1;
-    const bool coop = imr_coop || (!cq && !quad && !lane && !rl && h->mat_elems_c > 0 && h->solver_id == 1 && nslabs <= h->coop_max_slabs);
+    const bool coop = imr_coop || (!cq && !quad && !lane && !rl && h->mat_elems_c > 0 && (h->solver_id == 1 || h->big) && nslabs <= h->coop_max_slabs);      // (Ntot > 96: also the Jacobi solver)
     prop_kernel_t kfwd, kbwd;
     lane_init_t klinit = nullptr;
     lane_term_t klterm = nullptr;
@@ -1539,7 +1537,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
                                          : (size_t)2 * stride * 8;
     const size_t lds_cq = lds_stage + (size_t)32 * h->NT * 8 + (size_t)(6 * (h->NT + 2) + 2 * h->NT) * 64 * 8 + (size_t)(h->Nc + (h->Nc + 1) / 2) * h->NT * 64 * 8;      // tables, x exchange, wg-sum scratch, trace hand-off
     const size_t lds_fwd = (lane || rl) ? 0 : cq ? lds_cq : imr_coop ? coop_imr_lds_bytes(h->NT, stride)
-                                           : lds_stage + (size_t)32 * h->NT * 8 + (coop ? (size_t)2 * h->KT * 64 * 8 : 0);
+                                           : lds_stage + (size_t)32 * h->NT * 8 + (coop ? (size_t)2 * h->KT * 64 * 8 + 128 : 0);      // (+ the Jacobi solver's partial norms)
     const size_t lds_bwd = rl ? (h->rl_npj > 8 ? (size_t)2 * h->Nc * h->rl_stride * 8 : 0) : lane ? 0 : (coop || cq) ? lds_fwd
                                 : imr_quad ? lds_fwd + (size_t)JQ_MAXNC * nthreads * 8 + (size_t)(nthreads / 64) * h->NT * 64 * 8
                                 : quad ? lds_stage + (size_t)bwd_lds_tail(h->NT, h->Nc, nthreads / 64, (long long)h->NT * 64)   // (a 16-row block per register)

@@ -457,3 +457,31 @@ def test_split_batches_give_the_results_of_the_unsplit_batch(hip):
         assert abs(a[4][j, 0] - r["objfv"]) <= 1e-10 * abs(r["objfv"])
     hiprt.hipFree(d_packed)
     wa.close()
+
+
+@pytest.mark.parametrize("Ntot,N,structure", [(112, 4, False), (160, 5, True)])
+def test_jacobi_solver_beyond_96_levels_matches_the_oracle(hip, Ntot, N, structure):
+    """JACOBI_SOLVER (src/linear_solvers.jl:110-153) on the cooperative kernels with 7 .. 16 waves per slab: early exit,
+    iteration cap, a three-node ensemble (the device tests convergence per slab instead of per sample: agreement to O(tol))."""
+    from oracle.oracle import Oracle
+    from test_gpu_random import random_problem
+    jq = hip
+    rng = np.random.default_rng(77 + Ntot)
+    p, pcof = random_problem(jq, rng, Ntot, N, 2, 1, 6, 4, 1, structure)
+    wa = jq.Working_Arrays_HIP(p, pcof.size)
+    for max_iter, tol in ((40, 1e-13), (3, 1e-30), (40, 1e-6)):
+        p.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER, max_iter=max_iter, tol=tol, nrhs=1)
+        r = Oracle(p, use_sparse=False).traceobjgrad(pcof)
+        objfv, tg, *_ = jq.traceobjgrad(pcof, p, wa, False, True)
+        assert wa.last_timing()["kernel_family"] == 1
+        bound = max(1e-9, 100 * tol)
+        assert abs(objfv - r["objfv"]) <= bound * abs(r["objfv"])
+        assert rel(tg, r["totalgrad"]) < bound
+    nodes, weights, shift = 0.05 * rng.standard_normal(3), rng.random(3), 0.05 * rng.standard_normal(Ntot)
+    shift[0] = 0.0      # (the reference shifts the levels j >= 2 only, src/ipopt_interface.jl:41-44)
+    p.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER, max_iter=40, tol=1e-13, nrhs=1)
+    ref = Oracle(p, use_sparse=False).eval_f_g_grad(pcof, nodes, weights, shift)
+    jq.eval_f_g_grad(pcof, p, wa, nodes, weights, True, shift=shift)
+    assert abs(p.last_infidelity - ref["last_infidelity"]) <= 1e-9 * abs(ref["last_infidelity"])
+    assert rel(p.last_infidelity_grad, ref["last_infidelity_grad"]) < 1e-9
+    wa.close()
