@@ -1359,9 +1359,6 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     const bool imr_coop = imr && !imr_rl && !imr_quad;
     if (imr_coop && (h->mat_elems_c == 0 || coop_imr_lds_bytes(h->NT, h->mat_elems_c) > 163840))
         return fail(h, JQ_EUNSUPPORTED, "implicit midpoint: needs Ntot <= 16 with N <= 4, or 16 < Ntot <= 96");
-    if (imr_coop && nslabs > 4 * h->coop_max_slabs)
-        return fail(h, JQ_EUNSUPPORTED, "implicit midpoint for Ntot > 16 is implemented for small batches only (cooperative "
-                                        "kernels, at most four workgroups per CU)");
     const int cpw = imr_rl ? imr_cols_per_wave(h->N) : 4;   // columns per wave of the row-lane kernels
     const bool rl = imr_rl || (!imr && h->rl_npj > 0 && h->solver_id == 1 && ncols_used <= h->rl_max_cols);
     const bool lane = !rl && h->lane_np > 0 && h->solver_id == 1 && ncols_used >= h->lane_min_cols && ncols_used <= h->lane_max_cols;

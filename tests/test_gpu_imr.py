@@ -158,3 +158,35 @@ def test_imr_random_problems_match_oracle(jq, cfg):
         assert abs(p.last_infidelity - inf) <= 1e-9 * abs(inf)
         assert np.linalg.norm(p.last_infidelity_grad - g) <= 1e-9 * np.linalg.norm(g)
     wa.close()
+
+
+def test_implicit_midpoint_large_batch_on_the_cooperative_kernels(jq):
+    """1500 slabs (more than four rounds of one workgroup per CU) of a dense Ntot = 40 problem: one-hot ensemble weights select the
+    first, a middle and the last sample, each against the oracle's evaluation of that sample."""
+    from oracle.oracle import Oracle
+    from test_gpu_random import random_problem
+
+    rng = np.random.default_rng(11)
+    Ntot, N = 40, 4
+    p, pcof = random_problem(jq, rng, Ntot, N, 2, 1, 8, 3, 1, False)
+    p.Integrator_id = jq.Implicit_Midpoint
+    p.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER_M, max_iter=60, tol=1e-11, nrhs=N)
+    wa = jq.Working_Arrays_M_HIP(p, pcof.size)
+    ns = 6000
+    nodes = 0.02 * rng.standard_normal(ns)
+    shift = 0.05 * rng.standard_normal(Ntot)
+    shift[0] = 0.0
+    for j in (0, 2999, 5999):
+        w = np.zeros(ns)
+        w[j] = 1.0
+        jq.eval_f_g_grad(pcof, p, wa, nodes, w, True, shift=shift)
+        assert wa.last_timing()["kernel_family"] == 5
+        H0 = p.Hconst.copy()
+        p.Hconst = H0 + np.diag(nodes[j] * shift)
+        try:
+            r = Oracle(p, use_sparse=False).traceobjgrad_imr(pcof, 60, 1e-11)
+        finally:
+            p.Hconst = H0
+        assert abs(p.last_infidelity - r["primaryobjf"]) <= 1e-10 * abs(r["primaryobjf"])
+        assert np.linalg.norm(p.last_infidelity_grad - r["infidelgrad"]) <= 1e-9 * np.linalg.norm(r["infidelgrad"])
+    wa.close()
