@@ -132,6 +132,15 @@ def issue_bound(launch_s, steps_per_launch, products_per_step, waves_per_simd):
                     "1.3 x its nominal issue count; the kernel as a whole runs within ~10 % of the bare product"}
 
 
+_T0 = time.perf_counter()
+
+
+def _trace(msg):
+    if os.environ.get("JQ_BENCH_TRACE"):
+        sys.stderr.write("[bench %7.1f s] %s\n" % (time.perf_counter() - _T0, msg))
+        sys.stderr.flush()
+
+
 def main():
     args = parse_args()
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
@@ -154,6 +163,7 @@ def main():
     from juqbox_jl_amd import _lib
     from juqbox_jl_amd.ipopt_interface import shard_bounds
 
+    _trace("imports done")
     L = _lib.load()
     ndev_visible = L.jq_device_count()
     ngpus = args.gpus                                  # GPUs of the whole job
@@ -177,6 +187,7 @@ def main():
     nsamples_total = args.samples_per_gpu * ngpus
     nodes, weights, shift = jq.cases.cnot3_ensemble(nsamples_total)
     wa = jq.Working_Arrays_HIP(params, pcof.size, devices=ngpus if args.single_process else None)
+    _trace("handle created")
 
     def step():
         jq.eval_f_g_grad(pcof, params, wa, nodes, weights, True, shift=shift)
@@ -209,7 +220,9 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    _trace("warm-up done")
     elapsed, tms = timed(step, args.steps)
+    _trace("timed steps done")
     prop_ms = sum(t["ms_propagate"] for t in tms)
     bwd_ms = sum(t["ms_backward"] for t in tms)
     fwd_ms = sum(t["ms_forward"] for t in tms)
@@ -229,6 +242,7 @@ def main():
             jq.eval_f_g_grad(pcof, params, wa, n2, w2, True, shift=s2)
         strong_step()                                   # (buffers grow to the shard size here)
         el2, tms2 = timed(strong_step, 1)
+        _trace("strong-scaling run done")
         strong = {"total_samples": ns, "samples_per_gpu": ns // ngpus, "seconds": el2, "evals_per_s": ns / el2,
                   "note": "fixed ensemble, block-partitioned over the GPUs, one all-reduce; compare evals_per_s across n_gpus"}
 
@@ -338,6 +352,7 @@ def main():
                 other[str(ns)] = {"evals_per_s": ns / (t2["ms_total"] * 1e-3), "ms": t2["ms_total"], "kernel_family": t2["kernel_family"],
                                   "kernel_band": t2["kernel_band"]}
             out["other_batch_sizes"] = other
+            _trace("latency / other batch sizes done")
             # the other BASELINE.json configurations (parity-test cases, not bench lines): time of one evaluation on this GPU --
             # single samples and, for the risk-neutral SWAP-02 case, its 512-node ensemble; Ntot <= 16: VALU row-lane kernels,
             # no MFMA percentage is quoted
@@ -365,8 +380,10 @@ def main():
                 out["baseline_configs"] = cfgs
             except Exception as e:  # noqa: BLE001  (never let a side measurement take the bench line down)
                 out["baseline_configs"] = {"error": repr(e)}
+            _trace("baseline configs done")
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(params, pcof)
+                _trace("cpu baseline done")
         print(json.dumps(out), flush=True)
     wa.close()
     if dist is not None:

@@ -412,5 +412,19 @@ def cnot3_ensemble(nsamples, ep_max=2 * np.pi * 1.0e-4):
     i2 = np.tile(np.repeat(np.arange(Nt[1]), Nt[0]), Nt[2])
     i3 = np.repeat(np.arange(Nt[2]), Nt[0] * Nt[1])
     shift = (i1 + i2 + i3).astype(np.float64)
-    x, w = np.polynomial.legendre.leggauss(nsamples)
+    if nsamples <= 4096:
+        x, w = np.polynomial.legendre.leggauss(nsamples)
+    else:
+        # numpy's leggauss diagonalises an n x n companion matrix: O(n^3), eight minutes at n = 24 576 (bench.py's strong-scaling
+        # ensemble).  Large ensembles use a COMPOSITE Gauss-Legendre rule instead: k equal panels with n / k <= 4096 nodes each
+        # (24 576 = 8 panels of 3 072); sample counts without such a divisor fall back to scipy's O(n) asymptotic rule.
+        k = next((k for k in range(2, 65) if nsamples % k == 0 and nsamples // k <= 4096), 0)
+        if k:
+            xp, wp = np.polynomial.legendre.leggauss(nsamples // k)
+            centers = -1.0 + (2.0 * np.arange(k) + 1.0) / k
+            x = (centers[:, None] + xp[None, :] / k).ravel()
+            w = np.tile(wp / k, k)
+        else:
+            from scipy.special import roots_legendre
+            x, w = roots_legendre(nsamples)
     return x * ep_max, w * 0.5, shift

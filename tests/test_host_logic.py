@@ -137,3 +137,23 @@ def test_eval_f_g_grad_resets_the_memoised_gradients_like_the_reference():
     assert params.last_infidelity == 0.25 and params.last_leak == 0.5
     assert np.all(params.last_infidelity_grad == 0.0) and np.all(params.last_leak_grad == 0.0)
     assert np.array_equal(params.last_pcof, pcof + 1e-3)
+
+
+def test_large_cnot3_ensembles_are_built_without_the_cubic_eigenvalue_solve():
+    """bench.py's strong-scaling ensemble (24 576 samples): numpy's leggauss would diagonalise a 24 576 x 24 576 matrix (eight
+    minutes); the composite rule must be a valid quadrature (weights sum to one, exact for low-order polynomials on
+    [-ep_max, ep_max], nodes increasing and inside the interval) and quick."""
+    import time
+    import juqbox_jl_amd as jq
+    ep_max = 2 * np.pi * 1.0e-4
+    t0 = time.perf_counter()
+    x, w, shift = jq.cases.cnot3_ensemble(24576)
+    assert time.perf_counter() - t0 < 60.0
+    assert x.size == w.size == 24576 and shift.size == 96
+    assert abs(w.sum() - 1.0) < 1e-13 and np.all(w > 0)
+    assert np.all(np.diff(x) > 0) and abs(x[0]) < ep_max and abs(x[-1]) < ep_max
+    t = x / ep_max
+    assert abs((w * t).sum()) < 1e-13 and abs((w * t ** 2).sum() - 1.0 / 3.0) < 1e-12 and abs((w * t ** 4).sum() - 1.0 / 5.0) < 1e-12
+    # a sample count without a suitable divisor
+    x2, w2, _ = jq.cases.cnot3_ensemble(4099)
+    assert abs(w2.sum() - 1.0) < 1e-12 and np.all(np.diff(x2) > 0)
