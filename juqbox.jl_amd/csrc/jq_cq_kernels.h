@@ -200,6 +200,22 @@ struct CoopQ {
         acc = fma(o.c[2], n.b, acc);      // (the coefficients of a missing neighbour are zero)
         return fma(o.c[3], n.a, acc);
     }
+    // M x for a constant trace image (my block).  ORD: control q acts on subsystem q only -- q = 0: the 4 x 4 diagonal blocks
+    // (MFMA), q = 1: the (i, i+-4) couplings (lane shifts), q = 2: the (i, i+-16) couplings (neighbour blocks) -- so one part
+    // of the product and one LDS read suffice; otherwise the whole product (the absent parts of an image are stored as zeros).
+    template <bool ORD>
+    __device__ __forceinline__ double trace_mm(const double* M, int q, const Sh& s, const Nb& n) const
+    {
+        if constexpr (ORD) {
+            if (q == 0) return __builtin_amdgcn_mfma_f64_4x4x4f64(M[mt * 64], s.x, 0.0, 0, 0, 0);
+            const d4 cc = t4q_cload(t4q_c<NT>(M, lane), mt);
+            if (q == 1) return fma(cc[1], s.up, cc[0] * s.dn);
+            return fma(cc[3], n.a, cc[2] * n.b);
+        } else {
+            const Op o = load(M);
+            return nbr(own(0.0, o, s), o, n);
+        }
+    }
     // one publication of a Neumann series: Y <- C + S Y
     template <int P, int C>
     __device__ __forceinline__ double hstep(double Cv, double Y, const Op& S)
@@ -480,7 +496,7 @@ __global__ __launch_bounds__(64 * NT + 128) void k_forward_cq(PropArgs a)
 // finishes the four sums with rotate-adds inside the rows and writes them to the trace record of the step.
 //   group q < Nc (adjoint wave):  rows 0, 1, 2 = t1, t4, t3 of control q
 //   group Nc + j (state wave):    rows 0, 1 = t2, t5 of control 2 j, rows 2, 3 = t2, t5 of control 2 j + 1
-template <int NT, bool MODD>
+template <int NT, bool MODD, bool ORD>
 __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -517,8 +533,8 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
     double carry[JQ_MAXNC];
 #pragma unroll
     for (int q = 0; q < JQ_MAXNC; ++q) carry[q] = 0.0;
-    // my blocks of the constant trace images (Hsym_q: image q, Hanti_q: image Nc + q) are loaded where they are used; the absent
-    // parts of a single-subsystem operator are stored as zeros, so the trace products are branch-free
+    // my blocks of the constant trace images (Hsym_q: image q, Hanti_q: image Nc + q) are loaded where they are used (trace_mm);
+    // ORD: control q acts on subsystem q only (host: a.bw_trace[q] == 1 << q for all q < Ncoupled <= 3), else branch-free full products
     double* redw = red + (size_t)wave * 64 + lane_;      // my block's slot of group 0
     // the trace scalars of step k (adjoint waves; call behind a barrier that follows the step's last hand-off)
     auto finish_traces = [&](int k) {
@@ -615,8 +631,7 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
                 for (int q = 0; q < JQ_MAXNC; ++q) {
                     t2[q] = 0.0;
                     if (q < Nc) {
-                        const Op Hs = c.load(c.ring.cimg(q));
-                        t2[q] = v05w * c.nbr(c.own(0.0, Hs, sx), Hs, nx);
+                        t2[q] = v05w * c.template trace_mm<ORD>(c.ring.cimg(q), q, sx, nx);
                     }
                 }
             }
@@ -655,8 +670,7 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
                 for (int q = 0; q < JQ_MAXNC; ++q) {
                     t5[q] = 0.0;
                     if (q < Nc) {
-                        const Op Ha = c.load(c.ring.cimg(Nc + q));
-                        t5[q] = -(v05w * c.nbr(c.own(0.0, Ha, sx), Ha, nx));
+                        t5[q] = -(v05w * c.template trace_mm<ORD>(c.ring.cimg(Nc + q), q, sx, nx));
                     }
                 }
                 redw[(size_t)Nc * NT * 64] = cq_part4(t2[0], t2[1], t5[0], t5[1]);
@@ -695,8 +709,7 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
 #pragma unroll
             for (int q = 0; q < JQ_MAXNC; ++q)
                 if (q < Nc) {
-                    const Op Hs = c.load(c.ring.cimg(q));
-                    carry[q] = -(u0 * c.nbr(c.own(0.0, Hs, sx), Hs, nn));
+                    carry[q] = -(u0 * c.template trace_mm<ORD>(c.ring.cimg(q), q, sx, nn));
                 }
         }
         JQ_TS_DECL
@@ -759,8 +772,7 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
                 for (int q = 0; q < JQ_MAXNC; ++q) {
                     Tq[q] = 0.0;
                     if (q < Nc) {
-                        const Op Ha = c.load(c.ring.cimg(Nc + q));
-                        Tq[q] = c.nbr(c.own(0.0, Ha, sx), Ha, nn);
+                        Tq[q] = c.template trace_mm<ORD>(c.ring.cimg(Nc + q), q, sx, nn);
                     }
                 }
             }
@@ -805,8 +817,7 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
 #pragma unroll
                 for (int q = 0; q < JQ_MAXNC; ++q)
                     if (q < Nc) {
-                        const Op Hs = c.load(c.ring.cimg(q));
-                        const double pq = -(un * c.nbr(c.own(0.0, Hs, sx), Hs, nn));
+                        const double pq = -(un * c.template trace_mm<ORD>(c.ring.cimg(q), q, sx, nn));
                         const double t4 = (pq + carry[q]) * wgt;
                         carry[q] = pq;
                         redw[(size_t)q * NT * 64] = cq_part4(uw * Tq[q], unw * Tq[q], t4, 0.0);      // rows 0, 2, 1: t1, t3, t4

@@ -14,9 +14,11 @@
 #if JQ_VARIANT == 9     // cooperative-quad (latency) kernels of the JQ_BW_T4 structure (JQ_BW = 7)
 #include "jq_cq_kernels.h"
 template __global__ void k_forward_cq<JQ_NT, false>(PropArgs);
-template __global__ void k_backward_cq<JQ_NT, false>(PropArgs);
+template __global__ void k_backward_cq<JQ_NT, false, false>(PropArgs);
+template __global__ void k_backward_cq<JQ_NT, false, true>(PropArgs);      // (control q acts on subsystem q only)
 template __global__ void k_forward_cq<JQ_NT, true>(PropArgs);      // (odd number of Neumann terms)
-template __global__ void k_backward_cq<JQ_NT, true>(PropArgs);
+template __global__ void k_backward_cq<JQ_NT, true, false>(PropArgs);
+template __global__ void k_backward_cq<JQ_NT, true, true>(PropArgs);
 #elif JQ_VARIANT == 7
 #include "jq_quad_imr_kernels.h"
 template __global__ void k_forward_quad_imr<JQ_NT>(PropArgs);

@@ -1052,22 +1052,29 @@ static int select_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
 JQ_DECLQ(1) JQ_DECLQ(2) JQ_DECLQ(3) JQ_DECLQ(4) JQ_DECLQ(5) JQ_DECLQ(6)
 #undef JQ_DECLQ
 template <int NT, bool MODD> __global__ void k_forward_cq(PropArgs);            // jq_cq_kernels.h (own translation units)
-template <int NT, bool MODD> __global__ void k_backward_cq(PropArgs);
+template <int NT, bool MODD, bool ORD> __global__ void k_backward_cq(PropArgs);
 #define JQ_DECLCQ(nt)                                                      \
     extern template __global__ void k_forward_cq<nt, false>(PropArgs);     \
-    extern template __global__ void k_backward_cq<nt, false>(PropArgs);    \
+    extern template __global__ void k_backward_cq<nt, false, false>(PropArgs);    \
+    extern template __global__ void k_backward_cq<nt, false, true>(PropArgs);     \
     extern template __global__ void k_forward_cq<nt, true>(PropArgs);      \
-    extern template __global__ void k_backward_cq<nt, true>(PropArgs);
+    extern template __global__ void k_backward_cq<nt, true, false>(PropArgs);     \
+    extern template __global__ void k_backward_cq<nt, true, true>(PropArgs);
 JQ_DECLCQ(1) JQ_DECLCQ(2) JQ_DECLCQ(3) JQ_DECLCQ(4) JQ_DECLCQ(5) JQ_DECLCQ(6)
 #undef JQ_DECLCQ
 // (instantiated for even and odd numbers of Neumann terms: the parities of the LDS exchange are compile-time constants)
 static int select_cq_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
 {
     const bool modd = (h->m > 0 ? h->m : 0) & 1;
+    // control q acts on subsystem q only (the usual Juqbox set-up: Hsym_ops = [a + a', b + b', c + c']): its trace products need
+    // one part of the product each
+    bool ord = h->Nc <= 3 && !getenv("JQ_CQ_GENERIC_TRACES");
+    for (int q = 0; q < h->Nc && ord; ++q) ord = (h->bw_trace[q] == (1 << q));
 #define JQ_PICKCQ(nt)                                                              \
     if (h->NT == nt) {                                                             \
         *fwd = modd ? k_forward_cq<nt, true> : k_forward_cq<nt, false>;            \
-        *bwd = modd ? k_backward_cq<nt, true> : k_backward_cq<nt, false>;          \
+        *bwd = modd ? (ord ? k_backward_cq<nt, true, true> : k_backward_cq<nt, true, false>)          \
+                    : (ord ? k_backward_cq<nt, false, true> : k_backward_cq<nt, false, false>);       \
         return JQ_OK;                                                              \
     }
     JQ_PICKCQ(1) JQ_PICKCQ(2) JQ_PICKCQ(3) JQ_PICKCQ(4) JQ_PICKCQ(5) JQ_PICKCQ(6)

@@ -485,3 +485,39 @@ def test_jacobi_solver_beyond_96_levels_matches_the_oracle(hip, Ntot, N, structu
     assert abs(p.last_infidelity - ref["last_infidelity"]) <= 1e-9 * abs(ref["last_infidelity"])
     assert rel(p.last_infidelity_grad, ref["last_infidelity_grad"]) < 1e-9
     wa.close()
+
+
+@pytest.mark.parametrize("Ng3,oft", [(1, 1), (2, 3), (5, 2)])
+def test_cooperative_quad_kernels_with_single_subsystem_controls_match_the_oracle(hip, Ng3, oft):
+    """cnot3-type problems (control q acts on subsystem q only: the trace products of the cooperative-quad backward sweep use one
+    part of the product each) against the oracle, and against the same kernels with the branch-free full trace products
+    (JQ_CQ_GENERIC_TRACES=1); Ntot = 32 / 48 / 96, 7 time steps, objFuncType 1 / 3 / 2, a five-node ensemble."""
+    from oracle.oracle import Oracle
+    jq = hip
+    params, info = jq.cases.cnot3(Ng3=Ng3)
+    params.nsteps = 7
+    params.T = params.T * 7 / 32386
+    params.objFuncType = oft
+    rng = np.random.default_rng(Ng3)
+    pcof = 0.02 * rng.standard_normal(info["nCoeff"])
+    r = Oracle(params).traceobjgrad(pcof)
+    res = []
+    for env in ({}, {"JQ_CQ_GENERIC_TRACES": "1"}):
+        os.environ.update(env)
+        try:
+            wa = jq.Working_Arrays_HIP(params, pcof.size)
+            objfv, tg, prim, sec, tinf, ig, lg = jq.traceobjgrad(pcof, params, wa, False, True)
+            assert wa.last_timing()["kernel_family"] == 8
+            nodes, weights, shift = jq.cases.cnot3_ensemble(5)
+            jq.eval_f_g_grad(pcof, params, wa, nodes, weights, True, shift=np.arange(params.Ntot) * 1.0)
+            res.append((objfv, tg, ig, params.last_infidelity, params.last_infidelity_grad.copy()))
+            wa.close()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        gn = np.linalg.norm(r["totalgrad"])
+        assert abs(objfv - r["objfv"]) <= 1e-10 * abs(r["objfv"])
+        assert np.linalg.norm(tg - r["totalgrad"]) <= 1e-10 * gn and np.linalg.norm(ig - r["infidelgrad"]) <= 1e-10 * gn
+    a, b = res
+    assert abs(a[0] - b[0]) <= 1e-13 * abs(b[0]) and rel(a[1], b[1]) < 1e-12 and rel(a[4], b[4]) < 1e-12
+    assert abs(a[3] - b[3]) <= 1e-13 * abs(b[3])
