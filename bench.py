@@ -255,7 +255,9 @@ def main():
         f_bwd = 2.0 * Ntot * Ntot * (2 * (9 + 2 * m) + 7 * Nc)                 # dense-contraction FLOP / SVTS, backward sweep
         f_fwd = 2.0 * Ntot * Ntot * (9 + 2 * m)
         avg_launch_s = bwd_ms * 1e-3 / max(nb, 1)
-        fam = {0: "k_backward", 1: "k_backward_coop", 2: "k_backward_lane", 3: "k_backward_rowlane", 6: "k_backward"}.get(tm.get("kernel_family", 0))
+        fam = {0: "k_backward", 1: "k_backward_coop", 2: "k_backward_lane", 3: "k_backward_rowlane", 4: "k_backward_rowlane_imr",
+               5: "k_backward_coop_imr", 6: "k_backward", 7: "k_backward_quad_imr", 8: "k_backward_cq"}.get(
+                   tm.get("kernel_family", 0), "k_backward")
         kname = "%s<%d, %d>" % (fam, tm.get("kernel_size", 0), tm.get("kernel_band", 0))
         band = tm.get("kernel_band")
         band_note = {9: " (band 9 = block tridiagonal with diagonal off-diagonal blocks)",
