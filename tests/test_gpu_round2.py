@@ -521,3 +521,46 @@ def test_cooperative_quad_kernels_with_single_subsystem_controls_match_the_oracl
     a, b = res
     assert abs(a[0] - b[0]) <= 1e-13 * abs(b[0]) and rel(a[1], b[1]) < 1e-12 and rel(a[4], b[4]) < 1e-12
     assert abs(a[3] - b[3]) <= 1e-13 * abs(b[3])
+
+
+@pytest.mark.gpu
+def test_handles_release_their_device_memory(hip):
+    """jq_destroy gives back everything a handle allocated (operators, state batches, the split-batch buffers, the ensemble
+    results): 30 create / evaluate / destroy cycles over the kernel families leave the device's free memory where it was."""
+    import ctypes
+    import gc
+    from juqbox_jl_amd import _lib
+    jq = hip
+    L = _lib.load()
+    L.hipMemGetInfo.restype = ctypes.c_int
+
+    def free_bytes():
+        f, t = ctypes.c_size_t(), ctypes.c_size_t()
+        assert L.hipMemGetInfo(ctypes.byref(f), ctypes.byref(t)) == 0
+        return f.value
+
+    def cycle(case, nsamples):
+        params, info = getattr(jq.cases, case)()
+        params.T = params.T * 40 / params.nsteps
+        params.nsteps = 40
+        pcof = 0.01 * np.cos(np.arange(info["nCoeff"]) + 1.0)
+        wa = jq.Working_Arrays_HIP(params, pcof.size)
+        jq.traceobjgrad(pcof, params, wa, False, True)
+        nodes = np.linspace(-1e-4, 1e-4, nsamples)
+        weights = np.full(nsamples, 1.0 / nsamples)
+        shift = np.arange(params.Ntot, dtype=np.float64) % 3
+        shift[0] = 0.0
+        jq.eval_f_g_grad(pcof, params, wa, nodes, weights, True, shift=shift)
+        assert np.isfinite(params.last_infidelity)
+        wa.close()
+
+    cycle("cnot3", 1100)                  # (first use: module load, RCCL-free single device, allocator pools)
+    gc.collect()
+    before = free_bytes()
+    for k in range(10):
+        cycle("cnot3", 1100 + 7 * k)      # split batches (full round + remainder) on the quad-layout kernels
+        cycle("cnot2", 300)
+        cycle("rabi", 64)
+    gc.collect()
+    after = free_bytes()
+    assert abs(before - after) <= 8 << 20, "device memory not returned: %d bytes" % (before - after)
