@@ -1,0 +1,262 @@
+// jq_cq_imr_kernels.h -- IMPLICIT MIDPOINT propagators (traceobjgrad for Working_Arrays_M, src/evalobjgrad.jl:1042-1481;
+// m_step!, src/ImplicitMidpoint.jl:120-227; jacobi_midpoint, src/linear_solvers.jl:156-270) as "cooperative quad" kernels: the
+// LATENCY path of the JQ_BW_T4 structure for N = 4 (cnot3: one evaluation, small ensembles).
+//
+// The quad-layout kernels of jq_quad_imr_kernels.h give one wave the four columns of an evaluation and ALL 16-row blocks: every
+// fixed-point iteration x <- rhs + B x, B = h/2 [S -K; K S], is four products of NT blocks each on a wave that issues one
+// instruction every ~10 cycles (cnot3: ~2 100 cycles per iteration, 0.77 s per evaluation).  Here, as in jq_cq_kernels.h, wave mt
+// of a workgroup owns block mt of every array (one register per array), publishes its block of (x_u, x_v) in LDS (channels 0 and
+// 1 of the exchange image), passes ONE workgroup barrier per iteration and reads the two neighbouring blocks.  The stopping rule of
+// the reference -- |x_it - x_{it+1}|^2 < tol^2 for the u and the v part, summed over the evaluation -- needs a sum over all waves:
+// the per-lane squares of both parts are folded into one register (rows 0, 1: u part, rows 2, 3: v part; v_permlane32/16_swap) and
+// published in channel 2 TOGETHER with x_{it+1}, so that the test of iteration it rides on the barrier of iteration it + 1: every
+// wave adds the NT blocks in the same order (identical decisions in all waves), finishes the sums with four rotate-adds and either
+// keeps x_it (converged: the speculative publication of x_{it+1} is dropped) or goes on with the neighbours it has just read.
+// Publications per implicit step: 2 + (number of iterations), against the same number of four-product sweeps of a lone wave.
+// The parity of a publication is a run-time value here (the iteration count is data dependent).
+//
+// Same operator stream (K, S of the midpoint = time point 2n+1 of step n; window staging of WinRing: the DMA of the time points
+// 2n+5, 2n+6 is issued behind the first barrier of step n and drained in front of the first barrier of step n+1), state file,
+// terminal kernels and trace slots as the quad-layout kernels; one trace record row per wave.
+#pragma once
+#include "jq_cq_kernels.h"
+
+template <int NT>
+struct CqImr {
+    typedef typename CoopQ<NT>::Op Op;
+    typedef typename CoopQ<NT>::Sh Sh;
+    typedef typename CoopQ<NT>::Nb Nb;
+    static constexpr int CHS = CoopQ<NT>::CHS, PAR = CoopQ<NT>::PAR;
+    CoopQ<NT>* c;
+    jq_lds_double* x0;      // front pad block of channel 0 in parity 0, this lane (block w of a channel: + (w + 1) * 64)
+    Op K, S;                // my block of the midpoint operators of this step (pre-scaled by h/2)
+    double cw;              // h/2 * eps * ws[row] of this lane
+    double tol2;
+    int max_iter, par;
+    bool use_shift;
+
+    struct Acc {
+        double au, kv, av;  // q_u = au - kv ; q_v = av
+    };
+    // the part of  q = rhs + [S -K; K S] p  that needs only my block
+    __device__ __forceinline__ Acc own(double ru, double rv, double pu, double pv) const
+    {
+        const Sh su = c->sh(pu), sv = c->sh(pv);
+        Acc r;
+        r.au = c->own(ru, S, su);
+        r.kv = c->own(0.0, K, sv);
+        r.av = c->own(c->own(rv, K, su), S, sv);
+        if (use_shift) {      // the diagonal shift of K, row-wise (src/ipopt_interface.jl:41-44)
+            r.kv = fma(cw, pv, r.kv);
+            r.av = fma(cw, pu, r.av);
+        }
+        return r;
+    }
+    // ... and the (i, i+-16) couplings with the neighbours' blocks of the publication at LDS offset po
+    __device__ __forceinline__ void nbr(Acc& r, int po) const
+    {
+        Nb nu, nv;
+        nu.b = c->xb[po], nu.a = c->xb[po + 128];
+        nv.b = c->xb[po + CHS], nv.a = c->xb[po + CHS + 128];
+        r.au = c->nbr(r.au, S, nu);
+        r.kv = c->nbr(r.kv, K, nv);
+        r.av = c->nbr(c->nbr(r.av, K, nu), S, nv);
+    }
+    __device__ __forceinline__ void post(int po, double xu, double xv) const
+    {
+        c->xb[po + 64] = xu;
+        c->xb[po + CHS + 64] = xv;
+    }
+    // One implicit-midpoint step of (u, v); (fu, fv): forcing already multiplied by h.  FIRST: the first step of a time step
+    // (its first barrier drains the DMA issued one time step ago and is followed by the next DMA, see WinRing).
+    template <bool FIRST>
+    __device__ __forceinline__ void step(double& u, double& v, double fu, double fv)
+    {
+        // x = (u, v): B x, rhs = (x + f) + B x, x_1 = rhs + B x
+        int po = par * PAR;
+        post(po, u, v);
+        Acc b = own(0.0, 0.0, u, v);
+        c->template sync<FIRST>();
+        if (FIRST) {
+            c->ring.issue_next();
+            c->ring.issue_next();
+        }
+        nbr(b, po);
+        par ^= 1;
+        const double Bu = b.au - b.kv, Bv = b.av;
+        const double rhs_u = (u + fu) + Bu, rhs_v = (v + fv) + Bv;
+        double cu = rhs_u + Bu, cv = rhs_v + Bv;
+        // x_2
+        po = par * PAR;
+        post(po, cu, cv);
+        Acc nx = own(rhs_u, rhs_v, cu, cv);
+        c->sync();
+        nbr(nx, po);
+        par ^= 1;
+        double nu = nx.au - nx.kv, nv = nx.av;
+        // (cu, cv) = x_it, (nu, nv) = x_{it+1}; at it == max_iter x_it is kept without a test (jacobi_midpoint's iteration cap)
+        for (int it = 1; it < max_iter; ++it) {
+            double d = cu - nu, e = cv - nv;
+            d *= d;
+            e *= e;
+            row_swap32(d, e);
+            double p = d + e;        // rows 0, 1: u part; rows 2, 3: v part
+            double p2 = p;
+            row_swap16(p, p2);
+            p += p2;                 // rows 0, 1: 16 column partials of the u part (both rows alike); rows 2, 3: v part
+            po = par * PAR;
+            post(po, nu, nv);        // (speculative: dropped if x_it turns out to be converged)
+            c->xb[po + 2 * CHS + 64] = p;
+            nx = own(rhs_u, rhs_v, nu, nv);
+            c->sync();
+            par ^= 1;
+            double sum = x0[po + 2 * CHS + 64];
+#pragma unroll
+            for (int w = 1; w < NT; ++w) sum += x0[po + 2 * CHS + (w + 1) * 64];
+            sum = row_ror_add<8>(sum);
+            sum = row_ror_add<4>(sum);
+            sum = row_ror_add<2>(sum);
+            sum = row_ror_add<1>(sum);
+            if (__ballot(sum < tol2) == ~0ull) break;      // both parts below tol^2 (a NaN never converges, as in the reference)
+            nbr(nx, po);
+            cu = nu;
+            cv = nv;
+            nu = nx.au - nx.kv;
+            nv = nx.av;
+        }
+        u = cu;
+        v = cv;
+    }
+};
+
+#define JQ_CQ_IMR_PROLOGUE                                                                                                       \
+    extern __shared__ __attribute__((aligned(16))) char smem[];                                                                  \
+    constexpr int KT = 4 * NT;                                                                                                   \
+    const int lane_ = s.lane_, wave = s.wave;                                                                                    \
+    double* tab = (double*)(smem + a.lds_tab_off);                                                                               \
+    for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[(i & ~15) + 4 * (i & 3) + ((i >> 2) & 3)] = a.tabs[i];            \
+    CoopQ<NT> c;                                                                                                                 \
+    c.setup(tab + 32 * NT, wave, lane_);                                                                                         \
+    c.ring.init(smem, a, wave, lane_, NT);      /* (barrier inside: the tables and the zeroed exchange image are published) */   \
+    const double wdr = tab[16 * wave + s.g], wsr = tab[16 * NT + 16 * wave + s.g];                                               \
+    double* st = a.state + (size_t)s.slab * a.state_stride;                                                                      \
+    CqImr<NT> m;                                                                                                                 \
+    m.c = &c;                                                                                                                    \
+    m.x0 = (jq_lds_double*)(tab + 32 * NT + lane_);                                                                              \
+    m.cw = 0.5 * a.h * a.colinfo[(size_t)s.slab * 32 + s.col] * wsr;                                                             \
+    m.tol2 = a.jacobi_tol2, m.max_iter = a.m, m.par = 0, m.use_shift = a.use_shift;
+
+// grid = 4 * nslabs (workgroup = column quad qd of slab blockIdx.x / 4 = one evaluation, N = 4), block = 64 * NT
+template <int NT>
+__global__ __launch_bounds__(64 * NT) void k_forward_cq_imr(PropArgs a)
+{
+    const CqSetup<NT> s = cq_setup<NT>(a);
+    if (!s.active) return;      // (a quad without columns: the whole workgroup leaves before any barrier)
+    JQ_CQ_IMR_PROLOGUE
+    double* scratch = tab + 32 * NT + 2 * CoopQ<NT>::PAR;
+    double u = st[s.foff], v = st[(size_t)KT * 64 + s.foff];
+    const bool slot0 = wave == 0 && ((lane_ >> 2) & 3) == 0;      // the lanes that carry per-column partials between chunks
+    const size_t cslot = 16 * (lane_ >> 4) + s.col;
+    double leak = slot0 ? st[(size_t)(JQ_STATE_ARRAYS * KT + JQ_MAXNC) * 64 + cslot] : 0.0;
+    for (int n = 0; n < a.nsteps_chunk; ++n) {
+        m.K = c.load(c.ring.template ks<0, 1>());
+        m.S = c.load(c.ring.template ks<1, 1>());
+        double su = u, sv = v;
+        m.template step<true>(u, v, 0.0, 0.0);
+        c.ring.advance();
+        su += u;
+        sv += v;
+        leak += wdr * (su * su) + wdr * (sv * sv);      // penal_m (src/evalobjgrad.jl:1214, :2158-2166)
+        if (a.hist_r) {
+            const int scol = a.parts > 1 ? 16 * s.slab + s.col : s.col;
+            const int row = 16 * wave + 4 * ((lane_ >> 2) & 3) + (lane_ >> 4);
+            if (s.slab < a.parts && scol < a.N && row < a.Ntot) {
+                const size_t off = (size_t)(a.step0 + n + 1) * a.Ntot * a.N + (size_t)scol * a.Ntot + row;
+                a.hist_r[off] = u;
+                a.hist_i[off] = -v;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    st[s.foff] = u;
+    st[(size_t)KT * 64 + s.foff] = v;
+    const double tot = cq_wg_sum(leak, scratch, wave, lane_, NT);
+    if (slot0) st[(size_t)(JQ_STATE_ARRAYS * KT + JQ_MAXNC) * 64 + cslot] = tot;
+}
+
+// Backward sweep (src/evalobjgrad.jl:1290-1336): state re-integration with h < 0, adjoint m_step! with forcing
+// -W (v + v_s) / T and the two gradient scalars of adjoint_grad_calc_m per control (:2660-2702) in the slots of the midpoint weights
+// of k_gradacc (jq_rowlane_imr_kernels.h): tr[3] = -(B + C)/4, tr[4] = (A + D)/4.  One trace record row per wave (its block's share).
+template <int NT>
+__global__ __launch_bounds__(64 * NT) void k_backward_cq_imr(PropArgs a)
+{
+    typedef typename CoopQ<NT>::Sh Sh;
+    typedef typename CoopQ<NT>::Nb Nb;
+    const CqSetup<NT> s = cq_setup<NT>(a);
+    const int Nc = a.Ncoupled, ntr = Nc * JQ_NTR;
+    const size_t trow = ((size_t)s.slab * a.qps + s.qd) * NT;      // first of my workgroup's NT record rows
+    if (!s.active) {
+        if (s.qd < a.qps)
+            for (size_t k = threadIdx.x; k < (size_t)NT * a.nsteps_chunk * ntr; k += blockDim.x) a.traces[trow * a.nsteps_chunk * ntr + k] = 0.0;
+        return;
+    }
+    JQ_CQ_IMR_PROLOGUE
+    constexpr int CHS = CoopQ<NT>::CHS, PAR = CoopQ<NT>::PAR;
+    double u = st[s.foff], v = st[(size_t)KT * 64 + s.foff];
+    double lr = st[(size_t)2 * KT * 64 + s.foff], li = st[(size_t)3 * KT * 64 + s.foff];
+    const double wgt = a.colinfo[(size_t)s.slab * 32 + 16 + s.col];
+    const double cfw = a.forced ? -a.h * a.tinv * wdr : 0.0;      // h * (-tinv * W): W applied row-wise
+    double* trw = a.traces + ((trow + wave) * a.nsteps_chunk) * ntr;
+    for (int n = 0; n < a.nsteps_chunk; ++n) {
+        m.K = c.load(c.ring.template ks<0, 1>());
+        m.S = c.load(c.ring.template ks<1, 1>());
+        double su = u, sv = v, smu = lr, snu = li;
+        m.template step<true>(u, v, 0.0, 0.0);
+        c.ring.advance();
+        su += u;
+        sv += v;
+        m.template step<false>(lr, li, cfw * su, cfw * sv);
+        smu += lr;
+        snu += li;
+        // trace products with the constant images (Hsym_q: image q, Hanti_q: image Nc + q): one publication of (su, sv)
+        const int po = m.par * PAR;
+        m.post(po, su, sv);
+        const Sh shu = c.sh(su), shv = c.sh(sv);
+        c.sync();
+        m.par ^= 1;
+        Nb nsu, nsv;
+        nsu.b = c.xb[po], nsu.a = c.xb[po + 128];
+        nsv.b = c.xb[po + CHS], nsv.a = c.xb[po + CHS + 128];
+        double* tr = trw + (size_t)n * ntr;
+        for (int qp = 0; qp < Nc; qp += 2) {
+            double P[2] = {0.0, 0.0}, Q[2] = {0.0, 0.0};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = qp + j;
+                if (q < Nc) {
+                    const double* Hs = c.ring.cimg(q);
+                    const double* Ha = c.ring.cimg(Nc + q);
+                    const double B = -(smu * c.template trace_mm<false>(Hs, q, shv, nsv));
+                    const double D = snu * c.template trace_mm<false>(Ha, q, shv, nsv);
+                    const double C = snu * c.template trace_mm<false>(Hs, q, shu, nsu);
+                    const double A = smu * c.template trace_mm<false>(Ha, q, shu, nsu);
+                    P[j] = (B + C) * wgt;
+                    Q[j] = (A + D) * wgt;
+                }
+            }
+            // sums over the wave of P[0], P[1], Q[0], Q[1]: valid in the rows 0, 1, 2, 3 (wave_sum4: a, c, b, d)
+            const double r = wave_sum4(P[0], Q[0], P[1], Q[1]);
+            const int row = lane_ >> 4, q = qp + (row & 1);
+            if (q < Nc) {
+                const int l = lane_ & 15;
+                if (l == 0) tr[q * JQ_NTR + (row < 2 ? 3 : 4)] = row < 2 ? -0.25 * r : 0.25 * r;
+                else if (l < 4 && row < 2) tr[q * JQ_NTR + l - 1] = 0.0;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    st[s.foff] = u;
+    st[(size_t)KT * 64 + s.foff] = v;
+    st[(size_t)2 * KT * 64 + s.foff] = lr;
+    st[(size_t)3 * KT * 64 + s.foff] = li;
+}

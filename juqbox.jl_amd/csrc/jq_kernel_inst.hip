@@ -9,7 +9,7 @@
 //              9: cooperative-quad kernels (one 16-row block per wave; single evaluations / small ensembles; JQ_BW = 7)
 //              4: row-lane kernels (one lane per (row, column); JQ_NT = padded row length NPJ, JQ_BW unused)
 #if !defined(JQ_NT) || !defined(JQ_BW) || !defined(JQ_VARIANT)
-#error "compile with -DJQ_NT=<tiles> -DJQ_BW=<band> -DJQ_VARIANT=<0..9>"
+#error "compile with -DJQ_NT=<tiles> -DJQ_BW=<band> -DJQ_VARIANT=<0..10>"
 #endif
 #if JQ_VARIANT == 9     // cooperative-quad (latency) kernels of the JQ_BW_T4 structure (JQ_BW = 7)
 #include "jq_cq_kernels.h"
@@ -19,6 +19,10 @@ template __global__ void k_backward_cq<JQ_NT, false, true>(PropArgs);      // (c
 template __global__ void k_forward_cq<JQ_NT, true>(PropArgs);      // (odd number of Neumann terms)
 template __global__ void k_backward_cq<JQ_NT, true, false>(PropArgs);
 template __global__ void k_backward_cq<JQ_NT, true, true>(PropArgs);
+#elif JQ_VARIANT == 10  // cooperative-quad kernels of the implicit-midpoint integrator (JQ_BW = 7, N = 4)
+#include "jq_cq_imr_kernels.h"
+template __global__ void k_forward_cq_imr<JQ_NT>(PropArgs);
+template __global__ void k_backward_cq_imr<JQ_NT>(PropArgs);
 #elif JQ_VARIANT == 7
 #include "jq_quad_imr_kernels.h"
 template __global__ void k_forward_quad_imr<JQ_NT>(PropArgs);

@@ -1100,6 +1100,25 @@ static int select_quad_imr_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel
 #undef JQ_PICKQI
     return fail(h, JQ_EUNSUPPORTED, "unsupported Hilbert dimension");
 }
+template <int NT> __global__ void k_forward_cq_imr(PropArgs);      // jq_cq_imr_kernels.h (own translation units)
+template <int NT> __global__ void k_backward_cq_imr(PropArgs);
+#define JQ_DECLCI(nt)                                                    \
+    extern template __global__ void k_forward_cq_imr<nt>(PropArgs);      \
+    extern template __global__ void k_backward_cq_imr<nt>(PropArgs);
+JQ_DECLCI(1) JQ_DECLCI(2) JQ_DECLCI(3) JQ_DECLCI(4) JQ_DECLCI(5) JQ_DECLCI(6)
+#undef JQ_DECLCI
+static int select_cq_imr_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
+{
+#define JQ_PICKCI(nt)                            \
+    if (h->NT == nt) {                           \
+        *fwd = k_forward_cq_imr<nt>;             \
+        *bwd = k_backward_cq_imr<nt>;            \
+        return JQ_OK;                            \
+    }
+    JQ_PICKCI(1) JQ_PICKCI(2) JQ_PICKCI(3) JQ_PICKCI(4) JQ_PICKCI(5) JQ_PICKCI(6)
+#undef JQ_PICKCI
+    return fail(h, JQ_EUNSUPPORTED, "unsupported Hilbert dimension");
+}
 // (spw: slabs per workgroup = waves per SIMD: workgroups of 4 spw waves)
 static int select_quad_kernels(jq_handle* h, int spw, prop_kernel_t* fwd, prop_kernel_t* bwd)
 {
@@ -1406,6 +1425,10 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     const bool cq = !imr && !lane && !rl && h->solver_id == 1 && h->cq_max_quads > 0 && nquads_used <= h->cq_max_quads &&
                     !getenv("JQ_QUAD8");      // (JQ_QUAD8 asks for a quad-layout variant explicitly)
     const int qps = h->parts > 1 ? 4 : (h->sps * h->N + 3) / 4;      // column quads of a full slab
+    // ... and of the implicit-midpoint integrator (jq_cq_imr_kernels.h): N = 4, one workgroup of NT waves per evaluation
+    const char* e_icq = getenv("JQ_IMR_CQ");
+    const bool imr_cq = imr_quad && h->N == 4 && h->parts == 1 && h->cq_max_quads > 0 && nquads_used <= h->cq_max_quads &&
+                        !(e_icq && atoi(e_icq) == 0);
     if (cq) spw = 0;
     const bool quad = spw > 0;
     const bool quad8 = spw > 1;
@@ -1413,7 +1436,8 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     prop_kernel_t kfwd, kbwd;
     lane_init_t klinit = nullptr;
     lane_term_t klterm = nullptr;
-    int rc = imr_quad ? select_quad_imr_kernels(h, &kfwd, &kbwd)
+    int rc = imr_cq ? select_cq_imr_kernels(h, &kfwd, &kbwd)
+             : imr_quad ? select_quad_imr_kernels(h, &kfwd, &kbwd)
              : imr_coop ? select_coop_imr_kernels(h, &kfwd, &kbwd)
              : imr_rl ? select_rowlane_imr_kernels(h, &kfwd, &kbwd)
              : rl ? select_rowlane_kernels(h, &kfwd, &kbwd)
@@ -1421,11 +1445,11 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
                   : cq ? select_cq_kernels(h, &kfwd, &kbwd)
                   : coop ? select_coop_kernels(h, &kfwd, &kbwd) : quad ? select_quad_kernels(h, spw, &kfwd, &kbwd) : select_kernels(h, &kfwd, &kbwd);
     if (rc) return rc;
-    const int nblocks = cq ? 4 * nslabs : rl ? (int)nwaves_rl : lane ? (int)(ncols / 64) : quad8 ? (nslabs + spw - 1) / spw : (coop || quad) ? nslabs : (nslabs + JQ_WAVES - 1) / JQ_WAVES;
-    const int nthreads = (lane || rl) ? 64 : (coop || cq) ? 64 * h->NT : quad8 ? 256 * spw : 256;
+    const int nblocks = (cq || imr_cq) ? 4 * nslabs : rl ? (int)nwaves_rl : lane ? (int)(ncols / 64) : quad8 ? (nslabs + spw - 1) / spw : (coop || quad) ? nslabs : (nslabs + JQ_WAVES - 1) / JQ_WAVES;
+    const int nthreads = (lane || rl) ? 64 : (coop || cq || imr_cq) ? 64 * h->NT : quad8 ? 256 * spw : 256;
     // per-step trace records: one per wave (cooperative, lane, row-lane, implicit-midpoint kernels) or one per workgroup
     // (slab / quad kernels: summed over the workgroup's waves in LDS)
-    const int trace_rows = cq ? nslabs * qps : (lane || rl) ? nblocks : coop ? nslabs * h->NT : imr_quad ? nslabs * JQ_WAVES : nblocks;
+    const int trace_rows = imr_cq ? nslabs * qps * h->NT : cq ? nslabs * qps : (lane || rl) ? nblocks : coop ? nslabs * h->NT : imr_quad ? nslabs * JQ_WAVES : nblocks;
     const long long stride = rl ? h->rl_stride : lane ? h->lane_stride : coop ? h->mat_elems_c : h->mat_elems;
     const double* himg = rl ? h->d_himg_r : lane ? h->d_himg_l : coop ? h->d_himg_c : h->d_himg;
     const size_t state_doubles = rl ? (size_t)JQ_ROWLANE_ROWS * nwaves_rl * 64
@@ -1540,9 +1564,9 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
                              : batch < 0 ? (size_t)(2 * JQ_WIN_TPS + 2 * h->Nc) * stride * 8
                                          : (size_t)2 * stride * 8;
     const size_t lds_cq = lds_stage + (size_t)32 * h->NT * 8 + (size_t)(6 * (h->NT + 2) + 2 * h->NT) * 64 * 8 + (size_t)(h->Nc + (h->Nc + 1) / 2) * h->NT * 64 * 8;      // tables, x exchange, wg-sum scratch, trace hand-off
-    const size_t lds_fwd = (lane || rl) ? 0 : cq ? lds_cq : imr_coop ? coop_imr_lds_bytes(h->NT, stride)
+    const size_t lds_fwd = (lane || rl) ? 0 : (cq || imr_cq) ? lds_cq : imr_coop ? coop_imr_lds_bytes(h->NT, stride)
                                            : lds_stage + (size_t)32 * h->NT * 8 + (coop ? (size_t)2 * h->KT * 64 * 8 + 128 : 0);      // (+ the Jacobi solver's partial norms)
-    const size_t lds_bwd = rl ? (h->rl_npj > 8 ? (size_t)2 * h->Nc * h->rl_stride * 8 : 0) : lane ? 0 : (coop || cq) ? lds_fwd
+    const size_t lds_bwd = rl ? (h->rl_npj > 8 ? (size_t)2 * h->Nc * h->rl_stride * 8 : 0) : lane ? 0 : (coop || cq || imr_cq) ? lds_fwd
                                 : imr_quad ? lds_fwd + (size_t)JQ_MAXNC * nthreads * 8 + (size_t)(nthreads / 64) * h->NT * 64 * 8
                                 : quad ? lds_stage + (size_t)bwd_lds_tail(h->NT, h->Nc, nthreads / 64, (long long)h->NT * 64)   // (a 16-row block per register)
                                 : lds_stage + (size_t)bwd_lds_tail(h->NT, h->Nc, JQ_WAVES, h->park_lds ? (long long)h->KT * 64 : 0);
@@ -1727,7 +1751,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     h->timing.mfma_executed = imr ? 0 : (!coop && !lane && !rl && h->BW == JQ_BW_T4) ? mfma / 4 : mfma;   // (the iteration counts of the implicit-midpoint solver are data dependent)
     h->timing.mfma_backward = h->timing.mfma_executed == 0 ? 0 : (h->timing.mfma_executed == mfma ? mfma - mfma_fwd : (mfma - mfma_fwd) / 4);
     h->timing.svts = (long long)nsamples * h->N * h->nsteps;
-    h->timing.kernel_family = cq ? 8 : imr_quad ? 7 : imr_coop ? 5 : imr ? 4 : rl ? 3 : lane ? 2 : coop ? 1 : quad ? 6 : 0;
+    h->timing.kernel_family = imr_cq ? 9 : cq ? 8 : imr_quad ? 7 : imr_coop ? 5 : imr ? 4 : rl ? 3 : lane ? 2 : coop ? 1 : quad ? 6 : 0;
     h->timing.kernel_size = rl ? h->rl_npj : lane ? h->lane_np : h->NT;
     h->timing.kernel_band = (rl || lane) ? 0 : coop ? h->BWc : (quad || cq) ? JQ_BW_T4Q : h->BW;
     h->timing.reserved = 0;

@@ -1,24 +1,39 @@
-"""Development aid: timings of the implicit-midpoint path (GPU) next to the CPU oracle."""
-import json, sys, time
-import numpy as np
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
-import juqbox_jl_amd as jq
-from oracle.oracle import Oracle
-cases = sys.argv[1:] or ["swap02", "flux", "cnot1", "cnot2"]     # (cnot3: the CPU oracle takes ~18 s)
-for case in cases:
-    p, info = jq.cases.BUILDERS[case]()
-    g = json.load(open("tests/golden/%s.json" % info["golden"])) if info.get("golden") else None
-    pcof = np.array(g["pcof0"]) if g and "pcof0" in g else info["pcof0"]
-    p.Integrator_id = jq.Implicit_Midpoint
-    p.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER_M, max_iter=100, tol=1e-12, nrhs=p.N)
-    wa = jq.Working_Arrays_M_HIP(p, pcof.size)
-    jq.traceobjgrad(pcof, p, wa)
+"""Single-evaluation latency of the implicit-midpoint path at cnot3 on the quad-layout kernels (default) and on the cooperative
+kernels (JQ_QUAD=0), next to the Stormer-Verlet path.  python scripts/time_imr.py"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+from conftest import case_inputs  # noqa: E402
+import juqbox_jl_amd as jq  # noqa: E402
+
+
+def run(tag, imr, env):
+    params, info, pcof, _ = case_inputs("cnot3")
+    if imr:
+        params.Integrator_id = jq.Implicit_Midpoint
+        params.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER_M, max_iter=100, tol=1e-12, nrhs=params.N)
+    os.environ.update(env)
+    try:
+        wa = (jq.Working_Arrays_M_HIP if imr else jq.Working_Arrays_HIP)(params, pcof.size)
+        jq.traceobjgrad(pcof, params, wa, False, True)
+        t0 = time.perf_counter()
+        r = jq.traceobjgrad(pcof, params, wa, False, True)
+        dt = time.perf_counter() - t0
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
     t = wa.last_timing()
-    t0 = time.perf_counter(); Oracle(p).traceobjgrad_imr(pcof, 100, 1e-12); tc = time.perf_counter() - t0
-    x, w = np.polynomial.legendre.leggauss(512)
-    shift = p.shift_weights_reference() if p.Ntot <= 4 else 0.01 * np.arange(p.Ntot)
-    jq.eval_f_g_grad(pcof, p, wa, x * 0.05, w * 0.5, True, shift=shift)
-    t2 = wa.last_timing()
-    print("%-8s Ntot=%2d nsteps=%5d  GPU single %.1f ms (fwd %.1f bwd %.1f) | CPU oracle %.0f ms | GPU 512 samples %.1f ms" % (
-        case, p.Ntot, p.nsteps, t["ms_total"], t["ms_forward"], t["ms_backward"], tc * 1e3, t2["ms_total"]), flush=True)
+    print("%-28s %.3f s  (forward %.1f ms, backward %.1f ms, family %d)  objf %.15e  |grad| %.15e" %
+          (tag, dt, t["ms_forward"], t["ms_backward"], t["kernel_family"], r[0], float(np.linalg.norm(r[1]))), flush=True)
     wa.close()
+
+
+run("Stormer-Verlet", False, {})
+run("implicit midpoint, cq", True, {})
+run("implicit midpoint, quad", True, {"JQ_IMR_CQ": "0"})
+run("implicit midpoint, coop", True, {"JQ_QUAD": "0"})

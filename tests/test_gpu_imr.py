@@ -18,20 +18,25 @@ def _imr_params(jq, case):
     return params, pcof
 
 
-@pytest.mark.parametrize("case", ["rabi", "swap02", "flux", "cnot2", "cnot2-leakieq", "cnot2-jacobi", "cnot3", "cnot3:coop"])
+@pytest.mark.parametrize("case", ["rabi", "swap02", "flux", "cnot2", "cnot2-leakieq", "cnot2-jacobi", "cnot3", "cnot3:quad", "cnot3:coop"])
 def test_reference_imr_golden_through_the_callbacks(jq, case):
     """All seven implicit-midpoint goldens of the reference (second loop of test/runtests.jl:60-80): Ntot <= 16 on the
-    row-lane kernels (family 4), cnot3 (Ntot = 96 = 4 x 4 x 6) on the quad-layout kernels (family 7) and, with JQ_QUAD=0,
-    on the cooperative MFMA kernels (family 5)."""
+    row-lane kernels (family 4), cnot3 (Ntot = 96 = 4 x 4 x 6, N = 4) on the cooperative-quad kernels (family 9), with
+    JQ_IMR_CQ=0 on the quad-layout kernels (family 7) and, with JQ_QUAD=0, on the cooperative MFMA kernels (family 5)."""
     case, _, mode = case.partition(":")
     params, pcof = _imr_params(jq, case)
     golden = load_golden(case + "-imr")
-    if mode == "coop":
-        os.environ["JQ_QUAD"] = "0"
+    env = {"coop": {"JQ_QUAD": "0"}, "quad": {"JQ_IMR_CQ": "0"}}.get(mode, {})
+    os.environ.update(env)
     try:
         wa = jq.Working_Arrays_M_HIP(params, pcof.size)
+        _golden_checks(jq, params, pcof, wa, golden, mode)
     finally:
-        os.environ.pop("JQ_QUAD", None)
+        for k in env:
+            os.environ.pop(k, None)
+
+
+def _golden_checks(jq, params, pcof, wa, golden, mode):
     n = pcof.size
     if params.objFuncType == 3:                      # test/evalGrad.jl:14-25
         obj = np.array([jq.eval_f_par(pcof, params, wa), 0.0])
@@ -48,7 +53,7 @@ def test_reference_imr_golden_through_the_callbacks(jq, case):
         jq.eval_grad_f_par(pcof, grad, params, wa)
     assert reference_pass(obj, golden["obj0"]), (obj, golden["obj0"])
     assert reference_pass(grad, golden["grad0"])
-    assert wa.last_timing()["kernel_family"] == ((5 if mode == "coop" else 7) if params.Ntot > 16 else 4)
+    assert wa.last_timing()["kernel_family"] == ({"coop": 5, "quad": 7}.get(mode, 9) if params.Ntot > 16 else 4)
     wa.close()
 
 
@@ -108,7 +113,8 @@ def test_imr_is_refused_where_it_is_not_implemented(jq):
 @pytest.mark.parametrize("cfg", [(2, 1, 1, 1, 9, 1), (5, 3, 2, 2, 14, 3), (9, 2, 3, 1, 11, 2), (12, 4, 2, 2, 8, 1), (16, 4, 4, 1, 6, 3),
                                  (17, 5, 2, 1, 7, 3), (33, 3, 1, 2, 6, 1), (48, 4, 3, 1, 5, 2), (80, 16, 2, 1, 4, 1), (95, 2, 2, 1, 4, "band"),
                                  (48, 4, 2, 1, 5, "od"), (96, 4, 3, 1, 4, "od"), (32, 1, 2, 1, 6, "t4"), (48, 2, 3, 2, 5, "t4"),
-                                 (64, 4, 3, 1, 5, "t4"), (96, 4, 3, 1, 4, "t4"), (80, 3, 2, 1, 4, "t4")],
+                                 (64, 4, 3, 1, 5, "t4"), (96, 4, 3, 1, 4, "t4"), (80, 3, 2, 1, 4, "t4"), (96, 4, 3, 1, 4, "t4q"),
+                                 (48, 4, 4, 2, 7, "t4")],
                          ids=lambda c: "Ntot%d_N%d_Nc%d_f%d_o%s" % (c[0], c[1], c[2], c[3], c[5]))
 def test_imr_random_problems_match_oracle(jq, cfg):
     """Sizes and paddings the reference cases do not reach: every row-lane instantiation (NPJ 2..16), N = 1..4 columns
@@ -121,26 +127,36 @@ def test_imr_random_problems_match_oracle(jq, cfg):
     structure = False
     if oft == "od":          # Kronecker structure -> the JQ_BW_OD variant of the cooperative kernels
         structure, oft = "od", 1
-    if oft == "t4":          # 4 x 4 x n Kronecker structure -> the quad-layout kernels for N = 1, 2, 4 (N = 3: cooperative kernels)
-        structure, oft = "t4", 2
+    env = {"JQ_CHUNK_STEPS": "5"}
+    if oft == "t4q":         # ... N = 4 on the quad-layout kernels instead of the cooperative-quad ones
+        env["JQ_IMR_CQ"] = "0"
+        oft = "t4"
+    if oft == "t4":          # 4 x 4 x n Kronecker structure -> N = 4: the cooperative-quad kernels, N = 1, 2: the quad-layout kernels
+        structure, oft = "t4", 2             #                                (N = 3: cooperative kernels)
     if oft == "band":        # ladder-operator couplings: block band 1 (dense 96 x 96 images do not fit two LDS slots)
         structure, oft = True, 3
     p, pcof = random_problem(jq, rng, Ntot, N, Nc, Nfreq, nsteps, 3, oft, structure)
     p.Integrator_id = jq.Implicit_Midpoint
     p.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER_M, max_iter=60, tol=1e-11, nrhs=N)
     p.wmat = p.wmat_real.copy()
-    os.environ["JQ_CHUNK_STEPS"] = "5"
+    os.environ.update(env)
     try:
         wa = jq.Working_Arrays_M_HIP(p, pcof.size)
+        _random_checks(jq, p, pcof, wa, rng, Ntot, N, structure, "JQ_IMR_CQ" in env)
     finally:
-        os.environ.pop("JQ_CHUNK_STEPS", None)
+        for k in env:
+            os.environ.pop(k, None)
+
+
+def _random_checks(jq, p, pcof, wa, rng, Ntot, N, structure, noncq):
+    from oracle.oracle import Oracle
     r = Oracle(p, use_sparse=False).traceobjgrad_imr(pcof, 60, 1e-11, history=True)
     objfv, tg, prim, sec, tinf, ig, lg = jq.traceobjgrad(pcof, p, wa, False, True)
     gn = np.linalg.norm(r["totalgrad"])
     assert abs(prim - r["primaryobjf"]) <= 1e-9 and abs(sec - r["secondaryobjf"]) <= 1e-9 * max(abs(r["secondaryobjf"]), 1e-3)
     assert np.linalg.norm(tg - r["totalgrad"]) <= 1e-9 * gn and np.linalg.norm(ig - r["infidelgrad"]) <= 1e-9 * gn
     if structure == "t4":
-        assert wa.last_timing()["kernel_family"] == (7 if N in (1, 2, 4) else 5)
+        assert wa.last_timing()["kernel_family"] == (9 if N == 4 and not noncq else 7 if N in (1, 2, 4) else 5)
     _, hist, _ = jq.traceobjgrad(pcof, p, wa, True, False)
     assert np.max(np.abs(hist - r["history"])) < 1e-10
     for nq in (1, 3, 7):
@@ -190,3 +206,36 @@ def test_implicit_midpoint_large_batch_on_the_cooperative_kernels(jq):
         assert abs(p.last_infidelity - r["primaryobjf"]) <= 1e-10 * abs(r["primaryobjf"])
         assert np.linalg.norm(p.last_infidelity_grad - r["infidelgrad"]) <= 1e-9 * np.linalg.norm(r["infidelgrad"])
     wa.close()
+
+
+def test_imr_cooperative_quad_ensemble_matches_quad_layout(jq):
+    """45 samples (workgroups on many CUs, a ragged last slab) of a 4 x 4 x 5 problem with objFuncType 2 (two backward passes) and
+    three chunks: the cooperative-quad implicit-midpoint kernels against the quad-layout ones -- same fixed-point iterates and
+    stopping decisions, only the order of the sums differs."""
+    from test_gpu_random import random_problem
+    rng = np.random.default_rng(2024)
+    p, pcof = random_problem(jq, rng, 80, 4, 3, 2, 13, 3, 2, "t4")
+    p.Integrator_id = jq.Implicit_Midpoint
+    p.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER_M, max_iter=60, tol=1e-11, nrhs=4)
+    p.wmat = p.wmat_real.copy()
+    nodes, weights = 0.05 * rng.standard_normal(45), rng.random(45)
+    shift = 0.05 * rng.standard_normal(80)
+    shift[0] = 0.0
+    res = {}
+    for tag, env in (("cq", {}), ("quad", {"JQ_IMR_CQ": "0"})):
+        env = dict(env, JQ_CHUNK_STEPS="5")
+        os.environ.update(env)
+        try:
+            wa = jq.Working_Arrays_M_HIP(p, pcof.size)
+            jq.eval_f_g_grad(pcof, p, wa, nodes, weights, True, shift=shift)
+            res[tag] = (p.last_infidelity, p.last_leak, p.last_infidelity_grad.copy(), p.last_leak_grad.copy(),
+                        wa.last_timing()["kernel_family"])
+            wa.close()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    a, b = res["cq"], res["quad"]
+    assert a[4] == 9 and b[4] == 7
+    assert abs(a[0] - b[0]) <= 1e-12 * abs(b[0]) and abs(a[1] - b[1]) <= 1e-12 * abs(b[1])
+    assert np.linalg.norm(a[2] - b[2]) <= 1e-11 * np.linalg.norm(b[2])
+    assert np.linalg.norm(a[3] - b[3]) <= 1e-11 * np.linalg.norm(b[3])
