@@ -8,11 +8,15 @@
 // of a workgroup owns block mt of every array (one register per array), publishes its block of (x_u, x_v) in LDS (channels 0 and
 // 1 of the exchange image), passes ONE workgroup barrier per iteration and reads the two neighbouring blocks.  The stopping rule of
 // the reference -- |x_it - x_{it+1}|^2 < tol^2 for the u and the v part, summed over the evaluation -- needs a sum over all waves:
-// the per-lane squares of both parts are folded into one register (rows 0, 1: u part, rows 2, 3: v part; v_permlane32/16_swap) and
-// published in channel 2 TOGETHER with x_{it+1}, so that the test of iteration it rides on the barrier of iteration it + 1: every
-// wave adds the NT blocks in the same order (identical decisions in all waves), finishes the sums with four rotate-adds and either
-// keeps x_it (converged: the speculative publication of x_{it+1} is dropped) or goes on with the neighbours it has just read.
-// Publications per implicit step: 2 + (number of iterations), against the same number of four-product sweeps of a lone wave.
+// two extra REDUCER waves (one for the u part, one for the v part) read the published blocks of x_{it+1} behind the same barrier,
+// keep them for the next round, and leave their halves of the decision in LDS one barrier later, while the block waves go on
+// speculatively: when they learn that x_it was the result they have published x_{it+1} and x_{it+2} for nothing.  Every wave sees
+// the same decisions.  Publications per implicit step: 3 + (number of iterations).
+// Measured at cnot3 (scripts/time_imr_rounds.py): 785 cycles per publication round, 5.7 iterations per step; one evaluation 0.77 s on
+// the quad-layout kernels, 0.37 s with the block waves doing the reduction themselves (80 instructions per wave and round), 0.32 s
+// with one reducer wave (the block waves still folding their squares), 0.30 s as described (47 instructions per block wave).  The
+// round is bound by the two SIMDs that hold two block waves each (six blocks on four SIMDs): 2 x 47 instructions at the ~8 cycles
+// per instruction of two waves per SIMD (probes/dp_rate_probe.hip) = 750 cycles.
 // The parity of a publication is a run-time value here (the iteration count is data dependent).
 //
 // Same operator stream (K, S of the midpoint = time point 2n+1 of step n; window staging of WinRing: the DMA of the time points
@@ -34,6 +38,7 @@ struct CqImr {
     double tol2;
     int max_iter, par;
     bool use_shift;
+    volatile __attribute__((address_space(3))) int* flags;      // decisions of the reducer waves, [2 slots][2 parts]
 
     struct Acc {
         double au, kv, av;  // q_u = au - kv ; q_v = av
@@ -67,65 +72,93 @@ struct CqImr {
         c->xb[po + 64] = xu;
         c->xb[po + CHS + 64] = xv;
     }
-    // One implicit-midpoint step of (u, v); (fu, fv): forcing already multiplied by h.  FIRST: the first step of a time step
-    // (its first barrier drains the DMA issued one time step ago and is followed by the next DMA, see WinRing).
+    // One implicit-midpoint step of (u, v) on the block waves; (fu, fv): forcing already multiplied by h.  FIRST: the first step of
+    // a time step (its first barrier drains the DMA issued one time step ago and is followed by the next DMA, see WinRing).
+    // The reducer waves turn the publications j-1 and j into their parts of the decision on x_{j-1} between the barriers j and j+1;
+    // the block waves read it behind barrier j+1 -- and have meanwhile computed x_{j+1} and published it.
     template <bool FIRST>
     __device__ __forceinline__ void step(double& u, double& v, double fu, double fv)
     {
         // x = (u, v): B x, rhs = (x + f) + B x, x_1 = rhs + B x
         int po = par * PAR;
         post(po, u, v);
-        Acc b = own(0.0, 0.0, u, v);
+        Acc nx = own(0.0, 0.0, u, v);
         c->template sync<FIRST>();
         if (FIRST) {
             c->ring.issue_next();
             c->ring.issue_next();
         }
-        nbr(b, po);
+        nbr(nx, po);
         par ^= 1;
-        const double Bu = b.au - b.kv, Bv = b.av;
+        const double Bu = nx.au - nx.kv, Bv = nx.av;
         const double rhs_u = (u + fu) + Bu, rhs_v = (v + fv) + Bv;
-        double cu = rhs_u + Bu, cv = rhs_v + Bv;
-        // x_2
+        double au = rhs_u + Bu, av = rhs_v + Bv;      // x_1
         po = par * PAR;
-        post(po, cu, cv);
-        Acc nx = own(rhs_u, rhs_v, cu, cv);
+        post(po, au, av);
+        nx = own(rhs_u, rhs_v, au, av);
         c->sync();
         nbr(nx, po);
         par ^= 1;
-        double nu = nx.au - nx.kv, nv = nx.av;
-        // (cu, cv) = x_it, (nu, nv) = x_{it+1}; at it == max_iter x_it is kept without a test (jacobi_midpoint's iteration cap)
-        for (int it = 1; it < max_iter; ++it) {
-            double d = cu - nu, e = cv - nv;
-            d *= d;
-            e *= e;
-            row_swap32(d, e);
-            double p = d + e;        // rows 0, 1: u part; rows 2, 3: v part
-            double p2 = p;
-            row_swap16(p, p2);
-            p += p2;                 // rows 0, 1: 16 column partials of the u part (both rows alike); rows 2, 3: v part
+        double bu = nx.au - nx.kv, bv = nx.av;         // x_2
+        po = par * PAR;
+        post(po, bu, bv);
+        nx = own(rhs_u, rhs_v, bu, bv);
+        c->sync();
+        nbr(nx, po);
+        par ^= 1;
+        double cu = nx.au - nx.kv, cv = nx.av;         // x_3
+        // (au, av) = x_{j-2}, (bu, bv) = x_{j-1}, (cu, cv) = x_j
+        for (int j = 3;; ++j) {
             po = par * PAR;
-            post(po, nu, nv);        // (speculative: dropped if x_it turns out to be converged)
-            c->xb[po + 2 * CHS + 64] = p;
-            nx = own(rhs_u, rhs_v, nu, nv);
+            post(po, cu, cv);                          // (speculative, like x_{j-1}: dropped if x_{j-2} turns out to be the result)
+            nx = own(rhs_u, rhs_v, cu, cv);
             c->sync();
             par ^= 1;
-            double sum = x0[po + 2 * CHS + 64];
-#pragma unroll
-            for (int w = 1; w < NT; ++w) sum += x0[po + 2 * CHS + (w + 1) * 64];
-            sum = row_ror_add<8>(sum);
-            sum = row_ror_add<4>(sum);
-            sum = row_ror_add<2>(sum);
-            sum = row_ror_add<1>(sum);
-            if (__ballot(sum < tol2) == ~0ull) break;      // both parts below tol^2 (a NaN never converges, as in the reference)
-            nbr(nx, po);
-            cu = nu;
-            cv = nv;
-            nu = nx.au - nx.kv;
-            nv = nx.av;
+            const long long f = *(volatile __attribute__((address_space(3))) long long*)(flags + 2 * (j & 1));      // the decision on x_{j-2}
+            Acc t = nx;
+            nbr(t, po);                                // (the reads go out together with the flags')
+            if (__builtin_amdgcn_readfirstlane((int)f & (int)(f >> 32))) break;
+            au = bu, av = bv;
+            bu = cu, bv = cv;
+            cu = t.au - t.kv, cv = t.av;
         }
-        u = cu;
-        v = cv;
+        u = au;
+        v = av;
+    }
+    // The same step on a reducer wave (part 0: the u part = channel 0 of the exchange image, part 1: the v part): it passes the block
+    // waves' barriers; behind barrier j it reads the NT blocks of x_j (every block, in the same order), keeps them for the next
+    // round, and has the squared distance |x_{j-1} - x_j|^2 of its part summed over the evaluation (wave_sum): its half of the
+    // decision on x_{j-1} -- below tol^2, or the iteration cap of jacobi_midpoint reached -- goes to flags[(j - 1) & 1][part].  Like the
+    // block waves it learns the whole decision on x_{j-2} behind barrier j.
+    __device__ __forceinline__ void reducer_step(int part)
+    {
+        c->sync();
+        c->sync();      // x_1
+        double prev[NT];
+        {
+            const int po = (par ^ 1) * PAR + part * CHS;
+#pragma unroll
+            for (int w = 0; w < NT; ++w) prev[w] = x0[po + (w + 1) * 64];
+        }
+        for (int j = 2;; ++j) {
+            const int po = par * PAR + part * CHS;
+            c->sync();
+            par ^= 1;
+            if (j >= 3) {
+                const long long f = *(volatile __attribute__((address_space(3))) long long*)(flags + 2 * (j & 1));
+                if (__builtin_amdgcn_readfirstlane((int)f & (int)(f >> 32))) return;
+            }
+            double acc = 0.0;
+#pragma unroll
+            for (int w = 0; w < NT; ++w) {
+                const double cur = x0[po + (w + 1) * 64];
+                const double d = prev[w] - cur;
+                acc = fma(d, d, acc);
+                prev[w] = cur;
+            }
+            const bool keep = (j - 1 >= max_iter) || (wave_sum(acc) < tol2);      // (a NaN never converges, as in the reference)
+            flags[2 * ((j - 1) & 1) + part] = keep ? 1 : 0;
+        }
     }
 };
 
@@ -136,24 +169,33 @@ struct CqImr {
     double* tab = (double*)(smem + a.lds_tab_off);                                                                               \
     for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[(i & ~15) + 4 * (i & 3) + ((i >> 2) & 3)] = a.tabs[i];            \
     CoopQ<NT> c;                                                                                                                 \
-    c.setup(tab + 32 * NT, wave, lane_);                                                                                         \
-    c.ring.init(smem, a, wave, lane_, NT);      /* (barrier inside: the tables and the zeroed exchange image are published) */   \
+    c.setup(tab + 32 * NT, wave, lane_);        /* (reducer waves: chain 1, wave 0 / 1 -- they only read the exchange image) */  \
+    c.ring.init(smem, a, wave + NT * s.chain, lane_, NT + 2);      /* (barrier inside: tables, zeroed exchange image) */         \
+    c.ring.wave = wave, c.ring.nwaves = NT;     /* (from here on the block waves stage) */                                       \
     const double wdr = tab[16 * wave + s.g], wsr = tab[16 * NT + 16 * wave + s.g];                                               \
     double* st = a.state + (size_t)s.slab * a.state_stride;                                                                      \
     CqImr<NT> m;                                                                                                                 \
     m.c = &c;                                                                                                                    \
     m.x0 = (jq_lds_double*)(tab + 32 * NT + lane_);                                                                              \
     m.cw = 0.5 * a.h * a.colinfo[(size_t)s.slab * 32 + s.col] * wsr;                                                             \
-    m.tol2 = a.jacobi_tol2, m.max_iter = a.m, m.par = 0, m.use_shift = a.use_shift;
+    m.tol2 = a.jacobi_tol2, m.max_iter = a.m, m.par = 0, m.use_shift = a.use_shift;                                              \
+    m.flags = (volatile __attribute__((address_space(3))) int*)(tab + 32 * NT + 2 * CoopQ<NT>::PAR + NT * 64);
 
-// grid = 4 * nslabs (workgroup = column quad qd of slab blockIdx.x / 4 = one evaluation, N = 4), block = 64 * NT
+// grid = 4 * nslabs (workgroup = column quad qd of slab blockIdx.x / 4 = one evaluation, N = 4), block = 64 * (NT + 2): NT block
+// waves and the two reducer waves
 template <int NT>
-__global__ __launch_bounds__(64 * NT) void k_forward_cq_imr(PropArgs a)
+__global__ __launch_bounds__(64 * NT + 128) void k_forward_cq_imr(PropArgs a)
 {
     const CqSetup<NT> s = cq_setup<NT>(a);
     if (!s.active) return;      // (a quad without columns: the whole workgroup leaves before any barrier)
     JQ_CQ_IMR_PROLOGUE
     double* scratch = tab + 32 * NT + 2 * CoopQ<NT>::PAR;
+    if (s.chain) {      // reducer waves
+        for (int n = 0; n < a.nsteps_chunk; ++n) m.reducer_step(wave);
+        __syncthreads();      // (cq_wg_sum of the block waves)
+        __syncthreads();
+        return;
+    }
     double u = st[s.foff], v = st[(size_t)KT * 64 + s.foff];
     const bool slot0 = wave == 0 && ((lane_ >> 2) & 3) == 0;      // the lanes that carry per-column partials between chunks
     const size_t cslot = 16 * (lane_ >> 4) + s.col;
@@ -188,7 +230,7 @@ __global__ __launch_bounds__(64 * NT) void k_forward_cq_imr(PropArgs a)
 // -W (v + v_s) / T and the two gradient scalars of adjoint_grad_calc_m per control (:2660-2702) in the slots of the midpoint weights
 // of k_gradacc (jq_rowlane_imr_kernels.h): tr[3] = -(B + C)/4, tr[4] = (A + D)/4.  One trace record row per wave (its block's share).
 template <int NT>
-__global__ __launch_bounds__(64 * NT) void k_backward_cq_imr(PropArgs a)
+__global__ __launch_bounds__(64 * NT + 128) void k_backward_cq_imr(PropArgs a)
 {
     typedef typename CoopQ<NT>::Sh Sh;
     typedef typename CoopQ<NT>::Nb Nb;
@@ -202,6 +244,15 @@ __global__ __launch_bounds__(64 * NT) void k_backward_cq_imr(PropArgs a)
     }
     JQ_CQ_IMR_PROLOGUE
     constexpr int CHS = CoopQ<NT>::CHS, PAR = CoopQ<NT>::PAR;
+    if (s.chain) {      // reducer waves: state step, adjoint step, the publication of the trace products
+        for (int n = 0; n < a.nsteps_chunk; ++n) {
+            m.reducer_step(wave);
+            m.reducer_step(wave);
+            c.sync();
+            m.par ^= 1;
+        }
+        return;
+    }
     double u = st[s.foff], v = st[(size_t)KT * 64 + s.foff];
     double lr = st[(size_t)2 * KT * 64 + s.foff], li = st[(size_t)3 * KT * 64 + s.foff];
     const double wgt = a.colinfo[(size_t)s.slab * 32 + 16 + s.col];

@@ -1625,7 +1625,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
             for (int i = 0; i < 7; ++i) sched_pack(a.sched_bits, i, kinds[i], tps[i]);
         }
         HIPCHK(h, hipEventRecord(h->ev[evi++], s));
-        hipLaunchKernelGGL(kfwd, dim3(nblocks), dim3(cq ? nthreads + 128 : nthreads), lds_fwd, s, a);      // (cooperative quad: two staging waves)
+        hipLaunchKernelGGL(kfwd, dim3(nblocks), dim3(cq ? nthreads + 128 : imr_cq ? nthreads + 128 : nthreads), lds_fwd, s, a);      // (cooperative quad: two staging waves)
         HIPCHK(h, hipEventRecord(h->ev[evi++], s));
         mfma += (long long)nslabs * nc * (8 + 2 * h->m) * tiles;
     }
@@ -1687,7 +1687,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
                     }
                 }
                 HIPCHK(h, hipEventRecord(h->ev[evi++], s));
-                hipLaunchKernelGGL(kbwd, dim3(nblocks), dim3(cq ? 2 * nthreads : nthreads), lds_bwd, s, a);      // (cooperative quad: state and adjoint chain on separate waves)
+                hipLaunchKernelGGL(kbwd, dim3(nblocks), dim3(cq ? 2 * nthreads : imr_cq ? nthreads + 128 : nthreads), lds_bwd, s, a);      // (cooperative quad: state and adjoint chain on separate waves)
                 HIPCHK(h, hipEventRecord(h->ev[evi++], s));
                 hipLaunchKernelGGL(k_trace_reduce, dim3((unsigned)(((long long)nc * ntr + 255) / 256)), dim3(256), 0, s,
                                    h->d_traces, trace_rows, nc, ntr, h->d_R);
