@@ -256,7 +256,7 @@ def main():
         f_fwd = 2.0 * Ntot * Ntot * (9 + 2 * m)
         avg_launch_s = bwd_ms * 1e-3 / max(nb, 1)
         fam = {0: "k_backward", 1: "k_backward_coop", 2: "k_backward_lane", 3: "k_backward_rowlane", 4: "k_backward_rowlane_imr",
-               5: "k_backward_coop_imr", 6: "k_backward", 7: "k_backward_quad_imr", 8: "k_backward_cq"}.get(
+               5: "k_backward_coop_imr", 6: "k_backward", 7: "k_backward_quad_imr", 8: "k_backward_cq", 9: "k_backward_cq_imr"}.get(
                    tm.get("kernel_family", 0), "k_backward")
         kname = "%s<%d, %d>" % (fam, tm.get("kernel_size", 0), tm.get("kernel_band", 0))
         band = tm.get("kernel_band")
