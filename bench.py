@@ -344,6 +344,21 @@ def main():
             jq.eval_f_g_grad(pcof, params, wa, n9, w9, True, shift=s9)
             out["nine_node_ensemble"] = {"seconds": time.perf_counter() - t1, "evals_per_s": 9 / (time.perf_counter() - t1),
                                          "kernel_family": wa.last_timing()["kernel_family"]}
+            try:      # the reference's other integrator (implicit midpoint, the default of its examples) on the same problem
+                import copy
+                pm = copy.copy(params)
+                pm.Integrator_id = jq.Implicit_Midpoint
+                pm.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER_M, max_iter=100, tol=1e-12, nrhs=pm.N)
+                wm = jq.Working_Arrays_M_HIP(pm, pcof.size)
+                jq.traceobjgrad(pcof, pm, wm, False, True)
+                t1 = time.perf_counter()
+                jq.traceobjgrad(pcof, pm, wm, False, True)
+                out["single_evaluation_implicit_midpoint"] = {"seconds": time.perf_counter() - t1,
+                                                              "kernel_family": wm.last_timing()["kernel_family"],
+                                                              "solver": "jacobi_midpoint, max_iter 100, tol 1e-12 (test/runtests.jl:69-70)"}
+                wm.close()
+            except Exception as e:  # noqa: BLE001
+                out["single_evaluation_implicit_midpoint"] = {"error": str(e)[:200]}
             other = {}
             for ns in (4096, 6144):
                 if ns == args.samples_per_gpu:
