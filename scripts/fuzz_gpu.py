@@ -1,6 +1,6 @@
 """Randomised GPU-vs-oracle stress (development aid, not part of the test-suite): draws problem sizes, structures,
 kernel-family overrides, chunkings and ensemble sizes and compares objective / gradient with the CPU oracle.
-usage: fuzz_gpu.py [n_cases] [seed]"""
+usage: fuzz_gpu.py [n_cases] [seed]      (FUZZ_FOCUS=imr_cq: only the cooperative-quad implicit-midpoint kernels)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
@@ -31,11 +31,15 @@ def run(n_cases=50, seed=1, verbose=True):
         structure = rng.choice([False, True, "od", "t4", "t4"]) if Ntot > 16 else rng.choice([False, True, "t4"])
         structure = structure if isinstance(structure, str) else bool(structure)
         imr = bool(rng.random() < 0.3) and ((Ntot <= 16 and N <= 4) or (Ntot > 16 and structure is not False))
+        if os.environ.get("FUZZ_FOCUS") == "imr_cq":      # the cooperative-quad implicit-midpoint kernels: 4 x 4 x n structure, N = 4
+            Ntot, N, structure, imr = int(rng.choice([32, 48, 64, 80, 96])), 4, "t4", True
         env = {}
         if rng.random() < 0.5:
             env["JQ_CHUNK_STEPS"] = str(int(rng.integers(1, nsteps + 1)))
         mode = rng.choice(["auto", "JQ_COOP_MAX=0", "JQ_LANE=0", "JQ_ROWLANE_MAX=0", "JQ_OD=0", "JQ_QUAD=0", "JQ_WINDOW=0", "JQ_T4=0"])
-        if structure == "t4" and rng.random() < 0.5:      # the JQ_BW_T4 slab kernels instead of the quad-layout / cooperative ones
+        if os.environ.get("FUZZ_FOCUS") == "imr_cq":
+            mode = "auto"
+        elif structure == "t4" and rng.random() < 0.5:      # the JQ_BW_T4 slab kernels instead of the quad-layout / cooperative ones
             env["JQ_QUAD"] = "0"
             env["JQ_COOP_MAX"] = "0"
             env["JQ_LANE"] = "0"
