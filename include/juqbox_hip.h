@@ -92,7 +92,8 @@ typedef struct jq_timing {
                                2 lane (VALU, lane per column), 3 row-lane (VALU, lane per (row, column)),
                                4 row-lane, implicit midpoint, 5 cooperative, implicit midpoint,
                                6 quad layout (MFMA 4x4x4, four columns per wave; JQ_BW_T4), 7 the same, implicit midpoint,
-                               8 cooperative quad (one 16-row block per wave: single evaluations / small ensembles)  */
+                               8 cooperative quad (one 16-row block per wave: single evaluations / small ensembles),
+                               9 the same, implicit midpoint (N = 4)                                              */
     int32_t kernel_size;    /* template size parameter: NT (16-row tiles) for 0/1, NP for 2, NPJ for 3       */
     int32_t kernel_band;    /* block band of the MFMA families (9 = JQ_BW_OD: diagonal off-diagonal blocks,
                                8 = JQ_BW_T4: 4x4 diagonal blocks + diagonal couplings, 7 = the same, quad layout) */
@@ -143,9 +144,9 @@ int jq_set_linear_solver(jq_handle *h, int32_t solver_id, int32_t max_iter, doub
  * traceobjgrad method runs: 1 = the Stormer-Verlet path (default), 2 = the implicit-midpoint path
  * (traceobjgrad for Working_Arrays_M, src/evalobjgrad.jl:1042-1481) with the fixed-point solver
  * lsolver_object(solver=JACOBI_SOLVER_M, max_iter, tol) (src/linear_solvers.jl:52-55, :156-270).  For integrator 2 the
- * leakage weights are params.wmat (pass them with jq_update_wmat_diag).  Implemented for Ntot <= 16 with N <= 4
- * (row-lane kernels) and for 16 < Ntot <= 96 with block-banded operators in small batches (cooperative MFMA kernels);
- * JQ_EUNSUPPORTED otherwise. */
+ * leakage weights are params.wmat (pass them with jq_update_wmat_diag).  Implemented for Ntot <= 96 and N <= 16 columns per
+ * evaluation: row-lane kernels (Ntot <= 16, N <= 4), cooperative MFMA kernels (any batch size; dense 96 x 96 operators do not
+ * fit their LDS slots), quad-layout and cooperative-quad kernels for the 4 x 4 x n structure; JQ_EUNSUPPORTED otherwise. */
 int jq_set_integrator(jq_handle *h, int32_t integrator_id, int32_t max_iter, double tol);
 /* change_target!(params, new_Utarget) (src/evalobjgrad.jl:1492) */
 int jq_update_target(jq_handle *h, const double *Utarget_r, const double *Utarget_i);

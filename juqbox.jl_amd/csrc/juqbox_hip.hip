@@ -582,8 +582,9 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         h->nslots_bwd = 2;
         h->park_lds = (2 * slot + lds_bwd_fixed + park_bytes <= 163840) ? 1 : 0;
         // cooperative (row-split) kernels for small batches: NT waves per slab, needs NT >= 2
+        // (NT == 1: only the implicit-midpoint kernels are instantiated -- Ntot <= 16 with more than four columns per evaluation)
         h->mat_elems_c = 0;
-        if (h->NT >= 2) {
+        if (h->NT >= 2 || h->N > 4) {
             const long long ec = (((long long)h->NT * coop_row_elems(h->NT, h->BWc) + 127) / 128) * 128;
             const long long lds_c = (h->big ? 0 : 2 * ec * 8) + lds_fwd_fixed + 2LL * h->KT * 64 * 8;
             if (lds_c <= 163840) h->mat_elems_c = ec;
@@ -948,8 +949,8 @@ extern "C" int jq_set_integrator(jq_handle* h, int32_t integrator_id, int32_t ma
         return fail(h, JQ_EUNSUPPORTED, "jq_set_integrator: the implicit-midpoint path is implemented for N <= 16 (its solver's "
                                         "per-evaluation convergence test needs all columns of a sample in one workgroup)");
     if (!(h->rl_npj > 0 && h->N <= 4) && h->mat_elems_c == 0)
-        return fail(h, JQ_EUNSUPPORTED, "jq_set_integrator: the implicit-midpoint path needs Ntot <= 16 with N <= 4 (row-lane "
-                                        "kernels) or Ntot > 16 (cooperative kernels)");
+        return fail(h, JQ_EUNSUPPORTED, "jq_set_integrator: no implicit-midpoint kernels for these operators (the images of a step "
+                                        "do not fit the LDS)");
     h->integrator = 2;
     h->imr_max_iter = max_iter;
     h->imr_tol = tol;
@@ -1233,6 +1234,7 @@ static int select_rowlane_imr_kernels(jq_handle* h, prop_kernel_t* fwd, prop_ker
     extern template __global__ void k_forward_coop_imr<nt, bw>(PropArgs);     \
     extern template __global__ void k_backward_coop_imr<nt, bw>(PropArgs);
 JQ_FOR_EACH_COOP(JQ_DECLCI)
+JQ_DECLCI(1, 0)      // (Ntot <= 16 with N > 4: one wave per slab, the evaluation's columns in one wave)
 #undef JQ_DECLCI
 
 static int select_coop_imr_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
@@ -1244,6 +1246,7 @@ static int select_coop_imr_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel
         return JQ_OK;                          \
     }
     JQ_FOR_EACH_COOP(JQ_PICKCI)
+    JQ_PICKCI(1, 0)
 #undef JQ_PICKCI
     return fail(h, JQ_EUNSUPPORTED, "no cooperative implicit-midpoint kernel for this Hilbert dimension / band width");
 }
@@ -1384,10 +1387,10 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     const bool imr_quad = imr && !imr_rl && h->quad_max_slabs > 0 && (h->N == 1 || h->N == 2 || h->N == 4);
     const bool imr_coop = imr && !imr_rl && !imr_quad;
     if (imr_coop && (h->mat_elems_c == 0 || coop_imr_lds_bytes(h->NT, h->mat_elems_c) > 163840))
-        return fail(h, JQ_EUNSUPPORTED, "implicit midpoint: needs Ntot <= 16 with N <= 4, or 16 < Ntot <= 96");
+        return fail(h, JQ_EUNSUPPORTED, "implicit midpoint: the operator images of a step do not fit the LDS (dense Ntot = 96)");
     const int cpw = imr_rl ? imr_cols_per_wave(h->N) : 4;   // columns per wave of the row-lane kernels
     const bool rl = imr_rl || (!imr && h->rl_npj > 0 && h->solver_id == 1 && ncols_used <= h->rl_max_cols);
-    const bool lane = !rl && h->lane_np > 0 && h->solver_id == 1 && ncols_used >= h->lane_min_cols && ncols_used <= h->lane_max_cols;
+    const bool lane = !imr && !rl && h->lane_np > 0 && h->solver_id == 1 && ncols_used >= h->lane_min_cols && ncols_used <= h->lane_max_cols;
     const long long nwaves_rl = (ncols_used + cpw - 1) / cpw;
     const long long ncols = rl ? 4 * nwaves_rl : (ncols_used + 63) / 64 * 64;      // row-lane: column SLOTS (4 per wave)
     // JQ_BW_T4 structure, small batches: the quad-layout kernels (one workgroup per slab, its four waves carry four columns
@@ -1432,7 +1435,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     if (cq) spw = 0;
     const bool quad = spw > 0;
     const bool quad8 = spw > 1;
-    const bool coop = imr_coop || (!cq && !quad && !lane && !rl && h->mat_elems_c > 0 && (h->solver_id == 1 || h->big) && nslabs <= h->coop_max_slabs);      // (Ntot > 96: also the Jacobi solver)
+    const bool coop = imr_coop || (!cq && !quad && !lane && !rl && h->NT >= 2 && h->mat_elems_c > 0 && (h->solver_id == 1 || h->big) && nslabs <= h->coop_max_slabs);      // (Ntot > 96: also the Jacobi solver)
     prop_kernel_t kfwd, kbwd;
     lane_init_t klinit = nullptr;
     lane_term_t klterm = nullptr;

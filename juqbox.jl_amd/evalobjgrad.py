@@ -126,7 +126,8 @@ class Working_Arrays_M_HIP(Working_Arrays_HIP):
     """Working_Arrays_M (src/evalobjgrad.jl:445-500): selects the IMPLICIT-MIDPOINT method of traceobjgrad
     (:1042-1481) the way the reference does, by the type of `wa`.  `params.linear_solver` must be
     lsolver_object(solver=JACOBI_SOLVER_M, max_iter=..., tol=...) (test/runtests.jl:70); the leakage weights of this
-    path are params.wmat (:1147), not params.wmat_real.  Device support: Ntot <= 16."""
+    path are params.wmat (:1147), not params.wmat_real.  Device support: Ntot <= 96 (dense 96 x 96 operators excepted),
+    N <= 16."""
     INTEGRATOR = Implicit_Midpoint
     SOLVERS = (JACOBI_SOLVER_M,)
 

@@ -97,11 +97,11 @@ def test_imr_matches_oracle_including_history_and_ensemble(jq, case):
 
 
 def test_imr_is_refused_where_it_is_not_implemented(jq):
-    """Ntot <= 16 with more than 4 columns per evaluation has neither a row-lane nor a cooperative kernel."""
+    """More than 16 columns per evaluation: the solver's per-evaluation stopping test needs them in one workgroup."""
     from test_gpu_random import random_problem
-    p, pcof = random_problem(jq, np.random.default_rng(1), 16, 16, 1, 1, 5, 1, 1, False)
+    p, pcof = random_problem(jq, np.random.default_rng(1), 20, 18, 1, 1, 5, 1, 1, False)
     p.Integrator_id = jq.Implicit_Midpoint
-    p.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER_M, max_iter=50, tol=1e-11, nrhs=16)
+    p.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER_M, max_iter=50, tol=1e-11, nrhs=18)
     p.wmat = p.wmat_real.copy()
     wa = jq.Working_Arrays_M_HIP(p, pcof.size)
     with pytest.raises(RuntimeError) as e:
@@ -114,11 +114,12 @@ def test_imr_is_refused_where_it_is_not_implemented(jq):
                                  (17, 5, 2, 1, 7, 3), (33, 3, 1, 2, 6, 1), (48, 4, 3, 1, 5, 2), (80, 16, 2, 1, 4, 1), (95, 2, 2, 1, 4, "band"),
                                  (48, 4, 2, 1, 5, "od"), (96, 4, 3, 1, 4, "od"), (32, 1, 2, 1, 6, "t4"), (48, 2, 3, 2, 5, "t4"),
                                  (64, 4, 3, 1, 5, "t4"), (96, 4, 3, 1, 4, "t4"), (80, 3, 2, 1, 4, "t4"), (96, 4, 3, 1, 4, "t4q"),
-                                 (48, 4, 4, 2, 7, "t4")],
+                                 (48, 4, 4, 2, 7, "t4"), (16, 16, 1, 1, 5, 1), (9, 9, 2, 2, 7, 2), (12, 5, 3, 1, 6, 3), (6, 6, 1, 1, 9, 1),
+                                 (16, 7, 2, 1, 6, "t4")],
                          ids=lambda c: "Ntot%d_N%d_Nc%d_f%d_o%s" % (c[0], c[1], c[2], c[3], c[5]))
 def test_imr_random_problems_match_oracle(jq, cfg):
     """Sizes and paddings the reference cases do not reach: every row-lane instantiation (NPJ 2..16), N = 1..4 columns
-    (one, two or four evaluations per wave; an idle row for N = 3), 1..4 controls, objFuncType 1/2/3, several chunks,
+    (one, two or four evaluations per wave; an idle row for N = 3), Ntot <= 16 with 5..16 columns (one-wave cooperative kernels), 1..4 controls, objFuncType 1/2/3, several chunks,
     ensembles with ragged last waves."""
     from oracle.oracle import Oracle
     from test_gpu_random import random_problem
