@@ -30,7 +30,7 @@ def run(n_cases=50, seed=1, verbose=True):
         oft = int(rng.integers(1, 4))
         structure = rng.choice([False, True, "od", "t4", "t4"]) if Ntot > 16 else rng.choice([False, True, "t4"])
         structure = structure if isinstance(structure, str) else bool(structure)
-        imr = bool(rng.random() < 0.3) and ((Ntot <= 16 and N <= 4) or (Ntot > 16 and structure is not False))
+        imr = bool(rng.random() < 0.3) and (Ntot <= 16 or structure is not False)
         if os.environ.get("FUZZ_FOCUS") == "imr_cq":      # the cooperative-quad implicit-midpoint kernels: 4 x 4 x n structure, N = 4
             Ntot, N, structure, imr = int(rng.choice([32, 48, 64, 80, 96])), 4, "t4", True
         env = {}
