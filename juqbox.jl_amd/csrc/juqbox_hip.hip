@@ -523,6 +523,22 @@ static int create_impl(const jq_problem* p, jq_handle* h)
     h->wd.assign(p->wmat_real_diag, p->wmat_real_diag + p->Ntot);
     h->cfreq.assign(p->Cfreq, p->Cfreq + (size_t)nctrl * p->Nfreq);
 
+    // 4 x 4 x n structure with n = 7, 8 (Ntot 97 .. 128, e.g. cnot3 with more guard levels): the JQ_BW_T4 slab kernels and the
+    // quad-layout kernels are instantiated for it -- such a handle is not "big" (no cooperative kernels, no cooperative-quad ones:
+    // their LDS images do not fit).  JQ_T4BIG=0: treat it like any other Ntot > 96.
+    if (h->big && h->NT <= 8) {
+        bool t4 = block_band(h->Hconst.data(), h->Ntot) <= 1 && t4_structure(h->Hconst.data(), h->Ntot);
+        for (int q = 0; q < h->Nc && t4; ++q)
+            t4 = block_band(h->Hsym.data() + q * nn, h->Ntot) <= 1 && block_band(h->Hanti.data() + q * nn, h->Ntot) <= 1 &&
+                 t4_structure(h->Hsym.data() + q * nn, h->Ntot) && t4_structure(h->Hanti.data() + q * nn, h->Ntot);
+        for (const char* name : {"JQ_T4", "JQ_OD", "JQ_T4BIG"})
+            if (const char* e = getenv(name))
+                if (atoi(e) == 0) t4 = false;
+        if (const char* e = getenv("JQ_FORCE_DENSE"))
+            if (atoi(e) != 0) t4 = false;
+        if (t4) h->big = false;
+    }
+
     // block-band structure (16x16 blocks) of the operators: kernels exist for BW in {0,1,2,NT-1}
     {
         int bw = block_band(h->Hconst.data(), h->Ntot);
@@ -584,7 +600,7 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         // cooperative (row-split) kernels for small batches: NT waves per slab, needs NT >= 2
         // (NT == 1: only the implicit-midpoint kernels are instantiated -- Ntot <= 16 with more than four columns per evaluation)
         h->mat_elems_c = 0;
-        if (h->NT >= 2 || h->N > 4) {
+        if ((h->NT >= 2 || h->N > 4) && (h->NT <= 6 || h->big)) {      // (NT = 7, 8 with the JQ_BW_T4 structure: no cooperative kernels)
             const long long ec = (((long long)h->NT * coop_row_elems(h->NT, h->BWc) + 127) / 128) * 128;
             const long long lds_c = (h->big ? 0 : 2 * ec * 8) + lds_fwd_fixed + 2LL * h->KT * 64 * 8;
             if (lds_c <= 163840) h->mat_elems_c = ec;
@@ -634,7 +650,7 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         {
             const long long win = (2LL * JQ_WIN_TPS + 2LL * h->Nc) * slot;
             const long long tail = 32LL * h->NT * 8 + (6LL * (h->NT + 2) + 2 * h->NT) * 64 * 8 + (long long)(h->Nc + (h->Nc + 1) / 2) * h->NT * 64 * 8;
-            h->cq_max_quads = (h->BW == JQ_BW_T4 && h->NT >= 2 && h->quad_max_slabs > 0 && win + tail <= 163840) ? 2 * prop.multiProcessorCount : 0;      // (two rounds of them, 2 x 0.20 s at cnot3, still beat one round of the quad-layout kernels, 0.55 s)
+            h->cq_max_quads = (h->BW == JQ_BW_T4 && h->NT >= 2 && h->NT <= 6 && h->quad_max_slabs > 0 && win + tail <= 163840) ? 2 * prop.multiProcessorCount : 0;      // (two rounds of them, 2 x 0.20 s at cnot3, still beat one round of the quad-layout kernels, 0.55 s)
             if (const char* e = getenv("JQ_CQ"))
                 if (h->cq_max_quads > 0) h->cq_max_quads = atoi(e);
         }
@@ -948,7 +964,7 @@ extern "C" int jq_set_integrator(jq_handle* h, int32_t integrator_id, int32_t ma
     if (h->parts > 1)
         return fail(h, JQ_EUNSUPPORTED, "jq_set_integrator: the implicit-midpoint path is implemented for N <= 16 (its solver's "
                                         "per-evaluation convergence test needs all columns of a sample in one workgroup)");
-    if (!(h->rl_npj > 0 && h->N <= 4) && h->mat_elems_c == 0)
+    if (!(h->rl_npj > 0 && h->N <= 4) && h->mat_elems_c == 0 && !(h->quad_max_slabs > 0 && (h->N == 1 || h->N == 2 || h->N == 4)))
         return fail(h, JQ_EUNSUPPORTED, "jq_set_integrator: no implicit-midpoint kernels for these operators (the images of a step "
                                         "do not fit the LDS)");
     h->integrator = 2;
@@ -1018,7 +1034,7 @@ typedef void (*prop_kernel_t)(PropArgs);
 #define JQ_FOR_EACH_INST(X)                                                                       \
     X(1, 0) X(2, 0) X(2, 1) X(3, 0) X(3, 1) X(3, 2) X(4, 0) X(4, 1) X(4, 2) X(4, 3) X(5, 0) X(5, 1) \
     X(5, 2) X(5, 4) X(6, 0) X(6, 1) X(6, 2) X(6, 5) X(2, 9) X(3, 9) X(4, 9) X(5, 9) X(6, 9) X(1, 8) X(2, 8) X(3, 8)       \
-    X(4, 8) X(5, 8) X(6, 8)
+    X(4, 8) X(5, 8) X(6, 8) X(7, 8) X(8, 8)
 #define JQ_MINW_OF(nt) (((nt) <= JQ_MINW_MAXNT) ? 2 : 1)
 #define JQ_DECL(nt, bw)                                                                      \
     extern template __global__ void k_forward<nt, bw, JQ_MINW_OF(nt), false>(PropArgs);      \
@@ -1050,7 +1066,7 @@ static int select_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
     extern template __global__ void k_backward<nt, JQ_BW_T4Q, 2, false>(PropArgs);   \
     extern template __global__ void k_forward<nt, JQ_BW_T4Q, 3, false>(PropArgs);    \
     extern template __global__ void k_backward<nt, JQ_BW_T4Q, 3, false>(PropArgs);
-JQ_DECLQ(1) JQ_DECLQ(2) JQ_DECLQ(3) JQ_DECLQ(4) JQ_DECLQ(5) JQ_DECLQ(6)
+JQ_DECLQ(1) JQ_DECLQ(2) JQ_DECLQ(3) JQ_DECLQ(4) JQ_DECLQ(5) JQ_DECLQ(6) JQ_DECLQ(7) JQ_DECLQ(8)
 #undef JQ_DECLQ
 template <int NT, bool MODD> __global__ void k_forward_cq(PropArgs);            // jq_cq_kernels.h (own translation units)
 template <int NT, bool MODD, bool ORD> __global__ void k_backward_cq(PropArgs);
@@ -1087,7 +1103,7 @@ template <int NT> __global__ void k_backward_quad_imr(PropArgs);
 #define JQ_DECLQI(nt)                                                      \
     extern template __global__ void k_forward_quad_imr<nt>(PropArgs);      \
     extern template __global__ void k_backward_quad_imr<nt>(PropArgs);
-JQ_DECLQI(1) JQ_DECLQI(2) JQ_DECLQI(3) JQ_DECLQI(4) JQ_DECLQI(5) JQ_DECLQI(6)
+JQ_DECLQI(1) JQ_DECLQI(2) JQ_DECLQI(3) JQ_DECLQI(4) JQ_DECLQI(5) JQ_DECLQI(6) JQ_DECLQI(7) JQ_DECLQI(8)
 #undef JQ_DECLQI
 static int select_quad_imr_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
 {
@@ -1097,7 +1113,7 @@ static int select_quad_imr_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel
         *bwd = k_backward_quad_imr<nt>;            \
         return JQ_OK;                              \
     }
-    JQ_PICKQI(1) JQ_PICKQI(2) JQ_PICKQI(3) JQ_PICKQI(4) JQ_PICKQI(5) JQ_PICKQI(6)
+    JQ_PICKQI(1) JQ_PICKQI(2) JQ_PICKQI(3) JQ_PICKQI(4) JQ_PICKQI(5) JQ_PICKQI(6) JQ_PICKQI(7) JQ_PICKQI(8)
 #undef JQ_PICKQI
     return fail(h, JQ_EUNSUPPORTED, "unsupported Hilbert dimension");
 }
@@ -1129,7 +1145,7 @@ static int select_quad_kernels(jq_handle* h, int spw, prop_kernel_t* fwd, prop_k
         *bwd = spw == 3 ? k_backward<nt, JQ_BW_T4Q, 3, false> : spw == 2 ? k_backward<nt, JQ_BW_T4Q, 2, false> : k_backward<nt, JQ_BW_T4Q, 1, false>;  \
         return JQ_OK;                                                                                                                            \
     }
-    JQ_PICKQ(1) JQ_PICKQ(2) JQ_PICKQ(3) JQ_PICKQ(4) JQ_PICKQ(5) JQ_PICKQ(6)
+    JQ_PICKQ(1) JQ_PICKQ(2) JQ_PICKQ(3) JQ_PICKQ(4) JQ_PICKQ(5) JQ_PICKQ(6) JQ_PICKQ(7) JQ_PICKQ(8)
 #undef JQ_PICKQ
     return fail(h, JQ_EUNSUPPORTED, "unsupported Hilbert dimension");
 }

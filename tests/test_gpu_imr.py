@@ -115,7 +115,7 @@ def test_imr_is_refused_where_it_is_not_implemented(jq):
                                  (48, 4, 2, 1, 5, "od"), (96, 4, 3, 1, 4, "od"), (32, 1, 2, 1, 6, "t4"), (48, 2, 3, 2, 5, "t4"),
                                  (64, 4, 3, 1, 5, "t4"), (96, 4, 3, 1, 4, "t4"), (80, 3, 2, 1, 4, "t4"), (96, 4, 3, 1, 4, "t4q"),
                                  (48, 4, 4, 2, 7, "t4"), (16, 16, 1, 1, 5, 1), (9, 9, 2, 2, 7, 2), (12, 5, 3, 1, 6, 3), (6, 6, 1, 1, 9, 1),
-                                 (16, 7, 2, 1, 6, "t4")],
+                                 (16, 7, 2, 1, 6, "t4"), (112, 4, 3, 1, 4, "t4"), (128, 2, 2, 1, 4, "t4")],
                          ids=lambda c: "Ntot%d_N%d_Nc%d_f%d_o%s" % (c[0], c[1], c[2], c[3], c[5]))
 def test_imr_random_problems_match_oracle(jq, cfg):
     """Sizes and paddings the reference cases do not reach: every row-lane instantiation (NPJ 2..16), N = 1..4 columns
@@ -157,7 +157,7 @@ def _random_checks(jq, p, pcof, wa, rng, Ntot, N, structure, noncq):
     assert abs(prim - r["primaryobjf"]) <= 1e-9 and abs(sec - r["secondaryobjf"]) <= 1e-9 * max(abs(r["secondaryobjf"]), 1e-3)
     assert np.linalg.norm(tg - r["totalgrad"]) <= 1e-9 * gn and np.linalg.norm(ig - r["infidelgrad"]) <= 1e-9 * gn
     if structure == "t4":
-        assert wa.last_timing()["kernel_family"] == (9 if N == 4 and not noncq else 7 if N in (1, 2, 4) else 5)
+        assert wa.last_timing()["kernel_family"] == (9 if N == 4 and not noncq and Ntot <= 96 else 7 if N in (1, 2, 4) else 5)
     _, hist, _ = jq.traceobjgrad(pcof, p, wa, True, False)
     assert np.max(np.abs(hist - r["history"])) < 1e-10
     for nq in (1, 3, 7):

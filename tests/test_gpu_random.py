@@ -133,6 +133,11 @@ CASES = [
     (48, 3, 2, 1, 2, 1, 3, "t4", 1),
     (64, 6, 3, 1, 1, 3, 1, "t4", 0),
     (96, 2, 1, 2, 4, 7, 2, "t4", 3),
+    # 4 x 4 x 7 and 4 x 4 x 8 (Ntot 97 .. 128): JQ_BW_T4 slab kernels and quad-layout kernels with NT = 7, 8 (no cooperative /
+    # cooperative-quad kernels: "coop" falls back to the slab kernels, "slab-od" to the Ntot > 96 cooperative kernels)
+    (112, 4, 3, 1, 5, 6, 1, "t4", 2),
+    (128, 3, 2, 2, 4, 3, 2, "t4", 0),
+    (100, 2, 1, 1, 6, 4, 3, "t4", 3),
 ]
 
 
@@ -195,11 +200,11 @@ def test_random_problem_matches_oracle(jq, cfg, mode):
         assert np.linalg.norm(lg - r["leakgrad"]) <= TOL * gn
     if banded == "t4" and mode in ("slab", "slab-od"):      # the kernel variant under test really ran
         t = wa.last_timing()
-        assert t["kernel_family"] == 0 and (t["kernel_band"] == 8) == (mode == "slab")
+        assert t["kernel_family"] == (0 if Ntot <= 96 or mode == "slab" else 1) and (t["kernel_band"] == 8) == (mode == "slab")
     if mode in ("quad4", "quad8", "quad12"):
         assert wa.last_timing()["kernel_family"] == 6
     if banded == "t4" and Ntot > 16 and mode in ("auto", "coop"):      # auto: the cooperative-quad (latency) kernels
-        assert wa.last_timing()["kernel_family"] == (8 if mode == "auto" else 1)
+        assert wa.last_timing()["kernel_family"] == ((8 if mode == "auto" else 1) if Ntot <= 96 else (6 if mode == "auto" else 0))
     # per-step states
     _, hist, _ = jq.traceobjgrad(pcof, p, wa, True, False)
     assert np.max(np.abs(hist - r["history"])) < 1e-10
