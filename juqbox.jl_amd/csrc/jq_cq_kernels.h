@@ -519,9 +519,9 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
     double* tab = (double*)(smem + a.lds_tab_off);
     for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[(i & ~15) + 4 * (i & 3) + ((i >> 2) & 3)] = a.tabs[i];   // [block][g][r]
     CoopQ<NT> c;
-    double* scratch = tab + 32 * NT + 2 * CoopQ<NT>::PAR;      // [2 NT][64]
+    double* scratch = tab + 32 * NT + 2 * CoopQ<NT>::PAR;      // [2 NT][64]: the workgroup sums after the last time step
     const int ntr = Nc * JQ_NTR, ngroups = Nc + (Nc + 1) / 2;
-    double* red = scratch + 2 * NT * 64;                        // [ngroups][NT][64]
+    double* red = scratch;                                      // [ngroups][NT][64]: trace hand-off (dead by then: same LDS)
     c.setup(tab + 32 * NT, wave, lane_);
     c.ring.init(smem, a, wave_all, lane_, 2 * NT);
     c.ring.wave = wave, c.ring.nwaves = NT;      // (from here on the state waves stage)

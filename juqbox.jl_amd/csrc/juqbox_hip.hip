@@ -649,8 +649,8 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         // neighbour to split the work with).  JQ_CQ=0 disables them, JQ_CQ=<n> bounds the number of quads.
         {
             const long long win = (2LL * JQ_WIN_TPS + 2LL * h->Nc) * slot;
-            const long long tail = 32LL * h->NT * 8 + (6LL * (h->NT + 2) + 2 * h->NT) * 64 * 8 + (long long)(h->Nc + (h->Nc + 1) / 2) * h->NT * 64 * 8;
-            h->cq_max_quads = (h->BW == JQ_BW_T4 && h->NT >= 2 && h->NT <= 6 && h->quad_max_slabs > 0 && win + tail <= 163840) ? 2 * prop.multiProcessorCount : 0;      // (two rounds of them, 2 x 0.20 s at cnot3, still beat one round of the quad-layout kernels, 0.55 s)
+            const long long tail = 32LL * h->NT * 8 + 6LL * (h->NT + 2) * 64 * 8 + (long long)std::max(2, h->Nc + (h->Nc + 1) / 2) * h->NT * 64 * 8;      // (run_eval: lds_cq)
+            h->cq_max_quads = (h->BW == JQ_BW_T4 && h->NT >= 2 && h->NT <= 7 && h->quad_max_slabs > 0 && win + tail <= 163840) ? 2 * prop.multiProcessorCount : 0;      // (two rounds of them, 2 x 0.20 s at cnot3, still beat one round of the quad-layout kernels, 0.55 s)
             if (const char* e = getenv("JQ_CQ"))
                 if (h->cq_max_quads > 0) h->cq_max_quads = atoi(e);
         }
@@ -1077,7 +1077,7 @@ template <int NT, bool MODD, bool ORD> __global__ void k_backward_cq(PropArgs);
     extern template __global__ void k_forward_cq<nt, true>(PropArgs);      \
     extern template __global__ void k_backward_cq<nt, true, false>(PropArgs);     \
     extern template __global__ void k_backward_cq<nt, true, true>(PropArgs);
-JQ_DECLCQ(1) JQ_DECLCQ(2) JQ_DECLCQ(3) JQ_DECLCQ(4) JQ_DECLCQ(5) JQ_DECLCQ(6)
+JQ_DECLCQ(1) JQ_DECLCQ(2) JQ_DECLCQ(3) JQ_DECLCQ(4) JQ_DECLCQ(5) JQ_DECLCQ(6) JQ_DECLCQ(7)
 #undef JQ_DECLCQ
 // (instantiated for even and odd numbers of Neumann terms: the parities of the LDS exchange are compile-time constants)
 static int select_cq_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
@@ -1094,7 +1094,7 @@ static int select_cq_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bw
                     : (ord ? k_backward_cq<nt, false, true> : k_backward_cq<nt, false, false>);       \
         return JQ_OK;                                                              \
     }
-    JQ_PICKCQ(1) JQ_PICKCQ(2) JQ_PICKCQ(3) JQ_PICKCQ(4) JQ_PICKCQ(5) JQ_PICKCQ(6)
+    JQ_PICKCQ(1) JQ_PICKCQ(2) JQ_PICKCQ(3) JQ_PICKCQ(4) JQ_PICKCQ(5) JQ_PICKCQ(6) JQ_PICKCQ(7)
 #undef JQ_PICKCQ
     return fail(h, JQ_EUNSUPPORTED, "unsupported Hilbert dimension");
 }
@@ -1122,7 +1122,7 @@ template <int NT> __global__ void k_backward_cq_imr(PropArgs);
 #define JQ_DECLCI(nt)                                                    \
     extern template __global__ void k_forward_cq_imr<nt>(PropArgs);      \
     extern template __global__ void k_backward_cq_imr<nt>(PropArgs);
-JQ_DECLCI(1) JQ_DECLCI(2) JQ_DECLCI(3) JQ_DECLCI(4) JQ_DECLCI(5) JQ_DECLCI(6)
+JQ_DECLCI(1) JQ_DECLCI(2) JQ_DECLCI(3) JQ_DECLCI(4) JQ_DECLCI(5) JQ_DECLCI(6) JQ_DECLCI(7)
 #undef JQ_DECLCI
 static int select_cq_imr_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
 {
@@ -1132,7 +1132,7 @@ static int select_cq_imr_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t
         *bwd = k_backward_cq_imr<nt>;            \
         return JQ_OK;                            \
     }
-    JQ_PICKCI(1) JQ_PICKCI(2) JQ_PICKCI(3) JQ_PICKCI(4) JQ_PICKCI(5) JQ_PICKCI(6)
+    JQ_PICKCI(1) JQ_PICKCI(2) JQ_PICKCI(3) JQ_PICKCI(4) JQ_PICKCI(5) JQ_PICKCI(6) JQ_PICKCI(7)
 #undef JQ_PICKCI
     return fail(h, JQ_EUNSUPPORTED, "unsupported Hilbert dimension");
 }
@@ -1582,7 +1582,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
                              : batch > 0   ? (size_t)2 * (2 * batch + 1) * 2 * stride * 8 + (size_t)2 * h->Nc * stride * 8
                              : batch < 0 ? (size_t)(2 * JQ_WIN_TPS + 2 * h->Nc) * stride * 8
                                          : (size_t)2 * stride * 8;
-    const size_t lds_cq = lds_stage + (size_t)32 * h->NT * 8 + (size_t)(6 * (h->NT + 2) + 2 * h->NT) * 64 * 8 + (size_t)(h->Nc + (h->Nc + 1) / 2) * h->NT * 64 * 8;      // tables, x exchange, wg-sum scratch, trace hand-off
+    const size_t lds_cq = lds_stage + (size_t)32 * h->NT * 8 + (size_t)6 * (h->NT + 2) * 64 * 8 + (size_t)std::max(2, h->Nc + (h->Nc + 1) / 2) * h->NT * 64 * 8;      // tables, x exchange, trace hand-off / wg-sum scratch (one region)
     const size_t lds_fwd = (lane || rl) ? 0 : (cq || imr_cq) ? lds_cq : imr_coop ? coop_imr_lds_bytes(h->NT, stride)
                                            : lds_stage + (size_t)32 * h->NT * 8 + (coop ? (size_t)2 * h->KT * 64 * 8 + 128 : 0);      // (+ the Jacobi solver's partial norms)
     const size_t lds_bwd = rl ? (h->rl_npj > 8 ? (size_t)2 * h->Nc * h->rl_stride * 8 : 0) : lane ? 0 : (coop || cq || imr_cq) ? lds_fwd

@@ -157,7 +157,7 @@ def _random_checks(jq, p, pcof, wa, rng, Ntot, N, structure, noncq):
     assert abs(prim - r["primaryobjf"]) <= 1e-9 and abs(sec - r["secondaryobjf"]) <= 1e-9 * max(abs(r["secondaryobjf"]), 1e-3)
     assert np.linalg.norm(tg - r["totalgrad"]) <= 1e-9 * gn and np.linalg.norm(ig - r["infidelgrad"]) <= 1e-9 * gn
     if structure == "t4":
-        assert wa.last_timing()["kernel_family"] == (9 if N == 4 and not noncq and Ntot <= 96 else 7 if N in (1, 2, 4) else 5)
+        assert wa.last_timing()["kernel_family"] == (9 if N == 4 and not noncq and Ntot <= 112 else 7 if N in (1, 2, 4) else 5)
     _, hist, _ = jq.traceobjgrad(pcof, p, wa, True, False)
     assert np.max(np.abs(hist - r["history"])) < 1e-10
     for nq in (1, 3, 7):

@@ -133,8 +133,8 @@ CASES = [
     (48, 3, 2, 1, 2, 1, 3, "t4", 1),
     (64, 6, 3, 1, 1, 3, 1, "t4", 0),
     (96, 2, 1, 2, 4, 7, 2, "t4", 3),
-    # 4 x 4 x 7 and 4 x 4 x 8 (Ntot 97 .. 128): JQ_BW_T4 slab kernels and quad-layout kernels with NT = 7, 8 (no cooperative /
-    # cooperative-quad kernels: "coop" falls back to the slab kernels, "slab-od" to the Ntot > 96 cooperative kernels)
+    # 4 x 4 x 7 and 4 x 4 x 8 (Ntot 97 .. 128): JQ_BW_T4 slab kernels and quad-layout kernels with NT = 7, 8, cooperative-quad
+    # kernels with NT = 7 (no cooperative kernels: "coop" falls back to the slab kernels, "slab-od" to the Ntot > 96 cooperative ones)
     (112, 4, 3, 1, 5, 6, 1, "t4", 2),
     (128, 3, 2, 2, 4, 3, 2, "t4", 0),
     (100, 2, 1, 1, 6, 4, 3, "t4", 3),
@@ -204,7 +204,7 @@ def test_random_problem_matches_oracle(jq, cfg, mode):
     if mode in ("quad4", "quad8", "quad12"):
         assert wa.last_timing()["kernel_family"] == 6
     if banded == "t4" and Ntot > 16 and mode in ("auto", "coop"):      # auto: the cooperative-quad (latency) kernels
-        assert wa.last_timing()["kernel_family"] == ((8 if mode == "auto" else 1) if Ntot <= 96 else (6 if mode == "auto" else 0))
+        assert wa.last_timing()["kernel_family"] == ((8 if mode == "auto" else 1) if Ntot <= 96 else ((8 if Ntot <= 112 else 6) if mode == "auto" else 0))
     # per-step states
     _, hist, _ = jq.traceobjgrad(pcof, p, wa, True, False)
     assert np.max(np.abs(hist - r["history"])) < 1e-10
