@@ -829,7 +829,11 @@ static int try_embed(jq_handle* h, const jq_problem* p)
         for (int d2 = 1; d2 <= 4; ++d2) {
             if (Ntot % (d1 * d2) != 0) continue;
             const int d3 = Ntot / (d1 * d2);
-            if (d3 > 6 || d3 >= best_d3) continue;
+            if (d3 > 8 || d3 >= best_d3) continue;      // (the JQ_BW_T4 families are instantiated for n <= 8)
+            // n = 7, 8 (quad-layout kernels with one slab per workgroup only, no / fewer cooperative-quad kernels): worth it when
+            // the padding at most doubles the space (measured, scripts/time_embed_big.py: 3 x 4 x 7 10 x / 3 x faster for one evaluation /
+            // 3 072 samples, 3 x 3 x 8 3.3 x / 1.9 x; 2 x 2 x 8 1.7 x faster / 1.5 x SLOWER)
+            if (d3 > 6 && 16 * d3 > 2 * Ntot) continue;
             for (int r = 0; r < Ntot; ++r) row[r] = (r % d1) + 4 * ((r / d1) % d2) + 16 * (r / (d1 * d2));
             const int NE = 16 * d3;
             E.assign((size_t)NE * NE, 0.0);

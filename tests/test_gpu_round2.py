@@ -336,7 +336,8 @@ def test_cnot2_goldens_on_the_quad_layout_kernels_through_the_embedding(hip, cas
     wa.close()
 
 
-@pytest.mark.parametrize("dims,N,nq", [((3, 4, 1), 4, 700), ((2, 2, 3), 3, 5), ((3, 3, 5), 4, 40), ((4, 2, 6), 2, 9), ((2, 4, 2), 16, 3)])
+@pytest.mark.parametrize("dims,N,nq", [((3, 4, 1), 4, 700), ((2, 2, 3), 3, 5), ((3, 3, 5), 4, 40), ((4, 2, 6), 2, 9), ((2, 4, 2), 16, 3),
+                                       ((3, 4, 7), 4, 9), ((3, 3, 8), 2, 5)])
 def test_random_kronecker_problems_take_the_embedded_kernels(hip, dims, N, nq):
     """Random d1 x d2 x d3 problems (dense blocks on the fastest factor, diagonal couplings of the other two): large batches
     go to the embedded twin by default (family 6 or 0 with band 7 / 8), results against the oracle; with JQ_EMBED=0 the same
