@@ -38,7 +38,7 @@ def problem(dims, N, nsteps, rng):
     return p, 0.3 * rng.standard_normal(2 * Nc * 2 * 4)
 
 
-for dims in ((3, 4, 7), (3, 3, 8), (4, 3, 8), (2, 2, 8)):
+for dims in [tuple(int(c) for c in a.split("x")) for a in sys.argv[1:]] or ((3, 4, 7), (3, 3, 8), (4, 3, 8), (2, 2, 8)):
     rng = np.random.default_rng(5)
     p, pcof = problem(dims, 4, 2000, rng)
     line = "%d x %d x %d (Ntot %3d):" % (dims + (p.Ntot,))
