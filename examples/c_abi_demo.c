@@ -42,6 +42,10 @@ int main(void)
     p.Hconst = Hconst, p.Hsym_ops = Hsym, p.Hanti_ops = Hanti, p.Uinit = Uinit, p.Utarget_r = Vr, p.Utarget_i = Vi;
     p.wmat_real_diag = wdiag, p.Cfreq = Cfreq;
 
+    if (jq_abi_version() != JQ_ABI_VERSION) {
+        fprintf(stderr, "c_abi_demo: library ABI %d, header ABI %d\n", jq_abi_version(), JQ_ABI_VERSION);
+        return 3;
+    }
     if (jq_device_count() < 1) {
         fprintf(stderr, "c_abi_demo: no HIP device visible (%s has no CPU fallback)\n", jq_version());
         return 3;

@@ -31,6 +31,13 @@
 extern "C" {
 #endif
 
+/* ABI version of this header: the layout of jq_problem / jq_timing and the set of entry points.  jq_abi_version() returns the
+ * value the LIBRARY was built with; every binding (juqbox.jl_amd/_lib.py, julia/hip_backend.jl, examples/c_abi_demo.c) compares
+ * the two when it loads the library, so a caller compiled against an older header fails loudly instead of having
+ * jq_last_timing write past its struct.  History: 1 = round 1; 2 = jq_timing.mfma_backward, jq_problem.Hunc_ops / Rfreq;
+ * 3 = jq_timing.ms_allreduce / ms_shard_min / ms_shard_max, jq_abi_version(), up to JQ_MAX_CONTROLS control Hamiltonians. */
+#define JQ_ABI_VERSION 3
+
 #define JQ_OK 0
 #define JQ_EINVAL -1      /* bad argument (the reference's @assert / error(...) sites)            */
 #define JQ_EDIM -2        /* DimensionMismatch: nCoeff != length(pcof) (src/bsplines.jl:178-181)   */
@@ -99,6 +106,10 @@ typedef struct jq_timing {
                                8 = JQ_BW_T4: 4x4 diagonal blocks + diagonal couplings, 7 = the same, quad layout) */
     int32_t reserved;
     int64_t mfma_backward;  /* the part of mfma_executed issued by the k_backward launches                  */
+    double ms_allreduce;    /* multi-device handles: host wall time of the ONE all-reduce (group start .. result on the host);
+                               0 for single-device handles (their caller runs the collective)                  */
+    double ms_shard_min;    /* multi-device handles: smallest / largest ms_total over the devices that had a shard */
+    double ms_shard_max;    /* (single-device handles: both = ms_total)                                        */
 } jq_timing;
 
 /* ---- lifetime --------------------------------------------------------------------------------*/
@@ -122,10 +133,17 @@ const char *jq_last_error(const jq_handle *h);
  *   jq_set_* / jq_update_* apply to every device.
  * librccl.so is loaded at run time by this call (JQ_EUNSUPPORTED if it cannot be found); single-device users never
  * need it.  Errors: JQ_EINVAL if ndev < 1, ndev > jq_device_count() or a device id repeats.
+ * JQ_RCCL_LIB=<path> makes this call load exactly that librccl.
+ * TEST MODE: with JQ_MULTI_SAME_DEVICE=1 in the environment the `ndev` (<= 16) sub-handles may share physical GPUs (ids modulo
+ * the visible count) and the all-reduce is replaced by a host-side sum in device order -- host threads, streams, sharding and
+ * packing are the production code.  It exists so that the ndev > 1 paths run on a one-GPU box (tests/test_gpu_round3.py).
  */
 int jq_create_multi(const jq_problem *problem, const int32_t *devices, int32_t ndev, jq_handle **out);
 /* number of GPUs behind a handle (1 for jq_create handles) */
 int jq_num_devices(const jq_handle *h);
+/* HIP device id a handle is bound to (the first device of a multi-device handle; -1 for NULL): device pointers handed to
+ * jq_eval_f_g_grad_dev must live on THIS device */
+int jq_handle_device(const jq_handle *h);
 /*
  * The contiguous block partition of `nquad` ensemble samples over `world` shards (devices of a multi-device handle, or
  * the ranks of a torch.distributed / MPI job with one process per GPU): shard `rank` owns samples [*lo, *hi); the first
@@ -233,8 +251,12 @@ int jq_traceobj_sweep(jq_handle *h, const double *pcof, int32_t ncoeff, const do
 
 /* ---- measurement -----------------------------------------------------------------------------*/
 int jq_last_timing(const jq_handle *h, jq_timing *t);
-/* Library build info: "gfx950 juqbox_hip <version>" */
+/* Library build info: "gfx950 juqbox_hip <version> src:<12 hex digits>" -- the digits are the SHA-256 prefix of the library's
+ * sources (the .hip and .h files under csrc/ and include/juqbox_hip.h) at build time, so measurements recorded for one build (profiles/) cannot
+ * be paired with another build by accident (bench.py compares it). */
 const char *jq_version(void);
+/* JQ_ABI_VERSION of the header the library was built with */
+int jq_abi_version(void);
 
 #ifdef __cplusplus
 }

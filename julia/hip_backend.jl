@@ -52,6 +52,17 @@ struct JQTiming                           # == jq_timing
     kernel_band::Int32
     reserved::Int32
     mfma_backward::Int64
+    ms_allreduce::Float64
+    ms_shard_min::Float64
+    ms_shard_max::Float64
+end
+
+# the struct layouts above are those of JQ_ABI_VERSION 3 of include/juqbox_hip.h: refuse a library built for another one
+const JQ_ABI_VERSION = 3
+function jq_check_abi()
+    v = ccall((:jq_abi_version, libjq), Cint, ())
+    v == JQ_ABI_VERSION || error("libjuqbox_hip has ABI version $v, hip_backend.jl was written for $JQ_ABI_VERSION")
+    return nothing
 end
 
 abstract type AbstractWorkingArraysHIP end
@@ -74,6 +85,7 @@ leak_weights(::Working_Arrays_HIP, params) = Vector{Float64}(diag(params.wmat_re
 leak_weights(::Working_Arrays_M_HIP, params) = Vector{Float64}(diag(params.wmat))       # :1147
 
 function jq_new_handle(params, devices)
+    jq_check_abi()
     Ntot = params.N + params.Nguard
     Hc   = Matrix{Float64}(params.Hconst)                          # dense, column-major (also for use_sparse)
     Hs   = params.Ncoupled > 0 ? reduce(hcat, [vec(Matrix{Float64}(h)) for h in params.Hsym_ops]) : zeros(1, 1)
@@ -116,6 +128,7 @@ function Working_Arrays_M_HIP(params::objparams, nCoeff::Int64; devices = nothin
 end
 
 num_devices(wa::AbstractWorkingArraysHIP) = ccall((:jq_num_devices, libjq), Cint, (Ptr{Cvoid},), wa.handle)
+handle_device(wa::AbstractWorkingArraysHIP) = ccall((:jq_handle_device, libjq), Cint, (Ptr{Cvoid},), wa.handle)
 
 # params is mutated freely by scripts (Hconst inside eval_f_g_grad!, wmat_real, max_iter, targets): push before each call
 function sync!(wa::AbstractWorkingArraysHIP, params::objparams)

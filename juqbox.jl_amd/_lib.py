@@ -29,7 +29,11 @@ class jq_timing(ctypes.Structure):
                 ("ms_forward", ctypes.c_double), ("ms_backward", ctypes.c_double),
                 ("n_forward_launches", ctypes.c_int64), ("n_backward_launches", ctypes.c_int64), ("mfma_executed", ctypes.c_int64), ("svts", ctypes.c_int64),
                 ("kernel_family", ctypes.c_int32), ("kernel_size", ctypes.c_int32), ("kernel_band", ctypes.c_int32),
-                ("reserved", ctypes.c_int32), ("mfma_backward", ctypes.c_int64)]
+                ("reserved", ctypes.c_int32), ("mfma_backward", ctypes.c_int64),
+                ("ms_allreduce", ctypes.c_double), ("ms_shard_min", ctypes.c_double), ("ms_shard_max", ctypes.c_double)]
+
+
+JQ_ABI_VERSION = 3      # the struct layouts above (include/juqbox_hip.h JQ_ABI_VERSION); load() refuses any other library
 
 
 # every symbol include/juqbox_hip.h declares: name -> (restype, argtypes)
@@ -55,10 +59,12 @@ SYMBOLS = {
     "jq_create_multi": (ctypes.c_int, [ctypes.POINTER(jq_problem), ctypes.POINTER(ctypes.c_int32), c_i32,
                                        ctypes.POINTER(ctypes.c_void_p)]),
     "jq_num_devices": (ctypes.c_int, [ctypes.c_void_p]),
+    "jq_handle_device": (ctypes.c_int, [ctypes.c_void_p]),
     "jq_shard_bounds": (ctypes.c_int, [c_i32, c_i32, c_i32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "jq_traceobj_sweep": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_i32, c_dp, c_i32, c_dp, c_dp]),
     "jq_last_timing": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(jq_timing)]),
     "jq_version": (ctypes.c_char_p, []),
+    "jq_abi_version": (ctypes.c_int, []),
 }
 
 _lib = None
@@ -82,6 +88,9 @@ def load():
             fn = getattr(L, name)          # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        if L.jq_abi_version() != JQ_ABI_VERSION:
+            raise ImportError("libjuqbox_hip.so has ABI version %d, this binding is written for %d (rebuild: make -C "
+                              "juqbox.jl_amd/csrc)" % (L.jq_abi_version(), JQ_ABI_VERSION))
         _lib = L
     return _lib
 

@@ -19,6 +19,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -27,7 +28,10 @@
 #include <thread>
 #include <vector>
 
-#define JQ_VERSION "gfx950 juqbox_hip 0.2.0"
+#ifndef JQ_SRC_HASH
+#define JQ_SRC_HASH "unknown"      // (the Makefile passes the SHA-256 prefix of the library's sources)
+#endif
+#define JQ_VERSION "gfx950 juqbox_hip 0.3.0 src:" JQ_SRC_HASH
 #ifndef JQ_MINW_MAXNT
 #define JQ_MINW_MAXNT 2      // tile counts up to which two workgroups share a CU (slab kernels; jq_kernel_inst.hip)
 #endif
@@ -101,6 +105,8 @@ struct jq_handle {
     // handle owns no device memory itself
     std::vector<jq_handle*> subs;
     std::vector<ncclComm_t> comms;
+    bool host_reduce = false;   // JQ_MULTI_SAME_DEVICE test mode: host-side sum instead of the ncclAllReduce (no communicators)
+    bool comm_broken = false;   // an RCCL call failed inside a collective: the communicators are aborted at destroy, calls refuse
     std::vector<hipEvent_t> ev;
     std::string err;
     jq_timing timing = {};
@@ -122,6 +128,14 @@ static int fail(jq_handle* h, int code, const char* msg)
     h->err = msg;
     return code;
 }
+
+// restores the caller's current HIP device when a multi-device entry point returns (a Julia / PyTorch caller that was on
+// another device must not find itself switched)
+struct DeviceGuard {
+    int prev = -1;
+    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
 
 // A-fragment tile image of a column-major Ntot x Ntot matrix: only the tiles of the block band
 // |mt - kk/4| <= BW are stored, in walk order (kk outer, mt inner); tile (mt,kk) lane l holds
@@ -322,8 +336,25 @@ static int dev_alloc(jq_handle* h, T** p, size_t count)
         (void)hipFree(*p);
         *p = nullptr;
     }
-    HIPCHK(h, hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T)));
+    if (hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) {
+        *p = nullptr;
+        (void)hipGetLastError();      // (clear the sticky error: the handle stays usable for smaller requests)
+        char buf[160];
+        snprintf(buf, sizeof buf, "out of device memory (%zu bytes requested)", std::max<size_t>(count, 1) * sizeof(T));
+        return fail(h, JQ_ENOMEM, buf);
+    }
     return JQ_OK;
+}
+// grow-only buffer with its capacity: the capacity is zeroed BEFORE the old buffer is released, so a failed allocation
+// leaves (nullptr, 0) behind and the next call allocates again instead of launching on a stale capacity
+template <typename T>
+static int dev_grow(jq_handle* h, T** p, size_t* cap, size_t need)
+{
+    if (need <= *cap && *p) return JQ_OK;
+    *cap = 0;
+    const int rc = dev_alloc(h, p, need);
+    if (rc == JQ_OK) *cap = need;
+    return rc;
 }
 
 static int upload_operators(jq_handle* h)
@@ -418,6 +449,8 @@ extern "C" int jq_device_count(void)
 extern "C" int jq_set_device(int device) { return hipSetDevice(device) == hipSuccess ? JQ_OK : JQ_EHIP; }
 
 extern "C" const char* jq_version(void) { return JQ_VERSION; }
+
+extern "C" int jq_abi_version(void) { return JQ_ABI_VERSION; }
 
 extern "C" const char* jq_last_error(const jq_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
@@ -920,6 +953,7 @@ static int multi_traceobj_sweep(jq_handle* h, const double* pcof, int ncoeff, co
 // a single evaluation cannot be sharded: multi-device handles run it on their first device
 #define JQ_ON_FIRST(h, call)                         \
     if (!(h)->subs.empty()) {                        \
+        DeviceGuard guard_;                          \
         jq_handle* s0_ = (h)->subs[0];               \
         const int rc_ = (call);                      \
         if (rc_ != JQ_OK) (h)->err = s0_->err;       \
@@ -1332,9 +1366,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
             const jq_timing t1 = h->timing;
             const size_t npk = (size_t)2 + 2 * (size_t)ncoeff;
             if (rc == JQ_OK && d_packed) {
-                if (npk > h->cap_pk2) {
-                    if ((rc = dev_alloc(h, &h->d_pk2, npk)) == JQ_OK) h->cap_pk2 = npk;
-                }
+                rc = dev_grow(h, &h->d_pk2, &h->cap_pk2, npk);
                 if (rc == JQ_OK && hipMemcpyAsync(h->d_pk2, d_packed, npk * sizeof(double), hipMemcpyDeviceToDevice, h->stream) != hipSuccess)
                     rc = fail(h, JQ_EHIP, "hipMemcpyAsync (packed result of the first part of a split batch)");
             }
@@ -1355,6 +1387,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
             h->timing.n_forward_launches += t1.n_forward_launches, h->timing.n_backward_launches += t1.n_backward_launches;
             h->timing.mfma_executed += t1.mfma_executed, h->timing.mfma_backward += t1.mfma_backward, h->timing.svts += t1.svts;
             h->timing.kernel_family = t1.kernel_family, h->timing.kernel_size = t1.kernel_size, h->timing.kernel_band = t1.kernel_band;
+            h->timing.ms_shard_min = h->timing.ms_shard_max = h->timing.ms_total;
             return JQ_OK;
         }
     }
@@ -1495,35 +1528,22 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     }
 
     // ---- capacity ------------------------------------------------------------------------------
-    if ((size_t)ncoeff > h->cap_pcof) {
-        if ((rc = dev_alloc(h, &h->d_pcof, (size_t)ncoeff))) return rc;
-        h->cap_pcof = ncoeff;
-    }
-    if (state_doubles > h->cap_state) {
+    if ((rc = dev_grow(h, &h->d_pcof, &h->cap_pcof, (size_t)ncoeff))) return rc;
+    if (state_doubles > h->cap_state || !h->d_state || !h->d_state_save) {
+        h->cap_state = 0;
         if ((rc = dev_alloc(h, &h->d_state, state_doubles))) return rc;
         if ((rc = dev_alloc(h, &h->d_state_save, state_doubles))) return rc;
         h->cap_state = state_doubles;
     }
-    if (colinfo_doubles > h->cap_colinfo) {
-        if ((rc = dev_alloc(h, &h->d_colinfo, colinfo_doubles))) return rc;
-        h->cap_colinfo = colinfo_doubles;
-    }
-    if (!lane && !rl && (size_t)nslabs > h->cap_slabs) {
+    if ((rc = dev_grow(h, &h->d_colinfo, &h->cap_colinfo, colinfo_doubles))) return rc;
+    if (!lane && !rl && ((size_t)nslabs > h->cap_slabs || !h->d_park)) {
+        h->cap_slabs = 0;
         if ((rc = dev_alloc(h, &h->d_park, (size_t)nslabs * h->KT * 64))) return rc;
         h->cap_slabs = nslabs;
     }
-    if (adjoint && (size_t)trace_rows * cs * ntr > h->cap_traces) {
-        if ((rc = dev_alloc(h, &h->d_traces, (size_t)trace_rows * cs * ntr))) return rc;
-        h->cap_traces = (size_t)trace_rows * cs * ntr;
-    }
-    if ((size_t)2 * ncoeff > h->cap_grad) {
-        if ((rc = dev_alloc(h, &h->d_grad, (size_t)2 * ncoeff))) return rc;
-        h->cap_grad = 2 * ncoeff;
-    }
-    if ((size_t)nsamples * 4 > h->cap_res) {
-        if ((rc = dev_alloc(h, &h->d_res, (size_t)nsamples * 4))) return rc;
-        h->cap_res = (size_t)nsamples * 4;
-    }
+    if (adjoint && (rc = dev_grow(h, &h->d_traces, &h->cap_traces, (size_t)trace_rows * cs * ntr))) return rc;
+    if ((rc = dev_grow(h, &h->d_grad, &h->cap_grad, (size_t)2 * ncoeff))) return rc;
+    if ((rc = dev_grow(h, &h->d_res, &h->cap_res, (size_t)nsamples * 4))) return rc;
 
     // ---- inputs --------------------------------------------------------------------------------
     hipStream_t s = h->stream;
@@ -1724,10 +1744,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     HIPCHK(h, hipGetLastError());
     if (d_packed) {
         if (wgt) {
-            if ((size_t)nsamples > h->cap_wq) {
-                if ((rc = dev_alloc(h, &h->d_wq, (size_t)nsamples))) return rc;
-                h->cap_wq = nsamples;
-            }
+            if ((rc = dev_grow(h, &h->d_wq, &h->cap_wq, (size_t)nsamples))) return rc;
             HIPCHK(h, hipMemcpyAsync(h->d_wq, wgt, (size_t)nsamples * sizeof(double), hipMemcpyHostToDevice, s));
         }
         hipLaunchKernelGGL(k_pack, dim3(1), dim3(256), 0, s, h->d_res, wgt ? h->d_wq : nullptr, nsamples, h->d_grad, ncoeff,
@@ -1778,6 +1795,8 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     h->timing.kernel_size = rl ? h->rl_npj : lane ? h->lane_np : h->NT;
     h->timing.kernel_band = (rl || lane) ? 0 : coop ? h->BWc : (quad || cq) ? JQ_BW_T4Q : h->BW;
     h->timing.reserved = 0;
+    h->timing.ms_allreduce = 0.0;
+    h->timing.ms_shard_min = h->timing.ms_shard_max = h->timing.ms_total;
     return JQ_OK;
 }
 
@@ -1959,6 +1978,19 @@ extern "C" int jq_eval_f_g_grad_dev(jq_handle* h, const double* pcof, int32_t nc
     if (nquad < 0) return fail(h, JQ_EINVAL, "jq_eval_f_g_grad_dev: nquad must be >= 0");
     if (!h->subs.empty())
         return fail(h, JQ_EINVAL, "jq_eval_f_g_grad_dev: multi-device handles reduce inside jq_eval_f_g_grad; use that entry");
+    {   // the packed vector must live on the handle's GPU (a tensor allocated on torch's current device of a process that
+        // created the handle on another one would hand k_pack a peer pointer)
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, d_packed) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(h, JQ_EINVAL, "jq_eval_f_g_grad_dev: d_packed is not a device pointer");
+        }
+        if (at.type != hipMemoryTypeDevice || at.device != h->device) {
+            char buf[160];
+            snprintf(buf, sizeof buf, "jq_eval_f_g_grad_dev: d_packed lives on device %d, the handle on device %d", at.device, h->device);
+            return fail(h, JQ_EINVAL, buf);
+        }
+    }
     if (nquad == 0) {     // a rank without a shard contributes zeros to the all-reduce
         HIPCHK(h, hipSetDevice(h->device));
         HIPCHK(h, hipMemsetAsync(d_packed, 0, (2 + 2 * (size_t)ncoeff) * sizeof(double), h->stream));
@@ -2001,6 +2033,7 @@ struct RcclApi {
     void* lib = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;      // (optional)
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
@@ -2018,7 +2051,18 @@ static int load_rccl(std::string* err)
     // mapped, then the loader's search path.
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void* lib = nullptr;
-    {
+    // JQ_RCCL_LIB=<path>: load exactly this file (deployments with RCCL elsewhere; the tests point it at a missing file to
+    // check that a failing load is an error code, not a crash)
+    const char* forced = getenv("JQ_RCCL_LIB");
+    if (forced && *forced) {
+        lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+        if (!lib) {
+            const char* e = dlerror();      // (ONE call: dlerror() clears the pending message)
+            *err = std::string("jq_create_multi: cannot load librccl from JQ_RCCL_LIB (") + (e ? e : "?") + ")";
+            return JQ_EUNSUPPORTED;
+        }
+    }
+    if (!lib) {
         Dl_info di;
         if (dladdr((void*)&hipGetDeviceCount, &di) && di.dli_fname) {
             std::string dir(di.dli_fname);
@@ -2039,13 +2083,15 @@ static int load_rccl(std::string* err)
         lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
     }
     if (!lib) {
-        *err = std::string("jq_create_multi: cannot load librccl (") + (dlerror() ? dlerror() : "?") + ")";
+        const char* e = dlerror();      // (ONE call: dlerror() clears the pending message, a second call returns NULL)
+        *err = std::string("jq_create_multi: cannot load librccl (") + (e ? e : "?") + ")";
         return JQ_EUNSUPPORTED;
     }
     RcclApi a;
     a.lib = lib;
     a.CommInitAll = (decltype(a.CommInitAll))dlsym(lib, "ncclCommInitAll");
     a.CommDestroy = (decltype(a.CommDestroy))dlsym(lib, "ncclCommDestroy");
+    a.CommAbort = (decltype(a.CommAbort))dlsym(lib, "ncclCommAbort");
     a.AllReduce = (decltype(a.AllReduce))dlsym(lib, "ncclAllReduce");
     a.GroupStart = (decltype(a.GroupStart))dlsym(lib, "ncclGroupStart");
     a.GroupEnd = (decltype(a.GroupEnd))dlsym(lib, "ncclGroupEnd");
@@ -2080,14 +2126,20 @@ extern "C" int jq_shard_bounds(int32_t nquad, int32_t rank, int32_t world, int32
 
 extern "C" int jq_num_devices(const jq_handle* h) { return !h ? 0 : h->subs.empty() ? 1 : (int)h->subs.size(); }
 
+extern "C" int jq_handle_device(const jq_handle* h) { return h ? h->device : -1; }
+
 static void destroy_multi(jq_handle* h)
 {
+    int prev = 0;
+    const bool have_prev = hipGetDevice(&prev) == hipSuccess;
     for (size_t d = 0; d < h->comms.size(); ++d)
         if (h->comms[d] && g_rccl.CommDestroy) {
             (void)hipSetDevice(h->subs[d]->device);
-            (void)g_rccl.CommDestroy(h->comms[d]);
+            if (h->comm_broken && g_rccl.CommAbort) (void)g_rccl.CommAbort(h->comms[d]);
+            else (void)g_rccl.CommDestroy(h->comms[d]);
         }
     for (jq_handle* sub : h->subs) jq_destroy(sub);
+    if (have_prev) (void)hipSetDevice(prev);
     delete h;
 }
 
@@ -2100,7 +2152,13 @@ extern "C" int jq_create_multi(const jq_problem* problem, const int32_t* devices
     *out = nullptr;
     int avail = 0;
     if (hipGetDeviceCount(&avail) != hipSuccess) avail = 0;
-    if (ndev < 1 || ndev > avail) {
+    // JQ_MULTI_SAME_DEVICE=1 (TEST MODE, tests/test_gpu_round3.py): the `ndev` sub-handles may share physical GPUs (device id
+    // taken modulo the visible count, ndev <= 16) -- own streams, own host threads, the same sharding and packing code -- and the
+    // ONE step that needs distinct devices, the ncclAllReduce, is replaced by a host-side sum of the devices' packed vectors in
+    // device order.  This is how the ndev > 1 code runs on a one-GPU box; it is not a production path (no speed-up).
+    bool same_dev = false;
+    if (const char* e = getenv("JQ_MULTI_SAME_DEVICE")) same_dev = atoi(e) != 0;
+    if (ndev < 1 || (same_dev ? (avail < 1 || ndev > 16) : ndev > avail)) {
         char buf[160];
         snprintf(buf, sizeof buf, "jq_create_multi: ndev = %d but %d HIP device(s) are visible", ndev, avail);
         g_create_error = buf;
@@ -2109,18 +2167,19 @@ extern "C" int jq_create_multi(const jq_problem* problem, const int32_t* devices
     std::vector<int> devs(ndev);
     for (int d = 0; d < ndev; ++d) {
         devs[d] = devices ? devices[d] : d;
-        if (devs[d] < 0 || devs[d] >= avail || std::count(devs.begin(), devs.begin() + d, devs[d])) {
+        if (same_dev && devs[d] >= 0) devs[d] %= avail;
+        if (devs[d] < 0 || devs[d] >= avail || (!same_dev && std::count(devs.begin(), devs.begin() + d, devs[d]))) {
             g_create_error = "jq_create_multi: device ids must be distinct and < jq_device_count()";
             return JQ_EINVAL;
         }
     }
-    int prev = 0;
-    (void)hipGetDevice(&prev);
+    DeviceGuard guard;
     jq_handle* h = new (std::nothrow) jq_handle();
     if (!h) {
         g_create_error = "jq_create_multi: out of host memory";
         return JQ_ENOMEM;
     }
+    h->host_reduce = same_dev;
     int rc = JQ_OK;
     for (int d = 0; d < ndev && rc == JQ_OK; ++d) {
         if (hipSetDevice(devs[d]) != hipSuccess) {
@@ -2132,12 +2191,12 @@ extern "C" int jq_create_multi(const jq_problem* problem, const int32_t* devices
         rc = jq_create(problem, &sub);      // (sets g_create_error on failure)
         if (rc == JQ_OK) h->subs.push_back(sub);
     }
-    if (rc == JQ_OK) {
+    if (rc == JQ_OK && !h->host_reduce) {
         std::string err;
         rc = load_rccl(&err);
         if (rc != JQ_OK) g_create_error = err;
     }
-    if (rc == JQ_OK) {
+    if (rc == JQ_OK && !h->host_reduce) {
         h->comms.assign(ndev, nullptr);
         const ncclResult_t r = g_rccl.CommInitAll(h->comms.data(), ndev, devs.data());
         if (r != ncclSuccess) {
@@ -2146,7 +2205,6 @@ extern "C" int jq_create_multi(const jq_problem* problem, const int32_t* devices
             rc = JQ_EHIP;
         }
     }
-    (void)hipSetDevice(prev);
     if (rc != JQ_OK) {
         if (h->subs.empty()) delete h; else destroy_multi(h);
         return rc;
@@ -2174,13 +2232,16 @@ static int multi_forall(jq_handle* h, F f)
 }
 
 // timing of a multi-device call: the slowest device's times, work summed over the devices
-static void multi_timing(jq_handle* h)
+static void multi_timing(jq_handle* h, double ms_allreduce)
 {
     jq_timing t = {};
     bool first = true;
+    double smin = 0.0, smax = 0.0;
     for (const jq_handle* sub : h->subs) {
         const jq_timing& u = sub->timing;
         if (u.svts == 0) continue;     // device without a shard in the last call
+        smin = first ? u.ms_total : std::min(smin, u.ms_total);
+        smax = first ? u.ms_total : std::max(smax, u.ms_total);
         if (first || u.ms_total > t.ms_total) {
             const long long mf = t.mfma_executed, mb = t.mfma_backward, sv = t.svts;
             t = u;
@@ -2193,15 +2254,22 @@ static void multi_timing(jq_handle* h)
         t.svts += u.svts;
         first = false;
     }
+    t.ms_allreduce = ms_allreduce;
+    t.ms_shard_min = smin;
+    t.ms_shard_max = smax;
     h->timing = t;
 }
 
 static int multi_eval_f_g_grad(jq_handle* h, const double* pcof, int ncoeff, const double* nodes, const double* weights, int nquad,
                                const double* shift, bool adjoint, double* out2, double* infid_grad, double* leak_grad)
 {
+    if (h->comm_broken)
+        return fail(h, JQ_EHIP, "jq_eval_f_g_grad: an earlier RCCL failure left the communicators of this handle unusable; destroy it");
+    DeviceGuard guard;
     const int nd = (int)h->subs.size();
     const size_t npk = 2 + 2 * (size_t)ncoeff;
     std::vector<int> rcs(nd, JQ_OK);
+    std::vector<std::vector<double>> hostpk(h->host_reduce ? nd : 0);
     std::vector<std::thread> th;
     for (int d = 0; d < nd; ++d)
         th.emplace_back([&, d]() {
@@ -2211,17 +2279,19 @@ static int multi_eval_f_g_grad(jq_handle* h, const double* pcof, int ncoeff, con
             sub->timing = jq_timing{};
             auto body = [&]() -> int {
                 HIPCHK(sub, hipSetDevice(sub->device));
-                if (npk > sub->cap_pack) {
-                    int rc = dev_alloc(sub, &sub->d_pack, npk);
-                    if (rc) return rc;
-                    sub->cap_pack = npk;
-                }
+                if (int rc = dev_grow(sub, &sub->d_pack, &sub->cap_pack, npk)) return rc;
                 if (hi > lo) {
                     EvalOut o;
-                    return run_eval(sub, pcof, ncoeff, hi - lo, nodes + lo, weights + lo, shift, adjoint, nullptr, nullptr, &o, sub->d_pack);
+                    if (int rc = run_eval(sub, pcof, ncoeff, hi - lo, nodes + lo, weights + lo, shift, adjoint, nullptr, nullptr, &o, sub->d_pack)) return rc;
+                } else {
+                    HIPCHK(sub, hipMemsetAsync(sub->d_pack, 0, npk * sizeof(double), sub->stream));   // no shard: contributes zeros
+                    HIPCHK(sub, hipStreamSynchronize(sub->stream));
                 }
-                HIPCHK(sub, hipMemsetAsync(sub->d_pack, 0, npk * sizeof(double), sub->stream));   // no shard: contributes zeros
-                HIPCHK(sub, hipStreamSynchronize(sub->stream));
+                if (h->host_reduce) {      // (test mode: the packed vector goes to the host instead of into an all-reduce)
+                    hostpk[d].resize(npk);
+                    HIPCHK(sub, hipMemcpyAsync(hostpk[d].data(), sub->d_pack, npk * sizeof(double), hipMemcpyDeviceToHost, sub->stream));
+                    HIPCHK(sub, hipStreamSynchronize(sub->stream));
+                }
                 return JQ_OK;
             };
             rcs[d] = body();
@@ -2232,21 +2302,50 @@ static int multi_eval_f_g_grad(jq_handle* h, const double* pcof, int ncoeff, con
             h->err = h->subs[d]->err;
             return rcs[d];
         }
-    // ONE all-reduce (sum, fp64) of the packed vector over the devices
-    NCCLCHK(h, g_rccl.GroupStart());
-    for (int d = 0; d < nd; ++d) {
-        jq_handle* sub = h->subs[d];
-        HIPCHK(h, hipSetDevice(sub->device));
-        NCCLCHK(h, g_rccl.AllReduce(sub->d_pack, sub->d_pack, npk, ncclDouble, ncclSum, h->comms[d], sub->stream));
+    std::vector<double> packed(npk, 0.0);
+    const auto t0 = std::chrono::steady_clock::now();
+    if (h->host_reduce) {
+        for (int d = 0; d < nd; ++d)      // fixed order: device 0, 1, ...
+            for (size_t i = 0; i < npk; ++i) packed[i] += hostpk[d][i];
+    } else {
+        // ONE all-reduce (sum, fp64) of the packed vector over the devices.  Errors inside the group are collected: the group
+        // is ALWAYS closed (an open group would make the next collective on these communicators hang), then the first error
+        // is reported and the communicators are marked unusable.
+        std::string first_err;
+        auto note = [&](const char* what, const char* msg) {
+            if (first_err.empty()) first_err = std::string(what) + ": " + msg;
+        };
+        ncclResult_t r = g_rccl.GroupStart();
+        if (r != ncclSuccess) {
+            h->comm_broken = true;
+            h->err = std::string("RCCL error in ncclGroupStart: ") + g_rccl.GetErrorString(r);
+            return JQ_EHIP;
+        }
+        for (int d = 0; d < nd; ++d) {
+            jq_handle* sub = h->subs[d];
+            const hipError_t e = hipSetDevice(sub->device);
+            if (e != hipSuccess) {
+                note("hipSetDevice", hipGetErrorString(e));
+                continue;
+            }
+            r = g_rccl.AllReduce(sub->d_pack, sub->d_pack, npk, ncclDouble, ncclSum, h->comms[d], sub->stream);
+            if (r != ncclSuccess) note("ncclAllReduce", g_rccl.GetErrorString(r));
+        }
+        r = g_rccl.GroupEnd();
+        if (r != ncclSuccess) note("ncclGroupEnd", g_rccl.GetErrorString(r));
+        if (!first_err.empty()) {
+            h->comm_broken = true;
+            h->err = "RCCL all-reduce failed (" + first_err + ")";
+            return JQ_EHIP;
+        }
+        for (int d = nd - 1; d >= 0; --d) {
+            jq_handle* sub = h->subs[d];
+            HIPCHK(h, hipSetDevice(sub->device));
+            if (d == 0) HIPCHK(h, hipMemcpyAsync(packed.data(), sub->d_pack, npk * sizeof(double), hipMemcpyDeviceToHost, sub->stream));
+            HIPCHK(h, hipStreamSynchronize(sub->stream));
+        }
     }
-    NCCLCHK(h, g_rccl.GroupEnd());
-    std::vector<double> packed(npk);
-    for (int d = nd - 1; d >= 0; --d) {
-        jq_handle* sub = h->subs[d];
-        HIPCHK(h, hipSetDevice(sub->device));
-        if (d == 0) HIPCHK(h, hipMemcpyAsync(packed.data(), sub->d_pack, npk * sizeof(double), hipMemcpyDeviceToHost, sub->stream));
-        HIPCHK(h, hipStreamSynchronize(sub->stream));
-    }
+    const double ms_ar = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     out2[0] = packed[0];
     out2[1] = packed[1];
     if (adjoint)
@@ -2254,13 +2353,14 @@ static int multi_eval_f_g_grad(jq_handle* h, const double* pcof, int ncoeff, con
             infid_grad[i] = packed[2 + i];
             leak_grad[i] = packed[2 + (size_t)ncoeff + i];
         }
-    multi_timing(h);
+    multi_timing(h, ms_ar);
     return JQ_OK;
 }
 
 static int multi_traceobj_sweep(jq_handle* h, const double* pcof, int ncoeff, const double* nodes, int nquad, const double* shift,
                                 double* out)
 {
+    DeviceGuard guard;
     const int nd = (int)h->subs.size();
     std::vector<int> rcs(nd, JQ_OK);
     std::vector<std::thread> th;
@@ -2278,7 +2378,7 @@ static int multi_traceobj_sweep(jq_handle* h, const double* pcof, int ncoeff, co
             h->err = h->subs[d]->err;
             return rcs[d];
         }
-    multi_timing(h);
+    multi_timing(h, 0.0);
     return JQ_OK;
 }
 

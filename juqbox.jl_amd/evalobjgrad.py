@@ -75,6 +75,8 @@ class Working_Arrays_HIP:
             raise _lib.JuqboxHipError(rc, msg.decode() if msg else "?")
         self.handle = h
         self.num_devices = L.jq_num_devices(h)
+        self.device = L.jq_handle_device(h)      # HIP device the handle is bound to (first one of a multi-device handle)
+        self.last_allreduce_ms = 0.0             # one process per GPU: wall time of the caller's all-reduce (ipopt_interface.py)
 
     def close(self):
         if getattr(self, "handle", None):

@@ -19,12 +19,28 @@ def _dist():
     return None
 
 
+def _shard_bounds_py(nquad, rank, world):
+    """jq_shard_bounds restated (juqbox_hip.hip): shard `rank` owns [lo, hi); the first nquad % world shards get one more."""
+    nquad, rank, world = int(nquad), int(rank), int(world)
+    if nquad < 0 or world < 1 or not 0 <= rank < world:
+        raise ValueError("shard_bounds: need nquad >= 0, world >= 1, 0 <= rank < world")
+    base, rem = divmod(nquad, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
 def shard_bounds(nquad, rank, world):
     """Contiguous block partition of the nquad ensemble samples over `world` ranks: the library's own
-    jq_shard_bounds (the partition a multi-device handle uses for its GPUs), so ranks and devices shard alike."""
+    jq_shard_bounds (the partition a multi-device handle uses for its GPUs), so ranks and devices shard alike.
+    Pure host arithmetic: where the library cannot be loaded (CPU-only sharding tests on a box without the build) the
+    same rule is evaluated in Python (tests/test_host_logic.py pins the two against each other)."""
     import ctypes
+    try:
+        L = _lib.load()
+    except (ImportError, OSError, AttributeError):
+        return _shard_bounds_py(nquad, rank, world)
     lo, hi = ctypes.c_int32(), ctypes.c_int32()
-    _lib.check(_lib.load().jq_shard_bounds(int(nquad), int(rank), int(world), ctypes.byref(lo), ctypes.byref(hi)))
+    _lib.check(L.jq_shard_bounds(int(nquad), int(rank), int(world), ctypes.byref(lo), ctypes.byref(hi)))
     return lo.value, hi.value
 
 
@@ -65,13 +81,17 @@ def _hip_shard_eval_dev(pcof, params, wa, nodes, weights, shift, compute_adjoint
     L, h = _lib.load(), wa.handle
     n = pcof.size
     wa.sync_params()
-    t = torch.empty(2 + 2 * n, dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
+    t = torch.empty(2 + 2 * n, dtype=torch.float64, device=torch.device("cuda", wa.device))      # on the HANDLE's device
     sh = _f64(shift) if shift is not None else None
     import ctypes
     _lib.check(L.jq_eval_f_g_grad_dev(h, _ptr(pcof), n, _ptr(nodes), _ptr(weights), nodes.size, _ptr(sh),
                                       1 if compute_adjoint else 0, ctypes.c_void_p(t.data_ptr())), h)
+    import time
+    t0 = time.perf_counter()                      # (jq_eval_f_g_grad_dev returned after its stream was synchronised)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return t.cpu().numpy()
+    res = t.cpu().numpy()                         # waits for the collective
+    wa.last_allreduce_ms = (time.perf_counter() - t0) * 1e3
+    return res
 
 
 def eval_f_g_grad(pcof, params, wa, nodes=(0.0,), weights=(1.0,), compute_adjoint=True, shift=None,
@@ -99,14 +119,20 @@ def eval_f_g_grad(pcof, params, wa, nodes=(0.0,), weights=(1.0,), compute_adjoin
     params.last_infidelity_grad = np.zeros(n)
     params.last_leak_grad = np.zeros(n) if params.objFuncType != 1 else np.zeros(0)
     packed = np.zeros(2 + 2 * n)
-    if dist is not None and dist.get_backend() == "nccl" and _shard_eval is _hip_shard_eval:
+    if dist is not None and dist.get_backend() == "nccl" and _shard_eval is _hip_shard_eval and wa.num_devices == 1:
         # one process per GPU (also with a single rank): partial sums stay on the device for the RCCL all-reduce
         packed[:] = _hip_shard_eval_dev(pcof, params, wa, nodes[lo:hi].copy(), weights[lo:hi].copy(), shift, compute_adjoint)
     else:
         if hi > lo:
             packed[:] = _shard_eval(pcof, params, wa, nodes[lo:hi].copy(), weights[lo:hi].copy(), shift, compute_adjoint)
         if dist is not None and dist.get_world_size() > 1:
-            allreduce_sum_(packed)
+            if dist.get_backend() == "nccl":      # (multi-device handle under an RCCL process group: collective on a device copy)
+                import torch
+                t = torch.from_numpy(packed).to(torch.device("cuda", wa.device))
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                packed[:] = t.cpu().numpy()
+            else:
+                allreduce_sum_(packed)
     params.last_pcof = pcof.copy()
     params.last_infidelity = float(packed[0])
     params.last_leak = float(packed[1])

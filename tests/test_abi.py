@@ -151,3 +151,26 @@ def test_the_header_is_plain_c_and_a_c_program_links_against_the_library(tmp_pat
         pytest.skip("a HIP device is visible: tests/test_gpu_parity.py runs the program")
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 3 and "no HIP device" in r.stderr and r.stdout == ""
+
+
+def test_abi_version_and_source_hash():
+    """jq_abi_version() equals the header's JQ_ABI_VERSION and the binding's; jq_version() carries the source hash of the build
+    (12 hex digits), which bench.py uses to refuse PMC records of another build."""
+    import re
+    from juqbox_jl_amd import _lib
+    L = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "juqbox_hip.h")).read()
+    v = int(re.search(r"#define JQ_ABI_VERSION (\d+)", hdr).group(1))
+    assert L.jq_abi_version() == v == _lib.JQ_ABI_VERSION
+    assert re.search(r"src:[0-9a-f]{12}$", L.jq_version().decode()), L.jq_version()
+    assert L.jq_handle_device(None) == -1 and L.jq_num_devices(None) == 0
+
+
+def test_python_shard_bounds_fallback_equals_the_library_rule():
+    from juqbox_jl_amd.ipopt_interface import _shard_bounds_py, shard_bounds
+    for nquad in (0, 1, 5, 64, 513):
+        for world in (1, 2, 3, 8, 16):
+            for r in range(world):
+                assert _shard_bounds_py(nquad, r, world) == shard_bounds(nquad, r, world)
+    with pytest.raises(ValueError):
+        _shard_bounds_py(8, 2, 2)
