@@ -38,6 +38,8 @@ extern "C" {
  * 3 = jq_timing.ms_allreduce / ms_shard_min / ms_shard_max, jq_abi_version(), up to JQ_MAX_CONTROLS control Hamiltonians. */
 #define JQ_ABI_VERSION 3
 
+#define JQ_MAX_CONTROLS 16 /* control Hamiltonians per problem (Ncoupled or Nunc)                   */
+
 #define JQ_OK 0
 #define JQ_EINVAL -1      /* bad argument (the reference's @assert / error(...) sites)            */
 #define JQ_EDIM -2        /* DimensionMismatch: nCoeff != length(pcof) (src/bsplines.jl:178-181)   */
@@ -55,7 +57,8 @@ typedef struct jq_handle jq_handle;
 typedef struct jq_problem {
     int32_t Ntot;          /* prod(Ne+Ng): Hilbert dimension incl. guard levels                   */
     int32_t N;             /* prod(Ne): number of initial-condition columns                       */
-    int32_t Ncoupled;      /* number of (Hsym_ops[k], Hanti_ops[k]) control pairs                 */
+    int32_t Ncoupled;      /* number of (Hsym_ops[k], Hanti_ops[k]) control pairs, <= JQ_MAX_CONTROLS (with more than four the
+                              backward sweep runs once per group of four controls)                   */
     int32_t Nfreq;         /* carrier frequencies per control = size(Cfreq,2)                     */
     int32_t nsteps;        /* params.nsteps                                                        */
     int32_t neumann_terms; /* params.linear_solver.max_iter (NEUMANN_SOLVER, linear_solvers.jl:37) */
@@ -168,7 +171,9 @@ int jq_set_linear_solver(jq_handle *h, int32_t solver_id, int32_t max_iter, doub
 int jq_set_integrator(jq_handle *h, int32_t integrator_id, int32_t max_iter, double tol);
 /* change_target!(params, new_Utarget) (src/evalobjgrad.jl:1492) */
 int jq_update_target(jq_handle *h, const double *Utarget_r, const double *Utarget_i);
-/* params.Hconst is mutated freely (src/ipopt_interface.jl:41-44, run_all.jl:13-15) */
+/* params.Hconst is mutated freely (src/ipopt_interface.jl:41-44, run_all.jl:13-15).  Kernels, operator images and LDS plan are
+ * chosen from the operators' nonzero structure at jq_create; a new drift with entries outside that structure re-plans the handle
+ * in place (same pointer, settings kept) -- slower kernels may result, never an error for a valid Hconst. */
 int jq_update_hconst(jq_handle *h, const double *Hconst);
 /* params.wmat_real = orig_wmatsetup(Ne,Ng) (e.g. test/cases/cnot3-setup.jl:253) */
 int jq_update_wmat_diag(jq_handle *h, const double *wmat_real_diag);

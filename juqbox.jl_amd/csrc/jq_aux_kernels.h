@@ -294,11 +294,13 @@ __global__ void k_trace_reduce(const double* __restrict__ traces, int nslabs, in
 #define JQ_GRADACC_THREADS 256
 __global__ __launch_bounds__(JQ_GRADACC_THREADS) void k_gradacc(SplineArgs s, const double* __restrict__ R,
                                                                 const double* __restrict__ tb, int n0, int nsteps_chunk,
-                                                                double h, double* grad)
+                                                                double h, double* grad, int q0, int ng)
 {
+    // (q0, ng): the control group [q0, q0 + ng) this backward sweep computed the traces of (R rows: [ng][JQ_NTR] per step);
+    // the grid covers the coefficients of those controls only
     __shared__ double red[JQ_GRADACC_THREADS];
-    const int idx = blockIdx.x;
     const int per_osc = 2 * s.Nfreq * s.D1;
+    const int idx = blockIdx.x + q0 * per_osc;
     const int q = idx / per_osc;
     const int rem = idx - q * per_osc;
     const int freq = rem / (2 * s.D1);
@@ -308,11 +310,11 @@ __global__ __launch_bounds__(JQ_GRADACC_THREADS) void k_gradacc(SplineArgs s, co
     const double om = s.cfreq[q + freq * s.Ncoupled];
     const double width = 3.0 * s.dtknot;
     const double tc = s.dtknot * ((double)kc - 1.5);
-    const int ntr = s.Ncoupled * JQ_NTR;
+    const int ntr = ng * JQ_NTR;
     double acc = 0.0;
     for (int m = threadIdx.x; m < nsteps_chunk; m += JQ_GRADACC_THREADS) {
         const double t0 = tb[n0 + m];
-        const double* r = R + (size_t)m * ntr + q * JQ_NTR;
+        const double* r = R + (size_t)m * ntr + (q - q0) * JQ_NTR;
         double step_acc = 0.0;
 #pragma unroll
         for (int w = 0; w < 3; ++w) {

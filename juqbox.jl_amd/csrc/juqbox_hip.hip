@@ -53,7 +53,11 @@ struct jq_handle {
     int parts = 1;              // N > 16: a sample's columns take `parts` = ceil(N / 16) consecutive slabs (sps = 1)
     int BW = 0;                 // block band width the kernels are instantiated for (JQ_BW_OD: see jq_kernels.h)
     int BWc = 0;                // ... of the cooperative kernels (plain band)
-    int bw_trace[JQ_MAXNC] = {0, 0, 0, 0};
+    // More than JQ_MAXNC (= 4, the kernels' trace / carry bookkeeping) control Hamiltonians: the propagators see ALL controls
+    // in K(t), S(t) (k_ctrl / k_stream are generic), only the gradient traces are per control -- the backward sweep then runs once
+    // per GROUP of at most JQ_MAXNC controls (ctrl_groups(); 5 .. 8 controls: two sweeps), each with its own trace images.
+    int NcK = 0;                // controls per backward sweep the LDS plan is made for: min(Nc, JQ_MAXNC)
+    int bw_trace[JQ_MAX_CONTROLS] = {0};
     long long mat_elems = 0;    // doubles per operator image slot ("stride"): band tiles, padded to 1 KiB
     long long mat_elems_c = 0;  // ... in the row-window layout of the cooperative kernels (0: not available)
     int coop_max_slabs = 256;   // batches with at most this many slabs (= CUs: one workgroup each) use the cooperative kernels
@@ -64,6 +68,7 @@ struct jq_handle {
     int batch = 0;              // > 0: batched staging (K/S images of `batch` time steps per DMA burst); < 0: window staging
     bool big = false;           // Ntot > 96 (NT = 7 .. 16): only the cooperative kernels with operators read from HBM (jq_coop_kernels.h
                                 // OpCursor) exist -- Stormer-Verlet, Neumann solver, any batch size
+    bool replanned = false;     // jq_update_hconst re-planned this handle: every later drift update plans again
     bool in_split = false;      // run_eval is evaluating one part of a split batch
     double* d_pk2 = nullptr;    // packed result of the first part of a split batch
     size_t cap_pk2 = 0;
@@ -86,6 +91,7 @@ struct jq_handle {
     double *d_himg_c = nullptr, *d_cimg_c = nullptr;   // operator images in the cooperative layout
     double *d_himg_l = nullptr, *d_uinit_l = nullptr, *d_vtr_l = nullptr, *d_vti_l = nullptr;   // lane kernels
     double *d_himg_r = nullptr, *d_uinit_r = nullptr, *d_vtr_r = nullptr, *d_vti_r = nullptr;   // row-lane kernels
+    double *d_cimg_l = nullptr, *d_cimg_r = nullptr;   // their trace images in control-group order
     double *d_himg = nullptr, *d_uimg = nullptr, *d_vtr = nullptr, *d_vti = nullptr, *d_tabs = nullptr;
     double *d_tf = nullptr, *d_tb = nullptr, *d_cfreq = nullptr, *d_pcof = nullptr;
     double *d_stream = nullptr, *d_pq = nullptr;
@@ -127,6 +133,14 @@ static int fail(jq_handle* h, int code, const char* msg)
 {
     h->err = msg;
     return code;
+}
+
+// control groups: group g of ctrl_ngroups(Nc) holds the controls [ctrl_gstart(Nc, g), ctrl_gstart(Nc, g + 1)); sizes differ by <= 1
+static int ctrl_ngroups(int Nc) { return (Nc + JQ_MAXNC - 1) / JQ_MAXNC; }
+static int ctrl_gstart(int Nc, int g)
+{
+    const int ng = ctrl_ngroups(Nc), base = Nc / ng, rem = Nc % ng;
+    return g * base + std::min(g, rem);
 }
 
 // restores the caller's current HIP device when a multi-device entry point returns (a Julia / PyTorch caller that was on
@@ -371,13 +385,20 @@ static int upload_operators(jq_handle* h)
         }
     }
     HIPCHK(h, hipMemcpy(h->d_himg, img.data(), img.size() * sizeof(double), hipMemcpyHostToDevice));
-    // images of the trace products: [Hsym_q | Hanti_q], each pair in its own band (0 or BW)
+    // images of the trace products, per control group g: [Hsym_q, q in g | Hanti_q, q in g] at image offset 2 gstart(g) -- for
+    // Nc <= JQ_MAXNC simply [Hsym_q | Hanti_q] -- each pair in its own band (0 or BW)
+    auto cslot = [&](int q, bool anti) {      // image index of control q's symmetric / antisymmetric trace image
+        int g = 0;
+        while (ctrl_gstart(h->Nc, g + 1) <= q) ++g;
+        const int gs = ctrl_gstart(h->Nc, g), ng = ctrl_gstart(h->Nc, g + 1) - gs;
+        return (size_t)(2 * gs + (anti ? ng : 0) + (q - gs));
+    };
     std::vector<double> cimg((size_t)(2 * h->Nc) * h->mat_elems, 0.0);
     for (int q = 0; q < h->Nc && !h->big; ++q) {
         const int bwq = (h->BW == JQ_BW_T4) ? JQ_BW_T4 : (h->bw_trace[q] == 0) ? 0 : h->BW;
         const bool sd = (h->BW == JQ_BW_T4) ? false : (h->bw_trace[q] == 2);
-        tile_image(h->Hsym.data() + q * nn, h->Ntot, h->NT, bwq, cimg.data() + (size_t)q * h->mat_elems, sd);
-        tile_image(h->Hanti.data() + q * nn, h->Ntot, h->NT, bwq, cimg.data() + (size_t)(h->Nc + q) * h->mat_elems, sd);
+        tile_image(h->Hsym.data() + q * nn, h->Ntot, h->NT, bwq, cimg.data() + cslot(q, false) * h->mat_elems, sd);
+        tile_image(h->Hanti.data() + q * nn, h->Ntot, h->NT, bwq, cimg.data() + cslot(q, true) * h->mat_elems, sd);
     }
     HIPCHK(h, hipMemcpy(h->d_cimg, cimg.data(), cimg.size() * sizeof(double), hipMemcpyHostToDevice));
     if (h->mat_elems_c > 0) {
@@ -388,9 +409,13 @@ static int upload_operators(jq_handle* h)
             tile_image_coop(h->Hanti.data() + q * nn, h->Ntot, h->NT, h->BWc, ic.data() + (size_t)(1 + h->Nc + q) * h->mat_elems_c);
         }
         HIPCHK(h, hipMemcpy(h->d_himg_c, ic.data(), ic.size() * sizeof(double), hipMemcpyHostToDevice));
-        // trace images [Hsym_q | Hanti_q] = images 1.. of the same array
-        HIPCHK(h, hipMemcpy(h->d_cimg_c, ic.data() + h->mat_elems_c, (size_t)2 * h->Nc * h->mat_elems_c * sizeof(double),
-                            hipMemcpyHostToDevice));
+        // trace images: the images 1.. of the same array, in control-group order
+        std::vector<double> cc((size_t)2 * h->Nc * h->mat_elems_c);
+        for (int q = 0; q < h->Nc; ++q) {
+            std::copy_n(ic.data() + (size_t)(1 + q) * h->mat_elems_c, h->mat_elems_c, cc.data() + cslot(q, false) * h->mat_elems_c);
+            std::copy_n(ic.data() + (size_t)(1 + h->Nc + q) * h->mat_elems_c, h->mat_elems_c, cc.data() + cslot(q, true) * h->mat_elems_c);
+        }
+        HIPCHK(h, hipMemcpy(h->d_cimg_c, cc.data(), cc.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     if (h->lane_np > 0) {
         std::vector<double> il((size_t)(1 + 2 * h->Nc) * h->lane_stride, 0.0);
@@ -400,6 +425,12 @@ static int upload_operators(jq_handle* h)
             plain_image(h->Hanti.data() + q * nn, h->Ntot, h->lane_np, il.data() + (size_t)(1 + h->Nc + q) * h->lane_stride);
         }
         HIPCHK(h, hipMemcpy(h->d_himg_l, il.data(), il.size() * sizeof(double), hipMemcpyHostToDevice));
+        std::vector<double> cl((size_t)2 * h->Nc * h->lane_stride);
+        for (int q = 0; q < h->Nc; ++q) {
+            std::copy_n(il.data() + (size_t)(1 + q) * h->lane_stride, h->lane_stride, cl.data() + cslot(q, false) * h->lane_stride);
+            std::copy_n(il.data() + (size_t)(1 + h->Nc + q) * h->lane_stride, h->lane_stride, cl.data() + cslot(q, true) * h->lane_stride);
+        }
+        HIPCHK(h, hipMemcpy(h->d_cimg_l, cl.data(), cl.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     if (h->rl_npj > 0) {
         std::vector<double> ir((size_t)(1 + 2 * h->Nc) * h->rl_stride, 0.0);
@@ -409,6 +440,12 @@ static int upload_operators(jq_handle* h)
             rowlane_image(h->Hanti.data() + q * nn, h->Ntot, h->rl_npj, ir.data() + (size_t)(1 + h->Nc + q) * h->rl_stride);
         }
         HIPCHK(h, hipMemcpy(h->d_himg_r, ir.data(), ir.size() * sizeof(double), hipMemcpyHostToDevice));
+        std::vector<double> cr((size_t)2 * h->Nc * h->rl_stride);
+        for (int q = 0; q < h->Nc; ++q) {
+            std::copy_n(ir.data() + (size_t)(1 + q) * h->rl_stride, h->rl_stride, cr.data() + cslot(q, false) * h->rl_stride);
+            std::copy_n(ir.data() + (size_t)(1 + h->Nc + q) * h->rl_stride, h->rl_stride, cr.data() + cslot(q, true) * h->rl_stride);
+        }
+        HIPCHK(h, hipMemcpy(h->d_cimg_r, cr.data(), cr.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     return JQ_OK;
 }
@@ -465,7 +502,7 @@ extern "C" void jq_destroy(jq_handle* h)
     }
     (void)hipSetDevice(h->device);
     if (h->emb) jq_destroy(h->emb);
-    double** bufs[] = {&h->d_rfreq, &h->d_wq, &h->d_pk2, &h->d_pack, &h->d_himg_r, &h->d_uinit_r, &h->d_vtr_r, &h->d_vti_r, &h->d_himg_l, &h->d_uinit_l, &h->d_vtr_l, &h->d_vti_l, &h->d_himg_c, &h->d_cimg_c, &h->d_park, &h->d_cimg, &h->d_himg,  &h->d_uimg,       &h->d_vtr,     &h->d_vti,    &h->d_tabs, &h->d_tf,   &h->d_tb,
+    double** bufs[] = {&h->d_cimg_l, &h->d_cimg_r, &h->d_rfreq, &h->d_wq, &h->d_pk2, &h->d_pack, &h->d_himg_r, &h->d_uinit_r, &h->d_vtr_r, &h->d_vti_r, &h->d_himg_l, &h->d_uinit_l, &h->d_vtr_l, &h->d_vti_l, &h->d_himg_c, &h->d_cimg_c, &h->d_park, &h->d_cimg, &h->d_himg,  &h->d_uimg,       &h->d_vtr,     &h->d_vti,    &h->d_tabs, &h->d_tf,   &h->d_tb,
                        &h->d_cfreq, &h->d_pcof,       &h->d_stream,  &h->d_pq,     &h->d_state, &h->d_state_save,
                        &h->d_colinfo, &h->d_traces,   &h->d_R,       &h->d_grad,   &h->d_res};
     for (auto b : bufs)
@@ -498,7 +535,7 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         return fail(h, JQ_EINVAL, "jq_create: NULL array in problem description");
     const int nctrl = p->Nunc > 0 ? p->Nunc : p->Ncoupled;     // control pairs the kernels see
     if (nctrl < 1) return fail(h, JQ_EUNSUPPORTED, "jq_create: at least one control Hamiltonian is required");
-    if (nctrl > JQ_MAXNC) return fail(h, JQ_EUNSUPPORTED, "jq_create: more than 4 control Hamiltonians are not supported");
+    if (nctrl > JQ_MAX_CONTROLS) return fail(h, JQ_EUNSUPPORTED, "jq_create: more than 16 control Hamiltonians are not supported");
     if (p->Ntot > 256)
         return fail(h, JQ_EUNSUPPORTED, "jq_create: Ntot > 256 (more than 16 tile rows = waves per 16-column slab)");
     if (p->objFuncType < 1 || p->objFuncType > 3) return fail(h, JQ_EINVAL, "jq_create: objFuncType must be 1, 2 or 3");
@@ -513,7 +550,7 @@ static int create_impl(const jq_problem* p, jq_handle* h)
     }
     HIPCHK(h, hipStreamCreate(&h->stream));
 
-    h->Ntot = p->Ntot; h->N = p->N; h->Nc = nctrl; h->Nfreq = p->Nfreq; h->nsteps = p->nsteps;
+    h->Ntot = p->Ntot; h->N = p->N; h->Nc = nctrl; h->NcK = std::min(nctrl, JQ_MAXNC); h->Nfreq = p->Nfreq; h->nsteps = p->nsteps;
     h->m = p->neumann_terms; h->objFuncType = p->objFuncType; h->T = p->T;
     h->NT = (p->Ntot + 15) / 16;
     h->big = h->NT > 6;
@@ -621,7 +658,7 @@ static int create_impl(const jq_problem* p, jq_handle* h)
                                              : 64LL * band_tiles(h->NT, h->BW) + (h->BW == JQ_BW_OD ? JQ_OD_COEFS(h->NT) : 0)) + 127) / 128) * 128;
         const long long slot = h->mat_elems * 8;
         const long long lds_fwd_fixed = (long long)32 * h->NT * 8;
-        const long long lds_bwd_fixed = bwd_lds_tail(h->NT, h->Nc, JQ_WAVES, 0);
+        const long long lds_bwd_fixed = bwd_lds_tail(h->NT, h->NcK, JQ_WAVES, 0);
         const long long park_bytes = (long long)JQ_WAVES * h->KT * 64 * 8;
         if (h->big) {
             h->mat_elems = 128;       // (no slab-kernel images: placeholders)
@@ -650,7 +687,7 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         // resident in LDS, one workgroup barrier per time step.  Used whenever it fits next to the backward kernel's carry
         // and parking images (kernels compiled for two workgroups per CU: in half of the LDS); JQ_WINDOW=0 disables it.
         {
-            const long long win = (2LL * JQ_WIN_TPS + 2LL * h->Nc) * slot;
+            const long long win = (2LL * JQ_WIN_TPS + 2LL * h->NcK) * slot;
             const long long budget = (h->NT <= JQ_MINW_MAXNT) ? 81920 : 163840;
             bool w = !h->big && win + lds_bwd_fixed + park_bytes <= budget;
             if (const char* e = getenv("JQ_WINDOW"))
@@ -667,8 +704,8 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         // (they always use the window staging and need less LDS next to it than the slab kernels -- a register per 16-row block
         // to park -- so they are also available when the slab kernels have to fall back to the per-operator ring: Ntot > 80, Nc = 4)
         {
-            const long long win = (2LL * JQ_WIN_TPS + 2LL * h->Nc) * slot;
-            const long long quad_fixed = bwd_lds_tail(h->NT, h->Nc, JQ_WAVES, (long long)h->NT * 64);
+            const long long win = (2LL * JQ_WIN_TPS + 2LL * h->NcK) * slot;
+            const long long quad_fixed = bwd_lds_tail(h->NT, h->NcK, JQ_WAVES, (long long)h->NT * 64);
             bool w = h->BW == JQ_BW_T4 && win + quad_fixed <= 163840;
             if (const char* e = getenv("JQ_WINDOW"))
                 if (atoi(e) == 0) w = false;
@@ -681,8 +718,8 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         // quad still gets a CU of its own (LDS: the window staging, one workgroup per CU).  NT >= 2 (a single block has no
         // neighbour to split the work with).  JQ_CQ=0 disables them, JQ_CQ=<n> bounds the number of quads.
         {
-            const long long win = (2LL * JQ_WIN_TPS + 2LL * h->Nc) * slot;
-            const long long tail = 32LL * h->NT * 8 + 6LL * (h->NT + 2) * 64 * 8 + (long long)std::max(2, h->Nc + (h->Nc + 1) / 2) * h->NT * 64 * 8;      // (run_eval: lds_cq)
+            const long long win = (2LL * JQ_WIN_TPS + 2LL * h->NcK) * slot;
+            const long long tail = 32LL * h->NT * 8 + 6LL * (h->NT + 2) * 64 * 8 + (long long)std::max(2, h->NcK + (h->NcK + 1) / 2) * h->NT * 64 * 8;      // (run_eval: lds_cq)
             h->cq_max_quads = (h->BW == JQ_BW_T4 && h->NT >= 2 && h->NT <= 7 && h->quad_max_slabs > 0 && win + tail <= 163840) ? 2 * prop.multiProcessorCount : 0;      // (two rounds of them, 2 x 0.20 s at cnot3, still beat one round of the quad-layout kernels, 0.55 s)
             if (const char* e = getenv("JQ_CQ"))
                 if (h->cq_max_quads > 0) h->cq_max_quads = atoi(e);
@@ -690,7 +727,7 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         if (const char* e = getenv("JQ_BATCH")) {
             const int v = atoi(e);
             if (v >= 2 && slot <= 8192) {
-                const long long fixed = lds_bwd_fixed + park_bytes + 2LL * h->Nc * slot;
+                const long long fixed = lds_bwd_fixed + park_bytes + 2LL * h->NcK * slot;
                 const long long per_buf = (163840 - fixed) / 2;
                 long long B = (per_buf / (2 * slot) - 1) / 2;
                 if (B > v) B = v;
@@ -759,6 +796,7 @@ static int create_impl(const jq_problem* p, jq_handle* h)
     }
     if (h->lane_np > 0) {
         if ((rc = dev_alloc(h, &h->d_himg_l, (size_t)(1 + 2 * h->Nc) * h->lane_stride))) return rc;
+        if ((rc = dev_alloc(h, &h->d_cimg_l, (size_t)(2 * h->Nc) * h->lane_stride))) return rc;
         if ((rc = dev_alloc(h, &h->d_uinit_l, (size_t)h->N * h->lane_np))) return rc;
         if ((rc = dev_alloc(h, &h->d_vtr_l, (size_t)h->N * h->lane_np))) return rc;
         if ((rc = dev_alloc(h, &h->d_vti_l, (size_t)h->N * h->lane_np))) return rc;
@@ -768,6 +806,7 @@ static int create_impl(const jq_problem* p, jq_handle* h)
     }
     if (h->rl_npj > 0) {
         if ((rc = dev_alloc(h, &h->d_himg_r, (size_t)(1 + 2 * h->Nc) * h->rl_stride))) return rc;
+        if ((rc = dev_alloc(h, &h->d_cimg_r, (size_t)(2 * h->Nc) * h->rl_stride))) return rc;
         if ((rc = dev_alloc(h, &h->d_uinit_r, (size_t)h->N * 16))) return rc;
         if ((rc = dev_alloc(h, &h->d_vtr_r, (size_t)h->N * 16))) return rc;
         if ((rc = dev_alloc(h, &h->d_vti_r, (size_t)h->N * 16))) return rc;
@@ -1033,16 +1072,58 @@ extern "C" int jq_update_target(jq_handle* h, const double* Utr, const double* U
     return upload_targets(h);
 }
 
+// Re-plan a single-device handle for a new drift Hamiltonian: a fresh plan (create_impl + try_embed) from the handle's own copy
+// of the problem, the settings applied since jq_create carried over, then swapped into the caller's handle.
+static int replan(jq_handle* h, const double* Hconst)
+{
+    jq_problem q;
+    memset(&q, 0, sizeof q);
+    q.Ntot = h->Ntot; q.N = h->N; q.Ncoupled = h->Nc; q.Nfreq = h->Nfreq; q.nsteps = h->nsteps; q.neumann_terms = std::max(h->m, 0);
+    q.objFuncType = h->objFuncType; q.Nunc = 0; q.T = h->T;      // (uncoupled controls were turned into pairs by create_impl)
+    q.Hconst = Hconst; q.Hsym_ops = h->Hsym.data(); q.Hanti_ops = h->Hanti.data(); q.Uinit = h->Uinit.data();
+    q.Utarget_r = h->Utr.data(); q.Utarget_i = h->Uti.data(); q.wmat_real_diag = h->wd.data(); q.Cfreq = h->cfreq.data();
+    jq_handle* n = new (std::nothrow) jq_handle();
+    if (!n) return fail(h, JQ_ENOMEM, "jq_update_hconst: out of host memory");
+    int rc = create_impl(&q, n);
+    if (rc == JQ_OK) rc = try_embed(n, &q);
+    auto settings = [&](jq_handle* t) {
+        t->solver_id = h->solver_id; t->m = h->m; t->solver_tol = h->solver_tol;
+    };
+    if (rc == JQ_OK) {
+        settings(n);
+        if (n->emb) settings(n->emb);
+        for (jq_handle* t : {n, n->emb}) {
+            if (!t || h->rfreq.empty() || rc != JQ_OK) continue;
+            t->rfreq = h->rfreq;
+            if ((rc = dev_alloc(t, &t->d_rfreq, t->rfreq.size())) == JQ_OK &&
+                hipMemcpy(t->d_rfreq, t->rfreq.data(), t->rfreq.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+                rc = fail(n, JQ_EHIP, "jq_update_hconst: upload of the rotation frequencies failed");
+        }
+    }
+    if (rc == JQ_OK && h->integrator == 2) rc = jq_set_integrator(n, 2, h->imr_max_iter, h->imr_tol);
+    if (rc != JQ_OK) {
+        h->err = "jq_update_hconst: re-planning for the new Hconst failed: " + n->err;
+        jq_destroy(n);
+        return rc;
+    }
+    n->replanned = true;
+    std::swap(*h, *n);
+    jq_destroy(n);      // (the old plan and its device memory)
+    return JQ_OK;
+}
+
 extern "C" int jq_update_hconst(jq_handle* h, const double* Hconst)
 {
     if (!h) return JQ_EINVAL;
     if (!Hconst) return fail(h, JQ_EINVAL, "jq_update_hconst: NULL pointer");
     if (!h->subs.empty()) return multi_forall(h, [&](jq_handle* sub) { return jq_update_hconst(sub, Hconst); });
     HIPCHK(h, hipSetDevice(h->device));
-    if ((h->BW == JQ_BW_T4) ? !t4_structure(Hconst, h->Ntot)
-        : (h->BW == JQ_BW_OD) ? !offdiag_blocks_diagonal(Hconst, h->Ntot) : block_band(Hconst, h->Ntot) > h->BW)
-        return fail(h, JQ_EUNSUPPORTED, "jq_update_hconst: new Hconst has entries outside the block band the kernels were "
-                                        "selected for; create a new handle");
+    // The kernels, operator images and LDS plan were chosen from the nonzero structure of H0, Hsym_q, Hanti_q at jq_create.  The
+    // reference lets scripts mutate params.Hconst arbitrarily: a drift with entries outside that structure (or any new drift
+    // after such a re-plan, which may have the structure back) re-plans the handle in place -- same pointer, same settings.
+    if (h->replanned || ((h->BW == JQ_BW_T4) ? !t4_structure(Hconst, h->Ntot)
+        : (h->BW == JQ_BW_OD) ? !offdiag_blocks_diagonal(Hconst, h->Ntot) : block_band(Hconst, h->Ntot) > h->BW))
+        return replan(h, Hconst);
     h->Hconst.assign(Hconst, Hconst + (size_t)h->Ntot * h->Ntot);
     if (h->emb) {
         jq_handle* e = h->emb;
@@ -1123,7 +1204,7 @@ static int select_cq_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bw
     const bool modd = (h->m > 0 ? h->m : 0) & 1;
     // control q acts on subsystem q only (the usual Juqbox set-up: Hsym_ops = [a + a', b + b', c + c']): its trace products need
     // one part of the product each
-    bool ord = h->Nc <= 3 && !getenv("JQ_CQ_GENERIC_TRACES");
+    bool ord = h->Nc <= 3 && !getenv("JQ_CQ_GENERIC_TRACES");      // (more than JQ_MAXNC controls: generic traces per control group)
     for (int q = 0; q < h->Nc && ord; ++q) ord = (h->bw_trace[q] == (1 << q));
 #define JQ_PICKCQ(nt)                                                              \
     if (h->NT == nt) {                                                             \
@@ -1323,7 +1404,7 @@ static double t4_plan_cost(const jq_handle* h, long long nsamples)
     double best = rel[0] * (double)((nslabs + 4 * h->num_cu - 1) / (4 * h->num_cu));
     if (nslabs <= h->quad_max_slabs)
         for (int k = 1; k <= 3; ++k) {
-            if ((size_t)(2 * JQ_WIN_TPS + 2 * h->Nc) * h->mat_elems * 8 + (size_t)bwd_lds_tail(h->NT, h->Nc, 4 * k, (long long)h->NT * 64) > 163840) continue;
+            if ((size_t)(2 * JQ_WIN_TPS + 2 * h->NcK) * h->mat_elems * 8 + (size_t)bwd_lds_tail(h->NT, h->NcK, 4 * k, (long long)h->NT * 64) > 163840) continue;
             if (h->NT <= 2 && nslabs > h->num_cu) continue;
             best = std::min(best, rel[k] * (double)((nslabs + k * h->num_cu - 1) / (k * h->num_cu)));
         }
@@ -1455,7 +1536,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     if (!imr && !lane && !rl && h->solver_id == 1 && nslabs <= h->quad_max_slabs) {
         const double rel[4] = {1.0, 0.29, 0.47, 0.615};      // (round 2: 0.553 / 0.90 / 1.177 s against 1.917 s)
         auto quad_lds = [&](int k) {    // backward kernel, k slabs per workgroup
-            return (size_t)(2 * JQ_WIN_TPS + 2 * h->Nc) * h->mat_elems * 8 + (size_t)bwd_lds_tail(h->NT, h->Nc, 4 * k, (long long)h->NT * 64);
+            return (size_t)(2 * JQ_WIN_TPS + 2 * h->NcK) * h->mat_elems * 8 + (size_t)bwd_lds_tail(h->NT, h->NcK, 4 * k, (long long)h->NT * 64);
         };
         double best = rel[0] * ((nslabs + 4 * h->num_cu - 1) / (4 * h->num_cu));
         for (int k = 1; k <= 3; ++k) {
@@ -1511,7 +1592,8 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     const size_t state_doubles = rl ? (size_t)JQ_ROWLANE_ROWS * nwaves_rl * 64
                                     : lane ? (size_t)JQ_LANE_ROWS(h->lane_np) * ncols : (size_t)nslabs * h->state_stride;
     const size_t colinfo_doubles = (lane || rl) ? (size_t)2 * ncols : (size_t)nslabs * 32;
-    const int ntr = h->Nc * JQ_NTR;
+    const int ntr = h->NcK * JQ_NTR;      // (trace scalars per step of the LARGEST control group)
+    const int ngroups = ctrl_ngroups(h->Nc);
     const bool two_pass = adjoint && h->objFuncType != 1;
     // chunk length: the tile stream of h->chunk_steps steps fits its buffer; the per-step trace records of a backward chunk
     // ([trace_rows][cs][ntr] doubles) are bounded by JQ_TRACE_BYTES (default 4 GiB) so that large ensembles take more,
@@ -1588,31 +1670,32 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     const double dt = h->T / h->nsteps;
     PropArgs a;
     memset(&a, 0, sizeof a);
-    a.stream = h->d_stream; a.cimg = rl ? h->d_himg_r + h->rl_stride : lane ? h->d_himg_l + h->lane_stride : coop ? h->d_cimg_c : h->d_cimg; a.state = h->d_state; a.colinfo = h->d_colinfo;
+    const double* cimg_base = rl ? h->d_cimg_r : lane ? h->d_cimg_l : coop ? h->d_cimg_c : h->d_cimg;      // (control-group order)
+    a.stream = h->d_stream; a.cimg = cimg_base; a.state = h->d_state; a.colinfo = h->d_colinfo;
     a.traces = h->d_traces;
     a.tabs = h->d_tabs; a.stride = stride; a.pieces = (int)(stride * 8 / 1024); a.nslots = h->nslots; a.m = h->m;
-    a.nslabs = rl ? (int)nwaves_rl : lane ? (int)ncols : nslabs; a.Ncoupled = h->Nc; a.Ntot = h->Ntot; a.N = h->N; a.use_shift = use_shift ? 1 : 0;
+    a.nslabs = rl ? (int)nwaves_rl : lane ? (int)ncols : nslabs; a.Ncoupled = ctrl_gstart(h->Nc, 1) /* first control group */; a.Ntot = h->Ntot; a.N = h->N; a.use_shift = use_shift ? 1 : 0;
     a.tinv = 1.0 / h->T; a.state_stride = h->state_stride; a.parts = h->parts; a.nsamples = nsamples; a.sps = h->sps; a.qps = qps;
     a.jacobi_tol2 = (h->solver_id == 2) ? h->solver_tol * h->solver_tol : 0.0;
     if (imr) {   // fixed-point solver of the implicit-midpoint step: iteration cap and per-lane threshold (jq_rowlane_imr_kernels.h)
         a.m = h->imr_max_iter;
         a.jacobi_tol2 = h->imr_tol * h->imr_tol;
     }
-    for (int q = 0; q < JQ_MAXNC; ++q) a.bw_trace[q] = h->bw_trace[q];
+    for (int q = 0; q < JQ_MAXNC; ++q) a.bw_trace[q] = h->bw_trace[q];      // (first control group; the backward sweeps set their own)
     // dynamic LDS layout: [operator staging | tables wd, ws | (backward: carry, parking images)]
     // cooperative kernels: [two operator slots | tables wd, ws | two x exchange buffers]
     const int batch = coop ? 0 : (quad || cq) ? -1 : h->batch;
     const size_t lds_stage = (coop && h->big) ? 0      // operators are read from HBM, no LDS staging
-                             : batch > 0   ? (size_t)2 * (2 * batch + 1) * 2 * stride * 8 + (size_t)2 * h->Nc * stride * 8
-                             : batch < 0 ? (size_t)(2 * JQ_WIN_TPS + 2 * h->Nc) * stride * 8
+                             : batch > 0   ? (size_t)2 * (2 * batch + 1) * 2 * stride * 8 + (size_t)2 * h->NcK * stride * 8
+                             : batch < 0 ? (size_t)(2 * JQ_WIN_TPS + 2 * h->NcK) * stride * 8
                                          : (size_t)2 * stride * 8;
-    const size_t lds_cq = lds_stage + (size_t)32 * h->NT * 8 + (size_t)6 * (h->NT + 2) * 64 * 8 + (size_t)std::max(2, h->Nc + (h->Nc + 1) / 2) * h->NT * 64 * 8;      // tables, x exchange, trace hand-off / wg-sum scratch (one region)
+    const size_t lds_cq = lds_stage + (size_t)32 * h->NT * 8 + (size_t)6 * (h->NT + 2) * 64 * 8 + (size_t)std::max(2, h->NcK + (h->NcK + 1) / 2) * h->NT * 64 * 8;      // tables, x exchange, trace hand-off / wg-sum scratch (one region)
     const size_t lds_fwd = (lane || rl) ? 0 : (cq || imr_cq) ? lds_cq : imr_coop ? coop_imr_lds_bytes(h->NT, stride)
                                            : lds_stage + (size_t)32 * h->NT * 8 + (coop ? (size_t)2 * h->KT * 64 * 8 + 128 : 0);      // (+ the Jacobi solver's partial norms)
-    const size_t lds_bwd = rl ? (h->rl_npj > 8 ? (size_t)2 * h->Nc * h->rl_stride * 8 : 0) : lane ? 0 : (coop || cq || imr_cq) ? lds_fwd
+    const size_t lds_bwd = rl ? (h->rl_npj > 8 ? (size_t)2 * h->NcK * h->rl_stride * 8 : 0) : lane ? 0 : (coop || cq || imr_cq) ? lds_fwd
                                 : imr_quad ? lds_fwd + (size_t)JQ_MAXNC * nthreads * 8 + (size_t)(nthreads / 64) * h->NT * 64 * 8
-                                : quad ? lds_stage + (size_t)bwd_lds_tail(h->NT, h->Nc, nthreads / 64, (long long)h->NT * 64)   // (a 16-row block per register)
-                                : lds_stage + (size_t)bwd_lds_tail(h->NT, h->Nc, JQ_WAVES, h->park_lds ? (long long)h->KT * 64 : 0);
+                                : quad ? lds_stage + (size_t)bwd_lds_tail(h->NT, h->NcK, nthreads / 64, (long long)h->NT * 64)   // (a 16-row block per register)
+                                : lds_stage + (size_t)bwd_lds_tail(h->NT, h->NcK, JQ_WAVES, h->park_lds ? (long long)h->KT * 64 : 0);
     a.batch = batch; a.lds_tab_off = (int)lds_stage;
     a.park = h->d_park; a.park_lds = quad ? 1 : h->park_lds;
     if (cq) a.nslots = 0;
@@ -1624,7 +1707,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
 
     // events: [0]=start [1]=end, then pairs around every propagator launch
     const int nchunks = (h->nsteps + cs - 1) / cs;
-    const size_t nev = 2 + 2 * (size_t)nchunks * (1 + (adjoint ? (two_pass ? 2 : 1) : 0));
+    const size_t nev = 2 + 2 * (size_t)nchunks * (1 + (adjoint ? (two_pass ? 2 : 1) * ngroups : 0));
     while (h->ev.size() < nev) {
         hipEvent_t e;
         HIPCHK(h, hipEventCreate(&e));
@@ -1643,9 +1726,9 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
 
     long long mfma = 0, mfma_fwd = 0;
     const long long tiles = (lane || rl) ? 0 : coop ? coop_tiles(h->NT, h->BWc) : band_tiles(h->NT, h->BW);
-    long long trace_tiles = 0;
+    std::vector<long long> ttiles(h->Nc, 0);
     for (int q = 0; q < h->Nc && !lane && !rl; ++q)
-        trace_tiles += coop ? coop_tiles(h->NT, h->BWc)
+        ttiles[q] = coop ? coop_tiles(h->NT, h->BWc)
                             : (h->BW == JQ_BW_T4) ? ((h->bw_trace[q] & JQ_T4_DIAG) ? 4 * h->NT : 0)
                                                   : band_tiles(h->NT, h->bw_trace[q] == 0 ? 0 : h->BW, h->bw_trace[q] == 2);
     // ---- forward sweep -------------------------------------------------------------------------
@@ -1695,14 +1778,27 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
                            h->N, h->sps, nsamples, leak_scale, h->d_res);
 
     // ---- backward sweep(s) ---------------------------------------------------------------------
+    // one sweep per (control group, forcing): the forced adjoint gives the total gradient, the unforced one (objFuncType != 1)
+    // the infidelity gradient; every sweep restarts from the state the forward sweep and the terminal kernel left behind
     if (adjoint) {
-        if (two_pass)
+        const int nsweeps = (two_pass ? 2 : 1) * ngroups;
+        if (nsweeps > 1)
             HIPCHK(h, hipMemcpyAsync(h->d_state_save, h->d_state, state_doubles * sizeof(double),
                                      hipMemcpyDeviceToDevice, s));
-        for (int pass = 0; pass < (two_pass ? 2 : 1); ++pass) {
-            if (pass == 1)
+        for (int sweep = 0; sweep < nsweeps; ++sweep) {
+            const int pass = sweep / ngroups, grp = sweep % ngroups;
+            const int q0 = ctrl_gstart(h->Nc, grp), ng = ctrl_gstart(h->Nc, grp + 1) - q0;
+            const int ntr_g = ng * JQ_NTR;
+            if (sweep > 0)
                 HIPCHK(h, hipMemcpyAsync(h->d_state, h->d_state_save, state_doubles * sizeof(double),
                                          hipMemcpyDeviceToDevice, s));
+            a.Ncoupled = ng;
+            a.cimg = cimg_base + (size_t)2 * q0 * stride;
+            long long trace_tiles = 0;
+            for (int q = 0; q < JQ_MAXNC; ++q) {
+                a.bw_trace[q] = q < ng ? h->bw_trace[q0 + q] : 0;
+                if (q < ng) trace_tiles += ttiles[q0 + q];
+            }
             for (int n0 = 0; n0 < h->nsteps; n0 += cs) {
                 const int nc = std::min(cs, h->nsteps - n0);
                 const int ntp = 2 * nc + 1;
@@ -1711,7 +1807,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
                                    h->d_pq, h->Nc, stride, -0.5 * dt, h->d_stream);
                 a.nsteps_chunk = nc; a.step0 = n0; a.first_chunk = (n0 == 0); a.h = -dt; a.forced = (pass == 0);
                 a.hist_r = nullptr; a.hist_i = nullptr;
-                a.period = 13 + 3 * h->Nc; a.npro = (n0 == 0) ? h->Nc : 0; a.nslots = h->nslots_bwd;
+                a.period = 13 + 3 * ng; a.npro = (n0 == 0) ? ng : 0; a.nslots = h->nslots_bwd;
                 {   // Kp05 S05 Kn0 S0 Kn1 S1 Kp05 | S0 | Hanti_q.. | Kn0 Kn1 S05 Kp05 S1 | (Hanti_q Hsym_q)..
                     const int kinds_s[8] = {0, 1, 0, 1, 0, 1, 0, 1}, tps_s[8] = {1, 1, 0, 0, 2, 2, 1, 0};
                     const int kinds_c[8] = {0, 1, 0, 0, 1, 1, 0, 1}, tps_c[8] = {1, 1, 0, 2, 0, 2, 1, 0};
@@ -1721,21 +1817,22 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
                     a.sched_bits[0] = a.sched_bits[1] = a.sched_bits[2] = a.pro_bits = 0;
                     int k = 0;
                     for (int i = 0; i < 8; ++i) sched_pack(a.sched_bits, k++, kinds[i], tps[i]);
-                    for (int q = 0; q < h->Nc; ++q) sched_pack(a.sched_bits, k++, 2, h->Nc + q);   // early traces: Hanti_q
+                    for (int q = 0; q < ng; ++q) sched_pack(a.sched_bits, k++, 2, ng + q);   // early traces: Hanti_q
                     for (int i = 0; i < 5; ++i) sched_pack(a.sched_bits, k++, kinds2[i], tps2[i]);
-                    for (int q = 0; q < h->Nc; ++q) {
-                        sched_pack(a.sched_bits, k++, 2, h->Nc + q);                               // late traces: Hanti_q
-                        sched_pack(a.sched_bits, k++, 2, q);                                       //              Hsym_q
+                    for (int q = 0; q < ng; ++q) {
+                        sched_pack(a.sched_bits, k++, 2, ng + q);                               // late traces: Hanti_q
+                        sched_pack(a.sched_bits, k++, 2, q);                                    //              Hsym_q
                         sched_pack(&a.pro_bits, q, 2, q);          // first chunk: carry products with Hsym_q
                     }
                 }
                 HIPCHK(h, hipEventRecord(h->ev[evi++], s));
                 hipLaunchKernelGGL(kbwd, dim3(nblocks), dim3(cq ? 2 * nthreads : imr_cq ? nthreads + 128 : nthreads), lds_bwd, s, a);      // (cooperative quad: state and adjoint chain on separate waves)
                 HIPCHK(h, hipEventRecord(h->ev[evi++], s));
-                hipLaunchKernelGGL(k_trace_reduce, dim3((unsigned)(((long long)nc * ntr + 255) / 256)), dim3(256), 0, s,
-                                   h->d_traces, trace_rows, nc, ntr, h->d_R);
-                hipLaunchKernelGGL(k_gradacc, dim3(ncoeff), dim3(JQ_GRADACC_THREADS), 0, s, sp, h->d_R, h->d_tb, n0, nc, -dt,
-                                   h->d_grad + (size_t)pass * ncoeff);
+                hipLaunchKernelGGL(k_trace_reduce, dim3((unsigned)(((long long)nc * ntr_g + 255) / 256)), dim3(256), 0, s,
+                                   h->d_traces, trace_rows, nc, ntr_g, h->d_R);
+                // gradbcarrier2! as a scatter: one workgroup per coefficient of the group's controls
+                hipLaunchKernelGGL(k_gradacc, dim3(ng * 2 * h->Nfreq * D1), dim3(JQ_GRADACC_THREADS), 0, s, sp, h->d_R, h->d_tb, n0, nc, -dt,
+                                   h->d_grad + (size_t)pass * ncoeff, q0, ng);
                 mfma += (long long)nslabs * nc * (2 * (8 + 2 * h->m) * tiles + 4 * trace_tiles);
                 if (n0 == 0) mfma += (long long)nslabs * trace_tiles;
             }

@@ -317,3 +317,121 @@ def test_bench_under_torch_distributed_run_one_rank(hip):
     assert j["per_rank_ms"]["min"] <= j["per_rank_ms"]["max"] and j["allreduce_ms"] >= 0.0
     assert j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["cores"] == 1
     assert j["strong_scaling"]["total_samples"] == 512 and "strong_scaling_small" in j
+
+
+# ---- (5) more than four control Hamiltonians, drift updates outside the planned structure -------------------------------------
+_MANY_CONTROLS = [
+    # id, (Ntot, N, Nc, Nfreq, nsteps, m, objFuncType, structure), environment, implicit midpoint
+    ("rowlane-5", (12, 4, 5, 1, 25, 3, 1, False), {}, False),
+    ("lane-7", (8, 3, 7, 1, 20, 2, 3, False), {"JQ_ROWLANE_MAX": "0"}, False),
+    ("slab-dense-6", (40, 3, 6, 1, 12, 2, 2, False), {"JQ_COOP_MAX": "0", "JQ_LANE": "0", "JQ_QUAD": "0"}, False),
+    ("coop-8", (64, 4, 8, 1, 10, 3, 1, False), {}, False),
+    ("coop-big-5", (130, 2, 5, 1, 8, 2, 3, True), {}, False),
+    ("cq-6", (96, 4, 6, 1, 12, 6, 3, "t4"), {}, False),
+    ("quad12-5", (96, 4, 5, 2, 10, 5, 1, "t4"), {"JQ_QUAD8": "2"}, False),
+    ("slab-t4-7", (48, 4, 7, 1, 10, 3, 2, "t4"), {"JQ_COOP_MAX": "0", "JQ_LANE": "0", "JQ_QUAD": "0"}, False),
+    ("slab-od-5", (80, 5, 5, 1, 8, 4, 1, "od"), {"JQ_COOP_MAX": "0", "JQ_LANE": "0", "JQ_QUAD": "0"}, False),
+    ("imr-rowlane-5", (12, 4, 5, 1, 15, 3, 3, False), {}, True),
+    ("imr-coop-6", (48, 4, 6, 1, 8, 2, 1, False), {}, True),
+    ("imr-cq-5", (96, 4, 5, 1, 8, 3, 2, "t4"), {}, True),
+    ("imr-quad-7", (64, 2, 7, 1, 8, 3, 1, "t4"), {"JQ_IMR_CQ": "0"}, True),
+]
+
+
+@pytest.mark.parametrize("name,cfg,env,imr", _MANY_CONTROLS, ids=[c[0] for c in _MANY_CONTROLS])
+def test_more_than_four_controls_match_the_oracle(hip, name, cfg, env, imr):
+    """objparams has no limit on the number of control Hamiltonians (src/evalobjgrad.jl:152-343); the kernels' trace / carry
+    bookkeeping holds four, so the backward sweep runs once per group of at most four controls (5 .. 8 controls: two sweeps,
+    each with its own trace images; K(t), S(t) always contain every control).  Objective, all three gradients and a weighted
+    ensemble against the oracle on every kernel family, both integrators."""
+    from oracle.oracle import Oracle
+    from test_gpu_random import random_problem
+    jq = hip
+    Ntot, N, Nc, Nfreq, nsteps, m, oft, banded = cfg
+    rng = np.random.default_rng(300 + Ntot + Nc)
+    p, pcof = random_problem(jq, rng, Ntot, N, Nc, Nfreq, nsteps, m, oft, banded)
+    if imr:
+        p.Integrator_id = jq.Implicit_Midpoint
+        p.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER_M, max_iter=80, tol=1e-12, nrhs=N)
+        p.wmat = p.wmat_real.copy()
+    os.environ.update(env)
+    try:
+        wa = (jq.Working_Arrays_M_HIP if imr else jq.Working_Arrays_HIP)(p, pcof.size)
+        orc = Oracle(p, use_sparse=False)
+        r = orc.traceobjgrad_imr(pcof, 80, 1e-12) if imr else orc.traceobjgrad(pcof)
+        objfv, tg, prim, sec, tinf, ig, lg = jq.traceobjgrad(pcof, p, wa, False, True)
+        gn = np.linalg.norm(r["totalgrad"])
+        assert abs(prim - r["primaryobjf"]) <= 1e-9 and abs(sec - r["secondaryobjf"]) <= 1e-9 * max(abs(r["secondaryobjf"]), 1e-3)
+        assert np.linalg.norm(tg - r["totalgrad"]) <= 1e-9 * gn
+        assert np.linalg.norm(ig - r["infidelgrad"]) <= 1e-9 * gn
+        if oft != 1:
+            assert np.linalg.norm(lg - r["leakgrad"]) <= 1e-9 * gn
+        # every control's block of the gradient is non-trivial and right (a group that was skipped would leave zeros)
+        per = pcof.size // Nc
+        for q in range(Nc):
+            blk = slice(q * per, (q + 1) * per)
+            assert np.linalg.norm(r["totalgrad"][blk]) > 0
+            assert np.linalg.norm(tg[blk] - r["totalgrad"][blk]) <= 1e-9 * gn
+        if not imr:
+            nq = 2 * max(1, 16 // N) + 1
+            nodes, weights = 0.1 * rng.standard_normal(nq), rng.random(nq)
+            shift = rng.standard_normal(Ntot) * 0.05
+            shift[0] = 0.0
+            ref = orc.eval_f_g_grad(pcof, nodes, weights, shift)
+            jq.eval_f_g_grad(pcof, p, wa, nodes, weights, True, shift=shift)
+            gref = ref["last_infidelity_grad"]
+            assert abs(p.last_infidelity - ref["last_infidelity"]) <= 1e-9 * abs(ref["last_infidelity"])
+            assert np.linalg.norm(p.last_infidelity_grad - gref) <= 1e-9 * np.linalg.norm(gref)
+            if oft != 1:
+                assert np.linalg.norm(p.last_leak_grad - ref["last_leak_grad"]) <= 1e-9 * np.linalg.norm(gref)
+        wa.close()
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
+
+
+def test_seventeen_controls_are_refused(hip):
+    from juqbox_jl_amd import _lib
+    from test_gpu_random import random_problem
+    p, pcof = random_problem(hip, np.random.default_rng(2), 8, 2, 17, 1, 5, 1, 1, False)
+    with pytest.raises(_lib.JuqboxHipError) as e:
+        hip.Working_Arrays_HIP(p, pcof.size)
+    assert e.value.code == _lib.JQ_EUNSUPPORTED
+
+
+@pytest.mark.parametrize("structure,Ntot,imr", [("t4", 96, False), ("od", 80, False), (True, 50, False), ("t4", 64, True)])
+def test_hconst_update_outside_the_planned_structure_replans(hip, structure, Ntot, imr):
+    """Scripts mutate params.Hconst arbitrarily (src/ipopt_interface.jl:41-44, run_all.jl:13-15).  A new drift with entries outside
+    the structure the kernels were chosen for (4 x 4 x n Kronecker structure, diagonal off-diagonal blocks, block band) re-plans
+    the handle in place (round 2: JQ_EUNSUPPORTED): results against the oracle with the dense drift, then back with the structured
+    one -- where the fast kernel family must be in use again."""
+    from oracle.oracle import Oracle
+    from test_gpu_random import random_problem
+    jq = hip
+    rng = np.random.default_rng(41 + Ntot)
+    p, pcof = random_problem(jq, rng, Ntot, 4, 3, 1, 10, 3, 3, structure)
+    if imr:
+        p.Integrator_id = jq.Implicit_Midpoint
+        p.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER_M, max_iter=80, tol=1e-12, nrhs=4)
+        p.wmat = p.wmat_real.copy()
+    wa = (jq.Working_Arrays_M_HIP if imr else jq.Working_Arrays_HIP)(p, pcof.size)
+    p.linear_solver.max_iter += 0
+    H0 = p.Hconst.copy()
+
+    def check():
+        orc = Oracle(p, use_sparse=False)
+        r = orc.traceobjgrad_imr(pcof, 80, 1e-12) if imr else orc.traceobjgrad(pcof)
+        objfv, tg, prim, sec, tinf, ig, lg = jq.traceobjgrad(pcof, p, wa, False, True)
+        gn = np.linalg.norm(r["totalgrad"])
+        assert abs(prim - r["primaryobjf"]) <= 1e-9 and np.linalg.norm(tg - r["totalgrad"]) <= 1e-9 * gn
+        assert np.linalg.norm(lg - r["leakgrad"]) <= 1e-9 * gn
+        return wa.last_timing()
+    t0 = check()
+    D = rng.standard_normal((Ntot, Ntot))
+    p.Hconst = H0 + 0.05 * (D + D.T)                    # dense: outside every structure
+    t1 = check()
+    assert (t1["kernel_family"], t1["kernel_band"]) != (t0["kernel_family"], t0["kernel_band"])
+    p.Hconst = H0 * 1.01                                # structured again: the plan comes back
+    t2 = check()
+    assert (t2["kernel_family"], t2["kernel_band"]) == (t0["kernel_family"], t0["kernel_band"])
+    wa.close()
