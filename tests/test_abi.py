@@ -43,7 +43,7 @@ def _problem(jq, params, **over):
 
 @pytest.mark.parametrize("over,code", [
     (dict(nsteps=0), -1), (dict(T=0.0), -1), (dict(N=0), -1), (dict(Nunc=-1), -1), (dict(Nunc=1), -1), (dict(objFuncType=9), -1),
-    (dict(neumann_terms=-1), -1), (dict(Ntot=257), -3), (dict(Ncoupled=0), -3), (dict(Ncoupled=5), -3),
+    (dict(neumann_terms=-1), -1), (dict(Ntot=257), -3), (dict(Ncoupled=0), -3), (dict(Ncoupled=17), -3),
 ])
 def test_create_validates_before_touching_the_device(jq, over, code):
     from juqbox_jl_amd import _lib
