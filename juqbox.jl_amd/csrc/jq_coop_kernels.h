@@ -143,7 +143,7 @@ struct Coop {
     int kb0;
     int row_off;        // doubles from the start of an operator image to my row's tiles
     d4 xown;            // my rows of the staged / published x (JQ_BW_OD: B operand of the diagonal block)
-    double* nrm;        // LDS [NT]: the waves' partial residual norms of the Jacobi solver
+    double* nrm;        // LDS [NT][16]: the waves' column totals of the Jacobi solver's residual norm
 
     // write my rows of Z into the other exchange buffer (visible after the next barrier)
     __device__ __forceinline__ void stage(const d4& Z)
@@ -217,28 +217,43 @@ __device__ __forceinline__ double dot4(const d4& a, const d4& b)
 // out = bpa + sum_{j=1..m} S^j A with the resident operator S (Horner form, see jq_kernels.h); on entry
 // NOTHING needs to be published; on exit the exchange buffer holds an intermediate iterate.
 // tol2 > 0: JACOBI_SOLVER instead (jacobi!, src/linear_solvers.jl:110-153; jq_kernels.h jacobi_add): X_j = A + S X_{j-1}, X_0 = A,
-// stop at the first j with ||X_j - X_{j-1}||_F^2 < tol2 (over the slab, like the slab kernels) or at j = m; the waves' partial
-// norms meet in LDS (one more barrier per iteration; the publication barrier of the next iteration protects their reuse).
+// stop at the first j with ||X_j - X_{j-1}||_F^2 < tol2 or at j = m -- PER SAMPLE like the reference (round 3): every wave
+// leaves the 16 column totals of its tile row in LDS [tile row][column] (one more barrier per iteration; the publication
+// barrier of the next iteration protects their reuse), every lane adds the waves' totals of its sample's columns in a fixed
+// order; a converged sample keeps its iterate while the workgroup iterates on for the others (the exit is workgroup-uniform:
+// all waves see the same totals).
 template <int NT, int BW>
-__device__ __forceinline__ d4 coop_horner(Coop<NT, BW>& c, const d4& bpa, const d4& A, int m, double tol2 = 0.0)
+__device__ __forceinline__ d4 coop_horner(Coop<NT, BW>& c, const d4& bpa, const d4& A, int m, double tol2 = 0.0, int ncol = 16)
 {
     if (m <= 0) return bpa;
     if (tol2 > 0.0) {
         d4 X = A;
+        const int lane = threadIdx.x & 63, col = lane & 15;
+        const int n = ncol < 16 ? ncol : 16, c0 = col - col % n;
+        bool done = false;
         for (int j = 1; j <= m; ++j) {
             c.stage(X);
             c.publish();
             const d4 Xn = c.mm_c(A);
             const d4 d = Xn - X;
-            const double e = wave_sum(dot4(d, d));
-            if ((threadIdx.x & 63) == 0) c.nrm[c.mt] = e;
+            double e = dot4(d, d);
+            e += __shfl_xor(e, 16);
+            e += __shfl_xor(e, 32);      // column totals of this tile row
+            if (lane < 16) c.nrm[16 * c.mt + lane] = e;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             double err2 = 0.0;
-            for (int w = 0; w < NT; ++w) err2 += c.nrm[w];
-            X = Xn;
-            if (err2 < tol2) break;
+            for (int k = 0; k < n; ++k) {      // my sample's columns, the waves' totals in wave order
+                double t = 0.0;
+                if (c0 + k < 16)               // (ragged tail of the slab: a short group of unused, zero columns)
+                    for (int w = 0; w < NT; ++w) t += c.nrm[16 * w + c0 + k];
+                err2 += t;
+            }
+            X = done ? X : Xn;                 // a converged sample keeps its iterate
+            done = done || err2 < tol2;
+            // every wave holds all 16 columns in its lanes and reads the same totals: the wave vote is the workgroup's verdict
+            if (__all(done)) break;
         }
         return (bpa - A) + X;
     }
@@ -268,7 +283,7 @@ __device__ __forceinline__ void coop_state(Coop<NT, BW>& c, const PropArgs& a, d
     c.stage(v);
     c.publish_next_op();
     A = c.mm_c(A);
-    v05 = coop_horner<NT, BW>(c, v + A, A, a.m, a.jacobi_tol2);
+    v05 = coop_horner<NT, BW>(c, v + A, A, a.m, a.jacobi_tol2, a.N);
     c.stage(v05);
     c.publish();
     vN = c.mm_c(v05);
@@ -288,7 +303,7 @@ __device__ __forceinline__ void coop_state(Coop<NT, BW>& c, const PropArgs& a, d
     c.stage(un);
     c.publish_next_op();
     A = c.mm_c(A);
-    un = coop_horner<NT, BW>(c, un + A, A, a.m, a.jacobi_tol2);
+    un = coop_horner<NT, BW>(c, un + A, A, a.m, a.jacobi_tol2, a.N);
 }
 
 template <int NT, int BW>
@@ -443,7 +458,7 @@ __global__ __launch_bounds__(64 * NT) void k_backward_coop(PropArgs a)
         c.publish_next_op();
         R = c.mm_c(R);
         R += (cfw * wdr) * u;
-        const d4 X = coop_horner<NT, BW>(c, mu + R, R, a.m, a.jacobi_tol2);
+        const d4 X = coop_horner<NT, BW>(c, mu + R, R, a.m, a.jacobi_tol2, a.N);
         // early traces with X: tr1 = tr(vr0' Hanti_q X), tr3 = tr(vr' Hanti_q X)
         c.stage(X);
         for (int q = 0; q < JQ_MAXNC; ++q) {
@@ -479,7 +494,7 @@ __global__ __launch_bounds__(64 * NT) void k_backward_coop(PropArgs a)
         c.stage(L);
         c.publish();
         Qv = c.mm_c(Qv);
-        const d4 nbn = coop_horner<NT, BW>(c, (nb + L) + Qv, Qv, a.m, a.jacobi_tol2);
+        const d4 nbn = coop_horner<NT, BW>(c, (nb + L) + Qv, Qv, a.m, a.jacobi_tol2, a.N);
         const d4 Bq = nb + nbn;   // -(li0 + li)
         // use 11: Kp05 -- G = X + c K05 nb_new
         c.stage(nbn);

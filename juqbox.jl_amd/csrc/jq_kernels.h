@@ -1163,14 +1163,32 @@ __device__ __forceinline__ double a_diff2(const Arr<NT>& x, const Arr<NT>& y)
     return s;
 }
 
+// Sum of a per-lane value over the lanes of ONE SAMPLE of a slab (slab layout: column = lane & 15, four lane rows per column;
+// a sample = N consecutive columns): the same value in every lane of the sample, columns added in a fixed order.  N >= 16 (a
+// sample wider than the slab): the slab's 16 columns.
+__device__ __forceinline__ double sample_sum(double x, int N)
+{
+    x += __shfl_xor(x, 16);
+    x += __shfl_xor(x, 32);      // column totals
+    const int lane = threadIdx.x & 63, col = lane & 15;
+    const int n = N < 16 ? N : 16, c0 = col - col % n;
+    double s = 0.0;
+    for (int k = 0; k < n; ++k) {
+        const double v = __shfl(x, (lane & 48) | ((c0 + k) & 15));
+        s += (c0 + k < 16) ? v : 0.0;      // (the unused tail columns of a ragged slab form a short group of their own)
+    }
+    return s;
+}
+
 // JACOBI_SOLVER (jacobi!, src/linear_solvers.jl:110-153): X_j = A + S X_{j-1}, X_0 = A, stop at the first
 // j with ||X_j - X_{j-1}||_F < tol or at j = max_iter.  It is the same fixed-point iteration as the Horner
-// form above, plus the convergence test.  The reference tests each sample's Ntot x N block on its own; here
-// the test is on the whole 16-column slab (a wave-uniform decision), i.e. never earlier than the
-// reference, so the two results differ by less than tol.
+// form above, plus the convergence test.  The reference solves each evaluation's Ntot x N block on its own, so the test is
+// PER SAMPLE here too (round 3; rounds 1-2 tested the whole 16-column slab and agreed with the reference only to O(tol)): the
+// residual norm is summed over the lanes of a sample (sample_sum), a sample that has converged keeps its iterate while the wave
+// iterates on for the others.  N > 16 (a sample spans several slabs = waves): per 16-column part.
 template <int NT, int BW>
 __device__ __forceinline__ void jacobi_add(Arr<NT>& out, const Arr<NT>& bpa, const Arr<NT>& A, const double* S, int max_iter,
-                                           double tol2, Arr<NT>& Ya, Arr<NT>& Yb)
+                                           double tol2, Arr<NT>& Ya, Arr<NT>& Yb, int ncol)
 {
     // out = bpa - A + X_j
     if (max_iter <= 0) {
@@ -1179,14 +1197,20 @@ __device__ __forceinline__ void jacobi_add(Arr<NT>& out, const Arr<NT>& bpa, con
     }
     mm_c<NT, BW>(Ya, A, S, A);  // X_1
     bool in_a = true;
-    double err2 = wave_sum(a_diff2(Ya, A));
-    for (int j = 2; j <= max_iter && !(err2 < tol2); ++j) {
+    bool done = sample_sum(a_diff2(Ya, A), ncol) < tol2;      // (per lane: the same for all lanes of a sample)
+    for (int j = 2; j <= max_iter && !__all(done); ++j) {
         if (in_a) {
             mm_c<NT, BW>(Yb, A, S, Ya);
-            err2 = wave_sum(a_diff2(Yb, Ya));
+            const bool conv = sample_sum(a_diff2(Yb, Ya), ncol) < tol2;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) Yb.t[i] = done ? Ya.t[i] : Yb.t[i];      // converged samples keep their iterate
+            done = done || conv;
         } else {
             mm_c<NT, BW>(Ya, A, S, Yb);
-            err2 = wave_sum(a_diff2(Ya, Yb));
+            const bool conv = sample_sum(a_diff2(Ya, Yb), ncol) < tol2;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) Ya.t[i] = done ? Yb.t[i] : Ya.t[i];
+            done = done || conv;
         }
         in_a = !in_a;
     }
@@ -1196,10 +1220,10 @@ __device__ __forceinline__ void jacobi_add(Arr<NT>& out, const Arr<NT>& bpa, con
 
 template <int NT, int BW, bool JAC>
 __device__ __forceinline__ void horner_add(Arr<NT>& out, const Arr<NT>& bpa, const Arr<NT>& A, const double* S, int m,
-                                           Arr<NT>& Ya, Arr<NT>& Yb, double jacobi_tol2)
+                                           Arr<NT>& Ya, Arr<NT>& Yb, double jacobi_tol2, int ncol)
 {
     if (JAC) {
-        jacobi_add<NT, BW>(out, bpa, A, S, m, jacobi_tol2, Ya, Yb);
+        jacobi_add<NT, BW>(out, bpa, A, S, m, jacobi_tol2, Ya, Yb, ncol);
         return;
     }
     if (m <= 0) {
@@ -1284,7 +1308,7 @@ __device__ __forceinline__ void sv_state(Ring& p, const PropArgs& a, bool active
     if (active) {
         mm_c<NT, BW>(A, A, M, v);
         a_add(v, A);
-        horner_add<NT, BW, JAC>(v, v, A, M, a.m, Ya, Yb, a.jacobi_tol2);
+        horner_add<NT, BW, JAC>(v, v, A, M, a.m, Ya, Yb, a.jacobi_tol2, a.N);
         mm_c<NT, BW>(vN, v, M, v);
     }
     // use 2: Kn0 -- unew = u - c K0 v05
@@ -1307,7 +1331,7 @@ __device__ __forceinline__ void sv_state(Ring& p, const PropArgs& a, bool active
     if (active) {
         mm_c<NT, BW>(A, A, M, unew);
         a_add(unew, A);
-        horner_add<NT, BW, JAC>(unew, unew, A, M, a.m, Ya, Yb, a.jacobi_tol2);
+        horner_add<NT, BW, JAC>(unew, unew, A, M, a.m, Ya, Yb, a.jacobi_tol2, a.N);
     }
 }
 
@@ -1533,7 +1557,7 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
             mm_c<NT, BW>(L, L, M, mu);
             a_axpy_rows(L, cfw, wd, g, u);  // u holds vr before the state step (:862)
             a_add(mu, L);
-            horner_add<NT, BW, JAC>(mu, mu, L, M, a.m, Ya, Yb, a.jacobi_tol2);
+            horner_add<NT, BW, JAC>(mu, mu, L, M, a.m, Ya, Yb, a.jacobi_tol2, a.N);
         }
         // early traces with X (lets vr0 = u die here): tr1 = tr(vr0' Hanti_q X), tr3 = tr(vr' Hanti_q X)
         for (int q = 0; q < Nc; ++q) {
@@ -1567,7 +1591,7 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
             mm_c<NT, BW>(vN, vN, M, L);       // vN = Q
             a_add(L, nb);
             a_add(L, vN);                     // L = nb + L + Q
-            horner_add<NT, BW, JAC>(L, L, vN, M, a.m, Ya, Yb, a.jacobi_tol2);  // L = nb_new
+            horner_add<NT, BW, JAC>(L, L, vN, M, a.m, Ya, Yb, a.jacobi_tol2, a.N);  // L = nb_new
             a_add(nb, L);                     // nb = nb_old + nb_new = -(li0 + li)
         }
         // use 11: Kp05 -- vN(scratch G) = X + c K05 nb_new (= lambda_r^{1/2} - c K05 li_new)

@@ -672,7 +672,7 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         h->mat_elems_c = 0;
         if ((h->NT >= 2 || h->N > 4) && (h->NT <= 6 || h->big)) {      // (NT = 7, 8 with the JQ_BW_T4 structure: no cooperative kernels)
             const long long ec = (((long long)h->NT * coop_row_elems(h->NT, h->BWc) + 127) / 128) * 128;
-            const long long lds_c = (h->big ? 0 : 2 * ec * 8) + lds_fwd_fixed + 2LL * h->KT * 64 * 8;
+            const long long lds_c = (h->big ? 0 : 2 * ec * 8) + lds_fwd_fixed + 2LL * h->KT * 64 * 8 + 16LL * h->NT * 8;      // (operator slots, tables, x exchange, Jacobi column norms)
             if (lds_c <= 163840) h->mat_elems_c = ec;
         }
         h->coop_max_slabs = prop.multiProcessorCount;   // one cooperative workgroup per CU = one round
@@ -1676,7 +1676,9 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     a.tabs = h->d_tabs; a.stride = stride; a.pieces = (int)(stride * 8 / 1024); a.nslots = h->nslots; a.m = h->m;
     a.nslabs = rl ? (int)nwaves_rl : lane ? (int)ncols : nslabs; a.Ncoupled = ctrl_gstart(h->Nc, 1) /* first control group */; a.Ntot = h->Ntot; a.N = h->N; a.use_shift = use_shift ? 1 : 0;
     a.tinv = 1.0 / h->T; a.state_stride = h->state_stride; a.parts = h->parts; a.nsamples = nsamples; a.sps = h->sps; a.qps = qps;
-    a.jacobi_tol2 = (h->solver_id == 2) ? h->solver_tol * h->solver_tol : 0.0;
+    // JACOBI_SOLVER: the kernels iterate on c-scaled right-hand sides (A = c rhs, c = h / 2: DESIGN.md section 3), so their
+    // residual norm is |c| times the reference's ||X_j - X_{j-1}|| (src/linear_solvers.jl:121): the threshold is scaled alike
+    a.jacobi_tol2 = (h->solver_id == 2) ? (h->solver_tol * 0.5 * dt) * (h->solver_tol * 0.5 * dt) : 0.0;
     if (imr) {   // fixed-point solver of the implicit-midpoint step: iteration cap and per-lane threshold (jq_rowlane_imr_kernels.h)
         a.m = h->imr_max_iter;
         a.jacobi_tol2 = h->imr_tol * h->imr_tol;
@@ -1691,7 +1693,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
                                          : (size_t)2 * stride * 8;
     const size_t lds_cq = lds_stage + (size_t)32 * h->NT * 8 + (size_t)6 * (h->NT + 2) * 64 * 8 + (size_t)std::max(2, h->NcK + (h->NcK + 1) / 2) * h->NT * 64 * 8;      // tables, x exchange, trace hand-off / wg-sum scratch (one region)
     const size_t lds_fwd = (lane || rl) ? 0 : (cq || imr_cq) ? lds_cq : imr_coop ? coop_imr_lds_bytes(h->NT, stride)
-                                           : lds_stage + (size_t)32 * h->NT * 8 + (coop ? (size_t)2 * h->KT * 64 * 8 + 128 : 0);      // (+ the Jacobi solver's partial norms)
+                                           : lds_stage + (size_t)32 * h->NT * 8 + (coop ? (size_t)2 * h->KT * 64 * 8 + (size_t)16 * h->NT * 8 : 0);      // (+ the Jacobi solver's column norms [NT][16])
     const size_t lds_bwd = rl ? (h->rl_npj > 8 ? (size_t)2 * h->NcK * h->rl_stride * 8 : 0) : lane ? 0 : (coop || cq || imr_cq) ? lds_fwd
                                 : imr_quad ? lds_fwd + (size_t)JQ_MAXNC * nthreads * 8 + (size_t)(nthreads / 64) * h->NT * 64 * 8
                                 : quad ? lds_stage + (size_t)bwd_lds_tail(h->NT, h->NcK, nthreads / 64, (long long)h->NT * 64)   // (a 16-row block per register)

@@ -463,7 +463,7 @@ def test_split_batches_give_the_results_of_the_unsplit_batch(hip):
 @pytest.mark.parametrize("Ntot,N,structure", [(112, 4, False), (160, 5, True)])
 def test_jacobi_solver_beyond_96_levels_matches_the_oracle(hip, Ntot, N, structure):
     """JACOBI_SOLVER (src/linear_solvers.jl:110-153) on the cooperative kernels with 7 .. 16 waves per slab: early exit,
-    iteration cap, a three-node ensemble (the device tests convergence per slab instead of per sample: agreement to O(tol))."""
+    iteration cap, a three-node ensemble with loose tolerances (convergence is tested per sample like the reference: 1e-10)."""
     from oracle.oracle import Oracle
     from test_gpu_random import random_problem
     jq = hip
@@ -475,16 +475,16 @@ def test_jacobi_solver_beyond_96_levels_matches_the_oracle(hip, Ntot, N, structu
         r = Oracle(p, use_sparse=False).traceobjgrad(pcof)
         objfv, tg, *_ = jq.traceobjgrad(pcof, p, wa, False, True)
         assert wa.last_timing()["kernel_family"] == 1
-        bound = max(1e-9, 100 * tol)
-        assert abs(objfv - r["objfv"]) <= bound * abs(r["objfv"])
-        assert rel(tg, r["totalgrad"]) < bound
-    nodes, weights, shift = 0.05 * rng.standard_normal(3), rng.random(3), 0.05 * rng.standard_normal(Ntot)
+        assert abs(objfv - r["objfv"]) <= 1e-10 * abs(r["objfv"])      # (per-sample convergence test: irrespective of tol)
+        assert rel(tg, r["totalgrad"]) < 1e-10
+    nodes, weights, shift = 0.3 * rng.standard_normal(3), rng.random(3), 0.3 * rng.standard_normal(Ntot)
     shift[0] = 0.0      # (the reference shifts the levels j >= 2 only, src/ipopt_interface.jl:41-44)
-    p.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER, max_iter=40, tol=1e-13, nrhs=1)
-    ref = Oracle(p, use_sparse=False).eval_f_g_grad(pcof, nodes, weights, shift)
-    jq.eval_f_g_grad(pcof, p, wa, nodes, weights, True, shift=shift)
-    assert abs(p.last_infidelity - ref["last_infidelity"]) <= 1e-9 * abs(ref["last_infidelity"])
-    assert rel(p.last_infidelity_grad, ref["last_infidelity_grad"]) < 1e-9
+    for tol in (1e-13, 1e-6, 1e-4):      # loose tolerances: the samples of the slab stop after different iteration counts
+        p.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER, max_iter=40, tol=tol, nrhs=1)
+        ref = Oracle(p, use_sparse=False).eval_f_g_grad(pcof, nodes, weights, shift)
+        jq.eval_f_g_grad(pcof, p, wa, nodes, weights, True, shift=shift)
+        assert abs(p.last_infidelity - ref["last_infidelity"]) <= 1e-10 * abs(ref["last_infidelity"])
+        assert rel(p.last_infidelity_grad, ref["last_infidelity_grad"]) < 1e-10
     wa.close()
 
 
