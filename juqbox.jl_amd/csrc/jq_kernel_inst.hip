@@ -25,8 +25,11 @@ template __global__ void k_forward_cq_imr<JQ_NT>(PropArgs);
 template __global__ void k_backward_cq_imr<JQ_NT>(PropArgs);
 #elif JQ_VARIANT == 7
 #include "jq_quad_imr_kernels.h"
-template __global__ void k_forward_quad_imr<JQ_NT>(PropArgs);
-template __global__ void k_backward_quad_imr<JQ_NT>(PropArgs);
+template __global__ void k_forward_quad_imr<JQ_NT, 1>(PropArgs);
+template __global__ void k_backward_quad_imr<JQ_NT, 1>(PropArgs);
+// (SPW = 2 -- two slabs per workgroup, two waves per SIMD, operators re-read from LDS per application -- was measured in round 3:
+//  cnot3 x 3 072 samples 0.323 s against 0.225 s for three rounds of SPW = 1: the 36 LDS reads per application saturate the
+//  LDS port with eight waves per CU; not instantiated)
 #elif JQ_VARIANT == 6
 #include "jq_coop_imr_kernels.h"
 template __global__ void k_forward_coop_imr<JQ_NT, JQ_BW>(PropArgs);

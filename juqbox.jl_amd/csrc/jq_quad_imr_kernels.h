@@ -25,7 +25,25 @@ __device__ __forceinline__ double quad_sample_sum(double x, int N, int j)
     return r;
 }
 
-template <int NT>
+// ru, rv summed over the wave at once (N = 4: the 64 lanes are ONE evaluation): after the row swaps the rows 0, 1 of the
+// register hold the wave total of a, the rows 2, 3 that of b (20 VALU instructions; two wave_sum: 46)
+__device__ __forceinline__ double wave_sum2(double a, double b)
+{
+    row_swap32(a, b);
+    double p = a + b;      // rows 0, 1: a0+a2, a1+a3;  rows 2, 3: b0+b2, b1+b3
+    double q = p;
+    row_swap16(p, q);      // p: [p0 p0 p2 p2], q: [p1 p1 p3 p3]
+    double r = p + q;
+    r = row_ror_add<8>(r);
+    r = row_ror_add<4>(r);
+    r = row_ror_add<2>(r);
+    return row_ror_add<1>(r);
+}
+
+// OPREG: the operators of a step live in registers for all its fixed-point iterations (one slab per workgroup, one wave per
+// SIMD: 512 registers); otherwise (two slabs per workgroup, two waves per SIMD: 256 registers) every application re-reads
+// its A operands and coefficient records from the LDS images.
+template <int NT, bool OPREG>
 struct QuadImr {
     const double* K;     // images of the step (LDS, lane offset applied)
     const double* S;
@@ -34,21 +52,86 @@ struct QuadImr {
     int g, N, j, max_iter;
     bool use_shift;
     double tol2;
+    // the operators of the step in registers (every fixed-point iteration multiplies with the same K, S) and this lane's
+    // ensemble-shift coefficients ceps * ws[row] per block (constant over the sweep)
+    OpQ<NT> oK, oS;
+    double cw[NT];
 
-    // q = rhs + [S -K; K S] p   (K, S pre-scaled by h/2; the diagonal shift of K applied row-wise)
+    __device__ __forceinline__ void load_ops()
+    {
+        if constexpr (OPREG) {
+            t4q_load<NT>(oK, K);
+            t4q_load<NT>(oS, S);
+        }
+    }
+    __device__ __forceinline__ void init_shift()
+    {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) cw[i] = use_shift ? ceps * ws[16 * i + g] : 0.0;
+    }
+
+    // (qu, qv) = (rhs_u, rhs_v) + [S -K; K S] (pu, pv)   (K, S pre-scaled by h/2; the diagonal ensemble shift of K row-wise).
+    // ONE pass over the blocks: the two products with pu (S pu, K pu) share its lane shifts, the two with pv likewise --
+    // 48 v_mov_b32_dpp per application instead of 96 (round 2: four independent mm_t4q) -- and -K pv is formed with the
+    // FMA's sign modifier and one sign flip per block for the MFMA operand instead of a negated copy of pv.
     __device__ __forceinline__ void apply(const Arr<NT>& rhs_u, const Arr<NT>& rhs_v, const Arr<NT>& pu, const Arr<NT>& pv, Arr<NT>& qu,
                                           Arr<NT>& qv) const
     {
-        constexpr int FULL = JQ_T4_DIAG | JQ_T4_RTERMS | JQ_T4_MTERMS;
-        Arr<NT> npv = pv;
-        a_neg(npv);
-        mm_t4q<NT, false, FULL>(qu, rhs_u, S, pu);
-        mm_t4q<NT, false, FULL>(qu, qu, K, npv);
-        mm_t4q<NT, false, FULL>(qv, rhs_v, K, pu);
-        mm_t4q<NT, false, FULL>(qv, qv, S, pv);
-        if (use_shift) {
-            a_axpy_rows(qu, ceps, ws, g, npv);
-            a_axpy_rows(qv, ceps, ws, g, pu);
+        double uold = 0.0, vold = 0.0;
+        const int lane = threadIdx.x & 63;
+        const double *Kp = K, *Sp = S;
+        if constexpr (!OPREG) {
+            // the images do not change between the fixed-point iterations: without this the compiler hoists all 60 operand
+            // reads out of the iteration loop -- into registers this variant does not have (184 spilled to scratch)
+            // (an opaque ZERO offset, not an opaque pointer: the pointers must stay visibly LDS addresses -- ds_read, not flat loads)
+            int z = 0;
+            asm volatile("" : "+v"(z));
+            Kp += z;
+            Sp += z;
+        }
+        const double *maK = t4q_a(Kp, lane), *maS = t4q_a(Sp, lane);
+        const d4 *cfK = t4q_c<NT>(Kp, lane), *cfS = t4q_c<NT>(Sp, lane);
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) {
+            const double xu = pu.t[mt][0], xv = pv.t[mt][0];
+            const double un = pu.t[mt + 1 < NT ? mt + 1 : mt][0], vn = pv.t[mt + 1 < NT ? mt + 1 : mt][0];
+            const double uu = row_shift4<0x114>(xu), ud = row_shift4<0x104>(xu);
+            const double vu = row_shift4<0x114>(xv), vd = row_shift4<0x104>(xv);
+            const d4 cs = OPREG ? oS.c[mt] : t4q_cload(cfS, mt), ck = OPREG ? oK.c[mt] : t4q_cload(cfK, mt);
+            const double aS = OPREG ? oS.a[mt] : maS[mt * 64], aK = OPREG ? oK.a[mt] : maK[mt * 64];
+            double au = __builtin_amdgcn_mfma_f64_4x4x4f64(aS, xu, rhs_u.t[mt][0], 0, 0, 0);
+            au = __builtin_amdgcn_mfma_f64_4x4x4f64(aK, -xv, au, 0, 0, 0);
+            double av = __builtin_amdgcn_mfma_f64_4x4x4f64(aK, xu, rhs_v.t[mt][0], 0, 0, 0);
+            av = __builtin_amdgcn_mfma_f64_4x4x4f64(aS, xv, av, 0, 0, 0);
+            au = fma(cs[0], uu, au);
+            av = fma(ck[0], uu, av);
+            au = fma(cs[1], ud, au);
+            av = fma(ck[1], ud, av);
+            au = fma(-ck[0], vu, au);
+            av = fma(cs[0], vu, av);
+            au = fma(-ck[1], vd, au);
+            av = fma(cs[1], vd, av);
+            if (mt > 0) {
+                au = fma(cs[2], uold, au);
+                av = fma(ck[2], uold, av);
+                au = fma(-ck[2], vold, au);
+                av = fma(cs[2], vold, av);
+            }
+            if (mt + 1 < NT) {
+                au = fma(cs[3], un, au);
+                av = fma(ck[3], un, av);
+                au = fma(-ck[3], vn, au);
+                av = fma(cs[3], vn, av);
+            }
+            au = fma(-cw[mt], xv, au);      // (cw = 0 without an ensemble shift: cheaper than a select per block)
+            av = fma(cw[mt], xu, av);
+            uold = xu;
+            vold = xv;
+            qu.t[mt][0] = au;
+            qv.t[mt][0] = av;
+            // (operands from LDS: without a fence per block the scheduler hoists the reads of all six blocks to the top -- 120
+            // registers of operands in flight)
+            if constexpr (!OPREG) __builtin_amdgcn_sched_barrier(0);
         }
     }
     // one implicit-midpoint step of (u, v); (fu, fv): forcing already multiplied by h, added to the right-hand side
@@ -65,6 +148,26 @@ struct QuadImr {
         }
         Arr<NT> cu, cv, nu, nv;
         apply(rhs_u, rhs_v, u, v, cu, cv);           // x_1
+        if (N == 4) {
+            // the 64 lanes are ONE evaluation: the stopping decision is wave-uniform, the iterates alternate between two
+            // register sets (no copies), both norms come out of one reduction
+            for (int it = 1;; it += 2) {
+                apply(rhs_u, rhs_v, cu, cv, nu, nv);     // x_{it+1};  residual at x_it = x_it - x_{it+1}
+                bool conv = __all(wave_sum2(a_diff2(cu, nu), a_diff2(cv, nv)) < tol2);
+                if (conv || it >= max_iter) {            // keeps x_it
+                    u = cu;
+                    v = cv;
+                    return;
+                }
+                apply(rhs_u, rhs_v, nu, nv, cu, cv);     // x_{it+2}
+                conv = __all(wave_sum2(a_diff2(nu, cu), a_diff2(nv, cv)) < tol2);
+                if (conv || it + 1 >= max_iter) {        // keeps x_{it+1}
+                    u = nu;
+                    v = nv;
+                    return;
+                }
+            }
+        }
         bool done = !valid;
         for (int it = 1; it <= max_iter; ++it) {
             apply(rhs_u, rhs_v, cu, cv, nu, nv);     // x_{it+1};  residual at x_it = x_it - x_{it+1}
@@ -87,28 +190,30 @@ struct QuadImr {
     extern __shared__ __attribute__((aligned(16))) char smem[];                                                               \
     constexpr int KT = 4 * NT;                                                                                                \
     const int lane_ = threadIdx.x & 63;                                                                                       \
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                                                        \
-    const int col = 4 * wave + (lane_ & 3);                                                                                   \
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      /* (SPW slabs per workgroup: 4 SPW waves) */      \
+    const int col = 4 * (wave & 3) + (lane_ & 3);                                                                             \
     const int lane = ((lane_ >> 2) & 3) * 64 + 16 * (lane_ >> 4) + col;   /* this lane's offset in a block of the slab image */ \
     const int g = 4 * (lane_ >> 4) + ((lane_ >> 2) & 3);                  /* ... of the row tables */                         \
-    const int slab = blockIdx.x;                                                                                              \
+    const int slab = (int)blockIdx.x * SPW + (wave >> 2);                                                                     \
+    const bool active = slab < a.nslabs;                                                                                      \
     double* tab = (double*)(smem + a.lds_tab_off);                                                                            \
     const double* wd = tab;                                                                                                   \
     for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[(i & ~15) + 4 * (i & 3) + ((i >> 2) & 3)] = a.tabs[i];         \
-    double* st = a.state + (size_t)slab * a.state_stride;                                                                     \
+    double* st = a.state + (size_t)(active ? slab : 0) * a.state_stride;                                                      \
     Ring p;                                                                                                                   \
-    p.init(smem, a, wave, lane_);      /* (window mode: ends with a barrier, the tables are published too) */                 \
-    QuadImr<NT> m;                                                                                                            \
+    p.init(smem, a, wave, lane_, 4 * SPW);      /* (window mode: ends with a barrier, the tables are published too) */        \
+    QuadImr<NT, SPW == 1> m;                                                                                                  \
     m.ws = tab + 16 * NT;                                                                                                     \
-    m.ceps = 0.5 * a.h * a.colinfo[(size_t)slab * 32 + col];                                                                  \
+    m.ceps = active ? 0.5 * a.h * a.colinfo[(size_t)slab * 32 + col] : 0.0;                                                   \
     m.g = g, m.N = a.N, m.j = lane_ & 3, m.max_iter = a.m, m.use_shift = a.use_shift, m.tol2 = a.jacobi_tol2;                 \
-    const bool valid = col < (16 / a.N) * a.N;                                                                                \
+    m.init_shift();                                                                                                           \
+    const bool valid = active && col < (16 / a.N) * a.N;                                                                      \
     Arr<NT> zero;                                                                                                             \
     a_zero(zero);
 
 // Forward sweep.  a.m = max_iter, a.jacobi_tol2 = tol^2; array file of the slab kernels.
-template <int NT>
-__global__ __launch_bounds__(256) void k_forward_quad_imr(PropArgs a)
+template <int NT, int SPW>
+__global__ __launch_bounds__(256 * SPW) void k_forward_quad_imr(PropArgs a)
 {
     JQ_QUAD_IMR_PROLOGUE
     Arr<NT> u, v;
@@ -120,6 +225,8 @@ __global__ __launch_bounds__(256) void k_forward_quad_imr(PropArgs a)
         p.begin_step(n);
         m.K = p.template next_ks<0, 1>();
         m.S = p.template next_ks<1, 1>();
+        m.load_ops();
+        if (!active) continue;      // (a wave without a slab only takes part in the staging)
         Arr<NT> su = u, sv = v;
         m.step(u, v, zero, zero, valid);
         a_add(su, u);
@@ -128,6 +235,7 @@ __global__ __launch_bounds__(256) void k_forward_quad_imr(PropArgs a)
         if (a.hist_r) hist_store<NT>(a, slab, col, 4 * ((lane_ >> 2) & 3) + (lane_ >> 4), n, u, v);
     }
     p.drain();
+    if (!active) return;
     a_store(u, st, lane);
     a_store(v, st + KT * 64, lane);
     leak = row_ror_add<8>(row_ror_add<4>(leak));
@@ -137,8 +245,8 @@ __global__ __launch_bounds__(256) void k_forward_quad_imr(PropArgs a)
 // Backward sweep (src/evalobjgrad.jl:1290-1336): state re-integration with h < 0, adjoint m_step! with forcing
 // -W (v + v_s) / T and the two gradient scalars of adjoint_grad_calc_m per control (:2660-2702), written in the slots of
 // the midpoint weights of k_gradacc (jq_rowlane_imr_kernels.h): tr[3] = -(B + C)/4, tr[4] = (A + D)/4.
-template <int NT>
-__global__ __launch_bounds__(256) void k_backward_quad_imr(PropArgs a)
+template <int NT, int SPW>
+__global__ __launch_bounds__(256 * SPW) void k_backward_quad_imr(PropArgs a)
 {
     JQ_QUAD_IMR_PROLOGUE
     const int Nc = a.Ncoupled;
@@ -147,13 +255,21 @@ __global__ __launch_bounds__(256) void k_backward_quad_imr(PropArgs a)
     a_load(v, st + KT * 64, lane);
     a_load(lr, st + 2 * KT * 64, lane);
     a_load(li, st + 3 * KT * 64, lane);
-    const double wgt = a.colinfo[(size_t)slab * 32 + 16 + col];
+    const double wgt = active ? a.colinfo[(size_t)slab * 32 + 16 + col] : 0.0;
     const double cfw = a.forced ? -a.h * a.tinv : 0.0;            // h * (-tinv * W): W applied row-wise
-    double* trw = a.traces + ((size_t)(slab * JQ_WAVES + wave) * a.nsteps_chunk) * (Nc * JQ_NTR);
+    double* trw = a.traces + ((size_t)((active ? slab : 0) * JQ_WAVES + (wave & 3)) * a.nsteps_chunk) * (Nc * JQ_NTR);
     for (int n = 0; n < a.nsteps_chunk; ++n) {
         p.begin_step(n);
         m.K = p.template next_ks<0, 1>();
         m.S = p.template next_ks<1, 1>();
+        m.load_ops();
+        if (!active) {      // (keep the cursor of the constant images in step with the other waves)
+            for (int q = 0; q < Nc; ++q) {
+                (void)p.next_c(q);
+                (void)p.next_c(Nc + q);
+            }
+            continue;
+        }
         Arr<NT> su = u, sv = v, smu = lr, snu = li;
         m.step(u, v, zero, zero, valid);
         a_add(su, u);
@@ -191,6 +307,7 @@ __global__ __launch_bounds__(256) void k_backward_quad_imr(PropArgs a)
         }
     }
     p.drain();
+    if (!active) return;
     a_store(u, st, lane);
     a_store(v, st + KT * 64, lane);
     a_store(lr, st + 2 * KT * 64, lane);

@@ -1217,20 +1217,20 @@ static int select_cq_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bw
 #undef JQ_PICKCQ
     return fail(h, JQ_EUNSUPPORTED, "unsupported Hilbert dimension");
 }
-template <int NT> __global__ void k_forward_quad_imr(PropArgs);      // jq_quad_imr_kernels.h (own translation units)
-template <int NT> __global__ void k_backward_quad_imr(PropArgs);
-#define JQ_DECLQI(nt)                                                      \
-    extern template __global__ void k_forward_quad_imr<nt>(PropArgs);      \
-    extern template __global__ void k_backward_quad_imr<nt>(PropArgs);
+template <int NT, int SPW> __global__ void k_forward_quad_imr(PropArgs);      // jq_quad_imr_kernels.h (own translation units)
+template <int NT, int SPW> __global__ void k_backward_quad_imr(PropArgs);
+#define JQ_DECLQI(nt)                                                         \
+    extern template __global__ void k_forward_quad_imr<nt, 1>(PropArgs);      \
+    extern template __global__ void k_backward_quad_imr<nt, 1>(PropArgs);
 JQ_DECLQI(1) JQ_DECLQI(2) JQ_DECLQI(3) JQ_DECLQI(4) JQ_DECLQI(5) JQ_DECLQI(6) JQ_DECLQI(7) JQ_DECLQI(8)
 #undef JQ_DECLQI
 static int select_quad_imr_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
 {
-#define JQ_PICKQI(nt)                              \
-    if (h->NT == nt) {                             \
-        *fwd = k_forward_quad_imr<nt>;             \
-        *bwd = k_backward_quad_imr<nt>;            \
-        return JQ_OK;                              \
+#define JQ_PICKQI(nt)                                 \
+    if (h->NT == nt) {                                \
+        *fwd = k_forward_quad_imr<nt, 1>;             \
+        *bwd = k_backward_quad_imr<nt, 1>;            \
+        return JQ_OK;                                 \
     }
     JQ_PICKQI(1) JQ_PICKQI(2) JQ_PICKQI(3) JQ_PICKQI(4) JQ_PICKQI(5) JQ_PICKQI(6) JQ_PICKQI(7) JQ_PICKQI(8)
 #undef JQ_PICKQI
@@ -1556,6 +1556,8 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
             while (spw > 1 && quad_lds(spw) > 163840) --spw;
         }
     }
+    // (one slab per workgroup, one wave per SIMD, the operators of a step in registers for all its fixed-point iterations; a
+    // two-slab variant that re-reads them from LDS was measured 1.4 x slower, jq_kernel_inst.hip)
     if (imr_quad) spw = 1;
     // latency regime of the JQ_BW_T4 structure: one workgroup of NT waves per column quad (jq_cq_kernels.h)
     const long long nquads_used = (ncols_used + 3) / 4;
