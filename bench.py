@@ -416,6 +416,13 @@ def main():
                 out["single_evaluation_implicit_midpoint"] = {"seconds": time.perf_counter() - t1,
                                                               "kernel_family": wm.last_timing()["kernel_family"],
                                                               "solver": "jacobi_midpoint, max_iter 100, tol 1e-12 (test/runtests.jl:69-70)"}
+                # ... and its ensemble throughput on the same 3 072-sample workload (the examples' default integrator)
+                jq.eval_f_g_grad(pcof, pm, wm, nodes, weights, True, shift=shift)
+                t1 = time.perf_counter()
+                jq.eval_f_g_grad(pcof, pm, wm, nodes, weights, True, shift=shift)
+                dt_m = time.perf_counter() - t1
+                out["ensemble_implicit_midpoint"] = {"samples": int(nodes.size), "seconds": dt_m, "evals_per_s": nodes.size / dt_m,
+                                                     "kernel_family": wm.last_timing()["kernel_family"]}
                 wm.close()
             except Exception as e:  # noqa: BLE001
                 out["single_evaluation_implicit_midpoint"] = {"error": str(e)[:200]}
