@@ -595,6 +595,65 @@ __device__ __forceinline__ void mm_t4q(Arr<NT>& D, const Arr<NT>& C, const doubl
         t4q_block<NT, ZEROC, MODE>(D, C, x, mt, a, c, xold);
     }
 }
+// Two / three products with the SAME right-hand side in one pass over the blocks (round 3): D_k = C_k + M_k x.  The lane shifts
+// of x (four v_mov_b32_dpp per block, as expensive as the block's MFMA) are made once for all of them.  x must not alias a D_k.
+template <int NT, int NP, bool Z0, bool Z1, bool Z2>
+__device__ __forceinline__ void mm_t4q_multi(Arr<NT>& D0, const Arr<NT>& C0, const double* m0, Arr<NT>& D1, const Arr<NT>& C1,
+                                             const double* m1, Arr<NT>& D2, const Arr<NT>& C2, const double* m2, const Arr<NT>& x)
+{
+    const int lane = threadIdx.x & 63;
+    const double* ma[3] = {t4q_a(m0, lane), t4q_a(m1, lane), t4q_a(NP > 2 ? m2 : m1, lane)};
+    const d4* cf[3] = {t4q_c<NT>(m0, lane), t4q_c<NT>(m1, lane), t4q_c<NT>(NP > 2 ? m2 : m1, lane)};
+    double xold = 0.0;
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) {
+        // (operands of THIS block only: a one-block-ahead prefetch like mm_t4q's costs 10 NP registers, which the twelve-wave
+        // variants do not have; their other two waves per SIMD cover the LDS latency)
+        double a[3];
+        d4 c[3];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            a[k] = ma[k][mt * 64];
+            c[k] = t4q_cload(cf[k], mt);
+        }
+        const double xc = x.t[mt][0], xn = x.t[mt + 1 < NT ? mt + 1 : mt][0];
+        const double su = row_shift4<0x114>(xc), sd = row_shift4<0x104>(xc);
+        double acc[3] = {Z0 ? 0.0 : C0.t[mt][0], Z1 ? 0.0 : C1.t[mt][0], (NP > 2 && !Z2) ? C2.t[mt][0] : 0.0};
+#pragma unroll
+        for (int k = 0; k < NP; ++k) acc[k] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[k], xc, acc[k], 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) acc[k] = fma(c[k][0], su, acc[k]);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) acc[k] = fma(c[k][1], sd, acc[k]);
+        if (mt > 0) {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) acc[k] = fma(c[k][2], xold, acc[k]);
+        }
+        if (mt + 1 < NT) {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) acc[k] = fma(c[k][3], xn, acc[k]);
+        }
+        xold = xc;
+        D0.t[mt][0] = acc[0];
+        D1.t[mt][0] = acc[1];
+        if constexpr (NP > 2) D2.t[mt][0] = acc[2];
+        // (fence per block: the scheduler otherwise hoists the operand reads of all blocks to the top -- 15 NT doubles in flight,
+        // 200 spilled registers in the twelve-wave variants)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+template <int NT, bool Z0, bool Z1>
+__device__ __forceinline__ void mm_t4q2(Arr<NT>& D0, const Arr<NT>& C0, const double* m0, Arr<NT>& D1, const Arr<NT>& C1,
+                                        const double* m1, const Arr<NT>& x)
+{
+    mm_t4q_multi<NT, 2, Z0, Z1, true>(D0, C0, m0, D1, C1, m1, D1, C1, m1, x);
+}
+template <int NT, bool Z0, bool Z1, bool Z2>
+__device__ __forceinline__ void mm_t4q3(Arr<NT>& D0, const Arr<NT>& C0, const double* m0, Arr<NT>& D1, const Arr<NT>& C1,
+                                        const double* m1, Arr<NT>& D2, const Arr<NT>& C2, const double* m2, const Arr<NT>& x)
+{
+    mm_t4q_multi<NT, 3, Z0, Z1, Z2>(D0, C0, m0, D1, C1, m1, D2, C2, m2, x);
+}
 // the same with the operator in registers (the m + 1 products of a Horner chain share it: no LDS latency at their heads)
 template <int NT>
 __device__ __forceinline__ void t4q_load(OpQ<NT>& op, const double* mat)
@@ -1286,17 +1345,80 @@ __device__ __forceinline__ void a_unpark(Arr<NT>& a, const double* park)
         for (int r = 0; r < JQ_RL; ++r) a.t[i][r] = park[(JQ_RL * i + r) * 64];
 }
 
+// Which sweeps use the fused passes of sv_state (measured with scripts/exp_variants.sh at cnot3 x 3 072 samples, DESIGN.md
+// section 6, round 3): forward 337 -> 318 ms -- most of it (-17 ms) from having four stages instead of six (fewer branch fences),
+// the shared lane shifts add -2.5 ms; the twelve-wave backward kernel loses with ANY of it in its state step (104 -> 144 .. 540 B
+// of scratch: 838 -> 915 .. 1 400 ms) and gains 6 ms from K0 X / K1 X in one pass (no extra registers).
+#ifndef JQ_FWD_FUSE
+#define JQ_FWD_FUSE 3
+#endif
+#ifndef JQ_BWD_FUSE
+#define JQ_BWD_FUSE 3
+#endif
+#ifndef JQ_BWD_FUSE3      // ... of the twelve-wave backward kernel (168 registers per wave)
+#define JQ_BWD_FUSE3 0
+#endif
+#ifndef JQ_BWD_ADJ_FUSE   // adjoint step: K0 X and K1 X in one pass
+#define JQ_BWD_ADJ_FUSE 1
+#endif
 // State (re-)integration, operator uses 0..5 of one Stormer-Verlet step (forward step!,
 // src/StormerVerlet.jl:461-504, also used with h<0 by the backward sweep, src/evalobjgrad.jl:879).
 //   in : u (preserved), v (CONSUMED: overwritten in place by v05 = v(t+h/2))
 //   out: unew = u(t+h), vN = v05 + S05 v05 (the caller finishes v(t+h) = vN + Kp05 unew with use 6)
 //   A, Ya, Yb: scratch arrays.          Operator order per step: Kp05 S05 Kn0 S0 Kn1 S1 (Kp05).
 // At most 8 arrays are live here (u, v/v05, unew, vN, A, Ya, Yb + one of the caller's).
-template <int NT, int BW, bool JAC>
+// FUSE (quad layout only): bit 0 = K05 u with S0 u in one pass, bit 1 = S05 v05 with K0 v05 and K1 v05 in one pass
+template <int NT, int BW, bool JAC, int FUSE = 0>
 __device__ __forceinline__ void sv_state(Ring& p, const PropArgs& a, bool active, double ceps, const double* ws, int g,
                                          const Arr<NT>& u, Arr<NT>& v, Arr<NT>& unew, Arr<NT>& vN, Arr<NT>& A, Arr<NT>& Ya,
                                          Arr<NT>& Yb)
 {
+    if constexpr (BW == JQ_BW_T4Q && !JAC && FUSE != 0) {
+        // Quad layout (always window staging: every image of the step is resident, the order of the uses is free): the products
+        // that share a right-hand side are made in ONE pass over the blocks so that they share its lane shifts -- K05 u with
+        // S0 u, and S05 v05 with K0 v05 and K1 v05: 5 + 2m passes instead of 8 + 2m (the products are the same 8 + 2m).
+        // (One `if (active)` block per stage like the generic path below: the branches keep hipcc from hoisting the operand
+        // reads of later stages -- one basic block for the whole step spills 200+ registers in the twelve-wave variants.)
+        const double* M0 = p.next_ks<0, 1>();      // Kp05
+        const double* M1 = p.next_ks<1, 0>();      // S0
+        if (active) {
+            if constexpr (FUSE & 1) {
+                mm_t4q2<NT, true, false>(A, A, M0, unew, u, M1, u);        // A = c K05 u ;  unew = u + c S0 u
+            } else {
+                mm_z<NT, BW>(A, M0, u);
+                mm_c<NT, BW>(unew, u, M1, u);
+            }
+            if (a.use_shift) a_axpy_rows(A, ceps, ws, g, u);
+        }
+        M0 = p.next_ks<1, 1>();                    // S05
+        if (active) {
+            mm_c<NT, BW>(A, A, M0, v);                                 // A = c (K05 u + S05 v)
+            a_add(v, A);
+            horner_add<NT, BW, JAC>(v, v, A, M0, a.m, Ya, Yb, a.jacobi_tol2, a.N);       // v = v05
+        }
+        M1 = p.next_ks<0, 0>();                    // Kn0
+        const double* M2 = p.next_ks<0, 2>();      // Kn1
+        if (active) {
+            if constexpr (FUSE & 2) {
+                mm_t4q3<NT, false, false, true>(vN, v, M0, unew, unew, M1, A, A, M2, v);     // vN = v05 + S05 v05 ; unew -= c K0 v05 ; A = -c K1 v05
+            } else {
+                mm_c<NT, BW>(vN, v, M0, v);
+                mm_c<NT, BW>(unew, unew, M1, v);
+                mm_z<NT, BW>(A, M2, v);
+            }
+            if (a.use_shift) {
+                a_axpy_rows(unew, -ceps, ws, g, v);
+                a_axpy_rows(A, -ceps, ws, g, v);
+            }
+        }
+        M0 = p.next_ks<1, 2>();                    // S1
+        if (active) {
+            mm_c<NT, BW>(A, A, M0, unew);                              // A = c (S1 (u + c kappa1) - K1 v05)
+            a_add(unew, A);
+            horner_add<NT, BW, JAC>(unew, unew, A, M0, a.m, Ya, Yb, a.jacobi_tol2, a.N);
+        }
+        return;
+    }
     // use 0: Kp05 -- A = c K05 u
     const double* M = p.next_ks<0, 1>();
     if (active) {
@@ -1385,7 +1507,7 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
     {                                                                                                            \
         p.begin_step(NSTEP);                                                                                     \
         if (active) leak += a_wsq(wd, g, U); /* trapezoidal part: tr(vr' W vr) at t_n (:700) */                  \
-        sv_state<NT, BW, JAC>(p, a, active, ceps, ws, g, U, V, UN, VN, A, Ya, Yb);                                    \
+        sv_state<NT, BW, JAC, JQ_FWD_FUSE>(p, a, active, ceps, ws, g, U, V, UN, VN, A, Ya, Yb);                       \
         /* use 6: Kp05 again -- v(t+h) = v05 + c (K05 u_new + S05 v05) */                                        \
         const double* M6 = p.next_ks<0, 1>();                                                                             \
         if (active) {                                                                                            \
@@ -1536,7 +1658,7 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
         // ---- state step (lambda_r parked) ------------------------------------------------------
         if (active) a_park(mu, P0);
         // mu's registers serve as the scratch array A of the state step
-        sv_state<NT, BW, JAC>(p, a, active, ceps, ws, g, u, v, un, vN, mu, Ya, Yb);
+        sv_state<NT, BW, JAC, (MINW >= 3 ? JQ_BWD_FUSE3 : JQ_BWD_FUSE)>(p, a, active, ceps, ws, g, u, v, un, vN, mu, Ya, Yb);
         // (every wave has passed a workgroup barrier since it finished step n-1: begin_step in window mode, the operator
         // switches of sv_state otherwise)
         if (n > 0) flush_traces(n - 1);
@@ -1568,6 +1690,18 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
                 if ((lane_ & 15) == 0) rec[((size_t)(n & 1) * NWAVES + wave) * rslots + 4 * q + (lane_ >> 4)] = ts;
             }
         }
+        if constexpr (QUAD && !JAC && (JQ_BWD_ADJ_FUSE & 1)) {
+            // uses 8 and 9 in one pass (they share X): L = -c K0 X ; vN(scratch Q) = -c K1 X
+            M = p.next_ks<0, 0>();
+            const double* M9 = p.next_ks<0, 2>();
+            if (active) {
+                mm_t4q2<NT, true, true>(L, L, M, vN, vN, M9, mu);
+                if (a.use_shift) {
+                    a_axpy_rows(L, -ceps, ws, g, mu);
+                    a_axpy_rows(vN, -ceps, ws, g, mu);
+                }
+            }
+        } else {
         // use 8: Kn0 -- L = -c K0 X
         M = p.next_ks<0, 0>();
         if (active) {
@@ -1579,6 +1713,7 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
         if (active) {
             mm_z<NT, BW>(vN, M, mu);
             if (a.use_shift) a_axpy_rows(vN, -ceps, ws, g, mu);
+        }
         }
         // use 10: S05 -- L = -c l2 = -c (K0 X + S05 li + hi0) ; Q = -c (S05 (li + c l2) + K1 X + hi1) ;
         //               nb_new = nb + L + sum_j S^j Q          (li_new = li + c (l2 + l1))

@@ -2,6 +2,11 @@
 // recurrence Y <- A + S Y with parts of the product switched off, to see what each instruction class costs when the
 // SIMD has other waves to issue from.  MODE bits: 1 = MFMA, 2 = lane shifts (v_mov_b32_dpp), 4 = (i, i+-4) FMAs,
 // 8 = (i, i+-16) FMAs.  Cycles are per product and SIMD (all waves of the SIMD do one product each).
+// 16 (round 3) = the middle-subsystem coupling on the matrix pipe INSTEAD of lane shifts + FMAs: v_mfma_f64_4x4x4_4b always
+// contracts the index in the lane bits [5:4] and never moves its block index (bits [3:2]), so the (i, i+-4) coupling needs the
+// state with the middle index in [5:4]: one MFMA with the state in the A slot and the identity in B transposes it (fast index
+// <-> column index ... in the layout (fast, column-block, middle) of DESIGN.md section 9), a second one applies the 4 x 4
+// coupling matrix and transposes back.  Per block: 3 MFMAs + 2 slow-coupling FMAs instead of 1 MFMA + 4 v_mov_b32_dpp + 4 FMAs.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
@@ -37,6 +42,10 @@ __global__ __launch_bounds__(256 * WPS) void k_probe(const double* img, double* 
             const double x = Y[mt];
             double acc = A[mt];
             if (MODE & 1) acc = __builtin_amdgcn_mfma_f64_4x4x4f64(cr[mt][0], x, acc, 0, 0, 0);
+            if (MODE & 16) {      // transposition (state as the A operand, identity as B), then the coupling matrix as B
+                const double xt = __builtin_amdgcn_mfma_f64_4x4x4f64(x, cr[mt][1], 0.0, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_4x4x4f64(xt, cr[mt][2], acc, 0, 0, 0);
+            }
             double xdn = x, xup = x;
             if (MODE & 2) {
                 xdn = row_shift<0x114>(x);
@@ -76,7 +85,7 @@ int run(const double* dimg, double* dout)
     CK(hipDeviceSynchronize());
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
-    const int nm = (MODE & 1) ? NT : 0, nmov = (MODE & 2) ? 4 * NT : 0, nf = ((MODE & 4) ? 2 * NT : 0) + ((MODE & 8) ? 2 * NT - 2 : 0);
+    const int nm = ((MODE & 1) ? NT : 0) + ((MODE & 16) ? 2 * NT : 0), nmov = (MODE & 2) ? 4 * NT : 0, nf = ((MODE & 4) ? 2 * NT : 0) + ((MODE & 8) ? 2 * NT - 2 : 0);
     const double ns = ms * 1e6 / reps;
     printf("mode %2d (%d MFMA, %2d dpp mov, %2d FMA per product) %d wave(s)/SIMD: %7.1f ns = %6.0f clk per product round; per wave %6.0f clk (issue model 16/4/4: %4d)\n",
            MODE, nm, nmov, nf, WPS, ns, ns * 2.4, ns * 2.4 / WPS, 16 * nm + 4 * nmov + 4 * nf);
@@ -106,5 +115,6 @@ int main()
     runw<13>(dimg, dout);
     runw<3>(dimg, dout);
     runw<14>(dimg, dout);
+    runw<25>(dimg, dout);      // 1 + 8 + 16: the product with the middle coupling on two more MFMAs per block (no shifts)
     return 0;
 }
