@@ -144,6 +144,9 @@ const char *jq_last_error(const jq_handle *h);
 int jq_create_multi(const jq_problem *problem, const int32_t *devices, int32_t ndev, jq_handle **out);
 /* number of GPUs behind a handle (1 for jq_create handles) */
 int jq_num_devices(const jq_handle *h);
+/* compute units of the handle's GPU (256 on MI355X): the granularity of the batch-size staircase -- one round of the throughput
+ * kernels is 3 slabs (= 3 * (16 / N) samples for N <= 16) per compute unit */
+int jq_num_compute_units(const jq_handle *h);
 /* HIP device id a handle is bound to (the first device of a multi-device handle; -1 for NULL): device pointers handed to
  * jq_eval_f_g_grad_dev must live on THIS device */
 int jq_handle_device(const jq_handle *h);

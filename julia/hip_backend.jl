@@ -128,6 +128,7 @@ function Working_Arrays_M_HIP(params::objparams, nCoeff::Int64; devices = nothin
 end
 
 num_devices(wa::AbstractWorkingArraysHIP) = ccall((:jq_num_devices, libjq), Cint, (Ptr{Cvoid},), wa.handle)
+num_compute_units(wa::AbstractWorkingArraysHIP) = ccall((:jq_num_compute_units, libjq), Cint, (Ptr{Cvoid},), wa.handle)
 handle_device(wa::AbstractWorkingArraysHIP) = ccall((:jq_handle_device, libjq), Cint, (Ptr{Cvoid},), wa.handle)
 
 # params is mutated freely by scripts (Hconst inside eval_f_g_grad!, wmat_real, max_iter, targets): push before each call

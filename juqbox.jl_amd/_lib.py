@@ -60,6 +60,7 @@ SYMBOLS = {
                                        ctypes.POINTER(ctypes.c_void_p)]),
     "jq_num_devices": (ctypes.c_int, [ctypes.c_void_p]),
     "jq_handle_device": (ctypes.c_int, [ctypes.c_void_p]),
+    "jq_num_compute_units": (ctypes.c_int, [ctypes.c_void_p]),
     "jq_shard_bounds": (ctypes.c_int, [c_i32, c_i32, c_i32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "jq_traceobj_sweep": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_i32, c_dp, c_i32, c_dp, c_dp]),
     "jq_last_timing": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(jq_timing)]),

@@ -2229,6 +2229,8 @@ extern "C" int jq_num_devices(const jq_handle* h) { return !h ? 0 : h->subs.empt
 
 extern "C" int jq_handle_device(const jq_handle* h) { return h ? h->device : -1; }
 
+extern "C" int jq_num_compute_units(const jq_handle* h) { return !h ? 0 : h->subs.empty() ? h->num_cu : h->subs[0]->num_cu; }
+
 static void destroy_multi(jq_handle* h)
 {
     int prev = 0;
