@@ -23,7 +23,7 @@ def run(n_cases=50, seed=1, verbose=True):
         case += 1
         Ntot = int(rng.choice([2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 14, 16, 17, 20, 31, 32, 33, 40, 48, 50, 63, 64, 65, 80, 81, 95, 96, 100, 112, 128]))
         N = int(rng.integers(1, min(Ntot, 16) + 1))
-        Nc = int(rng.integers(1, 5))
+        Nc = int(rng.integers(1, 5)) if rng.random() < 0.75 else int(rng.integers(5, 10))      # (round 3: control groups)
         Nfreq = int(rng.integers(1, 4))
         nsteps = int(rng.integers(3, 24))
         m = int(rng.integers(0, 8))
@@ -51,16 +51,24 @@ def run(n_cases=50, seed=1, verbose=True):
             k, v = mode.split("=")
             env[k] = v
         p, pcof = random_problem(jq, rng, Ntot, N, Nc, Nfreq, nsteps, m, oft, structure)
+        jac = (not imr) and rng.random() < 0.15      # (round 3: the Jacobi solver with a loose tolerance -- per-sample convergence)
+        jtol = float(10.0 ** rng.integers(-12, -4))
         if imr:
             p.Integrator_id = jq.Implicit_Midpoint
             p.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER_M, max_iter=80, tol=1e-11, nrhs=N)
             p.wmat = p.wmat_real.copy()
+        elif jac:
+            p.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER, max_iter=60, tol=jtol, nrhs=N)
+        replan = rng.random() < 0.1                  # (round 3: a drift outside the planned structure before the evaluation)
         os.environ.update(env)
         try:
             wa = (jq.Working_Arrays_M_HIP if imr else jq.Working_Arrays_HIP)(p, pcof.size)
         finally:
             for k in env:
                 os.environ.pop(k, None)
+        if replan:
+            D = rng.standard_normal((Ntot, Ntot))
+            p.Hconst = p.Hconst + 0.02 * (D + D.T)
         nq = int(rng.choice([1, 2, 5, 17, 70]))
         nodes, weights = 0.05 * rng.standard_normal(nq), rng.random(nq)
         shift = 0.05 * rng.standard_normal(Ntot); shift[0] = 0.0
@@ -91,8 +99,9 @@ def run(n_cases=50, seed=1, verbose=True):
         worst = max(worst, err)
         compared += 1
         flag = "" if err < 1e-8 else "   <<<<<< MISMATCH"
-        nonlocal_print("%3d Ntot=%2d N=%2d Nc=%d Nf=%d steps=%2d m=%d oft=%d %-5s %s nq=%2d fam=%d %-18s env=%s err=%.1e%s" % (
-            case, Ntot, N, Nc, Nfreq, nsteps, m, oft, structure, "IMR" if imr else "SV ", nq, fam, mode, env.get("JQ_CHUNK_STEPS", "-"), err, flag), flush=True)
+        nonlocal_print("%3d Ntot=%2d N=%2d Nc=%d Nf=%d steps=%2d m=%d oft=%d %-5s %s nq=%2d fam=%d %-18s env=%s%s%s err=%.1e%s" % (
+            case, Ntot, N, Nc, Nfreq, nsteps, m, oft, structure, "IMR" if imr else ("JAC" if jac else "SV "), nq, fam, mode,
+            env.get("JQ_CHUNK_STEPS", "-"), " replan" if replan else "", (" tol=%.0e" % jtol) if jac else "", err, flag), flush=True)
         wa.close()
     nonlocal_print("worst relative error %.2e over %d compared cases (of %d drawn) in %.0f s" % (worst, compared, n_cases, time.time() - t0))
 
