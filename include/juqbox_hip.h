@@ -168,9 +168,10 @@ int jq_set_linear_solver(jq_handle *h, int32_t solver_id, int32_t max_iter, doub
  * traceobjgrad method runs: 1 = the Stormer-Verlet path (default), 2 = the implicit-midpoint path
  * (traceobjgrad for Working_Arrays_M, src/evalobjgrad.jl:1042-1481) with the fixed-point solver
  * lsolver_object(solver=JACOBI_SOLVER_M, max_iter, tol) (src/linear_solvers.jl:52-55, :156-270).  For integrator 2 the
- * leakage weights are params.wmat (pass them with jq_update_wmat_diag).  Implemented for Ntot <= 96 and N <= 16 columns per
- * evaluation: row-lane kernels (Ntot <= 16, N <= 4), cooperative MFMA kernels (any batch size; dense 96 x 96 operators do not
- * fit their LDS slots), quad-layout and cooperative-quad kernels for the 4 x 4 x n structure; JQ_EUNSUPPORTED otherwise. */
+ * leakage weights are params.wmat (pass them with jq_update_wmat_diag).  Implemented for N <= 16 columns per evaluation:
+ * row-lane kernels (Ntot <= 16, N <= 4), cooperative MFMA kernels (any batch size; Ntot <= 96: both images of a step resident in
+ * LDS -- dense 96 x 96 operators do not fit; Ntot 97 .. 256: images read from HBM / L2 per product), quad-layout and
+ * cooperative-quad kernels for the 4 x 4 x n structure; JQ_EUNSUPPORTED otherwise. */
 int jq_set_integrator(jq_handle *h, int32_t integrator_id, int32_t max_iter, double tol);
 /* change_target!(params, new_Utarget) (src/evalobjgrad.jl:1492) */
 int jq_update_target(jq_handle *h, const double *Utarget_r, const double *Utarget_i);

@@ -12,11 +12,16 @@
 // per step; the two slots are re-used for the (Hsym_q, Hanti_q) pair of every control after the adjoint solve).
 // Per-evaluation convergence: every wave writes its rows' partial sums of squares per lane, and after one barrier
 // every lane adds up the NT x 4 x N entries of its own evaluation -- all waves reach the same decision.
+// Ntot > 96 (NT = 7 .. 16, round 3): the images do not fit the LDS; like the Stormer-Verlet BIG variants (jq_coop_kernels.h) a
+// wave reads its own tile row of K(t+h/2), S(t+h/2) -- and of the trace images -- straight from the tile stream in HBM / L2 for
+// every product (the ~8 products of a step with the same two images hit L2); LDS holds the tables, the exchange buffers and the
+// norm partials only.
 #pragma once
 #include "jq_coop_kernels.h"
 
 template <int NT, int BW>
 struct CoopImr {
+    static constexpr bool BIG = (NT > 6);
     Coop<NT, BW> c;          // exchange buffers + product (c.M is pointed at the wanted image by hand; its ring is unused)
     char* smem;
     const double* stream;
@@ -51,9 +56,36 @@ struct CoopImr {
         Kimg = (const double*)smem + c.row_off + lane;
         Simg = Kimg + stride;
     }
+    // the two images of the next products: `s0`, `s1` in global memory.  LDS variants: fetched into the two slots (all waves take
+    // part; ends with a barrier); BIG: the products read them where they are.
+    __device__ __forceinline__ void use_images(const double* s0, const double* s1)
+    {
+        if constexpr (BIG) {
+            Kimg = s0 + c.row_off + lane;
+            Simg = s1 + c.row_off + lane;
+        } else {
+            __syncthreads();                               // every wave is done with the previous pair
+            unsigned lo;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lo));
+            const char* p0 = (const char*)s0 + lo * 16u;
+            const char* p1 = (const char*)s1 + lo * 16u;
+            for (int p = wave; p < pieces; p += NT) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p0 + (size_t)p * 1024),
+                                                 (__attribute__((address_space(3))) void*)(smem + p * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p1 + (size_t)p * 1024),
+                                                 (__attribute__((address_space(3))) void*)(smem + stride * 8 + p * 1024), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
     // fetch two consecutive images (2*pieces KiB) into the two slots; all waves take part; ends with a barrier
     __device__ __forceinline__ void load_pair(const double* src)
     {
+        if constexpr (BIG) {
+            use_images(src, src + stride);
+            return;
+        }
         __syncthreads();                                   // every wave is done with the previous pair
         unsigned lo;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lo));
@@ -143,6 +175,7 @@ struct CoopImr {
 // dynamic LDS of the cooperative implicit-midpoint kernels (bytes)
 __host__ __device__ inline size_t coop_imr_lds_bytes(int NT, long long stride)
 {
+    if (NT > 6) stride = 0;      // (BIG: no operator slots)
     return (size_t)2 * stride * 8 + (size_t)32 * NT * 8 + (size_t)2 * (4 * NT * 64) * 8 + (size_t)2 * NT * 64 * 8;
 }
 
@@ -238,21 +271,7 @@ __global__ __launch_bounds__(64 * NT) void k_backward_coop_imr(PropArgs a)
         const d4 smu = lr + lrs, snu = li + lis;
         for (int q = 0; q < Nc; ++q) {
             // the two slots now take (Hsym_q, Hanti_q): a.cimg = [Hsym_0.. | Hanti_0..] -> two separate fetches
-            __syncthreads();
-            {
-                unsigned lo;
-                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lo));
-                const char* s0 = (const char*)(a.cimg + (size_t)q * a.stride) + lo * 16u;
-                const char* s1 = (const char*)(a.cimg + (size_t)(Nc + q) * a.stride) + lo * 16u;
-                for (int p = wave; p < a.pieces; p += NT) {
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s0 + (size_t)p * 1024),
-                                                     (__attribute__((address_space(3))) void*)(smem + p * 1024), 16, 0, 0);
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s1 + (size_t)p * 1024),
-                                                     (__attribute__((address_space(3))) void*)(smem + a.stride * 8 + p * 1024), 16, 0, 0);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-            }
+            m.use_images(a.cimg + (size_t)q * a.stride, a.cimg + (size_t)(Nc + q) * a.stride);
             m.pub(sv);
             const double B = -dot4(smu, m.mulK());       // slot 0 holds Hsym_q
             const double D = dot4(snu, m.mulS());        // slot 1 holds Hanti_q

@@ -621,6 +621,10 @@ static int create_impl(const jq_problem* p, jq_handle* h)
             if (atoi(e) != 0) bw = h->NT - 1;
         h->BW = (bw <= 2 && bw < h->NT - 1) ? bw : h->NT - 1;
         if (h->big && h->BW == 0) h->BW = 1;      // (the big variants are instantiated for block bands 1, 2 and dense)
+        // dense at this size = band code 15 (a full window for every NT <= 16): NT - 1 = 7, 8, 9 are the codes of the quad-layout,
+        // JQ_BW_T4 and JQ_BW_OD structures -- round 2 instantiated <10, 9> as "dense" and got the JQ_BW_OD product (wrong results
+        // for dense operators with Ntot 145 .. 160; found by the round-3 tests)
+        if (h->big && h->BW > 2) h->BW = 15;
         h->BWc = h->BW;
         // block tridiagonal with DIAGONAL off-diagonal blocks (operators of the slowest subsystem, cnot3):
         // MFMA only for the diagonal blocks, 16 coefficients per off-diagonal block (JQ_OD=0 disables)
@@ -662,6 +666,10 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         const long long park_bytes = (long long)JQ_WAVES * h->KT * 64 * 8;
         if (h->big) {
             h->mat_elems = 128;       // (no slab-kernel images: placeholders)
+            // Only the cooperative kernels (band BWc) exist at this size.  BW must not keep a dense band NT - 1 that happens to
+            // equal one of the structure codes (NT = 8, 9, 10: 7 = JQ_BW_T4Q, 8 = JQ_BW_T4, 9 = JQ_BW_OD) -- round 2 sent dense
+            // problems with Ntot 113 .. 160 to kernel families that do not exist for them (found by the round-3 tests)
+            h->BW = -1;
         } else if (2 * slot + lds_fwd_fixed > 163840)
             return fail(h, JQ_EUNSUPPORTED, "jq_create: operator images do not fit the LDS double buffer");
         h->nslots = 2;
@@ -1037,7 +1045,6 @@ extern "C" int jq_set_integrator(jq_handle* h, int32_t integrator_id, int32_t ma
     }
     if (integrator_id != 2) return fail(h, JQ_EUNSUPPORTED, "jq_set_integrator: 1 = Stormer-Verlet, 2 = implicit midpoint");
     if (max_iter < 1 || !(tol > 0.0)) return fail(h, JQ_EINVAL, "jq_set_integrator: implicit midpoint needs max_iter >= 1 and tol > 0");
-    if (h->big) return fail(h, JQ_EUNSUPPORTED, "jq_set_integrator: the implicit-midpoint path is implemented for Ntot <= 96");
     if (h->parts > 1)
         return fail(h, JQ_EUNSUPPORTED, "jq_set_integrator: the implicit-midpoint path is implemented for N <= 16 (its solver's "
                                         "per-evaluation convergence test needs all columns of a sample in one workgroup)");
@@ -1122,7 +1129,7 @@ extern "C" int jq_update_hconst(jq_handle* h, const double* Hconst)
     // reference lets scripts mutate params.Hconst arbitrarily: a drift with entries outside that structure (or any new drift
     // after such a re-plan, which may have the structure back) re-plans the handle in place -- same pointer, same settings.
     if (h->replanned || ((h->BW == JQ_BW_T4) ? !t4_structure(Hconst, h->Ntot)
-        : (h->BW == JQ_BW_OD) ? !offdiag_blocks_diagonal(Hconst, h->Ntot) : block_band(Hconst, h->Ntot) > h->BW))
+        : (h->BW == JQ_BW_OD) ? !offdiag_blocks_diagonal(Hconst, h->Ntot) : block_band(Hconst, h->Ntot) > (h->big ? h->BWc : h->BW)))
         return replan(h, Hconst);
     h->Hconst.assign(Hconst, Hconst + (size_t)h->Ntot * h->Ntot);
     if (h->emb) {
@@ -1276,11 +1283,12 @@ static int select_quad_kernels(jq_handle* h, int spw, prop_kernel_t* fwd, prop_k
     X(2, 0) X(2, 1) X(3, 0) X(3, 1) X(3, 2) X(4, 0) X(4, 1) X(4, 2) X(4, 3) X(5, 0) X(5, 1) X(5, 2) X(5, 4) \
     X(6, 0) X(6, 1) X(6, 2) X(6, 5) X(2, 9) X(3, 9) X(4, 9) X(5, 9) X(6, 9)
 JQ_FOR_EACH_COOP(JQ_DECLC)
-// Ntot > 96 (NT = 7 .. 16): block band 1, 2 or dense; operators read from HBM (jq_coop_kernels.h OpCursor)
+// Ntot > 96 (NT = 7 .. 16): block band 1, 2 or dense (band code 15 for every NT: a full window); operators read from HBM
+// (jq_coop_kernels.h OpCursor)
 #define JQ_FOR_EACH_BIG(X)                                                                                   \
-    X(7, 1) X(7, 2) X(7, 6) X(8, 1) X(8, 2) X(8, 7) X(9, 1) X(9, 2) X(9, 8) X(10, 1) X(10, 2) X(10, 9)      \
-    X(11, 1) X(11, 2) X(11, 10) X(12, 1) X(12, 2) X(12, 11) X(13, 1) X(13, 2) X(13, 12) X(14, 1) X(14, 2)   \
-    X(14, 13) X(15, 1) X(15, 2) X(15, 14) X(16, 1) X(16, 2) X(16, 15)
+    X(7, 1) X(7, 2) X(7, 15) X(8, 1) X(8, 2) X(8, 15) X(9, 1) X(9, 2) X(9, 15) X(10, 1) X(10, 2) X(10, 15)  \
+    X(11, 1) X(11, 2) X(11, 15) X(12, 1) X(12, 2) X(12, 15) X(13, 1) X(13, 2) X(13, 15) X(14, 1) X(14, 2)   \
+    X(14, 15) X(15, 1) X(15, 2) X(15, 15) X(16, 1) X(16, 2) X(16, 15)
 JQ_FOR_EACH_BIG(JQ_DECLC)
 #undef JQ_DECLC
 
@@ -1369,6 +1377,7 @@ static int select_rowlane_imr_kernels(jq_handle* h, prop_kernel_t* fwd, prop_ker
     extern template __global__ void k_forward_coop_imr<nt, bw>(PropArgs);     \
     extern template __global__ void k_backward_coop_imr<nt, bw>(PropArgs);
 JQ_FOR_EACH_COOP(JQ_DECLCI)
+JQ_FOR_EACH_BIG(JQ_DECLCI)      // (Ntot > 96: operators read from HBM / L2 per product)
 JQ_DECLCI(1, 0)      // (Ntot <= 16 with N > 4: one wave per slab, the evaluation's columns in one wave)
 #undef JQ_DECLCI
 
@@ -1381,6 +1390,7 @@ static int select_coop_imr_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel
         return JQ_OK;                          \
     }
     JQ_FOR_EACH_COOP(JQ_PICKCI)
+    JQ_FOR_EACH_BIG(JQ_PICKCI)
     JQ_PICKCI(1, 0)
 #undef JQ_PICKCI
     return fail(h, JQ_EUNSUPPORTED, "no cooperative implicit-midpoint kernel for this Hilbert dimension / band width");

@@ -21,7 +21,7 @@ def run(n_cases=50, seed=1, verbose=True):
     case = -1
     while compared < n_cases and case + 1 < 2 * n_cases:     # draws without kernels (JQ_EUNSUPPORTED) are replaced, not counted
         case += 1
-        Ntot = int(rng.choice([2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 14, 16, 17, 20, 31, 32, 33, 40, 48, 50, 63, 64, 65, 80, 81, 95, 96, 100, 112, 128]))
+        Ntot = int(rng.choice([2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 14, 16, 17, 20, 31, 32, 33, 40, 48, 50, 63, 64, 65, 80, 81, 95, 96, 100, 112, 128, 150, 200]))
         N = int(rng.integers(1, min(Ntot, 16) + 1))
         Nc = int(rng.integers(1, 5)) if rng.random() < 0.75 else int(rng.integers(5, 10))      # (round 3: control groups)
         Nfreq = int(rng.integers(1, 4))
@@ -31,8 +31,8 @@ def run(n_cases=50, seed=1, verbose=True):
         structure = rng.choice([False, True, "od", "t4", "t4"]) if Ntot > 16 else rng.choice([False, True, "t4"])
         structure = structure if isinstance(structure, str) else bool(structure)
         imr = bool(rng.random() < 0.3) and (Ntot <= 16 or structure is not False)
-        if Ntot > 96:      # 4 x 4 x 7 / 4 x 4 x 8 on the NT = 7, 8 instantiations; anything else at this size: cooperative kernels, Stormer-Verlet
-            imr = imr and structure == "t4" and N in (1, 2, 4)
+        if Ntot > 96:      # 4 x 4 x 7 / 4 x 4 x 8 on the NT = 7, 8 instantiations (N = 1, 2, 4); anything else at this size: cooperative kernels
+            imr = imr and (structure != "t4" or N in (1, 2, 4))
         if os.environ.get("FUZZ_FOCUS") == "imr_cq":      # the cooperative-quad implicit-midpoint kernels: 4 x 4 x n structure, N = 4
             Ntot, N, structure, imr = int(rng.choice([32, 48, 64, 80, 96])), 4, "t4", True
         env = {}

@@ -115,7 +115,10 @@ def test_imr_is_refused_where_it_is_not_implemented(jq):
                                  (48, 4, 2, 1, 5, "od"), (96, 4, 3, 1, 4, "od"), (32, 1, 2, 1, 6, "t4"), (48, 2, 3, 2, 5, "t4"),
                                  (64, 4, 3, 1, 5, "t4"), (96, 4, 3, 1, 4, "t4"), (80, 3, 2, 1, 4, "t4"), (96, 4, 3, 1, 4, "t4q"),
                                  (48, 4, 4, 2, 7, "t4"), (16, 16, 1, 1, 5, 1), (9, 9, 2, 2, 7, 2), (12, 5, 3, 1, 6, 3), (6, 6, 1, 1, 9, 1),
-                                 (16, 7, 2, 1, 6, "t4"), (112, 4, 3, 1, 4, "t4"), (128, 2, 2, 1, 4, "t4")],
+                                 (16, 7, 2, 1, 6, "t4"), (112, 4, 3, 1, 4, "t4"), (128, 2, 2, 1, 4, "t4"),
+                                 # Ntot > 96 without the 4 x 4 x n structure (round 3): cooperative kernels, images from HBM / L2
+                                 (100, 3, 2, 1, 4, "band"), (130, 4, 1, 1, 3, 1), (160, 5, 2, 1, 3, "band"), (200, 16, 1, 1, 3, "band"),
+                                 (256, 2, 1, 1, 2, 3), (112, 3, 2, 1, 3, "od")],
                          ids=lambda c: "Ntot%d_N%d_Nc%d_f%d_o%s" % (c[0], c[1], c[2], c[3], c[5]))
 def test_imr_random_problems_match_oracle(jq, cfg):
     """Sizes and paddings the reference cases do not reach: every row-lane instantiation (NPJ 2..16), N = 1..4 columns

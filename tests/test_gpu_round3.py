@@ -435,3 +435,33 @@ def test_hconst_update_outside_the_planned_structure_replans(hip, structure, Nto
     t2 = check()
     assert (t2["kernel_family"], t2["kernel_band"]) == (t0["kernel_family"], t0["kernel_band"])
     wa.close()
+
+
+@pytest.mark.parametrize("Ntot", [120, 130, 150])
+def test_dense_operators_beyond_96_levels_whose_band_equals_a_structure_code(hip, Ntot):
+    """Dense operators with NT = 8, 9, 10 tile rows: their block band NT - 1 = 7, 8, 9 equals the codes of the quad-layout /
+    JQ_BW_T4 / JQ_BW_OD structures.  Round 2 mistook such handles for structured ones: kernel families that do not exist at this
+    size (JQ_EUNSUPPORTED at NT = 9) and, at NT = 10, the JQ_BW_OD product for a dense matrix (WRONG results, Ntot 145 .. 160).
+    Dense is band code 15 at every NT > 6 now; both integrators against the oracle."""
+    from oracle.oracle import Oracle
+    from test_gpu_random import random_problem
+    jq = hip
+    p, pcof = random_problem(jq, np.random.default_rng(900 + Ntot), Ntot, 3, 2, 1, 4, 2, 3, False)
+    wa = jq.Working_Arrays_HIP(p, pcof.size)
+    r = Oracle(p, use_sparse=False).traceobjgrad(pcof)
+    objfv, tg, prim, sec, tinf, ig, lg = jq.traceobjgrad(pcof, p, wa, False, True)
+    assert wa.last_timing()["kernel_family"] == 1 and wa.last_timing()["kernel_band"] == 15      # (dense at this size: band code 15)
+    gn = np.linalg.norm(r["totalgrad"])
+    assert abs(prim - r["primaryobjf"]) <= 1e-9 and np.linalg.norm(tg - r["totalgrad"]) <= 1e-9 * gn
+    assert np.linalg.norm(lg - r["leakgrad"]) <= 1e-9 * gn
+    wa.close()
+    p.Integrator_id = jq.Implicit_Midpoint
+    p.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER_M, max_iter=60, tol=1e-11, nrhs=3)
+    p.wmat = p.wmat_real.copy()
+    wm = jq.Working_Arrays_M_HIP(p, pcof.size)
+    r = Oracle(p, use_sparse=False).traceobjgrad_imr(pcof, 60, 1e-11)
+    objfv, tg, prim, sec, tinf, ig, lg = jq.traceobjgrad(pcof, p, wm, False, True)
+    assert wm.last_timing()["kernel_family"] == 5
+    gn = np.linalg.norm(r["totalgrad"])
+    assert abs(prim - r["primaryobjf"]) <= 1e-9 and np.linalg.norm(tg - r["totalgrad"]) <= 1e-9 * gn
+    wm.close()
