@@ -169,9 +169,10 @@ int jq_set_linear_solver(jq_handle *h, int32_t solver_id, int32_t max_iter, doub
  * (traceobjgrad for Working_Arrays_M, src/evalobjgrad.jl:1042-1481) with the fixed-point solver
  * lsolver_object(solver=JACOBI_SOLVER_M, max_iter, tol) (src/linear_solvers.jl:52-55, :156-270).  For integrator 2 the
  * leakage weights are params.wmat (pass them with jq_update_wmat_diag).  Implemented for N <= 16 columns per evaluation:
- * row-lane kernels (Ntot <= 16, N <= 4), cooperative MFMA kernels (any batch size; Ntot <= 96: both images of a step resident in
- * LDS -- dense 96 x 96 operators do not fit; Ntot 97 .. 256: images read from HBM / L2 per product), quad-layout and
- * cooperative-quad kernels for the 4 x 4 x n structure; JQ_EUNSUPPORTED otherwise. */
+ * row-lane kernels (Ntot <= 16, N <= 4), cooperative MFMA kernels (any Ntot <= 256 and batch size; both images of a step resident
+ * in LDS when they fit, else -- dense 96 x 96, Ntot > 96 -- read from HBM / L2 per product), quad-layout and cooperative-quad
+ * kernels for the 4 x 4 x n structure with N = 1, 2, 4.  JQ_EUNSUPPORTED only for N > 16 (the solver's per-evaluation stopping
+ * rule needs an evaluation's columns in one workgroup). */
 int jq_set_integrator(jq_handle *h, int32_t integrator_id, int32_t max_iter, double tol);
 /* change_target!(params, new_Utarget) (src/evalobjgrad.jl:1492) */
 int jq_update_target(jq_handle *h, const double *Utarget_r, const double *Utarget_i);

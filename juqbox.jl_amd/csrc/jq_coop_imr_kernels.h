@@ -19,10 +19,9 @@
 #pragma once
 #include "jq_coop_kernels.h"
 
-template <int NT, int BW>
+template <int NT, int BW, bool BIG = (NT > 6)>
 struct CoopImr {
-    static constexpr bool BIG = (NT > 6);
-    Coop<NT, BW> c;          // exchange buffers + product (c.M is pointed at the wanted image by hand; its ring is unused)
+    Coop<NT, BW, BIG> c;     // exchange buffers + product (c.M is pointed at the wanted image by hand; its ring is unused)
     char* smem;
     const double* stream;
     const double* cimg;
@@ -175,11 +174,11 @@ struct CoopImr {
 // dynamic LDS of the cooperative implicit-midpoint kernels (bytes)
 __host__ __device__ inline size_t coop_imr_lds_bytes(int NT, long long stride)
 {
-    if (NT > 6) stride = 0;      // (BIG: no operator slots)
+    if (NT > 6) stride = 0;      // (images from HBM: no operator slots; the caller passes 0 for the <6, 5, true> variant as well)
     return (size_t)2 * stride * 8 + (size_t)32 * NT * 8 + (size_t)2 * (4 * NT * 64) * 8 + (size_t)2 * NT * 64 * 8;
 }
 
-template <int NT, int BW>
+template <int NT, int BW, bool HBM = (NT > 6)>
 __global__ __launch_bounds__(64 * NT) void k_forward_coop_imr(PropArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -190,7 +189,7 @@ __global__ __launch_bounds__(64 * NT) void k_forward_coop_imr(PropArgs a)
     const int slab = blockIdx.x;
     double* tab = (double*)(smem + a.lds_tab_off);
     for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[(i & ~15) + 4 * (i & 3) + ((i >> 2) & 3)] = a.tabs[i];   // [block][g][r]
-    CoopImr<NT, BW> m;
+    CoopImr<NT, BW, HBM> m;
     m.setup(smem, a, wave, lane);
     __syncthreads();
     const d4 wdr = rows4(tab, wave, g), wsr = rows4(tab + 16 * NT, wave, g);
@@ -232,7 +231,7 @@ __global__ __launch_bounds__(64 * NT) void k_forward_coop_imr(PropArgs a)
 
 // Backward sweep (src/evalobjgrad.jl:1290-1336); trace records per wave as in k_backward_coop, in the slots of the
 // midpoint weights of k_gradacc (jq_rowlane_imr_kernels.h): tr[3] = -(B + C)/4, tr[4] = (A + D)/4.
-template <int NT, int BW>
+template <int NT, int BW, bool HBM = (NT > 6)>
 __global__ __launch_bounds__(64 * NT) void k_backward_coop_imr(PropArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -244,7 +243,7 @@ __global__ __launch_bounds__(64 * NT) void k_backward_coop_imr(PropArgs a)
     const int Nc = a.Ncoupled;
     double* tab = (double*)(smem + a.lds_tab_off);
     for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[(i & ~15) + 4 * (i & 3) + ((i >> 2) & 3)] = a.tabs[i];   // [block][g][r]
-    CoopImr<NT, BW> m;
+    CoopImr<NT, BW, HBM> m;
     m.setup(smem, a, wave, lane);
     __syncthreads();
     const d4 wdr = rows4(tab, wave, g), wsr = rows4(tab + 16 * NT, wave, g);

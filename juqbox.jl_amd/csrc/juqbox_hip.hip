@@ -60,6 +60,7 @@ struct jq_handle {
     int bw_trace[JQ_MAX_CONTROLS] = {0};
     long long mat_elems = 0;    // doubles per operator image slot ("stride"): band tiles, padded to 1 KiB
     long long mat_elems_c = 0;  // ... in the row-window layout of the cooperative kernels (0: not available)
+    bool coop_ok = false;       // the cooperative Stormer-Verlet kernels fit the LDS (dense 96 x 96: only the implicit-midpoint variant that reads its images from HBM)
     int coop_max_slabs = 256;   // batches with at most this many slabs (= CUs: one workgroup each) use the cooperative kernels
     long long state_stride = 0;
     int nslots = 2;             // LDS ring depth of the forward kernel
@@ -678,10 +679,19 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         // cooperative (row-split) kernels for small batches: NT waves per slab, needs NT >= 2
         // (NT == 1: only the implicit-midpoint kernels are instantiated -- Ntot <= 16 with more than four columns per evaluation)
         h->mat_elems_c = 0;
-        if ((h->NT >= 2 || h->N > 4) && (h->NT <= 6 || h->big)) {      // (NT = 7, 8 with the JQ_BW_T4 structure: no cooperative kernels)
+        if (h->NT > 6) {      // (more than six tile rows: the HBM-operand variants, instantiated for the bands 1, 2 and dense = 15;
+            //  also for the 4 x 4 x 7 / 4 x 4 x 8 structures -- round 3: their fallback when the quad-layout kernels do not apply,
+            //  e.g. implicit midpoint with N = 3)
+            if (h->BWc == 0) h->BWc = 1;
+            if (h->BWc > 2) h->BWc = 15;
+        }
+        if (h->NT >= 2 || h->N > 4) {
             const long long ec = (((long long)h->NT * coop_row_elems(h->NT, h->BWc) + 127) / 128) * 128;
-            const long long lds_c = (h->big ? 0 : 2 * ec * 8) + lds_fwd_fixed + 2LL * h->KT * 64 * 8 + 16LL * h->NT * 8;      // (operator slots, tables, x exchange, Jacobi column norms)
-            if (lds_c <= 163840) h->mat_elems_c = ec;
+            const long long lds_c = (h->NT > 6 ? 0 : 2 * ec * 8) + lds_fwd_fixed + 2LL * h->KT * 64 * 8 + 16LL * h->NT * 8;      // (operator slots, tables, x exchange, Jacobi column norms)
+            h->mat_elems_c = ec;                  // (the images are built whenever the layout exists ...)
+            // (... the Stormer-Verlet kernels need two of them in LDS -- or none: NT > 6; the 4 x 4 x 7 / 4 x 4 x 8 structures keep
+            //  their JQ_BW_T4 slab kernels as the Stormer-Verlet fallback: the cooperative layout serves their implicit-midpoint path)
+            h->coop_ok = lds_c <= 163840 && (h->NT <= 6 || h->big);
         }
         h->coop_max_slabs = prop.multiProcessorCount;   // one cooperative workgroup per CU = one round
         if (const char* e = getenv("JQ_COOP_MAX")) h->coop_max_slabs = atoi(e);
@@ -1373,21 +1383,30 @@ static int select_rowlane_imr_kernels(jq_handle* h, prop_kernel_t* fwd, prop_ker
     return fail(h, JQ_EUNSUPPORTED, "no implicit-midpoint kernel for this Hilbert dimension");
 }
 
-#define JQ_DECLCI(nt, bw)                                                    \
-    extern template __global__ void k_forward_coop_imr<nt, bw>(PropArgs);     \
-    extern template __global__ void k_backward_coop_imr<nt, bw>(PropArgs);
+template <int NT, int BW, bool HBM> __global__ void k_forward_coop_imr(PropArgs);      // jq_coop_imr_kernels.h
+template <int NT, int BW, bool HBM> __global__ void k_backward_coop_imr(PropArgs);
+#define JQ_DECLCI(nt, bw)                                                                 \
+    extern template __global__ void k_forward_coop_imr<nt, bw, (nt > 6)>(PropArgs);       \
+    extern template __global__ void k_backward_coop_imr<nt, bw, (nt > 6)>(PropArgs);
+extern template __global__ void k_forward_coop_imr<6, 5, true>(PropArgs);      // (dense 96 x 96: images from HBM / L2)
+extern template __global__ void k_backward_coop_imr<6, 5, true>(PropArgs);
 JQ_FOR_EACH_COOP(JQ_DECLCI)
 JQ_FOR_EACH_BIG(JQ_DECLCI)      // (Ntot > 96: operators read from HBM / L2 per product)
 JQ_DECLCI(1, 0)      // (Ntot <= 16 with N > 4: one wave per slab, the evaluation's columns in one wave)
 #undef JQ_DECLCI
 
-static int select_coop_imr_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
+static int select_coop_imr_kernels(jq_handle* h, bool hbm, prop_kernel_t* fwd, prop_kernel_t* bwd)
 {
-#define JQ_PICKCI(nt, bw)                      \
-    if (h->NT == nt && h->BWc == bw) {         \
-        *fwd = k_forward_coop_imr<nt, bw>;     \
-        *bwd = k_backward_coop_imr<nt, bw>;    \
-        return JQ_OK;                          \
+    if (hbm) {
+        *fwd = k_forward_coop_imr<6, 5, true>;
+        *bwd = k_backward_coop_imr<6, 5, true>;
+        return JQ_OK;
+    }
+#define JQ_PICKCI(nt, bw)                                 \
+    if (h->NT == nt && h->BWc == bw) {                    \
+        *fwd = k_forward_coop_imr<nt, bw, (nt > 6)>;      \
+        *bwd = k_backward_coop_imr<nt, bw, (nt > 6)>;     \
+        return JQ_OK;                                     \
     }
     JQ_FOR_EACH_COOP(JQ_PICKCI)
     JQ_FOR_EACH_BIG(JQ_PICKCI)
@@ -1530,8 +1549,11 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     // (any batch size: one workgroup per slab, rounds of one workgroup per CU)
     const bool imr_quad = imr && !imr_rl && h->quad_max_slabs > 0 && (h->N == 1 || h->N == 2 || h->N == 4);
     const bool imr_coop = imr && !imr_rl && !imr_quad;
-    if (imr_coop && (h->mat_elems_c == 0 || coop_imr_lds_bytes(h->NT, h->mat_elems_c) > 163840))
-        return fail(h, JQ_EUNSUPPORTED, "implicit midpoint: the operator images of a step do not fit the LDS (dense Ntot = 96)");
+    // (both images of a step resident in LDS when they fit; dense 96 x 96 operators: the <6, 5> instantiation that reads them from
+    //  HBM / L2 per product like the Ntot > 96 variants)
+    const bool imr_hbm = imr_coop && h->NT <= 6 && h->mat_elems_c > 0 && coop_imr_lds_bytes(h->NT, h->mat_elems_c) > 163840;
+    if (imr_coop && (h->mat_elems_c == 0 || (imr_hbm && !(h->NT == 6 && h->BWc == 5))))
+        return fail(h, JQ_EUNSUPPORTED, "implicit midpoint: no kernels for these operators (no cooperative layout / images that do not fit the LDS)");
     const int cpw = imr_rl ? imr_cols_per_wave(h->N) : 4;   // columns per wave of the row-lane kernels
     const bool rl = imr_rl || (!imr && h->rl_npj > 0 && h->solver_id == 1 && ncols_used <= h->rl_max_cols);
     const bool lane = !imr && !rl && h->lane_np > 0 && h->solver_id == 1 && ncols_used >= h->lane_min_cols && ncols_used <= h->lane_max_cols;
@@ -1581,13 +1603,13 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     if (cq) spw = 0;
     const bool quad = spw > 0;
     const bool quad8 = spw > 1;
-    const bool coop = imr_coop || (!cq && !quad && !lane && !rl && h->NT >= 2 && h->mat_elems_c > 0 && (h->solver_id == 1 || h->big) && nslabs <= h->coop_max_slabs);      // (Ntot > 96: also the Jacobi solver)
+    const bool coop = imr_coop || (!cq && !quad && !lane && !rl && h->NT >= 2 && h->coop_ok && (h->solver_id == 1 || h->big) && nslabs <= h->coop_max_slabs);      // (Ntot > 96: also the Jacobi solver)
     prop_kernel_t kfwd, kbwd;
     lane_init_t klinit = nullptr;
     lane_term_t klterm = nullptr;
     int rc = imr_cq ? select_cq_imr_kernels(h, &kfwd, &kbwd)
              : imr_quad ? select_quad_imr_kernels(h, &kfwd, &kbwd)
-             : imr_coop ? select_coop_imr_kernels(h, &kfwd, &kbwd)
+             : imr_coop ? select_coop_imr_kernels(h, imr_hbm, &kfwd, &kbwd)
              : imr_rl ? select_rowlane_imr_kernels(h, &kfwd, &kbwd)
              : rl ? select_rowlane_kernels(h, &kfwd, &kbwd)
              : lane ? select_lane_kernels(h, &kfwd, &kbwd, &klinit, &klterm)
@@ -1699,12 +1721,12 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     // dynamic LDS layout: [operator staging | tables wd, ws | (backward: carry, parking images)]
     // cooperative kernels: [two operator slots | tables wd, ws | two x exchange buffers]
     const int batch = coop ? 0 : (quad || cq) ? -1 : h->batch;
-    const size_t lds_stage = (coop && h->big) ? 0      // operators are read from HBM, no LDS staging
+    const size_t lds_stage = (coop && (h->NT > 6 || imr_hbm)) ? 0      // operators are read from HBM, no LDS staging
                              : batch > 0   ? (size_t)2 * (2 * batch + 1) * 2 * stride * 8 + (size_t)2 * h->NcK * stride * 8
                              : batch < 0 ? (size_t)(2 * JQ_WIN_TPS + 2 * h->NcK) * stride * 8
                                          : (size_t)2 * stride * 8;
     const size_t lds_cq = lds_stage + (size_t)32 * h->NT * 8 + (size_t)6 * (h->NT + 2) * 64 * 8 + (size_t)std::max(2, h->NcK + (h->NcK + 1) / 2) * h->NT * 64 * 8;      // tables, x exchange, trace hand-off / wg-sum scratch (one region)
-    const size_t lds_fwd = (lane || rl) ? 0 : (cq || imr_cq) ? lds_cq : imr_coop ? coop_imr_lds_bytes(h->NT, stride)
+    const size_t lds_fwd = (lane || rl) ? 0 : (cq || imr_cq) ? lds_cq : imr_coop ? coop_imr_lds_bytes(h->NT, imr_hbm ? 0 : stride)
                                            : lds_stage + (size_t)32 * h->NT * 8 + (coop ? (size_t)2 * h->KT * 64 * 8 + (size_t)16 * h->NT * 8 : 0);      // (+ the Jacobi solver's column norms [NT][16])
     const size_t lds_bwd = rl ? (h->rl_npj > 8 ? (size_t)2 * h->NcK * h->rl_stride * 8 : 0) : lane ? 0 : (coop || cq || imr_cq) ? lds_fwd
                                 : imr_quad ? lds_fwd + (size_t)JQ_MAXNC * nthreads * 8 + (size_t)(nthreads / 64) * h->NT * 64 * 8

@@ -118,7 +118,11 @@ def test_imr_is_refused_where_it_is_not_implemented(jq):
                                  (16, 7, 2, 1, 6, "t4"), (112, 4, 3, 1, 4, "t4"), (128, 2, 2, 1, 4, "t4"),
                                  # Ntot > 96 without the 4 x 4 x n structure (round 3): cooperative kernels, images from HBM / L2
                                  (100, 3, 2, 1, 4, "band"), (130, 4, 1, 1, 3, 1), (160, 5, 2, 1, 3, "band"), (200, 16, 1, 1, 3, "band"),
-                                 (256, 2, 1, 1, 2, 3), (112, 3, 2, 1, 3, "od")],
+                                 (256, 2, 1, 1, 2, 3), (112, 3, 2, 1, 3, "od"),
+                                 # dense 96 x 96 (both images of a step do not fit the LDS: the <6, 5> variant that reads them from HBM / L2)
+                                 (96, 4, 2, 1, 4, 1), (90, 7, 1, 1, 3, 2),
+                                 # 4 x 4 x 7 / 4 x 4 x 8 with N = 3, 5 (no quad-layout kernels for these N: cooperative layout, images from HBM / L2)
+                                 (112, 3, 2, 1, 3, "t4"), (128, 5, 1, 1, 3, "t4")],
                          ids=lambda c: "Ntot%d_N%d_Nc%d_f%d_o%s" % (c[0], c[1], c[2], c[3], c[5]))
 def test_imr_random_problems_match_oracle(jq, cfg):
     """Sizes and paddings the reference cases do not reach: every row-lane instantiation (NPJ 2..16), N = 1..4 columns
