@@ -277,15 +277,15 @@ __global__ __launch_bounds__(64 * NT) void k_backward_coop_imr(PropArgs a)
             m.pub(su);
             const double C = dot4(snu, m.mulK());
             const double A = dot4(smu, m.mulS());
-            const double P = wave_sum((B + C) * wgt), Q = wave_sum((A + D) * wgt);
+            const double PQ = wave_sum2((B + C) * wgt, (A + D) * wgt);      // rows 0, 1: P;  rows 2, 3: Q
+            double* tr = trw + (size_t)n * (Nc * JQ_NTR) + q * JQ_NTR;
             if (lane == 0) {
-                double* tr = trw + (size_t)n * (Nc * JQ_NTR) + q * JQ_NTR;
                 tr[0] = 0.0;
                 tr[1] = 0.0;
                 tr[2] = 0.0;
-                tr[3] = -0.25 * P;
-                tr[4] = 0.25 * Q;
+                tr[3] = -0.25 * PQ;
             }
+            if (lane == 32) tr[4] = 0.25 * PQ;
         }
     }
     for (int r = 0; r < 4; ++r) {

@@ -468,11 +468,8 @@ __global__ __launch_bounds__(64 * NT) void k_backward_coop(PropArgs a)
                 else
                     c.next_op();
                 const d4 Tq = c.mm_z();
-                const double t1 = wave_sum(dot4(u, Tq) * wgt), t3 = wave_sum(dot4(un, Tq) * wgt);
-                if (lane == 0) {
-                    trw[(size_t)n * (Nc * JQ_NTR) + q * JQ_NTR + 0] = t1;
-                    trw[(size_t)n * (Nc * JQ_NTR) + q * JQ_NTR + 2] = t3;
-                }
+                const double ts = wave_sum2(dot4(u, Tq) * wgt, dot4(un, Tq) * wgt);      // rows 0, 1: t1;  rows 2, 3: t3
+                if ((lane & 31) == 0) trw[(size_t)n * (Nc * JQ_NTR) + q * JQ_NTR + (lane >> 4)] = ts;
             }
         }
         // use 8: Kn0 -- L = -c K0 X ; use 9: Kn1 -- Q = -c K1 X       (x = X stays published)
@@ -511,20 +508,18 @@ __global__ __launch_bounds__(64 * NT) void k_backward_coop(PropArgs a)
             if (q < Nc) {
                 c.stage(Bq);
                 c.publish_next_op();   // Hanti_q
-                const double t5 = wave_sum(-dot4(v05, c.mm_z()) * wgt);
+                const double t5 = -dot4(v05, c.mm_z()) * wgt;
                 c.stage(X);
                 c.publish_next_op();   // Hsym_q
-                const double t2 = wave_sum(dot4(v05, c.mm_z()) * wgt);
+                const double t2 = dot4(v05, c.mm_z()) * wgt;
                 c.stage(nbn);
                 c.publish();
                 const double p4 = -dot4(un, c.mm_z());
-                const double t4 = wave_sum((p4 + carry[q]) * wgt);
+                // one reduction for the three: row 0: t5, row 1: t2, row 3: t4
+                const double ts = wave_sum4_rows(t5, t2, 0.0, (p4 + carry[q]) * wgt);
                 carry[q] = p4;
-                if (lane == 0) {
-                    trw[(size_t)n * (Nc * JQ_NTR) + q * JQ_NTR + 1] = t2;
-                    trw[(size_t)n * (Nc * JQ_NTR) + q * JQ_NTR + 3] = t4;
-                    trw[(size_t)n * (Nc * JQ_NTR) + q * JQ_NTR + 4] = t5;
-                }
+                if ((lane & 15) == 0 && lane != 32)
+                    trw[(size_t)n * (Nc * JQ_NTR) + q * JQ_NTR + (lane == 0 ? 4 : lane == 16 ? 1 : 3)] = ts;
             }
         }
         u = un;

@@ -834,6 +834,22 @@ __device__ __forceinline__ double wave_sum4(double a, double b, double c, double
     r = row_ror_add<2>(r);
     return row_ror_add<1>(r);
 }
+// the same with the sums of r0 .. r3 in the rows 0 .. 3 (lane 16 r holds the r-th sum): the trace scalars of the latency kernels
+// (round 3: they reduced every scalar with its own wave_sum -- 23 instructions each at the lone-wave issue rate)
+__device__ __forceinline__ double wave_sum4_rows(double r0, double r1, double r2, double r3) { return wave_sum4(r0, r2, r1, r3); }
+// two sums at once: the rows 0, 1 hold the wave total of a, the rows 2, 3 that of b (20 VALU instructions; two wave_sum: 46)
+__device__ __forceinline__ double wave_sum2(double a, double b)
+{
+    row_swap32(a, b);
+    double p = a + b;      // rows 0, 1: a0+a2, a1+a3;  rows 2, 3: b0+b2, b1+b3
+    double q = p;
+    row_swap16(p, q);      // p: [p0 p0 p2 p2], q: [p1 p1 p3 p3]
+    double r = p + q;
+    r = row_ror_add<8>(r);
+    r = row_ror_add<4>(r);
+    r = row_ror_add<2>(r);
+    return row_ror_add<1>(r);
+}
 // ---------------------------------------------------------------------------------------------
 // One entry of the per-step operator schedule: which image the next product group multiplies with.
 //   kind 0/1: K / S of the tile stream at time point 2*n + tp of the chunk;  kind 2: constant image #tp

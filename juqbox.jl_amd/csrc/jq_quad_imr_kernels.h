@@ -25,21 +25,6 @@ __device__ __forceinline__ double quad_sample_sum(double x, int N, int j)
     return r;
 }
 
-// ru, rv summed over the wave at once (N = 4: the 64 lanes are ONE evaluation): after the row swaps the rows 0, 1 of the
-// register hold the wave total of a, the rows 2, 3 that of b (20 VALU instructions; two wave_sum: 46)
-__device__ __forceinline__ double wave_sum2(double a, double b)
-{
-    row_swap32(a, b);
-    double p = a + b;      // rows 0, 1: a0+a2, a1+a3;  rows 2, 3: b0+b2, b1+b3
-    double q = p;
-    row_swap16(p, q);      // p: [p0 p0 p2 p2], q: [p1 p1 p3 p3]
-    double r = p + q;
-    r = row_ror_add<8>(r);
-    r = row_ror_add<4>(r);
-    r = row_ror_add<2>(r);
-    return row_ror_add<1>(r);
-}
-
 // OPREG: the operators of a step live in registers for all its fixed-point iterations (one slab per workgroup, one wave per
 // SIMD: 512 registers); otherwise (two slabs per workgroup, two waves per SIMD: 256 registers) every application re-reads
 // its A operands and coefficient records from the LDS images.
@@ -295,15 +280,15 @@ __global__ __launch_bounds__(256 * SPW) void k_backward_quad_imr(PropArgs a)
             const double C = a_dot(snu, Y);
             mm_z_bw<NT, JQ_BW_T4Q>(Y, Ha, su, bwq);
             const double A = a_dot(smu, Y);
-            const double P = wave_sum((B + C) * wgt), Q = wave_sum((A + D) * wgt);
+            const double PQ = wave_sum2((B + C) * wgt, (A + D) * wgt);      // rows 0, 1: P;  rows 2, 3: Q
+            double* tr = trw + (size_t)n * (Nc * JQ_NTR) + q * JQ_NTR;
             if (lane_ == 0) {
-                double* tr = trw + (size_t)n * (Nc * JQ_NTR) + q * JQ_NTR;
                 tr[0] = 0.0;
                 tr[1] = 0.0;
                 tr[2] = 0.0;
-                tr[3] = -0.25 * P;
-                tr[4] = 0.25 * Q;
+                tr[3] = -0.25 * PQ;
             }
+            if (lane_ == 32) tr[4] = 0.25 * PQ;
         }
     }
     p.drain();

@@ -191,16 +191,15 @@ __global__ __launch_bounds__(64) void k_backward_rowlane_imr(PropArgs a)
                 const double C = snu * rmv<NPJ, true>(0.0, Hs[q], su);
                 const double A = smu * rmv<NPJ, true>(0.0, Ha[q], su);
                 const double D = snu * rmv<NPJ, true>(0.0, Ha[q], sv);
-                const double P = wave_sum((B + C) * wgt);
-                const double Q = wave_sum((A + D) * wgt);
+                const double PQ = wave_sum2((B + C) * wgt, (A + D) * wgt);      // rows 0, 1: P;  rows 2, 3: Q
+                double* tr = trw + (size_t)n * (Nc * JQ_NTR) + q * JQ_NTR;
                 if (lane == 0) {
-                    double* tr = trw + (size_t)n * (Nc * JQ_NTR) + q * JQ_NTR;
                     tr[0] = 0.0;
                     tr[1] = 0.0;
                     tr[2] = 0.0;
-                    tr[3] = -0.25 * P;
-                    tr[4] = 0.25 * Q;
+                    tr[3] = -0.25 * PQ;
                 }
+                if (lane == 32) tr[4] = 0.25 * PQ;
             }
         }
         K = Kn;

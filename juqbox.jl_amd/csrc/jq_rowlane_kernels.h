@@ -247,6 +247,7 @@ __global__ __launch_bounds__(64) void k_backward_rowlane(PropArgs a)
         G = rmv<NPJ, false>(G, o.S1, X);
         G = fma(cfw, un, G);
         // traces (adjoint_grad_calc!, src/evalobjgrad.jl:2581-2618), weighted and summed over the wave
+        double t5p[JQ_MAXNC] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int q = 0; q < JQ_MAXNC; ++q) {
             if (q < Nc) {
@@ -255,22 +256,18 @@ __global__ __launch_bounds__(64) void k_backward_rowlane(PropArgs a)
                     Hs[q] = row_load_lds<NPJ>(lds_c + (size_t)q * a.stride, row);
                 }
                 const double HaX = rmv<NPJ, true>(0.0, Ha[q], X);
-                const double t1 = wave_sum(u * HaX * wgt);
-                const double t3 = wave_sum(un * HaX * wgt);
-                const double t5 = wave_sum(-v05 * rmv<NPJ, true>(0.0, Ha[q], Bq) * wgt);
-                const double t2 = wave_sum(v05 * rmv<NPJ, true>(0.0, Hs[q], X) * wgt);
+                t5p[q] = -v05 * rmv<NPJ, true>(0.0, Ha[q], Bq) * wgt;
+                const double t2 = v05 * rmv<NPJ, true>(0.0, Hs[q], X) * wgt;
                 const double p4 = -un * rmv<NPJ, true>(0.0, Hs[q], nbn);
-                const double t4 = wave_sum((p4 + carry[q]) * wgt);
+                // t1 .. t4 of the control in ONE reduction: lane 16 r holds the sum of the r-th value
+                const double ts = wave_sum4_rows(u * HaX * wgt, t2, un * HaX * wgt, (p4 + carry[q]) * wgt);
                 carry[q] = p4;
-                if (lane == 0) {
-                    double* tr = trw + (size_t)n * (Nc * JQ_NTR) + q * JQ_NTR;
-                    tr[0] = t1;
-                    tr[1] = t2;
-                    tr[2] = t3;
-                    tr[3] = t4;
-                    tr[4] = t5;
-                }
+                if (row == 0) trw[(size_t)n * (Nc * JQ_NTR) + q * JQ_NTR + (lane >> 4)] = ts;
             }
+        }
+        {   // ... and the t5 of all (at most four) controls in one more
+            const double ts = wave_sum4_rows(t5p[0], t5p[1], t5p[2], t5p[3]);
+            if (row == 0 && (lane >> 4) < Nc) trw[(size_t)n * (Nc * JQ_NTR) + (lane >> 4) * JQ_NTR + 4] = ts;
         }
         u = un;
         v = vnew;
