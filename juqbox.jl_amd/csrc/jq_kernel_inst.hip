@@ -46,6 +46,7 @@ template __global__ void k_backward_rowlane_imr<JQ_NT>(PropArgs);
 #include "jq_rowlane_kernels.h"
 template __global__ void k_forward_rowlane<JQ_NT>(PropArgs);
 template __global__ void k_backward_rowlane<JQ_NT>(PropArgs);
+template __global__ void k_backward_rowlane2<JQ_NT>(PropArgs);      // (state and adjoint chain on two waves)
 #elif JQ_VARIANT == 3
 #include "jq_lane_kernels.h"
 template __global__ void k_forward_lane<JQ_NT>(PropArgs);

@@ -283,3 +283,137 @@ __global__ __launch_bounds__(64) void k_backward_rowlane(PropArgs a)
     for (int q = 0; q < JQ_MAXNC; ++q)
         if (q < Nc) st[(size_t)(JQ_ROWLANE_ARRAYS + q) * nw * 64] = carry[q];
 }
+
+// The backward sweep on TWO waves per four columns (round 3): wave 0 re-integrates the state, wave 1 runs the adjoint step and the
+// traces of the same time step -- the adjoint step needs the state step only through u(t_{n+1}), v05 and u(t_n) of its own lanes,
+// which the state wave leaves in a double-buffered LDS record; ONE workgroup barrier per time step keeps the state wave at most
+// one step ahead.  A lone wave issues one instruction every ~11 cycles whatever its kind (probes/dp_rate_probe.hip), so the sweep
+// is bound by the instruction count of its longest chain: 18 + 4 Nc products + the trace reductions instead of 36 + 4 Nc.
+// Same state file, trace records and results as k_backward_rowlane (the arithmetic of each chain is unchanged: bit-identical).
+// Dynamic LDS: [constant images (NPJ > 8) | records 2 x 3 x 64 doubles].
+template <int NPJ>
+__global__ __launch_bounds__(128) void k_backward_rowlane2(PropArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // 0: state chain, 1: adjoint chain
+    const int row = lane & 15;
+    const long long w = blockIdx.x, nw = a.nslabs;
+    const long long col = 4 * w + (lane >> 4);
+    const int Nc = a.Ncoupled;
+    const double wd = a.tabs[row];
+    double* st = a.state + w * 64 + lane;
+    const double sw = 0.5 * a.h * a.colinfo[col] * a.tabs[16 + row];
+    constexpr bool RESIDENT = (NPJ <= 8);
+    extern __shared__ double lds_c[];
+    double* rec = lds_c + (RESIDENT ? 0 : (size_t)2 * Nc * a.stride) + lane;      // [slot][u, v05, un][64]
+    if (!RESIDENT) {
+        for (int i = threadIdx.x; i < 2 * Nc * (int)a.stride; i += 128) {
+            const int im = i / (int)a.stride, e = i - im * (int)a.stride;
+            lds_c[im * (int)a.stride + (e % NPJ) * 16 + e / NPJ] = a.cimg[i];
+        }
+    }
+    __syncthreads();
+    RowOps<NPJ> o, nxt;
+    o.Kn0 = row_load<NPJ>(as_const(a.stream), row);
+    o.S0 = row_load<NPJ>(as_const(a.stream) + a.stride, row);
+    rops_load_half(o, a, 0, row);
+
+    if (role == 0) {
+        // ---- state chain: one step ahead of the adjoint chain at most
+        double u = st[0], v = st[nw * 64];
+        for (int n = 0; n < a.nsteps_chunk; ++n) {
+            rops_load_half(nxt, a, min(n + 1, a.nsteps_chunk - 1), row);
+            double un, v05, vnew;
+            row_state<NPJ>(a, o, sw, u, v, un, v05, vnew);
+            double* r = rec + (n & 1) * 192;
+            r[0] = u;
+            r[64] = v05;
+            r[128] = un;
+            u = un;
+            v = vnew;
+            rops_advance(o, nxt);
+            __syncthreads();      // record n is published (and record n - 1 has been consumed: its slot is the next one written)
+        }
+        st[0] = u;
+        st[nw * 64] = v;
+        return;
+    }
+    // ---- adjoint chain
+    double mu = st[2 * nw * 64], nb = st[3 * nw * 64];
+    const double wgt = a.colinfo[4 * nw + col];
+    const double cfw = (a.forced ? 0.5 * a.h * a.tinv : 0.0) * wd;
+    double carry[JQ_MAXNC];
+    RowMat<NPJ> Hs[JQ_MAXNC], Ha[JQ_MAXNC];
+#pragma unroll
+    for (int q = 0; q < JQ_MAXNC; ++q) {
+        const int qq = min(q, Nc - 1);
+        carry[q] = (q < Nc) ? st[(size_t)(JQ_ROWLANE_ARRAYS + q) * nw * 64] : 0.0;
+        if (RESIDENT || a.first_chunk) Hs[q] = row_load<NPJ>(as_const(a.cimg) + (size_t)qq * a.stride, row);
+        if (RESIDENT) Ha[q] = row_load<NPJ>(as_const(a.cimg) + (size_t)(Nc + qq) * a.stride, row);
+    }
+    double* trw = a.traces + ((size_t)w * a.nsteps_chunk) * (Nc * JQ_NTR);
+    if (a.first_chunk) {
+        const double u0 = st[0];      // (read before the state wave stores: it stores at the end of the chunk only)
+#pragma unroll
+        for (int q = 0; q < JQ_MAXNC; ++q)
+            if (q < Nc) carry[q] = -u0 * rmv<NPJ, true>(0.0, Hs[q], nb);
+    }
+    for (int n = 0; n < a.nsteps_chunk; ++n) {
+        rops_load_half(nxt, a, min(n + 1, a.nsteps_chunk - 1), row);
+        __syncthreads();          // the state wave has published record n
+        const double* r = rec + (n & 1) * 192;
+        const double u = r[0], v05 = r[64], un = r[128];
+        // adjoint step! (src/StormerVerlet.jl:255-303) with nb = -lambda_i, see k_backward
+        double R = rmv<NPJ, true>(0.0, o.Kp05, nb);
+        if (a.use_shift) R = fma(sw, nb, R);
+        R = rmv<NPJ, false>(R, o.S0, mu);
+        R = fma(cfw, u, R);
+        const double X = row_horner<NPJ>(mu + R, R, o.S0, a.m);
+        double L = rmv<NPJ, true>(0.0, o.Kn0, X);
+        if (a.use_shift) L = fma(-sw, X, L);
+        double Qv = rmv<NPJ, true>(0.0, o.Kn1, X);
+        if (a.use_shift) Qv = fma(-sw, X, Qv);
+        {
+            double P = rmv<NPJ, true>(0.0, o.S05, nb);
+            P = fma(-cfw, v05, P);
+            L += P;
+            Qv += P;
+        }
+        Qv = rmv<NPJ, false>(Qv, o.S05, L);
+        const double nbn = row_horner<NPJ>((nb + L) + Qv, Qv, o.S05, a.m);
+        const double Bq = nb + nbn;
+        double G = rmv<NPJ, false>(X, o.Kp05, nbn);
+        if (a.use_shift) G = fma(sw, nbn, G);
+        G = rmv<NPJ, false>(G, o.S1, X);
+        G = fma(cfw, un, G);
+        double t5p[JQ_MAXNC] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < JQ_MAXNC; ++q) {
+            if (q < Nc) {
+                if (!RESIDENT) {
+                    Ha[q] = row_load_lds<NPJ>(lds_c + (size_t)(Nc + q) * a.stride, row);
+                    Hs[q] = row_load_lds<NPJ>(lds_c + (size_t)q * a.stride, row);
+                }
+                const double HaX = rmv<NPJ, true>(0.0, Ha[q], X);
+                t5p[q] = -v05 * rmv<NPJ, true>(0.0, Ha[q], Bq) * wgt;
+                const double t2 = v05 * rmv<NPJ, true>(0.0, Hs[q], X) * wgt;
+                const double p4 = -un * rmv<NPJ, true>(0.0, Hs[q], nbn);
+                const double ts = wave_sum4_rows(u * HaX * wgt, t2, un * HaX * wgt, (p4 + carry[q]) * wgt);
+                carry[q] = p4;
+                if (row == 0) trw[(size_t)n * (Nc * JQ_NTR) + q * JQ_NTR + (lane >> 4)] = ts;
+            }
+        }
+        {
+            const double ts = wave_sum4_rows(t5p[0], t5p[1], t5p[2], t5p[3]);
+            if (row == 0 && (lane >> 4) < Nc) trw[(size_t)n * (Nc * JQ_NTR) + (lane >> 4) * JQ_NTR + 4] = ts;
+        }
+        mu = G;
+        nb = nbn;
+        rops_advance(o, nxt);
+    }
+    st[2 * nw * 64] = mu;
+    st[3 * nw * 64] = nb;
+#pragma unroll
+    for (int q = 0; q < JQ_MAXNC; ++q)
+        if (q < Nc) st[(size_t)(JQ_ROWLANE_ARRAYS + q) * nw * 64] = carry[q];
+}

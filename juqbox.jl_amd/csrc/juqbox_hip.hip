@@ -1347,17 +1347,18 @@ static int select_lane_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* 
 #define JQ_FOR_EACH_ROWLANE(X) X(2) X(4) X(6) X(8) X(12) X(16)
 #define JQ_DECLR(npj)                                                     \
     extern template __global__ void k_forward_rowlane<npj>(PropArgs);     \
-    extern template __global__ void k_backward_rowlane<npj>(PropArgs);
+    extern template __global__ void k_backward_rowlane<npj>(PropArgs);    \
+    extern template __global__ void k_backward_rowlane2<npj>(PropArgs);
 JQ_FOR_EACH_ROWLANE(JQ_DECLR)
 #undef JQ_DECLR
 
-static int select_rowlane_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
+static int select_rowlane_kernels(jq_handle* h, bool split, prop_kernel_t* fwd, prop_kernel_t* bwd)
 {
-#define JQ_PICKR(npj)                     \
-    if (h->rl_npj == npj) {               \
-        *fwd = k_forward_rowlane<npj>;    \
-        *bwd = k_backward_rowlane<npj>;   \
-        return JQ_OK;                     \
+#define JQ_PICKR(npj)                                                          \
+    if (h->rl_npj == npj) {                                                    \
+        *fwd = k_forward_rowlane<npj>;                                         \
+        *bwd = split ? k_backward_rowlane2<npj> : k_backward_rowlane<npj>;     \
+        return JQ_OK;                                                          \
     }
     JQ_FOR_EACH_ROWLANE(JQ_PICKR)
 #undef JQ_PICKR
@@ -1604,6 +1605,11 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     const bool quad = spw > 0;
     const bool quad8 = spw > 1;
     const bool coop = imr_coop || (!cq && !quad && !lane && !rl && h->NT >= 2 && h->coop_ok && (h->solver_id == 1 || h->big) && nslabs <= h->coop_max_slabs);      // (Ntot > 96: also the Jacobi solver)
+    // row-lane kernels, Stormer-Verlet: the backward sweep's two chains on two waves (jq_rowlane_kernels.h k_backward_rowlane2);
+    // JQ_RL_SPLIT=0: one wave (tests: the two variants must agree bit for bit)
+    bool rl_split = rl && !imr;
+    if (const char* e = getenv("JQ_RL_SPLIT"))
+        if (atoi(e) == 0) rl_split = false;
     prop_kernel_t kfwd, kbwd;
     lane_init_t klinit = nullptr;
     lane_term_t klterm = nullptr;
@@ -1611,7 +1617,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
              : imr_quad ? select_quad_imr_kernels(h, &kfwd, &kbwd)
              : imr_coop ? select_coop_imr_kernels(h, imr_hbm, &kfwd, &kbwd)
              : imr_rl ? select_rowlane_imr_kernels(h, &kfwd, &kbwd)
-             : rl ? select_rowlane_kernels(h, &kfwd, &kbwd)
+             : rl ? select_rowlane_kernels(h, rl_split, &kfwd, &kbwd)
              : lane ? select_lane_kernels(h, &kfwd, &kbwd, &klinit, &klterm)
                   : cq ? select_cq_kernels(h, &kfwd, &kbwd)
                   : coop ? select_coop_kernels(h, &kfwd, &kbwd) : quad ? select_quad_kernels(h, spw, &kfwd, &kbwd) : select_kernels(h, &kfwd, &kbwd);
@@ -1728,7 +1734,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     const size_t lds_cq = lds_stage + (size_t)32 * h->NT * 8 + (size_t)6 * (h->NT + 2) * 64 * 8 + (size_t)std::max(2, h->NcK + (h->NcK + 1) / 2) * h->NT * 64 * 8;      // tables, x exchange, trace hand-off / wg-sum scratch (one region)
     const size_t lds_fwd = (lane || rl) ? 0 : (cq || imr_cq) ? lds_cq : imr_coop ? coop_imr_lds_bytes(h->NT, imr_hbm ? 0 : stride)
                                            : lds_stage + (size_t)32 * h->NT * 8 + (coop ? (size_t)2 * h->KT * 64 * 8 + (size_t)16 * h->NT * 8 : 0);      // (+ the Jacobi solver's column norms [NT][16])
-    const size_t lds_bwd = rl ? (h->rl_npj > 8 ? (size_t)2 * h->NcK * h->rl_stride * 8 : 0) : lane ? 0 : (coop || cq || imr_cq) ? lds_fwd
+    const size_t lds_bwd = rl ? (h->rl_npj > 8 ? (size_t)2 * h->NcK * h->rl_stride * 8 : 0) + (rl_split ? (size_t)2 * 3 * 64 * 8 : 0) : lane ? 0 : (coop || cq || imr_cq) ? lds_fwd
                                 : imr_quad ? lds_fwd + (size_t)JQ_MAXNC * nthreads * 8 + (size_t)(nthreads / 64) * h->NT * 64 * 8
                                 : quad ? lds_stage + (size_t)bwd_lds_tail(h->NT, h->NcK, nthreads / 64, (long long)h->NT * 64)   // (a 16-row block per register)
                                 : lds_stage + (size_t)bwd_lds_tail(h->NT, h->NcK, JQ_WAVES, h->park_lds ? (long long)h->KT * 64 : 0);
@@ -1862,7 +1868,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
                     }
                 }
                 HIPCHK(h, hipEventRecord(h->ev[evi++], s));
-                hipLaunchKernelGGL(kbwd, dim3(nblocks), dim3(cq ? 2 * nthreads : imr_cq ? nthreads + 128 : nthreads), lds_bwd, s, a);      // (cooperative quad: state and adjoint chain on separate waves)
+                hipLaunchKernelGGL(kbwd, dim3(nblocks), dim3((cq || rl_split) ? 2 * nthreads : imr_cq ? nthreads + 128 : nthreads), lds_bwd, s, a);      // (cooperative quad: state and adjoint chain on separate waves)
                 HIPCHK(h, hipEventRecord(h->ev[evi++], s));
                 hipLaunchKernelGGL(k_trace_reduce, dim3((unsigned)(((long long)nc * ntr_g + 255) / 256)), dim3(256), 0, s,
                                    h->d_traces, trace_rows, nc, ntr_g, h->d_R);

@@ -465,3 +465,31 @@ def test_dense_operators_beyond_96_levels_whose_band_equals_a_structure_code(hip
     gn = np.linalg.norm(r["totalgrad"])
     assert abs(prim - r["primaryobjf"]) <= 1e-9 and np.linalg.norm(tg - r["totalgrad"]) <= 1e-9 * gn
     wm.close()
+
+
+@pytest.mark.parametrize("case", ["swap02", "cnot2-leakieq", "flux"])
+def test_rowlane_backward_sweep_on_two_waves_equals_the_one_wave_kernel(hip, case):
+    """k_backward_rowlane2 (state chain and adjoint chain of the backward sweep on two waves, one barrier per time step) against
+    k_backward_rowlane (JQ_RL_SPLIT=0): each chain's arithmetic is the same instruction sequence, so objective and gradients agree
+    to the last bits (1e-14); single evaluations and a ragged ensemble; the golden through the default (two-wave) kernel."""
+    jq = hip
+    params, info, pcof, golden = case_inputs(case)
+    res = {}
+    for tag in ("split", "one"):
+        if tag == "one":
+            os.environ["JQ_RL_SPLIT"] = "0"
+        try:
+            wa = jq.Working_Arrays_HIP(params, pcof.size)
+            o = jq.traceobjgrad(pcof, params, wa, False, True)
+            assert wa.last_timing()["kernel_family"] == 3
+            nodes, weights, shift = _ensemble(params, 7, seed=3)
+            jq.eval_f_g_grad(pcof, params, wa, nodes, weights, True, shift=shift)
+            res[tag] = (o, params.last_infidelity, params.last_leak, params.last_infidelity_grad.copy(), params.last_leak_grad.copy())
+            wa.close()
+        finally:
+            os.environ.pop("JQ_RL_SPLIT", None)
+    a, b = res["split"], res["one"]
+    assert a[0][0] == b[0][0]                                  # (the forward sweep is the same kernel)
+    for k in (1, 5, 6):
+        assert rel(a[0][k], b[0][k]) < 1e-14 or not np.any(b[0][k])
+    assert a[1] == b[1] and a[2] == b[2] and rel(a[3], b[3]) < 1e-14
