@@ -42,6 +42,7 @@ template __global__ void k_backward_coop_imr<6, 5, true>(PropArgs);
 #include "jq_rowlane_imr_kernels.h"
 template __global__ void k_forward_rowlane_imr<JQ_NT>(PropArgs);
 template __global__ void k_backward_rowlane_imr<JQ_NT>(PropArgs);
+template __global__ void k_backward_rowlane_imr2<JQ_NT>(PropArgs);      // (state and adjoint chain on two waves)
 #elif JQ_VARIANT == 4
 #include "jq_rowlane_kernels.h"
 template __global__ void k_forward_rowlane<JQ_NT>(PropArgs);

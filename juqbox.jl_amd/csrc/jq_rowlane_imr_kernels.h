@@ -57,6 +57,27 @@ __device__ __forceinline__ void imr_solve(const PropArgs& a, const RowMat<NPJ>& 
     };
     double cu, cv;
     apply(xu, xv, cu, cv);                      // x_1
+    if (a.N >= 3) {
+        // ONE evaluation per wave (N = 4: all four 16-lane rows, N = 3: three of them, the idle row holds zeros): the stopping
+        // decision is wave-uniform, both norms come out of one reduction (wave_sum2: rows 0, 1 hold ru, rows 2, 3 rv; two
+        // sample_sum: ~60 instructions against the ~32 of the four products), the iterates alternate between two register pairs
+        for (int it = 1;; it += 2) {
+            double nu, nv;
+            apply(cu, cv, nu, nv);              // x_{it+1};  residual at x_it = x_it - x_{it+1}
+            double du = valid ? cu - nu : 0.0, dv = valid ? cv - nv : 0.0;
+            if (__all(wave_sum2(du * du, dv * dv) < tol2) || it >= a.m) break;      // keeps x_it = (cu, cv)
+            apply(nu, nv, cu, cv);              // x_{it+2}
+            du = valid ? nu - cu : 0.0, dv = valid ? nv - cv : 0.0;
+            if (__all(wave_sum2(du * du, dv * dv) < tol2) || it + 1 >= a.m) {       // keeps x_{it+1}
+                cu = nu;
+                cv = nv;
+                break;
+            }
+        }
+        xu = cu;
+        xv = cv;
+        return;
+    }
     bool done = !valid;
     for (int it = 1; it <= a.m; ++it) {
         double nu, nv;
@@ -207,6 +228,108 @@ __global__ __launch_bounds__(64) void k_backward_rowlane_imr(PropArgs a)
     }
     st[0] = u;
     st[nw * 64] = v;
+    st[2 * nw * 64] = lr;
+    st[3 * nw * 64] = li;
+}
+
+// The backward sweep on TWO waves per wave-load of columns (round 3, like k_backward_rowlane2): wave 0 re-integrates the state
+// (its own fixed-point solves), wave 1 runs the adjoint m_step! and the traces of the same time step; the adjoint step needs the
+// state step only through the step sums su = u + u_s, sv = v + v_s of its own lanes (forcing and traces), left in a double-buffered
+// LDS record under ONE workgroup barrier per time step.  Each chain's arithmetic is unchanged.
+// Dynamic LDS: [constant images (NPJ > 8) | records 2 x 2 x 64 doubles].
+template <int NPJ>
+__global__ __launch_bounds__(128) void k_backward_rowlane_imr2(PropArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // 0: state chain, 1: adjoint chain
+    const int row = lane & 15;
+    const long long w = blockIdx.x, nw = a.nslabs;
+    const int c = lane >> 4, cpw = imr_cols_per_wave(a.N);
+    const bool valid = c < cpw;
+    const long long slot = 4 * w + c;
+    const int Nc = a.Ncoupled;
+    const double wd = a.tabs[row];
+    double* st = a.state + w * 64 + lane;
+    const double sw = 0.5 * a.h * a.colinfo[slot] * a.tabs[16 + row];
+    extern __shared__ double lds_c[];
+    constexpr bool RESIDENT = (NPJ <= 8);
+    double* rec = lds_c + (RESIDENT ? 0 : (size_t)2 * Nc * a.stride) + lane;      // [slot][su, sv][64]
+    if (!RESIDENT) {
+        for (int i = threadIdx.x; i < 2 * Nc * (int)a.stride; i += 128) {
+            const int im = i / (int)a.stride, e = i - im * (int)a.stride;
+            lds_c[im * (int)a.stride + (e % NPJ) * 16 + e / NPJ] = a.cimg[i];
+        }
+    }
+    __syncthreads();
+    cmat_t s0 = as_const(a.stream);
+    RowMat<NPJ> K = row_load<NPJ>(s0 + 2 * a.stride, row), S = row_load<NPJ>(s0 + 3 * a.stride, row);
+    if (role == 0) {
+        double u = st[0], v = st[nw * 64];
+        for (int n = 0; n < a.nsteps_chunk; ++n) {
+            const int nn = min(n + 1, a.nsteps_chunk - 1);
+            const RowMat<NPJ> Kn = row_load<NPJ>(s0 + (size_t)(2 * (2 * nn + 1)) * a.stride, row);
+            const RowMat<NPJ> Sn = row_load<NPJ>(s0 + (size_t)(2 * (2 * nn + 1) + 1) * a.stride, row);
+            const double us = u, vs = v;
+            imr_step<NPJ>(a, K, S, sw, u, v, 0.0, 0.0, c, valid);
+            double* r = rec + (n & 1) * 128;
+            r[0] = u + us;
+            r[64] = v + vs;
+            K = Kn;
+            S = Sn;
+            __syncthreads();      // record n is published (record n - 1 has been consumed)
+        }
+        st[0] = u;
+        st[nw * 64] = v;
+        return;
+    }
+    double lr = st[2 * nw * 64], li = st[3 * nw * 64];
+    const double wgt = a.colinfo[4 * nw + slot];
+    const double cfw = a.forced ? -a.h * a.tinv * wd : 0.0;      // h * (-tinv * W)
+    RowMat<NPJ> Hs[JQ_MAXNC], Ha[JQ_MAXNC];
+#pragma unroll
+    for (int q = 0; q < JQ_MAXNC; ++q) {
+        const int qq = min(q, Nc - 1);
+        if (RESIDENT) {
+            Hs[q] = row_load<NPJ>(as_const(a.cimg) + (size_t)qq * a.stride, row);
+            Ha[q] = row_load<NPJ>(as_const(a.cimg) + (size_t)(Nc + qq) * a.stride, row);
+        }
+    }
+    double* trw = a.traces + ((size_t)w * a.nsteps_chunk) * (Nc * JQ_NTR);
+    for (int n = 0; n < a.nsteps_chunk; ++n) {
+        const int nn = min(n + 1, a.nsteps_chunk - 1);
+        const RowMat<NPJ> Kn = row_load<NPJ>(s0 + (size_t)(2 * (2 * nn + 1)) * a.stride, row);
+        const RowMat<NPJ> Sn = row_load<NPJ>(s0 + (size_t)(2 * (2 * nn + 1) + 1) * a.stride, row);
+        __syncthreads();          // the state wave has published record n
+        const double* r = rec + (n & 1) * 128;
+        const double su = r[0], sv = r[64];
+        const double lrs = lr, lis = li;
+        imr_step<NPJ>(a, K, S, sw, lr, li, cfw * su, cfw * sv, c, valid);
+        const double smu = lr + lrs, snu = li + lis;
+#pragma unroll
+        for (int q = 0; q < JQ_MAXNC; ++q) {
+            if (q < Nc) {
+                if (!RESIDENT) {
+                    Hs[q] = row_load_lds<NPJ>(lds_c + (size_t)q * a.stride, row);
+                    Ha[q] = row_load_lds<NPJ>(lds_c + (size_t)(Nc + q) * a.stride, row);
+                }
+                const double B = -smu * rmv<NPJ, true>(0.0, Hs[q], sv);
+                const double C = snu * rmv<NPJ, true>(0.0, Hs[q], su);
+                const double A = smu * rmv<NPJ, true>(0.0, Ha[q], su);
+                const double D = snu * rmv<NPJ, true>(0.0, Ha[q], sv);
+                const double PQ = wave_sum2((B + C) * wgt, (A + D) * wgt);      // rows 0, 1: P;  rows 2, 3: Q
+                double* tr = trw + (size_t)n * (Nc * JQ_NTR) + q * JQ_NTR;
+                if (lane == 0) {
+                    tr[0] = 0.0;
+                    tr[1] = 0.0;
+                    tr[2] = 0.0;
+                    tr[3] = -0.25 * PQ;
+                }
+                if (lane == 32) tr[4] = 0.25 * PQ;
+            }
+        }
+        K = Kn;
+        S = Sn;
+    }
     st[2 * nw * 64] = lr;
     st[3 * nw * 64] = li;
 }

@@ -1367,17 +1367,18 @@ static int select_rowlane_kernels(jq_handle* h, bool split, prop_kernel_t* fwd, 
 
 #define JQ_DECLM(npj)                                                        \
     extern template __global__ void k_forward_rowlane_imr<npj>(PropArgs);    \
-    extern template __global__ void k_backward_rowlane_imr<npj>(PropArgs);
+    extern template __global__ void k_backward_rowlane_imr<npj>(PropArgs);   \
+    extern template __global__ void k_backward_rowlane_imr2<npj>(PropArgs);
 JQ_FOR_EACH_ROWLANE(JQ_DECLM)
 #undef JQ_DECLM
 
-static int select_rowlane_imr_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
+static int select_rowlane_imr_kernels(jq_handle* h, bool split, prop_kernel_t* fwd, prop_kernel_t* bwd)
 {
-#define JQ_PICKM(npj)                         \
-    if (h->rl_npj == npj) {                   \
-        *fwd = k_forward_rowlane_imr<npj>;    \
-        *bwd = k_backward_rowlane_imr<npj>;   \
-        return JQ_OK;                         \
+#define JQ_PICKM(npj)                                                                  \
+    if (h->rl_npj == npj) {                                                            \
+        *fwd = k_forward_rowlane_imr<npj>;                                             \
+        *bwd = split ? k_backward_rowlane_imr2<npj> : k_backward_rowlane_imr<npj>;     \
+        return JQ_OK;                                                                  \
     }
     JQ_FOR_EACH_ROWLANE(JQ_PICKM)
 #undef JQ_PICKM
@@ -1607,7 +1608,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     const bool coop = imr_coop || (!cq && !quad && !lane && !rl && h->NT >= 2 && h->coop_ok && (h->solver_id == 1 || h->big) && nslabs <= h->coop_max_slabs);      // (Ntot > 96: also the Jacobi solver)
     // row-lane kernels, Stormer-Verlet: the backward sweep's two chains on two waves (jq_rowlane_kernels.h k_backward_rowlane2);
     // JQ_RL_SPLIT=0: one wave (tests: the two variants must agree bit for bit)
-    bool rl_split = rl && !imr;
+    bool rl_split = rl;      // (both integrators)
     if (const char* e = getenv("JQ_RL_SPLIT"))
         if (atoi(e) == 0) rl_split = false;
     prop_kernel_t kfwd, kbwd;
@@ -1616,7 +1617,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     int rc = imr_cq ? select_cq_imr_kernels(h, &kfwd, &kbwd)
              : imr_quad ? select_quad_imr_kernels(h, &kfwd, &kbwd)
              : imr_coop ? select_coop_imr_kernels(h, imr_hbm, &kfwd, &kbwd)
-             : imr_rl ? select_rowlane_imr_kernels(h, &kfwd, &kbwd)
+             : imr_rl ? select_rowlane_imr_kernels(h, rl_split, &kfwd, &kbwd)
              : rl ? select_rowlane_kernels(h, rl_split, &kfwd, &kbwd)
              : lane ? select_lane_kernels(h, &kfwd, &kbwd, &klinit, &klterm)
                   : cq ? select_cq_kernels(h, &kfwd, &kbwd)
@@ -1734,7 +1735,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     const size_t lds_cq = lds_stage + (size_t)32 * h->NT * 8 + (size_t)6 * (h->NT + 2) * 64 * 8 + (size_t)std::max(2, h->NcK + (h->NcK + 1) / 2) * h->NT * 64 * 8;      // tables, x exchange, trace hand-off / wg-sum scratch (one region)
     const size_t lds_fwd = (lane || rl) ? 0 : (cq || imr_cq) ? lds_cq : imr_coop ? coop_imr_lds_bytes(h->NT, imr_hbm ? 0 : stride)
                                            : lds_stage + (size_t)32 * h->NT * 8 + (coop ? (size_t)2 * h->KT * 64 * 8 + (size_t)16 * h->NT * 8 : 0);      // (+ the Jacobi solver's column norms [NT][16])
-    const size_t lds_bwd = rl ? (h->rl_npj > 8 ? (size_t)2 * h->NcK * h->rl_stride * 8 : 0) + (rl_split ? (size_t)2 * 3 * 64 * 8 : 0) : lane ? 0 : (coop || cq || imr_cq) ? lds_fwd
+    const size_t lds_bwd = rl ? (h->rl_npj > 8 ? (size_t)2 * h->NcK * h->rl_stride * 8 : 0) + (rl_split ? (size_t)2 * 3 * 64 * 8 : 0) /* records: 3 values per lane and slot, implicit midpoint 2 */ : lane ? 0 : (coop || cq || imr_cq) ? lds_fwd
                                 : imr_quad ? lds_fwd + (size_t)JQ_MAXNC * nthreads * 8 + (size_t)(nthreads / 64) * h->NT * 64 * 8
                                 : quad ? lds_stage + (size_t)bwd_lds_tail(h->NT, h->NcK, nthreads / 64, (long long)h->NT * 64)   // (a 16-row block per register)
                                 : lds_stage + (size_t)bwd_lds_tail(h->NT, h->NcK, JQ_WAVES, h->park_lds ? (long long)h->KT * 64 : 0);
