@@ -469,6 +469,16 @@ def main():
                     cfgs[cname] = {"Ntot": int(pc.Ntot), "nsteps": int(pc.nsteps), "samples": nq, "ms_per_evaluation": tc["ms_total"],
                                    "svts_per_s": tc["svts"] / (tc["ms_total"] * 1e-3), "kernel_family": tc["kernel_family"]}
                     wc.close()
+                    # the same with the implicit-midpoint integrator (the default of the reference's example scripts)
+                    import copy
+                    pmc_ = copy.copy(pc)
+                    pmc_.Integrator_id = jq.Implicit_Midpoint
+                    pmc_.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER_M, max_iter=100, tol=1e-12, nrhs=pmc_.N)
+                    wmc = jq.Working_Arrays_M_HIP(pmc_, pcf.size)
+                    for _ in range(2):
+                        jq.eval_f_g_grad(pcf, pmc_, wmc, nd, wq, True, shift=shc)
+                    cfgs[cname]["ms_per_evaluation_implicit_midpoint"] = wmc.last_timing()["ms_total"]
+                    wmc.close()
                 out["baseline_configs"] = cfgs
             except Exception as e:  # noqa: BLE001  (never let a side measurement take the bench line down)
                 out["baseline_configs"] = {"error": repr(e)}
