@@ -783,7 +783,7 @@ static int create_impl(const jq_problem* p, jq_handle* h)
         h->rl_stride = 16LL * h->rl_npj;
         // cross-over measured with scripts/time_cases.py: ~2 waves per SIMD against the lane kernels (Ntot <= 8),
         // ~4 against the MFMA slab kernels (Ntot 9..16)
-        h->rl_max_cols = (h->rl_npj > 8 ? 4 : 2) * 4 * 4 * prop.multiProcessorCount;
+        h->rl_max_cols = 2 * 4 * 4 * prop.multiProcessorCount;      // (round 3: also for NPJ = 12, 16 -- cnot2 x 4 096 samples 94 ms here, 61 ms on the MFMA kernels)
         if (const char* e = getenv("JQ_ROWLANE_MAX")) h->rl_max_cols = atoi(e);
         if (const char* e = getenv("JQ_LANE_MIN")) h->lane_min_cols = atoi(e);
         if (const char* e = getenv("JQ_LANE_MAX")) h->lane_max_cols = atoi(e);
@@ -1608,7 +1608,9 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     const bool coop = imr_coop || (!cq && !quad && !lane && !rl && h->NT >= 2 && h->coop_ok && (h->solver_id == 1 || h->big) && nslabs <= h->coop_max_slabs);      // (Ntot > 96: also the Jacobi solver)
     // row-lane kernels, Stormer-Verlet: the backward sweep's two chains on two waves (jq_rowlane_kernels.h k_backward_rowlane2);
     // JQ_RL_SPLIT=0: one wave (tests: the two variants must agree bit for bit)
-    bool rl_split = rl;      // (both integrators)
+    // (both integrators; while the doubled wave count still finds idle issue slots: measured with scripts/time_rl_crossover.py --
+    //  NPJ <= 8: up to three waves per SIMD, NPJ = 12, 16 (constant images in LDS, 24 .. 32 operand registers per image row): one)
+    bool rl_split = rl && 2 * nwaves_rl <= (long long)(h->rl_npj > 8 ? 4 : 12) * h->num_cu;
     if (const char* e = getenv("JQ_RL_SPLIT"))
         if (atoi(e) == 0) rl_split = false;
     prop_kernel_t kfwd, kbwd;
