@@ -1459,7 +1459,12 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     // two rounds 2.35 s).  A batch of q full rounds + a remainder is evaluated as two batches when the plan says that is
     // faster -- the remainder on whatever suits ITS size (3 200 samples: 1.18 + 0.20 s on the cooperative-quad kernels).
     // Samples are independent and the results are sums over samples, so only the order of those sums changes.
-    if (!h->in_split && h->quad_max_slabs > 0 && h->integrator == 1 && h->solver_id == 1 && !hist_r && eps && nsamples > 1 && !getenv("JQ_NOSPLIT")) {
+    // (the cost model is that of the 4 x 4 x n MFMA families: a batch that the row-lane / lane kernels take -- small Hilbert spaces
+    //  with that structure, e.g. SWAP-02 -- must not be split: round 2 did, and paid two latency-bound launches for one)
+    const long long ncols_split = (long long)nsamples * h->N;
+    const bool small_family_batch = (h->rl_npj > 0 && ncols_split <= h->rl_max_cols) ||
+                                    (h->lane_np > 0 && ncols_split >= h->lane_min_cols && ncols_split <= h->lane_max_cols);
+    if (!h->in_split && !small_family_batch && h->quad_max_slabs > 0 && h->integrator == 1 && h->solver_id == 1 && !hist_r && eps && nsamples > 1 && !getenv("JQ_NOSPLIT")) {
         // candidates: the largest number of FULL rounds of the quad-layout kernels with 1, 2 or 3 slabs per workgroup
         long long n_main = 0;
         double best = t4_plan_cost(h, nsamples) - 1e-9;
