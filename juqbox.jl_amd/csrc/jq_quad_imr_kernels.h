@@ -28,6 +28,9 @@ __device__ __forceinline__ double quad_sample_sum(double x, int N, int j)
 // OPREG: the operators of a step live in registers for all its fixed-point iterations (one slab per workgroup, one wave per
 // SIMD: 512 registers); otherwise (two slabs per workgroup, two waves per SIMD: 256 registers) every application re-reads
 // its A operands and coefficient records from the LDS images.
+#ifndef JQ_IMR_CREG      // experiment: coupling-coefficient records of the step's operators in registers (1) or re-read from LDS (0)
+#define JQ_IMR_CREG 1
+#endif
 template <int NT, bool OPREG>
 struct QuadImr {
     const double* K;     // images of the step (LDS, lane offset applied)
@@ -62,10 +65,9 @@ struct QuadImr {
     __device__ __forceinline__ void apply(const Arr<NT>& rhs_u, const Arr<NT>& rhs_v, const Arr<NT>& pu, const Arr<NT>& pv, Arr<NT>& qu,
                                           Arr<NT>& qv) const
     {
-        double uold = 0.0, vold = 0.0;
         const int lane = threadIdx.x & 63;
         const double *Kp = K, *Sp = S;
-        if constexpr (!OPREG) {
+        if constexpr (!OPREG || !JQ_IMR_CREG) {
             // the images do not change between the fixed-point iterations: without this the compiler hoists all 60 operand
             // reads out of the iteration loop -- into registers this variant does not have (184 spilled to scratch)
             // (an opaque ZERO offset, not an opaque pointer: the pointers must stay visibly LDS addresses -- ds_read, not flat loads)
@@ -76,18 +78,29 @@ struct QuadImr {
         }
         const double *maK = t4q_a(Kp, lane), *maS = t4q_a(Sp, lane);
         const d4 *cfK = t4q_c<NT>(Kp, lane), *cfS = t4q_c<NT>(Sp, lane);
+        // pass 1: the four MFMAs of every block (two chains of two per block, the chains of all blocks independent of each other);
+        // pass 2: lane shifts and coupling FMAs.  In ONE pass per block every MFMA result was consumed by the next instruction:
+        // 26 hazard s_nop per application at the lone wave's issue rate (round 3: 321 -> 295 instructions per iteration)
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) {
+            const double xu = pu.t[mt][0], xv = pv.t[mt][0];
+            const double aS = OPREG ? oS.a[mt] : maS[mt * 64], aK = OPREG ? oK.a[mt] : maK[mt * 64];
+            double au = __builtin_amdgcn_mfma_f64_4x4x4f64(aS, xu, rhs_u.t[mt][0], 0, 0, 0);
+            double av = __builtin_amdgcn_mfma_f64_4x4x4f64(aK, xu, rhs_v.t[mt][0], 0, 0, 0);
+            au = __builtin_amdgcn_mfma_f64_4x4x4f64(aK, -xv, au, 0, 0, 0);
+            av = __builtin_amdgcn_mfma_f64_4x4x4f64(aS, xv, av, 0, 0, 0);
+            qu.t[mt][0] = au;
+            qv.t[mt][0] = av;
+        }
+        double uold = 0.0, vold = 0.0;
 #pragma unroll
         for (int mt = 0; mt < NT; ++mt) {
             const double xu = pu.t[mt][0], xv = pv.t[mt][0];
             const double un = pu.t[mt + 1 < NT ? mt + 1 : mt][0], vn = pv.t[mt + 1 < NT ? mt + 1 : mt][0];
             const double uu = row_shift4<0x114>(xu), ud = row_shift4<0x104>(xu);
             const double vu = row_shift4<0x114>(xv), vd = row_shift4<0x104>(xv);
-            const d4 cs = OPREG ? oS.c[mt] : t4q_cload(cfS, mt), ck = OPREG ? oK.c[mt] : t4q_cload(cfK, mt);
-            const double aS = OPREG ? oS.a[mt] : maS[mt * 64], aK = OPREG ? oK.a[mt] : maK[mt * 64];
-            double au = __builtin_amdgcn_mfma_f64_4x4x4f64(aS, xu, rhs_u.t[mt][0], 0, 0, 0);
-            au = __builtin_amdgcn_mfma_f64_4x4x4f64(aK, -xv, au, 0, 0, 0);
-            double av = __builtin_amdgcn_mfma_f64_4x4x4f64(aK, xu, rhs_v.t[mt][0], 0, 0, 0);
-            av = __builtin_amdgcn_mfma_f64_4x4x4f64(aS, xv, av, 0, 0, 0);
+            const d4 cs = (OPREG && JQ_IMR_CREG) ? oS.c[mt] : t4q_cload(cfS, mt), ck = (OPREG && JQ_IMR_CREG) ? oK.c[mt] : t4q_cload(cfK, mt);
+            double au = qu.t[mt][0], av = qv.t[mt][0];
             au = fma(cs[0], uu, au);
             av = fma(ck[0], uu, av);
             au = fma(cs[1], ud, au);
@@ -114,8 +127,6 @@ struct QuadImr {
             vold = xv;
             qu.t[mt][0] = au;
             qv.t[mt][0] = av;
-            // (operands from LDS: without a fence per block the scheduler hoists the reads of all six blocks to the top -- 120
-            // registers of operands in flight)
             if constexpr (!OPREG) __builtin_amdgcn_sched_barrier(0);
         }
     }
