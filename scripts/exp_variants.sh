@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../juqbox.jl_amd/csrc"
 mkdir -p build/exp ../exp
 # EXP_OBJ / EXP_VARIANT: which object is rebuilt (default: k_6_7.o = quad layout, 12 waves; EXP_OBJ=u_6_7 EXP_VARIANT=9: cooperative quad)
 EXP_OBJ=${EXP_OBJ:-k_6_7}; EXP_VARIANT=${EXP_VARIANT:-0}
-SCHED=$([ "$EXP_VARIANT" = 0 ] && echo "-mllvm -amdgpu-sched-strategy=iterative-maxocc")
+SCHED=${EXP_SCHED-$([ "$EXP_VARIANT" = 0 ] && echo "-mllvm -amdgpu-sched-strategy=iterative-maxocc")}
 OBJS=$(ls build/*.o | grep -v "build/$EXP_OBJ.o")
 for spec in "$@"; do
   tag=${spec%%:*}; flags=${spec#*:}
