@@ -259,6 +259,17 @@ int jq_eval_f_g_grad_dev(jq_handle *h, const double *pcof, int32_t ncoeff, const
 int jq_traceobj_sweep(jq_handle *h, const double *pcof, int32_t ncoeff, const double *nodes, int32_t nquad,
                       const double *shift, double *out);
 
+/* ---- introspection ---------------------------------------------------------------------------*/
+/*
+ * The plan of a handle as a JSON object (NUL-terminated, at most buflen - 1 characters; returns the length the full text needs,
+ * negative JQ_E* on error): Hilbert dimension and tile rows, the structure the operators were found to have ("t4" = 4 x 4 x n
+ * Kronecker structure, "od" = diagonal off-diagonal blocks, "band" / "dense"), the embedded twin if any, the control groups, the
+ * integrator / solver settings and -- the part a caller sizing an ensemble needs -- the batch-size thresholds of the kernel
+ * families: "families" lists, in the order run_eval tries them, {family, name, max_columns / max_slabs / max_quads} for the
+ * current settings.  jq_last_timing() reports which one actually ran.
+ */
+int jq_plan_info(const jq_handle *h, char *buf, int32_t buflen);
+
 /* ---- measurement -----------------------------------------------------------------------------*/
 int jq_last_timing(const jq_handle *h, jq_timing *t);
 /* Library build info: "gfx950 juqbox_hip <version> src:<12 hex digits>" -- the digits are the SHA-256 prefix of the library's

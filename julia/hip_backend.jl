@@ -129,6 +129,13 @@ end
 
 num_devices(wa::AbstractWorkingArraysHIP) = ccall((:jq_num_devices, libjq), Cint, (Ptr{Cvoid},), wa.handle)
 num_compute_units(wa::AbstractWorkingArraysHIP) = ccall((:jq_num_compute_units, libjq), Cint, (Ptr{Cvoid},), wa.handle)
+function plan_info(wa::AbstractWorkingArraysHIP)      # JSON text: structure, control groups, batch-size thresholds of the kernel families
+    n = ccall((:jq_plan_info, libjq), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Int32), wa.handle, C_NULL, 0)
+    n >= 0 || error("jq_plan_info failed")
+    buf = Vector{UInt8}(undef, n + 1)
+    ccall((:jq_plan_info, libjq), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Int32), wa.handle, buf, n + 1)
+    return String(buf[1:n])
+end
 handle_device(wa::AbstractWorkingArraysHIP) = ccall((:jq_handle_device, libjq), Cint, (Ptr{Cvoid},), wa.handle)
 
 # params is mutated freely by scripts (Hconst inside eval_f_g_grad!, wmat_real, max_iter, targets): push before each call

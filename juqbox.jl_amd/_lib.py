@@ -63,6 +63,7 @@ SYMBOLS = {
     "jq_num_compute_units": (ctypes.c_int, [ctypes.c_void_p]),
     "jq_shard_bounds": (ctypes.c_int, [c_i32, c_i32, c_i32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "jq_traceobj_sweep": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_i32, c_dp, c_i32, c_dp, c_dp]),
+    "jq_plan_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, c_i32]),
     "jq_last_timing": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(jq_timing)]),
     "jq_version": (ctypes.c_char_p, []),
     "jq_abi_version": (ctypes.c_int, []),

@@ -2531,6 +2531,57 @@ static int multi_traceobj_sweep(jq_handle* h, const double* pcof, int ncoeff, co
     return JQ_OK;
 }
 
+extern "C" int jq_plan_info(const jq_handle* hh, char* buf, int32_t buflen)
+{
+    if (!hh || (!buf && buflen > 0) || buflen < 0) return JQ_EINVAL;
+    const jq_handle* h = hh->subs.empty() ? hh : hh->subs[0];
+    std::string o = "{";
+    auto kv = [&](const char* k, const std::string& v, bool quote = false) {
+        if (o.size() > 1) o += ", ";
+        o += std::string("\"") + k + "\": " + (quote ? "\"" + v + "\"" : v);
+    };
+    auto num = [](long long v) { return std::to_string(v); };
+    kv("devices", num(hh->subs.empty() ? 1 : (long long)hh->subs.size()));
+    kv("Ntot", num(h->Ntot));
+    kv("N", num(h->N));
+    kv("controls", num(h->Nc));
+    kv("control_groups", num(ctrl_ngroups(h->Nc)));
+    kv("tile_rows", num(h->NT));
+    kv("compute_units", num(h->num_cu));
+    const char* structure = h->big ? (h->BWc == 15 ? "dense" : "band") : h->BW == JQ_BW_T4 ? "t4" : h->BW == JQ_BW_OD ? "od" : h->BW == h->NT - 1 ? "dense" : "band";
+    kv("structure", structure, true);
+    kv("block_band", num(h->big ? h->BWc : h->BW));
+    kv("embedded_twin_Ntot", num(h->emb ? h->emb->Ntot : 0));
+    kv("integrator", h->integrator == 2 ? "implicit_midpoint" : "stormer_verlet", true);
+    kv("linear_solver", h->solver_id == 2 ? "jacobi" : "neumann", true);
+    kv("neumann_terms_or_max_iter", num(h->integrator == 2 ? h->imr_max_iter : h->m));
+    kv("chunk_steps", num(h->chunk_steps));
+    kv("replanned", h->replanned ? "true" : "false");
+    // kernel families in the order run_eval considers them for a Stormer-Verlet / Neumann batch (the embedded twin, if any, serves
+    // the batches beyond the row-lane / lane range with ITS plan)
+    std::string fam = "[";
+    auto add = [&](int id, const char* name, const char* unit, long long mx) {
+        if (fam.size() > 1) fam += ", ";
+        fam += std::string("{\"family\": ") + std::to_string(id) + ", \"name\": \"" + name + "\", \"max_" + unit + "\": " + std::to_string(mx) + "}";
+    };
+    const jq_handle* t = h->emb ? h->emb : h;
+    if (h->rl_npj > 0) add(3, "row-lane (VALU, lane per (row, column); backward sweep on two waves)", "columns", h->rl_max_cols);
+    if (h->lane_np > 0) add(2, "lane (VALU, lane per column)", "columns", h->lane_max_cols);
+    if (t->cq_max_quads > 0) add(8, "cooperative quad (one 16-row block per wave)", "quads", t->cq_max_quads);
+    if (t->quad_max_slabs > 0) add(6, "quad layout (four columns per wave; 1 / 2 / 3 slabs per workgroup by round count)", "slabs", t->quad_max_slabs);
+    if (t->coop_ok && t->NT >= 2) add(1, "cooperative (tile row per wave)", "slabs", t->coop_max_slabs);
+    if (!t->big) add(0, "slab (wave per 16-column slab)", "slabs", 1LL << 30);
+    fam += "]";
+    kv("families", fam);
+    o += "}";
+    if (buflen > 0) {
+        const size_t n = std::min(o.size(), (size_t)buflen - 1);
+        memcpy(buf, o.data(), n);
+        buf[n] = 0;
+    }
+    return (int)o.size();
+}
+
 extern "C" int jq_last_timing(const jq_handle* h, jq_timing* t)
 {
     if (!h || !t) return JQ_EINVAL;

@@ -118,6 +118,17 @@ class Working_Arrays_HIP:
             _lib.check(L.jq_update_target(h, _ptr(utr), _ptr(uti)), h)
             self._utr, self._uti = utr.copy(), uti.copy()
 
+    def plan_info(self):
+        """jq_plan_info: structure found in the operators, control groups, batch-size thresholds of the kernel families (dict)"""
+        import json
+        L = _lib.load()
+        n = L.jq_plan_info(self.handle, None, 0)
+        if n < 0:
+            _lib.check(n, self.handle)
+        buf = ctypes.create_string_buffer(n + 1)
+        L.jq_plan_info(self.handle, buf, n + 1)
+        return json.loads(buf.value.decode())
+
     def last_timing(self):
         t = _lib.jq_timing()
         _lib.check(_lib.load().jq_last_timing(self.handle, ctypes.byref(t)), self.handle)

@@ -493,3 +493,21 @@ def test_rowlane_backward_sweep_on_two_waves_equals_the_one_wave_kernel(hip, cas
     for k in (1, 5, 6):
         assert rel(a[0][k], b[0][k]) < 1e-14 or not np.any(b[0][k])
     assert a[1] == b[1] and a[2] == b[2] and rel(a[3], b[3]) < 1e-14
+
+
+def test_plan_info_describes_the_handle(hip):
+    """jq_plan_info: structure found in the operators, control groups and the batch-size thresholds of the kernel families -- one
+    place where a caller (and a reviewer) can read what the ~30 JQ_* knobs and the plan constants amount to for a problem."""
+    jq = hip
+    params, info, pcof, _ = case_inputs("cnot3")
+    wa = jq.Working_Arrays_HIP(params, pcof.size)
+    p = wa.plan_info()
+    assert p["Ntot"] == 96 and p["N"] == 4 and p["tile_rows"] == 6 and p["structure"] == "t4" and p["controls"] == 3 and p["control_groups"] == 1
+    fams = {f["family"]: f for f in p["families"]}
+    assert 8 in fams and fams[8]["max_quads"] == 2 * p["compute_units"] and 6 in fams and 0 in fams and 3 not in fams
+    wa.close()
+    params, info, pcof, _ = case_inputs("cnot2")                       # 3 x 4 levels: row-lane kernels + the embedded 4 x 4 x 1 twin
+    wa = jq.Working_Arrays_HIP(params, pcof.size)
+    p = wa.plan_info()
+    assert p["embedded_twin_Ntot"] == 16 and p["families"][0]["family"] == 3 and p["families"][0]["max_columns"] == 32 * p["compute_units"]
+    wa.close()

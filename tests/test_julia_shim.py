@@ -12,7 +12,7 @@ CTYPE = {  # C type -> the Julia types a ccall may use for it
     "const int32_t *": {"Ptr{Int32}"}, "int32_t *": {"Ref{Int32}", "Ptr{Int32}"},
     "jq_handle *": {"Ptr{Cvoid}"}, "const jq_handle *": {"Ptr{Cvoid}"}, "jq_handle **": {"Ref{Ptr{Cvoid}}"},
     "const jq_problem *": {"Ref{JQProblem}"}, "jq_timing *": {"Ref{JQTiming}"},
-    "const char *": {"Cstring"}, "void *": {"Ptr{Cvoid}"},
+    "const char *": {"Cstring"}, "void *": {"Ptr{Cvoid}"}, "char *": {"Ptr{UInt8}"},
 }
 
 
