@@ -44,24 +44,40 @@ struct QuadImr {
     // ensemble-shift coefficients ceps * ws[row] per block (constant over the sweep)
     OpQ<NT> oK, oS;
     double cw[NT];
+    // N = 4: the four columns of the quad are ONE evaluation (one ensemble shift eps), so the shift eps * diag(ws) of K can sit on
+    // the diagonal of the MFMA's A operand (lane 16 k + 4 b + i holds B[i][k]: the lanes with k == i) instead of costing two FMAs
+    // per block and application: cwa = this lane's addend to oK.a (zero off the diagonal)
+    double cwa[NT];
 
+    __device__ __forceinline__ bool folded() const { return OPREG && N == 4; }
     __device__ __forceinline__ void load_ops()
     {
         if constexpr (OPREG) {
             t4q_load<NT>(oK, K);
             t4q_load<NT>(oS, S);
+            if (N == 4) {
+#pragma unroll
+                for (int i = 0; i < NT; ++i) oK.a[i] += cwa[i];
+            }
         }
     }
     __device__ __forceinline__ void init_shift()
     {
+        const int lane = threadIdx.x & 63;
+        const bool dg = (lane >> 4) == (lane & 3);
 #pragma unroll
-        for (int i = 0; i < NT; ++i) cw[i] = use_shift ? ceps * ws[16 * i + g] : 0.0;
+        for (int i = 0; i < NT; ++i) {
+            cw[i] = use_shift ? ceps * ws[16 * i + g] : 0.0;
+            cwa[i] = (use_shift && dg) ? ceps * ws[16 * i + 4 * (lane & 3) + ((lane >> 2) & 3)] : 0.0;
+        }
     }
 
     // (qu, qv) = (rhs_u, rhs_v) + [S -K; K S] (pu, pv)   (K, S pre-scaled by h/2; the diagonal ensemble shift of K row-wise).
     // ONE pass over the blocks: the two products with pu (S pu, K pu) share its lane shifts, the two with pv likewise --
     // 48 v_mov_b32_dpp per application instead of 96 (round 2: four independent mm_t4q) -- and -K pv is formed with the
     // FMA's sign modifier and one sign flip per block for the MFMA operand instead of a negated copy of pv.
+    // FOLD: the ensemble shift is part of oK.a (folded()): no shift FMAs
+    template <bool FOLD = false>
     __device__ __forceinline__ void apply(const Arr<NT>& rhs_u, const Arr<NT>& rhs_v, const Arr<NT>& pu, const Arr<NT>& pv, Arr<NT>& qu,
                                           Arr<NT>& qv) const
     {
@@ -121,8 +137,10 @@ struct QuadImr {
                 au = fma(-ck[3], vn, au);
                 av = fma(cs[3], vn, av);
             }
-            au = fma(-cw[mt], xv, au);      // (cw = 0 without an ensemble shift: cheaper than a select per block)
-            av = fma(cw[mt], xu, av);
+            if constexpr (!FOLD) {
+                au = fma(-cw[mt], xv, au);      // (cw = 0 without an ensemble shift: cheaper than a select per block)
+                av = fma(cw[mt], xu, av);
+            }
             uold = xu;
             vold = xv;
             qu.t[mt][0] = au;
@@ -130,9 +148,46 @@ struct QuadImr {
             if constexpr (!OPREG) __builtin_amdgcn_sched_barrier(0);
         }
     }
+    // N = 4: the 64 lanes are ONE evaluation -- the stopping decision is wave-uniform, the iterates alternate between two register
+    // sets (no copies), both norms come out of one reduction
+    template <bool FOLD>
+    __device__ __forceinline__ void step4(Arr<NT>& u, Arr<NT>& v, const Arr<NT>& fu, const Arr<NT>& fv) const
+    {
+        Arr<NT> rhs_u = u, rhs_v = v;
+        a_add(rhs_u, fu);
+        a_add(rhs_v, fv);
+        {
+            Arr<NT> tu, tv;
+            apply<FOLD>(rhs_u, rhs_v, u, v, tu, tv);       // rhs = (x + f) + B x
+            rhs_u = tu;
+            rhs_v = tv;
+        }
+        Arr<NT> cu, cv, nu, nv;
+        apply<FOLD>(rhs_u, rhs_v, u, v, cu, cv);           // x_1
+        for (int it = 1;; it += 2) {
+            apply<FOLD>(rhs_u, rhs_v, cu, cv, nu, nv);     // x_{it+1};  residual at x_it = x_it - x_{it+1}
+            bool conv = __all(wave_sum2(a_diff2(cu, nu), a_diff2(cv, nv)) < tol2);
+            if (conv || it >= max_iter) {                  // keeps x_it
+                u = cu;
+                v = cv;
+                return;
+            }
+            apply<FOLD>(rhs_u, rhs_v, nu, nv, cu, cv);     // x_{it+2}
+            conv = __all(wave_sum2(a_diff2(nu, cu), a_diff2(nv, cv)) < tol2);
+            if (conv || it + 1 >= max_iter) {              // keeps x_{it+1}
+                u = nu;
+                v = nv;
+                return;
+            }
+        }
+    }
     // one implicit-midpoint step of (u, v); (fu, fv): forcing already multiplied by h, added to the right-hand side
     __device__ __forceinline__ void step(Arr<NT>& u, Arr<NT>& v, const Arr<NT>& fu, const Arr<NT>& fv, bool valid) const
     {
+        if (N == 4) {
+            step4<OPREG>(u, v, fu, fv);
+            return;
+        }
         Arr<NT> rhs_u = u, rhs_v = v;
         a_add(rhs_u, fu);
         a_add(rhs_v, fv);
@@ -144,26 +199,6 @@ struct QuadImr {
         }
         Arr<NT> cu, cv, nu, nv;
         apply(rhs_u, rhs_v, u, v, cu, cv);           // x_1
-        if (N == 4) {
-            // the 64 lanes are ONE evaluation: the stopping decision is wave-uniform, the iterates alternate between two
-            // register sets (no copies), both norms come out of one reduction
-            for (int it = 1;; it += 2) {
-                apply(rhs_u, rhs_v, cu, cv, nu, nv);     // x_{it+1};  residual at x_it = x_it - x_{it+1}
-                bool conv = __all(wave_sum2(a_diff2(cu, nu), a_diff2(cv, nv)) < tol2);
-                if (conv || it >= max_iter) {            // keeps x_it
-                    u = cu;
-                    v = cv;
-                    return;
-                }
-                apply(rhs_u, rhs_v, nu, nv, cu, cv);     // x_{it+2}
-                conv = __all(wave_sum2(a_diff2(nu, cu), a_diff2(nv, cv)) < tol2);
-                if (conv || it + 1 >= max_iter) {        // keeps x_{it+1}
-                    u = nu;
-                    v = nv;
-                    return;
-                }
-            }
-        }
         bool done = !valid;
         for (int it = 1; it <= max_iter; ++it) {
             apply(rhs_u, rhs_v, cu, cv, nu, nv);     // x_{it+1};  residual at x_it = x_it - x_{it+1}
