@@ -35,6 +35,9 @@ struct CqImr {
     jq_lds_double* x0;      // front pad block of channel 0 in parity 0, this lane (block w of a channel: + (w + 1) * 64)
     Op K, S;                // my block of the midpoint operators of this step (pre-scaled by h/2)
     double cw;              // h/2 * eps * ws[row] of this lane
+    double cwa;             // the same on the diagonal of the MFMA's A operand of K (lanes with k == i, zero elsewhere): the four
+                            // columns of the quad are ONE evaluation (N = 4), so the ensemble shift rides on K's 4 x 4 blocks
+                            // (fold_shift) instead of costing two FMAs per application
     double tol2;
     int max_iter, par;
     bool use_shift;
@@ -51,12 +54,10 @@ struct CqImr {
         r.au = c->own(ru, S, su);
         r.kv = c->own(0.0, K, sv);
         r.av = c->own(c->own(rv, K, su), S, sv);
-        if (use_shift) {      // the diagonal shift of K, row-wise (src/ipopt_interface.jl:41-44)
-            r.kv = fma(cw, pv, r.kv);
-            r.av = fma(cw, pu, r.av);
-        }
+        // (the diagonal shift of K, src/ipopt_interface.jl:41-44, is part of K.a: fold_shift)
         return r;
     }
+    __device__ __forceinline__ void fold_shift() { K.a += cwa; }      // (call after loading K; cwa = 0 without an ensemble shift)
     // ... and the (i, i+-16) couplings with the neighbours' blocks of the publication at LDS offset po
     __device__ __forceinline__ void nbr(Acc& r, int po) const
     {
@@ -178,6 +179,8 @@ struct CqImr {
     m.c = &c;                                                                                                                    \
     m.x0 = (jq_lds_double*)(tab + 32 * NT + lane_);                                                                              \
     m.cw = 0.5 * a.h * a.colinfo[(size_t)s.slab * 32 + s.col] * wsr;                                                             \
+    m.cwa = (a.use_shift && (lane_ >> 4) == (lane_ & 3))                                                                         \
+                ? 0.5 * a.h * a.colinfo[(size_t)s.slab * 32 + s.col] * tab[16 * NT + 16 * wave + 4 * (lane_ & 3) + ((lane_ >> 2) & 3)] : 0.0; \
     m.tol2 = a.jacobi_tol2, m.max_iter = a.m, m.par = 0, m.use_shift = a.use_shift;                                              \
     m.flags = (volatile __attribute__((address_space(3))) int*)(tab + 32 * NT + 2 * CoopQ<NT>::PAR + NT * 64);
 
@@ -202,6 +205,7 @@ __global__ __launch_bounds__(64 * NT + 128) void k_forward_cq_imr(PropArgs a)
     double leak = slot0 ? st[(size_t)(JQ_STATE_ARRAYS * KT + JQ_MAXNC) * 64 + cslot] : 0.0;
     for (int n = 0; n < a.nsteps_chunk; ++n) {
         m.K = c.load(c.ring.template ks<0, 1>());
+        m.fold_shift();
         m.S = c.load(c.ring.template ks<1, 1>());
         double su = u, sv = v;
         m.template step<true>(u, v, 0.0, 0.0);
@@ -260,6 +264,7 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq_imr(PropArgs a)
     double* trw = a.traces + ((trow + wave) * a.nsteps_chunk) * ntr;
     for (int n = 0; n < a.nsteps_chunk; ++n) {
         m.K = c.load(c.ring.template ks<0, 1>());
+        m.fold_shift();
         m.S = c.load(c.ring.template ks<1, 1>());
         double su = u, sv = v, smu = lr, snu = li;
         m.template step<true>(u, v, 0.0, 0.0);
