@@ -944,7 +944,11 @@ __device__ __forceinline__ void hist_store(const PropArgs& a, int slab, int col,
 //   use (backward: 4 image fetches per step instead of 13 + 3 Ncoupled), and there is ONE workgroup barrier per time step
 //   instead of one per operator use (measured: the per-use wait + barrier + DMA issue was 15% of the cnot3 evaluation).
 #define JQ_WIN_TPS 5
-struct Ring {
+// WIN: the kernel only ever runs in window mode (the quad-layout kernels): the mode tests are compile-time -- ~ 35 scalar branches
+// per backward step less (3 072 cnot3 samples 1 127 -> 1 114 ms); a scheduling barrier stands where each of them was, without it
+// hipcc hoists the operand reads of later stages over the whole step (380 / 496 B of scratch, 1.8 x slower).
+template <bool WIN>
+struct RingT {
     char* smem;
     // copies of the launch parameters the staging needs (kept in SGPRs; taking the address of the kernel
     // argument struct would make hipcc spill all of it to scratch)
@@ -1059,7 +1063,7 @@ struct Ring {
     }
     __device__ __forceinline__ void begin_step(int n)
     {
-        if (batch < 0) {
+        if (WIN || batch < 0) {
             if (n > 0) {
                 // every wave has finished step n-1 behind this barrier: its time points 2n-2, 2n-1 make room for 2n+3, 2n+4;
                 // the images of this step (issued one step ago) have landed
@@ -1105,7 +1109,7 @@ struct Ring {
         ip = 0;
         wave = wave_;
         lane = lane_;
-        if (batch < 0) {
+        if (WIN || batch < 0) {
             stride_b = (unsigned)(stride * 8);
             slot_bytes = (int)(2 * stride_b);
             // resident constant images behind the ring of time points
@@ -1140,7 +1144,7 @@ struct Ring {
     __device__ __forceinline__ const double* next()
     {
         const double* M;
-        if (batch < 0) {
+        if (WIN || batch < 0) {
             const unsigned e = (unsigned)qword & 63u, kind = e & 3u, tp = e >> 2;
             unsigned off;
             if (kind == 2) {
@@ -1196,12 +1200,14 @@ struct Ring {
     template <int KIND, int TP>
     __device__ __forceinline__ const double* next_ks()
     {
-        if (batch < 0) return (const double*)(smem + ((TP == 0 ? wb0 : TP == 1 ? wb1 : wb2) + KIND * stride_b)) + lane;
+        if constexpr (WIN) __builtin_amdgcn_sched_barrier(0);
+        if (WIN || batch < 0) return (const double*)(smem + ((TP == 0 ? wb0 : TP == 1 ? wb1 : wb2) + KIND * stride_b)) + lane;
         return next();
     }
     __device__ __forceinline__ const double* next_c(int idx)
     {
-        if (batch < 0) return (const double*)(smem + ((unsigned)(JQ_WIN_TPS * slot_bytes) + (unsigned)idx * stride_b)) + lane;
+        if constexpr (WIN) __builtin_amdgcn_sched_barrier(0);
+        if (WIN || batch < 0) return (const double*)(smem + ((unsigned)(JQ_WIN_TPS * slot_bytes) + (unsigned)idx * stride_b)) + lane;
         return next();
     }
     __device__ __forceinline__ void drain()
@@ -1211,6 +1217,7 @@ struct Ring {
         asm volatile("" ::: "memory");
     }
 };
+typedef RingT<false> Ring;
 
 // ---------------------------------------------------------------------------------------------
 // Scaled, signed operator stream.  With c = h/2 the tile stream holds (k_stream)
@@ -1318,7 +1325,14 @@ __device__ __forceinline__ void horner_add(Arr<NT>& out, const Arr<NT>& bpa, con
         OpQ<NT> op;
         t4q_load(op, S);
         mm_t4q_regs(Ya, A, op, A);
-        for (--rem; rem > 0; --rem) mm_t4q_regs(Ya, A, op, Ya);
+        // the recurrence two products per loop iteration: a taken branch costs 60 - 80 cycles of the SIMD's issue time even with three
+        // waves to choose from (probes/lone_wave_probe.hip; 3 072 cnot3 samples 1 152 -> 1 133 ms, 2 048: 853 -> 827 ms; four per iteration
+        // or a fully unrolled switch lose again: code size, 244 B of scratch)
+        for (--rem; rem >= 2; rem -= 2) {
+            mm_t4q_regs(Ya, A, op, Ya);
+            mm_t4q_regs(Ya, A, op, Ya);
+        }
+        if (rem > 0) mm_t4q_regs(Ya, A, op, Ya);
         mm_t4q_regs(out, bpa, op, Ya);
         return;
     }
@@ -1385,7 +1399,7 @@ __device__ __forceinline__ void a_unpark(Arr<NT>& a, const double* park)
 // At most 8 arrays are live here (u, v/v05, unew, vN, A, Ya, Yb + one of the caller's).
 // FUSE (quad layout only): bit 0 = K05 u with S0 u in one pass, bit 1 = S05 v05 with K0 v05 and K1 v05 in one pass
 template <int NT, int BW, bool JAC, int FUSE = 0>
-__device__ __forceinline__ void sv_state(Ring& p, const PropArgs& a, bool active, double ceps, const double* ws, int g,
+__device__ __forceinline__ void sv_state(RingT<BW == JQ_BW_T4Q>& p, const PropArgs& a, bool active, double ceps, const double* ws, int g,
                                          const Arr<NT>& u, Arr<NT>& v, Arr<NT>& unew, Arr<NT>& vN, Arr<NT>& A, Arr<NT>& Ya,
                                          Arr<NT>& Yb)
 {
@@ -1395,8 +1409,8 @@ __device__ __forceinline__ void sv_state(Ring& p, const PropArgs& a, bool active
         // S0 u, and S05 v05 with K0 v05 and K1 v05: 5 + 2m passes instead of 8 + 2m (the products are the same 8 + 2m).
         // (One `if (active)` block per stage like the generic path below: the branches keep hipcc from hoisting the operand
         // reads of later stages -- one basic block for the whole step spills 200+ registers in the twelve-wave variants.)
-        const double* M0 = p.next_ks<0, 1>();      // Kp05
-        const double* M1 = p.next_ks<1, 0>();      // S0
+        const double* M0 = p.template next_ks<0, 1>();      // Kp05
+        const double* M1 = p.template next_ks<1, 0>();      // S0
         if (active) {
             if constexpr (FUSE & 1) {
                 mm_t4q2<NT, true, false>(A, A, M0, unew, u, M1, u);        // A = c K05 u ;  unew = u + c S0 u
@@ -1406,14 +1420,14 @@ __device__ __forceinline__ void sv_state(Ring& p, const PropArgs& a, bool active
             }
             if (a.use_shift) a_axpy_rows(A, ceps, ws, g, u);
         }
-        M0 = p.next_ks<1, 1>();                    // S05
+        M0 = p.template next_ks<1, 1>();                    // S05
         if (active) {
             mm_c<NT, BW>(A, A, M0, v);                                 // A = c (K05 u + S05 v)
             a_add(v, A);
             horner_add<NT, BW, JAC>(v, v, A, M0, a.m, Ya, Yb, a.jacobi_tol2, a.N);       // v = v05
         }
-        M1 = p.next_ks<0, 0>();                    // Kn0
-        const double* M2 = p.next_ks<0, 2>();      // Kn1
+        M1 = p.template next_ks<0, 0>();                    // Kn0
+        const double* M2 = p.template next_ks<0, 2>();      // Kn1
         if (active) {
             if constexpr (FUSE & 2) {
                 mm_t4q3<NT, false, false, true>(vN, v, M0, unew, unew, M1, A, A, M2, v);     // vN = v05 + S05 v05 ; unew -= c K0 v05 ; A = -c K1 v05
@@ -1427,7 +1441,7 @@ __device__ __forceinline__ void sv_state(Ring& p, const PropArgs& a, bool active
                 a_axpy_rows(A, -ceps, ws, g, v);
             }
         }
-        M0 = p.next_ks<1, 2>();                    // S1
+        M0 = p.template next_ks<1, 2>();                    // S1
         if (active) {
             mm_c<NT, BW>(A, A, M0, unew);                              // A = c (S1 (u + c kappa1) - K1 v05)
             a_add(unew, A);
@@ -1436,13 +1450,13 @@ __device__ __forceinline__ void sv_state(Ring& p, const PropArgs& a, bool active
         return;
     }
     // use 0: Kp05 -- A = c K05 u
-    const double* M = p.next_ks<0, 1>();
+    const double* M = p.template next_ks<0, 1>();
     if (active) {
         mm_z<NT, BW>(A, M, u);
         if (a.use_shift) a_axpy_rows(A, ceps, ws, g, u);
     }
     // use 1: S05 -- A = c (K05 u + S05 v) ; v05 = v + sum_j S^j A (in place) ; vN = v05 + S05 v05
-    M = p.next_ks<1, 1>();
+    M = p.template next_ks<1, 1>();
     if (active) {
         mm_c<NT, BW>(A, A, M, v);
         a_add(v, A);
@@ -1450,22 +1464,22 @@ __device__ __forceinline__ void sv_state(Ring& p, const PropArgs& a, bool active
         mm_c<NT, BW>(vN, v, M, v);
     }
     // use 2: Kn0 -- unew = u - c K0 v05
-    M = p.next_ks<0, 0>();
+    M = p.template next_ks<0, 0>();
     if (active) {
         mm_c<NT, BW>(unew, u, M, v);
         if (a.use_shift) a_axpy_rows(unew, -ceps, ws, g, v);
     }
     // use 3: S0 -- unew = u + c (S0 u - K0 v05) = u + c kappa1
-    M = p.next_ks<1, 0>();
+    M = p.template next_ks<1, 0>();
     if (active) mm_c<NT, BW>(unew, unew, M, u);
     // use 4: Kn1 -- A = -c K1 v05
-    M = p.next_ks<0, 2>();
+    M = p.template next_ks<0, 2>();
     if (active) {
         mm_z<NT, BW>(A, M, v);
         if (a.use_shift) a_axpy_rows(A, -ceps, ws, g, v);
     }
     // use 5: S1 -- A = c (S1 (u + c kappa1) - K1 v05) ; unew += sum_j S^j A
-    M = p.next_ks<1, 2>();
+    M = p.template next_ks<1, 2>();
     if (active) {
         mm_c<NT, BW>(A, A, M, unew);
         a_add(unew, A);
@@ -1514,7 +1528,7 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
         a_zero(ua);
         a_zero(va);
     }
-    Ring p;
+    RingT<QUAD> p;
     p.init(smem, a, wave, lane_, NWAVES);
 
     // one time step: (u, v) -> (unew, vN); v is consumed (becomes v05).  The two array pairs swap
@@ -1525,7 +1539,7 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
         if (active) leak += a_wsq(wd, g, U); /* trapezoidal part: tr(vr' W vr) at t_n (:700) */                  \
         sv_state<NT, BW, JAC, JQ_FWD_FUSE>(p, a, active, ceps, ws, g, U, V, UN, VN, A, Ya, Yb);                       \
         /* use 6: Kp05 again -- v(t+h) = v05 + c (K05 u_new + S05 v05) */                                        \
-        const double* M6 = p.next_ks<0, 1>();                                                                             \
+        const double* M6 = p.template next_ks<0, 1>();                                                                             \
         if (active) {                                                                                            \
             mm_c<NT, BW>(VN, VN, M6, UN);                                                                        \
             if (a.use_shift) a_axpy_rows(VN, ceps, ws, g, UN);                                                   \
@@ -1610,7 +1624,7 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
     const int rslots = 8 * Nc;
     for (int i = threadIdx.x; i < 2 * NWAVES * rslots; i += blockDim.x) rec[i] = 0.0;   // (inactive waves never write theirs)
     auto flush_traces = [&](int k) {
-        if (a.batch > 0) {   // batched staging has no workgroup barrier in every step
+        if (!QUAD && a.batch > 0) {   // batched staging has no workgroup barrier in every step
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -1654,7 +1668,7 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
     // forcing weight c*tinv: c*hr0 = c*tinv*W*vr etc. (:862, :882-888); 0 for step_no_forcing!
     const double cfw = a.forced ? 0.5 * a.h * a.tinv : 0.0;
 
-    Ring p;
+    RingT<QUAD> p;
     p.init(smem, a, wave, lane_, NWAVES);
 
     if (a.first_chunk) {
@@ -1679,7 +1693,7 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
         // switches of sv_state otherwise)
         if (n > 0) flush_traces(n - 1);
         // use 6: Kp05 -- finish the state step; first adjoint product L = c K05 nb (= -c K05 lambda_i)
-        const double* M = p.next_ks<0, 1>();
+        const double* M = p.template next_ks<0, 1>();
         if (active) {
             mm_c<NT, BW>(vN, vN, M, un);
             if (a.use_shift) a_axpy_rows(vN, ceps, ws, g, un);
@@ -1690,7 +1704,7 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
         }
         // ---- adjoint step ----------------------------------------------------------------------
         // use 7: S0 -- L = c (S0 mu - K05 li + hr0) ; X = mu + sum_j S^j L   (in place: mu becomes X)
-        M = p.next_ks<1, 0>();
+        M = p.template next_ks<1, 0>();
         if (active) {
             mm_c<NT, BW>(L, L, M, mu);
             a_axpy_rows(L, cfw, wd, g, u);  // u holds vr before the state step (:862)
@@ -1708,8 +1722,8 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
         }
         if constexpr (QUAD && !JAC && (JQ_BWD_ADJ_FUSE & 1)) {
             // uses 8 and 9 in one pass (they share X): L = -c K0 X ; vN(scratch Q) = -c K1 X
-            M = p.next_ks<0, 0>();
-            const double* M9 = p.next_ks<0, 2>();
+            M = p.template next_ks<0, 0>();
+            const double* M9 = p.template next_ks<0, 2>();
             if (active) {
                 mm_t4q2<NT, true, true>(L, L, M, vN, vN, M9, mu);
                 if (a.use_shift) {
@@ -1719,13 +1733,13 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
             }
         } else {
         // use 8: Kn0 -- L = -c K0 X
-        M = p.next_ks<0, 0>();
+        M = p.template next_ks<0, 0>();
         if (active) {
             mm_z<NT, BW>(L, M, mu);
             if (a.use_shift) a_axpy_rows(L, -ceps, ws, g, mu);
         }
         // use 9: Kn1 -- vN(scratch Q) = -c K1 X
-        M = p.next_ks<0, 2>();
+        M = p.template next_ks<0, 2>();
         if (active) {
             mm_z<NT, BW>(vN, M, mu);
             if (a.use_shift) a_axpy_rows(vN, -ceps, ws, g, mu);
@@ -1733,7 +1747,7 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
         }
         // use 10: S05 -- L = -c l2 = -c (K0 X + S05 li + hi0) ; Q = -c (S05 (li + c l2) + K1 X + hi1) ;
         //               nb_new = nb + L + sum_j S^j Q          (li_new = li + c (l2 + l1))
-        M = p.next_ks<1, 1>();
+        M = p.template next_ks<1, 1>();
         if (active) {
             mm_z<NT, BW>(Ya, M, nb);
             a_axpy_rows(Ya, -cfw, wd, g, v);  // v holds vi05;  Ya = c (-S05 li - hi0)
@@ -1746,13 +1760,13 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
             a_add(nb, L);                     // nb = nb_old + nb_new = -(li0 + li)
         }
         // use 11: Kp05 -- vN(scratch G) = X + c K05 nb_new (= lambda_r^{1/2} - c K05 li_new)
-        M = p.next_ks<0, 1>();
+        M = p.template next_ks<0, 1>();
         if (active) {
             mm_c<NT, BW>(vN, mu, M, L);
             if (a.use_shift) a_axpy_rows(vN, ceps, ws, g, L);
         }
         // use 12: S1 -- lambda_r_new = X + c (S1 X - K05 li_new + hr1)
-        M = p.next_ks<1, 2>();
+        M = p.template next_ks<1, 2>();
         if (active) {
             mm_c<NT, BW>(vN, vN, M, mu);
             a_axpy_rows(vN, cfw, wd, g, un);

@@ -231,7 +231,7 @@ struct QuadImr {
     const double* wd = tab;                                                                                                   \
     for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[(i & ~15) + 4 * (i & 3) + ((i >> 2) & 3)] = a.tabs[i];         \
     double* st = a.state + (size_t)(active ? slab : 0) * a.state_stride;                                                      \
-    Ring p;                                                                                                                   \
+    RingT<true> p;                                                                                                                \
     p.init(smem, a, wave, lane_, 4 * SPW);      /* (window mode: ends with a barrier, the tables are published too) */        \
     QuadImr<NT, SPW == 1> m;                                                                                                  \
     m.ws = tab + 16 * NT;                                                                                                     \

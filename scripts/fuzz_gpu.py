@@ -60,6 +60,17 @@ def run(n_cases=50, seed=1, verbose=True):
         elif jac:
             p.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER, max_iter=60, tol=jtol, nrhs=N)
         replan = rng.random() < 0.1                  # (round 3: a drift outside the planned structure before the evaluation)
+        only = os.environ.get("FUZZ_ONLY")           # replay ONE case of a run (same n_cases and seed): the others only draw
+        if only and os.environ.get("FUZZ_DRY") and case in [int(x) for x in only.split(",")]:
+            print("%d Ntot=%d N=%d Nc=%d Nf=%d steps=%d m=%d oft=%d %s imr=%s mode=%s env=%s replan=%s" % (
+                case, Ntot, N, Nc, Nfreq, nsteps, m, oft, structure, imr, mode, env, replan), flush=True)
+        if only and (os.environ.get("FUZZ_DRY") or case not in [int(x) for x in only.split(",")]):
+            if replan:
+                rng.standard_normal((Ntot, Ntot))
+            nq = int(rng.choice([1, 2, 5, 17, 70]))
+            rng.standard_normal(nq), rng.random(nq), rng.standard_normal(Ntot)
+            compared += 1        # (a replay of a run without unsupported draws; with them the indices shift)
+            continue
         os.environ.update(env)
         try:
             wa = (jq.Working_Arrays_M_HIP if imr else jq.Working_Arrays_HIP)(p, pcof.size)
@@ -82,6 +93,12 @@ def run(n_cases=50, seed=1, verbose=True):
             r = o2.traceobjgrad_imr(pcof, 80, 1e-11) if imr else o2.traceobjgrad(pcof)
             inf += wq * r["primaryobjf"]; leak += wq * r["secondaryobjf"]; gi += wq * r["infidelgrad"]; gl += wq * r["leakgrad"]
         p.Hconst = H0
+        # implicit midpoint: a draw whose fixed-point iteration does not converge within its 80 iterations (large dt ||H||: every
+        # iteration amplifies rounding differences) is reported but not held to the tolerance
+        unconv = False
+        if imr:
+            ra, rb = orc.traceobjgrad_imr(pcof, 80, 1e-11), orc.traceobjgrad_imr(pcof, 79, 1e-11)
+            unconv = abs(ra["primaryobjf"] - rb["primaryobjf"]) > 1e-10 * max(1.0, abs(ra["primaryobjf"]))
         try:
             jq.eval_f_g_grad(pcof, p, wa, nodes, weights, True, shift=shift)
         except RuntimeError as e:
@@ -96,9 +113,10 @@ def run(n_cases=50, seed=1, verbose=True):
         e3 = np.linalg.norm(p.last_infidelity_grad - gi) / max(np.linalg.norm(gi), 1e-300)
         e4 = np.linalg.norm(p.last_leak_grad - gl) / max(np.linalg.norm(gi), 1e-300) if oft != 1 else 0.0
         err = max(e1, e2, e3, e4)
-        worst = max(worst, err)
+        if not unconv:
+            worst = max(worst, err)
         compared += 1
-        flag = "" if err < 1e-8 else "   <<<<<< MISMATCH"
+        flag = "   (fixed-point iteration not converged: not counted)" if unconv else ("" if err < 1e-8 else "   <<<<<< MISMATCH")
         nonlocal_print("%3d Ntot=%2d N=%2d Nc=%d Nf=%d steps=%2d m=%d oft=%d %-5s %s nq=%2d fam=%d %-18s env=%s%s%s err=%.1e%s" % (
             case, Ntot, N, Nc, Nfreq, nsteps, m, oft, structure, "IMR" if imr else ("JAC" if jac else "SV "), nq, fam, mode,
             env.get("JQ_CHUNK_STEPS", "-"), " replan" if replan else "", (" tol=%.0e" % jtol) if jac else "", err, flag), flush=True)
