@@ -50,10 +50,10 @@ struct WinRing {
         //  the DMA with its readers.)
         unsigned lo;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lo));
-        const char* src = gsrc + lo * 16u;
+        const unsigned lo16 = lo * 16u;      // (scalar base + 32-bit lane offset: no 64-bit per-lane address)
         const unsigned ldst = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)dst;
         for (int p = wave; p < pieces; p += nwaves)
-            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(ldst + (unsigned)p * 1024u), "v"(src + (size_t)p * 1024) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldst + (unsigned)p * 1024u), "v"(lo16), "s"(gsrc + (size_t)p * 1024) : "memory");
     }
     __device__ __forceinline__ void issue_next()
     {

@@ -982,6 +982,18 @@ struct RingT {
     }
     __device__ __forceinline__ void dma(const double* gsrc, char* dst, int pieces) const
     {
+        if constexpr (WIN) {
+            // scalar base + 32-bit lane offset: no 64-bit per-lane address (hipcc kept its zero-extended half in scratch and
+            // re-spilled it in every step: 8 B per lane and step = 25 GB per launch through to HBM).  begin_step / init drain the
+            // DMA (vmcnt(0)) in front of the workgroup barrier that publishes the images.
+            const unsigned lo16 = lane_off16();
+            const unsigned ldst = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)dst;
+            for (int p = wave; p < pieces; p += nwaves) {
+                const char* sp = (const char*)gsrc + (size_t)p * 1024;
+                asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldst + (unsigned)p * 1024u), "v"(lo16), "s"(sp) : "memory");
+            }
+            return;
+        }
         const char* src = (const char*)gsrc + lane_off16();
         for (int p = wave; p < pieces; p += nwaves)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)p * 1024),

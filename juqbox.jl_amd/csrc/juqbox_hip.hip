@@ -1426,12 +1426,17 @@ struct EvalOut {
 // JQ_BW_T4 structure, Stormer-Verlet / Neumann: estimated time of one batch in units of a slab-kernel round (4 #CU slabs), by the
 // plan run_eval would choose -- cooperative-quad kernels (<= cq_max_quads column quads: 0.196 s per round of #CU quads against
 // 1.917 s at cnot3), quad-layout kernels with 1 / 2 / 3 slabs per workgroup, slab kernels.  (The same figures as in run_eval.)
+// Time of one round of the 4 x 4 x n kernel families relative to a round of the slab kernels (4 #CU slabs), measured at cnot3
+// (scripts/time_staircase.py, round 3: 0.495 / 0.748 / 1.104 s for #CU / 2 #CU / 3 #CU slabs on the quad-layout kernels with 1 / 2 / 3
+// slabs per workgroup, 0.192 s for a round of the cooperative-quad kernels)
+static const double T4_REL[4] = {1.0, 0.276, 0.417, 0.615};
+static const double T4_REL_CQ = 0.107;
 static double t4_plan_cost(const jq_handle* h, long long nsamples)
 {
     const long long nslabs = h->parts > 1 ? nsamples * h->parts : (nsamples + h->sps - 1) / h->sps;
     const long long nquads = (nsamples * h->N + 3) / 4;
-    if (h->cq_max_quads > 0 && nquads <= h->cq_max_quads) return 0.102 * (double)((nquads + h->num_cu - 1) / h->num_cu);
-    const double rel[4] = {1.0, 0.29, 0.47, 0.615};
+    if (h->cq_max_quads > 0 && nquads <= h->cq_max_quads) return T4_REL_CQ * (double)((nquads + h->num_cu - 1) / h->num_cu);
+    const double* rel = T4_REL;
     double best = rel[0] * (double)((nslabs + 4 * h->num_cu - 1) / (4 * h->num_cu));
     if (nslabs <= h->quad_max_slabs)
         for (int k = 1; k <= 3; ++k) {
@@ -1569,11 +1574,11 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     // JQ_BW_T4 structure, small batches: the quad-layout kernels (one workgroup per slab, its four waves carry four columns
     // each; 3 x shorter dependent chain than the cooperative kernels).  JQ_QUAD=0 disables them.
     // Which kernels for nslabs slabs of this structure?  Time of one round relative to the slab kernels' round of 4 #CU slabs
-    // (measured at cnot3): quad layout with 1 / 2 / 3 slabs per workgroup 0.29 / 0.47 / 0.615 for #CU / 2 #CU /
+    // (T4_REL, measured at cnot3): quad layout with 1 / 2 / 3 slabs per workgroup for #CU / 2 #CU /
     // 3 #CU slabs.  Fewest "round units" wins; spw = 0: slab kernels.
     int spw = 0;
     if (!imr && !lane && !rl && h->solver_id == 1 && nslabs <= h->quad_max_slabs) {
-        const double rel[4] = {1.0, 0.29, 0.47, 0.615};      // (round 2: 0.553 / 0.90 / 1.177 s against 1.917 s)
+        const double* rel = T4_REL;
         auto quad_lds = [&](int k) {    // backward kernel, k slabs per workgroup
             return (size_t)(2 * JQ_WIN_TPS + 2 * h->NcK) * h->mat_elems * 8 + (size_t)bwd_lds_tail(h->NT, h->NcK, 4 * k, (long long)h->NT * 64);
         };
