@@ -21,7 +21,10 @@ __device__ __forceinline__ double row_shift(double x)
     b.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], CTRL, 0xf, 0xf, true);
     return b.d;
 }
-template <int NT, int MODE, int WPS>
+// UNR (round 3, late): products per loop iteration.  With one product per iteration the loop's taken branch costs the SIMD 30 - 80
+// cycles (probes/lone_wave_probe.hip) -- the figures of rounds 1 - 3 (354 cycles per product at four waves per SIMD, "6.7 cycles per
+// fp64 FMA") include it.
+template <int NT, int MODE, int WPS, int UNR = 1>
 __global__ __launch_bounds__(256 * WPS) void k_probe(const double* img, double* out, int reps)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -35,7 +38,10 @@ __global__ __launch_bounds__(256 * WPS) void k_probe(const double* img, double* 
     double cr[NT][5];
     for (int mt = 0; mt < NT; ++mt)
         for (int k = 0; k < 5; ++k) cr[mt][k] = M[mt * 320 + k * 64];
-    for (int r = 0; r < reps; ++r) {
+#pragma unroll 1
+    for (int r = 0; r < reps; r += UNR) {
+#pragma unroll
+      for (int un = 0; un < UNR; ++un) {
         double xold = 0.0;
 #pragma unroll
         for (int mt = 0; mt < NT; ++mt) {
@@ -65,12 +71,13 @@ __global__ __launch_bounds__(256 * WPS) void k_probe(const double* img, double* 
             Y[mt] = acc;
         }
         asm volatile("" ::: "memory");
+      }
     }
     double s = 0;
     for (int i = 0; i < NT; ++i) s += Y[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
-template <int NT, int MODE, int WPS>
+template <int NT, int MODE, int WPS, int UNR = 1>
 int run(const double* dimg, double* dout)
 {
     const size_t lds = NT * 320 * 8;
@@ -78,15 +85,16 @@ int run(const double* dimg, double* dout)
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    hipLaunchKernelGGL((k_probe<NT, MODE, WPS>), dim3(256), dim3(256 * WPS), lds, 0, dimg, dout, 10);
+    hipLaunchKernelGGL((k_probe<NT, MODE, WPS, UNR>), dim3(256), dim3(256 * WPS), lds, 0, dimg, dout, 16);
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL((k_probe<NT, MODE, WPS>), dim3(256), dim3(256 * WPS), lds, 0, dimg, dout, reps);
+    hipLaunchKernelGGL((k_probe<NT, MODE, WPS, UNR>), dim3(256), dim3(256 * WPS), lds, 0, dimg, dout, reps);
     CK(hipEventRecord(e1));
     CK(hipDeviceSynchronize());
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
     const int nm = ((MODE & 1) ? NT : 0) + ((MODE & 16) ? 2 * NT : 0), nmov = (MODE & 2) ? 4 * NT : 0, nf = ((MODE & 4) ? 2 * NT : 0) + ((MODE & 8) ? 2 * NT - 2 : 0);
     const double ns = ms * 1e6 / reps;
+    if (UNR > 1) printf("[%d products per loop iteration] ", UNR);
     printf("mode %2d (%d MFMA, %2d dpp mov, %2d FMA per product) %d wave(s)/SIMD: %7.1f ns = %6.0f clk per product round; per wave %6.0f clk (issue model 16/4/4: %4d)\n",
            MODE, nm, nmov, nf, WPS, ns, ns * 2.4, ns * 2.4 / WPS, 16 * nm + 4 * nmov + 4 * nf);
     return 0;
@@ -116,5 +124,11 @@ int main()
     runw<3>(dimg, dout);
     runw<14>(dimg, dout);
     runw<25>(dimg, dout);      // 1 + 8 + 16: the product with the middle coupling on two more MFMAs per block (no shifts)
+    // the same without the loop branch per product
+    run<6, 15, 1, 8>(dimg, dout), run<6, 15, 2, 8>(dimg, dout), run<6, 15, 3, 8>(dimg, dout), run<6, 15, 4, 8>(dimg, dout);
+    run<6, 1, 1, 8>(dimg, dout), run<6, 1, 4, 8>(dimg, dout);
+    run<6, 2, 1, 8>(dimg, dout), run<6, 2, 4, 8>(dimg, dout);
+    run<6, 12, 1, 8>(dimg, dout), run<6, 12, 4, 8>(dimg, dout);
+    run<6, 25, 3, 8>(dimg, dout), run<6, 25, 4, 8>(dimg, dout);
     return 0;
 }
