@@ -123,11 +123,16 @@ def issue_bound(launch_s, steps_per_launch, products_per_step, waves_per_simd):
             txt = None
     if not txt or "mode 15" not in txt:
         try:
-            txt = open(os.path.join(ROOT, "profiles", "r02_issue_probes.txt")).read()
-            src = "profiles/r02_issue_probes.txt (recorded run of probes/t4q_issue_probe)"
+            txt = open(os.path.join(ROOT, "profiles", "r03_issue_probes.txt")).read()
+            src = "profiles/r03_issue_probes.txt (recorded run of probes/t4q_issue_probe)"
         except OSError:
             return None
-    mm = re.search(r"mode 15 .*? %d wave\(s\)/SIMD:.*?per wave\s+(\d+) clk" % waves_per_simd, txt)
+    # the probe with EIGHT products per loop iteration (round 3: a loop branch per product cost 30 cycles of the SIMD's time and was
+    # in every earlier figure); an older probe output only has the one-product loop
+    mm = re.search(r"\[8 products per loop iteration\] mode 15 .*? %d wave\(s\)/SIMD:.*?per wave\s+(\d+) clk" % waves_per_simd, txt)
+    unrolled = mm is not None
+    if not mm:
+        mm = re.search(r"mode 15 .*? %d wave\(s\)/SIMD:.*?per wave\s+(\d+) clk" % waves_per_simd, txt)
     if not mm:
         return None
     probe_clk = float(mm.group(1))
@@ -135,8 +140,9 @@ def issue_bound(launch_s, steps_per_launch, products_per_step, waves_per_simd):
     return {"bare_product_clk_per_wave": probe_clk, "kernel_clk_per_product_and_wave": kernel_clk,
             "frac_of_formulation_bound": probe_clk / kernel_clk, "waves_per_simd": waves_per_simd,
             "products_per_backward_step": products_per_step, "nominal_issue_model_clk": 280, "source": src,
-            "note": "fp64 VALU instructions cost 6-7 cycles on gfx950, not 4 (probes/dp_rate_probe.hip): the bare product takes "
-                    "1.3 x its nominal issue count; the kernel as a whole runs within ~10 % of the bare product"}
+            "probe_loop": "8 products per loop iteration" if unrolled else "1 product per loop iteration (includes a taken branch)",
+            "note": "bare product: 6 MFMA (16 clk) + 24 v_mov_b32_dpp (4.2) + 22 fp64 FMA (4.65, probes/lone_wave_probe.hip) = 299 clk "
+                    "nominal; every instruction of the kernel -- scalar, branch, wait -- costs the SIMD ~4.6 clk (DESIGN.md section 6)"}
 
 
 _T0 = time.perf_counter()
