@@ -35,10 +35,13 @@ extern "C" {
  * value the LIBRARY was built with; every binding (juqbox.jl_amd/_lib.py, julia/hip_backend.jl, examples/c_abi_demo.c) compares
  * the two when it loads the library, so a caller compiled against an older header fails loudly instead of having
  * jq_last_timing write past its struct.  History: 1 = round 1; 2 = jq_timing.mfma_backward, jq_problem.Hunc_ops / Rfreq;
- * 3 = jq_timing.ms_allreduce / ms_shard_min / ms_shard_max, jq_abi_version(), up to JQ_MAX_CONTROLS control Hamiltonians. */
-#define JQ_ABI_VERSION 3
+ * 3 = jq_timing.ms_allreduce / ms_shard_min / ms_shard_max, jq_abi_version(), up to JQ_MAX_CONTROLS control Hamiltonians;
+ * 4 = jq_problem.Hconst_csc / Hsym_csc / Hanti_csc (sparse operator storage), jq_csc, jq_update_hconst_csc, jq_update_wmat (full /
+ *     complex leakage weights). */
+#define JQ_ABI_VERSION 4
 
 #define JQ_MAX_CONTROLS 16 /* control Hamiltonians per problem (Ncoupled or Nunc)                   */
+#define JQ_MAX_WRANK 16    /* largest rank of a full leakage-weight matrix (jq_update_wmat)         */
 
 #define JQ_OK 0
 #define JQ_EINVAL -1      /* bad argument (the reference's @assert / error(...) sites)            */
@@ -48,6 +51,20 @@ extern "C" {
 #define JQ_ENOMEM -5
 
 typedef struct jq_handle jq_handle;
+
+/*
+ * A sparse operator exactly as Julia's SparseMatrixCSC{Float64,Int64} stores it (the reference keeps Hconst, Hsym_ops, Hanti_ops
+ * like this when objparams(...; use_sparse=true), src/evalobjgrad.jl:249-262, and multiplies them through KS!/KS_alloc,
+ * :2392-2426, :3072-3105): m x n, column j holds the entries nzval[colptr[j]-1 .. colptr[j+1]-2] in the rows
+ * rowval[...] -- colptr and rowval are 1-BASED Int64, like the fields of the Julia struct, so the binding passes the three
+ * vectors without copying or shifting them.  Repeated (row, column) entries are summed.
+ */
+typedef struct jq_csc {
+    int64_t m, n;            /* size; must be Ntot x Ntot                                           */
+    const int64_t *colptr;   /* [n + 1], colptr[0] == 1, colptr[n] == nnz + 1                       */
+    const int64_t *rowval;   /* [nnz], 1 <= rowval <= m                                             */
+    const double *nzval;     /* [nnz]                                                               */
+} jq_csc;
 
 /*
  * Problem description = the objparams fields the device needs (src/evalobjgrad.jl:53-148;
@@ -85,6 +102,13 @@ typedef struct jq_problem {
      * reference's adjoint_grad_calc_m has no term for uncoupled controls). */
     const double *Hunc_ops;  /* [Nunc][Ntot x Ntot], NULL when Nunc == 0                           */
     const double *Rfreq;     /* [Nunc] rotation frequencies params.Rfreq, NULL when Nunc == 0      */
+    /* Sparse storage of the coupled operators (use_sparse = true): when Hconst == NULL, Hconst_csc is read instead; likewise
+     * Hsym_csc / Hanti_csc (arrays of Ncoupled descriptors) when Hsym_ops / Hanti_ops == NULL.  The library plans its kernels
+     * from the nonzero structure either way, so the dense and the CSC form of the same operators give bit-identical results.
+     * All three NULL (with the dense pointers set): a dense problem, as before. */
+    const jq_csc *Hconst_csc;
+    const jq_csc *Hsym_csc;  /* [Ncoupled]                                                         */
+    const jq_csc *Hanti_csc; /* [Ncoupled]                                                         */
 } jq_problem;
 
 /* Timing of the last evaluation, measured with HIP events on the library's stream. */
@@ -180,8 +204,26 @@ int jq_update_target(jq_handle *h, const double *Utarget_r, const double *Utarge
  * chosen from the operators' nonzero structure at jq_create; a new drift with entries outside that structure re-plans the handle
  * in place (same pointer, settings kept) -- slower kernels may result, never an error for a valid Hconst. */
 int jq_update_hconst(jq_handle *h, const double *Hconst);
-/* params.wmat_real = orig_wmatsetup(Ne,Ng) (e.g. test/cases/cnot3-setup.jl:253) */
+/* the same with the new drift in sparse storage (use_sparse = true problems) */
+int jq_update_hconst_csc(jq_handle *h, const jq_csc *Hconst);
+/* params.wmat_real = orig_wmatsetup(Ne,Ng) (e.g. test/cases/cnot3-setup.jl:253); returns the handle to Diagonal weights */
 int jq_update_wmat_diag(jq_handle *h, const double *wmat_real_diag);
+/*
+ * Full leakage weights: params.wmat_real / params.wmat_imag as Ntot x Ntot matrices, what objparams(...;
+ * use_custom_forbidden=true, forb_states, forb_weights) builds (src/evalobjgrad.jl:214-232: W = sum_k w_k f_k f_k^H).  They enter
+ * the objective through penalf2aTrap / penalf2a (full versions, :2183-2223) and penalf2imag (:2226-2228) at :700, :716-718 and the
+ * adjoint forcing through the products at :862, :882-888.  wmat_imag may be NULL (= 0).
+ * The device exploits the structure: W = wmat_real + i wmat_imag must be Hermitian (wmat_real symmetric, wmat_imag
+ * antisymmetric -- what the constructor produces) and is eigen-decomposed on the host into rank <= JQ_MAX_WRANK terms
+ * lam_k f_k f_k^H; W x then costs two column dot products and two axpys per term instead of dense products.  A diagonal
+ * wmat_real with wmat_imag == 0 is recognised and takes the Diagonal fast path (as jq_update_wmat_diag).
+ * Stormer-Verlet integrator with the Neumann solver only (the implicit-midpoint path of the reference reads params.wmat, which is
+ * always Diagonal, :90, :1155).  Errors: JQ_EUNSUPPORTED for a non-Hermitian W, rank > JQ_MAX_WRANK, or a handle set to the
+ * implicit-midpoint integrator / Jacobi solver; evaluations on kernel families without the low-rank terms are refused, never
+ * silently evaluated with other weights.  Parity-unpinned in the reference (no test or golden uses the branch): checked against
+ * the CPU oracle, whose gradient is checked by finite differences (tests/test_dense_wmat.py).
+ */
+int jq_update_wmat(jq_handle *h, const double *wmat_real, const double *wmat_imag);
 
 /* ---- the hot path ----------------------------------------------------------------------------*/
 /*

@@ -12,8 +12,18 @@
 # tests/test_julia_shim.py checks every struct layout and ccall signature of this file against include/juqbox_hip.h
 # (Julia itself is not available in the build image).
 using LinearAlgebra
+using SparseArrays
 
 const libjq = get(ENV, "JUQBOX_HIP_LIB", "libjuqbox_hip")      # on LD_LIBRARY_PATH, or an absolute path
+
+struct JQCsc                              # == jq_csc: the fields of a SparseMatrixCSC{Float64,Int64}, 1-based, passed as they are
+    m::Int64
+    n::Int64
+    colptr::Ptr{Int64}
+    rowval::Ptr{Int64}
+    nzval::Ptr{Float64}
+end
+JQCsc(A::SparseMatrixCSC{Float64,Int64}) = JQCsc(size(A, 1), size(A, 2), pointer(A.colptr), pointer(A.rowval), pointer(A.nzval))
 
 struct JQProblem                          # == jq_problem
     Ntot::Int32
@@ -35,6 +45,9 @@ struct JQProblem                          # == jq_problem
     Cfreq::Ptr{Float64}
     Hunc_ops::Ptr{Float64}
     Rfreq::Ptr{Float64}
+    Hconst_csc::Ptr{JQCsc}                # use_sparse = true: read when the dense pointer above is NULL
+    Hsym_csc::Ptr{JQCsc}
+    Hanti_csc::Ptr{JQCsc}
 end
 
 struct JQTiming                           # == jq_timing
@@ -57,8 +70,8 @@ struct JQTiming                           # == jq_timing
     ms_shard_max::Float64
 end
 
-# the struct layouts above are those of JQ_ABI_VERSION 3 of include/juqbox_hip.h: refuse a library built for another one
-const JQ_ABI_VERSION = 3
+# the struct layouts above are those of JQ_ABI_VERSION 4 of include/juqbox_hip.h: refuse a library built for another one
+const JQ_ABI_VERSION = 4
 function jq_check_abi()
     v = ccall((:jq_abi_version, libjq), Cint, ())
     v == JQ_ABI_VERSION || error("libjuqbox_hip has ABI version $v, hip_backend.jl was written for $JQ_ABI_VERSION")
@@ -81,27 +94,57 @@ end
 jq_create_error() = unsafe_string(ccall((:jq_last_error, libjq), Cstring, (Ptr{Cvoid},), C_NULL))
 jqcheck(wa, rc) = rc == 0 || error(unsafe_string(ccall((:jq_last_error, libjq), Cstring, (Ptr{Cvoid},), wa.handle)))
 
-leak_weights(::Working_Arrays_HIP, params) = Vector{Float64}(diag(params.wmat_real))    # src/evalobjgrad.jl:583
-leak_weights(::Working_Arrays_M_HIP, params) = Vector{Float64}(diag(params.wmat))       # :1147
+# Leakage weights.  The Stormer-Verlet path reads params.wmat_real / params.wmat_imag (src/evalobjgrad.jl:629-630): Diagonal by
+# default, FULL matrices with use_custom_forbidden (:214-232) -- those go to jq_update_wmat; the diagonal alone would silently
+# change the objective and the gradient.  The implicit-midpoint path reads params.wmat (:1155), a Diagonal by its field type (:90).
+full_weights(params) = !(params.wmat_real isa Diagonal) || !iszero(params.wmat_imag)
+function push_weights!(wa::Working_Arrays_HIP, params)
+    if full_weights(params)
+        params.wmat_imag isa Diagonal && !iszero(params.wmat_imag) &&
+            error("hip_backend: a non-zero Diagonal wmat_imag is not a Hermitian weight (the reference ignores it in the objective, " *
+                  "src/evalobjgrad.jl:2231-2233, but not in the forcing): refusing instead of evaluating something else")
+        Wr = Matrix{Float64}(params.wmat_real)
+        Wi = Matrix{Float64}(params.wmat_imag)
+        jqcheck(wa, ccall((:jq_update_wmat, libjq), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), wa.handle, Wr, Wi))
+    else
+        wd = Vector{Float64}(diag(params.wmat_real))
+        jqcheck(wa, ccall((:jq_update_wmat_diag, libjq), Cint, (Ptr{Cvoid}, Ptr{Float64}), wa.handle, wd))
+    end
+end
+function push_weights!(wa::Working_Arrays_M_HIP, params)
+    params.wmat isa Diagonal || error("hip_backend: the implicit-midpoint path needs Diagonal params.wmat")
+    wd = Vector{Float64}(diag(params.wmat))
+    jqcheck(wa, ccall((:jq_update_wmat_diag, libjq), Cint, (Ptr{Cvoid}, Ptr{Float64}), wa.handle, wd))
+end
 
 function jq_new_handle(params, devices)
     jq_check_abi()
     Ntot = params.N + params.Nguard
-    Hc   = Matrix{Float64}(params.Hconst)                          # dense, column-major (also for use_sparse)
-    Hs   = params.Ncoupled > 0 ? reduce(hcat, [vec(Matrix{Float64}(h)) for h in params.Hsym_ops]) : zeros(1, 1)
-    Ha   = params.Ncoupled > 0 ? reduce(hcat, [vec(Matrix{Float64}(h)) for h in params.Hanti_ops]) : zeros(1, 1)
+    # use_sparse = true (src/evalobjgrad.jl:249-262): Hconst, Hsym_ops, Hanti_ops are SparseMatrixCSC{Float64,Int64}; their
+    # colptr / rowval / nzval go to the library as they are (jq_csc), nothing is densified on this side
+    sparse = params.Hconst isa SparseMatrixCSC{Float64,Int64} && params.Nunc == 0 &&
+             all(h -> h isa SparseMatrixCSC{Float64,Int64}, params.Hsym_ops) && all(h -> h isa SparseMatrixCSC{Float64,Int64}, params.Hanti_ops)
+    Hc   = sparse ? zeros(1, 1) : Matrix{Float64}(params.Hconst)                          # dense, column-major
+    Hs   = (!sparse && params.Ncoupled > 0) ? reduce(hcat, [vec(Matrix{Float64}(h)) for h in params.Hsym_ops]) : zeros(1, 1)
+    Ha   = (!sparse && params.Ncoupled > 0) ? reduce(hcat, [vec(Matrix{Float64}(h)) for h in params.Hanti_ops]) : zeros(1, 1)
+    c0   = sparse ? [JQCsc(params.Hconst)] : JQCsc[]
+    cs   = sparse ? [JQCsc(h) for h in params.Hsym_ops] : JQCsc[]
+    ca   = sparse ? [JQCsc(h) for h in params.Hanti_ops] : JQCsc[]
     Hu   = params.Nunc > 0 ? reduce(hcat, [vec(Matrix{Float64}(h)) for h in params.Hunc_ops]) : zeros(1, 1)   # lab-frame evaluation
     Rf   = Vector{Float64}(params.Rfreq)
-    wd   = Vector{Float64}(diag(params.wmat_real))                 # Diagonal weights only
+    wd   = zeros(Ntot)                                             # the weights follow the creation: push_weights!
     Cf   = Matrix{Float64}(params.Cfreq[1:params.Ncoupled+params.Nunc, :])
     Ui   = Matrix{Float64}(params.Uinit)
     h    = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve Hc Hs Ha Hu Rf wd Cf Ui params begin
+    GC.@preserve Hc Hs Ha Hu Rf wd Cf Ui c0 cs ca params begin
         prob = JQProblem(Ntot, params.N, params.Ncoupled, params.Nfreq, params.nsteps,
                          params.linear_solver.max_iter, params.objFuncType, params.Nunc, params.T,
-                         pointer(Hc), pointer(Hs), pointer(Ha), pointer(Ui),
+                         sparse ? Ptr{Float64}(C_NULL) : pointer(Hc), sparse ? Ptr{Float64}(C_NULL) : pointer(Hs),
+                         sparse ? Ptr{Float64}(C_NULL) : pointer(Ha), pointer(Ui),
                          pointer(params.Utarget_r), pointer(params.Utarget_i), pointer(wd), pointer(Cf),
-                         params.Nunc > 0 ? pointer(Hu) : Ptr{Float64}(C_NULL), params.Nunc > 0 ? pointer(Rf) : Ptr{Float64}(C_NULL))
+                         params.Nunc > 0 ? pointer(Hu) : Ptr{Float64}(C_NULL), params.Nunc > 0 ? pointer(Rf) : Ptr{Float64}(C_NULL),
+                         sparse ? pointer(c0) : Ptr{JQCsc}(C_NULL), sparse ? pointer(cs) : Ptr{JQCsc}(C_NULL),
+                         sparse ? pointer(ca) : Ptr{JQCsc}(C_NULL))
         if devices === nothing
             rc = ccall((:jq_create, libjq), Cint, (Ref{JQProblem}, Ref{Ptr{Cvoid}}), prob, h)
         else
@@ -148,10 +191,16 @@ function sync!(wa::AbstractWorkingArraysHIP, params::objparams)
         jqcheck(wa, ccall((:jq_set_linear_solver, libjq), Cint, (Ptr{Cvoid}, Int32, Int32, Float64),
                           wa.handle, ls.solver_id, ls.max_iter, ls.tol))
     end
-    Hc = Matrix{Float64}(params.Hconst)
-    wd = leak_weights(wa, params)
-    jqcheck(wa, ccall((:jq_update_hconst, libjq), Cint, (Ptr{Cvoid}, Ptr{Float64}), wa.handle, Hc))
-    jqcheck(wa, ccall((:jq_update_wmat_diag, libjq), Cint, (Ptr{Cvoid}, Ptr{Float64}), wa.handle, wd))
+    if params.Hconst isa SparseMatrixCSC{Float64,Int64}
+        Hsp = params.Hconst
+        GC.@preserve Hsp begin
+            jqcheck(wa, ccall((:jq_update_hconst_csc, libjq), Cint, (Ptr{Cvoid}, Ref{JQCsc}), wa.handle, JQCsc(Hsp)))
+        end
+    else
+        Hc = Matrix{Float64}(params.Hconst)
+        jqcheck(wa, ccall((:jq_update_hconst, libjq), Cint, (Ptr{Cvoid}, Ptr{Float64}), wa.handle, Hc))
+    end
+    push_weights!(wa, params)
     jqcheck(wa, ccall((:jq_update_target, libjq), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}),
                       wa.handle, params.Utarget_r, params.Utarget_i))
 end

@@ -17,11 +17,18 @@ c_i32 = ctypes.c_int32
 JQ_OK, JQ_EINVAL, JQ_EDIM, JQ_EUNSUPPORTED, JQ_EHIP, JQ_ENOMEM = 0, -1, -2, -3, -4, -5
 
 
+class jq_csc(ctypes.Structure):
+    """Julia's SparseMatrixCSC{Float64,Int64}: m, n, colptr, rowval (1-based Int64), nzval"""
+    _fields_ = [("m", ctypes.c_int64), ("n", ctypes.c_int64), ("colptr", ctypes.POINTER(ctypes.c_int64)),
+                ("rowval", ctypes.POINTER(ctypes.c_int64)), ("nzval", c_dp)]
+
+
 class jq_problem(ctypes.Structure):
     _fields_ = [("Ntot", c_i32), ("N", c_i32), ("Ncoupled", c_i32), ("Nfreq", c_i32), ("nsteps", c_i32),
                 ("neumann_terms", c_i32), ("objFuncType", c_i32), ("Nunc", c_i32), ("T", ctypes.c_double),
                 ("Hconst", c_dp), ("Hsym_ops", c_dp), ("Hanti_ops", c_dp), ("Uinit", c_dp), ("Utarget_r", c_dp),
-                ("Utarget_i", c_dp), ("wmat_real_diag", c_dp), ("Cfreq", c_dp), ("Hunc_ops", c_dp), ("Rfreq", c_dp)]
+                ("Utarget_i", c_dp), ("wmat_real_diag", c_dp), ("Cfreq", c_dp), ("Hunc_ops", c_dp), ("Rfreq", c_dp),
+                ("Hconst_csc", ctypes.POINTER(jq_csc)), ("Hsym_csc", ctypes.POINTER(jq_csc)), ("Hanti_csc", ctypes.POINTER(jq_csc))]
 
 
 class jq_timing(ctypes.Structure):
@@ -33,7 +40,7 @@ class jq_timing(ctypes.Structure):
                 ("ms_allreduce", ctypes.c_double), ("ms_shard_min", ctypes.c_double), ("ms_shard_max", ctypes.c_double)]
 
 
-JQ_ABI_VERSION = 3      # the struct layouts above (include/juqbox_hip.h JQ_ABI_VERSION); load() refuses any other library
+JQ_ABI_VERSION = 4      # the struct layouts above (include/juqbox_hip.h JQ_ABI_VERSION); load() refuses any other library
 
 
 # every symbol include/juqbox_hip.h declares: name -> (restype, argtypes)
@@ -48,7 +55,9 @@ SYMBOLS = {
     "jq_set_integrator": (ctypes.c_int, [ctypes.c_void_p, c_i32, c_i32, ctypes.c_double]),
     "jq_update_target": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp]),
     "jq_update_hconst": (ctypes.c_int, [ctypes.c_void_p, c_dp]),
+    "jq_update_hconst_csc": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(jq_csc)]),
     "jq_update_wmat_diag": (ctypes.c_int, [ctypes.c_void_p, c_dp]),
+    "jq_update_wmat": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp]),
     "jq_traceobjgrad": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_i32, c_i32, c_dp, c_dp, c_dp, c_dp]),
     "jq_state_history": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_i32, c_dp, c_dp]),
     "jq_traceobj_verbose": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_i32, c_dp, c_dp, c_dp]),

@@ -268,6 +268,61 @@ __device__ __forceinline__ d4 coop_horner(Coop<NT, BW>& c, const d4& bpa, const 
     return c.mm_c(bpa);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Low-rank full leakage weights (PropArgs::wlr; jq_kernels.h WLow) in the cooperative layout: a column's rows are spread over the
+// g-groups of a wave AND over the NT waves, so a column dot product is a lane partial, two cross-row adds and a sum over the
+// waves through LDS: xch[parity][value][wave][column], one workgroup barrier per call (double buffered: the slot written by
+// call j is read behind barrier j and written again by call j + 2, behind barrier j + 1).
+#define JQ_COOP_WDOTS 6
+template <int NT>
+struct CoopW {
+    const double* tab;      // a_0 rows of this wave / lane (rows 16 mt + 4 r + g: element r at tab[4 r])
+    const double* lamp;
+    double* xch;
+    int r, stride, par, wave, lane;
+    __device__ __forceinline__ void init(const PropArgs& a, double* lds, int wave_, int lane_)
+    {
+        r = a.wrank;
+        stride = a.wstride;
+        lamp = a.wlr;
+        tab = a.wlr + JQ_MAX_WRANK + 16 * wave_ + (lane_ >> 4);
+        xch = lds;
+        par = 0;
+        wave = wave_;
+        lane = lane_;
+    }
+    __device__ __forceinline__ double lam(int k) const { return lamp[k]; }
+    __device__ __forceinline__ d4 rows(int k, int ab) const
+    {
+        const double* t = tab + (size_t)(2 * k + ab) * stride;
+        return (d4){t[0], t[4], t[8], t[12]};
+    }
+    // v[d] <- sum over the slab column of this lane (all waves) of the per-lane partials v[d]; valid in every lane
+    template <int D>
+    __device__ __forceinline__ void colsum(double (&v)[D])
+    {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            v[d] += __shfl_xor(v[d], 16);
+            v[d] += __shfl_xor(v[d], 32);
+        }
+        double* x = xch + (size_t)par * (JQ_COOP_WDOTS * NT * 16);
+        if (lane < 16)
+#pragma unroll
+            for (int d = 0; d < D; ++d) x[(d * NT + wave) * 16 + lane] = v[d];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            double s = 0.0;
+            for (int w = 0; w < NT; ++w) s += x[(d * NT + w) * 16 + (lane & 15)];
+            v[d] = s;
+        }
+        par ^= 1;
+    }
+};
+
 // State (re-)integration: uses 0..5 of a step in the cooperative schedule Kp05 S05 Kn0 Kn1 S0 S1 (Kp05).
 //   in: u, v (my rows)   out: un = u(t+h), v05, vN = v05 + S05 v05 (caller adds Kp05 un with use 6)
 template <int NT, int BW>
@@ -354,9 +409,12 @@ __global__ __launch_bounds__(64 * NT) void k_forward_coop(PropArgs a)
     // partials are combined (in wave order) at the end of the chunk
     double leak = 0.0;
     const double ceps = 0.5 * a.h * a.colinfo[(size_t)slab * 32 + (lane & 15)];
+    CoopW<NT> wl;
+    wl.init(a, c.nrm + 16 * NT, wave, lane);
 
     for (int n = 0; n < a.nsteps_chunk; ++n) {
         d4 un, v05, vN;
+        const d4 u0 = u;
         leak += dot4(wdr, u * u);  // trapezoidal part at t_n (src/evalobjgrad.jl:700)
         coop_state<NT, BW>(c, a, ceps, wsr, u, v, un, v05, vN);
         // use 6: Kp05 -- v(t+h) = v05 + c (K05 u_new + S05 v05)
@@ -366,6 +424,17 @@ __global__ __launch_bounds__(64 * NT) void k_forward_coop(PropArgs a)
         if (a.use_shift) v += (ceps * wsr) * un;
         u = un;
         leak += dot4(wdr, u * u) + 2.0 * dot4(wdr, v05 * v05);  // (:716, penalf2a :2170-2180)
+        if (wl.r > 0) {   // full weights: tr(vr' Wr vr) at t_n and t_n+1, 2 tr(vi05' Wr vi05), -2 tr(vi05' Wi vr(t_n)) (:700, :716-718)
+            double lk = 0.0;
+            for (int k = 0; k < wl.r; ++k) {
+                const d4 ak = wl.rows(k, 0), bk = wl.rows(k, 1);
+                double d[6] = {dot4(ak, u0), dot4(bk, u0), dot4(ak, u), dot4(bk, u), dot4(ak, v05), dot4(bk, v05)};
+                wl.template colsum<6>(d);
+                lk += wl.lam(k) * ((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]) + 2.0 * (d[4] * d[4] + d[5] * d[5]) -
+                                   2.0 * (d[5] * d[0] - d[4] * d[1]));
+            }
+            if (wave == 0 && lane < 16) leak += lk;
+        }
         if (a.hist_r) {
             const int col = a.parts > 1 ? 16 * slab + (lane & 15) : (lane & 15);      // column of sample 0
             if (slab < a.parts && col < a.N) {
@@ -426,6 +495,10 @@ __global__ __launch_bounds__(64 * NT) void k_backward_coop(PropArgs a)
     double carry[JQ_MAXNC];
     for (int q = 0; q < JQ_MAXNC; ++q) carry[q] = (q < Nc) ? st[(JQ_STATE_ARRAYS * KT + q) * 64 + lane] / NT : 0.0;
     double* trw = a.traces + ((size_t)(slab * NT + wave) * a.nsteps_chunk) * (Nc * JQ_NTR);
+    // full leakage weights in low-rank form: forcing hr0, hi0, hr1, hi1 of src/evalobjgrad.jl:862, :882-888 (see k_backward)
+    CoopW<NT> wl;
+    wl.init(a, c.nrm + 16 * NT, wave, lane);
+    const bool wforce = a.wrank > 0 && a.forced;
 
     if (a.first_chunk) {
         // carry_q = tr(vr' Hsym_q lambdai) at t = T (see k_backward)
@@ -458,6 +531,14 @@ __global__ __launch_bounds__(64 * NT) void k_backward_coop(PropArgs a)
         c.publish_next_op();
         R = c.mm_c(R);
         R += (cfw * wdr) * u;
+        if (wforce)
+            for (int k = 0; k < wl.r; ++k) {
+                const d4 ak = wl.rows(k, 0), bk = wl.rows(k, 1);
+                double d[2] = {dot4(ak, u), dot4(bk, u)};
+                wl.template colsum<2>(d);
+                const double cl = cfw * wl.lam(k);
+                R += (cl * d[0]) * ak + (cl * d[1]) * bk;      // + c hr0
+            }
         const d4 X = coop_horner<NT, BW>(c, mu + R, R, a.m, a.jacobi_tol2, a.N);
         // early traces with X: tr1 = tr(vr0' Hanti_q X), tr3 = tr(vr' Hanti_q X)
         c.stage(X);
@@ -485,6 +566,15 @@ __global__ __launch_bounds__(64 * NT) void k_backward_coop(PropArgs a)
         {
             d4 P = c.mm_z();
             P -= (cfw * wdr) * v05;
+            if (wforce)
+                for (int k = 0; k < wl.r; ++k) {
+                    const d4 ak = wl.rows(k, 0), bk = wl.rows(k, 1);
+                    double d[4] = {dot4(ak, un), dot4(bk, un), dot4(ak, v05), dot4(bk, v05)};
+                    wl.template colsum<4>(d);
+                    const double cl = cfw * wl.lam(k);
+                    P -= (cl * d[2]) * ak + (cl * d[3]) * bk;      // - c hi0 (goes into L and Q)
+                    Qv += (cl * d[0]) * bk - (cl * d[1]) * ak;     // Q: - c (hi1 - hi0) = + c Wi vr(t_n) / T
+                }
             L += P;
             Qv += P;
         }
@@ -503,6 +593,14 @@ __global__ __launch_bounds__(64 * NT) void k_backward_coop(PropArgs a)
         c.publish_next_op();
         G = c.mm_c(G);
         G += (cfw * wdr) * un;
+        if (wforce)
+            for (int k = 0; k < wl.r; ++k) {
+                const d4 ak = wl.rows(k, 0), bk = wl.rows(k, 1);
+                double d[4] = {dot4(ak, un), dot4(bk, un), dot4(ak, v05), dot4(bk, v05)};
+                wl.template colsum<4>(d);
+                const double cl = cfw * wl.lam(k);
+                G += (cl * (d[0] - d[3])) * ak + (cl * (d[1] + d[2])) * bk;      // + c hr1
+            }
         // late traces: tr5 = tr(vi05' Hanti (li0+li)), tr2 = tr(vi05' Hsym X), tr4 = tr(vr' Hsym li) + carry
         for (int q = 0; q < JQ_MAXNC; ++q) {
             if (q < Nc) {

@@ -8,8 +8,9 @@
 //              5: row-lane kernels of the implicit-midpoint integrator (JQ_NT = NPJ)
 //              9: cooperative-quad kernels (one 16-row block per wave; single evaluations / small ensembles; JQ_BW = 7)
 //              4: row-lane kernels (one lane per (row, column); JQ_NT = padded row length NPJ, JQ_BW unused)
+//             11: quad-layout kernels (one slab per workgroup) with the low-rank full leakage weights compiled in (JQ_BW = 7)
 #if !defined(JQ_NT) || !defined(JQ_BW) || !defined(JQ_VARIANT)
-#error "compile with -DJQ_NT=<tiles> -DJQ_BW=<band> -DJQ_VARIANT=<0..10>"
+#error "compile with -DJQ_NT=<tiles> -DJQ_BW=<band> -DJQ_VARIANT=<0..11>"
 #endif
 #if JQ_VARIANT == 9     // cooperative-quad (latency) kernels of the JQ_BW_T4 structure (JQ_BW = 7)
 #include "jq_cq_kernels.h"
@@ -48,6 +49,8 @@ template __global__ void k_backward_rowlane_imr2<JQ_NT>(PropArgs);      // (stat
 template __global__ void k_forward_rowlane<JQ_NT>(PropArgs);
 template __global__ void k_backward_rowlane<JQ_NT>(PropArgs);
 template __global__ void k_backward_rowlane2<JQ_NT>(PropArgs);      // (state and adjoint chain on two waves)
+template __global__ void k_forward_rowlane<JQ_NT, true>(PropArgs);      // (low-rank full leakage weights, jq_update_wmat)
+template __global__ void k_backward_rowlane<JQ_NT, true>(PropArgs);
 #elif JQ_VARIANT == 3
 #include "jq_lane_kernels.h"
 template __global__ void k_forward_lane<JQ_NT>(PropArgs);
@@ -64,7 +67,10 @@ template __global__ void k_backward_coop<JQ_NT, JQ_BW>(PropArgs);
 #define JQ_MINW_MAXNT 2      // tile counts up to which two workgroups share a CU (slab kernels)
 #endif
 #define JQ_MINW ((JQ_NT <= JQ_MINW_MAXNT) ? 2 : 1)
-#if JQ_BW == 7 && JQ_VARIANT == 8   // quad layout, workgroups of 4 / 8 waves (1 / 2 slabs): built with the max-ILP scheduler (Makefile)
+#if JQ_BW == 7 && JQ_VARIANT == 11  // quad layout, one slab per workgroup, full leakage weights (jq_update_wmat)
+template __global__ void k_forward<JQ_NT, JQ_BW, 1, false, true>(PropArgs);
+template __global__ void k_backward<JQ_NT, JQ_BW, 1, false, true>(PropArgs);
+#elif JQ_BW == 7 && JQ_VARIANT == 8   // quad layout, workgroups of 4 / 8 waves (1 / 2 slabs): built with the max-ILP scheduler (Makefile)
 template __global__ void k_forward<JQ_NT, JQ_BW, 1, false>(PropArgs);
 template __global__ void k_backward<JQ_NT, JQ_BW, 1, false>(PropArgs);
 template __global__ void k_forward<JQ_NT, JQ_BW, 2, false>(PropArgs);

@@ -898,11 +898,78 @@ struct PropArgs {
     // scalar ALU ops only (a table in memory costs a dependent scalar load in front of every DMA issue)
     unsigned long long sched_bits[3];  // entries 0..29 of the per-step schedule
     unsigned long long pro_bits;       // entries of the prologue (backward first chunk)
+    // Full / complex leakage weights (use_custom_forbidden, src/evalobjgrad.jl:214-232) in low-rank form
+    //   W = wmat_real + i wmat_imag = sum_{k < wrank} lam_k f_k f_k^H ,  f_k = a_k + i b_k   (jq_update_wmat: eigen-decomposition)
+    // wlr (global memory, natural row order): lam[JQ_MAX_WRANK], then per k the rows a_k[wstride], b_k[wstride] (zero padded).
+    // wrank == 0: Diagonal weights (the table wd); wrank > 0: wd is all zero and the kernels add the low-rank terms.
+    const double* wlr;
+    int wrank;
+    int wstride;
 };
+#ifndef JQ_MAX_WRANK
+#define JQ_MAX_WRANK 16       // largest rank of a full weight matrix the kernels take (include/juqbox_hip.h)
+#endif
 __host__ __device__ inline void sched_pack(unsigned long long* words, int i, int kind, int tp)
 {
     words[i / 10] |= (unsigned long long)((kind & 3) | ((tp & 15) << 2)) << (6 * (i % 10));
 }
+
+// ---------------------------------------------------------------------------------------------
+// Low-rank leakage weights (PropArgs::wlr) in the slab / quad layouts.  W x for one state column is
+//   sum_k lam_k [ a_k (a_k.x) + b_k (b_k.x) ]  (wmat_real x)   and   sum_k lam_k [ b_k (a_k.x) - a_k (b_k.x) ]  (wmat_imag x),
+// i.e. two column dot products and two axpys per forbidden state instead of a dense product.  A column's rows sit in the
+// lanes l, l ^ 16, l ^ 32, l ^ 48 (slab layout: row 16 i + 4 r + (l >> 4)) or in the 16 lanes with the same l & 3 (quad layout:
+// row 16 i + 4 ((l >> 2) & 3) + (l >> 4)); the dots are all-reduced over them, so every lane of a column holds the column's value.
+template <bool QUAD>
+__device__ __forceinline__ double col_allsum(double x)
+{
+    if constexpr (QUAD) x = row_ror_add<8>(row_ror_add<4>(x));
+    x += __shfl_xor(x, 16);
+    x += __shfl_xor(x, 32);
+    return x;
+}
+template <int NT, bool QUAD>
+struct WLow {
+    const double* tab;      // first row of a_0 of this lane (rows 16 i + 4 q further on)
+    const double* lamp;     // lam[k]
+    int r, stride;
+    bool lead;      // one lane per column: adds the column's scalar terms to a per-lane partial sum
+    __device__ __forceinline__ void init(const PropArgs& a, int lane_)
+    {
+        r = a.wrank;
+        stride = a.wstride;
+        lamp = a.wlr;
+        tab = a.wlr + JQ_MAX_WRANK + (QUAD ? 4 * ((lane_ >> 2) & 3) + (lane_ >> 4) : (lane_ >> 4));
+        lead = QUAD ? lane_ < 4 : lane_ < 16;
+    }
+    __device__ __forceinline__ double lam(int k) const { return lamp[k]; }
+    // (da, db) = (a_k . x, b_k . x) of this lane's column
+    __device__ __forceinline__ void dots(int k, const Arr<NT>& x, double& da, double& db) const
+    {
+        const double* ta = tab + (size_t)(2 * k) * stride;
+        const double* tb = ta + stride;
+        double sa = 0.0, sb = 0.0;
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int q = 0; q < JQ_RL; ++q) {
+                sa = fma(ta[16 * i + 4 * q], x.t[i][q], sa);
+                sb = fma(tb[16 * i + 4 * q], x.t[i][q], sb);
+            }
+        da = col_allsum<QUAD>(sa);
+        db = col_allsum<QUAD>(sb);
+    }
+    // y += ca a_k + cb b_k
+    __device__ __forceinline__ void axpy2(int k, Arr<NT>& y, double ca, double cb) const
+    {
+        const double* ta = tab + (size_t)(2 * k) * stride;
+        const double* tb = ta + stride;
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int q = 0; q < JQ_RL; ++q) y.t[i][q] = fma(ca, ta[16 * i + 4 * q], fma(cb, tb[16 * i + 4 * q], y.t[i][q]));
+    }
+};
 
 // usaver[:,:,step+1] = vr ; usavei = -vi (src/evalobjgrad.jl:748-752); only sample 0 (slab 0, columns < N)
 // (col: state column of this lane; g: its row in a 4-row group -- quad layout: its row in a 16-row block)
@@ -1502,7 +1569,13 @@ __device__ __forceinline__ void sv_state(RingT<BW == JQ_BW_T4Q>& p, const PropAr
 // ---------------------------------------------------------------------------------------------
 // Forward sweep over one chunk of time steps (src/evalobjgrad.jl:698-753).
 // schedule (period 7): Kp05 S05 Kn0 S0 Kn1 S1 Kp05
-template <int NT, int BW, int MINW, bool JAC>
+// WLRT: low-rank full leakage weights (PropArgs::wlr) compiled in.  The structure-specific throughput kernels (JQ_BW_T4, the quad
+// layout) carry them only in dedicated instantiations (WLRT = true: quad layout, one slab per workgroup), so the Diagonal fast
+// path is untouched; the band / dense / JQ_BW_OD slab kernels test a.wrank at run time (a handful of scalar branches per step
+// next to >= 8 + 2 m products of 64-cycle MFMAs).
+template <int BW, bool JAC, bool WLRT>
+constexpr bool jq_wlr_on() { return WLRT || (!JAC && BW != JQ_BW_T4 && BW != JQ_BW_T4Q); }
+template <int NT, int BW, int MINW, bool JAC, bool WLRT = false>
 __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_T4Q) ? 1 : MINW) void k_forward(PropArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1542,6 +1615,9 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
     }
     RingT<QUAD> p;
     p.init(smem, a, wave, lane_, NWAVES);
+    constexpr bool WLR = jq_wlr_on<BW, JAC, WLRT>();
+    WLow<NT, QUAD> wl;
+    if constexpr (WLR) wl.init(a, lane_);
 
     // one time step: (u, v) -> (unew, vN); v is consumed (becomes v05).  The two array pairs swap
     // roles every step, so the loop body is written for two steps and nothing is ever copied.
@@ -1557,6 +1633,18 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
             if (a.use_shift) a_axpy_rows(VN, ceps, ws, g, UN);                                                   \
             /* leak integrand: tr(vr' W vr + 2 vi05' W vi05) after the step (:716, penalf2a :2170-2180) */       \
             leak += a_wsq(wd, g, UN) + 2.0 * a_wsq(wd, g, V);                                                    \
+            if constexpr (WLR)                                                                                   \
+                if (wl.r > 0) {   /* full weights: tr(vr' Wr vr) at t_n and t_n+1, 2 tr(vi05' Wr vi05), -2 tr(vi05' Wi vr(t_n)) (:700, :716-718) */ \
+                    double lk = 0.0;                                                                             \
+                    for (int k = 0; k < wl.r; ++k) {                                                             \
+                        double p0, q0, p1, q1, rr, ss;                                                           \
+                        wl.dots(k, U, p0, q0);                                                                   \
+                        wl.dots(k, UN, p1, q1);                                                                  \
+                        wl.dots(k, V, rr, ss);                                                                   \
+                        lk += wl.lam(k) * ((p0 * p0 + q0 * q0) + (p1 * p1 + q1 * q1) + 2.0 * (rr * rr + ss * ss) - 2.0 * (ss * p0 - rr * q0)); \
+                    }                                                                                            \
+                    if (wl.lead) leak += lk;                                                                     \
+                }                                                                                                \
             if (a.hist_r) hist_store<NT>(a, slab, col, QUAD ? 4 * ((lane_ >> 2) & 3) + (lane_ >> 4) : g, NSTEP, UN, VN); \
         }                                                                                                        \
     }
@@ -1596,7 +1684,7 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
 // Register budget (512 per lane, 8 per array element pair): at most 9 state-sized arrays are live at
 // any point (8 since vr0 dies after the early traces); the one array that is dormant in each phase (lambda_r during the state step, v during the
 // adjoint step and the traces) is parked in the wave's LDS (or global) parking image.
-template <int NT, int BW, int MINW, bool JAC>
+template <int NT, int BW, int MINW, bool JAC, bool WLRT = false>
 __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_T4Q) ? 1 : MINW) void k_backward(PropArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1682,6 +1770,12 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
 
     RingT<QUAD> p;
     p.init(smem, a, wave, lane_, NWAVES);
+    // full leakage weights in low-rank form (WLow): forcing hr0 = Wr vr(t_n+1) / T, hi0 = Wr vi05 / T, hr1 = (Wr vr(t_n) + Wi vi05) / T,
+    // hi1 = hi0 - Wi vr(t_n) / T (src/evalobjgrad.jl:862, :882-888)
+    constexpr bool WLR = jq_wlr_on<BW, JAC, WLRT>();
+    WLow<NT, QUAD> wl;
+    if constexpr (WLR) wl.init(a, lane_);
+    const bool wforce = WLR && a.wrank > 0 && a.forced;
 
     if (a.first_chunk) {
         // carry_q = tr(vr' Hsym_q lambdai) at t = T: the "vr0/lambdai0" term of the first backward
@@ -1720,6 +1814,14 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
         if (active) {
             mm_c<NT, BW>(L, L, M, mu);
             a_axpy_rows(L, cfw, wd, g, u);  // u holds vr before the state step (:862)
+            if constexpr (WLR)
+                if (wforce)
+                    for (int k = 0; k < wl.r; ++k) {
+                        double pu, qu;
+                        wl.dots(k, u, pu, qu);
+                        const double cl = cfw * wl.lam(k);
+                        wl.axpy2(k, L, cl * pu, cl * qu);      // + c hr0
+                    }
             a_add(mu, L);
             horner_add<NT, BW, JAC>(mu, mu, L, M, a.m, Ya, Yb, a.jacobi_tol2, a.N);
         }
@@ -1763,6 +1865,16 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
         if (active) {
             mm_z<NT, BW>(Ya, M, nb);
             a_axpy_rows(Ya, -cfw, wd, g, v);  // v holds vi05;  Ya = c (-S05 li - hi0)
+            if constexpr (WLR)
+                if (wforce)
+                    for (int k = 0; k < wl.r; ++k) {
+                        double pn, qn, rr, ss;
+                        wl.dots(k, un, pn, qn);
+                        wl.dots(k, v, rr, ss);
+                        const double cl = cfw * wl.lam(k);
+                        wl.axpy2(k, Ya, -cl * rr, -cl * ss);     // - c hi0 (goes into L and Q)
+                        wl.axpy2(k, vN, -cl * qn, cl * pn);      // Q: - c (hi1 - hi0) = + c Wi vr(t_n) / T
+                    }
             a_add(L, Ya);
             a_add(vN, Ya);
             mm_c<NT, BW>(vN, vN, M, L);       // vN = Q
@@ -1782,6 +1894,15 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
         if (active) {
             mm_c<NT, BW>(vN, vN, M, mu);
             a_axpy_rows(vN, cfw, wd, g, un);
+            if constexpr (WLR)
+                if (wforce)
+                    for (int k = 0; k < wl.r; ++k) {
+                        double pn, qn, rr, ss;
+                        wl.dots(k, un, pn, qn);
+                        wl.dots(k, v, rr, ss);
+                        const double cl = cfw * wl.lam(k);
+                        wl.axpy2(k, vN, cl * (pn - ss), cl * (qn + rr));      // + c hr1
+                    }
         }
         // ---- late traces (adjoint_grad_calc!, :2581-2618), per control q, weighted by the sample weight:
         //   tr5 = tr(vi05' Hanti (li0+li))   tr2 = tr(vi05' Hsym X)   tr4 = tr(vr' Hsym li) + tr(vr0' Hsym li0)

@@ -146,11 +146,42 @@ __device__ __forceinline__ void row_state(const PropArgs& a, const RowOps<NPJ>& 
     if (a.use_shift) vnew = fma(sw, un, vnew);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Low-rank full leakage weights (PropArgs::wlr; jq_kernels.h WLow) in the row-lane layout: the 16 lanes of a DPP row are the rows
+// of one column, so a column dot product is one multiply and four DPP rotate-adds (valid in every lane of the row).  The table is
+// copied to LDS once (a lone wave would wait ~1 us per global read in every time step): [lam[JQ_MAX_WRANK] | a_k[16], b_k[16] per k].
+#define JQ_RL_WTAB (JQ_MAX_WRANK + 2 * JQ_MAX_WRANK * 16)
+__device__ __forceinline__ double rl_colsum(double x)
+{
+    x = row_ror_add<8>(x);
+    x = row_ror_add<4>(x);
+    x = row_ror_add<2>(x);
+    return row_ror_add<1>(x);
+}
+struct RowW {
+    const double* tab;      // LDS
+    int r, row;
+    __device__ __forceinline__ void init(const PropArgs& a, double* lds, int lane, int nthreads)
+    {
+        r = a.wrank;
+        row = lane & 15;
+        tab = lds;
+        if (r > 0) {      // (a.wstride == 16: Ntot <= 16 is one tile row)
+            for (int i = threadIdx.x; i < JQ_MAX_WRANK + 2 * r * 16; i += nthreads) lds[i] = a.wlr[i];
+            __syncthreads();
+        }
+    }
+    __device__ __forceinline__ double lam(int k) const { return tab[k]; }
+    __device__ __forceinline__ double a(int k) const { return tab[JQ_MAX_WRANK + 32 * k + row]; }
+    __device__ __forceinline__ double b(int k) const { return tab[JQ_MAX_WRANK + 32 * k + 16 + row]; }
+};
+
 #define JQ_ROWLANE_ARRAYS 4                                   // U, V, MU, NB
 #define JQ_ROWLANE_ROWS (JQ_ROWLANE_ARRAYS + JQ_MAXNC + 1)    // + carry rows + leak row
 
 // Forward sweep of one chunk; a.nslabs = number of waves (4 columns each), grid = a.nslabs, block = 64.
-template <int NPJ>
+// (WF: low-rank full leakage weights compiled in -- separate instantiations, the Diagonal fast path is untouched)
+template <int NPJ, bool WF = false>
 __global__ __launch_bounds__(64) void k_forward_rowlane(PropArgs a)
 {
     const int lane = threadIdx.x;
@@ -162,6 +193,9 @@ __global__ __launch_bounds__(64) void k_forward_rowlane(PropArgs a)
     double u = st[0], v = st[nw * 64];
     double leak = st[(size_t)(JQ_ROWLANE_ARRAYS + JQ_MAXNC) * nw * 64];
     const double sw = 0.5 * a.h * a.colinfo[col] * a.tabs[16 + row];
+    extern __shared__ double lds_w[];
+    RowW wl;
+    if constexpr (WF) wl.init(a, lds_w, lane, 64);
     RowOps<NPJ> o, nxt;
     o.Kn0 = row_load<NPJ>(as_const(a.stream), row);
     o.S0 = row_load<NPJ>(as_const(a.stream) + a.stride, row);
@@ -171,6 +205,16 @@ __global__ __launch_bounds__(64) void k_forward_rowlane(PropArgs a)
         double un, v05, vnew;
         leak = fma(wd, u * u, leak);
         row_state<NPJ>(a, o, sw, u, v, un, v05, vnew);
+        if constexpr (WF) {   // full weights: tr(vr' Wr vr) at t_n and t_n+1, 2 tr(vi05' Wr vi05), -2 tr(vi05' Wi vr(t_n)) (:700, :716-718)
+            double lk = 0.0;
+            for (int k = 0; k < wl.r; ++k) {
+                const double ak = wl.a(k), bk = wl.b(k);
+                const double p0 = rl_colsum(ak * u), q0 = rl_colsum(bk * u), p1 = rl_colsum(ak * un), q1 = rl_colsum(bk * un);
+                const double rr = rl_colsum(ak * v05), ss = rl_colsum(bk * v05);
+                lk += wl.lam(k) * ((p0 * p0 + q0 * q0) + (p1 * p1 + q1 * q1) + 2.0 * (rr * rr + ss * ss) - 2.0 * (ss * p0 - rr * q0));
+            }
+            if (row == 0) leak += lk;
+        }
         u = un;
         v = vnew;
         leak = fma(wd, u * u + 2.0 * v05 * v05, leak);
@@ -187,7 +231,7 @@ __global__ __launch_bounds__(64) void k_forward_rowlane(PropArgs a)
 }
 
 // Backward sweep of one chunk (state re-integration, adjoint step, trace scalars per wave and step).
-template <int NPJ>
+template <int NPJ, bool WF = false>
 __global__ __launch_bounds__(64) void k_backward_rowlane(PropArgs a)
 {
     const int lane = threadIdx.x;
@@ -232,6 +276,10 @@ __global__ __launch_bounds__(64) void k_backward_rowlane(PropArgs a)
             if (q < Nc) carry[q] = -u * rmv<NPJ, true>(0.0, Hs[q], nb);
     }
 
+    // full leakage weights in low-rank form (behind the constant images in LDS): forcing of src/evalobjgrad.jl:862, :882-888
+    RowW wl;
+    if constexpr (WF) wl.init(a, lds_c + (RESIDENT ? 0 : (size_t)2 * Nc * a.stride), lane, 64);
+    const double cf0 = a.forced ? 0.5 * a.h * a.tinv : 0.0;
     RowOps<NPJ> o, nxt;
     o.Kn0 = row_load<NPJ>(as_const(a.stream), row);
     o.S0 = row_load<NPJ>(as_const(a.stream) + a.stride, row);
@@ -245,6 +293,17 @@ __global__ __launch_bounds__(64) void k_backward_rowlane(PropArgs a)
         if (a.use_shift) R = fma(sw, nb, R);
         R = rmv<NPJ, false>(R, o.S0, mu);
         R = fma(cfw, u, R);
+        double wP = 0.0, wQ = 0.0, wG = 0.0;      // low-rank parts of c hi0, c (hi1 - hi0), c hr1
+        if constexpr (WF)
+            for (int k = 0; k < wl.r; ++k) {
+                const double ak = wl.a(k), bk = wl.b(k), cl = cf0 * wl.lam(k);
+                const double pu = rl_colsum(ak * u), qu = rl_colsum(bk * u), pn = rl_colsum(ak * un), qn = rl_colsum(bk * un);
+                const double rr = rl_colsum(ak * v05), ss = rl_colsum(bk * v05);
+                R = fma(cl * pu, ak, fma(cl * qu, bk, R));                    // + c hr0
+                wP = fma(cl * rr, ak, fma(cl * ss, bk, wP));                  // c Wr vi05 / T
+                wQ = fma(cl * pn, bk, fma(-cl * qn, ak, wQ));                 // c Wi vr(t_n) / T
+                wG = fma(cl * (pn - ss), ak, fma(cl * (qn + rr), bk, wG));    // c (Wr vr(t_n) + Wi vi05) / T
+            }
         const double X = row_horner<NPJ>(mu + R, R, o.S0, a.m);
         double L = rmv<NPJ, true>(0.0, o.Kn0, X);
         if (a.use_shift) L = fma(-sw, X, L);
@@ -253,8 +312,10 @@ __global__ __launch_bounds__(64) void k_backward_rowlane(PropArgs a)
         {
             double P = rmv<NPJ, true>(0.0, o.S05, nb);
             P = fma(-cfw, v05, P);
+            if constexpr (WF) P -= wP;
             L += P;
             Qv += P;
+            if constexpr (WF) Qv += wQ;
         }
         Qv = rmv<NPJ, false>(Qv, o.S05, L);
         const double nbn = row_horner<NPJ>((nb + L) + Qv, Qv, o.S05, a.m);
@@ -263,6 +324,7 @@ __global__ __launch_bounds__(64) void k_backward_rowlane(PropArgs a)
         if (a.use_shift) G = fma(sw, nbn, G);
         G = rmv<NPJ, false>(G, o.S1, X);
         G = fma(cfw, un, G);
+        if constexpr (WF) G += wG;
         // traces (adjoint_grad_calc!, src/evalobjgrad.jl:2581-2618), weighted and summed over the wave
         double t5p[JQ_MAXNC] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll

@@ -86,6 +86,12 @@ struct jq_handle {
     std::vector<double> Hconst, Hsym, Hanti, Uinit, Utr, Uti, wd, cfreq;
     std::vector<double> rfreq;  // uncoupled controls (Nunc > 0): params.Rfreq; empty otherwise
     double* d_rfreq = nullptr;
+    // Full leakage weights (jq_update_wmat): W = wmat_real + i wmat_imag = sum_{k < wrank} lam_k f_k f_k^H.  wrank > 0: `wd` is all
+    // zero, Wr / Wi keep the caller's matrices (re-planning applies them again), wlr is the kernels' table
+    // lam[JQ_MAX_WRANK] | a_k[NP], b_k[NP] per k in natural row order (PropArgs::wlr).
+    int wrank = 0;
+    std::vector<double> Wr, Wi, wlr;
+    double* d_wlr = nullptr;
     std::vector<double> tf, tb;
     // device buffers (owned)
     double *d_cimg = nullptr, *d_park = nullptr;
@@ -503,7 +509,7 @@ extern "C" void jq_destroy(jq_handle* h)
     }
     (void)hipSetDevice(h->device);
     if (h->emb) jq_destroy(h->emb);
-    double** bufs[] = {&h->d_cimg_l, &h->d_cimg_r, &h->d_rfreq, &h->d_wq, &h->d_pk2, &h->d_pack, &h->d_himg_r, &h->d_uinit_r, &h->d_vtr_r, &h->d_vti_r, &h->d_himg_l, &h->d_uinit_l, &h->d_vtr_l, &h->d_vti_l, &h->d_himg_c, &h->d_cimg_c, &h->d_park, &h->d_cimg, &h->d_himg,  &h->d_uimg,       &h->d_vtr,     &h->d_vti,    &h->d_tabs, &h->d_tf,   &h->d_tb,
+    double** bufs[] = {&h->d_wlr, &h->d_cimg_l, &h->d_cimg_r, &h->d_rfreq, &h->d_wq, &h->d_pk2, &h->d_pack, &h->d_himg_r, &h->d_uinit_r, &h->d_vtr_r, &h->d_vti_r, &h->d_himg_l, &h->d_uinit_l, &h->d_vtr_l, &h->d_vti_l, &h->d_himg_c, &h->d_cimg_c, &h->d_park, &h->d_cimg, &h->d_himg,  &h->d_uimg,       &h->d_vtr,     &h->d_vti,    &h->d_tabs, &h->d_tf,   &h->d_tb,
                        &h->d_cfreq, &h->d_pcof,       &h->d_stream,  &h->d_pq,     &h->d_state, &h->d_state_save,
                        &h->d_colinfo, &h->d_traces,   &h->d_R,       &h->d_grad,   &h->d_res};
     for (auto b : bufs)
@@ -521,7 +527,78 @@ static long long bwd_lds_tail(int NT, int Nc, int nwaves, long long park_doubles
     return 32LL * NT * 8 + (long long)Nc * 64 * nwaves * 8 + (long long)nwaves * park_doubles * 8 + 2LL * nwaves * 8 * Nc * 8;
 }
 
+// Dense column-major copy of a sparse operator in Julia's SparseMatrixCSC form (jq_csc: 1-based Int64 colptr / rowval); repeated
+// entries are summed.  The planner then sees exactly the structure it would see for the dense form of the same operator.
+static int csc_to_dense(jq_handle* h, const jq_csc* A, int Ntot, double* out, const char* what)
+{
+    char buf[200];
+    if (!A || !A->colptr || (!A->rowval && A->colptr[A->n] > 1) || (!A->nzval && A->colptr[A->n] > 1)) {
+        snprintf(buf, sizeof buf, "%s: NULL sparse descriptor or array", what);
+        return fail(h, JQ_EINVAL, buf);
+    }
+    if (A->m != Ntot || A->n != Ntot) {
+        snprintf(buf, sizeof buf, "%s: sparse operator is %lld x %lld, expected %d x %d", what, (long long)A->m, (long long)A->n, Ntot, Ntot);
+        return fail(h, JQ_EINVAL, buf);
+    }
+    std::fill(out, out + (size_t)Ntot * Ntot, 0.0);
+    if (A->colptr[0] != 1) {
+        snprintf(buf, sizeof buf, "%s: colptr[1] must be 1 (1-based SparseMatrixCSC fields)", what);
+        return fail(h, JQ_EINVAL, buf);
+    }
+    for (int j = 0; j < Ntot; ++j) {
+        const int64_t b = A->colptr[j], e = A->colptr[j + 1];
+        if (e < b || e - 1 > (int64_t)Ntot * Ntot * 4) {
+            snprintf(buf, sizeof buf, "%s: colptr is not non-decreasing", what);
+            return fail(h, JQ_EINVAL, buf);
+        }
+        for (int64_t k = b - 1; k < e - 1; ++k) {
+            const int64_t r = A->rowval[k];
+            if (r < 1 || r > Ntot) {
+                snprintf(buf, sizeof buf, "%s: rowval out of range (1 .. Ntot)", what);
+                return fail(h, JQ_EINVAL, buf);
+            }
+            out[(r - 1) + (size_t)Ntot * j] += A->nzval[k];
+        }
+    }
+    return JQ_OK;
+}
+
+static int create_dense(const jq_problem* p, jq_handle* h);
+
+// Sparse storage (jq_problem::Hconst_csc / Hsym_csc / Hanti_csc) is turned into the dense form first; everything else -- planning from
+// the nonzero structure, images, kernels -- is one code path.
 static int create_impl(const jq_problem* p, jq_handle* h)
+{
+    if (!p) return fail(h, JQ_EINVAL, "jq_create: problem is NULL");
+    const bool sparse = (!p->Hconst && p->Hconst_csc) || (!p->Hsym_ops && p->Hsym_csc) || (!p->Hanti_ops && p->Hanti_csc);
+    if (!sparse) return create_dense(p, h);
+    if (p->Ntot < 1 || p->Ntot > 256 || p->Ncoupled < 0 || p->Ncoupled > JQ_MAX_CONTROLS) return create_dense(p, h);      // (its messages)
+    const size_t nn = (size_t)p->Ntot * p->Ntot;
+    std::vector<double> H0, Hs, Ha;
+    jq_problem q = *p;
+    q.Hconst_csc = q.Hsym_csc = q.Hanti_csc = nullptr;
+    int rc;
+    if (!p->Hconst && p->Hconst_csc) {
+        H0.resize(nn);
+        if ((rc = csc_to_dense(h, p->Hconst_csc, p->Ntot, H0.data(), "jq_create: Hconst_csc"))) return rc;
+        q.Hconst = H0.data();
+    }
+    if (!p->Hsym_ops && p->Hsym_csc) {
+        Hs.resize(nn * std::max(p->Ncoupled, 1));
+        for (int k = 0; k < p->Ncoupled; ++k)
+            if ((rc = csc_to_dense(h, p->Hsym_csc + k, p->Ntot, Hs.data() + nn * k, "jq_create: Hsym_csc"))) return rc;
+        q.Hsym_ops = Hs.data();
+    }
+    if (!p->Hanti_ops && p->Hanti_csc) {
+        Ha.resize(nn * std::max(p->Ncoupled, 1));
+        for (int k = 0; k < p->Ncoupled; ++k)
+            if ((rc = csc_to_dense(h, p->Hanti_csc + k, p->Ntot, Ha.data() + nn * k, "jq_create: Hanti_csc"))) return rc;
+        q.Hanti_ops = Ha.data();
+    }
+    return create_dense(&q, h);
+}
+
+static int create_dense(const jq_problem* p, jq_handle* h)
 {
     if (!p) return fail(h, JQ_EINVAL, "jq_create: problem is NULL");
     if (p->Ntot < 1 || p->N < 1 || p->N > p->Ntot) return fail(h, JQ_EINVAL, "jq_create: need 1 <= N <= Ntot");
@@ -959,6 +1036,7 @@ static int try_embed(jq_handle* h, const jq_problem* p)
     q.Hconst = H0.data(); q.Hsym_ops = Hs.data(); q.Hanti_ops = Ha.data(); q.Uinit = U0.data();
     q.Utarget_r = Vr.data(); q.Utarget_i = Vi.data(); q.wmat_real_diag = wd.data(); q.Cfreq = h->cfreq.data();
     q.Hunc_ops = nullptr; q.Rfreq = nullptr;
+    q.Hconst_csc = q.Hsym_csc = q.Hanti_csc = nullptr;
     jq_handle* e = new (std::nothrow) jq_handle();
     if (!e) return fail(h, JQ_ENOMEM, "jq_create: out of host memory");
     e->is_emb = true;
@@ -1035,6 +1113,8 @@ extern "C" int jq_set_linear_solver(jq_handle* h, int32_t solver_id, int32_t max
     if (max_iter < 0) return fail(h, JQ_EINVAL, "jq_set_linear_solver: max_iter must be >= 0");
     if (solver_id == 2) {
         if (!(tol > 0.0)) return fail(h, JQ_EINVAL, "jq_set_linear_solver: JACOBI_SOLVER needs tol > 0");
+        if (h->wrank > 0)
+            return fail(h, JQ_EUNSUPPORTED, "jq_set_linear_solver: full leakage weights (jq_update_wmat) are implemented for the Neumann solver only");
     } else if (solver_id != 1) {
         return fail(h, JQ_EUNSUPPORTED, "jq_set_linear_solver: only NEUMANN_SOLVER (1) and JACOBI_SOLVER (2) are implemented");
     }
@@ -1055,6 +1135,9 @@ extern "C" int jq_set_integrator(jq_handle* h, int32_t integrator_id, int32_t ma
     }
     if (integrator_id != 2) return fail(h, JQ_EUNSUPPORTED, "jq_set_integrator: 1 = Stormer-Verlet, 2 = implicit midpoint");
     if (max_iter < 1 || !(tol > 0.0)) return fail(h, JQ_EINVAL, "jq_set_integrator: implicit midpoint needs max_iter >= 1 and tol > 0");
+    if (h->wrank > 0)
+        return fail(h, JQ_EUNSUPPORTED, "jq_set_integrator: the handle carries full leakage weights (jq_update_wmat); the implicit-midpoint "
+                                        "path weights with params.wmat (Diagonal): pass it with jq_update_wmat_diag first");
     if (h->parts > 1)
         return fail(h, JQ_EUNSUPPORTED, "jq_set_integrator: the implicit-midpoint path is implemented for N <= 16 (its solver's "
                                         "per-evaluation convergence test needs all columns of a sample in one workgroup)");
@@ -1118,6 +1201,7 @@ static int replan(jq_handle* h, const double* Hconst)
         }
     }
     if (rc == JQ_OK && h->integrator == 2) rc = jq_set_integrator(n, 2, h->imr_max_iter, h->imr_tol);
+    if (rc == JQ_OK && h->wrank > 0) rc = jq_update_wmat(n, h->Wr.data(), h->Wi.data());      // full leakage weights
     if (rc != JQ_OK) {
         h->err = "jq_update_hconst: re-planning for the new Hconst failed: " + n->err;
         jq_destroy(n);
@@ -1153,14 +1237,189 @@ extern "C" int jq_update_hconst(jq_handle* h, const double* Hconst)
     return upload_operators(h);
 }
 
+extern "C" int jq_update_hconst_csc(jq_handle* h, const jq_csc* Hconst)
+{
+    if (!h) return JQ_EINVAL;
+    if (!Hconst) return fail(h, JQ_EINVAL, "jq_update_hconst_csc: NULL pointer");
+    std::vector<double> H0((size_t)h->Ntot * h->Ntot);
+    const int rc = csc_to_dense(h, Hconst, h->Ntot, H0.data(), "jq_update_hconst_csc");
+    return rc ? rc : jq_update_hconst(h, H0.data());
+}
+
 extern "C" int jq_update_wmat_diag(jq_handle* h, const double* w)
 {
     if (!h) return JQ_EINVAL;
     if (!w) return fail(h, JQ_EINVAL, "jq_update_wmat_diag: NULL pointer");
     if (!h->subs.empty()) return multi_forall(h, [&](jq_handle* sub) { return jq_update_wmat_diag(sub, w); });
     h->wd.assign(w, w + h->Ntot);
-    if (h->emb) embed_rows(w, h->Ntot, 1, h->emb_row, h->emb->Ntot, h->emb->wd.data());
+    h->wrank = 0;      // back to Diagonal weights
+    h->Wr.clear(), h->Wi.clear();
+    if (h->emb) {
+        embed_rows(w, h->Ntot, 1, h->emb_row, h->emb->Ntot, h->emb->wd.data());
+        h->emb->wrank = 0;
+    }
     return JQ_OK;
+}
+
+// Eigen-decomposition of a Hermitian n x n matrix A = Ar + i Ai (column-major) by cyclic complex Jacobi rotations: on return
+// lam[k] and the columns V[:, k] = Vr + i Vi with A = V diag(lam) V^H.  n <= 256, called once per jq_update_wmat.
+static void hermitian_eig(int n, std::vector<double>& Ar, std::vector<double>& Ai, std::vector<double>& lam, std::vector<double>& Vr,
+                          std::vector<double>& Vi)
+{
+    Vr.assign((size_t)n * n, 0.0);
+    Vi.assign((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) Vr[i + (size_t)n * i] = 1.0;
+    auto at = [n](std::vector<double>& M, int i, int j) -> double& { return M[i + (size_t)n * j]; };
+    double total = 0.0;
+    for (size_t i = 0; i < Ar.size(); ++i) total += Ar[i] * Ar[i] + Ai[i] * Ai[i];
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0;
+        for (int q = 1; q < n; ++q)
+            for (int p = 0; p < q; ++p) off += at(Ar, p, q) * at(Ar, p, q) + at(Ai, p, q) * at(Ai, p, q);
+        if (off <= 1e-32 * total) break;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double xr = at(Ar, p, q), xi = at(Ai, p, q);
+                const double g = std::hypot(xr, xi);
+                if (g == 0.0 || g * g <= 1e-36 * total) continue;
+                // a_pq = g e^{i phi}; with P = diag(1, e^{-i phi}) the 2 x 2 block is P [[a_pp, g], [g, a_qq]] P^H, the real
+                // rotation R = [[c, s], [-s, c]] diagonalises the real block: U = P R
+                const double er = xr / g, ei = xi / g;      // e^{i phi}
+                const double theta = (at(Ar, q, q) - at(Ar, p, p)) / (2.0 * g);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+                // U = [[c, s], [-s e^{-i phi}, c e^{-i phi}]] (rows p, q; columns p, q)
+                // columns: M[:, p] <- c M[:, p] - s e^{-i phi} M[:, q] ; M[:, q] <- s M[:, p] + c e^{-i phi} M[:, q]
+                auto cols = [&](std::vector<double>& Mr, std::vector<double>& Mi) {
+                    for (int i = 0; i < n; ++i) {
+                        const double pr = at(Mr, i, p), pi = at(Mi, i, p), qr = at(Mr, i, q), qi = at(Mi, i, q);
+                        const double wr = er * qr + ei * qi, wi = er * qi - ei * qr;      // e^{-i phi} M[i, q]
+                        at(Mr, i, p) = c * pr - sn * wr;
+                        at(Mi, i, p) = c * pi - sn * wi;
+                        at(Mr, i, q) = sn * pr + c * wr;
+                        at(Mi, i, q) = sn * pi + c * wi;
+                    }
+                };
+                cols(Ar, Ai);
+                cols(Vr, Vi);
+                // rows (U^H from the left): M[p, :] <- c M[p, :] - s e^{i phi} M[q, :] ; M[q, :] <- s M[p, :] + c e^{i phi} M[q, :]
+                for (int j = 0; j < n; ++j) {
+                    const double pr = at(Ar, p, j), pi = at(Ai, p, j), qr = at(Ar, q, j), qi = at(Ai, q, j);
+                    const double wr = er * qr - ei * qi, wi = er * qi + ei * qr;          // e^{i phi} M[q, j]
+                    at(Ar, p, j) = c * pr - sn * wr;
+                    at(Ai, p, j) = c * pi - sn * wi;
+                    at(Ar, q, j) = sn * pr + c * wr;
+                    at(Ai, q, j) = sn * pi + c * wi;
+                }
+                at(Ar, p, q) = at(Ai, p, q) = at(Ar, q, p) = at(Ai, q, p) = 0.0;
+                at(Ai, p, p) = at(Ai, q, q) = 0.0;
+            }
+    }
+    lam.resize(n);
+    for (int i = 0; i < n; ++i) lam[i] = at(Ar, i, i);
+}
+
+// the kernels' low-rank table of one (sub-)handle from the eigenpairs: lam[JQ_MAX_WRANK] | a_k[NP], b_k[NP] per k
+static int upload_wlr(jq_handle* h, const std::vector<int>& keep, const std::vector<double>& lam, const std::vector<double>& Vr,
+                      const std::vector<double>& Vi, int n, const std::vector<int>* row_map)
+{
+    HIPCHK(h, hipSetDevice(h->device));
+    const int stride = h->NP;
+    h->wlr.assign((size_t)JQ_MAX_WRANK + (size_t)2 * JQ_MAX_WRANK * stride, 0.0);
+    for (size_t k = 0; k < keep.size(); ++k) {
+        h->wlr[k] = lam[keep[k]];
+        for (int i = 0; i < n; ++i) {
+            const int row = row_map ? (*row_map)[i] : i;
+            h->wlr[JQ_MAX_WRANK + (2 * k) * stride + row] = Vr[i + (size_t)n * keep[k]];
+            h->wlr[JQ_MAX_WRANK + (2 * k + 1) * stride + row] = Vi[i + (size_t)n * keep[k]];
+        }
+    }
+    int rc;
+    if (!h->d_wlr && (rc = dev_alloc(h, &h->d_wlr, h->wlr.size()))) return rc;
+    HIPCHK(h, hipMemcpy(h->d_wlr, h->wlr.data(), h->wlr.size() * sizeof(double), hipMemcpyHostToDevice));
+    h->wrank = (int)keep.size();
+    std::fill(h->wd.begin(), h->wd.end(), 0.0);
+    return JQ_OK;
+}
+
+extern "C" int jq_update_wmat(jq_handle* h, const double* Wr, const double* Wi)
+{
+    if (!h) return JQ_EINVAL;
+    if (!Wr) return fail(h, JQ_EINVAL, "jq_update_wmat: NULL pointer");
+    if (!h->subs.empty()) return multi_forall(h, [&](jq_handle* sub) { return jq_update_wmat(sub, Wr, Wi); });
+    const int n = h->Ntot;
+    const size_t nn = (size_t)n * n;
+    double wmax = 0.0;
+    bool diagonal = true;
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) {
+            const double a = Wr[i + (size_t)n * j], b = Wi ? Wi[i + (size_t)n * j] : 0.0;
+            if (!std::isfinite(a) || !std::isfinite(b)) return fail(h, JQ_EINVAL, "jq_update_wmat: non-finite entry");
+            wmax = std::max(wmax, std::max(std::fabs(a), std::fabs(b)));
+            if (b != 0.0 || (i != j && a != 0.0)) diagonal = false;
+        }
+    if (diagonal) {      // Diagonal weights written as a full matrix: the fast path
+        std::vector<double> d(n);
+        for (int i = 0; i < n; ++i) d[i] = Wr[i + (size_t)n * i];
+        return jq_update_wmat_diag(h, d.data());
+    }
+    if (h->integrator == 2)
+        return fail(h, JQ_EUNSUPPORTED, "jq_update_wmat: the implicit-midpoint path weights with params.wmat (always Diagonal, "
+                                        "src/evalobjgrad.jl:90, :1155): pass it with jq_update_wmat_diag");
+    if (h->solver_id != 1)
+        return fail(h, JQ_EUNSUPPORTED, "jq_update_wmat: full leakage weights are implemented for the Neumann solver only");
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i <= j; ++i) {
+            const double ds = Wr[i + (size_t)n * j] - Wr[j + (size_t)n * i];
+            const double da = Wi ? Wi[i + (size_t)n * j] + Wi[j + (size_t)n * i] : 0.0;
+            if (std::fabs(ds) > 1e-12 * wmax || std::fabs(da) > 1e-12 * wmax)
+                return fail(h, JQ_EUNSUPPORTED, "jq_update_wmat: wmat_real + i wmat_imag must be Hermitian (wmat_real symmetric, wmat_imag "
+                                                "antisymmetric), as objparams builds it from forb_states (src/evalobjgrad.jl:220-231)");
+        }
+    std::vector<double> Ar(Wr, Wr + nn), Ai(nn, 0.0), lam, Vr, Vi;
+    if (Wi) Ai.assign(Wi, Wi + nn);
+    for (int j = 0; j < n; ++j)      // exactly Hermitian input for the rotations
+        for (int i = 0; i < j; ++i) {
+            const double sr = 0.5 * (Ar[i + (size_t)n * j] + Ar[j + (size_t)n * i]), si = 0.5 * (Ai[i + (size_t)n * j] - Ai[j + (size_t)n * i]);
+            Ar[i + (size_t)n * j] = Ar[j + (size_t)n * i] = sr;
+            Ai[i + (size_t)n * j] = si, Ai[j + (size_t)n * i] = -si;
+        }
+    for (int i = 0; i < n; ++i) Ai[i + (size_t)n * i] = 0.0;
+    hermitian_eig(n, Ar, Ai, lam, Vr, Vi);
+    double lmax = 0.0;
+    for (double l : lam) lmax = std::max(lmax, std::fabs(l));
+    std::vector<int> keep;
+    for (int k = 0; k < n; ++k)
+        if (std::fabs(lam[k]) > 1e-13 * lmax) keep.push_back(k);
+    if ((int)keep.size() > JQ_MAX_WRANK) {
+        char buf[200];
+        snprintf(buf, sizeof buf, "jq_update_wmat: the weight matrix has rank %d; full leakage weights are implemented up to rank %d "
+                                  "(forbidden states)", (int)keep.size(), JQ_MAX_WRANK);
+        return fail(h, JQ_EUNSUPPORTED, buf);
+    }
+    {   // the kept terms must reproduce W (guards the decomposition itself)
+        double err = 0.0;
+        for (int j = 0; j < n; ++j)
+            for (int i = 0; i < n; ++i) {
+                double sr = 0.0, si = 0.0;
+                for (int k : keep) {
+                    const double ar = Vr[i + (size_t)n * k], ai = Vi[i + (size_t)n * k], br = Vr[j + (size_t)n * k], bi = Vi[j + (size_t)n * k];
+                    sr += lam[k] * (ar * br + ai * bi);      // f_i conj(f_j)
+                    si += lam[k] * (ai * br - ar * bi);
+                }
+                err = std::max(err, std::max(std::fabs(sr - Wr[i + (size_t)n * j]), std::fabs(si - (Wi ? Wi[i + (size_t)n * j] : 0.0))));
+            }
+        if (err > 1e-11 * wmax) return fail(h, JQ_EHIP, "jq_update_wmat: internal error, the eigen-decomposition does not reproduce W");
+    }
+    h->Wr.assign(Wr, Wr + nn);
+    h->Wi.assign(nn, 0.0);
+    if (Wi) h->Wi.assign(Wi, Wi + nn);
+    int rc = upload_wlr(h, keep, lam, Vr, Vi, n, nullptr);
+    if (rc == JQ_OK && h->emb) {
+        rc = upload_wlr(h->emb, keep, lam, Vr, Vi, n, &h->emb_row);
+        if (rc != JQ_OK) h->err = h->emb->err;
+    }
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1286,6 +1545,25 @@ static int select_quad_kernels(jq_handle* h, int spw, prop_kernel_t* fwd, prop_k
     return fail(h, JQ_EUNSUPPORTED, "unsupported Hilbert dimension");
 }
 
+// ... with the low-rank full leakage weights compiled in (jq_update_wmat; one slab per workgroup)
+#define JQ_DECLQW(nt)                                                                  \
+    extern template __global__ void k_forward<nt, JQ_BW_T4Q, 1, false, true>(PropArgs);    \
+    extern template __global__ void k_backward<nt, JQ_BW_T4Q, 1, false, true>(PropArgs);
+JQ_DECLQW(1) JQ_DECLQW(2) JQ_DECLQW(3) JQ_DECLQW(4) JQ_DECLQW(5) JQ_DECLQW(6) JQ_DECLQW(7) JQ_DECLQW(8)
+#undef JQ_DECLQW
+static int select_quad_w_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
+{
+#define JQ_PICKQW(nt)                                          \
+    if (h->NT == nt) {                                         \
+        *fwd = k_forward<nt, JQ_BW_T4Q, 1, false, true>;       \
+        *bwd = k_backward<nt, JQ_BW_T4Q, 1, false, true>;      \
+        return JQ_OK;                                          \
+    }
+    JQ_PICKQW(1) JQ_PICKQW(2) JQ_PICKQW(3) JQ_PICKQW(4) JQ_PICKQW(5) JQ_PICKQW(6) JQ_PICKQW(7) JQ_PICKQW(8)
+#undef JQ_PICKQW
+    return fail(h, JQ_EUNSUPPORTED, "unsupported Hilbert dimension");
+}
+
 #define JQ_DECLC(nt, bw)                                                   \
     extern template __global__ void k_forward_coop<nt, bw>(PropArgs);       \
     extern template __global__ void k_backward_coop<nt, bw>(PropArgs);
@@ -1348,6 +1626,8 @@ static int select_lane_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* 
 #define JQ_DECLR(npj)                                                     \
     extern template __global__ void k_forward_rowlane<npj>(PropArgs);     \
     extern template __global__ void k_backward_rowlane<npj>(PropArgs);    \
+    extern template __global__ void k_forward_rowlane<npj, true>(PropArgs);     \
+    extern template __global__ void k_backward_rowlane<npj, true>(PropArgs);    \
     extern template __global__ void k_backward_rowlane2<npj>(PropArgs);
 JQ_FOR_EACH_ROWLANE(JQ_DECLR)
 #undef JQ_DECLR
@@ -1356,8 +1636,8 @@ static int select_rowlane_kernels(jq_handle* h, bool split, prop_kernel_t* fwd, 
 {
 #define JQ_PICKR(npj)                                                          \
     if (h->rl_npj == npj) {                                                    \
-        *fwd = k_forward_rowlane<npj>;                                         \
-        *bwd = split ? k_backward_rowlane2<npj> : k_backward_rowlane<npj>;     \
+        *fwd = h->wrank > 0 ? k_forward_rowlane<npj, true> : k_forward_rowlane<npj>;                                         \
+        *bwd = h->wrank > 0 ? k_backward_rowlane<npj, true> : split ? k_backward_rowlane2<npj> : k_backward_rowlane<npj>;     \
         return JQ_OK;                                                          \
     }
     JQ_FOR_EACH_ROWLANE(JQ_PICKR)
@@ -1469,7 +1749,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     const long long ncols_split = (long long)nsamples * h->N;
     const bool small_family_batch = (h->rl_npj > 0 && ncols_split <= h->rl_max_cols) ||
                                     (h->lane_np > 0 && ncols_split >= h->lane_min_cols && ncols_split <= h->lane_max_cols);
-    if (!h->in_split && !small_family_batch && h->quad_max_slabs > 0 && h->integrator == 1 && h->solver_id == 1 && !hist_r && eps && nsamples > 1 && !getenv("JQ_NOSPLIT")) {
+    if (!h->in_split && !small_family_batch && h->wrank == 0 && h->quad_max_slabs > 0 && h->integrator == 1 && h->solver_id == 1 && !hist_r && eps && nsamples > 1 && !getenv("JQ_NOSPLIT")) {
         // candidates: the largest number of FULL rounds of the quad-layout kernels with 1, 2 or 3 slabs per workgroup
         long long n_main = 0;
         double best = t4_plan_cost(h, nsamples) - 1e-9;
@@ -1531,7 +1811,8 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     // rows are the user's), the implicit-midpoint path too.
     if (h->emb && !hist_r && h->integrator == 1) {
         const long long nc_used = (long long)nsamples * h->N;
-        const bool small_family = h->solver_id == 1 && ((h->rl_npj > 0 && nc_used <= h->rl_max_cols) ||
+        // (full leakage weights: the row-lane kernels take every batch of an Ntot <= 16 problem -- the lane kernels have no low-rank terms)
+        const bool small_family = h->solver_id == 1 && ((h->rl_npj > 0 && (nc_used <= h->rl_max_cols || h->wrank > 0)) ||
                                                         (h->lane_np > 0 && nc_used >= h->lane_min_cols && nc_used <= h->lane_max_cols));
         if (h->emb_mode == 2 || !small_family) {
             jq_handle* e = h->emb;
@@ -1567,8 +1848,14 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     if (imr_coop && (h->mat_elems_c == 0 || (imr_hbm && !(h->NT == 6 && h->BWc == 5))))
         return fail(h, JQ_EUNSUPPORTED, "implicit midpoint: no kernels for these operators (no cooperative layout / images that do not fit the LDS)");
     const int cpw = imr_rl ? imr_cols_per_wave(h->N) : 4;   // columns per wave of the row-lane kernels
-    const bool rl = imr_rl || (!imr && h->rl_npj > 0 && h->solver_id == 1 && ncols_used <= h->rl_max_cols);
-    const bool lane = !imr && !rl && h->lane_np > 0 && h->solver_id == 1 && ncols_used >= h->lane_min_cols && ncols_used <= h->lane_max_cols;
+    // Full leakage weights (jq_update_wmat; low-rank terms in the kernels): row-lane kernels for every batch of an Ntot <= 16 problem,
+    // quad-layout kernels with one slab per workgroup (their WLRT instantiations) for the 4 x 4 x n structure, else the cooperative
+    // (small batches, Ntot > 96) or the band / dense / JQ_BW_OD slab kernels; no lane, cooperative-quad, JQ_BW_T4 slab kernels.
+    const bool wfull = h->wrank > 0;
+    if (wfull && (imr || h->solver_id != 1))
+        return fail(h, JQ_EUNSUPPORTED, "full leakage weights (jq_update_wmat): Stormer-Verlet integrator with the Neumann solver only");
+    const bool rl = imr_rl || (!imr && h->rl_npj > 0 && h->solver_id == 1 && (ncols_used <= h->rl_max_cols || wfull));
+    const bool lane = !imr && !rl && !wfull && h->lane_np > 0 && h->solver_id == 1 && ncols_used >= h->lane_min_cols && ncols_used <= h->lane_max_cols;
     const long long nwaves_rl = (ncols_used + cpw - 1) / cpw;
     const long long ncols = rl ? 4 * nwaves_rl : (ncols_used + 63) / 64 * 64;      // row-lane: column SLOTS (4 per wave)
     // JQ_BW_T4 structure, small batches: the quad-layout kernels (one workgroup per slab, its four waves carry four columns
@@ -1599,13 +1886,17 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
             spw = std::max(1, std::min(3, atoi(e) + 1));
             while (spw > 1 && quad_lds(spw) > 163840) --spw;
         }
+        if (wfull) spw = 1;      // (the instantiations with the low-rank terms: one slab per workgroup, any number of rounds)
     }
+    if (wfull && !rl && h->BW == JQ_BW_T4 && spw == 0)
+        return fail(h, JQ_EUNSUPPORTED, "full leakage weights (jq_update_wmat): the quad-layout kernels are disabled or do not fit for this "
+                                        "4 x 4 x n problem, and the JQ_BW_T4 slab kernels have no low-rank terms");
     // (one slab per workgroup, one wave per SIMD, the operators of a step in registers for all its fixed-point iterations; a
     // two-slab variant that re-reads them from LDS was measured 1.4 x slower, jq_kernel_inst.hip)
     if (imr_quad) spw = 1;
     // latency regime of the JQ_BW_T4 structure: one workgroup of NT waves per column quad (jq_cq_kernels.h)
     const long long nquads_used = (ncols_used + 3) / 4;
-    const bool cq = !imr && !lane && !rl && h->solver_id == 1 && h->cq_max_quads > 0 && nquads_used <= h->cq_max_quads &&
+    const bool cq = !imr && !lane && !rl && !wfull && h->solver_id == 1 && h->cq_max_quads > 0 && nquads_used <= h->cq_max_quads &&
                     !getenv("JQ_QUAD8");      // (JQ_QUAD8 asks for a quad-layout variant explicitly)
     const int qps = h->parts > 1 ? 4 : (h->sps * h->N + 3) / 4;      // column quads of a full slab
     // ... and of the implicit-midpoint integrator (jq_cq_imr_kernels.h): N = 4, one workgroup of NT waves per evaluation
@@ -1615,7 +1906,12 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     if (cq) spw = 0;
     const bool quad = spw > 0;
     const bool quad8 = spw > 1;
-    const bool coop = imr_coop || (!cq && !quad && !lane && !rl && h->NT >= 2 && h->coop_ok && (h->solver_id == 1 || h->big) && nslabs <= h->coop_max_slabs);      // (Ntot > 96: also the Jacobi solver)
+    // (full leakage weights: the cooperative kernels sum their column dot products over the waves through an LDS record of
+    //  2 x JQ_COOP_WDOTS x NT x 16 doubles behind the Jacobi norms; where that does not fit next to the operator slots the slab kernels serve)
+    const size_t coop_w_bytes = wfull ? (size_t)2 * JQ_COOP_WDOTS * h->NT * 16 * 8 : 0;
+    const bool coop_w_fits = !wfull || h->NT > 6 ||
+                             (size_t)2 * h->mat_elems_c * 8 + (size_t)32 * h->NT * 8 + (size_t)2 * h->KT * 64 * 8 + (size_t)16 * h->NT * 8 + coop_w_bytes <= 163840;
+    const bool coop = imr_coop || (!cq && !quad && !lane && !rl && h->NT >= 2 && h->coop_ok && coop_w_fits && (h->solver_id == 1 || h->big) && nslabs <= h->coop_max_slabs);      // (Ntot > 96: also the Jacobi solver)
     // row-lane kernels, Stormer-Verlet: the backward sweep's two chains on two waves (jq_rowlane_kernels.h k_backward_rowlane2);
     // JQ_RL_SPLIT=0: one wave (tests: the two variants must agree bit for bit)
     // (both integrators; while the doubled wave count still finds idle issue slots: measured with scripts/time_rl_crossover.py --
@@ -1623,6 +1919,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     bool rl_split = rl && 2 * nwaves_rl <= (long long)(h->rl_npj > 8 ? 4 : 12) * h->num_cu;
     if (const char* e = getenv("JQ_RL_SPLIT"))
         if (atoi(e) == 0) rl_split = false;
+    if (wfull) rl_split = false;      // (the one-wave backward kernel carries the low-rank terms)
     prop_kernel_t kfwd, kbwd;
     lane_init_t klinit = nullptr;
     lane_term_t klterm = nullptr;
@@ -1633,7 +1930,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
              : rl ? select_rowlane_kernels(h, rl_split, &kfwd, &kbwd)
              : lane ? select_lane_kernels(h, &kfwd, &kbwd, &klinit, &klterm)
                   : cq ? select_cq_kernels(h, &kfwd, &kbwd)
-                  : coop ? select_coop_kernels(h, &kfwd, &kbwd) : quad ? select_quad_kernels(h, spw, &kfwd, &kbwd) : select_kernels(h, &kfwd, &kbwd);
+                  : coop ? select_coop_kernels(h, &kfwd, &kbwd) : quad ? (wfull ? select_quad_w_kernels(h, &kfwd, &kbwd) : select_quad_kernels(h, spw, &kfwd, &kbwd)) : select_kernels(h, &kfwd, &kbwd);
     if (rc) return rc;
     const int nblocks = (cq || imr_cq) ? 4 * nslabs : rl ? (int)nwaves_rl : lane ? (int)(ncols / 64) : quad8 ? (nslabs + spw - 1) / spw : (coop || quad) ? nslabs : (nslabs + JQ_WAVES - 1) / JQ_WAVES;
     const int nthreads = (lane || rl) ? 64 : (coop || cq || imr_cq) ? 64 * h->NT : quad8 ? 256 * spw : 256;
@@ -1729,6 +2026,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     a.tabs = h->d_tabs; a.stride = stride; a.pieces = (int)(stride * 8 / 1024); a.nslots = h->nslots; a.m = h->m;
     a.nslabs = rl ? (int)nwaves_rl : lane ? (int)ncols : nslabs; a.Ncoupled = ctrl_gstart(h->Nc, 1) /* first control group */; a.Ntot = h->Ntot; a.N = h->N; a.use_shift = use_shift ? 1 : 0;
     a.tinv = 1.0 / h->T; a.state_stride = h->state_stride; a.parts = h->parts; a.nsamples = nsamples; a.sps = h->sps; a.qps = qps;
+    a.wlr = h->d_wlr; a.wrank = h->wrank; a.wstride = h->NP;
     // JACOBI_SOLVER: the kernels iterate on c-scaled right-hand sides (A = c rhs, c = h / 2: DESIGN.md section 3), so their
     // residual norm is |c| times the reference's ||X_j - X_{j-1}|| (src/linear_solvers.jl:121): the threshold is scaled alike
     a.jacobi_tol2 = (h->solver_id == 2) ? (h->solver_tol * 0.5 * dt) * (h->solver_tol * 0.5 * dt) : 0.0;
@@ -1745,9 +2043,9 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
                              : batch < 0 ? (size_t)(2 * JQ_WIN_TPS + 2 * h->NcK) * stride * 8
                                          : (size_t)2 * stride * 8;
     const size_t lds_cq = lds_stage + (size_t)32 * h->NT * 8 + (size_t)6 * (h->NT + 2) * 64 * 8 + (size_t)std::max(2, h->NcK + (h->NcK + 1) / 2) * h->NT * 64 * 8;      // tables, x exchange, trace hand-off / wg-sum scratch (one region)
-    const size_t lds_fwd = (lane || rl) ? 0 : (cq || imr_cq) ? lds_cq : imr_coop ? coop_imr_lds_bytes(h->NT, imr_hbm ? 0 : stride)
-                                           : lds_stage + (size_t)32 * h->NT * 8 + (coop ? (size_t)2 * h->KT * 64 * 8 + (size_t)16 * h->NT * 8 : 0);      // (+ the Jacobi solver's column norms [NT][16])
-    const size_t lds_bwd = rl ? (h->rl_npj > 8 ? (size_t)2 * h->NcK * h->rl_stride * 8 : 0) + (rl_split ? (size_t)2 * 3 * 64 * 8 : 0) /* records: 3 values per lane and slot, implicit midpoint 2 */ : lane ? 0 : (coop || cq || imr_cq) ? lds_fwd
+    const size_t lds_fwd = rl ? (wfull ? (size_t)JQ_RL_WTAB * 8 : 0) : lane ? 0 : (cq || imr_cq) ? lds_cq : imr_coop ? coop_imr_lds_bytes(h->NT, imr_hbm ? 0 : stride)
+                                           : lds_stage + (size_t)32 * h->NT * 8 + (coop ? (size_t)2 * h->KT * 64 * 8 + (size_t)16 * h->NT * 8 + coop_w_bytes : 0);      // (+ the Jacobi solver's column norms [NT][16], the low-rank weights' dot exchange)
+    const size_t lds_bwd = rl ? (h->rl_npj > 8 ? (size_t)2 * h->NcK * h->rl_stride * 8 : 0) + (rl_split ? (size_t)2 * 3 * 64 * 8 : 0) /* records: 3 values per lane and slot, implicit midpoint 2 */ + (wfull ? (size_t)JQ_RL_WTAB * 8 : 0) /* low-rank weight table */ : lane ? 0 : (coop || cq || imr_cq) ? lds_fwd
                                 : imr_quad ? lds_fwd + (size_t)JQ_MAXNC * nthreads * 8 + (size_t)(nthreads / 64) * h->NT * 64 * 8
                                 : quad ? lds_stage + (size_t)bwd_lds_tail(h->NT, h->NcK, nthreads / 64, (long long)h->NT * 64)   // (a 16-row block per register)
                                 : lds_stage + (size_t)bwd_lds_tail(h->NT, h->NcK, JQ_WAVES, h->park_lds ? (long long)h->KT * 64 : 0);

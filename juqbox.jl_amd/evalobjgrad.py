@@ -26,6 +26,32 @@ def _ptr(a):
     return a.ctypes.data_as(_lib.c_dp) if a is not None else None
 
 
+class _Csc:
+    """A dense operator in the fields of Julia's SparseMatrixCSC{Float64,Int64} (1-based Int64 colptr / rowval) with the
+    jq_csc descriptor pointing at them -- what the Julia binding passes for use_sparse = true problems."""
+
+    def __init__(self, M):
+        M = np.asarray(M, dtype=np.float64)
+        n = M.shape[0]
+        cols, rows, vals = [1], [], []
+        for j in range(n):
+            nz = np.nonzero(M[:, j])[0]
+            rows.extend((nz + 1).tolist())
+            vals.extend(M[nz, j].tolist())
+            cols.append(len(rows) + 1)
+        self.colptr = np.array(cols, dtype=np.int64)
+        self.rowval = np.array(rows if rows else [1], dtype=np.int64)
+        self.nzval = np.array(vals if vals else [0.0], dtype=np.float64)
+        self.desc = _lib.jq_csc(n, n, self.colptr.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+                                self.rowval.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), _ptr(self.nzval))
+
+
+def _csc_array(mats):
+    keep = [_Csc(M) for M in mats]
+    arr = (_lib.jq_csc * max(len(keep), 1))(*[k.desc for k in keep])
+    return keep, arr
+
+
 class Working_Arrays_HIP:
     """Owns the device handle for one `objparams`.  Mutable fields of `params` that scripts change
     after construction (Hconst, wmat_real, Utarget_r/i, linear_solver.max_iter) are re-synchronised
@@ -35,13 +61,30 @@ class Working_Arrays_HIP:
     SOLVERS = (NEUMANN_SOLVER, JACOBI_SOLVER)
 
     def _weights(self, p):
-        """leakage weights of this path: params.wmat_real (src/evalobjgrad.jl:583)"""
+        """leakage weights of this path: params.wmat_real (src/evalobjgrad.jl:583) -- a vector (the Diagonal default) or, with
+        use_custom_forbidden (:214-232), a full matrix next to params.wmat_imag: then (wmat_real, wmat_imag) stacked"""
+        if np.ndim(p.wmat_real) == 2:
+            wi = getattr(p, "wmat_imag", None)
+            wi = np.zeros_like(p.wmat_real) if wi is None or np.ndim(wi) != 2 else wi      # (Diagonal(zeros(Ntot)), :236)
+            return np.concatenate([_f64(p.wmat_real), _f64(wi)])
         return _f64(p.wmat_real)
 
-    def __init__(self, params: objparams, nCoeff: int, devices=None):
+    def _push_weights(self, w):
+        L, p, h = _lib.load(), self.params, self.handle
+        if w.size == p.Ntot:
+            _lib.check(L.jq_update_wmat_diag(h, _ptr(w)), h)
+        elif w.size == 2 * p.Ntot * p.Ntot:
+            wr, wi = w[:p.Ntot * p.Ntot].copy(), w[p.Ntot * p.Ntot:].copy()
+            _lib.check(L.jq_update_wmat(h, _ptr(wr), _ptr(wi)), h)
+        else:
+            raise ValueError("wmat_real must be a vector of length Ntot (Diagonal) or an Ntot x Ntot matrix")
+
+    def __init__(self, params: objparams, nCoeff: int, devices=None, csc=None):
         """devices: None = the current HIP device (one process per GPU); an int n or a list of device ids = ONE process
         driving several GPUs (jq_create_multi: the ensemble of eval_f_g_grad is sharded over them and summed with one
-        RCCL all-reduce inside the library)."""
+        RCCL all-reduce inside the library).
+        csc: hand the operators over in sparse (SparseMatrixCSC) storage like the Julia binding does for use_sparse = true
+        problems (default: params.use_sparse); the results are bit-identical to the dense form."""
         L = _lib.load()
         if params.linear_solver.solver_id not in self.SOLVERS:
             raise ValueError("Please specify a supported linear solver")
@@ -52,7 +95,8 @@ class Working_Arrays_HIP:
         hs = np.concatenate([_f64(h) for h in p.Hsym_ops]) if p.Ncoupled else np.zeros(1)
         ha = np.concatenate([_f64(h) for h in p.Hanti_ops]) if p.Ncoupled else np.zeros(1)
         self._hconst = _f64(p.Hconst).copy()
-        self._wd = self._weights(p).copy()
+        w0 = self._weights(p).copy()
+        self._wd = w0 if w0.size == p.Ntot else np.zeros(p.Ntot)      # (full weights follow the creation: jq_update_wmat)
         self._utr = _f64(p.Utarget_r).copy()
         self._uti = _f64(p.Utarget_i).copy()
         self._m = int(p.linear_solver.max_iter) if self.INTEGRATOR == Stormer_Verlet else 0
@@ -61,8 +105,18 @@ class Working_Arrays_HIP:
         hu = np.concatenate([_f64(h) for h in p.Hunc_ops]) if nunc else None
         rf = _f64(p.Rfreq[:nunc]) if nunc else None
         keep = [self._hconst, hs, ha, _f64(p.Uinit), self._utr, self._uti, self._wd, _f64(p.Cfreq[:p.Ncoupled + nunc, :]), hu, rf]
-        prob = _lib.jq_problem(p.Ntot, p.N, p.Ncoupled, p.Nfreq, p.nsteps, self._m, p.objFuncType, nunc, p.T,
-                               *[_ptr(a) for a in keep])
+        ptrs = [_ptr(a) for a in keep]
+        sparse_args = [None, None, None]
+        use_csc = bool(getattr(p, "use_sparse", False)) if csc is None else bool(csc)
+        if use_csc and not nunc:
+            k0, a0 = _csc_array([p.Hconst])
+            ks, as_ = _csc_array(p.Hsym_ops)
+            ka, aa = _csc_array(p.Hanti_ops)
+            keep += [k0, a0, ks, as_, ka, aa]
+            ptrs[0] = ptrs[1] = ptrs[2] = None
+            sparse_args = [a0, as_, aa]
+        self._csc = use_csc and not nunc
+        prob = _lib.jq_problem(p.Ntot, p.N, p.Ncoupled, p.Nfreq, p.nsteps, self._m, p.objFuncType, nunc, p.T, *ptrs, *sparse_args)
         h = ctypes.c_void_p()
         if devices is None:
             rc = L.jq_create(ctypes.byref(prob), ctypes.byref(h))
@@ -77,6 +131,13 @@ class Working_Arrays_HIP:
         self.num_devices = L.jq_num_devices(h)
         self.device = L.jq_handle_device(h)      # HIP device the handle is bound to (first one of a multi-device handle)
         self.last_allreduce_ms = 0.0             # one process per GPU: wall time of the caller's all-reduce (ipopt_interface.py)
+        if w0.size != p.Ntot:
+            try:
+                self._push_weights(w0)
+            except Exception:
+                self.close()
+                raise
+            self._wd = w0
 
     def close(self):
         if getattr(self, "handle", None):
@@ -105,13 +166,15 @@ class Working_Arrays_HIP:
             self._solver = key
         hc = _f64(p.Hconst)
         if not np.array_equal(hc, self._hconst):
-            _lib.check(L.jq_update_hconst(h, _ptr(hc)), h)
+            if self._csc:
+                k0 = _Csc(p.Hconst)
+                _lib.check(L.jq_update_hconst_csc(h, ctypes.byref(k0.desc)), h)
+            else:
+                _lib.check(L.jq_update_hconst(h, _ptr(hc)), h)
             self._hconst = hc.copy()
         wd = self._weights(p)
-        if wd.size != p.Ntot:
-            raise NotImplementedError("only Diagonal weight matrices (given as their diagonal) are supported")
-        if not np.array_equal(wd, self._wd):
-            _lib.check(L.jq_update_wmat_diag(h, _ptr(wd)), h)
+        if wd.size != self._wd.size or not np.array_equal(wd, self._wd):
+            self._push_weights(wd)
             self._wd = wd.copy()
         utr, uti = _f64(p.Utarget_r), _f64(p.Utarget_i)
         if not (np.array_equal(utr, self._utr) and np.array_equal(uti, self._uti)):

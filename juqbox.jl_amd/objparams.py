@@ -45,7 +45,8 @@ class objparams:
 
     def __init__(self, Ne, Ng, T, nsteps, *, Uinit, Utarget, Cfreq, Rfreq, Hconst,
                  Hsym_ops=(), Hanti_ops=(), Hunc_ops=(), objFuncType=1, leak_ubound=1.0e-3,
-                 wmatScale=1.0, use_sparse=False, linear_solver=None, Integrator=Stormer_Verlet):
+                 wmatScale=1.0, use_sparse=False, linear_solver=None, Integrator=Stormer_Verlet,
+                 use_custom_forbidden=False, forb_states=None, forb_weights=None):
         self.Ne = [int(x) for x in Ne]
         self.Ng = [int(x) for x in Ng]
         self.Nt = [a + b for a, b in zip(self.Ne, self.Ng)]
@@ -106,9 +107,25 @@ class objparams:
             assert h.shape == (nt, nt)
         self.use_sparse = bool(use_sparse)
 
-        # leakage weights: Diagonal in the reference unless use_custom_forbidden (unpinned, unsupported)
+        # leakage weights.  Default: Diagonal (stored as the vector of its diagonal).  use_custom_forbidden (:214-232; parity-unpinned
+        # in the reference: no test or example uses it): W = sum_k forb_weights[k] f_k f_k^H as FULL matrices wmat_real / wmat_imag
+        # (W[i,j] += w conj(f_j) f_i), read by the Stormer-Verlet path only -- the implicit-midpoint path weights with `wmat`.
         self.wmat = wmatScale * setup_utils.wmatsetup(self.Ne, self.Ng)          # :211
-        self.wmat_real = self.wmat.copy()                                       # :235 (diag)
+        if use_custom_forbidden:
+            fs = np.asarray(forb_states, dtype=np.complex128)
+            fw = np.asarray(forb_weights, dtype=np.float64).ravel()
+            if fs.ndim != 2 or fs.shape[0] != nt:
+                raise ValueError("Forbidden states array is an incorrect size. Make sure guard levels are accounted for!")   # ArgumentError, :216-219
+            W = np.zeros((nt, nt), dtype=np.complex128)
+            for k in range(fs.shape[1]):
+                W += fw[k] * np.outer(fs[:, k], np.conj(fs[:, k]))               # :222-231
+            self.forb_states, self.forb_weights = fs, fw
+            self.wmat_real = np.asfortranarray(W.real.copy())
+            self.wmat_imag = np.asfortranarray(W.imag.copy())
+        else:
+            self.forb_states, self.forb_weights = np.zeros((1, 1)), np.zeros(1)  # :233, :237
+            self.wmat_real = self.wmat.copy()                                   # :235 (diag)
+            self.wmat_imag = np.zeros(nt)                                       # :236 Diagonal(zeros(Ntot))
 
         self.objFuncType = int(objFuncType)
         self.leak_ubound = float(leak_ubound)

@@ -47,6 +47,11 @@ typedef struct {
     double *Hanti;   /* Ncoupled * Ntot*Ntot */
     double *Uinit, *Utr, *Uti; /* Ntot*N */
     double *wdiag;   /* Ntot: diag(wmat_real) */
+    /* use_custom_forbidden (src/evalobjgrad.jl:214-232): full Ntot x Ntot wmat_real / wmat_imag (column-major), NULL for the
+     * Diagonal default.  Stormer-Verlet path only (the implicit-midpoint path weights with params.wmat, always Diagonal, :90).
+     * Parity status of this branch: UNPINNED in the reference (no test or golden uses it); the restatement follows the
+     * cited lines and its gradient is checked by finite differences (tests/test_dense_wmat.py). */
+    double *wreal, *wimag;
     double *Cfreq;   /* Ncoupled x Nfreq, column-major */
     /* uncoupled controls (lab-frame evaluation; src/evalobjgrad.jl:2373-2387): nunc > 0 replaces the coupled pairs -- the
      * reference asserts Ncoupled == 0 || Nunc == 0 (:176).  Hsym[q] holds Hunc_ops[q] when it is symmetric (else zeros),
@@ -322,11 +327,44 @@ static double step_adj(const oracle_t *o, work_t *w, double t, double *mu, doubl
     return t + h;
 }
 
-/* penalf2aTrap (:2199-2208), penalf2a (:2170-2180) for Diagonal weights */
+/* tr(A' * B * C), B Ntot x Ntot: adjoint_trace_operator! dense (src/evalobjgrad.jl:2114-2131) */
+static double trace_abc(const oracle_t *o, const double *A, const double *B, const double *C)
+{
+    double trace = 0.0;
+    int i, j, k, n = o->Ntot;
+    for (j = 0; j < o->N; j++)
+        for (i = 0; i < n; i++) {
+            double btmp = 0.0;
+            for (k = 0; k < n; k++) btmp += B[i + (size_t)k * n] * C[k + (size_t)j * n];
+            trace += A[i + (size_t)j * n] * btmp;
+        }
+    return trace;
+}
+
+/* penalf2imag (:2226-2233): tr(vi' * wmat_imag * vr); 0 for Diagonal weights */
+static double penalf2imag(const oracle_t *o, const double *vr, const double *vi)
+{
+    return o->wimag ? trace_abc(o, vi, o->wimag, vr) : 0.0;
+}
+
+/* Y = alpha * W * X + beta * Y for a full weight matrix: the mul! calls at :862, :882-888 */
+static void wmul(const oracle_t *o, double *Y, const double *W, const double *X, double alpha, double beta)
+{
+    int i, j, k, n = o->Ntot;
+    for (j = 0; j < o->N; j++)
+        for (i = 0; i < n; i++) {
+            double s = 0.0;
+            for (k = 0; k < n; k++) s += W[i + (size_t)k * n] * X[k + (size_t)j * n];
+            Y[i + (size_t)j * n] = alpha * s + (beta == 0.0 ? 0.0 : beta * Y[i + (size_t)j * n]);
+        }
+}
+
+/* penalf2aTrap (:2199-2208 Diagonal, :2211-2223 full), penalf2a (:2170-2180 Diagonal, :2183-2196 full) */
 static double penalf2aTrap(const oracle_t *o, const double *vr)
 {
     double f = 0.0;
     int i, j;
+    if (o->wreal) return trace_abc(o, vr, o->wreal, vr);
     for (j = 0; j < o->N; j++)
         for (i = 0; i < o->Ntot; i++) f += o->wdiag[i] * vr[i + (size_t)j * o->Ntot] * vr[i + (size_t)j * o->Ntot];
     return f;
@@ -336,6 +374,7 @@ static double penalf2a(const oracle_t *o, const double *vr, const double *vi)
 {
     double f = 0.0;
     int i, j;
+    if (o->wreal) return trace_abc(o, vr, o->wreal, vr) + 2.0 * trace_abc(o, vi, o->wreal, vi);
     for (j = 0; j < o->N; j++)
         for (i = 0; i < o->Ntot; i++) {
             double a = vr[i + (size_t)j * o->Ntot], b = vi[i + (size_t)j * o->Ntot];
@@ -502,7 +541,7 @@ void jqo_destroy(void *h)
     pattern_free(&o->patS);
     free(o->patHsym); free(o->patHanti);
     free(o->Hconst); free(o->Hsym); free(o->Hanti); free(o->Uinit); free(o->Utr); free(o->Uti);
-    free(o->wdiag); free(o->Cfreq); free(o->Rfreq);
+    free(o->wdiag); free(o->Cfreq); free(o->Rfreq); free(o->wreal); free(o->wimag);
     free(o);
 }
 
@@ -518,6 +557,20 @@ double *jqo_hconst(void *h) { return ((oracle_t *)h)->Hconst; }
 /* leakage weights: the Stormer-Verlet path reads params.wmat_real (src/evalobjgrad.jl:583), the implicit-midpoint
  * path params.wmat (:1147); the test setups overwrite only the former (e.g. test/cases/cnot2-setup.jl) */
 void jqo_set_wdiag(void *h, const double *w) { memcpy(((oracle_t *)h)->wdiag, w, (size_t)((oracle_t *)h)->Ntot * sizeof(double)); }
+/* params.wmat_real / params.wmat_imag as full matrices (use_custom_forbidden, src/evalobjgrad.jl:214-232); NULL, NULL returns to
+ * the Diagonal weights.  Only the Stormer-Verlet path reads them. */
+void jqo_set_wdense(void *h, const double *wr, const double *wi)
+{
+    oracle_t *o = (oracle_t *)h;
+    size_t nn = (size_t)o->Ntot * o->Ntot;
+    free(o->wreal); free(o->wimag);
+    o->wreal = o->wimag = NULL;
+    if (!wr) return;
+    o->wreal = (double *)malloc(nn * sizeof(double));
+    o->wimag = (double *)calloc(nn, sizeof(double));
+    memcpy(o->wreal, wr, nn * sizeof(double));
+    if (wi) memcpy(o->wimag, wi, nn * sizeof(double));
+}
 
 /* p_k(t), q_k(t) for all coupled controls at time t -- exposes bcarrier2 for unit tests */
 int jqo_controls(void *h, const double *pcof, int ncoeff, double t, double *pq /* 2*Ncoupled */)
@@ -612,8 +665,8 @@ int jqo_traceobjgrad(void *h, const double *pcof, int ncoeff, int evaladjoint, d
         KS(o, w.K1, w.S1, t + dt);
         t = step_fwd(o, &w, t, vr, vi, vi05, dt);
         forbidden = tinv * penalf2a(o, vr, vi05);
-        /* penalf2imag == 0 for Diagonal wmat_imag (:2231-2233) */
-        objfv = objfv + dt * 0.5 * (forbidden0 + forbidden - 2.0 * 0.0);
+        /* :717 forbidden_imag1 = tinv*penalf2imag(vr0, vi05, wmat_imag); 0 for Diagonal wmat_imag (:2231-2233) */
+        objfv = objfv + dt * 0.5 * (forbidden0 + forbidden - 2.0 * (tinv * penalf2imag(o, vr0, vi05)));
         if (hist_r) {
             size_t off = (size_t)step * len;
             memcpy(hist_r + off, vr, (size_t)len * sizeof(double));
@@ -663,6 +716,8 @@ int jqo_traceobjgrad(void *h, const double *pcof, int ncoeff, int evaladjoint, d
         /* backward time stepping loop :859-921 */
         for (step = nsteps - 1; step >= 0; step--) {
             double t0 = t;
+            if (o->wreal) wmul(o, hr0, o->wreal, vr, tinv, 0.0); /* :862 */
+            else
             for (j = 0; j < N; j++) /* hr0 = tinv*W*vr (:862) */
                 for (i = 0; i < Ntot; i++) hr0[i + (size_t)j * Ntot] = tinv * o->wdiag[i] * vr[i + (size_t)j * Ntot];
             memcpy(vr0, vr, (size_t)len * sizeof(double));
@@ -670,6 +725,13 @@ int jqo_traceobjgrad(void *h, const double *pcof, int ncoeff, int evaladjoint, d
             KS(o, w.K05, w.S05, t + 0.5 * dt);
             KS(o, w.K1, w.S1, t + dt);
             t = step_fwd(o, &w, t, vr, vi, vi05, dt); /* :879 */
+            if (o->wreal) {
+                wmul(o, hi0, o->wreal, vi05, tinv, 0.0);  /* :882 */
+                wmul(o, hr1, o->wreal, vr, tinv, 0.0);    /* :883 */
+                wmul(o, hr1, o->wimag, vi05, tinv, 1.0);  /* :886 */
+                memcpy(hi1, hi0, (size_t)len * sizeof(double)); /* :887 */
+                wmul(o, hi1, o->wimag, vr, -tinv, 1.0);   /* :888 */
+            } else
             for (j = 0; j < N; j++)
                 for (i = 0; i < Ntot; i++) {
                     size_t ix = i + (size_t)j * Ntot;

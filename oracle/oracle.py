@@ -34,6 +34,7 @@ def lib():
         L.jqo_set_uncoupled.argtypes = [ctypes.c_void_p, c_dp]
         L.jqo_set_target.argtypes = [ctypes.c_void_p, c_dp, c_dp]
         L.jqo_set_wdiag.argtypes = [ctypes.c_void_p, c_dp]
+        L.jqo_set_wdense.argtypes = [ctypes.c_void_p, c_dp, c_dp]
         L.jqo_hconst.restype = c_dp
         L.jqo_hconst.argtypes = [ctypes.c_void_p]
         L.jqo_controls.argtypes = [ctypes.c_void_p, c_dp, ctypes.c_int, ctypes.c_double, c_dp]
@@ -75,9 +76,13 @@ class Oracle:
             ha = np.concatenate([_f(h) for h in p.Hanti_ops]) if p.Ncoupled else np.zeros(0)
         self.Ncoupled = nctrl
         sparse = p.use_sparse if use_sparse is None else use_sparse
+        # leakage weights: a vector = the Diagonal default; a full matrix = use_custom_forbidden (src/evalobjgrad.jl:214-232), then
+        # with wmat_imag next to it (Stormer-Verlet path only; parity-unpinned in the reference)
+        dense_w = np.ndim(p.wmat_real) == 2
+        wdiag = np.diag(np.asarray(p.wmat_real)).copy() if dense_w else p.wmat_real
         self._keep = [_f(p.Hconst), hs, ha, _f(p.Uinit), _f(p.Utarget_r), _f(p.Utarget_i),
-                      _f(p.wmat_real), _f(p.Cfreq[:nctrl, :])]
-        self._wmat_real, self._wmat = _f(p.wmat_real), _f(getattr(p, "wmat", p.wmat_real))
+                      _f(wdiag), _f(p.Cfreq[:nctrl, :])]
+        self._wmat_real, self._wmat = _f(wdiag), _f(getattr(p, "wmat", wdiag))
         self.h = lib().jqo_create(p.Ntot, p.N, nctrl, p.Nfreq, p.nsteps, p.T,
                                   *[_p(a) for a in self._keep], p.objFuncType,
                                   p.linear_solver.solver_id, p.linear_solver.max_iter, p.linear_solver.tol,
@@ -85,6 +90,10 @@ class Oracle:
         if nunc:
             self._rfreq = _f(p.Rfreq[:nunc])
             lib().jqo_set_uncoupled(self.h, _p(self._rfreq))
+        if dense_w:
+            wi = getattr(p, "wmat_imag", None)
+            wi = _f(wi) if wi is not None and np.ndim(wi) == 2 else None
+            lib().jqo_set_wdense(self.h, _p(_f(p.wmat_real)), _p(wi))
 
     def __del__(self):
         if getattr(self, "h", None):

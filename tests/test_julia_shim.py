@@ -13,6 +13,7 @@ CTYPE = {  # C type -> the Julia types a ccall may use for it
     "jq_handle *": {"Ptr{Cvoid}"}, "const jq_handle *": {"Ptr{Cvoid}"}, "jq_handle **": {"Ref{Ptr{Cvoid}}"},
     "const jq_problem *": {"Ref{JQProblem}"}, "jq_timing *": {"Ref{JQTiming}"},
     "const char *": {"Cstring"}, "void *": {"Ptr{Cvoid}"}, "char *": {"Ptr{UInt8}"},
+    "const jq_csc *": {"Ref{JQCsc}", "Ptr{JQCsc}"}, "const int64_t *": {"Ptr{Int64}"},
 }
 
 
@@ -25,12 +26,16 @@ def header():
     txt = open(os.path.join(ROOT, "include", "juqbox_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     structs = {}
-    for name in ("jq_problem", "jq_timing"):
+    for name in ("jq_problem", "jq_timing", "jq_csc"):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), txt, flags=re.S).group(1)
         fields = []
         for decl in body.split(";"):
             decl = decl.strip()
             if decl:
+                if re.match(r"^[\w ]+ \w+(\s*,\s*\w+)+$", decl):      # "int64_t m, n"
+                    typ, names = decl.split(" ", 1)[0], decl.split(" ", 1)[1]
+                    fields.extend((nm.strip(), _norm(typ)) for nm in names.split(","))
+                    continue
                 m = re.match(r"(.*?)(\w+)$", decl)
                 fields.append((m.group(2), _norm(m.group(1))))
         structs[name] = fields
@@ -50,7 +55,7 @@ def julia():
     txt = open(os.path.join(ROOT, "julia", "hip_backend.jl")).read()
     txt = re.sub(r"#.*", "", txt)
     structs = {}
-    for name in ("JQProblem", "JQTiming"):
+    for name in ("JQProblem", "JQTiming", "JQCsc"):
         body = re.search(r"struct %s\s*\n(.*?)\nend" % name, txt, flags=re.S).group(1)
         structs[name] = [tuple(x.strip() for x in ln.split("::")) for ln in body.splitlines() if "::" in ln]
     calls = []
@@ -77,7 +82,7 @@ def julia():
 def test_struct_layouts_match_the_header():
     hs, _ = header()
     js, _ = julia()
-    for cname, jname in (("jq_problem", "JQProblem"), ("jq_timing", "JQTiming")):
+    for cname, jname in (("jq_problem", "JQProblem"), ("jq_timing", "JQTiming"), ("jq_csc", "JQCsc")):
         cf, jf = hs[cname], js[jname]
         assert [n for n, _ in cf] == [n for n, _ in jf], (cname, "field names / order")
         for (n, ct), (_, jt) in zip(cf, jf):
@@ -102,3 +107,33 @@ def test_the_shim_binds_every_hot_path_entry_point():
     _, calls = julia()
     bound = {c[0] for c in calls}
     assert set(protos) - bound == set(), "header entry points the Julia shim does not bind: %s" % sorted(set(protos) - bound)
+
+
+def test_full_leakage_weights_are_passed_or_refused_never_truncated():
+    """Round-3 review: the shim passed diag(params.wmat_real) whatever the weights were -- a use_custom_forbidden problem
+    (src/evalobjgrad.jl:214-232) evaluated to other numbers without an error.  Now: full weights go to jq_update_wmat, the one
+    case that is no Hermitian weight is refused, and diag(...) is only taken from a Diagonal."""
+    raw = open(os.path.join(ROOT, "julia", "hip_backend.jl")).read()
+    txt = re.sub(r"#.*", "", raw)
+    assert "full_weights(params) = !(params.wmat_real isa Diagonal) || !iszero(params.wmat_imag)" in txt
+    body = re.search(r"function push_weights!\(wa::Working_Arrays_HIP, params\)(.*?)\nend", txt, flags=re.S).group(1)
+    full, diagonal = body.split("\n    else\n")
+    assert ":jq_update_wmat," in full and "Matrix{Float64}(params.wmat_real)" in full and "Matrix{Float64}(params.wmat_imag)" in full
+    assert "error(" in full and "Diagonal wmat_imag" in full
+    assert ":jq_update_wmat_diag" in diagonal and "diag(params.wmat_real)" in diagonal
+    # no other place reads the diagonal of wmat_real, and the weights are pushed before every evaluation
+    assert txt.count("diag(params.wmat_real)") == 1
+    assert "push_weights!(wa, params)" in re.search(r"function sync!(.*?)\nend", txt, flags=re.S).group(1)
+    # the implicit-midpoint type reads params.wmat (Diagonal by its field type, src/evalobjgrad.jl:90) and says so if it is not
+    imr = re.search(r"function push_weights!\(wa::Working_Arrays_M_HIP, params\)(.*?)\nend", txt, flags=re.S).group(1)
+    assert "params.wmat isa Diagonal || error(" in imr
+
+
+def test_sparse_operators_are_passed_in_csc_form():
+    """use_sparse = true problems hand colptr / rowval / nzval (1-based Int64) over, nothing is densified"""
+    txt = re.sub(r"#.*", "", open(os.path.join(ROOT, "julia", "hip_backend.jl")).read())
+    assert "JQCsc(A::SparseMatrixCSC{Float64,Int64}) = JQCsc(size(A, 1), size(A, 2), pointer(A.colptr), pointer(A.rowval), pointer(A.nzval))" in txt
+    new = re.search(r"function jq_new_handle(.*?)\nend", txt, flags=re.S).group(1)
+    assert "sparse ? zeros(1, 1) : Matrix{Float64}(params.Hconst)" in new
+    assert "sparse ? pointer(c0) : Ptr{JQCsc}(C_NULL)" in new
+    assert ":jq_update_hconst_csc" in txt
