@@ -8,7 +8,8 @@
 //              5: row-lane kernels of the implicit-midpoint integrator (JQ_NT = NPJ)
 //              9: cooperative-quad kernels (one 16-row block per wave; single evaluations / small ensembles; JQ_BW = 7)
 //              4: row-lane kernels (one lane per (row, column); JQ_NT = padded row length NPJ, JQ_BW unused)
-//             11: quad-layout kernels (one slab per workgroup) with the low-rank full leakage weights compiled in (JQ_BW = 7)
+//             11: kernels with the low-rank full leakage weights compiled in: quad layout with one slab per workgroup (JQ_BW = 7),
+//                 slab kernels (other JQ_BW; built for <1, 0> and <6, 5>, which have no cooperative sibling)
 #if !defined(JQ_NT) || !defined(JQ_BW) || !defined(JQ_VARIANT)
 #error "compile with -DJQ_NT=<tiles> -DJQ_BW=<band> -DJQ_VARIANT=<0..11>"
 #endif
@@ -70,6 +71,9 @@ template __global__ void k_backward_coop<JQ_NT, JQ_BW>(PropArgs);
 #if JQ_BW == 7 && JQ_VARIANT == 11  // quad layout, one slab per workgroup, full leakage weights (jq_update_wmat)
 template __global__ void k_forward<JQ_NT, JQ_BW, 1, false, true>(PropArgs);
 template __global__ void k_backward<JQ_NT, JQ_BW, 1, false, true>(PropArgs);
+#elif JQ_VARIANT == 11              // slab kernels with the full leakage weights
+template __global__ void k_forward<JQ_NT, JQ_BW, JQ_MINW, false, true>(PropArgs);
+template __global__ void k_backward<JQ_NT, JQ_BW, JQ_MINW, false, true>(PropArgs);
 #elif JQ_BW == 7 && JQ_VARIANT == 8   // quad layout, workgroups of 4 / 8 waves (1 / 2 slabs): built with the max-ILP scheduler (Makefile)
 template __global__ void k_forward<JQ_NT, JQ_BW, 1, false>(PropArgs);
 template __global__ void k_backward<JQ_NT, JQ_BW, 1, false>(PropArgs);

@@ -1569,12 +1569,12 @@ __device__ __forceinline__ void sv_state(RingT<BW == JQ_BW_T4Q>& p, const PropAr
 // ---------------------------------------------------------------------------------------------
 // Forward sweep over one chunk of time steps (src/evalobjgrad.jl:698-753).
 // schedule (period 7): Kp05 S05 Kn0 S0 Kn1 S1 Kp05
-// WLRT: low-rank full leakage weights (PropArgs::wlr) compiled in.  The structure-specific throughput kernels (JQ_BW_T4, the quad
-// layout) carry them only in dedicated instantiations (WLRT = true: quad layout, one slab per workgroup), so the Diagonal fast
-// path is untouched; the band / dense / JQ_BW_OD slab kernels test a.wrank at run time (a handful of scalar branches per step
-// next to >= 8 + 2 m products of 64-cycle MFMAs).
+// WLRT: low-rank full leakage weights (PropArgs::wlr) compiled in -- dedicated instantiations only (quad layout with one slab per
+// workgroup; the slab kernels <1, 0> and <6, 5>, which have no cooperative sibling), so every Diagonal fast path is untouched.
+// (A run-time test of a.wrank in the band / dense / JQ_BW_OD slab kernels was measured first: the never-taken branches cost
+//  their register allocation 17 - 23 % -- cnot3 on <6, 9> 342 -> 402 ms, on <6, 1> 564 -> 692 ms per 4 000 steps.)
 template <int BW, bool JAC, bool WLRT>
-constexpr bool jq_wlr_on() { return WLRT || (!JAC && BW != JQ_BW_T4 && BW != JQ_BW_T4Q); }
+constexpr bool jq_wlr_on() { return WLRT; }
 template <int NT, int BW, int MINW, bool JAC, bool WLRT = false>
 __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_T4Q) ? 1 : MINW) void k_forward(PropArgs a)
 {

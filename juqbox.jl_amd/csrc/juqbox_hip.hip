@@ -69,7 +69,7 @@ struct jq_handle {
     int batch = 0;              // > 0: batched staging (K/S images of `batch` time steps per DMA burst); < 0: window staging
     bool big = false;           // Ntot > 96 (NT = 7 .. 16): only the cooperative kernels with operators read from HBM (jq_coop_kernels.h
                                 // OpCursor) exist -- Stormer-Verlet, Neumann solver, any batch size
-    bool replanned = false;     // jq_update_hconst re-planned this handle: every later drift update plans again
+    bool replanned = false;     // jq_update_hconst re-planned this handle (a later drift plans again when it violates the plan or regains a better structure)
     bool in_split = false;      // run_eval is evaluating one part of a split batch
     double* d_pk2 = nullptr;    // packed result of the first part of a split batch
     size_t cap_pk2 = 0;
@@ -120,6 +120,7 @@ struct jq_handle {
     std::vector<ncclComm_t> comms;
     bool host_reduce = false;   // JQ_MULTI_SAME_DEVICE test mode: host-side sum instead of the ncclAllReduce (no communicators)
     bool comm_broken = false;   // an RCCL call failed inside a collective: the communicators are aborted at destroy, calls refuse
+    int rccl_checks = 0;        // all-reduces of this handle that were verified against the host-order sum (JQ_RCCL_SELFCHECK)
     std::vector<hipEvent_t> ev;
     std::string err;
     jq_timing timing = {};
@@ -1222,9 +1223,34 @@ extern "C" int jq_update_hconst(jq_handle* h, const double* Hconst)
     // The kernels, operator images and LDS plan were chosen from the nonzero structure of H0, Hsym_q, Hanti_q at jq_create.  The
     // reference lets scripts mutate params.Hconst arbitrarily: a drift with entries outside that structure (or any new drift
     // after such a re-plan, which may have the structure back) re-plans the handle in place -- same pointer, same settings.
-    if (h->replanned || ((h->BW == JQ_BW_T4) ? !t4_structure(Hconst, h->Ntot)
-        : (h->BW == JQ_BW_OD) ? !offdiag_blocks_diagonal(Hconst, h->Ntot) : block_band(Hconst, h->Ntot) > (h->big ? h->BWc : h->BW)))
-        return replan(h, Hconst);
+    // (After a re-plan the handle keeps its new, more general plan while the drifts fit it -- a script that mutates Hconst per
+    //  iteration, like eval_f_g_grad!'s loop, must not pay a full re-creation per call; it plans again only when a drift violates
+    //  the current structure, or when the drift has regained a structure that admits a strictly better kernel family than the
+    //  current plan's: 4 x 4 x n when the plan is not JQ_BW_T4, diagonal off-diagonal blocks when it is a plain band.)
+    const bool fits = (h->BW == JQ_BW_T4) ? t4_structure(Hconst, h->Ntot)
+                      : (h->BW == JQ_BW_OD) ? offdiag_blocks_diagonal(Hconst, h->Ntot) : block_band(Hconst, h->Ntot) <= (h->big ? h->BWc : h->BW);
+    bool better = false;
+    if (fits && h->replanned && h->BW != JQ_BW_T4) {
+        const size_t nn = (size_t)h->Ntot * h->Ntot;
+        int bw = block_band(Hconst, h->Ntot);
+        for (int q = 0; q < h->Nc; ++q)
+            bw = std::max(bw, std::max(block_band(h->Hsym.data() + q * nn, h->Ntot), block_band(h->Hanti.data() + q * nn, h->Ntot)));
+        bool t4 = bw <= 1 && (!h->big || h->NT <= 8) && t4_structure(Hconst, h->Ntot);
+        bool od = !h->big && h->BW != JQ_BW_OD && h->NT >= 2 && bw == 1 && offdiag_blocks_diagonal(Hconst, h->Ntot);
+        for (int q = 0; q < h->Nc && (t4 || od); ++q) {
+            const double *hs = h->Hsym.data() + q * nn, *ha = h->Hanti.data() + q * nn;
+            t4 = t4 && t4_structure(hs, h->Ntot) && t4_structure(ha, h->Ntot);
+            od = od && offdiag_blocks_diagonal(hs, h->Ntot) && offdiag_blocks_diagonal(ha, h->Ntot);
+        }
+        // ... or a narrower block band than the plan's (the selection rule of create_dense)
+        bool narrower = false;
+        if (h->BW != JQ_BW_OD) {
+            const int want = h->big ? (bw > 2 ? 15 : std::max(bw, 1)) : ((bw <= 2 && bw < h->NT - 1) ? bw : h->NT - 1);
+            narrower = want < (h->big ? h->BWc : h->BW);
+        }
+        better = t4 || od || narrower;
+    }
+    if (!fits || better) return replan(h, Hconst);
     h->Hconst.assign(Hconst, Hconst + (size_t)h->Ntot * h->Ntot);
     if (h->emb) {
         jq_handle* e = h->emb;
@@ -1439,9 +1465,27 @@ typedef void (*prop_kernel_t)(PropArgs);
 JQ_FOR_EACH_INST(JQ_DECL)
 #undef JQ_DECL
 
+// slab kernels with the low-rank full leakage weights compiled in (the two without a cooperative sibling)
+extern template __global__ void k_forward<1, 0, JQ_MINW_OF(1), false, true>(PropArgs);
+extern template __global__ void k_backward<1, 0, JQ_MINW_OF(1), false, true>(PropArgs);
+extern template __global__ void k_forward<6, 5, JQ_MINW_OF(6), false, true>(PropArgs);
+extern template __global__ void k_backward<6, 5, JQ_MINW_OF(6), false, true>(PropArgs);
+
 static int select_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
 {
     const bool jac = (h->solver_id == 2);
+    if (h->wrank > 0) {
+        if (h->NT == 1 && h->BW == 0) {
+            *fwd = k_forward<1, 0, JQ_MINW_OF(1), false, true>, *bwd = k_backward<1, 0, JQ_MINW_OF(1), false, true>;
+            return JQ_OK;
+        }
+        if (h->NT == 6 && h->BW == 5) {
+            *fwd = k_forward<6, 5, JQ_MINW_OF(6), false, true>, *bwd = k_backward<6, 5, JQ_MINW_OF(6), false, true>;
+            return JQ_OK;
+        }
+        return fail(h, JQ_EUNSUPPORTED, "full leakage weights (jq_update_wmat): no kernels with the low-rank terms for this plan (row-lane kernels "
+                                        "disabled, or cooperative kernels that do not fit the LDS)");
+    }
 #define JQ_PICK(nt, bw)                                                                                  \
     if (h->NT == nt && h->BW == bw) {                                                                    \
         *fwd = jac ? k_forward<nt, bw, JQ_MINW_OF(nt), true> : k_forward<nt, bw, JQ_MINW_OF(nt), false>; \
@@ -1850,7 +1894,8 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     const int cpw = imr_rl ? imr_cols_per_wave(h->N) : 4;   // columns per wave of the row-lane kernels
     // Full leakage weights (jq_update_wmat; low-rank terms in the kernels): row-lane kernels for every batch of an Ntot <= 16 problem,
     // quad-layout kernels with one slab per workgroup (their WLRT instantiations) for the 4 x 4 x n structure, else the cooperative
-    // (small batches, Ntot > 96) or the band / dense / JQ_BW_OD slab kernels; no lane, cooperative-quad, JQ_BW_T4 slab kernels.
+    // kernels (every batch size) and, where those do not exist, the slab kernels <1, 0> / <6, 5>; no lane, cooperative-quad,
+    // JQ_BW_T4 slab kernels.
     const bool wfull = h->wrank > 0;
     if (wfull && (imr || h->solver_id != 1))
         return fail(h, JQ_EUNSUPPORTED, "full leakage weights (jq_update_wmat): Stormer-Verlet integrator with the Neumann solver only");
@@ -1911,7 +1956,8 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     const size_t coop_w_bytes = wfull ? (size_t)2 * JQ_COOP_WDOTS * h->NT * 16 * 8 : 0;
     const bool coop_w_fits = !wfull || h->NT > 6 ||
                              (size_t)2 * h->mat_elems_c * 8 + (size_t)32 * h->NT * 8 + (size_t)2 * h->KT * 64 * 8 + (size_t)16 * h->NT * 8 + coop_w_bytes <= 163840;
-    const bool coop = imr_coop || (!cq && !quad && !lane && !rl && h->NT >= 2 && h->coop_ok && coop_w_fits && (h->solver_id == 1 || h->big) && nslabs <= h->coop_max_slabs);      // (Ntot > 96: also the Jacobi solver)
+    const bool coop = imr_coop || (!cq && !quad && !lane && !rl && h->NT >= 2 && h->coop_ok && coop_w_fits && (h->solver_id == 1 || h->big) &&
+                                   (nslabs <= h->coop_max_slabs || wfull));      // (Ntot > 96: also the Jacobi solver; full weights: every batch size -- the slab kernels have no low-rank terms)
     // row-lane kernels, Stormer-Verlet: the backward sweep's two chains on two waves (jq_rowlane_kernels.h k_backward_rowlane2);
     // JQ_RL_SPLIT=0: one wave (tests: the two variants must agree bit for bit)
     // (both integrators; while the doubled wave count still finds idle issue slots: measured with scripts/time_rl_crossover.py --
@@ -2755,6 +2801,25 @@ static int multi_eval_f_g_grad(jq_handle* h, const double* pcof, int ncoeff, con
             return rcs[d];
         }
     std::vector<double> packed(npk, 0.0);
+    // Self-check of the collective (the first 8-GPU run verifies itself): on the FIRST all-reduce of a handle the devices' packed
+    // vectors are also copied to the host before the collective and their sum in device order is compared with what RCCL returns
+    // (1e-13 relative to the largest entry: the ring order differs from the device order in the last bits only).
+    // JQ_RCCL_SELFCHECK=0 switches it off, =2 checks every call.
+    int selfcheck = 1;
+    if (const char* e = getenv("JQ_RCCL_SELFCHECK")) selfcheck = atoi(e);
+    const bool check_now = !h->host_reduce && (selfcheck >= 2 || (selfcheck == 1 && h->rccl_checks == 0));
+    std::vector<double> expect;
+    if (check_now) {
+        expect.assign(npk, 0.0);
+        std::vector<double> tmp(npk);
+        for (int d = 0; d < nd; ++d) {
+            jq_handle* sub = h->subs[d];
+            HIPCHK(h, hipSetDevice(sub->device));
+            HIPCHK(h, hipMemcpyAsync(tmp.data(), sub->d_pack, npk * sizeof(double), hipMemcpyDeviceToHost, sub->stream));
+            HIPCHK(h, hipStreamSynchronize(sub->stream));
+            for (size_t i = 0; i < npk; ++i) expect[i] += tmp[i];
+        }
+    }
     const auto t0 = std::chrono::steady_clock::now();
     if (h->host_reduce) {
         for (int d = 0; d < nd; ++d)      // fixed order: device 0, 1, ...
@@ -2798,6 +2863,18 @@ static int multi_eval_f_g_grad(jq_handle* h, const double* pcof, int ncoeff, con
         }
     }
     const double ms_ar = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (check_now) {
+        double scale = 0.0, worst = 0.0;
+        for (size_t i = 0; i < npk; ++i) scale = std::max(scale, std::fabs(expect[i]));
+        for (size_t i = 0; i < npk; ++i) worst = std::max(worst, std::fabs(packed[i] - expect[i]));
+        if (!(worst <= 1e-13 * scale)) {
+            char buf[256];
+            snprintf(buf, sizeof buf, "RCCL all-reduce self-check failed: result differs from the host-order sum of the %d devices' packed "
+                                      "vectors by %.3e (largest entry %.3e); JQ_RCCL_SELFCHECK=0 disables the check", nd, worst, scale);
+            return fail(h, JQ_EHIP, buf);
+        }
+        ++h->rccl_checks;
+    }
     out2[0] = packed[0];
     out2[1] = packed[1];
     if (adjoint)

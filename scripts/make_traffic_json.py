@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """profiles/r02_pmc.json (round 1: r01_hbm_traffic.json) from rocprofv3 PMC passes (rocpd sqlite files).
 
-usage: make_traffic_json.py out.json [--version "<jq_version>"] [--samples N] <db> [<db> ...]
+usage: make_traffic_json.py out.json [--version "<jq_version>"] [--samples N] [--nsteps S] <db> [<db> ...]
 Every db is one `rocprofv3 --pmc <counters> --kernel-trace` pass of the same command.  FETCH_SIZE / WRITE_SIZE
 are in KiB; per MI355X_MICROARCH.md (HBM section) FETCH_SIZE under-reports wide (16 B/lane) coalesced reads by
 exactly 2x on gfx950, so fetch bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE is taken as is.  SQ_* counters are
@@ -28,12 +28,14 @@ def short(name):
 
 def main():
     out_path, rest = sys.argv[1], sys.argv[2:]
-    version, samples = None, None
+    version, samples, nsteps = None, None, None
     while rest and rest[0].startswith("--"):
         if rest[0] == "--version":
             version = rest[1]
         elif rest[0] == "--samples":
             samples = int(rest[1])
+        elif rest[0] == "--nsteps":      # time steps of ONE sweep of the profiled command (one evaluation, objFuncType 1: one backward sweep)
+            nsteps = int(rest[1])
         rest = rest[2:]
     dbs = rest
     acc = defaultdict(lambda: defaultdict(float))
@@ -81,8 +83,14 @@ def main():
                     e["wait_inst_frac"] = sq["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"]
         if samples is not None:
             e["samples_per_gpu"] = samples
+        if nsteps is not None and launches[k] and k.startswith(("k_forward", "k_backward")):
+            # bench.py joins this record only with a run of the same chunking (time steps per propagator launch)
+            e["steps_per_launch"] = nsteps / launches[k]
         kernels[k] = e
-    json.dump({"note": __doc__.split("usage:")[1].strip(), "library_version": version, "kernels": kernels}, open(out_path, "w"), indent=1)
+    import os
+    chunk_env = {v: os.environ.get(v) for v in ("JQ_CHUNK_STEPS", "JQ_TRACE_BYTES", "JQ_STREAM_BYTES")}
+    json.dump({"note": __doc__.split("usage:")[1].strip(), "library_version": version, "chunk_env": chunk_env, "kernels": kernels},
+              open(out_path, "w"), indent=1)
     print("wrote", out_path, "kernels:", ", ".join(sorted(kernels)))
 
 

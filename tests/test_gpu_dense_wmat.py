@@ -92,9 +92,9 @@ def test_cnot2(jq, oft, env, family):
 
 @pytest.mark.parametrize("oft,nforb,env,family,band", [
     (1, 2, {}, 6, 7), (3, 4, {}, 6, 7),                                   # quad layout, WLRT instantiation
-    (1, 2, {"JQ_T4": "0"}, 1, 9), (2, 2, {"JQ_T4": "0", "JQ_COOP_MAX": "0"}, 0, 9),      # JQ_BW_OD: cooperative / slab
-    (1, 3, {"JQ_T4": "0", "JQ_OD": "0", "JQ_COOP_MAX": "0"}, 0, 1),      # block-tridiagonal band tiles
-    (3, 2, {"JQ_FORCE_DENSE": "1", "JQ_COOP_MAX": "0", "JQ_EMBED": "0"}, 0, 5),      # dense 96 x 96 tiles
+    (1, 2, {"JQ_T4": "0"}, 1, 9), (2, 2, {"JQ_T4": "0", "JQ_COOP_MAX": "0"}, 1, 9),      # JQ_BW_OD: cooperative kernels, whatever JQ_COOP_MAX says
+    (1, 3, {"JQ_T4": "0", "JQ_OD": "0"}, 1, 1),                           # block-tridiagonal band tiles
+    (3, 2, {"JQ_FORCE_DENSE": "1", "JQ_EMBED": "0"}, 0, 5),               # dense 96 x 96 tiles: no cooperative kernels, slab <6, 5>
 ])
 def test_cnot3_short(jq, oft, nforb, env, family, band):
     p, pcof = forbidden_problem("cnot3", nforb, 23, True, oft, nsteps=300)
@@ -111,19 +111,19 @@ def test_cnot3_short(jq, oft, nforb, env, family, band):
     (81, 9, 2, 1, 5, 1, 2, False, 4), (40, 3, 2, 2, 7, 3, 3, "od", 2), (48, 4, 4, 1, 6, 3, 1, "t4", 3), (36, 5, 3, 2, 7, 4, 2, "t4", 2),
     (112, 4, 3, 1, 5, 6, 1, "t4", 2), (130, 4, 2, 1, 5, 3, 3, True, 3), (200, 6, 1, 2, 4, 2, 1, False, 2), (40, 20, 2, 1, 6, 2, 1, False, 2),
 ], ids=lambda c: "Ntot%d_N%d_%s_r%d" % (c[0], c[1], c[7] if isinstance(c[7], str) else ("band" if c[7] else "dense"), c[8]))
-@pytest.mark.parametrize("mode", ["auto", "slab"])
-def test_random_problems(jq, cfg, mode):
+def test_random_problems(jq, cfg):
     """sizes, structures and ranks the reference cases do not reach: every tile count, ragged slabs, N > 16, Ntot > 96 (cooperative
-    kernels with the operators read from HBM), rank up to JQ_MAX_WRANK; `slab`: JQ_COOP_MAX=0"""
+    kernels with the operators read from HBM), rank up to JQ_MAX_WRANK, more slabs than one round of cooperative workgroups"""
     Ntot, N, Nc, Nfreq, nsteps, m, oft, banded, nforb = cfg
     rng = np.random.default_rng(77 + Ntot)
     p, pcof = random_problem(jq, rng, Ntot, N, Nc, Nfreq, nsteps, m, oft, banded)
     set_forbidden(p, rng, nforb, complex_states=(Ntot % 2 == 0))
-    if mode == "slab" and (Ntot <= 16 or Ntot > 96):
-        pytest.skip("slab: the MFMA slab kernels (16 < Ntot <= 96)")
-    wa = make_wa(jq, p, pcof.size, {"JQ_COOP_MAX": "0"} if mode == "slab" else {})
+    wa = make_wa(jq, p, pcof.size)
     sps = max(16 // N, 1)
-    compare(jq, p, pcof, wa, ensembles=(sps + 1, 3 * sps + 2), rng=rng, tol=1e-9)      # (random problems: see tests/test_gpu_random.py)
+    ens = (sps + 1, 3 * sps + 2) + ((300 * sps + 1,) if Ntot == 33 else ())
+    compare(jq, p, pcof, wa, ensembles=ens, rng=rng, tol=1e-9)      # (random problems: see tests/test_gpu_random.py)
+    if Ntot == 33:
+        assert wa.last_timing()["kernel_family"] == 1      # 301 slabs on the cooperative kernels: the slab kernels have no low-rank terms
     wa.close()
 
 

@@ -1,7 +1,10 @@
 """CPU: host-side logic of the package (set-up utilities, problem sizes, memoisation, sharding)."""
+import os
+import sys
+
 import numpy as np
 import pytest
-from conftest import case_inputs
+from conftest import ROOT, case_inputs
 
 # sizes of the reference configurations ("Config sizes")
 EXPECTED = {
@@ -157,3 +160,61 @@ def test_large_cnot3_ensembles_are_built_without_the_cubic_eigenvalue_solve():
     # a sample count without a suitable divisor
     x2, w2, _ = jq.cases.cnot3_ensemble(4099)
     assert abs(w2.sum() - 1.0) < 1e-12 and np.all(np.diff(x2) > 0)
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_bench_counts_gpus_without_initialising_hip(tmp_path, monkeypatch):
+    """round-3 review: bench.py's parent process counted devices through torch before it spawned the ranks.  Now: the KFD topology
+    in sysfs (a node with simd_count > 0 is a GPU; CPUs have none), cut down by the *_VISIBLE_DEVICES variables."""
+    b = _bench_module()
+    for i, simd in enumerate((0, 0, 1024, 1024, 1024)):      # two CPU nodes, three GPUs
+        d = tmp_path / "nodes" / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text("cpu_cores_count %d\nsimd_count %d\ngfx_target_version %d\n" % (0 if simd else 64, simd, 90500 if simd else 0))
+    pattern = str(tmp_path / "nodes" / "*" / "properties")
+    for v in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(v, raising=False)
+    assert b.visible_gpu_count(pattern) == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert b.visible_gpu_count(pattern) == 2
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "1")
+    assert b.visible_gpu_count(pattern) == 1
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert b.visible_gpu_count(pattern) == 0
+
+
+def test_bench_spawns_its_ranks_through_the_launcher_command_line(tmp_path, monkeypatch):
+    """`python bench.py --gpus 4` without a launcher: the command line it starts (stub launcher: prints its arguments) is the
+    driver's own form -- one node, 4 ranks, rendezvous on 127.0.0.1 -- followed by bench.py and the caller's arguments."""
+    import subprocess
+    b = _bench_module()
+    stub = tmp_path / "stub_launcher.py"
+    stub.write_text("import sys, os\nprint('STUB ' + ' '.join(sys.argv[1:]))\nprint('IPC', os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'))\n")
+    monkeypatch.setenv("JQ_BENCH_LAUNCHER", "%s %s" % (sys.executable, stub))
+    args = type("A", (), {"gpus": 4})()
+    cmd = b.rank_launch_command(args, ["--gpus", "4", "--steps", "3"], 29511)
+    assert cmd[:2] == [sys.executable, str(stub)]
+    assert cmd[2:] == ["--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1", "--master-port", "29511",
+                       os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3"]
+    monkeypatch.delenv("JQ_BENCH_LAUNCHER")
+    assert b.rank_launch_command(args, [], 1)[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    # the whole path: spawn_ranks with four GPUs "visible" runs the stub and relays its exit code
+    monkeypatch.setenv("JQ_BENCH_LAUNCHER", "%s %s" % (sys.executable, stub))
+    monkeypatch.setattr(b, "visible_gpu_count", lambda: 4)
+    monkeypatch.setattr(b.sys, "argv", ["bench.py", "--gpus", "4"])
+    monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+    out = tmp_path / "out.txt"
+    real_call = subprocess.call
+    monkeypatch.setattr(b.subprocess, "call", lambda cmd, env=None: real_call(cmd, env=env, stdout=open(out, "w")))
+    assert b.spawn_ranks(args) == 0
+    txt = out.read_text()
+    assert "STUB --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1" in txt and "IPC 0" in txt
+    monkeypatch.setattr(b, "visible_gpu_count", lambda: 3)
+    assert b.spawn_ranks(args) == 2      # fewer GPUs than ranks: refused before anything starts
