@@ -38,6 +38,10 @@
 
 static thread_local std::string g_create_error;
 
+// build manifest (scripts/make_manifest.py -> build/manifest.c): {"<object tag>": {"vgpr_form": .., "fallback": .., "max_vgprs": ..,
+// "max_agprs": .., "max_scratch_bytes": ..}, ...} -- flat entries, quoted by jq_plan_info
+extern "C" const char jq_build_manifest[];
+
 struct jq_handle {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -2953,6 +2957,42 @@ extern "C" int jq_plan_info(const jq_handle* hh, char* buf, int32_t buflen)
     if (!t->big) add(0, "slab (wave per 16-column slab)", "slabs", 1LL << 30);
     fam += "]";
     kv("families", fam);
+    {   // the objects this handle's kernels come from, as the build manifest records them (register form, registers, scratch)
+        const std::string man(jq_build_manifest);
+        std::vector<std::string> tags;
+        auto tag = [&](const char* prefix, int a, int b) {
+            char buf[32];
+            if (b >= 0) snprintf(buf, sizeof buf, "%s_%d_%d", prefix, a, b);
+            else snprintf(buf, sizeof buf, "%s_%d", prefix, a);
+            tags.push_back(buf);
+        };
+        for (const jq_handle* x : {h, (const jq_handle*)h->emb}) {
+            if (!x) continue;
+            if (x->BW == JQ_BW_T4) {
+                for (const char* pre : {"k", "s", "u", "w", "q", "v"}) tag(pre, x->NT, JQ_BW_T4Q);
+                tag("k", x->NT, JQ_BW_T4);
+            } else if (!x->big) {
+                tag("k", x->NT, x->BW);
+                tag("j", x->NT, x->BW);
+            }
+            if (x->mat_elems_c > 0) tag("c", x->NT, x->BWc), tag("i", x->NT, x->BWc);
+            if (x->rl_npj > 0) tag("r", x->rl_npj, -1), tag("m", x->rl_npj, -1);
+            if (x->lane_np > 0) tag("l", x->lane_np, -1);
+        }
+        std::string objs = "{";
+        for (const std::string& t : tags) {
+            const std::string key = "\"" + t + "\": {";
+            const size_t at = man.find(key);
+            if (at == std::string::npos) continue;
+            const size_t end = man.find('}', at);
+            if (end == std::string::npos) continue;
+            if (objs.size() > 1) objs += ", ";
+            objs += man.substr(at, end - at + 1);
+        }
+        objs += "}";
+        kv("build", std::string("{\"manifest\": ") + (man.size() > 2 ? "true" : "false") + ", \"objects\": " + objs + "}");
+    }
+    kv("full_weight_rank", num(h->wrank));
     o += "}";
     if (buflen > 0) {
         const size_t n = std::min(o.size(), (size_t)buflen - 1);

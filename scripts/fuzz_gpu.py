@@ -17,6 +17,7 @@ def run(n_cases=50, seed=1, verbose=True):
     rng = np.random.default_rng(seed)
     worst = 0.0
     compared = 0
+    n_unconv = 0
     t0 = time.time()
     case = -1
     while compared < n_cases and case + 1 < 2 * n_cases:     # draws without kernels (JQ_EUNSUPPORTED) are replaced, not counted
@@ -95,10 +96,14 @@ def run(n_cases=50, seed=1, verbose=True):
         p.Hconst = H0
         # implicit midpoint: a draw whose fixed-point iteration does not converge within its 80 iterations (large dt ||H||: every
         # iteration amplifies rounding differences) is reported but not held to the tolerance
-        unconv = False
+        # (advisor, round 3: such a draw was never flagged whatever its error -- a genuinely wrong result would have passed.  It is
+        #  now held to a LOOSE bound: 1e-4, or 100 x the oracle's own change between 79 and 80 iterations, whichever is larger.)
+        unconv, loose = False, 0.0
         if imr:
             ra, rb = orc.traceobjgrad_imr(pcof, 80, 1e-11), orc.traceobjgrad_imr(pcof, 79, 1e-11)
-            unconv = abs(ra["primaryobjf"] - rb["primaryobjf"]) > 1e-10 * max(1.0, abs(ra["primaryobjf"]))
+            own = abs(ra["primaryobjf"] - rb["primaryobjf"]) / max(1.0, abs(ra["primaryobjf"]))
+            unconv = own > 1e-10
+            loose = max(1e-4, 100.0 * own)
         try:
             jq.eval_f_g_grad(pcof, p, wa, nodes, weights, True, shift=shift)
         except RuntimeError as e:
@@ -115,13 +120,19 @@ def run(n_cases=50, seed=1, verbose=True):
         err = max(e1, e2, e3, e4)
         if not unconv:
             worst = max(worst, err)
+        else:
+            n_unconv += 1
+            if err >= loose:
+                worst = max(worst, err)      # above even the loose bound: a genuine mismatch
         compared += 1
-        flag = "   (fixed-point iteration not converged: not counted)" if unconv else ("" if err < 1e-8 else "   <<<<<< MISMATCH")
+        flag = (("   (fixed-point iteration not converged: loose bound %.0e)" % loose) if err < loose else "   <<<<<< MISMATCH (unconverged draw, above its loose bound)") \
+            if unconv else ("" if err < 1e-8 else "   <<<<<< MISMATCH")
         nonlocal_print("%3d Ntot=%2d N=%2d Nc=%d Nf=%d steps=%2d m=%d oft=%d %-5s %s nq=%2d fam=%d %-18s env=%s%s%s err=%.1e%s" % (
             case, Ntot, N, Nc, Nfreq, nsteps, m, oft, structure, "IMR" if imr else ("JAC" if jac else "SV "), nq, fam, mode,
             env.get("JQ_CHUNK_STEPS", "-"), " replan" if replan else "", (" tol=%.0e" % jtol) if jac else "", err, flag), flush=True)
         wa.close()
-    nonlocal_print("worst relative error %.2e over %d compared cases (of %d drawn) in %.0f s" % (worst, compared, n_cases, time.time() - t0))
+    nonlocal_print("worst relative error %.2e over %d compared cases (of %d drawn; %d implicit-midpoint draws with an unconverged fixed-point "
+                   "iteration held to their loose bound only) in %.0f s" % (worst, compared, n_cases, n_unconv, time.time() - t0))
 
     return worst, compared
 

@@ -174,3 +174,30 @@ def test_python_shard_bounds_fallback_equals_the_library_rule():
                 assert _shard_bounds_py(nquad, r, world) == shard_bounds(nquad, r, world)
     with pytest.raises(ValueError):
         _shard_bounds_py(8, 2, 2)
+
+
+def test_build_manifest_of_the_bench_path():
+    """Round-3 review: the Makefile silently rebuilt an object in the default register form when hipcc 7.2 crashed in VGPR form, and
+    nothing recorded which.  csrc/build/manifest.json (scripts/make_manifest.py) now does: the objects the benchmark runs -- k_6_7
+    (three slabs per workgroup), s_6_7 (one / two slabs), u_6_7 (cooperative quad) -- must be in VGPR form, not fallen back, and within
+    their scratch budget; the known fallbacks are exactly the ones listed here (none on the bench path)."""
+    import json
+    path = os.path.join(ROOT, "juqbox.jl_amd", "csrc", "build", "manifest.json")
+    if not os.path.exists(path):
+        pytest.skip("no build directory here (the library was built elsewhere)")
+    man = json.load(open(path))["objects"]
+    assert len(man) >= 200
+    for tag, budget in (("k_6_7", 160), ("s_6_7", 64), ("u_6_7", 0), ("w_6_7", 0), ("v_6_7", 0)):
+        e = man[tag]
+        assert e["vgpr_form"] and not e["fallback"], (tag, e["flags"])
+        assert e["max_scratch_bytes"] <= budget, (tag, e["max_scratch_bytes"])
+    assert man["k_6_7"]["max_vgprs"] <= 168          # three waves per SIMD
+    fallbacks = sorted(t for t, e in man.items() if e["fallback"])
+    assert set(fallbacks) <= {"k_6_5", "k_7_8", "w_6_5"}, fallbacks      # dense 96 x 96 / 4 x 4 x 7 slab kernels: hipcc 7.2 fails in VGPR form
+    # the library carries the same manifest (jq_plan_info quotes it)
+    from juqbox_jl_amd import _lib
+    import ctypes
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    txt = ctypes.string_at(ctypes.addressof(ctypes.c_char.in_dll(L, "jq_build_manifest"))).decode()
+    emb = json.loads(txt)
+    assert emb["k_6_7"]["max_scratch_bytes"] == man["k_6_7"]["max_scratch_bytes"] and emb["k_6_5"]["fallback"] is True

@@ -121,7 +121,7 @@ def test_random_problems(jq, cfg):
     wa = make_wa(jq, p, pcof.size)
     sps = max(16 // N, 1)
     ens = (sps + 1, 3 * sps + 2) + ((300 * sps + 1,) if Ntot == 33 else ())
-    compare(jq, p, pcof, wa, ensembles=ens, rng=rng, tol=1e-9)      # (random problems: see tests/test_gpu_random.py)
+    compare(jq, p, pcof, wa, ensembles=ens, rng=rng)
     if Ntot == 33:
         assert wa.last_timing()["kernel_family"] == 1      # 301 slabs on the cooperative kernels: the slab kernels have no low-rank terms
     wa.close()

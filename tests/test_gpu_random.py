@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 def _clean_env():
     yield
     os.environ.pop("JQ_QUAD8", None)
-TOL = 1e-9   # random problems are less well conditioned than the reference cases; observed ~1e-13
+TOL = 1e-10   # the reference's own tolerance (test/evalGrad.jl:4-5); observed ~1e-13 on these random problems
 
 
 def random_problem(jq, rng, Ntot, N, Nc, Nfreq, nsteps, m, objFuncType, banded):

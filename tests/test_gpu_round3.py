@@ -361,17 +361,20 @@ def test_more_than_four_controls_match_the_oracle(hip, name, cfg, env, imr):
         r = orc.traceobjgrad_imr(pcof, 80, 1e-12) if imr else orc.traceobjgrad(pcof)
         objfv, tg, prim, sec, tinf, ig, lg = jq.traceobjgrad(pcof, p, wa, False, True)
         gn = np.linalg.norm(r["totalgrad"])
-        assert abs(prim - r["primaryobjf"]) <= 1e-9 and abs(sec - r["secondaryobjf"]) <= 1e-9 * max(abs(r["secondaryobjf"]), 1e-3)
-        assert np.linalg.norm(tg - r["totalgrad"]) <= 1e-9 * gn
-        assert np.linalg.norm(ig - r["infidelgrad"]) <= 1e-9 * gn
+        # Stormer-Verlet: the reference's own tolerance; implicit midpoint: the fixed-point solver stops at ITS tolerance (1e-12 per
+        # evaluation and step, accumulated over the steps and amplified by the random problem's conditioning): 1e-9
+        tol = 1e-9 if imr else 1e-10
+        assert abs(prim - r["primaryobjf"]) <= tol and abs(sec - r["secondaryobjf"]) <= tol * max(abs(r["secondaryobjf"]), 1e-3)
+        assert np.linalg.norm(tg - r["totalgrad"]) <= tol * gn
+        assert np.linalg.norm(ig - r["infidelgrad"]) <= tol * gn
         if oft != 1:
-            assert np.linalg.norm(lg - r["leakgrad"]) <= 1e-9 * gn
+            assert np.linalg.norm(lg - r["leakgrad"]) <= tol * gn
         # every control's block of the gradient is non-trivial and right (a group that was skipped would leave zeros)
         per = pcof.size // Nc
         for q in range(Nc):
             blk = slice(q * per, (q + 1) * per)
             assert np.linalg.norm(r["totalgrad"][blk]) > 0
-            assert np.linalg.norm(tg[blk] - r["totalgrad"][blk]) <= 1e-9 * gn
+            assert np.linalg.norm(tg[blk] - r["totalgrad"][blk]) <= tol * gn
         if not imr:
             nq = 2 * max(1, 16 // N) + 1
             nodes, weights = 0.1 * rng.standard_normal(nq), rng.random(nq)
@@ -380,10 +383,10 @@ def test_more_than_four_controls_match_the_oracle(hip, name, cfg, env, imr):
             ref = orc.eval_f_g_grad(pcof, nodes, weights, shift)
             jq.eval_f_g_grad(pcof, p, wa, nodes, weights, True, shift=shift)
             gref = ref["last_infidelity_grad"]
-            assert abs(p.last_infidelity - ref["last_infidelity"]) <= 1e-9 * abs(ref["last_infidelity"])
-            assert np.linalg.norm(p.last_infidelity_grad - gref) <= 1e-9 * np.linalg.norm(gref)
+            assert abs(p.last_infidelity - ref["last_infidelity"]) <= tol * abs(ref["last_infidelity"])
+            assert np.linalg.norm(p.last_infidelity_grad - gref) <= tol * np.linalg.norm(gref)
             if oft != 1:
-                assert np.linalg.norm(p.last_leak_grad - ref["last_leak_grad"]) <= 1e-9 * np.linalg.norm(gref)
+                assert np.linalg.norm(p.last_leak_grad - ref["last_leak_grad"]) <= tol * np.linalg.norm(gref)
         wa.close()
     finally:
         for k in env:
@@ -423,8 +426,9 @@ def test_hconst_update_outside_the_planned_structure_replans(hip, structure, Nto
         r = orc.traceobjgrad_imr(pcof, 80, 1e-12) if imr else orc.traceobjgrad(pcof)
         objfv, tg, prim, sec, tinf, ig, lg = jq.traceobjgrad(pcof, p, wa, False, True)
         gn = np.linalg.norm(r["totalgrad"])
-        assert abs(prim - r["primaryobjf"]) <= 1e-9 and np.linalg.norm(tg - r["totalgrad"]) <= 1e-9 * gn
-        assert np.linalg.norm(lg - r["leakgrad"]) <= 1e-9 * gn
+        tol = 1e-9 if imr else 1e-10      # (implicit midpoint: bounded by the fixed-point solver's own tolerance, see above)
+        assert abs(prim - r["primaryobjf"]) <= tol and np.linalg.norm(tg - r["totalgrad"]) <= tol * gn
+        assert np.linalg.norm(lg - r["leakgrad"]) <= tol * gn
         return wa.last_timing()
     t0 = check()
     D = rng.standard_normal((Ntot, Ntot))
@@ -452,8 +456,8 @@ def test_dense_operators_beyond_96_levels_whose_band_equals_a_structure_code(hip
     objfv, tg, prim, sec, tinf, ig, lg = jq.traceobjgrad(pcof, p, wa, False, True)
     assert wa.last_timing()["kernel_family"] == 1 and wa.last_timing()["kernel_band"] == 15      # (dense at this size: band code 15)
     gn = np.linalg.norm(r["totalgrad"])
-    assert abs(prim - r["primaryobjf"]) <= 1e-9 and np.linalg.norm(tg - r["totalgrad"]) <= 1e-9 * gn
-    assert np.linalg.norm(lg - r["leakgrad"]) <= 1e-9 * gn
+    assert abs(prim - r["primaryobjf"]) <= 1e-10 and np.linalg.norm(tg - r["totalgrad"]) <= 1e-10 * gn
+    assert np.linalg.norm(lg - r["leakgrad"]) <= 1e-10 * gn
     wa.close()
     p.Integrator_id = jq.Implicit_Midpoint
     p.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER_M, max_iter=60, tol=1e-11, nrhs=3)
@@ -463,7 +467,8 @@ def test_dense_operators_beyond_96_levels_whose_band_equals_a_structure_code(hip
     objfv, tg, prim, sec, tinf, ig, lg = jq.traceobjgrad(pcof, p, wm, False, True)
     assert wm.last_timing()["kernel_family"] == 5
     gn = np.linalg.norm(r["totalgrad"])
-    assert abs(prim - r["primaryobjf"]) <= 1e-9 and np.linalg.norm(tg - r["totalgrad"]) <= 1e-9 * gn
+    # (implicit midpoint with tol = 1e-11 per step: the solver's tolerance bounds the agreement, not the arithmetic)
+    assert abs(prim - r["primaryobjf"]) <= 1e-9 and np.linalg.norm(tg - r["totalgrad"]) <= 1e-9 * gn, "implicit midpoint: solver tolerance 1e-11"
     wm.close()
 
 

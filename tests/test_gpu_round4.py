@@ -1,0 +1,102 @@
+"""GPU (-m gpu), round 4:
+ (1) bench.py --single-process --gpus K in the same-device TEST MODE (JQ_MULTI_SAME_DEVICE=1): the reporting code of the one-process /
+     K-device path -- per-shard min / max, in-library all-reduce time, both strong-scaling points, CPU baseline -- runs on a one-GPU box;
+ (2) jq_update_hconst after a re-plan: the handle keeps its plan while the drifts fit it (no re-creation per call) and plans again
+     when a drift regains a better structure;
+ (3) build manifest: the kernels the bench path runs were built in VGPR form and within their scratch budget."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("K", [2, 4])
+def test_bench_single_process_same_device(K):
+    env = dict(os.environ, JQ_MULTI_SAME_DEVICE="1", JQ_BENCH_SAMPLES="128")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--single-process", "--gpus", str(K), "--steps", "1", "--warmup", "1",
+           "--strong-samples", "512", "--strong-small-samples", "256", "--quick-extras"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "per_rank_ms", "allreduce_ms", "strong_scaling", "strong_scaling_small"):
+        assert k in j, k
+    assert j["n_gpus"] == K and j["config"]["rccl_world_size"] == K
+    assert j["config"]["launcher"].startswith("TEST MODE same-device") and "not a multi-GPU measurement" in j["config"]["launcher"]
+    assert j["config"]["samples_per_gpu"] == 128 and j["value"] > 0
+    assert 0.0 < j["per_rank_ms"]["min"] <= j["per_rank_ms"]["max"] and j["allreduce_ms"] >= 0.0
+    for key, total in (("strong_scaling", 512), ("strong_scaling_small", 256)):
+        sp = j[key]
+        assert sp["total_samples"] == total and sp["samples_per_gpu"] == total // K and sp["evals_per_s"] > 0
+        assert 0.0 < sp["per_rank_ms"]["min"] <= sp["per_rank_ms"]["max"] and sp["allreduce_ms"] >= 0.0
+    assert j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["cores"] == 1 and j["cpu_baseline"]["kind"] == "port"
+    # without the test mode the same request is refused on a box with fewer GPUs
+    from juqbox_jl_amd import _lib
+    if _lib.load().jq_device_count() < K:
+        env.pop("JQ_MULTI_SAME_DEVICE")
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+        assert r.returncode != 0 and "GPU(s) are visible" in r.stderr and not any(ln.startswith("{") for ln in r.stdout.splitlines())
+
+
+def test_replanned_handle_keeps_its_plan_while_the_drift_fits(jq):
+    """advisor, round 3: after one out-of-structure drift every later jq_update_hconst re-created the whole handle (streams,
+    allocations, uploads, the embedded twin) -- per call, on every device -- even when the new drift fitted the current plan.  A script
+    that mutates params.Hconst per iteration (eval_f_g_grad!'s own loop does) must only pay for an upload."""
+    from oracle.oracle import Oracle
+    from test_gpu_random import random_problem
+    rng = np.random.default_rng(12)
+    p, pcof = random_problem(jq, rng, 64, 4, 2, 1, 8, 3, 1, "t4")
+    wa = jq.Working_Arrays_HIP(p, pcof.size)
+    H0 = p.Hconst.copy()
+    D = rng.standard_normal((64, 64))
+    p.Hconst = H0 + 0.02 * (D + D.T)
+    jq.traceobjgrad(pcof, p, wa, False, True)
+    info = wa.plan_info()
+    assert info["replanned"] is True and info["structure"] == "dense"
+    times = []
+    for k in range(6):                                   # six more dense drifts: the plan stays, each update is an upload
+        p.Hconst = H0 + (0.02 + 0.001 * k) * (D + D.T)
+        t0 = time.perf_counter()
+        wa.sync_params()
+        times.append(time.perf_counter() - t0)
+        assert wa.plan_info() == info
+    r = Oracle(p, use_sparse=False).traceobjgrad(pcof)
+    objfv, tg = jq.traceobjgrad(pcof, p, wa, False, True)[:2]
+    assert abs(objfv - r["objfv"]) <= 1e-10 * abs(r["objfv"]) and np.linalg.norm(tg - r["totalgrad"]) <= 1e-10 * np.linalg.norm(r["totalgrad"])
+    p.Hconst = H0 * 1.01                                 # the 4 x 4 x n structure is back: planned again, fast family in use
+    jq.traceobjgrad(pcof, p, wa, False, True)
+    assert wa.plan_info()["structure"] == "t4" and wa.last_timing()["kernel_family"] in (6, 8)
+    t0 = time.perf_counter()
+    p.Hconst = H0 + 0.02 * (D + D.T)
+    wa.sync_params()                                     # (a genuine re-plan, for scale)
+    t_replan = time.perf_counter() - t0
+    assert max(times) < 0.5 * t_replan, (times, t_replan)
+    wa.close()
+
+
+def test_manifest_of_the_bench_path_kernels():
+    """verdict, round 3: Makefile silently rebuilt an object without -amdgpu-mfma-vgpr-form=1 when hipcc crashed, and nothing said
+    which.  The build now writes csrc/build/manifest.json (flags, fallback, registers, scratch per kernel); jq_plan_info quotes it
+    for the kernels a handle selects.  The objects of the bench path must be in VGPR form and within their scratch budget."""
+    import juqbox_jl_amd as jq
+    p, info = jq.cases.cnot3()
+    wa = jq.Working_Arrays_HIP(p, info["nCoeff"])
+    pi = wa.plan_info()
+    wa.close()
+    bk = pi["build"]
+    assert bk["manifest"] is True
+    for obj in ("k_6_7", "s_6_7", "u_6_7"):
+        e = bk["objects"][obj]
+        assert e["vgpr_form"] is True and e["fallback"] is False, (obj, e)
+    assert bk["objects"]["k_6_7"]["max_scratch_bytes"] <= 160
+    assert bk["objects"]["s_6_7"]["max_scratch_bytes"] <= 64
