@@ -497,7 +497,14 @@ extern "C" int jq_device_count(void)
 
 extern "C" int jq_set_device(int device) { return hipSetDevice(device) == hipSuccess ? JQ_OK : JQ_EHIP; }
 
-extern "C" const char* jq_version(void) { return JQ_VERSION; }
+// experiment builds (scripts/exp_variants.sh) link one object that defines jq_variant_tag: their version string -- and with it the
+// build identity bench.py compares with profiles/ -- differs from the production build's although host.o is shared
+extern "C" __attribute__((weak)) const char jq_variant_tag[];
+extern "C" const char* jq_version(void)
+{
+    static const std::string v = std::string(JQ_VERSION) + (jq_variant_tag ? std::string("+") + jq_variant_tag : std::string());
+    return v.c_str();
+}
 
 extern "C" int jq_abi_version(void) { return JQ_ABI_VERSION; }
 
