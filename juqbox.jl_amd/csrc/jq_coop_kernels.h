@@ -414,7 +414,6 @@ __global__ __launch_bounds__(64 * NT) void k_forward_coop(PropArgs a)
 
     for (int n = 0; n < a.nsteps_chunk; ++n) {
         d4 un, v05, vN;
-        const d4 u0 = u;
         leak += dot4(wdr, u * u);  // trapezoidal part at t_n (src/evalobjgrad.jl:700)
         coop_state<NT, BW>(c, a, ceps, wsr, u, v, un, v05, vN);
         // use 6: Kp05 -- v(t+h) = v05 + c (K05 u_new + S05 v05)
@@ -422,19 +421,19 @@ __global__ __launch_bounds__(64 * NT) void k_forward_coop(PropArgs a)
         c.publish_next_op();
         v = c.mm_c(vN);
         if (a.use_shift) v += (ceps * wsr) * un;
-        u = un;
-        leak += dot4(wdr, u * u) + 2.0 * dot4(wdr, v05 * v05);  // (:716, penalf2a :2170-2180)
         if (wl.r > 0) {   // full weights: tr(vr' Wr vr) at t_n and t_n+1, 2 tr(vi05' Wr vi05), -2 tr(vi05' Wi vr(t_n)) (:700, :716-718)
             double lk = 0.0;
             for (int k = 0; k < wl.r; ++k) {
                 const d4 ak = wl.rows(k, 0), bk = wl.rows(k, 1);
-                double d[6] = {dot4(ak, u0), dot4(bk, u0), dot4(ak, u), dot4(bk, u), dot4(ak, v05), dot4(bk, v05)};
+                double d[6] = {dot4(ak, u), dot4(bk, u), dot4(ak, un), dot4(bk, un), dot4(ak, v05), dot4(bk, v05)};
                 wl.template colsum<6>(d);
                 lk += wl.lam(k) * ((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]) + 2.0 * (d[4] * d[4] + d[5] * d[5]) -
                                    2.0 * (d[5] * d[0] - d[4] * d[1]));
             }
             if (wave == 0 && lane < 16) leak += lk;
         }
+        u = un;
+        leak += dot4(wdr, u * u) + 2.0 * dot4(wdr, v05 * v05);  // (:716, penalf2a :2170-2180)
         if (a.hist_r) {
             const int col = a.parts > 1 ? 16 * slab + (lane & 15) : (lane & 15);      // column of sample 0
             if (slab < a.parts && col < a.N) {

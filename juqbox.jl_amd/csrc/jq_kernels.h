@@ -560,6 +560,18 @@ __device__ __forceinline__ void t4q_block(Arr<NT>& D, const Arr<NT>& C, const Ar
     constexpr bool diag = MODE & JQ_T4_DIAG, rt = MODE & JQ_T4_RTERMS, mtm = MODE & JQ_T4_MTERMS;
     const double xc = x.t[mt][0];
     double acc = ZEROC ? 0.0 : C.t[mt][0];
+#ifdef JQ_EXP_MFMA_LAST      // experiment: coupling FMAs first, the MFMA last (its result is not read by the VALU for a whole product)
+    const double xnext = x.t[mt + 1 < NT ? mt + 1 : mt][0];
+    if constexpr (rt) {
+        acc = fma(c[0], row_shift4<0x114>(xc), acc);
+        acc = fma(c[1], row_shift4<0x104>(xc), acc);
+    }
+    if constexpr (mtm) {
+        if (mt > 0) acc = fma(c[2], xold, acc);
+        if (mt + 1 < NT) acc = fma(c[3], xnext, acc);
+    }
+    if constexpr (diag) acc = __builtin_amdgcn_mfma_f64_4x4x4f64(a, xc, acc, 0, 0, 0);
+#else
     if constexpr (diag) acc = __builtin_amdgcn_mfma_f64_4x4x4f64(a, xc, acc, 0, 0, 0);
     if constexpr (rt) {
         acc = fma(c[0], row_shift4<0x114>(xc), acc);
@@ -569,6 +581,7 @@ __device__ __forceinline__ void t4q_block(Arr<NT>& D, const Arr<NT>& C, const Ar
         if (mt > 0) acc = fma(c[2], xold, acc);
         if (mt + 1 < NT) acc = fma(c[3], x.t[mt + 1 < NT ? mt + 1 : mt][0], acc);
     }
+#endif
     xold = xc;
     D.t[mt][0] = acc;
 }
@@ -584,6 +597,18 @@ __device__ __forceinline__ void mm_t4q(Arr<NT>& D, const Arr<NT>& C, const doubl
     if constexpr (diag) a_cur = ma[0];
     if constexpr (coef) c_cur = t4q_cload(cf, 0);
     double xold = 0.0;
+#ifdef JQ_EXP_NOPF      // experiment: the operands of THIS block only (no one-block-ahead prefetch: 10 registers less in flight)
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) {
+        double a = 0.0;
+        d4 c = {0.0, 0.0, 0.0, 0.0};
+        if constexpr (diag) a = ma[mt * 64];
+        if constexpr (coef) c = t4q_cload(cf, mt);
+        t4q_block<NT, ZEROC, MODE>(D, C, x, mt, a, c, xold);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return;
+#endif
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt) {
         const double a = a_cur;
@@ -619,8 +644,10 @@ __device__ __forceinline__ void mm_t4q_multi(Arr<NT>& D0, const Arr<NT>& C0, con
         const double xc = x.t[mt][0], xn = x.t[mt + 1 < NT ? mt + 1 : mt][0];
         const double su = row_shift4<0x114>(xc), sd = row_shift4<0x104>(xc);
         double acc[3] = {Z0 ? 0.0 : C0.t[mt][0], Z1 ? 0.0 : C1.t[mt][0], (NP > 2 && !Z2) ? C2.t[mt][0] : 0.0};
+#ifndef JQ_EXP_MFMA_LAST
 #pragma unroll
         for (int k = 0; k < NP; ++k) acc[k] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[k], xc, acc[k], 0, 0, 0);
+#endif
 #pragma unroll
         for (int k = 0; k < NP; ++k) acc[k] = fma(c[k][0], su, acc[k]);
 #pragma unroll
@@ -633,6 +660,10 @@ __device__ __forceinline__ void mm_t4q_multi(Arr<NT>& D0, const Arr<NT>& C0, con
 #pragma unroll
             for (int k = 0; k < NP; ++k) acc[k] = fma(c[k][3], xn, acc[k]);
         }
+#ifdef JQ_EXP_MFMA_LAST
+#pragma unroll
+        for (int k = 0; k < NP; ++k) acc[k] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[k], xc, acc[k], 0, 0, 0);
+#endif
         xold = xc;
         D0.t[mt][0] = acc[0];
         D1.t[mt][0] = acc[1];
