@@ -412,6 +412,31 @@ def main():
                                              "would have to execute for the same result; not a hardware utilisation",
                     "all_propagators_mfma_frac": mfma * flop_per_mfma / (prop_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                     "forward_ms": fwd_ms, "backward_ms": bwd_ms}
+        # ... and of the forward propagator (27 % of the step; no trace products: a better fraction than the backward kernel's, which
+        # the whole-step figure all_propagators_mfma_frac hides)
+        nf = sum(t["n_forward_launches"] for t in tms)
+        fwd_launch_s = fwd_ms * 1e-3 / max(nf, 1)
+        mfma_fwd_launch = (mfma - mfma_bwd) / max(nf, 1)
+        fname = kname.replace("k_backward", "k_forward")
+        pf, fsrc = {}, "analytic (library count)"
+        if pmc_file:
+            try:
+                pf = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))["kernels"].get(fname, {})
+            except Exception:  # noqa: BLE001
+                pf = {}
+        if pf.get("mfma_16x16x4_equiv_per_launch") and pf.get("steps_per_launch") in (None, nsteps * args.steps / max(nf, 1)):
+            devf = abs(pf["mfma_16x16x4_equiv_per_launch"] - mfma_fwd_launch) / max(mfma_fwd_launch, 1.0)
+            if devf < 0.01:
+                mfma_fwd_launch = pf["mfma_16x16x4_equiv_per_launch"]
+                fsrc = "rocprofv3 PMC SQ_INSTS_MFMA (profiles/%s, same build)" % pmc_file
+        ach_f = mfma_fwd_launch * flop_per_mfma / fwd_launch_s / 1e12 if fwd_launch_s > 0 else 0.0
+        fma_fwd = (mfma_fwd_launch * 4.0 / (4 * NT)) * fma_per_product * 128.0
+        roofline_forward = {"bound": "mfma", "kernel": fname, "achieved": ach_f, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": ach_f / FP64_MFMA_PEAK_TFLOPS, "launches": int(nf), "avg_launch_ms": fwd_launch_s * 1e3,
+                            "mfma_count_source": fsrc, "valu_per_mfma": pf.get("valu_per_mfma"), "wait_frac": pf.get("wait_frac"),
+                            "traffic": pf.get("hbm_bytes_per_launch"),
+                            "frac_incl_coupling_fma": (ach_f + fma_fwd / fwd_launch_s / 1e12) / FP64_MFMA_PEAK_TFLOPS if fwd_launch_s > 0 else None,
+                            "products_per_step": 8 + 2 * m}
         if band == 7 and not args.no_extras and not args.quick_extras:
             roofline["issue_bound"] = issue_bound(avg_launch_s, nsteps * args.steps / max(nb, 1), 2 * (8 + 2 * m) + 4 * Nc,
                                                   min(3, max(1, round(args.samples_per_gpu * N / 16 / 256))))
@@ -435,7 +460,7 @@ def main():
                "svts_per_s": nsamples_total * N * nsteps * args.steps / elapsed,
                "ensemble_infidelity": infid_weak,
                "per_rank_ms": per_rank_ms, "allreduce_ms": allreduce_ms,
-               "roofline": roofline}
+               "roofline": roofline, "roofline_forward": roofline_forward}
         if strong is not None:
             out["strong_scaling"] = strong
             out["strong_scaling_small"] = strong_small
