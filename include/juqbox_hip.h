@@ -186,17 +186,21 @@ int jq_shard_bounds(int32_t nquad, int32_t rank, int32_t world, int32_t *lo, int
 int jq_set_neumann_terms(jq_handle *h, int32_t m);
 /* params.linear_solver = lsolver_object(solver=..., max_iter=..., tol=...) (src/linear_solvers.jl:28-78):
  * solver_id 1 = NEUMANN_SOLVER (neumann!, :81-106; tol ignored), 2 = JACOBI_SOLVER (jacobi!, :110-153; `tol` is
- * the already nrhs-scaled tolerance, :40).  Other ids: JQ_EUNSUPPORTED. */
+ * the already nrhs-scaled tolerance, :40).  Other ids: JQ_EUNSUPPORTED.
+ * JACOBI_SOLVER convergence is tested per evaluation like the reference's norm(T - X) over the Ntot x N block -- for N <= 16.  With
+ * N > 16 columns per evaluation (the columns take ceil(N / 16) slabs, which live in different waves / workgroups) every 16-column
+ * part is tested on its own: parts may stop at different iterations, and the result then differs from the reference's by O(tol)
+ * instead of agreeing to rounding (tests/test_gpu_round4.py holds such a case to c * tol). */
 int jq_set_linear_solver(jq_handle *h, int32_t solver_id, int32_t max_iter, double tol);
 /* params.Integrator_id (src/evalobjgrad.jl:100, constants Stormer_Verlet = 1, Implicit_Midpoint = 2) selects which
  * traceobjgrad method runs: 1 = the Stormer-Verlet path (default), 2 = the implicit-midpoint path
  * (traceobjgrad for Working_Arrays_M, src/evalobjgrad.jl:1042-1481) with the fixed-point solver
  * lsolver_object(solver=JACOBI_SOLVER_M, max_iter, tol) (src/linear_solvers.jl:52-55, :156-270).  For integrator 2 the
- * leakage weights are params.wmat (pass them with jq_update_wmat_diag).  Implemented for N <= 16 columns per evaluation:
- * row-lane kernels (Ntot <= 16, N <= 4), cooperative MFMA kernels (any Ntot <= 256 and batch size; both images of a step resident
- * in LDS when they fit, else -- dense 96 x 96, Ntot > 96 -- read from HBM / L2 per product), quad-layout and cooperative-quad
- * kernels for the 4 x 4 x n structure with N = 1, 2, 4.  JQ_EUNSUPPORTED only for N > 16 (the solver's per-evaluation stopping
- * rule needs an evaluation's columns in one workgroup). */
+ * leakage weights are params.wmat (pass them with jq_update_wmat_diag).  Kernels: row-lane (Ntot <= 16, N <= 4), cooperative MFMA
+ * (any Ntot <= 256 and batch size; both images of a step resident in LDS when they fit, else -- dense 96 x 96, Ntot > 96 -- read from
+ * HBM / L2 per product), quad-layout and cooperative-quad kernels for the 4 x 4 x n structure with N = 1, 2, 4.  N > 16 columns per
+ * evaluation (round 4): the solver's per-evaluation stopping rule needs an evaluation's columns in one workgroup, so ONE cooperative
+ * workgroup per evaluation walks over its 16-column parts (a correctness-first path: the parts' iterates live in HBM / L2). */
 int jq_set_integrator(jq_handle *h, int32_t integrator_id, int32_t max_iter, double tol);
 /* change_target!(params, new_Utarget) (src/evalobjgrad.jl:1492) */
 int jq_update_target(jq_handle *h, const double *Utarget_r, const double *Utarget_i);

@@ -177,8 +177,9 @@ __global__ void k_terminal(double* state, long long stride, const double* __rest
 // k_terminal for N > 16: the columns of a sample are spread over `parts` consecutive slabs (16 columns each); the trace
 // fidelity couples them (the only cross-column coupling of an evaluation, src/evalobjgrad.jl:818, :2029-2041).
 // grid = nsamples, block = 64; sums over lanes and parts in a fixed order.
+// imr != 0: the implicit-midpoint convention of k_terminal_imr (lambda(T) = -2/N (...), the true lambda_i in slot NU)
 __global__ void k_terminal_parts(double* state, long long stride, const double* __restrict__ vtr_img,
-                                 const double* __restrict__ vti_img, int KT, int N, int parts, double leak_scale, double* res)
+                                 const double* __restrict__ vti_img, int KT, int N, int parts, double leak_scale, double* res, int imr)
 {
     __shared__ double part[3][64];
     const int lane = threadIdx.x;
@@ -209,8 +210,13 @@ __global__ void k_terminal_parts(double* state, long long stride, const double* 
         double* st = state + ((size_t)blockIdx.x * parts + p) * stride;
         const double *tr = vtr_img + (size_t)p * KT * 64, *ti = vti_img + (size_t)p * KT * 64;
         for (int kk = 0; kk < KT; ++kk) {
-            st[(2 * KT + kk) * 64 + lane] = (sre * tr[kk * 64 + lane] + sim * ti[kk * 64 + lane]) / N;        // lambdar
-            st[(3 * KT + kk) * 64 + lane] = -((sim * tr[kk * 64 + lane] - sre * ti[kk * 64 + lane]) / N);   // nb = -lambdai
+            if (imr) {
+                st[(2 * KT + kk) * 64 + lane] = -2.0 / N * (sre * tr[kk * 64 + lane] + sim * ti[kk * 64 + lane]);    // lambdar
+                st[(3 * KT + kk) * 64 + lane] = -2.0 / N * (-sre * ti[kk * 64 + lane] + sim * tr[kk * 64 + lane]);   // lambdai
+            } else {
+                st[(2 * KT + kk) * 64 + lane] = (sre * tr[kk * 64 + lane] + sim * ti[kk * 64 + lane]) / N;        // lambdar
+                st[(3 * KT + kk) * 64 + lane] = -((sim * tr[kk * 64 + lane] - sre * ti[kk * 64 + lane]) / N);   // nb = -lambdai
+            }
         }
     }
     if (lane == 0) {

@@ -295,3 +295,192 @@ __global__ __launch_bounds__(64 * NT) void k_backward_coop_imr(PropArgs a)
         st[(3 * KT + 4 * wave + r) * 64 + lane] = li[r];
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// N > 16 columns per evaluation (round 4).  The fixed-point solver stops on the residual norm of the WHOLE evaluation
+// (jacobi_midpoint, src/linear_solvers.jl:156-270: norms over the Ntot x N block), so the `parts` = ceil(N / 16) slabs of an
+// evaluation cannot iterate in different workgroups.  Here ONE workgroup of NT waves owns an evaluation and walks over its parts
+// inside every phase of a step; what a part needs between phases -- right-hand side, current and next iterate, the step sums for
+// the forcing and the traces -- lives in a work area in HBM / L2 (10 arrays per part), the state file is read and written every
+// step.  Same products (CoopImr::applyB), same iterates and decisions as the one-slab kernels; a correctness-first path (every
+// phase pays the L2 latency per part), for the sizes the reference allows and no example uses.
+//   work area per evaluation: [parts][10][KT * 64]: rhs_u, rhs_v, cur_u, cur_v, nxt_u, nxt_v, su, sv, smu, snu
+#define JQ_IMRP_ARRAYS 10
+template <int NT, int BW, bool HBM>
+struct ImrParts {
+    CoopImr<NT, BW, HBM> m;
+    double* work;      // this evaluation's work area (lane offset applied)
+    double* st0;       // state file of part 0 (lane offset applied)
+    long long sstride; // doubles between the parts' state files
+    int parts, wave, lane;
+    static constexpr int KT = 4 * NT;
+    __device__ __forceinline__ double* warr(int p, int k) const { return work + ((size_t)p * JQ_IMRP_ARRAYS + k) * (KT * 64) + (size_t)(4 * wave) * 64; }
+    __device__ __forceinline__ double* sarr(int p, int k) const { return st0 + (size_t)p * sstride + (size_t)(k * KT + 4 * wave) * 64; }
+    static __device__ __forceinline__ d4 ld(const double* a) { return (d4){a[0], a[64], a[128], a[192]}; }
+    static __device__ __forceinline__ void sto(double* a, const d4& x) { a[0] = x[0], a[64] = x[1], a[128] = x[2], a[192] = x[3]; }
+    // totals of two per-lane partials over the workgroup (wave order), valid in every lane of every wave
+    __device__ __forceinline__ void wg_total2(double pu, double pv, double& ru, double& rv)
+    {
+        const double t = wave_sum2(pu, pv);      // rows 0, 1: total of pu;  rows 2, 3: total of pv
+        if (lane == 0) m.normbuf[wave] = t;
+        if (lane == 32) m.normbuf[NT + wave] = t;
+        __syncthreads();
+        ru = 0.0, rv = 0.0;
+        for (int w = 0; w < NT; ++w) {
+            ru += m.normbuf[w];
+            rv += m.normbuf[NT + w];
+        }
+        __syncthreads();
+    }
+    // One implicit-midpoint step of all parts of the evaluation: x <- solution of (I - B) x = x + f + B x with f_p = cf * (work
+    // array fk_u / fk_v of the part) or 0; in / out: the state-file arrays (ku, kv) of every part.  On return the work arrays su / sv
+    // (SUMS = 0) or smu / snu (SUMS = 1) hold new + old.
+    template <int SUMS>
+    __device__ __forceinline__ void step(const PropArgs& a, const d4& sw, int ku, int kv, bool forced, const d4& cf)
+    {
+        for (int p = 0; p < parts; ++p) {
+            const d4 u = ld(sarr(p, ku)), v = ld(sarr(p, kv));
+            d4 fu = {0.0, 0.0, 0.0, 0.0}, fv = fu;
+            if (forced) fu = cf * ld(warr(p, 6)), fv = cf * ld(warr(p, 7));
+            d4 bu, bv;
+            m.applyB(a, sw, u, v, bu, bv);
+            const d4 rhs_u = (u + fu) + bu, rhs_v = (v + fv) + bv;
+            sto(warr(p, 0), rhs_u), sto(warr(p, 1), rhs_v);
+            sto(warr(p, 2), rhs_u + bu), sto(warr(p, 3), rhs_v + bv);      // x_1 = rhs + B x_0
+        }
+        int cur = 2, nxt = 4;      // work arrays of the current / next iterate
+        bool done = false;
+        for (int it = 1; it <= a.m && !done; ++it) {
+            double pu = 0.0, pv = 0.0;
+            for (int p = 0; p < parts; ++p) {
+                const d4 cu = ld(warr(p, cur)), cv = ld(warr(p, cur + 1));
+                d4 bu, bv;
+                m.applyB(a, sw, cu, cv, bu, bv);
+                const d4 nu = ld(warr(p, 0)) + bu, nv = ld(warr(p, 1)) + bv;      // x_{it+1}; residual at x_it = x_it - x_{it+1}
+                sto(warr(p, nxt), nu), sto(warr(p, nxt + 1), nv);
+                const d4 du = cu - nu, dv = cv - nv;
+                pu += dot4(du, du);
+                pv += dot4(dv, dv);
+            }
+            double ru, rv;
+            wg_total2(pu, pv, ru, rv);
+            const bool conv = (ru < a.jacobi_tol2) && (rv < a.jacobi_tol2);
+            if (!conv && it < a.m) {
+                const int t = cur;
+                cur = nxt, nxt = t;
+            } else {
+                done = true;      // (the same decision in every lane of the workgroup: the totals are)
+            }
+        }
+        for (int p = 0; p < parts; ++p) {
+            const d4 xu = ld(warr(p, cur)), xv = ld(warr(p, cur + 1));
+            const d4 ou = ld(sarr(p, ku)), ov = ld(sarr(p, kv));
+            sto(warr(p, SUMS ? 8 : 6), xu + ou), sto(warr(p, SUMS ? 9 : 7), xv + ov);
+            sto(sarr(p, ku), xu), sto(sarr(p, kv), xv);
+        }
+    }
+};
+
+// grid = nsamples (one workgroup per evaluation), block = 64 NT
+template <int NT, int BW, bool HBM = (NT > 6)>
+__global__ __launch_bounds__(64 * NT) void k_forward_coop_imr_parts(PropArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KT = 4 * NT;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4;
+    const int smp = blockIdx.x;
+    double* tab = (double*)(smem + a.lds_tab_off);
+    for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[(i & ~15) + 4 * (i & 3) + ((i >> 2) & 3)] = a.tabs[i];   // [block][g][r]
+    ImrParts<NT, BW, HBM> ip;
+    ip.m.setup(smem, a, wave, lane);
+    ip.parts = a.parts, ip.wave = wave, ip.lane = lane, ip.sstride = a.state_stride;
+    ip.st0 = a.state + (size_t)smp * a.parts * a.state_stride + lane;
+    ip.work = a.park + (size_t)smp * a.parts * JQ_IMRP_ARRAYS * (KT * 64) + lane;
+    __syncthreads();
+    const d4 wdr = rows4(tab, wave, g), wsr = rows4(tab + 16 * NT, wave, g);
+    const d4 sw = (0.5 * a.h * a.colinfo[(size_t)smp * a.parts * 32 + (lane & 15)]) * wsr;      // (one evaluation: the same shift in every part)
+    double* leakp = a.state + (size_t)smp * a.parts * a.state_stride + (size_t)(JQ_STATE_ARRAYS * KT + JQ_MAXNC) * 64 + lane;   // part 0's row
+    double leak = 0.0;
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    for (int n = 0; n < a.nsteps_chunk; ++n) {
+        ip.m.load_pair(a.stream + (size_t)(2 * (2 * n + 1)) * a.stride);
+        ip.template step<0>(a, sw, 0, 1, false, zero);
+        for (int p = 0; p < a.parts; ++p) {
+            const d4 su = ip.ld(ip.warr(p, 6)), sv = ip.ld(ip.warr(p, 7));
+            leak += dot4(wdr, su * su + sv * sv);      // penal_m (src/evalobjgrad.jl:1214, :2158-2166)
+            if (a.hist_r && smp == 0) {
+                const int col = 16 * p + (lane & 15);
+                if (col < a.N) {
+                    const d4 u = ip.ld(ip.sarr(p, 0)), v = ip.ld(ip.sarr(p, 1));
+                    const size_t off = (size_t)(a.step0 + n + 1) * a.Ntot * a.N + (size_t)col * a.Ntot;
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * wave + 4 * r + g;
+                        if (row < a.Ntot) {
+                            a.hist_r[off + row] = u[r];
+                            a.hist_i[off + row] = -v[r];
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // the waves' leak partials are combined in wave order into part 0's row of the state file (k_terminal_parts adds the parts' rows)
+    wg_sum_store<NT>(leak, ip.m.normbuf, leakp - lane, wave, lane, true);
+}
+
+template <int NT, int BW, bool HBM = (NT > 6)>
+__global__ __launch_bounds__(64 * NT) void k_backward_coop_imr_parts(PropArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KT = 4 * NT;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4;
+    const int smp = blockIdx.x;
+    const int Nc = a.Ncoupled;
+    double* tab = (double*)(smem + a.lds_tab_off);
+    for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[(i & ~15) + 4 * (i & 3) + ((i >> 2) & 3)] = a.tabs[i];   // [block][g][r]
+    ImrParts<NT, BW, HBM> ip;
+    ip.m.setup(smem, a, wave, lane);
+    ip.parts = a.parts, ip.wave = wave, ip.lane = lane, ip.sstride = a.state_stride;
+    ip.st0 = a.state + (size_t)smp * a.parts * a.state_stride + lane;
+    ip.work = a.park + (size_t)smp * a.parts * JQ_IMRP_ARRAYS * (KT * 64) + lane;
+    __syncthreads();
+    const d4 wdr = rows4(tab, wave, g), wsr = rows4(tab + 16 * NT, wave, g);
+    const d4 sw = (0.5 * a.h * a.colinfo[(size_t)smp * a.parts * 32 + (lane & 15)]) * wsr;
+    const double wgt = a.colinfo[(size_t)smp * a.parts * 32 + 16 + (lane & 15)];
+    const d4 cfw = (a.forced ? -a.h * a.tinv : 0.0) * wdr;            // h * (-tinv * W)
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    double* trw = a.traces + ((size_t)(smp * NT + wave) * a.nsteps_chunk) * (Nc * JQ_NTR);
+    for (int n = 0; n < a.nsteps_chunk; ++n) {
+        ip.m.load_pair(a.stream + (size_t)(2 * (2 * n + 1)) * a.stride);
+        ip.template step<0>(a, sw, 0, 1, false, zero);        // state: su, sv = new + old
+        ip.template step<1>(a, sw, 2, 3, true, cfw);          // adjoint with the forcing h (-tinv W) (su, sv): smu, snu
+        for (int q = 0; q < Nc; ++q) {
+            ip.m.use_images(a.cimg + (size_t)q * a.stride, a.cimg + (size_t)(Nc + q) * a.stride);
+            double PB = 0.0, PA = 0.0;      // per-lane partials of (B + C) and (A + D) over the parts
+            for (int p = 0; p < a.parts; ++p) {
+                const d4 su = ip.ld(ip.warr(p, 6)), sv = ip.ld(ip.warr(p, 7)), smu = ip.ld(ip.warr(p, 8)), snu = ip.ld(ip.warr(p, 9));
+                ip.m.pub(sv);
+                const double B = -dot4(smu, ip.m.mulK());       // slot 0 holds Hsym_q
+                const double D = dot4(snu, ip.m.mulS());        // slot 1 holds Hanti_q
+                ip.m.pub(su);
+                const double C = dot4(snu, ip.m.mulK());
+                const double A = dot4(smu, ip.m.mulS());
+                PB += B + C;
+                PA += A + D;
+            }
+            const double PQ = wave_sum2(PB * wgt, PA * wgt);      // rows 0, 1: P;  rows 2, 3: Q
+            double* tr = trw + (size_t)n * (Nc * JQ_NTR) + q * JQ_NTR;
+            if (lane == 0) {
+                tr[0] = 0.0;
+                tr[1] = 0.0;
+                tr[2] = 0.0;
+                tr[3] = -0.25 * PQ;
+            }
+            if (lane == 32) tr[4] = 0.25 * PQ;
+        }
+    }
+}

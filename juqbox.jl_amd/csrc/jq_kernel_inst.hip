@@ -36,9 +36,15 @@ template __global__ void k_backward_quad_imr<JQ_NT, 1>(PropArgs);
 #include "jq_coop_imr_kernels.h"
 template __global__ void k_forward_coop_imr<JQ_NT, JQ_BW, (JQ_NT > 6)>(PropArgs);
 template __global__ void k_backward_coop_imr<JQ_NT, JQ_BW, (JQ_NT > 6)>(PropArgs);
+#if JQ_NT >= 2                    // N > 16 columns per evaluation (needs Ntot > 16): one workgroup per evaluation, its parts in turn
+template __global__ void k_forward_coop_imr_parts<JQ_NT, JQ_BW, (JQ_NT > 6)>(PropArgs);
+template __global__ void k_backward_coop_imr_parts<JQ_NT, JQ_BW, (JQ_NT > 6)>(PropArgs);
+#endif
 #if JQ_NT == 6 && JQ_BW == 5      // dense 96 x 96: both images of a step do not fit the LDS -- read from HBM / L2 per product
 template __global__ void k_forward_coop_imr<6, 5, true>(PropArgs);
 template __global__ void k_backward_coop_imr<6, 5, true>(PropArgs);
+template __global__ void k_forward_coop_imr_parts<6, 5, true>(PropArgs);
+template __global__ void k_backward_coop_imr_parts<6, 5, true>(PropArgs);
 #endif
 #elif JQ_VARIANT == 5
 #include "jq_rowlane_imr_kernels.h"

@@ -1150,9 +1150,9 @@ extern "C" int jq_set_integrator(jq_handle* h, int32_t integrator_id, int32_t ma
     if (h->wrank > 0)
         return fail(h, JQ_EUNSUPPORTED, "jq_set_integrator: the handle carries full leakage weights (jq_update_wmat); the implicit-midpoint "
                                         "path weights with params.wmat (Diagonal): pass it with jq_update_wmat_diag first");
-    if (h->parts > 1)
-        return fail(h, JQ_EUNSUPPORTED, "jq_set_integrator: the implicit-midpoint path is implemented for N <= 16 (its solver's "
-                                        "per-evaluation convergence test needs all columns of a sample in one workgroup)");
+    // (N > 16 columns per evaluation: one workgroup per evaluation walks over its 16-column parts, jq_coop_imr_kernels.h ImrParts)
+    if (h->parts > 1 && h->mat_elems_c == 0)
+        return fail(h, JQ_EUNSUPPORTED, "jq_set_integrator: no implicit-midpoint kernels for these operators with N > 16 (no cooperative layout)");
     if (!(h->rl_npj > 0 && h->N <= 4) && h->mat_elems_c == 0 && !(h->quad_max_slabs > 0 && (h->N == 1 || h->N == 2 || h->N == 4)))
         return fail(h, JQ_EUNSUPPORTED, "jq_set_integrator: no implicit-midpoint kernels for these operators (the images of a step "
                                         "do not fit the LDS)");
@@ -1732,6 +1732,35 @@ JQ_FOR_EACH_BIG(JQ_DECLCI)      // (Ntot > 96: operators read from HBM / L2 per 
 JQ_DECLCI(1, 0)      // (Ntot <= 16 with N > 4: one wave per slab, the evaluation's columns in one wave)
 #undef JQ_DECLCI
 
+template <int NT, int BW, bool HBM> __global__ void k_forward_coop_imr_parts(PropArgs);      // N > 16: one workgroup per evaluation
+template <int NT, int BW, bool HBM> __global__ void k_backward_coop_imr_parts(PropArgs);
+#define JQ_DECLCIP(nt, bw)                                                                      \
+    extern template __global__ void k_forward_coop_imr_parts<nt, bw, (nt > 6)>(PropArgs);       \
+    extern template __global__ void k_backward_coop_imr_parts<nt, bw, (nt > 6)>(PropArgs);
+extern template __global__ void k_forward_coop_imr_parts<6, 5, true>(PropArgs);
+extern template __global__ void k_backward_coop_imr_parts<6, 5, true>(PropArgs);
+JQ_FOR_EACH_COOP(JQ_DECLCIP)
+JQ_FOR_EACH_BIG(JQ_DECLCIP)
+#undef JQ_DECLCIP
+static int select_coop_imr_parts_kernels(jq_handle* h, bool hbm, prop_kernel_t* fwd, prop_kernel_t* bwd)
+{
+    if (hbm) {
+        *fwd = k_forward_coop_imr_parts<6, 5, true>;
+        *bwd = k_backward_coop_imr_parts<6, 5, true>;
+        return JQ_OK;
+    }
+#define JQ_PICKCIP(nt, bw)                                      \
+    if (h->NT == nt && h->BWc == bw) {                          \
+        *fwd = k_forward_coop_imr_parts<nt, bw, (nt > 6)>;      \
+        *bwd = k_backward_coop_imr_parts<nt, bw, (nt > 6)>;     \
+        return JQ_OK;                                           \
+    }
+    JQ_FOR_EACH_COOP(JQ_PICKCIP)
+    JQ_FOR_EACH_BIG(JQ_PICKCIP)
+#undef JQ_PICKCIP
+    return fail(h, JQ_EUNSUPPORTED, "no cooperative implicit-midpoint kernel for this Hilbert dimension / band width");
+}
+
 static int select_coop_imr_kernels(jq_handle* h, bool hbm, prop_kernel_t* fwd, prop_kernel_t* bwd)
 {
     if (hbm) {
@@ -1897,6 +1926,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     // (any batch size: one workgroup per slab, rounds of one workgroup per CU)
     const bool imr_quad = imr && !imr_rl && h->quad_max_slabs > 0 && (h->N == 1 || h->N == 2 || h->N == 4);
     const bool imr_coop = imr && !imr_rl && !imr_quad;
+    const bool imr_parts = imr_coop && h->parts > 1;      // N > 16: one workgroup per evaluation, its 16-column parts in turn
     // (both images of a step resident in LDS when they fit; dense 96 x 96 operators: the <6, 5> instantiation that reads them from
     //  HBM / L2 per product like the Ntot > 96 variants)
     const bool imr_hbm = imr_coop && h->NT <= 6 && h->mat_elems_c > 0 && coop_imr_lds_bytes(h->NT, h->mat_elems_c) > 163840;
@@ -1982,18 +2012,18 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     lane_term_t klterm = nullptr;
     int rc = imr_cq ? select_cq_imr_kernels(h, &kfwd, &kbwd)
              : imr_quad ? select_quad_imr_kernels(h, &kfwd, &kbwd)
-             : imr_coop ? select_coop_imr_kernels(h, imr_hbm, &kfwd, &kbwd)
+             : imr_coop ? (imr_parts ? select_coop_imr_parts_kernels(h, imr_hbm, &kfwd, &kbwd) : select_coop_imr_kernels(h, imr_hbm, &kfwd, &kbwd))
              : imr_rl ? select_rowlane_imr_kernels(h, rl_split, &kfwd, &kbwd)
              : rl ? select_rowlane_kernels(h, rl_split, &kfwd, &kbwd)
              : lane ? select_lane_kernels(h, &kfwd, &kbwd, &klinit, &klterm)
                   : cq ? select_cq_kernels(h, &kfwd, &kbwd)
                   : coop ? select_coop_kernels(h, &kfwd, &kbwd) : quad ? (wfull ? select_quad_w_kernels(h, &kfwd, &kbwd) : select_quad_kernels(h, spw, &kfwd, &kbwd)) : select_kernels(h, &kfwd, &kbwd);
     if (rc) return rc;
-    const int nblocks = (cq || imr_cq) ? 4 * nslabs : rl ? (int)nwaves_rl : lane ? (int)(ncols / 64) : quad8 ? (nslabs + spw - 1) / spw : (coop || quad) ? nslabs : (nslabs + JQ_WAVES - 1) / JQ_WAVES;
+    const int nblocks = imr_parts ? nsamples : (cq || imr_cq) ? 4 * nslabs : rl ? (int)nwaves_rl : lane ? (int)(ncols / 64) : quad8 ? (nslabs + spw - 1) / spw : (coop || quad) ? nslabs : (nslabs + JQ_WAVES - 1) / JQ_WAVES;
     const int nthreads = (lane || rl) ? 64 : (coop || cq || imr_cq) ? 64 * h->NT : quad8 ? 256 * spw : 256;
     // per-step trace records: one per wave (cooperative, lane, row-lane, implicit-midpoint kernels) or one per workgroup
     // (slab / quad kernels: summed over the workgroup's waves in LDS)
-    const int trace_rows = imr_cq ? nslabs * qps * h->NT : cq ? nslabs * qps : (lane || rl) ? nblocks : coop ? nslabs * h->NT : imr_quad ? nslabs * JQ_WAVES : nblocks;
+    const int trace_rows = imr_parts ? nsamples * h->NT : imr_cq ? nslabs * qps * h->NT : cq ? nslabs * qps : (lane || rl) ? nblocks : coop ? nslabs * h->NT : imr_quad ? nslabs * JQ_WAVES : nblocks;
     const long long stride = rl ? h->rl_stride : lane ? h->lane_stride : coop ? h->mat_elems_c : h->mat_elems;
     const double* himg = rl ? h->d_himg_r : lane ? h->d_himg_l : coop ? h->d_himg_c : h->d_himg;
     const size_t state_doubles = rl ? (size_t)JQ_ROWLANE_ROWS * nwaves_rl * 64
@@ -2025,10 +2055,12 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
         h->cap_state = state_doubles;
     }
     if ((rc = dev_grow(h, &h->d_colinfo, &h->cap_colinfo, colinfo_doubles))) return rc;
-    if (!lane && !rl && ((size_t)nslabs > h->cap_slabs || !h->d_park)) {
+    // (parking images of the slab kernels: one array per slab; implicit midpoint with N > 16: the work area of ImrParts, ten)
+    const size_t park_slabs = (size_t)nslabs * (imr_parts ? JQ_IMRP_ARRAYS : 1);
+    if (!lane && !rl && (park_slabs > h->cap_slabs || !h->d_park)) {
         h->cap_slabs = 0;
-        if ((rc = dev_alloc(h, &h->d_park, (size_t)nslabs * h->KT * 64))) return rc;
-        h->cap_slabs = nslabs;
+        if ((rc = dev_alloc(h, &h->d_park, park_slabs * h->KT * 64))) return rc;
+        h->cap_slabs = park_slabs;
     }
     if (adjoint && (rc = dev_grow(h, &h->d_traces, &h->cap_traces, (size_t)trace_rows * cs * ntr))) return rc;
     if ((rc = dev_grow(h, &h->d_grad, &h->cap_grad, (size_t)2 * ncoeff))) return rc;
@@ -2168,7 +2200,10 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     HIPCHK(h, hipGetLastError());
     mfma_fwd = mfma;
     const double leak_scale = imr ? 0.25 * dt * (1.0 / h->T) : 0.5 * dt * (1.0 / h->T);
-    if (imr_coop || imr_quad)
+    if (imr_parts)
+        hipLaunchKernelGGL(k_terminal_parts, dim3(nsamples), dim3(64), 0, s, h->d_state, h->state_stride, h->d_vtr, h->d_vti, h->KT,
+                           h->N, h->parts, leak_scale, h->d_res, 1);
+    else if (imr_coop || imr_quad)
         hipLaunchKernelGGL(k_terminal_imr, dim3(nslabs), dim3(64), 0, s, h->d_state, h->state_stride, h->d_vtr, h->d_vti, h->KT,
                            h->N, h->sps, nsamples, leak_scale, h->d_res);
     else if (imr)
@@ -2182,7 +2217,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
                            nsamples, leak_scale, h->d_res);
     else if (h->parts > 1)
         hipLaunchKernelGGL(k_terminal_parts, dim3(nsamples), dim3(64), 0, s, h->d_state, h->state_stride, h->d_vtr, h->d_vti, h->KT,
-                           h->N, h->parts, leak_scale, h->d_res);
+                           h->N, h->parts, leak_scale, h->d_res, 0);
     else
         hipLaunchKernelGGL(k_terminal, dim3(nslabs), dim3(64), 0, s, h->d_state, h->state_stride, h->d_vtr, h->d_vti, h->KT,
                            h->N, h->sps, nsamples, leak_scale, h->d_res);

@@ -24,6 +24,8 @@ def run(n_cases=50, seed=1, verbose=True):
         case += 1
         Ntot = int(rng.choice([2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 14, 16, 17, 20, 31, 32, 33, 40, 48, 50, 63, 64, 65, 80, 81, 95, 96, 100, 112, 128, 150, 200]))
         N = int(rng.integers(1, min(Ntot, 16) + 1))
+        if Ntot >= 17 and rng.random() < 0.12:      # (round 4: more than 16 columns per evaluation, both integrators)
+            N = int(rng.integers(17, min(Ntot, 32) + 1))
         Nc = int(rng.integers(1, 5)) if rng.random() < 0.75 else int(rng.integers(5, 10))      # (round 3: control groups)
         Nfreq = int(rng.integers(1, 4))
         nsteps = int(rng.integers(3, 24))
@@ -33,7 +35,7 @@ def run(n_cases=50, seed=1, verbose=True):
         structure = structure if isinstance(structure, str) else bool(structure)
         imr = bool(rng.random() < 0.3) and (Ntot <= 16 or structure is not False)
         if Ntot > 96:      # 4 x 4 x 7 / 4 x 4 x 8 on the NT = 7, 8 instantiations (N = 1, 2, 4); anything else at this size: cooperative kernels
-            imr = imr and (structure != "t4" or N in (1, 2, 4))
+            imr = imr and (structure != "t4" or N in (1, 2, 4) or N > 16)
         if os.environ.get("FUZZ_FOCUS") == "imr_cq":      # the cooperative-quad implicit-midpoint kernels: 4 x 4 x n structure, N = 4
             Ntot, N, structure, imr = int(rng.choice([32, 48, 64, 80, 96])), 4, "t4", True
         env = {}
@@ -52,7 +54,15 @@ def run(n_cases=50, seed=1, verbose=True):
             k, v = mode.split("=")
             env[k] = v
         p, pcof = random_problem(jq, rng, Ntot, N, Nc, Nfreq, nsteps, m, oft, structure)
-        jac = (not imr) and rng.random() < 0.15      # (round 3: the Jacobi solver with a loose tolerance -- per-sample convergence)
+        jac = (not imr) and N <= 16 and rng.random() < 0.15      # (round 3: the Jacobi solver with a loose tolerance -- per-sample convergence;
+        #                                                             N > 16 converges per 16-column part: O(tol), tests/test_gpu_round4.py)
+        wfull = (not imr) and (not jac) and rng.random() < 0.12      # (round 4: full / complex leakage weights, rank 1 .. 4)
+        if wfull:
+            nf = int(rng.integers(1, 5))
+            fs = rng.standard_normal((Ntot, nf)) + (1j * rng.standard_normal((Ntot, nf)) if rng.random() < 0.7 else 0)
+            fs = fs / np.linalg.norm(fs, axis=0)
+            Wf = sum((0.5 + rng.random()) * np.outer(fs[:, k], np.conj(fs[:, k])) for k in range(nf))
+            p.wmat_real, p.wmat_imag = np.asfortranarray(Wf.real.copy()), np.asfortranarray(Wf.imag.copy())
         jtol = float(10.0 ** rng.integers(-12, -4))
         if imr:
             p.Integrator_id = jq.Implicit_Midpoint
@@ -128,7 +138,7 @@ def run(n_cases=50, seed=1, verbose=True):
         flag = (("   (fixed-point iteration not converged: loose bound %.0e)" % loose) if err < loose else "   <<<<<< MISMATCH (unconverged draw, above its loose bound)") \
             if unconv else ("" if err < 1e-8 else "   <<<<<< MISMATCH")
         nonlocal_print("%3d Ntot=%2d N=%2d Nc=%d Nf=%d steps=%2d m=%d oft=%d %-5s %s nq=%2d fam=%d %-18s env=%s%s%s err=%.1e%s" % (
-            case, Ntot, N, Nc, Nfreq, nsteps, m, oft, structure, "IMR" if imr else ("JAC" if jac else "SV "), nq, fam, mode,
+            case, Ntot, N, Nc, Nfreq, nsteps, m, oft, structure, "IMR" if imr else ("JAC" if jac else ("SVW" if wfull else "SV ")), nq, fam, mode,
             env.get("JQ_CHUNK_STEPS", "-"), " replan" if replan else "", (" tol=%.0e" % jtol) if jac else "", err, flag), flush=True)
         wa.close()
     nonlocal_print("worst relative error %.2e over %d compared cases (of %d drawn; %d implicit-midpoint draws with an unconverged fixed-point "
