@@ -21,6 +21,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -936,6 +937,7 @@ struct PropArgs {
     const double* wlr;
     int wrank;
     int wstride;
+    int wlr_lds;            // slab / quad kernels: byte offset in dynamic LDS where the workgroup keeps a copy of the table, or -1 (read it from global memory)
 };
 #ifndef JQ_MAX_WRANK
 #define JQ_MAX_WRANK 16       // largest rank of a full weight matrix the kernels take (include/juqbox_hip.h)
@@ -951,13 +953,19 @@ __host__ __device__ inline void sched_pack(unsigned long long* words, int i, int
 // i.e. two column dot products and two axpys per forbidden state instead of a dense product.  A column's rows sit in the
 // lanes l, l ^ 16, l ^ 32, l ^ 48 (slab layout: row 16 i + 4 r + (l >> 4)) or in the 16 lanes with the same l & 3 (quad layout:
 // row 16 i + 4 ((l >> 2) & 3) + (l >> 4)); the dots are all-reduced over them, so every lane of a column holds the column's value.
+// (the cross-row stages use gfx950's row-swap instructions on two copies of the value -- v_permlane32_swap leaves [lo | lo] and
+//  [hi | hi], v_permlane16_swap the even and the odd rows twice -- six VALU instructions per value; __shfl_xor goes through the LDS
+//  crossbar, whose latency a lone wave cannot hide: cnot3 with two forbidden states 601 -> 5xx ms per evaluation)
 template <bool QUAD>
 __device__ __forceinline__ double col_allsum(double x)
 {
     if constexpr (QUAD) x = row_ror_add<8>(row_ror_add<4>(x));
-    x += __shfl_xor(x, 16);
-    x += __shfl_xor(x, 32);
-    return x;
+    double y = x;
+    row_swap32(x, y);      // x = [x_lo, x_lo], y = [x_hi, x_hi] (32-lane halves)
+    x += y;
+    y = x;
+    row_swap16(x, y);      // x: rows 0, 0, 2, 2; y: rows 1, 1, 3, 3
+    return x + y;
 }
 template <int NT, bool QUAD>
 struct WLow {
@@ -965,12 +973,21 @@ struct WLow {
     const double* lamp;     // lam[k]
     int r, stride;
     bool lead;      // one lane per column: adds the column's scalar terms to a per-lane partial sum
-    __device__ __forceinline__ void init(const PropArgs& a, int lane_)
+    // (smem: the workgroup's dynamic LDS.  With a.wlr_lds >= 0 the table is copied there once -- a lone wave cannot hide the latency
+    //  of global reads inside every time step; contains a workgroup barrier then: call it from every wave)
+    __device__ __forceinline__ void init(const PropArgs& a, int lane_, char* smem)
     {
         r = a.wrank;
         stride = a.wstride;
-        lamp = a.wlr;
-        tab = a.wlr + JQ_MAX_WRANK + (QUAD ? 4 * ((lane_ >> 2) & 3) + (lane_ >> 4) : (lane_ >> 4));
+        const double* base = a.wlr;
+        if (r > 0 && a.wlr_lds >= 0) {
+            double* l = (double*)(smem + a.wlr_lds);
+            for (int i = threadIdx.x; i < JQ_MAX_WRANK + 2 * r * stride; i += blockDim.x) l[i] = a.wlr[i];
+            __syncthreads();
+            base = l;
+        }
+        lamp = base;
+        tab = base + JQ_MAX_WRANK + (QUAD ? 4 * ((lane_ >> 2) & 3) + (lane_ >> 4) : (lane_ >> 4));
         lead = QUAD ? lane_ < 4 : lane_ < 16;
     }
     __device__ __forceinline__ double lam(int k) const { return lamp[k]; }
@@ -1469,6 +1486,22 @@ __device__ __forceinline__ void horner_add(Arr<NT>& out, const Arr<NT>& bpa, con
 
 // LDS / global parking of a dormant state array (one [4*NT][64] image per wave)
 template <int NT>
+__device__ __forceinline__ void a_park(const Arr<NT>& a, __attribute__((address_space(3))) double* park)
+{
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < JQ_RL; ++r) park[(JQ_RL * i + r) * 64] = a.t[i][r];
+}
+template <int NT>
+__device__ __forceinline__ void a_unpark(Arr<NT>& a, const __attribute__((address_space(3))) double* park)
+{
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < JQ_RL; ++r) a.t[i][r] = park[(JQ_RL * i + r) * 64];
+}
+template <int NT>
 __device__ __forceinline__ void a_park(const Arr<NT>& a, double* park)
 {
 #pragma unroll
@@ -1648,7 +1681,7 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
     p.init(smem, a, wave, lane_, NWAVES);
     constexpr bool WLR = jq_wlr_on<BW, JAC, WLRT>();
     WLow<NT, QUAD> wl;
-    if constexpr (WLR) wl.init(a, lane_);
+    if constexpr (WLR) wl.init(a, lane_, smem);
 
     // one time step: (u, v) -> (unew, vN); v is consumed (becomes v05).  The two array pairs swap
     // roles every step, so the loop body is written for two steps and nothing is ever copied.
@@ -1715,7 +1748,10 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
 // Register budget (512 per lane, 8 per array element pair): at most 9 state-sized arrays are live at
 // any point (8 since vr0 dies after the early traces); the one array that is dormant in each phase (lambda_r during the state step, v during the
 // adjoint step and the traces) is parked in the wave's LDS (or global) parking image.
-template <int NT, int BW, int MINW, bool JAC, bool WLRT = false>
+// UNI: every wave's columns belong to ONE ensemble sample (quad layout with N a multiple of 4, or N > 16): its shift and weight
+// are wave-uniform and live in scalar registers -- four vector registers less in the 168-register three-slab kernel (round 4: with
+// the LDS parking pointer 136 -> 108 B of scratch, 60 -> 38 scratch instructions per step, 1 098 -> 1 085 ms; results bit-identical)
+template <int NT, int BW, int MINW, bool JAC, bool WLRT = false, bool UNI = false>
 __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_T4Q) ? 1 : MINW) void k_backward(PropArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1742,9 +1778,17 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
     double* carry = tab + 32 * NT;  // [Ncoupled][threads of the workgroup]
     for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[(i & ~15) + 4 * (i & 3) + ((i >> 2) & 3)] = a.tabs[i];   // [block][g][r]
     double* st = a.state + (size_t)(active ? slab : 0) * a.state_stride;
-    // parking image of this wave: in LDS when it fits, else in HBM
-    double* P0 = a.park_lds ? (carry + Nc * NTHREADS + (size_t)wave * (JQ_RL * NT) * 64 + lane_)
-                            : (a.park + (size_t)(active ? slab : 0) * KT * 64 + lane);
+    // parking image of this wave: in LDS when it fits, else in HBM.  The quad-layout kernels always park in LDS: a 32-bit LDS pointer
+    // (ds_read / ds_write) instead of a generic one -- flat_load / flat_store carry a 64-bit address per lane and count on vmcnt AND
+    // lgkmcnt (round 4: cnot3 x 3 072 samples 1 098 -> 1 090 ms, fewer spilled registers)
+    typedef __attribute__((address_space(3))) double lds_double;
+    typedef typename std::conditional<QUAD, lds_double*, double*>::type park_ptr;
+    park_ptr P0;
+    if constexpr (QUAD)
+        P0 = (lds_double*)(carry + Nc * NTHREADS + (size_t)wave * (JQ_RL * NT) * 64 + lane_);
+    else
+        P0 = a.park_lds ? (carry + Nc * NTHREADS + (size_t)wave * (JQ_RL * NT) * 64 + lane_)
+                        : (a.park + (size_t)(active ? slab : 0) * KT * 64 + lane);
     // Per-step trace scalars: every wave leaves its Ncoupled * JQ_NTR wave sums of step n in the LDS record
     // rec[n & 1][wave][8 Ncoupled] (one wave_sum4 group of four slots per control for the early values t1, t3 and one for
     // the late values t2, t4, t5; a group's values a, b, c sit in the rows = slots 0, 2, 1); once the whole workgroup has passed a barrier behind step n, wave 0 adds the waves' records in
@@ -1789,6 +1833,10 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
         a_load(nb, st + 3 * KT * 64, lane);
         ceps = 0.5 * a.h * a.colinfo[(size_t)slab * 32 + col];
         wgt = a.colinfo[(size_t)slab * 32 + 16 + col];
+        if constexpr (UNI) {
+            ceps = lane_bcast(ceps, 0);
+            wgt = lane_bcast(wgt, 0);
+        }
         for (int q = 0; q < Nc; ++q) carry[q * NTHREADS + threadIdx.x] = cslot ? st[(JQ_STATE_ARRAYS * KT + q) * 64 + clane] : 0.0;
     } else {
         a_zero(u);
@@ -1805,7 +1853,7 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
     // hi1 = hi0 - Wi vr(t_n) / T (src/evalobjgrad.jl:862, :882-888)
     constexpr bool WLR = jq_wlr_on<BW, JAC, WLRT>();
     WLow<NT, QUAD> wl;
-    if constexpr (WLR) wl.init(a, lane_);
+    if constexpr (WLR) wl.init(a, lane_, smem);
     const bool wforce = WLR && a.wrank > 0 && a.forced;
 
     if (a.first_chunk) {

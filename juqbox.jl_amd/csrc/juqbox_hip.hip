@@ -1515,7 +1515,8 @@ static int select_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
     extern template __global__ void k_forward<nt, JQ_BW_T4Q, 2, false>(PropArgs);    \
     extern template __global__ void k_backward<nt, JQ_BW_T4Q, 2, false>(PropArgs);   \
     extern template __global__ void k_forward<nt, JQ_BW_T4Q, 3, false>(PropArgs);    \
-    extern template __global__ void k_backward<nt, JQ_BW_T4Q, 3, false>(PropArgs);
+    extern template __global__ void k_backward<nt, JQ_BW_T4Q, 3, false>(PropArgs);   \
+    extern template __global__ void k_backward<nt, JQ_BW_T4Q, 3, false, false, true>(PropArgs);
 JQ_DECLQ(1) JQ_DECLQ(2) JQ_DECLQ(3) JQ_DECLQ(4) JQ_DECLQ(5) JQ_DECLQ(6) JQ_DECLQ(7) JQ_DECLQ(8)
 #undef JQ_DECLQ
 template <int NT, bool MODD> __global__ void k_forward_cq(PropArgs);            // jq_cq_kernels.h (own translation units)
@@ -1589,10 +1590,13 @@ static int select_cq_imr_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t
 // (spw: slabs per workgroup = waves per SIMD: workgroups of 4 spw waves)
 static int select_quad_kernels(jq_handle* h, int spw, prop_kernel_t* fwd, prop_kernel_t* bwd)
 {
+    // one ensemble sample per wave (four columns of a slab): N a multiple of 4 (N <= 16 divides the slab into whole samples), or N > 16
+    const bool uni = (h->N % 4 == 0 || h->parts > 1) && !getenv("JQ_NO_UNI");
 #define JQ_PICKQ(nt)                                                                                                                             \
     if (h->NT == nt) {                                                                                                                           \
         *fwd = spw == 3 ? k_forward<nt, JQ_BW_T4Q, 3, false> : spw == 2 ? k_forward<nt, JQ_BW_T4Q, 2, false> : k_forward<nt, JQ_BW_T4Q, 1, false>;     \
-        *bwd = spw == 3 ? k_backward<nt, JQ_BW_T4Q, 3, false> : spw == 2 ? k_backward<nt, JQ_BW_T4Q, 2, false> : k_backward<nt, JQ_BW_T4Q, 1, false>;  \
+        *bwd = spw == 3 ? (uni ? k_backward<nt, JQ_BW_T4Q, 3, false, false, true> : k_backward<nt, JQ_BW_T4Q, 3, false>)                      \
+                        : spw == 2 ? k_backward<nt, JQ_BW_T4Q, 2, false> : k_backward<nt, JQ_BW_T4Q, 1, false>;  \
         return JQ_OK;                                                                                                                            \
     }
     JQ_PICKQ(1) JQ_PICKQ(2) JQ_PICKQ(3) JQ_PICKQ(4) JQ_PICKQ(5) JQ_PICKQ(6) JQ_PICKQ(7) JQ_PICKQ(8)
@@ -2115,7 +2119,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     a.tabs = h->d_tabs; a.stride = stride; a.pieces = (int)(stride * 8 / 1024); a.nslots = h->nslots; a.m = h->m;
     a.nslabs = rl ? (int)nwaves_rl : lane ? (int)ncols : nslabs; a.Ncoupled = ctrl_gstart(h->Nc, 1) /* first control group */; a.Ntot = h->Ntot; a.N = h->N; a.use_shift = use_shift ? 1 : 0;
     a.tinv = 1.0 / h->T; a.state_stride = h->state_stride; a.parts = h->parts; a.nsamples = nsamples; a.sps = h->sps; a.qps = qps;
-    a.wlr = h->d_wlr; a.wrank = h->wrank; a.wstride = h->NP;
+    a.wlr = h->d_wlr; a.wrank = h->wrank; a.wstride = h->NP; a.wlr_lds = -1;
     // JACOBI_SOLVER: the kernels iterate on c-scaled right-hand sides (A = c rhs, c = h / 2: DESIGN.md section 3), so their
     // residual norm is |c| times the reference's ||X_j - X_{j-1}|| (src/linear_solvers.jl:121): the threshold is scaled alike
     a.jacobi_tol2 = (h->solver_id == 2) ? (h->solver_tol * 0.5 * dt) * (h->solver_tol * 0.5 * dt) : 0.0;
@@ -2138,13 +2142,17 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
                                 : imr_quad ? lds_fwd + (size_t)JQ_MAXNC * nthreads * 8 + (size_t)(nthreads / 64) * h->NT * 64 * 8
                                 : quad ? lds_stage + (size_t)bwd_lds_tail(h->NT, h->NcK, nthreads / 64, (long long)h->NT * 64)   // (a 16-row block per register)
                                 : lds_stage + (size_t)bwd_lds_tail(h->NT, h->NcK, JQ_WAVES, h->park_lds ? (long long)h->KT * 64 : 0);
+    // full leakage weights on the slab / quad kernels: a copy of the low-rank table behind everything else in LDS when it fits
+    const size_t wlr_bytes = (wfull && !coop && !rl && !lane) ? ((size_t)JQ_MAX_WRANK + (size_t)2 * h->wrank * h->NP) * 8 : 0;
+    const int wlr_lds_fwd = (wlr_bytes && lds_fwd + wlr_bytes <= 163840) ? (int)lds_fwd : -1;
+    const int wlr_lds_bwd = (wlr_bytes && lds_bwd + wlr_bytes <= 163840) ? (int)lds_bwd : -1;
     a.batch = batch; a.lds_tab_off = (int)lds_stage;
     a.park = h->d_park; a.park_lds = quad ? 1 : h->park_lds;
     if (cq) a.nslots = 0;
     if (const char* e = getenv("JQ_DEBUG")) a.debug = atoi(e);
     if (!lane && !rl) {
-        HIPCHK(h, hipFuncSetAttribute((const void*)kfwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fwd));
-        HIPCHK(h, hipFuncSetAttribute((const void*)kbwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bwd));
+        HIPCHK(h, hipFuncSetAttribute((const void*)kfwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_fwd + (wlr_lds_fwd >= 0 ? wlr_bytes : 0))));
+        HIPCHK(h, hipFuncSetAttribute((const void*)kbwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_bwd + (wlr_lds_bwd >= 0 ? wlr_bytes : 0))));
     }
 
     // events: [0]=start [1]=end, then pairs around every propagator launch
@@ -2182,6 +2190,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
                            h->Nc, stride, 0.5 * dt, h->d_stream);
         a.nsteps_chunk = nc; a.step0 = n0; a.first_chunk = (n0 == 0); a.h = dt; a.forced = 1;
         a.hist_r = hist_r; a.hist_i = hist_i;
+        a.wlr_lds = wlr_lds_fwd;
         a.period = 7; a.npro = 0; a.nslots = h->nslots;
         {   // slab kernels: Kp05 S05 Kn0 S0 Kn1 S1 Kp05 ; cooperative kernels: Kp05 S05 Kn0 Kn1 S0 S1 Kp05
             // {kind (0 K, 1 S, 2 constant image), time point offset / image index}
@@ -2193,7 +2202,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
             for (int i = 0; i < 7; ++i) sched_pack(a.sched_bits, i, kinds[i], tps[i]);
         }
         HIPCHK(h, hipEventRecord(h->ev[evi++], s));
-        hipLaunchKernelGGL(kfwd, dim3(nblocks), dim3(cq ? nthreads + 128 : imr_cq ? nthreads + 128 : nthreads), lds_fwd, s, a);      // (cooperative quad: two staging waves)
+        hipLaunchKernelGGL(kfwd, dim3(nblocks), dim3(cq ? nthreads + 128 : imr_cq ? nthreads + 128 : nthreads), lds_fwd + (wlr_lds_fwd >= 0 ? wlr_bytes : 0), s, a);      // (cooperative quad: two staging waves)
         HIPCHK(h, hipEventRecord(h->ev[evi++], s));
         mfma += (long long)nslabs * nc * (8 + 2 * h->m) * tiles;
     }
@@ -2252,6 +2261,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
                                    h->d_pq, h->Nc, stride, -0.5 * dt, h->d_stream);
                 a.nsteps_chunk = nc; a.step0 = n0; a.first_chunk = (n0 == 0); a.h = -dt; a.forced = (pass == 0);
                 a.hist_r = nullptr; a.hist_i = nullptr;
+                a.wlr_lds = wlr_lds_bwd;
                 a.period = 13 + 3 * ng; a.npro = (n0 == 0) ? ng : 0; a.nslots = h->nslots_bwd;
                 {   // Kp05 S05 Kn0 S0 Kn1 S1 Kp05 | S0 | Hanti_q.. | Kn0 Kn1 S05 Kp05 S1 | (Hanti_q Hsym_q)..
                     const int kinds_s[8] = {0, 1, 0, 1, 0, 1, 0, 1}, tps_s[8] = {1, 1, 0, 0, 2, 2, 1, 0};
@@ -2271,7 +2281,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
                     }
                 }
                 HIPCHK(h, hipEventRecord(h->ev[evi++], s));
-                hipLaunchKernelGGL(kbwd, dim3(nblocks), dim3((cq || rl_split) ? 2 * nthreads : imr_cq ? nthreads + 128 : nthreads), lds_bwd, s, a);      // (cooperative quad: state and adjoint chain on separate waves)
+                hipLaunchKernelGGL(kbwd, dim3(nblocks), dim3((cq || rl_split) ? 2 * nthreads : imr_cq ? nthreads + 128 : nthreads), lds_bwd + (wlr_lds_bwd >= 0 ? wlr_bytes : 0), s, a);      // (cooperative quad: state and adjoint chain on separate waves)
                 HIPCHK(h, hipEventRecord(h->ev[evi++], s));
                 hipLaunchKernelGGL(k_trace_reduce, dim3((unsigned)(((long long)nc * ntr_g + 255) / 256)), dim3(256), 0, s,
                                    h->d_traces, trace_rows, nc, ntr_g, h->d_R);

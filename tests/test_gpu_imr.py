@@ -96,17 +96,20 @@ def test_imr_matches_oracle_including_history_and_ensemble(jq, case):
     wa.close()
 
 
-def test_imr_is_refused_where_it_is_not_implemented(jq):
-    """More than 16 columns per evaluation: the solver's per-evaluation stopping test needs them in one workgroup."""
+def test_imr_with_more_than_16_columns_runs_on_the_parts_kernels(jq):
+    """Rounds 1-3 refused more than 16 columns per evaluation (the solver's per-evaluation stopping test needs them in one
+    workgroup); round 4: one cooperative workgroup per evaluation walks over its 16-column parts (tests/test_gpu_round4.py)."""
+    from oracle.oracle import Oracle
     from test_gpu_random import random_problem
     p, pcof = random_problem(jq, np.random.default_rng(1), 20, 18, 1, 1, 5, 1, 1, False)
     p.Integrator_id = jq.Implicit_Midpoint
     p.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER_M, max_iter=50, tol=1e-11, nrhs=18)
     p.wmat = p.wmat_real.copy()
     wa = jq.Working_Arrays_M_HIP(p, pcof.size)
-    with pytest.raises(RuntimeError) as e:
-        jq.traceobjgrad(pcof, p, wa)
-    assert "implicit" in str(e.value).lower()
+    r = Oracle(p, use_sparse=False).traceobjgrad_imr(pcof, 50, 1e-11)
+    objfv, tg = jq.traceobjgrad(pcof, p, wa)[:2]
+    assert wa.last_timing()["kernel_family"] == 5
+    assert abs(objfv - r["objfv"]) <= 1e-9 * abs(r["objfv"]) and np.linalg.norm(tg - r["totalgrad"]) <= 1e-9 * np.linalg.norm(r["totalgrad"])
     wa.close()
 
 
