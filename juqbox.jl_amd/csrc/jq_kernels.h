@@ -211,6 +211,19 @@ __device__ __forceinline__ void a_axpy_rows(Arr<NT>& y, double c, const double* 
     for (int i = 0; i < NT; ++i) y.t[i] += jq_row(c * t4[4 * i]) * x.t[i];
 #endif
 }
+// y += (+-) tab .* x   (a table that carries its coefficient already)
+template <int NT, bool NEG>
+__device__ __forceinline__ void a_axpy_rows1(Arr<NT>& y, const double* tab, int g, const Arr<NT>& x)
+{
+#if JQ_RL == 1
+#pragma unroll
+    for (int i = 0; i < NT; ++i) y.t[i][0] = fma(NEG ? -tab[16 * i + g] : tab[16 * i + g], x.t[i][0], y.t[i][0]);
+#else
+    const d4* t4 = (const d4*)(tab + 4 * g);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) y.t[i] += jq_row(NEG ? -t4[4 * i] : t4[4 * i]) * x.t[i];
+#endif
+}
 // sum_rows tab[row] * x[row]^2
 template <int NT>
 __device__ __forceinline__ double a_wsq(const double* tab, int g, const Arr<NT>& x)
@@ -586,8 +599,13 @@ __device__ __forceinline__ void t4q_block(Arr<NT>& D, const Arr<NT>& C, const Ar
     xold = xc;
     D.t[mt][0] = acc;
 }
-template <int NT, bool ZEROC, int MODE>
-__device__ __forceinline__ void mm_t4q(Arr<NT>& D, const Arr<NT>& C, const double* mat, const Arr<NT>& x)
+// SH (round 4): the ensemble shift of the sample, K' = K + eps diag(ws), folded into the MFMA's A operand -- lane 16 k + 4 b + i holds
+// B[i][k], so the lanes with k == i carry the diagonal and, there, the operand's row equals the row of the lane in the STATE layout:
+// a' = a + shd * ws[row], shd = (k == i) ? +-c eps : 0 per lane, ws read from the same row table a_axpy_rows reads.  One FMA per block
+// on the operand instead of a multiply and an FMA per block on the result (a wave must hold ONE sample: the UNI kernels).
+template <int NT, bool ZEROC, int MODE, bool SH = false>
+__device__ __forceinline__ void mm_t4q(Arr<NT>& D, const Arr<NT>& C, const double* mat, const Arr<NT>& x, double shd = 0.0,
+                                       const double* wsr = nullptr)
 {
     constexpr bool diag = MODE & JQ_T4_DIAG, coef = (MODE & (JQ_T4_RTERMS | JQ_T4_MTERMS)) != 0;
     const int lane = threadIdx.x & 63;
@@ -596,6 +614,7 @@ __device__ __forceinline__ void mm_t4q(Arr<NT>& D, const Arr<NT>& C, const doubl
     double a_cur = 0.0;
     d4 c_cur = {0.0, 0.0, 0.0, 0.0};
     if constexpr (diag) a_cur = ma[0];
+    if constexpr (diag && SH) a_cur = fma(shd, wsr[0], a_cur);
     if constexpr (coef) c_cur = t4q_cload(cf, 0);
     double xold = 0.0;
 #ifdef JQ_EXP_NOPF      // experiment: the operands of THIS block only (no one-block-ahead prefetch: 10 registers less in flight)
@@ -616,6 +635,7 @@ __device__ __forceinline__ void mm_t4q(Arr<NT>& D, const Arr<NT>& C, const doubl
         const d4 c = c_cur;
         if (mt + 1 < NT) {
             if constexpr (diag) a_cur = ma[(mt + 1) * 64];
+            if constexpr (diag && SH) a_cur = fma(shd, wsr[16 * (mt + 1)], a_cur);
             if constexpr (coef) c_cur = t4q_cload(cf, mt + 1);
         }
         t4q_block<NT, ZEROC, MODE>(D, C, x, mt, a, c, xold);
@@ -623,9 +643,10 @@ __device__ __forceinline__ void mm_t4q(Arr<NT>& D, const Arr<NT>& C, const doubl
 }
 // Two / three products with the SAME right-hand side in one pass over the blocks (round 3): D_k = C_k + M_k x.  The lane shifts
 // of x (four v_mov_b32_dpp per block, as expensive as the block's MFMA) are made once for all of them.  x must not alias a D_k.
-template <int NT, int NP, bool Z0, bool Z1, bool Z2>
+template <int NT, int NP, bool Z0, bool Z1, bool Z2, int SH = 0>      // SH: bit k = operator k is a K image and takes the folded shift
 __device__ __forceinline__ void mm_t4q_multi(Arr<NT>& D0, const Arr<NT>& C0, const double* m0, Arr<NT>& D1, const Arr<NT>& C1,
-                                             const double* m1, Arr<NT>& D2, const Arr<NT>& C2, const double* m2, const Arr<NT>& x)
+                                             const double* m1, Arr<NT>& D2, const Arr<NT>& C2, const double* m2, const Arr<NT>& x,
+                                             double sh0 = 0.0, double sh1 = 0.0, double sh2 = 0.0, const double* wsr = nullptr)
 {
     const int lane = threadIdx.x & 63;
     const double* ma[3] = {t4q_a(m0, lane), t4q_a(m1, lane), t4q_a(NP > 2 ? m2 : m1, lane)};
@@ -641,6 +662,12 @@ __device__ __forceinline__ void mm_t4q_multi(Arr<NT>& D0, const Arr<NT>& C0, con
         for (int k = 0; k < NP; ++k) {
             a[k] = ma[k][mt * 64];
             c[k] = t4q_cload(cf[k], mt);
+        }
+        if constexpr (SH != 0) {      // (shift folded into the A operands of the K images, see mm_t4q)
+            const double w = wsr[16 * mt];
+            if constexpr (SH & 1) a[0] = fma(sh0, w, a[0]);
+            if constexpr (SH & 2) a[1] = fma(sh1, w, a[1]);
+            if constexpr (NP > 2 && (SH & 4)) a[2] = fma(sh2, w, a[2]);
         }
         const double xc = x.t[mt][0], xn = x.t[mt + 1 < NT ? mt + 1 : mt][0];
         const double su = row_shift4<0x114>(xc), sd = row_shift4<0x104>(xc);
@@ -674,17 +701,18 @@ __device__ __forceinline__ void mm_t4q_multi(Arr<NT>& D0, const Arr<NT>& C0, con
         __builtin_amdgcn_sched_barrier(0);
     }
 }
-template <int NT, bool Z0, bool Z1>
+template <int NT, bool Z0, bool Z1, int SH = 0>
 __device__ __forceinline__ void mm_t4q2(Arr<NT>& D0, const Arr<NT>& C0, const double* m0, Arr<NT>& D1, const Arr<NT>& C1,
-                                        const double* m1, const Arr<NT>& x)
+                                        const double* m1, const Arr<NT>& x, double sh0 = 0.0, double sh1 = 0.0, const double* wsr = nullptr)
 {
-    mm_t4q_multi<NT, 2, Z0, Z1, true>(D0, C0, m0, D1, C1, m1, D1, C1, m1, x);
+    mm_t4q_multi<NT, 2, Z0, Z1, true, SH>(D0, C0, m0, D1, C1, m1, D1, C1, m1, x, sh0, sh1, 0.0, wsr);
 }
-template <int NT, bool Z0, bool Z1, bool Z2>
+template <int NT, bool Z0, bool Z1, bool Z2, int SH = 0>
 __device__ __forceinline__ void mm_t4q3(Arr<NT>& D0, const Arr<NT>& C0, const double* m0, Arr<NT>& D1, const Arr<NT>& C1,
-                                        const double* m1, Arr<NT>& D2, const Arr<NT>& C2, const double* m2, const Arr<NT>& x)
+                                        const double* m1, Arr<NT>& D2, const Arr<NT>& C2, const double* m2, const Arr<NT>& x,
+                                        double sh0 = 0.0, double sh1 = 0.0, double sh2 = 0.0, const double* wsr = nullptr)
 {
-    mm_t4q_multi<NT, 3, Z0, Z1, Z2>(D0, C0, m0, D1, C1, m1, D2, C2, m2, x);
+    mm_t4q_multi<NT, 3, Z0, Z1, Z2, SH>(D0, C0, m0, D1, C1, m1, D2, C2, m2, x, sh0, sh1, sh2, wsr);
 }
 // the same with the operator in registers (the m + 1 products of a Horner chain share it: no LDS latency at their heads)
 template <int NT>
@@ -1541,7 +1569,9 @@ __device__ __forceinline__ void a_unpark(Arr<NT>& a, const double* park)
 //   A, Ya, Yb: scratch arrays.          Operator order per step: Kp05 S05 Kn0 S0 Kn1 S1 (Kp05).
 // At most 8 arrays are live here (u, v/v05, unew, vN, A, Ya, Yb + one of the caller's).
 // FUSE (quad layout only): bit 0 = K05 u with S0 u in one pass, bit 1 = S05 v05 with K0 v05 and K1 v05 in one pass
-template <int NT, int BW, bool JAC, int FUSE = 0>
+// FOLD (quad layout, one sample per wave): `ceps` is the per-lane MASKED shift (+c eps on the lanes that hold the diagonal of the MFMA's
+// A operand, 0 elsewhere; 0 everywhere without a shift) and every product with a K image folds it into its operand (mm_t4q SH)
+template <int NT, int BW, bool JAC, int FUSE = 0, bool FOLD = false>
 __device__ __forceinline__ void sv_state(RingT<BW == JQ_BW_T4Q>& p, const PropArgs& a, bool active, double ceps, const double* ws, int g,
                                          const Arr<NT>& u, Arr<NT>& v, Arr<NT>& unew, Arr<NT>& vN, Arr<NT>& A, Arr<NT>& Ya,
                                          Arr<NT>& Yb)
@@ -1555,6 +1585,10 @@ __device__ __forceinline__ void sv_state(RingT<BW == JQ_BW_T4Q>& p, const PropAr
         const double* M0 = p.template next_ks<0, 1>();      // Kp05
         const double* M1 = p.template next_ks<1, 0>();      // S0
         if (active) {
+            if constexpr (FOLD) {
+                static_assert(!FOLD || (FUSE & 3) == 3 || FUSE == 0, "FOLD: fused or generic path");
+                mm_t4q2<NT, true, false, 1>(A, A, M0, unew, u, M1, u, ceps, 0.0, ws + g);
+            } else {
             if constexpr (FUSE & 1) {
                 mm_t4q2<NT, true, false>(A, A, M0, unew, u, M1, u);        // A = c K05 u ;  unew = u + c S0 u
             } else {
@@ -1562,6 +1596,7 @@ __device__ __forceinline__ void sv_state(RingT<BW == JQ_BW_T4Q>& p, const PropAr
                 mm_c<NT, BW>(unew, u, M1, u);
             }
             if (a.use_shift) a_axpy_rows(A, ceps, ws, g, u);
+            }
         }
         M0 = p.template next_ks<1, 1>();                    // S05
         if (active) {
@@ -1572,6 +1607,9 @@ __device__ __forceinline__ void sv_state(RingT<BW == JQ_BW_T4Q>& p, const PropAr
         M1 = p.template next_ks<0, 0>();                    // Kn0
         const double* M2 = p.template next_ks<0, 2>();      // Kn1
         if (active) {
+            if constexpr (FOLD) {
+                mm_t4q3<NT, false, false, true, 6>(vN, v, M0, unew, unew, M1, A, A, M2, v, 0.0, -ceps, -ceps, ws + g);
+            } else {
             if constexpr (FUSE & 2) {
                 mm_t4q3<NT, false, false, true>(vN, v, M0, unew, unew, M1, A, A, M2, v);     // vN = v05 + S05 v05 ; unew -= c K0 v05 ; A = -c K1 v05
             } else {
@@ -1583,6 +1621,7 @@ __device__ __forceinline__ void sv_state(RingT<BW == JQ_BW_T4Q>& p, const PropAr
                 a_axpy_rows(unew, -ceps, ws, g, v);
                 a_axpy_rows(A, -ceps, ws, g, v);
             }
+            }
         }
         M0 = p.template next_ks<1, 2>();                    // S1
         if (active) {
@@ -1592,11 +1631,16 @@ __device__ __forceinline__ void sv_state(RingT<BW == JQ_BW_T4Q>& p, const PropAr
         }
         return;
     }
+    constexpr int FULLQ = JQ_T4_DIAG | JQ_T4_RTERMS | JQ_T4_MTERMS;
     // use 0: Kp05 -- A = c K05 u
     const double* M = p.template next_ks<0, 1>();
     if (active) {
-        mm_z<NT, BW>(A, M, u);
-        if (a.use_shift) a_axpy_rows(A, ceps, ws, g, u);
+        if constexpr (FOLD) {
+            mm_t4q<NT, true, FULLQ, true>(A, A, M, u, ceps, ws + g);
+        } else {
+            mm_z<NT, BW>(A, M, u);
+            if (a.use_shift) a_axpy_rows(A, ceps, ws, g, u);
+        }
     }
     // use 1: S05 -- A = c (K05 u + S05 v) ; v05 = v + sum_j S^j A (in place) ; vN = v05 + S05 v05
     M = p.template next_ks<1, 1>();
@@ -1609,8 +1653,12 @@ __device__ __forceinline__ void sv_state(RingT<BW == JQ_BW_T4Q>& p, const PropAr
     // use 2: Kn0 -- unew = u - c K0 v05
     M = p.template next_ks<0, 0>();
     if (active) {
-        mm_c<NT, BW>(unew, u, M, v);
-        if (a.use_shift) a_axpy_rows(unew, -ceps, ws, g, v);
+        if constexpr (FOLD) {
+            mm_t4q<NT, false, FULLQ, true>(unew, u, M, v, -ceps, ws + g);
+        } else {
+            mm_c<NT, BW>(unew, u, M, v);
+            if (a.use_shift) a_axpy_rows(unew, -ceps, ws, g, v);
+        }
     }
     // use 3: S0 -- unew = u + c (S0 u - K0 v05) = u + c kappa1
     M = p.template next_ks<1, 0>();
@@ -1618,8 +1666,12 @@ __device__ __forceinline__ void sv_state(RingT<BW == JQ_BW_T4Q>& p, const PropAr
     // use 4: Kn1 -- A = -c K1 v05
     M = p.template next_ks<0, 2>();
     if (active) {
-        mm_z<NT, BW>(A, M, v);
-        if (a.use_shift) a_axpy_rows(A, -ceps, ws, g, v);
+        if constexpr (FOLD) {
+            mm_t4q<NT, true, FULLQ, true>(A, A, M, v, -ceps, ws + g);
+        } else {
+            mm_z<NT, BW>(A, M, v);
+            if (a.use_shift) a_axpy_rows(A, -ceps, ws, g, v);
+        }
     }
     // use 5: S1 -- A = c (S1 (u + c kappa1) - K1 v05) ; unew += sum_j S^j A
     M = p.template next_ks<1, 2>();
@@ -1639,7 +1691,7 @@ __device__ __forceinline__ void sv_state(RingT<BW == JQ_BW_T4Q>& p, const PropAr
 //  their register allocation 17 - 23 % -- cnot3 on <6, 9> 342 -> 402 ms, on <6, 1> 564 -> 692 ms per 4 000 steps.)
 template <int BW, bool JAC, bool WLRT>
 constexpr bool jq_wlr_on() { return WLRT; }
-template <int NT, int BW, int MINW, bool JAC, bool WLRT = false>
+template <int NT, int BW, int MINW, bool JAC, bool WLRT = false, bool UNI = false>      // (UNI: see k_backward)
 __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_T4Q) ? 1 : MINW) void k_forward(PropArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1673,6 +1725,7 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
         // lanes of group 0 carry it between chunks
         leak = (!QUAD || ((lane_ >> 2) & 3) == 0) ? st[(JQ_STATE_ARRAYS * KT + JQ_MAXNC) * 64 + (QUAD ? 16 * (lane_ >> 4) + col : lane)] : 0.0;
         ceps = 0.5 * a.h * a.colinfo[(size_t)slab * 32 + col];
+        if constexpr (UNI) ceps = (a.use_shift && (lane_ >> 4) == (lane_ & 3)) ? lane_bcast(ceps, 0) : 0.0;      // (masked: folded into the A operands)
     } else {
         a_zero(ua);
         a_zero(va);
@@ -1689,12 +1742,16 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
     {                                                                                                            \
         p.begin_step(NSTEP);                                                                                     \
         if (active) leak += a_wsq(wd, g, U); /* trapezoidal part: tr(vr' W vr) at t_n (:700) */                  \
-        sv_state<NT, BW, JAC, JQ_FWD_FUSE>(p, a, active, ceps, ws, g, U, V, UN, VN, A, Ya, Yb);                       \
+        sv_state<NT, BW, JAC, JQ_FWD_FUSE, UNI>(p, a, active, ceps, ws, g, U, V, UN, VN, A, Ya, Yb);                  \
         /* use 6: Kp05 again -- v(t+h) = v05 + c (K05 u_new + S05 v05) */                                        \
         const double* M6 = p.template next_ks<0, 1>();                                                                             \
         if (active) {                                                                                            \
-            mm_c<NT, BW>(VN, VN, M6, UN);                                                                        \
-            if (a.use_shift) a_axpy_rows(VN, ceps, ws, g, UN);                                                   \
+            if constexpr (UNI) {                                                                                 \
+                mm_t4q<NT, false, JQ_T4_DIAG | JQ_T4_RTERMS | JQ_T4_MTERMS, true>(VN, VN, M6, UN, ceps, ws + g);   \
+            } else {                                                                                             \
+                mm_c<NT, BW>(VN, VN, M6, UN);                                                                    \
+                if (a.use_shift) a_axpy_rows(VN, ceps, ws, g, UN);                                               \
+            }                                                                                                    \
             /* leak integrand: tr(vr' W vr + 2 vi05' W vi05) after the step (:716, penalf2a :2170-2180) */       \
             leak += a_wsq(wd, g, UN) + 2.0 * a_wsq(wd, g, V);                                                    \
             if constexpr (WLR)                                                                                   \
@@ -1776,7 +1833,11 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
     const double* wd = tab;
     const double* ws = tab + 16 * NT;
     double* carry = tab + 32 * NT;  // [Ncoupled][threads of the workgroup]
-    for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[(i & ~15) + 4 * (i & 3) + ((i >> 2) & 3)] = a.tabs[i];   // [block][g][r]
+    // forcing weight c*tinv: c*hr0 = c*tinv*W*vr etc. (:862, :882-888); 0 for step_no_forcing!.  The table wd carries it (round 4:
+    // cfw * wd[row] was formed per element and use -- the same rounded product, three times six multiplies per step)
+    const double cfw = a.forced ? 0.5 * a.h * a.tinv : 0.0;
+    for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x)
+        tab[(i & ~15) + 4 * (i & 3) + ((i >> 2) & 3)] = (i < 16 * NT) ? cfw * a.tabs[i] : a.tabs[i];   // [block][g][r]
     double* st = a.state + (size_t)(active ? slab : 0) * a.state_stride;
     // parking image of this wave: in LDS when it fits, else in HBM.  The quad-layout kernels always park in LDS: a 32-bit LDS pointer
     // (ds_read / ds_write) instead of a generic one -- flat_load / flat_store carry a 64-bit address per lane and count on vmcnt AND
@@ -1834,8 +1895,10 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
         ceps = 0.5 * a.h * a.colinfo[(size_t)slab * 32 + col];
         wgt = a.colinfo[(size_t)slab * 32 + 16 + col];
         if constexpr (UNI) {
-            ceps = lane_bcast(ceps, 0);
             wgt = lane_bcast(wgt, 0);
+            // the sample's shift, folded into the A operands of the K products (mm_t4q SH): nonzero on the lanes that hold the
+            // diagonal of the operand (k == i), zero without a shift -- the run-time tests of a.use_shift disappear
+            ceps = (a.use_shift && (lane_ >> 4) == (lane_ & 3)) ? lane_bcast(ceps, 0) : 0.0;
         }
         for (int q = 0; q < Nc; ++q) carry[q * NTHREADS + threadIdx.x] = cslot ? st[(JQ_STATE_ARRAYS * KT + q) * 64 + clane] : 0.0;
     } else {
@@ -1844,9 +1907,6 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
         a_zero(mu);
         a_zero(nb);
     }
-    // forcing weight c*tinv: c*hr0 = c*tinv*W*vr etc. (:862, :882-888); 0 for step_no_forcing!
-    const double cfw = a.forced ? 0.5 * a.h * a.tinv : 0.0;
-
     RingT<QUAD> p;
     p.init(smem, a, wave, lane_, NWAVES);
     // full leakage weights in low-rank form (WLow): forcing hr0 = Wr vr(t_n+1) / T, hi0 = Wr vi05 / T, hr1 = (Wr vr(t_n) + Wi vi05) / T,
@@ -1873,17 +1933,23 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
         // ---- state step (lambda_r parked) ------------------------------------------------------
         if (active) a_park(mu, P0);
         // mu's registers serve as the scratch array A of the state step
-        sv_state<NT, BW, JAC, (MINW >= 3 ? JQ_BWD_FUSE3 : JQ_BWD_FUSE)>(p, a, active, ceps, ws, g, u, v, un, vN, mu, Ya, Yb);
+        sv_state<NT, BW, JAC, (MINW >= 3 ? JQ_BWD_FUSE3 : JQ_BWD_FUSE), UNI>(p, a, active, ceps, ws, g, u, v, un, vN, mu, Ya, Yb);
         // (every wave has passed a workgroup barrier since it finished step n-1: begin_step in window mode, the operator
         // switches of sv_state otherwise)
         if (n > 0) flush_traces(n - 1);
         // use 6: Kp05 -- finish the state step; first adjoint product L = c K05 nb (= -c K05 lambda_i)
         const double* M = p.template next_ks<0, 1>();
         if (active) {
-            mm_c<NT, BW>(vN, vN, M, un);
-            if (a.use_shift) a_axpy_rows(vN, ceps, ws, g, un);
-            mm_z<NT, BW>(L, M, nb);
-            if (a.use_shift) a_axpy_rows(L, ceps, ws, g, nb);
+            if constexpr (UNI) {
+                constexpr int FULLQ = JQ_T4_DIAG | JQ_T4_RTERMS | JQ_T4_MTERMS;
+                mm_t4q<NT, false, FULLQ, true>(vN, vN, M, un, ceps, ws + g);
+                mm_t4q<NT, true, FULLQ, true>(L, L, M, nb, ceps, ws + g);
+            } else {
+                mm_c<NT, BW>(vN, vN, M, un);
+                if (a.use_shift) a_axpy_rows(vN, ceps, ws, g, un);
+                mm_z<NT, BW>(L, M, nb);
+                if (a.use_shift) a_axpy_rows(L, ceps, ws, g, nb);
+            }
             a_unpark(mu, P0);
             a_park(vN, P0);     // vi(t_n) sleeps until the end of the step
         }
@@ -1892,7 +1958,7 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
         M = p.template next_ks<1, 0>();
         if (active) {
             mm_c<NT, BW>(L, L, M, mu);
-            a_axpy_rows(L, cfw, wd, g, u);  // u holds vr before the state step (:862)
+            a_axpy_rows1<NT, false>(L, wd, g, u);  // u holds vr before the state step (:862)
             if constexpr (WLR)
                 if (wforce)
                     for (int k = 0; k < wl.r; ++k) {
@@ -1909,7 +1975,9 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
             M = p.next_c(Nc + q);  // Hanti_q
             if (active) {
                 mm_z_bw<NT, BW>(Ya, M, mu, a.bw_trace[q]);
-                const double ts = wave_sum4(a_dot(u, Ya) * wgt, a_dot(un, Ya) * wgt, 0.0, 0.0);   // rows 0, 2: t1, t3
+                // (UNI: the weight of the wave's one sample multiplies the SUMS)
+                const double ts = UNI ? wave_sum4(a_dot(u, Ya), a_dot(un, Ya), 0.0, 0.0) * wgt
+                                      : wave_sum4(a_dot(u, Ya) * wgt, a_dot(un, Ya) * wgt, 0.0, 0.0);   // rows 0, 2: t1, t3
                 if ((lane_ & 15) == 0) rec[((size_t)(n & 1) * NWAVES + wave) * rslots + 4 * q + (lane_ >> 4)] = ts;
             }
         }
@@ -1918,10 +1986,14 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
             M = p.template next_ks<0, 0>();
             const double* M9 = p.template next_ks<0, 2>();
             if (active) {
-                mm_t4q2<NT, true, true>(L, L, M, vN, vN, M9, mu);
-                if (a.use_shift) {
-                    a_axpy_rows(L, -ceps, ws, g, mu);
-                    a_axpy_rows(vN, -ceps, ws, g, mu);
+                if constexpr (UNI) {
+                    mm_t4q2<NT, true, true, 3>(L, L, M, vN, vN, M9, mu, -ceps, -ceps, ws + g);
+                } else {
+                    mm_t4q2<NT, true, true>(L, L, M, vN, vN, M9, mu);
+                    if (a.use_shift) {
+                        a_axpy_rows(L, -ceps, ws, g, mu);
+                        a_axpy_rows(vN, -ceps, ws, g, mu);
+                    }
                 }
             }
         } else {
@@ -1943,7 +2015,7 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
         M = p.template next_ks<1, 1>();
         if (active) {
             mm_z<NT, BW>(Ya, M, nb);
-            a_axpy_rows(Ya, -cfw, wd, g, v);  // v holds vi05;  Ya = c (-S05 li - hi0)
+            a_axpy_rows1<NT, true>(Ya, wd, g, v);  // v holds vi05;  Ya = c (-S05 li - hi0)
             if constexpr (WLR)
                 if (wforce)
                     for (int k = 0; k < wl.r; ++k) {
@@ -1965,14 +2037,18 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
         // use 11: Kp05 -- vN(scratch G) = X + c K05 nb_new (= lambda_r^{1/2} - c K05 li_new)
         M = p.template next_ks<0, 1>();
         if (active) {
-            mm_c<NT, BW>(vN, mu, M, L);
-            if (a.use_shift) a_axpy_rows(vN, ceps, ws, g, L);
+            if constexpr (UNI) {
+                mm_t4q<NT, false, JQ_T4_DIAG | JQ_T4_RTERMS | JQ_T4_MTERMS, true>(vN, mu, M, L, ceps, ws + g);
+            } else {
+                mm_c<NT, BW>(vN, mu, M, L);
+                if (a.use_shift) a_axpy_rows(vN, ceps, ws, g, L);
+            }
         }
         // use 12: S1 -- lambda_r_new = X + c (S1 X - K05 li_new + hr1)
         M = p.template next_ks<1, 2>();
         if (active) {
             mm_c<NT, BW>(vN, vN, M, mu);
-            a_axpy_rows(vN, cfw, wd, g, un);
+            a_axpy_rows1<NT, false>(vN, wd, g, un);
             if constexpr (WLR)
                 if (wforce)
                     for (int k = 0; k < wl.r; ++k) {
@@ -2002,7 +2078,7 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
                 const double p4 = -a_dot(un, Ya);
                 t4 = p4 + carry[q * NTHREADS + threadIdx.x];
                 carry[q * NTHREADS + threadIdx.x] = p4;
-                const double ts = wave_sum4(t2 * wgt, t4 * wgt, t5 * wgt, 0.0);                     // rows 0, 2, 1: t2, t4, t5
+                const double ts = UNI ? wave_sum4(t2, t4, t5, 0.0) * wgt : wave_sum4(t2 * wgt, t4 * wgt, t5 * wgt, 0.0);   // rows 0, 2, 1: t2, t4, t5
                 if ((lane_ & 15) == 0) rec[((size_t)(n & 1) * NWAVES + wave) * rslots + 4 * (Nc + q) + (lane_ >> 4)] = ts;
             }
         }
