@@ -85,15 +85,10 @@ template __global__ void k_forward<JQ_NT, JQ_BW, 1, false>(PropArgs);
 template __global__ void k_backward<JQ_NT, JQ_BW, 1, false>(PropArgs);
 template __global__ void k_forward<JQ_NT, JQ_BW, 2, false>(PropArgs);
 template __global__ void k_backward<JQ_NT, JQ_BW, 2, false>(PropArgs);
-template __global__ void k_forward<JQ_NT, JQ_BW, 1, false, false, true>(PropArgs);       // (UNI: one ensemble sample per wave)
-template __global__ void k_backward<JQ_NT, JQ_BW, 1, false, false, true>(PropArgs);
-template __global__ void k_forward<JQ_NT, JQ_BW, 2, false, false, true>(PropArgs);
-template __global__ void k_backward<JQ_NT, JQ_BW, 2, false, false, true>(PropArgs);
 #elif JQ_BW == 7                    // quad layout, workgroups of 12 waves (3 slabs, 168 registers per wave): default scheduler
 template __global__ void k_forward<JQ_NT, JQ_BW, 3, false>(PropArgs);
 template __global__ void k_backward<JQ_NT, JQ_BW, 3, false>(PropArgs);
-template __global__ void k_forward<JQ_NT, JQ_BW, 3, false, false, true>(PropArgs);       // (UNI: one ensemble sample per wave)
-template __global__ void k_backward<JQ_NT, JQ_BW, 3, false, false, true>(PropArgs);
+template __global__ void k_backward<JQ_NT, JQ_BW, 3, false, false, true>(PropArgs);      // (UNI: one ensemble sample per wave)
 #else
 template __global__ void k_forward<JQ_NT, JQ_BW, JQ_MINW, (JQ_VARIANT == 1)>(PropArgs);
 template __global__ void k_backward<JQ_NT, JQ_BW, JQ_MINW, (JQ_VARIANT == 1)>(PropArgs);

@@ -1516,11 +1516,6 @@ static int select_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
     extern template __global__ void k_backward<nt, JQ_BW_T4Q, 2, false>(PropArgs);   \
     extern template __global__ void k_forward<nt, JQ_BW_T4Q, 3, false>(PropArgs);    \
     extern template __global__ void k_backward<nt, JQ_BW_T4Q, 3, false>(PropArgs);   \
-    extern template __global__ void k_forward<nt, JQ_BW_T4Q, 1, false, false, true>(PropArgs);    \
-    extern template __global__ void k_backward<nt, JQ_BW_T4Q, 1, false, false, true>(PropArgs);   \
-    extern template __global__ void k_forward<nt, JQ_BW_T4Q, 2, false, false, true>(PropArgs);    \
-    extern template __global__ void k_backward<nt, JQ_BW_T4Q, 2, false, false, true>(PropArgs);   \
-    extern template __global__ void k_forward<nt, JQ_BW_T4Q, 3, false, false, true>(PropArgs);    \
     extern template __global__ void k_backward<nt, JQ_BW_T4Q, 3, false, false, true>(PropArgs);
 JQ_DECLQ(1) JQ_DECLQ(2) JQ_DECLQ(3) JQ_DECLQ(4) JQ_DECLQ(5) JQ_DECLQ(6) JQ_DECLQ(7) JQ_DECLQ(8)
 #undef JQ_DECLQ
@@ -1595,19 +1590,16 @@ static int select_cq_imr_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t
 // (spw: slabs per workgroup = waves per SIMD: workgroups of 4 spw waves)
 static int select_quad_kernels(jq_handle* h, int spw, prop_kernel_t* fwd, prop_kernel_t* bwd)
 {
-    // one ensemble sample per wave (four columns of a slab): N a multiple of 4 (N <= 16 divides the slab into whole samples), or N > 16
+    // one ensemble sample per wave (four columns of a slab): N a multiple of 4 (N <= 16 divides the slab into whole samples), or N > 16.
+    // Only the twelve-wave BACKWARD kernel has a UNI variant: folding the shift into the MFMA's A operand adds a dependent FMA in front
+    // of every MFMA, which three waves per SIMD hide (- 1.2 %) and one or two do not (measured: forward sweep + 1.2 %, one / two slabs
+    // per workgroup + 1.6 ... 3.4 %)
     const bool uni = (h->N % 4 == 0 || h->parts > 1) && !getenv("JQ_NO_UNI");
 #define JQ_PICKQ(nt)                                                                                                                             \
     if (h->NT == nt) {                                                                                                                           \
-        if (uni) {                                                                                                                               \
-            *fwd = spw == 3 ? k_forward<nt, JQ_BW_T4Q, 3, false, false, true> : spw == 2 ? k_forward<nt, JQ_BW_T4Q, 2, false, false, true>      \
-                                                                               : k_forward<nt, JQ_BW_T4Q, 1, false, false, true>;              \
-            *bwd = spw == 3 ? k_backward<nt, JQ_BW_T4Q, 3, false, false, true> : spw == 2 ? k_backward<nt, JQ_BW_T4Q, 2, false, false, true>    \
-                                                                                : k_backward<nt, JQ_BW_T4Q, 1, false, false, true>;            \
-            return JQ_OK;                                                                                                                        \
-        }                                                                                                                                        \
         *fwd = spw == 3 ? k_forward<nt, JQ_BW_T4Q, 3, false> : spw == 2 ? k_forward<nt, JQ_BW_T4Q, 2, false> : k_forward<nt, JQ_BW_T4Q, 1, false>;     \
-        *bwd = spw == 3 ? k_backward<nt, JQ_BW_T4Q, 3, false> : spw == 2 ? k_backward<nt, JQ_BW_T4Q, 2, false> : k_backward<nt, JQ_BW_T4Q, 1, false>;  \
+        *bwd = spw == 3 ? (uni ? k_backward<nt, JQ_BW_T4Q, 3, false, false, true> : k_backward<nt, JQ_BW_T4Q, 3, false>)                      \
+                        : spw == 2 ? k_backward<nt, JQ_BW_T4Q, 2, false> : k_backward<nt, JQ_BW_T4Q, 1, false>;  \
         return JQ_OK;                                                                                                                            \
     }
     JQ_PICKQ(1) JQ_PICKQ(2) JQ_PICKQ(3) JQ_PICKQ(4) JQ_PICKQ(5) JQ_PICKQ(6) JQ_PICKQ(7) JQ_PICKQ(8)
