@@ -89,6 +89,7 @@ template __global__ void k_backward<JQ_NT, JQ_BW, 2, false>(PropArgs);
 template __global__ void k_forward<JQ_NT, JQ_BW, 3, false>(PropArgs);
 template __global__ void k_backward<JQ_NT, JQ_BW, 3, false>(PropArgs);
 template __global__ void k_backward<JQ_NT, JQ_BW, 3, false, false, true>(PropArgs);      // (UNI: one ensemble sample per wave)
+template __global__ void k_backward<JQ_NT, JQ_BW, 3, false, false, true, true>(PropArgs);      // (UNI + ORD: control q on subsystem q only)
 #else
 template __global__ void k_forward<JQ_NT, JQ_BW, JQ_MINW, (JQ_VARIANT == 1)>(PropArgs);
 template __global__ void k_backward<JQ_NT, JQ_BW, JQ_MINW, (JQ_VARIANT == 1)>(PropArgs);

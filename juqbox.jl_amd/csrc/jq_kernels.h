@@ -643,10 +643,16 @@ __device__ __forceinline__ void mm_t4q(Arr<NT>& D, const Arr<NT>& C, const doubl
 }
 // Two / three products with the SAME right-hand side in one pass over the blocks (round 3): D_k = C_k + M_k x.  The lane shifts
 // of x (four v_mov_b32_dpp per block, as expensive as the block's MFMA) are made once for all of them.  x must not alias a D_k.
-template <int NT, int NP, bool Z0, bool Z1, bool Z2, int SH = 0>      // SH: bit k = operator k is a K image and takes the folded shift
+struct T4qNoHook {
+    __device__ __forceinline__ void operator()(int, double, double) const {}
+};
+// (HOOK: called once per 16-row block with the block's two lane-shifted copies of x -- products with single-subsystem operators
+//  that only need those, e.g. the trace products of a control of the middle subsystem, ride along without shifts of their own)
+template <int NT, int NP, bool Z0, bool Z1, bool Z2, int SH = 0, typename HOOK = T4qNoHook>      // SH: bit k = operator k is a K image and takes the folded shift
 __device__ __forceinline__ void mm_t4q_multi(Arr<NT>& D0, const Arr<NT>& C0, const double* m0, Arr<NT>& D1, const Arr<NT>& C1,
                                              const double* m1, Arr<NT>& D2, const Arr<NT>& C2, const double* m2, const Arr<NT>& x,
-                                             double sh0 = 0.0, double sh1 = 0.0, double sh2 = 0.0, const double* wsr = nullptr)
+                                             double sh0 = 0.0, double sh1 = 0.0, double sh2 = 0.0, const double* wsr = nullptr,
+                                             HOOK hook = HOOK())
 {
     const int lane = threadIdx.x & 63;
     const double* ma[3] = {t4q_a(m0, lane), t4q_a(m1, lane), t4q_a(NP > 2 ? m2 : m1, lane)};
@@ -666,12 +672,13 @@ __device__ __forceinline__ void mm_t4q_multi(Arr<NT>& D0, const Arr<NT>& C0, con
         if constexpr (SH != 0) {      // (shift folded into the A operands of the K images, see mm_t4q)
             const double w = wsr[16 * mt];
             if constexpr (SH & 1) a[0] = fma(sh0, w, a[0]);
-            if constexpr (SH & 2) a[1] = fma(sh1, w, a[1]);
+            if constexpr (NP > 1 && (SH & 2)) a[1] = fma(sh1, w, a[1]);
             if constexpr (NP > 2 && (SH & 4)) a[2] = fma(sh2, w, a[2]);
         }
         const double xc = x.t[mt][0], xn = x.t[mt + 1 < NT ? mt + 1 : mt][0];
         const double su = row_shift4<0x114>(xc), sd = row_shift4<0x104>(xc);
-        double acc[3] = {Z0 ? 0.0 : C0.t[mt][0], Z1 ? 0.0 : C1.t[mt][0], (NP > 2 && !Z2) ? C2.t[mt][0] : 0.0};
+        hook(mt, su, sd);
+        double acc[3] = {Z0 ? 0.0 : C0.t[mt][0], (NP > 1 && !Z1) ? C1.t[mt][0] : 0.0, (NP > 2 && !Z2) ? C2.t[mt][0] : 0.0};
 #ifndef JQ_EXP_MFMA_LAST
 #pragma unroll
         for (int k = 0; k < NP; ++k) acc[k] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[k], xc, acc[k], 0, 0, 0);
@@ -694,7 +701,7 @@ __device__ __forceinline__ void mm_t4q_multi(Arr<NT>& D0, const Arr<NT>& C0, con
 #endif
         xold = xc;
         D0.t[mt][0] = acc[0];
-        D1.t[mt][0] = acc[1];
+        if constexpr (NP > 1) D1.t[mt][0] = acc[1];
         if constexpr (NP > 2) D2.t[mt][0] = acc[2];
         // (fence per block: the scheduler otherwise hoists the operand reads of all blocks to the top -- 15 NT doubles in flight,
         // 200 spilled registers in the twelve-wave variants)
@@ -1808,9 +1815,15 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
 // UNI: every wave's columns belong to ONE ensemble sample (quad layout with N a multiple of 4, or N > 16): its shift and weight
 // are wave-uniform and live in scalar registers -- four vector registers less in the 168-register three-slab kernel (round 4: with
 // the LDS parking pointer 136 -> 108 B of scratch, 60 -> 38 scratch instructions per step, 1 098 -> 1 085 ms; results bit-identical)
-template <int NT, int BW, int MINW, bool JAC, bool WLRT = false, bool UNI = false>
+// ORD (with UNI, quad layout): control q acts on subsystem q only -- the usual Juqbox set-up, Hsym_ops = [a + a', b + b', c + c'];
+// host: a.bw_trace[q] == 1 << q for all q < Ncoupled, 2 <= Ncoupled <= 3.  The trace products are then one part of a product each at
+// compile time (no mode dispatch), and Hsym_1 lambda_i_new of the MIDDLE subsystem's control (lane-shift couplings only) rides along
+// in the pass that shifts lambda_i_new anyway (K05 lambda_i_new, use 11): backward sweep 755 -> 737 ms (round 4).  Letting Hanti_1 X and
+// Hsym_1 X ride along with K0 X / K1 X as well keeps vr(t_n+1) alive through that pass: 464 B of scratch, 1 327 ms -- rejected.
+template <int NT, int BW, int MINW, bool JAC, bool WLRT = false, bool UNI = false, bool ORD = false>
 __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_T4Q) ? 1 : MINW) void k_backward(PropArgs a)
 {
+    static_assert(!ORD || (UNI && BW == JQ_BW_T4Q && !JAC), "ORD: a variant of the UNI quad-layout kernel");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KT = 4 * NT;
     const int lane_ = threadIdx.x & 63;
@@ -1933,7 +1946,9 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
         // ---- state step (lambda_r parked) ------------------------------------------------------
         if (active) a_park(mu, P0);
         // mu's registers serve as the scratch array A of the state step
-        sv_state<NT, BW, JAC, (MINW >= 3 ? JQ_BWD_FUSE3 : JQ_BWD_FUSE), UNI>(p, a, active, ceps, ws, g, u, v, un, vN, mu, Ya, Yb);
+        // (UNI: the fused stages -- shared lane shifts of u and of v05 -- also in the twelve-wave kernel: round 3 measured them slower there,
+        //  104 -> 144 ... 172 B of scratch; with the registers the UNI variant frees they pay: backward sweep 772 -> 757 ms, round 4)
+        sv_state<NT, BW, JAC, (MINW >= 3 ? (UNI ? 3 : JQ_BWD_FUSE3) : JQ_BWD_FUSE), UNI>(p, a, active, ceps, ws, g, u, v, un, vN, mu, Ya, Yb);
         // (every wave has passed a workgroup barrier since it finished step n-1: begin_step in window mode, the operator
         // switches of sv_state otherwise)
         if (n > 0) flush_traces(n - 1);
@@ -1971,10 +1986,17 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
             horner_add<NT, BW, JAC>(mu, mu, L, M, a.m, Ya, Yb, a.jacobi_tol2, a.N);
         }
         // early traces with X (lets vr0 = u die here): tr1 = tr(vr0' Hanti_q X), tr3 = tr(vr' Hanti_q X)
+        double o_p4 = 0.0;      // ORD: the new part of tr4 of control 1, formed in the pass of use 11
         for (int q = 0; q < Nc; ++q) {
             M = p.next_c(Nc + q);  // Hanti_q
             if (active) {
-                mm_z_bw<NT, BW>(Ya, M, mu, a.bw_trace[q]);
+                if constexpr (ORD) {
+                    if (q == 0) mm_t4q<NT, true, JQ_T4_DIAG>(Ya, Ya, M, mu);
+                    else if (q == 1) mm_t4q<NT, true, JQ_T4_RTERMS>(Ya, Ya, M, mu);
+                    else mm_t4q<NT, true, JQ_T4_MTERMS>(Ya, Ya, M, mu);
+                } else {
+                    mm_z_bw<NT, BW>(Ya, M, mu, a.bw_trace[q]);
+                }
                 // (UNI: the weight of the wave's one sample multiplies the SUMS)
                 const double ts = UNI ? wave_sum4(a_dot(u, Ya), a_dot(un, Ya), 0.0, 0.0) * wgt
                                       : wave_sum4(a_dot(u, Ya) * wgt, a_dot(un, Ya) * wgt, 0.0, 0.0);   // rows 0, 2: t1, t3
@@ -2037,7 +2059,15 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
         // use 11: Kp05 -- vN(scratch G) = X + c K05 nb_new (= lambda_r^{1/2} - c K05 li_new)
         M = p.template next_ks<0, 1>();
         if (active) {
-            if constexpr (UNI) {
+            if constexpr (ORD) {
+                // ... and Hsym_1 lambda_i_new (the new part of tr4 of control 1) from the same shifted copies of L = -lambda_i_new
+                const d4* cfs = t4q_c<NT>(p.next_c(1), lane_);
+                mm_t4q_multi<NT, 1, false, true, true, 1>(vN, mu, M, vN, mu, M, vN, mu, M, L, ceps, 0.0, 0.0, ws + g,
+                                                          [&](int mt, double su, double sd) {
+                                                              const d4 cs = t4q_cload(cfs, mt);
+                                                              o_p4 = fma(-un.t[mt][0], fma(cs[1], sd, cs[0] * su), o_p4);
+                                                          });
+            } else if constexpr (UNI) {
                 mm_t4q<NT, false, JQ_T4_DIAG | JQ_T4_RTERMS | JQ_T4_MTERMS, true>(vN, mu, M, L, ceps, ws + g);
             } else {
                 mm_c<NT, BW>(vN, mu, M, L);
@@ -2067,15 +2097,37 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
             const int bwq = a.bw_trace[q];
             M = p.next_c(Nc + q);  // Hanti_q
             if (active) {
-                mm_z_bw<NT, BW>(Ya, M, nb, bwq);
+                if constexpr (ORD) {
+                    if (q == 0) mm_t4q<NT, true, JQ_T4_DIAG>(Ya, Ya, M, nb);
+                    else if (q == 1) mm_t4q<NT, true, JQ_T4_RTERMS>(Ya, Ya, M, nb);
+                    else mm_t4q<NT, true, JQ_T4_MTERMS>(Ya, Ya, M, nb);
+                } else {
+                    mm_z_bw<NT, BW>(Ya, M, nb, bwq);
+                }
                 t5 = -a_dot(v, Ya);
             }
             M = p.next_c(q);  // Hsym_q
             if (active) {
-                mm_z_bw<NT, BW>(Ya, M, mu, bwq);
-                t2 = a_dot(v, Ya);
-                mm_z_bw<NT, BW>(Ya, M, L, bwq);
-                const double p4 = -a_dot(un, Ya);
+                double p4;
+                if constexpr (ORD) {
+                    if (q == 1) {
+                        mm_t4q<NT, true, JQ_T4_RTERMS>(Ya, Ya, M, mu);
+                        t2 = a_dot(v, Ya);
+                        p4 = o_p4;
+                    } else {
+                        if (q == 0) mm_t4q<NT, true, JQ_T4_DIAG>(Ya, Ya, M, mu);
+                        else mm_t4q<NT, true, JQ_T4_MTERMS>(Ya, Ya, M, mu);
+                        t2 = a_dot(v, Ya);
+                        if (q == 0) mm_t4q<NT, true, JQ_T4_DIAG>(Ya, Ya, M, L);
+                        else mm_t4q<NT, true, JQ_T4_MTERMS>(Ya, Ya, M, L);
+                        p4 = -a_dot(un, Ya);
+                    }
+                } else {
+                    mm_z_bw<NT, BW>(Ya, M, mu, bwq);
+                    t2 = a_dot(v, Ya);
+                    mm_z_bw<NT, BW>(Ya, M, L, bwq);
+                    p4 = -a_dot(un, Ya);
+                }
                 t4 = p4 + carry[q * NTHREADS + threadIdx.x];
                 carry[q * NTHREADS + threadIdx.x] = p4;
                 const double ts = UNI ? wave_sum4(t2, t4, t5, 0.0) * wgt : wave_sum4(t2 * wgt, t4 * wgt, t5 * wgt, 0.0);   // rows 0, 2, 1: t2, t4, t5

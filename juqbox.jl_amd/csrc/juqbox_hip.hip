@@ -1516,7 +1516,8 @@ static int select_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
     extern template __global__ void k_backward<nt, JQ_BW_T4Q, 2, false>(PropArgs);   \
     extern template __global__ void k_forward<nt, JQ_BW_T4Q, 3, false>(PropArgs);    \
     extern template __global__ void k_backward<nt, JQ_BW_T4Q, 3, false>(PropArgs);   \
-    extern template __global__ void k_backward<nt, JQ_BW_T4Q, 3, false, false, true>(PropArgs);
+    extern template __global__ void k_backward<nt, JQ_BW_T4Q, 3, false, false, true>(PropArgs);   \
+    extern template __global__ void k_backward<nt, JQ_BW_T4Q, 3, false, false, true, true>(PropArgs);
 JQ_DECLQ(1) JQ_DECLQ(2) JQ_DECLQ(3) JQ_DECLQ(4) JQ_DECLQ(5) JQ_DECLQ(6) JQ_DECLQ(7) JQ_DECLQ(8)
 #undef JQ_DECLQ
 template <int NT, bool MODD> __global__ void k_forward_cq(PropArgs);            // jq_cq_kernels.h (own translation units)
@@ -1595,10 +1596,14 @@ static int select_quad_kernels(jq_handle* h, int spw, prop_kernel_t* fwd, prop_k
     // of every MFMA, which three waves per SIMD hide (- 1.2 %) and one or two do not (measured: forward sweep + 1.2 %, one / two slabs
     // per workgroup + 1.6 ... 3.4 %)
     const bool uni = (h->N % 4 == 0 || h->parts > 1) && !getenv("JQ_NO_UNI");
+    // ... and its ORD variant when control q acts on subsystem q only (like the cooperative-quad kernels, select_cq_kernels)
+    bool ord = uni && h->Nc >= 2 && h->Nc <= 3 && !getenv("JQ_NO_ORD");
+    for (int q = 0; q < h->Nc && ord; ++q) ord = (h->bw_trace[q] == (1 << q));
 #define JQ_PICKQ(nt)                                                                                                                             \
     if (h->NT == nt) {                                                                                                                           \
         *fwd = spw == 3 ? k_forward<nt, JQ_BW_T4Q, 3, false> : spw == 2 ? k_forward<nt, JQ_BW_T4Q, 2, false> : k_forward<nt, JQ_BW_T4Q, 1, false>;     \
-        *bwd = spw == 3 ? (uni ? k_backward<nt, JQ_BW_T4Q, 3, false, false, true> : k_backward<nt, JQ_BW_T4Q, 3, false>)                      \
+        *bwd = spw == 3 ? (ord ? k_backward<nt, JQ_BW_T4Q, 3, false, false, true, true>                                                       \
+                                : uni ? k_backward<nt, JQ_BW_T4Q, 3, false, false, true> : k_backward<nt, JQ_BW_T4Q, 3, false>)                 \
                         : spw == 2 ? k_backward<nt, JQ_BW_T4Q, 2, false> : k_backward<nt, JQ_BW_T4Q, 1, false>;  \
         return JQ_OK;                                                                                                                            \
     }
