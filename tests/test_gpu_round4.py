@@ -172,3 +172,34 @@ def test_implicit_midpoint_with_more_than_16_columns(jq, cfg):
     assert abs(p.last_infidelity - inf) <= tol * abs(inf) and abs(p.last_leak - leak) <= tol * max(abs(leak), 1e-3)
     assert np.linalg.norm(p.last_infidelity_grad - gi) <= tol * np.linalg.norm(gi)
     wa.close()
+
+
+def test_uni_and_ord_variants_of_the_throughput_kernel_agree(jq):
+    """Round 4: the twelve-wave backward kernel has a one-sample-per-wave variant (UNI: the sample's shift folded into the MFMA's A
+    operand, weight after the reduction, fused state-step stages) and, on top, one for controls that act on one subsystem each (ORD:
+    compile-time trace modes, Hsym_1 lambda_i rides along with K05 lambda_i).  They reorder floating-point operations only: against
+    the generic kernel (JQ_NO_UNI=1) and against each other the ensemble results agree to 1e-12; the default is the ORD kernel, which
+    tests/test_gpu_round2.py pins against the oracle at full length."""
+    params, info = jq.cases.cnot3()
+    params.T, params.nsteps = params.T * 600 / params.nsteps, 600
+    pcof = np.array(json.load(open(os.path.join(ROOT, "tests", "golden", "cnot3.json")))["pcof0"])
+    nodes, weights, shift = jq.cases.cnot3_ensemble(3072)
+    res = {}
+    for tag, env in (("ord", {}), ("uni", {"JQ_NO_ORD": "1"}), ("generic", {"JQ_NO_UNI": "1"})):
+        os.environ.update(env)
+        try:
+            wa = jq.Working_Arrays_HIP(params, pcof.size)
+            jq.eval_f_g_grad(pcof, params, wa, nodes, weights, True, shift=shift)
+            t = wa.last_timing()
+            assert t["kernel_family"] == 6 and t["kernel_band"] == 7
+            res[tag] = (params.last_infidelity, params.last_leak, params.last_infidelity_grad.copy())
+            wa.close()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    g = np.linalg.norm(res["generic"][2])
+    for tag in ("ord", "uni"):
+        assert abs(res[tag][0] - res["generic"][0]) <= 1e-13 * abs(res["generic"][0])
+        assert abs(res[tag][1] - res["generic"][1]) <= 1e-12 * abs(res["generic"][1])
+        assert np.linalg.norm(res[tag][2] - res["generic"][2]) <= 1e-12 * g
+    assert not np.array_equal(res["ord"][2], res["generic"][2])      # (different kernels did run)
