@@ -316,3 +316,346 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq_imr(PropArgs a)
     st[(size_t)2 * KT * 64 + s.foff] = lr;
     st[(size_t)3 * KT * 64 + s.foff] = li;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Backward sweep with the two chains of a time step on TWO SETS of waves (round 4; the Stormer-Verlet cooperative-quad kernels
+// have worked this way since round 2).  k_backward_cq_imr above runs the state step and the adjoint step of a time step one after
+// the other on the same NT block waves: 2 x (3 + iterations) publication rounds plus one for the trace products.  But the state
+// re-integration does not depend on the adjoint: here set 0 (NT block waves + 2 reducer waves) solves the state step of time step
+// k while set 1 solves the adjoint step of time step k - 1 -- a software pipeline of depth one inside a chunk: n + 1 "super-steps"
+// for n time steps, set 1 idle in the first, set 0 in the last.  Both sets pass the SAME workgroup barriers: a super-step takes
+// max(rounds of the two solves) rounds instead of their sum.  With four waves per SIMD a round is bound by the SIMD's issue rate
+// (~4.6 cycles per instruction of any kind), so the round loops are kept as lean as the one-set kernel's: while both sets iterate
+// every wave reads both sets' decisions behind the barrier (one more LDS read); once one set has its result its waves only pass
+// the barriers and watch the other set's decisions, and the other set runs the one-set loop -- all waves leave at the same barrier.
+// The state set hands su = u_old + u_new, sv (the adjoint's forcing and the trace products' vectors) to the adjoint set through
+// LDS, double-buffered over the super-steps: no publication round for the trace products any more.
+// Staging: the implicit-midpoint kernels read only the MIDPOINT operators (time point 2k+1 of step k), and set 1 needs those of
+// step k - 1 in super-step k: the ring of JQ_WIN_TPS slots holds the midpoints of the steps k - 1 .. k + 3 here (the even time
+// points are never fetched); behind the first barrier of super-step k the slot of step k - 1 is dead and receives step k + 4.
+// LDS behind the tables: [set][2 parities][3 channels][NT + 2 blocks][64] exchange images (channel 2 of image b, parities 0 / 1:
+// su, sv of the super-steps with k & 1 == b), then the decisions [set][2 slots][2 parts].
+// NT <= 6 (2 (NT + 2) waves <= 16); the results differ from k_backward_cq_imr's in nothing (same operations per chain, same order).
+template <int NT>
+struct CqImr2 : CqImr<NT> {
+    typedef CqImr<NT> B;
+    typedef typename B::Acc Acc;
+    static constexpr int CHS = B::CHS, PAR = B::PAR;
+    volatile __attribute__((address_space(3))) int* flags_o;      // the other set's decisions
+
+    __device__ __forceinline__ int decided(volatile __attribute__((address_space(3))) int* f, int j) const
+    {
+        const long long v = *(volatile __attribute__((address_space(3))) long long*)(f + 2 * (j & 1));
+        return __builtin_amdgcn_readfirstlane((int)v & (int)(v >> 32));
+    }
+    // a block wave of a set without work in this super-step (set 1 in the first, set 0 in the last): passes the other set's barriers
+    template <bool STAGE, typename G>
+    __device__ __forceinline__ void idle2(bool oact, G stage)
+    {
+        this->c->template sync<STAGE>();
+        stage();
+        this->c->sync();
+        this->c->sync();
+        if (oact)
+            for (int j = 3;; ++j) {
+                this->c->sync();
+                if (decided(flags_o, j)) break;
+            }
+    }
+    // CqImr::step next to a set that is active in this super-step (oact) or not.  getf(fu, fv): the forcing, available behind the
+    // first barrier; stage(): the window staging of this wave, behind the first barrier
+    template <bool STAGE, typename F, typename G>
+    __device__ __forceinline__ void step2(bool oact, double& u, double& v, F getf, G stage)
+    {
+        int po = this->par * PAR;
+        this->post(po, u, v);
+        Acc nx = this->own(0.0, 0.0, u, v);
+        this->c->template sync<STAGE>();
+        stage();
+        double fu, fv;
+        getf(fu, fv);
+        this->nbr(nx, po);
+        this->par ^= 1;
+        const double Bu = nx.au - nx.kv, Bv = nx.av;
+        const double rhs_u = (u + fu) + Bu, rhs_v = (v + fv) + Bv;
+        double au = rhs_u + Bu, av = rhs_v + Bv;      // x_1
+        po = this->par * PAR;
+        this->post(po, au, av);
+        nx = this->own(rhs_u, rhs_v, au, av);
+        this->c->sync();
+        this->nbr(nx, po);
+        this->par ^= 1;
+        double bu = nx.au - nx.kv, bv = nx.av;         // x_2
+        po = this->par * PAR;
+        this->post(po, bu, bv);
+        nx = this->own(rhs_u, rhs_v, bu, bv);
+        this->c->sync();
+        this->nbr(nx, po);
+        this->par ^= 1;
+        double cu = nx.au - nx.kv, cv = nx.av;         // x_3
+        // (au, av) = x_{j-2}, (bu, bv) = x_{j-1}, (cu, cv) = x_j
+        int j = 3;
+        bool dme = false, doth = !oact;
+        if (!doth)
+            for (;; ++j) {                             // both sets iterate
+                po = this->par * PAR;
+                this->post(po, cu, cv);
+                nx = this->own(rhs_u, rhs_v, cu, cv);
+                this->c->sync();
+                this->par ^= 1;
+                const int km = decided(this->flags, j), ko = decided(flags_o, j);      // the decisions on the two x_{j-2}
+                Acc t = nx;
+                this->nbr(t, po);
+                if (!km) {
+                    au = bu, av = bv;
+                    bu = cu, bv = cv;
+                    cu = t.au - t.kv, cv = t.av;
+                }
+                if (km | ko) {
+                    dme = km != 0, doth = ko != 0;
+                    ++j;
+                    break;
+                }
+            }
+        if (!dme) {
+            for (;; ++j) {                             // the other set has its result (or no work): CqImr::step's loop
+                po = this->par * PAR;
+                this->post(po, cu, cv);
+                nx = this->own(rhs_u, rhs_v, cu, cv);
+                this->c->sync();
+                this->par ^= 1;
+                const int km = decided(this->flags, j);
+                Acc t = nx;
+                this->nbr(t, po);
+                if (km) break;
+                au = bu, av = bv;
+                bu = cu, bv = cv;
+                cu = t.au - t.kv, cv = t.av;
+            }
+        } else if (!doth) {
+            for (;; ++j) {                             // mine is x_{j-2} = (au, av); the other set still iterates
+                this->c->sync();
+                if (decided(flags_o, j)) break;
+            }
+        }
+        u = au;
+        v = av;
+    }
+    // CqImr::reducer_step likewise
+    __device__ __forceinline__ void reducer_idle2(bool oact)
+    {
+        this->c->sync();
+        this->c->sync();
+        this->c->sync();
+        if (oact)
+            for (int j = 3;; ++j) {
+                this->c->sync();
+                if (decided(flags_o, j)) break;
+            }
+    }
+    __device__ __forceinline__ void reducer2(bool oact, int part)
+    {
+        this->c->sync();
+        this->c->sync();      // x_1
+        double prev[NT];
+        {
+            const int po = (this->par ^ 1) * PAR + part * CHS;
+#pragma unroll
+            for (int w = 0; w < NT; ++w) prev[w] = this->x0[po + (w + 1) * 64];
+        }
+        // behind barrier j: the decision on x_{j-1} from the published x_j
+        auto decide = [&](int j, int po) {
+            double acc = 0.0;
+#pragma unroll
+            for (int w = 0; w < NT; ++w) {
+                const double cur = this->x0[po + (w + 1) * 64];
+                const double d = prev[w] - cur;
+                acc = fma(d, d, acc);
+                prev[w] = cur;
+            }
+            const bool keep = (j - 1 >= this->max_iter) || (wave_sum(acc) < this->tol2);      // (a NaN never converges, as in the reference)
+            this->flags[2 * ((j - 1) & 1) + part] = keep ? 1 : 0;
+        };
+        {
+            const int po = this->par * PAR + part * CHS;
+            this->c->sync();
+            this->par ^= 1;
+            decide(2, po);
+        }
+        int j = 3;
+        bool dme = false, doth = !oact;
+        if (!doth)
+            for (;; ++j) {
+                const int po = this->par * PAR + part * CHS;
+                this->c->sync();
+                this->par ^= 1;
+                const int km = decided(this->flags, j), ko = decided(flags_o, j);
+                if (!km) decide(j, po);
+                if (km | ko) {
+                    dme = km != 0, doth = ko != 0;
+                    ++j;
+                    break;
+                }
+            }
+        if (!dme) {
+            for (;; ++j) {
+                const int po = this->par * PAR + part * CHS;
+                this->c->sync();
+                this->par ^= 1;
+                if (decided(this->flags, j)) break;
+                decide(j, po);
+            }
+        } else if (!doth) {
+            for (;; ++j) {
+                this->c->sync();
+                if (decided(flags_o, j)) break;
+            }
+        }
+    }
+};
+
+// grid = 4 * nslabs (workgroup = one evaluation, N = 4), block = 2 * 64 * (NT + 2): set 0 = waves 0 .. NT + 1 (state chain: NT block
+// waves, 2 reducer waves), set 1 = the next NT + 2 (adjoint chain).  Dynamic LDS: staging + tables + 4 PAR doubles + 64 bytes.
+template <int NT>
+__global__ __launch_bounds__(128 * NT + 256) void k_backward_cq_imr2(PropArgs a)
+{
+    static_assert(NT <= 6, "2 (NT + 2) waves per workgroup");
+    typedef typename CoopQ<NT>::Sh Sh;
+    typedef typename CoopQ<NT>::Nb Nb;
+    constexpr int CHS = CoopQ<NT>::CHS, PAR = CoopQ<NT>::PAR, KT = 4 * NT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    CqSetup<NT> s = cq_setup<NT>(a);
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int set = wid >= NT + 2 ? 1 : 0, wv = wid - set * (NT + 2);      // wv < NT: block wave wv; NT, NT + 1: reducer of part 0, 1
+    const bool reducer = wv >= NT;
+    const int wave = reducer ? 0 : wv, lane_ = s.lane_;
+    s.foff = (size_t)(4 * wave + ((lane_ >> 2) & 3)) * 64 + 16 * (lane_ >> 4) + s.col;
+    const int Nc = a.Ncoupled, ntr = Nc * JQ_NTR;
+    const size_t trow = ((size_t)s.slab * a.qps + s.qd) * NT;      // first of my workgroup's NT record rows
+    if (!s.active) {
+        if (s.qd < a.qps)
+            for (size_t k = threadIdx.x; k < (size_t)NT * a.nsteps_chunk * ntr; k += blockDim.x) a.traces[trow * a.nsteps_chunk * ntr + k] = 0.0;
+        return;
+    }
+    double* tab = (double*)(smem + a.lds_tab_off);
+    for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[(i & ~15) + 4 * (i & 3) + ((i >> 2) & 3)] = a.tabs[i];
+    double* xbuf = tab + 32 * NT;
+    for (int i = threadIdx.x; i < 4 * PAR + 8; i += blockDim.x) xbuf[i] = 0.0;      // (the pads stay zero; the decisions too)
+    const int n = a.nsteps_chunk;
+    CoopQ<NT> c;
+    c.mt = wave, c.lane = lane_;
+    c.xb = (jq_lds_double*)(xbuf + set * 2 * PAR + wave * 64 + lane_);
+    // the ring of midpoint operators (see above): slot i % JQ_WIN_TPS <- time point 2 i + 1; the constant images behind it
+    WinRing& r = c.ring;
+    r.smem = smem, r.wave = wid, r.lane = lane_, r.nwaves = 2 * NT + 4;
+    r.stride_b = (unsigned)(a.stride * 8), r.slot_bytes = 2 * r.stride_b, r.cbase = JQ_WIN_TPS * r.slot_bytes, r.pieces2 = 2 * a.pieces;
+    int inext = 0;
+    unsigned snext = 0;
+    auto fetch = [&] {
+        if (inext >= n) return;
+        r.dma((const char*)a.stream + (size_t)(2 * inext + 1) * r.slot_bytes, smem + snext, r.pieces2);
+        ++inext;
+        snext += r.slot_bytes;
+        if (snext == r.cbase) snext = 0;
+    };
+    r.dma((const char*)a.cimg, smem + r.cbase, 2 * a.Ncoupled * a.pieces);
+    for (int i = 0; i < JQ_WIN_TPS - 1; ++i) fetch();      // steps 0 .. 3; super-step k fetches step k + 4 into the slot of step k - 1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();      // (tables, zeroed exchange images, the first operators)
+    asm volatile("" ::: "memory");
+    r.wave = wave, r.nwaves = NT;      // (from here on the block waves of set 0 stage)
+    double* st = a.state + (size_t)s.slab * a.state_stride;
+    CqImr2<NT> m;
+    m.c = &c;
+    m.x0 = (jq_lds_double*)(xbuf + set * 2 * PAR + lane_);
+    m.cw = 0.0;
+    m.cwa = (a.use_shift && (lane_ >> 4) == (lane_ & 3))
+                ? 0.5 * a.h * a.colinfo[(size_t)s.slab * 32 + s.col] * tab[16 * NT + 16 * wave + 4 * (lane_ & 3) + ((lane_ >> 2) & 3)] : 0.0;
+    m.tol2 = a.jacobi_tol2, m.max_iter = a.m, m.par = 0, m.use_shift = a.use_shift;
+    m.flags = (volatile __attribute__((address_space(3))) int*)(xbuf + 4 * PAR) + 4 * set;
+    m.flags_o = (volatile __attribute__((address_space(3))) int*)(xbuf + 4 * PAR) + 4 * (1 - set);
+    if (reducer) {
+        for (int k = 0; k <= n; ++k) {
+            const bool act = set == 0 ? k < n : k >= 1, oact = set == 0 ? k >= 1 : k < n;
+            if (act) m.reducer2(oact, wv - NT);
+            else m.reducer_idle2(oact);
+        }
+        return;
+    }
+    // su, sv of super-step k: channel 2 of image k & 1, parities 0 / 1; my block at + 64 of hb[...], the neighbours' at + 0, + 128
+    jq_lds_double* hb = (jq_lds_double*)(xbuf + wave * 64 + lane_);
+    unsigned cur = 0;      // byte offset of the ring slot of step k
+    if (set == 0) {
+        double u = st[s.foff], v = st[(size_t)KT * 64 + s.foff];
+        for (int k = 0; k < n; ++k) {
+            m.K = c.load((const double*)(smem + cur) + lane_);
+            m.fold_shift();
+            m.S = c.load((const double*)(smem + cur + r.stride_b) + lane_);
+            cur += r.slot_bytes;
+            if (cur == r.cbase) cur = 0;
+            const double u0 = u, v0 = v;
+            m.template step2<true>(k >= 1, u, v, [](double& fu, double& fv) { fu = 0.0, fv = 0.0; }, fetch);
+            const int ho = (k & 1) * 2 * PAR + 2 * CHS + 64;
+            hb[ho] = u0 + u;
+            hb[ho + PAR] = v0 + v;
+        }
+        m.template idle2<true>(true, [] {});
+        st[s.foff] = u;
+        st[(size_t)KT * 64 + s.foff] = v;
+        return;
+    }
+    double lr = st[(size_t)2 * KT * 64 + s.foff], li = st[(size_t)3 * KT * 64 + s.foff];
+    const double wgt = a.colinfo[(size_t)s.slab * 32 + 16 + s.col];
+    const double cfw = a.forced ? -a.h * a.tinv * tab[16 * wave + s.g] : 0.0;      // h * (-tinv * W): W applied row-wise
+    double* trw = a.traces + ((trow + wave) * a.nsteps_chunk) * ntr;
+    m.template idle2<false>(true, [] {});
+    for (int k = 1; k <= n; ++k) {
+        m.K = c.load((const double*)(smem + cur) + lane_);      // operators of time step k - 1
+        m.fold_shift();
+        m.S = c.load((const double*)(smem + cur + r.stride_b) + lane_);
+        cur += r.slot_bytes;
+        if (cur == r.cbase) cur = 0;
+        const int ho = ((k + 1) & 1) * 2 * PAR + 2 * CHS;      // su, sv of super-step k - 1
+        const double l0 = lr, l1 = li;
+        double su = 0.0, sv = 0.0;
+        m.template step2<false>(k < n, lr, li, [&](double& fu, double& fv) {
+            su = hb[ho + 64], sv = hb[ho + PAR + 64];
+            fu = cfw * su, fv = cfw * sv;
+        }, [] {});
+        const double smu = l0 + lr, snu = l1 + li;
+        // trace products with the constant images (Hsym_q: image q, Hanti_q: image Nc + q)
+        const Sh shu = c.sh(su), shv = c.sh(sv);
+        Nb nsu, nsv;
+        nsu.b = hb[ho], nsu.a = hb[ho + 128];
+        nsv.b = hb[ho + PAR], nsv.a = hb[ho + PAR + 128];
+        double* tr = trw + (size_t)(k - 1) * ntr;
+        for (int qp = 0; qp < Nc; qp += 2) {
+            double P[2] = {0.0, 0.0}, Q[2] = {0.0, 0.0};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = qp + j;
+                if (q < Nc) {
+                    const double* Hs = c.ring.cimg(q);
+                    const double* Ha = c.ring.cimg(Nc + q);
+                    const double B = -(smu * c.template trace_mm<false>(Hs, q, shv, nsv));
+                    const double D = snu * c.template trace_mm<false>(Ha, q, shv, nsv);
+                    const double C = snu * c.template trace_mm<false>(Hs, q, shu, nsu);
+                    const double A = smu * c.template trace_mm<false>(Ha, q, shu, nsu);
+                    P[j] = (B + C) * wgt;
+                    Q[j] = (A + D) * wgt;
+                }
+            }
+            // sums over the wave of P[0], P[1], Q[0], Q[1]: valid in the rows 0, 1, 2, 3 (wave_sum4: a, c, b, d)
+            const double r4 = wave_sum4(P[0], Q[0], P[1], Q[1]);
+            const int row = lane_ >> 4, q = qp + (row & 1);
+            if (q < Nc) {
+                const int l = lane_ & 15;
+                if (l == 0) tr[q * JQ_NTR + (row < 2 ? 3 : 4)] = row < 2 ? -0.25 * r4 : 0.25 * r4;
+                else if (l < 4 && row < 2) tr[q * JQ_NTR + l - 1] = 0.0;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    st[(size_t)2 * KT * 64 + s.foff] = lr;
+    st[(size_t)3 * KT * 64 + s.foff] = li;
+}

@@ -25,6 +25,9 @@ template __global__ void k_backward_cq<JQ_NT, true, true>(PropArgs);
 #include "jq_cq_imr_kernels.h"
 template __global__ void k_forward_cq_imr<JQ_NT>(PropArgs);
 template __global__ void k_backward_cq_imr<JQ_NT>(PropArgs);
+#if JQ_NT <= 6
+template __global__ void k_backward_cq_imr2<JQ_NT>(PropArgs);      // (state and adjoint chain on two sets of waves)
+#endif
 #elif JQ_VARIANT == 7
 #include "jq_quad_imr_kernels.h"
 template __global__ void k_forward_quad_imr<JQ_NT, 1>(PropArgs);

@@ -40,11 +40,12 @@ __device__ __forceinline__ double sample_sum(double x, int N, int c)
     return r;
 }
 
-// x <- the iterate the reference's jacobi_midpoint returns for  x = rhs + [S -K; K S] x  started from (xu, xv)
+// x <- the iterate the reference's jacobi_midpoint returns for  x = rhs + [S -K; K S] x  started from (xu, xv);
+// (bxu, bxv) = B x_0, which the caller has from forming rhs
 // (K, S pre-scaled by h/2; sw: the lane's eps*c*ws shift of diag(K); idle rows: valid == false)
 template <int NPJ>
 __device__ __forceinline__ void imr_solve(const PropArgs& a, const RowMat<NPJ>& K, const RowMat<NPJ>& S, double sw, double rhs_u,
-                                          double rhs_v, double& xu, double& xv, int c, bool valid)
+                                          double rhs_v, double bxu, double bxv, double& xu, double& xv, int c, bool valid)
 {
     const double tol2 = a.jacobi_tol2;
     auto apply = [&](double pu, double pv, double& qu, double& qv) {      // q = rhs + B p
@@ -55,8 +56,7 @@ __device__ __forceinline__ void imr_solve(const PropArgs& a, const RowMat<NPJ>& 
             qv = fma(sw, pu, qv);
         }
     };
-    double cu, cv;
-    apply(xu, xv, cu, cv);                      // x_1
+    double cu = rhs_u + bxu, cv = rhs_v + bxv;   // x_1 = rhs + B x_0
     if (a.N >= 3) {
         // ONE evaluation per wave (N = 4: all four 16-lane rows, N = 3: three of them, the idle row holds zeros): the stopping
         // decision is wave-uniform, both norms come out of one reduction (wave_sum2: rows 0, 1 hold ru, rows 2, 3 rv; two
@@ -101,13 +101,14 @@ template <int NPJ>
 __device__ __forceinline__ void imr_step(const PropArgs& a, const RowMat<NPJ>& K, const RowMat<NPJ>& S, double sw, double& u,
                                          double& v, double fu, double fv, int c, bool valid)
 {
-    double rhs_u = rmv<NPJ, false>(rmv<NPJ, false>(u + fu, S, u), K, -v);
-    double rhs_v = rmv<NPJ, false>(rmv<NPJ, false>(v + fv, S, v), K, u);
+    // B x ONCE: rhs = (x + f) + B x, x_1 = rhs + B x (as the cooperative kernels do)
+    double bu = rmv<NPJ, false>(rmv<NPJ, false>(0.0, S, u), K, -v);
+    double bv = rmv<NPJ, false>(rmv<NPJ, false>(0.0, K, u), S, v);
     if (a.use_shift) {
-        rhs_u = fma(-sw, v, rhs_u);
-        rhs_v = fma(sw, u, rhs_v);
+        bu = fma(-sw, v, bu);
+        bv = fma(sw, u, bv);
     }
-    imr_solve<NPJ>(a, K, S, sw, rhs_u, rhs_v, u, v, c, valid);
+    imr_solve<NPJ>(a, K, S, sw, (u + fu) + bu, (v + fv) + bv, bu, bv, u, v, c, valid);
 }
 
 // Forward sweep.  a.m = max_iter, a.jacobi_tol2 = tol^2; state file as in jq_rowlane_kernels.h, but the four column

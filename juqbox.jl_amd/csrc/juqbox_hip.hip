@@ -1571,13 +1571,29 @@ static int select_quad_imr_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel
 }
 template <int NT> __global__ void k_forward_cq_imr(PropArgs);      // jq_cq_imr_kernels.h (own translation units)
 template <int NT> __global__ void k_backward_cq_imr(PropArgs);
+template <int NT> __global__ void k_backward_cq_imr2(PropArgs);    // (state and adjoint chain on two sets of waves, NT <= 6)
 #define JQ_DECLCI(nt)                                                    \
     extern template __global__ void k_forward_cq_imr<nt>(PropArgs);      \
     extern template __global__ void k_backward_cq_imr<nt>(PropArgs);
 JQ_DECLCI(1) JQ_DECLCI(2) JQ_DECLCI(3) JQ_DECLCI(4) JQ_DECLCI(5) JQ_DECLCI(6) JQ_DECLCI(7)
 #undef JQ_DECLCI
-static int select_cq_imr_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
+#define JQ_DECLCI(nt) extern template __global__ void k_backward_cq_imr2<nt>(PropArgs);
+JQ_DECLCI(1) JQ_DECLCI(2) JQ_DECLCI(3) JQ_DECLCI(4) JQ_DECLCI(5) JQ_DECLCI(6)
+#undef JQ_DECLCI
+// dynamic LDS of k_backward_cq_imr2: staging + tables + two exchange images (one per set of waves) + the decisions
+static size_t cq_imr2_lds(const jq_handle* h, size_t lds_stage) { return lds_stage + (size_t)32 * h->NT * 8 + (size_t)12 * (h->NT + 2) * 64 * 8 + 64; }
+// two: the backward sweep with the state and the adjoint chain on two sets of waves (NT <= 6, LDS permitting; JQ_IMR_CQ2=0: the
+// one-set kernel of round 3)
+static int select_cq_imr_kernels(jq_handle* h, bool two, prop_kernel_t* fwd, prop_kernel_t* bwd)
 {
+#define JQ_PICKCI(nt)                            \
+    if (h->NT == nt && two) {                    \
+        *fwd = k_forward_cq_imr<nt>;             \
+        *bwd = k_backward_cq_imr2<nt>;           \
+        return JQ_OK;                            \
+    }
+    JQ_PICKCI(1) JQ_PICKCI(2) JQ_PICKCI(3) JQ_PICKCI(4) JQ_PICKCI(5) JQ_PICKCI(6)
+#undef JQ_PICKCI
 #define JQ_PICKCI(nt)                            \
     if (h->NT == nt) {                           \
         *fwd = k_forward_cq_imr<nt>;             \
@@ -2001,6 +2017,9 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     const char* e_icq = getenv("JQ_IMR_CQ");
     const bool imr_cq = imr_quad && h->N == 4 && h->parts == 1 && h->cq_max_quads > 0 && nquads_used <= h->cq_max_quads &&
                         !(e_icq && atoi(e_icq) == 0);
+    const char* e_icq2 = getenv("JQ_IMR_CQ2");
+    const bool imr_cq2 = imr_cq && h->NT <= 6 && !(e_icq2 && atoi(e_icq2) == 0) &&
+                         cq_imr2_lds(h, (size_t)(2 * JQ_WIN_TPS + 2 * h->NcK) * h->mat_elems * 8) <= 163840;
     if (cq) spw = 0;
     const bool quad = spw > 0;
     const bool quad8 = spw > 1;
@@ -2022,7 +2041,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     prop_kernel_t kfwd, kbwd;
     lane_init_t klinit = nullptr;
     lane_term_t klterm = nullptr;
-    int rc = imr_cq ? select_cq_imr_kernels(h, &kfwd, &kbwd)
+    int rc = imr_cq ? select_cq_imr_kernels(h, imr_cq2, &kfwd, &kbwd)
              : imr_quad ? select_quad_imr_kernels(h, &kfwd, &kbwd)
              : imr_coop ? (imr_parts ? select_coop_imr_parts_kernels(h, imr_hbm, &kfwd, &kbwd) : select_coop_imr_kernels(h, imr_hbm, &kfwd, &kbwd))
              : imr_rl ? select_rowlane_imr_kernels(h, rl_split, &kfwd, &kbwd)
@@ -2146,7 +2165,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     const size_t lds_cq = lds_stage + (size_t)32 * h->NT * 8 + (size_t)6 * (h->NT + 2) * 64 * 8 + (size_t)std::max(2, h->NcK + (h->NcK + 1) / 2) * h->NT * 64 * 8;      // tables, x exchange, trace hand-off / wg-sum scratch (one region)
     const size_t lds_fwd = rl ? (wfull ? (size_t)JQ_RL_WTAB * 8 : 0) : lane ? 0 : (cq || imr_cq) ? lds_cq : imr_coop ? coop_imr_lds_bytes(h->NT, imr_hbm ? 0 : stride)
                                            : lds_stage + (size_t)32 * h->NT * 8 + (coop ? (size_t)2 * h->KT * 64 * 8 + (size_t)16 * h->NT * 8 + coop_w_bytes : 0);      // (+ the Jacobi solver's column norms [NT][16], the low-rank weights' dot exchange)
-    const size_t lds_bwd = rl ? (h->rl_npj > 8 ? (size_t)2 * h->NcK * h->rl_stride * 8 : 0) + (rl_split ? (size_t)2 * 3 * 64 * 8 : 0) /* records: 3 values per lane and slot, implicit midpoint 2 */ + (wfull ? (size_t)JQ_RL_WTAB * 8 : 0) /* low-rank weight table */ : lane ? 0 : (coop || cq || imr_cq) ? lds_fwd
+    const size_t lds_bwd = rl ? (h->rl_npj > 8 ? (size_t)2 * h->NcK * h->rl_stride * 8 : 0) + (rl_split ? (size_t)2 * 3 * 64 * 8 : 0) /* records: 3 values per lane and slot, implicit midpoint 2 */ + (wfull ? (size_t)JQ_RL_WTAB * 8 : 0) /* low-rank weight table */ : lane ? 0 : imr_cq2 ? cq_imr2_lds(h, lds_stage) : (coop || cq || imr_cq) ? lds_fwd
                                 : imr_quad ? lds_fwd + (size_t)JQ_MAXNC * nthreads * 8 + (size_t)(nthreads / 64) * h->NT * 64 * 8
                                 : quad ? lds_stage + (size_t)bwd_lds_tail(h->NT, h->NcK, nthreads / 64, (long long)h->NT * 64)   // (a 16-row block per register)
                                 : lds_stage + (size_t)bwd_lds_tail(h->NT, h->NcK, JQ_WAVES, h->park_lds ? (long long)h->KT * 64 : 0);
@@ -2289,7 +2308,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
                     }
                 }
                 HIPCHK(h, hipEventRecord(h->ev[evi++], s));
-                hipLaunchKernelGGL(kbwd, dim3(nblocks), dim3((cq || rl_split) ? 2 * nthreads : imr_cq ? nthreads + 128 : nthreads), lds_bwd + (wlr_lds_bwd >= 0 ? wlr_bytes : 0), s, a);      // (cooperative quad: state and adjoint chain on separate waves)
+                hipLaunchKernelGGL(kbwd, dim3(nblocks), dim3((cq || rl_split) ? 2 * nthreads : imr_cq2 ? 2 * (nthreads + 128) : imr_cq ? nthreads + 128 : nthreads), lds_bwd + (wlr_lds_bwd >= 0 ? wlr_bytes : 0), s, a);      // (cooperative quad: state and adjoint chain on separate waves)
                 HIPCHK(h, hipEventRecord(h->ev[evi++], s));
                 hipLaunchKernelGGL(k_trace_reduce, dim3((unsigned)(((long long)nc * ntr_g + 255) / 256)), dim3(256), 0, s,
                                    h->d_traces, trace_rows, nc, ntr_g, h->d_R);

@@ -35,5 +35,6 @@ def run(tag, imr, env):
 
 run("Stormer-Verlet", False, {})
 run("implicit midpoint, cq", True, {})
+run("implicit midpoint, cq one set", True, {"JQ_IMR_CQ2": "0"})
 run("implicit midpoint, quad", True, {"JQ_IMR_CQ": "0"})
 run("implicit midpoint, coop", True, {"JQ_QUAD": "0"})
