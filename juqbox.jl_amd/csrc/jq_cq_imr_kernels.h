@@ -44,7 +44,7 @@ struct CqImr {
     volatile __attribute__((address_space(3))) int* flags;      // decisions of the reducer waves, [2 slots][2 parts]
 
     struct Acc {
-        double au, kv, av;  // q_u = au - kv ; q_v = av
+        double au, kv, av, sv;  // q_u = au - kv ; q_v = av + sv  (four independent chains of one MFMA and four FMAs each)
     };
     // the part of  q = rhs + [S -K; K S] p  that needs only my block
     __device__ __forceinline__ Acc own(double ru, double rv, double pu, double pv) const
@@ -53,7 +53,8 @@ struct CqImr {
         Acc r;
         r.au = c->own(ru, S, su);
         r.kv = c->own(0.0, K, sv);
-        r.av = c->own(c->own(rv, K, su), S, sv);
+        r.av = c->own(rv, K, su);
+        r.sv = c->own(0.0, S, sv);
         // (the diagonal shift of K, src/ipopt_interface.jl:41-44, is part of K.a: fold_shift)
         return r;
     }
@@ -66,7 +67,8 @@ struct CqImr {
         nv.b = c->xb[po + CHS], nv.a = c->xb[po + CHS + 128];
         r.au = c->nbr(r.au, S, nu);
         r.kv = c->nbr(r.kv, K, nv);
-        r.av = c->nbr(c->nbr(r.av, K, nu), S, nv);
+        r.av = c->nbr(r.av, K, nu);
+        r.sv = c->nbr(r.sv, S, nv);
     }
     __device__ __forceinline__ void post(int po, double xu, double xv) const
     {
@@ -91,7 +93,7 @@ struct CqImr {
         }
         nbr(nx, po);
         par ^= 1;
-        const double Bu = nx.au - nx.kv, Bv = nx.av;
+        const double Bu = nx.au - nx.kv, Bv = (nx.av + nx.sv);
         const double rhs_u = (u + fu) + Bu, rhs_v = (v + fv) + Bv;
         double au = rhs_u + Bu, av = rhs_v + Bv;      // x_1
         po = par * PAR;
@@ -100,31 +102,45 @@ struct CqImr {
         c->sync();
         nbr(nx, po);
         par ^= 1;
-        double bu = nx.au - nx.kv, bv = nx.av;         // x_2
+        double bu = nx.au - nx.kv, bv = (nx.av + nx.sv);         // x_2
         po = par * PAR;
         post(po, bu, bv);
         nx = own(rhs_u, rhs_v, bu, bv);
         c->sync();
         nbr(nx, po);
         par ^= 1;
-        double cu = nx.au - nx.kv, cv = nx.av;         // x_3
-        // (au, av) = x_{j-2}, (bu, bv) = x_{j-1}, (cu, cv) = x_j
-        for (int j = 3;; ++j) {
-            po = par * PAR;
-            post(po, cu, cv);                          // (speculative, like x_{j-1}: dropped if x_{j-2} turns out to be the result)
-            nx = own(rhs_u, rhs_v, cu, cv);
+        double cu = nx.au - nx.kv, cv = (nx.av + nx.sv);         // x_3
+        // (au, av) = x_{j-2}, (bu, bv) = x_{j-1}, (cu, cv) = x_j.  The loop is written for three rounds: the new iterate replaces the
+        // oldest one and the three register pairs take turns (a rotating copy cost six moves per round on waves whose SIMD is
+        // bound by its issue rate)
+        int j = 3;
+        auto turn = [&](double xu, double xv, double& ou, double& ov) -> bool {
+            const int po_ = par * PAR;
+            post(po_, xu, xv);                         // (speculative, like x_{j-1}: dropped if x_{j-2} turns out to be the result)
+            Acc t = own(rhs_u, rhs_v, xu, xv);
             c->sync();
             par ^= 1;
             const long long f = *(volatile __attribute__((address_space(3))) long long*)(flags + 2 * (j & 1));      // the decision on x_{j-2}
-            Acc t = nx;
-            nbr(t, po);                                // (the reads go out together with the flags')
-            if (__builtin_amdgcn_readfirstlane((int)f & (int)(f >> 32))) break;
-            au = bu, av = bv;
-            bu = cu, bv = cv;
-            cu = t.au - t.kv, cv = t.av;
+            ++j;
+            nbr(t, po_);                               // (the reads go out together with the flags')
+            if (__builtin_amdgcn_readfirstlane((int)f & (int)(f >> 32))) return true;
+            ou = t.au - t.kv, ov = t.av + t.sv;
+            return false;
+        };
+        for (;;) {
+            if (turn(cu, cv, au, av)) {
+                u = au, v = av;
+                return;
+            }
+            if (turn(au, av, bu, bv)) {
+                u = bu, v = bv;
+                return;
+            }
+            if (turn(bu, bv, cu, cv)) {
+                u = cu, v = cv;
+                return;
+            }
         }
-        u = au;
-        v = av;
     }
     // The same step on a reducer wave (part 0: the u part = channel 0 of the exchange image, part 1: the v part): it passes the block
     // waves' barriers; behind barrier j it reads the NT blocks of x_j (every block, in the same order), keeps them for the next
@@ -376,7 +392,7 @@ struct CqImr2 : CqImr<NT> {
         getf(fu, fv);
         this->nbr(nx, po);
         this->par ^= 1;
-        const double Bu = nx.au - nx.kv, Bv = nx.av;
+        const double Bu = nx.au - nx.kv, Bv = (nx.av + nx.sv);
         const double rhs_u = (u + fu) + Bu, rhs_v = (v + fv) + Bv;
         double au = rhs_u + Bu, av = rhs_v + Bv;      // x_1
         po = this->par * PAR;
@@ -385,61 +401,51 @@ struct CqImr2 : CqImr<NT> {
         this->c->sync();
         this->nbr(nx, po);
         this->par ^= 1;
-        double bu = nx.au - nx.kv, bv = nx.av;         // x_2
+        double bu = nx.au - nx.kv, bv = (nx.av + nx.sv);         // x_2
         po = this->par * PAR;
         this->post(po, bu, bv);
         nx = this->own(rhs_u, rhs_v, bu, bv);
         this->c->sync();
         this->nbr(nx, po);
         this->par ^= 1;
-        double cu = nx.au - nx.kv, cv = nx.av;         // x_3
-        // (au, av) = x_{j-2}, (bu, bv) = x_{j-1}, (cu, cv) = x_j
+        double cu = nx.au - nx.kv, cv = (nx.av + nx.sv);         // x_3
+        // (au, av) = x_{j-2}, (bu, bv) = x_{j-1}, (cu, cv) = x_j; three rounds per loop iteration as in CqImr::step.  Every round
+        // reads both sets' decisions (those of a set that has its result, or no work, are stale: doth is true then)
         int j = 3;
-        bool dme = false, doth = !oact;
+        bool doth = !oact;
+        auto turn = [&](double xu, double xv, double& ou, double& ov) -> bool {
+            const int po_ = this->par * PAR;
+            this->post(po_, xu, xv);
+            Acc t = this->own(rhs_u, rhs_v, xu, xv);
+            this->c->sync();
+            this->par ^= 1;
+            const int km = decided(this->flags, j), ko = decided(flags_o, j);      // the decisions on the two x_{j-2}
+            ++j;
+            if (ko) doth = true;
+            this->nbr(t, po_);
+            if (km) return true;
+            ou = t.au - t.kv, ov = t.av + t.sv;
+            return false;
+        };
+        for (;;) {
+            if (turn(cu, cv, au, av)) {
+                u = au, v = av;
+                break;
+            }
+            if (turn(au, av, bu, bv)) {
+                u = bu, v = bv;
+                break;
+            }
+            if (turn(bu, bv, cu, cv)) {
+                u = cu, v = cv;
+                break;
+            }
+        }
         if (!doth)
-            for (;; ++j) {                             // both sets iterate
-                po = this->par * PAR;
-                this->post(po, cu, cv);
-                nx = this->own(rhs_u, rhs_v, cu, cv);
-                this->c->sync();
-                this->par ^= 1;
-                const int km = decided(this->flags, j), ko = decided(flags_o, j);      // the decisions on the two x_{j-2}
-                Acc t = nx;
-                this->nbr(t, po);
-                if (!km) {
-                    au = bu, av = bv;
-                    bu = cu, bv = cv;
-                    cu = t.au - t.kv, cv = t.av;
-                }
-                if (km | ko) {
-                    dme = km != 0, doth = ko != 0;
-                    ++j;
-                    break;
-                }
-            }
-        if (!dme) {
-            for (;; ++j) {                             // the other set has its result (or no work): CqImr::step's loop
-                po = this->par * PAR;
-                this->post(po, cu, cv);
-                nx = this->own(rhs_u, rhs_v, cu, cv);
-                this->c->sync();
-                this->par ^= 1;
-                const int km = decided(this->flags, j);
-                Acc t = nx;
-                this->nbr(t, po);
-                if (km) break;
-                au = bu, av = bv;
-                bu = cu, bv = cv;
-                cu = t.au - t.kv, cv = t.av;
-            }
-        } else if (!doth) {
-            for (;; ++j) {                             // mine is x_{j-2} = (au, av); the other set still iterates
+            for (;; ++j) {                             // the other set still iterates
                 this->c->sync();
                 if (decided(flags_o, j)) break;
             }
-        }
-        u = au;
-        v = av;
     }
     // CqImr::reducer_step likewise
     __device__ __forceinline__ void reducer_idle2(bool oact)
@@ -514,8 +520,8 @@ struct CqImr2 : CqImr<NT> {
     }
 };
 
-// grid = 4 * nslabs (workgroup = one evaluation, N = 4), block = 2 * 64 * (NT + 2): set 0 = waves 0 .. NT + 1 (state chain: NT block
-// waves, 2 reducer waves), set 1 = the next NT + 2 (adjoint chain).  Dynamic LDS: staging + tables + 4 PAR doubles + 64 bytes.
+// grid = 4 * nslabs (workgroup = one evaluation, N = 4), block = 2 * 64 * (NT + 2): set 0 = state chain (NT block waves, 2 reducer
+// waves), set 1 = adjoint chain.  Dynamic LDS: staging + tables + 4 PAR doubles + 64 bytes.
 template <int NT>
 __global__ __launch_bounds__(128 * NT + 256) void k_backward_cq_imr2(PropArgs a)
 {
@@ -526,8 +532,11 @@ __global__ __launch_bounds__(128 * NT + 256) void k_backward_cq_imr2(PropArgs a)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     CqSetup<NT> s = cq_setup<NT>(a);
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int set = wid >= NT + 2 ? 1 : 0, wv = wid - set * (NT + 2);      // wv < NT: block wave wv; NT, NT + 1: reducer of part 0, 1
-    const bool reducer = wv >= NT;
+    // waves 0 .. 2 NT - 1: block wave wid % NT of set wid / NT; the last four: reducers (set 0 part 0, 1; set 1 part 0, 1) -- with
+    // NT = 6 every SIMD (wave id mod 4) gets three block waves and one reducer wave
+    const bool reducer = wid >= 2 * NT;
+    const int set = reducer ? (wid - 2 * NT) >> 1 : (wid >= NT ? 1 : 0);
+    const int wv = reducer ? NT + ((wid - 2 * NT) & 1) : wid - set * NT;      // wv < NT: block wave wv; NT, NT + 1: reducer of part 0, 1
     const int wave = reducer ? 0 : wv, lane_ = s.lane_;
     s.foff = (size_t)(4 * wave + ((lane_ >> 2) & 3)) * 64 + 16 * (lane_ >> 4) + s.col;
     const int Nc = a.Ncoupled, ntr = Nc * JQ_NTR;

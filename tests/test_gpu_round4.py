@@ -203,3 +203,39 @@ def test_uni_and_ord_variants_of_the_throughput_kernel_agree(jq):
         assert abs(res[tag][1] - res["generic"][1]) <= 1e-12 * abs(res["generic"][1])
         assert np.linalg.norm(res[tag][2] - res["generic"][2]) <= 1e-12 * g
     assert not np.array_equal(res["ord"][2], res["generic"][2])      # (different kernels did run)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nsamples", [0, 5])
+def test_two_set_cooperative_quad_implicit_midpoint_kernel_is_the_one_set_kernel(jq, nsamples):
+    """Round 4: k_backward_cq_imr2 runs the state chain of time step k and the adjoint chain of step k - 1 on two sets of waves
+    (a pipeline of depth one inside a chunk, prologue and epilogue super-steps, odd chunk lengths).  Each chain performs the
+    operations of the one-set kernel (JQ_IMR_CQ2=0) in the same order: bit-identical results -- for one evaluation and for a
+    small ensemble with shifts, with a step count that is odd and leaves a ragged last chunk."""
+    params, info = jq.cases.cnot3()
+    params.T, params.nsteps = params.T * 1501 / params.nsteps, 1501
+    params.Integrator_id = jq.Implicit_Midpoint
+    params.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER_M, max_iter=100, tol=1e-12, nrhs=params.N)
+    pcof = np.array(json.load(open(os.path.join(ROOT, "tests", "golden", "cnot3.json")))["pcof0"])
+    res = {}
+    for tag, env in (("two", {"JQ_CHUNK_STEPS": "400"}), ("one", {"JQ_IMR_CQ2": "0", "JQ_CHUNK_STEPS": "400"}), ("two_whole", {})):
+        os.environ.update(env)
+        try:
+            wa = jq.Working_Arrays_M_HIP(params, pcof.size)
+            if nsamples:
+                nodes, weights, shift = jq.cases.cnot3_ensemble(nsamples)
+                jq.eval_f_g_grad(pcof, params, wa, nodes, weights, True, shift=shift)
+                res[tag] = (params.last_infidelity, params.last_leak, params.last_infidelity_grad.copy())
+            else:
+                f, g, *_ = jq.traceobjgrad(pcof, params, wa, False, True)
+                res[tag] = (f, 0.0, np.array(g))
+            assert wa.last_timing()["kernel_family"] == 9
+            wa.close()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    assert res["two"][0] == res["one"][0] and res["two"][1] == res["one"][1]
+    assert np.array_equal(res["two"][2], res["one"][2])
+    # (one chunk instead of four: the gradient's partial sums are grouped differently)
+    assert abs(res["two"][0] - res["two_whole"][0]) <= 1e-13 * abs(res["two"][0])
+    assert np.linalg.norm(res["two"][2] - res["two_whole"][2]) <= 1e-12 * np.linalg.norm(res["two"][2])
