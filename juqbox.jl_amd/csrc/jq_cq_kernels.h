@@ -110,6 +110,20 @@ struct WinRing {
 #define JQ_TS_PRINT(w)
 #endif
 typedef __attribute__((address_space(3))) double jq_lds_double;
+// Two column quads per workgroup (k_forward_cq<.., 2>): every array is a PAIR of doubles per lane, quad A in channel C of the exchange
+// image and quad B in channel C + 1; the propagation code below is written once for T = double and T = D2.
+struct D2 {
+    double a, b;
+    __device__ __forceinline__ D2() {}
+    __device__ __forceinline__ D2(double x) : a(x), b(x) {}
+    __device__ __forceinline__ D2(double x, double y) : a(x), b(y) {}
+};
+__device__ __forceinline__ D2 operator+(D2 x, D2 y) { return D2(x.a + y.a, x.b + y.b); }
+__device__ __forceinline__ D2 operator*(D2 x, D2 y) { return D2(x.a * y.a, x.b * y.b); }
+__device__ __forceinline__ D2 operator*(double c, D2 y) { return D2(c * y.a, c * y.b); }
+__device__ __forceinline__ D2 operator-(D2 x) { return D2(-x.a, -x.b); }
+__device__ __forceinline__ D2 fma(D2 c, D2 x, D2 y) { return D2(fma(c.a, x.a, y.a), fma(c.b, x.b, y.b)); }
+__device__ __forceinline__ D2 fma(double c, D2 x, D2 y) { return D2(fma(c, x.a, y.a), fma(c, x.b, y.b)); }
 // Exchange image in LDS: [2 parities][3 channels][NT + 2 blocks][64] doubles -- a zero block in front of and behind the NT
 // blocks of a channel, so that the neighbours of the edge blocks need no clamping.  Channel 0: forward sweep / state chain of
 // the backward sweep; channel 1: adjoint chain; channel 2: its second vector of the last publication of a step.
@@ -143,6 +157,12 @@ struct CoopQ {
     // my block of channel C, parity P
     template <int P, int C>
     __device__ __forceinline__ void post(double x) { xb[P * PAR + C * CHS + 64] = x; }
+    template <int P, int C>
+    __device__ __forceinline__ void post(D2 x)
+    {
+        xb[P * PAR + C * CHS + 64] = x.a;
+        xb[P * PAR + (C + 1) * CHS + 64] = x.b;
+    }
     template <int P, int C>
     __device__ __forceinline__ double block() const { return xb[P * PAR + C * CHS + 64]; }
     template <bool DMA = false>
@@ -184,22 +204,42 @@ struct CoopQ {
         acc = fma(o.c[0], s.dn, acc);
         return fma(o.c[1], s.up, acc);
     }
+    struct Sh2 {
+        Sh a, b;
+    };
+    __device__ __forceinline__ Sh2 sh(D2 x) const
+    {
+        Sh2 s;
+        s.a = sh(x.a), s.b = sh(x.b);
+        return s;
+    }
+    __device__ __forceinline__ D2 own(D2 C, const Op& o, const Sh2& s) const { return D2(own(C.a, o, s.a), own(C.b, o, s.b)); }
     // the neighbours' blocks of the vector published in channel C, parity P
     struct Nb {
         double b, a;
     };
-    template <int P, int C>
-    __device__ __forceinline__ Nb nbs() const
+    struct Nb2 {
+        Nb a, b;
+    };
+    template <int P, int C, typename T = double>
+    __device__ __forceinline__ auto nbs() const
     {
-        Nb n;
-        n.b = xb[P * PAR + C * CHS], n.a = xb[P * PAR + C * CHS + 128];
-        return n;
+        if constexpr (std::is_same<T, D2>::value) {
+            Nb2 n;
+            n.a = nbs<P, C>(), n.b = nbs<P, C + 1>();
+            return n;
+        } else {
+            Nb n;
+            n.b = xb[P * PAR + C * CHS], n.a = xb[P * PAR + C * CHS + 128];
+            return n;
+        }
     }
     __device__ __forceinline__ double nbr(double acc, const Op& o, const Nb& n) const
     {
         acc = fma(o.c[2], n.b, acc);      // (the coefficients of a missing neighbour are zero)
         return fma(o.c[3], n.a, acc);
     }
+    __device__ __forceinline__ D2 nbr(D2 acc, const Op& o, const Nb2& n) const { return D2(nbr(acc.a, o, n.a), nbr(acc.b, o, n.b)); }
     // M x for a constant trace image (my block).  ORD: control q acts on subsystem q only -- q = 0: the 4 x 4 diagonal blocks
     // (MFMA), q = 1: the (i, i+-4) couplings (lane shifts), q = 2: the (i, i+-16) couplings (neighbour blocks) -- so one part
     // of the product and one LDS read suffice; otherwise the whole product (the absent parts of an image are stored as zeros).
@@ -217,25 +257,25 @@ struct CoopQ {
         }
     }
     // one publication of a Neumann series: Y <- C + S Y
-    template <int P, int C>
-    __device__ __forceinline__ double hstep(double Cv, double Y, const Op& S)
+    template <int P, int C, typename T>
+    __device__ __forceinline__ T hstep(T Cv, T Y, const Op& S)
     {
         post<P, C>(Y);
-        const double t = own(Cv, S, sh(Y));
+        const T t = own(Cv, S, sh(Y));
         sync();
-        return nbr(t, S, nbs<P, C>());
+        return nbr(t, S, nbs<P, C, T>());
     }
     // base + sum_{j=1..m} S^j A  (Horner form, jq_kernels.h): m publications in channel C, the first one in parity PS; m is odd iff
     // MODD.  The inner m - 1 publications run in pairs (static parities); the next publication after the series has parity PS ^ MODD.
     // (pre: issues the loads of the operators that the publication AFTER the series needs, one interval ahead)
-    template <int PS, int C, bool MODD, typename F>
-    __device__ __forceinline__ double horner(double base, double A, const Op& S, int m, F pre)
+    template <int PS, int C, bool MODD, typename T, typename F>
+    __device__ __forceinline__ T horner(T base, T A, const Op& S, int m, F pre)
     {
         if (m <= 0) {
             pre();
             return base;
         }
-        double Y = A;
+        T Y = A;
         int q = m - 1;      // inner publications; odd iff m is even
         constexpr int PA = MODD ? PS : (PS ^ 1);      // parity of the first publication of the pairs
         if constexpr (!MODD) {
@@ -249,8 +289,8 @@ struct CoopQ {
         pre();
         return hstep<PA, C>(base, Y, S);      // (the final publication: parity PS ^ ((m - 1) & 1) = PA)
     }
-    template <int PS, int C, bool MODD>
-    __device__ __forceinline__ double horner(double base, double A, const Op& S, int m)
+    template <int PS, int C, bool MODD, typename T>
+    __device__ __forceinline__ T horner(T base, T A, const Op& S, int m)
     {
         return horner<PS, C, MODD>(base, A, S, m, [] {});
     }
@@ -318,23 +358,20 @@ __device__ __forceinline__ void cq_next_ops(CoopQ<NT>& c, CqOps<NT>& o)
 //   I1: P0   I2: P0^1   first Neumann series: from P0   I3: P0^M   I4: P0^M^1   second series: from P0^M   I5: P0      (M = m & 1)
 // State step up to its second-to-last publication: in u, v; out un = u(t+h), v05, vN = v05 + S05 v05 (the caller publishes un
 // once more and adds Kp05 un).
-template <int NT, int P0, bool MODD>
-__device__ __forceinline__ void cq_state(CoopQ<NT>& c, const PropArgs& a, const CqOps<NT>& o, double cw, double u, double v, double& un,
-                                         double& v05, double& vN)
+template <int NT, int P0, bool MODD, typename T>
+__device__ __forceinline__ void cq_state(CoopQ<NT>& c, const PropArgs& a, const CqOps<NT>& o, T cw, T u, T v, T& un, T& v05, T& vN)
 {
-    typedef typename CoopQ<NT>::Sh Sh;
-    typedef typename CoopQ<NT>::Nb Nb;
     constexpr int M = MODD ? 1 : 0;
     // x = u: A = c K05 u ; P = u + c S0 u
     c.template post<P0, 0>(u);
-    double A, P;
+    T A, P;
     {
-        const Sh s = c.sh(u);
-        A = c.own(0.0, o.Kp05, s);
+        const auto s = c.sh(u);
+        A = c.own(T(0.0), o.Kp05, s);
         P = c.own(u, o.S0, s);
         if (a.use_shift) A = fma(cw, u, A);
         c.sync();
-        const Nb n = c.template nbs<P0, 0>();
+        const auto n = c.template nbs<P0, 0, T>();
         A = c.nbr(A, o.Kp05, n);
         P = c.nbr(P, o.S0, n);
     }
@@ -342,21 +379,21 @@ __device__ __forceinline__ void cq_state(CoopQ<NT>& c, const PropArgs& a, const 
     c.template post<P0 ^ 1, 0>(v);
     A = c.own(A, o.S05, c.sh(v));
     c.sync();
-    A = c.nbr(A, o.S05, c.template nbs<P0 ^ 1, 0>());
+    A = c.nbr(A, o.S05, c.template nbs<P0 ^ 1, 0, T>());
     v05 = c.template horner<P0, 0, MODD>(v + A, A, o.S05, a.m);
     // x = v05: vN = v05 + c S05 v05 ; un = u + c (S0 u - K0 v05) ; A = -c K1 v05
     c.template post<P0 ^ M, 0>(v05);
     {
-        const Sh s = c.sh(v05);
+        const auto s = c.sh(v05);
         vN = c.own(v05, o.S05, s);
         un = c.own(P, o.Kn0, s);
-        A = c.own(0.0, o.Kn1, s);
+        A = c.own(T(0.0), o.Kn1, s);
         if (a.use_shift) {
             un = fma(-cw, v05, un);
             A = fma(-cw, v05, A);
         }
         c.sync();
-        const Nb n = c.template nbs<P0 ^ M, 0>();
+        const auto n = c.template nbs<P0 ^ M, 0, T>();
         vN = c.nbr(vN, o.S05, n);
         un = c.nbr(un, o.Kn0, n);
         A = c.nbr(A, o.Kn1, n);
@@ -365,26 +402,27 @@ __device__ __forceinline__ void cq_state(CoopQ<NT>& c, const PropArgs& a, const 
     c.template post<P0 ^ M ^ 1, 0>(un);
     A = c.own(A, o.S1, c.sh(un));
     c.sync();
-    A = c.nbr(A, o.S1, c.template nbs<P0 ^ M ^ 1, 0>());
+    A = c.nbr(A, o.S1, c.template nbs<P0 ^ M ^ 1, 0, T>());
     un = c.template horner<P0 ^ M, 0, MODD>(un + A, A, o.S1, a.m);
 }
 
 template <int NT>
 struct CqSetup {
     int lane_, wave, chain, qd, slab, col, g;      // wave: my block; chain: 0 = forward sweep / state chain, 1 = adjoint chain
+    int used;           // columns of the slab that carry a state
     bool active;
     size_t foff;        // offset of my element in an array image of the slab file
 };
 template <int NT>
-__device__ __forceinline__ CqSetup<NT> cq_setup(const PropArgs& a)
+__device__ __forceinline__ CqSetup<NT> cq_setup(const PropArgs& a, int slab, int qd)
 {
     CqSetup<NT> s;
     s.lane_ = threadIdx.x & 63;
     s.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     s.chain = s.wave >= NT ? 1 : 0;
     s.wave -= s.chain * NT;
-    s.slab = blockIdx.x >> 2;
-    s.qd = blockIdx.x & 3;
+    s.slab = slab;
+    s.qd = qd;
     s.col = 4 * s.qd + (s.lane_ & 3);
     s.g = 4 * (s.lane_ >> 4) + ((s.lane_ >> 2) & 3);      // offset in a block of the row tables ([block][row in group][group])
     s.foff = (size_t)(4 * s.wave + ((s.lane_ >> 2) & 3)) * 64 + 16 * (s.lane_ >> 4) + s.col;
@@ -398,8 +436,14 @@ __device__ __forceinline__ CqSetup<NT> cq_setup(const PropArgs& a)
         if (ns > a.sps) ns = a.sps;
         used = ns * a.N;
     }
+    s.used = used;
     s.active = 4 * s.qd < used;
     return s;
+}
+template <int NT>
+__device__ __forceinline__ CqSetup<NT> cq_setup(const PropArgs& a)
+{
+    return cq_setup<NT>(a, (int)blockIdx.x >> 2, (int)blockIdx.x & 3);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -407,13 +451,20 @@ __device__ __forceinline__ CqSetup<NT> cq_setup(const PropArgs& a)
 // The two extra waves only stage: they pass the barriers and, behind the last one of step n, issue the DMA of the time points
 // 2n+5, 2n+6 into the slots of 2n, 2n+1 (whose operators everybody has loaded) -- ~25 instructions per step that would
 // otherwise sit on the critical path of the six propagating waves (a wave issues one instruction every ~10 cycles).
-template <int NT, bool MODD>
+// NS = 2 (257 .. 512 column quads on 256 CUs; round 4): TWO column quads per workgroup, grid = 2 * nslabs -- workgroup b works on the
+// quads 2 (b & 1) and 2 (b & 1) + 1 of slab b / 2, every array a pair of doubles per lane (D2), quad B in channel 1 of the exchange
+// image.  The same barriers serve both quads: a publication interval of the forward sweep (two waves per SIMD) is bound by latency,
+// not by issue, so twice the work per interval costs ~ 1.5 x -- against 2 x for two rounds of workgroups.  (The backward sweep's
+// twelve waves are issue-bound and hold 150 registers: it stays at one quad per workgroup.)
+template <int NT, bool MODD, int NS = 1>
 __global__ __launch_bounds__(64 * NT + 128) void k_forward_cq(PropArgs a)
 {
+    typedef typename std::conditional<NS == 2, D2, double>::type T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KT = 4 * NT;
-    const CqSetup<NT> s = cq_setup<NT>(a);
+    const CqSetup<NT> s = NS == 2 ? cq_setup<NT>(a, (int)blockIdx.x >> 1, 2 * ((int)blockIdx.x & 1)) : cq_setup<NT>(a);
     if (!s.active) return;      // (a quad without columns: the whole workgroup leaves before any barrier)
+    const bool actB = NS == 2 && 4 * (s.qd + 1) < s.used;      // (the slab's last quad pair may be half empty)
     const int lane_ = s.lane_, wave = s.wave;
     double* tab = (double*)(smem + a.lds_tab_off);
     for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[(i & ~15) + 4 * (i & 3) + ((i >> 2) & 3)] = a.tabs[i];   // [block][g][r]
@@ -432,42 +483,61 @@ __global__ __launch_bounds__(64 * NT + 128) void k_forward_cq(PropArgs a)
             c.ring.issue_next();
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();      // (cq_wg_sum of the propagating waves)
-        __syncthreads();
+        for (int k = 0; k < NS; ++k) {
+            __syncthreads();      // (cq_wg_sum of the propagating waves)
+            __syncthreads();
+        }
         return;
     }
     const double wdr = tab[16 * wave + s.g], wsr = tab[16 * NT + 16 * wave + s.g];
 
     double* st = a.state + (size_t)s.slab * a.state_stride;
-    double u = st[s.foff], v = st[(size_t)KT * 64 + s.foff];
     const bool slot0 = wave == 0 && ((lane_ >> 2) & 3) == 0;      // the lanes that carry per-column partials between chunks
     const size_t cslot = 16 * (lane_ >> 4) + s.col;
-    double leak = slot0 ? st[(size_t)(JQ_STATE_ARRAYS * KT + JQ_MAXNC) * 64 + cslot] : 0.0;
-    const double cw = 0.5 * a.h * a.colinfo[(size_t)s.slab * 32 + s.col] * wsr;      // h/2 eps ws[row]
+    const size_t lslot = (size_t)(JQ_STATE_ARRAYS * KT + JQ_MAXNC) * 64 + cslot;
+    T u, v, leak, cw;
+    if constexpr (NS == 2) {      // (quad B: four columns further in every image)
+        u = D2(st[s.foff], actB ? st[s.foff + 4] : 0.0);
+        v = D2(st[(size_t)KT * 64 + s.foff], actB ? st[(size_t)KT * 64 + s.foff + 4] : 0.0);
+        leak = D2(slot0 ? st[lslot] : 0.0, slot0 && actB ? st[lslot + 4] : 0.0);
+        cw = D2(0.5 * a.h * a.colinfo[(size_t)s.slab * 32 + s.col] * wsr, actB ? 0.5 * a.h * a.colinfo[(size_t)s.slab * 32 + s.col + 4] * wsr : 0.0);
+    } else {
+        u = st[s.foff], v = st[(size_t)KT * 64 + s.foff];
+        leak = slot0 ? st[lslot] : 0.0;
+        cw = 0.5 * a.h * a.colinfo[(size_t)s.slab * 32 + s.col] * wsr;      // h/2 eps ws[row]
+    }
     CqOps<NT> o = cq_first_ops<NT>(c);
 
+    auto hist = [&](int n, int colq, double hu, double hv) {
+        const int scol = a.parts > 1 ? 16 * s.slab + colq : colq;
+        const int row = 16 * wave + 4 * ((lane_ >> 2) & 3) + (lane_ >> 4);
+        if (s.slab < a.parts && scol < a.N && row < a.Ntot) {
+            const size_t off = (size_t)(a.step0 + n + 1) * a.Ntot * a.N + (size_t)scol * a.Ntot + row;
+            a.hist_r[off] = hu;
+            a.hist_i[off] = -hv;
+        }
+    };
     // one time step whose first publication has parity P0 (the next step's has P0 ^ 1: 5 + 2 m publications)
     auto step = [&](auto P0c, int n) {
         constexpr int P0 = decltype(P0c)::value;
         leak = fma(wdr, u * u, leak);      // trapezoidal part at t_n (src/evalobjgrad.jl:700)
-        double un, v05, vN;
+        T un, v05, vN;
         cq_state<NT, P0, MODD>(c, a, o, cw, u, v, un, v05, vN);
         // Kp05 again: v(t+h) = v05 + c (K05 u_new + S05 v05)
         c.template post<P0, 0>(un);
         v = c.own(vN, o.Kp05, c.sh(un));
         if (a.use_shift) v = fma(cw, un, v);
         c.sync();
-        v = c.nbr(v, o.Kp05, c.template nbs<P0, 0>());
+        v = c.nbr(v, o.Kp05, c.template nbs<P0, 0, T>());
         cq_next_ops<NT>(c, o);      // (the staging waves drained the DMA of its time points in front of this barrier)
         u = un;
-        leak += wdr * (u * u) + 2.0 * (wdr * (v05 * v05));      // (:716, penalf2a :2170-2180)
+        leak = leak + (wdr * (u * u) + 2.0 * (wdr * (v05 * v05)));      // (:716, penalf2a :2170-2180)
         if (a.hist_r) {
-            const int scol = a.parts > 1 ? 16 * s.slab + s.col : s.col;
-            const int row = 16 * wave + 4 * ((lane_ >> 2) & 3) + (lane_ >> 4);
-            if (s.slab < a.parts && scol < a.N && row < a.Ntot) {
-                const size_t off = (size_t)(a.step0 + n + 1) * a.Ntot * a.N + (size_t)scol * a.Ntot + row;
-                a.hist_r[off] = u;
-                a.hist_i[off] = -v;
+            if constexpr (NS == 2) {
+                hist(n, s.col, u.a, v.a);
+                if (actB) hist(n, s.col + 4, u.b, v.b);
+            } else {
+                hist(n, s.col, u, v);
             }
         }
     };
@@ -478,10 +548,23 @@ __global__ __launch_bounds__(64 * NT + 128) void k_forward_cq(PropArgs a)
     }
     if (n < a.nsteps_chunk) step(std::integral_constant<int, 0>{}, n);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    st[s.foff] = u;
-    st[(size_t)KT * 64 + s.foff] = v;
-    const double tot = cq_wg_sum(leak, scratch, wave, lane_, NT);
-    if (slot0) st[(size_t)(JQ_STATE_ARRAYS * KT + JQ_MAXNC) * 64 + cslot] = tot;
+    if constexpr (NS == 2) {
+        st[s.foff] = u.a;
+        st[(size_t)KT * 64 + s.foff] = v.a;
+        if (actB) {
+            st[s.foff + 4] = u.b;
+            st[(size_t)KT * 64 + s.foff + 4] = v.b;
+        }
+        const double totA = cq_wg_sum(leak.a, scratch, wave, lane_, NT);
+        const double totB = cq_wg_sum(leak.b, scratch, wave, lane_, NT);
+        if (slot0) st[lslot] = totA;
+        if (slot0 && actB) st[lslot + 4] = totB;
+    } else {
+        st[s.foff] = u;
+        st[(size_t)KT * 64 + s.foff] = v;
+        const double tot = cq_wg_sum(leak, scratch, wave, lane_, NT);
+        if (slot0) st[lslot] = tot;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -19,6 +19,8 @@ template __global__ void k_forward_cq<JQ_NT, false>(PropArgs);
 template __global__ void k_backward_cq<JQ_NT, false, false>(PropArgs);
 template __global__ void k_backward_cq<JQ_NT, false, true>(PropArgs);      // (control q acts on subsystem q only)
 template __global__ void k_forward_cq<JQ_NT, true>(PropArgs);      // (odd number of Neumann terms)
+template __global__ void k_forward_cq<JQ_NT, false, 2>(PropArgs);      // (two column quads per workgroup: 257 .. 512 quads)
+template __global__ void k_forward_cq<JQ_NT, true, 2>(PropArgs);
 template __global__ void k_backward_cq<JQ_NT, true, false>(PropArgs);
 template __global__ void k_backward_cq<JQ_NT, true, true>(PropArgs);
 #elif JQ_VARIANT == 10  // cooperative-quad kernels of the implicit-midpoint integrator (JQ_BW = 7, N = 4)

@@ -1520,19 +1520,22 @@ static int select_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
     extern template __global__ void k_backward<nt, JQ_BW_T4Q, 3, false, false, true, true>(PropArgs);
 JQ_DECLQ(1) JQ_DECLQ(2) JQ_DECLQ(3) JQ_DECLQ(4) JQ_DECLQ(5) JQ_DECLQ(6) JQ_DECLQ(7) JQ_DECLQ(8)
 #undef JQ_DECLQ
-template <int NT, bool MODD> __global__ void k_forward_cq(PropArgs);            // jq_cq_kernels.h (own translation units)
+template <int NT, bool MODD, int NS> __global__ void k_forward_cq(PropArgs);    // jq_cq_kernels.h (own translation units); NS: column quads per workgroup
 template <int NT, bool MODD, bool ORD> __global__ void k_backward_cq(PropArgs);
 #define JQ_DECLCQ(nt)                                                      \
-    extern template __global__ void k_forward_cq<nt, false>(PropArgs);     \
+    extern template __global__ void k_forward_cq<nt, false, 1>(PropArgs);  \
+    extern template __global__ void k_forward_cq<nt, false, 2>(PropArgs);  \
     extern template __global__ void k_backward_cq<nt, false, false>(PropArgs);    \
     extern template __global__ void k_backward_cq<nt, false, true>(PropArgs);     \
-    extern template __global__ void k_forward_cq<nt, true>(PropArgs);      \
+    extern template __global__ void k_forward_cq<nt, true, 1>(PropArgs);   \
+    extern template __global__ void k_forward_cq<nt, true, 2>(PropArgs);   \
     extern template __global__ void k_backward_cq<nt, true, false>(PropArgs);     \
     extern template __global__ void k_backward_cq<nt, true, true>(PropArgs);
 JQ_DECLCQ(1) JQ_DECLCQ(2) JQ_DECLCQ(3) JQ_DECLCQ(4) JQ_DECLCQ(5) JQ_DECLCQ(6) JQ_DECLCQ(7)
 #undef JQ_DECLCQ
 // (instantiated for even and odd numbers of Neumann terms: the parities of the LDS exchange are compile-time constants)
-static int select_cq_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
+// fwd2: the forward kernel with two column quads per workgroup (grid = 2 * nslabs)
+static int select_cq_kernels(jq_handle* h, bool fwd2, prop_kernel_t* fwd, prop_kernel_t* bwd)
 {
     const bool modd = (h->m > 0 ? h->m : 0) & 1;
     // control q acts on subsystem q only (the usual Juqbox set-up: Hsym_ops = [a + a', b + b', c + c']): its trace products need
@@ -1541,7 +1544,7 @@ static int select_cq_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bw
     for (int q = 0; q < h->Nc && ord; ++q) ord = (h->bw_trace[q] == (1 << q));
 #define JQ_PICKCQ(nt)                                                              \
     if (h->NT == nt) {                                                             \
-        *fwd = modd ? k_forward_cq<nt, true> : k_forward_cq<nt, false>;            \
+        *fwd = fwd2 ? (modd ? k_forward_cq<nt, true, 2> : k_forward_cq<nt, false, 2>) : (modd ? k_forward_cq<nt, true, 1> : k_forward_cq<nt, false, 1>);            \
         *bwd = modd ? (ord ? k_backward_cq<nt, true, true> : k_backward_cq<nt, true, false>)          \
                     : (ord ? k_backward_cq<nt, false, true> : k_backward_cq<nt, false, false>);       \
         return JQ_OK;                                                              \
@@ -2017,6 +2020,10 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     const char* e_icq = getenv("JQ_IMR_CQ");
     const bool imr_cq = imr_quad && h->N == 4 && h->parts == 1 && h->cq_max_quads > 0 && nquads_used <= h->cq_max_quads &&
                         !(e_icq && atoi(e_icq) == 0);
+    // more column quads than CUs: the forward sweep takes two quads per workgroup (one round of workgroups at ~ 1.5 x the time
+    // instead of two rounds; JQ_CQ_FWD2=0: one quad per workgroup, =1: always two)
+    const char* e_cf2 = getenv("JQ_CQ_FWD2");
+    const bool cq_fwd2 = cq && (e_cf2 ? atoi(e_cf2) != 0 : nquads_used > h->num_cu);
     const char* e_icq2 = getenv("JQ_IMR_CQ2");
     const bool imr_cq2 = imr_cq && h->NT <= 6 && !(e_icq2 && atoi(e_icq2) == 0) &&
                          cq_imr2_lds(h, (size_t)(2 * JQ_WIN_TPS + 2 * h->NcK) * h->mat_elems * 8) <= 163840;
@@ -2047,7 +2054,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
              : imr_rl ? select_rowlane_imr_kernels(h, rl_split, &kfwd, &kbwd)
              : rl ? select_rowlane_kernels(h, rl_split, &kfwd, &kbwd)
              : lane ? select_lane_kernels(h, &kfwd, &kbwd, &klinit, &klterm)
-                  : cq ? select_cq_kernels(h, &kfwd, &kbwd)
+                  : cq ? select_cq_kernels(h, cq_fwd2, &kfwd, &kbwd)
                   : coop ? select_coop_kernels(h, &kfwd, &kbwd) : quad ? (wfull ? select_quad_w_kernels(h, &kfwd, &kbwd) : select_quad_kernels(h, spw, &kfwd, &kbwd)) : select_kernels(h, &kfwd, &kbwd);
     if (rc) return rc;
     const int nblocks = imr_parts ? nsamples : (cq || imr_cq) ? 4 * nslabs : rl ? (int)nwaves_rl : lane ? (int)(ncols / 64) : quad8 ? (nslabs + spw - 1) / spw : (coop || quad) ? nslabs : (nslabs + JQ_WAVES - 1) / JQ_WAVES;
@@ -2229,7 +2236,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
             for (int i = 0; i < 7; ++i) sched_pack(a.sched_bits, i, kinds[i], tps[i]);
         }
         HIPCHK(h, hipEventRecord(h->ev[evi++], s));
-        hipLaunchKernelGGL(kfwd, dim3(nblocks), dim3(cq ? nthreads + 128 : imr_cq ? nthreads + 128 : nthreads), lds_fwd + (wlr_lds_fwd >= 0 ? wlr_bytes : 0), s, a);      // (cooperative quad: two staging waves)
+        hipLaunchKernelGGL(kfwd, dim3(cq_fwd2 ? nblocks / 2 : nblocks), dim3(cq ? nthreads + 128 : imr_cq ? nthreads + 128 : nthreads), lds_fwd + (wlr_lds_fwd >= 0 ? wlr_bytes : 0), s, a);      // (cooperative quad: two staging waves)
         HIPCHK(h, hipEventRecord(h->ev[evi++], s));
         mfma += (long long)nslabs * nc * (8 + 2 * h->m) * tiles;
     }

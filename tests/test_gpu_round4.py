@@ -239,3 +239,31 @@ def test_two_set_cooperative_quad_implicit_midpoint_kernel_is_the_one_set_kernel
     # (one chunk instead of four: the gradient's partial sums are grouped differently)
     assert abs(res["two"][0] - res["two_whole"][0]) <= 1e-13 * abs(res["two"][0])
     assert np.linalg.norm(res["two"][2] - res["two_whole"][2]) <= 1e-12 * np.linalg.norm(res["two"][2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nsamples", [2, 5, 300])
+def test_forward_cooperative_quad_kernel_with_two_quads_per_workgroup(jq, nsamples):
+    """Round 4: with more column quads than CUs the forward cooperative-quad kernel takes two quads per workgroup (k_forward_cq<.., 2>:
+    every array a pair of doubles per lane, the second quad in channel 1 of the exchange image).  Each quad sees the operations of
+    the one-quad kernel in the same order: bit-identical results, also with an odd number of quads (a half-empty last pair) and
+    several chunks; 300 samples take that kernel by themselves (more quads than CUs)."""
+    params, info = jq.cases.cnot3()
+    params.T, params.nsteps = params.T * 901 / params.nsteps, 901
+    pcof = np.array(json.load(open(os.path.join(ROOT, "tests", "golden", "cnot3.json")))["pcof0"])
+    nodes, weights, shift = jq.cases.cnot3_ensemble(nsamples)
+    res = {}
+    for tag, env in (("two", {"JQ_CQ_FWD2": "1", "JQ_CHUNK_STEPS": "250"}), ("one", {"JQ_CQ_FWD2": "0", "JQ_CHUNK_STEPS": "250"}), ("auto", {"JQ_CHUNK_STEPS": "250"})):
+        os.environ.update(env)
+        try:
+            wa = jq.Working_Arrays_HIP(params, pcof.size)
+            jq.eval_f_g_grad(pcof, params, wa, nodes, weights, True, shift=shift)
+            assert wa.last_timing()["kernel_family"] == 8
+            res[tag] = (params.last_infidelity, params.last_leak, params.last_infidelity_grad.copy())
+            wa.close()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    for tag in ("one", "auto"):
+        assert res["two"][0] == res[tag][0] and res["two"][1] == res[tag][1]
+        assert np.array_equal(res["two"][2], res[tag][2])
