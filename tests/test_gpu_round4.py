@@ -267,3 +267,33 @@ def test_forward_cooperative_quad_kernel_with_two_quads_per_workgroup(jq, nsampl
     for tag in ("one", "auto"):
         assert res["two"][0] == res[tag][0] and res["two"][1] == res[tag][1]
         assert np.array_equal(res["two"][2], res[tag][2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,nquad,K", [("swap02_rn", 13, 4), ("cnot2-leakieq", 7, 3)])
+def test_multi_handle_against_the_oracle_loop(jq, case, nquad, K):
+    """The K-sub-handle tests of round 3 compare the multi-device handle with the single handle (which the oracle pins elsewhere);
+    here the sharded evaluation itself -- ragged shards, host threads, packing, the host-order sum that stands in for the all-reduce in
+    the same-device mode -- is held against the oracle's loop over the samples (src/ipopt_interface.jl:38-65) at the 1e-10 of every
+    Stormer-Verlet comparison."""
+    from conftest import case_inputs
+    from oracle.oracle import Oracle
+    params, info, pcof, _ = case_inputs(case)
+    x, w = np.polynomial.legendre.leggauss(nquad)
+    nodes, weights = x * 0.5 * (2 * np.pi * 2e-2), w * 0.5
+    shift = params.shift_weights_reference() if params.Ntot <= 4 else 0.05 * np.arange(params.Ntot)
+    ref = Oracle(params).eval_f_g_grad(pcof, nodes, weights, shift)
+    os.environ["JQ_MULTI_SAME_DEVICE"] = "1"
+    try:
+        wam = jq.Working_Arrays_HIP(params, pcof.size, devices=K)
+        assert wam.num_devices == K
+        jq.eval_f_g_grad(pcof, params, wam, nodes, weights, True, shift=shift if params.Ntot > 4 else None)
+        wam.close()
+    finally:
+        os.environ.pop("JQ_MULTI_SAME_DEVICE", None)
+    gn = np.linalg.norm(ref["last_infidelity_grad"])
+    assert abs(params.last_infidelity - ref["last_infidelity"]) <= 1e-10 * abs(ref["last_infidelity"])
+    assert abs(params.last_leak - ref["last_leak"]) <= 1e-10 * abs(ref["last_leak"])
+    assert np.linalg.norm(params.last_infidelity_grad - ref["last_infidelity_grad"]) <= 1e-10 * gn
+    if params.objFuncType != 1:
+        assert np.linalg.norm(params.last_leak_grad - ref["last_leak_grad"]) <= 1e-10 * gn
