@@ -352,16 +352,32 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq_imr(PropArgs a)
 // LDS behind the tables: [set][2 parities][3 channels][NT + 2 blocks][64] exchange images (channel 2 of image b, parities 0 / 1:
 // su, sv of the super-steps with k & 1 == b), then the decisions [set][2 slots][2 parts].
 // NT <= 6 (2 (NT + 2) waves <= 16); the results differ from k_backward_cq_imr's in nothing (same operations per chain, same order).
-template <int NT>
+typedef int jq_int4 __attribute__((ext_vector_type(4)));
+template <int NT, int SET>
 struct CqImr2 : CqImr<NT> {
     typedef CqImr<NT> B;
     typedef typename B::Acc Acc;
     static constexpr int CHS = B::CHS, PAR = B::PAR;
-    volatile __attribute__((address_space(3))) int* flags_o;      // the other set's decisions
+    // decisions of the four reducer waves, [2 slots][2 sets][2 parts]: ONE 16-byte LDS read per round has both sets' (B::flags = my
+    // set's pair of slot 0, for the reducers' writes)
+    volatile __attribute__((address_space(3))) int* fl;
 
-    __device__ __forceinline__ int decided(volatile __attribute__((address_space(3))) int* f, int j) const
+    // km: my set's decision on its x_{j-2}, ko: the other set's
+    __device__ __forceinline__ void decisions(int j, int& km, int& ko) const
     {
-        const long long v = *(volatile __attribute__((address_space(3))) long long*)(f + 2 * (j & 1));
+        const jq_int4 v = *(volatile __attribute__((address_space(3))) jq_int4*)(fl + 4 * (j & 1));
+        const int s0 = v.x & v.y, s1 = v.z & v.w;
+        km = __builtin_amdgcn_readfirstlane(SET ? s1 : s0);
+        ko = __builtin_amdgcn_readfirstlane(SET ? s0 : s1);
+    }
+    __device__ __forceinline__ int decided_o(int j) const
+    {
+        const long long v = *(volatile __attribute__((address_space(3))) long long*)(fl + 4 * (j & 1) + 2 * (1 - SET));
+        return __builtin_amdgcn_readfirstlane((int)v & (int)(v >> 32));
+    }
+    __device__ __forceinline__ int decided_m(int j) const
+    {
+        const long long v = *(volatile __attribute__((address_space(3))) long long*)(fl + 4 * (j & 1) + 2 * SET);
         return __builtin_amdgcn_readfirstlane((int)v & (int)(v >> 32));
     }
     // a block wave of a set without work in this super-step (set 1 in the first, set 0 in the last): passes the other set's barriers
@@ -375,11 +391,15 @@ struct CqImr2 : CqImr<NT> {
         if (oact)
             for (int j = 3;; ++j) {
                 this->c->sync();
-                if (decided(flags_o, j)) break;
+                if (decided_o(j)) break;
             }
     }
     // CqImr::step next to a set that is active in this super-step (oact) or not.  getf(fu, fv): the forcing, available behind the
-    // first barrier; stage(): the window staging of this wave, behind the first barrier
+    // first barrier; stage(): the window staging of this wave, behind the first barrier.
+    // With four waves per SIMD a round is bound by the SIMD's issue rate: every instruction of the round loop counts (~ 1.3 % of the
+    // sweep each; both sets' decisions in one LDS read: 162 -> 157 ms).  (Measured and rejected: parities and decision slots as
+    // compile-time constants -- the step instantiated for both parities of its first publication, the loop written for six rounds:
+    // the address arithmetic disappears, but hipcc fills the six exits with copies of the iterate registers: 157 -> 160 ms.)
     template <bool STAGE, typename F, typename G>
     __device__ __forceinline__ void step2(bool oact, double& u, double& v, F getf, G stage)
     {
@@ -419,7 +439,8 @@ struct CqImr2 : CqImr<NT> {
             Acc t = this->own(rhs_u, rhs_v, xu, xv);
             this->c->sync();
             this->par ^= 1;
-            const int km = decided(this->flags, j), ko = decided(flags_o, j);      // the decisions on the two x_{j-2}
+            int km, ko;
+            decisions(j, km, ko);                      // on the two x_{j-2}
             ++j;
             if (ko) doth = true;
             this->nbr(t, po_);
@@ -444,7 +465,7 @@ struct CqImr2 : CqImr<NT> {
         if (!doth)
             for (;; ++j) {                             // the other set still iterates
                 this->c->sync();
-                if (decided(flags_o, j)) break;
+                if (decided_o(j)) break;
             }
     }
     // CqImr::reducer_step likewise
@@ -456,7 +477,7 @@ struct CqImr2 : CqImr<NT> {
         if (oact)
             for (int j = 3;; ++j) {
                 this->c->sync();
-                if (decided(flags_o, j)) break;
+                if (decided_o(j)) break;
             }
     }
     __device__ __forceinline__ void reducer2(bool oact, int part)
@@ -480,7 +501,7 @@ struct CqImr2 : CqImr<NT> {
                 prev[w] = cur;
             }
             const bool keep = (j - 1 >= this->max_iter) || (wave_sum(acc) < this->tol2);      // (a NaN never converges, as in the reference)
-            this->flags[2 * ((j - 1) & 1) + part] = keep ? 1 : 0;
+            fl[4 * ((j - 1) & 1) + 2 * SET + part] = keep ? 1 : 0;
         };
         {
             const int po = this->par * PAR + part * CHS;
@@ -495,7 +516,8 @@ struct CqImr2 : CqImr<NT> {
                 const int po = this->par * PAR + part * CHS;
                 this->c->sync();
                 this->par ^= 1;
-                const int km = decided(this->flags, j), ko = decided(flags_o, j);
+                int km, ko;
+                decisions(j, km, ko);
                 if (!km) decide(j, po);
                 if (km | ko) {
                     dme = km != 0, doth = ko != 0;
@@ -508,13 +530,13 @@ struct CqImr2 : CqImr<NT> {
                 const int po = this->par * PAR + part * CHS;
                 this->c->sync();
                 this->par ^= 1;
-                if (decided(this->flags, j)) break;
+                if (decided_m(j)) break;
                 decide(j, po);
             }
         } else if (!doth) {
             for (;; ++j) {
                 this->c->sync();
-                if (decided(flags_o, j)) break;
+                if (decided_o(j)) break;
             }
         }
     }
@@ -574,20 +596,31 @@ __global__ __launch_bounds__(128 * NT + 256) void k_backward_cq_imr2(PropArgs a)
     asm volatile("" ::: "memory");
     r.wave = wave, r.nwaves = NT;      // (from here on the block waves of set 0 stage)
     double* st = a.state + (size_t)s.slab * a.state_stride;
-    CqImr2<NT> m;
-    m.c = &c;
-    m.x0 = (jq_lds_double*)(xbuf + set * 2 * PAR + lane_);
-    m.cw = 0.0;
-    m.cwa = (a.use_shift && (lane_ >> 4) == (lane_ & 3))
-                ? 0.5 * a.h * a.colinfo[(size_t)s.slab * 32 + s.col] * tab[16 * NT + 16 * wave + 4 * (lane_ & 3) + ((lane_ >> 2) & 3)] : 0.0;
-    m.tol2 = a.jacobi_tol2, m.max_iter = a.m, m.par = 0, m.use_shift = a.use_shift;
-    m.flags = (volatile __attribute__((address_space(3))) int*)(xbuf + 4 * PAR) + 4 * set;
-    m.flags_o = (volatile __attribute__((address_space(3))) int*)(xbuf + 4 * PAR) + 4 * (1 - set);
+    auto init = [&](auto& m) {
+        m.c = &c;
+        m.x0 = (jq_lds_double*)(xbuf + set * 2 * PAR + lane_);
+        m.cw = 0.0;
+        m.cwa = (a.use_shift && (lane_ >> 4) == (lane_ & 3))
+                    ? 0.5 * a.h * a.colinfo[(size_t)s.slab * 32 + s.col] * tab[16 * NT + 16 * wave + 4 * (lane_ & 3) + ((lane_ >> 2) & 3)] : 0.0;
+        m.tol2 = a.jacobi_tol2, m.max_iter = a.m, m.par = 0, m.use_shift = a.use_shift;
+        m.fl = (volatile __attribute__((address_space(3))) int*)(xbuf + 4 * PAR);
+        m.flags = m.fl + 2 * set;
+    };
     if (reducer) {
-        for (int k = 0; k <= n; ++k) {
-            const bool act = set == 0 ? k < n : k >= 1, oact = set == 0 ? k >= 1 : k < n;
-            if (act) m.reducer2(oact, wv - NT);
-            else m.reducer_idle2(oact);
+        if (set == 0) {
+            CqImr2<NT, 0> m;
+            init(m);
+            for (int k = 0; k <= n; ++k) {
+                if (k < n) m.reducer2(k >= 1, wv - NT);
+                else m.reducer_idle2(true);
+            }
+        } else {
+            CqImr2<NT, 1> m;
+            init(m);
+            for (int k = 0; k <= n; ++k) {
+                if (k >= 1) m.reducer2(k < n, wv - NT);
+                else m.reducer_idle2(true);
+            }
         }
         return;
     }
@@ -595,6 +628,8 @@ __global__ __launch_bounds__(128 * NT + 256) void k_backward_cq_imr2(PropArgs a)
     jq_lds_double* hb = (jq_lds_double*)(xbuf + wave * 64 + lane_);
     unsigned cur = 0;      // byte offset of the ring slot of step k
     if (set == 0) {
+        CqImr2<NT, 0> m;
+        init(m);
         double u = st[s.foff], v = st[(size_t)KT * 64 + s.foff];
         for (int k = 0; k < n; ++k) {
             m.K = c.load((const double*)(smem + cur) + lane_);
@@ -613,6 +648,8 @@ __global__ __launch_bounds__(128 * NT + 256) void k_backward_cq_imr2(PropArgs a)
         st[(size_t)KT * 64 + s.foff] = v;
         return;
     }
+    CqImr2<NT, 1> m;
+    init(m);
     double lr = st[(size_t)2 * KT * 64 + s.foff], li = st[(size_t)3 * KT * 64 + s.foff];
     const double wgt = a.colinfo[(size_t)s.slab * 32 + 16 + s.col];
     const double cfw = a.forced ? -a.h * a.tinv * tab[16 * wave + s.g] : 0.0;      // h * (-tinv * W): W applied row-wise
