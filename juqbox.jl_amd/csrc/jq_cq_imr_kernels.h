@@ -165,16 +165,19 @@ struct CqImr {
                 const long long f = *(volatile __attribute__((address_space(3))) long long*)(flags + 2 * (j & 1));
                 if (__builtin_amdgcn_readfirstlane((int)f & (int)(f >> 32))) return;
             }
-            double acc = 0.0;
+            double acc = 0.0, acc1 = 0.0;      // (two chains: the reducer's round trip is on the critical path of the forward sweep)
 #pragma unroll
             for (int w = 0; w < NT; ++w) {
                 const double cur = x0[po + (w + 1) * 64];
                 const double d = prev[w] - cur;
-                acc = fma(d, d, acc);
+                if (w & 1) acc1 = fma(d, d, acc1);
+                else acc = fma(d, d, acc);
                 prev[w] = cur;
             }
-            const bool keep = (j - 1 >= max_iter) || (wave_sum(acc) < tol2);      // (a NaN never converges, as in the reference)
-            flags[2 * ((j - 1) & 1) + part] = keep ? 1 : 0;
+            acc += acc1;
+            // (the sum is valid in the lanes 48 .. 63: they write the decision, the others a dummy word behind the decisions)
+            const bool keep = (j - 1 >= max_iter) || (wave_sum_hi(acc) < tol2);      // (a NaN never converges, as in the reference)
+            flags[((c->lane >= 48) ? 0 : 4) + 2 * ((j - 1) & 1) + part] = keep ? 1 : 0;
         }
     }
 };
@@ -492,16 +495,19 @@ struct CqImr2 : CqImr<NT> {
         }
         // behind barrier j: the decision on x_{j-1} from the published x_j
         auto decide = [&](int j, int po) {
-            double acc = 0.0;
+            double acc = 0.0, acc1 = 0.0;
 #pragma unroll
             for (int w = 0; w < NT; ++w) {
                 const double cur = this->x0[po + (w + 1) * 64];
                 const double d = prev[w] - cur;
-                acc = fma(d, d, acc);
+                if (w & 1) acc1 = fma(d, d, acc1);
+                else acc = fma(d, d, acc);
                 prev[w] = cur;
             }
-            const bool keep = (j - 1 >= this->max_iter) || (wave_sum(acc) < this->tol2);      // (a NaN never converges, as in the reference)
-            fl[4 * ((j - 1) & 1) + 2 * SET + part] = keep ? 1 : 0;
+            acc += acc1;
+            // (the sum is valid in the lanes 48 .. 63: they write the decision, the others a dummy word behind the decisions)
+            const bool keep = (j - 1 >= this->max_iter) || (wave_sum_hi(acc) < this->tol2);      // (a NaN never converges, as in the reference)
+            fl[((this->c->lane >= 48) ? 0 : 8) + 4 * ((j - 1) & 1) + 2 * SET + part] = keep ? 1 : 0;
         };
         {
             const int po = this->par * PAR + part * CHS;
