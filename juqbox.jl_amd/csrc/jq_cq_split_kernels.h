@@ -1,0 +1,450 @@
+// jq_cq_split_kernels.h -- the backward sweep of the cooperative-quad kernels (jq_cq_kernels.h) on THREE workgroups per column quad:
+// the latency path of the JQ_BW_T4 structure for single evaluations and small ensembles (3 x quads <= CUs).
+//
+// k_backward_cq runs the state re-integration and the adjoint step on two sets of NT waves of ONE workgroup: both sets pass the same
+// 5 + 2 m barriers per time step, and with three waves per SIMD a publication interval is bound by the SIMD's issue rate (340 .. 405
+// cycles per Neumann publication against 232 in the forward sweep, two waves per SIMD).  Measured (round 4, state waves idling at the
+// barriers): the adjoint chain alone takes 92 ms of the 119 ms per cnot3 evaluation -- 21 ms of them in the trace products -- and
+// the state chain alone is the forward sweep (71 ms).  But the coupling between the chains is ONE-WAY and per block: the adjoint step
+// of time step n needs vr(t_n+1), vi05, vr(t_n) of the wave's own 16-row block only (its forcing), and the trace products of
+// adjoint_grad_calc! need those three and X, -lambda_i(new), -(li0 + li) with their neighbouring blocks.  So the three jobs run as a
+// software pipeline over three workgroups on three CUs:
+//   role 0  state re-integration  (the state path of k_backward_cq minus its trace products): stores u, v05, un of every step
+//   role 1  adjoint step          (the adjoint path minus its trace products), >= 1 step behind: loads u, v05, un; stores X, nbn, Bq
+//   role 2  trace products        (no publications, no LDS exchange), behind role 1: loads the six arrays with their neighbouring
+//                                 blocks, forms the 5 Ncoupled scalars of the step and writes the trace record
+// through a ring of JQ_CQ3_SLOTS time steps in global memory, [slot][array][block][64] doubles per quad, with three progress counters
+// (steps finished by role 0 / 1 / 2).  Role r + 1 waits for role r's counter; role 0 waits for role 2's before it reuses a slot.
+// Everything a role stores in a step is complete before the last barrier of that step (s_waitcnt vmcnt(0) in front of it: the
+// stores are acknowledged by the L2), the counter is written behind it; the consumers read counters and data with agent-scope loads
+// (past their CU's vector cache).  The three workgroups of a quad have block indices 24 i + j, + 8, + 16 (j < 8): workgroups are
+// handed to the eight XCDs round-robin, so the three share one XCD and its L2 -- no cache maintenance between them.  Each role checks
+// that (XCC_ID register) and that no wait exceeds ~ 1 s; otherwise it raises the error word of the quad and every wait of the quad
+// is abandoned: the launch ends with garbage, the host falls back to k_backward_cq and disables the split for the handle.
+// The arithmetic of every chain and of the trace sums is k_backward_cq's, operation for operation: bit-identical results.
+#pragma once
+#include "jq_cq_kernels.h"
+
+#define JQ_CQ3_SLOTS 8        // ring depth in time steps
+#define JQ_CQ3_ARRAYS 6       // u (vr before the state step), v05, un, X, nbn (-lambda_i new), Bq (-(li0 + li))
+#define JQ_CQ3_HEAD 64        // doubles in front of a quad's ring: [0] steps of role 0, [8] role 1, [16] role 2, [24] error, [32 + r] XCC of role r
+#define JQ_CQ3_SPIN 4000000   // polls (with s_sleep) before a wait is declared dead
+
+template <int NT>
+struct Cq3Hand {
+    double* ring;                     // this lane's element of block 0, array 0, slot 0
+    unsigned long long *head, *gerr;
+    bool dead;                        // (wave-uniform) a wait of this quad timed out, or the workgroups do not share an XCD
+    static constexpr size_t SLOT = (size_t)JQ_CQ3_ARRAYS * NT * 64;
+
+    __device__ __forceinline__ void init(const PropArgs& a, size_t quad, int lane_)
+    {
+        double* base = a.park + JQ_CQ3_HEAD + quad * ((size_t)JQ_CQ3_HEAD + JQ_CQ3_SLOTS * SLOT);      // (a.park[0]: the error word of the launch)
+        head = (unsigned long long*)base;
+        gerr = (unsigned long long*)a.park;
+        ring = base + JQ_CQ3_HEAD + lane_;
+        dead = false;
+    }
+    __device__ __forceinline__ size_t off(int step, int arr, int blk) const { return ((size_t)(step & (JQ_CQ3_SLOTS - 1)) * JQ_CQ3_ARRAYS + arr) * NT * 64 + (size_t)blk * 64; }
+    // (agent scope: a plain store may rest in the CU's vector cache for a while -- its vmcnt acknowledgement does not mean "in the L2")
+    __device__ __forceinline__ void store(int step, int arr, int blk, double x) const
+    {
+        __hip_atomic_store(ring + off(step, arr, blk), x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // (agent scope: the slot was read JQ_CQ3_SLOTS steps ago -- a line of it may still sit in this CU's vector cache)
+    __device__ __forceinline__ double load(int step, int arr, int blk) const
+    {
+        return __hip_atomic_load(ring + off(step, arr, blk), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __device__ __forceinline__ void publish(int role, unsigned long long steps) const
+    {
+        __hip_atomic_store(head + 8 * role, steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // wait until role `role` has finished `steps` steps (call on ONE wave; the others meet it at the next workgroup barrier)
+    __device__ __forceinline__ void wait(int role, unsigned long long steps)
+    {
+        if (dead) return;
+        for (int k = 0; k < JQ_CQ3_SPIN; ++k) {
+            if (__hip_atomic_load(head + 8 * role, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= steps) return;
+            if (__hip_atomic_load(head + 24, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        __hip_atomic_store(head + 24, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(gerr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        dead = true;
+    }
+};
+
+// grid = 24 * ceil(quads / 8), block = 64 * (NT + 2): workgroup b has role (b / 8) % 3 of quad 8 (b / 24) + b % 8 (slab = quad / 4);
+// roles 0 and 1: NT block waves and two staging waves (as k_forward_cq), role 2: NT block waves (the other two leave).
+// a.park: the hand-off buffer (zeroed by the host before every launch).  Dynamic LDS as k_backward_cq.
+template <int NT, bool MODD, bool ORD>
+__global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KT = 4 * NT;
+    constexpr int M = MODD ? 1 : 0;
+    typedef typename CoopQ<NT>::Sh Sh;
+    typedef typename CoopQ<NT>::Nb Nb;
+    typedef typename CoopQ<NT>::Op Op;
+    const int role = ((int)blockIdx.x >> 3) % 3;
+    const int quad = 8 * ((int)blockIdx.x / 24) + ((int)blockIdx.x & 7);
+    const CqSetup<NT> s = cq_setup<NT>(a, quad >> 2, quad & 3);
+    const int Nc = a.Ncoupled;
+    const size_t trow = (size_t)s.slab * a.qps + s.qd;
+    if (s.slab >= a.nslabs) return;
+    if (!s.active) {
+        if (role == 2 && s.qd < a.qps)
+            for (int k = threadIdx.x; k < a.nsteps_chunk * Nc * JQ_NTR; k += blockDim.x) a.traces[trow * a.nsteps_chunk * Nc * JQ_NTR + k] = 0.0;
+        return;
+    }
+    const int lane_ = s.lane_, wave = s.wave;      // (s.chain: the two staging waves)
+    double* tab = (double*)(smem + a.lds_tab_off);
+    for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[(i & ~15) + 4 * (i & 3) + ((i >> 2) & 3)] = a.tabs[i];   // [block][g][r]
+    if (role == 2 && s.chain) return;      // (the trace workgroup has no staging waves)
+    CoopQ<NT> c;
+    double* scratch = tab + 32 * NT + 2 * CoopQ<NT>::PAR;      // [NT][64] workgroup sums / [ngroups][NT][64] trace hand-off (role 2)
+    Cq3Hand<NT> hd;
+    hd.init(a, (size_t)quad, lane_);
+    const int nst = a.nsteps_chunk;
+    // the three workgroups must share an L2: XCC_ID (hardware register 20, bits 3:0) of every role goes into the header, role 2 compares
+    {
+        const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11));
+        if (threadIdx.x == 0) __hip_atomic_store(hd.head + 32 + role, (unsigned long long)xcc + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    double* st = a.state + (size_t)s.slab * a.state_stride;
+    const double wgt = a.colinfo[(size_t)s.slab * 32 + 16 + s.col];
+    const size_t cslot = 16 * (lane_ >> 4) + s.col;
+
+    if (role == 2) {
+        // ---- trace products (adjoint_grad_calc!, src/evalobjgrad.jl:2581-2618), per control q -- the sums of k_backward_cq:
+        //   group q < Nc:  rows 0, 1, 2 = t1, t4, t3     group Nc + j:  rows 0, 1 = t2, t5 of control 2 j, rows 2, 3 = of control 2 j + 1
+        c.mt = wave, c.lane = lane_;
+        c.xb = nullptr;
+        WinRing& r = c.ring;      // (only the constant images are staged)
+        r.smem = smem, r.wave = wave, r.lane = lane_, r.nwaves = NT;
+        r.stride_b = (unsigned)(a.stride * 8), r.slot_bytes = 2 * r.stride_b, r.cbase = JQ_WIN_TPS * r.slot_bytes, r.pieces2 = 2 * a.pieces;
+        r.dma((const char*)a.cimg, smem + r.cbase, 2 * a.Ncoupled * a.pieces);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int ntr = Nc * JQ_NTR, ngroups = Nc + (Nc + 1) / 2;
+        // hand-off of the column partials, [step parity][ngroups][NT][64] (one barrier per step here: the waves that finish step k - 1
+        // read while the others already write step k) and the scratch of cq_wg_sum: in the ring area of the window staging (unused)
+        double* red = (double*)smem;
+        const size_t redsz = (size_t)ngroups * NT * 64;
+        scratch = red + 2 * redsz;
+        auto finish_traces = [&](int k) {
+            for (int g = wave; g < ngroups; g += NT) {
+                const double* rr = red + (size_t)(k & 1) * redsz + (size_t)g * NT * 64 + lane_;
+                double sum = rr[0];
+#pragma unroll
+                for (int w = 1; w < NT; ++w) sum += rr[w * 64];
+                sum = row_ror_add<8>(sum);
+                sum = row_ror_add<4>(sum);
+                sum = row_ror_add<2>(sum);
+                sum = row_ror_add<1>(sum);
+                const int row = lane_ >> 4;
+                int q, kk;
+                if (g < Nc)
+                    q = g, kk = row == 0 ? 0 : row == 1 ? 3 : row == 2 ? 2 : -1;
+                else
+                    q = 2 * (g - Nc) + (row >> 1), kk = (row & 1) ? 4 : 1;
+                if ((lane_ & 15) == 0 && kk >= 0 && q < Nc) a.traces[(trow * a.nsteps_chunk + k) * ntr + q * JQ_NTR + kk] = sum;
+            }
+        };
+        double carry[JQ_MAXNC];
+        const bool slot0 = wave == 0 && ((lane_ >> 2) & 3) == 0;
+#pragma unroll
+        for (int q = 0; q < JQ_MAXNC; ++q) carry[q] = (q < Nc && slot0) ? st[(size_t)(JQ_STATE_ARRAYS * KT + q) * 64 + cslot] : 0.0;
+        if (a.first_chunk) {
+            // carry_q = tr(vr' Hsym_q lambdai) at t = T (see k_backward): vr(T) and -lambda_i(T) from the state file
+            const double u0 = st[s.foff], nb0 = st[(size_t)3 * KT * 64 + s.foff];
+            Nb nn;
+            nn.b = wave > 0 ? st[(size_t)3 * KT * 64 + s.foff - 256] : 0.0;
+            nn.a = wave + 1 < NT ? st[(size_t)3 * KT * 64 + s.foff + 256] : 0.0;
+            const Sh sx = c.sh(nb0);
+#pragma unroll
+            for (int q = 0; q < JQ_MAXNC; ++q)
+                if (q < Nc) carry[q] = -(u0 * c.template trace_mm<ORD>(c.ring.cimg(q), q, sx, nn));
+        }
+        // the six arrays of a step with the neighbouring blocks of X, nbn, Bq (zeros beyond the edge blocks)
+        struct Rec {
+            double u, v05, un, X, nbn, Bq;
+            Nb nX, nN, nB;
+        };
+        auto fetch = [&](int n) {
+            Rec e;
+            e.u = hd.load(n, 0, wave), e.v05 = hd.load(n, 1, wave), e.un = hd.load(n, 2, wave);
+            e.X = hd.load(n, 3, wave), e.nbn = hd.load(n, 4, wave), e.Bq = hd.load(n, 5, wave);
+            const int wb = wave > 0 ? wave - 1 : wave, wa_ = wave + 1 < NT ? wave + 1 : wave;
+            e.nX.b = hd.load(n, 3, wb), e.nX.a = hd.load(n, 3, wa_);
+            e.nN.b = hd.load(n, 4, wb), e.nN.a = hd.load(n, 4, wa_);
+            e.nB.b = hd.load(n, 5, wb), e.nB.a = hd.load(n, 5, wa_);
+            if (wave == 0) e.nX.b = 0.0, e.nN.b = 0.0, e.nB.b = 0.0;
+            if (wave + 1 == NT) e.nX.a = 0.0, e.nN.a = 0.0, e.nB.a = 0.0;
+            return e;
+        };
+        if (wave == 0) hd.wait(1, 1);
+        __syncthreads();
+        Rec cur = fetch(0);
+        for (int n = 0; n < nst; ++n) {
+            // (role 1 is asked for one step more than needed: the loads of step n + 1 travel while step n is worked on)
+            if (wave == 0) hd.wait(1, (unsigned long long)(n + 2 < nst ? n + 2 : nst));
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (cur has landed; my record of step n - 1 is written)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (wave == 0 && lane_ == 0) hd.publish(2, (unsigned long long)(n + 1));      // (everybody's loads of the steps <= n have landed)
+            if (n > 0) finish_traces(n - 1);
+            Rec nxt = cur;
+            if (n + 1 < nst) nxt = fetch(n + 1);
+            double* redw = red + (size_t)(n & 1) * redsz + (size_t)wave * 64 + lane_;
+            const double v05w = cur.v05 * wgt, uw = cur.u * wgt, unw = cur.un * wgt;
+            const Sh sX = c.sh(cur.X), sN = c.sh(cur.nbn), sB = c.sh(cur.Bq);
+            double t2[JQ_MAXNC], t5[JQ_MAXNC];
+#pragma unroll
+            for (int q = 0; q < JQ_MAXNC; ++q) {
+                t2[q] = 0.0, t5[q] = 0.0;
+                if (q < Nc) {
+                    t2[q] = v05w * c.template trace_mm<ORD>(c.ring.cimg(q), q, sX, cur.nX);
+                    t5[q] = -(v05w * c.template trace_mm<ORD>(c.ring.cimg(Nc + q), q, sB, cur.nB));
+                    const double Tq = c.template trace_mm<ORD>(c.ring.cimg(Nc + q), q, sX, cur.nX);
+                    const double pq = -(cur.un * c.template trace_mm<ORD>(c.ring.cimg(q), q, sN, cur.nN));
+                    const double t4 = (pq + carry[q]) * wgt;
+                    carry[q] = pq;
+                    redw[(size_t)q * NT * 64] = cq_part4(uw * Tq, unw * Tq, t4, 0.0);      // rows 0, 2, 1: t1, t3, t4
+                }
+            }
+            redw[(size_t)Nc * NT * 64] = cq_part4(t2[0], t2[1], t5[0], t5[1]);
+            if (Nc > 2) redw[(size_t)(Nc + 1) * NT * 64] = cq_part4(t2[2], t2[3], t5[2], t5[3]);
+            cur = nxt;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (wave == 0 && lane_ == 0) hd.publish(2, (unsigned long long)nst);
+        finish_traces(nst - 1);
+        // the three roles ran on one XCD?  (headers: XCC + 1 of every role; 0: a role that never started cannot be the case here)
+        if (threadIdx.x == 0) {
+            const unsigned long long x0 = __hip_atomic_load(hd.head + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long x1 = __hip_atomic_load(hd.head + 33, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long x2 = __hip_atomic_load(hd.head + 34, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (x0 != x2 || x1 != x2) __hip_atomic_store(hd.gerr, 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int q = 0; q < JQ_MAXNC; ++q)
+            if (q < Nc) {
+                const double tot = cq_wg_sum(carry[q], scratch, wave, lane_, NT);
+                if (wave == 0 && ((lane_ >> 2) & 3) == 0) st[(size_t)(JQ_STATE_ARRAYS * KT + q) * 64 + cslot] = tot;
+            }
+        return;
+    }
+
+    // ---- roles 0 and 1: a chain of publications as in k_forward_cq (NT block waves, two staging waves) --------------------------------
+    c.setup(tab + 32 * NT, s.chain ? 0 : wave, lane_);
+    c.ring.init(smem, a, wave + NT * s.chain, lane_, NT + 2);      // (barrier inside)
+    if (s.chain) {      // staging waves
+        c.ring.wave = wave, c.ring.nwaves = 2;
+        const int nb = 4 + 2 * (a.m > 0 ? a.m : 0);
+        for (int n = 0; n < nst; ++n) {
+            for (int k = 0; k < nb; ++k) __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (my pieces of the time points 2n+3, 2n+4)
+            __builtin_amdgcn_s_barrier();
+            c.ring.issue_next();
+            c.ring.issue_next();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+    // (the tables are complete behind the barrier of ring.init)
+    const double wdr = tab[16 * wave + s.g], wsr = tab[16 * NT + 16 * wave + s.g];
+    const double cw = 0.5 * a.h * a.colinfo[(size_t)s.slab * 32 + s.col] * wsr;      // h/2 eps ws[row]
+    if (role == 0) {
+        // ---- state re-integration (src/evalobjgrad.jl:879): the state path of k_backward_cq; u, v05, un of step n -> ring
+        double u = st[s.foff], v = st[(size_t)KT * 64 + s.foff];
+        Op Kp05 = c.load(c.ring.template ks<0, 1>()), S0 = c.load(c.ring.template ks<1, 0>());
+        auto step = [&](auto P0c, int n) {
+            constexpr int P0 = decltype(P0c)::value;
+            // (a slot is reused when the trace workgroup has read it)
+            if (wave == 0 && n >= JQ_CQ3_SLOTS) hd.wait(2, (unsigned long long)(n - JQ_CQ3_SLOTS + 1));
+            double un, v05, vN;
+            // x = u: A = c K05 u ; P = u + c S0 u
+            c.template post<P0, 0>(u);
+            const Op S05 = c.load(c.ring.template ks<1, 1>());
+            double A, P;
+            {
+                const Sh sx = c.sh(u);
+                A = c.own(0.0, Kp05, sx);
+                P = c.own(u, S0, sx);
+                if (a.use_shift) A = fma(cw, u, A);
+                c.sync();
+                const Nb nn = c.template nbs<P0, 0>();
+                A = c.nbr(A, Kp05, nn);
+                P = c.nbr(P, S0, nn);
+            }
+            hd.store(n, 0, wave, u);      // (behind the barrier: wave 0 has seen the slot free)
+            // x = v: A = c (K05 u + S05 v) ; v05 = v + sum_j S^j A
+            c.template post<P0 ^ 1, 0>(v);
+            A = c.own(A, S05, c.sh(v));
+            c.sync();
+            A = c.nbr(A, S05, c.template nbs<P0 ^ 1, 0>());
+            Op Kn0, Kn1;
+            v05 = c.template horner<P0, 0, MODD>(v + A, A, S05, a.m, [&] {
+                Kn0 = c.load(c.ring.template ks<0, 0>());
+                Kn1 = c.load(c.ring.template ks<0, 2>());
+            });
+            hd.store(n, 1, wave, v05);
+            // x = v05: vN = v05 + c S05 v05 ; un = u + c (S0 u - K0 v05) ; A = -c K1 v05
+            c.template post<P0 ^ M, 0>(v05);
+            const Op S1 = c.load(c.ring.template ks<1, 2>());
+            {
+                const Sh sx = c.sh(v05);
+                vN = c.own(v05, S05, sx);
+                un = c.own(P, Kn0, sx);
+                A = c.own(0.0, Kn1, sx);
+                if (a.use_shift) {
+                    un = fma(-cw, v05, un);
+                    A = fma(-cw, v05, A);
+                }
+                c.sync();
+                const Nb nn = c.template nbs<P0 ^ M, 0>();
+                vN = c.nbr(vN, S05, nn);
+                un = c.nbr(un, Kn0, nn);
+                A = c.nbr(A, Kn1, nn);
+            }
+            // x = un: A = c (S1 un - K1 v05)
+            c.template post<P0 ^ M ^ 1, 0>(un);
+            A = c.own(A, S1, c.sh(un));
+            c.sync();
+            A = c.nbr(A, S1, c.template nbs<P0 ^ M ^ 1, 0>());
+            un = c.template horner<P0 ^ M, 0, MODD>(un + A, A, S1, a.m, [&] { Kp05 = c.load(c.ring.template ks<0, 1>()); });
+            hd.store(n, 2, wave, un);
+            // x = un: v(t_n) = v05 + c (K05 un + S05 v05)
+            c.template post<P0, 0>(un);
+            v = c.own(vN, Kp05, c.sh(un));
+            if (a.use_shift) v = fma(cw, un, v);
+            c.template sync<true>();      // (vmcnt(0): the three stores of the step are in the L2)
+            if (wave == 0 && lane_ == 0) hd.publish(0, (unsigned long long)(n + 1));
+            v = c.nbr(v, Kp05, c.template nbs<P0, 0>());
+            // (the time points of the next step have landed; those of this step are dead)
+            c.ring.advance();
+            Kp05 = c.load(c.ring.template ks<0, 1>());
+            S0 = c.load(c.ring.template ks<1, 0>());
+            u = un;
+        };
+        int n = 0;
+        for (; n + 1 < nst; n += 2) {
+            step(std::integral_constant<int, 0>{}, n);
+            step(std::integral_constant<int, 1>{}, n + 1);
+        }
+        if (n < nst) step(std::integral_constant<int, 0>{}, n);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st[s.foff] = u;
+        st[(size_t)KT * 64 + s.foff] = v;
+        return;
+    }
+    // ---- adjoint step! with forcing (src/StormerVerlet.jl:255-303): the adjoint path of k_backward_cq; u, v05, un of step n from the
+    //      ring (fetched one step ahead), X, nbn, Bq of step n -> ring
+    double mu = st[(size_t)2 * KT * 64 + s.foff], nb = st[(size_t)3 * KT * 64 + s.foff];
+    Op Kp05 = c.load(c.ring.template ks<0, 1>()), S05 = c.load(c.ring.template ks<1, 1>());
+    const double cfw = (a.forced ? 0.5 * a.h * a.tinv : 0.0) * wdr;      // forcing weight c tinv wd[row]; 0 for step_no_forcing!
+    double hu = 0.0, hv = 0.0, hn = 0.0;      // u, v05, un of the step (fetched one step ahead)
+    auto step = [&](auto P0c, int n) {
+        constexpr int P0 = decltype(P0c)::value;
+        if (wave == 0) hd.wait(0, (unsigned long long)(n + 2 < nst ? n + 2 : nst));
+        // x = nb (-lambda_i): L = c K05 nb, Tn = c S05 nb (for the second half of the step)
+        c.template post<P0, 1>(nb);
+        const Op S0 = c.load(c.ring.template ks<1, 0>());
+        double L, Tn;
+        {
+            const Sh sx = c.sh(nb);
+            L = c.own(0.0, Kp05, sx);
+            Tn = c.own(0.0, S05, sx);
+            if (a.use_shift) L = fma(cw, nb, L);
+            c.sync();      // (behind it everybody knows that role 0 has finished the steps <= n + 1)
+            const Nb nn = c.template nbs<P0, 1>();
+            L = c.nbr(L, Kp05, nn);
+            Tn = c.nbr(Tn, S05, nn);
+        }
+        if (n == 0) hu = hd.load(0, 0, wave), hv = hd.load(0, 1, wave), hn = hd.load(0, 2, wave);      // (first step of the chunk: latency exposed once)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (hu, hv, hn of this step have landed)
+        const double u = hu, v05 = hv, un = hn;      // vr before the state step (:862), vi05, vr after it
+        if (n + 1 < nst) hu = hd.load(n + 1, 0, wave), hv = hd.load(n + 1, 1, wave), hn = hd.load(n + 1, 2, wave);
+        // x = mu: L = c (S0 mu - K05 li + hr0) ; X = mu + sum_j S0^j L
+        c.template post<P0 ^ 1, 1>(mu);
+        L = c.own(L, S0, c.sh(mu));
+        L = fma(cfw, u, L);
+        c.sync();
+        L = c.nbr(L, S0, c.template nbs<P0 ^ 1, 1>());
+        Op Kn0, Kn1, S1;
+        const double X = c.template horner<P0, 1, MODD>(mu + L, L, S0, a.m, [&] {
+            Kn0 = c.load(c.ring.template ks<0, 0>());
+            Kn1 = c.load(c.ring.template ks<0, 2>());
+            S1 = c.load(c.ring.template ks<1, 2>());
+        });
+        hd.store(n, 3, wave, X);
+        // x = X: Lk = -c K0 X, Q = -c K1 X, SX = c S1 X
+        c.template post<P0 ^ M, 1>(X);
+        double Lk, Q, SX;
+        {
+            const Sh sx = c.sh(X);
+            Lk = c.own(0.0, Kn0, sx);
+            Q = c.own(0.0, Kn1, sx);
+            SX = c.own(0.0, S1, sx);
+            if (a.use_shift) {
+                Lk = fma(-cw, X, Lk);
+                Q = fma(-cw, X, Q);
+            }
+            c.sync();
+            const Nb nn = c.template nbs<P0 ^ M, 1>();
+            Lk = c.nbr(Lk, Kn0, nn);
+            Q = c.nbr(Q, Kn1, nn);
+            SX = c.nbr(SX, S1, nn);
+        }
+        // Lk = -c l2 = -c (K0 X + S05 li + hi0) ; Q = -c (S05 (li + c l2) + K1 X + hi1)
+        {
+            const double Pn = fma(-cfw, v05, Tn);
+            Lk += Pn;
+            Q += Pn;
+        }
+        // x = Lk: Q += c S05 Lk ; nb_new = nb + Lk + sum_j S05^j Q
+        c.template post<P0 ^ M ^ 1, 1>(Lk);
+        Q = c.own(Q, S05, c.sh(Lk));
+        c.sync();
+        Q = c.nbr(Q, S05, c.template nbs<P0 ^ M ^ 1, 1>());
+        const double nbn = c.template horner<P0 ^ M, 1, MODD>((nb + Lk) + Q, Q, S05, a.m);
+        const double Bq = nb + nbn;      // -(li0 + li)
+        hd.store(n, 4, wave, nbn);
+        hd.store(n, 5, wave, Bq);
+        // x = nb_new: lambda_r_new = X + c (S1 X - K05 li_new + hr1)
+        c.template post<P0, 1>(nbn);
+        double G;
+        {
+            const Sh sx = c.sh(nbn);
+            G = c.own(X, Kp05, sx);
+            if (a.use_shift) G = fma(cw, nbn, G);
+            G += SX;
+            // (vmcnt(0): the three stores of the step are in the L2 -- and the loads of the next step's u, v05, un have landed)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            c.sync();
+            if (wave == 0 && lane_ == 0) hd.publish(1, (unsigned long long)(n + 1));
+            const Nb nn = c.template nbs<P0, 1>();
+            G = c.nbr(G, Kp05, nn);
+            G = fma(cfw, un, G);
+            // (the time points of the next step have landed)
+            c.ring.advance();
+            Kp05 = c.load(c.ring.template ks<0, 1>());
+            S05 = c.load(c.ring.template ks<1, 1>());
+        }
+        mu = G;
+        nb = nbn;
+    };
+    int n = 0;
+    for (; n + 1 < nst; n += 2) {
+        step(std::integral_constant<int, 0>{}, n);
+        step(std::integral_constant<int, 1>{}, n + 1);
+    }
+    if (n < nst) step(std::integral_constant<int, 0>{}, n);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    st[(size_t)2 * KT * 64 + s.foff] = mu;
+    st[(size_t)3 * KT * 64 + s.foff] = nb;
+}

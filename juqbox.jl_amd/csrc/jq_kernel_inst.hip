@@ -14,7 +14,7 @@
 #error "compile with -DJQ_NT=<tiles> -DJQ_BW=<band> -DJQ_VARIANT=<0..11>"
 #endif
 #if JQ_VARIANT == 9     // cooperative-quad (latency) kernels of the JQ_BW_T4 structure (JQ_BW = 7)
-#include "jq_cq_kernels.h"
+#include "jq_cq_split_kernels.h"
 template __global__ void k_forward_cq<JQ_NT, false>(PropArgs);
 template __global__ void k_backward_cq<JQ_NT, false, false>(PropArgs);
 template __global__ void k_backward_cq<JQ_NT, false, true>(PropArgs);      // (control q acts on subsystem q only)
@@ -23,6 +23,10 @@ template __global__ void k_forward_cq<JQ_NT, false, 2>(PropArgs);      // (two c
 template __global__ void k_forward_cq<JQ_NT, true, 2>(PropArgs);
 template __global__ void k_backward_cq<JQ_NT, true, false>(PropArgs);
 template __global__ void k_backward_cq<JQ_NT, true, true>(PropArgs);
+template __global__ void k_backward_cq3<JQ_NT, false, false>(PropArgs);     // (backward sweep on three workgroups per column quad)
+template __global__ void k_backward_cq3<JQ_NT, false, true>(PropArgs);
+template __global__ void k_backward_cq3<JQ_NT, true, false>(PropArgs);
+template __global__ void k_backward_cq3<JQ_NT, true, true>(PropArgs);
 #elif JQ_VARIANT == 10  // cooperative-quad kernels of the implicit-midpoint integrator (JQ_BW = 7, N = 4)
 #include "jq_cq_imr_kernels.h"
 template __global__ void k_forward_cq_imr<JQ_NT>(PropArgs);

@@ -99,6 +99,9 @@ struct jq_handle {
     std::vector<double> tf, tb;
     // device buffers (owned)
     double *d_cimg = nullptr, *d_park = nullptr;
+    double* d_cq3 = nullptr;    // hand-off buffer of k_backward_cq3 (jq_cq_split_kernels.h)
+    size_t cap_cq3 = 0;
+    bool cq3_off = false;       // a launch of k_backward_cq3 reported a dead wait / workgroups on different XCDs: not used again
     double *d_himg_c = nullptr, *d_cimg_c = nullptr;   // operator images in the cooperative layout
     double *d_himg_l = nullptr, *d_uinit_l = nullptr, *d_vtr_l = nullptr, *d_vti_l = nullptr;   // lane kernels
     double *d_himg_r = nullptr, *d_uinit_r = nullptr, *d_vtr_r = nullptr, *d_vti_r = nullptr;   // row-lane kernels
@@ -521,7 +524,7 @@ extern "C" void jq_destroy(jq_handle* h)
     }
     (void)hipSetDevice(h->device);
     if (h->emb) jq_destroy(h->emb);
-    double** bufs[] = {&h->d_wlr, &h->d_cimg_l, &h->d_cimg_r, &h->d_rfreq, &h->d_wq, &h->d_pk2, &h->d_pack, &h->d_himg_r, &h->d_uinit_r, &h->d_vtr_r, &h->d_vti_r, &h->d_himg_l, &h->d_uinit_l, &h->d_vtr_l, &h->d_vti_l, &h->d_himg_c, &h->d_cimg_c, &h->d_park, &h->d_cimg, &h->d_himg,  &h->d_uimg,       &h->d_vtr,     &h->d_vti,    &h->d_tabs, &h->d_tf,   &h->d_tb,
+    double** bufs[] = {&h->d_cq3, &h->d_wlr, &h->d_cimg_l, &h->d_cimg_r, &h->d_rfreq, &h->d_wq, &h->d_pk2, &h->d_pack, &h->d_himg_r, &h->d_uinit_r, &h->d_vtr_r, &h->d_vti_r, &h->d_himg_l, &h->d_uinit_l, &h->d_vtr_l, &h->d_vti_l, &h->d_himg_c, &h->d_cimg_c, &h->d_park, &h->d_cimg, &h->d_himg,  &h->d_uimg,       &h->d_vtr,     &h->d_vti,    &h->d_tabs, &h->d_tf,   &h->d_tb,
                        &h->d_cfreq, &h->d_pcof,       &h->d_stream,  &h->d_pq,     &h->d_state, &h->d_state_save,
                        &h->d_colinfo, &h->d_traces,   &h->d_R,       &h->d_grad,   &h->d_res};
     for (auto b : bufs)
@@ -1522,6 +1525,7 @@ JQ_DECLQ(1) JQ_DECLQ(2) JQ_DECLQ(3) JQ_DECLQ(4) JQ_DECLQ(5) JQ_DECLQ(6) JQ_DECLQ
 #undef JQ_DECLQ
 template <int NT, bool MODD, int NS> __global__ void k_forward_cq(PropArgs);    // jq_cq_kernels.h (own translation units); NS: column quads per workgroup
 template <int NT, bool MODD, bool ORD> __global__ void k_backward_cq(PropArgs);
+template <int NT, bool MODD, bool ORD> __global__ void k_backward_cq3(PropArgs);    // jq_cq_split_kernels.h: three workgroups per column quad
 #define JQ_DECLCQ(nt)                                                      \
     extern template __global__ void k_forward_cq<nt, false, 1>(PropArgs);  \
     extern template __global__ void k_forward_cq<nt, false, 2>(PropArgs);  \
@@ -1530,12 +1534,17 @@ template <int NT, bool MODD, bool ORD> __global__ void k_backward_cq(PropArgs);
     extern template __global__ void k_forward_cq<nt, true, 1>(PropArgs);   \
     extern template __global__ void k_forward_cq<nt, true, 2>(PropArgs);   \
     extern template __global__ void k_backward_cq<nt, true, false>(PropArgs);     \
-    extern template __global__ void k_backward_cq<nt, true, true>(PropArgs);
+    extern template __global__ void k_backward_cq<nt, true, true>(PropArgs);      \
+    extern template __global__ void k_backward_cq3<nt, false, false>(PropArgs);   \
+    extern template __global__ void k_backward_cq3<nt, false, true>(PropArgs);    \
+    extern template __global__ void k_backward_cq3<nt, true, false>(PropArgs);    \
+    extern template __global__ void k_backward_cq3<nt, true, true>(PropArgs);
 JQ_DECLCQ(1) JQ_DECLCQ(2) JQ_DECLCQ(3) JQ_DECLCQ(4) JQ_DECLCQ(5) JQ_DECLCQ(6) JQ_DECLCQ(7)
 #undef JQ_DECLCQ
 // (instantiated for even and odd numbers of Neumann terms: the parities of the LDS exchange are compile-time constants)
-// fwd2: the forward kernel with two column quads per workgroup (grid = 2 * nslabs)
-static int select_cq_kernels(jq_handle* h, bool fwd2, prop_kernel_t* fwd, prop_kernel_t* bwd)
+// fwd2: the forward kernel with two column quads per workgroup (grid = 2 * nslabs); bwd3: the backward sweep on three workgroups per
+// quad (k_backward_cq3)
+static int select_cq_kernels(jq_handle* h, bool fwd2, bool bwd3, prop_kernel_t* fwd, prop_kernel_t* bwd)
 {
     const bool modd = (h->m > 0 ? h->m : 0) & 1;
     // control q acts on subsystem q only (the usual Juqbox set-up: Hsym_ops = [a + a', b + b', c + c']): its trace products need
@@ -1545,8 +1554,10 @@ static int select_cq_kernels(jq_handle* h, bool fwd2, prop_kernel_t* fwd, prop_k
 #define JQ_PICKCQ(nt)                                                              \
     if (h->NT == nt) {                                                             \
         *fwd = fwd2 ? (modd ? k_forward_cq<nt, true, 2> : k_forward_cq<nt, false, 2>) : (modd ? k_forward_cq<nt, true, 1> : k_forward_cq<nt, false, 1>);            \
-        *bwd = modd ? (ord ? k_backward_cq<nt, true, true> : k_backward_cq<nt, true, false>)          \
-                    : (ord ? k_backward_cq<nt, false, true> : k_backward_cq<nt, false, false>);       \
+        *bwd = bwd3 ? (modd ? (ord ? k_backward_cq3<nt, true, true> : k_backward_cq3<nt, true, false>)          \
+                            : (ord ? k_backward_cq3<nt, false, true> : k_backward_cq3<nt, false, false>))       \
+                    : modd ? (ord ? k_backward_cq<nt, true, true> : k_backward_cq<nt, true, false>)          \
+                           : (ord ? k_backward_cq<nt, false, true> : k_backward_cq<nt, false, false>);       \
         return JQ_OK;                                                              \
     }
     JQ_PICKCQ(1) JQ_PICKCQ(2) JQ_PICKCQ(3) JQ_PICKCQ(4) JQ_PICKCQ(5) JQ_PICKCQ(6) JQ_PICKCQ(7)
@@ -1850,8 +1861,18 @@ __global__ void k_add_to(double* __restrict__ y, const double* __restrict__ x, i
 
 // The batched evaluation behind every hot-path entry point.
 // d_packed != nullptr: the packed ensemble result (k_pack) is also left at this DEVICE address of h's GPU.
+#define JQ_ERETRY_INTERNAL (-1000)      // run_eval_impl: k_backward_cq3 gave up (the handle no longer uses it): evaluate again
+static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamples, const double* eps, const double* wgt,
+                         const double* shift, bool adjoint, double* hist_r, double* hist_i, EvalOut* out, double* d_packed);
 static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, const double* eps, const double* wgt,
                     const double* shift, bool adjoint, double* hist_r, double* hist_i, EvalOut* out, double* d_packed = nullptr)
+{
+    int rc = run_eval_impl(h, pcof, ncoeff, nsamples, eps, wgt, shift, adjoint, hist_r, hist_i, out, d_packed);
+    if (rc == JQ_ERETRY_INTERNAL) rc = run_eval_impl(h, pcof, ncoeff, nsamples, eps, wgt, shift, adjoint, hist_r, hist_i, out, d_packed);
+    return rc;
+}
+static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamples, const double* eps, const double* wgt,
+                         const double* shift, bool adjoint, double* hist_r, double* hist_i, EvalOut* out, double* d_packed)
 {
     HIPCHK(h, hipSetDevice(h->device));
     // Ensembles that do not fill their last round: the time of a batch is a staircase in its size (every workgroup runs the
@@ -2024,6 +2045,19 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     // instead of two rounds; JQ_CQ_FWD2=0: one quad per workgroup, =1: always two)
     const char* e_cf2 = getenv("JQ_CQ_FWD2");
     const bool cq_fwd2 = cq && (e_cf2 ? atoi(e_cf2) != 0 : nquads_used > h->num_cu);
+    // single evaluations and small ensembles: the backward sweep on three workgroups (CUs) per column quad -- state re-integration,
+    // adjoint step, trace products, pipelined through a ring in global memory (jq_cq_split_kernels.h).  All 3 x quads workgroups must
+    // be resident at once (groups of 8 quads: 24 workgroups); JQ_CQ3=0: the one-workgroup kernel
+    const long long nq_pad = (nquads_used + 7) / 8 * 8;
+    const char* e_c3 = getenv("JQ_CQ3");
+    const bool cq3 = cq && adjoint && !h->cq3_off && 3 * nq_pad <= h->num_cu && !(e_c3 && atoi(e_c3) == 0);
+    const size_t cq3_quad = 64 + (size_t)8 * 6 * h->NT * 64;      // doubles per quad: JQ_CQ3_HEAD + JQ_CQ3_SLOTS * JQ_CQ3_ARRAYS * NT * 64
+    const size_t cq3_need = 64 + (size_t)nq_pad * cq3_quad;
+    if (cq3) {
+        const int rc0 = dev_grow(h, &h->d_cq3, &h->cap_cq3, cq3_need);
+        if (rc0) return rc0;
+        HIPCHK(h, hipMemsetAsync(h->d_cq3, 0, 64 * sizeof(double), h->stream));      // (the error word of the evaluation)
+    }
     const char* e_icq2 = getenv("JQ_IMR_CQ2");
     const bool imr_cq2 = imr_cq && h->NT <= 6 && !(e_icq2 && atoi(e_icq2) == 0) &&
                          cq_imr2_lds(h, (size_t)(2 * JQ_WIN_TPS + 2 * h->NcK) * h->mat_elems * 8) <= 163840;
@@ -2054,7 +2088,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
              : imr_rl ? select_rowlane_imr_kernels(h, rl_split, &kfwd, &kbwd)
              : rl ? select_rowlane_kernels(h, rl_split, &kfwd, &kbwd)
              : lane ? select_lane_kernels(h, &kfwd, &kbwd, &klinit, &klterm)
-                  : cq ? select_cq_kernels(h, cq_fwd2, &kfwd, &kbwd)
+                  : cq ? select_cq_kernels(h, cq_fwd2, cq3, &kfwd, &kbwd)
                   : coop ? select_coop_kernels(h, &kfwd, &kbwd) : quad ? (wfull ? select_quad_w_kernels(h, &kfwd, &kbwd) : select_quad_kernels(h, spw, &kfwd, &kbwd)) : select_kernels(h, &kfwd, &kbwd);
     if (rc) return rc;
     const int nblocks = imr_parts ? nsamples : (cq || imr_cq) ? 4 * nslabs : rl ? (int)nwaves_rl : lane ? (int)(ncols / 64) : quad8 ? (nslabs + spw - 1) / spw : (coop || quad) ? nslabs : (nslabs + JQ_WAVES - 1) / JQ_WAVES;
@@ -2314,7 +2348,14 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
                         sched_pack(&a.pro_bits, q, 2, q);          // first chunk: carry products with Hsym_q
                     }
                 }
+                if (cq3) {      // (progress counters and rings of the launch; the error word in front survives until the end of the evaluation)
+                    HIPCHK(h, hipMemsetAsync(h->d_cq3 + 64, 0, (cq3_need - 64) * sizeof(double), s));
+                    a.park = h->d_cq3;
+                }
                 HIPCHK(h, hipEventRecord(h->ev[evi++], s));
+                if (cq3)
+                    hipLaunchKernelGGL(kbwd, dim3((unsigned)(3 * nq_pad)), dim3(nthreads + 128), lds_bwd, s, a);      // (three workgroups per quad: NT block waves + two staging waves each)
+                else
                 hipLaunchKernelGGL(kbwd, dim3(nblocks), dim3((cq || rl_split) ? 2 * nthreads : imr_cq2 ? 2 * (nthreads + 128) : imr_cq ? nthreads + 128 : nthreads), lds_bwd + (wlr_lds_bwd >= 0 ? wlr_bytes : 0), s, a);      // (cooperative quad: state and adjoint chain on separate waves)
                 HIPCHK(h, hipEventRecord(h->ev[evi++], s));
                 hipLaunchKernelGGL(k_trace_reduce, dim3((unsigned)(((long long)nc * ntr_g + 255) / 256)), dim3(256), 0, s,
@@ -2351,7 +2392,22 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
                                      hipMemcpyDeviceToHost, s));
         }
     }
+    unsigned long long cq3_err = 0;
+    if (cq3) HIPCHK(h, hipMemcpyAsync(&cq3_err, h->d_cq3, sizeof(cq3_err), hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
+    if (cq3 && getenv("JQ_DEBUG_TIMING")) {      // development aid: progress counters, error word and XCC ids (+ 1) of the first quads
+        std::vector<unsigned long long> hw((size_t)64 + 2 * cq3_quad);
+        HIPCHK(h, hipMemcpy(hw.data(), h->d_cq3, hw.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int qd = 0; qd < 2; ++qd) {
+            const unsigned long long* q = hw.data() + 64 + (size_t)qd * cq3_quad;
+            fprintf(stderr, "jq cq3 quad %d: steps %llu %llu %llu, error %llu (launch %llu), xcc %llu %llu %llu\n", qd, q[0], q[8], q[16], q[24], hw[0], q[32], q[33], q[34]);
+        }
+    }
+    if (cq3_err) {      // a wait between the three workgroups of a quad was abandoned (1), or they ran on different XCDs (2): the results are void
+        h->cq3_off = true;
+        if (getenv("JQ_DEBUG_TIMING")) fprintf(stderr, "jq: k_backward_cq3 reported %llu -- evaluated again with k_backward_cq\n", cq3_err);
+        return JQ_ERETRY_INTERNAL;
+    }
 
     float ms = 0.f;
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
@@ -2380,7 +2436,7 @@ static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, 
     h->timing.kernel_family = imr_cq ? 9 : cq ? 8 : imr_quad ? 7 : imr_coop ? 5 : imr ? 4 : rl ? 3 : lane ? 2 : coop ? 1 : quad ? 6 : 0;
     h->timing.kernel_size = rl ? h->rl_npj : lane ? h->lane_np : h->NT;
     h->timing.kernel_band = (rl || lane) ? 0 : coop ? h->BWc : (quad || cq) ? JQ_BW_T4Q : h->BW;
-    h->timing.reserved = 0;
+    h->timing.reserved = cq3 ? 3 : 0;      // (workgroups per column quad in the backward sweep of the cooperative-quad kernels)
     h->timing.ms_allreduce = 0.0;
     h->timing.ms_shard_min = h->timing.ms_shard_max = h->timing.ms_total;
     return JQ_OK;
