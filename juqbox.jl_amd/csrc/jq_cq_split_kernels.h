@@ -28,7 +28,7 @@
 #define JQ_CQ3_SLOTS 8        // ring depth in time steps
 #define JQ_CQ3_ARRAYS 6       // u (vr before the state step), v05, un, X, nbn (-lambda_i new), Bq (-(li0 + li))
 #define JQ_CQ3_HEAD 64        // doubles in front of a quad's ring: [0] steps of role 0, [8] role 1, [16] role 2, [24] error, [32 + r] XCC of role r
-#define JQ_CQ3_SPIN 4000000   // polls (with s_sleep) before a wait is declared dead
+#define JQ_CQ3_SPIN 1000000   // polls (with s_sleep; ~ 2 us each) before a wait is declared dead
 
 template <int NT>
 struct Cq3Hand {

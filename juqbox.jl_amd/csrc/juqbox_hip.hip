@@ -2050,7 +2050,8 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     // be resident at once (groups of 8 quads: 24 workgroups); JQ_CQ3=0: the one-workgroup kernel
     const long long nq_pad = (nquads_used + 7) / 8 * 8;
     const char* e_c3 = getenv("JQ_CQ3");
-    const bool cq3 = cq && adjoint && !h->cq3_off && 3 * nq_pad <= h->num_cu && !(e_c3 && atoi(e_c3) == 0);
+    // (not for the sub-handles of the same-device test mode: their launches share the GPU, the workgroups of a quad might not all be resident)
+    const bool cq3 = cq && adjoint && !h->cq3_off && 3 * nq_pad <= h->num_cu && !(e_c3 && atoi(e_c3) == 0) && !getenv("JQ_MULTI_SAME_DEVICE");
     const size_t cq3_quad = 64 + (size_t)8 * 6 * h->NT * 64;      // doubles per quad: JQ_CQ3_HEAD + JQ_CQ3_SLOTS * JQ_CQ3_ARRAYS * NT * 64
     const size_t cq3_need = 64 + (size_t)nq_pad * cq3_quad;
     if (cq3) {
@@ -2403,6 +2404,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
             fprintf(stderr, "jq cq3 quad %d: steps %llu %llu %llu, error %llu (launch %llu), xcc %llu %llu %llu\n", qd, q[0], q[8], q[16], q[24], hw[0], q[32], q[33], q[34]);
         }
     }
+    if (cq3 && getenv("JQ_CQ3_FAULT")) cq3_err = 1;      // (test hook: as if a wait of k_backward_cq3 had been abandoned)
     if (cq3_err) {      // a wait between the three workgroups of a quad was abandoned (1), or they ran on different XCDs (2): the results are void
         h->cq3_off = true;
         if (getenv("JQ_DEBUG_TIMING")) fprintf(stderr, "jq: k_backward_cq3 reported %llu -- evaluated again with k_backward_cq\n", cq3_err);

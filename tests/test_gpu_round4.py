@@ -297,3 +297,69 @@ def test_multi_handle_against_the_oracle_loop(jq, case, nquad, K):
     assert np.linalg.norm(params.last_infidelity_grad - ref["last_infidelity_grad"]) <= 1e-10 * gn
     if params.objFuncType != 1:
         assert np.linalg.norm(params.last_leak_grad - ref["last_leak_grad"]) <= 1e-10 * gn
+
+
+def _cq3_problem(jq, kind):
+    """cnot3 shortened (4 x 4 x 6, NT = 6, even m), or random 4 x 4 x n problems with N = 4 (NT = 3 / 7; objFuncType 3: two backward passes)"""
+    if kind == "cnot3":
+        params, info = jq.cases.cnot3()
+        params.T, params.nsteps = params.T * 1101 / params.nsteps, 1101
+        pcof = np.array(json.load(open(os.path.join(ROOT, "tests", "golden", "cnot3.json")))["pcof0"])
+        return params, pcof
+    from test_gpu_random import random_problem
+    Ntot, m = {"t4x3": (48, 5), "t4x7": (112, 4)}[kind]
+    rng = np.random.default_rng(5 + Ntot)
+    params, pcof = random_problem(jq, rng, Ntot, 4, 3, 2, 57, m, 3, "t4")
+    return params, pcof
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,nsamples", [("cnot3", 1), ("cnot3", 5), ("cnot3", 21), ("t4x3", 3), ("t4x7", 2)])
+def test_backward_sweep_on_three_workgroups_per_quad_is_the_one_workgroup_kernel(jq, kind, nsamples):
+    """Round 4: k_backward_cq3 runs the state re-integration, the adjoint step and the trace products of a column quad on three
+    workgroups (CUs) that hand their per-step arrays on through a ring in global memory.  Every chain and every trace sum performs the
+    operations of k_backward_cq (JQ_CQ3=0) in the same order: bit-identical results -- single evaluation and small ensembles (groups
+    of 8 quads with idle ones), several chunks with odd lengths, odd / even numbers of Neumann terms, NT = 3, 6, 7, objFuncType 3
+    (a second, unforced backward pass), and run to run."""
+    params, pcof = _cq3_problem(jq, kind)
+    rng = np.random.default_rng(3)
+    nodes, weights = 0.02 * rng.standard_normal(nsamples), rng.random(nsamples)
+    shift = 0.01 * np.arange(params.Ntot)
+    res = {}
+    for tag, env in (("three", {"JQ_CHUNK_STEPS": "300" if kind == "cnot3" else "20"}), ("one", {"JQ_CQ3": "0", "JQ_CHUNK_STEPS": "300" if kind == "cnot3" else "20"}),
+                     ("three_again", {})):
+        os.environ.update(env)
+        try:
+            wa = jq.Working_Arrays_HIP(params, pcof.size)
+            jq.eval_f_g_grad(pcof, params, wa, nodes, weights, True, shift=shift)
+            t = wa.last_timing()
+            assert t["kernel_family"] == 8 and t["reserved"] == (0 if tag == "one" else 3), t
+            res[tag] = (params.last_infidelity, params.last_leak, params.last_infidelity_grad.copy(),
+                        params.last_leak_grad.copy() if params.objFuncType != 1 else np.zeros(1))
+            wa.close()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    a, b, c = res["three"], res["one"], res["three_again"]
+    assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    # (one chunk instead of several: the gradient's partial sums are grouped differently)
+    assert abs(a[0] - c[0]) <= 1e-13 * abs(a[0]) and np.linalg.norm(a[2] - c[2]) <= 1e-12 * np.linalg.norm(a[2])
+
+
+@pytest.mark.gpu
+def test_three_workgroup_kernel_falls_back_when_it_reports_a_dead_wait(jq):
+    """k_backward_cq3 raises an error word when a wait between its workgroups is abandoned or when they do not share an XCD; the
+    evaluation is then repeated with k_backward_cq and the handle stops using the split (JQ_CQ3_FAULT=1 simulates the report)."""
+    params, pcof = _cq3_problem(jq, "cnot3")
+    wa = jq.Working_Arrays_HIP(params, pcof.size)
+    f0, g0, *_ = jq.traceobjgrad(pcof, params, wa, False, True)
+    assert wa.last_timing()["reserved"] == 3
+    os.environ["JQ_CQ3_FAULT"] = "1"
+    try:
+        f1, g1, *_ = jq.traceobjgrad(pcof, params, wa, False, True)
+    finally:
+        os.environ.pop("JQ_CQ3_FAULT", None)
+    assert wa.last_timing()["reserved"] == 0 and f1 == f0 and np.array_equal(g1, g0)
+    f2, g2, *_ = jq.traceobjgrad(pcof, params, wa, False, True)      # (the handle stays on the one-workgroup kernel)
+    assert wa.last_timing()["reserved"] == 0 and f2 == f0 and np.array_equal(g2, g0)
+    wa.close()
