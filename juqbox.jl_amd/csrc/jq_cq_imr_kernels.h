@@ -23,7 +23,7 @@
 // 2n+5, 2n+6 is issued behind the first barrier of step n and drained in front of the first barrier of step n+1), state file,
 // terminal kernels and trace slots as the quad-layout kernels; one trace record row per wave.
 #pragma once
-#include "jq_cq_kernels.h"
+#include "jq_cq_split_kernels.h"
 
 template <int NT>
 struct CqImr {
@@ -708,6 +708,170 @@ __global__ __launch_bounds__(128 * NT + 256) void k_backward_cq_imr2(PropArgs a)
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    st[(size_t)2 * KT * 64 + s.foff] = lr;
+    st[(size_t)3 * KT * 64 + s.foff] = li;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward sweep on THREE workgroups (CUs) per evaluation, as k_backward_cq3 (jq_cq_split_kernels.h, whose hand-off ring, progress
+// counters, XCD check and dead-wait fallback this kernel shares): the two sets of k_backward_cq_imr2 on one CU are bound by the
+// SIMDs' issue rate (four waves per SIMD); with a CU of its own a chain runs at the forward sweep's pace.
+//   role 0  state re-integration: CqImr::step per time step; stores su = u_old + u_new, sv
+//   role 1  adjoint step, >= 1 step behind: loads su, sv of its block (forcing -W (v + v_s) / T); stores smu, snu
+//   role 2  trace products (adjoint_grad_calc_m): loads su, sv with their neighbouring blocks, smu, snu; one record row per block wave
+// Roles 0 and 1: NT block waves + two reducer waves, the code of k_forward_cq_imr (one more barrier per step: behind it the stores
+// of the step are acknowledged and the counter is published).  Bit-identical to k_backward_cq_imr / _imr2.
+// grid = 24 * ceil(evaluations / 8), block = 64 * (NT + 2); a.park: the hand-off buffer, zeroed by the host before every launch.
+template <int NT>
+__global__ __launch_bounds__(64 * NT + 128) void k_backward_cq_imr3(PropArgs a)
+{
+    typedef typename CoopQ<NT>::Sh Sh;
+    typedef typename CoopQ<NT>::Nb Nb;
+    const int role = ((int)blockIdx.x >> 3) % 3;
+    const int quad = 8 * ((int)blockIdx.x / 24) + ((int)blockIdx.x & 7);
+    const CqSetup<NT> s = cq_setup<NT>(a, quad >> 2, quad & 3);
+    const int Nc = a.Ncoupled, ntr = Nc * JQ_NTR, nst = a.nsteps_chunk;
+    const size_t trow = ((size_t)s.slab * a.qps + s.qd) * NT;      // first of my evaluation's NT record rows
+    if (s.slab >= a.nslabs) return;
+    if (!s.active) {
+        if (role == 2 && s.qd < a.qps)
+            for (size_t k = threadIdx.x; k < (size_t)NT * nst * ntr; k += blockDim.x) a.traces[trow * nst * ntr + k] = 0.0;
+        return;
+    }
+    Cq3Hand<NT> hd;
+    hd.init(a, (size_t)quad, s.lane_);
+    {
+        const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11));
+        if (threadIdx.x == 0) __hip_atomic_store(hd.head + 32 + role, (unsigned long long)xcc + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (role == 2) {
+        if (s.chain) return;      // (no reducer waves here)
+        extern __shared__ __attribute__((aligned(16))) char smem2[];
+        const int lane_ = s.lane_, wave = s.wave;
+        CoopQ<NT> c;
+        c.mt = wave, c.lane = lane_, c.xb = nullptr;
+        WinRing& r = c.ring;      // (only the constant images are staged)
+        r.smem = smem2, r.wave = wave, r.lane = lane_, r.nwaves = NT;
+        r.stride_b = (unsigned)(a.stride * 8), r.slot_bytes = 2 * r.stride_b, r.cbase = JQ_WIN_TPS * r.slot_bytes, r.pieces2 = 2 * a.pieces;
+        r.dma((const char*)a.cimg, smem2 + r.cbase, 2 * a.Ncoupled * a.pieces);
+        const double wgt = a.colinfo[(size_t)s.slab * 32 + 16 + s.col];
+        double* trw = a.traces + ((trow + wave) * nst) * ntr;
+        if (wave == 0) hd.wait(1, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        struct Rec {
+            double su, sv, smu, snu;
+            Nb nu, nv;
+        };
+        auto fetch = [&](int n) {
+            Rec e;
+            e.su = hd.load(n, 0, wave), e.sv = hd.load(n, 1, wave), e.smu = hd.load(n, 2, wave), e.snu = hd.load(n, 3, wave);
+            const int wb = wave > 0 ? wave - 1 : wave, wa_ = wave + 1 < NT ? wave + 1 : wave;
+            e.nu.b = hd.load(n, 0, wb), e.nu.a = hd.load(n, 0, wa_);
+            e.nv.b = hd.load(n, 1, wb), e.nv.a = hd.load(n, 1, wa_);
+            if (wave == 0) e.nu.b = 0.0, e.nv.b = 0.0;
+            if (wave + 1 == NT) e.nu.a = 0.0, e.nv.a = 0.0;
+            return e;
+        };
+        Rec cur = fetch(0);
+        for (int n = 0; n < nst; ++n) {
+            if (wave == 0) hd.wait(1, (unsigned long long)(n + 2 < nst ? n + 2 : nst));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (cur has landed)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (wave == 0 && lane_ == 0) hd.publish(2, (unsigned long long)(n + 1));
+            Rec nxt = cur;
+            if (n + 1 < nst) nxt = fetch(n + 1);
+            const Sh shu = c.sh(cur.su), shv = c.sh(cur.sv);
+            double* tr = trw + (size_t)n * ntr;
+            for (int qp = 0; qp < Nc; qp += 2) {
+                double P[2] = {0.0, 0.0}, Q[2] = {0.0, 0.0};
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int q = qp + j;
+                    if (q < Nc) {
+                        const double* Hs = c.ring.cimg(q);
+                        const double* Ha = c.ring.cimg(Nc + q);
+                        const double B = -(cur.smu * c.template trace_mm<false>(Hs, q, shv, cur.nv));
+                        const double D = cur.snu * c.template trace_mm<false>(Ha, q, shv, cur.nv);
+                        const double C = cur.snu * c.template trace_mm<false>(Hs, q, shu, cur.nu);
+                        const double A = cur.smu * c.template trace_mm<false>(Ha, q, shu, cur.nu);
+                        P[j] = (B + C) * wgt;
+                        Q[j] = (A + D) * wgt;
+                    }
+                }
+                const double r4 = wave_sum4(P[0], Q[0], P[1], Q[1]);
+                const int row = lane_ >> 4, q = qp + (row & 1);
+                if (q < Nc) {
+                    const int l = lane_ & 15;
+                    if (l == 0) tr[q * JQ_NTR + (row < 2 ? 3 : 4)] = row < 2 ? -0.25 * r4 : 0.25 * r4;
+                    else if (l < 4 && row < 2) tr[q * JQ_NTR + l - 1] = 0.0;
+                }
+            }
+            cur = nxt;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            hd.publish(2, (unsigned long long)nst);
+            const unsigned long long x0 = __hip_atomic_load(hd.head + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long x1 = __hip_atomic_load(hd.head + 33, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long x2 = __hip_atomic_load(hd.head + 34, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (x0 != x2 || x1 != x2) __hip_atomic_store(hd.gerr, 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    JQ_CQ_IMR_PROLOGUE
+    (void)wsr;
+    if (s.chain) {      // reducer waves: one solve and the publication barrier per time step (+ the start barrier of role 1)
+        if (role == 1) c.sync();
+        for (int n = 0; n < nst; ++n) {
+            m.reducer_step(wave);
+            c.sync();
+        }
+        return;
+    }
+    if (role == 0) {
+        double u = st[s.foff], v = st[(size_t)KT * 64 + s.foff];
+        for (int n = 0; n < nst; ++n) {
+            if (wave == 0 && n >= JQ_CQ3_SLOTS) hd.wait(2, (unsigned long long)(n - JQ_CQ3_SLOTS + 1));      // (the slot is free)
+            m.K = c.load(c.ring.template ks<0, 1>());
+            m.fold_shift();
+            m.S = c.load(c.ring.template ks<1, 1>());
+            const double u0 = u, v0 = v;
+            m.template step<true>(u, v, 0.0, 0.0);      // (wave 0 reaches the step's first barrier only when the slot is free)
+            c.ring.advance();
+            hd.store(n, 0, wave, u0 + u);
+            hd.store(n, 1, wave, v0 + v);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            c.sync();
+            if (wave == 0 && lane_ == 0) hd.publish(0, (unsigned long long)(n + 1));
+        }
+        st[s.foff] = u;
+        st[(size_t)KT * 64 + s.foff] = v;
+        return;
+    }
+    double lr = st[(size_t)2 * KT * 64 + s.foff], li = st[(size_t)3 * KT * 64 + s.foff];
+    const double cfw = a.forced ? -a.h * a.tinv * wdr : 0.0;      // h * (-tinv * W): W applied row-wise
+    if (wave == 0) hd.wait(0, 1);
+    c.sync();
+    double hsu = hd.load(0, 0, wave), hsv = hd.load(0, 1, wave);
+    for (int n = 0; n < nst; ++n) {
+        if (wave == 0) hd.wait(0, (unsigned long long)(n + 2 < nst ? n + 2 : nst));
+        m.K = c.load(c.ring.template ks<0, 1>());
+        m.fold_shift();
+        m.S = c.load(c.ring.template ks<1, 1>());
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (su, sv of this step have landed)
+        const double su = hsu, sv = hsv, l0 = lr, l1 = li;
+        m.template step<true>(lr, li, cfw * su, cfw * sv);
+        c.ring.advance();
+        if (n + 1 < nst) hsu = hd.load(n + 1, 0, wave), hsv = hd.load(n + 1, 1, wave);      // (role 0 has finished the steps <= n + 1: seen in front of the step's barriers)
+        hd.store(n, 2, wave, l0 + lr);
+        hd.store(n, 3, wave, l1 + li);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        c.sync();
+        if (wave == 0 && lane_ == 0) hd.publish(1, (unsigned long long)(n + 1));
+    }
     st[(size_t)2 * KT * 64 + s.foff] = lr;
     st[(size_t)3 * KT * 64 + s.foff] = li;
 }

@@ -31,6 +31,7 @@ template __global__ void k_backward_cq3<JQ_NT, true, true>(PropArgs);
 #include "jq_cq_imr_kernels.h"
 template __global__ void k_forward_cq_imr<JQ_NT>(PropArgs);
 template __global__ void k_backward_cq_imr<JQ_NT>(PropArgs);
+template __global__ void k_backward_cq_imr3<JQ_NT>(PropArgs);      // (three workgroups per evaluation: state chain, adjoint chain, trace products)
 #if JQ_NT <= 6
 template __global__ void k_backward_cq_imr2<JQ_NT>(PropArgs);      // (state and adjoint chain on two sets of waves)
 #endif

@@ -1591,6 +1591,10 @@ template <int NT> __global__ void k_backward_cq_imr2(PropArgs);    // (state and
     extern template __global__ void k_backward_cq_imr<nt>(PropArgs);
 JQ_DECLCI(1) JQ_DECLCI(2) JQ_DECLCI(3) JQ_DECLCI(4) JQ_DECLCI(5) JQ_DECLCI(6) JQ_DECLCI(7)
 #undef JQ_DECLCI
+template <int NT> __global__ void k_backward_cq_imr3(PropArgs);    // (three workgroups per evaluation, as k_backward_cq3)
+#define JQ_DECLCI(nt) extern template __global__ void k_backward_cq_imr3<nt>(PropArgs);
+JQ_DECLCI(1) JQ_DECLCI(2) JQ_DECLCI(3) JQ_DECLCI(4) JQ_DECLCI(5) JQ_DECLCI(6) JQ_DECLCI(7)
+#undef JQ_DECLCI
 #define JQ_DECLCI(nt) extern template __global__ void k_backward_cq_imr2<nt>(PropArgs);
 JQ_DECLCI(1) JQ_DECLCI(2) JQ_DECLCI(3) JQ_DECLCI(4) JQ_DECLCI(5) JQ_DECLCI(6)
 #undef JQ_DECLCI
@@ -1598,8 +1602,16 @@ JQ_DECLCI(1) JQ_DECLCI(2) JQ_DECLCI(3) JQ_DECLCI(4) JQ_DECLCI(5) JQ_DECLCI(6)
 static size_t cq_imr2_lds(const jq_handle* h, size_t lds_stage) { return lds_stage + (size_t)32 * h->NT * 8 + (size_t)12 * (h->NT + 2) * 64 * 8 + 64; }
 // two: the backward sweep with the state and the adjoint chain on two sets of waves (NT <= 6, LDS permitting; JQ_IMR_CQ2=0: the
 // one-set kernel of round 3)
-static int select_cq_imr_kernels(jq_handle* h, bool two, prop_kernel_t* fwd, prop_kernel_t* bwd)
+static int select_cq_imr_kernels(jq_handle* h, bool two, bool three, prop_kernel_t* fwd, prop_kernel_t* bwd)
 {
+#define JQ_PICKCI(nt)                            \
+    if (h->NT == nt && three) {                  \
+        *fwd = k_forward_cq_imr<nt>;             \
+        *bwd = k_backward_cq_imr3<nt>;           \
+        return JQ_OK;                            \
+    }
+    JQ_PICKCI(1) JQ_PICKCI(2) JQ_PICKCI(3) JQ_PICKCI(4) JQ_PICKCI(5) JQ_PICKCI(6) JQ_PICKCI(7)
+#undef JQ_PICKCI
 #define JQ_PICKCI(nt)                            \
     if (h->NT == nt && two) {                    \
         *fwd = k_forward_cq_imr<nt>;             \
@@ -2051,7 +2063,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     const long long nq_pad = (nquads_used + 7) / 8 * 8;
     const char* e_c3 = getenv("JQ_CQ3");
     // (not for the sub-handles of the same-device test mode: their launches share the GPU, the workgroups of a quad might not all be resident)
-    const bool cq3 = cq && adjoint && !h->cq3_off && 3 * nq_pad <= h->num_cu && !(e_c3 && atoi(e_c3) == 0) && !getenv("JQ_MULTI_SAME_DEVICE");
+    const bool cq3 = (cq || imr_cq) && adjoint && !h->cq3_off && 3 * nq_pad <= h->num_cu && !(e_c3 && atoi(e_c3) == 0) && !getenv("JQ_MULTI_SAME_DEVICE");
     const size_t cq3_quad = 64 + (size_t)8 * 6 * h->NT * 64;      // doubles per quad: JQ_CQ3_HEAD + JQ_CQ3_SLOTS * JQ_CQ3_ARRAYS * NT * 64
     const size_t cq3_need = 64 + (size_t)nq_pad * cq3_quad;
     if (cq3) {
@@ -2059,8 +2071,9 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
         if (rc0) return rc0;
         HIPCHK(h, hipMemsetAsync(h->d_cq3, 0, 64 * sizeof(double), h->stream));      // (the error word of the evaluation)
     }
+    const bool imr_cq3 = imr_cq && cq3;
     const char* e_icq2 = getenv("JQ_IMR_CQ2");
-    const bool imr_cq2 = imr_cq && h->NT <= 6 && !(e_icq2 && atoi(e_icq2) == 0) &&
+    const bool imr_cq2 = imr_cq && !imr_cq3 && h->NT <= 6 && !(e_icq2 && atoi(e_icq2) == 0) &&
                          cq_imr2_lds(h, (size_t)(2 * JQ_WIN_TPS + 2 * h->NcK) * h->mat_elems * 8) <= 163840;
     if (cq) spw = 0;
     const bool quad = spw > 0;
@@ -2083,7 +2096,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     prop_kernel_t kfwd, kbwd;
     lane_init_t klinit = nullptr;
     lane_term_t klterm = nullptr;
-    int rc = imr_cq ? select_cq_imr_kernels(h, imr_cq2, &kfwd, &kbwd)
+    int rc = imr_cq ? select_cq_imr_kernels(h, imr_cq2, imr_cq3, &kfwd, &kbwd)
              : imr_quad ? select_quad_imr_kernels(h, &kfwd, &kbwd)
              : imr_coop ? (imr_parts ? select_coop_imr_parts_kernels(h, imr_hbm, &kfwd, &kbwd) : select_coop_imr_kernels(h, imr_hbm, &kfwd, &kbwd))
              : imr_rl ? select_rowlane_imr_kernels(h, rl_split, &kfwd, &kbwd)
