@@ -2060,7 +2060,8 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     // single evaluations and small ensembles: the backward sweep on three workgroups (CUs) per column quad -- state re-integration,
     // adjoint step, trace products, pipelined through a ring in global memory (jq_cq_split_kernels.h).  All 3 x quads workgroups must
     // be resident at once (groups of 8 quads: 24 workgroups); JQ_CQ3=0: the one-workgroup kernel
-    const long long nq_pad = (nquads_used + 7) / 8 * 8;
+    // (the kernels address quad q as quad q & 3 of slab q >> 2: every slab has four quad slots, a ragged last slab leaves some idle)
+    const long long nq_pad = (4LL * nslabs + 7) / 8 * 8;
     const char* e_c3 = getenv("JQ_CQ3");
     // (not for the sub-handles of the same-device test mode: their launches share the GPU, the workgroups of a quad might not all be resident)
     const bool cq3 = (cq || imr_cq) && adjoint && !h->cq3_off && 3 * nq_pad <= h->num_cu && !(e_c3 && atoi(e_c3) == 0) && !getenv("JQ_MULTI_SAME_DEVICE");

@@ -209,16 +209,19 @@ def test_uni_and_ord_variants_of_the_throughput_kernel_agree(jq):
 @pytest.mark.parametrize("nsamples", [0, 5])
 def test_two_set_cooperative_quad_implicit_midpoint_kernel_is_the_one_set_kernel(jq, nsamples):
     """Round 4: k_backward_cq_imr2 runs the state chain of time step k and the adjoint chain of step k - 1 on two sets of waves
-    (a pipeline of depth one inside a chunk, prologue and epilogue super-steps, odd chunk lengths).  Each chain performs the
-    operations of the one-set kernel (JQ_IMR_CQ2=0) in the same order: bit-identical results -- for one evaluation and for a
-    small ensemble with shifts, with a step count that is odd and leaves a ragged last chunk."""
+    (a pipeline of depth one inside a chunk, prologue and epilogue super-steps, odd chunk lengths); k_backward_cq_imr3 (the default for
+    single evaluations and small ensembles) gives each chain and the trace products a workgroup of their own (three CUs, a ring in
+    global memory).  Each chain performs the operations of the one-set kernel (JQ_CQ3=0 JQ_IMR_CQ2=0) in the same order:
+    bit-identical results -- for one evaluation and for a small ensemble with shifts, with a step count that is odd and leaves a
+    ragged last chunk."""
     params, info = jq.cases.cnot3()
     params.T, params.nsteps = params.T * 1501 / params.nsteps, 1501
     params.Integrator_id = jq.Implicit_Midpoint
     params.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER_M, max_iter=100, tol=1e-12, nrhs=params.N)
     pcof = np.array(json.load(open(os.path.join(ROOT, "tests", "golden", "cnot3.json")))["pcof0"])
     res = {}
-    for tag, env in (("two", {"JQ_CHUNK_STEPS": "400"}), ("one", {"JQ_IMR_CQ2": "0", "JQ_CHUNK_STEPS": "400"}), ("two_whole", {})):
+    for tag, env in (("three", {"JQ_CHUNK_STEPS": "400"}), ("two", {"JQ_CQ3": "0", "JQ_CHUNK_STEPS": "400"}),
+                     ("one", {"JQ_CQ3": "0", "JQ_IMR_CQ2": "0", "JQ_CHUNK_STEPS": "400"}), ("three_whole", {})):
         os.environ.update(env)
         try:
             wa = jq.Working_Arrays_M_HIP(params, pcof.size)
@@ -229,16 +232,18 @@ def test_two_set_cooperative_quad_implicit_midpoint_kernel_is_the_one_set_kernel
             else:
                 f, g, *_ = jq.traceobjgrad(pcof, params, wa, False, True)
                 res[tag] = (f, 0.0, np.array(g))
-            assert wa.last_timing()["kernel_family"] == 9
+            t = wa.last_timing()
+            assert t["kernel_family"] == 9 and t["reserved"] == (3 if tag.startswith("three") else 0)
             wa.close()
         finally:
             for k in env:
                 os.environ.pop(k, None)
-    assert res["two"][0] == res["one"][0] and res["two"][1] == res["one"][1]
-    assert np.array_equal(res["two"][2], res["one"][2])
+    for tag in ("two", "one"):
+        assert res["three"][0] == res[tag][0] and res["three"][1] == res[tag][1]
+        assert np.array_equal(res["three"][2], res[tag][2])
     # (one chunk instead of four: the gradient's partial sums are grouped differently)
-    assert abs(res["two"][0] - res["two_whole"][0]) <= 1e-13 * abs(res["two"][0])
-    assert np.linalg.norm(res["two"][2] - res["two_whole"][2]) <= 1e-12 * np.linalg.norm(res["two"][2])
+    assert abs(res["three"][0] - res["three_whole"][0]) <= 1e-13 * abs(res["three"][0])
+    assert np.linalg.norm(res["three"][2] - res["three_whole"][2]) <= 1e-12 * np.linalg.norm(res["three"][2])
 
 
 @pytest.mark.gpu
