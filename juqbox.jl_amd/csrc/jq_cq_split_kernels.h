@@ -35,6 +35,7 @@ struct Cq3Hand {
     double* ring;                     // this lane's element of block 0, array 0, slot 0
     unsigned long long *head, *gerr;
     bool dead;                        // (wave-uniform) a wait of this quad timed out, or the workgroups do not share an XCD
+    unsigned long long seen, pend;    // the upstream role's counter: last value known / value asked for by the previous wait
     static constexpr size_t SLOT = (size_t)JQ_CQ3_ARRAYS * NT * 64;
 
     __device__ __forceinline__ void init(const PropArgs& a, size_t quad, int lane_)
@@ -44,6 +45,7 @@ struct Cq3Hand {
         gerr = (unsigned long long*)a.park;
         ring = base + JQ_CQ3_HEAD + lane_;
         dead = false;
+        seen = 0ull, pend = 0ull;
     }
     __device__ __forceinline__ size_t off(int step, int arr, int blk) const { return ((size_t)(step & (JQ_CQ3_SLOTS - 1)) * JQ_CQ3_ARRAYS + arr) * NT * 64 + (size_t)blk * 64; }
     // (agent scope: a plain store may rest in the CU's vector cache for a while -- its vmcnt acknowledgement does not mean "in the L2")
@@ -60,18 +62,34 @@ struct Cq3Hand {
     {
         __hip_atomic_store(head + 8 * role, steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // wait until role `role` has finished `steps` steps (call on ONE wave; the others meet it at the next workgroup barrier)
+    // wait until role `role` has finished `steps` steps (call on ONE wave, always for the same role; the others meet it at the next
+    // workgroup barrier).  A counter read costs an L2 round trip (~ 0.5 us) and the waiting wave holds up its whole workgroup, so the
+    // read is taken off the critical path: every call folds in the value it asked for one call ago (`pend`, a load that has had a
+    // whole time step to land) and asks for the next one; it only polls when that is not enough (first version: a blocking read per
+    // step, 16 ms of the 94 ms of the adjoint workgroup at cnot3).
     __device__ __forceinline__ void wait(int role, unsigned long long steps)
     {
         if (dead) return;
-        for (int k = 0; k < JQ_CQ3_SPIN; ++k) {
-            if (__hip_atomic_load(head + 8 * role, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= steps) return;
-            if (__hip_atomic_load(head + 24, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) break;
-            __builtin_amdgcn_s_sleep(2);
+        if (pend > seen) seen = pend;
+        if (seen < steps) {
+            bool ok = false;
+            for (int k = 0; k < JQ_CQ3_SPIN; ++k) {
+                seen = __hip_atomic_load(head + 8 * role, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (seen >= steps) {
+                    ok = true;
+                    break;
+                }
+                if (__hip_atomic_load(head + 24, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (!ok) {
+                __hip_atomic_store(head + 24, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(gerr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                dead = true;
+                return;
+            }
         }
-        __hip_atomic_store(head + 24, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(gerr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        dead = true;
+        pend = __hip_atomic_load(head + 8 * role, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (used by the next call)
     }
 };
 
