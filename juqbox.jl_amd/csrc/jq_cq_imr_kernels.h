@@ -823,14 +823,17 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq_imr3(PropArgs a)
     }
     JQ_CQ_IMR_PROLOGUE
     (void)wsr;
-    if (s.chain) {      // reducer waves: one solve and the publication barrier per time step (+ the start barrier of role 1)
+    if (s.chain) {      // reducer waves: one solve and the publication barrier per time step (+ the start barrier of role 1, the last publication)
         if (role == 1) c.sync();
         for (int n = 0; n < nst; ++n) {
             m.reducer_step(wave);
             c.sync();
         }
+        c.sync();
         return;
     }
+    // (a step's stores are published one step later -- behind the barrier that follows the NEXT solve: their latency is off the
+    //  critical path; the consumers fetch a step ahead anyway)
     if (role == 0) {
         double u = st[s.foff], v = st[(size_t)KT * 64 + s.foff];
         for (int n = 0; n < nst; ++n) {
@@ -841,12 +844,15 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq_imr3(PropArgs a)
             const double u0 = u, v0 = v;
             m.template step<true>(u, v, 0.0, 0.0);      // (wave 0 reaches the step's first barrier only when the slot is free)
             c.ring.advance();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the stores of step n - 1: long acknowledged)
+            c.sync();
+            if (wave == 0 && lane_ == 0) hd.publish(0, (unsigned long long)n);
             hd.store(n, 0, wave, u0 + u);
             hd.store(n, 1, wave, v0 + v);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            c.sync();
-            if (wave == 0 && lane_ == 0) hd.publish(0, (unsigned long long)(n + 1));
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        c.sync();
+        if (wave == 0 && lane_ == 0) hd.publish(0, (unsigned long long)nst);
         st[s.foff] = u;
         st[(size_t)KT * 64 + s.foff] = v;
         return;
@@ -861,17 +867,19 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq_imr3(PropArgs a)
         m.K = c.load(c.ring.template ks<0, 1>());
         m.fold_shift();
         m.S = c.load(c.ring.template ks<1, 1>());
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (su, sv of this step have landed)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (su, sv of this step have landed; my stores of step n - 1 are acknowledged)
         const double su = hsu, sv = hsv, l0 = lr, l1 = li;
         m.template step<true>(lr, li, cfw * su, cfw * sv);
         c.ring.advance();
+        c.sync();
+        if (wave == 0 && lane_ == 0) hd.publish(1, (unsigned long long)n);      // (everybody's stores of the steps < n: acknowledged in front of the solve)
         if (n + 1 < nst) hsu = hd.load(n + 1, 0, wave), hsv = hd.load(n + 1, 1, wave);      // (role 0 has finished the steps <= n + 1: seen in front of the step's barriers)
         hd.store(n, 2, wave, l0 + lr);
         hd.store(n, 3, wave, l1 + li);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        c.sync();
-        if (wave == 0 && lane_ == 0) hd.publish(1, (unsigned long long)(n + 1));
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    c.sync();
+    if (wave == 0 && lane_ == 0) hd.publish(1, (unsigned long long)nst);
     st[(size_t)2 * KT * 64 + s.foff] = lr;
     st[(size_t)3 * KT * 64 + s.foff] = li;
 }

@@ -15,8 +15,8 @@
 //                                 blocks, forms the 5 Ncoupled scalars of the step and writes the trace record
 // through a ring of JQ_CQ3_SLOTS time steps in global memory, [slot][array][block][64] doubles per quad, with three progress counters
 // (steps finished by role 0 / 1 / 2).  Role r + 1 waits for role r's counter; role 0 waits for role 2's before it reuses a slot.
-// Everything a role stores in a step is complete before the last barrier of that step (s_waitcnt vmcnt(0) in front of it: the
-// stores are acknowledged by the L2), the counter is written behind it; the consumers read counters and data with agent-scope loads
+// Everything a role stores in a step is acknowledged by the L2 (s_waitcnt vmcnt(0)) in front of the SECOND barrier of the next step --
+// more than a publication interval later, so that the store latency is off the critical path --, the counter is written behind it; the consumers read counters and data with agent-scope loads
 // (past their CU's vector cache).  The three workgroups of a quad have block indices 24 i + j, + 8, + 16 (j < 8): workgroups are
 // handed to the eight XCDs round-robin, so the three share one XCD and its L2 -- no cache maintenance between them.  Each role checks
 // that (XCC_ID register) and that no wait exceeds ~ 1 s; otherwise it raises the error word of the quad and every wait of the quad
@@ -271,6 +271,7 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
             c.ring.issue_next();
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();      // (the block waves' last publication)
         return;
     }
     // (the tables are complete behind the barrier of ring.init)
@@ -299,11 +300,14 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
                 A = c.nbr(A, Kp05, nn);
                 P = c.nbr(P, S0, nn);
             }
-            hd.store(n, 0, wave, u);      // (behind the barrier: wave 0 has seen the slot free)
             // x = v: A = c (K05 u + S05 v) ; v05 = v + sum_j S^j A
             c.template post<P0 ^ 1, 0>(v);
             A = c.own(A, S05, c.sh(v));
+            // (the stores of step n - 1 were issued more than an interval ago: acknowledged by now, and behind the barrier by every wave)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             c.sync();
+            if (wave == 0 && lane_ == 0) hd.publish(0, (unsigned long long)n);
+            hd.store(n, 0, wave, u);      // (behind the step's first barrier: wave 0 has seen the slot free)
             A = c.nbr(A, S05, c.template nbs<P0 ^ 1, 0>());
             Op Kn0, Kn1;
             v05 = c.template horner<P0, 0, MODD>(v + A, A, S05, a.m, [&] {
@@ -340,8 +344,7 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
             c.template post<P0, 0>(un);
             v = c.own(vN, Kp05, c.sh(un));
             if (a.use_shift) v = fma(cw, un, v);
-            c.template sync<true>();      // (vmcnt(0): the three stores of the step are in the L2)
-            if (wave == 0 && lane_ == 0) hd.publish(0, (unsigned long long)(n + 1));
+            c.sync();      // (the step's stores are published behind the second barrier of the next step: their latency is off the critical path)
             v = c.nbr(v, Kp05, c.template nbs<P0, 0>());
             // (the time points of the next step have landed; those of this step are dead)
             c.ring.advance();
@@ -356,6 +359,8 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
         }
         if (n < nst) step(std::integral_constant<int, 0>{}, n);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wave == 0 && lane_ == 0) hd.publish(0, (unsigned long long)nst);
         st[s.foff] = u;
         st[(size_t)KT * 64 + s.foff] = v;
         return;
@@ -384,14 +389,15 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
             Tn = c.nbr(Tn, S05, nn);
         }
         if (n == 0) hu = hd.load(0, 0, wave), hv = hd.load(0, 1, wave), hn = hd.load(0, 2, wave);      // (first step of the chunk: latency exposed once)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (hu, hv, hn of this step have landed)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (hu, hv, hn of this step have landed; my stores of step n - 1 are acknowledged)
         const double u = hu, v05 = hv, un = hn;      // vr before the state step (:862), vi05, vr after it
-        if (n + 1 < nst) hu = hd.load(n + 1, 0, wave), hv = hd.load(n + 1, 1, wave), hn = hd.load(n + 1, 2, wave);
         // x = mu: L = c (S0 mu - K05 li + hr0) ; X = mu + sum_j S0^j L
         c.template post<P0 ^ 1, 1>(mu);
         L = c.own(L, S0, c.sh(mu));
         L = fma(cfw, u, L);
         c.sync();
+        if (wave == 0 && lane_ == 0) hd.publish(1, (unsigned long long)n);      // (everybody's stores of the steps < n are in the L2)
+        if (n + 1 < nst) hu = hd.load(n + 1, 0, wave), hv = hd.load(n + 1, 1, wave), hn = hd.load(n + 1, 2, wave);
         L = c.nbr(L, S0, c.template nbs<P0 ^ 1, 1>());
         Op Kn0, Kn1, S1;
         const double X = c.template horner<P0, 1, MODD>(mu + L, L, S0, a.m, [&] {
@@ -441,10 +447,7 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
             G = c.own(X, Kp05, sx);
             if (a.use_shift) G = fma(cw, nbn, G);
             G += SX;
-            // (vmcnt(0): the three stores of the step are in the L2 -- and the loads of the next step's u, v05, un have landed)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            c.sync();
-            if (wave == 0 && lane_ == 0) hd.publish(1, (unsigned long long)(n + 1));
+            c.sync();      // (the step's stores are published behind the second barrier of the next step)
             const Nb nn = c.template nbs<P0, 1>();
             G = c.nbr(G, Kp05, nn);
             G = fma(cfw, un, G);
@@ -463,6 +466,8 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
     }
     if (n < nst) step(std::integral_constant<int, 0>{}, n);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wave == 0 && lane_ == 0) hd.publish(1, (unsigned long long)nst);
     st[(size_t)2 * KT * 64 + s.foff] = mu;
     st[(size_t)3 * KT * 64 + s.foff] = nb;
 }
