@@ -368,3 +368,30 @@ def test_three_workgroup_kernel_falls_back_when_it_reports_a_dead_wait(jq):
     f2, g2, *_ = jq.traceobjgrad(pcof, params, wa, False, True)      # (the handle stays on the one-workgroup kernel)
     assert wa.last_timing()["reserved"] == 0 and f2 == f0 and np.array_equal(g2, g0)
     wa.close()
+
+
+@pytest.mark.gpu
+def test_three_workgroup_kernels_across_changing_ensemble_sizes(jq):
+    """One handle, ensemble sizes that move in and out of the three-workgroup regime (its hand-off buffer grows, the one-workgroup
+    kernel takes over beyond 80 samples and hands back): every result equals the one of a handle that never uses the split."""
+    params, pcof = _cq3_problem(jq, "cnot3")
+    os.environ["JQ_CQ3"] = "0"
+    try:
+        wb = jq.Working_Arrays_HIP(params, pcof.size)
+    finally:
+        os.environ.pop("JQ_CQ3", None)
+    wa = jq.Working_Arrays_HIP(params, pcof.size)
+    for ns in (1, 80, 9, 81, 2, 33, 300, 5):
+        nodes, weights, shift = jq.cases.cnot3_ensemble(ns)
+        jq.eval_f_g_grad(pcof, params, wa, nodes, weights, True, shift=shift)
+        a = (params.last_infidelity, params.last_leak, params.last_infidelity_grad.copy())
+        assert wa.last_timing()["reserved"] == (3 if ns <= 80 else 0), ns
+        os.environ["JQ_CQ3"] = "0"
+        try:
+            jq.eval_f_g_grad(pcof, params, wb, nodes, weights, True, shift=shift)
+        finally:
+            os.environ.pop("JQ_CQ3", None)
+        assert wb.last_timing()["reserved"] == 0
+        assert a[0] == params.last_infidelity and a[1] == params.last_leak and np.array_equal(a[2], params.last_infidelity_grad), ns
+    wa.close()
+    wb.close()
