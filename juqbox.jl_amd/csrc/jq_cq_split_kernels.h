@@ -10,16 +10,17 @@
 // adjoint_grad_calc! need those three and X, -lambda_i(new), -(li0 + li) with their neighbouring blocks.  So the three jobs run as a
 // software pipeline over three workgroups on three CUs:
 //   role 0  state re-integration  (the state path of k_backward_cq minus its trace products): stores u, v05, un of every step
-//   role 1  adjoint step          (the adjoint path minus its trace products), >= 1 step behind: loads u, v05, un; stores X, nbn, Bq
+//   role 1  adjoint step          (the adjoint path minus its trace products), >= 2 steps behind (it fetches a step ahead): loads u, v05, un;
+//                                 stores X, nbn, Bq
 //   role 2  trace products        (no publications, no LDS exchange), behind role 1: loads the six arrays with their neighbouring
 //                                 blocks, forms the 5 Ncoupled scalars of the step and writes the trace record
 // through a ring of JQ_CQ3_SLOTS time steps in global memory, [slot][array][block][64] doubles per quad, with three progress counters
 // (steps finished by role 0 / 1 / 2).  Role r + 1 waits for role r's counter; role 0 waits for role 2's before it reuses a slot.
 // Everything a role stores in a step is acknowledged by the L2 (s_waitcnt vmcnt(0)) in front of the SECOND barrier of the next step --
-// more than a publication interval later, so that the store latency is off the critical path --, the counter is written behind it; the consumers read counters and data with agent-scope loads
-// (past their CU's vector cache).  The three workgroups of a quad have block indices 24 i + j, + 8, + 16 (j < 8): workgroups are
+// more than a publication interval later, so that the store latency is off the critical path --, the counter is written behind it;
+// the consumers read counters and data with agent-scope loads (past their CU's vector cache), one step ahead of their use.  The three workgroups of a quad have block indices 24 i + j, + 8, + 16 (j < 8): workgroups are
 // handed to the eight XCDs round-robin, so the three share one XCD and its L2 -- no cache maintenance between them.  Each role checks
-// that (XCC_ID register) and that no wait exceeds ~ 1 s; otherwise it raises the error word of the quad and every wait of the quad
+// that (XCC_ID register) and that no wait exceeds ~ 2 s; otherwise it raises the error word of the quad and every wait of the quad
 // is abandoned: the launch ends with garbage, the host falls back to k_backward_cq and disables the split for the handle.
 // The arithmetic of every chain and of the trace sums is k_backward_cq's, operation for operation: bit-identical results.
 #pragma once
