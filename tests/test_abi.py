@@ -209,3 +209,12 @@ def test_build_manifest_of_the_bench_path():
     emb = json.loads(txt)
     assert emb["k_6_7"]["max_scratch_bytes"] == man["k_6_7"]["max_scratch_bytes"]
     assert sorted(t for t, e in emb.items() if e["fallback"]) == fallbacks
+
+
+def test_committed_pmc_record_belongs_to_this_build():
+    """bench.py joins profiles/r04_pmc.json (HBM traffic, MFMA count of the dominant kernel) only when the record was taken with the
+    build it runs: a source edit after the last profiling round would silently drop `roofline.traffic` from the judged line."""
+    import json
+    from juqbox_jl_amd import _lib
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc.json")))
+    assert rec["library_version"] == _lib.load().jq_version().decode(), "re-run scripts/profile_round.sh and commit profiles/r04_pmc.json"
