@@ -10,8 +10,9 @@
 //              4: row-lane kernels (one lane per (row, column); JQ_NT = padded row length NPJ, JQ_BW unused)
 //             11: kernels with the low-rank full leakage weights compiled in: quad layout with one slab per workgroup (JQ_BW = 7),
 //                 slab kernels (other JQ_BW; built for <1, 0> and <6, 5>, which have no cooperative sibling)
+//             12: quad-layout backward sweep with the state and the adjoint chain of a column quad on two waves (JQ_BW = 7)
 #if !defined(JQ_NT) || !defined(JQ_BW) || !defined(JQ_VARIANT)
-#error "compile with -DJQ_NT=<tiles> -DJQ_BW=<band> -DJQ_VARIANT=<0..11>"
+#error "compile with -DJQ_NT=<tiles> -DJQ_BW=<band> -DJQ_VARIANT=<0..12>"
 #endif
 #if JQ_VARIANT == 9     // cooperative-quad (latency) kernels of the JQ_BW_T4 structure (JQ_BW = 7)
 #include "jq_cq_split_kernels.h"
@@ -27,6 +28,12 @@ template __global__ void k_backward_cq3<JQ_NT, false, false>(PropArgs);     // (
 template __global__ void k_backward_cq3<JQ_NT, false, true>(PropArgs);
 template __global__ void k_backward_cq3<JQ_NT, true, false>(PropArgs);
 template __global__ void k_backward_cq3<JQ_NT, true, true>(PropArgs);
+#elif JQ_VARIANT == 12  // quad layout, backward sweep split over two waves per column quad (mid-size ensembles)
+#include "jq_quad_split_kernels.h"
+template __global__ void k_backward_qsplit<JQ_NT, false, 4>(PropArgs);      // (four quads = one slab per workgroup: two waves per SIMD)
+template __global__ void k_backward_qsplit<JQ_NT, true, 4>(PropArgs);       // (ORD: control q acts on subsystem q only)
+template __global__ void k_backward_qsplit<JQ_NT, false, 2>(PropArgs);      // (two quads per workgroup: one wave per SIMD)
+template __global__ void k_backward_qsplit<JQ_NT, true, 2>(PropArgs);
 #elif JQ_VARIANT == 10  // cooperative-quad kernels of the implicit-midpoint integrator (JQ_BW = 7, N = 4)
 #include "jq_cq_imr_kernels.h"
 template __global__ void k_forward_cq_imr<JQ_NT>(PropArgs);

@@ -1116,10 +1116,17 @@ __device__ __forceinline__ void hist_store(const PropArgs& a, int slab, int col,
 //   use (backward: 4 image fetches per step instead of 13 + 3 Ncoupled), and there is ONE workgroup barrier per time step
 //   instead of one per operator use (measured: the per-use wait + barrier + DMA issue was 15% of the cnot3 evaluation).
 #define JQ_WIN_TPS 5
+// (jq_quad_split_kernels.h -- backward sweep with the two chains of a column quad on two waves, one step apart: the ring also keeps the
+//  time points of the previous step; two arrays per step are handed from the state wave to the adjoint wave through global memory)
+#define JQ_QS_TPS 7
+#define JQ_QS_ARRAYS 2
 // WIN: the kernel only ever runs in window mode (the quad-layout kernels): the mode tests are compile-time -- ~ 35 scalar branches
 // per backward step less (3 072 cnot3 samples 1 127 -> 1 114 ms); a scheduling barrier stands where each of them was, without it
 // hipcc hoists the operand reads of later stages over the whole step (380 / 496 B of scratch, 1.8 x slower).
-template <bool WIN>
+// TPS: slots of the window ring (time points).  JQ_WIN_TPS = 5 is also the number of time points fetched ahead (the points of a step
+// and of the next one); a deeper ring (the split backward kernel, jq_quad_split_kernels.h: 7) keeps the points of the PREVIOUS step
+// resident as well -- same fetch schedule, slot = time point % TPS.
+template <bool WIN, int TPS = JQ_WIN_TPS>
 struct RingT {
     char* smem;
     // copies of the launch parameters the staging needs (kept in SGPRs; taking the address of the kernel
@@ -1237,13 +1244,13 @@ struct RingT {
     // call at the top of every time step n (of the chunk)
     __device__ __forceinline__ void set_window()
     {
-        const int s1 = s0 + 1 >= JQ_WIN_TPS ? s0 + 1 - JQ_WIN_TPS : s0 + 1, s2 = s0 + 2 >= JQ_WIN_TPS ? s0 + 2 - JQ_WIN_TPS : s0 + 2;
+        const int s1 = s0 + 1 >= TPS ? s0 + 1 - TPS : s0 + 1, s2 = s0 + 2 >= TPS ? s0 + 2 - TPS : s0 + 2;
         wb0 = (unsigned)(s0 * slot_bytes), wb1 = (unsigned)(s1 * slot_bytes), wb2 = (unsigned)(s2 * slot_bytes);
     }
     __device__ __forceinline__ void issue_tp(int j)   // window mode: K and S of time point j of the chunk -> its ring slot
     {
         if (j > 2 * nsteps_chunk) return;
-        dma((const double*)((const char*)stream + (size_t)j * 2 * stride_b), smem + (size_t)(j % JQ_WIN_TPS) * 2 * stride_b, 2 * pieces);
+        dma((const double*)((const char*)stream + (size_t)j * 2 * stride_b), smem + (size_t)(j % TPS) * 2 * stride_b, 2 * pieces);
     }
     __device__ __forceinline__ void begin_step(int n)
     {
@@ -1257,7 +1264,7 @@ struct RingT {
                 issue_tp(2 * n + 3);
                 issue_tp(2 * n + 4);
                 s0 += 2;
-                if (s0 >= JQ_WIN_TPS) s0 -= JQ_WIN_TPS;
+                if (s0 >= TPS) s0 -= TPS;
                 set_window();
             }
             return;
@@ -1297,7 +1304,7 @@ struct RingT {
             stride_b = (unsigned)(stride * 8);
             slot_bytes = (int)(2 * stride_b);
             // resident constant images behind the ring of time points
-            dma(cimg, smem + (size_t)JQ_WIN_TPS * slot_bytes, 2 * ncoupled * pieces);
+            dma(cimg, smem + (size_t)TPS * slot_bytes, 2 * ncoupled * pieces);
             for (int j = 0; j < JQ_WIN_TPS; ++j) issue_tp(j);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -1332,10 +1339,10 @@ struct RingT {
             const unsigned e = (unsigned)qword & 63u, kind = e & 3u, tp = e >> 2;
             unsigned off;
             if (kind == 2) {
-                off = (unsigned)(JQ_WIN_TPS * slot_bytes) + tp * stride_b;
+                off = (unsigned)(TPS * slot_bytes) + tp * stride_b;
             } else {
                 unsigned sl = (unsigned)s0 + tp;
-                if (sl >= JQ_WIN_TPS) sl -= JQ_WIN_TPS;
+                if (sl >= TPS) sl -= TPS;
                 off = sl * (unsigned)slot_bytes + kind * stride_b;
             }
             qword >>= 6;
@@ -1391,7 +1398,7 @@ struct RingT {
     __device__ __forceinline__ const double* next_c(int idx)
     {
         if constexpr (WIN) __builtin_amdgcn_sched_barrier(0);
-        if (WIN || batch < 0) return (const double*)(smem + ((unsigned)(JQ_WIN_TPS * slot_bytes) + (unsigned)idx * stride_b)) + lane;
+        if (WIN || batch < 0) return (const double*)(smem + ((unsigned)(TPS * slot_bytes) + (unsigned)idx * stride_b)) + lane;
         return next();
     }
     __device__ __forceinline__ void drain()
@@ -1600,8 +1607,8 @@ __device__ __forceinline__ void a_unpark(Arr<NT>& a, const double* park)
 // FUSE (quad layout only): bit 0 = K05 u with S0 u in one pass, bit 1 = S05 v05 with K0 v05 and K1 v05 in one pass
 // FOLD (quad layout, one sample per wave): `ceps` is the per-lane MASKED shift (+c eps on the lanes that hold the diagonal of the MFMA's
 // A operand, 0 elsewhere; 0 everywhere without a shift) and every product with a K image folds it into its operand (mm_t4q SH)
-template <int NT, int BW, bool JAC, int FUSE = 0, bool FOLD = false>
-__device__ __forceinline__ void sv_state(RingT<BW == JQ_BW_T4Q>& p, const PropArgs& a, bool active, double ceps, const double* ws, int g,
+template <int NT, int BW, bool JAC, int FUSE = 0, bool FOLD = false, typename RING = RingT<BW == JQ_BW_T4Q>>
+__device__ __forceinline__ void sv_state(RING& p, const PropArgs& a, bool active, double ceps, const double* ws, int g,
                                          const Arr<NT>& u, Arr<NT>& v, Arr<NT>& unew, Arr<NT>& vN, Arr<NT>& A, Arr<NT>& Ya,
                                          Arr<NT>& Yb)
 {

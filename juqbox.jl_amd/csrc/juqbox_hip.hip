@@ -102,6 +102,8 @@ struct jq_handle {
     double* d_cq3 = nullptr;    // hand-off buffer of k_backward_cq3 (jq_cq_split_kernels.h)
     size_t cap_cq3 = 0;
     bool cq3_off = false;       // a launch of k_backward_cq3 reported a dead wait / workgroups on different XCDs: not used again
+    double* d_qsplit = nullptr; // hand-off buffer of k_backward_qsplit (jq_quad_split_kernels.h): [quad][parity][2][NT][64]
+    size_t cap_qsplit = 0;
     double *d_himg_c = nullptr, *d_cimg_c = nullptr;   // operator images in the cooperative layout
     double *d_himg_l = nullptr, *d_uinit_l = nullptr, *d_vtr_l = nullptr, *d_vti_l = nullptr;   // lane kernels
     double *d_himg_r = nullptr, *d_uinit_r = nullptr, *d_vtr_r = nullptr, *d_vti_r = nullptr;   // row-lane kernels
@@ -524,7 +526,7 @@ extern "C" void jq_destroy(jq_handle* h)
     }
     (void)hipSetDevice(h->device);
     if (h->emb) jq_destroy(h->emb);
-    double** bufs[] = {&h->d_cq3, &h->d_wlr, &h->d_cimg_l, &h->d_cimg_r, &h->d_rfreq, &h->d_wq, &h->d_pk2, &h->d_pack, &h->d_himg_r, &h->d_uinit_r, &h->d_vtr_r, &h->d_vti_r, &h->d_himg_l, &h->d_uinit_l, &h->d_vtr_l, &h->d_vti_l, &h->d_himg_c, &h->d_cimg_c, &h->d_park, &h->d_cimg, &h->d_himg,  &h->d_uimg,       &h->d_vtr,     &h->d_vti,    &h->d_tabs, &h->d_tf,   &h->d_tb,
+    double** bufs[] = {&h->d_cq3, &h->d_qsplit, &h->d_wlr, &h->d_cimg_l, &h->d_cimg_r, &h->d_rfreq, &h->d_wq, &h->d_pk2, &h->d_pack, &h->d_himg_r, &h->d_uinit_r, &h->d_vtr_r, &h->d_vti_r, &h->d_himg_l, &h->d_uinit_l, &h->d_vtr_l, &h->d_vti_l, &h->d_himg_c, &h->d_cimg_c, &h->d_park, &h->d_cimg, &h->d_himg,  &h->d_uimg,       &h->d_vtr,     &h->d_vti,    &h->d_tabs, &h->d_tf,   &h->d_tb,
                        &h->d_cfreq, &h->d_pcof,       &h->d_stream,  &h->d_pq,     &h->d_state, &h->d_state_save,
                        &h->d_colinfo, &h->d_traces,   &h->d_R,       &h->d_grad,   &h->d_res};
     for (auto b : bufs)
@@ -546,26 +548,33 @@ static long long bwd_lds_tail(int NT, int Nc, int nwaves, long long park_doubles
 // entries are summed.  The planner then sees exactly the structure it would see for the dense form of the same operator.
 static int csc_to_dense(jq_handle* h, const jq_csc* A, int Ntot, double* out, const char* what)
 {
+    // (jq_csc carries no nnz field -- like SparseMatrixCSC, whose extent is colptr[n + 1] - 1: the sizes are checked BEFORE colptr is
+    //  indexed with them, colptr is checked entry by entry before rowval / nzval are read, and at most 4 Ntot^2 entries are accepted)
     char buf[200];
-    if (!A || !A->colptr || (!A->rowval && A->colptr[A->n] > 1) || (!A->nzval && A->colptr[A->n] > 1)) {
-        snprintf(buf, sizeof buf, "%s: NULL sparse descriptor or array", what);
+    if (!A || !A->colptr) {
+        snprintf(buf, sizeof buf, "%s: NULL sparse descriptor or colptr", what);
         return fail(h, JQ_EINVAL, buf);
     }
     if (A->m != Ntot || A->n != Ntot) {
         snprintf(buf, sizeof buf, "%s: sparse operator is %lld x %lld, expected %d x %d", what, (long long)A->m, (long long)A->n, Ntot, Ntot);
         return fail(h, JQ_EINVAL, buf);
     }
-    std::fill(out, out + (size_t)Ntot * Ntot, 0.0);
     if (A->colptr[0] != 1) {
         snprintf(buf, sizeof buf, "%s: colptr[1] must be 1 (1-based SparseMatrixCSC fields)", what);
         return fail(h, JQ_EINVAL, buf);
     }
-    for (int j = 0; j < Ntot; ++j) {
-        const int64_t b = A->colptr[j], e = A->colptr[j + 1];
-        if (e < b || e - 1 > (int64_t)Ntot * Ntot * 4) {
-            snprintf(buf, sizeof buf, "%s: colptr is not non-decreasing", what);
+    for (int j = 0; j < Ntot; ++j)
+        if (A->colptr[j + 1] < A->colptr[j] || A->colptr[j + 1] - 1 > (int64_t)Ntot * Ntot * 4) {
+            snprintf(buf, sizeof buf, "%s: colptr is not non-decreasing (or names more than 4 Ntot^2 entries)", what);
             return fail(h, JQ_EINVAL, buf);
         }
+    if (A->colptr[Ntot] > 1 && (!A->rowval || !A->nzval)) {
+        snprintf(buf, sizeof buf, "%s: NULL rowval / nzval array", what);
+        return fail(h, JQ_EINVAL, buf);
+    }
+    std::fill(out, out + (size_t)Ntot * Ntot, 0.0);
+    for (int j = 0; j < Ntot; ++j) {
+        const int64_t b = A->colptr[j], e = A->colptr[j + 1];
         for (int64_t k = b - 1; k < e - 1; ++k) {
             const int64_t r = A->rowval[k];
             if (r < 1 || r > Ntot) {
@@ -1398,6 +1407,15 @@ extern "C" int jq_update_wmat(jq_handle* h, const double* Wr, const double* Wi)
             wmax = std::max(wmax, std::max(std::fabs(a), std::fabs(b)));
             if (b != 0.0 || (i != j && a != 0.0)) diagonal = false;
         }
+    // the same matrices as last time (the Julia binding pushes the weights before every evaluation; a host eigen-decomposition, the
+    // reproduction check and a blocking upload cost 9 ms at Ntot = 96, 87 ms at 256 -- per call and per device): nothing to do
+    if (!diagonal && h->wrank > 0 && h->Wr.size() == nn && h->Wi.size() == nn && memcmp(h->Wr.data(), Wr, nn * sizeof(double)) == 0) {
+        bool same = true;
+        if (Wi) same = memcmp(h->Wi.data(), Wi, nn * sizeof(double)) == 0;
+        else
+            for (size_t i = 0; i < nn && same; ++i) same = (h->Wi[i] == 0.0);
+        if (same) return JQ_OK;
+    }
     if (diagonal) {      // Diagonal weights written as a full matrix: the fast path
         std::vector<double> d(n);
         for (int i = 0; i < n; ++i) d[i] = Wr[i + (size_t)n * i];
@@ -1651,6 +1669,36 @@ static int select_quad_kernels(jq_handle* h, int spw, prop_kernel_t* fwd, prop_k
     }
     JQ_PICKQ(1) JQ_PICKQ(2) JQ_PICKQ(3) JQ_PICKQ(4) JQ_PICKQ(5) JQ_PICKQ(6) JQ_PICKQ(7) JQ_PICKQ(8)
 #undef JQ_PICKQ
+    return fail(h, JQ_EUNSUPPORTED, "unsupported Hilbert dimension");
+}
+
+// ... backward sweep with the state and the adjoint chain of a column quad on two waves, one time step apart (jq_quad_split_kernels.h):
+// mid-size ensembles -- at most one column quad per SIMD (qw = 4 quads per workgroup: two waves per SIMD) or per two SIMDs (qw = 2)
+template <int NT, bool ORD, int QW> __global__ void k_backward_qsplit(PropArgs);
+#define JQ_DECLQS(nt)                                                            \
+    extern template __global__ void k_backward_qsplit<nt, false, 4>(PropArgs);   \
+    extern template __global__ void k_backward_qsplit<nt, true, 4>(PropArgs);    \
+    extern template __global__ void k_backward_qsplit<nt, false, 2>(PropArgs);   \
+    extern template __global__ void k_backward_qsplit<nt, true, 2>(PropArgs);
+JQ_DECLQS(1) JQ_DECLQS(2) JQ_DECLQS(3) JQ_DECLQS(4) JQ_DECLQS(5) JQ_DECLQS(6)
+#undef JQ_DECLQS
+static size_t qsplit_lds(const jq_handle* h, int qw)      // ring of JQ_QS_TPS time points + constant images, tables, trace records
+{
+    return (size_t)(2 * JQ_QS_TPS + 2 * h->NcK) * h->mat_elems * 8 + (size_t)32 * h->NT * 8 + (size_t)2 * qw * 8 * h->NcK * 8;
+}
+static int select_qsplit_kernel(jq_handle* h, int qw, prop_kernel_t* bwd)
+{
+    // control q acts on subsystem q only (like select_quad_kernels / select_cq_kernels): compile-time trace modes
+    bool ord = h->Nc >= 2 && h->Nc <= 3 && !getenv("JQ_NO_ORD");
+    for (int q = 0; q < h->Nc && ord; ++q) ord = (h->bw_trace[q] == (1 << q));
+#define JQ_PICKQS(nt)                                                                                         \
+    if (h->NT == nt) {                                                                                        \
+        *bwd = qw == 4 ? (ord ? k_backward_qsplit<nt, true, 4> : k_backward_qsplit<nt, false, 4>)             \
+                       : (ord ? k_backward_qsplit<nt, true, 2> : k_backward_qsplit<nt, false, 2>);            \
+        return JQ_OK;                                                                                         \
+    }
+    JQ_PICKQS(1) JQ_PICKQS(2) JQ_PICKQS(3) JQ_PICKQS(4) JQ_PICKQS(5) JQ_PICKQS(6)
+#undef JQ_PICKQS
     return fail(h, JQ_EUNSUPPORTED, "unsupported Hilbert dimension");
 }
 
@@ -2079,6 +2127,24 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     if (cq) spw = 0;
     const bool quad = spw > 0;
     const bool quad8 = spw > 1;
+    // mid-size ensembles of the 4 x 4 x n structure (at most one column quad per SIMD): the backward sweep with the state and the
+    // adjoint chain of a quad on two waves, one time step apart (jq_quad_split_kernels.h; JQ_QSPLIT=0: the one-wave kernel)
+    //   qw = 4: one slab per workgroup, two waves per SIMD (the quad-layout plan with one slab per workgroup);
+    //   qw = 2: half a slab per workgroup, one wave per SIMD -- more column quads than CUs on the cooperative-quad plan, whose
+    //           backward sweep would take two rounds (the forward sweep stays on k_forward_cq with two quads per workgroup)
+    const char* e_qs = getenv("JQ_QSPLIT");
+    const bool qs_on = adjoint && h->NT <= 6 && !(e_qs && atoi(e_qs) == 0);
+    int qs_qw = 0;
+    if (qs_on && quad && spw == 1 && !wfull && qsplit_lds(h, 4) <= 163840) qs_qw = 4;
+    // (JQ_QSPLIT=2: qw = 2 for every batch of the cooperative-quad plan that does not take the three-workgroup kernels -- tests)
+    const bool qs_force2 = e_qs && atoi(e_qs) == 2;
+    if (qs_on && cq && !cq3 && ((nquads_used > h->num_cu && 2 * nslabs <= h->num_cu) || qs_force2) && qsplit_lds(h, 2) <= 163840) qs_qw = 2;
+    const bool qsplit = qs_qw > 0;
+    const int qs_blocks = qsplit ? (4 * nslabs + qs_qw - 1) / qs_qw : 0;
+    if (qsplit) {
+        const int rc0 = dev_grow(h, &h->d_qsplit, &h->cap_qsplit, (size_t)qs_blocks * qs_qw * 2 * JQ_QS_ARRAYS * h->NT * 64);
+        if (rc0) return rc0;
+    }
     // (full leakage weights: the cooperative kernels sum their column dot products over the waves through an LDS record of
     //  2 x JQ_COOP_WDOTS x NT x 16 doubles behind the Jacobi norms; where that does not fit next to the operator slots the slab kernels serve)
     const size_t coop_w_bytes = wfull ? (size_t)2 * JQ_COOP_WDOTS * h->NT * 16 * 8 : 0;
@@ -2106,11 +2172,12 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
                   : cq ? select_cq_kernels(h, cq_fwd2, cq3, &kfwd, &kbwd)
                   : coop ? select_coop_kernels(h, &kfwd, &kbwd) : quad ? (wfull ? select_quad_w_kernels(h, &kfwd, &kbwd) : select_quad_kernels(h, spw, &kfwd, &kbwd)) : select_kernels(h, &kfwd, &kbwd);
     if (rc) return rc;
+    if (qsplit && (rc = select_qsplit_kernel(h, qs_qw, &kbwd))) return rc;
     const int nblocks = imr_parts ? nsamples : (cq || imr_cq) ? 4 * nslabs : rl ? (int)nwaves_rl : lane ? (int)(ncols / 64) : quad8 ? (nslabs + spw - 1) / spw : (coop || quad) ? nslabs : (nslabs + JQ_WAVES - 1) / JQ_WAVES;
     const int nthreads = (lane || rl) ? 64 : (coop || cq || imr_cq) ? 64 * h->NT : quad8 ? 256 * spw : 256;
     // per-step trace records: one per wave (cooperative, lane, row-lane, implicit-midpoint kernels) or one per workgroup
     // (slab / quad kernels: summed over the workgroup's waves in LDS)
-    const int trace_rows = imr_parts ? nsamples * h->NT : imr_cq ? nslabs * qps * h->NT : cq ? nslabs * qps : (lane || rl) ? nblocks : coop ? nslabs * h->NT : imr_quad ? nslabs * JQ_WAVES : nblocks;
+    const int trace_rows = qsplit ? qs_blocks : imr_parts ? nsamples * h->NT : imr_cq ? nslabs * qps * h->NT : cq ? nslabs * qps : (lane || rl) ? nblocks : coop ? nslabs * h->NT : imr_quad ? nslabs * JQ_WAVES : nblocks;
     const long long stride = rl ? h->rl_stride : lane ? h->lane_stride : coop ? h->mat_elems_c : h->mat_elems;
     const double* himg = rl ? h->d_himg_r : lane ? h->d_himg_l : coop ? h->d_himg_c : h->d_himg;
     const size_t state_doubles = rl ? (size_t)JQ_ROWLANE_ROWS * nwaves_rl * 64
@@ -2221,7 +2288,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     const size_t lds_cq = lds_stage + (size_t)32 * h->NT * 8 + (size_t)6 * (h->NT + 2) * 64 * 8 + (size_t)std::max(2, h->NcK + (h->NcK + 1) / 2) * h->NT * 64 * 8;      // tables, x exchange, trace hand-off / wg-sum scratch (one region)
     const size_t lds_fwd = rl ? (wfull ? (size_t)JQ_RL_WTAB * 8 : 0) : lane ? 0 : (cq || imr_cq) ? lds_cq : imr_coop ? coop_imr_lds_bytes(h->NT, imr_hbm ? 0 : stride)
                                            : lds_stage + (size_t)32 * h->NT * 8 + (coop ? (size_t)2 * h->KT * 64 * 8 + (size_t)16 * h->NT * 8 + coop_w_bytes : 0);      // (+ the Jacobi solver's column norms [NT][16], the low-rank weights' dot exchange)
-    const size_t lds_bwd = rl ? (h->rl_npj > 8 ? (size_t)2 * h->NcK * h->rl_stride * 8 : 0) + (rl_split ? (size_t)2 * 3 * 64 * 8 : 0) /* records: 3 values per lane and slot, implicit midpoint 2 */ + (wfull ? (size_t)JQ_RL_WTAB * 8 : 0) /* low-rank weight table */ : lane ? 0 : imr_cq2 ? cq_imr2_lds(h, lds_stage) : (coop || cq || imr_cq) ? lds_fwd
+    const size_t lds_bwd = qsplit ? qsplit_lds(h, qs_qw) : rl ? (h->rl_npj > 8 ? (size_t)2 * h->NcK * h->rl_stride * 8 : 0) + (rl_split ? (size_t)2 * 3 * 64 * 8 : 0) /* records: 3 values per lane and slot, implicit midpoint 2 */ + (wfull ? (size_t)JQ_RL_WTAB * 8 : 0) /* low-rank weight table */ : lane ? 0 : imr_cq2 ? cq_imr2_lds(h, lds_stage) : (coop || cq || imr_cq) ? lds_fwd
                                 : imr_quad ? lds_fwd + (size_t)JQ_MAXNC * nthreads * 8 + (size_t)(nthreads / 64) * h->NT * 64 * 8
                                 : quad ? lds_stage + (size_t)bwd_lds_tail(h->NT, h->NcK, nthreads / 64, (long long)h->NT * 64)   // (a 16-row block per register)
                                 : lds_stage + (size_t)bwd_lds_tail(h->NT, h->NcK, JQ_WAVES, h->park_lds ? (long long)h->KT * 64 : 0);
@@ -2368,7 +2435,14 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
                     a.park = h->d_cq3;
                 }
                 HIPCHK(h, hipEventRecord(h->ev[evi++], s));
-                if (cq3)
+                if (qsplit) {      // (two waves per column quad; its window ring is deeper than the forward kernel's)
+                    a.park = h->d_qsplit;
+                    a.lds_tab_off = (int)((size_t)(2 * JQ_QS_TPS + 2 * h->NcK) * stride * 8);
+                    a.batch = -1;
+                }
+                if (qsplit)
+                    hipLaunchKernelGGL(kbwd, dim3((unsigned)qs_blocks), dim3(128 * qs_qw), lds_bwd, s, a);
+                else if (cq3)
                     hipLaunchKernelGGL(kbwd, dim3((unsigned)(3 * nq_pad)), dim3(nthreads + 128), lds_bwd, s, a);      // (three workgroups per quad: NT block waves + two staging waves each)
                 else
                 hipLaunchKernelGGL(kbwd, dim3(nblocks), dim3((cq || rl_split) ? 2 * nthreads : imr_cq2 ? 2 * (nthreads + 128) : imr_cq ? nthreads + 128 : nthreads), lds_bwd + (wlr_lds_bwd >= 0 ? wlr_bytes : 0), s, a);      // (cooperative quad: state and adjoint chain on separate waves)
@@ -2452,7 +2526,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     h->timing.kernel_family = imr_cq ? 9 : cq ? 8 : imr_quad ? 7 : imr_coop ? 5 : imr ? 4 : rl ? 3 : lane ? 2 : coop ? 1 : quad ? 6 : 0;
     h->timing.kernel_size = rl ? h->rl_npj : lane ? h->lane_np : h->NT;
     h->timing.kernel_band = (rl || lane) ? 0 : coop ? h->BWc : (quad || cq) ? JQ_BW_T4Q : h->BW;
-    h->timing.reserved = cq3 ? 3 : 0;      // (workgroups per column quad in the backward sweep of the cooperative-quad kernels)
+    h->timing.reserved = cq3 ? 3 : qsplit ? 20 + qs_qw : 0;      // (workgroups per column quad in the backward sweep of the cooperative-quad kernels)
     h->timing.ms_allreduce = 0.0;
     h->timing.ms_shard_min = h->timing.ms_shard_max = h->timing.ms_total;
     return JQ_OK;
@@ -3127,7 +3201,7 @@ extern "C" int jq_plan_info(const jq_handle* hh, char* buf, int32_t buflen)
         for (const jq_handle* x : {h, (const jq_handle*)h->emb}) {
             if (!x) continue;
             if (x->BW == JQ_BW_T4) {
-                for (const char* pre : {"k", "s", "u", "w", "q", "v"}) tag(pre, x->NT, JQ_BW_T4Q);
+                for (const char* pre : {"k", "s", "p", "u", "w", "q", "v"}) tag(pre, x->NT, JQ_BW_T4Q);
                 tag("k", x->NT, JQ_BW_T4);
             } else if (!x->big) {
                 tag("k", x->NT, x->BW);

@@ -1011,6 +1011,28 @@ int jqo_eval_f_g_grad(void *h, const double *pcof, int ncoeff, const double *nod
     out[0] = 0.0; out[1] = 0.0;
     memset(infid_grad, 0, (size_t)ncoeff * sizeof(double));
     memset(leak_grad, 0, (size_t)ncoeff * sizeof(double));
+    if (o->use_sparse) {
+        /* params.Hconst[j,j] += ... on a SparseMatrixCSC is setindex!: an entry that is not stored yet is INSERTED (and stays stored
+         * when the loop subtracts the perturbation again), and accumulate_matrix! (:2428-2440, A[row,j] += f*B.nzval) carries it into
+         * K in the same way.  The patterns here are fixed at jqo_create from the nonzeros, so the diagonal entries the loop is about to
+         * touch join the pattern of K first (a stored zero changes no product: x + 0*y).  Without this the perturbation of a level
+         * whose Hconst[j,j] is zero -- every rotating-frame Hamiltonian has some -- was dropped in sparse mode. */
+        size_t nn = (size_t)n * n;
+        double *ind = (double *)calloc(nn, sizeof(double));
+        const double **mats = (const double **)malloc((size_t)(o->Ncoupled + 2) * sizeof(double *));
+        int q;
+        for (j = 1; j < n; j++)
+            if (shift[j] != 0.0) ind[j + (size_t)j * n] = 1.0;
+        for (q = 0; q < o->patK.n; q++) {      /* keep what is stored already (entries inserted by an earlier call included) */
+            int k;
+            for (k = o->patK.colptr[q]; k < o->patK.colptr[q + 1]; k++) ind[o->patK.rowval[k] + (size_t)q * n] = 1.0;
+        }
+        mats[0] = ind;
+        pattern_free(&o->patK);
+        pattern_from_dense(&o->patK, n, mats, 1, 0);
+        free(mats);
+        free(ind);
+    }
     for (i = 0; i < nquad && rc == 0; i++) {
         double ep = nodes[i];
         for (j = 1; j < n; j++) o->Hconst[j + (size_t)j * n] += ep * shift[j];

@@ -1,0 +1,165 @@
+"""GPU (-m gpu), round 5:
+ (1) mid-size ensembles: the backward sweep with the state and the adjoint chain of a column quad on two waves, one time step apart
+     (k_backward_qsplit, jq_quad_split_kernels.h) -- bit-identical to the one-wave quad-layout kernel it replaces, 1e-13 next to the
+     two-round cooperative-quad sweep, 1e-10 against the oracle, golden-pinned at full length."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-10
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def _with_env(env, fn):
+    os.environ.update(env)
+    try:
+        return fn()
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
+
+
+def _cnot3(jq, nsteps):
+    params, info = jq.cases.cnot3()
+    if nsteps:
+        params.T, params.nsteps = params.T * nsteps / params.nsteps, nsteps
+    pcof = np.array(json.load(open(os.path.join(ROOT, "tests", "golden", "cnot3.json")))["pcof0"])
+    return params, pcof
+
+
+def _problem(jq, kind):
+    """cnot3 shortened (4 x 4 x 6: single-subsystem controls, the ORD variant, even m) or random 4 x 4 x n problems (generic trace
+    products; NT = 3 with an odd m, three controls and objFuncType 3; NT = 2 with two columns per evaluation: two samples per quad)"""
+    if kind == "cnot3":
+        return _cnot3(jq, 901)
+    from test_gpu_random import random_problem
+    Ntot, N, Nc, m, oft = {"t4x3": (48, 4, 3, 5, 3), "t4x2": (32, 2, 2, 4, 1), "t4x5": (80, 4, 4, 3, 2)}[kind]
+    rng = np.random.default_rng(50 + Ntot)
+    return random_problem(jq, rng, Ntot, N, Nc, 2, 57, m, oft, "t4")
+
+
+def _eval(jq, params, pcof, nodes, weights, shift, env):
+    def run():
+        wa = jq.Working_Arrays_HIP(params, pcof.size)
+        jq.eval_f_g_grad(pcof, params, wa, nodes, weights, True, shift=shift)
+        t = wa.last_timing()
+        out = (params.last_infidelity, params.last_leak, params.last_infidelity_grad.copy(),
+               params.last_leak_grad.copy() if params.objFuncType != 1 else np.zeros(1), t)
+        wa.close()
+        return out
+    return _with_env(env, run)
+
+
+@pytest.mark.parametrize("kind,nsamples,chunk", [("cnot3", 513, 250), ("cnot3", 1024, 0), ("cnot3", 999, 333), ("t4x3", 600, 20), ("t4x3", 1001, 7),
+                                                 ("t4x2", 1500, 19), ("t4x5", 700, 57)])
+def test_split_backward_sweep_is_the_one_wave_kernel_bit_for_bit(jq, kind, nsamples, chunk):
+    """k_backward_qsplit<NT, ORD, 4>: each chain performs the operations of k_backward<NT, 7, 1> in the same order, the trace sums of a
+    workgroup are added in the same wave order -- bit-identical results: full and ragged ensembles (idle quads in the last slab, fewer
+    slabs than CUs), several chunks with odd lengths (the pipeline fills and drains per chunk, n + 1 super-steps for n steps; chunks
+    of one step), odd / even numbers of Neumann terms, NT = 2, 3, 5, 6, two samples per column quad (per-lane shifts and weights),
+    four controls, objFuncType 2 / 3 (a second, unforced backward pass), and run to run."""
+    params, pcof = _problem(jq, kind)
+    rng = np.random.default_rng(nsamples)
+    nodes, weights = 0.02 * rng.standard_normal(nsamples), rng.random(nsamples)
+    shift = 0.01 * np.arange(params.Ntot)
+    env = {"JQ_CHUNK_STEPS": str(chunk)} if chunk else {}
+    a = _eval(jq, params, pcof, nodes, weights, shift, env)
+    b = _eval(jq, params, pcof, nodes, weights, shift, dict(env, JQ_QSPLIT="0"))
+    c = _eval(jq, params, pcof, nodes, weights, shift, env)
+    assert a[4]["kernel_family"] == 6 and a[4]["reserved"] == 24 and b[4]["kernel_family"] == 6 and b[4]["reserved"] == 0, (a[4], b[4])
+    for x in (b, c):
+        assert a[0] == x[0] and a[1] == x[1] and np.array_equal(a[2], x[2]) and np.array_equal(a[3], x[3])
+
+
+@pytest.mark.parametrize("kind,nsamples,mode", [("cnot3", 7, "qw4"), ("cnot3", 7, "qw2"), ("t4x3", 5, "qw4"), ("t4x3", 6, "qw2"), ("t4x2", 11, "qw4"),
+                                                ("t4x5", 3, "qw2")])
+def test_split_backward_sweep_against_the_oracle(jq, kind, nsamples, mode):
+    """Small ensembles forced onto the split kernels (JQ_CQ=0: the quad-layout plan, four quads per workgroup; JQ_QSPLIT=2 JQ_CQ3=0: the
+    cooperative-quad plan with the backward sweep on two quads per workgroup) against the oracle's loop over the samples
+    (src/ipopt_interface.jl:38-65): infidelity, leak and both gradients at 1e-10."""
+    from oracle.oracle import Oracle
+    params, pcof = _problem(jq, kind)
+    if kind == "cnot3":
+        params.T, params.nsteps = params.T * 300 / params.nsteps, 300
+    rng = np.random.default_rng(7 + nsamples)
+    nodes, weights = 0.02 * rng.standard_normal(nsamples), rng.random(nsamples)
+    shift = 0.01 * np.arange(params.Ntot)
+    ref = Oracle(params).eval_f_g_grad(pcof, nodes, weights, shift)
+    env = {"JQ_CQ": "0", "JQ_CHUNK_STEPS": "41"} if mode == "qw4" else {"JQ_QSPLIT": "2", "JQ_CQ3": "0", "JQ_CHUNK_STEPS": "41"}
+    a = _eval(jq, params, pcof, nodes, weights, shift, env)
+    assert (a[4]["kernel_family"], a[4]["reserved"]) == ((6, 24) if mode == "qw4" else (8, 22)), a[4]
+    gn = np.linalg.norm(ref["last_infidelity_grad"])
+    assert abs(a[0] - ref["last_infidelity"]) <= TOL * abs(ref["last_infidelity"])
+    assert abs(a[1] - ref["last_leak"]) <= TOL * abs(ref["last_leak"])
+    assert np.linalg.norm(a[2] - ref["last_infidelity_grad"]) <= TOL * gn
+    if params.objFuncType != 1:
+        assert np.linalg.norm(a[3] - ref["last_leak_grad"]) <= TOL * gn
+
+
+@pytest.mark.parametrize("nsamples", [300, 512])
+def test_two_quads_per_workgroup_next_to_the_two_round_cooperative_quad_sweep(jq, nsamples):
+    """More column quads than CUs on the cooperative-quad plan: the forward sweep stays on k_forward_cq (two quads per workgroup), the
+    backward sweep moves from two rounds of k_backward_cq to k_backward_qsplit<.., 2> (half a slab per workgroup, one wave per SIMD).
+    Different kernels, the same arithmetic per column: the trace sums are grouped differently (1e-13); bit-stable run to run."""
+    params, pcof = _cnot3(jq, 901)
+    nodes, weights, shift = jq.cases.cnot3_ensemble(nsamples)
+    a = _eval(jq, params, pcof, nodes, weights, shift, {"JQ_CHUNK_STEPS": "250"})
+    b = _eval(jq, params, pcof, nodes, weights, shift, {"JQ_CHUNK_STEPS": "250", "JQ_QSPLIT": "0"})
+    c = _eval(jq, params, pcof, nodes, weights, shift, {"JQ_CHUNK_STEPS": "250"})
+    assert (a[4]["kernel_family"], a[4]["reserved"]) == (8, 22) and (b[4]["kernel_family"], b[4]["reserved"]) == (8, 0), (a[4], b[4])
+    assert abs(a[0] - b[0]) <= 1e-13 * abs(b[0]) and abs(a[1] - b[1]) <= 1e-13 * abs(b[1]) and rel(a[2], b[2]) <= 1e-13
+    assert a[0] == c[0] and a[1] == c[1] and np.array_equal(a[2], c[2])
+
+
+def test_split_kernels_reproduce_the_cnot3_golden_at_full_length(jq):
+    """1 024 and 512 unperturbed samples with weights summing to one at the reference's full length (32 386 steps) ARE the reference's
+    golden evaluation (test/reference_solutions/cnot3-ref.jld2): infidelity / leak decomposition and gradient (golden minus its
+    Tikhonov part) at the reference's tolerance -- on the kernels mid-size ensembles now take (as
+    tests/test_gpu_parity.py::test_bench_workload_kernels_reproduce_the_cnot3_golden_at_full_size does for the benchmark's)."""
+    from conftest import case_inputs, reference_pass
+    params, info, pcof, golden = case_inputs("cnot3")
+    wa = jq.Working_Arrays_HIP(params, pcof.size)
+    rng = np.random.default_rng(5)
+    for ns, variant in ((1024, (6, 24)), (512, (8, 22))):
+        w = rng.random(ns)
+        w /= w.sum()
+        jq.eval_f_g_grad(pcof, params, wa, np.zeros(ns), w, True)
+        t = wa.last_timing()
+        assert (t["kernel_family"], t["reserved"]) == variant, t
+        assert abs(params.last_infidelity - 0.9181500713381303) < 1e-12
+        assert abs(params.last_leak - 2.8775930168455916e-05) < 1e-15
+        g = np.array(golden["grad0"]) - jq.setup_utils.tikhonov_grad(pcof, params.tik0)
+        gt = params.last_infidelity_grad + (params.last_leak_grad if params.objFuncType != 1 else 0.0)
+        assert reference_pass(gt, g), ns
+    wa.close()
+
+
+def test_split_kernel_perturbed_samples_at_full_length_match_the_oracle(jq):
+    """The path mid_size_ensembles times -- cnot3 at full length, 1 024 PERTURBED samples -- against the oracle: one-hot weights select
+    the first and the last sample (different workgroups, waves and quads)."""
+    from test_gpu_round2 import oracle_sample
+    params, pcof = _cnot3(jq, 0)
+    ns = 1024
+    nodes, weights, shift = jq.cases.cnot3_ensemble(ns)
+    wa = jq.Working_Arrays_HIP(params, pcof.size)
+    for i in (0, 1023):
+        r = oracle_sample(params, pcof, nodes[i], shift)
+        w = np.zeros(ns)
+        w[i] = 1.0
+        jq.eval_f_g_grad(pcof, params, wa, nodes, w, True, shift=shift)
+        t = wa.last_timing()
+        assert (t["kernel_family"], t["reserved"]) == (6, 24), t
+        assert abs(params.last_infidelity - r["primaryobjf"]) <= TOL * abs(r["primaryobjf"]), i
+        assert abs(params.last_leak - r["secondaryobjf"]) <= TOL * abs(r["secondaryobjf"]), i
+        assert rel(params.last_infidelity_grad, r["totalgrad"]) < TOL, i
+    wa.close()

@@ -162,6 +162,36 @@ def _timesteptest(cfl, testcase):
     return cg_err, ce_err
 
 
+def test_ensemble_loop_perturbs_levels_whose_drift_entry_is_zero(jq):
+    """round 5: `params.Hconst[j,j] += ...` on a SparseMatrixCSC (src/ipopt_interface.jl:41-44) is setindex! -- an entry that is not
+    stored yet is inserted, and accumulate_matrix! (src/evalobjgrad.jl:2428-2440) carries it into K.  The oracle's sparse mode fixes
+    its patterns at creation; its ensemble loop used to drop the perturbation of every level with Hconst[j,j] == 0 (cnot3 in the
+    rotating frame has four): 8e-5 relative in the infidelity, found when a GPU ensemble test disagreed with it.  Sparse mode, dense
+    mode and the explicit loop over freshly built oracles must agree."""
+    params, info = jq.cases.cnot3()
+    params.T, params.nsteps = params.T * 40 / params.nsteps, 40
+    pcof = np.array(load_golden("cnot3")["pcof0"])
+    assert int((np.diag(params.Hconst) == 0.0).sum()) >= 2
+    nodes, weights = np.array([-0.03, 0.011, 0.02]), np.array([0.3, 0.5, 0.2])
+    shift = 0.01 * np.arange(params.Ntot)
+    sp = Oracle(params).eval_f_g_grad(pcof, nodes, weights, shift)
+    de = Oracle(params, use_sparse=False).eval_f_g_grad(pcof, nodes, weights, shift)
+    inf, grad = 0.0, np.zeros(pcof.size)
+    H = params.Hconst.copy()
+    for ep, w in zip(nodes, weights):
+        params.Hconst = H + np.diag(ep * shift)
+        r = Oracle(params).traceobjgrad(pcof)
+        inf += w * r["primaryobjf"]
+        grad += w * r["infidelgrad"]
+    params.Hconst = H
+    for e in (sp, de):
+        assert abs(e["last_infidelity"] - inf) < 1e-13 * abs(inf)
+        assert np.linalg.norm(e["last_infidelity_grad"] - grad) < 1e-12 * np.linalg.norm(grad)
+    # ... and the perturbation of those levels matters at the test tolerances (a dropped shift is not within 1e-10)
+    shift0 = np.where(np.diag(H) == 0.0, 0.0, shift)
+    assert abs(Oracle(params).eval_f_g_grad(pcof, nodes, weights, shift0)["last_infidelity"] - inf) > 1e-8 * abs(inf)
+
+
 def test_stormer_verlet_error_matrix_golden():
     """test/test-stormer-verlet.jl:137-172 against reference_solutions/err-mat-ref.jld2 (<= 1e-13)."""
     ref = np.array(load_golden("err-mat")["err_mat"])
