@@ -24,6 +24,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -101,7 +103,16 @@ struct jq_handle {
     double *d_cimg = nullptr, *d_park = nullptr;
     double* d_cq3 = nullptr;    // hand-off buffer of k_backward_cq3 (jq_cq_split_kernels.h)
     size_t cap_cq3 = 0;
-    bool cq3_off = false;       // a launch of k_backward_cq3 reported a dead wait / workgroups on different XCDs: not used again
+    // Three-workgroup latency kernels (k_backward_cq3 / k_backward_cq_imr3): their workgroups wait for each other, so all of them must be
+    // resident at once.  Inside this process that is CHECKED (DevGate below: the split is taken only while no other evaluation runs on
+    // the device, and nothing else starts until it is through); what other processes, CU masks or a partitioned device do cannot be
+    // seen from here -- a wait that is declared dead raises the error word, the evaluation is repeated without the split (the word is
+    // read after the FIRST backward launch), and the handle leaves the split alone for cq3_skip evaluations (4, 8, 16 ... per fault;
+    // for good after JQ_CQ3_MAX_FAULTS faults).
+    bool cq3_off = false;       // never again on this handle (too many faults)
+    int cq3_faults = 0;         // launches that reported a dead wait / workgroups on different XCDs
+    int cq3_skip = 0;           // evaluations left for which the split is not tried
+    std::string cq3_last;       // why the last batch of the latency families did / did not take the split (jq_plan_info)
     double* d_qsplit = nullptr; // hand-off buffer of k_backward_qsplit (jq_quad_split_kernels.h): [quad][parity][2][NT][64]
     size_t cap_qsplit = 0;
     double *d_himg_c = nullptr, *d_cimg_c = nullptr;   // operator images in the cooperative layout
@@ -1921,14 +1932,72 @@ __global__ void k_add_to(double* __restrict__ y, const double* __restrict__ x, i
 
 // The batched evaluation behind every hot-path entry point.
 // d_packed != nullptr: the packed ensemble result (k_pack) is also left at this DEVICE address of h's GPU.
-#define JQ_ERETRY_INTERNAL (-1000)      // run_eval_impl: k_backward_cq3 gave up (the handle no longer uses it): evaluate again
+#define JQ_ERETRY_INTERNAL (-1000)      // run_eval_impl: k_backward_cq3 gave up (the handle leaves it alone for a while): evaluate again
+#define JQ_CQ3_MAX_FAULTS 6
+// Evaluations in flight per device, process-wide.  Every outermost run_eval is counted (enter / leave); an evaluation that wants the
+// three-workgroup latency kernels asks for the device EXCLUSIVELY (try_exclusive: granted when it is the only one in flight) and new
+// evaluations then wait at enter() until it is through (one latency evaluation: ~ 0.15 s at cnot3).  So inside a process a grid whose
+// workgroups wait for each other never shares the GPU with another launch of the library -- the co-residency it needs is checked,
+// not assumed (two handles in two threads, the sub-handles of a same-device multi handle, ...).
+struct DevGate {
+    std::mutex m;
+    std::condition_variable cv;
+    int active = 0;
+    bool exclusive = false;
+    void enter()
+    {
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return !exclusive; });
+        ++active;
+    }
+    void leave()
+    {
+        std::lock_guard<std::mutex> l(m);
+        --active;
+    }
+    bool try_exclusive()      // (the caller is one of the active evaluations)
+    {
+        std::lock_guard<std::mutex> l(m);
+        if (exclusive || active != 1) return false;
+        exclusive = true;
+        return true;
+    }
+    void release_exclusive()
+    {
+        {
+            std::lock_guard<std::mutex> l(m);
+            exclusive = false;
+        }
+        cv.notify_all();
+    }
+};
+static DevGate g_gate[64];
+static DevGate& dev_gate(int device) { return g_gate[(unsigned)device % 64u]; }
+static thread_local int g_eval_depth = 0;      // run_eval calls itself (split batches, the embedded twin): only the outermost call is counted
+struct GateHold {      // exclusive use of a device for the rest of a scope
+    DevGate* g = nullptr;
+    bool acquire(DevGate& gate)
+    {
+        if (gate.try_exclusive()) g = &gate;
+        return g != nullptr;
+    }
+    ~GateHold()
+    {
+        if (g) g->release_exclusive();
+    }
+};
 static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamples, const double* eps, const double* wgt,
                          const double* shift, bool adjoint, double* hist_r, double* hist_i, EvalOut* out, double* d_packed);
 static int run_eval(jq_handle* h, const double* pcof, int ncoeff, int nsamples, const double* eps, const double* wgt,
                     const double* shift, bool adjoint, double* hist_r, double* hist_i, EvalOut* out, double* d_packed = nullptr)
 {
+    DevGate& gate = dev_gate(h->device);
+    const bool outer = g_eval_depth++ == 0;
+    if (outer) gate.enter();
     int rc = run_eval_impl(h, pcof, ncoeff, nsamples, eps, wgt, shift, adjoint, hist_r, hist_i, out, d_packed);
     if (rc == JQ_ERETRY_INTERNAL) rc = run_eval_impl(h, pcof, ncoeff, nsamples, eps, wgt, shift, adjoint, hist_r, hist_i, out, d_packed);
+    if (outer) gate.leave();
+    --g_eval_depth;
     return rc;
 }
 static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamples, const double* eps, const double* wgt,
@@ -2112,7 +2181,24 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     const long long nq_pad = (4LL * nslabs + 7) / 8 * 8;
     const char* e_c3 = getenv("JQ_CQ3");
     // (not for the sub-handles of the same-device test mode: their launches share the GPU, the workgroups of a quad might not all be resident)
-    const bool cq3 = (cq || imr_cq) && adjoint && !h->cq3_off && 3 * nq_pad <= h->num_cu && !(e_c3 && atoi(e_c3) == 0) && !getenv("JQ_MULTI_SAME_DEVICE");
+    // Co-residency is checked, not assumed: the split is taken only when this evaluation is the only one of the process on the device
+    // (GateHold: others then wait until it is through), when no CU mask is in force (the grid is sized for all CUs the device
+    // reports), and not while the handle is cooling down after a fault.
+    GateHold gate_hold;
+    bool cq3 = false;
+    if ((cq || imr_cq) && adjoint) {
+        const char* why = nullptr;
+        if (e_c3 && atoi(e_c3) == 0) why = "not taken: JQ_CQ3=0";
+        else if (3 * nq_pad > h->num_cu) why = "not taken: three workgroups per column quad exceed the compute units";
+        else if (h->cq3_off) why = "not taken: switched off after repeated faults (dead waits between the workgroups of a quad)";
+        else if (h->cq3_skip > 0) why = "not taken: cooling down after a fault";
+        else if (getenv("HSA_CU_MASK") || getenv("ROC_GLOBAL_CU_MASK")) why = "not taken: a CU mask is set (HSA_CU_MASK / ROC_GLOBAL_CU_MASK)";
+        else if (g_eval_depth != 1) why = "not taken: nested evaluation (part of a split batch / embedded twin)";
+        else if (!gate_hold.acquire(dev_gate(h->device))) why = "not taken: another evaluation of this process is in flight on the device";
+        cq3 = (why == nullptr);
+        if (h->cq3_skip > 0) --h->cq3_skip;
+        h->cq3_last = cq3 ? "taken: three workgroups per column quad, device held exclusively" : why;
+    }
     const size_t cq3_quad = 64 + (size_t)8 * 6 * h->NT * 64;      // doubles per quad: JQ_CQ3_HEAD + JQ_CQ3_SLOTS * JQ_CQ3_ARRAYS * NT * 64
     const size_t cq3_need = 64 + (size_t)nq_pad * cq3_quad;
     if (cq3) {
@@ -2384,6 +2470,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     // ---- backward sweep(s) ---------------------------------------------------------------------
     // one sweep per (control group, forcing): the forced adjoint gives the total gradient, the unforced one (objFuncType != 1)
     // the infidelity gradient; every sweep restarts from the state the forward sweep and the terminal kernel left behind
+    unsigned long long cq3_fault = 0;
     if (adjoint) {
         const int nsweeps = (two_pass ? 2 : 1) * ngroups;
         if (nsweeps > 1)
@@ -2430,8 +2517,9 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
                         sched_pack(&a.pro_bits, q, 2, q);          // first chunk: carry products with Hsym_q
                     }
                 }
-                if (cq3) {      // (progress counters and rings of the launch; the error word in front survives until the end of the evaluation)
-                    HIPCHK(h, hipMemsetAsync(h->d_cq3 + 64, 0, (cq3_need - 64) * sizeof(double), s));
+                if (cq3) {      // (progress counters of the launch: the 64-double header in front of every quad's ring -- the ring itself is written
+                                // before it is read; the error word in front of everything survives until the end of the evaluation)
+                    HIPCHK(h, hipMemset2DAsync(h->d_cq3 + 64, cq3_quad * sizeof(double), 0, 64 * sizeof(double), (size_t)nq_pad, s));
                     a.park = h->d_cq3;
                 }
                 HIPCHK(h, hipEventRecord(h->ev[evi++], s));
@@ -2447,6 +2535,18 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
                 else
                 hipLaunchKernelGGL(kbwd, dim3(nblocks), dim3((cq || rl_split) ? 2 * nthreads : imr_cq2 ? 2 * (nthreads + 128) : imr_cq ? nthreads + 128 : nthreads), lds_bwd + (wlr_lds_bwd >= 0 ? wlr_bytes : 0), s, a);      // (cooperative quad: state and adjoint chain on separate waves)
                 HIPCHK(h, hipEventRecord(h->ev[evi++], s));
+                if (cq3 && sweep == 0 && n0 == 0) {
+                    // the first launch of the split says whether its workgroups were resident together: read the error word now instead
+                    // of running every other chunk and sweep (each dead wait costs ~ 2 s) before the evaluation is repeated anyway
+                    unsigned long long e1 = 0;
+                    HIPCHK(h, hipMemcpyAsync(&e1, h->d_cq3, sizeof(e1), hipMemcpyDeviceToHost, s));
+                    HIPCHK(h, hipStreamSynchronize(s));
+                    if (getenv("JQ_CQ3_FAULT")) e1 = 1;      // (test hook: as if a wait of k_backward_cq3 had been abandoned)
+                    if (e1) {
+                        cq3_fault = e1;
+                        break;
+                    }
+                }
                 hipLaunchKernelGGL(k_trace_reduce, dim3((unsigned)(((long long)nc * ntr_g + 255) / 256)), dim3(256), 0, s,
                                    h->d_traces, trace_rows, nc, ntr_g, h->d_R);
                 // gradbcarrier2! as a scatter: one workgroup per coefficient of the group's controls
@@ -2455,6 +2555,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
                 mfma += (long long)nslabs * nc * (2 * (8 + 2 * h->m) * tiles + 4 * trace_tiles);
                 if (n0 == 0) mfma += (long long)nslabs * trace_tiles;
             }
+            if (cq3_fault) break;
         }
     }
     HIPCHK(h, hipGetLastError());
@@ -2481,8 +2582,8 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
                                      hipMemcpyDeviceToHost, s));
         }
     }
-    unsigned long long cq3_err = 0;
-    if (cq3) HIPCHK(h, hipMemcpyAsync(&cq3_err, h->d_cq3, sizeof(cq3_err), hipMemcpyDeviceToHost, s));
+    unsigned long long cq3_err = cq3_fault;
+    if (cq3 && !cq3_fault) HIPCHK(h, hipMemcpyAsync(&cq3_err, h->d_cq3, sizeof(cq3_err), hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
     if (cq3 && getenv("JQ_DEBUG_TIMING")) {      // development aid: progress counters, error word and XCC ids (+ 1) of the first quads
         std::vector<unsigned long long> hw((size_t)64 + 2 * cq3_quad);
@@ -2494,7 +2595,9 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     }
     if (cq3 && getenv("JQ_CQ3_FAULT")) cq3_err = 1;      // (test hook: as if a wait of k_backward_cq3 had been abandoned)
     if (cq3_err) {      // a wait between the three workgroups of a quad was abandoned (1), or they ran on different XCDs (2): the results are void
-        h->cq3_off = true;
+        ++h->cq3_faults;
+        h->cq3_skip = 2 << std::min(h->cq3_faults, 10);      // (4, 8, 16, ... evaluations; the repeat below counts as one)
+        if (h->cq3_faults >= JQ_CQ3_MAX_FAULTS) h->cq3_off = true;
         if (getenv("JQ_DEBUG_TIMING")) fprintf(stderr, "jq: k_backward_cq3 reported %llu -- evaluated again with k_backward_cq\n", cq3_err);
         return JQ_ERETRY_INTERNAL;
     }
@@ -3225,6 +3328,12 @@ extern "C" int jq_plan_info(const jq_handle* hh, char* buf, int32_t buflen)
         kv("build", std::string("{\"manifest\": ") + (man.size() > 2 ? "true" : "false") + ", \"objects\": " + objs + "}");
     }
     kv("full_weight_rank", num(h->wrank));
+    {   // the three-workgroup latency kernels: what the last batch of the cooperative-quad families decided, and why
+        const jq_handle* t2 = h->emb ? h->emb : h;
+        const std::string d = t2->cq3_last.empty() ? "no batch of the cooperative-quad families yet" : t2->cq3_last;
+        kv("latency_split", std::string("{\"last_decision\": \"") + d + "\", \"faults\": " + num(t2->cq3_faults) + ", \"cooling_down\": " + num(t2->cq3_skip) +
+                                ", \"off\": " + (t2->cq3_off ? "true" : "false") + "}");
+    }
     o += "}";
     if (buflen > 0) {
         const size_t n = std::min(o.size(), (size_t)buflen - 1);

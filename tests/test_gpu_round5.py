@@ -163,3 +163,70 @@ def test_split_kernel_perturbed_samples_at_full_length_match_the_oracle(jq):
         assert abs(params.last_leak - r["secondaryobjf"]) <= TOL * abs(r["secondaryobjf"]), i
         assert rel(params.last_infidelity_grad, r["totalgrad"]) < TOL, i
     wa.close()
+
+
+# ---- (2) the three-workgroup latency kernels check the co-residency they need -------------------------------------------------------
+
+def test_two_handles_in_two_threads_in_the_split_regime(jq):
+    """verdict, round 4: k_backward_cq3's workgroups wait for each other, HIP promises neither their placement nor their co-residency,
+    and two handles launching split grids on one GPU at the same time is where co-residency really breaks (every quad could burn its
+    ~ 2 s timeout).  Round 5: inside a process the split takes the device EXCLUSIVELY (DevGate) -- an evaluation takes it only when
+    no other evaluation of the process is in flight there, and others wait until it is through.  Two threads, each with its own
+    handle, 12 evaluations each: every result bit-identical to the single-threaded one, no fault recorded, and the wall time bounded by
+    the serial time of all 24 evaluations (+ 50 %: thread start-up, the other thread's forward sweep in front of the gate) -- not by
+    timeouts."""
+    import threading
+    import time
+    params, pcof = _cnot3(jq, 2000)
+    nodes, weights, shift = jq.cases.cnot3_ensemble(9)
+    was = [jq.Working_Arrays_HIP(params, pcof.size) for _ in range(2)]
+    ps = [params, _cnot3(jq, 2000)[0]]      # (the mirror keeps the results on the params object: one per thread)
+    jq.eval_f_g_grad(pcof, ps[0], was[0], nodes, weights, True, shift=shift)
+    assert was[0].last_timing()["reserved"] == 3
+    ref = (ps[0].last_infidelity, ps[0].last_leak, ps[0].last_infidelity_grad.copy())
+    jq.eval_f_g_grad(pcof, ps[1], was[1], nodes, weights, True, shift=shift)      # (warm-up of the second handle)
+    t0 = time.perf_counter()
+    for k in range(4):
+        jq.eval_f_g_grad(pcof, ps[0], was[0], nodes, weights, True, shift=shift)
+    t_one = (time.perf_counter() - t0) / 4
+    bad, splits = [], [0, 0]
+
+    def work(i):
+        for k in range(12):
+            jq.eval_f_g_grad(pcof, ps[i], was[i], nodes, weights, True, shift=shift)
+            splits[i] += was[i].last_timing()["reserved"] == 3
+            if not (ps[i].last_infidelity == ref[0] and ps[i].last_leak == ref[1] and np.array_equal(ps[i].last_infidelity_grad, ref[2])):
+                bad.append((i, k))
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    wall = time.perf_counter() - t0
+    assert not bad, bad
+    for wa in was:
+        ls = wa.plan_info()["latency_split"]
+        assert ls["faults"] == 0 and ls["off"] is False, ls
+        wa.close()
+    assert sum(splits) >= 12, splits                     # (whoever finds the device free takes the split)
+    assert wall <= 1.5 * 24 * t_one + 0.5, (wall, t_one)
+
+
+def test_same_device_sub_handles_never_take_the_split(jq):
+    """The sub-handles of a same-device multi handle (JQ_MULTI_SAME_DEVICE test mode) evaluate their shards at the same time on one GPU:
+    none of them may hold the device exclusively -- decided by the gate now, not by reading the environment variable."""
+    params, pcof = _cnot3(jq, 600)
+    nodes, weights, shift = jq.cases.cnot3_ensemble(12)
+    single = _eval(jq, params, pcof, nodes, weights, shift, {})
+    assert single[4]["reserved"] == 3
+
+    def run():
+        wam = jq.Working_Arrays_HIP(params, pcof.size, devices=3)
+        jq.eval_f_g_grad(pcof, params, wam, nodes, weights, True, shift=shift)
+        out = (params.last_infidelity, params.last_infidelity_grad.copy(), wam.plan_info()["latency_split"])
+        wam.close()
+        return out
+    inf, grad, ls = _with_env({"JQ_MULTI_SAME_DEVICE": "1"}, run)
+    assert abs(inf - single[0]) <= 1e-13 * abs(single[0]) and rel(grad, single[2]) <= 1e-12
+    assert ls["faults"] == 0 and (ls["last_decision"].startswith("not taken: another evaluation") or ls["last_decision"].startswith("taken")), ls
