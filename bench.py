@@ -31,7 +31,7 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak: 256 CU x 4 SIMD x 32 F
                                # (v_mfma_f64_16x16x4_f64 issues every 64 clk; measured 75.4 TF, probes/)
 STRONG_TOTAL_SAMPLES = 24576   # fixed ensemble of the strong-scaling run = 8 GPUs x one full round (3072 samples) each
 STRONG_SMALL_SAMPLES = 4096    # second, SUB-SATURATING strong-scaling point: 8 GPUs get 512 samples each (latency regime)
-PMC_FILES = ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json")   # rocprofv3 PMC summaries (profiles/); used only when recorded for THIS build
+PMC_FILES = ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json")   # rocprofv3 PMC summaries (profiles/); used only when recorded for THIS build
 
 
 def parse_args():
@@ -48,6 +48,8 @@ def parse_args():
                     help="one process, --gpus devices behind one multi-device handle (RCCL inside the library)")
     ap.add_argument("--strong-samples", type=int, default=STRONG_TOTAL_SAMPLES)
     ap.add_argument("--strong-small-samples", type=int, default=STRONG_SMALL_SAMPLES)
+    ap.add_argument("--dense-only", type=int, default=0, metavar="SAMPLES",
+                    help="profiling runs: only the dense_operator block at this batch size (one full-length evaluation), printed as the line")
     ap.add_argument("--quick-extras", action="store_true",
                     help="tests: keep the strong-scaling points and a one-repetition CPU baseline, skip the other side measurements")
     return ap.parse_args()
@@ -180,6 +182,84 @@ def issue_bound(launch_s, steps_per_launch, products_per_step, waves_per_simd):
                     "nominal; every instruction of the kernel -- scalar, branch, wait -- costs the SIMD ~4.6 clk (DESIGN.md section 6)"}
 
 
+def dense_operator_block(jq, L, pcof, quick=False, samples=None):
+    """north_star's "dense (H x state-batch) contraction": cnot3's dimensions with a dense Hermitian drift (cases.cnot3_dense) -- the
+    path every user Hamiltonian without Kronecker structure takes: dense 16 x 16 x 4 fp64 MFMA tiles, k_forward / k_backward<6, 5>, one
+    wave per 16-column slab.  Outside the timed region of `value`.  Batch size: the best of a few candidates at 2 000 steps, then ONE
+    evaluation at the reference's full length (32 386 steps).  The fraction is EXECUTED fp64 MFMA FLOP (library count, checked against
+    the PMC record of profiles/ when it belongs to this build) over HIP-event time over the 78.6 TFLOP/s matrix peak."""
+    import numpy as np
+    pd, _ = jq.cases.cnot3_dense()
+    nfull = pd.nsteps
+    cand = [samples] if samples else ([1024] if quick else [1024, 2048, 4096, 8192])
+    best, sweep = cand[0], {}
+    if len(cand) > 1:
+        ps, _ = jq.cases.cnot3_dense()
+        ps.T, ps.nsteps = ps.T * 2000 / ps.nsteps, 2000
+        ws = jq.Working_Arrays_HIP(ps, pcof.size)
+        for ns in cand:
+            n2, w2, s2 = jq.cases.cnot3_ensemble(ns)
+            jq.eval_f_g_grad(pcof, ps, ws, n2, w2, True, shift=s2)
+            jq.eval_f_g_grad(pcof, ps, ws, n2, w2, True, shift=s2)
+            t = ws.last_timing()
+            sweep[str(ns)] = {"ms_per_2000_steps": t["ms_total"], "evals_per_s_at_full_length": ns / (t["ms_total"] * 1e-3 * nfull / 2000.0),
+                              "kernel_family": t["kernel_family"]}
+        ws.close()
+        best = max(cand, key=lambda ns: sweep[str(ns)]["evals_per_s_at_full_length"])
+    if quick:
+        pd.T, pd.nsteps = pd.T * 500 / pd.nsteps, 500
+    wd = jq.Working_Arrays_HIP(pd, pcof.size)
+    plan = wd.plan_info()
+    n2, w2, s2 = jq.cases.cnot3_ensemble(best)
+    t1 = time.perf_counter()
+    jq.eval_f_g_grad(pcof, pd, wd, n2, w2, True, shift=s2)
+    wall = time.perf_counter() - t1
+    t = wd.last_timing()
+    wd.close()
+    kb = "k_backward<%d, %d>" % (t["kernel_size"], t["kernel_band"])
+    nb, nf = max(t["n_backward_launches"], 1), max(t["n_forward_launches"], 1)
+    bwd_s, fwd_s = t["ms_backward"] * 1e-3 / nb, t["ms_forward"] * 1e-3 / nf
+    mf_b, mf_f = t["mfma_backward"] / nb, (t["mfma_executed"] - t["mfma_backward"]) / nf
+    libver = L.jq_version().decode()
+    src, check, pk = "analytic (library count)", None, {}
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_dense.json")))
+        pk = pj["kernels"].get(kb, {})
+        if pj.get("library_version") == libver and pk.get("samples_per_gpu") == best and pk.get("mfma_16x16x4_equiv_per_launch") \
+                and pk.get("steps_per_launch") in (None, pd.nsteps / nb):
+            dev = abs(pk["mfma_16x16x4_equiv_per_launch"] - mf_b) / mf_b
+            check = {"pmc": pk["mfma_16x16x4_equiv_per_launch"], "analytic": mf_b, "rel_diff": dev}
+            if dev < 0.01:
+                mf_b, src = pk["mfma_16x16x4_equiv_per_launch"], "rocprofv3 PMC SQ_INSTS_MFMA (profiles/r05_pmc_dense.json, same build)"
+        else:
+            pk = {}
+    except Exception:  # noqa: BLE001
+        pk = {}
+    ach_b = mf_b * 2048.0 / bwd_s / 1e12
+    ach_f = mf_f * 2048.0 / fwd_s / 1e12
+    Ntot, N, Nc, m = pd.Ntot, pd.N, pd.Ncoupled, pd.linear_solver.max_iter
+    return {"workload": "cnot3 dimensions (Ntot=96, N=4, %d steps, %d Neumann terms, 3 controls) with a DENSE Hermitian drift "
+                        "(cases.cnot3_dense) x %d perturbed samples" % (pd.nsteps, m, best),
+            "structure": plan["structure"], "block_band": plan["block_band"], "samples": best, "seconds": wall,
+            "evals_per_s": best / (t["ms_total"] * 1e-3), "ms_total": t["ms_total"], "ms_forward": t["ms_forward"], "ms_backward": t["ms_backward"],
+            "kernel_family": t["kernel_family"], "kernel": kb + " / k_forward<%d, %d> (dense 16x16x4 fp64 MFMA tiles, one wave per 16-column slab)" % (t["kernel_size"], t["kernel_band"]),
+            "batch_size_sweep": sweep,
+            "roofline": {"bound": "mfma", "kernel": kb, "achieved": ach_b, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach_b / FP64_MFMA_PEAK_TFLOPS, "avg_launch_ms": bwd_s * 1e3, "launches": int(t["n_backward_launches"]),
+                         "mfma_count_source": src, "mfma_count_check": check, "valu_per_mfma": pk.get("valu_per_mfma"),
+                         "wait_frac": pk.get("wait_frac"), "traffic": pk.get("hbm_bytes_per_launch"),
+                         "issue_bound": "one v_mfma_f64_16x16x4 occupies its SIMD's DP pipe for 64 clk and a wave's other VALU work does not "
+                                        "overlap it (probes/mfma_valu_overlap_probe): the fraction IS the pipe's MFMA share; 1 - frac is "
+                                        "vector updates, LDS waits and the per-operator barrier",
+                         "dense_contraction_tflops": 2.0 * Ntot * Ntot * (2 * (9 + 2 * m) + 7 * Nc) * best * N * pd.nsteps / nb / bwd_s / 1e12,
+                         "dense_contraction_note": "SURVEY.md 8(d)'s count (2 Ntot^2 per product and column, 9 + 2m products per step as the "
+                                                   "reference forms them); the kernels merge products (8 + 2m) and the trace operators keep their "
+                                                   "own band structure, so fewer tiles are executed than this count implies"},
+            "roofline_forward": {"kernel": kb.replace("backward", "forward"), "achieved": ach_f, "frac": ach_f / FP64_MFMA_PEAK_TFLOPS,
+                                 "avg_launch_ms": fwd_s * 1e3},
+            "all_propagators_mfma_frac": t["mfma_executed"] * 2048.0 / (t["ms_propagate"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS}
+
+
 _T0 = time.perf_counter()
 
 
@@ -235,6 +315,9 @@ def main():
 
     params, info = jq.cases.cnot3()
     pcof = np.array(json.load(open(os.path.join(ROOT, "tests", "golden", "cnot3.json")))["pcof0"])
+    if args.dense_only:
+        print(json.dumps({"dense_operator": dense_operator_block(jq, L, pcof, samples=args.dense_only)}), flush=True)
+        return
     nsamples_total = args.samples_per_gpu * ngpus
     nodes, weights, shift = jq.cases.cnot3_ensemble(nsamples_total)
     wa = jq.Working_Arrays_HIP(params, pcof.size, devices=ngpus if args.single_process else None)
@@ -525,6 +608,11 @@ def main():
                 mid[str(ns)] = {"evals_per_s": ns / (t2["ms_total"] * 1e-3), "ms": t2["ms_total"], "kernel_family": t2["kernel_family"]}
             out["mid_size_ensembles"] = mid
             _trace("latency / other batch sizes done")
+            try:
+                out["dense_operator"] = dense_operator_block(jq, L, pcof)
+            except Exception as e:  # noqa: BLE001  (a side measurement)
+                out["dense_operator"] = {"error": repr(e)[:300]}
+            _trace("dense operator done")
             # the other BASELINE.json configurations (parity-test cases, not bench lines): time of one evaluation on this GPU --
             # single samples and, for the risk-neutral SWAP-02 case, its 512-node ensemble; Ntot <= 16: VALU row-lane kernels,
             # no MFMA percentage is quoted

@@ -385,6 +385,20 @@ def cnot2_lab(Pmin=200, pcof_file=None):
                         rot_freq=[fa, fb])
 
 
+def cnot3_dense(eps=1.0e-2, seed=11):
+    """cnot3's dimensions (Ntot = 96, N = 4), controls, target, weights and time stepping with a DENSE Hermitian drift:
+    Hconst + eps (D + D') with D ~ N(0, 1 / Ntot) -- a user Hamiltonian without Kronecker structure (all-to-all couplings, another
+    basis).  Not a case of the reference; it is what north_star calls "the dense (H x state-batch) contraction": the planner finds
+    no structure to exploit and the propagators run on dense 16 x 16 x 4 MFMA tiles (kernels <6, 5>; bench.py's `dense_operator`
+    block).  The perturbation is small against the drift (|Hconst| ~ 10), so cnot3's nsteps still resolves it."""
+    params, info = cnot3()
+    rng = np.random.default_rng(seed)
+    D = rng.standard_normal((params.Ntot, params.Ntot)) / math.sqrt(params.Ntot)
+    params.Hconst = np.asfortranarray(params.Hconst + eps * (D + D.T))
+    params.use_sparse = False
+    return params, dict(info, golden=None)
+
+
 BUILDERS = {
     "rabi": rabi,
     "swap02": swap02,

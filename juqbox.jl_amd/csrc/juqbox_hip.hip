@@ -3325,7 +3325,13 @@ extern "C" int jq_plan_info(const jq_handle* hh, char* buf, int32_t buflen)
             objs += man.substr(at, end - at + 1);
         }
         objs += "}";
-        kv("build", std::string("{\"manifest\": ") + (man.size() > 2 ? "true" : "false") + ", \"objects\": " + objs + "}");
+        std::string hipcc = "null";      // the compiler the kernel objects came from (build manifest)
+        {
+            const size_t at = man.find("\"hipcc\": {");
+            const size_t end = at == std::string::npos ? at : man.find('}', at);
+            if (end != std::string::npos) hipcc = man.substr(at + 9, end - at - 8);
+        }
+        kv("build", std::string("{\"manifest\": ") + (man.size() > 2 ? "true" : "false") + ", \"hipcc\": " + hipcc + ", \"objects\": " + objs + "}");
     }
     kv("full_weight_rank", num(h->wrank));
     {   // the three-workgroup latency kernels: what the last batch of the cooperative-quad families decided, and why

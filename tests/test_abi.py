@@ -176,31 +176,39 @@ def test_python_shard_bounds_fallback_equals_the_library_rule():
         _shard_bounds_py(8, 2, 2)
 
 
-def test_build_manifest_of_the_bench_path():
+PINNED_HIPCC = "7.2.26015"      # the HIP version the kernel objects of this tree are tuned and checked with (scripts/make_manifest.py)
+
+
+def test_build_manifest_no_object_falls_back():
     """Round-3 review: the Makefile silently rebuilt an object in the default register form when hipcc 7.2 crashed in VGPR form, and
-    nothing recorded which.  csrc/build/manifest.json (scripts/make_manifest.py) now does: the objects the benchmark runs -- k_6_7
-    (three slabs per workgroup), s_6_7 (one / two slabs), u_6_7 (cooperative quad) -- must be in VGPR form, not fallen back, and within
-    their scratch budget; the known fallbacks are exactly the ones listed here (none on the bench path)."""
+    nothing recorded which.  csrc/build/manifest.json (scripts/make_manifest.py) does.  Round 5: the crash (LLVM's 'AMDGPU Rewrite
+    AGPR-Copy-MFMA' pass) only happens with the default scheduling strategy, so a crashing object is retried in VGPR form with another
+    one; NO object may end up in the default form any more -- every Neumann-path object of every family, not only the bench path's.
+    The objects the benchmark and the latency paths run must also be within their scratch budgets, and the manifest names the compiler
+    (another hipcc means another set of crashing objects: the version is pinned here so that a toolchain change is a visible edit)."""
     import json
     path = os.path.join(ROOT, "juqbox.jl_amd", "csrc", "build", "manifest.json")
     if not os.path.exists(path):
         pytest.skip("no build directory here (the library was built elsewhere)")
-    man = json.load(open(path))["objects"]
+    full = json.load(open(path))
+    man = full["objects"]
     assert len(man) >= 200
-    for tag, budget in (("k_6_7", 160), ("s_6_7", 64), ("u_6_7", 0), ("w_6_7", 0), ("v_6_7", 0)):
-        e = man[tag]
-        assert e["vgpr_form"] and not e["fallback"], (tag, e["flags"])
-        assert e["max_scratch_bytes"] <= budget, (tag, e["max_scratch_bytes"])
-    assert man["k_6_7"]["max_vgprs"] <= 168          # three waves per SIMD
-    # hipcc 7.2's 'AMDGPU Rewrite AGPR-Copy-MFMA' pass crashes on some of the widest SLAB kernels in VGPR form (which ones changes
-    # with unrelated edits: k_6_5 / k_7_8 / w_6_5 in one build, k_6_0 / w_6_5 in the next); the Makefile then rebuilds the object in the
-    # default form and the manifest says so.  What must never fall back silently: the structure-specific families the plan prefers.
     fallbacks = sorted(t for t, e in man.items() if e["fallback"])
-    print("objects rebuilt without the VGPR form:", fallbacks)
-    assert len(fallbacks) <= 6, fallbacks
-    for t in fallbacks:
-        pre, rest = t.split("_", 1)
-        assert pre in ("k", "w", "c", "i") and not rest.endswith("_7"), "unexpected fallback: " + t
+    retried = sorted(t for t, e in man.items() if e.get("retry"))
+    print("objects built with another scheduling strategy:", retried, "-- rebuilt without the VGPR form:", fallbacks)
+    kcd = ("j_", "l_", "r_", "m_")      # (default form by design: Jacobi slab variants, lane / row-lane VALU kernels)
+    assert not fallbacks, "objects fell back to the default register form: %s" % fallbacks
+    for t, e in man.items():
+        if not t.startswith(kcd):
+            assert e["vgpr_form"], t
+    for t in retried:      # never a quad-layout / cooperative-quad object: their scheduling strategies are tuned per object
+        assert not t.endswith("_7"), "unexpected retry: " + t
+    for tag, budget in (("k_6_7", 160), ("s_6_7", 64), ("p_6_7", 0), ("u_6_7", 0), ("w_6_7", 0), ("v_6_7", 0)):
+        assert man[tag]["max_scratch_bytes"] <= budget, (tag, man[tag]["max_scratch_bytes"])
+    assert man["k_6_7"]["max_vgprs"] <= 168          # three waves per SIMD
+    assert man["p_6_7"]["max_vgprs"] <= 256          # two waves per SIMD
+    hv = full["hipcc"]["hip_version"]
+    assert hv and hv.startswith(PINNED_HIPCC), "built with hipcc %s, pinned %s: re-check the fallbacks / scratch budgets and move the pin" % (hv, PINNED_HIPCC)
     # the library carries the same manifest (jq_plan_info quotes it)
     from juqbox_jl_amd import _lib
     import ctypes
@@ -208,13 +216,23 @@ def test_build_manifest_of_the_bench_path():
     txt = ctypes.string_at(ctypes.addressof(ctypes.c_char.in_dll(L, "jq_build_manifest"))).decode()
     emb = json.loads(txt)
     assert emb["k_6_7"]["max_scratch_bytes"] == man["k_6_7"]["max_scratch_bytes"]
-    assert sorted(t for t, e in emb.items() if e["fallback"]) == fallbacks
+    assert emb["hipcc"] == full["hipcc"]
+    assert sorted(t for t, e in emb.items() if t != "hipcc" and e["fallback"]) == fallbacks
 
 
 def test_committed_pmc_record_belongs_to_this_build():
-    """bench.py joins profiles/r04_pmc.json (HBM traffic, MFMA count of the dominant kernel) only when the record was taken with the
-    build it runs: a source edit after the last profiling round would silently drop `roofline.traffic` from the judged line."""
+    """bench.py joins profiles/r05_pmc.json (HBM traffic, MFMA count of the dominant kernel) only when the record was taken with the
+    build it runs.  A source, Makefile or flag edit after the last profiling round changes the library's source hash; bench.py then
+    degrades gracefully (analytic MFMA count, `traffic` null) -- so this is a release check, not a correctness test: it WARNS (advisor,
+    round 4: a red CPU suite until someone re-profiles on an MI355X helps nobody).  scripts/profile_round.sh is the fix."""
     import json
+    import warnings
     from juqbox_jl_amd import _lib
-    rec = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc.json")))
-    assert rec["library_version"] == _lib.load().jq_version().decode(), "re-run scripts/profile_round.sh and commit profiles/r04_pmc.json"
+    path = os.path.join(ROOT, "profiles", "r05_pmc.json")
+    if not os.path.exists(path):
+        warnings.warn("profiles/r05_pmc.json is missing: run scripts/profile_round.sh on an MI355X and commit it")
+        return
+    rec = json.load(open(path))
+    if rec["library_version"] != _lib.load().jq_version().decode():
+        warnings.warn("profiles/r05_pmc.json was recorded with %s, the library here is %s: bench.py will not quote it -- re-run "
+                      "scripts/profile_round.sh and commit the record" % (rec["library_version"], _lib.load().jq_version().decode()))

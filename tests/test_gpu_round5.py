@@ -230,3 +230,29 @@ def test_same_device_sub_handles_never_take_the_split(jq):
     inf, grad, ls = _with_env({"JQ_MULTI_SAME_DEVICE": "1"}, run)
     assert abs(inf - single[0]) <= 1e-13 * abs(single[0]) and rel(grad, single[2]) <= 1e-12
     assert ls["faults"] == 0 and (ls["last_decision"].startswith("not taken: another evaluation") or ls["last_decision"].startswith("taken")), ls
+
+
+# ---- (3) the dense-operator path (bench.py's dense_operator block) ------------------------------------------------------------------
+
+def test_dense_drift_at_full_length_matches_the_oracle(jq):
+    """north_star's "dense (H x state-batch) contraction": cnot3's dimensions with a dense Hermitian drift (cases.cnot3_dense) at the
+    reference's full length (32 386 steps), one evaluation, on the kernels bench.py's dense_operator block times (k_forward /
+    k_backward<6, 5>: dense 16 x 16 x 4 MFMA tiles, no structure exploited) against the oracle's DENSE products
+    (src/StormerVerlet.jl:461-504 dense step!): objective, infidelity / leak split and gradient at 1e-10."""
+    from oracle.oracle import Oracle
+    params, info = jq.cases.cnot3_dense()
+    pcof = np.array(json.load(open(os.path.join(ROOT, "tests", "golden", "cnot3.json")))["pcof0"])
+    wa = jq.Working_Arrays_HIP(params, pcof.size)
+    pi = wa.plan_info()
+    assert pi["structure"] == "dense" and pi["block_band"] == 5 and pi["tile_rows"] == 6, pi
+    objfv, tg, prim, sec, tinf, ig, lg = jq.traceobjgrad(pcof, params, wa, False, True)
+    t = wa.last_timing()
+    assert (t["kernel_family"], t["kernel_size"], t["kernel_band"]) == (0, 6, 5), t
+    wa.close()
+    r = Oracle(params, use_sparse=False).traceobjgrad(pcof)
+    assert abs(objfv - r["objfv"]) <= TOL * abs(r["objfv"])
+    assert abs(prim - r["primaryobjf"]) <= TOL * abs(r["primaryobjf"]) and abs(sec - r["secondaryobjf"]) <= TOL * abs(r["secondaryobjf"])
+    assert rel(tg, r["totalgrad"]) <= TOL
+    # ... and the dense drift is not a rounding-level change of cnot3 (the structured kernels would not notice a dropped perturbation)
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "cnot3.json")))
+    assert abs(objfv - g["obj0"]) > 1e-3
