@@ -181,16 +181,37 @@ function plan_info(wa::AbstractWorkingArraysHIP)      # JSON text: structure, co
 end
 handle_device(wa::AbstractWorkingArraysHIP) = ccall((:jq_handle_device, libjq), Cint, (Ptr{Cvoid},), wa.handle)
 
-# params is mutated freely by scripts (Hconst inside eval_f_g_grad!, wmat_real, max_iter, targets): push before each call
+# What the reference's solver WOULD use.  lsolver_object's `solve` closure captures max_iter (and tol) when it is constructed
+# (src/linear_solvers.jl:36-57): a script that later assigns params.linear_solver.max_iter without calling
+# recreate_linear_solver_closure! (:68-78; estimate_Neumann! does call it, src/evalobjgrad.jl:2924-2925) still solves with the OLD
+# values on the CPU path.  The captured variables are fields of the closure object (a Core.Box when the constructor reassigned them:
+# tol *= sqrt(nrhs)); after recreate_linear_solver_closure! the closure captures the object itself (field :lsolver) and the struct's
+# fields count.  Reading them here makes both back ends agree for such scripts too (round 4 read the struct's fields every call).
+function solver_in_effect(ls)
+    f = ls.solve
+    unbox(x) = x isa Core.Box ? x.contents : x
+    mi = hasfield(typeof(f), :max_iter) ? unbox(getfield(f, :max_iter)) : ls.max_iter
+    tl = hasfield(typeof(f), :tol) ? unbox(getfield(f, :tol)) : ls.tol
+    return Int32(mi), Float64(tl)
+end
+
+# params is mutated freely by scripts (Hconst inside eval_f_g_grad!, wmat_real, max_iter, targets): push before each call.
+# Order: Diagonal weights go in BEFORE the solver / integrator and full weights AFTER it -- full weights exist with the Neumann solver
+# only, so a script that switches (full weights, Neumann) <-> (Diagonal, Jacobi) in one step is valid in either direction
+# (jq_update_wmat returns at once when the matrices are the ones it has: no eigen-decomposition per call).
 function sync!(wa::AbstractWorkingArraysHIP, params::objparams)
     ls = params.linear_solver            # solver_id 1 = NEUMANN_SOLVER, 2 = JACOBI_SOLVER (src/linear_solvers.jl:5-8)
+    max_iter, tol = solver_in_effect(ls)
+    fullw = wa isa Working_Arrays_HIP && full_weights(params)
+    fullw || push_weights!(wa, params)
     if wa isa Working_Arrays_M_HIP
         jqcheck(wa, ccall((:jq_set_integrator, libjq), Cint, (Ptr{Cvoid}, Int32, Int32, Float64),
-                          wa.handle, 2, ls.max_iter, ls.tol))
+                          wa.handle, 2, max_iter, tol))
     else
         jqcheck(wa, ccall((:jq_set_linear_solver, libjq), Cint, (Ptr{Cvoid}, Int32, Int32, Float64),
-                          wa.handle, ls.solver_id, ls.max_iter, ls.tol))
+                          wa.handle, ls.solver_id, max_iter, tol))
     end
+    fullw && push_weights!(wa, params)
     if params.Hconst isa SparseMatrixCSC{Float64,Int64}
         Hsp = params.Hconst
         GC.@preserve Hsp begin
@@ -200,7 +221,6 @@ function sync!(wa::AbstractWorkingArraysHIP, params::objparams)
         Hc = Matrix{Float64}(params.Hconst)
         jqcheck(wa, ccall((:jq_update_hconst, libjq), Cint, (Ptr{Cvoid}, Ptr{Float64}), wa.handle, Hc))
     end
-    push_weights!(wa, params)
     jqcheck(wa, ccall((:jq_update_target, libjq), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}),
                       wa.handle, params.Utarget_r, params.Utarget_i))
 end

@@ -63,10 +63,16 @@ class Working_Arrays_HIP:
     def _weights(self, p):
         """leakage weights of this path: params.wmat_real (src/evalobjgrad.jl:583) -- a vector (the Diagonal default) or, with
         use_custom_forbidden (:214-232), a full matrix next to params.wmat_imag: then (wmat_real, wmat_imag) stacked"""
+        wi = getattr(p, "wmat_imag", None)
         if np.ndim(p.wmat_real) == 2:
-            wi = getattr(p, "wmat_imag", None)
             wi = np.zeros_like(p.wmat_real) if wi is None or np.ndim(wi) != 2 else wi      # (Diagonal(zeros(Ntot)), :236)
             return np.concatenate([_f64(p.wmat_real), _f64(wi)])
+        if wi is not None and np.any(np.asarray(wi) != 0):
+            # a Diagonal wmat_real next to a non-zero wmat_imag: the Julia binding passes both as full matrices (a full wmat_imag) or
+            # refuses (a Diagonal one is not a Hermitian weight); dropping wmat_imag silently would evaluate something else
+            if np.ndim(wi) == 2:
+                return np.concatenate([_f64(np.diag(np.asarray(p.wmat_real, dtype=np.float64))), _f64(wi)])
+            raise ValueError("a non-zero Diagonal wmat_imag is not a Hermitian leakage weight (julia/hip_backend.jl refuses it too)")
         return _f64(p.wmat_real)
 
     def _push_weights(self, w):
@@ -157,6 +163,12 @@ class Working_Arrays_HIP:
         if ls.solver_id not in self.SOLVERS:
             raise ValueError("Please specify a supported linear solver")
         key = (int(ls.solver_id), int(ls.max_iter), float(ls.tol))
+        # Diagonal weights go in BEFORE the solver / integrator, full weights AFTER it: full weights exist with the Neumann solver only,
+        # so (full weights, Neumann) <-> (Diagonal, Jacobi) is a valid switch in one step in either direction (as julia/hip_backend.jl)
+        wd = self._weights(p)
+        if wd.size == p.Ntot and (wd.size != self._wd.size or not np.array_equal(wd, self._wd)):
+            self._push_weights(wd)
+            self._wd = wd.copy()
         if key != self._solver:
             if self.INTEGRATOR == Stormer_Verlet:
                 _lib.check(L.jq_set_linear_solver(h, key[0], key[1], key[2]), h)
@@ -172,8 +184,7 @@ class Working_Arrays_HIP:
             else:
                 _lib.check(L.jq_update_hconst(h, _ptr(hc)), h)
             self._hconst = hc.copy()
-        wd = self._weights(p)
-        if wd.size != self._wd.size or not np.array_equal(wd, self._wd):
+        if wd.size != self._wd.size or not np.array_equal(wd, self._wd):      # (full weights)
             self._push_weights(wd)
             self._wd = wd.copy()
         utr, uti = _f64(p.Utarget_r), _f64(p.Utarget_i)

@@ -256,3 +256,62 @@ def test_dense_drift_at_full_length_matches_the_oracle(jq):
     # ... and the dense drift is not a rounding-level change of cnot3 (the structured kernels would not notice a dropped perturbation)
     g = json.load(open(os.path.join(ROOT, "tests", "golden", "cnot3.json")))
     assert abs(objfv - g["obj0"]) > 1e-3
+
+
+# ---- (4) bindings: the order of the pushes --------------------------------------------------------------------------------------------
+
+def test_switching_weights_and_solver_in_one_step(jq):
+    """advisor, round 4: sync set the solver before the weights, so a script that went from (full leakage weights, Neumann) to (Diagonal
+    weights, Jacobi) in ONE step got JQ_EUNSUPPORTED (the Jacobi solver was refused while the full weights were still on the device).
+    Diagonal weights now go in before the solver, full weights after it: both directions work and agree with the oracle; and a vector
+    wmat_real next to a full wmat_imag is passed on (not dropped), a Diagonal non-zero wmat_imag refused like the Julia binding does."""
+    from oracle.oracle import Oracle
+    from test_dense_wmat import forbidden_problem
+    p, pcof = forbidden_problem("swap02", 2, 25, True, 1)
+    full_r, full_i = p.wmat_real.copy(), p.wmat_imag.copy()
+    neumann = p.linear_solver
+    wa = jq.Working_Arrays_HIP(p, pcof.size)
+
+    def check():
+        r = Oracle(p, use_sparse=False).traceobjgrad(pcof)
+        objfv, tg = jq.traceobjgrad(pcof, p, wa, False, True)[:2]
+        assert abs(objfv - r["objfv"]) <= TOL * abs(r["objfv"]) and rel(tg, r["totalgrad"]) <= TOL
+    check()
+    p.wmat_real, p.wmat_imag = np.diag(full_r).copy(), np.zeros(p.Ntot)                       # -> Diagonal + Jacobi in one step
+    p.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER, max_iter=60, tol=1e-13, nrhs=p.N)
+    check()
+    p.wmat_real, p.wmat_imag, p.linear_solver = full_r, full_i, neumann                       # ... and back in one step
+    check()
+    p.wmat_real = np.diag(full_r).copy()                                                      # a vector next to a FULL wmat_imag: both are passed
+    with pytest.raises(Exception) as e:                                                       # (diag(Wr) + i Wi is still Hermitian; the oracle takes matrices)
+        p.wmat_imag = np.ones(p.Ntot)                                                         # a non-zero DIAGONAL wmat_imag is refused
+        jq.traceobjgrad(pcof, p, wa, False, True)
+    assert "Hermitian" in str(e.value)
+    p.wmat_imag = full_i
+    o1 = jq.traceobjgrad(pcof, p, wa, False, True)[0]
+    p.wmat_real = np.diag(np.diag(full_r))                                                    # the same weights written as two full matrices
+    o2 = jq.traceobjgrad(pcof, p, wa, False, True)[0]
+    assert o1 == o2
+    wa.close()
+
+
+def test_all_reduce_self_check_comparison_runs_in_the_same_device_mode(jq):
+    """advisor, round 4: the self-check of the first ncclAllReduce had never executed (the same-device test mode sums on the host) and
+    scaled its tolerance by the TOTAL's largest entry although two summation orders differ by roundings of the PARTIAL sums.  The
+    comparison is a function now (tolerance 1e-13 x the sum of the devices' largest entries, non-finite results reported as such) and
+    JQ_RCCL_SELFCHECK=3 runs it in the test mode: host-order sum against the reverse-order sum of the same packed vectors."""
+    from conftest import case_inputs
+    params, info, pcof, _ = case_inputs("swap02_rn")
+    x, w = np.polynomial.legendre.leggauss(11)
+    nodes, weights = x * 0.5 * (2 * np.pi * 2e-2), w * 0.5
+    shift = params.shift_weights_reference()
+
+    def run():
+        wam = jq.Working_Arrays_HIP(params, pcof.size, devices=4)
+        for _ in range(2):
+            jq.eval_f_g_grad(pcof, params, wam, nodes, weights, True)
+        n = wam.plan_info()["rccl_selfchecks"]
+        wam.close()
+        return n
+    assert _with_env({"JQ_MULTI_SAME_DEVICE": "1", "JQ_RCCL_SELFCHECK": "3"}, run) == 2
+    assert _with_env({"JQ_MULTI_SAME_DEVICE": "1"}, run) == 0
