@@ -34,6 +34,8 @@ template __global__ void k_backward_qsplit<JQ_NT, false, 4>(PropArgs);      // (
 template __global__ void k_backward_qsplit<JQ_NT, true, 4>(PropArgs);       // (ORD: control q acts on subsystem q only)
 template __global__ void k_backward_qsplit<JQ_NT, false, 2>(PropArgs);      // (two quads per workgroup: one wave per SIMD)
 template __global__ void k_backward_qsplit<JQ_NT, true, 2>(PropArgs);
+template __global__ void k_backward_qsplit<JQ_NT, true, 4, true>(PropArgs);      // (RIDE: three single-subsystem controls, all trace products ride along)
+template __global__ void k_backward_qsplit<JQ_NT, true, 2, true>(PropArgs);
 #elif JQ_VARIANT == 10  // cooperative-quad kernels of the implicit-midpoint integrator (JQ_BW = 7, N = 4)
 #include "jq_cq_imr_kernels.h"
 template __global__ void k_forward_cq_imr<JQ_NT>(PropArgs);

@@ -30,13 +30,91 @@
 // doubles of hand-off buffer per column quad (host: allocation)
 __host__ __device__ constexpr size_t jq_qs_quad_doubles(int NT) { return (size_t)2 * JQ_QS_ARRAYS * NT * 64; }
 
+// NP (1 or 2) products D_k = C_k + M_k x in ONE pass over the blocks like mm_t4q_multi, with a functor called once per 16-row block with
+// the block of x, its two lane-shifted copies and its neighbouring blocks: ride(mt, xc, su, sd, xold, xn).  Partial products with
+// single-subsystem operators (the trace products of adjoint_grad_calc!) and their dot products ride along in the pass of a full
+// product with the same right-hand side -- no shifts, no passes and no result arrays of their own, and independent instructions in
+// a chain that is bound by the latency of its dependent ones.  x must not alias a D_k.
+template <int NT, int NP, bool Z0, bool Z1, typename RIDE>
+__device__ __forceinline__ void mm_t4q_ride(Arr<NT>& D0, const Arr<NT>& C0, const double* m0, Arr<NT>& D1, const Arr<NT>& C1, const double* m1,
+                                            const Arr<NT>& x, RIDE ride)
+{
+    static_assert(NP == 1 || NP == 2, "");
+    const int lane = threadIdx.x & 63;
+    const double* ma[2] = {t4q_a(m0, lane), t4q_a(m1, lane)};
+    const d4* cf[2] = {t4q_c<NT>(m0, lane), t4q_c<NT>(m1, lane)};
+    double xold = 0.0;
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) {
+        double a[2];
+        d4 c[2];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            a[k] = ma[k][mt * 64];
+            c[k] = t4q_cload(cf[k], mt);
+        }
+        const double xc = x.t[mt][0], xn = x.t[mt + 1 < NT ? mt + 1 : mt][0];
+        const double su = row_shift4<0x114>(xc), sd = row_shift4<0x104>(xc);
+        double acc[2] = {Z0 ? 0.0 : C0.t[mt][0], (NP > 1 && !Z1) ? C1.t[mt][0] : 0.0};
+#pragma unroll
+        for (int k = 0; k < NP; ++k) acc[k] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[k], xc, acc[k], 0, 0, 0);
+        ride(mt, xc, su, sd, xold, xn);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) acc[k] = fma(c[k][0], su, acc[k]);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) acc[k] = fma(c[k][1], sd, acc[k]);
+        if (mt > 0) {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) acc[k] = fma(c[k][2], xold, acc[k]);
+        }
+        if (mt + 1 < NT) {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) acc[k] = fma(c[k][3], xn, acc[k]);
+        }
+        xold = xc;
+        D0.t[mt][0] = acc[0];
+        if constexpr (NP > 1) D1.t[mt][0] = acc[1];
+        __builtin_amdgcn_sched_barrier(0);      // (fence per block, see mm_t4q_multi)
+    }
+}
+// The three single-subsystem operators of a set (Hsym_q or Hanti_q, q = 0, 1, 2; control q acts on subsystem q only): this lane's
+// operands in the resident constant images -- operator 0: diagonal 4 x 4 blocks (the MFMA's A operand), operator 1: couplings of the
+// neighbouring 4-row groups (lane-shift terms), operator 2: couplings of the neighbouring 16-row blocks.  apply() gives block mt of
+// y_q = (operator q) x, operation for operation what mm_t4q<.., JQ_T4_DIAG / JQ_T4_RTERMS / JQ_T4_MTERMS> computes.
+template <int NT>
+struct OrdOps {
+    const double* a0;
+    const d4 *c1, *c2;
+    __device__ __forceinline__ void init(const double* M0, const double* M1, const double* M2, int lane)
+    {
+        a0 = t4q_a(M0, lane);
+        c1 = t4q_c<NT>(M1, lane);
+        c2 = t4q_c<NT>(M2, lane);
+    }
+    __device__ __forceinline__ void apply(int mt, double xc, double su, double sd, double xold, double xn, double& y0, double& y1, double& y2) const
+    {
+        y0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a0[mt * 64], xc, 0.0, 0, 0, 0);
+        const d4 k1 = t4q_cload(c1, mt);
+        y1 = fma(k1[1], sd, k1[0] * su);
+        const d4 k2 = t4q_cload(c2, mt);
+        y2 = 0.0;
+        if (mt > 0) y2 = fma(k2[2], xold, y2);
+        if (mt + 1 < NT) y2 = fma(k2[3], xn, y2);
+    }
+};
+
 // grid = ceil(4 nslabs / QW), block = 128 QW threads.  a.park: the hand-off buffer, [quad][parity][array][block][64].
 // Dynamic LDS: [ring of JQ_QS_TPS time points | constant trace images | tables wd, ws | trace records 2 x QW x 8 Nc].
 // ORD: control q acts on subsystem q only (compile-time trace modes, Hsym_1 lambda_i rides along with K05 lambda_i; see k_backward).
-template <int NT, bool ORD, int QW>
+// RIDE (with ORD and exactly three controls): ALL twelve trace products ride along in the passes of the adjoint step that shift the same
+// right-hand side (mm_t4q_ride): Hanti_q X with K0 X / K1 X, Hanti_q (-lambda_i) with S05 (-lambda_i), Hsym_q (-lambda_i new) and
+// Hanti_q (-lambda_i new) with K05 (-lambda_i new), Hsym_q X with S1 X; tr5 is then the sum of two dot products (with -lambda_i old and new) instead of
+// one dot product with their sum -- the only difference in rounding to the other variants (1e-16).
+template <int NT, bool ORD, int QW, bool RIDE = false>
 __global__ __launch_bounds__(128 * QW, 1) void k_backward_qsplit(PropArgs a)
 {
     static_assert(QW == 4 || QW == 2 || QW == 1, "quads per workgroup");
+    static_assert(!RIDE || ORD, "RIDE: a variant of the ORD kernel");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KT = 4 * NT;
     constexpr int BW = JQ_BW_T4Q;
@@ -178,6 +256,129 @@ __global__ __launch_bounds__(128 * QW, 1) void k_backward_qsplit(PropArgs a)
             }
     }
     p.begin_step(0);      // (super-step 0: the state waves' first step)
+    if constexpr (RIDE) {
+        OrdOps<NT> hs, ha;      // (the constant images are resident: the operand pointers do not change)
+        hs.init(p.next_c(0), p.next_c(1), p.next_c(2), lane_);
+        ha.init(p.next_c(3), p.next_c(4), p.next_c(5), lane_);
+        for (int k = 1; k <= nst; ++k) {
+            const int n = k - 1;
+            p.begin_step(k);
+            if (active) {
+                const double* hsrc = hand + (size_t)(n & 1) * JQ_QS_ARRAYS * NT * 64;
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    v.t[i][0] = hsrc[i * 64];
+                    un.t[i][0] = hsrc[(NT + i) * 64];
+                }
+            }
+            double t1[3] = {0.0, 0.0, 0.0}, t3[3] = {0.0, 0.0, 0.0}, t2[3] = {0.0, 0.0, 0.0}, s4[3] = {0.0, 0.0, 0.0}, t5a[3] = {0.0, 0.0, 0.0},
+                   t5b[3] = {0.0, 0.0, 0.0};
+            // use 6 (adjoint part): L = c K05 nb ; rides (EARLY): Hanti_q nb (the old part of tr5).
+            // Measured at cnot3 (backward sweep, ms): two quads per workgroup (the adjoint wave ALONE on its SIMD, bound by the latency
+            // of its dependent chain: every independent instruction is free) 210.5 without rides, 198.3 with this ride here, 205.6 with
+            // it in use 10; four quads per workgroup (two waves per SIMD: the pipe is full, rides buy nothing) 281.9 / 312.3 / 280.0 --
+            // there the ride needs vi05 in the first pass of the step, a moment after it was asked for, and the wave that stalls on the
+            // L2 round trip holds up a SIMD that has no idle slots to lose.
+            constexpr bool EARLY = (QW <= 2);
+            const double* M = p.template next_ks<0, 1>();
+            if (active) {
+                if constexpr (EARLY)
+                    mm_t4q_ride<NT, 1, true, true>(L, L, M, L, L, M, nb, [&](int mt, double xc, double su, double sd, double xo, double xn) {
+                        double y0, y1, y2;
+                        ha.apply(mt, xc, su, sd, xo, xn, y0, y1, y2);
+                        t5a[0] = fma(v.t[mt][0], y0, t5a[0]), t5a[1] = fma(v.t[mt][0], y1, t5a[1]), t5a[2] = fma(v.t[mt][0], y2, t5a[2]);
+                    });
+                else
+                    mm_z<NT, BW>(L, M, nb);
+                if (a.use_shift) a_axpy_rows(L, ceps, ws, g, nb);
+            }
+            // use 7: S0 -- L = c (S0 mu - K05 li + hr0) ; X = mu + sum_j S^j L
+            M = p.template next_ks<1, 0>();
+            if (active) {
+                mm_c<NT, BW>(L, L, M, mu);
+                a_axpy_rows1<NT, false>(L, wd, g, u);
+                a_add(mu, L);
+                horner_add<NT, BW, false>(mu, mu, L, M, a.m, Ya, Yb, a.jacobi_tol2, a.N);
+            }
+            // uses 8 and 9: L = -c K0 X ; vN = -c K1 X ; rides: Hanti_q X (tr1, tr3) -- Hsym_q X rides in use 12 (fewer live values there:
+            // with both sets in this pass the four-quad variant spilled 80 - 136 B per lane and was 11 % SLOWER than without any rides)
+            M = p.template next_ks<0, 0>();
+            const double* M9 = p.template next_ks<0, 2>();
+            if (active) {
+                mm_t4q_ride<NT, 2, true, true>(L, L, M, vN, vN, M9, mu, [&](int mt, double xc, double su, double sd, double xo, double xn) {
+                    double y0, y1, y2;
+                    ha.apply(mt, xc, su, sd, xo, xn, y0, y1, y2);
+                    t1[0] = fma(u.t[mt][0], y0, t1[0]), t1[1] = fma(u.t[mt][0], y1, t1[1]), t1[2] = fma(u.t[mt][0], y2, t1[2]);
+                    t3[0] = fma(un.t[mt][0], y0, t3[0]), t3[1] = fma(un.t[mt][0], y1, t3[1]), t3[2] = fma(un.t[mt][0], y2, t3[2]);
+                });
+                if (a.use_shift) {
+                    a_axpy_rows(L, -ceps, ws, g, mu);
+                    a_axpy_rows(vN, -ceps, ws, g, mu);
+                }
+                // (the early group's wave sums here: tr1, tr3 die before the second Neumann series)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const double te = wave_sum4(t1[q] * wgt, t3[q] * wgt, 0.0, 0.0);   // rows 0, 2: t1, t3
+                    if ((lane_ & 15) == 0) rec[((size_t)(n & 1) * QW + qw) * rslots + 4 * q + (lane_ >> 4)] = te;
+                }
+            }
+            // use 10: S05 -- as in the generic path ; rides of its first product (S05 nb): Hanti_q nb (the old part of tr5)
+            M = p.template next_ks<1, 1>();
+            if (active) {
+                if constexpr (EARLY)
+                    mm_z<NT, BW>(Ya, M, nb);
+                else
+                    mm_t4q_ride<NT, 1, true, true>(Ya, Ya, M, Ya, Ya, M, nb, [&](int mt, double xc, double su, double sd, double xo, double xn) {
+                        double y0, y1, y2;
+                        ha.apply(mt, xc, su, sd, xo, xn, y0, y1, y2);
+                        t5a[0] = fma(v.t[mt][0], y0, t5a[0]), t5a[1] = fma(v.t[mt][0], y1, t5a[1]), t5a[2] = fma(v.t[mt][0], y2, t5a[2]);
+                    });
+                a_axpy_rows1<NT, true>(Ya, wd, g, v);
+                a_add(L, Ya);
+                a_add(vN, Ya);
+                mm_c<NT, BW>(vN, vN, M, L);
+                a_add(L, nb);
+                a_add(L, vN);
+                horner_add<NT, BW, false>(L, L, vN, M, a.m, Ya, Yb, a.jacobi_tol2, a.N);
+                a_add(nb, L);
+            }
+            // use 11: Kp05 -- vN = X + c K05 nb_new ; rides: Hsym_q L (the new part of tr4), Hanti_q L (the new part of tr5)
+            M = p.template next_ks<0, 1>();
+            if (active) {
+                mm_t4q_ride<NT, 1, false, true>(vN, mu, M, vN, mu, M, L, [&](int mt, double xc, double su, double sd, double xo, double xn) {
+                    double y0, y1, y2;
+                    hs.apply(mt, xc, su, sd, xo, xn, y0, y1, y2);
+                    s4[0] = fma(un.t[mt][0], y0, s4[0]), s4[1] = fma(un.t[mt][0], y1, s4[1]), s4[2] = fma(un.t[mt][0], y2, s4[2]);
+                    ha.apply(mt, xc, su, sd, xo, xn, y0, y1, y2);
+                    t5b[0] = fma(v.t[mt][0], y0, t5b[0]), t5b[1] = fma(v.t[mt][0], y1, t5b[1]), t5b[2] = fma(v.t[mt][0], y2, t5b[2]);
+                });
+                if (a.use_shift) a_axpy_rows(vN, ceps, ws, g, L);
+            }
+            // use 12: S1 -- lambda_r_new = X + c (S1 X - K05 li_new + hr1) ; rides: Hsym_q X (tr2)
+            M = p.template next_ks<1, 2>();
+            if (active) {
+                mm_t4q_ride<NT, 1, false, true>(vN, vN, M, vN, vN, M, mu, [&](int mt, double xc, double su, double sd, double xo, double xn) {
+                    double y0, y1, y2;
+                    hs.apply(mt, xc, su, sd, xo, xn, y0, y1, y2);
+                    t2[0] = fma(v.t[mt][0], y0, t2[0]), t2[1] = fma(v.t[mt][0], y1, t2[1]), t2[2] = fma(v.t[mt][0], y2, t2[2]);
+                });
+                a_axpy_rows1<NT, false>(vN, wd, g, un);
+                // the late group's wave sums (rows 0, 2, 1 = t2, t4, t5)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const double p4 = -s4[q];
+                    const double t4 = p4 + carry[q];
+                    carry[q] = p4;
+                    const double t5 = -(t5a[q] + t5b[q]);
+                    const double tl = wave_sum4(t2[q] * wgt, t4 * wgt, t5 * wgt, 0.0);
+                    if ((lane_ & 15) == 0) rec[((size_t)(n & 1) * QW + qw) * rslots + 4 * (3 + q) + (lane_ >> 4)] = tl;
+                }
+                u = un;
+                mu = vN;
+                nb = L;
+            }
+        }
+    } else
     for (int k = 1; k <= nst; ++k) {
         const int n = k - 1;      // the step of this super-step
         p.begin_step(k);

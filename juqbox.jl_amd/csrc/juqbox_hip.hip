@@ -1685,12 +1685,14 @@ static int select_quad_kernels(jq_handle* h, int spw, prop_kernel_t* fwd, prop_k
 
 // ... backward sweep with the state and the adjoint chain of a column quad on two waves, one time step apart (jq_quad_split_kernels.h):
 // mid-size ensembles -- at most one column quad per SIMD (qw = 4 quads per workgroup: two waves per SIMD) or per two SIMDs (qw = 2)
-template <int NT, bool ORD, int QW> __global__ void k_backward_qsplit(PropArgs);
+template <int NT, bool ORD, int QW, bool RIDE = false> __global__ void k_backward_qsplit(PropArgs);
 #define JQ_DECLQS(nt)                                                            \
     extern template __global__ void k_backward_qsplit<nt, false, 4>(PropArgs);   \
     extern template __global__ void k_backward_qsplit<nt, true, 4>(PropArgs);    \
     extern template __global__ void k_backward_qsplit<nt, false, 2>(PropArgs);   \
-    extern template __global__ void k_backward_qsplit<nt, true, 2>(PropArgs);
+    extern template __global__ void k_backward_qsplit<nt, true, 2>(PropArgs);    \
+    extern template __global__ void k_backward_qsplit<nt, true, 4, true>(PropArgs);    \
+    extern template __global__ void k_backward_qsplit<nt, true, 2, true>(PropArgs);
 JQ_DECLQS(1) JQ_DECLQS(2) JQ_DECLQS(3) JQ_DECLQS(4) JQ_DECLQS(5) JQ_DECLQS(6)
 #undef JQ_DECLQS
 static size_t qsplit_lds(const jq_handle* h, int qw)      // ring of JQ_QS_TPS time points + constant images, tables, trace records
@@ -1702,10 +1704,12 @@ static int select_qsplit_kernel(jq_handle* h, int qw, prop_kernel_t* bwd)
     // control q acts on subsystem q only (like select_quad_kernels / select_cq_kernels): compile-time trace modes
     bool ord = h->Nc >= 2 && h->Nc <= 3 && !getenv("JQ_NO_ORD");
     for (int q = 0; q < h->Nc && ord; ++q) ord = (h->bw_trace[q] == (1 << q));
+    // ... and with exactly three of them every trace product rides along in a pass of the adjoint step (RIDE; JQ_QS_RIDE=0: separate passes)
+    const bool ride = ord && h->Nc == 3 && !(getenv("JQ_QS_RIDE") && atoi(getenv("JQ_QS_RIDE")) == 0);
 #define JQ_PICKQS(nt)                                                                                         \
     if (h->NT == nt) {                                                                                        \
-        *bwd = qw == 4 ? (ord ? k_backward_qsplit<nt, true, 4> : k_backward_qsplit<nt, false, 4>)             \
-                       : (ord ? k_backward_qsplit<nt, true, 2> : k_backward_qsplit<nt, false, 2>);            \
+        *bwd = qw == 4 ? (ride ? k_backward_qsplit<nt, true, 4, true> : ord ? k_backward_qsplit<nt, true, 4> : k_backward_qsplit<nt, false, 4>)             \
+                       : (ride ? k_backward_qsplit<nt, true, 2, true> : ord ? k_backward_qsplit<nt, true, 2> : k_backward_qsplit<nt, false, 2>);            \
         return JQ_OK;                                                                                         \
     }
     JQ_PICKQS(1) JQ_PICKQS(2) JQ_PICKQS(3) JQ_PICKQS(4) JQ_PICKQS(5) JQ_PICKQS(6)

@@ -73,12 +73,23 @@ def test_split_backward_sweep_is_the_one_wave_kernel_bit_for_bit(jq, kind, nsamp
     nodes, weights = 0.02 * rng.standard_normal(nsamples), rng.random(nsamples)
     shift = 0.01 * np.arange(params.Ntot)
     env = {"JQ_CHUNK_STEPS": str(chunk)} if chunk else {}
+    env["JQ_QS_RIDE"] = "0"      # (cnot3 would take the RIDE variant: below)
     a = _eval(jq, params, pcof, nodes, weights, shift, env)
     b = _eval(jq, params, pcof, nodes, weights, shift, dict(env, JQ_QSPLIT="0"))
     c = _eval(jq, params, pcof, nodes, weights, shift, env)
     assert a[4]["kernel_family"] == 6 and a[4]["reserved"] == 24 and b[4]["kernel_family"] == 6 and b[4]["reserved"] == 0, (a[4], b[4])
     for x in (b, c):
         assert a[0] == x[0] and a[1] == x[1] and np.array_equal(a[2], x[2]) and np.array_equal(a[3], x[3])
+    if kind == "cnot3":
+        # three single-subsystem controls: the default is the variant whose twelve trace products ride along in the passes of the adjoint
+        # step (k_backward_qsplit<.., RIDE>).  tr5 is then the sum of two dot products instead of a dot product with a sum: the only
+        # difference in rounding (observed 4e-17); bit-stable run to run
+        del env["JQ_QS_RIDE"]
+        d = _eval(jq, params, pcof, nodes, weights, shift, env)
+        e = _eval(jq, params, pcof, nodes, weights, shift, env)
+        assert d[4]["reserved"] == 24
+        assert abs(d[0] - a[0]) <= 1e-13 * abs(a[0]) and abs(d[1] - a[1]) <= 1e-13 * abs(a[1]) and rel(d[2], a[2]) <= 1e-13
+        assert d[0] == e[0] and d[1] == e[1] and np.array_equal(d[2], e[2])
 
 
 @pytest.mark.parametrize("kind,nsamples,mode", [("cnot3", 7, "qw4"), ("cnot3", 7, "qw2"), ("t4x3", 5, "qw4"), ("t4x3", 6, "qw2"), ("t4x2", 11, "qw4"),
