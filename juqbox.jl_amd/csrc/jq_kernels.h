@@ -731,7 +731,16 @@ __device__ __forceinline__ void t4q_load(OpQ<NT>& op, const double* mat)
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt) {
         op.a[mt] = ma[mt * 64];
+#ifdef JQ_EXP_OPQ_EDGE
+        // (round 5 experiment: the first block has no neighbour below and the last one none above -- their coefficients c[2] / c[3]
+        //  are never used, but a 32-byte read keeps the register pair of the whole record alive: read the halves that are used)
+        const double* cd = (const double*)(cf + mt * 16);
+        op.c[mt][0] = cd[0], op.c[mt][1] = cd[1];
+        op.c[mt][2] = mt > 0 ? cd[2] : 0.0;
+        op.c[mt][3] = mt + 1 < NT ? cd[3] : 0.0;
+#else
         op.c[mt] = t4q_cload(cf, mt);
+#endif
     }
 }
 template <int NT>
@@ -1491,7 +1500,9 @@ __device__ __forceinline__ void jacobi_add(Arr<NT>& out, const Arr<NT>& bpa, con
     for (int i = 0; i < NT; ++i) out.t[i] = (bpa.t[i] - A.t[i]) + (in_a ? Ya.t[i] : Yb.t[i]);
 }
 
-template <int NT, int BW, bool JAC>
+// REGOP (quad layout): the operator of the chain's m + 1 products is held in 10 NT registers (OpQ); false: every product reads it from
+// LDS again (mm_t4q) -- 60 registers less inside the recurrence at NT = 6
+template <int NT, int BW, bool JAC, bool REGOP = true>
 __device__ __forceinline__ void horner_add(Arr<NT>& out, const Arr<NT>& bpa, const Arr<NT>& A, const double* S, int m,
                                            Arr<NT>& Ya, Arr<NT>& Yb, double jacobi_tol2, int ncol)
 {
@@ -1511,7 +1522,7 @@ __device__ __forceinline__ void horner_add(Arr<NT>& out, const Arr<NT>& bpa, con
 #ifdef JQ_EXP_NOOPQ
     if constexpr (false) {
 #else
-    if constexpr (BW == JQ_BW_T4Q) {
+    if constexpr (BW == JQ_BW_T4Q && REGOP) {
 #endif
         OpQ<NT> op;
         t4q_load(op, S);
@@ -1598,6 +1609,12 @@ __device__ __forceinline__ void a_unpark(Arr<NT>& a, const double* park)
 #ifndef JQ_BWD_ADJ_FUSE   // adjoint step: K0 X and K1 X in one pass
 #define JQ_BWD_ADJ_FUSE 1
 #endif
+#ifndef JQ_BWD3_NOOPQ     // twelve-wave backward kernel: Neumann recurrences of the ADJOINT step with the operator re-read from LDS per product
+#define JQ_BWD3_NOOPQ 0
+#endif
+#ifndef JQ_BWD3_NOOPQ_STATE   // ... and of the state re-integration inside it
+#define JQ_BWD3_NOOPQ_STATE 0
+#endif
 // State (re-)integration, operator uses 0..5 of one Stormer-Verlet step (forward step!,
 // src/StormerVerlet.jl:461-504, also used with h<0 by the backward sweep, src/evalobjgrad.jl:879).
 //   in : u (preserved), v (CONSUMED: overwritten in place by v05 = v(t+h/2))
@@ -1607,7 +1624,7 @@ __device__ __forceinline__ void a_unpark(Arr<NT>& a, const double* park)
 // FUSE (quad layout only): bit 0 = K05 u with S0 u in one pass, bit 1 = S05 v05 with K0 v05 and K1 v05 in one pass
 // FOLD (quad layout, one sample per wave): `ceps` is the per-lane MASKED shift (+c eps on the lanes that hold the diagonal of the MFMA's
 // A operand, 0 elsewhere; 0 everywhere without a shift) and every product with a K image folds it into its operand (mm_t4q SH)
-template <int NT, int BW, bool JAC, int FUSE = 0, bool FOLD = false, typename RING = RingT<BW == JQ_BW_T4Q>>
+template <int NT, int BW, bool JAC, int FUSE = 0, bool FOLD = false, bool REGOP = true, typename RING = RingT<BW == JQ_BW_T4Q>>
 __device__ __forceinline__ void sv_state(RING& p, const PropArgs& a, bool active, double ceps, const double* ws, int g,
                                          const Arr<NT>& u, Arr<NT>& v, Arr<NT>& unew, Arr<NT>& vN, Arr<NT>& A, Arr<NT>& Ya,
                                          Arr<NT>& Yb)
@@ -1638,7 +1655,7 @@ __device__ __forceinline__ void sv_state(RING& p, const PropArgs& a, bool active
         if (active) {
             mm_c<NT, BW>(A, A, M0, v);                                 // A = c (K05 u + S05 v)
             a_add(v, A);
-            horner_add<NT, BW, JAC>(v, v, A, M0, a.m, Ya, Yb, a.jacobi_tol2, a.N);       // v = v05
+            horner_add<NT, BW, JAC, REGOP>(v, v, A, M0, a.m, Ya, Yb, a.jacobi_tol2, a.N);       // v = v05
         }
         M1 = p.template next_ks<0, 0>();                    // Kn0
         const double* M2 = p.template next_ks<0, 2>();      // Kn1
@@ -1663,7 +1680,7 @@ __device__ __forceinline__ void sv_state(RING& p, const PropArgs& a, bool active
         if (active) {
             mm_c<NT, BW>(A, A, M0, unew);                              // A = c (S1 (u + c kappa1) - K1 v05)
             a_add(unew, A);
-            horner_add<NT, BW, JAC>(unew, unew, A, M0, a.m, Ya, Yb, a.jacobi_tol2, a.N);
+            horner_add<NT, BW, JAC, REGOP>(unew, unew, A, M0, a.m, Ya, Yb, a.jacobi_tol2, a.N);
         }
         return;
     }
@@ -1683,7 +1700,7 @@ __device__ __forceinline__ void sv_state(RING& p, const PropArgs& a, bool active
     if (active) {
         mm_c<NT, BW>(A, A, M, v);
         a_add(v, A);
-        horner_add<NT, BW, JAC>(v, v, A, M, a.m, Ya, Yb, a.jacobi_tol2, a.N);
+        horner_add<NT, BW, JAC, REGOP>(v, v, A, M, a.m, Ya, Yb, a.jacobi_tol2, a.N);
         mm_c<NT, BW>(vN, v, M, v);
     }
     // use 2: Kn0 -- unew = u - c K0 v05
@@ -1714,7 +1731,7 @@ __device__ __forceinline__ void sv_state(RING& p, const PropArgs& a, bool active
     if (active) {
         mm_c<NT, BW>(A, A, M, unew);
         a_add(unew, A);
-        horner_add<NT, BW, JAC>(unew, unew, A, M, a.m, Ya, Yb, a.jacobi_tol2, a.N);
+        horner_add<NT, BW, JAC, REGOP>(unew, unew, A, M, a.m, Ya, Yb, a.jacobi_tol2, a.N);
     }
 }
 
@@ -1957,6 +1974,9 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
     WLow<NT, QUAD> wl;
     if constexpr (WLR) wl.init(a, lane_, smem);
     const bool wforce = WLR && a.wrank > 0 && a.forced;
+    // (twelve-wave kernel, 168 registers per wave: JQ_BWD3_NOOPQ=1 lets the Neumann recurrences read their operator from LDS per product
+    //  instead of holding it in 60 registers -- no spill stores left in the time loop, round 5 experiment)
+    constexpr bool BREG = !(QUAD && MINW >= 3 && JQ_BWD3_NOOPQ);
 
     if (a.first_chunk) {
         // carry_q = tr(vr' Hsym_q lambdai) at t = T: the "vr0/lambdai0" term of the first backward
@@ -1977,7 +1997,7 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
         // mu's registers serve as the scratch array A of the state step
         // (UNI: the fused stages -- shared lane shifts of u and of v05 -- also in the twelve-wave kernel: round 3 measured them slower there,
         //  104 -> 144 ... 172 B of scratch; with the registers the UNI variant frees they pay: backward sweep 772 -> 757 ms, round 4)
-        sv_state<NT, BW, JAC, (MINW >= 3 ? (UNI ? 3 : JQ_BWD_FUSE3) : JQ_BWD_FUSE), UNI>(p, a, active, ceps, ws, g, u, v, un, vN, mu, Ya, Yb);
+        sv_state<NT, BW, JAC, (MINW >= 3 ? (UNI ? 3 : JQ_BWD_FUSE3) : JQ_BWD_FUSE), UNI, !(QUAD && MINW >= 3 && JQ_BWD3_NOOPQ_STATE)>(p, a, active, ceps, ws, g, u, v, un, vN, mu, Ya, Yb);
         // (every wave has passed a workgroup barrier since it finished step n-1: begin_step in window mode, the operator
         // switches of sv_state otherwise)
         if (n > 0) flush_traces(n - 1);
@@ -2012,7 +2032,7 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
                         wl.axpy2(k, L, cl * pu, cl * qu);      // + c hr0
                     }
             a_add(mu, L);
-            horner_add<NT, BW, JAC>(mu, mu, L, M, a.m, Ya, Yb, a.jacobi_tol2, a.N);
+            horner_add<NT, BW, JAC, BREG>(mu, mu, L, M, a.m, Ya, Yb, a.jacobi_tol2, a.N);
         }
         // early traces with X (lets vr0 = u die here): tr1 = tr(vr0' Hanti_q X), tr3 = tr(vr' Hanti_q X)
         double o_p4 = 0.0;      // ORD: the new part of tr4 of control 1, formed in the pass of use 11
@@ -2082,7 +2102,7 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
             mm_c<NT, BW>(vN, vN, M, L);       // vN = Q
             a_add(L, nb);
             a_add(L, vN);                     // L = nb + L + Q
-            horner_add<NT, BW, JAC>(L, L, vN, M, a.m, Ya, Yb, a.jacobi_tol2, a.N);  // L = nb_new
+            horner_add<NT, BW, JAC, BREG>(L, L, vN, M, a.m, Ya, Yb, a.jacobi_tol2, a.N);  // L = nb_new
             a_add(nb, L);                     // nb = nb_old + nb_new = -(li0 + li)
         }
         // use 11: Kp05 -- vN(scratch G) = X + c K05 nb_new (= lambda_r^{1/2} - c K05 li_new)

@@ -1910,13 +1910,16 @@ struct EvalOut {
 // Time of one round of the 4 x 4 x n kernel families relative to a round of the slab kernels (4 #CU slabs), measured at cnot3
 // (scripts/time_staircase.py, round 3: 0.495 / 0.748 / 1.104 s for #CU / 2 #CU / 3 #CU slabs on the quad-layout kernels with 1 / 2 / 3
 // slabs per workgroup, 0.192 s for a round of the cooperative-quad kernels)
-static const double T4_REL[4] = {1.0, 0.276, 0.417, 0.615};
-static const double T4_REL_CQ = 0.107;
+// (round 5, same unit of 1.7935 s: 0.408 / 0.741 / 1.038 s -- one slab per workgroup now runs its backward sweep on two waves per column
+//  quad, jq_quad_split_kernels.h; 0.192 s for up to #CU column quads on the cooperative-quad kernels, 0.298 s for up to 2 #CU)
+static const double T4_REL[4] = {1.0, 0.2275, 0.413, 0.579};
+static const double T4_REL_CQ = 0.107;      // <= #CU column quads
+static const double T4_REL_CQ2 = 0.166;     // <= 2 #CU: forward sweep with two quads per workgroup, backward sweep k_backward_qsplit<.., 2>
 static double t4_plan_cost(const jq_handle* h, long long nsamples)
 {
     const long long nslabs = h->parts > 1 ? nsamples * h->parts : (nsamples + h->sps - 1) / h->sps;
     const long long nquads = (nsamples * h->N + 3) / 4;
-    if (h->cq_max_quads > 0 && nquads <= h->cq_max_quads) return T4_REL_CQ * (double)((nquads + h->num_cu - 1) / h->num_cu);
+    if (h->cq_max_quads > 0 && nquads <= h->cq_max_quads) return nquads <= h->num_cu ? T4_REL_CQ : nquads <= 2 * h->num_cu ? T4_REL_CQ2 : T4_REL_CQ * (double)((nquads + h->num_cu - 1) / h->num_cu);
     const double* rel = T4_REL;
     double best = rel[0] * (double)((nslabs + 4 * h->num_cu - 1) / (4 * h->num_cu));
     if (nslabs <= h->quad_max_slabs)
