@@ -97,23 +97,28 @@ struct Cq3Hand {
 // grid = 24 * ceil(quads / 8), block = 64 * (NT + 2): workgroup b has role (b / 8) % 3 of quad 8 (b / 24) + b % 8 (slab = quad / 4);
 // roles 0 and 1: NT block waves and two staging waves (as k_forward_cq), role 2: NT block waves (the other two leave).
 // a.park: the hand-off buffer (zeroed by the host before every launch).  Dynamic LDS as k_backward_cq.
-template <int NT, bool MODD, bool ORD>
+// NR = 2 (round 5; 2 x quads <= CUs, i.e. 81 .. 128 cnot3 samples): TWO workgroups per quad, grid = 16 * ceil(quads / 8) -- role 0 as above,
+// role 1 runs the adjoint step AND all trace products (the adjoint path of k_backward_cq with the state waves' share of the traces:
+// its publications carry every neighbouring block the trace products need; nothing but u, vi05, vr(t_n) crosses the ring, role 0
+// reuses a slot when role 1 has loaded it).  The trace sums are those of k_backward_cq, term for term: bit-identical results.
+template <int NT, bool MODD, bool ORD, int NR = 3>
 __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
 {
+    static_assert(NR == 3 || NR == 2, "workgroups per column quad");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KT = 4 * NT;
     constexpr int M = MODD ? 1 : 0;
     typedef typename CoopQ<NT>::Sh Sh;
     typedef typename CoopQ<NT>::Nb Nb;
     typedef typename CoopQ<NT>::Op Op;
-    const int role = ((int)blockIdx.x >> 3) % 3;
-    const int quad = 8 * ((int)blockIdx.x / 24) + ((int)blockIdx.x & 7);
+    const int role = ((int)blockIdx.x >> 3) % NR;
+    const int quad = 8 * ((int)blockIdx.x / (8 * NR)) + ((int)blockIdx.x & 7);
     const CqSetup<NT> s = cq_setup<NT>(a, quad >> 2, quad & 3);
     const int Nc = a.Ncoupled;
     const size_t trow = (size_t)s.slab * a.qps + s.qd;
     if (s.slab >= a.nslabs) return;
     if (!s.active) {
-        if (role == 2 && s.qd < a.qps)
+        if (role == NR - 1 && s.qd < a.qps)
             for (int k = threadIdx.x; k < a.nsteps_chunk * Nc * JQ_NTR; k += blockDim.x) a.traces[trow * a.nsteps_chunk * Nc * JQ_NTR + k] = 0.0;
         return;
     }
@@ -273,6 +278,11 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();      // (the block waves' last publication)
+        if (NR == 2 && role == 1)          // (... and the barriers of their cq_wg_sum of the trace carries)
+            for (int q = 0; q < Nc; ++q) {
+                __syncthreads();
+                __syncthreads();
+            }
         return;
     }
     // (the tables are complete behind the barrier of ring.init)
@@ -284,8 +294,9 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
         Op Kp05 = c.load(c.ring.template ks<0, 1>()), S0 = c.load(c.ring.template ks<1, 0>());
         auto step = [&](auto P0c, int n) {
             constexpr int P0 = decltype(P0c)::value;
-            // (a slot is reused when the trace workgroup has read it)
-            if (wave == 0 && n >= JQ_CQ3_SLOTS) hd.wait(2, (unsigned long long)(n - JQ_CQ3_SLOTS + 1));
+            // (a slot is reused when the trace workgroup has read it; NR = 2: when the adjoint workgroup has -- it publishes n once the
+            //  loads of the steps <= n have landed in all its waves)
+            if (wave == 0 && n >= JQ_CQ3_SLOTS) hd.wait(NR - 1, (unsigned long long)(n - JQ_CQ3_SLOTS + (NR == 3 ? 1 : 0)));
             double un, v05, vN;
             // x = u: A = c K05 u ; P = u + c S0 u
             c.template post<P0, 0>(u);
@@ -372,6 +383,49 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
     Op Kp05 = c.load(c.ring.template ks<0, 1>()), S05 = c.load(c.ring.template ks<1, 1>());
     const double cfw = (a.forced ? 0.5 * a.h * a.tinv : 0.0) * wdr;      // forcing weight c tinv wd[row]; 0 for step_no_forcing!
     double hu = 0.0, hv = 0.0, hn = 0.0;      // u, v05, un of the step (fetched one step ahead)
+    // NR = 2: the trace scalars of k_backward_cq (its adjoint waves' t1, t3, t4 and its state waves' t2, t5), handed over through red
+    const int ntr = Nc * JQ_NTR, ngroups = Nc + (Nc + 1) / 2;
+    double* red = scratch;                                      // [ngroups][NT][64]
+    double* redw = red + (size_t)wave * 64 + lane_;
+    double carry[JQ_MAXNC];
+#pragma unroll
+    for (int q = 0; q < JQ_MAXNC; ++q) carry[q] = 0.0;
+    auto finish_traces = [&](int k) {
+        for (int g = wave; g < ngroups; g += NT) {
+            const double* r = red + (size_t)g * NT * 64 + lane_;
+            double sum = r[0];
+#pragma unroll
+            for (int w = 1; w < NT; ++w) sum += r[w * 64];
+            sum = row_ror_add<8>(sum);
+            sum = row_ror_add<4>(sum);
+            sum = row_ror_add<2>(sum);
+            sum = row_ror_add<1>(sum);
+            const int row = lane_ >> 4;
+            int q, kk;
+            if (g < Nc)
+                q = g, kk = row == 0 ? 0 : row == 1 ? 3 : row == 2 ? 2 : -1;
+            else
+                q = 2 * (g - Nc) + (row >> 1), kk = (row & 1) ? 4 : 1;
+            if ((lane_ & 15) == 0 && kk >= 0 && q < Nc) a.traces[(trow * a.nsteps_chunk + k) * ntr + q * JQ_NTR + kk] = sum;
+        }
+    };
+    if constexpr (NR == 2) {
+        const bool slot0 = wave == 0 && ((lane_ >> 2) & 3) == 0;      // the lanes that carry per-column partials between chunks
+#pragma unroll
+        for (int q = 0; q < JQ_MAXNC; ++q)
+            if (q < Nc && slot0) carry[q] = st[(size_t)(JQ_STATE_ARRAYS * KT + q) * 64 + cslot];
+        if (a.first_chunk) {
+            // carry_q = tr(vr' Hsym_q lambdai) at t = T (see k_backward): vr(T) and -lambda_i(T) with its neighbouring blocks from the state file
+            const double u0 = st[s.foff];
+            Nb nn;
+            nn.b = wave > 0 ? st[(size_t)3 * KT * 64 + s.foff - 256] : 0.0;
+            nn.a = wave + 1 < NT ? st[(size_t)3 * KT * 64 + s.foff + 256] : 0.0;
+            const Sh sx = c.sh(nb);
+#pragma unroll
+            for (int q = 0; q < JQ_MAXNC; ++q)
+                if (q < Nc) carry[q] = -(u0 * c.template trace_mm<ORD>(c.ring.cimg(q), q, sx, nn));
+        }
+    }
     auto step = [&](auto P0c, int n) {
         constexpr int P0 = decltype(P0c)::value;
         if (wave == 0) hd.wait(0, (unsigned long long)(n + 2 < nst ? n + 2 : nst));
@@ -389,6 +443,8 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
             L = c.nbr(L, Kp05, nn);
             Tn = c.nbr(Tn, S05, nn);
         }
+        if constexpr (NR == 2)
+            if (n > 0) finish_traces(n - 1);      // (behind the step's first barrier: everybody's hand-off of step n - 1 is in red)
         if (n == 0) hu = hd.load(0, 0, wave), hv = hd.load(0, 1, wave), hn = hd.load(0, 2, wave);      // (first step of the chunk: latency exposed once)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (hu, hv, hn of this step have landed; my stores of step n - 1 are acknowledged)
         const double u = hu, v05 = hv, un = hn;      // vr before the state step (:862), vi05, vr after it
@@ -406,10 +462,11 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
             Kn1 = c.load(c.ring.template ks<0, 2>());
             S1 = c.load(c.ring.template ks<1, 2>());
         });
-        hd.store(n, 3, wave, X);
-        // x = X: Lk = -c K0 X, Q = -c K1 X, SX = c S1 X
+        if constexpr (NR == 3) hd.store(n, 3, wave, X);
+        // x = X: Lk = -c K0 X, Q = -c K1 X, SX = c S1 X ; NR = 2: Hanti_q X (tr1, tr3), Hsym_q X (tr2)
         c.template post<P0 ^ M, 1>(X);
-        double Lk, Q, SX;
+        double Lk, Q, SX, Tq[JQ_MAXNC], t2[JQ_MAXNC];
+        const double v05w = v05 * wgt;
         {
             const Sh sx = c.sh(X);
             Lk = c.own(0.0, Kn0, sx);
@@ -424,6 +481,15 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
             Lk = c.nbr(Lk, Kn0, nn);
             Q = c.nbr(Q, Kn1, nn);
             SX = c.nbr(SX, S1, nn);
+#pragma unroll
+            for (int q = 0; q < JQ_MAXNC; ++q) {
+                Tq[q] = 0.0, t2[q] = 0.0;
+                if constexpr (NR == 2)
+                    if (q < Nc) {
+                        Tq[q] = c.template trace_mm<ORD>(c.ring.cimg(Nc + q), q, sx, nn);
+                        t2[q] = v05w * c.template trace_mm<ORD>(c.ring.cimg(q), q, sx, nn);
+                    }
+            }
         }
         // Lk = -c l2 = -c (K0 X + S05 li + hi0) ; Q = -c (S05 (li + c l2) + K1 X + hi1)
         {
@@ -438,10 +504,13 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
         Q = c.nbr(Q, S05, c.template nbs<P0 ^ M ^ 1, 1>());
         const double nbn = c.template horner<P0 ^ M, 1, MODD>((nb + Lk) + Q, Q, S05, a.m);
         const double Bq = nb + nbn;      // -(li0 + li)
-        hd.store(n, 4, wave, nbn);
-        hd.store(n, 5, wave, Bq);
-        // x = nb_new: lambda_r_new = X + c (S1 X - K05 li_new + hr1)
+        if constexpr (NR == 3) {
+            hd.store(n, 4, wave, nbn);
+            hd.store(n, 5, wave, Bq);
+        }
+        // x = nb_new: lambda_r_new = X + c (S1 X - K05 li_new + hr1) ; NR = 2: Hsym_q li_new (tr4), Hanti_q (li0 + li) (tr5)
         c.template post<P0, 1>(nbn);
+        if constexpr (NR == 2) c.template post<P0, 2>(Bq);      // (channel 2: the neighbouring blocks of -(li0 + li) for tr5)
         double G;
         {
             const Sh sx = c.sh(nbn);
@@ -456,6 +525,25 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
             c.ring.advance();
             Kp05 = c.load(c.ring.template ks<0, 1>());
             S05 = c.load(c.ring.template ks<1, 1>());
+            if constexpr (NR == 2) {
+                const double uw = u * wgt, unw = un * wgt;
+                const Sh sb = c.sh(Bq);
+                const Nb nx = c.template nbs<P0, 2>();
+                double t5[JQ_MAXNC];
+#pragma unroll
+                for (int q = 0; q < JQ_MAXNC; ++q) {
+                    t5[q] = 0.0;
+                    if (q < Nc) {
+                        const double pq = -(un * c.template trace_mm<ORD>(c.ring.cimg(q), q, sx, nn));
+                        const double t4 = (pq + carry[q]) * wgt;
+                        carry[q] = pq;
+                        redw[(size_t)q * NT * 64] = cq_part4(uw * Tq[q], unw * Tq[q], t4, 0.0);      // rows 0, 2, 1: t1, t3, t4
+                        t5[q] = -(v05w * c.template trace_mm<ORD>(c.ring.cimg(Nc + q), q, sb, nx));
+                    }
+                }
+                redw[(size_t)Nc * NT * 64] = cq_part4(t2[0], t2[1], t5[0], t5[1]);
+                if (Nc > 2) redw[(size_t)(Nc + 1) * NT * 64] = cq_part4(t2[2], t2[3], t5[2], t5[3]);
+            }
         }
         mu = G;
         nb = nbn;
@@ -466,9 +554,25 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
         step(std::integral_constant<int, 1>{}, n + 1);
     }
     if (n < nst) step(std::integral_constant<int, 0>{}, n);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     if (wave == 0 && lane_ == 0) hd.publish(1, (unsigned long long)nst);
     st[(size_t)2 * KT * 64 + s.foff] = mu;
     st[(size_t)3 * KT * 64 + s.foff] = nb;
+    if constexpr (NR == 2) {
+        finish_traces(nst - 1);
+        // the two roles ran on one XCD?
+        if (threadIdx.x == 0) {
+            const unsigned long long x0 = __hip_atomic_load(hd.head + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long x1 = __hip_atomic_load(hd.head + 33, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (x0 != x1) __hip_atomic_store(hd.gerr, 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int q = 0; q < JQ_MAXNC; ++q)
+            if (q < Nc) {      // (the staging waves pass these barriers too)
+                const double tot = cq_wg_sum(carry[q], scratch, wave, lane_, NT);
+                if (wave == 0 && ((lane_ >> 2) & 3) == 0) st[(size_t)(JQ_STATE_ARRAYS * KT + q) * 64 + cslot] = tot;
+            }
+    }
 }

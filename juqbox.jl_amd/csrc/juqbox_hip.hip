@@ -1554,7 +1554,7 @@ JQ_DECLQ(1) JQ_DECLQ(2) JQ_DECLQ(3) JQ_DECLQ(4) JQ_DECLQ(5) JQ_DECLQ(6) JQ_DECLQ
 #undef JQ_DECLQ
 template <int NT, bool MODD, int NS> __global__ void k_forward_cq(PropArgs);    // jq_cq_kernels.h (own translation units); NS: column quads per workgroup
 template <int NT, bool MODD, bool ORD> __global__ void k_backward_cq(PropArgs);
-template <int NT, bool MODD, bool ORD> __global__ void k_backward_cq3(PropArgs);    // jq_cq_split_kernels.h: three workgroups per column quad
+template <int NT, bool MODD, bool ORD, int NR = 3> __global__ void k_backward_cq3(PropArgs);    // jq_cq_split_kernels.h: three (NR = 2: two) workgroups per column quad
 #define JQ_DECLCQ(nt)                                                      \
     extern template __global__ void k_forward_cq<nt, false, 1>(PropArgs);  \
     extern template __global__ void k_forward_cq<nt, false, 2>(PropArgs);  \
@@ -1567,14 +1567,19 @@ template <int NT, bool MODD, bool ORD> __global__ void k_backward_cq3(PropArgs);
     extern template __global__ void k_backward_cq3<nt, false, false>(PropArgs);   \
     extern template __global__ void k_backward_cq3<nt, false, true>(PropArgs);    \
     extern template __global__ void k_backward_cq3<nt, true, false>(PropArgs);    \
-    extern template __global__ void k_backward_cq3<nt, true, true>(PropArgs);
+    extern template __global__ void k_backward_cq3<nt, true, true>(PropArgs);     \
+    extern template __global__ void k_backward_cq3<nt, false, false, 2>(PropArgs);   \
+    extern template __global__ void k_backward_cq3<nt, false, true, 2>(PropArgs);    \
+    extern template __global__ void k_backward_cq3<nt, true, false, 2>(PropArgs);    \
+    extern template __global__ void k_backward_cq3<nt, true, true, 2>(PropArgs);
 JQ_DECLCQ(1) JQ_DECLCQ(2) JQ_DECLCQ(3) JQ_DECLCQ(4) JQ_DECLCQ(5) JQ_DECLCQ(6) JQ_DECLCQ(7)
 #undef JQ_DECLCQ
 // (instantiated for even and odd numbers of Neumann terms: the parities of the LDS exchange are compile-time constants)
 // fwd2: the forward kernel with two column quads per workgroup (grid = 2 * nslabs); bwd3: the backward sweep on three workgroups per
 // quad (k_backward_cq3)
-static int select_cq_kernels(jq_handle* h, bool fwd2, bool bwd3, prop_kernel_t* fwd, prop_kernel_t* bwd)
+static int select_cq_kernels(jq_handle* h, bool fwd2, int bwd_nr, prop_kernel_t* fwd, prop_kernel_t* bwd)      // bwd_nr: workgroups per quad in the backward sweep (0 / 1: one)
 {
+    const bool bwd3 = bwd_nr == 3, bwd2 = bwd_nr == 2;
     const bool modd = (h->m > 0 ? h->m : 0) & 1;
     // control q acts on subsystem q only (the usual Juqbox set-up: Hsym_ops = [a + a', b + b', c + c']): its trace products need
     // one part of the product each
@@ -1585,6 +1590,8 @@ static int select_cq_kernels(jq_handle* h, bool fwd2, bool bwd3, prop_kernel_t* 
         *fwd = fwd2 ? (modd ? k_forward_cq<nt, true, 2> : k_forward_cq<nt, false, 2>) : (modd ? k_forward_cq<nt, true, 1> : k_forward_cq<nt, false, 1>);            \
         *bwd = bwd3 ? (modd ? (ord ? k_backward_cq3<nt, true, true> : k_backward_cq3<nt, true, false>)          \
                             : (ord ? k_backward_cq3<nt, false, true> : k_backward_cq3<nt, false, false>))       \
+             : bwd2 ? (modd ? (ord ? k_backward_cq3<nt, true, true, 2> : k_backward_cq3<nt, true, false, 2>)    \
+                            : (ord ? k_backward_cq3<nt, false, true, 2> : k_backward_cq3<nt, false, false, 2>)) \
                     : modd ? (ord ? k_backward_cq<nt, true, true> : k_backward_cq<nt, true, false>)          \
                            : (ord ? k_backward_cq<nt, false, true> : k_backward_cq<nt, false, false>);       \
         return JQ_OK;                                                              \
@@ -2191,20 +2198,25 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     // Co-residency is checked, not assumed: the split is taken only when this evaluation is the only one of the process on the device
     // (GateHold: others then wait until it is through), when no CU mask is in force (the grid is sized for all CUs the device
     // reports), and not while the handle is cooling down after a fault.
+    // (round 5: 2 x quads <= CUs -- 81 .. 128 cnot3 samples -- two workgroups per quad: state re-integration | adjoint step + trace products,
+    //  Stormer-Verlet only; JQ_CQ3=3: three or none)
     GateHold gate_hold;
     bool cq3 = false;
+    int cq_nr = 0;      // workgroups per column quad of the split backward sweep
     if ((cq || imr_cq) && adjoint) {
         const char* why = nullptr;
+        cq_nr = 3 * nq_pad <= h->num_cu ? 3 : (cq && 2 * nq_pad <= h->num_cu && !(e_c3 && atoi(e_c3) == 3)) ? 2 : 0;
         if (e_c3 && atoi(e_c3) == 0) why = "not taken: JQ_CQ3=0";
-        else if (3 * nq_pad > h->num_cu) why = "not taken: three workgroups per column quad exceed the compute units";
+        else if (cq_nr == 0) why = "not taken: two / three workgroups per column quad exceed the compute units";
         else if (h->cq3_off) why = "not taken: switched off after repeated faults (dead waits between the workgroups of a quad)";
         else if (h->cq3_skip > 0) why = "not taken: cooling down after a fault";
         else if (getenv("HSA_CU_MASK") || getenv("ROC_GLOBAL_CU_MASK")) why = "not taken: a CU mask is set (HSA_CU_MASK / ROC_GLOBAL_CU_MASK)";
         else if (g_eval_depth != 1) why = "not taken: nested evaluation (part of a split batch / embedded twin)";
         else if (!gate_hold.acquire(dev_gate(h->device))) why = "not taken: another evaluation of this process is in flight on the device";
         cq3 = (why == nullptr);
+        if (!cq3) cq_nr = 0;
         if (h->cq3_skip > 0) --h->cq3_skip;
-        h->cq3_last = cq3 ? "taken: three workgroups per column quad, device held exclusively" : why;
+        h->cq3_last = cq3 ? (cq_nr == 3 ? "taken: three workgroups per column quad, device held exclusively" : "taken: two workgroups per column quad, device held exclusively") : why;
     }
     const size_t cq3_quad = 64 + (size_t)8 * 6 * h->NT * 64;      // doubles per quad: JQ_CQ3_HEAD + JQ_CQ3_SLOTS * JQ_CQ3_ARRAYS * NT * 64
     const size_t cq3_need = 64 + (size_t)nq_pad * cq3_quad;
@@ -2213,7 +2225,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
         if (rc0) return rc0;
         HIPCHK(h, hipMemsetAsync(h->d_cq3, 0, 64 * sizeof(double), h->stream));      // (the error word of the evaluation)
     }
-    const bool imr_cq3 = imr_cq && cq3;
+    const bool imr_cq3 = imr_cq && cq3 && cq_nr == 3;
     const char* e_icq2 = getenv("JQ_IMR_CQ2");
     const bool imr_cq2 = imr_cq && !imr_cq3 && h->NT <= 6 && !(e_icq2 && atoi(e_icq2) == 0) &&
                          cq_imr2_lds(h, (size_t)(2 * JQ_WIN_TPS + 2 * h->NcK) * h->mat_elems * 8) <= 163840;
@@ -2262,7 +2274,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
              : imr_rl ? select_rowlane_imr_kernels(h, rl_split, &kfwd, &kbwd)
              : rl ? select_rowlane_kernels(h, rl_split, &kfwd, &kbwd)
              : lane ? select_lane_kernels(h, &kfwd, &kbwd, &klinit, &klterm)
-                  : cq ? select_cq_kernels(h, cq_fwd2, cq3, &kfwd, &kbwd)
+                  : cq ? select_cq_kernels(h, cq_fwd2, cq_nr, &kfwd, &kbwd)
                   : coop ? select_coop_kernels(h, &kfwd, &kbwd) : quad ? (wfull ? select_quad_w_kernels(h, &kfwd, &kbwd) : select_quad_kernels(h, spw, &kfwd, &kbwd)) : select_kernels(h, &kfwd, &kbwd);
     if (rc) return rc;
     if (qsplit && (rc = select_qsplit_kernel(h, qs_qw, &kbwd))) return rc;
@@ -2538,7 +2550,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
                 if (qsplit)
                     hipLaunchKernelGGL(kbwd, dim3((unsigned)qs_blocks), dim3(128 * qs_qw), lds_bwd, s, a);
                 else if (cq3)
-                    hipLaunchKernelGGL(kbwd, dim3((unsigned)(3 * nq_pad)), dim3(nthreads + 128), lds_bwd, s, a);      // (three workgroups per quad: NT block waves + two staging waves each)
+                    hipLaunchKernelGGL(kbwd, dim3((unsigned)(cq_nr * nq_pad)), dim3(nthreads + 128), lds_bwd, s, a);      // (three / two workgroups per quad: NT block waves + two staging waves each)
                 else
                 hipLaunchKernelGGL(kbwd, dim3(nblocks), dim3((cq || rl_split) ? 2 * nthreads : imr_cq2 ? 2 * (nthreads + 128) : imr_cq ? nthreads + 128 : nthreads), lds_bwd + (wlr_lds_bwd >= 0 ? wlr_bytes : 0), s, a);      // (cooperative quad: state and adjoint chain on separate waves)
                 HIPCHK(h, hipEventRecord(h->ev[evi++], s));
@@ -2636,7 +2648,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     h->timing.kernel_family = imr_cq ? 9 : cq ? 8 : imr_quad ? 7 : imr_coop ? 5 : imr ? 4 : rl ? 3 : lane ? 2 : coop ? 1 : quad ? 6 : 0;
     h->timing.kernel_size = rl ? h->rl_npj : lane ? h->lane_np : h->NT;
     h->timing.kernel_band = (rl || lane) ? 0 : coop ? h->BWc : (quad || cq) ? JQ_BW_T4Q : h->BW;
-    h->timing.reserved = cq3 ? 3 : qsplit ? 20 + qs_qw : 0;      // (workgroups per column quad in the backward sweep of the cooperative-quad kernels)
+    h->timing.reserved = cq3 ? cq_nr : qsplit ? 20 + qs_qw : 0;      // (workgroups per column quad in the backward sweep of the cooperative-quad kernels)
     h->timing.ms_allreduce = 0.0;
     h->timing.ms_shard_min = h->timing.ms_shard_max = h->timing.ms_total;
     return JQ_OK;

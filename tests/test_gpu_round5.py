@@ -326,3 +326,25 @@ def test_all_reduce_self_check_comparison_runs_in_the_same_device_mode(jq):
         return n
     assert _with_env({"JQ_MULTI_SAME_DEVICE": "1", "JQ_RCCL_SELFCHECK": "3"}, run) == 2
     assert _with_env({"JQ_MULTI_SAME_DEVICE": "1"}, run) == 0
+
+
+# ---- (5) latency path, 81 .. 128 samples: two workgroups per column quad ---------------------------------------------------------------
+
+@pytest.mark.parametrize("kind,nsamples,chunk", [("cnot3", 81, 300), ("cnot3", 128, 0), ("cnot3", 97, 1), ("t4x3", 100, 20), ("t4x5", 90, 19)])
+def test_backward_sweep_on_two_workgroups_per_quad_is_the_one_workgroup_kernel(jq, kind, nsamples, chunk):
+    """Round 5: with 2 x quads <= CUs < 3 x quads (81 .. 128 cnot3 samples) k_backward_cq3<.., NR = 2> gives a column quad two workgroups --
+    state re-integration | adjoint step + ALL trace products (the adjoint path of k_backward_cq with the state waves' share of the
+    traces; only u, vi05, vr(t_n) cross the ring).  Every chain and every trace sum performs the operations of k_backward_cq (JQ_CQ3=0)
+    in the same order: bit-identical results -- ragged groups of 8 quads, several chunks (also of one step), odd / even numbers of
+    Neumann terms, NT = 3, 5, 6, single-subsystem and generic trace products, objFuncType 2 / 3, and run to run."""
+    params, pcof = _problem(jq, kind)
+    rng = np.random.default_rng(nsamples)
+    nodes, weights = 0.02 * rng.standard_normal(nsamples), rng.random(nsamples)
+    shift = 0.01 * np.arange(params.Ntot)
+    env = {"JQ_CHUNK_STEPS": str(chunk)} if chunk else {}
+    a = _eval(jq, params, pcof, nodes, weights, shift, env)
+    b = _eval(jq, params, pcof, nodes, weights, shift, dict(env, JQ_CQ3="0"))
+    c = _eval(jq, params, pcof, nodes, weights, shift, env)
+    assert (a[4]["kernel_family"], a[4]["reserved"]) == (8, 2) and (b[4]["kernel_family"], b[4]["reserved"]) == (8, 0), (a[4], b[4])
+    for x in (b, c):
+        assert a[0] == x[0] and a[1] == x[1] and np.array_equal(a[2], x[2]) and np.array_equal(a[3], x[3])
