@@ -1004,6 +1004,7 @@ struct PropArgs {
     int wrank;
     int wstride;
     int wlr_lds;            // slab / quad kernels: byte offset in dynamic LDS where the workgroup keeps a copy of the table, or -1 (read it from global memory)
+    int wlr_sc_lds;         // quad layout: byte offset of the per-wave column scalars of the terms ([wave][JQ_MAX_WRANK][6][4] doubles), or -1
 };
 #ifndef JQ_MAX_WRANK
 #define JQ_MAX_WRANK 16       // largest rank of a full weight matrix the kernels take (include/juqbox_hip.h)
@@ -1039,6 +1040,17 @@ struct WLow {
     const double* lamp;     // lam[k]
     int r, stride;
     bool lead;      // one lane per column: adds the column's scalar terms to a per-lane partial sum
+    // Column scalars of the terms kept across uses and steps (quad layout, round 5): the dots of a step's vr(t_n), vi05 are needed at
+    // two sites of the adjoint step, and the dots with vr(t_n+1) ARE the previous step's dots with vr(t_n) -- five dot pairs per term
+    // and step become two (a dot pair is ~ 64 instructions with its two column sums; cnot3: 57 -> ~ 36 ms per forbidden state).  The
+    // rank is a run-time number, so the scalars live in LDS: [term][slot 0 .. 5][column of the quad], written by the lead lanes.
+    __attribute__((address_space(3))) double* sc;
+    bool has_sc;
+    __device__ __forceinline__ void put(int k, int j, double val) const
+    {
+        if (lead) sc[(k * 6 + j) * 4] = val;
+    }
+    __device__ __forceinline__ double get(int k, int j) const { return sc[(k * 6 + j) * 4]; }
     // (smem: the workgroup's dynamic LDS.  With a.wlr_lds >= 0 the table is copied there once -- a lone wave cannot hide the latency
     //  of global reads inside every time step; contains a workgroup barrier then: call it from every wave)
     __device__ __forceinline__ void init(const PropArgs& a, int lane_, char* smem)
@@ -1055,6 +1067,8 @@ struct WLow {
         lamp = base;
         tab = base + JQ_MAX_WRANK + (QUAD ? 4 * ((lane_ >> 2) & 3) + (lane_ >> 4) : (lane_ >> 4));
         lead = QUAD ? lane_ < 4 : lane_ < 16;
+        has_sc = QUAD && r > 0 && a.wlr_sc_lds >= 0;
+        sc = (__attribute__((address_space(3))) double*)(smem + (has_sc ? a.wlr_sc_lds : 0)) + (size_t)(threadIdx.x >> 6) * (JQ_MAX_WRANK * 24) + (lane_ & 3);
     }
     __device__ __forceinline__ double lam(int k) const { return lamp[k]; }
     // (da, db) = (a_k . x, b_k . x) of this lane's column
@@ -1812,8 +1826,10 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
                     double lk = 0.0;                                                                             \
                     for (int k = 0; k < wl.r; ++k) {                                                             \
                         double p0, q0, p1, q1, rr, ss;                                                           \
-                        wl.dots(k, U, p0, q0);                                                                   \
+                        if (wl.has_sc) p0 = wl.get(k, 0), q0 = wl.get(k, 1);      /* last step's dots with vr(t_n+1) */ \
+                        else wl.dots(k, U, p0, q0);                                                              \
                         wl.dots(k, UN, p1, q1);                                                                  \
+                        if (wl.has_sc) wl.put(k, 0, p1), wl.put(k, 1, q1);                                       \
                         wl.dots(k, V, rr, ss);                                                                   \
                         lk += wl.lam(k) * ((p0 * p0 + q0 * q0) + (p1 * p1 + q1 * q1) + 2.0 * (rr * rr + ss * ss) - 2.0 * (ss * p0 - rr * q0)); \
                     }                                                                                            \
@@ -1822,6 +1838,13 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
             if (a.hist_r) hist_store<NT>(a, slab, col, QUAD ? 4 * ((lane_ >> 2) & 3) + (lane_ >> 4) : g, NSTEP, UN, VN); \
         }                                                                                                        \
     }
+    if constexpr (WLR)
+        if (wl.has_sc && active)      // (the first step's dots with vr(t_0) of the chunk)
+            for (int k = 0; k < wl.r; ++k) {
+                double p0, q0;
+                wl.dots(k, ua, p0, q0);
+                wl.put(k, 0, p0), wl.put(k, 1, q0);
+            }
     int n = 0;
     for (; n + 1 < a.nsteps_chunk; n += 2) {
         JQ_FWD_STEP(ua, va, ub, vb, n)
@@ -1990,6 +2013,13 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
         }
     }
 
+    if constexpr (WLR)
+        if (wforce && wl.has_sc && active)      // (the first step's dots with vr(t_n+1): the state the chunk starts from)
+            for (int k = 0; k < wl.r; ++k) {
+                double pu, qu;
+                wl.dots(k, u, pu, qu);
+                wl.put(k, 0, pu), wl.put(k, 1, qu);
+            }
     for (int n = 0; n < a.nsteps_chunk; ++n) {
         p.begin_step(n);
         // ---- state step (lambda_r parked) ------------------------------------------------------
@@ -2027,7 +2057,8 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
                 if (wforce)
                     for (int k = 0; k < wl.r; ++k) {
                         double pu, qu;
-                        wl.dots(k, u, pu, qu);
+                        if (wl.has_sc) pu = wl.get(k, 0), qu = wl.get(k, 1);      // (carried: the previous step's dots with vr(t_n))
+                        else wl.dots(k, u, pu, qu);
                         const double cl = cfw * wl.lam(k);
                         wl.axpy2(k, L, cl * pu, cl * qu);      // + c hr0
                     }
@@ -2093,6 +2124,7 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
                         double pn, qn, rr, ss;
                         wl.dots(k, un, pn, qn);
                         wl.dots(k, v, rr, ss);
+                        if (wl.has_sc) wl.put(k, 2, pn), wl.put(k, 3, qn), wl.put(k, 4, rr), wl.put(k, 5, ss);      // (again at use 12)
                         const double cl = cfw * wl.lam(k);
                         wl.axpy2(k, Ya, -cl * rr, -cl * ss);     // - c hi0 (goes into L and Q)
                         wl.axpy2(k, vN, -cl * qn, cl * pn);      // Q: - c (hi1 - hi0) = + c Wi vr(t_n) / T
@@ -2132,8 +2164,13 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
                 if (wforce)
                     for (int k = 0; k < wl.r; ++k) {
                         double pn, qn, rr, ss;
-                        wl.dots(k, un, pn, qn);
-                        wl.dots(k, v, rr, ss);
+                        if (wl.has_sc) {
+                            pn = wl.get(k, 2), qn = wl.get(k, 3), rr = wl.get(k, 4), ss = wl.get(k, 5);
+                            wl.put(k, 0, pn), wl.put(k, 1, qn);      // (the next step's dots with vr(t_n+1))
+                        } else {
+                            wl.dots(k, un, pn, qn);
+                            wl.dots(k, v, rr, ss);
+                        }
                         const double cl = cfw * wl.lam(k);
                         wl.axpy2(k, vN, cl * (pn - ss), cl * (qn + rr));      // + c hr1
                     }

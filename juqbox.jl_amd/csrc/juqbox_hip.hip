@@ -2240,7 +2240,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     const char* e_qs = getenv("JQ_QSPLIT");
     const bool qs_on = adjoint && h->NT <= 6 && !(e_qs && atoi(e_qs) == 0);
     int qs_qw = 0;
-    if (qs_on && quad && spw == 1 && !wfull && qsplit_lds(h, 4) <= 163840) qs_qw = 4;
+    if (qs_on && quad && !imr && spw == 1 && !wfull && qsplit_lds(h, 4) <= 163840) qs_qw = 4;      // (!imr: the implicit-midpoint quad kernels also run with spw = 1)
     // (JQ_QSPLIT=2: qw = 2 for every batch of the cooperative-quad plan that does not take the three-workgroup kernels -- tests)
     const bool qs_force2 = e_qs && atoi(e_qs) == 2;
     if (qs_on && cq && !cq3 && ((nquads_used > h->num_cu && 2 * nslabs <= h->num_cu) || qs_force2) && qsplit_lds(h, 2) <= 163840) qs_qw = 2;
@@ -2374,7 +2374,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     a.tabs = h->d_tabs; a.stride = stride; a.pieces = (int)(stride * 8 / 1024); a.nslots = h->nslots; a.m = h->m;
     a.nslabs = rl ? (int)nwaves_rl : lane ? (int)ncols : nslabs; a.Ncoupled = ctrl_gstart(h->Nc, 1) /* first control group */; a.Ntot = h->Ntot; a.N = h->N; a.use_shift = use_shift ? 1 : 0;
     a.tinv = 1.0 / h->T; a.state_stride = h->state_stride; a.parts = h->parts; a.nsamples = nsamples; a.sps = h->sps; a.qps = qps;
-    a.wlr = h->d_wlr; a.wrank = h->wrank; a.wstride = h->NP; a.wlr_lds = -1;
+    a.wlr = h->d_wlr; a.wrank = h->wrank; a.wstride = h->NP; a.wlr_lds = -1; a.wlr_sc_lds = -1;
     // JACOBI_SOLVER: the kernels iterate on c-scaled right-hand sides (A = c rhs, c = h / 2: DESIGN.md section 3), so their
     // residual norm is |c| times the reference's ||X_j - X_{j-1}|| (src/linear_solvers.jl:121): the threshold is scaled alike
     a.jacobi_tol2 = (h->solver_id == 2) ? (h->solver_tol * 0.5 * dt) * (h->solver_tol * 0.5 * dt) : 0.0;
@@ -2401,13 +2401,18 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     const size_t wlr_bytes = (wfull && !coop && !rl && !lane) ? ((size_t)JQ_MAX_WRANK + (size_t)2 * h->wrank * h->NP) * 8 : 0;
     const int wlr_lds_fwd = (wlr_bytes && lds_fwd + wlr_bytes <= 163840) ? (int)lds_fwd : -1;
     const int wlr_lds_bwd = (wlr_bytes && lds_bwd + wlr_bytes <= 163840) ? (int)lds_bwd : -1;
+    // ... and, quad layout, the per-wave column scalars of the terms behind it (jq_kernels.h WLow::sc; JQ_WLR_SC=0: recompute every dot)
+    const size_t wsc_bytes = (wlr_bytes && quad && !(getenv("JQ_WLR_SC") && atoi(getenv("JQ_WLR_SC")) == 0)) ? (size_t)(nthreads / 64) * JQ_MAX_WRANK * 24 * 8 : 0;
+    const size_t wsc_off_fwd = lds_fwd + (wlr_lds_fwd >= 0 ? wlr_bytes : 0), wsc_off_bwd = lds_bwd + (wlr_lds_bwd >= 0 ? wlr_bytes : 0);
+    const int wsc_lds_fwd = (wsc_bytes && wsc_off_fwd + wsc_bytes <= 163840) ? (int)wsc_off_fwd : -1;
+    const int wsc_lds_bwd = (wsc_bytes && wsc_off_bwd + wsc_bytes <= 163840) ? (int)wsc_off_bwd : -1;
     a.batch = batch; a.lds_tab_off = (int)lds_stage;
     a.park = h->d_park; a.park_lds = quad ? 1 : h->park_lds;
     if (cq) a.nslots = 0;
     if (const char* e = getenv("JQ_DEBUG")) a.debug = atoi(e);
     if (!lane && !rl) {
-        HIPCHK(h, hipFuncSetAttribute((const void*)kfwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_fwd + (wlr_lds_fwd >= 0 ? wlr_bytes : 0))));
-        HIPCHK(h, hipFuncSetAttribute((const void*)kbwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_bwd + (wlr_lds_bwd >= 0 ? wlr_bytes : 0))));
+        HIPCHK(h, hipFuncSetAttribute((const void*)kfwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_fwd + (wlr_lds_fwd >= 0 ? wlr_bytes : 0) + (wsc_lds_fwd >= 0 ? wsc_bytes : 0))));
+        HIPCHK(h, hipFuncSetAttribute((const void*)kbwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_bwd + (wlr_lds_bwd >= 0 ? wlr_bytes : 0) + (wsc_lds_bwd >= 0 ? wsc_bytes : 0))));
     }
 
     // events: [0]=start [1]=end, then pairs around every propagator launch
@@ -2446,6 +2451,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
         a.nsteps_chunk = nc; a.step0 = n0; a.first_chunk = (n0 == 0); a.h = dt; a.forced = 1;
         a.hist_r = hist_r; a.hist_i = hist_i;
         a.wlr_lds = wlr_lds_fwd;
+        a.wlr_sc_lds = wsc_lds_fwd;
         a.period = 7; a.npro = 0; a.nslots = h->nslots;
         {   // slab kernels: Kp05 S05 Kn0 S0 Kn1 S1 Kp05 ; cooperative kernels: Kp05 S05 Kn0 Kn1 S0 S1 Kp05
             // {kind (0 K, 1 S, 2 constant image), time point offset / image index}
@@ -2457,7 +2463,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
             for (int i = 0; i < 7; ++i) sched_pack(a.sched_bits, i, kinds[i], tps[i]);
         }
         HIPCHK(h, hipEventRecord(h->ev[evi++], s));
-        hipLaunchKernelGGL(kfwd, dim3(cq_fwd2 ? nblocks / 2 : nblocks), dim3(cq ? nthreads + 128 : imr_cq ? nthreads + 128 : nthreads), lds_fwd + (wlr_lds_fwd >= 0 ? wlr_bytes : 0), s, a);      // (cooperative quad: two staging waves)
+        hipLaunchKernelGGL(kfwd, dim3(cq_fwd2 ? nblocks / 2 : nblocks), dim3(cq ? nthreads + 128 : imr_cq ? nthreads + 128 : nthreads), lds_fwd + (wlr_lds_fwd >= 0 ? wlr_bytes : 0) + (wsc_lds_fwd >= 0 ? wsc_bytes : 0), s, a);      // (cooperative quad: two staging waves)
         HIPCHK(h, hipEventRecord(h->ev[evi++], s));
         mfma += (long long)nslabs * nc * (8 + 2 * h->m) * tiles;
     }
@@ -2518,6 +2524,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
                 a.nsteps_chunk = nc; a.step0 = n0; a.first_chunk = (n0 == 0); a.h = -dt; a.forced = (pass == 0);
                 a.hist_r = nullptr; a.hist_i = nullptr;
                 a.wlr_lds = wlr_lds_bwd;
+                a.wlr_sc_lds = wsc_lds_bwd;
                 a.period = 13 + 3 * ng; a.npro = (n0 == 0) ? ng : 0; a.nslots = h->nslots_bwd;
                 {   // Kp05 S05 Kn0 S0 Kn1 S1 Kp05 | S0 | Hanti_q.. | Kn0 Kn1 S05 Kp05 S1 | (Hanti_q Hsym_q)..
                     const int kinds_s[8] = {0, 1, 0, 1, 0, 1, 0, 1}, tps_s[8] = {1, 1, 0, 0, 2, 2, 1, 0};
@@ -2552,7 +2559,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
                 else if (cq3)
                     hipLaunchKernelGGL(kbwd, dim3((unsigned)(cq_nr * nq_pad)), dim3(nthreads + 128), lds_bwd, s, a);      // (three / two workgroups per quad: NT block waves + two staging waves each)
                 else
-                hipLaunchKernelGGL(kbwd, dim3(nblocks), dim3((cq || rl_split) ? 2 * nthreads : imr_cq2 ? 2 * (nthreads + 128) : imr_cq ? nthreads + 128 : nthreads), lds_bwd + (wlr_lds_bwd >= 0 ? wlr_bytes : 0), s, a);      // (cooperative quad: state and adjoint chain on separate waves)
+                hipLaunchKernelGGL(kbwd, dim3(nblocks), dim3((cq || rl_split) ? 2 * nthreads : imr_cq2 ? 2 * (nthreads + 128) : imr_cq ? nthreads + 128 : nthreads), lds_bwd + (wlr_lds_bwd >= 0 ? wlr_bytes : 0) + (wsc_lds_bwd >= 0 ? wsc_bytes : 0), s, a);      // (cooperative quad: state and adjoint chain on separate waves)
                 HIPCHK(h, hipEventRecord(h->ev[evi++], s));
                 if (cq3 && sweep == 0 && n0 == 0) {
                     // the first launch of the split says whether its workgroups were resident together: read the error word now instead

@@ -16,7 +16,8 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
 pcof = np.array(json.load(open(os.path.join(ROOT, "tests/golden/cnot3.json")))["pcof0"])
 params, info = jq.cases.cnot3()
-params.T, params.nsteps = params.T * nsteps / params.nsteps, nsteps
+if nsteps:      # (0: the reference's full length)
+    params.T, params.nsteps = params.T * nsteps / params.nsteps, nsteps
 stop = os.path.join(ROOT, "gpurun_out", "soak_stop")
 if role == "throughput":      # 3 072 perturbed samples, back to back, until the main process says stop
     wa = jq.Working_Arrays_HIP(params, pcof.size)
@@ -88,4 +89,4 @@ os.remove(stop)
 for imr in (False, True):
     print("plan (%s): %s" % ("implicit midpoint" if imr else "Stormer-Verlet", was[imr][1].plan_info()["latency_split"]))
 print("%d evaluations (%d rounds x 3 ensemble sizes x 2 integrators x %d steps) next to the load processes: %d mismatches, %d evaluations on the "
-      "one-workgroup kernel (fallback / cooling down), %.0f s, slowest evaluation %.2f s" % (nev, rounds, nsteps, bad, nfb, dt, worst))
+      "one-workgroup kernel (fallback / cooling down), %.0f s, slowest evaluation %.2f s" % (nev, rounds, params.nsteps, bad, nfb, dt, worst))
