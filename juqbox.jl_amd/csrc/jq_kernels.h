@@ -1040,10 +1040,11 @@ struct WLow {
     const double* lamp;     // lam[k]
     int r, stride;
     bool lead;      // one lane per column: adds the column's scalar terms to a per-lane partial sum
-    // Column scalars of the terms kept across uses and steps (quad layout, round 5): the dots of a step's vr(t_n), vi05 are needed at
-    // two sites of the adjoint step, and the dots with vr(t_n+1) ARE the previous step's dots with vr(t_n) -- five dot pairs per term
-    // and step become two (a dot pair is ~ 64 instructions with its two column sums; cnot3: 57 -> ~ 36 ms per forbidden state).  The
-    // rank is a run-time number, so the scalars live in LDS: [term][slot 0 .. 5][column of the quad], written by the lead lanes.
+    // Column scalars of the terms kept across uses and steps (quad layout, round 5 EXPERIMENT, off by default: host JQ_WLR_SC=1): the dots
+    // of a step's vr(t_n), vi05 are needed at two sites of the adjoint step, and the dots with vr(t_n+1) ARE the previous step's dots with
+    // vr(t_n) -- five dot pairs per term and step become two.  The rank is a run-time number, so the scalars live in LDS: [term][slot
+    // 0 .. 5][column of the quad], written by the lead lanes.  Measured SLOWER (cnot3: 57 -> 70 ms per forbidden state): the LDS round
+    // trips sit on the critical path of a wave that is alone on its SIMD, the recomputed dots are independent instructions.
     __attribute__((address_space(3))) double* sc;
     bool has_sc;
     __device__ __forceinline__ void put(int k, int j, double val) const

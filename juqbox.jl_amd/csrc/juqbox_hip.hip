@@ -2401,8 +2401,10 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     const size_t wlr_bytes = (wfull && !coop && !rl && !lane) ? ((size_t)JQ_MAX_WRANK + (size_t)2 * h->wrank * h->NP) * 8 : 0;
     const int wlr_lds_fwd = (wlr_bytes && lds_fwd + wlr_bytes <= 163840) ? (int)lds_fwd : -1;
     const int wlr_lds_bwd = (wlr_bytes && lds_bwd + wlr_bytes <= 163840) ? (int)lds_bwd : -1;
-    // ... and, quad layout, the per-wave column scalars of the terms behind it (jq_kernels.h WLow::sc; JQ_WLR_SC=0: recompute every dot)
-    const size_t wsc_bytes = (wlr_bytes && quad && !(getenv("JQ_WLR_SC") && atoi(getenv("JQ_WLR_SC")) == 0)) ? (size_t)(nthreads / 64) * JQ_MAX_WRANK * 24 * 8 : 0;
+    // ... and, quad layout, the per-wave column scalars of the terms behind it (jq_kernels.h WLow::sc).  OFF unless JQ_WLR_SC=1: measured
+    // SLOWER than recomputing the dots (round 5, cnot3: 57 -> 70 ms per forbidden state -- an LDS round trip on the critical path of a
+    // wave that is alone on its SIMD costs more than the ~ 64 independent instructions of a dot pair; profiles/r05_exp_variants.txt (3))
+    const size_t wsc_bytes = (wlr_bytes && quad && getenv("JQ_WLR_SC") && atoi(getenv("JQ_WLR_SC")) == 1) ? (size_t)(nthreads / 64) * JQ_MAX_WRANK * 24 * 8 : 0;
     const size_t wsc_off_fwd = lds_fwd + (wlr_lds_fwd >= 0 ? wlr_bytes : 0), wsc_off_bwd = lds_bwd + (wlr_lds_bwd >= 0 ? wlr_bytes : 0);
     const int wsc_lds_fwd = (wsc_bytes && wsc_off_fwd + wsc_bytes <= 163840) ? (int)wsc_off_fwd : -1;
     const int wsc_lds_bwd = (wsc_bytes && wsc_off_bwd + wsc_bytes <= 163840) ? (int)wsc_off_bwd : -1;
