@@ -119,7 +119,6 @@ __global__ __launch_bounds__(128 * QW, 1) void k_backward_qsplit(PropArgs a)
     constexpr int KT = 4 * NT;
     constexpr int BW = JQ_BW_T4Q;
     constexpr int NWAVES = 2 * QW;
-    constexpr int FULLQ = JQ_T4_DIAG | JQ_T4_RTERMS | JQ_T4_MTERMS;
     const int lane_ = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool adj = wave >= QW;
@@ -151,6 +150,12 @@ __global__ __launch_bounds__(128 * QW, 1) void k_backward_qsplit(PropArgs a)
 
     RingT<true, JQ_QS_TPS> p;
     p.init(smem, a, wave, lane_, NWAVES);
+    // The adjoint wave -- the longer chain, 32 of the 52 products of a step -- goes first in the issue arbitration of the SIMD it shares
+    // with the state wave of its quad (QW = 4): it then runs almost as if it were alone there, and the state wave, which has slack
+    // until the step's barrier, takes the slots that are left.  One s_setprio: cnot3 x 1 024 samples, backward sweep 280.6 -> 250.0 ms
+    // (priority 1 or 3 alike).  (The same in k_backward_cq, whose two sets of waves meet at 5 + 2 m barriers per step: + 2 % -- there the
+    //  set that is held back is waited for at the next barrier.)
+    if (QW == 4 && adj) __builtin_amdgcn_s_setprio(3);
 
     if (!adj) {
         // ---- state re-integration: the forward step with h < 0 (src/evalobjgrad.jl:879) ----------------------------------------
@@ -279,7 +284,10 @@ __global__ __launch_bounds__(128 * QW, 1) void k_backward_qsplit(PropArgs a)
             // it in use 10; four quads per workgroup (two waves per SIMD: the pipe is full, rides buy nothing) 281.9 / 312.3 / 280.0 --
             // there the ride needs vi05 in the first pass of the step, a moment after it was asked for, and the wave that stalls on the
             // L2 round trip holds up a SIMD that has no idle slots to lose.
-            constexpr bool EARLY = (QW <= 2);
+#ifndef JQ_QS_EARLY4
+#define JQ_QS_EARLY4 0
+#endif
+            constexpr bool EARLY = (QW <= 2) || JQ_QS_EARLY4;
             const double* M = p.template next_ks<0, 1>();
             if (active) {
                 if constexpr (EARLY)

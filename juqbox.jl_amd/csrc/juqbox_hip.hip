@@ -1712,7 +1712,11 @@ static int select_qsplit_kernel(jq_handle* h, int qw, prop_kernel_t* bwd)
     bool ord = h->Nc >= 2 && h->Nc <= 3 && !getenv("JQ_NO_ORD");
     for (int q = 0; q < h->Nc && ord; ++q) ord = (h->bw_trace[q] == (1 << q));
     // ... and with exactly three of them every trace product rides along in a pass of the adjoint step (RIDE; JQ_QS_RIDE=0: separate passes)
-    const bool ride = ord && h->Nc == 3 && !(getenv("JQ_QS_RIDE") && atoi(getenv("JQ_QS_RIDE")) == 0);
+    // -- where the adjoint wave is alone on its SIMD (qw = 2: - 6 %); with two waves per SIMD and the adjoint wave first in the issue
+    // arbitration the rides buy nothing (248.9 ms without, 250.0 with): qw = 4 keeps the separate passes (bit-identical to the one-wave
+    // kernel); JQ_QS_RIDE=1 forces the rides there too
+    const char* e_ride = getenv("JQ_QS_RIDE");
+    const bool ride = ord && h->Nc == 3 && !(e_ride && atoi(e_ride) == 0) && (qw == 2 || (e_ride && atoi(e_ride) == 1));
 #define JQ_PICKQS(nt)                                                                                         \
     if (h->NT == nt) {                                                                                        \
         *bwd = qw == 4 ? (ride ? k_backward_qsplit<nt, true, 4, true> : ord ? k_backward_qsplit<nt, true, 4> : k_backward_qsplit<nt, false, 4>)             \
@@ -1917,9 +1921,9 @@ struct EvalOut {
 // Time of one round of the 4 x 4 x n kernel families relative to a round of the slab kernels (4 #CU slabs), measured at cnot3
 // (scripts/time_staircase.py, round 3: 0.495 / 0.748 / 1.104 s for #CU / 2 #CU / 3 #CU slabs on the quad-layout kernels with 1 / 2 / 3
 // slabs per workgroup, 0.192 s for a round of the cooperative-quad kernels)
-// (round 5, same unit of 1.7935 s: 0.408 / 0.741 / 1.038 s -- one slab per workgroup now runs its backward sweep on two waves per column
+// (round 5, same unit of 1.7935 s: 0.378 / 0.741 / 1.038 s -- one slab per workgroup now runs its backward sweep on two waves per column
 //  quad, jq_quad_split_kernels.h; 0.192 s for up to #CU column quads on the cooperative-quad kernels, 0.298 s for up to 2 #CU)
-static const double T4_REL[4] = {1.0, 0.2275, 0.413, 0.579};
+static const double T4_REL[4] = {1.0, 0.2108, 0.413, 0.579};
 static const double T4_REL_CQ = 0.107;      // <= #CU column quads
 static const double T4_REL_CQ2 = 0.166;     // <= 2 #CU: forward sweep with two quads per workgroup, backward sweep k_backward_qsplit<.., 2>
 static double t4_plan_cost(const jq_handle* h, long long nsamples)

@@ -73,7 +73,6 @@ def test_split_backward_sweep_is_the_one_wave_kernel_bit_for_bit(jq, kind, nsamp
     nodes, weights = 0.02 * rng.standard_normal(nsamples), rng.random(nsamples)
     shift = 0.01 * np.arange(params.Ntot)
     env = {"JQ_CHUNK_STEPS": str(chunk)} if chunk else {}
-    env["JQ_QS_RIDE"] = "0"      # (cnot3 would take the RIDE variant: below)
     a = _eval(jq, params, pcof, nodes, weights, shift, env)
     b = _eval(jq, params, pcof, nodes, weights, shift, dict(env, JQ_QSPLIT="0"))
     c = _eval(jq, params, pcof, nodes, weights, shift, env)
@@ -81,10 +80,10 @@ def test_split_backward_sweep_is_the_one_wave_kernel_bit_for_bit(jq, kind, nsamp
     for x in (b, c):
         assert a[0] == x[0] and a[1] == x[1] and np.array_equal(a[2], x[2]) and np.array_equal(a[3], x[3])
     if kind == "cnot3":
-        # three single-subsystem controls: the default is the variant whose twelve trace products ride along in the passes of the adjoint
-        # step (k_backward_qsplit<.., RIDE>).  tr5 is then the sum of two dot products instead of a dot product with a sum: the only
-        # difference in rounding (observed 4e-17); bit-stable run to run
-        del env["JQ_QS_RIDE"]
+        # three single-subsystem controls: the variant whose twelve trace products ride along in the passes of the adjoint step
+        # (k_backward_qsplit<.., RIDE>; the default with two quads per workgroup, forced here with JQ_QS_RIDE=1).  tr5 is then the sum of
+        # two dot products instead of a dot product with a sum: the only difference in rounding (observed 4e-17); bit-stable run to run
+        env["JQ_QS_RIDE"] = "1"
         d = _eval(jq, params, pcof, nodes, weights, shift, env)
         e = _eval(jq, params, pcof, nodes, weights, shift, env)
         assert d[4]["reserved"] == 24
