@@ -205,7 +205,8 @@ def dense_operator_block(jq, L, pcof, quick=False, samples=None):
             sweep[str(ns)] = {"ms_per_2000_steps": t["ms_total"], "evals_per_s_at_full_length": ns / (t["ms_total"] * 1e-3 * nfull / 2000.0),
                               "kernel_family": t["kernel_family"]}
         ws.close()
-        best = max(cand, key=lambda ns: sweep[str(ns)]["evals_per_s_at_full_length"])
+        top = max(sweep[str(ns)]["evals_per_s_at_full_length"] for ns in cand)
+        best = min(ns for ns in cand if sweep[str(ns)]["evals_per_s_at_full_length"] >= 0.995 * top)      # (the smallest batch at the best rate)
     if quick:
         pd.T, pd.nsteps = pd.T * 500 / pd.nsteps, 500
     wd = jq.Working_Arrays_HIP(pd, pcof.size)

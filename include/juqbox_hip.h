@@ -191,10 +191,11 @@ int jq_set_neumann_terms(jq_handle *h, int32_t m);
 /* params.linear_solver = lsolver_object(solver=..., max_iter=..., tol=...) (src/linear_solvers.jl:28-78):
  * solver_id 1 = NEUMANN_SOLVER (neumann!, :81-106; tol ignored), 2 = JACOBI_SOLVER (jacobi!, :110-153; `tol` is
  * the already nrhs-scaled tolerance, :40).  Other ids: JQ_EUNSUPPORTED.
- * JACOBI_SOLVER convergence is tested per evaluation like the reference's norm(T - X) over the Ntot x N block -- for N <= 16.  With
- * N > 16 columns per evaluation (the columns take ceil(N / 16) slabs, which live in different waves / workgroups) every 16-column
- * part is tested on its own: parts may stop at different iterations, and the result then differs from the reference's by O(tol)
- * instead of agreeing to rounding (tests/test_gpu_round4.py holds such a case to c * tol). */
+ * JACOBI_SOLVER convergence is tested per evaluation like the reference's norm(T - X) over the Ntot x N block -- for N <= 64 with
+ * Ntot <= 96 (round 5: N > 16 columns take ceil(N / 16) slabs; up to four of them are the waves of ONE workgroup, which adds their
+ * residual norms before it decides).  With N > 64, or with Ntot > 96 (cooperative kernels: a slab per workgroup), every 16-column
+ * part is still tested on its own: parts may stop at different iterations, and the result then differs from the reference's by
+ * O(tol) instead of agreeing to rounding (tests/test_gpu_round4.py holds such a case to c * tol). */
 int jq_set_linear_solver(jq_handle *h, int32_t solver_id, int32_t max_iter, double tol);
 /* params.Integrator_id (src/evalobjgrad.jl:100, constants Stormer_Verlet = 1, Implicit_Midpoint = 2) selects which
  * traceobjgrad method runs: 1 = the Stormer-Verlet path (default), 2 = the implicit-midpoint path

@@ -20,7 +20,7 @@
 // more than a publication interval later, so that the store latency is off the critical path --, the counter is written behind it;
 // the consumers read counters and data with agent-scope loads (past their CU's vector cache), one step ahead of their use.  The three workgroups of a quad have block indices 24 i + j, + 8, + 16 (j < 8): workgroups are
 // handed to the eight XCDs round-robin, so the three share one XCD and its L2 -- no cache maintenance between them.  Each role checks
-// that (XCC_ID register) and that no wait exceeds ~ 2 s; otherwise it raises the error word of the quad and every wait of the quad
+// that (XCC_ID register) and that no wait exceeds ~ 1.3 s; otherwise it raises the error word of the quad and every wait of the quad
 // is abandoned: the launch ends with garbage, the host falls back to k_backward_cq and disables the split for the handle.
 // The arithmetic of every chain and of the trace sums is k_backward_cq's, operation for operation: bit-identical results.
 #pragma once
@@ -29,7 +29,9 @@
 #define JQ_CQ3_SLOTS 8        // ring depth in time steps
 #define JQ_CQ3_ARRAYS 6       // u (vr before the state step), v05, un, X, nbn (-lambda_i new), Bq (-(li0 + li))
 #define JQ_CQ3_HEAD 64        // doubles in front of a quad's ring: [0] steps of role 0, [8] role 1, [16] role 2, [24] error, [32 + r] XCC of role r
-#define JQ_CQ3_SPIN 1000000   // polls (with s_sleep; ~ 2 us each) before a wait is declared dead
+#define JQ_CQ3_SPIN 1000000   // polls (with s_sleep; ~ 1.3 us each: ~ 1.3 s) before a wait is declared dead.  Round 5 tried 150 000 (~ 0.2 s): next to a
+                              // process whose launches hold every CU for 0.15 - 0.37 s (the throughput kernels) a role legitimately waits that long for its
+                              // partners to become resident -- more faults, longer cool-downs, 58 s instead of 50 s for the soak of profiles/r05_cq3_soak_load.txt
 
 template <int NT>
 struct Cq3Hand {

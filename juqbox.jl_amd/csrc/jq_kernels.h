@@ -1005,6 +1005,8 @@ struct PropArgs {
     int wstride;
     int wlr_lds;            // slab / quad kernels: byte offset in dynamic LDS where the workgroup keeps a copy of the table, or -1 (read it from global memory)
     int wlr_sc_lds;         // quad layout: byte offset of the per-wave column scalars of the terms ([wave][JQ_MAX_WRANK][6][4] doubles), or -1
+    int jac_wg_lds;         // JAC slab kernels, N > 16 with one workgroup per sample (its <= 4 parts = waves): byte offset of the residual
+                            // exchange [2][JQ_WAVES] doubles -- the stopping test then sums the parts like the reference; -1: per part
 };
 #ifndef JQ_MAX_WRANK
 #define JQ_MAX_WRANK 16       // largest rank of a full weight matrix the kernels take (include/juqbox_hip.h)
@@ -1483,13 +1485,48 @@ __device__ __forceinline__ double sample_sum(double x, int N)
 // PER SAMPLE here too (round 3; rounds 1-2 tested the whole 16-column slab and agreed with the reference only to O(tol)): the
 // residual norm is summed over the lanes of a sample (sample_sum), a sample that has converged keeps its iterate while the wave
 // iterates on for the others.  N > 16 (a sample spans several slabs = waves): per 16-column part.
+// jac_wg >= 0 (N > 16 with the <= 4 parts of a sample on the waves of ONE workgroup, round 5): the residual norm of the reference is over
+// the whole Ntot x N block (src/linear_solvers.jl:121), so the parts' squared norms are added through LDS -- one workgroup barrier per
+// iteration, the decision is workgroup-uniform and every wave iterates equally long.  ([2][JQ_WAVES] doubles at byte offset jac_wg of
+// the dynamic LDS, double-buffered by the iteration's parity.)
+__device__ __forceinline__ double jacobi_wg_sum(double r, int jac_wg, int it)
+{
+    extern __shared__ __attribute__((aligned(16))) char jq_smem_[];
+    double* ex = (double*)(jq_smem_ + jac_wg) + (it & 1) * JQ_WAVES;
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if ((threadIdx.x & 63) == 0) ex[wave] = r;      // (r is the same in all lanes: the slab's 16 columns, sample_sum)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    double s = 0.0;
+    for (int w = 0; w < nw; ++w) s += ex[w];
+    return s;
+}
 template <int NT, int BW>
 __device__ __forceinline__ void jacobi_add(Arr<NT>& out, const Arr<NT>& bpa, const Arr<NT>& A, const double* S, int max_iter,
-                                           double tol2, Arr<NT>& Ya, Arr<NT>& Yb, int ncol)
+                                           double tol2, Arr<NT>& Ya, Arr<NT>& Yb, int ncol, int jac_wg = -1)
 {
     // out = bpa - A + X_j
     if (max_iter <= 0) {
         out = bpa;
+        return;
+    }
+    if (jac_wg >= 0) {      // (one sample per workgroup: the same iteration count in every wave)
+        mm_c<NT, BW>(Ya, A, S, A);  // X_1
+        bool in_a = true;
+        bool done = jacobi_wg_sum(sample_sum(a_diff2(Ya, A), ncol), jac_wg, 1) < tol2;
+        for (int j = 2; j <= max_iter && !done; ++j) {
+            if (in_a) {
+                mm_c<NT, BW>(Yb, A, S, Ya);
+                done = jacobi_wg_sum(sample_sum(a_diff2(Yb, Ya), ncol), jac_wg, j) < tol2;
+            } else {
+                mm_c<NT, BW>(Ya, A, S, Yb);
+                done = jacobi_wg_sum(sample_sum(a_diff2(Ya, Yb), ncol), jac_wg, j) < tol2;
+            }
+            in_a = !in_a;
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i) out.t[i] = (bpa.t[i] - A.t[i]) + (in_a ? Ya.t[i] : Yb.t[i]);
         return;
     }
     mm_c<NT, BW>(Ya, A, S, A);  // X_1
@@ -1519,10 +1556,10 @@ __device__ __forceinline__ void jacobi_add(Arr<NT>& out, const Arr<NT>& bpa, con
 // LDS again (mm_t4q) -- 60 registers less inside the recurrence at NT = 6
 template <int NT, int BW, bool JAC, bool REGOP = true>
 __device__ __forceinline__ void horner_add(Arr<NT>& out, const Arr<NT>& bpa, const Arr<NT>& A, const double* S, int m,
-                                           Arr<NT>& Ya, Arr<NT>& Yb, double jacobi_tol2, int ncol)
+                                           Arr<NT>& Ya, Arr<NT>& Yb, double jacobi_tol2, int ncol, int jac_wg = -1)
 {
     if (JAC) {
-        jacobi_add<NT, BW>(out, bpa, A, S, m, jacobi_tol2, Ya, Yb, ncol);
+        jacobi_add<NT, BW>(out, bpa, A, S, m, jacobi_tol2, Ya, Yb, ncol, jac_wg);
         return;
     }
     if (m <= 0) {
@@ -1670,7 +1707,7 @@ __device__ __forceinline__ void sv_state(RING& p, const PropArgs& a, bool active
         if (active) {
             mm_c<NT, BW>(A, A, M0, v);                                 // A = c (K05 u + S05 v)
             a_add(v, A);
-            horner_add<NT, BW, JAC, REGOP>(v, v, A, M0, a.m, Ya, Yb, a.jacobi_tol2, a.N);       // v = v05
+            horner_add<NT, BW, JAC, REGOP>(v, v, A, M0, a.m, Ya, Yb, a.jacobi_tol2, a.N, a.jac_wg_lds);       // v = v05
         }
         M1 = p.template next_ks<0, 0>();                    // Kn0
         const double* M2 = p.template next_ks<0, 2>();      // Kn1
@@ -1695,7 +1732,7 @@ __device__ __forceinline__ void sv_state(RING& p, const PropArgs& a, bool active
         if (active) {
             mm_c<NT, BW>(A, A, M0, unew);                              // A = c (S1 (u + c kappa1) - K1 v05)
             a_add(unew, A);
-            horner_add<NT, BW, JAC, REGOP>(unew, unew, A, M0, a.m, Ya, Yb, a.jacobi_tol2, a.N);
+            horner_add<NT, BW, JAC, REGOP>(unew, unew, A, M0, a.m, Ya, Yb, a.jacobi_tol2, a.N, a.jac_wg_lds);
         }
         return;
     }
@@ -1715,7 +1752,7 @@ __device__ __forceinline__ void sv_state(RING& p, const PropArgs& a, bool active
     if (active) {
         mm_c<NT, BW>(A, A, M, v);
         a_add(v, A);
-        horner_add<NT, BW, JAC, REGOP>(v, v, A, M, a.m, Ya, Yb, a.jacobi_tol2, a.N);
+        horner_add<NT, BW, JAC, REGOP>(v, v, A, M, a.m, Ya, Yb, a.jacobi_tol2, a.N, a.jac_wg_lds);
         mm_c<NT, BW>(vN, v, M, v);
     }
     // use 2: Kn0 -- unew = u - c K0 v05
@@ -1746,7 +1783,7 @@ __device__ __forceinline__ void sv_state(RING& p, const PropArgs& a, bool active
     if (active) {
         mm_c<NT, BW>(A, A, M, unew);
         a_add(unew, A);
-        horner_add<NT, BW, JAC, REGOP>(unew, unew, A, M, a.m, Ya, Yb, a.jacobi_tol2, a.N);
+        horner_add<NT, BW, JAC, REGOP>(unew, unew, A, M, a.m, Ya, Yb, a.jacobi_tol2, a.N, a.jac_wg_lds);
     }
 }
 
@@ -1775,7 +1812,9 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
     const int col = QUAD ? 4 * (wave & 3) + (lane_ & 3) : (lane_ & 15);
     const int lane = QUAD ? ((lane_ >> 2) & 3) * 64 + 16 * (lane_ >> 4) + col : lane_;
     const int g = QUAD ? 4 * (lane_ >> 4) + ((lane_ >> 2) & 3) : lane_ >> 4;
-    const int slab = QUAD ? (int)blockIdx.x * (NWAVES / 4) + (wave >> 2) : blockIdx.x * JQ_WAVES + wave;
+    // (JAC with one workgroup per sample, a.jac_wg_lds >= 0: the workgroup has as many waves as the sample has parts)
+    const int wpw = (JAC && !QUAD) ? (int)(blockDim.x >> 6) : JQ_WAVES;
+    const int slab = QUAD ? (int)blockIdx.x * (NWAVES / 4) + (wave >> 2) : blockIdx.x * wpw + wave;
     const bool active = slab < a.nslabs;
 
     double* tab = (double*)(smem + a.lds_tab_off);
@@ -1799,7 +1838,7 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
         a_zero(va);
     }
     RingT<QUAD> p;
-    p.init(smem, a, wave, lane_, NWAVES);
+    p.init(smem, a, wave, lane_, QUAD ? NWAVES : wpw);
     constexpr bool WLR = jq_wlr_on<BW, JAC, WLRT>();
     WLow<NT, QUAD> wl;
     if constexpr (WLR) wl.init(a, lane_, smem);
@@ -1905,7 +1944,8 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
     const int col = QUAD ? 4 * (wave & 3) + (lane_ & 3) : (lane_ & 15);
     const int lane = QUAD ? ((lane_ >> 2) & 3) * 64 + 16 * (lane_ >> 4) + col : lane_;
     const int g = QUAD ? 4 * (lane_ >> 4) + ((lane_ >> 2) & 3) : lane_ >> 4;
-    const int slab = QUAD ? (int)blockIdx.x * (NWAVES / 4) + (wave >> 2) : blockIdx.x * JQ_WAVES + wave;
+    const int wpw = (JAC && !QUAD) ? (int)(blockDim.x >> 6) : JQ_WAVES;      // (see k_forward)
+    const int slab = QUAD ? (int)blockIdx.x * (NWAVES / 4) + (wave >> 2) : blockIdx.x * wpw + wave;
     const bool active = slab < a.nslabs;
     const int Nc = a.Ncoupled;
     // per-lane trace carries in the array file: like the leak partial of k_forward
@@ -1991,7 +2031,7 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
         a_zero(nb);
     }
     RingT<QUAD> p;
-    p.init(smem, a, wave, lane_, NWAVES);
+    p.init(smem, a, wave, lane_, QUAD ? NWAVES : wpw);
     // full leakage weights in low-rank form (WLow): forcing hr0 = Wr vr(t_n+1) / T, hi0 = Wr vi05 / T, hr1 = (Wr vr(t_n) + Wi vi05) / T,
     // hi1 = hi0 - Wi vr(t_n) / T (src/evalobjgrad.jl:862, :882-888)
     constexpr bool WLR = jq_wlr_on<BW, JAC, WLRT>();
@@ -2064,7 +2104,7 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
                         wl.axpy2(k, L, cl * pu, cl * qu);      // + c hr0
                     }
             a_add(mu, L);
-            horner_add<NT, BW, JAC, BREG>(mu, mu, L, M, a.m, Ya, Yb, a.jacobi_tol2, a.N);
+            horner_add<NT, BW, JAC, BREG>(mu, mu, L, M, a.m, Ya, Yb, a.jacobi_tol2, a.N, a.jac_wg_lds);
         }
         // early traces with X (lets vr0 = u die here): tr1 = tr(vr0' Hanti_q X), tr3 = tr(vr' Hanti_q X)
         double o_p4 = 0.0;      // ORD: the new part of tr4 of control 1, formed in the pass of use 11
@@ -2135,7 +2175,7 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
             mm_c<NT, BW>(vN, vN, M, L);       // vN = Q
             a_add(L, nb);
             a_add(L, vN);                     // L = nb + L + Q
-            horner_add<NT, BW, JAC, BREG>(L, L, vN, M, a.m, Ya, Yb, a.jacobi_tol2, a.N);  // L = nb_new
+            horner_add<NT, BW, JAC, BREG>(L, L, vN, M, a.m, Ya, Yb, a.jacobi_tol2, a.N, a.jac_wg_lds);  // L = nb_new
             a_add(nb, L);                     // nb = nb_old + nb_new = -(li0 + li)
         }
         // use 11: Kp05 -- vN(scratch G) = X + c K05 nb_new (= lambda_r^{1/2} - c K05 li_new)

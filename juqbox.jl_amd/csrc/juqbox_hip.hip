@@ -2282,8 +2282,14 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
                   : coop ? select_coop_kernels(h, &kfwd, &kbwd) : quad ? (wfull ? select_quad_w_kernels(h, &kfwd, &kbwd) : select_quad_kernels(h, spw, &kfwd, &kbwd)) : select_kernels(h, &kfwd, &kbwd);
     if (rc) return rc;
     if (qsplit && (rc = select_qsplit_kernel(h, qs_qw, &kbwd))) return rc;
-    const int nblocks = imr_parts ? nsamples : (cq || imr_cq) ? 4 * nslabs : rl ? (int)nwaves_rl : lane ? (int)(ncols / 64) : quad8 ? (nslabs + spw - 1) / spw : (coop || quad) ? nslabs : (nslabs + JQ_WAVES - 1) / JQ_WAVES;
-    const int nthreads = (lane || rl) ? 64 : (coop || cq || imr_cq) ? 64 * h->NT : quad8 ? 256 * spw : 256;
+    // Jacobi solver with N > 16 on the slab kernels: ONE workgroup per sample when its parts fit one (<= JQ_WAVES = 4 slabs, N <= 64) -- the
+    // waves add their parts' residual norms through LDS, so the stopping test is the reference's (norm over the whole Ntot x N block,
+    // src/linear_solvers.jl:121) and not a test per 16-column part (round 5; JQ_JAC_WG=0: per part).  More parts, or the cooperative
+    // kernels (Ntot > 96): per part as before (include/juqbox_hip.h).
+    const bool jac_wg = !imr && h->solver_id == 2 && h->parts > 1 && h->parts <= JQ_WAVES && !coop && !cq && !quad && !lane && !rl &&
+                        !(getenv("JQ_JAC_WG") && atoi(getenv("JQ_JAC_WG")) == 0);
+    const int nblocks = jac_wg ? nsamples : imr_parts ? nsamples : (cq || imr_cq) ? 4 * nslabs : rl ? (int)nwaves_rl : lane ? (int)(ncols / 64) : quad8 ? (nslabs + spw - 1) / spw : (coop || quad) ? nslabs : (nslabs + JQ_WAVES - 1) / JQ_WAVES;
+    const int nthreads = jac_wg ? 64 * h->parts : (lane || rl) ? 64 : (coop || cq || imr_cq) ? 64 * h->NT : quad8 ? 256 * spw : 256;
     // per-step trace records: one per wave (cooperative, lane, row-lane, implicit-midpoint kernels) or one per workgroup
     // (slab / quad kernels: summed over the workgroup's waves in LDS)
     const int trace_rows = qsplit ? qs_blocks : imr_parts ? nsamples * h->NT : imr_cq ? nslabs * qps * h->NT : cq ? nslabs * qps : (lane || rl) ? nblocks : coop ? nslabs * h->NT : imr_quad ? nslabs * JQ_WAVES : nblocks;
@@ -2378,7 +2384,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     a.tabs = h->d_tabs; a.stride = stride; a.pieces = (int)(stride * 8 / 1024); a.nslots = h->nslots; a.m = h->m;
     a.nslabs = rl ? (int)nwaves_rl : lane ? (int)ncols : nslabs; a.Ncoupled = ctrl_gstart(h->Nc, 1) /* first control group */; a.Ntot = h->Ntot; a.N = h->N; a.use_shift = use_shift ? 1 : 0;
     a.tinv = 1.0 / h->T; a.state_stride = h->state_stride; a.parts = h->parts; a.nsamples = nsamples; a.sps = h->sps; a.qps = qps;
-    a.wlr = h->d_wlr; a.wrank = h->wrank; a.wstride = h->NP; a.wlr_lds = -1; a.wlr_sc_lds = -1;
+    a.wlr = h->d_wlr; a.wrank = h->wrank; a.wstride = h->NP; a.wlr_lds = -1; a.wlr_sc_lds = -1; a.jac_wg_lds = -1;
     // JACOBI_SOLVER: the kernels iterate on c-scaled right-hand sides (A = c rhs, c = h / 2: DESIGN.md section 3), so their
     // residual norm is |c| times the reference's ||X_j - X_{j-1}|| (src/linear_solvers.jl:121): the threshold is scaled alike
     a.jacobi_tol2 = (h->solver_id == 2) ? (h->solver_tol * 0.5 * dt) * (h->solver_tol * 0.5 * dt) : 0.0;
@@ -2412,13 +2418,15 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     const size_t wsc_off_fwd = lds_fwd + (wlr_lds_fwd >= 0 ? wlr_bytes : 0), wsc_off_bwd = lds_bwd + (wlr_lds_bwd >= 0 ? wlr_bytes : 0);
     const int wsc_lds_fwd = (wsc_bytes && wsc_off_fwd + wsc_bytes <= 163840) ? (int)wsc_off_fwd : -1;
     const int wsc_lds_bwd = (wsc_bytes && wsc_off_bwd + wsc_bytes <= 163840) ? (int)wsc_off_bwd : -1;
+    const size_t jac_bytes = jac_wg ? (size_t)2 * JQ_WAVES * 8 : 0;      // (residual exchange of the workgroup-wide Jacobi test, behind everything else)
+    if (jac_wg && std::max(lds_fwd, lds_bwd) + jac_bytes > 163840) return fail(h, JQ_EHIP, "internal error: no LDS left for the Jacobi residual exchange");
     a.batch = batch; a.lds_tab_off = (int)lds_stage;
     a.park = h->d_park; a.park_lds = quad ? 1 : h->park_lds;
     if (cq) a.nslots = 0;
     if (const char* e = getenv("JQ_DEBUG")) a.debug = atoi(e);
     if (!lane && !rl) {
-        HIPCHK(h, hipFuncSetAttribute((const void*)kfwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_fwd + (wlr_lds_fwd >= 0 ? wlr_bytes : 0) + (wsc_lds_fwd >= 0 ? wsc_bytes : 0))));
-        HIPCHK(h, hipFuncSetAttribute((const void*)kbwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_bwd + (wlr_lds_bwd >= 0 ? wlr_bytes : 0) + (wsc_lds_bwd >= 0 ? wsc_bytes : 0))));
+        HIPCHK(h, hipFuncSetAttribute((const void*)kfwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_fwd + (wlr_lds_fwd >= 0 ? wlr_bytes : 0) + (wsc_lds_fwd >= 0 ? wsc_bytes : 0) + jac_bytes)));
+        HIPCHK(h, hipFuncSetAttribute((const void*)kbwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_bwd + (wlr_lds_bwd >= 0 ? wlr_bytes : 0) + (wsc_lds_bwd >= 0 ? wsc_bytes : 0) + jac_bytes)));
     }
 
     // events: [0]=start [1]=end, then pairs around every propagator launch
@@ -2458,6 +2466,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
         a.hist_r = hist_r; a.hist_i = hist_i;
         a.wlr_lds = wlr_lds_fwd;
         a.wlr_sc_lds = wsc_lds_fwd;
+        a.jac_wg_lds = jac_wg ? (int)lds_fwd : -1;
         a.period = 7; a.npro = 0; a.nslots = h->nslots;
         {   // slab kernels: Kp05 S05 Kn0 S0 Kn1 S1 Kp05 ; cooperative kernels: Kp05 S05 Kn0 Kn1 S0 S1 Kp05
             // {kind (0 K, 1 S, 2 constant image), time point offset / image index}
@@ -2469,7 +2478,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
             for (int i = 0; i < 7; ++i) sched_pack(a.sched_bits, i, kinds[i], tps[i]);
         }
         HIPCHK(h, hipEventRecord(h->ev[evi++], s));
-        hipLaunchKernelGGL(kfwd, dim3(cq_fwd2 ? nblocks / 2 : nblocks), dim3(cq ? nthreads + 128 : imr_cq ? nthreads + 128 : nthreads), lds_fwd + (wlr_lds_fwd >= 0 ? wlr_bytes : 0) + (wsc_lds_fwd >= 0 ? wsc_bytes : 0), s, a);      // (cooperative quad: two staging waves)
+        hipLaunchKernelGGL(kfwd, dim3(cq_fwd2 ? nblocks / 2 : nblocks), dim3(cq ? nthreads + 128 : imr_cq ? nthreads + 128 : nthreads), lds_fwd + (wlr_lds_fwd >= 0 ? wlr_bytes : 0) + (wsc_lds_fwd >= 0 ? wsc_bytes : 0) + jac_bytes, s, a);      // (cooperative quad: two staging waves)
         HIPCHK(h, hipEventRecord(h->ev[evi++], s));
         mfma += (long long)nslabs * nc * (8 + 2 * h->m) * tiles;
     }
@@ -2531,6 +2540,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
                 a.hist_r = nullptr; a.hist_i = nullptr;
                 a.wlr_lds = wlr_lds_bwd;
                 a.wlr_sc_lds = wsc_lds_bwd;
+                a.jac_wg_lds = jac_wg ? (int)lds_bwd : -1;
                 a.period = 13 + 3 * ng; a.npro = (n0 == 0) ? ng : 0; a.nslots = h->nslots_bwd;
                 {   // Kp05 S05 Kn0 S0 Kn1 S1 Kp05 | S0 | Hanti_q.. | Kn0 Kn1 S05 Kp05 S1 | (Hanti_q Hsym_q)..
                     const int kinds_s[8] = {0, 1, 0, 1, 0, 1, 0, 1}, tps_s[8] = {1, 1, 0, 0, 2, 2, 1, 0};
@@ -2565,11 +2575,11 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
                 else if (cq3)
                     hipLaunchKernelGGL(kbwd, dim3((unsigned)(cq_nr * nq_pad)), dim3(nthreads + 128), lds_bwd, s, a);      // (three / two workgroups per quad: NT block waves + two staging waves each)
                 else
-                hipLaunchKernelGGL(kbwd, dim3(nblocks), dim3((cq || rl_split) ? 2 * nthreads : imr_cq2 ? 2 * (nthreads + 128) : imr_cq ? nthreads + 128 : nthreads), lds_bwd + (wlr_lds_bwd >= 0 ? wlr_bytes : 0) + (wsc_lds_bwd >= 0 ? wsc_bytes : 0), s, a);      // (cooperative quad: state and adjoint chain on separate waves)
+                hipLaunchKernelGGL(kbwd, dim3(nblocks), dim3((cq || rl_split) ? 2 * nthreads : imr_cq2 ? 2 * (nthreads + 128) : imr_cq ? nthreads + 128 : nthreads), lds_bwd + (wlr_lds_bwd >= 0 ? wlr_bytes : 0) + (wsc_lds_bwd >= 0 ? wsc_bytes : 0) + jac_bytes, s, a);      // (cooperative quad: state and adjoint chain on separate waves)
                 HIPCHK(h, hipEventRecord(h->ev[evi++], s));
                 if (cq3 && sweep == 0 && n0 == 0) {
                     // the first launch of the split says whether its workgroups were resident together: read the error word now instead
-                    // of running every other chunk and sweep (each dead wait costs ~ 2 s) before the evaluation is repeated anyway
+                    // of running every other chunk and sweep (each dead wait costs ~ 1.3 s) before the evaluation is repeated anyway
                     unsigned long long e1 = 0;
                     HIPCHK(h, hipMemcpyAsync(&e1, h->d_cq3, sizeof(e1), hipMemcpyDeviceToHost, s));
                     HIPCHK(h, hipStreamSynchronize(s));
