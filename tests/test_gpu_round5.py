@@ -347,3 +347,35 @@ def test_backward_sweep_on_two_workgroups_per_quad_is_the_one_workgroup_kernel(j
     assert (a[4]["kernel_family"], a[4]["reserved"]) == (8, 2) and (b[4]["kernel_family"], b[4]["reserved"]) == (8, 0), (a[4], b[4])
     for x in (b, c):
         assert a[0] == x[0] and a[1] == x[1] and np.array_equal(a[2], x[2]) and np.array_equal(a[3], x[3])
+
+
+def test_implicit_midpoint_ensembles_never_take_the_split_kernel(jq):
+    """Found by the fuzz slice in round 5: the implicit-midpoint quad-layout path also runs "one slab per workgroup", and the first version
+    of the selection handed its backward sweep to the Stormer-Verlet split kernel (relative error 0.75).  A mid-size implicit-midpoint
+    ensemble stays on its own kernels (family 7) and agrees with the oracle."""
+    from oracle.oracle import Oracle
+    params, pcof = _problem(jq, "t4x3")
+    params.objFuncType = 1
+    params.Integrator_id = jq.Implicit_Midpoint
+    params.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER_M, max_iter=100, tol=1e-12, nrhs=params.N)
+    ns = 600
+    rng = np.random.default_rng(3)
+    nodes, weights = 0.02 * rng.standard_normal(ns), np.zeros(ns)
+    weights[[0, 311, 599]] = [0.2, 0.5, 0.3]
+    shift = 0.01 * np.arange(params.Ntot)
+    wa = jq.Working_Arrays_M_HIP(params, pcof.size)
+    jq.eval_f_g_grad(pcof, params, wa, nodes, weights, True, shift=shift)
+    t = wa.last_timing()
+    got = (params.last_infidelity, params.last_infidelity_grad.copy())
+    wa.close()
+    assert t["kernel_family"] == 7 and t["reserved"] == 0, t
+    inf, grad = 0.0, np.zeros(pcof.size)
+    H0 = params.Hconst.copy()
+    for i in (0, 311, 599):      # (the oracle's ensemble loop is the Stormer-Verlet one: per sample with the perturbed drift)
+        params.Hconst = H0 + np.diag(nodes[i] * shift)
+        r = Oracle(params, use_sparse=False).traceobjgrad_imr(pcof, 100, 1e-12)
+        inf += weights[i] * r["primaryobjf"]
+        grad += weights[i] * r["infidelgrad"]
+    params.Hconst = H0
+    assert abs(got[0] - inf) <= 1e-9 * abs(inf)
+    assert rel(got[1], grad) <= 1e-9
