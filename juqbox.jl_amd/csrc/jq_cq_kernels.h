@@ -323,6 +323,60 @@ __device__ __forceinline__ double cq_part4(double a, double b, double c, double 
     return p + q;
 }
 
+// Full leakage weights on the cooperative-quad kernels (round 5; REAL weight matrices of rank <= JQ_CQ_WRANK: wmat_imag = 0, i.e. real
+// forbidden states -- W = sum_k lam_k a_k a_k').  A column's dot products a_k . x run over the NT blocks of the quad, i.e. over NT waves:
+// the wave that owns block w leaves the 16 column partials of its rows for all four terms in ONE register (cq_part4 + the two rotate-adds
+// over the 4-row groups; row k of the register = term k) in LDS, wpart[vector][w][64], in front of a barrier the step has anyway;
+// whoever needs the dots adds the NT registers behind it.  A complex W needs vr(t_n) in the MIDDLE of the adjoint step of step n (the
+// term W_i vr(t_n) of hi1, src/evalobjgrad.jl:886-888), which the state chain of the same workgroup delivers at its END: not here
+// (the quad-layout kernels take those).
+#define JQ_CQ_WRANK 4
+// Both halves are one v_mfma_f64_4x4x4 in the quad layout (A operand: lane 16 k + 4 b + i holds A_b[i][k]; B operand / result: lane
+// 16 i + 4 b + j holds X_b[i][j]):
+//   part:  A_b[k][i] = a_k[4 b + i]           x  my block of x    ->  D_b[k][j] = sum_i a_k[4 b + i] x[4 b + i][j]; two rotate-adds over b
+//   apply: A_b[i][k] = coef_k[my row 4 b + i]  x  d[k][j] (the sum of the NT partial registers, the same for every b)  ->  (W x)[my row][j]
+struct CqW {
+    double akA;       // part(): a_k[16 blk + 4 b + i] on lane 16 i + 4 b + k
+    double* wpart;    // LDS [2][NT][64]
+    __device__ __forceinline__ void init(const PropArgs& a, char* smem, int blk, int lane_)
+    {
+        const int k = lane_ & 3, row = 16 * blk + 4 * ((lane_ >> 2) & 3) + (lane_ >> 4);
+        akA = k < a.wrank ? a.wlr[JQ_MAX_WRANK + (size_t)(2 * k) * a.wstride + row] : 0.0;
+        wpart = (double*)(smem + a.wlr_lds);
+    }
+    // apply()'s A operand: scale lam_k a_k[16 blk + 4 b + i] on lane 16 k + 4 b + i
+    __device__ __forceinline__ double coef(const PropArgs& a, int blk, int lane_, double scale) const
+    {
+        const int k = lane_ >> 4, row = 16 * blk + 4 * ((lane_ >> 2) & 3) + (lane_ & 3);
+        return k < a.wrank ? scale * a.wlr[k] * a.wlr[JQ_MAX_WRANK + (size_t)(2 * k) * a.wstride + row] : 0.0;
+    }
+    // my block's share of the four dots with x, for every column of the quad: register row k = term k, the same in every 4-row group
+    __device__ __forceinline__ double part(double x) const
+    {
+        return row_ror_add<8>(row_ror_add<4>(__builtin_amdgcn_mfma_f64_4x4x4f64(akA, x, 0.0, 0, 0, 0)));
+    }
+    template <int NT>
+    __device__ __forceinline__ void put(int vec, int blk, int lane_, double x) const
+    {
+#ifndef JQ_EXP_W_NOPUT      // (timing experiment: wrong results)
+        wpart[((size_t)vec * NT + blk) * 64 + lane_] = part(x);
+#endif
+    }
+    // sum_k coef_k[my row] (a_k . x)[my column] -- behind the barrier that follows the put()s
+    template <int NT>
+    __device__ __forceinline__ double apply(int vec, int lane_, double cA) const
+    {
+#ifdef JQ_EXP_W_NOAPPLY     // (timing experiment: wrong results)
+        return cA;
+#endif
+        const double* r = wpart + (size_t)vec * NT * 64 + lane_;
+        double d = r[0];
+#pragma unroll
+        for (int w = 1; w < NT; ++w) d += r[w * 64];
+        return __builtin_amdgcn_mfma_f64_4x4x4f64(cA, d, 0.0, 0, 0, 0);
+    }
+};
+
 // the six operator blocks of a time step (this wave's share of K, S at the time points 2n, 2n+1, 2n+2 of the chunk)
 template <int NT>
 struct CqOps {
@@ -456,9 +510,16 @@ __device__ __forceinline__ CqSetup<NT> cq_setup(const PropArgs& a)
 // image.  The same barriers serve both quads: a publication interval of the forward sweep (two waves per SIMD) is bound by latency,
 // not by issue, so twice the work per interval costs ~ 1.5 x -- against 2 x for two rounds of workgroups.  (The backward sweep's
 // twelve waves are issue-bound and hold 150 registers: it stays at one quad per workgroup.)
-template <int NT, bool MODD, int NS = 1>
+// WLR: full (real, rank <= JQ_CQ_WRANK) leakage weights.  The propagating waves do NOTHING for them: staging wave 0, which otherwise only
+// waits, reads the blocks of vi05 and vr(t_n+1) that they publish anyway (exchange image, behind the publication's barrier and before
+// the next one lets the image be overwritten), forms the dots a_k . x of the four columns and accumulates
+// lam_k [(a_k . vr(t_n))^2 + (a_k . vr(t_n+1))^2 + 2 (a_k . vi05)^2]  (penalf2aTrap, penalf2a: src/evalobjgrad.jl:2170-2223).
+// (First version: partial dots by the propagating waves, 34 instructions per step in lock-step: forward sweep 71 -> 91 ms; behind the
+//  last barrier instead of in front of it 86 ms; this version 71.)
+template <int NT, bool MODD, int NS = 1, bool WLR = false>
 __global__ __launch_bounds__(64 * NT + 128) void k_forward_cq(PropArgs a)
 {
+    static_assert(!WLR || NS == 1, "full weights: one column quad per workgroup");
     typedef typename std::conditional<NS == 2, D2, double>::type T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KT = 4 * NT;
@@ -474,17 +535,107 @@ __global__ __launch_bounds__(64 * NT + 128) void k_forward_cq(PropArgs a)
     c.ring.init(smem, a, wave + NT * s.chain, lane_, NT + 2);      // (barrier inside)
     if (s.chain) {      // staging waves
         c.ring.wave = wave, c.ring.nwaves = 2;
-        const int nb = 4 + 2 * (a.m > 0 ? a.m : 0);
-        for (int n = 0; n < a.nsteps_chunk; ++n) {
-            for (int k = 0; k < nb; ++k) __builtin_amdgcn_s_barrier();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (my pieces of the time points 2n+3, 2n+4)
+        const int mm = a.m > 0 ? a.m : 0;
+        const int nb = 4 + 2 * mm;
+        const bool wsum = WLR && wave == 0;
+        double wacc = 0.0;
+        if constexpr (!WLR) {
+            for (int n = 0; n < a.nsteps_chunk; ++n) {
+                for (int k = 0; k < nb; ++k) __builtin_amdgcn_s_barrier();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (my pieces of the time points 2n+3, 2n+4)
+                __builtin_amdgcn_s_barrier();
+                c.ring.issue_next();
+                c.ring.issue_next();
+            }
+        } else {
+        double wp0 = 0.0, wlam = 0.0, wrr = 0.0;
+        // a_k as the A operand of v_mfma_f64_4x4x4 (lane 16 i + 4 b + k holds a_k[16 w + 4 b + i], jq_kernels.h mm_t4q): the MFMA of block w
+        // adds, for every 4-row group b, the products of the group's four rows with the four columns -- D[k][j] on lane 16 k + 4 b + j
+        double akA[NT];
+        if (wsum) {
+            wlam = ((lane_ >> 4) < a.wrank && ((lane_ >> 2) & 3) == 0) ? a.wlr[lane_ >> 4] : 0.0;
+#pragma unroll
+            for (int w = 0; w < NT; ++w)
+                akA[w] = (lane_ & 3) < a.wrank ? a.wlr[JQ_MAX_WRANK + (size_t)(2 * (lane_ & 3)) * a.wstride + 16 * w + 4 * ((lane_ >> 2) & 3) + (lane_ >> 4)] : 0.0;
+        }
+        // The dots with a vector published in channel 0 of parity `par` in three phases, one per barrier interval (the whole of it in one
+        // interval made this wave late at the next barrier: forward sweep 71 -> 100 ms): load the NT blocks | NT MFMAs with the a_k
+        // operands | add the 4-row groups.  (This wave shares its SIMD with a propagating wave: 24 FMAs + a 9-instruction lane
+        // reduction instead of the MFMAs cost 81 ms.)
+        double X[NT], acc = 0.0;
+        auto wload = [&](int par) {
+            const jq_lds_double* x = c.xb + par * CoopQ<NT>::PAR + 64;
+#pragma unroll
+            for (int w = 0; w < NT; ++w) X[w] = x[w * 64];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (read before this wave arrives at the next barrier)
+        };
+        auto wfma = [&]() {
+            acc = 0.0;
+#pragma unroll
+            for (int w = 0; w < NT; ++w) acc = __builtin_amdgcn_mfma_f64_4x4x4f64(akA[w], X[w], acc, 0, 0, 0);
+        };
+        auto wred = [&]() { return row_ror_add<8>(row_ror_add<4>(acc)); };      // (over the 4-row groups: row k = term k, every lane its column)
+        // publications of a step: u | v | m x | vi05 | u' | m x | u(t_n+1); publication k of the chunk has parity k & 1, 5 + 2 m per step.
+        //   vr(t_n) = the u of step n: load behind barrier 1, multiply-add behind 2, reduce + accumulate step n - 1 behind 3
+        //   vi05 of step n:            load behind barrier 3 + m, multiply-add behind 4 + m, reduce behind 5 + m
+        //   vr(t_N) after the last step of the chunk: all phases behind its last barrier
+        // (This wave must reach every barrier before the propagating waves do -- an interval is ~ 230 cycles and a taken branch costs a
+        //  lone wave 20 ... 120 of them: one short piece of straight-line code per interval, none in the interval of the DMA issue.
+        //  Everything behind the last barrier: forward sweep 100 ms instead of 71; a loop over the barriers with the phase tests inside: 108;
+        //  vr(t_n+1) loaded behind the last barrier, next to the DMA issue: 84.)
+        auto bar = [&]() {
             __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        auto waccum = [&]() {
+            const double p1 = wred();
+            wacc += wlam * ((wp0 * wp0 + p1 * p1) + 2.0 * (wrr * wrr));
+            wp0 = p1;
+        };
+        for (int n = 0; n < a.nsteps_chunk; ++n) {
+            bar();      // 1: u = vr(t_n) is published
+            if (wsum) wload(n & 1);
+            bar();      // 2
+            if (wsum) wfma();
+            if (mm > 0) {
+                bar();      // 3
+                if (wsum) {
+                    if (n > 0) waccum();
+                    else wp0 = wred();
+                }
+                for (int k = 1; k < mm; ++k) bar();      // 4 .. 2 + m
+            }
+            bar();      // 3 + m: vi05 is published
+            if (wsum) {
+                if (mm == 0) {
+                    if (n > 0) waccum();
+                    else wp0 = wred();
+                }
+                wload((n ^ mm) & 1);
+            }
+            bar();      // 4 + m
+            if (wsum) wfma();
+            if (mm > 0) {
+                bar();      // 5 + m
+                if (wsum) wrr = wred();
+                for (int k = 1; k < mm; ++k) bar();      // 6 + m .. 4 + 2 m
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (my pieces of the time points 2n+3, 2n+4)
+            bar();      // 5 + 2 m: vr(t_n+1) is published
             c.ring.issue_next();
             c.ring.issue_next();
+            if (wsum && mm == 0) wrr = wred();
+        }
+        if (wsum && a.nsteps_chunk > 0) {
+            wload((a.nsteps_chunk - 1) & 1);
+            wfma();
+            waccum();
+        }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         for (int k = 0; k < NS; ++k) {
             __syncthreads();      // (cq_wg_sum of the propagating waves)
+            if (wsum) scratch[NT * 64 + lane_] = wacc;
             __syncthreads();
         }
         return;
@@ -562,7 +713,7 @@ __global__ __launch_bounds__(64 * NT + 128) void k_forward_cq(PropArgs a)
     } else {
         st[s.foff] = u;
         st[(size_t)KT * 64 + s.foff] = v;
-        const double tot = cq_wg_sum(leak, scratch, wave, lane_, NT);
+        const double tot = cq_wg_sum(leak, scratch, wave, lane_, WLR ? NT + 1 : NT);      // (WLR: + staging wave 0's low-rank terms)
         if (slot0) st[lslot] = tot;
     }
 }
@@ -579,7 +730,10 @@ __global__ __launch_bounds__(64 * NT + 128) void k_forward_cq(PropArgs a)
 // finishes the four sums with rotate-adds inside the rows and writes them to the trace record of the step.
 //   group q < Nc (adjoint wave):  rows 0, 1, 2 = t1, t4, t3 of control q
 //   group Nc + j (state wave):    rows 0, 1 = t2, t5 of control 2 j, rows 2, 3 = t2, t5 of control 2 j + 1
-template <int NT, bool MODD, bool ORD>
+// WLR: full (real, rank <= JQ_CQ_WRANK) leakage weights: the forcing terms hr0 = W vr(t_n+1) / T, hi0 = hi1 = W vi05 / T,
+// hr1 = W vr(t_n) / T (src/evalobjgrad.jl:862, :882-888) from the dots the state waves leave with their publications of vi05 and
+// vr(t_n) (CqW); W vr(t_n) is next step's W vr(t_n+1).
+template <int NT, bool MODD, bool ORD, bool WLR = false>
 __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -612,6 +766,8 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
     double* st = a.state + (size_t)s.slab * a.state_stride;
     const double cw = 0.5 * a.h * a.colinfo[(size_t)s.slab * 32 + s.col] * wsr;      // h/2 eps ws[row]
     const double wgt = a.colinfo[(size_t)s.slab * 32 + 16 + s.col];
+    CqW wq;
+    if constexpr (WLR) wq.init(a, smem, wave, lane_);
     const size_t cslot = 16 * (lane_ >> 4) + s.col;
     double carry[JQ_MAXNC];
 #pragma unroll
@@ -646,6 +802,10 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
         Op Kp05 = c.load(c.ring.template ks<0, 1>()), S0 = c.load(c.ring.template ks<1, 0>());
         if (a.first_chunk) {      // (vr(T) for the carry products of the adjoint waves; parity 1: the first step starts with 0)
             c.template post<1, 0>(u);
+            c.sync();
+        }
+        if constexpr (WLR) {      // (the dots with the state the chunk starts from: hr0 of its first step)
+            wq.template put<NT>(0, wave, lane_, u);
             c.sync();
         }
         JQ_TS_DECL
@@ -684,6 +844,7 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
             JQ_TS(n)
             // x = v05: vN = v05 + c S05 v05 ; un = u + c (S0 u - K0 v05) ; A = -c K1 v05
             c.template post<P0 ^ M, 0>(v05);
+            if constexpr (WLR) wq.template put<NT>(1, wave, lane_, v05);
             const Op S1 = c.load(c.ring.template ks<1, 2>());
             {
                 const Sh sx = c.sh(v05);
@@ -726,6 +887,7 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
             JQ_TS(n)
             // x = un: v(t_n) = v05 + c (K05 un + S05 v05)
             c.template post<P0, 0>(un);
+            if constexpr (WLR) wq.template put<NT>(0, wave, lane_, un);
             v = c.own(vN, Kp05, c.sh(un));
             if (a.use_shift) v = fma(cw, un, v);
             JQ_TS(n)
@@ -778,6 +940,8 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
         double mu = st[(size_t)2 * KT * 64 + s.foff], nb = st[(size_t)3 * KT * 64 + s.foff];
         Op Kp05 = c.load(c.ring.template ks<0, 1>()), S05 = c.load(c.ring.template ks<1, 1>());
         const double cfw = (a.forced ? 0.5 * a.h * a.tinv : 0.0) * wdr;      // forcing weight c tinv wd[row]; 0 for step_no_forcing!
+        const double wcf = WLR ? wq.coef(a, wave, lane_, a.forced ? 0.5 * a.h * a.tinv : 0.0) : 0.0;      // full weights: c tinv lam_k a_k[row] as an A operand
+        double Wu = 0.0;      // c tinv (W vr(t_n+1))[row, column]
         const bool slot0 = wave == 0 && ((lane_ >> 2) & 3) == 0;      // the lanes that carry per-column partials between chunks
 #pragma unroll
         for (int q = 0; q < JQ_MAXNC; ++q)
@@ -794,6 +958,10 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
                 if (q < Nc) {
                     carry[q] = -(u0 * c.template trace_mm<ORD>(c.ring.cimg(q), q, sx, nn));
                 }
+        }
+        if constexpr (WLR) {
+            c.sync();
+            Wu = wq.template apply<NT>(0, lane_, wcf);
         }
         JQ_TS_DECL
         auto step = [&](auto P0c, int n) {
@@ -821,6 +989,7 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
             c.template post<P0 ^ 1, 1>(mu);
             L = c.own(L, S0, c.sh(mu));
             L = fma(cfw, u, L);
+            if constexpr (WLR) L += Wu;
             JQ_TS(n)
             c.sync();
             JQ_TS(n)
@@ -862,7 +1031,8 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
             // Lk = -c l2 = -c (K0 X + S05 li + hi0) ; Q = -c (S05 (li + c l2) + K1 X + hi1)
             {
                 const double v05 = c.template block<P0 ^ M, 0>();
-                const double Pn = fma(-cfw, v05, Tn);
+                double Pn = fma(-cfw, v05, Tn);
+                if constexpr (WLR) Pn -= wq.template apply<NT>(1, lane_, wcf);
                 Lk += Pn;
                 Q += Pn;
             }
@@ -892,6 +1062,10 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
                 const double un = c.template block<P0, 0>();
                 G = c.nbr(G, Kp05, nn);
                 G = fma(cfw, un, G);
+                if constexpr (WLR) {
+                    Wu = wq.template apply<NT>(0, lane_, wcf);      // (hr1 of this step, hr0 of the next)
+                    G += Wu;
+                }
                 // (the time points of the next step have landed)
                 c.ring.advance();
                 Kp05 = c.load(c.ring.template ks<0, 1>());

@@ -24,6 +24,12 @@ template __global__ void k_forward_cq<JQ_NT, false, 2>(PropArgs);      // (two c
 template __global__ void k_forward_cq<JQ_NT, true, 2>(PropArgs);
 template __global__ void k_backward_cq<JQ_NT, true, false>(PropArgs);
 template __global__ void k_backward_cq<JQ_NT, true, true>(PropArgs);
+template __global__ void k_forward_cq<JQ_NT, false, 1, true>(PropArgs);      // (full leakage weights, real, rank <= 4: CqW)
+template __global__ void k_forward_cq<JQ_NT, true, 1, true>(PropArgs);
+template __global__ void k_backward_cq<JQ_NT, false, false, true>(PropArgs);
+template __global__ void k_backward_cq<JQ_NT, false, true, true>(PropArgs);
+template __global__ void k_backward_cq<JQ_NT, true, false, true>(PropArgs);
+template __global__ void k_backward_cq<JQ_NT, true, true, true>(PropArgs);
 template __global__ void k_backward_cq3<JQ_NT, false, false>(PropArgs);     // (backward sweep on three workgroups per column quad)
 template __global__ void k_backward_cq3<JQ_NT, false, true>(PropArgs);
 template __global__ void k_backward_cq3<JQ_NT, true, false>(PropArgs);

@@ -98,6 +98,7 @@ struct jq_handle {
     int wrank = 0;
     std::vector<double> Wr, Wi, wlr;
     double* d_wlr = nullptr;
+    bool wlr_real = false;      // every kept eigenvector is real (wmat_imag = 0): the cooperative-quad kernels take rank <= 4 of those
     std::vector<double> tf, tb;
     // device buffers (owned)
     double *d_cimg = nullptr, *d_park = nullptr;
@@ -1398,6 +1399,13 @@ static int upload_wlr(jq_handle* h, const std::vector<int>& keep, const std::vec
     if (!h->d_wlr && (rc = dev_alloc(h, &h->d_wlr, h->wlr.size()))) return rc;
     HIPCHK(h, hipMemcpy(h->d_wlr, h->wlr.data(), h->wlr.size() * sizeof(double), hipMemcpyHostToDevice));
     h->wrank = (int)keep.size();
+    h->wlr_real = true;
+    for (size_t k = 0; k < keep.size() && h->wlr_real; ++k)
+        for (int i = 0; i < n; ++i)
+            if (Vi[i + (size_t)n * keep[k]] != 0.0) {
+                h->wlr_real = false;
+                break;
+            }
     std::fill(h->wd.begin(), h->wd.end(), 0.0);
     return JQ_OK;
 }
@@ -1552,8 +1560,8 @@ static int select_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
     extern template __global__ void k_backward<nt, JQ_BW_T4Q, 3, false, false, true, true>(PropArgs);
 JQ_DECLQ(1) JQ_DECLQ(2) JQ_DECLQ(3) JQ_DECLQ(4) JQ_DECLQ(5) JQ_DECLQ(6) JQ_DECLQ(7) JQ_DECLQ(8)
 #undef JQ_DECLQ
-template <int NT, bool MODD, int NS> __global__ void k_forward_cq(PropArgs);    // jq_cq_kernels.h (own translation units); NS: column quads per workgroup
-template <int NT, bool MODD, bool ORD> __global__ void k_backward_cq(PropArgs);
+template <int NT, bool MODD, int NS, bool WLR = false> __global__ void k_forward_cq(PropArgs);    // jq_cq_kernels.h (own translation units); NS: column quads per workgroup; WLR: full (real, low-rank) leakage weights
+template <int NT, bool MODD, bool ORD, bool WLR = false> __global__ void k_backward_cq(PropArgs);
 template <int NT, bool MODD, bool ORD, int NR = 3> __global__ void k_backward_cq3(PropArgs);    // jq_cq_split_kernels.h: three (NR = 2: two) workgroups per column quad
 #define JQ_DECLCQ(nt)                                                      \
     extern template __global__ void k_forward_cq<nt, false, 1>(PropArgs);  \
@@ -1564,6 +1572,12 @@ template <int NT, bool MODD, bool ORD, int NR = 3> __global__ void k_backward_cq
     extern template __global__ void k_forward_cq<nt, true, 2>(PropArgs);   \
     extern template __global__ void k_backward_cq<nt, true, false>(PropArgs);     \
     extern template __global__ void k_backward_cq<nt, true, true>(PropArgs);      \
+    extern template __global__ void k_forward_cq<nt, false, 1, true>(PropArgs);          \
+    extern template __global__ void k_forward_cq<nt, true, 1, true>(PropArgs);           \
+    extern template __global__ void k_backward_cq<nt, false, false, true>(PropArgs);     \
+    extern template __global__ void k_backward_cq<nt, false, true, true>(PropArgs);      \
+    extern template __global__ void k_backward_cq<nt, true, false, true>(PropArgs);      \
+    extern template __global__ void k_backward_cq<nt, true, true, true>(PropArgs);       \
     extern template __global__ void k_backward_cq3<nt, false, false>(PropArgs);   \
     extern template __global__ void k_backward_cq3<nt, false, true>(PropArgs);    \
     extern template __global__ void k_backward_cq3<nt, true, false>(PropArgs);    \
@@ -1577,7 +1591,7 @@ JQ_DECLCQ(1) JQ_DECLCQ(2) JQ_DECLCQ(3) JQ_DECLCQ(4) JQ_DECLCQ(5) JQ_DECLCQ(6) JQ
 // (instantiated for even and odd numbers of Neumann terms: the parities of the LDS exchange are compile-time constants)
 // fwd2: the forward kernel with two column quads per workgroup (grid = 2 * nslabs); bwd3: the backward sweep on three workgroups per
 // quad (k_backward_cq3)
-static int select_cq_kernels(jq_handle* h, bool fwd2, int bwd_nr, prop_kernel_t* fwd, prop_kernel_t* bwd)      // bwd_nr: workgroups per quad in the backward sweep (0 / 1: one)
+static int select_cq_kernels(jq_handle* h, bool fwd2, int bwd_nr, bool wlr, prop_kernel_t* fwd, prop_kernel_t* bwd)      // bwd_nr: workgroups per quad in the backward sweep (0 / 1: one); wlr: full (real, low-rank) leakage weights
 {
     const bool bwd3 = bwd_nr == 3, bwd2 = bwd_nr == 2;
     const bool modd = (h->m > 0 ? h->m : 0) & 1;
@@ -1586,6 +1600,12 @@ static int select_cq_kernels(jq_handle* h, bool fwd2, int bwd_nr, prop_kernel_t*
     bool ord = h->Nc <= 3 && !getenv("JQ_CQ_GENERIC_TRACES");      // (more than JQ_MAXNC controls: generic traces per control group)
     for (int q = 0; q < h->Nc && ord; ++q) ord = (h->bw_trace[q] == (1 << q));
 #define JQ_PICKCQ(nt)                                                              \
+    if (h->NT == nt && wlr) {                                                      \
+        *fwd = modd ? k_forward_cq<nt, true, 1, true> : k_forward_cq<nt, false, 1, true>;                        \
+        *bwd = modd ? (ord ? k_backward_cq<nt, true, true, true> : k_backward_cq<nt, true, false, true>)         \
+                    : (ord ? k_backward_cq<nt, false, true, true> : k_backward_cq<nt, false, false, true>);      \
+        return JQ_OK;                                                              \
+    }                                                                              \
     if (h->NT == nt) {                                                             \
         *fwd = fwd2 ? (modd ? k_forward_cq<nt, true, 2> : k_forward_cq<nt, false, 2>) : (modd ? k_forward_cq<nt, true, 1> : k_forward_cq<nt, false, 1>);            \
         *bwd = bwd3 ? (modd ? (ord ? k_backward_cq3<nt, true, true> : k_backward_cq3<nt, true, false>)          \
@@ -2181,7 +2201,13 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     if (imr_quad) spw = 1;
     // latency regime of the JQ_BW_T4 structure: one workgroup of NT waves per column quad (jq_cq_kernels.h)
     const long long nquads_used = (ncols_used + 3) / 4;
-    const bool cq = !imr && !lane && !rl && !wfull && h->solver_id == 1 && h->cq_max_quads > 0 && nquads_used <= h->cq_max_quads &&
+    // (full weights, round 5: REAL weight matrices of rank <= 4 on the one-workgroup kernels with one quad per workgroup, LDS permitting --
+    //  jq_cq_kernels.h CqW; JQ_CQ_W=0: the quad-layout kernels as before)
+    const char* e_cqw = getenv("JQ_CQ_W");
+    const bool wfull_cq = wfull && h->wlr_real && h->wrank <= 4 && h->NT <= 7 && !(e_cqw && atoi(e_cqw) == 0) && (ncols_used + 3) / 4 <= h->num_cu &&
+                          (size_t)(2 * JQ_WIN_TPS + 2 * h->NcK) * h->mat_elems * 8 + (size_t)32 * h->NT * 8 + (size_t)6 * (h->NT + 2) * 64 * 8 +
+                                  (size_t)std::max(2, h->NcK + (h->NcK + 1) / 2) * h->NT * 64 * 8 + (size_t)2 * h->NT * 64 * 8 <= 163840;
+    const bool cq = !imr && !lane && !rl && (!wfull || wfull_cq) && h->solver_id == 1 && h->cq_max_quads > 0 && nquads_used <= h->cq_max_quads &&
                     !getenv("JQ_QUAD8");      // (JQ_QUAD8 asks for a quad-layout variant explicitly)
     const int qps = h->parts > 1 ? 4 : (h->sps * h->N + 3) / 4;      // column quads of a full slab
     // ... and of the implicit-midpoint integrator (jq_cq_imr_kernels.h): N = 4, one workgroup of NT waves per evaluation
@@ -2191,7 +2217,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     // more column quads than CUs: the forward sweep takes two quads per workgroup (one round of workgroups at ~ 1.5 x the time
     // instead of two rounds; JQ_CQ_FWD2=0: one quad per workgroup, =1: always two)
     const char* e_cf2 = getenv("JQ_CQ_FWD2");
-    const bool cq_fwd2 = cq && (e_cf2 ? atoi(e_cf2) != 0 : nquads_used > h->num_cu);
+    const bool cq_fwd2 = cq && !wfull && (e_cf2 ? atoi(e_cf2) != 0 : nquads_used > h->num_cu);
     // single evaluations and small ensembles: the backward sweep on three workgroups (CUs) per column quad -- state re-integration,
     // adjoint step, trace products, pipelined through a ring in global memory (jq_cq_split_kernels.h).  All 3 x quads workgroups must
     // be resident at once (groups of 8 quads: 24 workgroups); JQ_CQ3=0: the one-workgroup kernel
@@ -2211,6 +2237,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
         const char* why = nullptr;
         cq_nr = 3 * nq_pad <= h->num_cu ? 3 : (cq && 2 * nq_pad <= h->num_cu && !(e_c3 && atoi(e_c3) == 3)) ? 2 : 0;
         if (e_c3 && atoi(e_c3) == 0) why = "not taken: JQ_CQ3=0";
+        else if (wfull) why = "not taken: full leakage weights (the one-workgroup kernel carries the low-rank terms)";
         else if (cq_nr == 0) why = "not taken: two / three workgroups per column quad exceed the compute units";
         else if (h->cq3_off) why = "not taken: switched off after repeated faults (dead waits between the workgroups of a quad)";
         else if (h->cq3_skip > 0) why = "not taken: cooling down after a fault";
@@ -2247,7 +2274,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     if (qs_on && quad && !imr && spw == 1 && !wfull && qsplit_lds(h, 4) <= 163840) qs_qw = 4;      // (!imr: the implicit-midpoint quad kernels also run with spw = 1)
     // (JQ_QSPLIT=2: qw = 2 for every batch of the cooperative-quad plan that does not take the three-workgroup kernels -- tests)
     const bool qs_force2 = e_qs && atoi(e_qs) == 2;
-    if (qs_on && cq && !cq3 && ((nquads_used > h->num_cu && 2 * nslabs <= h->num_cu) || qs_force2) && qsplit_lds(h, 2) <= 163840) qs_qw = 2;
+    if (qs_on && cq && !cq3 && !wfull && ((nquads_used > h->num_cu && 2 * nslabs <= h->num_cu) || qs_force2) && qsplit_lds(h, 2) <= 163840) qs_qw = 2;
     const bool qsplit = qs_qw > 0;
     const int qs_blocks = qsplit ? (4 * nslabs + qs_qw - 1) / qs_qw : 0;
     if (qsplit) {
@@ -2278,7 +2305,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
              : imr_rl ? select_rowlane_imr_kernels(h, rl_split, &kfwd, &kbwd)
              : rl ? select_rowlane_kernels(h, rl_split, &kfwd, &kbwd)
              : lane ? select_lane_kernels(h, &kfwd, &kbwd, &klinit, &klterm)
-                  : cq ? select_cq_kernels(h, cq_fwd2, cq_nr, &kfwd, &kbwd)
+                  : cq ? select_cq_kernels(h, cq_fwd2, cq_nr, wfull, &kfwd, &kbwd)
                   : coop ? select_coop_kernels(h, &kfwd, &kbwd) : quad ? (wfull ? select_quad_w_kernels(h, &kfwd, &kbwd) : select_quad_kernels(h, spw, &kfwd, &kbwd)) : select_kernels(h, &kfwd, &kbwd);
     if (rc) return rc;
     if (qsplit && (rc = select_qsplit_kernel(h, qs_qw, &kbwd))) return rc;
@@ -2408,7 +2435,8 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
                                 : quad ? lds_stage + (size_t)bwd_lds_tail(h->NT, h->NcK, nthreads / 64, (long long)h->NT * 64)   // (a 16-row block per register)
                                 : lds_stage + (size_t)bwd_lds_tail(h->NT, h->NcK, JQ_WAVES, h->park_lds ? (long long)h->KT * 64 : 0);
     // full leakage weights on the slab / quad kernels: a copy of the low-rank table behind everything else in LDS when it fits
-    const size_t wlr_bytes = (wfull && !coop && !rl && !lane) ? ((size_t)JQ_MAX_WRANK + (size_t)2 * h->wrank * h->NP) * 8 : 0;
+    const size_t wlr_bytes = (wfull && cq) ? (size_t)2 * h->NT * 64 * 8      // (cooperative quad: the partial dots of two vectors, CqW)
+                             : (wfull && !coop && !rl && !lane) ? ((size_t)JQ_MAX_WRANK + (size_t)2 * h->wrank * h->NP) * 8 : 0;
     const int wlr_lds_fwd = (wlr_bytes && lds_fwd + wlr_bytes <= 163840) ? (int)lds_fwd : -1;
     const int wlr_lds_bwd = (wlr_bytes && lds_bwd + wlr_bytes <= 163840) ? (int)lds_bwd : -1;
     // ... and, quad layout, the per-wave column scalars of the terms behind it (jq_kernels.h WLow::sc).  OFF unless JQ_WLR_SC=1: measured

@@ -203,8 +203,13 @@ def test_build_manifest_no_object_falls_back():
             assert e["vgpr_form"], t
     for t in retried:      # never a quad-layout / cooperative-quad object: their scheduling strategies are tuned per object
         assert not t.endswith("_7"), "unexpected retry: " + t
+    # (p_6_7: the split kernel with the trace products riding along at FOUR quads per workgroup is not a default -- JQ_QS_RIDE=1, kept
+    #  for the tests that compare it; it holds 256 registers and a few spilled ones.  Every kernel a plan selects by itself: no scratch.)
+    not_default = ("_Z17k_backward_qsplitILi6ELb1ELi4ELb1EEv8PropArgs",)
     for tag, budget in (("k_6_7", 160), ("s_6_7", 64), ("p_6_7", 0), ("u_6_7", 0), ("w_6_7", 0), ("v_6_7", 0)):
-        assert man[tag]["max_scratch_bytes"] <= budget, (tag, man[tag]["max_scratch_bytes"])
+        worst = max(k["scratch_bytes"] for k in man[tag]["kernels"] if k["name"] not in not_default)
+        assert worst <= budget, (tag, worst)
+    assert all(k["scratch_bytes"] <= 128 for k in man["p_6_7"]["kernels"])
     assert man["k_6_7"]["max_vgprs"] <= 168          # three waves per SIMD
     assert man["p_6_7"]["max_vgprs"] <= 256          # two waves per SIMD
     hv = full["hipcc"]["hip_version"]

@@ -379,3 +379,72 @@ def test_implicit_midpoint_ensembles_never_take_the_split_kernel(jq):
     params.Hconst = H0
     assert abs(got[0] - inf) <= 1e-9 * abs(inf)
     assert rel(got[1], grad) <= 1e-9
+
+
+# ---- (6) full leakage weights on the latency path (real forbidden states, rank <= 4) ------------------------------------------------------
+
+def _real_forbidden(jq, kind, nforb, seed, oft):
+    """`kind` with `nforb` random REAL forbidden states (weights 0.5 .. 1.5): wmat_imag = 0 (src/evalobjgrad.jl:214-232)"""
+    params, pcof = _problem(jq, kind)
+    rng = np.random.default_rng(seed)
+    fs = rng.standard_normal((params.Ntot, nforb))
+    fs = fs / np.linalg.norm(fs, axis=0)
+    fw = 0.5 + rng.random(nforb)
+    params.forb_states, params.forb_weights = fs.astype(complex), fw
+    params.wmat_real = np.asfortranarray(sum(fw[k] * np.outer(fs[:, k], fs[:, k]) for k in range(nforb)))
+    params.wmat_imag = np.zeros_like(params.wmat_real)
+    params.objFuncType = oft
+    return params, pcof
+
+
+@pytest.mark.parametrize("kind,nforb,oft,chunk", [("cnot3", 1, 1, 0), ("cnot3", 2, 3, 250), ("cnot3", 4, 2, 1), ("t4x3", 3, 3, 20), ("t4x5", 4, 1, 19), ("t4x2", 2, 1, 0)])
+def test_real_full_weights_run_on_the_cooperative_quad_kernels(jq, kind, nforb, oft, chunk):
+    """Round 5: a REAL weight matrix of rank <= 4 (real forbidden states) no longer sends a single evaluation or a small ensemble to the
+    quad-layout kernels (0.45 s + 57 ms per state at cnot3): the cooperative-quad kernels carry the low-rank terms (CqW: the waves of a
+    quad leave partial dots with their publications).  1e-10 against the oracle -- objective, leak, gradients, the infidelity / leak
+    split of objFuncType 2 / 3, forward-only, ensembles (ragged quads), several chunks (also of one step), odd / even Neumann terms,
+    NT = 2, 3, 5, 6; the same numbers as the quad-layout kernels (JQ_CQ_W=0) to rounding."""
+    from test_gpu_dense_wmat import compare
+    params, pcof = _real_forbidden(jq, kind, nforb, 40 + nforb, oft)
+    env = {"JQ_CHUNK_STEPS": str(chunk)} if chunk else {}
+
+    def run():
+        wa = jq.Working_Arrays_HIP(params, pcof.size)
+        compare(jq, params, pcof, wa, family=8, ensembles=(3, 9), rng=np.random.default_rng(7))
+        t = wa.last_timing()
+        why = wa.plan_info()["latency_split"]
+        wa.close()
+        return t, why
+    t, why = _with_env(env, run)
+    assert t["kernel_family"] == 8 and t["reserved"] == 0, t
+    assert "full leakage weights" in why["last_decision"], why
+    rng = np.random.default_rng(5)
+    nodes, weights = 0.02 * rng.standard_normal(21), rng.random(21)
+    shift = 0.01 * np.arange(params.Ntot)
+    a = _eval(jq, params, pcof, nodes, weights, shift, env)
+    b = _eval(jq, params, pcof, nodes, weights, shift, dict(env, JQ_CQ_W="0"))
+    c = _eval(jq, params, pcof, nodes, weights, shift, env)
+    assert a[4]["kernel_family"] == 8 and b[4]["kernel_family"] == 6, (a[4], b[4])
+    assert abs(a[0] - b[0]) <= 1e-12 * abs(b[0]) and abs(a[1] - b[1]) <= 1e-12 * abs(b[1]) and rel(a[2], b[2]) <= 1e-11 and rel(a[3], b[3]) <= 1e-11
+    assert a[0] == c[0] and a[1] == c[1] and np.array_equal(a[2], c[2]) and np.array_equal(a[3], c[3])      # (run to run: bit-wise)
+
+
+def test_complex_or_higher_rank_full_weights_stay_on_the_quad_layout_kernels(jq):
+    """The cooperative-quad kernels take real weight matrices of rank <= 4 only (a complex W needs vr(t_n) in the middle of the adjoint
+    step, which the state chain of the same workgroup delivers at its end): complex forbidden states and rank 5 run where they ran,
+    and a switch of the weights on a live handle re-routes."""
+    from test_gpu_dense_wmat import compare, set_forbidden
+    params, pcof = _real_forbidden(jq, "cnot3", 5, 9, 1)
+    wa = jq.Working_Arrays_HIP(params, pcof.size)
+    compare(jq, params, pcof, wa, family=6)
+    set_forbidden(params, np.random.default_rng(2), 2, complex_states=True)
+    compare(jq, params, pcof, wa, family=6)
+    set_forbidden(params, np.random.default_rng(3), 2, complex_states=False)
+    compare(jq, params, pcof, wa, family=8)
+    # Diagonal weights again: the three-workgroup kernels are back
+    p0, _ = _problem(jq, "cnot3")
+    params.wmat_real, params.wmat_imag = p0.wmat_real, p0.wmat_imag
+    compare(jq, params, pcof, wa, family=8)
+    jq.traceobjgrad(pcof, params, wa, False, True)
+    assert wa.last_timing()["reserved"] == 3, wa.last_timing()
+    wa.close()
