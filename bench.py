@@ -568,6 +568,26 @@ def main():
             jq.eval_f_g_grad(pcof, params, wa, n9, w9, True, shift=s9)
             out["nine_node_ensemble"] = {"seconds": time.perf_counter() - t1, "evals_per_s": 9 / (time.perf_counter() - t1),
                                          "kernel_family": wa.last_timing()["kernel_family"]}
+            try:      # ... and of one evaluation with FULL leakage weights (use_custom_forbidden, src/evalobjgrad.jl:214-232): two real
+                      # forbidden states (latency path: cooperative-quad kernels with the low-rank terms) / two complex ones (quad layout)
+                import copy
+                fw = {}
+                for tag, cplx in (("real_rank2", False), ("complex_rank2", True)):
+                    pw = copy.copy(params)
+                    rng_w = np.random.default_rng(12)
+                    fs = rng_w.standard_normal((pw.Ntot, 2)) + (1j * rng_w.standard_normal((pw.Ntot, 2)) if cplx else 0)
+                    fs = fs / np.linalg.norm(fs, axis=0)
+                    W = sum((0.5 + 0.5 * k) * np.outer(fs[:, k], np.conj(fs[:, k])) for k in range(2))
+                    pw.wmat_real, pw.wmat_imag = np.asfortranarray(W.real.copy()), np.asfortranarray(W.imag.copy())
+                    ww = jq.Working_Arrays_HIP(pw, pcof.size)
+                    jq.traceobjgrad(pcof, pw, ww, False, True)
+                    t1 = time.perf_counter()
+                    jq.traceobjgrad(pcof, pw, ww, False, True)
+                    fw[tag] = {"seconds": time.perf_counter() - t1, "kernel_family": ww.last_timing()["kernel_family"]}
+                    ww.close()
+                out["single_evaluation_full_weights"] = fw
+            except Exception as e:  # noqa: BLE001
+                out["single_evaluation_full_weights"] = {"error": str(e)[:200]}
             try:      # the reference's other integrator (implicit midpoint, the default of its examples) on the same problem
                 import copy
                 pm = copy.copy(params)

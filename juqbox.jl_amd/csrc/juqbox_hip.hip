@@ -2154,8 +2154,8 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     const int cpw = imr_rl ? imr_cols_per_wave(h->N) : 4;   // columns per wave of the row-lane kernels
     // Full leakage weights (jq_update_wmat; low-rank terms in the kernels): row-lane kernels for every batch of an Ntot <= 16 problem,
     // quad-layout kernels with one slab per workgroup (their WLRT instantiations) for the 4 x 4 x n structure, else the cooperative
-    // kernels (every batch size) and, where those do not exist, the slab kernels <1, 0> / <6, 5>; no lane, cooperative-quad,
-    // JQ_BW_T4 slab kernels.
+    // kernels (every batch size) and, where those do not exist, the slab kernels <1, 0> / <6, 5>; no lane or JQ_BW_T4 slab kernels;
+    // cooperative-quad kernels for REAL weight matrices of rank <= 4 (wfull_cq below).
     const bool wfull = h->wrank > 0;
     if (wfull && (imr || h->solver_id != 1))
         return fail(h, JQ_EUNSUPPORTED, "full leakage weights (jq_update_wmat): Stormer-Verlet integrator with the Neumann solver only");
