@@ -241,3 +241,17 @@ def test_committed_pmc_record_belongs_to_this_build():
     if rec["library_version"] != _lib.load().jq_version().decode():
         warnings.warn("profiles/r05_pmc.json was recorded with %s, the library here is %s: bench.py will not quote it -- re-run "
                       "scripts/profile_round.sh and commit the record" % (rec["library_version"], _lib.load().jq_version().decode()))
+
+
+def test_every_environment_variable_the_library_reads_is_documented():
+    """Round-4 review: ~ 30 JQ_* variables select kernels at run time.  They exist for tests, experiments and bisection; each one the
+    library reads must have a row in INTEGRATION.md section 4 (what it does, when it is read)."""
+    import glob
+    import re
+    names = set()
+    for f in glob.glob(os.path.join(ROOT, "juqbox.jl_amd", "csrc", "*.h*")):
+        names |= set(re.findall(r'getenv\("([A-Z0-9_]+)"\)', open(f).read()))
+    assert len(names) >= 30
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = sorted(n for n in names if n not in doc)
+    assert not missing, "environment variables without a row in INTEGRATION.md: %s" % missing

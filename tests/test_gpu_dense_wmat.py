@@ -201,16 +201,19 @@ def test_refusals(jq):
     wm.close()
 
 
-def test_multi_device_handle_and_replanning_carry_the_weights(jq):
+@pytest.mark.parametrize("complex_states", [True, False])
+def test_multi_device_handle_and_replanning_carry_the_weights(jq, complex_states):
+    """(real forbidden states, round 5: the sub-handles' shards run on the cooperative-quad kernels with the low-rank terms)"""
     os.environ["JQ_MULTI_SAME_DEVICE"] = "1"
     try:
-        p, pcof = forbidden_problem("cnot3", 2, 26, True, 3, nsteps=200)
+        p, pcof = forbidden_problem("cnot3", 2, 26, complex_states, 3, nsteps=200)
         wa1 = make_wa(jq, p, pcof.size)
         wa3 = make_wa(jq, p, pcof.size, devices=3)
         rng = np.random.default_rng(9)
         nodes, weights = 1e-3 * rng.standard_normal(11), rng.random(11)
         shift = np.concatenate([[0.0], rng.standard_normal(p.Ntot - 1)])      # (the reference's 0.01 * 10^(j-2) overflows at Ntot = 96)
         jq.eval_f_g_grad(pcof, p, wa1, nodes, weights, True, shift=shift)
+        assert wa1.last_timing()["kernel_family"] == (6 if complex_states else 8)
         ref = (p.last_infidelity, p.last_leak, p.last_infidelity_grad.copy(), p.last_leak_grad.copy())
         jq.eval_f_g_grad(pcof, p, wa3, nodes, weights, True, shift=shift)
         assert abs(p.last_infidelity - ref[0]) <= 1e-13 * abs(ref[0]) and abs(p.last_leak - ref[1]) <= 1e-13 * abs(ref[1])
