@@ -2439,6 +2439,8 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
                              : (wfull && !coop && !rl && !lane) ? ((size_t)JQ_MAX_WRANK + (size_t)2 * h->wrank * h->NP) * 8 : 0;
     const int wlr_lds_fwd = (wlr_bytes && lds_fwd + wlr_bytes <= 163840) ? (int)lds_fwd : -1;
     const int wlr_lds_bwd = (wlr_bytes && lds_bwd + wlr_bytes <= 163840) ? (int)lds_bwd : -1;
+    // (the cooperative-quad kernels have no table in global memory to fall back to: wfull_cq above admitted them only when this fits)
+    if (wfull && cq && (wlr_lds_fwd < 0 || wlr_lds_bwd < 0)) return fail(h, JQ_EHIP, "internal error: no LDS left for the partial dots of the full leakage weights");
     // ... and, quad layout, the per-wave column scalars of the terms behind it (jq_kernels.h WLow::sc).  OFF unless JQ_WLR_SC=1: measured
     // SLOWER than recomputing the dots (round 5, cnot3: 57 -> 70 ms per forbidden state -- an LDS round trip on the critical path of a
     // wave that is alone on its SIMD costs more than the ~ 64 independent instructions of a dot pair; profiles/r05_exp_variants.txt (3))
