@@ -323,34 +323,47 @@ __device__ __forceinline__ double cq_part4(double a, double b, double c, double 
     return p + q;
 }
 
-// Full leakage weights on the cooperative-quad kernels (round 5; REAL weight matrices of rank <= JQ_CQ_WRANK: wmat_imag = 0, i.e. real
-// forbidden states -- W = sum_k lam_k a_k a_k').  A column's dot products a_k . x run over the NT blocks of the quad, i.e. over NT waves:
-// the wave that owns block w leaves the 16 column partials of its rows for all four terms in ONE register (cq_part4 + the two rotate-adds
-// over the 4-row groups; row k of the register = term k) in LDS, wpart[vector][w][64], in front of a barrier the step has anyway;
-// whoever needs the dots adds the NT registers behind it.  A complex W needs vr(t_n) in the MIDDLE of the adjoint step of step n (the
-// term W_i vr(t_n) of hi1, src/evalobjgrad.jl:886-888), which the state chain of the same workgroup delivers at its END: not here
-// (the quad-layout kernels take those).
-#define JQ_CQ_WRANK 4
+// Full leakage weights on the cooperative-quad kernels (round 5): W = sum_k lam_k f_k f_k^H, f_k = a_k + i b_k, in FOUR SLOTS -- a real
+// weight matrix (wmat_imag = 0, real forbidden states) of rank <= 4: slots a_0 .. a_3; a complex one of rank <= 2: a_0, b_0, a_1, b_1
+// (PropArgs::wcplx).  A column's dot products slot . x run over the NT blocks of the quad, i.e. over NT waves: the wave that owns block
+// w leaves the 16 column partials of its rows for all four slots in ONE register (row k of the register = slot k) in LDS,
+// wpart[vector][w][64], in front of a barrier the step has anyway; whoever needs the dots adds the NT registers behind it.
 // Both halves are one v_mfma_f64_4x4x4 in the quad layout (A operand: lane 16 k + 4 b + i holds A_b[i][k]; B operand / result: lane
 // 16 i + 4 b + j holds X_b[i][j]):
-//   part:  A_b[k][i] = a_k[4 b + i]           x  my block of x    ->  D_b[k][j] = sum_i a_k[4 b + i] x[4 b + i][j]; two rotate-adds over b
-//   apply: A_b[i][k] = coef_k[my row 4 b + i]  x  d[k][j] (the sum of the NT partial registers, the same for every b)  ->  (W x)[my row][j]
+//   part:  A_b[k][i] = slot_k[4 b + i]           x  my block of x    ->  D_b[k][j] = sum_i slot_k[4 b + i] x[4 b + i][j]; two rotate-adds over b
+//   apply: A_b[i][k] = coef_k[my row 4 b + i]     x  d[k][j] (the sum of the NT partial registers, the same for every b)  ->  (W x)[my row][j]
+// With (p, q) = (a . x, b . x):  W_r x = sum lam (a p + b q)  (coefficients lam a | lam b),  W_i x = sum lam (b p - a q)  (lam b | -lam a).
+// A complex W needs W_i vr(t_n) in the MIDDLE of the adjoint step of step n (hi1, src/evalobjgrad.jl:886-888), which the state chain of
+// the SAME workgroup delivers at its end: complex weights run on the two- / three-workgroup backward kernels only (the state role is
+// steps ahead there), real ones on the one-workgroup kernel too.
+#define JQ_CQ_WRANK 4
 struct CqW {
-    double akA;       // part(): a_k[16 blk + 4 b + i] on lane 16 i + 4 b + k
+    double akA;       // part(): slot_k[16 blk + 4 b + i] on lane 16 i + 4 b + k
     double* wpart;    // LDS [2][NT][64]
+    // row `row` of slot k (k < nslots) in the table lam[JQ_MAX_WRANK] | a_0 | b_0 | a_1 | b_1 ...
+    static __device__ __forceinline__ int nslots(const PropArgs& a) { return a.wcplx ? 2 * a.wrank : a.wrank; }
+    static __device__ __forceinline__ double slot(const PropArgs& a, int k, int row) { return a.wlr[JQ_MAX_WRANK + (size_t)(a.wcplx ? k : 2 * k) * a.wstride + row]; }
+    static __device__ __forceinline__ double lam(const PropArgs& a, int k) { return a.wlr[a.wcplx ? k >> 1 : k]; }
     __device__ __forceinline__ void init(const PropArgs& a, char* smem, int blk, int lane_)
     {
         const int k = lane_ & 3, row = 16 * blk + 4 * ((lane_ >> 2) & 3) + (lane_ >> 4);
-        akA = k < a.wrank ? a.wlr[JQ_MAX_WRANK + (size_t)(2 * k) * a.wstride + row] : 0.0;
+        akA = k < nslots(a) ? slot(a, k, row) : 0.0;
         wpart = (double*)(smem + a.wlr_lds);
     }
-    // apply()'s A operand: scale lam_k a_k[16 blk + 4 b + i] on lane 16 k + 4 b + i
-    __device__ __forceinline__ double coef(const PropArgs& a, int blk, int lane_, double scale) const
+    // apply()'s A operand for W_r: scale lam slot_k[16 blk + 4 b + i] on lane 16 k + 4 b + i
+    static __device__ __forceinline__ double coef(const PropArgs& a, int blk, int lane_, double scale)
     {
         const int k = lane_ >> 4, row = 16 * blk + 4 * ((lane_ >> 2) & 3) + (lane_ & 3);
-        return k < a.wrank ? scale * a.wlr[k] * a.wlr[JQ_MAX_WRANK + (size_t)(2 * k) * a.wstride + row] : 0.0;
+        return k < nslots(a) ? scale * lam(a, k) * slot(a, k, row) : 0.0;
     }
-    // my block's share of the four dots with x, for every column of the quad: register row k = term k, the same in every 4-row group
+    // ... for W_i (complex only; 0 for a real W): the slots of a term swapped, the second with a minus sign
+    static __device__ __forceinline__ double coef_imag(const PropArgs& a, int blk, int lane_, double scale)
+    {
+        const int k = lane_ >> 4, row = 16 * blk + 4 * ((lane_ >> 2) & 3) + (lane_ & 3);
+        if (!a.wcplx || k >= nslots(a)) return 0.0;
+        return (k & 1) ? -(scale * lam(a, k) * slot(a, k - 1, row)) : scale * lam(a, k) * slot(a, k + 1, row);
+    }
+    // my block's share of the four dots with x, for every column of the quad: register row k = slot k, the same in every 4-row group
     __device__ __forceinline__ double part(double x) const
     {
         return row_ror_add<8>(row_ror_add<4>(__builtin_amdgcn_mfma_f64_4x4x4f64(akA, x, 0.0, 0, 0, 0)));
@@ -362,7 +375,7 @@ struct CqW {
         wpart[((size_t)vec * NT + blk) * 64 + lane_] = part(x);
 #endif
     }
-    // sum_k coef_k[my row] (a_k . x)[my column] -- behind the barrier that follows the put()s
+    // sum_k coef_k[my row] (slot_k . x)[my column] -- behind the barrier that follows the put()s
     template <int NT>
     __device__ __forceinline__ double apply(int vec, int lane_, double cA) const
     {
@@ -510,10 +523,11 @@ __device__ __forceinline__ CqSetup<NT> cq_setup(const PropArgs& a)
 // image.  The same barriers serve both quads: a publication interval of the forward sweep (two waves per SIMD) is bound by latency,
 // not by issue, so twice the work per interval costs ~ 1.5 x -- against 2 x for two rounds of workgroups.  (The backward sweep's
 // twelve waves are issue-bound and hold 150 registers: it stays at one quad per workgroup.)
-// WLR: full (real, rank <= JQ_CQ_WRANK) leakage weights.  The propagating waves do NOTHING for them: staging wave 0, which otherwise only
+// WLR: full leakage weights in four slots (CqW).  The propagating waves do NOTHING for them: staging wave 0, which otherwise only
 // waits, reads the blocks of vi05 and vr(t_n+1) that they publish anyway (exchange image, behind the publication's barrier and before
 // the next one lets the image be overwritten), forms the dots a_k . x of the four columns and accumulates
-// lam_k [(a_k . vr(t_n))^2 + (a_k . vr(t_n+1))^2 + 2 (a_k . vi05)^2]  (penalf2aTrap, penalf2a: src/evalobjgrad.jl:2170-2223).
+// lam_k [(a_k . vr(t_n))^2 + (a_k . vr(t_n+1))^2 + 2 (a_k . vi05)^2] per slot, complex W: - 2 lam_k [(b_k . vi05)(a_k . vr(t_n)) - (a_k . vi05)
+// (b_k . vr(t_n))] on top  (penalf2aTrap, penalf2a, penalf2imag: src/evalobjgrad.jl:700, :716-718, :2170-2233).
 // (First version: partial dots by the propagating waves, 34 instructions per step in lock-step: forward sweep 71 -> 91 ms; behind the
 //  last barrier instead of in front of it 86 ms; this version 71.)
 template <int NT, bool MODD, int NS = 1, bool WLR = false>
@@ -548,15 +562,18 @@ __global__ __launch_bounds__(64 * NT + 128) void k_forward_cq(PropArgs a)
                 c.ring.issue_next();
             }
         } else {
-        double wp0 = 0.0, wlam = 0.0, wrr = 0.0;
+        double wp0 = 0.0, wlam = 0.0, wlamx = 0.0, wrr = 0.0;
         // a_k as the A operand of v_mfma_f64_4x4x4 (lane 16 i + 4 b + k holds a_k[16 w + 4 b + i], jq_kernels.h mm_t4q): the MFMA of block w
         // adds, for every 4-row group b, the products of the group's four rows with the four columns -- D[k][j] on lane 16 k + 4 b + j
         double akA[NT];
         if (wsum) {
-            wlam = ((lane_ >> 4) < a.wrank && ((lane_ >> 2) & 3) == 0) ? a.wlr[lane_ >> 4] : 0.0;
+            const bool mine = (lane_ >> 4) < CqW::nslots(a) && ((lane_ >> 2) & 3) == 0;      // (one lane per slot and column accumulates)
+            wlam = mine ? CqW::lam(a, lane_ >> 4) : 0.0;
+            // complex W: - 2 lam (s p0 - r q0) with (r, s) = (a, b) . vi05, (p0, q0) = (a, b) . vr(t_n): the rows of a term's two slots crossed
+            wlamx = (mine && a.wcplx) ? ((lane_ >> 4) & 1 ? 2.0 : -2.0) * wlam : 0.0;
 #pragma unroll
             for (int w = 0; w < NT; ++w)
-                akA[w] = (lane_ & 3) < a.wrank ? a.wlr[JQ_MAX_WRANK + (size_t)(2 * (lane_ & 3)) * a.wstride + 16 * w + 4 * ((lane_ >> 2) & 3) + (lane_ >> 4)] : 0.0;
+                akA[w] = (lane_ & 3) < CqW::nslots(a) ? CqW::slot(a, lane_ & 3, 16 * w + 4 * ((lane_ >> 2) & 3) + (lane_ >> 4)) : 0.0;
         }
         // The dots with a vector published in channel 0 of parity `par` in three phases, one per barrier interval (the whole of it in one
         // interval made this wave late at the next barrier: forward sweep 71 -> 100 ms): load the NT blocks | NT MFMAs with the a_k
@@ -590,6 +607,7 @@ __global__ __launch_bounds__(64 * NT + 128) void k_forward_cq(PropArgs a)
         auto waccum = [&]() {
             const double p1 = wred();
             wacc += wlam * ((wp0 * wp0 + p1 * p1) + 2.0 * (wrr * wrr));
+            wacc = fma(wlamx, __shfl_xor(wrr, 16) * wp0, wacc);      // (0 for a real W; row k ^ 1 = the other slot of the term)
             wp0 = p1;
         };
         for (int n = 0; n < a.nsteps_chunk; ++n) {
@@ -940,7 +958,7 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
         double mu = st[(size_t)2 * KT * 64 + s.foff], nb = st[(size_t)3 * KT * 64 + s.foff];
         Op Kp05 = c.load(c.ring.template ks<0, 1>()), S05 = c.load(c.ring.template ks<1, 1>());
         const double cfw = (a.forced ? 0.5 * a.h * a.tinv : 0.0) * wdr;      // forcing weight c tinv wd[row]; 0 for step_no_forcing!
-        const double wcf = WLR ? wq.coef(a, wave, lane_, a.forced ? 0.5 * a.h * a.tinv : 0.0) : 0.0;      // full weights: c tinv lam_k a_k[row] as an A operand
+        const double wcf = WLR ? CqW::coef(a, wave, lane_, a.forced ? 0.5 * a.h * a.tinv : 0.0) : 0.0;      // full weights: c tinv lam_k a_k[row] as an A operand
         double Wu = 0.0;      // c tinv (W vr(t_n+1))[row, column]
         const bool slot0 = wave == 0 && ((lane_ >> 2) & 3) == 0;      // the lanes that carry per-column partials between chunks
 #pragma unroll

@@ -27,7 +27,7 @@
 #include "jq_cq_kernels.h"
 
 #define JQ_CQ3_SLOTS 8        // ring depth in time steps
-#define JQ_CQ3_ARRAYS 6       // u (vr before the state step), v05, un, X, nbn (-lambda_i new), Bq (-(li0 + li))
+#define JQ_CQ3_ARRAYS 8       // u (vr before the state step), v05, un, X, nbn (-lambda_i new), Bq (-(li0 + li)); full weights: the blocks' partial dots with v05, un (CqW::part)
 #define JQ_CQ3_HEAD 64        // doubles in front of a quad's ring: [0] steps of role 0, [8] role 1, [16] role 2, [24] error, [32 + r] XCC of role r
 #define JQ_CQ3_SPIN 1000000   // polls (with s_sleep; ~ 1.3 us each: ~ 1.3 s) before a wait is declared dead.  Round 5 tried 150 000 (~ 0.2 s): next to a
                               // process whose launches hold every CU for 0.15 - 0.37 s (the throughput kernels) a role legitimately waits that long for its
@@ -103,7 +103,15 @@ struct Cq3Hand {
 // role 1 runs the adjoint step AND all trace products (the adjoint path of k_backward_cq with the state waves' share of the traces:
 // its publications carry every neighbouring block the trace products need; nothing but u, vi05, vr(t_n) crosses the ring, role 0
 // reuses a slot when role 1 has loaded it).  The trace sums are those of k_backward_cq, term for term: bit-identical results.
-template <int NT, bool MODD, bool ORD, int NR = 3>
+// WLR (round 5): full leakage weights in four slots -- real of rank <= 4 or complex of rank <= 2 (CqW, jq_cq_kernels.h).  Role 0 -- which has the slack -- forms the
+// dots: its block waves leave their partial dots with vi05 and vr(t_n) in LDS with the publications of those vectors (CqW::put), behind
+// the barrier wave 0 (vi05) / wave 1 (vr(t_n)) adds the NT registers and stores the sum as block 0 of array 6 / 7 of the step.  Role 1
+// fetches the two registers with the step's other operands, one step ahead, and applies each with ONE MFMA.  W vr(t_n+1) of a step is
+// W vr(t_n) of the step before; for the first step of a chunk role 0 leaves the dots of the state the chunk starts from where
+// "step -1" would have left them.  The same operations in the same order as the one-workgroup kernel's (k_backward_cq<.., WLR>):
+// bit-identical results.  (First version: the partial registers themselves through the ring, 12 more loads per step in the adjoint
+// waves: backward sweep 96 ms instead of 81.)
+template <int NT, bool MODD, bool ORD, int NR = 3, bool WLR = false>
 __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
 {
     static_assert(NR == 3 || NR == 2, "workgroups per column quad");
@@ -271,6 +279,7 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
     if (s.chain) {      // staging waves
         c.ring.wave = wave, c.ring.nwaves = 2;
         const int nb = 4 + 2 * (a.m > 0 ? a.m : 0);
+        if (WLR && role == 0) __builtin_amdgcn_s_barrier();      // (the block waves' partial dots with the state the chunk starts from)
         for (int n = 0; n < nst; ++n) {
             for (int k = 0; k < nb; ++k) __builtin_amdgcn_s_barrier();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (my pieces of the time points 2n+3, 2n+4)
@@ -294,6 +303,21 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
         // ---- state re-integration (src/evalobjgrad.jl:879): the state path of k_backward_cq; u, v05, un of step n -> ring
         double u = st[s.foff], v = st[(size_t)KT * 64 + s.foff];
         Op Kp05 = c.load(c.ring.template ks<0, 1>()), S0 = c.load(c.ring.template ks<1, 0>());
+        CqW wq;
+        // the sum of the NT partial registers of vector `vec` (behind the barrier that follows the put()s) -> block 0 of array `arr` of step n
+        auto wsum = [&](int n, int arr, int vec) {
+            const double* r = wq.wpart + (size_t)vec * NT * 64 + lane_;
+            double d = r[0];
+#pragma unroll
+            for (int w = 1; w < NT; ++w) d += r[w * 64];
+            hd.store(n, arr, 0, d);
+        };
+        if constexpr (WLR) {
+            wq.init(a, smem, wave, lane_);
+            wq.template put<NT>(0, wave, lane_, u);      // (vr at the start of the chunk: "vr(t_n) of step -1"; its slot is free, nothing is in flight)
+            c.sync();
+            if (wave == (NT > 1 ? 1 : 0)) wsum(-1, 7, 0);
+        }
         auto step = [&](auto P0c, int n) {
             constexpr int P0 = decltype(P0c)::value;
             // (a slot is reused when the trace workgroup has read it; NR = 2: when the adjoint workgroup has -- it publishes n once the
@@ -331,6 +355,7 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
             hd.store(n, 1, wave, v05);
             // x = v05: vN = v05 + c S05 v05 ; un = u + c (S0 u - K0 v05) ; A = -c K1 v05
             c.template post<P0 ^ M, 0>(v05);
+            if constexpr (WLR) wq.template put<NT>(1, wave, lane_, v05);
             const Op S1 = c.load(c.ring.template ks<1, 2>());
             {
                 const Sh sx = c.sh(v05);
@@ -347,6 +372,8 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
                 un = c.nbr(un, Kn0, nn);
                 A = c.nbr(A, Kn1, nn);
             }
+            if constexpr (WLR)
+                if (wave == 0) wsum(n, 6, 1);
             // x = un: A = c (S1 un - K1 v05)
             c.template post<P0 ^ M ^ 1, 0>(un);
             A = c.own(A, S1, c.sh(un));
@@ -356,10 +383,13 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
             hd.store(n, 2, wave, un);
             // x = un: v(t_n) = v05 + c (K05 un + S05 v05)
             c.template post<P0, 0>(un);
+            if constexpr (WLR) wq.template put<NT>(0, wave, lane_, un);
             v = c.own(vN, Kp05, c.sh(un));
             if (a.use_shift) v = fma(cw, un, v);
             c.sync();      // (the step's stores are published behind the second barrier of the next step: their latency is off the critical path)
             v = c.nbr(v, Kp05, c.template nbs<P0, 0>());
+            if constexpr (WLR)
+                if (wave == (NT > 1 ? 1 : 0)) wsum(n, 7, 0);
             // (the time points of the next step have landed; those of this step are dead)
             c.ring.advance();
             Kp05 = c.load(c.ring.template ks<0, 1>());
@@ -385,6 +415,17 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
     Op Kp05 = c.load(c.ring.template ks<0, 1>()), S05 = c.load(c.ring.template ks<1, 1>());
     const double cfw = (a.forced ? 0.5 * a.h * a.tinv : 0.0) * wdr;      // forcing weight c tinv wd[row]; 0 for step_no_forcing!
     double hu = 0.0, hv = 0.0, hn = 0.0;      // u, v05, un of the step (fetched one step ahead)
+    // full weights: the blocks' partial dots with v05, un of the step (fetched with them); c tinv W vr(t_n+1), W vi05, W vr(t_n) for my row
+    // (W_i: complex weight matrices -- this kernel takes them, the state role being ahead; its coefficients are 0 for a real W)
+    double pv = 0.0, pn = 0.0, Wu = 0.0, Wv = 0.0, Wn = 0.0, WvI = 0.0, WnI = 0.0, wcf = 0.0, wcfI = 0.0;
+    if constexpr (WLR) {
+        wcf = CqW::coef(a, wave, lane_, a.forced ? 0.5 * a.h * a.tinv : 0.0);
+        wcfI = CqW::coef_imag(a, wave, lane_, a.forced ? 0.5 * a.h * a.tinv : 0.0);
+    }
+    auto wfetch = [&](int n) {
+        if constexpr (WLR) pv = hd.load(n, 6, 0), pn = hd.load(n, 7, 0);
+    };
+    auto wapply = [&](double cA, double d) { return __builtin_amdgcn_mfma_f64_4x4x4f64(cA, d, 0.0, 0, 0, 0); };      // (the MFMA of CqW::apply)
     // NR = 2: the trace scalars of k_backward_cq (its adjoint waves' t1, t3, t4 and its state waves' t2, t5), handed over through red
     const int ntr = Nc * JQ_NTR, ngroups = Nc + (Nc + 1) / 2;
     double* red = scratch;                                      // [ngroups][NT][64]
@@ -447,16 +488,29 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
         }
         if constexpr (NR == 2)
             if (n > 0) finish_traces(n - 1);      // (behind the step's first barrier: everybody's hand-off of step n - 1 is in red)
-        if (n == 0) hu = hd.load(0, 0, wave), hv = hd.load(0, 1, wave), hn = hd.load(0, 2, wave);      // (first step of the chunk: latency exposed once)
+        if (n == 0) {      // (first step of the chunk: latency exposed once)
+            if constexpr (WLR) {
+                pn = hd.load(-1, 7, 0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                Wu = wapply(wcf, pn);
+            }
+            hu = hd.load(0, 0, wave), hv = hd.load(0, 1, wave), hn = hd.load(0, 2, wave);
+            wfetch(0);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (hu, hv, hn of this step have landed; my stores of step n - 1 are acknowledged)
         const double u = hu, v05 = hv, un = hn;      // vr before the state step (:862), vi05, vr after it
+        if constexpr (WLR) Wv = wapply(wcf, pv), Wn = wapply(wcf, pn), WvI = wapply(wcfI, pv), WnI = wapply(wcfI, pn);
         // x = mu: L = c (S0 mu - K05 li + hr0) ; X = mu + sum_j S0^j L
         c.template post<P0 ^ 1, 1>(mu);
         L = c.own(L, S0, c.sh(mu));
         L = fma(cfw, u, L);
+        if constexpr (WLR) L += Wu;
         c.sync();
         if (wave == 0 && lane_ == 0) hd.publish(1, (unsigned long long)n);      // (everybody's stores of the steps < n are in the L2)
-        if (n + 1 < nst) hu = hd.load(n + 1, 0, wave), hv = hd.load(n + 1, 1, wave), hn = hd.load(n + 1, 2, wave);
+        if (n + 1 < nst) {
+            hu = hd.load(n + 1, 0, wave), hv = hd.load(n + 1, 1, wave), hn = hd.load(n + 1, 2, wave);
+            wfetch(n + 1);
+        }
         L = c.nbr(L, S0, c.template nbs<P0 ^ 1, 1>());
         Op Kn0, Kn1, S1;
         const double X = c.template horner<P0, 1, MODD>(mu + L, L, S0, a.m, [&] {
@@ -495,9 +549,11 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
         }
         // Lk = -c l2 = -c (K0 X + S05 li + hi0) ; Q = -c (S05 (li + c l2) + K1 X + hi1)
         {
-            const double Pn = fma(-cfw, v05, Tn);
+            double Pn = fma(-cfw, v05, Tn);
+            if constexpr (WLR) Pn -= Wv;
             Lk += Pn;
             Q += Pn;
+            if constexpr (WLR) Q += WnI;      // - c (hi1 - hi0) = + c W_i vr(t_n) / T
         }
         // x = Lk: Q += c S05 Lk ; nb_new = nb + Lk + sum_j S05^j Q
         c.template post<P0 ^ M ^ 1, 1>(Lk);
@@ -523,6 +579,10 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
             const Nb nn = c.template nbs<P0, 1>();
             G = c.nbr(G, Kp05, nn);
             G = fma(cfw, un, G);
+            if constexpr (WLR) {
+                G += Wn + WvI;      // + c hr1 = c (W_r vr(t_n) + W_i vi05) / T
+                Wu = Wn;            // (c W_r vr(t_n) / T: hr0 of the next step)
+            }
             // (the time points of the next step have landed)
             c.ring.advance();
             Kp05 = c.load(c.ring.template ks<0, 1>());

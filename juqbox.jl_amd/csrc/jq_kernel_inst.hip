@@ -38,6 +38,14 @@ template __global__ void k_backward_cq3<JQ_NT, false, false, 2>(PropArgs);     /
 template __global__ void k_backward_cq3<JQ_NT, false, true, 2>(PropArgs);
 template __global__ void k_backward_cq3<JQ_NT, true, false, 2>(PropArgs);
 template __global__ void k_backward_cq3<JQ_NT, true, true, 2>(PropArgs);
+template __global__ void k_backward_cq3<JQ_NT, false, false, 3, true>(PropArgs);     // (... with full leakage weights, real, rank <= 4)
+template __global__ void k_backward_cq3<JQ_NT, false, true, 3, true>(PropArgs);
+template __global__ void k_backward_cq3<JQ_NT, true, false, 3, true>(PropArgs);
+template __global__ void k_backward_cq3<JQ_NT, true, true, 3, true>(PropArgs);
+template __global__ void k_backward_cq3<JQ_NT, false, false, 2, true>(PropArgs);
+template __global__ void k_backward_cq3<JQ_NT, false, true, 2, true>(PropArgs);
+template __global__ void k_backward_cq3<JQ_NT, true, false, 2, true>(PropArgs);
+template __global__ void k_backward_cq3<JQ_NT, true, true, 2, true>(PropArgs);
 #elif JQ_VARIANT == 12  // quad layout, backward sweep split over two waves per column quad (mid-size ensembles)
 #include "jq_quad_split_kernels.h"
 template __global__ void k_backward_qsplit<JQ_NT, false, 4>(PropArgs);      // (four quads = one slab per workgroup: two waves per SIMD)

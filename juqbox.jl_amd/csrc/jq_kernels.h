@@ -1007,6 +1007,7 @@ struct PropArgs {
     int wlr_sc_lds;         // quad layout: byte offset of the per-wave column scalars of the terms ([wave][JQ_MAX_WRANK][6][4] doubles), or -1
     int jac_wg_lds;         // JAC slab kernels, N > 16 with one workgroup per sample (its <= 4 parts = waves): byte offset of the residual
                             // exchange [2][JQ_WAVES] doubles -- the stopping test then sums the parts like the reference; -1: per part
+    int wcplx;              // cooperative-quad kernels (CqW): 0 = real weight matrix, the four slots are a_0 .. a_3; 1 = complex, rank <= 2: a_0, b_0, a_1, b_1
 };
 #ifndef JQ_MAX_WRANK
 #define JQ_MAX_WRANK 16       // largest rank of a full weight matrix the kernels take (include/juqbox_hip.h)

@@ -1562,7 +1562,7 @@ JQ_DECLQ(1) JQ_DECLQ(2) JQ_DECLQ(3) JQ_DECLQ(4) JQ_DECLQ(5) JQ_DECLQ(6) JQ_DECLQ
 #undef JQ_DECLQ
 template <int NT, bool MODD, int NS, bool WLR = false> __global__ void k_forward_cq(PropArgs);    // jq_cq_kernels.h (own translation units); NS: column quads per workgroup; WLR: full (real, low-rank) leakage weights
 template <int NT, bool MODD, bool ORD, bool WLR = false> __global__ void k_backward_cq(PropArgs);
-template <int NT, bool MODD, bool ORD, int NR = 3> __global__ void k_backward_cq3(PropArgs);    // jq_cq_split_kernels.h: three (NR = 2: two) workgroups per column quad
+template <int NT, bool MODD, bool ORD, int NR = 3, bool WLR = false> __global__ void k_backward_cq3(PropArgs);    // jq_cq_split_kernels.h: three (NR = 2: two) workgroups per column quad
 #define JQ_DECLCQ(nt)                                                      \
     extern template __global__ void k_forward_cq<nt, false, 1>(PropArgs);  \
     extern template __global__ void k_forward_cq<nt, false, 2>(PropArgs);  \
@@ -1578,6 +1578,14 @@ template <int NT, bool MODD, bool ORD, int NR = 3> __global__ void k_backward_cq
     extern template __global__ void k_backward_cq<nt, false, true, true>(PropArgs);      \
     extern template __global__ void k_backward_cq<nt, true, false, true>(PropArgs);      \
     extern template __global__ void k_backward_cq<nt, true, true, true>(PropArgs);       \
+    extern template __global__ void k_backward_cq3<nt, false, false, 3, true>(PropArgs);   \
+    extern template __global__ void k_backward_cq3<nt, false, true, 3, true>(PropArgs);    \
+    extern template __global__ void k_backward_cq3<nt, true, false, 3, true>(PropArgs);    \
+    extern template __global__ void k_backward_cq3<nt, true, true, 3, true>(PropArgs);     \
+    extern template __global__ void k_backward_cq3<nt, false, false, 2, true>(PropArgs);   \
+    extern template __global__ void k_backward_cq3<nt, false, true, 2, true>(PropArgs);    \
+    extern template __global__ void k_backward_cq3<nt, true, false, 2, true>(PropArgs);    \
+    extern template __global__ void k_backward_cq3<nt, true, true, 2, true>(PropArgs);     \
     extern template __global__ void k_backward_cq3<nt, false, false>(PropArgs);   \
     extern template __global__ void k_backward_cq3<nt, false, true>(PropArgs);    \
     extern template __global__ void k_backward_cq3<nt, true, false>(PropArgs);    \
@@ -1591,19 +1599,28 @@ JQ_DECLCQ(1) JQ_DECLCQ(2) JQ_DECLCQ(3) JQ_DECLCQ(4) JQ_DECLCQ(5) JQ_DECLCQ(6) JQ
 // (instantiated for even and odd numbers of Neumann terms: the parities of the LDS exchange are compile-time constants)
 // fwd2: the forward kernel with two column quads per workgroup (grid = 2 * nslabs); bwd3: the backward sweep on three workgroups per
 // quad (k_backward_cq3)
+// control q acts on subsystem q only (the usual Juqbox set-up: Hsym_ops = [a + a', b + b', c + c']): its trace products need one part of
+// the product each
+static bool cq_ord(const jq_handle* h)
+{
+    bool ord = h->Nc <= 3 && !getenv("JQ_CQ_GENERIC_TRACES");      // (more than JQ_MAXNC controls: generic traces per control group)
+    for (int q = 0; q < h->Nc && ord; ++q) ord = (h->bw_trace[q] == (1 << q));
+    return ord;
+}
 static int select_cq_kernels(jq_handle* h, bool fwd2, int bwd_nr, bool wlr, prop_kernel_t* fwd, prop_kernel_t* bwd)      // bwd_nr: workgroups per quad in the backward sweep (0 / 1: one); wlr: full (real, low-rank) leakage weights
 {
     const bool bwd3 = bwd_nr == 3, bwd2 = bwd_nr == 2;
     const bool modd = (h->m > 0 ? h->m : 0) & 1;
-    // control q acts on subsystem q only (the usual Juqbox set-up: Hsym_ops = [a + a', b + b', c + c']): its trace products need
-    // one part of the product each
-    bool ord = h->Nc <= 3 && !getenv("JQ_CQ_GENERIC_TRACES");      // (more than JQ_MAXNC controls: generic traces per control group)
-    for (int q = 0; q < h->Nc && ord; ++q) ord = (h->bw_trace[q] == (1 << q));
+    const bool ord = cq_ord(h);
 #define JQ_PICKCQ(nt)                                                              \
     if (h->NT == nt && wlr) {                                                      \
         *fwd = modd ? k_forward_cq<nt, true, 1, true> : k_forward_cq<nt, false, 1, true>;                        \
-        *bwd = modd ? (ord ? k_backward_cq<nt, true, true, true> : k_backward_cq<nt, true, false, true>)         \
-                    : (ord ? k_backward_cq<nt, false, true, true> : k_backward_cq<nt, false, false, true>);      \
+        *bwd = bwd3 ? (modd ? (ord ? k_backward_cq3<nt, true, true, 3, true> : k_backward_cq3<nt, true, false, 3, true>)          \
+                            : (ord ? k_backward_cq3<nt, false, true, 3, true> : k_backward_cq3<nt, false, false, 3, true>))       \
+             : bwd2 ? (modd ? (ord ? k_backward_cq3<nt, true, true, 2, true> : k_backward_cq3<nt, true, false, 2, true>)          \
+                            : (ord ? k_backward_cq3<nt, false, true, 2, true> : k_backward_cq3<nt, false, false, 2, true>))       \
+                    : modd ? (ord ? k_backward_cq<nt, true, true, true> : k_backward_cq<nt, true, false, true>)         \
+                           : (ord ? k_backward_cq<nt, false, true, true> : k_backward_cq<nt, false, false, true>);      \
         return JQ_OK;                                                              \
     }                                                                              \
     if (h->NT == nt) {                                                             \
@@ -2201,14 +2218,15 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     if (imr_quad) spw = 1;
     // latency regime of the JQ_BW_T4 structure: one workgroup of NT waves per column quad (jq_cq_kernels.h)
     const long long nquads_used = (ncols_used + 3) / 4;
-    // (full weights, round 5: REAL weight matrices of rank <= 4 on the one-workgroup kernels with one quad per workgroup, LDS permitting --
-    //  jq_cq_kernels.h CqW; JQ_CQ_W=0: the quad-layout kernels as before)
+    // (full weights, round 5: four slots -- real weight matrices of rank <= 4, complex ones of rank <= 2 -- on the cooperative-quad kernels with
+    //  one quad per workgroup, LDS permitting (jq_cq_kernels.h CqW); a complex W only with the backward sweep on two / three workgroups
+    //  per quad, see below; JQ_CQ_W=0: the quad-layout kernels as before)
     const char* e_cqw = getenv("JQ_CQ_W");
-    const bool wfull_cq = wfull && h->wlr_real && h->wrank <= 4 && h->NT <= 7 && !(e_cqw && atoi(e_cqw) == 0) && (ncols_used + 3) / 4 <= h->num_cu &&
+    const bool wfull_cq = wfull && (h->wlr_real ? h->wrank <= 4 : h->wrank <= 2) && h->NT <= 7 && !(e_cqw && atoi(e_cqw) == 0) && (ncols_used + 3) / 4 <= h->num_cu &&
                           (size_t)(2 * JQ_WIN_TPS + 2 * h->NcK) * h->mat_elems * 8 + (size_t)32 * h->NT * 8 + (size_t)6 * (h->NT + 2) * 64 * 8 +
                                   (size_t)std::max(2, h->NcK + (h->NcK + 1) / 2) * h->NT * 64 * 8 + (size_t)2 * h->NT * 64 * 8 <= 163840;
-    const bool cq = !imr && !lane && !rl && (!wfull || wfull_cq) && h->solver_id == 1 && h->cq_max_quads > 0 && nquads_used <= h->cq_max_quads &&
-                    !getenv("JQ_QUAD8");      // (JQ_QUAD8 asks for a quad-layout variant explicitly)
+    bool cq = !imr && !lane && !rl && (!wfull || wfull_cq) && h->solver_id == 1 && h->cq_max_quads > 0 && nquads_used <= h->cq_max_quads &&
+              !getenv("JQ_QUAD8");      // (JQ_QUAD8 asks for a quad-layout variant explicitly)
     const int qps = h->parts > 1 ? 4 : (h->sps * h->N + 3) / 4;      // column quads of a full slab
     // ... and of the implicit-midpoint integrator (jq_cq_imr_kernels.h): N = 4, one workgroup of NT waves per evaluation
     const char* e_icq = getenv("JQ_IMR_CQ");
@@ -2237,7 +2255,6 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
         const char* why = nullptr;
         cq_nr = 3 * nq_pad <= h->num_cu ? 3 : (cq && 2 * nq_pad <= h->num_cu && !(e_c3 && atoi(e_c3) == 3)) ? 2 : 0;
         if (e_c3 && atoi(e_c3) == 0) why = "not taken: JQ_CQ3=0";
-        else if (wfull) why = "not taken: full leakage weights (the one-workgroup kernel carries the low-rank terms)";
         else if (cq_nr == 0) why = "not taken: two / three workgroups per column quad exceed the compute units";
         else if (h->cq3_off) why = "not taken: switched off after repeated faults (dead waits between the workgroups of a quad)";
         else if (h->cq3_skip > 0) why = "not taken: cooling down after a fault";
@@ -2249,7 +2266,10 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
         if (h->cq3_skip > 0) --h->cq3_skip;
         h->cq3_last = cq3 ? (cq_nr == 3 ? "taken: three workgroups per column quad, device held exclusively" : "taken: two workgroups per column quad, device held exclusively") : why;
     }
-    const size_t cq3_quad = 64 + (size_t)8 * 6 * h->NT * 64;      // doubles per quad: JQ_CQ3_HEAD + JQ_CQ3_SLOTS * JQ_CQ3_ARRAYS * NT * 64
+    // A complex W needs W_i vr(t_n) in the middle of the adjoint step: only the split kernels, whose state role is steps ahead, have it.
+    // Without them (more than 128 samples, the gate taken, cooling down, JQ_CQ3=0 ...) the evaluation runs on the quad-layout kernels.
+    if (cq && wfull && !h->wlr_real && adjoint && !cq3) cq = false;
+    const size_t cq3_quad = 64 + (size_t)8 * 8 * h->NT * 64;      // doubles per quad: JQ_CQ3_HEAD + JQ_CQ3_SLOTS * JQ_CQ3_ARRAYS * NT * 64
     const size_t cq3_need = 64 + (size_t)nq_pad * cq3_quad;
     if (cq3) {
         const int rc0 = dev_grow(h, &h->d_cq3, &h->cap_cq3, cq3_need);
@@ -2411,7 +2431,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     a.tabs = h->d_tabs; a.stride = stride; a.pieces = (int)(stride * 8 / 1024); a.nslots = h->nslots; a.m = h->m;
     a.nslabs = rl ? (int)nwaves_rl : lane ? (int)ncols : nslabs; a.Ncoupled = ctrl_gstart(h->Nc, 1) /* first control group */; a.Ntot = h->Ntot; a.N = h->N; a.use_shift = use_shift ? 1 : 0;
     a.tinv = 1.0 / h->T; a.state_stride = h->state_stride; a.parts = h->parts; a.nsamples = nsamples; a.sps = h->sps; a.qps = qps;
-    a.wlr = h->d_wlr; a.wrank = h->wrank; a.wstride = h->NP; a.wlr_lds = -1; a.wlr_sc_lds = -1; a.jac_wg_lds = -1;
+    a.wlr = h->d_wlr; a.wrank = h->wrank; a.wstride = h->NP; a.wlr_lds = -1; a.wlr_sc_lds = -1; a.jac_wg_lds = -1; a.wcplx = (h->wrank > 0 && !h->wlr_real) ? 1 : 0;
     // JACOBI_SOLVER: the kernels iterate on c-scaled right-hand sides (A = c rhs, c = h / 2: DESIGN.md section 3), so their
     // residual norm is |c| times the reference's ||X_j - X_{j-1}|| (src/linear_solvers.jl:121): the threshold is scaled alike
     a.jacobi_tol2 = (h->solver_id == 2) ? (h->solver_tol * 0.5 * dt) * (h->solver_tol * 0.5 * dt) : 0.0;
@@ -2603,7 +2623,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
                 if (qsplit)
                     hipLaunchKernelGGL(kbwd, dim3((unsigned)qs_blocks), dim3(128 * qs_qw), lds_bwd, s, a);
                 else if (cq3)
-                    hipLaunchKernelGGL(kbwd, dim3((unsigned)(cq_nr * nq_pad)), dim3(nthreads + 128), lds_bwd, s, a);      // (three / two workgroups per quad: NT block waves + two staging waves each)
+                    hipLaunchKernelGGL(kbwd, dim3((unsigned)(cq_nr * nq_pad)), dim3(nthreads + 128), lds_bwd + (wlr_lds_bwd >= 0 ? wlr_bytes : 0), s, a);      // (three / two workgroups per quad: NT block waves + two staging waves each)
                 else
                 hipLaunchKernelGGL(kbwd, dim3(nblocks), dim3((cq || rl_split) ? 2 * nthreads : imr_cq2 ? 2 * (nthreads + 128) : imr_cq ? nthreads + 128 : nthreads), lds_bwd + (wlr_lds_bwd >= 0 ? wlr_bytes : 0) + (wsc_lds_bwd >= 0 ? wsc_bytes : 0) + jac_bytes, s, a);      // (cooperative quad: state and adjoint chain on separate waves)
                 HIPCHK(h, hipEventRecord(h->ev[evi++], s));

@@ -17,7 +17,7 @@ from test_gpu_random import random_problem
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-10
-ENVS = ("JQ_CHUNK_STEPS", "JQ_COOP_MAX", "JQ_LANE", "JQ_ROWLANE_MAX", "JQ_T4", "JQ_OD", "JQ_QUAD", "JQ_CQ", "JQ_EMBED", "JQ_FORCE_DENSE")
+ENVS = ("JQ_CHUNK_STEPS", "JQ_COOP_MAX", "JQ_LANE", "JQ_ROWLANE_MAX", "JQ_T4", "JQ_OD", "JQ_QUAD", "JQ_CQ", "JQ_EMBED", "JQ_FORCE_DENSE")      # (read at jq_create)
 
 
 def make_wa(jq, p, ncoef, env=None, **kw):
@@ -91,7 +91,8 @@ def test_cnot2(jq, oft, env, family):
 
 
 @pytest.mark.parametrize("oft,nforb,env,family,band", [
-    (1, 2, {}, 6, 7), (3, 4, {}, 6, 7),                                   # quad layout, WLRT instantiation
+    (1, 2, {"JQ_CQ_W": "0"}, 6, 7), (3, 4, {}, 6, 7),                     # quad layout, WLRT instantiation (complex rank 4: more than four slots)
+    (1, 2, {}, 8, 7), (2, 2, {}, 8, 7),                                   # round 5: complex rank <= 2 on the cooperative-quad kernels (split backward sweep)
     (1, 2, {"JQ_T4": "0"}, 1, 9), (2, 2, {"JQ_T4": "0", "JQ_COOP_MAX": "0"}, 1, 9),      # JQ_BW_OD: cooperative kernels, whatever JQ_COOP_MAX says
     (1, 3, {"JQ_T4": "0", "JQ_OD": "0"}, 1, 1),                           # block-tridiagonal band tiles
     (3, 2, {"JQ_FORCE_DENSE": "1", "JQ_EMBED": "0"}, 0, 5),               # dense 96 x 96 tiles: no cooperative kernels, slab <6, 5>
@@ -99,7 +100,12 @@ def test_cnot2(jq, oft, env, family):
 def test_cnot3_short(jq, oft, nforb, env, family, band):
     p, pcof = forbidden_problem("cnot3", nforb, 23, True, oft, nsteps=300)
     wa = make_wa(jq, p, pcof.size, env)
-    compare(jq, p, pcof, wa, family=family, ensembles=(3, 9), rng=np.random.default_rng(3))
+    if "JQ_CQ_W" in env:      # (read per evaluation)
+        os.environ["JQ_CQ_W"] = env["JQ_CQ_W"]
+    try:
+        compare(jq, p, pcof, wa, family=family, ensembles=(3, 9), rng=np.random.default_rng(3))
+    finally:
+        os.environ.pop("JQ_CQ_W", None)
     assert wa.last_timing()["kernel_band"] == band
     wa.close()
 
@@ -213,7 +219,7 @@ def test_multi_device_handle_and_replanning_carry_the_weights(jq, complex_states
         nodes, weights = 1e-3 * rng.standard_normal(11), rng.random(11)
         shift = np.concatenate([[0.0], rng.standard_normal(p.Ntot - 1)])      # (the reference's 0.01 * 10^(j-2) overflows at Ntot = 96)
         jq.eval_f_g_grad(pcof, p, wa1, nodes, weights, True, shift=shift)
-        assert wa1.last_timing()["kernel_family"] == (6 if complex_states else 8)
+        assert wa1.last_timing()["kernel_family"] == 8      # (round 5: four slots on the cooperative-quad kernels, real or complex)
         ref = (p.last_infidelity, p.last_leak, p.last_infidelity_grad.copy(), p.last_leak_grad.copy())
         jq.eval_f_g_grad(pcof, p, wa3, nodes, weights, True, shift=shift)
         assert abs(p.last_infidelity - ref[0]) <= 1e-13 * abs(ref[0]) and abs(p.last_leak - ref[1]) <= 1e-13 * abs(ref[1])

@@ -383,16 +383,17 @@ def test_implicit_midpoint_ensembles_never_take_the_split_kernel(jq):
 
 # ---- (6) full leakage weights on the latency path (real forbidden states, rank <= 4) ------------------------------------------------------
 
-def _real_forbidden(jq, kind, nforb, seed, oft):
-    """`kind` with `nforb` random REAL forbidden states (weights 0.5 .. 1.5): wmat_imag = 0 (src/evalobjgrad.jl:214-232)"""
+def _real_forbidden(jq, kind, nforb, seed, oft, cplx=False):
+    """`kind` with `nforb` random forbidden states (weights 0.5 .. 1.5), REAL -- wmat_imag = 0 -- unless cplx (src/evalobjgrad.jl:214-232)"""
     params, pcof = _problem(jq, kind)
     rng = np.random.default_rng(seed)
-    fs = rng.standard_normal((params.Ntot, nforb))
+    fs = rng.standard_normal((params.Ntot, nforb)) + (1j * rng.standard_normal((params.Ntot, nforb)) if cplx else 0)
     fs = fs / np.linalg.norm(fs, axis=0)
     fw = 0.5 + rng.random(nforb)
     params.forb_states, params.forb_weights = fs.astype(complex), fw
-    params.wmat_real = np.asfortranarray(sum(fw[k] * np.outer(fs[:, k], fs[:, k]) for k in range(nforb)))
-    params.wmat_imag = np.zeros_like(params.wmat_real)
+    W = sum(fw[k] * np.outer(fs[:, k], np.conj(fs[:, k])) for k in range(nforb))
+    params.wmat_real = np.asfortranarray(np.real(W).copy())
+    params.wmat_imag = np.asfortranarray(np.imag(W).copy()) if cplx else np.zeros_like(params.wmat_real)
     params.objFuncType = oft
     return params, pcof
 
@@ -416,8 +417,7 @@ def test_real_full_weights_run_on_the_cooperative_quad_kernels(jq, kind, nforb, 
         wa.close()
         return t, why
     t, why = _with_env(env, run)
-    assert t["kernel_family"] == 8 and t["reserved"] == 0, t
-    assert "full leakage weights" in why["last_decision"], why
+    assert t["kernel_family"] == 8 and t["reserved"] == 3, (t, why)      # (the backward sweep on three workgroups per quad, as with Diagonal weights)
     rng = np.random.default_rng(5)
     nodes, weights = 0.02 * rng.standard_normal(21), rng.random(21)
     shift = 0.01 * np.arange(params.Ntot)
@@ -427,21 +427,91 @@ def test_real_full_weights_run_on_the_cooperative_quad_kernels(jq, kind, nforb, 
     assert a[4]["kernel_family"] == 8 and b[4]["kernel_family"] == 6, (a[4], b[4])
     assert abs(a[0] - b[0]) <= 1e-12 * abs(b[0]) and abs(a[1] - b[1]) <= 1e-12 * abs(b[1]) and rel(a[2], b[2]) <= 1e-11 and rel(a[3], b[3]) <= 1e-11
     assert a[0] == c[0] and a[1] == c[1] and np.array_equal(a[2], c[2]) and np.array_equal(a[3], c[3])      # (run to run: bit-wise)
+    # the one-workgroup backward kernel performs the same operations in the same order
+    d = _eval(jq, params, pcof, nodes, weights, shift, dict(env, JQ_CQ3="0"))
+    assert a[4]["reserved"] == 3 and d[4]["reserved"] == 0, (a[4], d[4])
+    assert a[0] == d[0] and a[1] == d[1] and np.array_equal(a[2], d[2]) and np.array_equal(a[3], d[3])
 
 
-def test_complex_or_higher_rank_full_weights_stay_on_the_quad_layout_kernels(jq):
-    """The cooperative-quad kernels take real weight matrices of rank <= 4 only (a complex W needs vr(t_n) in the middle of the adjoint
-    step, which the state chain of the same workgroup delivers at its end): complex forbidden states and rank 5 run where they ran,
-    and a switch of the weights on a live handle re-routes."""
+@pytest.mark.parametrize("kind,nsamples,variant", [("cnot3", 100, 2), ("cnot3", 128, 2), ("t4x3", 100, 2), ("t4x5", 70, 3)])
+def test_real_full_weights_on_two_workgroups_per_quad(jq, kind, nsamples, variant):
+    """81 .. 128 samples with full (real) weights: two workgroups per quad (three for the 70 samples of the four-control problem),
+    single-subsystem and generic trace products; bit-identical to the one-workgroup kernel, and the oracle's numbers on three one-hot
+    samples."""
+    from oracle.oracle import Oracle
+    params, pcof = _real_forbidden(jq, kind, 3, 61, 1)
+    rng = np.random.default_rng(nsamples)
+    nodes, weights = 0.02 * rng.standard_normal(nsamples), np.zeros(nsamples)
+    hot = [0, nsamples // 2, nsamples - 1]
+    weights[hot] = [0.3, 0.5, 0.2]
+    shift = 0.01 * np.arange(params.Ntot)
+    a = _eval(jq, params, pcof, nodes, weights, shift, {})
+    b = _eval(jq, params, pcof, nodes, weights, shift, {"JQ_CQ3": "0"})
+    assert (a[4]["kernel_family"], a[4]["reserved"]) == (8, variant) and (b[4]["kernel_family"], b[4]["reserved"]) == (8, 0), (a[4], b[4])
+    assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2])
+    inf, leak, grad = 0.0, 0.0, np.zeros(pcof.size)
+    H0 = params.Hconst.copy()
+    for i in hot:
+        params.Hconst = H0 + np.diag(nodes[i] * shift)
+        r = Oracle(params, use_sparse=False).traceobjgrad(pcof)
+        inf += weights[i] * r["primaryobjf"]
+        leak += weights[i] * r["secondaryobjf"]
+        grad += weights[i] * r["infidelgrad"]
+    params.Hconst = H0
+    assert abs(a[0] - inf) <= TOL * abs(inf) and abs(a[1] - leak) <= TOL * abs(leak) and rel(a[2], grad) <= TOL
+
+
+@pytest.mark.parametrize("kind,nforb,oft,chunk,nsamples", [("cnot3", 1, 1, 0, 9), ("cnot3", 2, 3, 250, 100), ("t4x3", 2, 2, 20, 21), ("t4x5", 1, 3, 1, 90),
+                                                            ("t4x2", 2, 1, 0, 5)])
+def test_complex_full_weights_run_on_the_split_kernels(jq, kind, nforb, oft, chunk, nsamples):
+    """A COMPLEX weight matrix (complex forbidden states) of rank <= 2 fills the four slots with a_0, b_0, a_1, b_1.  Its term
+    W_i vr(t_n) of hi1 (src/evalobjgrad.jl:886-888) is needed in the middle of the adjoint step of step n: the backward sweep on two /
+    three workgroups per quad has it (the state role is steps ahead), the one-workgroup kernel does not -- without the split (JQ_CQ3=0,
+    more than 128 samples) the evaluation runs on the quad-layout kernels as before.  1e-10 against the oracle (objective with the
+    penalf2imag cross term, gradients, the objFuncType 2 / 3 split, forward-only, ensembles), the same numbers as the quad-layout
+    path to rounding, bit-stable run to run."""
+    from test_gpu_dense_wmat import compare
+    params, pcof = _real_forbidden(jq, kind, nforb, 70 + nforb, oft, cplx=True)
+    env = {"JQ_CHUNK_STEPS": str(chunk)} if chunk else {}
+
+    def run():
+        wa = jq.Working_Arrays_HIP(params, pcof.size)
+        compare(jq, params, pcof, wa, family=8, ensembles=(3, 9), rng=np.random.default_rng(7))
+        t = wa.last_timing()
+        wa.close()
+        return t
+    t = _with_env(env, run)
+    assert t["kernel_family"] == 8 and t["reserved"] == 3, t
+    rng = np.random.default_rng(5)
+    nodes, weights = 0.02 * rng.standard_normal(nsamples), rng.random(nsamples)
+    shift = 0.01 * np.arange(params.Ntot)
+    a = _eval(jq, params, pcof, nodes, weights, shift, env)
+    b = _eval(jq, params, pcof, nodes, weights, shift, dict(env, JQ_CQ3="0"))
+    c = _eval(jq, params, pcof, nodes, weights, shift, env)
+    assert a[4]["kernel_family"] == 8 and a[4]["reserved"] in (2, 3) and b[4]["kernel_family"] == 6, (a[4], b[4])
+    assert abs(a[0] - b[0]) <= 1e-12 * abs(b[0]) and abs(a[1] - b[1]) <= 1e-12 * abs(b[1]) and rel(a[2], b[2]) <= 1e-11 and rel(a[3], b[3]) <= 1e-11
+    assert a[0] == c[0] and a[1] == c[1] and np.array_equal(a[2], c[2]) and np.array_equal(a[3], c[3])
+
+
+def test_higher_rank_full_weights_stay_on_the_quad_layout_kernels(jq):
+    """Four slots: real rank 5 and complex rank 3 run where they ran; complex weights with more samples than the split kernels take
+    likewise; a switch of the weights on a live handle re-routes."""
     from test_gpu_dense_wmat import compare, set_forbidden
     params, pcof = _real_forbidden(jq, "cnot3", 5, 9, 1)
     wa = jq.Working_Arrays_HIP(params, pcof.size)
     compare(jq, params, pcof, wa, family=6)
-    set_forbidden(params, np.random.default_rng(2), 2, complex_states=True)
+    set_forbidden(params, np.random.default_rng(2), 3, complex_states=True)
     compare(jq, params, pcof, wa, family=6)
+    set_forbidden(params, np.random.default_rng(2), 2, complex_states=True)
+    compare(jq, params, pcof, wa, family=8)
+    nodes, weights = 0.01 * np.random.default_rng(1).standard_normal(130), np.full(130, 1.0 / 130)
+    jq.eval_f_g_grad(pcof, params, wa, nodes, weights, True, shift=0.01 * np.arange(params.Ntot))
+    assert wa.last_timing()["kernel_family"] == 6, wa.last_timing()      # (130 quads: no split, a complex W cannot take the one-workgroup kernel)
     set_forbidden(params, np.random.default_rng(3), 2, complex_states=False)
     compare(jq, params, pcof, wa, family=8)
-    # Diagonal weights again: the three-workgroup kernels are back
+    jq.eval_f_g_grad(pcof, params, wa, nodes, weights, True, shift=0.01 * np.arange(params.Ntot))
+    assert wa.last_timing()["kernel_family"] == 8, wa.last_timing()      # (... a real one can)
+    # Diagonal weights again
     p0, _ = _problem(jq, "cnot3")
     params.wmat_real, params.wmat_imag = p0.wmat_real, p0.wmat_imag
     compare(jq, params, pcof, wa, family=8)
