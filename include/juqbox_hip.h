@@ -231,10 +231,11 @@ int jq_update_wmat_diag(jq_handle *h, const double *wmat_real_diag);
  * implicit-midpoint integrator / Jacobi solver; evaluations on kernel families without the low-rank terms are refused, never
  * silently evaluated with other weights.  Parity-unpinned in the reference (no test or golden uses the branch): checked against
  * the CPU oracle, whose gradient is checked by finite differences (tests/test_dense_wmat.py).
- * Latency path (4 x 4 x n structure, at most one column quad per compute unit; round 5): a REAL W (wmat_imag = 0, i.e. real
- * forbidden states) of rank <= 4 runs on the cooperative-quad kernels (kernel_family 8, one workgroup per quad) -- one cnot3
- * evaluation 0.204 s for any rank 1 .. 4; a complex W or a higher rank on the quad-layout kernels (family 6: 0.55 s + ~ 0.1 s per
- * further forbidden state).
+ * Latency path (4 x 4 x n structure, at most one column quad per compute unit; round 5): a W that fits FOUR SLOTS -- real (wmat_imag
+ * = 0, i.e. real forbidden states) of rank <= 4, or complex of rank <= 2 -- runs on the cooperative-quad kernels (kernel_family 8): one
+ * cnot3 evaluation 0.161 s (Diagonal weights: 0.153 s) with the backward sweep on three workgroups per quad, real W on one workgroup
+ * (more than 128 samples, or the split not available) 0.204 s.  A complex W needs the split kernels; without them, and any W of higher
+ * rank, on the quad-layout kernels (family 6: 0.55 s + ~ 0.1 s per further forbidden state).
  */
 int jq_update_wmat(jq_handle *h, const double *wmat_real, const double *wmat_imag);
 
