@@ -1,6 +1,8 @@
 """Randomised GPU-vs-oracle stress (development aid, not part of the test-suite): draws problem sizes, structures,
 kernel-family overrides, chunkings and ensemble sizes and compares objective / gradient with the CPU oracle.
-usage: fuzz_gpu.py [n_cases] [seed]      (FUZZ_FOCUS=imr_cq: only the cooperative-quad implicit-midpoint kernels)"""
+usage: fuzz_gpu.py [n_cases] [seed]      (FUZZ_FOCUS=imr_cq: only the cooperative-quad implicit-midpoint kernels;
+FUZZ_FOCUS=wfull_cq: only the 4 x 4 x n structure with full leakage weights that fit the four slots of the cooperative-quad kernels --
+real rank <= 4, complex rank <= 2 -- and ensembles of 1 .. 140 samples: three / two / one workgroup per quad, the quad-layout fallback)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
@@ -38,11 +40,15 @@ def run(n_cases=50, seed=1, verbose=True):
             imr = imr and (structure != "t4" or N in (1, 2, 4) or N > 16)
         if os.environ.get("FUZZ_FOCUS") == "imr_cq":      # the cooperative-quad implicit-midpoint kernels: 4 x 4 x n structure, N = 4
             Ntot, N, structure, imr = int(rng.choice([32, 48, 64, 80, 96])), 4, "t4", True
+        focus_w = os.environ.get("FUZZ_FOCUS") == "wfull_cq"
+        if focus_w:
+            Ntot, N, structure, imr = int(rng.choice([16, 32, 48, 64, 80, 96, 112])), int(rng.choice([1, 2, 3, 4, 4, 4, 8])), "t4", False
+            Nc = int(rng.integers(1, 5))
         env = {}
         if rng.random() < 0.5:
             env["JQ_CHUNK_STEPS"] = str(int(rng.integers(1, nsteps + 1)))
         mode = rng.choice(["auto", "JQ_COOP_MAX=0", "JQ_LANE=0", "JQ_ROWLANE_MAX=0", "JQ_OD=0", "JQ_QUAD=0", "JQ_WINDOW=0", "JQ_T4=0"])
-        if os.environ.get("FUZZ_FOCUS") == "imr_cq":
+        if os.environ.get("FUZZ_FOCUS") in ("imr_cq", "wfull_cq"):
             mode = "auto"
         elif structure == "t4" and rng.random() < 0.5:      # the JQ_BW_T4 slab kernels instead of the quad-layout / cooperative ones
             env["JQ_QUAD"] = "0"
@@ -56,13 +62,21 @@ def run(n_cases=50, seed=1, verbose=True):
         p, pcof = random_problem(jq, rng, Ntot, N, Nc, Nfreq, nsteps, m, oft, structure)
         jac = (not imr) and N <= 16 and rng.random() < 0.15      # (round 3: the Jacobi solver with a loose tolerance -- per-sample convergence;
         #                                                             N > 16 converges per 16-column part: O(tol), tests/test_gpu_round4.py)
-        wfull = (not imr) and (not jac) and rng.random() < 0.12      # (round 4: full / complex leakage weights, rank 1 .. 4)
+        if focus_w:
+            jac = False
+        wfull = (not imr) and (not jac) and (focus_w or rng.random() < 0.12)      # (round 4: full / complex leakage weights, rank 1 .. 4)
         if wfull:
             nf = int(rng.integers(1, 5))
-            fs = rng.standard_normal((Ntot, nf)) + (1j * rng.standard_normal((Ntot, nf)) if rng.random() < 0.7 else 0)
+            cplx_w = rng.random() < (0.5 if focus_w else 0.7)
+            if focus_w and cplx_w:
+                nf = int(rng.integers(1, 3))
+            fs = rng.standard_normal((Ntot, nf)) + (1j * rng.standard_normal((Ntot, nf)) if cplx_w else 0)
             fs = fs / np.linalg.norm(fs, axis=0)
             Wf = sum((0.5 + rng.random()) * np.outer(fs[:, k], np.conj(fs[:, k])) for k in range(nf))
-            p.wmat_real, p.wmat_imag = np.asfortranarray(Wf.real.copy()), np.asfortranarray(Wf.imag.copy())
+            if not os.environ.get("FUZZ_NOWEIGHTS"):
+                p.wmat_real, p.wmat_imag = np.asfortranarray(Wf.real.copy()), np.asfortranarray(Wf.imag.copy())
+            if os.environ.get("FUZZ_ONLY") and not os.environ.get("FUZZ_DRY"):
+                print("   weights: %d states, complex %s" % (nf, cplx_w if focus_w else "?"), flush=True)
         jtol = float(10.0 ** rng.integers(-12, -4))
         if imr:
             p.Integrator_id = jq.Implicit_Midpoint
@@ -78,10 +92,15 @@ def run(n_cases=50, seed=1, verbose=True):
         if only and (os.environ.get("FUZZ_DRY") or case not in [int(x) for x in only.split(",")]):
             if replan:
                 rng.standard_normal((Ntot, Ntot))
-            nq = int(rng.choice([1, 2, 5, 17, 70]))
-            rng.standard_normal(nq), rng.random(nq), rng.standard_normal(Ntot)
+            nq = int(rng.choice([1, 2, 5, 17, 70, 100, 140])) if focus_w else int(rng.choice([1, 2, 5, 17, 70]))
+            rng.standard_normal(nq), rng.random(nq)
+            if focus_w and nq > 20:
+                rng.choice(nq, 4, replace=False)
+            rng.standard_normal(Ntot)
             compared += 1        # (a replay of a run without unsupported draws; with them the indices shift)
             continue
+        if os.environ.get("FUZZ_NOCHUNK"):      # (bisection aids for a replayed case)
+            env.pop("JQ_CHUNK_STEPS", None)
         os.environ.update(env)
         try:
             wa = (jq.Working_Arrays_M_HIP if imr else jq.Working_Arrays_HIP)(p, pcof.size)
@@ -90,15 +109,26 @@ def run(n_cases=50, seed=1, verbose=True):
                 os.environ.pop(k, None)
         if replan:
             D = rng.standard_normal((Ntot, Ntot))
-            p.Hconst = p.Hconst + 0.02 * (D + D.T)
-        nq = int(rng.choice([1, 2, 5, 17, 70]))
+            if not os.environ.get("FUZZ_NOREPLAN"):
+                p.Hconst = p.Hconst + 0.02 * (D + D.T)
+            if os.environ.get("FUZZ_REPLAN_FIRST"):      # (the same drift, but known to the handle before the weights are pushed again)
+                wa.close()
+                wa = jq.Working_Arrays_HIP(p, pcof.size)
+        nq = int(rng.choice([1, 2, 5, 17, 70, 100, 140])) if focus_w else int(rng.choice([1, 2, 5, 17, 70]))
         nodes, weights = 0.05 * rng.standard_normal(nq), rng.random(nq)
+        if focus_w and nq > 20:      # (the oracle loops over the samples: a few one-hot weights)
+            hot = rng.choice(nq, 4, replace=False)
+            w0 = weights.copy()
+            weights[:] = 0.0
+            weights[hot] = w0[hot]
         shift = 0.05 * rng.standard_normal(Ntot); shift[0] = 0.0
         orc = Oracle(p, use_sparse=False)
         inf = leak = 0.0
         gi, gl = np.zeros(pcof.size), np.zeros(pcof.size)
         H0 = p.Hconst.copy()
         for ep, wq in zip(nodes, weights):
+            if wq == 0.0:
+                continue
             p.Hconst = H0 + np.diag(ep * shift)
             o2 = Oracle(p, use_sparse=False)
             r = o2.traceobjgrad_imr(pcof, 80, 1e-11) if imr else o2.traceobjgrad(pcof)
@@ -128,6 +158,8 @@ def run(n_cases=50, seed=1, verbose=True):
         e3 = np.linalg.norm(p.last_infidelity_grad - gi) / max(np.linalg.norm(gi), 1e-300)
         e4 = np.linalg.norm(p.last_leak_grad - gl) / max(np.linalg.norm(gi), 1e-300) if oft != 1 else 0.0
         err = max(e1, e2, e3, e4)
+        if os.environ.get("FUZZ_ONLY"):
+            print("   infidelity %.3e leak %.3e (values %.6e / %.6e) grad %.3e leak grad %.3e" % (e1, e2, p.last_leak, leak, e3, e4), flush=True)
         if not unconv:
             worst = max(worst, err)
         else:

@@ -197,12 +197,18 @@ def test_build_manifest_no_object_falls_back():
     retried = sorted(t for t, e in man.items() if e.get("retry"))
     print("objects built with another scheduling strategy:", retried, "-- rebuilt without the VGPR form:", fallbacks)
     kcd = ("j_", "l_", "r_", "m_")      # (default form by design: Jacobi slab variants, lane / row-lane VALU kernels)
+    # ... and two named objects (csrc/Makefile says why): w_6_5, which hipcc 7.2 MISCOMPILES in VGPR form (wrong states for odd chunk
+    # lengths; tests/test_gpu_round5.py test_short_runs_with_odd_and_even_numbers_of_steps), and k_6_0, whose VGPR build cannot be validated
+    by_design = ("k_6_0", "w_6_5")
     assert not fallbacks, "objects fell back to the default register form: %s" % fallbacks
     for t, e in man.items():
-        if not t.startswith(kcd):
+        if t in by_design:
+            assert not e["vgpr_form"], t + ": must stay in the default register form (see csrc/Makefile)"
+        elif not t.startswith(kcd):
             assert e["vgpr_form"], t
-    for t in retried:      # never a quad-layout / cooperative-quad object: their scheduling strategies are tuned per object
-        assert not t.endswith("_7"), "unexpected retry: " + t
+    # a retried object (VGPR form with another scheduling strategy than its rule asks for) is an UNVALIDATED build: none at the moment --
+    # a new one must be checked on the GPU (scripts/repro_dense_k60.py is the pattern) and listed here or pinned to the default form
+    assert not retried, "objects built with a substitute scheduling strategy: %s" % retried
     # (p_6_7: the split kernel with the trace products riding along at FOUR quads per workgroup is not a default -- JQ_QS_RIDE=1, kept
     #  for the tests that compare it; it holds 256 registers and a few spilled ones.  Every kernel a plan selects by itself: no scratch.)
     not_default = ("_Z17k_backward_qsplitILi6ELb1ELi4ELb1EEv8PropArgs",)

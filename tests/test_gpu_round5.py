@@ -518,3 +518,37 @@ def test_higher_rank_full_weights_stay_on_the_quad_layout_kernels(jq):
     jq.traceobjgrad(pcof, params, wa, False, True)
     assert wa.last_timing()["reserved"] == 3, wa.last_timing()
     wa.close()
+
+
+# ---- (7) short runs with odd / even numbers of steps on the slab kernels (a miscompiled object found in round 5) --------------------------
+
+@pytest.mark.parametrize("structure,env,wts", [(False, {"JQ_COOP_MAX": "0"}, True), ("t4", {"JQ_FORCE_DENSE": "1", "JQ_EMBED": "0"}, True),
+                                               (False, {"JQ_COOP_MAX": "0"}, False), (True, {"JQ_COOP_MAX": "0", "JQ_OD": "0"}, True)])
+def test_short_runs_with_odd_and_even_numbers_of_steps(jq, structure, env, wts):
+    """Round 5: `scripts/fuzz_gpu.py` with FUZZ_FOCUS=wfull_cq drew a drift outside the 4 x 4 x n structure together with full weights --
+    the dense 96 x 96 slab kernels with the low-rank terms (object w_6_5) -- and 3 steps: infidelity off by 3e-4, gradient by 0.3.  hipcc
+    7.2 miscompiles that object in the VGPR register form (odd chunk lengths with Neumann terms only; rounds 3 and 4 shipped it in the
+    default form because the compiler crashed on it then).  It is pinned to the default form (csrc/Makefile, tests/test_abi.py); this
+    test runs the slab kernels of that size -- with and without weights, dense / forced-dense / banded -- for 3, 4, 5 and 8 steps and
+    0, 3 and 6 Neumann terms against the oracle."""
+    from oracle.oracle import Oracle
+    from test_gpu_random import random_problem
+    for ns in (3, 4, 5, 8):
+        for m in (0, 3, 6):
+            rng = np.random.default_rng(ns + 10 * m)
+            p, pcof = random_problem(jq, rng, 96, 4, 2, 1, ns, m, 3, structure)
+            if wts:
+                fs = rng.standard_normal((96, 2)) + 1j * rng.standard_normal((96, 2))
+                fs = fs / np.linalg.norm(fs, axis=0)
+                W = sum((0.5 + 0.3 * k) * np.outer(fs[:, k], np.conj(fs[:, k])) for k in range(2))
+                p.wmat_real, p.wmat_imag = np.asfortranarray(W.real.copy()), np.asfortranarray(W.imag.copy())
+            wa = _with_env(env, lambda: jq.Working_Arrays_HIP(p, pcof.size))
+            r = Oracle(p, use_sparse=False).traceobjgrad(pcof)
+            out = jq.traceobjgrad(pcof, p, wa, False, True)
+            t = wa.last_timing()
+            wa.close()
+            assert t["kernel_family"] in (0, 1), t
+            gn = np.linalg.norm(r["totalgrad"])
+            assert abs(out[2] - r["primaryobjf"]) <= TOL * abs(r["primaryobjf"]), (ns, m, t)
+            assert abs(out[3] - r["secondaryobjf"]) <= TOL * abs(r["secondaryobjf"]), (ns, m, t)
+            assert np.linalg.norm(out[1] - r["totalgrad"]) <= TOL * gn, (ns, m, t)
