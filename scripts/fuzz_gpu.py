@@ -2,7 +2,10 @@
 kernel-family overrides, chunkings and ensemble sizes and compares objective / gradient with the CPU oracle.
 usage: fuzz_gpu.py [n_cases] [seed]      (FUZZ_FOCUS=imr_cq: only the cooperative-quad implicit-midpoint kernels;
 FUZZ_FOCUS=wfull_cq: only the 4 x 4 x n structure with full leakage weights that fit the four slots of the cooperative-quad kernels --
-real rank <= 4, complex rank <= 2 -- and ensembles of 1 .. 140 samples: three / two / one workgroup per quad, the quad-layout fallback)"""
+real rank <= 4, complex rank <= 2 -- and ensembles of 1 .. 140 samples: three / two / one workgroup per quad, the quad-layout fallback;
+FUZZ_FOCUS=slab: every draw forced onto the slab kernels (family 0: no cooperative, quad-layout, lane or row-lane kernels) -- the
+objects k_*, j_*, w_* of every size and band, which small ensembles otherwise rarely reach; FUZZ_FOCUS=wfull: full weights in every
+Stormer-Verlet draw)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
@@ -54,6 +57,10 @@ def run(n_cases=50, seed=1, verbose=True):
             env["JQ_QUAD"] = "0"
             env["JQ_COOP_MAX"] = "0"
             env["JQ_LANE"] = "0"
+        if os.environ.get("FUZZ_FOCUS") == "slab":
+            imr = False
+            mode = "auto"
+            env.update({"JQ_COOP_MAX": "0", "JQ_QUAD": "0", "JQ_CQ": "0", "JQ_LANE": "0", "JQ_ROWLANE_MAX": "0"})
         if imr and mode == "JQ_COOP_MAX=0":
             mode = "auto"           # (the cooperative kernels are the only implicit-midpoint path for Ntot > 16)
         if mode != "auto":
@@ -64,7 +71,9 @@ def run(n_cases=50, seed=1, verbose=True):
         #                                                             N > 16 converges per 16-column part: O(tol), tests/test_gpu_round4.py)
         if focus_w:
             jac = False
-        wfull = (not imr) and (not jac) and (focus_w or rng.random() < 0.12)      # (round 4: full / complex leakage weights, rank 1 .. 4)
+        if os.environ.get("FUZZ_FOCUS") == "wfull":
+            jac = False
+        wfull = (not imr) and (not jac) and (focus_w or os.environ.get("FUZZ_FOCUS") == "wfull" or rng.random() < (0.3 if os.environ.get("FUZZ_FOCUS") == "slab" else 0.12))      # (round 4: full / complex leakage weights, rank 1 .. 4)
         if wfull:
             nf = int(rng.integers(1, 5))
             cplx_w = rng.random() < (0.5 if focus_w else 0.7)
