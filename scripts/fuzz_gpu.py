@@ -3,6 +3,9 @@ kernel-family overrides, chunkings and ensemble sizes and compares objective / g
 usage: fuzz_gpu.py [n_cases] [seed]      (FUZZ_FOCUS=imr_cq: only the cooperative-quad implicit-midpoint kernels;
 FUZZ_FOCUS=wfull_cq: only the 4 x 4 x n structure with full leakage weights that fit the four slots of the cooperative-quad kernels --
 real rank <= 4, complex rank <= 2 -- and ensembles of 1 .. 140 samples: three / two / one workgroup per quad, the quad-layout fallback;
+FUZZ_DUMP=<file.json>: DIFFERENTIAL mode -- no oracle; every draw's results are written to the file (exact decimal representations), to be
+compared with the same run of ANOTHER BUILD of the library (JQ_LIB; scripts/cmp_fuzz_dumps.py): what found nothing in round 5, after
+the oracle-based run had found an object that hipcc miscompiles in one register form;
 FUZZ_FOCUS=slab: every draw forced onto the slab kernels (family 0: no cooperative, quad-layout, lane or row-lane kernels) -- the
 objects k_*, j_*, w_* of every size and band, which small ensembles otherwise rarely reach; FUZZ_FOCUS=wfull: full weights in every
 Stormer-Verlet draw)"""
@@ -131,6 +134,23 @@ def run(n_cases=50, seed=1, verbose=True):
             weights[:] = 0.0
             weights[hot] = w0[hot]
         shift = 0.05 * rng.standard_normal(Ntot); shift[0] = 0.0
+        dump_path = os.environ.get("FUZZ_DUMP")
+        if dump_path:      # differential mode: this build's numbers only
+            try:
+                jq.eval_f_g_grad(pcof, p, wa, nodes, weights, True, shift=shift)
+                rec = [repr(float(p.last_infidelity)), repr(float(p.last_leak)), [repr(float(x)) for x in p.last_infidelity_grad],
+                       [repr(float(x)) for x in p.last_leak_grad] if oft != 1 else [], int(wa.last_timing()["kernel_family"])]
+            except RuntimeError as e:
+                rec = ["unsupported" if "error -3" in str(e) else "error: " + str(e)[-80:]]
+            dumped = globals().setdefault("_dumped", {})
+            dumped[str(case)] = rec
+            compared += 1
+            wa.close()
+            if compared == n_cases:
+                import json
+                json.dump(dumped, open(dump_path, "w"))
+                nonlocal_print("%d draws written to %s in %.0f s" % (compared, dump_path, time.time() - t0))
+            continue
         orc = Oracle(p, use_sparse=False)
         inf = leak = 0.0
         gi, gl = np.zeros(pcof.size), np.zeros(pcof.size)
