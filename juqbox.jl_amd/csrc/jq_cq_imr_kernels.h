@@ -740,6 +740,11 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq_imr3(PropArgs a)
     }
     Cq3Hand<NT> hd;
     hd.init(a, (size_t)quad, s.lane_);
+    // (test hook as in k_backward_cq3: JQ_DEBUG bit 16 / 32 -- the consumer roles / the state role start ~ 5 ms late; results unchanged)
+    if ((a.debug & 16) && role != 0)
+        for (int i = 0; i < 1500; ++i) __builtin_amdgcn_s_sleep(127);
+    if ((a.debug & 32) && role == 0)
+        for (int i = 0; i < 1500; ++i) __builtin_amdgcn_s_sleep(127);
     {
         const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11));
         if (threadIdx.x == 0) __hip_atomic_store(hd.head + 32 + role, (unsigned long long)xcc + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

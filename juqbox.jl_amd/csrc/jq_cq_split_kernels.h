@@ -28,6 +28,7 @@
 
 #define JQ_CQ3_SLOTS 8        // ring depth in time steps
 #define JQ_CQ3_ARRAYS 8       // u (vr before the state step), v05, un, X, nbn (-lambda_i new), Bq (-(li0 + li)); full weights: the blocks' partial dots with v05, un (CqW::part)
+#define JQ_CQ3_TAIL 64        // doubles behind a quad's ring: full weights, the dots with the state the chunk starts from (written once per launch, see below)
 #define JQ_CQ3_HEAD 64        // doubles in front of a quad's ring: [0] steps of role 0, [8] role 1, [16] role 2, [24] error, [32 + r] XCC of role r
 #define JQ_CQ3_SPIN 1000000   // polls (with s_sleep; ~ 1.3 us each: ~ 1.3 s) before a wait is declared dead.  Round 5 tried 150 000 (~ 0.2 s): next to a
                               // process whose launches hold every CU for 0.15 - 0.37 s (the throughput kernels) a role legitimately waits that long for its
@@ -43,13 +44,15 @@ struct Cq3Hand {
 
     __device__ __forceinline__ void init(const PropArgs& a, size_t quad, int lane_)
     {
-        double* base = a.park + JQ_CQ3_HEAD + quad * ((size_t)JQ_CQ3_HEAD + JQ_CQ3_SLOTS * SLOT);      // (a.park[0]: the error word of the launch)
+        double* base = a.park + JQ_CQ3_HEAD + quad * ((size_t)JQ_CQ3_HEAD + JQ_CQ3_SLOTS * SLOT + JQ_CQ3_TAIL);      // (a.park[0]: the error word of the launch)
         head = (unsigned long long*)base;
         gerr = (unsigned long long*)a.park;
         ring = base + JQ_CQ3_HEAD + lane_;
         dead = false;
         seen = 0ull, pend = 0ull;
     }
+    // the quad's tail area (this lane's element)
+    __device__ __forceinline__ double* tail() const { return ring + JQ_CQ3_SLOTS * SLOT; }
     __device__ __forceinline__ size_t off(int step, int arr, int blk) const { return ((size_t)(step & (JQ_CQ3_SLOTS - 1)) * JQ_CQ3_ARRAYS + arr) * NT * 64 + (size_t)blk * 64; }
     // (agent scope: a plain store may rest in the CU's vector cache for a while -- its vmcnt acknowledgement does not mean "in the L2")
     __device__ __forceinline__ void store(int step, int arr, int blk, double x) const
@@ -107,8 +110,11 @@ struct Cq3Hand {
 // dots: its block waves leave their partial dots with vi05 and vr(t_n) in LDS with the publications of those vectors (CqW::put), behind
 // the barrier wave 0 (vi05) / wave 1 (vr(t_n)) adds the NT registers and stores the sum as block 0 of array 6 / 7 of the step.  Role 1
 // fetches the two registers with the step's other operands, one step ahead, and applies each with ONE MFMA.  W vr(t_n+1) of a step is
-// W vr(t_n) of the step before; for the first step of a chunk role 0 leaves the dots of the state the chunk starts from where
-// "step -1" would have left them.  The same operations in the same order as the one-workgroup kernel's (k_backward_cq<.., WLR>):
+// W vr(t_n) of the step before; for the first step of a chunk role 0 leaves the dots of the state the chunk starts from in the quad's
+// TAIL area.  (First version: where "step -1" would have left them, array 7 of slot 7 -- which role 0 overwrites at step 7, and role 0
+// does not wait for anybody before step 8: when the adjoint workgroup starts late, the dots are gone before it reads them.  Idle GPU:
+// every test bit-identical; next to two load processes 43 of 240 evaluations differed -- scripts/soak_cq3_load.py with JQ_SOAK_WEIGHTS=1,
+// profiles/r05_cq3_soak_load.txt (d).)  The same operations in the same order as the one-workgroup kernel's (k_backward_cq<.., WLR>):
 // bit-identical results.  (First version: the partial registers themselves through the ring, 12 more loads per step in the adjoint
 // waves: backward sweep 96 ms instead of 81.)
 template <int NT, bool MODD, bool ORD, int NR = 3, bool WLR = false>
@@ -141,6 +147,14 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
     Cq3Hand<NT> hd;
     hd.init(a, (size_t)quad, lane_);
     const int nst = a.nsteps_chunk;
+    // TEST HOOK (JQ_DEBUG bit 16 / 32; results unchanged): the consumer roles / the state role start ~ 5 ms late -- on an idle GPU the roles
+    // of a quad start together and a hand-off that is only safe then passes every test (round 5: the first version of the full-weights
+    // hand-off was one; next to load processes it was not).  With bit 16 role 0 runs ahead as far as the protocol lets it before
+    // anybody reads; with bit 32 everybody waits for role 0.
+    if ((a.debug & 16) && role != 0)
+        for (int i = 0; i < 1500; ++i) __builtin_amdgcn_s_sleep(127);
+    if ((a.debug & 32) && role == 0)
+        for (int i = 0; i < 1500; ++i) __builtin_amdgcn_s_sleep(127);
     // the three workgroups must share an L2: XCC_ID (hardware register 20, bits 3:0) of every role goes into the header, role 2 compares
     {
         const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11));
@@ -314,15 +328,25 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
         };
         if constexpr (WLR) {
             wq.init(a, smem, wave, lane_);
-            wq.template put<NT>(0, wave, lane_, u);      // (vr at the start of the chunk: "vr(t_n) of step -1"; its slot is free, nothing is in flight)
+            wq.template put<NT>(0, wave, lane_, u);      // (vr at the start of the chunk)
             c.sync();
-            if (wave == (NT > 1 ? 1 : 0)) wsum(-1, 7, 0);
+            if (wave == (NT > 1 ? 1 : 0)) {
+                const double* r = wq.wpart + lane_;
+                double d = r[0];
+#pragma unroll
+                for (int w = 1; w < NT; ++w) d += r[w * 64];
+                __hip_atomic_store(hd.tail(), d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         auto step = [&](auto P0c, int n) {
             constexpr int P0 = decltype(P0c)::value;
-            // (a slot is reused when the trace workgroup has read it; NR = 2: when the adjoint workgroup has -- it publishes n once the
-            //  loads of the steps <= n have landed in all its waves)
-            if (wave == 0 && n >= JQ_CQ3_SLOTS) hd.wait(NR - 1, (unsigned long long)(n - JQ_CQ3_SLOTS + (NR == 3 ? 1 : 0)));
+            // (a slot is reused when the trace workgroup has read it -- it publishes k + 1 once the loads of the steps <= k have landed; NR = 2:
+            //  when the adjoint workgroup has -- it publishes k once the loads of the steps <= k have landed in all its waves, so the slot of
+            //  step n - 8 would be free at k = n - 8.  But k = 0 is also what the counter holds before that workgroup has started: the first
+            //  version waited for n - 8 and, at step 8, overwrote the operands of step 0 of an adjoint workgroup that started late -- never
+            //  on an idle GPU, where the roles start together; found with the late-start hook JQ_DEBUG=16, tests/test_gpu_round5.py (8).
+            //  One step more, as for NR = 3: the state role is at most 7 steps ahead instead of 8.)
+            if (wave == 0 && n >= JQ_CQ3_SLOTS) hd.wait(NR - 1, (unsigned long long)(n - JQ_CQ3_SLOTS + 1));
             double un, v05, vN;
             // x = u: A = c K05 u ; P = u + c S0 u
             c.template post<P0, 0>(u);
@@ -490,7 +514,7 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
             if (n > 0) finish_traces(n - 1);      // (behind the step's first barrier: everybody's hand-off of step n - 1 is in red)
         if (n == 0) {      // (first step of the chunk: latency exposed once)
             if constexpr (WLR) {
-                pn = hd.load(-1, 7, 0);
+                pn = __hip_atomic_load(hd.tail(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 Wu = wapply(wcf, pn);
             }

@@ -2269,7 +2269,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     // A complex W needs W_i vr(t_n) in the middle of the adjoint step: only the split kernels, whose state role is steps ahead, have it.
     // Without them (more than 128 samples, the gate taken, cooling down, JQ_CQ3=0 ...) the evaluation runs on the quad-layout kernels.
     if (cq && wfull && !h->wlr_real && adjoint && !cq3) cq = false;
-    const size_t cq3_quad = 64 + (size_t)8 * 8 * h->NT * 64;      // doubles per quad: JQ_CQ3_HEAD + JQ_CQ3_SLOTS * JQ_CQ3_ARRAYS * NT * 64
+    const size_t cq3_quad = 64 + (size_t)8 * 8 * h->NT * 64 + 64;      // doubles per quad: JQ_CQ3_HEAD + JQ_CQ3_SLOTS * JQ_CQ3_ARRAYS * NT * 64 + JQ_CQ3_TAIL
     const size_t cq3_need = 64 + (size_t)nq_pad * cq3_quad;
     if (cq3) {
         const int rc0 = dev_grow(h, &h->d_cq3, &h->cap_cq3, cq3_need);

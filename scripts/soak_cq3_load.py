@@ -47,18 +47,29 @@ if os.path.exists(stop):
     os.remove(stop)
 first = {}
 was = {}
+SIZES = {False: (1, 9, 80, 100), True: (1, 9, 80)}      # (100 samples: TWO workgroups per quad, Stormer-Verlet only -- added in round 5 after the
+#                                                          late-start hook had found a slot-reuse race of that kernel which this soak, without the size, could not see)
 for imr in (False, True):
     p2, _ = jq.cases.cnot3()
     p2.T, p2.nsteps = params.T, params.nsteps
     if imr:
         p2.Integrator_id = jq.Implicit_Midpoint
         p2.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER_M, max_iter=100, tol=1e-12, nrhs=p2.N)
+    elif os.environ.get("JQ_SOAK_WEIGHTS"):
+        # (round 5) the Stormer-Verlet evaluations of the MAIN process carry full leakage weights -- two complex forbidden states: four
+        # slots on the split kernels, two more arrays in the ring, the state role's partial dots in LDS.  A fall-back of those runs on the
+        # quad-layout kernels (a complex W cannot take the one-workgroup kernel): equal to 1e-12 then, not bit-wise
+        rng_w = np.random.default_rng(7)
+        fs = rng_w.standard_normal((p2.Ntot, 2)) + 1j * rng_w.standard_normal((p2.Ntot, 2))
+        fs /= np.linalg.norm(fs, axis=0)
+        Wc = sum((0.5 + 0.5 * k) * np.outer(fs[:, k], np.conj(fs[:, k])) for k in range(2))
+        p2.wmat_real, p2.wmat_imag = np.asfortranarray(Wc.real.copy()), np.asfortranarray(Wc.imag.copy())
     wa = (jq.Working_Arrays_M_HIP if imr else jq.Working_Arrays_HIP)(p2, pcof.size)
     was[imr] = (p2, wa)
-    for ns in (1, 9, 80):
+    for ns in SIZES[imr]:
         nodes, weights, shift = jq.cases.cnot3_ensemble(ns)
         jq.eval_f_g_grad(pcof, p2, wa, nodes, weights, True, shift=shift)
-        assert wa.last_timing()["reserved"] == 3
+        assert wa.last_timing()["reserved"] == (2 if ns > 80 else 3)
         first[imr, ns] = (p2.last_infidelity, p2.last_leak, p2.last_infidelity_grad.tobytes())
 loads = [subprocess.Popen([sys.executable, os.path.abspath(__file__), str(rounds), str(nsteps)], env=dict(os.environ, JQ_SOAK_ROLE=r),
                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in (sys.argv[3].split(",") if len(sys.argv) > 3 else ("throughput", "split"))]
@@ -69,15 +80,20 @@ worst = 0.0
 for r in range(rounds):
     for imr in (False, True):
         p2, wa = was[imr]
-        for ns in (1, 9, 80):
+        for ns in SIZES[imr]:
             nodes, weights, shift = jq.cases.cnot3_ensemble(ns)
             t1 = time.time()
             jq.eval_f_g_grad(pcof, p2, wa, nodes, weights, True, shift=shift)
             worst = max(worst, time.time() - t1)
             nev += 1
-            nfb += wa.last_timing()["reserved"] != 3
+            nfb += wa.last_timing()["reserved"] not in (2, 3)
             cur = (p2.last_infidelity, p2.last_leak, p2.last_infidelity_grad.tobytes())
-            if cur != first[imr, ns]:
+            same = cur == first[imr, ns]
+            if not same and wa.last_timing()["kernel_family"] == 6:      # (weighted run that fell back to the quad-layout kernels)
+                f0 = first[imr, ns]
+                g0, g1 = np.frombuffer(f0[2]), np.frombuffer(cur[2])
+                same = abs(cur[0] - f0[0]) <= 1e-12 * abs(f0[0]) and abs(cur[1] - f0[1]) <= 1e-12 * abs(f0[1]) and np.linalg.norm(g1 - g0) <= 1e-11 * np.linalg.norm(g0)
+            if not same:
                 bad += 1
                 print("MISMATCH imr=%s round %d ns %d" % (imr, r, ns), flush=True)
 dt = time.time() - t0
@@ -88,5 +104,5 @@ for p in loads:
 os.remove(stop)
 for imr in (False, True):
     print("plan (%s): %s" % ("implicit midpoint" if imr else "Stormer-Verlet", was[imr][1].plan_info()["latency_split"]))
-print("%d evaluations (%d rounds x 3 ensemble sizes x 2 integrators x %d steps) next to the load processes: %d mismatches, %d evaluations on the "
-      "one-workgroup kernel (fallback / cooling down), %.0f s, slowest evaluation %.2f s" % (nev, rounds, params.nsteps, bad, nfb, dt, worst))
+print("%s%d evaluations (%d rounds x 4 + 3 ensemble sizes (Stormer-Verlet + implicit midpoint) x %d steps) next to the load processes: %d mismatches, %d evaluations on the "
+      "one-workgroup kernel (fallback / cooling down), %.0f s, slowest evaluation %.2f s" % ("FULL WEIGHTS (complex, rank 2) in the Stormer-Verlet evaluations: " if os.environ.get("JQ_SOAK_WEIGHTS") else "", nev, rounds, params.nsteps, bad, nfb, dt, worst))

@@ -261,3 +261,33 @@ def test_every_environment_variable_the_library_reads_is_documented():
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     missing = sorted(n for n in names if n not in doc)
     assert not missing, "environment variables without a row in INTEGRATION.md: %s" % missing
+
+
+def test_makefile_rules_list_the_headers_their_headers_include():
+    """Round 5: the rule of the implicit-midpoint cooperative-quad objects named jq_cq_imr_kernels.h but not jq_cq_split_kernels.h, which it
+    includes -- a change of the hand-off ring layout alone left stale objects (found by the soak under load).  Every kernel-object rule
+    must list the transitive closure of the jq_*.h headers it names."""
+    import re
+    csrc = os.path.join(ROOT, "juqbox.jl_amd", "csrc")
+    inc = {}
+    for f in os.listdir(csrc):
+        if f.startswith("jq_") and f.endswith(".h"):
+            inc[f] = set(re.findall(r'#include "(jq_[a-z_]+\.h)"', open(os.path.join(csrc, f)).read()))
+
+    def closure(h):
+        out, todo = set(), [h]
+        while todo:
+            for g in inc[todo.pop()]:
+                if g not in out:
+                    out.add(g)
+                    todo.append(g)
+        return out
+    rules = re.findall(r"^\$\(OBJDIR\)/([a-z0-9_%]+)\.o:(.*)$", open(os.path.join(csrc, "Makefile")).read(), flags=re.M)
+    assert len(rules) >= 15
+    for target, deps in rules:
+        named = set(re.findall(r"(jq_[a-z_]+\.h)\b", deps)) & set(inc)      # (jq_kernel_inst.hip is not a header)
+        if "$(SRCS)" in deps:
+            continue
+        for h in named:
+            missing = closure(h) - named
+            assert not missing, "rule %s.o names %s but not %s" % (target, h, sorted(missing))

@@ -552,3 +552,54 @@ def test_short_runs_with_odd_and_even_numbers_of_steps(jq, structure, env, wts):
             assert abs(out[2] - r["primaryobjf"]) <= TOL * abs(r["primaryobjf"]), (ns, m, t)
             assert abs(out[3] - r["secondaryobjf"]) <= TOL * abs(r["secondaryobjf"]), (ns, m, t)
             assert np.linalg.norm(out[1] - r["totalgrad"]) <= TOL * gn, (ns, m, t)
+
+
+# ---- (8) hand-offs of the split kernels when the roles of a quad do NOT start together ---------------------------------------------------
+
+@pytest.mark.parametrize("kind,nsamples,wts", [("cnot3", 9, None), ("cnot3", 9, "real"), ("cnot3", 80, "complex"), ("cnot3", 100, "real"), ("t4x3", 40, "complex"),
+                                               ("t4x5", 90, None)])
+def test_split_kernels_with_late_roles(jq, kind, nsamples, wts):
+    """Round 5: the first version of the full-weights hand-off left the dots of the chunk's initial state in a ring slot that the state role
+    overwrites at step 7 -- and the state role waits for nobody before step 8.  On an idle GPU the roles of a quad start together and every
+    test was bit-identical; next to two load processes 43 of 240 weighted evaluations differed (`scripts/soak_cq3_load.py` with
+    JQ_SOAK_WEIGHTS=1).  JQ_DEBUG=16 / 32 makes the consumer roles / the state role of every quad start ~ 5 ms late: the results must not
+    change by a bit -- with and without weights, three and two workgroups per quad, several chunks."""
+    if wts:
+        params, pcof = _real_forbidden(jq, kind, 2, 11, 3, cplx=(wts == "complex"))
+    else:
+        params, pcof = _problem(jq, kind)
+    rng = np.random.default_rng(nsamples)
+    nodes, weights = 0.02 * rng.standard_normal(nsamples), rng.random(nsamples)
+    shift = 0.01 * np.arange(params.Ntot)
+    env = {"JQ_CHUNK_STEPS": "300"} if kind == "cnot3" else {}
+    a = _eval(jq, params, pcof, nodes, weights, shift, env)
+    assert a[4]["kernel_family"] == 8 and a[4]["reserved"] in (2, 3), a[4]
+    for bit in ("16", "32"):
+        b = _eval(jq, params, pcof, nodes, weights, shift, dict(env, JQ_DEBUG=bit))
+        assert b[4]["reserved"] == a[4]["reserved"], (a[4], b[4])
+        assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]), bit
+
+
+@pytest.mark.parametrize("nsamples", [1, 9, 80])
+def test_implicit_midpoint_split_kernel_with_late_roles(jq, nsamples):
+    """... and the three-workgroup kernel of the implicit-midpoint path (k_backward_cq_imr3, the same hand-off ring)."""
+    params, pcof = _cnot3(jq, 901)
+    params.Integrator_id = jq.Implicit_Midpoint
+    params.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER_M, max_iter=100, tol=1e-12, nrhs=params.N)
+    nodes, weights, shift = jq.cases.cnot3_ensemble(nsamples)
+
+    def run(env):
+        def go():
+            wa = jq.Working_Arrays_M_HIP(params, pcof.size)
+            jq.eval_f_g_grad(pcof, params, wa, nodes, weights, True, shift=shift)
+            t = wa.last_timing()
+            out = (params.last_infidelity, params.last_leak, params.last_infidelity_grad.copy(), t)
+            wa.close()
+            return out
+        return _with_env(env, go)
+    a = run({"JQ_CHUNK_STEPS": "300"})
+    assert a[3]["kernel_family"] == 9 and a[3]["reserved"] == 3, a[3]
+    for bit in ("16", "32"):
+        b = run({"JQ_CHUNK_STEPS": "300", "JQ_DEBUG": bit})
+        assert b[3]["reserved"] == 3
+        assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2]), bit
