@@ -2254,7 +2254,24 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     if ((cq || imr_cq) && adjoint) {
         const char* why = nullptr;
         cq_nr = 3 * nq_pad <= h->num_cu ? 3 : (cq && 2 * nq_pad <= h->num_cu && !(e_c3 && atoi(e_c3) == 3)) ? 2 : 0;
+        // The consumer roles read the state the sweep starts from out of the state file (the carry of the trace products, first chunk
+        // only), and the state role writes its end-of-chunk state there when it is through.  It cannot be through before they have
+        // started only if it has to WAIT for them -- which it does from step 8 on (the ring has 8 slots): the first chunk must be longer
+        // than the ring.  (Shorter first chunks -- tests, problems with a handful of steps -- were a race that the late-start hook
+        // JQ_DEBUG=16 exposed in round 5; they take the one-workgroup kernel.)
+        long long cs_first = h->chunk_steps;
+        {
+            size_t tbudget = (size_t)4 << 30;
+            if (const char* e = getenv("JQ_TRACE_BYTES")) {
+                const long long v = atoll(e);
+                if (v > 0) tbudget = (size_t)v;
+            }
+            const size_t rows = (size_t)nslabs * qps * (imr_cq ? h->NT : 1);
+            cs_first = std::max<long long>(1, std::min<long long>(cs_first, (long long)(tbudget / (rows * h->NcK * JQ_NTR * sizeof(double)))));
+            cs_first = std::min<long long>(cs_first, h->nsteps);
+        }
         if (e_c3 && atoi(e_c3) == 0) why = "not taken: JQ_CQ3=0";
+        else if (cs_first <= 8) why = "not taken: the first chunk of the sweep is not longer than the hand-off ring (8 steps)";
         else if (cq_nr == 0) why = "not taken: two / three workgroups per column quad exceed the compute units";
         else if (h->cq3_off) why = "not taken: switched off after repeated faults (dead waits between the workgroups of a quad)";
         else if (h->cq3_skip > 0) why = "not taken: cooling down after a fault";

@@ -329,12 +329,12 @@ def test_all_reduce_self_check_comparison_runs_in_the_same_device_mode(jq):
 
 # ---- (5) latency path, 81 .. 128 samples: two workgroups per column quad ---------------------------------------------------------------
 
-@pytest.mark.parametrize("kind,nsamples,chunk", [("cnot3", 81, 300), ("cnot3", 128, 0), ("cnot3", 97, 1), ("t4x3", 100, 20), ("t4x5", 90, 19)])
+@pytest.mark.parametrize("kind,nsamples,chunk", [("cnot3", 81, 300), ("cnot3", 128, 0), ("cnot3", 97, 9), ("t4x3", 100, 20), ("t4x5", 90, 19)])
 def test_backward_sweep_on_two_workgroups_per_quad_is_the_one_workgroup_kernel(jq, kind, nsamples, chunk):
     """Round 5: with 2 x quads <= CUs < 3 x quads (81 .. 128 cnot3 samples) k_backward_cq3<.., NR = 2> gives a column quad two workgroups --
     state re-integration | adjoint step + ALL trace products (the adjoint path of k_backward_cq with the state waves' share of the
     traces; only u, vi05, vr(t_n) cross the ring).  Every chain and every trace sum performs the operations of k_backward_cq (JQ_CQ3=0)
-    in the same order: bit-identical results -- ragged groups of 8 quads, several chunks (also of one step), odd / even numbers of
+    in the same order: bit-identical results -- ragged groups of 8 quads, several chunks (down to 9 steps: the shortest the split kernels take), odd / even numbers of
     Neumann terms, NT = 3, 5, 6, single-subsystem and generic trace products, objFuncType 2 / 3, and run to run."""
     params, pcof = _problem(jq, kind)
     rng = np.random.default_rng(nsamples)
@@ -398,7 +398,7 @@ def _real_forbidden(jq, kind, nforb, seed, oft, cplx=False):
     return params, pcof
 
 
-@pytest.mark.parametrize("kind,nforb,oft,chunk", [("cnot3", 1, 1, 0), ("cnot3", 2, 3, 250), ("cnot3", 4, 2, 1), ("t4x3", 3, 3, 20), ("t4x5", 4, 1, 19), ("t4x2", 2, 1, 0)])
+@pytest.mark.parametrize("kind,nforb,oft,chunk", [("cnot3", 1, 1, 0), ("cnot3", 2, 3, 250), ("cnot3", 4, 2, 9), ("t4x3", 3, 3, 20), ("t4x5", 4, 1, 19), ("t4x2", 2, 1, 0)])
 def test_real_full_weights_run_on_the_cooperative_quad_kernels(jq, kind, nforb, oft, chunk):
     """Round 5: a REAL weight matrix of rank <= 4 (real forbidden states) no longer sends a single evaluation or a small ensemble to the
     quad-layout kernels (0.45 s + 57 ms per state at cnot3): the cooperative-quad kernels carry the low-rank terms (CqW: the waves of a
@@ -461,7 +461,7 @@ def test_real_full_weights_on_two_workgroups_per_quad(jq, kind, nsamples, varian
     assert abs(a[0] - inf) <= TOL * abs(inf) and abs(a[1] - leak) <= TOL * abs(leak) and rel(a[2], grad) <= TOL
 
 
-@pytest.mark.parametrize("kind,nforb,oft,chunk,nsamples", [("cnot3", 1, 1, 0, 9), ("cnot3", 2, 3, 250, 100), ("t4x3", 2, 2, 20, 21), ("t4x5", 1, 3, 1, 90),
+@pytest.mark.parametrize("kind,nforb,oft,chunk,nsamples", [("cnot3", 1, 1, 0, 9), ("cnot3", 2, 3, 250, 100), ("t4x3", 2, 2, 20, 21), ("t4x5", 1, 3, 9, 90),
                                                             ("t4x2", 2, 1, 0, 5)])
 def test_complex_full_weights_run_on_the_split_kernels(jq, kind, nforb, oft, chunk, nsamples):
     """A COMPLEX weight matrix (complex forbidden states) of rank <= 2 fills the four slots with a_0, b_0, a_1, b_1.  Its term
@@ -556,14 +556,17 @@ def test_short_runs_with_odd_and_even_numbers_of_steps(jq, structure, env, wts):
 
 # ---- (8) hand-offs of the split kernels when the roles of a quad do NOT start together ---------------------------------------------------
 
-@pytest.mark.parametrize("kind,nsamples,wts", [("cnot3", 9, None), ("cnot3", 9, "real"), ("cnot3", 80, "complex"), ("cnot3", 100, "real"), ("t4x3", 40, "complex"),
-                                               ("t4x5", 90, None)])
-def test_split_kernels_with_late_roles(jq, kind, nsamples, wts):
+@pytest.mark.parametrize("kind,nsamples,wts,chunk", [("cnot3", 9, None, 300), ("cnot3", 9, "real", 300), ("cnot3", 80, "complex", 300), ("cnot3", 100, "real", 300),
+                                                     ("t4x3", 40, "complex", 0), ("t4x5", 90, None, 0), ("cnot3", 128, None, 9), ("cnot3", 33, "complex", 10),
+                                                     ("t4x3", 100, "real", 9), ("cnot3", 70, None, 9)])
+def test_split_kernels_with_late_roles(jq, kind, nsamples, wts, chunk):
     """Round 5: the first version of the full-weights hand-off left the dots of the chunk's initial state in a ring slot that the state role
     overwrites at step 7 -- and the state role waits for nobody before step 8.  On an idle GPU the roles of a quad start together and every
     test was bit-identical; next to two load processes 43 of 240 weighted evaluations differed (`scripts/soak_cq3_load.py` with
     JQ_SOAK_WEIGHTS=1).  JQ_DEBUG=16 / 32 makes the consumer roles / the state role of every quad start ~ 5 ms late: the results must not
-    change by a bit -- with and without weights, three and two workgroups per quad, several chunks."""
+    change by a bit -- with and without weights, three and two workgroups per quad, several chunks down to 9 steps.  (With a FIRST chunk
+    of at most 8 steps -- the length of the ring -- the state role can finish the launch, and overwrite the state file the consumers'
+    carries start from, before they have started: the hook showed that too; such sweeps take the one-workgroup kernel, next test.)"""
     if wts:
         params, pcof = _real_forbidden(jq, kind, 2, 11, 3, cplx=(wts == "complex"))
     else:
@@ -571,7 +574,9 @@ def test_split_kernels_with_late_roles(jq, kind, nsamples, wts):
     rng = np.random.default_rng(nsamples)
     nodes, weights = 0.02 * rng.standard_normal(nsamples), rng.random(nsamples)
     shift = 0.01 * np.arange(params.Ntot)
-    env = {"JQ_CHUNK_STEPS": "300"} if kind == "cnot3" else {}
+    env = {"JQ_CHUNK_STEPS": str(chunk)} if chunk else {}
+    if chunk and chunk < 10 and kind == "cnot3":      # (short chunks: a shorter run, the launches are what is tested)
+        params.T, params.nsteps = params.T * 60 / params.nsteps, 60
     a = _eval(jq, params, pcof, nodes, weights, shift, env)
     assert a[4]["kernel_family"] == 8 and a[4]["reserved"] in (2, 3), a[4]
     for bit in ("16", "32"):
@@ -603,3 +608,29 @@ def test_implicit_midpoint_split_kernel_with_late_roles(jq, nsamples):
         b = run({"JQ_CHUNK_STEPS": "300", "JQ_DEBUG": bit})
         assert b[3]["reserved"] == 3
         assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2]), bit
+
+
+@pytest.mark.parametrize("chunk,nsteps", [(1, 60), (8, 60), (0, 7)])
+def test_short_first_chunks_take_the_one_workgroup_kernel(jq, chunk, nsteps):
+    """The split kernels' consumer roles read the sweep's initial state from the state file, which the state role overwrites when it is
+    through with the chunk; it has to wait for them only from step 8 on.  A first chunk of <= 8 steps (tests with tiny chunks, problems
+    with a handful of steps) is not given to them -- `plan_info` says why -- and the late-start hook changes nothing."""
+    params, pcof = _cnot3(jq, nsteps)
+    nodes, weights, shift = jq.cases.cnot3_ensemble(9)
+    env = {"JQ_CHUNK_STEPS": str(chunk)} if chunk else {}
+
+    def run(extra):
+        def go():
+            wa = jq.Working_Arrays_HIP(params, pcof.size)
+            jq.eval_f_g_grad(pcof, params, wa, nodes, weights, True, shift=shift)
+            out = (params.last_infidelity, params.last_leak, params.last_infidelity_grad.copy(), wa.last_timing(), wa.plan_info()["latency_split"]["last_decision"])
+            wa.close()
+            return out
+        return _with_env(dict(env, **extra), go)
+    a = run({})
+    assert a[3]["kernel_family"] == 8 and a[3]["reserved"] == 0 and "first chunk" in a[4], (a[3], a[4])
+    b = run({"JQ_DEBUG": "16"})
+    assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2])
+    c = run({"JQ_CHUNK_STEPS": "9"}) if nsteps > 9 else None
+    if c is not None:
+        assert c[3]["reserved"] == 3, c[3]
