@@ -291,3 +291,15 @@ def test_makefile_rules_list_the_headers_their_headers_include():
         for h in named:
             missing = closure(h) - named
             assert not missing, "rule %s.o names %s but not %s" % (target, h, sorted(missing))
+
+
+def test_profiles_readme_names_files_that_exist():
+    """The round's profile files are renamed per build (`..._v6.txt`): every `r05_*` file the README of profiles/ names must exist, and every
+    `r05_*` file must be named there."""
+    import re
+    pdir = os.path.join(ROOT, "profiles")
+    text = open(os.path.join(pdir, "README.md")).read()
+    named = set(re.findall(r"`(r05_[A-Za-z0-9_.]+\.(?:txt|json|log))`", text))
+    have = set(f for f in os.listdir(pdir) if f.startswith("r05_"))
+    assert named - have == set(), "named in profiles/README.md but missing: %s" % sorted(named - have)
+    assert have - named == set(), "in profiles/ but not described: %s" % sorted(have - named)
