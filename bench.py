@@ -31,7 +31,7 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak: 256 CU x 4 SIMD x 32 F
                                # (v_mfma_f64_16x16x4_f64 issues every 64 clk; measured 75.4 TF, probes/)
 STRONG_TOTAL_SAMPLES = 24576   # fixed ensemble of the strong-scaling run = 8 GPUs x one full round (3072 samples) each
 STRONG_SMALL_SAMPLES = 4096    # second, SUB-SATURATING strong-scaling point: 8 GPUs get 512 samples each (latency regime)
-PMC_FILES = ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json")   # rocprofv3 PMC summaries (profiles/); used only when recorded for THIS build
+PMC_FILES = ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json")   # rocprofv3 PMC summaries (profiles/); used only when recorded for THIS build
 
 
 def parse_args():
@@ -224,14 +224,14 @@ def dense_operator_block(jq, L, pcof, quick=False, samples=None):
     libver = L.jq_version().decode()
     src, check, pk = "analytic (library count)", None, {}
     try:
-        pj = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_dense.json")))
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r06_pmc_dense.json")))
         pk = pj["kernels"].get(kb, {})
         if pj.get("library_version") == libver and pk.get("samples_per_gpu") == best and pk.get("mfma_16x16x4_equiv_per_launch") \
                 and pk.get("steps_per_launch") in (None, pd.nsteps / nb):
             dev = abs(pk["mfma_16x16x4_equiv_per_launch"] - mf_b) / mf_b
             check = {"pmc": pk["mfma_16x16x4_equiv_per_launch"], "analytic": mf_b, "rel_diff": dev}
             if dev < 0.01:
-                mf_b, src = pk["mfma_16x16x4_equiv_per_launch"], "rocprofv3 PMC SQ_INSTS_MFMA (profiles/r05_pmc_dense.json, same build)"
+                mf_b, src = pk["mfma_16x16x4_equiv_per_launch"], "rocprofv3 PMC SQ_INSTS_MFMA (profiles/r06_pmc_dense.json, same build)"
         else:
             pk = {}
     except Exception:  # noqa: BLE001
@@ -259,6 +259,139 @@ def dense_operator_block(jq, L, pcof, quick=False, samples=None):
             "roofline_forward": {"kernel": kb.replace("backward", "forward"), "achieved": ach_f, "frac": ach_f / FP64_MFMA_PEAK_TFLOPS,
                                  "avg_launch_ms": fwd_s * 1e3},
             "all_propagators_mfma_frac": t["mfma_executed"] * 2048.0 / (t["ms_propagate"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS}
+
+
+def lone_wave_chain_clk():
+    """probes/lone_wave_probe: clk per link of a DEPENDENT v_fmac_f64 chain of a wave that is alone on its SIMD (one chain / two
+    chains interleaved, unroll 16) -- what bounds the row-lane kernels, whose product is two interleaved accumulator chains of
+    NPJ / 2 links.  Run live when the binary is in the tree (build()), else the recorded run of profiles/r03_issue_probes.txt."""
+    import re
+    txt, src = None, None
+    exe = os.path.join(ROOT, "probes", "lone_wave_probe")
+    if os.access(exe, os.X_OK):
+        try:
+            txt = subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout
+            src = "probes/lone_wave_probe, run by this bench"
+        except Exception:  # noqa: BLE001
+            txt = None
+    if not txt or "two chains interleaved" not in txt:
+        try:
+            txt = open(os.path.join(ROOT, "profiles", "r03_issue_probes.txt")).read()
+            src = "profiles/r03_issue_probes.txt (recorded run of probes/lone_wave_probe)"
+        except OSError:
+            return None
+    out = {"source": src}
+    for key, label in (("one_chain", "ONE dependent chain"), ("two_chains", "two chains interleaved")):
+        mm = re.search(r"v_fmac_f64, %s\s+unroll 16, 1 wave\(s\)/SIMD:\s+([0-9.]+) clk" % label, txt)
+        if not mm:
+            return None
+        out[key] = float(mm.group(1))
+    return out
+
+
+def baseline_configs_block(jq, L, quick=False):
+    """BASELINE.json configs[0], [1], [2], [4] (rabi, cnot1, cnot2, SWAP-02 risk-neutral x 512 nodes; configs[3] = cnot3 is the bench
+    line itself): per config the GPU time of one evaluation (HIP events), the CPU oracle on ONE core in the same run (BASELINE.md
+    section 3; a bounded sample of the 512 nodes for the ensemble, stated), and a bound statement.  These Hilbert spaces (Ntot <= 12)
+    run on the VALU row-lane kernels: no MFMA percentage is quoted; a single evaluation is the latency of a sequential
+    chain of dependent products, so the statement is ACHIEVED clk per dependent product against the dependent-FMA chain latency a lone
+    wave can reach (probes/lone_wave_probe): a product of row length NPJ is two interleaved accumulator chains + one add."""
+    import copy
+    import numpy as np
+    from oracle.oracle import Oracle
+    chain = lone_wave_chain_clk()
+    ncu = 256
+    cfgs = {}
+    for cname, nq in (("rabi", 1), ("cnot1", 1), ("cnot2", 1), ("swap02_rn", 512)):
+        pc, ic = jq.cases.BUILDERS[cname]()
+        pcf = ic.get("pcof0")
+        if ic.get("golden"):
+            gj = json.load(open(os.path.join(ROOT, "tests", "golden", "%s.json" % ic["golden"])))
+            pcf = np.array(gj["pcof0"]) if "pcof0" in gj else pcf
+        pcf = np.asarray(pcf, dtype=np.float64)
+        wc = jq.Working_Arrays_HIP(pc, pcf.size)
+        ncu = L.jq_num_compute_units(wc.handle) or ncu
+        if nq == 1:
+            nd, wq, shc = np.zeros(1), np.ones(1), None
+        else:
+            nd, wq, shc = ic["nodes"], ic["weights"], pc.shift_weights_reference()
+        for _ in range(2):
+            jq.eval_f_g_grad(pcf, pc, wc, nd, wq, True, shift=shc)
+        tc = wc.last_timing()
+        gpu_infid = float(pc.last_infidelity)
+        m, nsteps, N = int(pc.linear_solver.max_iter), int(pc.nsteps), int(pc.N)
+        entry = {"Ntot": int(pc.Ntot), "N": N, "nsteps": nsteps, "neumann_terms": m, "samples": nq,
+                 "ms_per_evaluation": tc["ms_total"], "ms_forward": tc["ms_forward"], "ms_backward": tc["ms_backward"],
+                 "evals_per_s": nq / (tc["ms_total"] * 1e-3), "svts_per_s": tc["svts"] / (tc["ms_total"] * 1e-3),
+                 "kernel_family": tc["kernel_family"], "kernel_size": tc["kernel_size"]}
+        if nq > 1:      # strong scaling of THIS ensemble over 8 GPUs, predicted from one GPU: a rank's share is nq / 8 nodes
+            nsh = nq // 8
+            for _ in range(2):
+                jq.eval_f_g_grad(pcf, pc, wc, nd[:nsh], wq[:nsh], True, shift=shc)
+            t8 = wc.last_timing()["ms_total"]
+            entry["strong_scaling_prediction_8_gpus"] = {
+                "ms_one_gpu_all_nodes": tc["ms_total"], "ms_one_rank_share": t8, "nodes_per_rank": nsh, "predicted_speedup": tc["ms_total"] / t8,
+                "note": "the %d-node ensemble does not fill ONE GPU (%d columns on %d compute units): every node runs at the latency of its "
+                        "sequential time loop, and an eighth of the nodes takes as long as all of them -- splitting it over 8 GPUs buys "
+                        "~ 1 x, not 6 x (SURVEY.md 8(e)); north_star's >= 6 x needs a saturating ensemble (strong_scaling)" % (nq, nq * N, ncu)}
+        wc.close()
+        # ---- CPU oracle, one core, same run (dense products: these cases are use_sparse = false in the reference) ----
+        ncpu = nq if nq == 1 else (4 if quick else 16)       # bounded sample of the ensemble's nodes, scaled to the whole ensemble
+        orc = Oracle(pc)
+        reps = 1 if quick else (5 if nq == 1 else 1)
+        times, cpu_infid = [], 0.0
+        H0 = pc.Hconst.copy()
+        for _ in range(reps):
+            t1 = time.perf_counter()
+            if nq == 1:
+                cpu_infid = orc.traceobjgrad(pcf)["primaryobjf"]
+            else:
+                sub = np.linspace(0, nq - 1, ncpu).round().astype(int)      # nodes spread over the whole interval
+                r = orc.eval_f_g_grad(pcf, nd[sub], wq[sub], shc, True)
+                cpu_infid = r["last_infidelity"]
+            times.append(time.perf_counter() - t1)
+        pc.Hconst = H0
+        tcpu = float(np.median(times)) * (nq / ncpu)
+        entry["cpu_baseline"] = {"value": nq / tcpu, "unit": "evals/s", "cores": 1, "kind": "port", "seconds_per_evaluation": tcpu,
+                                 "sample": ("median of %d x one traceobjgrad (C restatement of the reference's Stormer-Verlet path, one thread)" % reps) if nq == 1 else
+                                           ("%d of the %d quadrature nodes (spread over the interval), one eval_f_g_grad loop on one thread, time "
+                                            "scaled by %d / %d" % (ncpu, nq, nq, ncpu))}
+        entry["gpu_over_cpu_1core"] = tcpu / (tc["ms_total"] * 1e-3)
+        if nq == 1:      # the same evaluation on both sides: a live parity check of the line's own numbers
+            entry["infidelity_gpu_vs_cpu_rel_diff"] = abs(gpu_infid - cpu_infid) / max(abs(cpu_infid), 1e-300)
+        # ---- bound: latency of the dependent chain --------------------------------------------------------------
+        if tc["kernel_family"] == 3 and chain:
+            npj = int(tc["kernel_size"])
+            nwaves = -(-(nq * N) // 4)
+            split = 2 * nwaves <= (4 if npj > 8 else 12) * ncu      # run_eval_impl: the backward sweep's two chains on two waves
+            prods = 8 + 2 * m                                        # dependent products of one Stormer-Verlet step (DESIGN.md section 3)
+            clk_f = tc["ms_forward"] * 1e-3 * 2.4e9 / (nsteps * prods)
+            clk_b = tc["ms_backward"] * 1e-3 * 2.4e9 / (nsteps * prods * (1 if split else 2))
+            # two interleaved chains of NPJ / 2 links each (two_chains clk per instruction, NPJ instructions) + the add that joins them
+            bound = npj * chain["two_chains"] + chain["one_chain"]
+            entry["bound"] = {"kind": "latency of the dependent fp64 FMA chain of a lone wave (no MFMA percentage at Ntot <= 16: SURVEY.md 8(d))",
+                              "dependent_products_per_step_and_chain": prods, "row_length_NPJ": npj,
+                              "backward_chains_on_two_waves": bool(split),
+                              "clk_per_dependent_product_forward": clk_f, "clk_per_dependent_product_backward": clk_b,
+                              "chain_latency_bound_clk_per_product": bound,
+                              "frac_forward": bound / clk_f, "frac_backward": bound / clk_b,
+                              "probe": chain,
+                              "note": "bound = NPJ x (clk per link of two interleaved dependent v_fmac_f64 chains) + one dependent add; the "
+                                      "remainder is operand loads, the leak / trace reductions of a step, s_nop hazard slots and loop "
+                                      "branches (a taken branch costs a lone wave 20 .. 120 clk)"}
+        # the same with the implicit-midpoint integrator (the default of the reference's example scripts)
+        if cname != "rabi":
+            pmc_ = copy.copy(pc)
+            pmc_.Integrator_id = jq.Implicit_Midpoint
+            pmc_.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER_M, max_iter=100, tol=1e-12, nrhs=pmc_.N)
+            wmc = jq.Working_Arrays_M_HIP(pmc_, pcf.size)
+            for _ in range(2):
+                jq.eval_f_g_grad(pcf, pmc_, wmc, nd, wq, True, shift=shc)
+            entry["ms_per_evaluation_implicit_midpoint"] = wmc.last_timing()["ms_total"]
+            wmc.close()
+        cfgs[cname] = entry
+    cfgs["cnot3"] = "the bench line itself (value / roofline / cpu_baseline; single_evaluation for one sample)"
+    return cfgs
 
 
 _T0 = time.perf_counter()
@@ -298,7 +431,7 @@ def main():
     ngpus = args.gpus                                  # GPUs of the whole job
     # TEST MODE of jq_create_multi (include/juqbox_hip.h): the sub-handles share the visible GPU(s), the all-reduce is a host-side
     # sum -- the line is labelled as such and is NOT a multi-GPU measurement; it exists so that this reporting code runs on a one-GPU box
-    same_device = args.single_process and os.environ.get("JQ_MULTI_SAME_DEVICE", "0") not in ("", "0")
+    same_device = args.single_process and "multi_same_device=1" in os.environ.get("JQ_OPTIONS", "").replace(" ", "")
     if args.single_process:
         if ndev_visible < (1 if same_device else ngpus):
             sys.stderr.write("bench.py: --gpus %d requested but only %d GPU(s) are visible\n" % (ngpus, ndev_visible))
@@ -397,14 +530,16 @@ def main():
                     "per_rank_ms": {"min": per_rank[0], "max": per_rank[1]}, "allreduce_ms": sum(ar_ms) / max(len(ar_ms), 1),
                     "kernel_family": tms2[-1]["kernel_family"], "note": note}
         strong = strong_point(args.strong_samples, "fixed ensemble, block-partitioned over the GPUs, one all-reduce; compare "
-                              "evals_per_s across n_gpus.  Saturating: every GPU keeps >= one full round (3 072 samples) up to 8 GPUs")
+                              "evals_per_s across n_gpus.  Saturating: every GPU keeps >= one full round (3 072 samples) up to 8 GPUs: "
+                              "predicted speed-up at 8 GPUs 8 x (a rank's share is exactly the weak-scaling workload of `value`)")
         _trace("strong-scaling run done")
         # the domain of north_star's '>= 6x at 8 GPUs' made explicit: a fixed ensemble that does NOT saturate 8 GPUs.  One GPU
         # needs 1.5 rounds of the throughput kernels; 8 GPUs run 512 samples each in the latency regime (one time loop's
         # latency), so the speed-up is bounded by (time of 4 096 on one GPU) / (latency of one 512-sample round) ~ 4-5 x
         strong_small = strong_point(args.strong_small_samples, "SUB-SATURATING fixed ensemble: at 8 GPUs each rank holds 512 samples "
-                                    "and runs at the latency of one time loop; expected speed-up at 8 GPUs ~ 4-5 x, not 8 x "
-                                    "(DESIGN.md section 7)")
+                                    "and runs at the latency of one time loop; predicted speed-up at 8 GPUs = this time / the 512-sample "
+                                    "time of mid_size_ensembles ~ 4.8 x, not 8 x; the SWAP-02 risk-neutral ensemble of BASELINE config 5 "
+                                    "(512 nodes): ~ 1 x (baseline_configs.swap02_rn.strong_scaling_prediction_8_gpus; DESIGN.md section 8)")
         _trace("small strong-scaling run done")
 
     if rank == 0:
@@ -533,14 +668,17 @@ def main():
                           "samples_per_gpu": args.samples_per_gpu, "columns_per_gpu": args.samples_per_gpu * N,
                           "svts_per_step_all_gpus": nsamples_total * N * nsteps, "parallelism": "ensemble-dp%d" % ngpus,
                           "launcher": ("TEST MODE same-device: one process, %d sub-handles of jq_create_multi on %d physical GPU(s), "
-                                       "host-side sum in place of the all-reduce (JQ_MULTI_SAME_DEVICE=1) -- not a multi-GPU measurement"
+                                       "host-side sum in place of the all-reduce (JQ_OPTIONS=multi_same_device=1) -- not a multi-GPU measurement"
                                        % (wa.num_devices, ndev_visible)) if same_device else
                                       ("one process, %d devices behind one jq_create_multi handle (RCCL all-reduce inside the "
                                        "library)" % wa.num_devices) if args.single_process else
                                       ("torch.distributed: %d rank(s), one process per GPU, backend %s"
                                        % (dist.get_world_size(), dist.get_backend()) if dist is not None else "one process, one GPU"),
-                          "ranks": world, "rccl_world_size": dist.get_world_size() if dist is not None else
-                                      (wa.num_devices if args.single_process else 1)},
+                          "ranks": world, "devices_behind_handle": wa.num_devices,
+                          # what the collective library itself reports: torch.distributed's world size, or ncclCommCount of the
+                          # library's own communicator (--single-process; 0 in the same-device test mode, which has none)
+                          "rccl_world_size": dist.get_world_size() if dist is not None else
+                                      (wa.rccl_world_size if args.single_process else 1)},
                "svts_per_s": nsamples_total * N * nsteps * args.steps / elapsed,
                "ensemble_infidelity": infid_weak,
                "per_rank_ms": per_rank_ms, "allreduce_ms": allreduce_ms,
@@ -631,44 +769,16 @@ def main():
             _trace("latency / other batch sizes done")
             try:
                 out["dense_operator"] = dense_operator_block(jq, L, pcof)
+                # north_star's sentence (">= 40 % fp64-MFMA utilisation on the H x state-batch kernel") is about THIS formulation: its
+                # roofline object is a sibling of `roofline` (which is the structured kernel the headline `value` runs on)
+                out["roofline_dense"] = dict(out["dense_operator"]["roofline"], workload=out["dense_operator"]["workload"],
+                                             evals_per_s=out["dense_operator"]["evals_per_s"])
             except Exception as e:  # noqa: BLE001  (a side measurement)
                 out["dense_operator"] = {"error": repr(e)[:300]}
             _trace("dense operator done")
-            # the other BASELINE.json configurations (parity-test cases, not bench lines): time of one evaluation on this GPU --
-            # single samples and, for the risk-neutral SWAP-02 case, its 512-node ensemble; Ntot <= 16: VALU row-lane kernels,
-            # no MFMA percentage is quoted
+            # the other BASELINE.json configurations (parity-test cases, not bench lines): see baseline_configs_block
             try:
-                cfgs = {}
-                for cname, nq in (("cnot1", 1), ("cnot2", 1), ("swap02_rn", 512)):
-                    pc, ic = jq.cases.BUILDERS[cname]()
-                    if ic.get("golden"):
-                        gj = json.load(open(os.path.join(ROOT, "tests", "golden", "%s.json" % ic["golden"])))
-                        pcf = np.array(gj["pcof0"]) if "pcof0" in gj else ic["pcof0"]
-                    else:
-                        pcf = ic["pcof0"]
-                    wc = jq.Working_Arrays_HIP(pc, pcf.size)
-                    if nq == 1:
-                        nd, wq, shc = np.zeros(1), np.ones(1), None
-                    else:
-                        xq, wq = np.polynomial.legendre.leggauss(nq)
-                        nd, wq, shc = xq * 0.5 * 2 * np.pi * 2e-2, wq * 0.5, pc.shift_weights_reference()
-                    for _ in range(2):
-                        jq.eval_f_g_grad(pcf, pc, wc, nd, wq, True, shift=shc)
-                    tc = wc.last_timing()
-                    cfgs[cname] = {"Ntot": int(pc.Ntot), "nsteps": int(pc.nsteps), "samples": nq, "ms_per_evaluation": tc["ms_total"],
-                                   "svts_per_s": tc["svts"] / (tc["ms_total"] * 1e-3), "kernel_family": tc["kernel_family"]}
-                    wc.close()
-                    # the same with the implicit-midpoint integrator (the default of the reference's example scripts)
-                    import copy
-                    pmc_ = copy.copy(pc)
-                    pmc_.Integrator_id = jq.Implicit_Midpoint
-                    pmc_.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER_M, max_iter=100, tol=1e-12, nrhs=pmc_.N)
-                    wmc = jq.Working_Arrays_M_HIP(pmc_, pcf.size)
-                    for _ in range(2):
-                        jq.eval_f_g_grad(pcf, pmc_, wmc, nd, wq, True, shift=shc)
-                    cfgs[cname]["ms_per_evaluation_implicit_midpoint"] = wmc.last_timing()["ms_total"]
-                    wmc.close()
-                out["baseline_configs"] = cfgs
+                out["baseline_configs"] = baseline_configs_block(jq, L, quick=False)
             except Exception as e:  # noqa: BLE001  (never let a side measurement take the bench line down)
                 out["baseline_configs"] = {"error": repr(e)}
             _trace("baseline configs done")

@@ -37,8 +37,11 @@ extern "C" {
  * jq_last_timing write past its struct.  History: 1 = round 1; 2 = jq_timing.mfma_backward, jq_problem.Hunc_ops / Rfreq;
  * 3 = jq_timing.ms_allreduce / ms_shard_min / ms_shard_max, jq_abi_version(), up to JQ_MAX_CONTROLS control Hamiltonians;
  * 4 = jq_problem.Hconst_csc / Hsym_csc / Hanti_csc (sparse operator storage), jq_csc, jq_update_hconst_csc, jq_update_wmat (full /
- *     complex leakage weights). */
-#define JQ_ABI_VERSION 4
+ *     complex leakage weights);
+ * 5 = per-handle options instead of environment variables (jq_create_opts, jq_create_multi_opts, jq_set_option, jq_get_option),
+ *     jq_timing.reserved renamed kernel_variant, jq_rccl_world_size; no size limits on Ntot, the number of control Hamiltonians or
+ *     the rank of a full weight matrix; full leakage weights with the Jacobi solver. */
+#define JQ_ABI_VERSION 5
 
 #define JQ_MAX_CONTROLS 16 /* control Hamiltonians per problem (Ncoupled or Nunc)                   */
 #define JQ_MAX_WRANK 16    /* largest rank of a full leakage-weight matrix (jq_update_wmat)         */
@@ -131,11 +134,12 @@ typedef struct jq_timing {
     int32_t kernel_size;    /* template size parameter: NT (16-row tiles) for 0/1, NP for 2, NPJ for 3       */
     int32_t kernel_band;    /* block band of the MFMA families (9 = JQ_BW_OD: diagonal off-diagonal blocks,
                                8 = JQ_BW_T4: 4x4 diagonal blocks + diagonal couplings, 7 = the same, quad layout) */
-    int32_t reserved;       /* variant of the backward sweep.  Family 8: workgroups (CUs) per column quad -- 3: state re-integration, adjoint
+    int32_t kernel_variant; /* variant of the backward sweep.  Family 8: workgroups (CUs) per column quad -- 3: state re-integration, adjoint
                                step and trace products pipelined over three workgroups (single evaluations, <= 80 cnot3 samples);
                                2: state re-integration | adjoint step + trace products (81 .. 128 samples); 22: more column quads than
                                CUs, backward sweep on k_backward_qsplit with two quads per workgroup.  Family 6: 24 = one slab per
-                               workgroup with the state and the adjoint chain of a quad on two waves (k_backward_qsplit).  Else 0 */
+                               workgroup with the state and the adjoint chain of a quad on two waves (k_backward_qsplit).  Family 3: 32 = the backward
+                               sweep's state and adjoint chain on two waves (k_backward_rowlane2).  Else 0 */
     int64_t mfma_backward;  /* the part of mfma_executed issued by the k_backward launches                  */
     double ms_allreduce;    /* multi-device handles: host wall time of the ONE all-reduce (group start .. result on the host);
                                0 for single-device handles (their caller runs the collective)                  */
@@ -149,6 +153,27 @@ int jq_set_device(int device);
 /* Replaces: objparams(...) constructor + Working_Arrays(params, nCoeff) (src/evalobjgrad.jl:152-343,
  * :405-440): validates sizes, uploads the operators as MFMA A-fragment tile images. */
 int jq_create(const jq_problem *problem, jq_handle **out);
+/*
+ * The same with OPTIONS for the new handle: "name=value,name=value" (integers; ',', ';' or blanks separate; NULL or "" = none).
+ * Options replace the JQ_* environment variables of ABI <= 4: they belong to ONE handle, are parsed once, and nothing in the
+ * environment changes kernel selection behind the caller's back any more.  The defaults are the measured optimum; options exist for
+ * tests (kernel variants that must agree bit for bit), bisection and experiments -- a production caller passes none.  The table of
+ * names is in INTEGRATION.md section 4 (generated from juqbox.jl_amd/csrc/jq_options.h).  The ONE environment variable that still
+ * reaches kernel selection is JQ_OPTIONS (same syntax, applied in front of `options`): for callers that cannot pass a string, e.g. an
+ * unmodified script.  Errors: JQ_EINVAL for an unknown name or a malformed string (message: jq_last_error(NULL)); options that exist
+ * in experiment builds only (-DJQ_EXPERIMENTS) are refused by a release library.
+ */
+int jq_create_opts(const jq_problem *problem, const char *options, jq_handle **out);
+/*
+ * Change one option of a handle (multi-device handles: of every device).  Options that shape the plan (structure, kernel families,
+ * chunking: marked "plan" in the table) re-plan the handle in place -- same pointer, settings kept, like jq_update_hconst with a drift
+ * outside the planned structure; the others take effect with the next evaluation.  value == JQ_OPTION_DEFAULT: back to "not set".
+ * Errors: JQ_EINVAL unknown name; JQ_EUNSUPPORTED an experiment-only option in a release library.
+ */
+#define JQ_OPTION_DEFAULT INT64_MIN
+int jq_set_option(jq_handle *h, const char *name, int64_t value);
+/* the value in force (the default when the option is not set; JQ_OPTION_DEFAULT for an unset option without a default) */
+int jq_get_option(const jq_handle *h, const char *name, int64_t *value);
 void jq_destroy(jq_handle *h);
 /* Message of the last failing call on `h` (h == NULL: last jq_create failure of this thread). */
 const char *jq_last_error(const jq_handle *h);
@@ -164,12 +189,17 @@ const char *jq_last_error(const jq_handle *h);
  *   jq_set_* / jq_update_* apply to every device.
  * librccl.so is loaded at run time by this call (JQ_EUNSUPPORTED if it cannot be found); single-device users never
  * need it.  Errors: JQ_EINVAL if ndev < 1, ndev > jq_device_count() or a device id repeats.
- * JQ_RCCL_LIB=<path> makes this call load exactly that librccl.
- * TEST MODE: with JQ_MULTI_SAME_DEVICE=1 in the environment the `ndev` (<= 16) sub-handles may share physical GPUs (ids modulo
+ * The environment variable JQ_RCCL_LIB=<path> makes this call load exactly that librccl.
+ * TEST MODE: with the option multi_same_device=1 (jq_create_multi_opts, or JQ_OPTIONS) the `ndev` (<= 16) sub-handles may share physical GPUs (ids modulo
  * the visible count) and the all-reduce is replaced by a host-side sum in device order -- host threads, streams, sharding and
  * packing are the production code.  It exists so that the ndev > 1 paths run on a one-GPU box (tests/test_gpu_round3.py).
  */
 int jq_create_multi(const jq_problem *problem, const int32_t *devices, int32_t ndev, jq_handle **out);
+/* ... with options (jq_create_opts) for every device's handle; multi_same_device=1 selects the TEST MODE below */
+int jq_create_multi_opts(const jq_problem *problem, const int32_t *devices, int32_t ndev, const char *options, jq_handle **out);
+/* ranks of the RCCL communicator behind a multi-device handle (ncclCommCount): ndev when RCCL saw every device; 0 for single-device
+ * handles and in the same-device test mode (no communicator) */
+int jq_rccl_world_size(const jq_handle *h);
 /* number of GPUs behind a handle (1 for jq_create handles) */
 int jq_num_devices(const jq_handle *h);
 /* compute units of the handle's GPU (256 on MI355X): the granularity of the batch-size staircase -- one round of the throughput

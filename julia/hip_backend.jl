@@ -63,15 +63,15 @@ struct JQTiming                           # == jq_timing
     kernel_family::Int32
     kernel_size::Int32
     kernel_band::Int32
-    reserved::Int32
+    kernel_variant::Int32
     mfma_backward::Int64
     ms_allreduce::Float64
     ms_shard_min::Float64
     ms_shard_max::Float64
 end
 
-# the struct layouts above are those of JQ_ABI_VERSION 4 of include/juqbox_hip.h: refuse a library built for another one
-const JQ_ABI_VERSION = 4
+# the struct layouts above are those of JQ_ABI_VERSION 5 of include/juqbox_hip.h: refuse a library built for another one
+const JQ_ABI_VERSION = 5
 function jq_check_abi()
     v = ccall((:jq_abi_version, libjq), Cint, ())
     v == JQ_ABI_VERSION || error("libjuqbox_hip has ABI version $v, hip_backend.jl was written for $JQ_ABI_VERSION")
@@ -117,7 +117,8 @@ function push_weights!(wa::Working_Arrays_M_HIP, params)
     jqcheck(wa, ccall((:jq_update_wmat_diag, libjq), Cint, (Ptr{Cvoid}, Ptr{Float64}), wa.handle, wd))
 end
 
-function jq_new_handle(params, devices)
+# options: "name=value,name=value" for jq_create_opts (INTEGRATION.md section 4) -- per handle, parsed once; "" = none (production)
+function jq_new_handle(params, devices, options::AbstractString = "")
     jq_check_abi()
     Ntot = params.N + params.Nguard
     # use_sparse = true (src/evalobjgrad.jl:249-262): Hconst, Hsym_ops, Hanti_ops are SparseMatrixCSC{Float64,Int64}; their
@@ -146,31 +147,46 @@ function jq_new_handle(params, devices)
                          sparse ? pointer(c0) : Ptr{JQCsc}(C_NULL), sparse ? pointer(cs) : Ptr{JQCsc}(C_NULL),
                          sparse ? pointer(ca) : Ptr{JQCsc}(C_NULL))
         if devices === nothing
-            rc = ccall((:jq_create, libjq), Cint, (Ref{JQProblem}, Ref{Ptr{Cvoid}}), prob, h)
+            rc = isempty(options) ? ccall((:jq_create, libjq), Cint, (Ref{JQProblem}, Ref{Ptr{Cvoid}}), prob, h) :
+                                    ccall((:jq_create_opts, libjq), Cint, (Ref{JQProblem}, Cstring, Ref{Ptr{Cvoid}}), prob, options, h)
         else
             devs = devices isa Integer ? collect(Int32, 0:devices-1) : collect(Int32, devices)
-            rc = ccall((:jq_create_multi, libjq), Cint, (Ref{JQProblem}, Ptr{Int32}, Int32, Ref{Ptr{Cvoid}}),
-                       prob, devs, length(devs), h)
+            rc = isempty(options) ? ccall((:jq_create_multi, libjq), Cint, (Ref{JQProblem}, Ptr{Int32}, Int32, Ref{Ptr{Cvoid}}),
+                                          prob, devs, length(devs), h) :
+                                    ccall((:jq_create_multi_opts, libjq), Cint, (Ref{JQProblem}, Ptr{Int32}, Int32, Cstring, Ref{Ptr{Cvoid}}),
+                                          prob, devs, length(devs), options, h)
         end
     end
     rc == 0 || error(jq_create_error())
     return h[]
 end
 
-function Working_Arrays_HIP(params::objparams, nCoeff::Int64; devices = nothing)
+function Working_Arrays_HIP(params::objparams, nCoeff::Int64; devices = nothing, options::AbstractString = "")
     @assert params.linear_solver.solver_id in (NEUMANN_SOLVER, JACOBI_SOLVER)
-    wa = Working_Arrays_HIP(jq_new_handle(params, devices), zeros(nCoeff))
+    wa = Working_Arrays_HIP(jq_new_handle(params, devices, options), zeros(nCoeff))
     finalizer(w -> ccall((:jq_destroy, libjq), Cvoid, (Ptr{Cvoid},), w.handle), wa)
     return wa
 end
-function Working_Arrays_M_HIP(params::objparams, nCoeff::Int64; devices = nothing)
+function Working_Arrays_M_HIP(params::objparams, nCoeff::Int64; devices = nothing, options::AbstractString = "")
     @assert params.linear_solver.solver_id == JACOBI_SOLVER_M
-    wa = Working_Arrays_M_HIP(jq_new_handle(params, devices), zeros(nCoeff))
+    wa = Working_Arrays_M_HIP(jq_new_handle(params, devices, options), zeros(nCoeff))
     finalizer(w -> ccall((:jq_destroy, libjq), Cvoid, (Ptr{Cvoid},), w.handle), wa)
     return wa
 end
 
 num_devices(wa::AbstractWorkingArraysHIP) = ccall((:jq_num_devices, libjq), Cint, (Ptr{Cvoid},), wa.handle)
+# ranks of the RCCL communicator behind a multi-device handle (ncclCommCount; 0: single device)
+rccl_world_size(wa::AbstractWorkingArraysHIP) = ccall((:jq_rccl_world_size, libjq), Cint, (Ptr{Cvoid},), wa.handle)
+# options of a live handle (INTEGRATION.md section 4); value = nothing: back to "not set"
+function set_option!(wa::AbstractWorkingArraysHIP, name::AbstractString, value)
+    v = value === nothing ? typemin(Int64) : Int64(value)      # JQ_OPTION_DEFAULT
+    jqcheck(wa, ccall((:jq_set_option, libjq), Cint, (Ptr{Cvoid}, Cstring, Int64), wa.handle, name, v))
+end
+function get_option(wa::AbstractWorkingArraysHIP, name::AbstractString)
+    v = Ref{Int64}(0)
+    ccall((:jq_get_option, libjq), Cint, (Ptr{Cvoid}, Cstring, Ref{Int64}), wa.handle, name, v) == 0 || error("hip_backend: unknown option $name")
+    return v[] == typemin(Int64) ? nothing : v[]
+end
 num_compute_units(wa::AbstractWorkingArraysHIP) = ccall((:jq_num_compute_units, libjq), Cint, (Ptr{Cvoid},), wa.handle)
 function plan_info(wa::AbstractWorkingArraysHIP)      # JSON text: structure, control groups, batch-size thresholds of the kernel families
     n = ccall((:jq_plan_info, libjq), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Int32), wa.handle, C_NULL, 0)

@@ -15,6 +15,7 @@ c_dp = ctypes.POINTER(ctypes.c_double)
 c_i32 = ctypes.c_int32
 
 JQ_OK, JQ_EINVAL, JQ_EDIM, JQ_EUNSUPPORTED, JQ_EHIP, JQ_ENOMEM = 0, -1, -2, -3, -4, -5
+JQ_OPTION_DEFAULT = -2 ** 63      # jq_set_option: back to "not set"
 
 
 class jq_csc(ctypes.Structure):
@@ -36,11 +37,11 @@ class jq_timing(ctypes.Structure):
                 ("ms_forward", ctypes.c_double), ("ms_backward", ctypes.c_double),
                 ("n_forward_launches", ctypes.c_int64), ("n_backward_launches", ctypes.c_int64), ("mfma_executed", ctypes.c_int64), ("svts", ctypes.c_int64),
                 ("kernel_family", ctypes.c_int32), ("kernel_size", ctypes.c_int32), ("kernel_band", ctypes.c_int32),
-                ("reserved", ctypes.c_int32), ("mfma_backward", ctypes.c_int64),
+                ("kernel_variant", ctypes.c_int32), ("mfma_backward", ctypes.c_int64),
                 ("ms_allreduce", ctypes.c_double), ("ms_shard_min", ctypes.c_double), ("ms_shard_max", ctypes.c_double)]
 
 
-JQ_ABI_VERSION = 4      # the struct layouts above (include/juqbox_hip.h JQ_ABI_VERSION); load() refuses any other library
+JQ_ABI_VERSION = 5      # the struct layouts above (include/juqbox_hip.h JQ_ABI_VERSION); load() refuses any other library
 
 
 # every symbol include/juqbox_hip.h declares: name -> (restype, argtypes)
@@ -48,6 +49,9 @@ SYMBOLS = {
     "jq_device_count": (ctypes.c_int, []),
     "jq_set_device": (ctypes.c_int, [ctypes.c_int]),
     "jq_create": (ctypes.c_int, [ctypes.POINTER(jq_problem), ctypes.POINTER(ctypes.c_void_p)]),
+    "jq_create_opts": (ctypes.c_int, [ctypes.POINTER(jq_problem), ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]),
+    "jq_set_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64]),
+    "jq_get_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]),
     "jq_destroy": (None, [ctypes.c_void_p]),
     "jq_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
     "jq_set_neumann_terms": (ctypes.c_int, [ctypes.c_void_p, c_i32]),
@@ -67,6 +71,9 @@ SYMBOLS = {
     "jq_eval_f_g_grad_dev": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_i32, c_dp, c_dp, c_i32, c_dp, c_i32, ctypes.c_void_p]),
     "jq_create_multi": (ctypes.c_int, [ctypes.POINTER(jq_problem), ctypes.POINTER(ctypes.c_int32), c_i32,
                                        ctypes.POINTER(ctypes.c_void_p)]),
+    "jq_create_multi_opts": (ctypes.c_int, [ctypes.POINTER(jq_problem), ctypes.POINTER(ctypes.c_int32), c_i32, ctypes.c_char_p,
+                                            ctypes.POINTER(ctypes.c_void_p)]),
+    "jq_rccl_world_size": (ctypes.c_int, [ctypes.c_void_p]),
     "jq_num_devices": (ctypes.c_int, [ctypes.c_void_p]),
     "jq_handle_device": (ctypes.c_int, [ctypes.c_void_p]),
     "jq_num_compute_units": (ctypes.c_int, [ctypes.c_void_p]),

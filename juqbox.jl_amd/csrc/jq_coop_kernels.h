@@ -19,7 +19,8 @@
 
 // BW == JQ_BW_OD (jq_kernels.h): the window is the row's own diagonal block (4 MFMA tiles); the two neighbouring
 // blocks are diagonal matrices, stored as 2 x 16 coefficients behind the tiles and applied with 8 FMAs.
-__host__ __device__ constexpr int coop_nb(int NT, int BW) { return (BW == JQ_BW_OD) ? 1 : ((2 * BW + 1 < NT) ? 2 * BW + 1 : NT); }
+// (band code 15 = dense for every NT: NT > 16 -- jq_huge_kernels.h -- must not get a 31-block window out of it)
+__host__ __device__ constexpr int coop_nb(int NT, int BW) { return (BW == JQ_BW_OD) ? 1 : (BW == 15) ? NT : ((2 * BW + 1 < NT) ? 2 * BW + 1 : NT); }
 __host__ __device__ constexpr int coop_row_elems(int NT, int BW) { return 4 * coop_nb(NT, BW) * 64 + (BW == JQ_BW_OD ? 32 : 0); }
 __host__ __device__ constexpr int coop_kb0(int NT, int BW, int mt)
 {
@@ -285,7 +286,7 @@ struct CoopW {
         r = a.wrank;
         stride = a.wstride;
         lamp = a.wlr;
-        tab = a.wlr + JQ_MAX_WRANK + 16 * wave_ + (lane_ >> 4);
+        tab = a.wlr + a.wlam + 16 * wave_ + (lane_ >> 4);
         xch = lds;
         par = 0;
         wave = wave_;

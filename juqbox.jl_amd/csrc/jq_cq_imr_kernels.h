@@ -732,6 +732,7 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq_imr3(PropArgs a)
     const CqSetup<NT> s = cq_setup<NT>(a, quad >> 2, quad & 3);
     const int Nc = a.Ncoupled, ntr = Nc * JQ_NTR, nst = a.nsteps_chunk;
     const size_t trow = ((size_t)s.slab * a.qps + s.qd) * NT;      // first of my evaluation's NT record rows
+    cq3_arrive(a);      // (start-up rendezvous of the whole grid: jq_cq_split_kernels.h)
     if (s.slab >= a.nslabs) return;
     if (!s.active) {
         if (role == 2 && s.qd < a.qps)
@@ -740,7 +741,11 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq_imr3(PropArgs a)
     }
     Cq3Hand<NT> hd;
     hd.init(a, (size_t)quad, s.lane_);
-    // (test hook as in k_backward_cq3: JQ_DEBUG bit 16 / 32 -- the consumer roles / the state role start ~ 5 ms late; results unchanged)
+    {
+        extern __shared__ __attribute__((aligned(16))) char smem_rdv[];      // (the window ring at the start of the LDS is not in use yet)
+        if (!cq3_rendezvous(a, (int*)smem_rdv)) return;
+    }
+    // (test hook as in k_backward_cq3: option debug bit 16 / 32 -- the consumer roles / the state role start ~ 5 ms late; results unchanged)
     if ((a.debug & 16) && role != 0)
         for (int i = 0; i < 1500; ++i) __builtin_amdgcn_s_sleep(127);
     if ((a.debug & 32) && role == 0)

@@ -30,9 +30,40 @@
 #define JQ_CQ3_ARRAYS 8       // u (vr before the state step), v05, un, X, nbn (-lambda_i new), Bq (-(li0 + li)); full weights: the blocks' partial dots with v05, un (CqW::part)
 #define JQ_CQ3_TAIL 64        // doubles behind a quad's ring: full weights, the dots with the state the chunk starts from (written once per launch, see below)
 #define JQ_CQ3_HEAD 64        // doubles in front of a quad's ring: [0] steps of role 0, [8] role 1, [16] role 2, [24] error, [32 + r] XCC of role r
-#define JQ_CQ3_SPIN 1000000   // polls (with s_sleep; ~ 1.3 us each: ~ 1.3 s) before a wait is declared dead.  Round 5 tried 150 000 (~ 0.2 s): next to a
-                              // process whose launches hold every CU for 0.15 - 0.37 s (the throughput kernels) a role legitimately waits that long for its
-                              // partners to become resident -- more faults, longer cool-downs, 58 s instead of 50 s for the soak of profiles/r05_cq3_soak_load.txt
+// Waiting.  Rounds 4 - 5 HOPED that the workgroups of a quad were resident together and policed it with one long timeout per wait
+// (1 000 000 polls ~ 1.3 s: next to a process whose launches hold every CU for 0.15 - 0.37 s a role legitimately waited that long for its
+// partners to START).  Round 6 separates the two questions.  (1) Are all workgroups of this launch resident?  Answered once, at the start,
+// by a rendezvous of the WHOLE grid (cq3_rendezvous): every workgroup counts itself in and waits at most a.rdv_polls polls (default 10 ms)
+// for the count to reach gridDim.x; otherwise the launch is abandoned at once with error word 3 and the host repeats the evaluation on
+// the one-workgroup kernel -- a busy GPU costs milliseconds, not a dead wait.  (2) After a passed rendezvous every partner IS resident
+// and stays so (workgroups are not preempted), so a wait between roles can only be a short one; a.wait_polls (the host passes ~ 10 x the
+// launch's expected duration) is a guard against the impossible, not a scheduling assumption.
+__device__ __forceinline__ void cq3_arrive(const PropArgs& a)      // (workgroups without work count too: the grid must be complete)
+{
+    if (threadIdx.x == 0) __hip_atomic_fetch_add((unsigned long long*)a.park + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// call from every wave of the workgroup that is still alive, after cq3_arrive; flag: one int of LDS nobody uses yet.  True: proceed.
+__device__ __forceinline__ bool cq3_rendezvous(const PropArgs& a, int* flag)
+{
+    unsigned long long* gerr = (unsigned long long*)a.park;
+    if (threadIdx.x == 0) {
+        int ok = 0;
+        for (int k = 0; k < a.rdv_polls; ++k) {
+            if (__hip_atomic_load(gerr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)gridDim.x) {
+                ok = 1;
+                break;
+            }
+            if (__hip_atomic_load(gerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) break;      // somebody gave up already
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (!ok) __hip_atomic_store(gerr, 3ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = ok;
+    }
+    __syncthreads();
+    const bool ok = *flag != 0;
+    __syncthreads();
+    return ok;
+}
 
 template <int NT>
 struct Cq3Hand {
@@ -40,6 +71,7 @@ struct Cq3Hand {
     unsigned long long *head, *gerr;
     bool dead;                        // (wave-uniform) a wait of this quad timed out, or the workgroups do not share an XCD
     unsigned long long seen, pend;    // the upstream role's counter: last value known / value asked for by the previous wait
+    int spin;                         // polls before a wait is declared dead (a.wait_polls)
     static constexpr size_t SLOT = (size_t)JQ_CQ3_ARRAYS * NT * 64;
 
     __device__ __forceinline__ void init(const PropArgs& a, size_t quad, int lane_)
@@ -50,6 +82,7 @@ struct Cq3Hand {
         ring = base + JQ_CQ3_HEAD + lane_;
         dead = false;
         seen = 0ull, pend = 0ull;
+        spin = a.wait_polls;
     }
     // the quad's tail area (this lane's element)
     __device__ __forceinline__ double* tail() const { return ring + JQ_CQ3_SLOTS * SLOT; }
@@ -79,7 +112,7 @@ struct Cq3Hand {
         if (pend > seen) seen = pend;
         if (seen < steps) {
             bool ok = false;
-            for (int k = 0; k < JQ_CQ3_SPIN; ++k) {
+            for (int k = 0; k < spin; ++k) {
                 seen = __hip_atomic_load(head + 8 * role, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (seen >= steps) {
                     ok = true;
@@ -132,6 +165,7 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
     const CqSetup<NT> s = cq_setup<NT>(a, quad >> 2, quad & 3);
     const int Nc = a.Ncoupled;
     const size_t trow = (size_t)s.slab * a.qps + s.qd;
+    cq3_arrive(a);
     if (s.slab >= a.nslabs) return;
     if (!s.active) {
         if (role == NR - 1 && s.qd < a.qps)
@@ -147,7 +181,8 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
     Cq3Hand<NT> hd;
     hd.init(a, (size_t)quad, lane_);
     const int nst = a.nsteps_chunk;
-    // TEST HOOK (JQ_DEBUG bit 16 / 32; results unchanged): the consumer roles / the state role start ~ 5 ms late -- on an idle GPU the roles
+    if (!cq3_rendezvous(a, (int*)smem)) return;      // (the window ring at the start of the LDS is not in use yet)
+    // TEST HOOK (option debug bit 16 / 32; results unchanged): the consumer roles / the state role start ~ 5 ms late -- on an idle GPU the roles
     // of a quad start together and a hand-off that is only safe then passes every test (round 5: the first version of the full-weights
     // hand-off was one; next to load processes it was not).  With bit 16 role 0 runs ahead as far as the protocol lets it before
     // anybody reads; with bit 32 everybody waits for role 0.
@@ -344,7 +379,7 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
             //  when the adjoint workgroup has -- it publishes k once the loads of the steps <= k have landed in all its waves, so the slot of
             //  step n - 8 would be free at k = n - 8.  But k = 0 is also what the counter holds before that workgroup has started: the first
             //  version waited for n - 8 and, at step 8, overwrote the operands of step 0 of an adjoint workgroup that started late -- never
-            //  on an idle GPU, where the roles start together; found with the late-start hook JQ_DEBUG=16, tests/test_gpu_round5.py (8).
+            //  on an idle GPU, where the roles start together; found with the late-start hook option debug=16, tests/test_gpu_round5.py (8).
             //  One step more, as for NR = 3: the state role is at most 7 steps ahead instead of 8.)
             if (wave == 0 && n >= JQ_CQ3_SLOTS) hd.wait(NR - 1, (unsigned long long)(n - JQ_CQ3_SLOTS + 1));
             double un, v05, vN;

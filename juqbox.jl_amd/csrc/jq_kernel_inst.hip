@@ -117,6 +117,9 @@ template __global__ void k_backward<JQ_NT, JQ_BW, 1, false, true>(PropArgs);
 #elif JQ_VARIANT == 11              // slab kernels with the full leakage weights
 template __global__ void k_forward<JQ_NT, JQ_BW, JQ_MINW, false, true>(PropArgs);
 template __global__ void k_backward<JQ_NT, JQ_BW, JQ_MINW, false, true>(PropArgs);
+#elif JQ_VARIANT == 13              // ... with the Jacobi solver too (ABI 5)
+template __global__ void k_forward<JQ_NT, JQ_BW, JQ_MINW, true, true>(PropArgs);
+template __global__ void k_backward<JQ_NT, JQ_BW, JQ_MINW, true, true>(PropArgs);
 #elif JQ_BW == 7 && JQ_VARIANT == 8   // quad layout, workgroups of 4 / 8 waves (1 / 2 slabs): built with the max-ILP scheduler (Makefile)
 template __global__ void k_forward<JQ_NT, JQ_BW, 1, false>(PropArgs);
 template __global__ void k_backward<JQ_NT, JQ_BW, 1, false>(PropArgs);

@@ -998,7 +998,7 @@ struct PropArgs {
     unsigned long long pro_bits;       // entries of the prologue (backward first chunk)
     // Full / complex leakage weights (use_custom_forbidden, src/evalobjgrad.jl:214-232) in low-rank form
     //   W = wmat_real + i wmat_imag = sum_{k < wrank} lam_k f_k f_k^H ,  f_k = a_k + i b_k   (jq_update_wmat: eigen-decomposition)
-    // wlr (global memory, natural row order): lam[JQ_MAX_WRANK], then per k the rows a_k[wstride], b_k[wstride] (zero padded).
+    // wlr (global memory, natural row order): lam[wlam], then per k the rows a_k[wstride], b_k[wstride] (zero padded).
     // wrank == 0: Diagonal weights (the table wd); wrank > 0: wd is all zero and the kernels add the low-rank terms.
     const double* wlr;
     int wrank;
@@ -1008,6 +1008,12 @@ struct PropArgs {
     int jac_wg_lds;         // JAC slab kernels, N > 16 with one workgroup per sample (its <= 4 parts = waves): byte offset of the residual
                             // exchange [2][JQ_WAVES] doubles -- the stopping test then sums the parts like the reference; -1: per part
     int wcplx;              // cooperative-quad kernels (CqW): 0 = real weight matrix, the four slots are a_0 .. a_3; 1 = complex, rank <= 2: a_0, b_0, a_1, b_1
+    int wlam;               // lam slots in front of the rows of the low-rank table: max(JQ_MAX_WRANK, wrank) -- ranks beyond JQ_MAX_WRANK (slab, cooperative and
+                            // run-time-size kernels only; the row-lane and cooperative-quad kernels see rank <= 16 / <= 4 and the constant)
+    // Two- / three-workgroup latency kernels (jq_cq_split_kernels.h): polls of the start-up rendezvous (every workgroup of the launch announces
+    // itself and waits for all the others: co-residency is established before anybody depends on it) and of a wait between roles afterwards
+    int rdv_polls;
+    int wait_polls;
 };
 #ifndef JQ_MAX_WRANK
 #define JQ_MAX_WRANK 16       // largest rank of a full weight matrix the kernels take (include/juqbox_hip.h)
@@ -1043,7 +1049,7 @@ struct WLow {
     const double* lamp;     // lam[k]
     int r, stride;
     bool lead;      // one lane per column: adds the column's scalar terms to a per-lane partial sum
-    // Column scalars of the terms kept across uses and steps (quad layout, round 5 EXPERIMENT, off by default: host JQ_WLR_SC=1): the dots
+    // Column scalars of the terms kept across uses and steps (quad layout, round 5 EXPERIMENT, off by default: host option wlr_sc=1): the dots
     // of a step's vr(t_n), vi05 are needed at two sites of the adjoint step, and the dots with vr(t_n+1) ARE the previous step's dots with
     // vr(t_n) -- five dot pairs per term and step become two.  The rank is a run-time number, so the scalars live in LDS: [term][slot
     // 0 .. 5][column of the quad], written by the lead lanes.  Measured SLOWER (cnot3: 57 -> 70 ms per forbidden state): the LDS round
@@ -1064,12 +1070,12 @@ struct WLow {
         const double* base = a.wlr;
         if (r > 0 && a.wlr_lds >= 0) {
             double* l = (double*)(smem + a.wlr_lds);
-            for (int i = threadIdx.x; i < JQ_MAX_WRANK + 2 * r * stride; i += blockDim.x) l[i] = a.wlr[i];
+            for (int i = threadIdx.x; i < a.wlam + 2 * r * stride; i += blockDim.x) l[i] = a.wlr[i];
             __syncthreads();
             base = l;
         }
         lamp = base;
-        tab = base + JQ_MAX_WRANK + (QUAD ? 4 * ((lane_ >> 2) & 3) + (lane_ >> 4) : (lane_ >> 4));
+        tab = base + a.wlam + (QUAD ? 4 * ((lane_ >> 2) & 3) + (lane_ >> 4) : (lane_ >> 4));
         lead = QUAD ? lane_ < 4 : lane_ < 16;
         has_sc = QUAD && r > 0 && a.wlr_sc_lds >= 0;
         sc = (__attribute__((address_space(3))) double*)(smem + (has_sc ? a.wlr_sc_lds : 0)) + (size_t)(threadIdx.x >> 6) * (JQ_MAX_WRANK * 24) + (lane_ & 3);
@@ -1513,6 +1519,12 @@ __device__ __forceinline__ void jacobi_add(Arr<NT>& out, const Arr<NT>& bpa, con
         return;
     }
     if (jac_wg >= 0) {      // (one sample per workgroup: the same iteration count in every wave)
+        // The exchange buffer is chosen by the parity of the iteration, which starts again at 1 in every call: a call that stopped on an
+        // odd iteration is followed by a sum in the SAME buffer, and nothing but the barriers inside jacobi_wg_sum separates the calls
+        // of a time step (window staging has no barrier between operator uses).  A fast wave could then overwrite ex[1][wave] while a
+        // slow one still adds up the previous call's last sum -- different `done` decisions, barrier counts that no longer match.  One
+        // barrier at the entry closes it: every wave has finished reading the previous call's sums before any wave writes a new one.
+        __builtin_amdgcn_s_barrier();
         mm_c<NT, BW>(Ya, A, S, A);  // X_1
         bool in_a = true;
         bool done = jacobi_wg_sum(sample_sum(a_diff2(Ya, A), ncol), jac_wg, 1) < tol2;

@@ -13,6 +13,8 @@
 #include "jq_rowlane_kernels.h"
 #include "jq_rowlane_imr_kernels.h"
 #include "jq_coop_imr_kernels.h"
+#include "jq_huge_kernels.h"
+#include "jq_options.h"
 
 #include <rccl/rccl.h>   // types and prototypes only: librccl is loaded at run time by jq_create_multi (load_rccl)
 
@@ -39,6 +41,12 @@
 #endif
 
 static thread_local std::string g_create_error;
+// JQ_DEBUG_TIMING=1: every propagator launch's HIP-event time on stderr (development aid; changes no result and no kernel choice)
+static bool debug_timing()
+{
+    static const bool on = getenv("JQ_DEBUG_TIMING") != nullptr;
+    return on;
+}
 
 // build manifest (scripts/make_manifest.py -> build/manifest.c): {"<object tag>": {"vgpr_form": .., "fallback": .., "max_vgprs": ..,
 // "max_agprs": .., "max_scratch_bytes": ..}, ...} -- flat entries, quoted by jq_plan_info
@@ -46,6 +54,7 @@ extern "C" const char jq_build_manifest[];
 
 struct jq_handle {
     int device = 0;
+    JqOptions opt;              // per-handle options (jq_options.h): jq_create_opts / JQ_OPTIONS / jq_set_option
     hipStream_t stream = nullptr;
     // problem
     int Ntot = 0, N = 0, Nc = 0, Nfreq = 0, nsteps = 0, m = 0, objFuncType = 1;
@@ -63,7 +72,7 @@ struct jq_handle {
     // in K(t), S(t) (k_ctrl / k_stream are generic), only the gradient traces are per control -- the backward sweep then runs once
     // per GROUP of at most JQ_MAXNC controls (ctrl_groups(); 5 .. 8 controls: two sweeps), each with its own trace images.
     int NcK = 0;                // controls per backward sweep the LDS plan is made for: min(Nc, JQ_MAXNC)
-    int bw_trace[JQ_MAX_CONTROLS] = {0};
+    std::vector<int> bw_trace;  // [Nc]
     long long mat_elems = 0;    // doubles per operator image slot ("stride"): band tiles, padded to 1 KiB
     long long mat_elems_c = 0;  // ... in the row-window layout of the cooperative kernels (0: not available)
     bool coop_ok = false;       // the cooperative Stormer-Verlet kernels fit the LDS (dense 96 x 96: only the implicit-midpoint variant that reads its images from HBM)
@@ -75,6 +84,10 @@ struct jq_handle {
     int batch = 0;              // > 0: batched staging (K/S images of `batch` time steps per DMA burst); < 0: window staging
     bool big = false;           // Ntot > 96 (NT = 7 .. 16): only the cooperative kernels with operators read from HBM (jq_coop_kernels.h
                                 // OpCursor) exist -- Stormer-Verlet, Neumann solver, any batch size
+    bool huge = false;          // Ntot > 256 (more than 16 tile rows): the run-time-size kernels of jq_huge_kernels.h (one workgroup of 16 waves per slab,
+                                // every vector of a step in a global work area, dense tiles); a huge handle is also `big`
+    bool force_plain = false;   // full leakage weights WITH the Jacobi solver on a 4 x 4 x n plan whose kernels do not combine the two (one tile row,
+                                // or seven / eight): the handle is planned without that structure (cooperative / slab kernels that do)
     bool replanned = false;     // jq_update_hconst re-planned this handle (a later drift plans again when it violates the plan or regains a better structure)
     bool in_split = false;      // run_eval is evaluating one part of a split batch
     double* d_pk2 = nullptr;    // packed result of the first part of a split batch
@@ -96,6 +109,7 @@ struct jq_handle {
     // zero, Wr / Wi keep the caller's matrices (re-planning applies them again), wlr is the kernels' table
     // lam[JQ_MAX_WRANK] | a_k[NP], b_k[NP] per k in natural row order (PropArgs::wlr).
     int wrank = 0;
+    int wlam = JQ_MAX_WRANK;    // lam slots in front of the rows of the table: max(JQ_MAX_WRANK, wrank)
     std::vector<double> Wr, Wi, wlr;
     double* d_wlr = nullptr;
     bool wlr_real = false;      // every kept eigenvector is real (wmat_imag = 0): the cooperative-quad kernels take rank <= 4 of those
@@ -112,6 +126,9 @@ struct jq_handle {
     // for good after JQ_CQ3_MAX_FAULTS faults).
     bool cq3_off = false;       // never again on this handle (too many faults)
     int cq3_faults = 0;         // launches that reported a dead wait / workgroups on different XCDs
+    int cq3_busy = 0;           // launches abandoned at their start-up rendezvous (the GPU was busy: not every workgroup became resident in time)
+    int cq3_busy_streak = 0;    // ... in a row (sets the cool-down)
+    double cq3_us_per_step = 0.0;   // measured duration of a split backward launch per time step (sizes the in-launch wait guard)
     int cq3_skip = 0;           // evaluations left for which the split is not tried
     std::string cq3_last;       // why the last batch of the latency families did / did not take the split (jq_plan_info)
     double* d_qsplit = nullptr; // hand-off buffer of k_backward_qsplit (jq_quad_split_kernels.h): [quad][parity][2][NT][64]
@@ -139,7 +156,7 @@ struct jq_handle {
     // handle owns no device memory itself
     std::vector<jq_handle*> subs;
     std::vector<ncclComm_t> comms;
-    bool host_reduce = false;   // JQ_MULTI_SAME_DEVICE test mode: host-side sum instead of the ncclAllReduce (no communicators)
+    bool host_reduce = false;   // option multi_same_device test mode: host-side sum instead of the ncclAllReduce (no communicators)
     bool comm_broken = false;   // an RCCL call failed inside a collective: the communicators are aborted at destroy, calls refuse
     int rccl_checks = 0;        // all-reduces of this handle that were verified against the host-order sum (JQ_RCCL_SELFCHECK)
     std::vector<hipEvent_t> ev;
@@ -608,7 +625,7 @@ static int create_impl(const jq_problem* p, jq_handle* h)
     if (!p) return fail(h, JQ_EINVAL, "jq_create: problem is NULL");
     const bool sparse = (!p->Hconst && p->Hconst_csc) || (!p->Hsym_ops && p->Hsym_csc) || (!p->Hanti_ops && p->Hanti_csc);
     if (!sparse) return create_dense(p, h);
-    if (p->Ntot < 1 || p->Ntot > 256 || p->Ncoupled < 0 || p->Ncoupled > JQ_MAX_CONTROLS) return create_dense(p, h);      // (its messages)
+    if (p->Ntot < 1 || p->Ntot > 16384 || p->Ncoupled < 0 || p->Ncoupled > 4096) return create_dense(p, h);      // (its messages)
     const size_t nn = (size_t)p->Ntot * p->Ntot;
     std::vector<double> H0, Hs, Ha;
     jq_problem q = *p;
@@ -649,9 +666,9 @@ static int create_dense(const jq_problem* p, jq_handle* h)
         return fail(h, JQ_EINVAL, "jq_create: NULL array in problem description");
     const int nctrl = p->Nunc > 0 ? p->Nunc : p->Ncoupled;     // control pairs the kernels see
     if (nctrl < 1) return fail(h, JQ_EUNSUPPORTED, "jq_create: at least one control Hamiltonian is required");
-    if (nctrl > JQ_MAX_CONTROLS) return fail(h, JQ_EUNSUPPORTED, "jq_create: more than 16 control Hamiltonians are not supported");
-    if (p->Ntot > 256)
-        return fail(h, JQ_EUNSUPPORTED, "jq_create: Ntot > 256 (more than 16 tile rows = waves per 16-column slab)");
+    // (sanity bounds, not design limits: an Ntot x Ntot fp64 operator set of this size would not fit the device anyway)
+    if (nctrl > 4096) return fail(h, JQ_EINVAL, "jq_create: more than 4096 control Hamiltonians");
+    if (p->Ntot > 16384) return fail(h, JQ_EINVAL, "jq_create: Ntot > 16384");
     if (p->objFuncType < 1 || p->objFuncType > 3) return fail(h, JQ_EINVAL, "jq_create: objFuncType must be 1, 2 or 3");
 
     HIPCHK(h, hipGetDevice(&h->device));
@@ -668,6 +685,8 @@ static int create_dense(const jq_problem* p, jq_handle* h)
     h->m = p->neumann_terms; h->objFuncType = p->objFuncType; h->T = p->T;
     h->NT = (p->Ntot + 15) / 16;
     h->big = h->NT > 6;
+    h->huge = h->NT > 16;
+    h->bw_trace.assign(nctrl, 0);
     h->KT = 4 * h->NT;
     h->NP = 16 * h->NT;
     h->parts = p->N > 16 ? (p->N + 15) / 16 : 1;
@@ -709,17 +728,13 @@ static int create_dense(const jq_problem* p, jq_handle* h)
 
     // 4 x 4 x n structure with n = 7, 8 (Ntot 97 .. 128, e.g. cnot3 with more guard levels): the JQ_BW_T4 slab kernels and the
     // quad-layout kernels are instantiated for it -- such a handle is not "big" (no cooperative kernels, no cooperative-quad ones:
-    // their LDS images do not fit).  JQ_T4BIG=0: treat it like any other Ntot > 96.
-    if (h->big && h->NT <= 8) {
+    // their LDS images do not fit).  option t4big=0: treat it like any other Ntot > 96.
+    if (h->big && h->NT <= 8 && !h->force_plain) {
         bool t4 = block_band(h->Hconst.data(), h->Ntot) <= 1 && t4_structure(h->Hconst.data(), h->Ntot);
         for (int q = 0; q < h->Nc && t4; ++q)
             t4 = block_band(h->Hsym.data() + q * nn, h->Ntot) <= 1 && block_band(h->Hanti.data() + q * nn, h->Ntot) <= 1 &&
                  t4_structure(h->Hsym.data() + q * nn, h->Ntot) && t4_structure(h->Hanti.data() + q * nn, h->Ntot);
-        for (const char* name : {"JQ_T4", "JQ_OD", "JQ_T4BIG"})
-            if (const char* e = getenv(name))
-                if (atoi(e) == 0) t4 = false;
-        if (const char* e = getenv("JQ_FORCE_DENSE"))
-            if (atoi(e) != 0) t4 = false;
+        if (!h->opt.on(O_T4) || !h->opt.on(O_OD) || !h->opt.on(O_T4BIG) || h->opt.on(O_FORCE_DENSE)) t4 = false;
         if (t4) h->big = false;
     }
 
@@ -731,36 +746,28 @@ static int create_dense(const jq_problem* p, jq_handle* h)
             h->bw_trace[q] = bq;
             bw = std::max(bw, bq);
         }
-        if (const char* e = getenv("JQ_FORCE_DENSE"))
-            if (atoi(e) != 0) bw = h->NT - 1;
+        if (h->opt.on(O_FORCE_DENSE)) bw = h->NT - 1;
         h->BW = (bw <= 2 && bw < h->NT - 1) ? bw : h->NT - 1;
         if (h->big && h->BW == 0) h->BW = 1;      // (the big variants are instantiated for block bands 1, 2 and dense)
         // dense at this size = band code 15 (a full window for every NT <= 16): NT - 1 = 7, 8, 9 are the codes of the quad-layout,
         // JQ_BW_T4 and JQ_BW_OD structures -- round 2 instantiated <10, 9> as "dense" and got the JQ_BW_OD product (wrong results
         // for dense operators with Ntot 145 .. 160; found by the round-3 tests)
         if (h->big && h->BW > 2) h->BW = 15;
+        if (h->huge) h->BW = 15;      // (the run-time-size kernels know dense windows only)
         h->BWc = h->BW;
         // block tridiagonal with DIAGONAL off-diagonal blocks (operators of the slowest subsystem, cnot3):
-        // MFMA only for the diagonal blocks, 16 coefficients per off-diagonal block (JQ_OD=0 disables)
+        // MFMA only for the diagonal blocks, 16 coefficients per off-diagonal block (option od=0 disables)
         bool od = (!h->big && bw == 1 && h->NT >= 2 && offdiag_blocks_diagonal(h->Hconst.data(), h->Ntot));
         for (int q = 0; q < h->Nc && od; ++q)
             od = offdiag_blocks_diagonal(h->Hsym.data() + q * nn, h->Ntot) && offdiag_blocks_diagonal(h->Hanti.data() + q * nn, h->Ntot);
-        if (const char* e = getenv("JQ_OD"))
-            if (atoi(e) == 0) od = false;
-        if (const char* e = getenv("JQ_FORCE_DENSE"))
-            if (atoi(e) != 0) od = false;
+        if (!h->opt.on(O_OD) || h->opt.on(O_FORCE_DENSE)) od = false;
         if (od) h->BW = h->BWc = JQ_BW_OD;
         // ... and, one level finer, 4x4 diagonal blocks + diagonal couplings of neighbouring 4-row groups: the slab kernels
-        // use v_mfma_f64_4x4x4 (JQ_BW_T4; JQ_T4=0 disables); the cooperative kernels stay on the JQ_BW_OD variant
+        // use v_mfma_f64_4x4x4 (JQ_BW_T4; option t4=0 disables); the cooperative kernels stay on the JQ_BW_OD variant
         bool t4 = !h->big && (bw <= 1) && t4_structure(h->Hconst.data(), h->Ntot);
         for (int q = 0; q < h->Nc && t4; ++q)
             t4 = t4_structure(h->Hsym.data() + q * nn, h->Ntot) && t4_structure(h->Hanti.data() + q * nn, h->Ntot);
-        if (const char* e = getenv("JQ_T4"))
-            if (atoi(e) == 0) t4 = false;
-        if (const char* e = getenv("JQ_OD"))
-            if (atoi(e) == 0) t4 = false;
-        if (const char* e = getenv("JQ_FORCE_DENSE"))
-            if (atoi(e) != 0) t4 = false;
+        if (!h->opt.on(O_T4) || !h->opt.on(O_OD) || h->opt.on(O_FORCE_DENSE) || h->force_plain) t4 = false;
         if (t4) h->BW = JQ_BW_T4;
         // trace image layout per control: 0 block diagonal, 1 band BW, 2 band BW without the diagonal blocks
         for (int q = 0; q < h->Nc && h->BW == JQ_BW_T4; ++q)
@@ -805,24 +812,24 @@ static int create_dense(const jq_problem* p, jq_handle* h)
             // (... the Stormer-Verlet kernels need two of them in LDS -- or none: NT > 6; the 4 x 4 x 7 / 4 x 4 x 8 structures keep
             //  their JQ_BW_T4 slab kernels as the Stormer-Verlet fallback: the cooperative layout serves their implicit-midpoint path)
             h->coop_ok = lds_c <= 163840 && (h->NT <= 6 || h->big);
+            if (h->huge) h->coop_ok = true;      // (static LDS only)
         }
         h->coop_max_slabs = prop.multiProcessorCount;   // one cooperative workgroup per CU = one round
-        if (const char* e = getenv("JQ_COOP_MAX")) h->coop_max_slabs = atoi(e);
+        if (h->opt.has(O_COOP_MAX)) h->coop_max_slabs = (int)h->opt.get(O_COOP_MAX);
         if (h->big) h->coop_max_slabs = 1 << 30;        // the only kernel family at this size
         // Batched staging (K/S images of B time steps per DMA burst, constants resident in LDS) exists for
         // small images but is OFF by default: measured on MI355X it does not help (swap02/cnot2: the
         // ~600-cycle dependent-product latency dominates, not the per-operator barrier) and its 150 KB of
-        // LDS allow only one workgroup per CU.  JQ_BATCH=<B> enables it for experiments.
+        // LDS allow only one workgroup per CU.  option batch=<B> enables it for experiments.
         h->batch = 0;
         // Window staging (jq_kernels.h Ring, batch < 0): five time points (K and S image each) and the constant trace images
         // resident in LDS, one workgroup barrier per time step.  Used whenever it fits next to the backward kernel's carry
-        // and parking images (kernels compiled for two workgroups per CU: in half of the LDS); JQ_WINDOW=0 disables it.
+        // and parking images (kernels compiled for two workgroups per CU: in half of the LDS); option window=0 disables it.
         {
             const long long win = (2LL * JQ_WIN_TPS + 2LL * h->NcK) * slot;
             const long long budget = (h->NT <= JQ_MINW_MAXNT) ? 81920 : 163840;
             bool w = !h->big && win + lds_bwd_fixed + park_bytes <= budget;
-            if (const char* e = getenv("JQ_WINDOW"))
-                if (atoi(e) == 0) w = false;
+            if (!h->opt.on(O_WINDOW)) w = false;
             if (w) {
                 h->batch = -1;
                 h->park_lds = 1;
@@ -830,7 +837,7 @@ static int create_dense(const jq_problem* p, jq_handle* h)
         }
         // Quad-layout kernels (jq_kernels.h JQ_BW_T4Q) for this structure: workgroups of 4, 8 or 12 waves carry 1, 2 or 3 slabs
         // (1, 2, 3 waves per SIMD; one workgroup per CU because of the LDS).  run_eval picks the variant -- or the slab
-        // kernels -- by the number of rounds the batch needs (quad_plan).  JQ_QUAD=0 disables them, JQ_QUAD=<n> limits them to
+        // kernels -- by the number of rounds the batch needs (quad_plan).  option quad=0 disables them, option quad=<n> limits them to
         // batches of at most n slabs.
         // (they always use the window staging and need less LDS next to it than the slab kernels -- a register per 16-row block
         // to park -- so they are also available when the slab kernels have to fall back to the per-operator ring: Ntot > 80, Nc = 4)
@@ -838,25 +845,22 @@ static int create_dense(const jq_problem* p, jq_handle* h)
             const long long win = (2LL * JQ_WIN_TPS + 2LL * h->NcK) * slot;
             const long long quad_fixed = bwd_lds_tail(h->NT, h->NcK, JQ_WAVES, (long long)h->NT * 64);
             bool w = h->BW == JQ_BW_T4 && win + quad_fixed <= 163840;
-            if (const char* e = getenv("JQ_WINDOW"))
-                if (atoi(e) == 0) w = false;
+            if (!h->opt.on(O_WINDOW)) w = false;
             h->quad_max_slabs = w ? (1 << 30) : 0;
         }
         h->num_cu = prop.multiProcessorCount;
-        if (const char* e = getenv("JQ_QUAD"))
-            if (h->quad_max_slabs > 0) h->quad_max_slabs = atoi(e);
+        if (h->opt.has(O_QUAD) && h->quad_max_slabs > 0) h->quad_max_slabs = (int)h->opt.get(O_QUAD);
         // Cooperative-quad kernels (jq_cq_kernels.h): the latency path -- one workgroup of NT waves per column quad while every
         // quad still gets a CU of its own (LDS: the window staging, one workgroup per CU).  NT >= 2 (a single block has no
-        // neighbour to split the work with).  JQ_CQ=0 disables them, JQ_CQ=<n> bounds the number of quads.
+        // neighbour to split the work with).  option cq=0 disables them, option cq=<n> bounds the number of quads.
         {
             const long long win = (2LL * JQ_WIN_TPS + 2LL * h->NcK) * slot;
             const long long tail = 32LL * h->NT * 8 + 6LL * (h->NT + 2) * 64 * 8 + (long long)std::max(2, h->NcK + (h->NcK + 1) / 2) * h->NT * 64 * 8;      // (run_eval: lds_cq)
             h->cq_max_quads = (h->BW == JQ_BW_T4 && h->NT >= 2 && h->NT <= 7 && h->quad_max_slabs > 0 && win + tail <= 163840) ? 2 * prop.multiProcessorCount : 0;      // (two rounds of them, 2 x 0.20 s at cnot3, still beat one round of the quad-layout kernels, 0.55 s)
-            if (const char* e = getenv("JQ_CQ"))
-                if (h->cq_max_quads > 0) h->cq_max_quads = atoi(e);
+            if (h->opt.has(O_CQ) && h->cq_max_quads > 0) h->cq_max_quads = (int)h->opt.get(O_CQ);
         }
-        if (const char* e = getenv("JQ_BATCH")) {
-            const int v = atoi(e);
+        if (h->opt.has(O_BATCH)) {      // (experiment builds only: jq_options.h)
+            const int v = (int)h->opt.get(O_BATCH);
             if (v >= 2 && slot <= 8192) {
                 const long long fixed = lds_bwd_fixed + park_bytes + 2LL * h->NcK * slot;
                 const long long per_buf = (163840 - fixed) / 2;
@@ -871,8 +875,8 @@ static int create_dense(const jq_problem* p, jq_handle* h)
     }
 
     // Lane kernels (jq_lane_kernels.h) for small Hilbert spaces: one lane per state column, operator images in
-    // VGPRs read through DPP row broadcasts.  Instantiated for NP in {2,4,6,8}.  JQ_LANE=0 disables them,
-    // JQ_LANE_MIN / JQ_LANE_MAX bound the column counts (samples x N) they are used for.
+    // VGPRs read through DPP row broadcasts.  Instantiated for NP in {2,4,6,8}.  option lane=0 disables them,
+    // option lane_min / option lane_max bound the column counts (samples x N) they are used for.
     h->lane_np = 0;
     {
         static const int nps[] = {2, 4, 6, 8};
@@ -881,25 +885,23 @@ static int create_dense(const jq_problem* p, jq_handle* h)
                 h->lane_np = v;
                 break;
             }
-        if (const char* e = getenv("JQ_LANE"))
-            if (atoi(e) == 0) h->lane_np = 0;
+        if (!h->opt.on(O_LANE)) h->lane_np = 0;
         h->lane_stride = ((long long)h->lane_np * h->lane_np + 15) / 16 * 16;
         h->lane_min_cols = 1;
         h->lane_max_cols = 1 << 30;
         // row-lane kernels (jq_rowlane_kernels.h): same sizes, one lane per (row, column), 4 columns per wave;
         // used while the batch is small enough that the evaluation is bound by the latency of one wave
-        // (measured cross-over with the lane kernels, scripts/time_cases.py).  JQ_ROWLANE_MAX overrides.
+        // (measured cross-over with the lane kernels, scripts/time_cases.py).  option rowlane_max overrides.
         h->rl_npj = h->Ntot <= 8 ? (h->Ntot + 1) / 2 * 2 : (h->Ntot <= 12 ? 12 : (h->Ntot <= 16 ? 16 : 0));
-        if (const char* e = getenv("JQ_LANE"))
-            if (atoi(e) == 0) h->rl_npj = 0;
+        if (!h->opt.on(O_LANE)) h->rl_npj = 0;
         if (h->is_emb) h->rl_npj = 0, h->lane_np = 0;      // an embedded twin only serves the JQ_BW_T4 / quad-layout families
         h->rl_stride = 16LL * h->rl_npj;
         // cross-over measured with scripts/time_cases.py: ~2 waves per SIMD against the lane kernels (Ntot <= 8),
         // ~4 against the MFMA slab kernels (Ntot 9..16)
         h->rl_max_cols = 2 * 4 * 4 * prop.multiProcessorCount;      // (round 3: also for NPJ = 12, 16 -- cnot2 x 4 096 samples 94 ms here, 61 ms on the MFMA kernels)
-        if (const char* e = getenv("JQ_ROWLANE_MAX")) h->rl_max_cols = atoi(e);
-        if (const char* e = getenv("JQ_LANE_MIN")) h->lane_min_cols = atoi(e);
-        if (const char* e = getenv("JQ_LANE_MAX")) h->lane_max_cols = atoi(e);
+        if (h->opt.has(O_ROWLANE_MAX)) h->rl_max_cols = (int)h->opt.get(O_ROWLANE_MAX);
+        if (h->opt.has(O_LANE_MIN)) h->lane_min_cols = (int)h->opt.get(O_LANE_MIN);
+        if (h->opt.has(O_LANE_MAX)) h->lane_max_cols = (int)h->opt.get(O_LANE_MAX);
     }
 
     // time tables, accumulated exactly like the reference: t = t + h (src/StormerVerlet.jl:502);
@@ -969,19 +971,13 @@ static int create_dense(const jq_problem* p, jq_handle* h)
 
     // chunking of the time loop: the tile stream of one chunk has (2*cs+1) time points x {K,S}
     size_t budget = (size_t)1 << 30;
-    if (const char* e = getenv("JQ_STREAM_BYTES")) {
-        const long long v = atoll(e);
-        if (v > 0) budget = (size_t)v;
-    }
+    if (h->opt.has(O_STREAM_BYTES) && h->opt.get(O_STREAM_BYTES) > 0) budget = (size_t)h->opt.get(O_STREAM_BYTES);
     // largest operator image of any kernel family the handle may use (slab, cooperative, lane, row-lane)
     const long long img_elems = std::max(std::max(h->mat_elems, h->mat_elems_c), std::max(h->lane_stride, h->rl_stride));
     const size_t per_tp = 2 * (size_t)img_elems * sizeof(double);
     long long cs = ((long long)(budget / per_tp) - 1) / 2;
     cs = std::max<long long>(1, std::min<long long>(cs, h->nsteps));
-    if (const char* e = getenv("JQ_CHUNK_STEPS")) {
-        const long long v = atoll(e);
-        if (v > 0) cs = std::min<long long>(v, h->nsteps);
-    }
+    if (h->opt.has(O_CHUNK_STEPS) && h->opt.get(O_CHUNK_STEPS) > 0) cs = std::min<long long>(h->opt.get(O_CHUNK_STEPS), h->nsteps);
     // k_ctrl / k_stream put the 2 cs + 1 time points of a chunk into gridDim.y (limit 65535)
     cs = std::min<long long>(cs, 32767);
     h->chunk_steps = (int)cs;
@@ -1015,14 +1011,9 @@ static void embed_rows(const double* A, int Ntot, int ncol, const std::vector<in
 
 static int try_embed(jq_handle* h, const jq_problem* p)
 {
-    if (const char* e = getenv("JQ_EMBED")) h->emb_mode = atoi(e);
+    h->emb_mode = (int)h->opt.get(O_EMBED);
     if (h->is_emb || h->emb_mode == 0 || h->BW == JQ_BW_T4 || h->big || h->Ntot > 96) return JQ_OK;
-    if (const char* e = getenv("JQ_T4"))
-        if (atoi(e) == 0) return JQ_OK;
-    if (const char* e = getenv("JQ_OD"))
-        if (atoi(e) == 0) return JQ_OK;
-    if (const char* e = getenv("JQ_FORCE_DENSE"))
-        if (atoi(e) != 0) return JQ_OK;
+    if (!h->opt.on(O_T4) || !h->opt.on(O_OD) || h->opt.on(O_FORCE_DENSE)) return JQ_OK;
     const int Ntot = h->Ntot, Nc = h->Nc;
     const size_t nn = (size_t)Ntot * Ntot;
     int best_d1 = 0, best_d2 = 0, best_d3 = 1 << 30;
@@ -1076,6 +1067,7 @@ static int try_embed(jq_handle* h, const jq_problem* p)
     jq_handle* e = new (std::nothrow) jq_handle();
     if (!e) return fail(h, JQ_ENOMEM, "jq_create: out of host memory");
     e->is_emb = true;
+    e->opt = h->opt;
     int rc = create_impl(&q, e);
     if (rc == JQ_OK && e->BW != JQ_BW_T4) rc = JQ_EUNSUPPORTED;      // (cannot happen: the structure test above passed)
     if (rc != JQ_OK) {      // the embedding is an optimisation: without it the handle works as before
@@ -1092,18 +1084,31 @@ static int try_embed(jq_handle* h, const jq_problem* p)
     return JQ_OK;
 }
 
-extern "C" int jq_create(const jq_problem* problem, jq_handle** out)
+// the options of a new handle: JQ_OPTIONS (the ONE environment variable that reaches the kernel selection; for callers that cannot pass a
+// string), then the caller's string
+static int parse_create_options(const char* options, JqOptions* opt)
 {
-    if (!out) {
-        g_create_error = "jq_create: out is NULL";
+    std::string err;
+    if (!opt->parse(getenv("JQ_OPTIONS"), &err)) {
+        g_create_error = "JQ_OPTIONS: " + err;
         return JQ_EINVAL;
     }
+    if (!opt->parse(options, &err)) {
+        g_create_error = "jq_create_opts: " + err;
+        return JQ_EINVAL;
+    }
+    return JQ_OK;
+}
+
+static int create_with(const jq_problem* problem, const JqOptions& opt, jq_handle** out)
+{
     *out = nullptr;
     jq_handle* h = new (std::nothrow) jq_handle();
     if (!h) {
         g_create_error = "jq_create: out of host memory";
         return JQ_ENOMEM;
     }
+    h->opt = opt;
     int rc = create_impl(problem, h);
     if (rc == JQ_OK) rc = try_embed(h, problem);
     if (rc != JQ_OK) {
@@ -1114,6 +1119,20 @@ extern "C" int jq_create(const jq_problem* problem, jq_handle** out)
     *out = h;
     return JQ_OK;
 }
+
+extern "C" int jq_create_opts(const jq_problem* problem, const char* options, jq_handle** out)
+{
+    if (!out) {
+        g_create_error = "jq_create: out is NULL";
+        return JQ_EINVAL;
+    }
+    *out = nullptr;
+    JqOptions opt;
+    if (int rc = parse_create_options(options, &opt)) return rc;
+    return create_with(problem, opt, out);
+}
+
+extern "C" int jq_create(const jq_problem* problem, jq_handle** out) { return jq_create_opts(problem, nullptr, out); }
 
 template <typename F>
 static int multi_forall(jq_handle* h, F f);
@@ -1142,6 +1161,24 @@ extern "C" int jq_set_neumann_terms(jq_handle* h, int32_t m)
     return JQ_OK;
 }
 
+static int replan(jq_handle* h, const double* Hconst);
+// Full leakage weights WITH the Jacobi solver: the cooperative kernels (two or more tile rows) and the slab kernels <1, 0> / <6, 5> combine
+// the two.  A 4 x 4 x n plan reaches neither when it has one tile row (its slab kernels are the JQ_BW_T4 ones) or seven / eight (no
+// cooperative layout that fits): such a handle is planned again WITHOUT that structure while the combination is in force, and with it
+// again afterwards.
+static int ensure_wjac_plan(jq_handle* h)
+{
+    const bool wjac = h->wrank > 0 && h->solver_id == 2;
+    const bool need_plain = wjac && (h->force_plain || (h->BW == JQ_BW_T4 && (h->NT == 1 || h->NT > 6)));
+    if (need_plain == h->force_plain) return JQ_OK;
+    h->force_plain = need_plain;
+    const std::vector<double> H0 = h->Hconst;
+    const bool was = h->replanned;
+    const int rc = replan(h, H0.data());
+    if (rc == JQ_OK) h->replanned = was;
+    return rc;
+}
+
 extern "C" int jq_set_linear_solver(jq_handle* h, int32_t solver_id, int32_t max_iter, double tol)
 {
     if (!h) return JQ_EINVAL;
@@ -1149,8 +1186,6 @@ extern "C" int jq_set_linear_solver(jq_handle* h, int32_t solver_id, int32_t max
     if (max_iter < 0) return fail(h, JQ_EINVAL, "jq_set_linear_solver: max_iter must be >= 0");
     if (solver_id == 2) {
         if (!(tol > 0.0)) return fail(h, JQ_EINVAL, "jq_set_linear_solver: JACOBI_SOLVER needs tol > 0");
-        if (h->wrank > 0)
-            return fail(h, JQ_EUNSUPPORTED, "jq_set_linear_solver: full leakage weights (jq_update_wmat) are implemented for the Neumann solver only");
     } else if (solver_id != 1) {
         return fail(h, JQ_EUNSUPPORTED, "jq_set_linear_solver: only NEUMANN_SOLVER (1) and JACOBI_SOLVER (2) are implemented");
     }
@@ -1158,7 +1193,7 @@ extern "C" int jq_set_linear_solver(jq_handle* h, int32_t solver_id, int32_t max
     h->m = max_iter;
     h->solver_tol = tol;
     if (h->emb) h->emb->solver_id = solver_id, h->emb->m = max_iter, h->emb->solver_tol = tol;
-    return JQ_OK;
+    return ensure_wjac_plan(h);
 }
 
 extern "C" int jq_set_integrator(jq_handle* h, int32_t integrator_id, int32_t max_iter, double tol)
@@ -1171,6 +1206,8 @@ extern "C" int jq_set_integrator(jq_handle* h, int32_t integrator_id, int32_t ma
     }
     if (integrator_id != 2) return fail(h, JQ_EUNSUPPORTED, "jq_set_integrator: 1 = Stormer-Verlet, 2 = implicit midpoint");
     if (max_iter < 1 || !(tol > 0.0)) return fail(h, JQ_EINVAL, "jq_set_integrator: implicit midpoint needs max_iter >= 1 and tol > 0");
+    if (h->huge)
+        return fail(h, JQ_EUNSUPPORTED, "jq_set_integrator: the implicit-midpoint path is implemented up to Ntot = 256 (the Stormer-Verlet path has no size limit)");
     if (h->wrank > 0)
         return fail(h, JQ_EUNSUPPORTED, "jq_set_integrator: the handle carries full leakage weights (jq_update_wmat); the implicit-midpoint "
                                         "path weights with params.wmat (Diagonal): pass it with jq_update_wmat_diag first");
@@ -1220,6 +1257,8 @@ static int replan(jq_handle* h, const double* Hconst)
     q.Utarget_r = h->Utr.data(); q.Utarget_i = h->Uti.data(); q.wmat_real_diag = h->wd.data(); q.Cfreq = h->cfreq.data();
     jq_handle* n = new (std::nothrow) jq_handle();
     if (!n) return fail(h, JQ_ENOMEM, "jq_update_hconst: out of host memory");
+    n->opt = h->opt;
+    n->force_plain = h->force_plain;
     int rc = create_impl(&q, n);
     if (rc == JQ_OK) rc = try_embed(n, &q);
     auto settings = [&](jq_handle* t) {
@@ -1263,9 +1302,9 @@ extern "C" int jq_update_hconst(jq_handle* h, const double* Hconst)
     //  the current structure, or when the drift has regained a structure that admits a strictly better kernel family than the
     //  current plan's: 4 x 4 x n when the plan is not JQ_BW_T4, diagonal off-diagonal blocks when it is a plain band.)
     const bool fits = (h->BW == JQ_BW_T4) ? t4_structure(Hconst, h->Ntot)
-                      : (h->BW == JQ_BW_OD) ? offdiag_blocks_diagonal(Hconst, h->Ntot) : block_band(Hconst, h->Ntot) <= (h->big ? h->BWc : h->BW);
+                      : (h->BW == JQ_BW_OD) ? offdiag_blocks_diagonal(Hconst, h->Ntot) : (h->huge || block_band(Hconst, h->Ntot) <= (h->big ? h->BWc : h->BW));
     bool better = false;
-    if (fits && h->replanned && h->BW != JQ_BW_T4) {
+    if (fits && h->replanned && h->BW != JQ_BW_T4 && !h->huge) {
         const size_t nn = (size_t)h->Ntot * h->Ntot;
         int bw = block_band(Hconst, h->Ntot);
         for (int q = 0; q < h->Nc; ++q)
@@ -1386,17 +1425,20 @@ static int upload_wlr(jq_handle* h, const std::vector<int>& keep, const std::vec
 {
     HIPCHK(h, hipSetDevice(h->device));
     const int stride = h->NP;
-    h->wlr.assign((size_t)JQ_MAX_WRANK + (size_t)2 * JQ_MAX_WRANK * stride, 0.0);
+    const int wlam = std::max<int>(JQ_MAX_WRANK, (int)keep.size());
+    const size_t old_size = h->wlr.size();
+    h->wlr.assign((size_t)wlam + (size_t)2 * wlam * stride, 0.0);
     for (size_t k = 0; k < keep.size(); ++k) {
         h->wlr[k] = lam[keep[k]];
         for (int i = 0; i < n; ++i) {
             const int row = row_map ? (*row_map)[i] : i;
-            h->wlr[JQ_MAX_WRANK + (2 * k) * stride + row] = Vr[i + (size_t)n * keep[k]];
-            h->wlr[JQ_MAX_WRANK + (2 * k + 1) * stride + row] = Vi[i + (size_t)n * keep[k]];
+            h->wlr[wlam + (2 * k) * stride + row] = Vr[i + (size_t)n * keep[k]];
+            h->wlr[wlam + (2 * k + 1) * stride + row] = Vi[i + (size_t)n * keep[k]];
         }
     }
+    h->wlam = wlam;
     int rc;
-    if (!h->d_wlr && (rc = dev_alloc(h, &h->d_wlr, h->wlr.size()))) return rc;
+    if ((!h->d_wlr || h->wlr.size() > old_size) && (rc = dev_alloc(h, &h->d_wlr, h->wlr.size()))) return rc;
     HIPCHK(h, hipMemcpy(h->d_wlr, h->wlr.data(), h->wlr.size() * sizeof(double), hipMemcpyHostToDevice));
     h->wrank = (int)keep.size();
     h->wlr_real = true;
@@ -1443,8 +1485,6 @@ extern "C" int jq_update_wmat(jq_handle* h, const double* Wr, const double* Wi)
     if (h->integrator == 2)
         return fail(h, JQ_EUNSUPPORTED, "jq_update_wmat: the implicit-midpoint path weights with params.wmat (always Diagonal, "
                                         "src/evalobjgrad.jl:90, :1155): pass it with jq_update_wmat_diag");
-    if (h->solver_id != 1)
-        return fail(h, JQ_EUNSUPPORTED, "jq_update_wmat: full leakage weights are implemented for the Neumann solver only");
     for (int j = 0; j < n; ++j)
         for (int i = 0; i <= j; ++i) {
             const double ds = Wr[i + (size_t)n * j] - Wr[j + (size_t)n * i];
@@ -1468,12 +1508,8 @@ extern "C" int jq_update_wmat(jq_handle* h, const double* Wr, const double* Wi)
     std::vector<int> keep;
     for (int k = 0; k < n; ++k)
         if (std::fabs(lam[k]) > 1e-13 * lmax) keep.push_back(k);
-    if ((int)keep.size() > JQ_MAX_WRANK) {
-        char buf[200];
-        snprintf(buf, sizeof buf, "jq_update_wmat: the weight matrix has rank %d; full leakage weights are implemented up to rank %d "
-                                  "(forbidden states)", (int)keep.size(), JQ_MAX_WRANK);
-        return fail(h, JQ_EUNSUPPORTED, buf);
-    }
+    // (any rank: up to JQ_MAX_WRANK on every kernel family with the low-rank terms, beyond it on the cooperative, slab and run-time-size
+    //  kernels -- run_eval routes; a full-rank W costs about two dense products per application)
     {   // the kept terms must reproduce W (guards the decomposition itself)
         double err = 0.0;
         for (int j = 0; j < n; ++j)
@@ -1488,15 +1524,21 @@ extern "C" int jq_update_wmat(jq_handle* h, const double* Wr, const double* Wi)
             }
         if (err > 1e-11 * wmax) return fail(h, JQ_EHIP, "jq_update_wmat: internal error, the eigen-decomposition does not reproduce W");
     }
-    h->Wr.assign(Wr, Wr + nn);
-    h->Wi.assign(nn, 0.0);
-    if (Wi) h->Wi.assign(Wi, Wi + nn);
     int rc = upload_wlr(h, keep, lam, Vr, Vi, n, nullptr);
     if (rc == JQ_OK && h->emb) {
         rc = upload_wlr(h->emb, keep, lam, Vr, Vi, n, &h->emb_row);
         if (rc != JQ_OK) h->err = h->emb->err;
     }
-    return rc;
+    if (rc != JQ_OK) {      // nothing half-applied: the early-out above must not take a failed upload for "these weights are in place"
+        h->Wr.clear(), h->Wi.clear();
+        h->wrank = 0;
+        if (h->emb) h->emb->wrank = 0;
+        return rc;
+    }
+    h->Wr.assign(Wr, Wr + nn);
+    h->Wi.assign(nn, 0.0);
+    if (Wi) h->Wi.assign(Wi, Wi + nn);
+    return ensure_wjac_plan(h);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1521,17 +1563,24 @@ extern template __global__ void k_forward<1, 0, JQ_MINW_OF(1), false, true>(Prop
 extern template __global__ void k_backward<1, 0, JQ_MINW_OF(1), false, true>(PropArgs);
 extern template __global__ void k_forward<6, 5, JQ_MINW_OF(6), false, true>(PropArgs);
 extern template __global__ void k_backward<6, 5, JQ_MINW_OF(6), false, true>(PropArgs);
+// ... and with the Jacobi solver (ABI 5: full weights are no longer tied to the Neumann solver)
+extern template __global__ void k_forward<1, 0, JQ_MINW_OF(1), true, true>(PropArgs);
+extern template __global__ void k_backward<1, 0, JQ_MINW_OF(1), true, true>(PropArgs);
+extern template __global__ void k_forward<6, 5, JQ_MINW_OF(6), true, true>(PropArgs);
+extern template __global__ void k_backward<6, 5, JQ_MINW_OF(6), true, true>(PropArgs);
 
 static int select_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
 {
     const bool jac = (h->solver_id == 2);
     if (h->wrank > 0) {
         if (h->NT == 1 && h->BW == 0) {
-            *fwd = k_forward<1, 0, JQ_MINW_OF(1), false, true>, *bwd = k_backward<1, 0, JQ_MINW_OF(1), false, true>;
+            *fwd = jac ? k_forward<1, 0, JQ_MINW_OF(1), true, true> : k_forward<1, 0, JQ_MINW_OF(1), false, true>;
+            *bwd = jac ? k_backward<1, 0, JQ_MINW_OF(1), true, true> : k_backward<1, 0, JQ_MINW_OF(1), false, true>;
             return JQ_OK;
         }
         if (h->NT == 6 && h->BW == 5) {
-            *fwd = k_forward<6, 5, JQ_MINW_OF(6), false, true>, *bwd = k_backward<6, 5, JQ_MINW_OF(6), false, true>;
+            *fwd = jac ? k_forward<6, 5, JQ_MINW_OF(6), true, true> : k_forward<6, 5, JQ_MINW_OF(6), false, true>;
+            *bwd = jac ? k_backward<6, 5, JQ_MINW_OF(6), true, true> : k_backward<6, 5, JQ_MINW_OF(6), false, true>;
             return JQ_OK;
         }
         return fail(h, JQ_EUNSUPPORTED, "full leakage weights (jq_update_wmat): no kernels with the low-rank terms for this plan (row-lane kernels "
@@ -1603,7 +1652,7 @@ JQ_DECLCQ(1) JQ_DECLCQ(2) JQ_DECLCQ(3) JQ_DECLCQ(4) JQ_DECLCQ(5) JQ_DECLCQ(6) JQ
 // the product each
 static bool cq_ord(const jq_handle* h)
 {
-    bool ord = h->Nc <= 3 && !getenv("JQ_CQ_GENERIC_TRACES");      // (more than JQ_MAXNC controls: generic traces per control group)
+    bool ord = h->Nc <= 3 && !h->opt.on(O_CQ_GENERIC_TRACES);      // (more than JQ_MAXNC controls: generic traces per control group)
     for (int q = 0; q < h->Nc && ord; ++q) ord = (h->bw_trace[q] == (1 << q));
     return ord;
 }
@@ -1673,7 +1722,7 @@ JQ_DECLCI(1) JQ_DECLCI(2) JQ_DECLCI(3) JQ_DECLCI(4) JQ_DECLCI(5) JQ_DECLCI(6)
 #undef JQ_DECLCI
 // dynamic LDS of k_backward_cq_imr2: staging + tables + two exchange images (one per set of waves) + the decisions
 static size_t cq_imr2_lds(const jq_handle* h, size_t lds_stage) { return lds_stage + (size_t)32 * h->NT * 8 + (size_t)12 * (h->NT + 2) * 64 * 8 + 64; }
-// two: the backward sweep with the state and the adjoint chain on two sets of waves (NT <= 6, LDS permitting; JQ_IMR_CQ2=0: the
+// two: the backward sweep with the state and the adjoint chain on two sets of waves (NT <= 6, LDS permitting; option imr_cq2=0: the
 // one-set kernel of round 3)
 static int select_cq_imr_kernels(jq_handle* h, bool two, bool three, prop_kernel_t* fwd, prop_kernel_t* bwd)
 {
@@ -1710,9 +1759,9 @@ static int select_quad_kernels(jq_handle* h, int spw, prop_kernel_t* fwd, prop_k
     // Only the twelve-wave BACKWARD kernel has a UNI variant: folding the shift into the MFMA's A operand adds a dependent FMA in front
     // of every MFMA, which three waves per SIMD hide (- 1.2 %) and one or two do not (measured: forward sweep + 1.2 %, one / two slabs
     // per workgroup + 1.6 ... 3.4 %)
-    const bool uni = (h->N % 4 == 0 || h->parts > 1) && !getenv("JQ_NO_UNI");
+    const bool uni = (h->N % 4 == 0 || h->parts > 1) && !h->opt.on(O_NO_UNI);
     // ... and its ORD variant when control q acts on subsystem q only (like the cooperative-quad kernels, select_cq_kernels)
-    bool ord = uni && h->Nc >= 2 && h->Nc <= 3 && !getenv("JQ_NO_ORD");
+    bool ord = uni && h->Nc >= 2 && h->Nc <= 3 && !h->opt.on(O_NO_ORD);
     for (int q = 0; q < h->Nc && ord; ++q) ord = (h->bw_trace[q] == (1 << q));
 #define JQ_PICKQ(nt)                                                                                                                             \
     if (h->NT == nt) {                                                                                                                           \
@@ -1746,14 +1795,15 @@ static size_t qsplit_lds(const jq_handle* h, int qw)      // ring of JQ_QS_TPS t
 static int select_qsplit_kernel(jq_handle* h, int qw, prop_kernel_t* bwd)
 {
     // control q acts on subsystem q only (like select_quad_kernels / select_cq_kernels): compile-time trace modes
-    bool ord = h->Nc >= 2 && h->Nc <= 3 && !getenv("JQ_NO_ORD");
+    bool ord = h->Nc >= 2 && h->Nc <= 3 && !h->opt.on(O_NO_ORD);
     for (int q = 0; q < h->Nc && ord; ++q) ord = (h->bw_trace[q] == (1 << q));
-    // ... and with exactly three of them every trace product rides along in a pass of the adjoint step (RIDE; JQ_QS_RIDE=0: separate passes)
+    // ... and with exactly three of them every trace product rides along in a pass of the adjoint step (RIDE; option qs_ride=0: separate passes)
     // -- where the adjoint wave is alone on its SIMD (qw = 2: - 6 %); with two waves per SIMD and the adjoint wave first in the issue
     // arbitration the rides buy nothing (248.9 ms without, 250.0 with): qw = 4 keeps the separate passes (bit-identical to the one-wave
-    // kernel); JQ_QS_RIDE=1 forces the rides there too
-    const char* e_ride = getenv("JQ_QS_RIDE");
-    const bool ride = ord && h->Nc == 3 && !(e_ride && atoi(e_ride) == 0) && (qw == 2 || (e_ride && atoi(e_ride) == 1));
+    // kernel); option qs_ride=1 forces the rides there too
+    const bool ride_set = h->opt.has(O_QS_RIDE);
+    const long long ride_v = h->opt.get(O_QS_RIDE);
+    const bool ride = ord && h->Nc == 3 && !(ride_set && ride_v == 0) && (qw == 2 || (ride_set && ride_v == 1));
 #define JQ_PICKQS(nt)                                                                                         \
     if (h->NT == nt) {                                                                                        \
         *bwd = qw == 4 ? (ride ? k_backward_qsplit<nt, true, 4, true> : ord ? k_backward_qsplit<nt, true, 4> : k_backward_qsplit<nt, false, 4>)             \
@@ -1802,6 +1852,10 @@ JQ_FOR_EACH_BIG(JQ_DECLC)
 
 static int select_coop_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
 {
+    if (h->huge) {
+        *fwd = k_forward_huge, *bwd = k_backward_huge;
+        return JQ_OK;
+    }
 #define JQ_PICKC(nt, bw)                      \
     if (h->NT == nt && h->BWc == bw) {        \
         *fwd = k_forward_coop<nt, bw>;        \
@@ -1979,6 +2033,19 @@ static double t4_plan_cost(const jq_handle* h, long long nsamples)
     return best;
 }
 
+// Chunk length of a backward sweep whose per-step trace records have `trace_rows` rows: the tile stream of h->chunk_steps steps fits its
+// buffer; the records of a chunk ([trace_rows][cs][NcK JQ_NTR] doubles) are bounded by the option trace_bytes (default 4 GiB), so that
+// large ensembles take more, shorter chunks instead of an allocation that grows with batch size x gate length.  ONE function for the
+// sweep and for the decision that depends on its first chunk (the split latency kernels need a first chunk longer than their ring).
+#define JQ_CQ3_RING 8      // = JQ_CQ3_SLOTS (jq_cq_split_kernels.h, compiled in its own translation units)
+static int backward_chunk_steps(const jq_handle* h, size_t trace_rows)
+{
+    size_t tbudget = (size_t)4 << 30;
+    if (h->opt.has(O_TRACE_BYTES) && h->opt.get(O_TRACE_BYTES) > 0) tbudget = (size_t)h->opt.get(O_TRACE_BYTES);
+    const long long cst = (long long)(tbudget / (std::max<size_t>(trace_rows, 1) * (size_t)h->NcK * JQ_NTR * sizeof(double)));
+    return (int)std::max<long long>(1, std::min<long long>(h->chunk_steps, cst));
+}
+
 __global__ void k_add_to(double* __restrict__ y, const double* __restrict__ x, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2069,7 +2136,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     const long long ncols_split = (long long)nsamples * h->N;
     const bool small_family_batch = (h->rl_npj > 0 && ncols_split <= h->rl_max_cols) ||
                                     (h->lane_np > 0 && ncols_split >= h->lane_min_cols && ncols_split <= h->lane_max_cols);
-    if (!h->in_split && !small_family_batch && h->wrank == 0 && h->quad_max_slabs > 0 && h->integrator == 1 && h->solver_id == 1 && !hist_r && eps && nsamples > 1 && !getenv("JQ_NOSPLIT")) {
+    if (!h->in_split && !small_family_batch && h->wrank == 0 && h->quad_max_slabs > 0 && h->integrator == 1 && h->solver_id == 1 && !hist_r && eps && nsamples > 1 && !h->opt.on(O_NOSPLIT)) {
         // candidates: the largest number of FULL rounds of the quad-layout kernels with 1, 2 or 3 slabs per workgroup
         long long n_main = 0;
         double best = t4_plan_cost(h, nsamples) - 1e-9;
@@ -2174,14 +2241,15 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     // kernels (every batch size) and, where those do not exist, the slab kernels <1, 0> / <6, 5>; no lane or JQ_BW_T4 slab kernels;
     // cooperative-quad kernels for REAL weight matrices of rank <= 4 (wfull_cq below).
     const bool wfull = h->wrank > 0;
-    if (wfull && (imr || h->solver_id != 1))
-        return fail(h, JQ_EUNSUPPORTED, "full leakage weights (jq_update_wmat): Stormer-Verlet integrator with the Neumann solver only");
+    if (wfull && imr)
+        return fail(h, JQ_EUNSUPPORTED, "full leakage weights (jq_update_wmat): the implicit-midpoint path weights with params.wmat (Diagonal)");
+    const bool wjac = wfull && h->solver_id == 2;      // full weights with the Jacobi solver: cooperative kernels, else the slab kernels <1, 0> / <6, 5>
     const bool rl = imr_rl || (!imr && h->rl_npj > 0 && h->solver_id == 1 && (ncols_used <= h->rl_max_cols || wfull));
     const bool lane = !imr && !rl && !wfull && h->lane_np > 0 && h->solver_id == 1 && ncols_used >= h->lane_min_cols && ncols_used <= h->lane_max_cols;
     const long long nwaves_rl = (ncols_used + cpw - 1) / cpw;
     const long long ncols = rl ? 4 * nwaves_rl : (ncols_used + 63) / 64 * 64;      // row-lane: column SLOTS (4 per wave)
     // JQ_BW_T4 structure, small batches: the quad-layout kernels (one workgroup per slab, its four waves carry four columns
-    // each; 3 x shorter dependent chain than the cooperative kernels).  JQ_QUAD=0 disables them.
+    // each; 3 x shorter dependent chain than the cooperative kernels).  option quad=0 disables them.
     // Which kernels for nslabs slabs of this structure?  Time of one round relative to the slab kernels' round of 4 #CU slabs
     // (T4_REL, measured at cnot3): quad layout with 1 / 2 / 3 slabs per workgroup for #CU / 2 #CU /
     // 3 #CU slabs.  Fewest "round units" wins; spw = 0: slab kernels.
@@ -2204,13 +2272,13 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
         // spills and two workgroups share a CU -- measured 3.5e9 vs 2.2e9 SVTS/s for cnot2 x 65 536 samples.  The quad
         // layout keeps the latency regime (at most one slab per CU).
         if (h->NT <= 2 && nslabs > h->num_cu) spw = 0;
-        if (const char* e = getenv("JQ_QUAD8")) {      // experiments / tests: force 4 / 8 / 12 waves (as far as the LDS allows)
-            spw = std::max(1, std::min(3, atoi(e) + 1));
+        if (h->opt.has(O_QUAD8)) {      // experiments / tests: force 4 / 8 / 12 waves (as far as the LDS allows)
+            spw = std::max(1, std::min(3, (int)h->opt.get(O_QUAD8) + 1));
             while (spw > 1 && quad_lds(spw) > 163840) --spw;
         }
         if (wfull) spw = 1;      // (the instantiations with the low-rank terms: one slab per workgroup, any number of rounds)
     }
-    if (wfull && !rl && h->BW == JQ_BW_T4 && spw == 0)
+    if (wfull && !wjac && !rl && h->BW == JQ_BW_T4 && spw == 0)
         return fail(h, JQ_EUNSUPPORTED, "full leakage weights (jq_update_wmat): the quad-layout kernels are disabled or do not fit for this "
                                         "4 x 4 x n problem, and the JQ_BW_T4 slab kernels have no low-rank terms");
     // (one slab per workgroup, one wave per SIMD, the operators of a step in registers for all its fixed-point iterations; a
@@ -2220,58 +2288,47 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     const long long nquads_used = (ncols_used + 3) / 4;
     // (full weights, round 5: four slots -- real weight matrices of rank <= 4, complex ones of rank <= 2 -- on the cooperative-quad kernels with
     //  one quad per workgroup, LDS permitting (jq_cq_kernels.h CqW); a complex W only with the backward sweep on two / three workgroups
-    //  per quad, see below; JQ_CQ_W=0: the quad-layout kernels as before)
-    const char* e_cqw = getenv("JQ_CQ_W");
-    const bool wfull_cq = wfull && (h->wlr_real ? h->wrank <= 4 : h->wrank <= 2) && h->NT <= 7 && !(e_cqw && atoi(e_cqw) == 0) && (ncols_used + 3) / 4 <= h->num_cu &&
+    //  per quad, see below; option cq_w=0: the quad-layout kernels as before)
+    const bool wfull_cq = wfull && (h->wlr_real ? h->wrank <= 4 : h->wrank <= 2) && h->NT <= 7 && h->opt.on(O_CQ_W) && (ncols_used + 3) / 4 <= h->num_cu &&
                           (size_t)(2 * JQ_WIN_TPS + 2 * h->NcK) * h->mat_elems * 8 + (size_t)32 * h->NT * 8 + (size_t)6 * (h->NT + 2) * 64 * 8 +
                                   (size_t)std::max(2, h->NcK + (h->NcK + 1) / 2) * h->NT * 64 * 8 + (size_t)2 * h->NT * 64 * 8 <= 163840;
     bool cq = !imr && !lane && !rl && (!wfull || wfull_cq) && h->solver_id == 1 && h->cq_max_quads > 0 && nquads_used <= h->cq_max_quads &&
-              !getenv("JQ_QUAD8");      // (JQ_QUAD8 asks for a quad-layout variant explicitly)
+              !h->opt.has(O_QUAD8);      // (quad8 asks for a quad-layout variant explicitly)
     const int qps = h->parts > 1 ? 4 : (h->sps * h->N + 3) / 4;      // column quads of a full slab
     // ... and of the implicit-midpoint integrator (jq_cq_imr_kernels.h): N = 4, one workgroup of NT waves per evaluation
-    const char* e_icq = getenv("JQ_IMR_CQ");
     const bool imr_cq = imr_quad && h->N == 4 && h->parts == 1 && h->cq_max_quads > 0 && nquads_used <= h->cq_max_quads &&
-                        !(e_icq && atoi(e_icq) == 0);
+                        h->opt.on(O_IMR_CQ);
     // more column quads than CUs: the forward sweep takes two quads per workgroup (one round of workgroups at ~ 1.5 x the time
-    // instead of two rounds; JQ_CQ_FWD2=0: one quad per workgroup, =1: always two)
-    const char* e_cf2 = getenv("JQ_CQ_FWD2");
-    const bool cq_fwd2 = cq && !wfull && (e_cf2 ? atoi(e_cf2) != 0 : nquads_used > h->num_cu);
+    // instead of two rounds; option cq_fwd2=0: one quad per workgroup, =1: always two)
+    const bool cq_fwd2 = cq && !wfull && (h->opt.has(O_CQ_FWD2) ? h->opt.on(O_CQ_FWD2) : nquads_used > h->num_cu);
     // single evaluations and small ensembles: the backward sweep on three workgroups (CUs) per column quad -- state re-integration,
     // adjoint step, trace products, pipelined through a ring in global memory (jq_cq_split_kernels.h).  All 3 x quads workgroups must
-    // be resident at once (groups of 8 quads: 24 workgroups); JQ_CQ3=0: the one-workgroup kernel
+    // be resident at once (groups of 8 quads: 24 workgroups); option cq3=0: the one-workgroup kernel
     // (the kernels address quad q as quad q & 3 of slab q >> 2: every slab has four quad slots, a ragged last slab leaves some idle)
     const long long nq_pad = (4LL * nslabs + 7) / 8 * 8;
-    const char* e_c3 = getenv("JQ_CQ3");
+    const bool c3_set = h->opt.has(O_CQ3);
+    const long long c3_v = h->opt.get(O_CQ3);
     // (not for the sub-handles of the same-device test mode: their launches share the GPU, the workgroups of a quad might not all be resident)
     // Co-residency is checked, not assumed: the split is taken only when this evaluation is the only one of the process on the device
     // (GateHold: others then wait until it is through), when no CU mask is in force (the grid is sized for all CUs the device
     // reports), and not while the handle is cooling down after a fault.
     // (round 5: 2 x quads <= CUs -- 81 .. 128 cnot3 samples -- two workgroups per quad: state re-integration | adjoint step + trace products,
-    //  Stormer-Verlet only; JQ_CQ3=3: three or none)
+    //  Stormer-Verlet only; option cq3=3: three or none)
     GateHold gate_hold;
     bool cq3 = false;
     int cq_nr = 0;      // workgroups per column quad of the split backward sweep
     if ((cq || imr_cq) && adjoint) {
         const char* why = nullptr;
-        cq_nr = 3 * nq_pad <= h->num_cu ? 3 : (cq && 2 * nq_pad <= h->num_cu && !(e_c3 && atoi(e_c3) == 3)) ? 2 : 0;
+        cq_nr = 3 * nq_pad <= h->num_cu ? 3 : (cq && 2 * nq_pad <= h->num_cu && !(c3_set && c3_v == 3)) ? 2 : 0;
         // The consumer roles read the state the sweep starts from out of the state file (the carry of the trace products, first chunk
         // only), and the state role writes its end-of-chunk state there when it is through.  It cannot be through before they have
         // started only if it has to WAIT for them -- which it does from step 8 on (the ring has 8 slots): the first chunk must be longer
         // than the ring.  (Shorter first chunks -- tests, problems with a handful of steps -- were a race that the late-start hook
-        // JQ_DEBUG=16 exposed in round 5; they take the one-workgroup kernel.)
-        long long cs_first = h->chunk_steps;
-        {
-            size_t tbudget = (size_t)4 << 30;
-            if (const char* e = getenv("JQ_TRACE_BYTES")) {
-                const long long v = atoll(e);
-                if (v > 0) tbudget = (size_t)v;
-            }
-            const size_t rows = (size_t)nslabs * qps * (imr_cq ? h->NT : 1);
-            cs_first = std::max<long long>(1, std::min<long long>(cs_first, (long long)(tbudget / (rows * h->NcK * JQ_NTR * sizeof(double)))));
-            cs_first = std::min<long long>(cs_first, h->nsteps);
-        }
-        if (e_c3 && atoi(e_c3) == 0) why = "not taken: JQ_CQ3=0";
-        else if (cs_first <= 8) why = "not taken: the first chunk of the sweep is not longer than the hand-off ring (8 steps)";
+        // option debug=16 exposed in round 5; they take the one-workgroup kernel.)
+        // (the SAME function gives the chunk length of the sweep below: backward_chunk_steps; the trace-record rows of these families)
+        const long long cs_first = std::min<long long>(backward_chunk_steps(h, (size_t)nslabs * qps * (imr_cq ? h->NT : 1)), h->nsteps);
+        if (c3_set && c3_v == 0) why = "not taken: option cq3=0";
+        else if (cs_first <= JQ_CQ3_RING) why = "not taken: the first chunk of the sweep is not longer than the hand-off ring (8 steps)";
         else if (cq_nr == 0) why = "not taken: two / three workgroups per column quad exceed the compute units";
         else if (h->cq3_off) why = "not taken: switched off after repeated faults (dead waits between the workgroups of a quad)";
         else if (h->cq3_skip > 0) why = "not taken: cooling down after a fault";
@@ -2284,7 +2341,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
         h->cq3_last = cq3 ? (cq_nr == 3 ? "taken: three workgroups per column quad, device held exclusively" : "taken: two workgroups per column quad, device held exclusively") : why;
     }
     // A complex W needs W_i vr(t_n) in the middle of the adjoint step: only the split kernels, whose state role is steps ahead, have it.
-    // Without them (more than 128 samples, the gate taken, cooling down, JQ_CQ3=0 ...) the evaluation runs on the quad-layout kernels.
+    // Without them (more than 128 samples, the gate taken, cooling down, option cq3=0 ...) the evaluation runs on the quad-layout kernels.
     if (cq && wfull && !h->wlr_real && adjoint && !cq3) cq = false;
     const size_t cq3_quad = 64 + (size_t)8 * 8 * h->NT * 64 + 64;      // doubles per quad: JQ_CQ3_HEAD + JQ_CQ3_SLOTS * JQ_CQ3_ARRAYS * NT * 64 + JQ_CQ3_TAIL
     const size_t cq3_need = 64 + (size_t)nq_pad * cq3_quad;
@@ -2294,23 +2351,22 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
         HIPCHK(h, hipMemsetAsync(h->d_cq3, 0, 64 * sizeof(double), h->stream));      // (the error word of the evaluation)
     }
     const bool imr_cq3 = imr_cq && cq3 && cq_nr == 3;
-    const char* e_icq2 = getenv("JQ_IMR_CQ2");
-    const bool imr_cq2 = imr_cq && !imr_cq3 && h->NT <= 6 && !(e_icq2 && atoi(e_icq2) == 0) &&
+    const bool imr_cq2 = imr_cq && !imr_cq3 && h->NT <= 6 && h->opt.on(O_IMR_CQ2) &&
                          cq_imr2_lds(h, (size_t)(2 * JQ_WIN_TPS + 2 * h->NcK) * h->mat_elems * 8) <= 163840;
     if (cq) spw = 0;
     const bool quad = spw > 0;
     const bool quad8 = spw > 1;
     // mid-size ensembles of the 4 x 4 x n structure (at most one column quad per SIMD): the backward sweep with the state and the
-    // adjoint chain of a quad on two waves, one time step apart (jq_quad_split_kernels.h; JQ_QSPLIT=0: the one-wave kernel)
+    // adjoint chain of a quad on two waves, one time step apart (jq_quad_split_kernels.h; option qsplit=0: the one-wave kernel)
     //   qw = 4: one slab per workgroup, two waves per SIMD (the quad-layout plan with one slab per workgroup);
     //   qw = 2: half a slab per workgroup, one wave per SIMD -- more column quads than CUs on the cooperative-quad plan, whose
     //           backward sweep would take two rounds (the forward sweep stays on k_forward_cq with two quads per workgroup)
-    const char* e_qs = getenv("JQ_QSPLIT");
-    const bool qs_on = adjoint && h->NT <= 6 && !(e_qs && atoi(e_qs) == 0);
+    const bool qs_set = h->opt.has(O_QSPLIT);
+    const bool qs_on = adjoint && h->NT <= 6 && !(qs_set && h->opt.get(O_QSPLIT) == 0);
     int qs_qw = 0;
     if (qs_on && quad && !imr && spw == 1 && !wfull && qsplit_lds(h, 4) <= 163840) qs_qw = 4;      // (!imr: the implicit-midpoint quad kernels also run with spw = 1)
-    // (JQ_QSPLIT=2: qw = 2 for every batch of the cooperative-quad plan that does not take the three-workgroup kernels -- tests)
-    const bool qs_force2 = e_qs && atoi(e_qs) == 2;
+    // (option qsplit=2: qw = 2 for every batch of the cooperative-quad plan that does not take the three-workgroup kernels -- tests)
+    const bool qs_force2 = qs_set && h->opt.get(O_QSPLIT) == 2;
     if (qs_on && cq && !cq3 && !wfull && ((nquads_used > h->num_cu && 2 * nslabs <= h->num_cu) || qs_force2) && qsplit_lds(h, 2) <= 163840) qs_qw = 2;
     const bool qsplit = qs_qw > 0;
     const int qs_blocks = qsplit ? (4 * nslabs + qs_qw - 1) / qs_qw : 0;
@@ -2323,15 +2379,16 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     const size_t coop_w_bytes = wfull ? (size_t)2 * JQ_COOP_WDOTS * h->NT * 16 * 8 : 0;
     const bool coop_w_fits = !wfull || h->NT > 6 ||
                              (size_t)2 * h->mat_elems_c * 8 + (size_t)32 * h->NT * 8 + (size_t)2 * h->KT * 64 * 8 + (size_t)16 * h->NT * 8 + coop_w_bytes <= 163840;
-    const bool coop = imr_coop || (!cq && !quad && !lane && !rl && h->NT >= 2 && h->coop_ok && coop_w_fits && (h->solver_id == 1 || h->big) &&
-                                   (nslabs <= h->coop_max_slabs || wfull));      // (Ntot > 96: also the Jacobi solver; full weights: every batch size -- the slab kernels have no low-rank terms)
+    const bool coop = imr_coop || (!cq && !quad && !lane && !rl && h->NT >= 2 && h->coop_ok && coop_w_fits && (h->solver_id == 1 || h->big || wjac) &&
+                                   (nslabs <= h->coop_max_slabs || wfull));
+    if (wjac && !coop && h->BW == JQ_BW_T4)      // (jq_update_wmat / jq_set_linear_solver re-plan such handles without the structure: cannot happen)
+        return fail(h, JQ_EHIP, "internal error: full leakage weights with the Jacobi solver on a 4 x 4 x n plan without cooperative kernels");      // (Ntot > 96: also the Jacobi solver; full weights: every batch size -- the slab kernels have no low-rank terms)
     // row-lane kernels, Stormer-Verlet: the backward sweep's two chains on two waves (jq_rowlane_kernels.h k_backward_rowlane2);
-    // JQ_RL_SPLIT=0: one wave (tests: the two variants must agree bit for bit)
+    // option rl_split=0: one wave (tests: the two variants must agree bit for bit)
     // (both integrators; while the doubled wave count still finds idle issue slots: measured with scripts/time_rl_crossover.py --
     //  NPJ <= 8: up to three waves per SIMD, NPJ = 12, 16 (constant images in LDS, 24 .. 32 operand registers per image row): one)
     bool rl_split = rl && 2 * nwaves_rl <= (long long)(h->rl_npj > 8 ? 4 : 12) * h->num_cu;
-    if (const char* e = getenv("JQ_RL_SPLIT"))
-        if (atoi(e) == 0) rl_split = false;
+    if (!h->opt.on(O_RL_SPLIT)) rl_split = false;
     if (wfull) rl_split = false;      // (the one-wave backward kernel carries the low-rank terms)
     prop_kernel_t kfwd, kbwd;
     lane_init_t klinit = nullptr;
@@ -2348,15 +2405,16 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     if (qsplit && (rc = select_qsplit_kernel(h, qs_qw, &kbwd))) return rc;
     // Jacobi solver with N > 16 on the slab kernels: ONE workgroup per sample when its parts fit one (<= JQ_WAVES = 4 slabs, N <= 64) -- the
     // waves add their parts' residual norms through LDS, so the stopping test is the reference's (norm over the whole Ntot x N block,
-    // src/linear_solvers.jl:121) and not a test per 16-column part (round 5; JQ_JAC_WG=0: per part).  More parts, or the cooperative
+    // src/linear_solvers.jl:121) and not a test per 16-column part (round 5; option jac_wg=0: per part).  More parts, or the cooperative
     // kernels (Ntot > 96): per part as before (include/juqbox_hip.h).
     const bool jac_wg = !imr && h->solver_id == 2 && h->parts > 1 && h->parts <= JQ_WAVES && !coop && !cq && !quad && !lane && !rl &&
-                        !(getenv("JQ_JAC_WG") && atoi(getenv("JQ_JAC_WG")) == 0);
+                        h->opt.on(O_JAC_WG);
     const int nblocks = jac_wg ? nsamples : imr_parts ? nsamples : (cq || imr_cq) ? 4 * nslabs : rl ? (int)nwaves_rl : lane ? (int)(ncols / 64) : quad8 ? (nslabs + spw - 1) / spw : (coop || quad) ? nslabs : (nslabs + JQ_WAVES - 1) / JQ_WAVES;
-    const int nthreads = jac_wg ? 64 * h->parts : (lane || rl) ? 64 : (coop || cq || imr_cq) ? 64 * h->NT : quad8 ? 256 * spw : 256;
+    const bool huge = coop && h->huge;
+    const int nthreads = huge ? 64 * JQ_HUGE_WAVES : jac_wg ? 64 * h->parts : (lane || rl) ? 64 : (coop || cq || imr_cq) ? 64 * h->NT : quad8 ? 256 * spw : 256;
     // per-step trace records: one per wave (cooperative, lane, row-lane, implicit-midpoint kernels) or one per workgroup
     // (slab / quad kernels: summed over the workgroup's waves in LDS)
-    const int trace_rows = qsplit ? qs_blocks : imr_parts ? nsamples * h->NT : imr_cq ? nslabs * qps * h->NT : cq ? nslabs * qps : (lane || rl) ? nblocks : coop ? nslabs * h->NT : imr_quad ? nslabs * JQ_WAVES : nblocks;
+    const int trace_rows = qsplit ? qs_blocks : imr_parts ? nsamples * h->NT : imr_cq ? nslabs * qps * h->NT : cq ? nslabs * qps : (lane || rl) ? nblocks : huge ? nslabs * JQ_HUGE_WAVES : coop ? nslabs * h->NT : imr_quad ? nslabs * JQ_WAVES : nblocks;
     const long long stride = rl ? h->rl_stride : lane ? h->lane_stride : coop ? h->mat_elems_c : h->mat_elems;
     const double* himg = rl ? h->d_himg_r : lane ? h->d_himg_l : coop ? h->d_himg_c : h->d_himg;
     const size_t state_doubles = rl ? (size_t)JQ_ROWLANE_ROWS * nwaves_rl * 64
@@ -2366,18 +2424,11 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     const int ngroups = ctrl_ngroups(h->Nc);
     const bool two_pass = adjoint && h->objFuncType != 1;
     // chunk length: the tile stream of h->chunk_steps steps fits its buffer; the per-step trace records of a backward chunk
-    // ([trace_rows][cs][ntr] doubles) are bounded by JQ_TRACE_BYTES (default 4 GiB) so that large ensembles take more,
+    // ([trace_rows][cs][ntr] doubles) are bounded by option trace_bytes (default 4 GiB) so that large ensembles take more,
     // shorter chunks instead of an allocation that grows with batch size x gate length
-    int cs = h->chunk_steps;
-    if (adjoint) {
-        size_t tbudget = (size_t)4 << 30;
-        if (const char* e = getenv("JQ_TRACE_BYTES")) {
-            const long long v = atoll(e);
-            if (v > 0) tbudget = (size_t)v;
-        }
-        const long long cst = (long long)(tbudget / ((size_t)trace_rows * ntr * sizeof(double)));
-        cs = (int)std::max<long long>(1, std::min<long long>(cs, cst));
-    }
+    const int cs = adjoint ? backward_chunk_steps(h, (size_t)trace_rows) : h->chunk_steps;
+    if (cq3 && std::min(cs, h->nsteps) <= JQ_CQ3_RING)      // (the decision above was made for this very chunking)
+        return fail(h, JQ_EHIP, "internal error: split latency kernels selected for a first chunk that is not longer than their hand-off ring");
 
     // ---- capacity ------------------------------------------------------------------------------
     if ((rc = dev_grow(h, &h->d_pcof, &h->cap_pcof, (size_t)ncoeff))) return rc;
@@ -2389,7 +2440,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     }
     if ((rc = dev_grow(h, &h->d_colinfo, &h->cap_colinfo, colinfo_doubles))) return rc;
     // (parking images of the slab kernels: one array per slab; implicit midpoint with N > 16: the work area of ImrParts, ten)
-    const size_t park_slabs = (size_t)nslabs * (imr_parts ? JQ_IMRP_ARRAYS : 1);
+    const size_t park_slabs = (size_t)nslabs * (imr_parts ? JQ_IMRP_ARRAYS : huge ? JQ_HUGE_VECS : 1);      // (huge: the work area of a slab)
     if (!lane && !rl && (park_slabs > h->cap_slabs || !h->d_park)) {
         h->cap_slabs = 0;
         if ((rc = dev_alloc(h, &h->d_park, park_slabs * h->KT * 64))) return rc;
@@ -2448,7 +2499,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     a.tabs = h->d_tabs; a.stride = stride; a.pieces = (int)(stride * 8 / 1024); a.nslots = h->nslots; a.m = h->m;
     a.nslabs = rl ? (int)nwaves_rl : lane ? (int)ncols : nslabs; a.Ncoupled = ctrl_gstart(h->Nc, 1) /* first control group */; a.Ntot = h->Ntot; a.N = h->N; a.use_shift = use_shift ? 1 : 0;
     a.tinv = 1.0 / h->T; a.state_stride = h->state_stride; a.parts = h->parts; a.nsamples = nsamples; a.sps = h->sps; a.qps = qps;
-    a.wlr = h->d_wlr; a.wrank = h->wrank; a.wstride = h->NP; a.wlr_lds = -1; a.wlr_sc_lds = -1; a.jac_wg_lds = -1; a.wcplx = (h->wrank > 0 && !h->wlr_real) ? 1 : 0;
+    a.wlr = h->d_wlr; a.wrank = h->wrank; a.wlam = h->wlam; a.wstride = h->NP; a.wlr_lds = -1; a.wlr_sc_lds = -1; a.jac_wg_lds = -1; a.wcplx = (h->wrank > 0 && !h->wlr_real) ? 1 : 0;
     // JACOBI_SOLVER: the kernels iterate on c-scaled right-hand sides (A = c rhs, c = h / 2: DESIGN.md section 3), so their
     // residual norm is |c| times the reference's ||X_j - X_{j-1}|| (src/linear_solvers.jl:121): the threshold is scaled alike
     a.jacobi_tol2 = (h->solver_id == 2) ? (h->solver_tol * 0.5 * dt) * (h->solver_tol * 0.5 * dt) : 0.0;
@@ -2456,7 +2507,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
         a.m = h->imr_max_iter;
         a.jacobi_tol2 = h->imr_tol * h->imr_tol;
     }
-    for (int q = 0; q < JQ_MAXNC; ++q) a.bw_trace[q] = h->bw_trace[q];      // (first control group; the backward sweeps set their own)
+    for (int q = 0; q < JQ_MAXNC; ++q) a.bw_trace[q] = q < h->Nc ? h->bw_trace[q] : 0;      // (first control group; the backward sweeps set their own)
     // dynamic LDS layout: [operator staging | tables wd, ws | (backward: carry, parking images)]
     // cooperative kernels: [two operator slots | tables wd, ws | two x exchange buffers]
     const int batch = coop ? 0 : (quad || cq) ? -1 : h->batch;
@@ -2465,23 +2516,23 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
                              : batch < 0 ? (size_t)(2 * JQ_WIN_TPS + 2 * h->NcK) * stride * 8
                                          : (size_t)2 * stride * 8;
     const size_t lds_cq = lds_stage + (size_t)32 * h->NT * 8 + (size_t)6 * (h->NT + 2) * 64 * 8 + (size_t)std::max(2, h->NcK + (h->NcK + 1) / 2) * h->NT * 64 * 8;      // tables, x exchange, trace hand-off / wg-sum scratch (one region)
-    const size_t lds_fwd = rl ? (wfull ? (size_t)JQ_RL_WTAB * 8 : 0) : lane ? 0 : (cq || imr_cq) ? lds_cq : imr_coop ? coop_imr_lds_bytes(h->NT, imr_hbm ? 0 : stride)
+    const size_t lds_fwd = huge ? 0 : rl ? (wfull ? (size_t)JQ_RL_WTAB * 8 : 0) : lane ? 0 : (cq || imr_cq) ? lds_cq : imr_coop ? coop_imr_lds_bytes(h->NT, imr_hbm ? 0 : stride)
                                            : lds_stage + (size_t)32 * h->NT * 8 + (coop ? (size_t)2 * h->KT * 64 * 8 + (size_t)16 * h->NT * 8 + coop_w_bytes : 0);      // (+ the Jacobi solver's column norms [NT][16], the low-rank weights' dot exchange)
-    const size_t lds_bwd = qsplit ? qsplit_lds(h, qs_qw) : rl ? (h->rl_npj > 8 ? (size_t)2 * h->NcK * h->rl_stride * 8 : 0) + (rl_split ? (size_t)2 * 3 * 64 * 8 : 0) /* records: 3 values per lane and slot, implicit midpoint 2 */ + (wfull ? (size_t)JQ_RL_WTAB * 8 : 0) /* low-rank weight table */ : lane ? 0 : imr_cq2 ? cq_imr2_lds(h, lds_stage) : (coop || cq || imr_cq) ? lds_fwd
+    const size_t lds_bwd = huge ? 0 : qsplit ? qsplit_lds(h, qs_qw) : rl ? (h->rl_npj > 8 ? (size_t)2 * h->NcK * h->rl_stride * 8 : 0) + (rl_split ? (size_t)2 * 3 * 64 * 8 : 0) /* records: 3 values per lane and slot, implicit midpoint 2 */ + (wfull ? (size_t)JQ_RL_WTAB * 8 : 0) /* low-rank weight table */ : lane ? 0 : imr_cq2 ? cq_imr2_lds(h, lds_stage) : (coop || cq || imr_cq) ? lds_fwd
                                 : imr_quad ? lds_fwd + (size_t)JQ_MAXNC * nthreads * 8 + (size_t)(nthreads / 64) * h->NT * 64 * 8
                                 : quad ? lds_stage + (size_t)bwd_lds_tail(h->NT, h->NcK, nthreads / 64, (long long)h->NT * 64)   // (a 16-row block per register)
                                 : lds_stage + (size_t)bwd_lds_tail(h->NT, h->NcK, JQ_WAVES, h->park_lds ? (long long)h->KT * 64 : 0);
     // full leakage weights on the slab / quad kernels: a copy of the low-rank table behind everything else in LDS when it fits
     const size_t wlr_bytes = (wfull && cq) ? (size_t)2 * h->NT * 64 * 8      // (cooperative quad: the partial dots of two vectors, CqW)
-                             : (wfull && !coop && !rl && !lane) ? ((size_t)JQ_MAX_WRANK + (size_t)2 * h->wrank * h->NP) * 8 : 0;
+                             : (wfull && !coop && !rl && !lane) ? ((size_t)h->wlam + (size_t)2 * h->wrank * h->NP) * 8 : 0;
     const int wlr_lds_fwd = (wlr_bytes && lds_fwd + wlr_bytes <= 163840) ? (int)lds_fwd : -1;
     const int wlr_lds_bwd = (wlr_bytes && lds_bwd + wlr_bytes <= 163840) ? (int)lds_bwd : -1;
     // (the cooperative-quad kernels have no table in global memory to fall back to: wfull_cq above admitted them only when this fits)
     if (wfull && cq && (wlr_lds_fwd < 0 || wlr_lds_bwd < 0)) return fail(h, JQ_EHIP, "internal error: no LDS left for the partial dots of the full leakage weights");
-    // ... and, quad layout, the per-wave column scalars of the terms behind it (jq_kernels.h WLow::sc).  OFF unless JQ_WLR_SC=1: measured
+    // ... and, quad layout, the per-wave column scalars of the terms behind it (jq_kernels.h WLow::sc).  OFF unless option wlr_sc=1: measured
     // SLOWER than recomputing the dots (round 5, cnot3: 57 -> 70 ms per forbidden state -- an LDS round trip on the critical path of a
     // wave that is alone on its SIMD costs more than the ~ 64 independent instructions of a dot pair; profiles/r05_exp_variants.txt (3))
-    const size_t wsc_bytes = (wlr_bytes && quad && getenv("JQ_WLR_SC") && atoi(getenv("JQ_WLR_SC")) == 1) ? (size_t)(nthreads / 64) * JQ_MAX_WRANK * 24 * 8 : 0;
+    const size_t wsc_bytes = (wlr_bytes && quad && h->opt.get(O_WLR_SC) == 1) ? (size_t)(nthreads / 64) * JQ_MAX_WRANK * 24 * 8 : 0;
     const size_t wsc_off_fwd = lds_fwd + (wlr_lds_fwd >= 0 ? wlr_bytes : 0), wsc_off_bwd = lds_bwd + (wlr_lds_bwd >= 0 ? wlr_bytes : 0);
     const int wsc_lds_fwd = (wsc_bytes && wsc_off_fwd + wsc_bytes <= 163840) ? (int)wsc_off_fwd : -1;
     const int wsc_lds_bwd = (wsc_bytes && wsc_off_bwd + wsc_bytes <= 163840) ? (int)wsc_off_bwd : -1;
@@ -2490,7 +2541,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     a.batch = batch; a.lds_tab_off = (int)lds_stage;
     a.park = h->d_park; a.park_lds = quad ? 1 : h->park_lds;
     if (cq) a.nslots = 0;
-    if (const char* e = getenv("JQ_DEBUG")) a.debug = atoi(e);
+    a.debug = (int)h->opt.get(O_DEBUG);
     if (!lane && !rl) {
         HIPCHK(h, hipFuncSetAttribute((const void*)kfwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_fwd + (wlr_lds_fwd >= 0 ? wlr_bytes : 0) + (wsc_lds_fwd >= 0 ? wsc_bytes : 0) + jac_bytes)));
         HIPCHK(h, hipFuncSetAttribute((const void*)kbwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_bwd + (wlr_lds_bwd >= 0 ? wlr_bytes : 0) + (wsc_lds_bwd >= 0 ? wsc_bytes : 0) + jac_bytes)));
@@ -2627,9 +2678,16 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
                     }
                 }
                 if (cq3) {      // (progress counters of the launch: the 64-double header in front of every quad's ring -- the ring itself is written
-                                // before it is read; the error word in front of everything survives until the end of the evaluation)
+                                // before it is read; the error word in front of everything survives until the end of the evaluation, the
+                                // arrival counter of the start-up rendezvous behind it is per launch)
                     HIPCHK(h, hipMemset2DAsync(h->d_cq3 + 64, cq3_quad * sizeof(double), 0, 64 * sizeof(double), (size_t)nq_pad, s));
+                    HIPCHK(h, hipMemsetAsync(h->d_cq3 + 1, 0, sizeof(double), s));
                     a.park = h->d_cq3;
+                    // rendezvous: option cq3_rdv_us (default 10 ms) in polls of ~ 1.3 us; waits after it: ~ 10 x the launch's expected duration
+                    // (measured on this handle; first launch: 25 us per step, four times the slowest size measured), at least 50 ms
+                    a.rdv_polls = (int)std::max<long long>(16, h->opt.get(O_CQ3_RDV_US) * 10 / 13);
+                    const double us_step = h->cq3_us_per_step > 0.0 ? h->cq3_us_per_step : 25.0;
+                    a.wait_polls = (int)std::min<double>(2.0e9, std::max(50.0e3, 10.0 * us_step * nc) / 1.3);
                 }
                 HIPCHK(h, hipEventRecord(h->ev[evi++], s));
                 if (qsplit) {      // (two waves per column quad; its window ring is deeper than the forward kernel's)
@@ -2650,7 +2708,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
                     unsigned long long e1 = 0;
                     HIPCHK(h, hipMemcpyAsync(&e1, h->d_cq3, sizeof(e1), hipMemcpyDeviceToHost, s));
                     HIPCHK(h, hipStreamSynchronize(s));
-                    if (getenv("JQ_CQ3_FAULT")) e1 = 1;      // (test hook: as if a wait of k_backward_cq3 had been abandoned)
+                    if (h->opt.on(O_CQ3_FAULT)) e1 = (unsigned long long)h->opt.get(O_CQ3_FAULT);      // (test hook: as if a wait had been abandoned (1) / the rendezvous had failed (3))
                     if (e1) {
                         cq3_fault = e1;
                         break;
@@ -2694,7 +2752,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     unsigned long long cq3_err = cq3_fault;
     if (cq3 && !cq3_fault) HIPCHK(h, hipMemcpyAsync(&cq3_err, h->d_cq3, sizeof(cq3_err), hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
-    if (cq3 && getenv("JQ_DEBUG_TIMING")) {      // development aid: progress counters, error word and XCC ids (+ 1) of the first quads
+    if (cq3 && debug_timing()) {      // development aid: progress counters, error word and XCC ids (+ 1) of the first quads
         std::vector<unsigned long long> hw((size_t)64 + 2 * cq3_quad);
         HIPCHK(h, hipMemcpy(hw.data(), h->d_cq3, hw.size() * sizeof(double), hipMemcpyDeviceToHost));
         for (int qd = 0; qd < 2; ++qd) {
@@ -2702,12 +2760,22 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
             fprintf(stderr, "jq cq3 quad %d: steps %llu %llu %llu, error %llu (launch %llu), xcc %llu %llu %llu\n", qd, q[0], q[8], q[16], q[24], hw[0], q[32], q[33], q[34]);
         }
     }
-    if (cq3 && getenv("JQ_CQ3_FAULT")) cq3_err = 1;      // (test hook: as if a wait of k_backward_cq3 had been abandoned)
+    if (cq3 && h->opt.on(O_CQ3_FAULT)) cq3_err = (unsigned long long)h->opt.get(O_CQ3_FAULT);
+    if (cq3_err == 3) {
+        // the launch was abandoned at its start-up rendezvous: not every workgroup became resident within cq3_rdv_us -- another process
+        // holds the compute units.  Nothing is wrong with the handle: repeat on the one-workgroup kernel (milliseconds lost), stay off
+        // the split for a few evaluations (2, 4, ... 64 while it keeps happening), never for good.
+        ++h->cq3_busy;
+        h->cq3_busy_streak = std::min(h->cq3_busy_streak + 1, 5);
+        h->cq3_skip = 2 << h->cq3_busy_streak;      // (the repeat below counts as one)
+        if (debug_timing()) fprintf(stderr, "jq: split latency kernel abandoned at its start-up rendezvous (GPU busy) -- evaluated again on one workgroup per quad\n");
+        return JQ_ERETRY_INTERNAL;
+    }
     if (cq3_err) {      // a wait between the three workgroups of a quad was abandoned (1), or they ran on different XCDs (2): the results are void
         ++h->cq3_faults;
         h->cq3_skip = 2 << std::min(h->cq3_faults, 10);      // (4, 8, 16, ... evaluations; the repeat below counts as one)
         if (h->cq3_faults >= JQ_CQ3_MAX_FAULTS) h->cq3_off = true;
-        if (getenv("JQ_DEBUG_TIMING")) fprintf(stderr, "jq: k_backward_cq3 reported %llu -- evaluated again with k_backward_cq\n", cq3_err);
+        if (debug_timing()) fprintf(stderr, "jq: k_backward_cq3 reported %llu -- evaluated again with k_backward_cq\n", cq3_err);
         return JQ_ERETRY_INTERNAL;
     }
 
@@ -2716,7 +2784,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     h->timing.ms_total = ms;
     double fwd = 0.0, bwd = 0.0;
     const size_t nfwd = (size_t)nchunks;
-    const bool show = getenv("JQ_DEBUG_TIMING") != nullptr;      // development aid: every propagator launch on stderr
+    const bool show = debug_timing();      // development aid: every propagator launch on stderr
     for (size_t i = 2, k = 0; i + 1 < evi; i += 2, ++k) {
         HIPCHK(h, hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
         if (show) fprintf(stderr, "jq launch %zu (%s): %.3f ms\n", k, k < (size_t)nchunks ? "forward" : "backward", ms);
@@ -2724,6 +2792,10 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
             fwd += ms;
         else
             bwd += ms;
+    }
+    if (cq3 && bwd > 0.0) {
+        h->cq3_us_per_step = 1.0e3 * bwd / ((double)h->nsteps * (two_pass ? 2 : 1) * ngroups);
+        h->cq3_busy_streak = 0;
     }
     h->timing.ms_forward = fwd;
     h->timing.ms_backward = bwd;
@@ -2738,7 +2810,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     h->timing.kernel_family = imr_cq ? 9 : cq ? 8 : imr_quad ? 7 : imr_coop ? 5 : imr ? 4 : rl ? 3 : lane ? 2 : coop ? 1 : quad ? 6 : 0;
     h->timing.kernel_size = rl ? h->rl_npj : lane ? h->lane_np : h->NT;
     h->timing.kernel_band = (rl || lane) ? 0 : coop ? h->BWc : (quad || cq) ? JQ_BW_T4Q : h->BW;
-    h->timing.reserved = cq3 ? cq_nr : qsplit ? 20 + qs_qw : 0;      // (workgroups per column quad in the backward sweep of the cooperative-quad kernels)
+    h->timing.kernel_variant = cq3 ? cq_nr : qsplit ? 20 + qs_qw : (rl && rl_split) ? 32 : 0;      // (workgroups per column quad in the backward sweep of the cooperative-quad kernels)
     h->timing.ms_allreduce = 0.0;
     h->timing.ms_shard_min = h->timing.ms_shard_max = h->timing.ms_total;
     return JQ_OK;
@@ -2982,6 +3054,7 @@ struct RcclApi {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;      // (optional)
 };
 static RcclApi g_rccl;
 
@@ -3040,6 +3113,7 @@ static int load_rccl(std::string* err)
     a.GroupStart = (decltype(a.GroupStart))dlsym(lib, "ncclGroupStart");
     a.GroupEnd = (decltype(a.GroupEnd))dlsym(lib, "ncclGroupEnd");
     a.GetErrorString = (decltype(a.GetErrorString))dlsym(lib, "ncclGetErrorString");
+    a.CommCount = (decltype(a.CommCount))dlsym(lib, "ncclCommCount");
     if (!a.CommInitAll || !a.CommDestroy || !a.AllReduce || !a.GroupStart || !a.GroupEnd || !a.GetErrorString) {
         *err = "jq_create_multi: librccl lacks a required symbol";
         return JQ_EUNSUPPORTED;
@@ -3091,19 +3165,25 @@ static void destroy_multi(jq_handle* h)
 
 extern "C" int jq_create_multi(const jq_problem* problem, const int32_t* devices, int32_t ndev, jq_handle** out)
 {
+    return jq_create_multi_opts(problem, devices, ndev, nullptr, out);
+}
+
+extern "C" int jq_create_multi_opts(const jq_problem* problem, const int32_t* devices, int32_t ndev, const char* options, jq_handle** out)
+{
     if (!out) {
         g_create_error = "jq_create_multi: out is NULL";
         return JQ_EINVAL;
     }
     *out = nullptr;
+    JqOptions opt;
+    if (int rc0 = parse_create_options(options, &opt)) return rc0;
     int avail = 0;
     if (hipGetDeviceCount(&avail) != hipSuccess) avail = 0;
-    // JQ_MULTI_SAME_DEVICE=1 (TEST MODE, tests/test_gpu_round3.py): the `ndev` sub-handles may share physical GPUs (device id
+    // option multi_same_device=1 (TEST MODE, tests/test_gpu_round3.py): the `ndev` sub-handles may share physical GPUs (device id
     // taken modulo the visible count, ndev <= 16) -- own streams, own host threads, the same sharding and packing code -- and the
     // ONE step that needs distinct devices, the ncclAllReduce, is replaced by a host-side sum of the devices' packed vectors in
     // device order.  This is how the ndev > 1 code runs on a one-GPU box; it is not a production path (no speed-up).
-    bool same_dev = false;
-    if (const char* e = getenv("JQ_MULTI_SAME_DEVICE")) same_dev = atoi(e) != 0;
+    const bool same_dev = opt.on(O_MULTI_SAME_DEVICE);
     if (ndev < 1 || (same_dev ? (avail < 1 || ndev > 16) : ndev > avail)) {
         char buf[160];
         snprintf(buf, sizeof buf, "jq_create_multi: ndev = %d but %d HIP device(s) are visible", ndev, avail);
@@ -3126,6 +3206,7 @@ extern "C" int jq_create_multi(const jq_problem* problem, const int32_t* devices
         return JQ_ENOMEM;
     }
     h->host_reduce = same_dev;
+    h->opt = opt;
     int rc = JQ_OK;
     for (int d = 0; d < ndev && rc == JQ_OK; ++d) {
         if (hipSetDevice(devs[d]) != hipSuccess) {
@@ -3134,7 +3215,7 @@ extern "C" int jq_create_multi(const jq_problem* problem, const int32_t* devices
             break;
         }
         jq_handle* sub = nullptr;
-        rc = jq_create(problem, &sub);      // (sets g_create_error on failure)
+        rc = create_with(problem, opt, &sub);      // (sets g_create_error on failure)
         if (rc == JQ_OK) h->subs.push_back(sub);
     }
     if (rc == JQ_OK && !h->host_reduce) {
@@ -3225,7 +3306,7 @@ static std::string allreduce_check(const std::vector<double>& expect, const std:
     }
     if (!(worst <= 1e-13 * partial_scale)) {
         snprintf(buf, sizeof buf, "RCCL all-reduce self-check failed: result differs from the host-order sum of the %d devices' packed "
-                                  "vectors by %.3e (sum of the devices' largest entries %.3e); JQ_RCCL_SELFCHECK=0 disables the check", nd, worst, partial_scale);
+                                  "vectors by %.3e (sum of the devices' largest entries %.3e); option rccl_selfcheck=0 disables the check", nd, worst, partial_scale);
         return buf;
     }
     return std::string();
@@ -3277,10 +3358,9 @@ static int multi_eval_f_g_grad(jq_handle* h, const double* pcof, int ncoeff, con
     // Self-check of the collective (the first 8-GPU run verifies itself): on the FIRST all-reduce of a handle the devices' packed
     // vectors are also copied to the host before the collective and their sum in device order is compared with what RCCL returns
     // (1e-13 relative to the largest entry: the ring order differs from the device order in the last bits only).
-    // JQ_RCCL_SELFCHECK=0 switches it off, =2 checks every call.
-    int selfcheck = 1;
-    if (const char* e = getenv("JQ_RCCL_SELFCHECK")) selfcheck = atoi(e);
-    // (JQ_RCCL_SELFCHECK=3 in the same-device test mode, where no collective runs: the comparison itself is exercised -- the host-order
+    // option rccl_selfcheck=0 switches it off, =2 checks every call.
+    const int selfcheck = (int)h->opt.get(O_RCCL_SELFCHECK);
+    // (option rccl_selfcheck=3 in the same-device test mode, where no collective runs: the comparison itself is exercised -- the host-order
     //  sum against the sum in REVERSE device order, i.e. two legitimate summation orders -- so that its tolerance has run somewhere)
     const bool check_now = (!h->host_reduce && (selfcheck >= 2 || (selfcheck == 1 && h->rccl_checks == 0))) || (h->host_reduce && selfcheck == 3);
     std::vector<double> expect;
@@ -3390,6 +3470,58 @@ static int multi_traceobj_sweep(jq_handle* h, const double* pcof, int ncoeff, co
     return JQ_OK;
 }
 
+extern "C" int jq_set_option(jq_handle* h, const char* name, int64_t value)
+{
+    if (!h) return JQ_EINVAL;
+    if (!name) return fail(h, JQ_EINVAL, "jq_set_option: NULL name");
+    const int o = JqOptions::find(name, strlen(name));
+    if (o < 0) return fail(h, JQ_EINVAL, (std::string("jq_set_option: unknown option '") + name + "'").c_str());
+    const long long v = (value == JQ_OPTION_DEFAULT) ? JQ_OPT_UNSET : (long long)value;
+    if (!h->subs.empty()) {
+        std::string err;
+        if (!h->opt.set(o, v, &err)) return fail(h, JQ_EUNSUPPORTED, ("jq_set_option: " + err).c_str());
+        if (o == O_MULTI_SAME_DEVICE) return fail(h, JQ_EINVAL, "jq_set_option: multi_same_device is an option of jq_create_multi_opts");
+        return multi_forall(h, [&](jq_handle* sub) { return jq_set_option(sub, name, value); });
+    }
+    const long long old = h->opt.v[o];
+    if (old == v) return JQ_OK;
+    std::string err;
+    if (!h->opt.set(o, v, &err)) return fail(h, JQ_EUNSUPPORTED, ("jq_set_option: " + err).c_str());
+    if (g_jq_opt[o].flags & JQ_OPT_PLAN) {      // shapes the plan: plan again from the handle's own copy of the problem
+        HIPCHK(h, hipSetDevice(h->device));
+        const std::vector<double> H0 = h->Hconst;
+        const int rc = replan(h, H0.data());
+        if (rc != JQ_OK) {
+            h->opt.v[o] = old;
+            return rc;
+        }
+        h->replanned = false;      // (an option change is not a drift outside the planned structure)
+        return JQ_OK;
+    }
+    if (h->emb) h->emb->opt = h->opt;
+    return JQ_OK;
+}
+
+extern "C" int jq_get_option(const jq_handle* h, const char* name, int64_t* value)
+{
+    if (!h || !name || !value) return JQ_EINVAL;
+    const int o = JqOptions::find(name, strlen(name));
+    if (o < 0) return JQ_EINVAL;
+    const long long v = h->opt.get(o);
+    *value = (v == JQ_OPT_UNSET) ? JQ_OPTION_DEFAULT : (int64_t)v;
+    return JQ_OK;
+}
+
+// ranks of the RCCL communicator behind a multi-device handle (ncclCommCount of its first communicator): what the first real
+// multi-GPU run prints to show that RCCL saw every device.  0: no communicator (single-device handle, same-device test mode).
+extern "C" int jq_rccl_world_size(const jq_handle* h)
+{
+    if (!h || h->comms.empty() || !h->comms[0] || !g_rccl.CommCount) return 0;
+    int n = 0;
+    if (g_rccl.CommCount(h->comms[0], &n) != ncclSuccess) return -1;
+    return n;
+}
+
 extern "C" int jq_plan_info(const jq_handle* hh, char* buf, int32_t buflen)
 {
     if (!hh || (!buf && buflen > 0) || buflen < 0) return JQ_EINVAL;
@@ -3474,11 +3606,12 @@ extern "C" int jq_plan_info(const jq_handle* hh, char* buf, int32_t buflen)
         kv("build", std::string("{\"manifest\": ") + (man.size() > 2 ? "true" : "false") + ", \"hipcc\": " + hipcc + ", \"objects\": " + objs + "}");
     }
     kv("full_weight_rank", num(h->wrank));
+    kv("options", hh->opt.str(), true);      // the options that are set (jq_create_opts / JQ_OPTIONS / jq_set_option); "" = all defaults
     kv("rccl_selfchecks", num(hh->rccl_checks));      // all-reduces of a multi-device handle verified against the host-order sum
     {   // the three-workgroup latency kernels: what the last batch of the cooperative-quad families decided, and why
         const jq_handle* t2 = h->emb ? h->emb : h;
         const std::string d = t2->cq3_last.empty() ? "no batch of the cooperative-quad families yet" : t2->cq3_last;
-        kv("latency_split", std::string("{\"last_decision\": \"") + d + "\", \"faults\": " + num(t2->cq3_faults) + ", \"cooling_down\": " + num(t2->cq3_skip) +
+        kv("latency_split", std::string("{\"last_decision\": \"") + d + "\", \"faults\": " + num(t2->cq3_faults) + ", \"abandoned_at_rendezvous\": " + num(t2->cq3_busy) + ", \"cooling_down\": " + num(t2->cq3_skip) +
                                 ", \"off\": " + (t2->cq3_off ? "true" : "false") + "}");
     }
     o += "}";

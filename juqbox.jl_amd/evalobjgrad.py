@@ -9,7 +9,9 @@
                                         same argument order and return tuples as
                                         src/evalobjgrad.jl:504, :1027-1036.
 """
+import contextlib
 import ctypes
+import threading
 
 import numpy as np
 
@@ -52,6 +54,36 @@ def _csc_array(mats):
     return keep, arr
 
 
+# ---- per-handle options (include/juqbox_hip.h: jq_create_opts / jq_set_option; the table of names is in INTEGRATION.md section 4) ----
+_defaults = threading.local()
+
+
+def _option_string(opts):
+    return ",".join("%s=%d" % (k, int(v)) for k, v in opts.items())
+
+
+def _norm_options(opts):
+    """{"quad": 0} or the historic spelling {"JQ_QUAD": "0"} -> {"quad": 0}"""
+    return {(k[3:].lower() if k.startswith("JQ_") else k): int(v) for k, v in (opts or {}).items()}
+
+
+@contextlib.contextmanager
+def options(**opts):
+    """Default options for the handles CREATED inside the `with` block (tests, bisection):
+        with jq.options(quad=0, coop_max=0):
+            wa = jq.Working_Arrays_HIP(params, nCoeff)
+    They are options of those handles from then on (nothing is read from the environment); an explicit `options=` argument of the
+    constructor is applied on top.  Nested blocks add up.  Options of an existing handle: wa.set_option(name, value)."""
+    prev = dict(getattr(_defaults, "opts", {}))
+    merged = dict(prev)
+    merged.update(_norm_options(opts))
+    _defaults.opts = merged
+    try:
+        yield
+    finally:
+        _defaults.opts = prev
+
+
 class Working_Arrays_HIP:
     """Owns the device handle for one `objparams`.  Mutable fields of `params` that scripts change
     after construction (Hconst, wmat_real, Utarget_r/i, linear_solver.max_iter) are re-synchronised
@@ -85,12 +117,13 @@ class Working_Arrays_HIP:
         else:
             raise ValueError("wmat_real must be a vector of length Ntot (Diagonal) or an Ntot x Ntot matrix")
 
-    def __init__(self, params: objparams, nCoeff: int, devices=None, csc=None):
+    def __init__(self, params: objparams, nCoeff: int, devices=None, csc=None, options=None):
         """devices: None = the current HIP device (one process per GPU); an int n or a list of device ids = ONE process
         driving several GPUs (jq_create_multi: the ensemble of eval_f_g_grad is sharded over them and summed with one
         RCCL all-reduce inside the library).
         csc: hand the operators over in sparse (SparseMatrixCSC) storage like the Julia binding does for use_sparse = true
-        problems (default: params.use_sparse); the results are bit-identical to the dense form."""
+        problems (default: params.use_sparse); the results are bit-identical to the dense form.
+        options: {name: value} for jq_create_opts (on top of the defaults of an enclosing `with options(...)` block)."""
         L = _lib.load()
         if params.linear_solver.solver_id not in self.SOLVERS:
             raise ValueError("Please specify a supported linear solver")
@@ -124,12 +157,18 @@ class Working_Arrays_HIP:
         self._csc = use_csc and not nunc
         prob = _lib.jq_problem(p.Ntot, p.N, p.Ncoupled, p.Nfreq, p.nsteps, self._m, p.objFuncType, nunc, p.T, *ptrs, *sparse_args)
         h = ctypes.c_void_p()
+        opts = dict(getattr(_defaults, "opts", {}))
+        opts.update(_norm_options(options))
+        self.options = opts
+        ostr = _option_string(opts).encode() if opts else None
         if devices is None:
-            rc = L.jq_create(ctypes.byref(prob), ctypes.byref(h))
+            opts.pop("multi_same_device", None)
+            ostr = _option_string(opts).encode() if opts else None
+            rc = L.jq_create_opts(ctypes.byref(prob), ostr, ctypes.byref(h))
         else:
             devs = list(range(devices)) if isinstance(devices, int) else [int(d) for d in devices]
             arr = (ctypes.c_int32 * len(devs))(*devs)
-            rc = L.jq_create_multi(ctypes.byref(prob), arr, len(devs), ctypes.byref(h))
+            rc = L.jq_create_multi_opts(ctypes.byref(prob), arr, len(devs), ostr, ctypes.byref(h))
         if rc != _lib.JQ_OK:
             msg = L.jq_last_error(None)
             raise _lib.JuqboxHipError(rc, msg.decode() if msg else "?")
@@ -191,6 +230,27 @@ class Working_Arrays_HIP:
         if not (np.array_equal(utr, self._utr) and np.array_equal(uti, self._uti)):
             _lib.check(L.jq_update_target(h, _ptr(utr), _ptr(uti)), h)
             self._utr, self._uti = utr.copy(), uti.copy()
+
+    def set_option(self, name, value=None):
+        """jq_set_option: change one option of this handle (value None: back to "not set"); plan-shaping options re-plan it"""
+        name = name[3:].lower() if name.startswith("JQ_") else name
+        v = _lib.JQ_OPTION_DEFAULT if value is None else int(value)
+        _lib.check(_lib.load().jq_set_option(self.handle, name.encode(), v), self.handle)
+
+    def get_option(self, name):
+        v = ctypes.c_int64()
+        rc = _lib.load().jq_get_option(self.handle, name.encode(), ctypes.byref(v))
+        if rc != _lib.JQ_OK:
+            raise KeyError(name)
+        return None if v.value == _lib.JQ_OPTION_DEFAULT else v.value
+
+    @property
+    def num_compute_units(self):
+        return _lib.load().jq_num_compute_units(self.handle)
+
+    @property
+    def rccl_world_size(self):
+        return _lib.load().jq_rccl_world_size(self.handle)
 
     def plan_info(self):
         """jq_plan_info: structure found in the operators, control groups, batch-size thresholds of the kernel families (dict)"""

@@ -43,7 +43,7 @@ def _problem(jq, params, **over):
 
 @pytest.mark.parametrize("over,code", [
     (dict(nsteps=0), -1), (dict(T=0.0), -1), (dict(N=0), -1), (dict(Nunc=-1), -1), (dict(Nunc=1), -1), (dict(objFuncType=9), -1),
-    (dict(neumann_terms=-1), -1), (dict(Ntot=257), -3), (dict(Ncoupled=0), -3), (dict(Ncoupled=17), -3),
+    (dict(neumann_terms=-1), -1), (dict(Ntot=20000), -1), (dict(Ncoupled=0), -3), (dict(Ncoupled=5000), -1),
 ])
 def test_create_validates_before_touching_the_device(jq, over, code):
     from juqbox_jl_amd import _lib
@@ -55,6 +55,24 @@ def test_create_validates_before_touching_the_device(jq, over, code):
     assert rc == code
     assert h.value is None
     assert len(L.jq_last_error(None)) > 0
+
+
+def test_options_are_parsed_before_the_device_is_touched():
+    """jq_create_opts / JQ_OPTIONS (ABI 5): "name=value,..." -- an unknown name, a malformed item or an experiment-only option is an error
+    with a message, whatever the problem is; the table of names is documented"""
+    from juqbox_jl_amd import _lib
+    L = _lib.load()
+    params, info, pcof, _ = case_inputs("swap02")
+    prob, keep = _problem(None, params)
+    h = ctypes.c_void_p()
+    for opts, word in ((b"nonsense=1", b"nonsense"), (b"quad", b"name=value"), (b"quad=zero", b"integer"), (b"quad=0,wlr_sc=1", b"experiment"), (b"debug=4", b"debug")):
+        assert L.jq_create_opts(ctypes.byref(prob), opts, ctypes.byref(h)) == _lib.JQ_EINVAL and h.value is None
+        assert word in L.jq_last_error(None), (opts, L.jq_last_error(None))
+    # well-formed options get as far as the device (none here: JQ_EHIP / JQ_EUNSUPPORTED, not JQ_EINVAL)
+    if L.jq_device_count() == 0:
+        assert L.jq_create_opts(ctypes.byref(prob), b"quad=0, coop_max=0;lane=0 chunk_steps=7", ctypes.byref(h)) in (_lib.JQ_EHIP, _lib.JQ_EUNSUPPORTED)
+    assert L.jq_set_option(None, b"quad", 0) == _lib.JQ_EINVAL and L.jq_get_option(None, b"quad", None) == _lib.JQ_EINVAL
+    assert L.jq_rccl_world_size(None) == 0
 
 
 def test_null_arguments_are_rejected():
@@ -196,16 +214,20 @@ def test_build_manifest_no_object_falls_back():
     fallbacks = sorted(t for t, e in man.items() if e["fallback"])
     retried = sorted(t for t, e in man.items() if e.get("retry"))
     print("objects built with another scheduling strategy:", retried, "-- rebuilt without the VGPR form:", fallbacks)
-    kcd = ("j_", "l_", "r_", "m_")      # (default form by design: Jacobi slab variants, lane / row-lane VALU kernels)
-    # ... and two named objects (csrc/Makefile says why): w_6_5, which hipcc 7.2 MISCOMPILES in VGPR form (wrong states for odd chunk
-    # lengths; tests/test_gpu_round5.py test_short_runs_with_odd_and_even_numbers_of_steps), and k_6_0, whose VGPR build cannot be validated
-    by_design = ("k_6_0", "w_6_5")
+    # Round 6 (csrc/Makefile, profiles/r06_register_forms.txt): the VGPR form only where it was measured to pay -- the slab kernels k_*, the
+    # quad-layout objects s_ / p_ / q_ / w_, the LDS-staged cooperative kernels c_* with NT <= 6 -- and the default form everywhere else:
+    # Jacobi objects j_ / x_, VALU kernels l_ / r_ / m_, cooperative-quad u_ / v_, cooperative implicit midpoint i_, the three-slab
+    # quad-layout kernels k_*_7 (the benchmark's), the Ntot > 96 cooperative kernels c_7.. c_16, and two named objects: w_6_5, which hipcc
+    # 7.2 MISCOMPILES in VGPR form (tests/test_gpu_round5.py test_short_runs_with_odd_and_even_numbers_of_steps), and k_6_0, which crashes it.
+    def default_form(t):
+        pre, nt = t.split("_")[0], int(t.split("_")[1])
+        return (pre in ("j", "x", "l", "r", "m", "u", "v", "i") or t in ("k_6_0", "w_6_5") or (pre == "k" and t.endswith("_7")) or (pre == "c" and nt >= 7))
     assert not fallbacks, "objects fell back to the default register form: %s" % fallbacks
+    nvgpr = 0
     for t, e in man.items():
-        if t in by_design:
-            assert not e["vgpr_form"], t + ": must stay in the default register form (see csrc/Makefile)"
-        elif not t.startswith(kcd):
-            assert e["vgpr_form"], t
+        assert bool(e["vgpr_form"]) == (not default_form(t)), t + ": register form differs from the rule in csrc/Makefile"
+        nvgpr += bool(e["vgpr_form"])
+    assert 60 <= nvgpr <= 110, nvgpr      # (every one of them is fenced by tests/test_gpu_forms.py / make check-forms)
     # a retried object (VGPR form with another scheduling strategy than its rule asks for) is an UNVALIDATED build: none at the moment --
     # a new one must be checked on the GPU (scripts/repro_dense_k60.py is the pattern) and listed here or pinned to the default form
     assert not retried, "objects built with a substitute scheduling strategy: %s" % retried
@@ -249,18 +271,24 @@ def test_committed_pmc_record_belongs_to_this_build():
                       "scripts/profile_round.sh and commit the record" % (rec["library_version"], _lib.load().jq_version().decode()))
 
 
-def test_every_environment_variable_the_library_reads_is_documented():
-    """Round-4 review: ~ 30 JQ_* variables select kernels at run time.  They exist for tests, experiments and bisection; each one the
-    library reads must have a row in INTEGRATION.md section 4 (what it does, when it is read)."""
+def test_the_library_reads_five_environment_variables_and_documents_every_option():
+    """Round-5 review: 37 JQ_* variables selected kernels at run time.  ABI 5: every knob is an option of a handle (jq_options.h);
+    the library reads JQ_OPTIONS (options for callers that cannot pass a string), JQ_DEBUG_TIMING (stderr trace), JQ_RCCL_LIB (which
+    librccl to load) and -- to stay off a grid sized for all CUs -- the runtime's own HSA_CU_MASK / ROC_GLOBAL_CU_MASK.  Nothing else.
+    Every option of the table and every variable has a row in INTEGRATION.md section 4."""
     import glob
     import re
     names = set()
     for f in glob.glob(os.path.join(ROOT, "juqbox.jl_amd", "csrc", "*.h*")):
         names |= set(re.findall(r'getenv\("([A-Z0-9_]+)"\)', open(f).read()))
-    assert len(names) >= 30
+    assert names == {"JQ_OPTIONS", "JQ_DEBUG_TIMING", "JQ_RCCL_LIB", "HSA_CU_MASK", "ROC_GLOBAL_CU_MASK"}, sorted(names)
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
-    missing = sorted(n for n in names if n not in doc)
-    assert not missing, "environment variables without a row in INTEGRATION.md: %s" % missing
+    assert not [n for n in names if n not in doc]
+    table = open(os.path.join(ROOT, "juqbox.jl_amd", "csrc", "jq_options.h")).read()
+    opts = re.findall(r'^    \{"([a-z0-9_]+)", ', table, flags=re.M)
+    assert len(opts) >= 30 and len(set(opts)) == len(opts)
+    missing = [o for o in opts if "`%s`" % o not in doc]
+    assert not missing, "options without a row in INTEGRATION.md section 4: %s" % missing
 
 
 def test_makefile_rules_list_the_headers_their_headers_include():
@@ -299,7 +327,7 @@ def test_profiles_readme_names_files_that_exist():
     import re
     pdir = os.path.join(ROOT, "profiles")
     text = open(os.path.join(pdir, "README.md")).read()
-    named = set(re.findall(r"`(r05_[A-Za-z0-9_.]+\.(?:txt|json|log))`", text))
-    have = set(f for f in os.listdir(pdir) if f.startswith("r05_"))
+    named = set(re.findall(r"`(r0[56]_[A-Za-z0-9_.]+\.(?:txt|json|log))`", text))
+    have = set(f for f in os.listdir(pdir) if f.startswith(("r05_", "r06_")))
     assert named - have == set(), "named in profiles/README.md but missing: %s" % sorted(named - have)
     assert have - named == set(), "in profiles/ but not described: %s" % sorted(have - named)

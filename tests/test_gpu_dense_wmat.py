@@ -17,17 +17,9 @@ from test_gpu_random import random_problem
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-10
-ENVS = ("JQ_CHUNK_STEPS", "JQ_COOP_MAX", "JQ_LANE", "JQ_ROWLANE_MAX", "JQ_T4", "JQ_OD", "JQ_QUAD", "JQ_CQ", "JQ_EMBED", "JQ_FORCE_DENSE")      # (read at jq_create)
-
-
 def make_wa(jq, p, ncoef, env=None, **kw):
-    for k, v in (env or {}).items():
-        os.environ[k] = v
-    try:
-        return jq.Working_Arrays_HIP(p, ncoef, **kw)
-    finally:
-        for k in ENVS:
-            os.environ.pop(k, None)
+    """env: options of the new handle in the historic spelling ({"JQ_QUAD": "0"} = option quad=0)"""
+    return jq.Working_Arrays_HIP(p, ncoef, options=env, **kw)
 
 
 def set_forbidden(p, rng, nforb, complex_states=True):
@@ -100,12 +92,7 @@ def test_cnot2(jq, oft, env, family):
 def test_cnot3_short(jq, oft, nforb, env, family, band):
     p, pcof = forbidden_problem("cnot3", nforb, 23, True, oft, nsteps=300)
     wa = make_wa(jq, p, pcof.size, env)
-    if "JQ_CQ_W" in env:      # (read per evaluation)
-        os.environ["JQ_CQ_W"] = env["JQ_CQ_W"]
-    try:
-        compare(jq, p, pcof, wa, family=family, ensembles=(3, 9), rng=np.random.default_rng(3))
-    finally:
-        os.environ.pop("JQ_CQ_W", None)
+    compare(jq, p, pcof, wa, family=family, ensembles=(3, 9), rng=np.random.default_rng(3))
     assert wa.last_timing()["kernel_band"] == band
     wa.close()
 
@@ -210,8 +197,7 @@ def test_refusals(jq):
 @pytest.mark.parametrize("complex_states", [True, False])
 def test_multi_device_handle_and_replanning_carry_the_weights(jq, complex_states):
     """(real forbidden states, round 5: the sub-handles' shards run on the cooperative-quad kernels with the low-rank terms)"""
-    os.environ["JQ_MULTI_SAME_DEVICE"] = "1"
-    try:
+    with jq.options(multi_same_device=1):
         p, pcof = forbidden_problem("cnot3", 2, 26, complex_states, 3, nsteps=200)
         wa1 = make_wa(jq, p, pcof.size)
         wa3 = make_wa(jq, p, pcof.size, devices=3)
@@ -232,8 +218,6 @@ def test_multi_device_handle_and_replanning_carry_the_weights(jq, complex_states
         compare(jq, p, pcof, wa1)
         assert wa1.plan_info()["replanned"] is True
         wa1.close()
-    finally:
-        os.environ.pop("JQ_MULTI_SAME_DEVICE", None)
 
 
 @pytest.mark.parametrize("case", ["swap02", "cnot2", "cnot3"])

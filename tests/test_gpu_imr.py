@@ -27,13 +27,9 @@ def test_reference_imr_golden_through_the_callbacks(jq, case):
     params, pcof = _imr_params(jq, case)
     golden = load_golden(case + "-imr")
     env = {"coop": {"JQ_QUAD": "0"}, "quad": {"JQ_IMR_CQ": "0"}}.get(mode, {})
-    os.environ.update(env)
-    try:
+    with jq.options(**env):
         wa = jq.Working_Arrays_M_HIP(params, pcof.size)
         _golden_checks(jq, params, pcof, wa, golden, mode)
-    finally:
-        for k in env:
-            os.environ.pop(k, None)
 
 
 def _golden_checks(jq, params, pcof, wa, golden, mode):
@@ -150,13 +146,9 @@ def test_imr_random_problems_match_oracle(jq, cfg):
     p.Integrator_id = jq.Implicit_Midpoint
     p.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER_M, max_iter=60, tol=1e-11, nrhs=N)
     p.wmat = p.wmat_real.copy()
-    os.environ.update(env)
-    try:
+    with jq.options(**env):
         wa = jq.Working_Arrays_M_HIP(p, pcof.size)
         _random_checks(jq, p, pcof, wa, rng, Ntot, N, structure, "JQ_IMR_CQ" in env)
-    finally:
-        for k in env:
-            os.environ.pop(k, None)
 
 
 def _random_checks(jq, p, pcof, wa, rng, Ntot, N, structure, noncq):
@@ -235,16 +227,12 @@ def test_imr_cooperative_quad_ensemble_matches_quad_layout(jq):
     res = {}
     for tag, env in (("cq", {}), ("quad", {"JQ_IMR_CQ": "0"})):
         env = dict(env, JQ_CHUNK_STEPS="5")
-        os.environ.update(env)
-        try:
+        with jq.options(**env):
             wa = jq.Working_Arrays_M_HIP(p, pcof.size)
             jq.eval_f_g_grad(pcof, p, wa, nodes, weights, True, shift=shift)
             res[tag] = (p.last_infidelity, p.last_leak, p.last_infidelity_grad.copy(), p.last_leak_grad.copy(),
                         wa.last_timing()["kernel_family"])
             wa.close()
-        finally:
-            for k in env:
-                os.environ.pop(k, None)
     a, b = res["cq"], res["quad"]
     assert a[4] == 9 and b[4] == 7
     assert abs(a[0] - b[0]) <= 1e-12 * abs(b[0]) and abs(a[1] - b[1]) <= 1e-12 * abs(b[1])

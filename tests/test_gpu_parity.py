@@ -49,18 +49,14 @@ def test_reference_golden_through_the_callbacks(hip, case):
     jq = hip
     case, _, mode = case.partition(":")
     params, info, pcof, golden = case_inputs(case)
+    opts = {}
     if mode:
-        os.environ["JQ_QUAD"] = "0"
+        opts["quad"] = 0
     if mode.startswith("slab"):
-        os.environ["JQ_COOP_MAX"] = "0"
+        opts["coop_max"] = 0
     if mode == "slab-band":
-        os.environ["JQ_OD"] = "0"
-    try:
-        wa = jq.Working_Arrays_HIP(params, pcof.size)
-    finally:
-        os.environ.pop("JQ_COOP_MAX", None)
-        os.environ.pop("JQ_OD", None)
-        os.environ.pop("JQ_QUAD", None)
+        opts["od"] = 0
+    wa = jq.Working_Arrays_HIP(params, pcof.size, options=opts)
     obj, grad = gpu_eval_like_evalGrad(jq, params, wa, pcof)
     assert reference_pass(obj, golden["obj0"]), (obj, golden["obj0"])
     assert reference_pass(grad, golden["grad0"])
@@ -258,12 +254,8 @@ def test_planned_kernels_match_the_slab_kernels_on_large_ensembles(hip, nsamples
     nodes, weights, shift = jq.cases.cnot3_ensemble(nsamples)
     out = {}
     for tag, env in (("plan", {}), ("slab", {"JQ_QUAD": "0", "JQ_COOP_MAX": "0"})):
-        os.environ.update(env)
-        try:
+        with jq.options(**env):
             wa = jq.Working_Arrays_HIP(params, pcof.size)
-        finally:
-            for k in env:
-                os.environ.pop(k, None)
         jq.eval_f_g_grad(pcof, params, wa, nodes, weights, True, shift=shift)
         out[tag] = (params.last_infidelity, params.last_leak, params.last_infidelity_grad.copy(), wa.last_timing()["kernel_family"])
         wa.close()

@@ -11,10 +11,6 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True)
-def _clean_env():
-    yield
-    os.environ.pop("JQ_QUAD8", None)
 TOL = 1e-10   # the reference's own tolerance (test/evalGrad.jl:4-5); observed ~1e-13 on these random problems
 
 
@@ -162,33 +158,25 @@ def test_random_problem_matches_oracle(jq, cfg, mode):
         pytest.skip("slab-od: the JQ_BW_T4 problems once more on the JQ_BW_OD / band kernels (JQ_T4=0)")
     rng = np.random.default_rng(1000 + Ntot * 31 + N)
     p, pcof = random_problem(jq, rng, Ntot, N, Nc, Nfreq, nsteps, m, oft, banded)
+    opts = {}
     if chunk:
-        os.environ["JQ_CHUNK_STEPS"] = str(chunk)
-    if mode in ("quad8", "quad12"):          # (read per evaluation: stays set for the whole test)
-        os.environ["JQ_QUAD8"] = "1" if mode == "quad8" else "2"
+        opts["chunk_steps"] = chunk
+    if mode in ("quad8", "quad12"):
+        opts["quad8"] = 1 if mode == "quad8" else 2
     if mode in ("slab", "slab-od"):
-        os.environ["JQ_COOP_MAX"] = "0"
-        os.environ["JQ_LANE"] = "0"
+        opts["coop_max"] = 0
+        opts["lane"] = 0
     if mode in ("slab", "slab-od", "coop"):
-        os.environ["JQ_QUAD"] = "0"
+        opts["quad"] = 0
     if mode == "slab-od":
-        os.environ["JQ_T4"] = "0"
+        opts["t4"] = 0
     if mode == "quad4":
-        os.environ["JQ_CQ"] = "0"
+        opts["cq"] = 0
     if mode == "nolane":
-        os.environ["JQ_LANE"] = "0"
+        opts["lane"] = 0
     if mode == "lane":
-        os.environ["JQ_ROWLANE_MAX"] = "0"
-    try:
-        wa = jq.Working_Arrays_HIP(p, pcof.size)
-    finally:
-        os.environ.pop("JQ_CHUNK_STEPS", None)
-        os.environ.pop("JQ_COOP_MAX", None)
-        os.environ.pop("JQ_LANE", None)
-        os.environ.pop("JQ_ROWLANE_MAX", None)
-        os.environ.pop("JQ_T4", None)
-        os.environ.pop("JQ_QUAD", None)
-        os.environ.pop("JQ_CQ", None)
+        opts["rowlane_max"] = 0
+    wa = jq.Working_Arrays_HIP(p, pcof.size, options=opts)
     r = Oracle(p, use_sparse=False).traceobjgrad(pcof, history=True)
     objfv, tg, prim, sec, tinf, ig, lg = jq.traceobjgrad(pcof, p, wa, False, True)
     gn = np.linalg.norm(r["totalgrad"])
@@ -225,4 +213,3 @@ def test_random_problem_matches_oracle(jq, cfg, mode):
         if oft != 1:
             assert np.linalg.norm(p.last_leak_grad - ref["last_leak_grad"]) <= TOL * np.linalg.norm(gref)
     wa.close()
-    os.environ.pop("JQ_QUAD8", None)

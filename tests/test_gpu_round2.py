@@ -134,13 +134,8 @@ def test_trace_record_budget_only_changes_the_chunking(hip):
     nodes, weights, shift = jq.cases.cnot3_ensemble(40)
     res = []
     for budget in (None, "20000"):
-        if budget:
-            os.environ["JQ_TRACE_BYTES"] = budget
-        try:
-            wa = jq.Working_Arrays_HIP(params, pcof.size)
-            jq.eval_f_g_grad(pcof, params, wa, nodes, weights, True, shift=shift)
-        finally:
-            os.environ.pop("JQ_TRACE_BYTES", None)
+        wa = jq.Working_Arrays_HIP(params, pcof.size, options={"trace_bytes": budget} if budget else None)
+        jq.eval_f_g_grad(pcof, params, wa, nodes, weights, True, shift=shift)
         res.append((params.last_infidelity, params.last_leak, params.last_infidelity_grad.copy(),
                     wa.last_timing()["n_backward_launches"]))
         wa.close()
@@ -313,11 +308,7 @@ def test_cnot2_goldens_on_the_quad_layout_kernels_through_the_embedding(hip, cas
     from conftest import reference_pass
     jq = hip
     params, info, pcof, golden = case_inputs(case)
-    os.environ["JQ_EMBED"] = "2"
-    try:
-        wa = jq.Working_Arrays_HIP(params, pcof.size)
-    finally:
-        os.environ.pop("JQ_EMBED", None)
+    wa = jq.Working_Arrays_HIP(params, pcof.size, options={"embed": 2})
     obj, grad = gpu_eval_like_evalGrad(jq, params, wa, pcof)
     t = wa.last_timing()
     assert (t["kernel_family"], t["kernel_band"], t["kernel_size"]) == (6, 7, 1)
@@ -377,14 +368,8 @@ def test_random_kronecker_problems_take_the_embedded_kernels(hip, dims, N, nq):
     shift = 0.05 * rng.standard_normal(Ntot)
     out = {}
     for mode in ("2", "0"):
-        os.environ["JQ_EMBED"] = mode
-        if mode == "2":
-            os.environ["JQ_LANE"] = "0"      # (a space that has the structure natively, 2 x 2 x 3, must use it too: no lane kernels)
-        try:
-            wa = jq.Working_Arrays_HIP(p, pcof.size)
-        finally:
-            os.environ.pop("JQ_EMBED", None)
-            os.environ.pop("JQ_LANE", None)
+        # (a space that has the structure natively, 2 x 2 x 3, must use it too: no lane kernels)
+        wa = jq.Working_Arrays_HIP(p, pcof.size, options=dict({"embed": mode}, **({"lane": 0} if mode == "2" else {})))
         jq.eval_f_g_grad(pcof, p, wa, nodes, weights, True, shift=shift)
         t = wa.last_timing()
         out[mode] = (p.last_infidelity, p.last_leak, p.last_infidelity_grad.copy(), p.last_leak_grad.copy(), t["kernel_family"], t["kernel_band"])
@@ -431,8 +416,7 @@ def test_split_batches_give_the_results_of_the_unsplit_batch(hip):
     weights = weights * (1.0 + 0.3 * np.cos(np.arange(ns)))      # (not uniform: a mix-up of the two parts' weights would show)
     res = {}
     for tag in ("split", "nosplit"):
-        if tag == "nosplit":
-            os.environ["JQ_NOSPLIT"] = "1"
+        wa.set_option("nosplit", 1 if tag == "nosplit" else None)
         try:
             jq.eval_f_g_grad(pcof, params, wa, nodes, weights, True, shift=shift)
             t = wa.last_timing()
@@ -442,7 +426,7 @@ def test_split_batches_give_the_results_of_the_unsplit_batch(hip):
             assert hiprt.hipMemcpy(packed.ctypes.data_as(ctypes.c_void_p), d_packed, ctypes.c_size_t(8 * npk), 2) == 0      # DeviceToHost
             sweep = jq.traceobj_sweep(pcof, params, wa, nodes, shift=shift)
         finally:
-            os.environ.pop("JQ_NOSPLIT", None)
+            wa.set_option("nosplit", None)
         res[tag] = (params.last_infidelity, params.last_leak, params.last_infidelity_grad.copy(), packed, np.asarray(sweep),
                     t["n_forward_launches"], t["svts"])
     a, b = res["split"], res["nosplit"]
@@ -504,8 +488,7 @@ def test_cooperative_quad_kernels_with_single_subsystem_controls_match_the_oracl
     r = Oracle(params).traceobjgrad(pcof)
     res = []
     for env in ({}, {"JQ_CQ_GENERIC_TRACES": "1"}):
-        os.environ.update(env)
-        try:
+        with jq.options(**env):
             wa = jq.Working_Arrays_HIP(params, pcof.size)
             objfv, tg, prim, sec, tinf, ig, lg = jq.traceobjgrad(pcof, params, wa, False, True)
             assert wa.last_timing()["kernel_family"] == 8
@@ -513,9 +496,6 @@ def test_cooperative_quad_kernels_with_single_subsystem_controls_match_the_oracl
             jq.eval_f_g_grad(pcof, params, wa, nodes, weights, True, shift=np.arange(params.Ntot) * 1.0)
             res.append((objfv, tg, ig, params.last_infidelity, params.last_infidelity_grad.copy()))
             wa.close()
-        finally:
-            for k in env:
-                os.environ.pop(k, None)
         gn = np.linalg.norm(r["totalgrad"])
         assert abs(objfv - r["objfv"]) <= 1e-10 * abs(r["objfv"])
         assert np.linalg.norm(tg - r["totalgrad"]) <= 1e-10 * gn and np.linalg.norm(ig - r["infidelgrad"]) <= 1e-10 * gn

@@ -35,10 +35,9 @@ def hip(jq):
 
 
 @pytest.fixture()
-def same_device():
-    os.environ["JQ_MULTI_SAME_DEVICE"] = "1"
-    yield
-    os.environ.pop("JQ_MULTI_SAME_DEVICE", None)
+def same_device(jq):
+    with jq.options(multi_same_device=1):      # (option of the multi-device handles created inside: jq_create_multi_opts)
+        yield
 
 
 def _ensemble(params, nquad, seed=0):
@@ -142,7 +141,7 @@ def test_multi_handle_reports_errors_of_a_sub_handle(hip, same_device):
 def test_same_device_mode_is_off_by_default(hip):
     from juqbox_jl_amd import _lib
     jq = hip
-    assert "JQ_MULTI_SAME_DEVICE" not in os.environ
+    assert "multi_same_device" not in os.environ.get("JQ_OPTIONS", "")
     params, info, pcof, _ = case_inputs("swap02")
     with pytest.raises(_lib.JuqboxHipError):
         jq.Working_Arrays_HIP(params, pcof.size, devices=[0, 0])
@@ -185,8 +184,7 @@ def _bitwise_rounds(jq, p, pcof, env, family, imr=False, nq=None, history=True):
     shift[0] = 0.0
     runs = []
     fam = None
-    os.environ.update(env)                      # (some knobs are read at jq_create, some per evaluation: set for the whole test)
-    try:
+    with jq.options(**env):      # (some knobs are read at jq_create, some per evaluation: set for the whole test)
         for handle in range(2):
             wa = (jq.Working_Arrays_M_HIP if imr else jq.Working_Arrays_HIP)(p, pcof.size)
             for rep in range(3 if handle == 0 else 1):
@@ -197,9 +195,6 @@ def _bitwise_rounds(jq, p, pcof, env, family, imr=False, nq=None, history=True):
                 hist = jq.traceobjgrad(pcof, p, wa, True, False)[1][:, :, ::max(1, p.nsteps // 7)] if history else None
                 runs.append((o, e, hist))
             wa.close()
-    finally:
-        for k in env:
-            os.environ.pop(k, None)
     o0, e0, h0 = runs[0]
     for o, e, hist in runs[1:]:
         assert o[0] == o0[0] and o[2] == o0[2] and o[3] == o0[3]
@@ -354,8 +349,7 @@ def test_more_than_four_controls_match_the_oracle(hip, name, cfg, env, imr):
         p.Integrator_id = jq.Implicit_Midpoint
         p.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER_M, max_iter=80, tol=1e-12, nrhs=N)
         p.wmat = p.wmat_real.copy()
-    os.environ.update(env)
-    try:
+    with jq.options(**env):
         wa = (jq.Working_Arrays_M_HIP if imr else jq.Working_Arrays_HIP)(p, pcof.size)
         orc = Oracle(p, use_sparse=False)
         r = orc.traceobjgrad_imr(pcof, 80, 1e-12) if imr else orc.traceobjgrad(pcof)
@@ -388,9 +382,6 @@ def test_more_than_four_controls_match_the_oracle(hip, name, cfg, env, imr):
             if oft != 1:
                 assert np.linalg.norm(p.last_leak_grad - ref["last_leak_grad"]) <= tol * np.linalg.norm(gref)
         wa.close()
-    finally:
-        for k in env:
-            os.environ.pop(k, None)
 
 
 def test_seventeen_controls_are_refused(hip):
@@ -481,18 +472,13 @@ def test_rowlane_backward_sweep_on_two_waves_equals_the_one_wave_kernel(hip, cas
     params, info, pcof, golden = case_inputs(case)
     res = {}
     for tag in ("split", "one"):
-        if tag == "one":
-            os.environ["JQ_RL_SPLIT"] = "0"
-        try:
-            wa = jq.Working_Arrays_HIP(params, pcof.size)
-            o = jq.traceobjgrad(pcof, params, wa, False, True)
-            assert wa.last_timing()["kernel_family"] == 3
-            nodes, weights, shift = _ensemble(params, 7, seed=3)
-            jq.eval_f_g_grad(pcof, params, wa, nodes, weights, True, shift=shift)
-            res[tag] = (o, params.last_infidelity, params.last_leak, params.last_infidelity_grad.copy(), params.last_leak_grad.copy())
-            wa.close()
-        finally:
-            os.environ.pop("JQ_RL_SPLIT", None)
+        wa = jq.Working_Arrays_HIP(params, pcof.size, options={"rl_split": 0} if tag == "one" else None)
+        o = jq.traceobjgrad(pcof, params, wa, False, True)
+        assert wa.last_timing()["kernel_family"] == 3 and wa.last_timing()["kernel_variant"] == (32 if tag == "split" else 0)
+        nodes, weights, shift = _ensemble(params, 7, seed=3)
+        jq.eval_f_g_grad(pcof, params, wa, nodes, weights, True, shift=shift)
+        res[tag] = (o, params.last_infidelity, params.last_leak, params.last_infidelity_grad.copy(), params.last_leak_grad.copy())
+        wa.close()
     a, b = res["split"], res["one"]
     assert a[0][0] == b[0][0]                                  # (the forward sweep is the same kernel)
     for k in (1, 5, 6):

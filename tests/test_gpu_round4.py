@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("K", [2, 4])
 def test_bench_single_process_same_device(K):
-    env = dict(os.environ, JQ_MULTI_SAME_DEVICE="1", JQ_BENCH_SAMPLES="128")
+    env = dict(os.environ, JQ_OPTIONS="multi_same_device=1", JQ_BENCH_SAMPLES="128")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--single-process", "--gpus", str(K), "--steps", "1", "--warmup", "1",
            "--strong-samples", "512", "--strong-small-samples", "256", "--quick-extras"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
@@ -31,7 +31,7 @@ def test_bench_single_process_same_device(K):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline", "per_rank_ms", "allreduce_ms", "strong_scaling", "strong_scaling_small"):
         assert k in j, k
-    assert j["n_gpus"] == K and j["config"]["rccl_world_size"] == K
+    assert j["n_gpus"] == K and j["config"]["devices_behind_handle"] == K and j["config"]["rccl_world_size"] == 0      # (test mode: no communicator)
     assert j["config"]["launcher"].startswith("TEST MODE same-device") and "not a multi-GPU measurement" in j["config"]["launcher"]
     assert j["config"]["samples_per_gpu"] == 128 and j["value"] > 0
     assert 0.0 < j["per_rank_ms"]["min"] <= j["per_rank_ms"]["max"] and j["allreduce_ms"] >= 0.0
@@ -43,7 +43,7 @@ def test_bench_single_process_same_device(K):
     # without the test mode the same request is refused on a box with fewer GPUs
     from juqbox_jl_amd import _lib
     if _lib.load().jq_device_count() < K:
-        env.pop("JQ_MULTI_SAME_DEVICE")
+        env.pop("JQ_OPTIONS")
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
         assert r.returncode != 0 and "GPU(s) are visible" in r.stderr and not any(ln.startswith("{") for ln in r.stdout.splitlines())
 
@@ -196,17 +196,13 @@ def test_uni_and_ord_variants_of_the_throughput_kernel_agree(jq):
     nodes, weights, shift = jq.cases.cnot3_ensemble(3072)
     res = {}
     for tag, env in (("ord", {}), ("uni", {"JQ_NO_ORD": "1"}), ("generic", {"JQ_NO_UNI": "1"})):
-        os.environ.update(env)
-        try:
+        with jq.options(**env):
             wa = jq.Working_Arrays_HIP(params, pcof.size)
             jq.eval_f_g_grad(pcof, params, wa, nodes, weights, True, shift=shift)
             t = wa.last_timing()
             assert t["kernel_family"] == 6 and t["kernel_band"] == 7
             res[tag] = (params.last_infidelity, params.last_leak, params.last_infidelity_grad.copy())
             wa.close()
-        finally:
-            for k in env:
-                os.environ.pop(k, None)
     g = np.linalg.norm(res["generic"][2])
     for tag in ("ord", "uni"):
         assert abs(res[tag][0] - res["generic"][0]) <= 1e-13 * abs(res["generic"][0])
@@ -232,8 +228,7 @@ def test_two_set_cooperative_quad_implicit_midpoint_kernel_is_the_one_set_kernel
     res = {}
     for tag, env in (("three", {"JQ_CHUNK_STEPS": "400"}), ("two", {"JQ_CQ3": "0", "JQ_CHUNK_STEPS": "400"}),
                      ("one", {"JQ_CQ3": "0", "JQ_IMR_CQ2": "0", "JQ_CHUNK_STEPS": "400"}), ("three_whole", {})):
-        os.environ.update(env)
-        try:
+        with jq.options(**env):
             wa = jq.Working_Arrays_M_HIP(params, pcof.size)
             if nsamples:
                 nodes, weights, shift = jq.cases.cnot3_ensemble(nsamples)
@@ -243,11 +238,8 @@ def test_two_set_cooperative_quad_implicit_midpoint_kernel_is_the_one_set_kernel
                 f, g, *_ = jq.traceobjgrad(pcof, params, wa, False, True)
                 res[tag] = (f, 0.0, np.array(g))
             t = wa.last_timing()
-            assert t["kernel_family"] == 9 and t["reserved"] == (3 if tag.startswith("three") else 0)
+            assert t["kernel_family"] == 9 and t["kernel_variant"] == (3 if tag.startswith("three") else 0)
             wa.close()
-        finally:
-            for k in env:
-                os.environ.pop(k, None)
     for tag in ("two", "one"):
         assert res["three"][0] == res[tag][0] and res["three"][1] == res[tag][1]
         assert np.array_equal(res["three"][2], res[tag][2])
@@ -269,16 +261,12 @@ def test_forward_cooperative_quad_kernel_with_two_quads_per_workgroup(jq, nsampl
     nodes, weights, shift = jq.cases.cnot3_ensemble(nsamples)
     res = {}
     for tag, env in (("two", {"JQ_CQ_FWD2": "1", "JQ_CHUNK_STEPS": "250"}), ("one", {"JQ_CQ_FWD2": "0", "JQ_CHUNK_STEPS": "250"}), ("auto", {"JQ_CHUNK_STEPS": "250"})):
-        os.environ.update(env)
-        try:
+        with jq.options(**env):
             wa = jq.Working_Arrays_HIP(params, pcof.size)
             jq.eval_f_g_grad(pcof, params, wa, nodes, weights, True, shift=shift)
             assert wa.last_timing()["kernel_family"] == 8
             res[tag] = (params.last_infidelity, params.last_leak, params.last_infidelity_grad.copy())
             wa.close()
-        finally:
-            for k in env:
-                os.environ.pop(k, None)
     for tag in ("one", "auto"):
         assert res["two"][0] == res[tag][0] and res["two"][1] == res[tag][1]
         assert np.array_equal(res["two"][2], res[tag][2])
@@ -298,14 +286,10 @@ def test_multi_handle_against_the_oracle_loop(jq, case, nquad, K):
     nodes, weights = x * 0.5 * (2 * np.pi * 2e-2), w * 0.5
     shift = params.shift_weights_reference() if params.Ntot <= 4 else 0.05 * np.arange(params.Ntot)
     ref = Oracle(params).eval_f_g_grad(pcof, nodes, weights, shift)
-    os.environ["JQ_MULTI_SAME_DEVICE"] = "1"
-    try:
-        wam = jq.Working_Arrays_HIP(params, pcof.size, devices=K)
-        assert wam.num_devices == K
-        jq.eval_f_g_grad(pcof, params, wam, nodes, weights, True, shift=shift if params.Ntot > 4 else None)
-        wam.close()
-    finally:
-        os.environ.pop("JQ_MULTI_SAME_DEVICE", None)
+    wam = jq.Working_Arrays_HIP(params, pcof.size, devices=K, options={"multi_same_device": 1})
+    assert wam.num_devices == K and wam.rccl_world_size == 0      # (test mode: no communicator)
+    jq.eval_f_g_grad(pcof, params, wam, nodes, weights, True, shift=shift if params.Ntot > 4 else None)
+    wam.close()
     gn = np.linalg.norm(ref["last_infidelity_grad"])
     assert abs(params.last_infidelity - ref["last_infidelity"]) <= 1e-10 * abs(ref["last_infidelity"])
     assert abs(params.last_leak - ref["last_leak"]) <= 1e-10 * abs(ref["last_leak"])
@@ -343,18 +327,14 @@ def test_backward_sweep_on_three_workgroups_per_quad_is_the_one_workgroup_kernel
     res = {}
     for tag, env in (("three", {"JQ_CHUNK_STEPS": "300" if kind == "cnot3" else "20"}), ("one", {"JQ_CQ3": "0", "JQ_CHUNK_STEPS": "300" if kind == "cnot3" else "20"}),
                      ("three_again", {})):
-        os.environ.update(env)
-        try:
+        with jq.options(**env):
             wa = jq.Working_Arrays_HIP(params, pcof.size)
             jq.eval_f_g_grad(pcof, params, wa, nodes, weights, True, shift=shift)
             t = wa.last_timing()
-            assert t["kernel_family"] == 8 and t["reserved"] == (0 if tag == "one" else 3), t
+            assert t["kernel_family"] == 8 and t["kernel_variant"] == (0 if tag == "one" else 3), t
             res[tag] = (params.last_infidelity, params.last_leak, params.last_infidelity_grad.copy(),
                         params.last_leak_grad.copy() if params.objFuncType != 1 else np.zeros(1))
             wa.close()
-        finally:
-            for k in env:
-                os.environ.pop(k, None)
     a, b, c = res["three"], res["one"], res["three_again"]
     assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
     # (one chunk instead of several: the gradient's partial sums are grouped differently)
@@ -370,22 +350,22 @@ def test_three_workgroup_kernel_falls_back_when_it_reports_a_dead_wait(jq):
     params, pcof = _cq3_problem(jq, "cnot3")
     wa = jq.Working_Arrays_HIP(params, pcof.size)
     f0, g0, *_ = jq.traceobjgrad(pcof, params, wa, False, True)
-    assert wa.last_timing()["reserved"] == 3
+    assert wa.last_timing()["kernel_variant"] == 3
     ls = wa.plan_info()["latency_split"]
     assert ls["last_decision"].startswith("taken") and ls["faults"] == 0 and ls["off"] is False
-    os.environ["JQ_CQ3_FAULT"] = "1"
+    wa.set_option("cq3_fault", 1)
     try:
         f1, g1, *_ = jq.traceobjgrad(pcof, params, wa, False, True)
     finally:
-        os.environ.pop("JQ_CQ3_FAULT", None)
-    assert wa.last_timing()["reserved"] == 0 and f1 == f0 and np.array_equal(g1, g0)
+        wa.set_option("cq3_fault", None)
+    assert wa.last_timing()["kernel_variant"] == 0 and f1 == f0 and np.array_equal(g1, g0)
     ls = wa.plan_info()["latency_split"]
     assert ls["last_decision"] == "not taken: cooling down after a fault" and ls["faults"] == 1 and ls["cooling_down"] == 3
     for k in range(3):      # (the handle stays on the one-workgroup kernel while it cools down)
         f2, g2, *_ = jq.traceobjgrad(pcof, params, wa, False, True)
-        assert wa.last_timing()["reserved"] == 0 and f2 == f0 and np.array_equal(g2, g0)
+        assert wa.last_timing()["kernel_variant"] == 0 and f2 == f0 and np.array_equal(g2, g0)
     f3, g3, *_ = jq.traceobjgrad(pcof, params, wa, False, True)      # ... and tries the split again afterwards
-    assert wa.last_timing()["reserved"] == 3 and f3 == f0 and np.array_equal(g3, g0)
+    assert wa.last_timing()["kernel_variant"] == 3 and f3 == f0 and np.array_equal(g3, g0)
     wa.close()
 
 
@@ -394,11 +374,7 @@ def test_three_workgroup_kernels_across_changing_ensemble_sizes(jq):
     """One handle, ensemble sizes that move in and out of the three-workgroup regime (its hand-off buffer grows, the one-workgroup
     kernel takes over beyond 80 samples and hands back): every result equals the one of a handle that never uses the split."""
     params, pcof = _cq3_problem(jq, "cnot3")
-    os.environ["JQ_CQ3"] = "0"
-    try:
-        wb = jq.Working_Arrays_HIP(params, pcof.size)
-    finally:
-        os.environ.pop("JQ_CQ3", None)
+    wb = jq.Working_Arrays_HIP(params, pcof.size, options={"cq3": 0})
     wa = jq.Working_Arrays_HIP(params, pcof.size)
     for ns in (1, 80, 9, 81, 2, 33, 300, 5):
         nodes, weights, shift = jq.cases.cnot3_ensemble(ns)
@@ -406,13 +382,9 @@ def test_three_workgroup_kernels_across_changing_ensemble_sizes(jq):
         a = (params.last_infidelity, params.last_leak, params.last_infidelity_grad.copy())
         # (more column quads than CUs: the backward sweep of both handles is k_backward_qsplit with two quads per workgroup, round 5)
         # (round 5: 81 .. 128 samples on two workgroups per quad)
-        assert wa.last_timing()["reserved"] == (3 if ns <= 80 else 2 if ns <= 128 else 22 if ns > 256 else 0), ns
-        os.environ["JQ_CQ3"] = "0"
-        try:
-            jq.eval_f_g_grad(pcof, params, wb, nodes, weights, True, shift=shift)
-        finally:
-            os.environ.pop("JQ_CQ3", None)
-        assert wb.last_timing()["reserved"] == (22 if ns > 256 else 0)
+        assert wa.last_timing()["kernel_variant"] == (3 if ns <= 80 else 2 if ns <= 128 else 22 if ns > 256 else 0), ns
+        jq.eval_f_g_grad(pcof, params, wb, nodes, weights, True, shift=shift)
+        assert wb.last_timing()["kernel_variant"] == (22 if ns > 256 else 0)
         assert a[0] == params.last_infidelity and a[1] == params.last_leak and np.array_equal(a[2], params.last_infidelity_grad), ns
     wa.close()
     wb.close()

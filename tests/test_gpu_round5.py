@@ -21,12 +21,10 @@ def rel(a, b):
 
 
 def _with_env(env, fn):
-    os.environ.update(env)
-    try:
+    """fn() with `env` -- options in the historic spelling ({"JQ_QUAD": "0"} = option quad=0) -- as the options of every handle it creates"""
+    import juqbox_jl_amd as jqm
+    with jqm.options(**env):
         return fn()
-    finally:
-        for k in env:
-            os.environ.pop(k, None)
 
 
 def _cnot3(jq, nsteps):
@@ -76,7 +74,7 @@ def test_split_backward_sweep_is_the_one_wave_kernel_bit_for_bit(jq, kind, nsamp
     a = _eval(jq, params, pcof, nodes, weights, shift, env)
     b = _eval(jq, params, pcof, nodes, weights, shift, dict(env, JQ_QSPLIT="0"))
     c = _eval(jq, params, pcof, nodes, weights, shift, env)
-    assert a[4]["kernel_family"] == 6 and a[4]["reserved"] == 24 and b[4]["kernel_family"] == 6 and b[4]["reserved"] == 0, (a[4], b[4])
+    assert a[4]["kernel_family"] == 6 and a[4]["kernel_variant"] == 24 and b[4]["kernel_family"] == 6 and b[4]["kernel_variant"] == 0, (a[4], b[4])
     for x in (b, c):
         assert a[0] == x[0] and a[1] == x[1] and np.array_equal(a[2], x[2]) and np.array_equal(a[3], x[3])
     if kind == "cnot3":
@@ -86,7 +84,7 @@ def test_split_backward_sweep_is_the_one_wave_kernel_bit_for_bit(jq, kind, nsamp
         env["JQ_QS_RIDE"] = "1"
         d = _eval(jq, params, pcof, nodes, weights, shift, env)
         e = _eval(jq, params, pcof, nodes, weights, shift, env)
-        assert d[4]["reserved"] == 24
+        assert d[4]["kernel_variant"] == 24
         assert abs(d[0] - a[0]) <= 1e-13 * abs(a[0]) and abs(d[1] - a[1]) <= 1e-13 * abs(a[1]) and rel(d[2], a[2]) <= 1e-13
         assert d[0] == e[0] and d[1] == e[1] and np.array_equal(d[2], e[2])
 
@@ -107,7 +105,7 @@ def test_split_backward_sweep_against_the_oracle(jq, kind, nsamples, mode):
     ref = Oracle(params).eval_f_g_grad(pcof, nodes, weights, shift)
     env = {"JQ_CQ": "0", "JQ_CHUNK_STEPS": "41"} if mode == "qw4" else {"JQ_QSPLIT": "2", "JQ_CQ3": "0", "JQ_CHUNK_STEPS": "41"}
     a = _eval(jq, params, pcof, nodes, weights, shift, env)
-    assert (a[4]["kernel_family"], a[4]["reserved"]) == ((6, 24) if mode == "qw4" else (8, 22)), a[4]
+    assert (a[4]["kernel_family"], a[4]["kernel_variant"]) == ((6, 24) if mode == "qw4" else (8, 22)), a[4]
     gn = np.linalg.norm(ref["last_infidelity_grad"])
     assert abs(a[0] - ref["last_infidelity"]) <= TOL * abs(ref["last_infidelity"])
     assert abs(a[1] - ref["last_leak"]) <= TOL * abs(ref["last_leak"])
@@ -126,7 +124,7 @@ def test_two_quads_per_workgroup_next_to_the_two_round_cooperative_quad_sweep(jq
     a = _eval(jq, params, pcof, nodes, weights, shift, {"JQ_CHUNK_STEPS": "250"})
     b = _eval(jq, params, pcof, nodes, weights, shift, {"JQ_CHUNK_STEPS": "250", "JQ_QSPLIT": "0"})
     c = _eval(jq, params, pcof, nodes, weights, shift, {"JQ_CHUNK_STEPS": "250"})
-    assert (a[4]["kernel_family"], a[4]["reserved"]) == (8, 22) and (b[4]["kernel_family"], b[4]["reserved"]) == (8, 0), (a[4], b[4])
+    assert (a[4]["kernel_family"], a[4]["kernel_variant"]) == (8, 22) and (b[4]["kernel_family"], b[4]["kernel_variant"]) == (8, 0), (a[4], b[4])
     assert abs(a[0] - b[0]) <= 1e-13 * abs(b[0]) and abs(a[1] - b[1]) <= 1e-13 * abs(b[1]) and rel(a[2], b[2]) <= 1e-13
     assert a[0] == c[0] and a[1] == c[1] and np.array_equal(a[2], c[2])
 
@@ -145,7 +143,7 @@ def test_split_kernels_reproduce_the_cnot3_golden_at_full_length(jq):
         w /= w.sum()
         jq.eval_f_g_grad(pcof, params, wa, np.zeros(ns), w, True)
         t = wa.last_timing()
-        assert (t["kernel_family"], t["reserved"]) == variant, t
+        assert (t["kernel_family"], t["kernel_variant"]) == variant, t
         assert abs(params.last_infidelity - 0.9181500713381303) < 1e-12
         assert abs(params.last_leak - 2.8775930168455916e-05) < 1e-15
         g = np.array(golden["grad0"]) - jq.setup_utils.tikhonov_grad(pcof, params.tik0)
@@ -168,7 +166,7 @@ def test_split_kernel_perturbed_samples_at_full_length_match_the_oracle(jq):
         w[i] = 1.0
         jq.eval_f_g_grad(pcof, params, wa, nodes, w, True, shift=shift)
         t = wa.last_timing()
-        assert (t["kernel_family"], t["reserved"]) == (6, 24), t
+        assert (t["kernel_family"], t["kernel_variant"]) == (6, 24), t
         assert abs(params.last_infidelity - r["primaryobjf"]) <= TOL * abs(r["primaryobjf"]), i
         assert abs(params.last_leak - r["secondaryobjf"]) <= TOL * abs(r["secondaryobjf"]), i
         assert rel(params.last_infidelity_grad, r["totalgrad"]) < TOL, i
@@ -192,7 +190,7 @@ def test_two_handles_in_two_threads_in_the_split_regime(jq):
     was = [jq.Working_Arrays_HIP(params, pcof.size) for _ in range(2)]
     ps = [params, _cnot3(jq, 2000)[0]]      # (the mirror keeps the results on the params object: one per thread)
     jq.eval_f_g_grad(pcof, ps[0], was[0], nodes, weights, True, shift=shift)
-    assert was[0].last_timing()["reserved"] == 3
+    assert was[0].last_timing()["kernel_variant"] == 3
     ref = (ps[0].last_infidelity, ps[0].last_leak, ps[0].last_infidelity_grad.copy())
     jq.eval_f_g_grad(pcof, ps[1], was[1], nodes, weights, True, shift=shift)      # (warm-up of the second handle)
     t0 = time.perf_counter()
@@ -204,7 +202,7 @@ def test_two_handles_in_two_threads_in_the_split_regime(jq):
     def work(i):
         for k in range(12):
             jq.eval_f_g_grad(pcof, ps[i], was[i], nodes, weights, True, shift=shift)
-            splits[i] += was[i].last_timing()["reserved"] == 3
+            splits[i] += was[i].last_timing()["kernel_variant"] == 3
             if not (ps[i].last_infidelity == ref[0] and ps[i].last_leak == ref[1] and np.array_equal(ps[i].last_infidelity_grad, ref[2])):
                 bad.append((i, k))
     th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
@@ -229,7 +227,7 @@ def test_same_device_sub_handles_never_take_the_split(jq):
     params, pcof = _cnot3(jq, 600)
     nodes, weights, shift = jq.cases.cnot3_ensemble(12)
     single = _eval(jq, params, pcof, nodes, weights, shift, {})
-    assert single[4]["reserved"] == 3
+    assert single[4]["kernel_variant"] == 3
 
     def run():
         wam = jq.Working_Arrays_HIP(params, pcof.size, devices=3)
@@ -344,7 +342,7 @@ def test_backward_sweep_on_two_workgroups_per_quad_is_the_one_workgroup_kernel(j
     a = _eval(jq, params, pcof, nodes, weights, shift, env)
     b = _eval(jq, params, pcof, nodes, weights, shift, dict(env, JQ_CQ3="0"))
     c = _eval(jq, params, pcof, nodes, weights, shift, env)
-    assert (a[4]["kernel_family"], a[4]["reserved"]) == (8, 2) and (b[4]["kernel_family"], b[4]["reserved"]) == (8, 0), (a[4], b[4])
+    assert (a[4]["kernel_family"], a[4]["kernel_variant"]) == (8, 2) and (b[4]["kernel_family"], b[4]["kernel_variant"]) == (8, 0), (a[4], b[4])
     for x in (b, c):
         assert a[0] == x[0] and a[1] == x[1] and np.array_equal(a[2], x[2]) and np.array_equal(a[3], x[3])
 
@@ -368,7 +366,7 @@ def test_implicit_midpoint_ensembles_never_take_the_split_kernel(jq):
     t = wa.last_timing()
     got = (params.last_infidelity, params.last_infidelity_grad.copy())
     wa.close()
-    assert t["kernel_family"] == 7 and t["reserved"] == 0, t
+    assert t["kernel_family"] == 7 and t["kernel_variant"] == 0, t
     inf, grad = 0.0, np.zeros(pcof.size)
     H0 = params.Hconst.copy()
     for i in (0, 311, 599):      # (the oracle's ensemble loop is the Stormer-Verlet one: per sample with the perturbed drift)
@@ -417,7 +415,7 @@ def test_real_full_weights_run_on_the_cooperative_quad_kernels(jq, kind, nforb, 
         wa.close()
         return t, why
     t, why = _with_env(env, run)
-    assert t["kernel_family"] == 8 and t["reserved"] == 3, (t, why)      # (the backward sweep on three workgroups per quad, as with Diagonal weights)
+    assert t["kernel_family"] == 8 and t["kernel_variant"] == 3, (t, why)      # (the backward sweep on three workgroups per quad, as with Diagonal weights)
     rng = np.random.default_rng(5)
     nodes, weights = 0.02 * rng.standard_normal(21), rng.random(21)
     shift = 0.01 * np.arange(params.Ntot)
@@ -429,7 +427,7 @@ def test_real_full_weights_run_on_the_cooperative_quad_kernels(jq, kind, nforb, 
     assert a[0] == c[0] and a[1] == c[1] and np.array_equal(a[2], c[2]) and np.array_equal(a[3], c[3])      # (run to run: bit-wise)
     # the one-workgroup backward kernel performs the same operations in the same order
     d = _eval(jq, params, pcof, nodes, weights, shift, dict(env, JQ_CQ3="0"))
-    assert a[4]["reserved"] == 3 and d[4]["reserved"] == 0, (a[4], d[4])
+    assert a[4]["kernel_variant"] == 3 and d[4]["kernel_variant"] == 0, (a[4], d[4])
     assert a[0] == d[0] and a[1] == d[1] and np.array_equal(a[2], d[2]) and np.array_equal(a[3], d[3])
 
 
@@ -447,7 +445,7 @@ def test_real_full_weights_on_two_workgroups_per_quad(jq, kind, nsamples, varian
     shift = 0.01 * np.arange(params.Ntot)
     a = _eval(jq, params, pcof, nodes, weights, shift, {})
     b = _eval(jq, params, pcof, nodes, weights, shift, {"JQ_CQ3": "0"})
-    assert (a[4]["kernel_family"], a[4]["reserved"]) == (8, variant) and (b[4]["kernel_family"], b[4]["reserved"]) == (8, 0), (a[4], b[4])
+    assert (a[4]["kernel_family"], a[4]["kernel_variant"]) == (8, variant) and (b[4]["kernel_family"], b[4]["kernel_variant"]) == (8, 0), (a[4], b[4])
     assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2])
     inf, leak, grad = 0.0, 0.0, np.zeros(pcof.size)
     H0 = params.Hconst.copy()
@@ -481,14 +479,14 @@ def test_complex_full_weights_run_on_the_split_kernels(jq, kind, nforb, oft, chu
         wa.close()
         return t
     t = _with_env(env, run)
-    assert t["kernel_family"] == 8 and t["reserved"] == 3, t
+    assert t["kernel_family"] == 8 and t["kernel_variant"] == 3, t
     rng = np.random.default_rng(5)
     nodes, weights = 0.02 * rng.standard_normal(nsamples), rng.random(nsamples)
     shift = 0.01 * np.arange(params.Ntot)
     a = _eval(jq, params, pcof, nodes, weights, shift, env)
     b = _eval(jq, params, pcof, nodes, weights, shift, dict(env, JQ_CQ3="0"))
     c = _eval(jq, params, pcof, nodes, weights, shift, env)
-    assert a[4]["kernel_family"] == 8 and a[4]["reserved"] in (2, 3) and b[4]["kernel_family"] == 6, (a[4], b[4])
+    assert a[4]["kernel_family"] == 8 and a[4]["kernel_variant"] in (2, 3) and b[4]["kernel_family"] == 6, (a[4], b[4])
     assert abs(a[0] - b[0]) <= 1e-12 * abs(b[0]) and abs(a[1] - b[1]) <= 1e-12 * abs(b[1]) and rel(a[2], b[2]) <= 1e-11 and rel(a[3], b[3]) <= 1e-11
     assert a[0] == c[0] and a[1] == c[1] and np.array_equal(a[2], c[2]) and np.array_equal(a[3], c[3])
 
@@ -516,7 +514,7 @@ def test_higher_rank_full_weights_stay_on_the_quad_layout_kernels(jq):
     params.wmat_real, params.wmat_imag = p0.wmat_real, p0.wmat_imag
     compare(jq, params, pcof, wa, family=8)
     jq.traceobjgrad(pcof, params, wa, False, True)
-    assert wa.last_timing()["reserved"] == 3, wa.last_timing()
+    assert wa.last_timing()["kernel_variant"] == 3, wa.last_timing()
     wa.close()
 
 
@@ -578,10 +576,10 @@ def test_split_kernels_with_late_roles(jq, kind, nsamples, wts, chunk):
     if chunk and chunk < 10 and kind == "cnot3":      # (short chunks: a shorter run, the launches are what is tested)
         params.T, params.nsteps = params.T * 60 / params.nsteps, 60
     a = _eval(jq, params, pcof, nodes, weights, shift, env)
-    assert a[4]["kernel_family"] == 8 and a[4]["reserved"] in (2, 3), a[4]
+    assert a[4]["kernel_family"] == 8 and a[4]["kernel_variant"] in (2, 3), a[4]
     for bit in ("16", "32"):
         b = _eval(jq, params, pcof, nodes, weights, shift, dict(env, JQ_DEBUG=bit))
-        assert b[4]["reserved"] == a[4]["reserved"], (a[4], b[4])
+        assert b[4]["kernel_variant"] == a[4]["kernel_variant"], (a[4], b[4])
         assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]), bit
 
 
@@ -603,10 +601,10 @@ def test_implicit_midpoint_split_kernel_with_late_roles(jq, nsamples):
             return out
         return _with_env(env, go)
     a = run({"JQ_CHUNK_STEPS": "300"})
-    assert a[3]["kernel_family"] == 9 and a[3]["reserved"] == 3, a[3]
+    assert a[3]["kernel_family"] == 9 and a[3]["kernel_variant"] == 3, a[3]
     for bit in ("16", "32"):
         b = run({"JQ_CHUNK_STEPS": "300", "JQ_DEBUG": bit})
-        assert b[3]["reserved"] == 3
+        assert b[3]["kernel_variant"] == 3
         assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2]), bit
 
 
@@ -628,9 +626,9 @@ def test_short_first_chunks_take_the_one_workgroup_kernel(jq, chunk, nsteps):
             return out
         return _with_env(dict(env, **extra), go)
     a = run({})
-    assert a[3]["kernel_family"] == 8 and a[3]["reserved"] == 0 and "first chunk" in a[4], (a[3], a[4])
+    assert a[3]["kernel_family"] == 8 and a[3]["kernel_variant"] == 0 and "first chunk" in a[4], (a[3], a[4])
     b = run({"JQ_DEBUG": "16"})
     assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2])
     c = run({"JQ_CHUNK_STEPS": "9"}) if nsteps > 9 else None
     if c is not None:
-        assert c[3]["reserved"] == 3, c[3]
+        assert c[3]["kernel_variant"] == 3, c[3]

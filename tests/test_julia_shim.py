@@ -13,7 +13,7 @@ CTYPE = {  # C type -> the Julia types a ccall may use for it
     "jq_handle *": {"Ptr{Cvoid}"}, "const jq_handle *": {"Ptr{Cvoid}"}, "jq_handle **": {"Ref{Ptr{Cvoid}}"},
     "const jq_problem *": {"Ref{JQProblem}"}, "jq_timing *": {"Ref{JQTiming}"},
     "const char *": {"Cstring"}, "void *": {"Ptr{Cvoid}"}, "char *": {"Ptr{UInt8}"},
-    "const jq_csc *": {"Ref{JQCsc}", "Ptr{JQCsc}"}, "const int64_t *": {"Ptr{Int64}"},
+    "const jq_csc *": {"Ref{JQCsc}", "Ptr{JQCsc}"}, "const int64_t *": {"Ptr{Int64}"}, "int64_t *": {"Ref{Int64}", "Ptr{Int64}"},
 }
 
 
