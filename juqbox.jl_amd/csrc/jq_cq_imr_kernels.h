@@ -12,7 +12,7 @@
 // keep them for the next round, and leave their halves of the decision in LDS one barrier later, while the block waves go on
 // speculatively: when they learn that x_it was the result they have published x_{it+1} and x_{it+2} for nothing.  Every wave sees
 // the same decisions.  Publications per implicit step: 3 + (number of iterations).
-// Measured at cnot3 (scripts/time_imr_rounds.py): 785 cycles per publication round, 5.7 iterations per step; one evaluation 0.77 s on
+// Measured at cnot3 (round 4, HISTORY.md): 785 cycles per publication round, 5.7 iterations per step; one evaluation 0.77 s on
 // the quad-layout kernels, 0.37 s with the block waves doing the reduction themselves (80 instructions per wave and round), 0.32 s
 // with one reducer wave (the block waves still folding their squares), 0.30 s as described (47 instructions per block wave).  The
 // round is bound by the two SIMDs that hold two block waves each (six blocks on four SIMDs): 2 x 47 instructions at the ~8 cycles

@@ -6,7 +6,7 @@
 // wave `mt` owns block mt of every array (ONE register per array), a product costs one block's work per wave
 //     D[mt] = C[mt] + B_mt x[mt] (one v_mfma_f64_4x4x4_4b) + c0 shr4(x[mt]) + c1 shl4(x[mt]) + c2 x[mt-1] + c3 x[mt+1]
 // plus the exchange of x with the two neighbouring waves through a double-buffered LDS image (one ds_write, one workgroup
-// barrier, two ds_reads).  What such a kernel pays for (measured, scripts/time_cq_intervals.py, JQ_CQ_TIMING):
+// barrier, two ds_reads).  What such a kernel pays for (measured in round 2, HISTORY.md):
 //   * a publication interval costs ~230 cycles even when it holds a single product (LDS write -> barrier -> LDS read -> two
 //     dependent FMAs), so the step is regrouped around PUBLICATIONS: every published x serves all the products that need it
 //     (K05 u and S0 u; S05 v05, K0 v05 and K1 v05; the products with X, ...): 5 + 2 m publications per forward step (20

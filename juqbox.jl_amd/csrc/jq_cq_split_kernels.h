@@ -33,9 +33,13 @@
 // Waiting.  Rounds 4 - 5 HOPED that the workgroups of a quad were resident together and policed it with one long timeout per wait
 // (1 000 000 polls ~ 1.3 s: next to a process whose launches hold every CU for 0.15 - 0.37 s a role legitimately waited that long for its
 // partners to START).  Round 6 separates the two questions.  (1) Are all workgroups of this launch resident?  Answered once, at the start,
-// by a rendezvous of the WHOLE grid (cq3_rendezvous): every workgroup counts itself in and waits at most a.rdv_polls polls (default 10 ms)
-// for the count to reach gridDim.x; otherwise the launch is abandoned at once with error word 3 and the host repeats the evaluation on
-// the one-workgroup kernel -- a busy GPU costs milliseconds, not a dead wait.  (2) After a passed rendezvous every partner IS resident
+// by a rendezvous of the WHOLE grid (cq3_rendezvous): every workgroup counts itself in; the LAST one to arrive sets the launch's state word
+// to GO, a workgroup that has polled a.rdv_polls times (the host passes about one launch duration, 2 .. 100 ms) sets it to ABANDON -- both
+// with a compare-and-swap from 0, so the decision is made ONCE and is the same for every workgroup (first version: "count reached
+// gridDim.x" against "my time is up" -- workgroups that gave up left, later arrivals completed the count and went on without them:
+// the soak next to two load processes reported their quads as "roles on different XCDs", profiles/r06_cq3_soak_load.txt (a)).
+// Abandoned: error word 3, every workgroup leaves at once, the host repeats the evaluation on the one-workgroup kernel -- a busy GPU
+// costs milliseconds, not a dead wait.  (2) After a passed rendezvous every partner IS resident
 // and stays so (workgroups are not preempted), so a wait between roles can only be a short one; a.wait_polls (the host passes ~ 10 x the
 // launch's expected duration) is a guard against the impossible, not a scheduling assumption.
 __device__ __forceinline__ void cq3_arrive(const PropArgs& a)      // (workgroups without work count too: the grid must be complete)
@@ -43,21 +47,33 @@ __device__ __forceinline__ void cq3_arrive(const PropArgs& a)      // (workgroup
     if (threadIdx.x == 0) __hip_atomic_fetch_add((unsigned long long*)a.park + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // call from every wave of the workgroup that is still alive, after cq3_arrive; flag: one int of LDS nobody uses yet.  True: proceed.
+// (a.park: [0] error word of the evaluation, [1] arrival counter, [2] state word of the launch: 0 undecided, 1 GO, 2 ABANDON; the host
+//  zeroes [1] and [2] before every launch)
 __device__ __forceinline__ bool cq3_rendezvous(const PropArgs& a, int* flag)
 {
     unsigned long long* gerr = (unsigned long long*)a.park;
     if (threadIdx.x == 0) {
-        int ok = 0;
+        unsigned long long st = 0ull;
+        if (__hip_atomic_load(gerr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)gridDim.x) {      // the grid is complete: GO, unless somebody gave up first
+            unsigned long long expect = 0ull;
+            __hip_atomic_compare_exchange_strong(gerr + 2, &expect, 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         for (int k = 0; k < a.rdv_polls; ++k) {
+            st = __hip_atomic_load(gerr + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (st != 0ull) break;
             if (__hip_atomic_load(gerr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)gridDim.x) {
-                ok = 1;
-                break;
+                unsigned long long expect = 0ull;
+                __hip_atomic_compare_exchange_strong(gerr + 2, &expect, 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                continue;      // (read the decided state in the next round)
             }
-            if (__hip_atomic_load(gerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) break;      // somebody gave up already
             __builtin_amdgcn_s_sleep(2);
         }
-        if (!ok) __hip_atomic_store(gerr, 3ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *flag = ok;
+        if (st == 0ull) {      // my time is up: ABANDON -- unless the launch was decided in this very moment
+            unsigned long long expect = 0ull;
+            st = __hip_atomic_compare_exchange_strong(gerr + 2, &expect, 2ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 2ull : expect;
+        }
+        if (st != 1ull) __hip_atomic_store(gerr, 3ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = st == 1ull ? 1 : 0;
     }
     __syncthreads();
     const bool ok = *flag != 0;

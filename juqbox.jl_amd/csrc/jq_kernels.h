@@ -1624,6 +1624,27 @@ __device__ __forceinline__ void horner_add(Arr<NT>& out, const Arr<NT>& bpa, con
     }
 }
 
+// out += sum_{j=1..m} S^j A TERM BY TERM (neumann!, src/linear_solvers.jl:81-106, literally): T_1 = S A, T_{j+1} = S T_j, the terms ping-pong between
+// Ya and A's OWN registers (A is destroyed), every term is added to out.  Three arrays where the Horner form needs four (out, A, Ya, Yb) --
+// m array additions more per call.  For the widest slab kernels (six tile rows, band / dense tiles): their backward sweep keeps eight
+// arrays alive through a recurrence and spills two of them (k_backward<6, 5>: 388 B of scratch per lane in round 5).
+#ifndef JQ_BWD_TERMS
+#define JQ_BWD_TERMS 1
+#endif
+constexpr bool jq_bwd_terms(int NT, int BW, bool JAC) { return JQ_BWD_TERMS && !JAC && NT >= 6 && BW != JQ_BW_OD && BW != JQ_BW_T4 && BW != JQ_BW_T4Q; }
+template <int NT, int BW>
+__device__ __forceinline__ void neumann_terms_add(Arr<NT>& out, Arr<NT>& A, const double* S, int m, Arr<NT>& Ya)
+{
+    for (int j = 0; j < m; j += 2) {
+        mm_z<NT, BW>(Ya, S, A);
+        a_add(out, Ya);
+        if (j + 1 < m) {
+            mm_z<NT, BW>(A, S, Ya);
+            a_add(out, A);
+        }
+    }
+}
+
 // LDS / global parking of a dormant state array (one [4*NT][64] image per wave)
 template <int NT>
 __device__ __forceinline__ void a_park(const Arr<NT>& a, __attribute__((address_space(3))) double* park)
@@ -1689,7 +1710,7 @@ __device__ __forceinline__ void a_unpark(Arr<NT>& a, const double* park)
 // FUSE (quad layout only): bit 0 = K05 u with S0 u in one pass, bit 1 = S05 v05 with K0 v05 and K1 v05 in one pass
 // FOLD (quad layout, one sample per wave): `ceps` is the per-lane MASKED shift (+c eps on the lanes that hold the diagonal of the MFMA's
 // A operand, 0 elsewhere; 0 everywhere without a shift) and every product with a K image folds it into its operand (mm_t4q SH)
-template <int NT, int BW, bool JAC, int FUSE = 0, bool FOLD = false, bool REGOP = true, typename RING = RingT<BW == JQ_BW_T4Q>>
+template <int NT, int BW, bool JAC, int FUSE = 0, bool FOLD = false, bool REGOP = true, bool TERMS = false, typename RING = RingT<BW == JQ_BW_T4Q>>
 __device__ __forceinline__ void sv_state(RING& p, const PropArgs& a, bool active, double ceps, const double* ws, int g,
                                          const Arr<NT>& u, Arr<NT>& v, Arr<NT>& unew, Arr<NT>& vN, Arr<NT>& A, Arr<NT>& Ya,
                                          Arr<NT>& Yb)
@@ -1765,7 +1786,8 @@ __device__ __forceinline__ void sv_state(RING& p, const PropArgs& a, bool active
     if (active) {
         mm_c<NT, BW>(A, A, M, v);
         a_add(v, A);
-        horner_add<NT, BW, JAC, REGOP>(v, v, A, M, a.m, Ya, Yb, a.jacobi_tol2, a.N, a.jac_wg_lds);
+        if constexpr (TERMS) neumann_terms_add<NT, BW>(v, A, M, a.m, Ya);
+        else horner_add<NT, BW, JAC, REGOP>(v, v, A, M, a.m, Ya, Yb, a.jacobi_tol2, a.N, a.jac_wg_lds);
         mm_c<NT, BW>(vN, v, M, v);
     }
     // use 2: Kn0 -- unew = u - c K0 v05
@@ -1796,7 +1818,8 @@ __device__ __forceinline__ void sv_state(RING& p, const PropArgs& a, bool active
     if (active) {
         mm_c<NT, BW>(A, A, M, unew);
         a_add(unew, A);
-        horner_add<NT, BW, JAC, REGOP>(unew, unew, A, M, a.m, Ya, Yb, a.jacobi_tol2, a.N, a.jac_wg_lds);
+        if constexpr (TERMS) neumann_terms_add<NT, BW>(unew, A, M, a.m, Ya);
+        else horner_add<NT, BW, JAC, REGOP>(unew, unew, A, M, a.m, Ya, Yb, a.jacobi_tol2, a.N, a.jac_wg_lds);
     }
 }
 
@@ -2081,7 +2104,7 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
         // mu's registers serve as the scratch array A of the state step
         // (UNI: the fused stages -- shared lane shifts of u and of v05 -- also in the twelve-wave kernel: round 3 measured them slower there,
         //  104 -> 144 ... 172 B of scratch; with the registers the UNI variant frees they pay: backward sweep 772 -> 757 ms, round 4)
-        sv_state<NT, BW, JAC, (MINW >= 3 ? (UNI ? 3 : JQ_BWD_FUSE3) : JQ_BWD_FUSE), UNI, !(QUAD && MINW >= 3 && JQ_BWD3_NOOPQ_STATE)>(p, a, active, ceps, ws, g, u, v, un, vN, mu, Ya, Yb);
+        sv_state<NT, BW, JAC, (MINW >= 3 ? (UNI ? 3 : JQ_BWD_FUSE3) : JQ_BWD_FUSE), UNI, !(QUAD && MINW >= 3 && JQ_BWD3_NOOPQ_STATE), jq_bwd_terms(NT, BW, JAC)>(p, a, active, ceps, ws, g, u, v, un, vN, mu, Ya, Yb);
         // (every wave has passed a workgroup barrier since it finished step n-1: begin_step in window mode, the operator
         // switches of sv_state otherwise)
         if (n > 0) flush_traces(n - 1);
@@ -2117,7 +2140,8 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
                         wl.axpy2(k, L, cl * pu, cl * qu);      // + c hr0
                     }
             a_add(mu, L);
-            horner_add<NT, BW, JAC, BREG>(mu, mu, L, M, a.m, Ya, Yb, a.jacobi_tol2, a.N, a.jac_wg_lds);
+            if constexpr (jq_bwd_terms(NT, BW, JAC)) neumann_terms_add<NT, BW>(mu, L, M, a.m, Ya);      // (L is scratch from here on)
+            else horner_add<NT, BW, JAC, BREG>(mu, mu, L, M, a.m, Ya, Yb, a.jacobi_tol2, a.N, a.jac_wg_lds);
         }
         // early traces with X (lets vr0 = u die here): tr1 = tr(vr0' Hanti_q X), tr3 = tr(vr' Hanti_q X)
         double o_p4 = 0.0;      // ORD: the new part of tr4 of control 1, formed in the pass of use 11
@@ -2188,7 +2212,8 @@ __global__ __launch_bounds__((BW == JQ_BW_T4Q) ? 256 * MINW : 256, (BW == JQ_BW_
             mm_c<NT, BW>(vN, vN, M, L);       // vN = Q
             a_add(L, nb);
             a_add(L, vN);                     // L = nb + L + Q
-            horner_add<NT, BW, JAC, BREG>(L, L, vN, M, a.m, Ya, Yb, a.jacobi_tol2, a.N, a.jac_wg_lds);  // L = nb_new
+            if constexpr (jq_bwd_terms(NT, BW, JAC)) neumann_terms_add<NT, BW>(L, vN, M, a.m, Ya);      // (vN = Q is scratch from here on)
+            else horner_add<NT, BW, JAC, BREG>(L, L, vN, M, a.m, Ya, Yb, a.jacobi_tol2, a.N, a.jac_wg_lds);  // L = nb_new
             a_add(nb, L);                     // nb = nb_old + nb_new = -(li0 + li)
         }
         // use 11: Kp05 -- vN(scratch G) = X + c K05 nb_new (= lambda_r^{1/2} - c K05 li_new)

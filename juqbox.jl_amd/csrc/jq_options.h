@@ -19,7 +19,7 @@ enum JqOpt {
     O_STREAM_BYTES, O_CHUNK_STEPS, O_BATCH,
     // ---- per evaluation -------------------------------------------------------------------------------------------------
     O_NOSPLIT, O_QUAD8, O_CQ_W, O_IMR_CQ, O_IMR_CQ2, O_CQ_FWD2, O_CQ3, O_QSPLIT, O_RL_SPLIT, O_JAC_WG, O_TRACE_BYTES, O_NO_UNI, O_NO_ORD,
-    O_QS_RIDE, O_CQ_GENERIC_TRACES, O_WLR_SC, O_RCCL_SELFCHECK, O_MULTI_SAME_DEVICE, O_CQ3_RDV_US,
+    O_QS_RIDE, O_CQ_GENERIC_TRACES, O_WLR_SC, O_RCCL_SELFCHECK, O_MULTI_SAME_DEVICE, O_CQ3_RDV_US, O_CQ3_WAIT_MS,
     // ---- test hooks (results unchanged) ---------------------------------------------------------------------------------
     O_DEBUG, O_CQ3_FAULT,
     O_COUNT
@@ -73,7 +73,8 @@ static const JqOptDesc g_jq_opt[O_COUNT] = {
     {"wlr_sc", 0, JQ_OPT_EXP, "1: full weights, quad layout: carry the column dots of a step in LDS (measured slower)"},
     {"rccl_selfcheck", 1, 0, "multi-device handles: 0 never, 1 on the first all-reduce, 2 on every all-reduce compare RCCL's result with the host-order sum (3: test mode)"},
     {"multi_same_device", 0, 0, "TEST MODE of jq_create_multi: 1 = up to 16 sub-handles may share physical GPUs, host-side sum in place of the all-reduce"},
-    {"cq3_rdv_us", 10000, 0, "two- / three-workgroup latency kernels: microseconds the workgroups of a launch wait for each other at its start before the launch is abandoned (not co-resident: fall back)"},
+    {"cq3_rdv_us", JQ_OPT_UNSET, 0, "two- / three-workgroup latency kernels: microseconds the workgroups of a launch wait for each other at its start before the launch is abandoned and the evaluation repeated on one workgroup per quad (default: one launch duration, 2 .. 100 ms)"},
+    {"cq3_wait_ms", JQ_OPT_UNSET, 0, "two- / three-workgroup latency kernels: milliseconds a wait between roles may take after a passed rendezvous before the launch is declared dead (default: 10 x the launch's expected duration, at least 50 ms)"},
     {"debug", 0, JQ_OPT_HOOK, "bit 16 / 32: the consumer roles / the state role of the split latency kernels start ~ 5 ms late (results unchanged); bits 1, 2, 4, 8: profiling experiments with WRONG results (experiment builds only)"},
     {"cq3_fault", 0, JQ_OPT_HOOK, "1: the split latency kernels report a dead wait, 3: a failed start-up rendezvous (exercises fall-back and cool-down)"},
 };

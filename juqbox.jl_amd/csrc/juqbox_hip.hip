@@ -35,7 +35,7 @@
 #ifndef JQ_SRC_HASH
 #define JQ_SRC_HASH "unknown"      // (the Makefile passes the SHA-256 prefix of the library's sources)
 #endif
-#define JQ_VERSION "gfx950 juqbox_hip 0.3.0 src:" JQ_SRC_HASH
+#define JQ_VERSION "gfx950 juqbox_hip 0.4.0 src:" JQ_SRC_HASH
 #ifndef JQ_MINW_MAXNT
 #define JQ_MINW_MAXNT 2      // tile counts up to which two workgroups share a CU (slab kernels; jq_kernel_inst.hip)
 #endif
@@ -126,6 +126,7 @@ struct jq_handle {
     // for good after JQ_CQ3_MAX_FAULTS faults).
     bool cq3_off = false;       // never again on this handle (too many faults)
     int cq3_faults = 0;         // launches that reported a dead wait / workgroups on different XCDs
+    int cq3_faults_xcd = 0;     // ... of them: the workgroups of a quad ran on different XCDs (error word 2)
     int cq3_busy = 0;           // launches abandoned at their start-up rendezvous (the GPU was busy: not every workgroup became resident in time)
     int cq3_busy_streak = 0;    // ... in a row (sets the cool-down)
     double cq3_us_per_step = 0.0;   // measured duration of a split backward launch per time step (sizes the in-launch wait guard)
@@ -1014,6 +1015,7 @@ static int try_embed(jq_handle* h, const jq_problem* p)
     h->emb_mode = (int)h->opt.get(O_EMBED);
     if (h->is_emb || h->emb_mode == 0 || h->BW == JQ_BW_T4 || h->big || h->Ntot > 96) return JQ_OK;
     if (!h->opt.on(O_T4) || !h->opt.on(O_OD) || h->opt.on(O_FORCE_DENSE)) return JQ_OK;
+    if (h->force_plain) return JQ_OK;      // (full weights with the Jacobi solver: the twin's 4 x 4 x n kernels do not combine the two either)
     const int Ntot = h->Ntot, Nc = h->Nc;
     const size_t nn = (size_t)Ntot * Ntot;
     int best_d1 = 0, best_d2 = 0, best_d3 = 1 << 30;
@@ -1025,7 +1027,7 @@ static int try_embed(jq_handle* h, const jq_problem* p)
             const int d3 = Ntot / (d1 * d2);
             if (d3 > 8 || d3 >= best_d3) continue;      // (the JQ_BW_T4 families are instantiated for n <= 8)
             // n = 7, 8 (quad-layout kernels with one slab per workgroup only, no / fewer cooperative-quad kernels): worth it when
-            // the padding at most doubles the space (measured, scripts/time_embed_big.py: 3 x 4 x 7 10 x / 3 x faster for one evaluation /
+            // the padding at most doubles the space (measured in round 3, HISTORY.md: 3 x 4 x 7 10 x / 3 x faster for one evaluation /
             // 3 072 samples, 3 x 3 x 8 3.3 x / 1.9 x; 2 x 2 x 8 1.7 x faster / 1.5 x SLOWER)
             if (d3 > 6 && 16 * d3 > 2 * Ntot) continue;
             for (int r = 0; r < Ntot; ++r) row[r] = (r % d1) + 4 * ((r / d1) % d2) + 16 * (r / (d1 * d2));
@@ -2385,7 +2387,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
         return fail(h, JQ_EHIP, "internal error: full leakage weights with the Jacobi solver on a 4 x 4 x n plan without cooperative kernels");      // (Ntot > 96: also the Jacobi solver; full weights: every batch size -- the slab kernels have no low-rank terms)
     // row-lane kernels, Stormer-Verlet: the backward sweep's two chains on two waves (jq_rowlane_kernels.h k_backward_rowlane2);
     // option rl_split=0: one wave (tests: the two variants must agree bit for bit)
-    // (both integrators; while the doubled wave count still finds idle issue slots: measured with scripts/time_rl_crossover.py --
+    // (both integrators; while the doubled wave count still finds idle issue slots: measured in round 3, HISTORY.md --
     //  NPJ <= 8: up to three waves per SIMD, NPJ = 12, 16 (constant images in LDS, 24 .. 32 operand registers per image row): one)
     bool rl_split = rl && 2 * nwaves_rl <= (long long)(h->rl_npj > 8 ? 4 : 12) * h->num_cu;
     if (!h->opt.on(O_RL_SPLIT)) rl_split = false;
@@ -2681,13 +2683,15 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
                                 // before it is read; the error word in front of everything survives until the end of the evaluation, the
                                 // arrival counter of the start-up rendezvous behind it is per launch)
                     HIPCHK(h, hipMemset2DAsync(h->d_cq3 + 64, cq3_quad * sizeof(double), 0, 64 * sizeof(double), (size_t)nq_pad, s));
-                    HIPCHK(h, hipMemsetAsync(h->d_cq3 + 1, 0, sizeof(double), s));
+                    HIPCHK(h, hipMemsetAsync(h->d_cq3 + 1, 0, 2 * sizeof(double), s));      // (arrival counter, state word of the launch)
                     a.park = h->d_cq3;
-                    // rendezvous: option cq3_rdv_us (default 10 ms) in polls of ~ 1.3 us; waits after it: ~ 10 x the launch's expected duration
-                    // (measured on this handle; first launch: 25 us per step, four times the slowest size measured), at least 50 ms
-                    a.rdv_polls = (int)std::max<long long>(16, h->opt.get(O_CQ3_RDV_US) * 10 / 13);
+                    // rendezvous: about ONE launch duration (2 .. 100 ms; option cq3_rdv_us overrides) in polls of ~ 1.3 us -- an abandoned launch
+                    // then costs at most what the launch itself would have; waits after a passed rendezvous: ~ 10 x the launch's expected
+                    // duration, at least 50 ms (measured on this handle; before the first launch: 25 us per step, four times the slowest size measured)
                     const double us_step = h->cq3_us_per_step > 0.0 ? h->cq3_us_per_step : 25.0;
-                    a.wait_polls = (int)std::min<double>(2.0e9, std::max(50.0e3, 10.0 * us_step * nc) / 1.3);
+                    const double rdv_us = h->opt.has(O_CQ3_RDV_US) ? (double)h->opt.get(O_CQ3_RDV_US) : std::min(100.0e3, std::max(2.0e3, us_step * nc));
+                    a.rdv_polls = (int)std::min<double>(2.0e9, std::max(16.0, rdv_us / 1.3));
+                    a.wait_polls = (int)std::min<double>(2.0e9, (h->opt.has(O_CQ3_WAIT_MS) ? 1.0e3 * (double)h->opt.get(O_CQ3_WAIT_MS) : std::max(50.0e3, 10.0 * us_step * nc)) / 1.3);
                 }
                 HIPCHK(h, hipEventRecord(h->ev[evi++], s));
                 if (qsplit) {      // (two waves per column quad; its window ring is deeper than the forward kernel's)
@@ -2773,6 +2777,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     }
     if (cq3_err) {      // a wait between the three workgroups of a quad was abandoned (1), or they ran on different XCDs (2): the results are void
         ++h->cq3_faults;
+        if (cq3_err == 2) ++h->cq3_faults_xcd;
         h->cq3_skip = 2 << std::min(h->cq3_faults, 10);      // (4, 8, 16, ... evaluations; the repeat below counts as one)
         if (h->cq3_faults >= JQ_CQ3_MAX_FAULTS) h->cq3_off = true;
         if (debug_timing()) fprintf(stderr, "jq: k_backward_cq3 reported %llu -- evaluated again with k_backward_cq\n", cq3_err);
@@ -3611,7 +3616,7 @@ extern "C" int jq_plan_info(const jq_handle* hh, char* buf, int32_t buflen)
     {   // the three-workgroup latency kernels: what the last batch of the cooperative-quad families decided, and why
         const jq_handle* t2 = h->emb ? h->emb : h;
         const std::string d = t2->cq3_last.empty() ? "no batch of the cooperative-quad families yet" : t2->cq3_last;
-        kv("latency_split", std::string("{\"last_decision\": \"") + d + "\", \"faults\": " + num(t2->cq3_faults) + ", \"abandoned_at_rendezvous\": " + num(t2->cq3_busy) + ", \"cooling_down\": " + num(t2->cq3_skip) +
+        kv("latency_split", std::string("{\"last_decision\": \"") + d + "\", \"faults\": " + num(t2->cq3_faults) + ", \"faults_xcd\": " + num(t2->cq3_faults_xcd) + ", \"abandoned_at_rendezvous\": " + num(t2->cq3_busy) + ", \"cooling_down\": " + num(t2->cq3_skip) +
                                 ", \"off\": " + (t2->cq3_off ? "true" : "false") + "}");
     }
     o += "}";

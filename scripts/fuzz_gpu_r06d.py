@@ -91,9 +91,8 @@ def run(n_cases=50, seed=1, verbose=True):
         imr = bool(rng.random() < 0.3) and (Ntot <= 16 or structure is not False)
         if Ntot > 96:      # 4 x 4 x 7 / 4 x 4 x 8 on the NT = 7, 8 instantiations (N = 1, 2, 4); anything else at this size: cooperative kernels
             imr = imr and (structure != "t4" or N in (1, 2, 4) or N > 16)
-        if Ntot > 256:     # (the implicit-midpoint path is implemented up to Ntot = 256; a small batch: the CPU oracle pays Ntot^2 per product and column)
+        if Ntot > 256:     # (the implicit-midpoint path is implemented up to Ntot = 256)
             imr = False
-            N = min(N, 6)
         if os.environ.get("FUZZ_FOCUS") == "imr_cq":      # the cooperative-quad implicit-midpoint kernels: 4 x 4 x n structure, N = 4
             Ntot, N, structure, imr = int(rng.choice([32, 48, 64, 80, 96])), 4, "t4", True
         focus_w = os.environ.get("FUZZ_FOCUS") == "wfull_cq"
@@ -158,7 +157,6 @@ def run(n_cases=50, seed=1, verbose=True):
             if replan:
                 rng.standard_normal((Ntot, Ntot))
             nq = int(rng.choice([1, 2, 5, 17, 70, 100, 140])) if focus_w else int(rng.choice([1, 2, 5, 17, 70]))
-            nq = min(nq, 2) if Ntot > 256 else min(nq, 5) if Ntot >= 128 else nq      # (the CPU oracle pays Ntot^2 per product, column and node)
             rng.standard_normal(nq), rng.random(nq)
             if focus_w and nq > 20:
                 rng.choice(nq, 4, replace=False)
@@ -176,7 +174,6 @@ def run(n_cases=50, seed=1, verbose=True):
                 wa.close()
                 wa = jq.Working_Arrays_HIP(p, pcof.size, options=env)
         nq = int(rng.choice([1, 2, 5, 17, 70, 100, 140])) if focus_w else int(rng.choice([1, 2, 5, 17, 70]))
-        nq = min(nq, 2) if Ntot > 256 else min(nq, 5) if Ntot >= 128 else nq      # (the CPU oracle pays Ntot^2 per product, column and node)
         nodes, weights = 0.05 * rng.standard_normal(nq), rng.random(nq)
         if focus_w and nq > 20:      # (the oracle loops over the samples: a few one-hot weights)
             hot = rng.choice(nq, 4, replace=False)

@@ -88,7 +88,7 @@ def main():
             e["steps_per_launch"] = nsteps / launches[k]
         kernels[k] = e
     import os
-    chunk_env = {v: os.environ.get(v) for v in ("JQ_CHUNK_STEPS", "JQ_TRACE_BYTES", "JQ_STREAM_BYTES")}
+    chunk_env = {"JQ_OPTIONS": os.environ.get("JQ_OPTIONS")}      # (options that change the chunking would change steps_per_launch)
     json.dump({"note": __doc__.split("usage:")[1].strip(), "library_version": version, "chunk_env": chunk_env, "kernels": kernels},
               open(out_path, "w"), indent=1)
     print("wrote", out_path, "kernels:", ", ".join(sorted(kernels)))

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Profile of the dense-operator path (bench.py's `dense_operator` block: cnot3 dimensions with a dense Hermitian drift, kernels
 # k_forward / k_backward<6, 5>), in one GPU call:
-#   1. rocprofv3 --kernel-trace --stats of ONE full-length evaluation     -> gpurun_out/dense_stats_<tag>.txt  (-> profiles/r05_dense_kernel_stats.txt)
-#   2. rocprofv3 --pmc passes of the same command                          -> gpurun_out/pmc_dense_<tag>.json   (-> profiles/r05_pmc_dense.json)
+#   1. rocprofv3 --kernel-trace --stats of ONE full-length evaluation     -> gpurun_out/dense_stats_<tag>.txt  (-> profiles/r06_dense_kernel_stats.txt)
+#   2. rocprofv3 --pmc passes of the same command                          -> gpurun_out/pmc_dense_<tag>.json   (-> profiles/r06_pmc_dense.json)
 #   3. the block itself (quotes the PMC record of THIS build)              -> gpurun_out/dense_<tag>.log
 # usage: scripts/profile_dense.sh <tag> [samples]
 tag=$1
@@ -21,7 +21,7 @@ done
 cd $R
 ver=$(python3 -c "import juqbox_jl_amd._lib as l; print(l.load().jq_version().decode())")
 python3 scripts/make_traffic_json.py gpurun_out/pmc_dense_${tag}.json --version "$ver" --samples $ns --nsteps 32386 $(find gpurun_out/profd_${tag}/pmc* -name "*.db") && head -40 gpurun_out/pmc_dense_${tag}.json
-cp gpurun_out/pmc_dense_${tag}.json profiles/r05_pmc_dense.json
+cp gpurun_out/pmc_dense_${tag}.json profiles/r06_pmc_dense.json
 python3 bench.py --dense-only $ns > gpurun_out/dense_${tag}.log 2> gpurun_out/dense_${tag}.err
 tail -1 gpurun_out/dense_${tag}.log | cut -c1-3000
 rm -rf gpurun_out/profd_${tag}

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything the judged profile files come from, in one GPU call (run through gpurun):
 #   1. rocprofv3 --kernel-trace --stats of one bench step           -> gpurun_out/stats_<tag>.txt
-#   2. rocprofv3 --pmc passes of the same command (HBM bytes; SQ)   -> gpurun_out/pmc_<tag>.json  (copied to profiles/r05_pmc.json,
+#   2. rocprofv3 --pmc passes of the same command (HBM bytes; SQ)   -> gpurun_out/pmc_<tag>.json  (copied to profiles/r06_pmc.json,
 #      which the bench line quotes: MFMA count, VALU per MFMA, stall fractions, HBM bytes per launch)
 #   3. the default bench.py line                                    -> gpurun_out/bench_<tag>.log
 # usage: scripts/profile_round.sh <tag>          (copy the three files into profiles/ afterwards)
@@ -21,7 +21,7 @@ cd $R
 ver=$(python3 -c "import juqbox_jl_amd._lib as l; print(l.load().jq_version().decode())")
 python3 scripts/make_traffic_json.py gpurun_out/pmc_${tag}.json --version "$ver" --samples ${JQ_BENCH_SAMPLES:-3072} --nsteps 32386 $(find gpurun_out/prof_${tag}/pmc* -name "*.db") && head -30 gpurun_out/pmc_${tag}.json
 # the bench line last: it quotes the PMC figures of THIS build
-cp gpurun_out/pmc_${tag}.json profiles/r05_pmc.json
+cp gpurun_out/pmc_${tag}.json profiles/r06_pmc.json
 python3 bench.py > gpurun_out/bench_${tag}.log 2> gpurun_out/bench_${tag}.err
 tail -1 gpurun_out/bench_${tag}.log | cut -c1-1500
 rm -rf gpurun_out/prof_${tag}      # (the rocpd databases are large; their summaries above are what is kept)

@@ -20,9 +20,7 @@ for structure, env, wts in ((False, {"JQ_COOP_MAX": "0"}, False), (False, {"JQ_C
                     fs = fs / np.linalg.norm(fs, axis=0)
                     W = sum((0.5 + 0.3 * k) * np.outer(fs[:, k], np.conj(fs[:, k])) for k in range(2))
                     p.wmat_real, p.wmat_imag = np.asfortranarray(W.real.copy()), np.asfortranarray(W.imag.copy())
-                os.environ.update(env)
-                wa = jq.Working_Arrays_HIP(p, pcof.size)
-                for k in env: os.environ.pop(k)
+                wa = jq.Working_Arrays_HIP(p, pcof.size, options=env)      # (historic spelling: {"JQ_QUAD": "0"} = option quad=0)
                 r = Oracle(p, use_sparse=False).traceobjgrad(pcof)
                 try:
                     out = jq.traceobjgrad(pcof, p, wa, False, True)

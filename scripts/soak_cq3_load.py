@@ -1,4 +1,4 @@
-"""Soak of the three-workgroup latency kernels UNDER LOAD: the soak of scripts/soak_cq3.py (every result compared bit for bit with the
+"""Soak of the three-workgroup latency kernels UNDER LOAD: an idle-GPU soak (every result compared bit for bit with the
 first one of its kind) while OTHER PROCESSES keep the GPU busy -- one runs the 3 072-sample throughput kernels back to back (every CU
 streaming, three waves per SIMD), one runs its own <= 80-sample split grids (a second set of workgroups that wait for each other).
 Inside a process the library never lets a split grid share the device (DevGate); across processes nothing can be checked, so this
@@ -38,7 +38,7 @@ if role == "split":           # its own split grids (80 samples = 240 workgroups
         cur = (params.last_infidelity, params.last_leak, params.last_infidelity_grad.tobytes())
         first = first or cur
         assert cur == first, "MISMATCH in the split load process"
-        fb += wa.last_timing()["reserved"] != 3
+        fb += wa.last_timing()["kernel_variant"] != 3
         n += 1
     print("split load: %d evaluations of 80 samples, %d on the one-workgroup kernel, plan: %s" % (n, fb, wa.plan_info()["latency_split"]), flush=True)
     sys.exit(0)
@@ -69,7 +69,7 @@ for imr in (False, True):
     for ns in SIZES[imr]:
         nodes, weights, shift = jq.cases.cnot3_ensemble(ns)
         jq.eval_f_g_grad(pcof, p2, wa, nodes, weights, True, shift=shift)
-        assert wa.last_timing()["reserved"] == (2 if ns > 80 else 3)
+        assert wa.last_timing()["kernel_variant"] == (2 if ns > 80 else 3)
         first[imr, ns] = (p2.last_infidelity, p2.last_leak, p2.last_infidelity_grad.tobytes())
 loads = [subprocess.Popen([sys.executable, os.path.abspath(__file__), str(rounds), str(nsteps)], env=dict(os.environ, JQ_SOAK_ROLE=r),
                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in (sys.argv[3].split(",") if len(sys.argv) > 3 else ("throughput", "split"))]
@@ -86,7 +86,7 @@ for r in range(rounds):
             jq.eval_f_g_grad(pcof, p2, wa, nodes, weights, True, shift=shift)
             worst = max(worst, time.time() - t1)
             nev += 1
-            nfb += wa.last_timing()["reserved"] not in (2, 3)
+            nfb += wa.last_timing()["kernel_variant"] not in (2, 3)
             cur = (p2.last_infidelity, p2.last_leak, p2.last_infidelity_grad.tobytes())
             same = cur == first[imr, ns]
             if not same and wa.last_timing()["kernel_family"] == 6:      # (weighted run that fell back to the quad-layout kernels)

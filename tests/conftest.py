@@ -18,6 +18,21 @@ ATOL = 1e-14
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+    config.addinivalue_line("markers", "slow: full-length (32 386-step) DUPLICATE of a test that also runs shortened or on another parameter set; "
+                                       "skipped unless --runslow / JQ_RUN_SLOW=1 (every kernel family keeps one full-length test in the default suite)")
+
+
+def pytest_addoption(parser):
+    parser.addoption("--runslow", action="store_true", default=False, help="also run the tests marked slow")
+
+
+def pytest_collection_modifyitems(config, items):
+    if config.getoption("--runslow") or os.environ.get("JQ_RUN_SLOW"):
+        return
+    skip = pytest.mark.skip(reason="slow duplicate: --runslow / JQ_RUN_SLOW=1")
+    for item in items:
+        if "slow" in item.keywords:
+            item.add_marker(skip)
 
 
 def load_golden(name):

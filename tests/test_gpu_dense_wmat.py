@@ -33,7 +33,9 @@ def set_forbidden(p, rng, nforb, complex_states=True):
 
 def compare(jq, p, pcof, wa, family=None, ensembles=(), rng=None, tol=TOL):
     from oracle.oracle import Oracle
-    r = Oracle(p, use_sparse=False).traceobjgrad(pcof)
+    # (the oracle's sparse-pattern products give bit-identical numbers 7 x faster for the reference's own sparse problems: cnot3)
+    sp = bool(getattr(p, "use_sparse", False))
+    r = Oracle(p, use_sparse=sp).traceobjgrad(pcof)
     objfv, tg, prim, sec, tinf, ig, lg = jq.traceobjgrad(pcof, p, wa, False, True)
     gn = np.linalg.norm(r["totalgrad"])
     assert abs(prim - r["primaryobjf"]) <= tol * max(abs(r["primaryobjf"]), 1e-4)
@@ -52,7 +54,7 @@ def compare(jq, p, pcof, wa, family=None, ensembles=(), rng=None, tol=TOL):
         weights = rng.random(nq)
         shift = rng.standard_normal(p.Ntot) * 0.05
         shift[0] = 0.0
-        ref = Oracle(p, use_sparse=False).eval_f_g_grad(pcof, nodes, weights, shift)
+        ref = Oracle(p, use_sparse=sp).eval_f_g_grad(pcof, nodes, weights, shift)
         jq.eval_f_g_grad(pcof, p, wa, nodes, weights, True, shift=shift)
         gref = np.linalg.norm(ref["last_infidelity_grad"])
         assert abs(p.last_infidelity - ref["last_infidelity"]) <= tol * abs(ref["last_infidelity"])
@@ -66,7 +68,7 @@ def compare(jq, p, pcof, wa, family=None, ensembles=(), rng=None, tol=TOL):
 @pytest.mark.parametrize("oft", [1, 3])
 @pytest.mark.parametrize("complex_states", [False, True])
 def test_swap02_row_lane(jq, oft, complex_states):
-    p, pcof = forbidden_problem("swap02", 2, 21, complex_states, oft)
+    p, pcof = forbidden_problem("swap02", 2, 21, complex_states, oft, nsteps=1501)      # (the oracle loops over 600 samples)
     wa = make_wa(jq, p, pcof.size)
     compare(jq, p, pcof, wa, family=3, ensembles=(1, 7, 600), rng=np.random.default_rng(1))
     wa.close()
@@ -76,7 +78,7 @@ def test_swap02_row_lane(jq, oft, complex_states):
 def test_cnot2(jq, oft, env, family):
     """row-lane kernels (NPJ = 12); JQ_LANE=0: the embedded 4 x 4 x 1 twin on the quad-layout kernels with the low-rank terms;
     JQ_LANE=0 JQ_EMBED=0: the dense NT = 1 slab kernels (run-time test of a.wrank)"""
-    p, pcof = forbidden_problem("cnot2", 3, 22, True, oft)
+    p, pcof = forbidden_problem("cnot2", 3, 22, True, oft, nsteps=1201)
     wa = make_wa(jq, p, pcof.size, env)
     compare(jq, p, pcof, wa, family=family, ensembles=(5, 70), rng=np.random.default_rng(2))
     wa.close()
@@ -165,20 +167,13 @@ def test_refusals(jq):
         with pytest.raises(_lib.JuqboxHipError) as e:
             jq.traceobjgrad(pcof, p, wa, False, True)
         assert e.value.code == _lib.JQ_EUNSUPPORTED and "Hermitian" in str(e.value)
-    # the Jacobi solver has no low-rank terms
+    # (round 6: the Jacobi solver and ranks above 16 are no longer refused -- tests/test_gpu_round6.py; here: the switch on a live handle)
     p.wmat_real, p.wmat_imag = good_r, good_i
     p.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER, max_iter=50, tol=1e-12, nrhs=p.N)
-    with pytest.raises(_lib.JuqboxHipError) as e:
-        jq.traceobjgrad(pcof, p, wa, False, True)
-    assert e.value.code == _lib.JQ_EUNSUPPORTED
+    compare(jq, p, pcof, wa)
+    assert wa.plan_info()["linear_solver"] == "jacobi" and wa.plan_info()["embedded_twin_Ntot"] == 0
     wa.close()
-    # rank above JQ_MAX_WRANK
     rng = np.random.default_rng(8)
-    p2, pcof2 = random_problem(jq, rng, 40, 4, 1, 1, 5, 2, 1, False)
-    set_forbidden(p2, rng, 17)
-    with pytest.raises(_lib.JuqboxHipError) as e:
-        make_wa(jq, p2, pcof2.size)
-    assert e.value.code == _lib.JQ_EUNSUPPORTED and "rank 17" in str(e.value)
     # the implicit-midpoint type never sees wmat_real: its weights are params.wmat (Diagonal), results unchanged by forb_states
     p3, info3, pcof3, _ = case_inputs("swap02")
     p3.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER_M, max_iter=100, tol=1e-12)

@@ -1,5 +1,9 @@
-"""GPU (-m gpu): a fixed-seed slice of the randomised stress of scripts/fuzz_gpu.py (problem sizes 2..96, structures,
-kernel-family overrides, chunkings, ensemble sizes, both integrators) against the CPU oracle."""
+"""GPU (-m gpu): fixed-seed slices of the randomised stress of scripts/fuzz_gpu.py (problem sizes 2 .. 300, structures, options that
+force kernel families, chunkings, ensemble sizes, both integrators, both solvers, Diagonal and full leakage weights) against the CPU oracle --
+at the REFERENCE'S OWN CRITERION and nothing looser: per quantity (infidelity, leak, infidelity gradient, leak gradient) the norm of the
+difference below atol = 1e-14 or the relative difference below rtol = 1e-10 (test/evalGrad.jl:4-5, :43-67; fuzz_gpu.ref_err =
+conftest.reference_pass).  Rounds 3 - 5 asserted 1e-9 here on a metric that divided the leak gradient's error by the infidelity gradient's
+norm; the one recorded draw above 1e-10 was that ratio (profiles/r06_fuzz_draw528.txt)."""
 import os
 import sys
 
@@ -11,12 +15,13 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "scripts"))
 
 def test_fixed_seed_fuzz_matches_oracle():
     import fuzz_gpu
-    worst, n = fuzz_gpu.run(60, 11, verbose=False)
+    worst, n = fuzz_gpu.run(45, 11, verbose=False)
     # n = cases really compared with the oracle (drawn combinations without kernels are skipped, not counted)
-    assert n == 60 and worst < 1e-9, (n, worst)
+    assert fuzz_gpu.RTOL == 1e-10 and fuzz_gpu.ATOL == 1e-14
+    assert n == 45 and worst < fuzz_gpu.RTOL, (n, worst)
 
 
-@pytest.mark.parametrize("focus,n,seed", [("wfull_cq", 70, 4242), ("slab", 40, 1313), ("wfull", 40, 1414)])
+@pytest.mark.parametrize("focus,n,seed", [("wfull_cq", 70, 4242), ("slab", 30, 1313), ("wfull", 30, 1414)])
 def test_fixed_seed_fuzz_focus_modes(focus, n, seed):
     """Round 5: the focus modes of the fuzz -- full weights on the cooperative-quad kernels (the mode that found a miscompiled kernel
     object: draw 64 of this seed is that case), every draw forced onto the slab kernels, full weights in every draw."""
@@ -26,4 +31,4 @@ def test_fixed_seed_fuzz_focus_modes(focus, n, seed):
         worst, m = fuzz_gpu.run(n, seed, verbose=False)
     finally:
         os.environ.pop("FUZZ_FOCUS", None)
-    assert m == n and worst < 1e-9, (focus, m, worst)
+    assert m == n and worst < fuzz_gpu.RTOL, (focus, m, worst)

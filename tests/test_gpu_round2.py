@@ -286,16 +286,15 @@ def test_sizes_beyond_the_round1_limits_match_the_oracle(hip, Ntot, N, Nc, nstep
         gl += wq * r["leakgrad"]
     wa = jq.Working_Arrays_HIP(p, pcof.size)
     jq.eval_f_g_grad(pcof, p, wa, nodes, weights, True, shift=shift)
-    assert abs(p.last_infidelity - inf) <= 1e-9 * abs(inf)
-    assert abs(p.last_leak - leak) <= 1e-9 * abs(leak)
-    assert rel(p.last_infidelity_grad, gi) < 1e-9
+    from conftest import reference_pass      # (the reference's criterion, rtol 1e-10 / atol 1e-14 per quantity: rounds 2 - 5 asserted 1e-9 here)
+    assert reference_pass(p.last_infidelity, inf) and reference_pass(p.last_leak, leak) and reference_pass(p.last_infidelity_grad, gi)
     if oft != 1:
-        assert np.linalg.norm(p.last_leak_grad - gl) <= 1e-9 * np.linalg.norm(gi)
+        assert reference_pass(p.last_leak_grad, gl)
     r0 = Oracle(p, use_sparse=False).traceobjgrad(pcof, evaladjoint=False, history=True)
     objfv, hist, fid = jq.traceobjgrad(pcof, p, wa, True, False)
     assert hist.shape == (Ntot, N, nsteps + 1)
     assert np.max(np.abs(hist - r0["history"])) < 1e-11
-    assert abs(objfv - r0["objfv"]) <= 1e-9 * abs(r0["objfv"])
+    assert reference_pass(objfv, r0["objfv"])
     wa.close()
 
 
@@ -385,7 +384,8 @@ def test_random_kronecker_problems_take_the_embedded_kernels(hip, dims, N, nq):
         for ep, wq in zip(nodes, weights):
             r = oracle_sample(p, pcof, ep, shift)
             inf += wq * r["primaryobjf"]; leak += wq * r["secondaryobjf"]; gi += wq * r["infidelgrad"]
-        assert abs(a[0] - inf) <= 1e-9 * abs(inf) and abs(a[1] - leak) <= 1e-9 * abs(leak) and rel(a[2], gi) < 1e-9
+        from conftest import reference_pass
+        assert reference_pass(a[0], inf) and reference_pass(a[1], leak) and reference_pass(a[2], gi)
 
 
 # ---- split batches (ensembles that do not fill their last round of the three-slab quad-layout kernels) -------------------

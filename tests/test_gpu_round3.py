@@ -384,13 +384,7 @@ def test_more_than_four_controls_match_the_oracle(hip, name, cfg, env, imr):
         wa.close()
 
 
-def test_seventeen_controls_are_refused(hip):
-    from juqbox_jl_amd import _lib
-    from test_gpu_random import random_problem
-    p, pcof = random_problem(hip, np.random.default_rng(2), 8, 2, 17, 1, 5, 1, 1, False)
-    with pytest.raises(_lib.JuqboxHipError) as e:
-        hip.Working_Arrays_HIP(p, pcof.size)
-    assert e.value.code == _lib.JQ_EUNSUPPORTED
+# (round 6: more than 16 controls are no longer refused -- tests/test_gpu_round6.py test_more_than_16_control_hamiltonians)
 
 
 @pytest.mark.parametrize("structure,Ntot,imr", [("t4", 96, False), ("od", 80, False), (True, 50, False), ("t4", 64, True)])

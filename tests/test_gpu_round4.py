@@ -95,9 +95,10 @@ def test_manifest_of_the_bench_path_kernels():
     wa.close()
     bk = pi["build"]
     assert bk["manifest"] is True
-    for obj in ("k_6_7", "s_6_7", "u_6_7"):
+    # (round 6, csrc/Makefile: VGPR form only where it was measured to pay -- s_6_7 yes; k_6_7, u_6_7 no difference: default form)
+    for obj, vf in (("k_6_7", False), ("s_6_7", True), ("u_6_7", False), ("p_6_7", True)):
         e = bk["objects"][obj]
-        assert e["vgpr_form"] is True and e["fallback"] is False, (obj, e)
+        assert e["vgpr_form"] is vf and e["fallback"] is False, (obj, e)
     assert bk["objects"]["k_6_7"]["max_scratch_bytes"] <= 160
     assert bk["objects"]["s_6_7"]["max_scratch_bytes"] <= 64
 

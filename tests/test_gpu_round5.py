@@ -242,13 +242,17 @@ def test_same_device_sub_handles_never_take_the_split(jq):
 
 # ---- (3) the dense-operator path (bench.py's dense_operator block) ------------------------------------------------------------------
 
-def test_dense_drift_at_full_length_matches_the_oracle(jq):
-    """north_star's "dense (H x state-batch) contraction": cnot3's dimensions with a dense Hermitian drift (cases.cnot3_dense) at the
-    reference's full length (32 386 steps), one evaluation, on the kernels bench.py's dense_operator block times (k_forward /
-    k_backward<6, 5>: dense 16 x 16 x 4 MFMA tiles, no structure exploited) against the oracle's DENSE products
-    (src/StormerVerlet.jl:461-504 dense step!): objective, infidelity / leak split and gradient at 1e-10."""
+@pytest.mark.parametrize("nsteps", [6001, pytest.param(0, marks=pytest.mark.slow)], ids=["6001_steps", "full_length"])
+def test_dense_drift_matches_the_oracle(jq, nsteps):
+    """north_star's "dense (H x state-batch) contraction": cnot3's dimensions with a dense Hermitian drift (cases.cnot3_dense), one
+    evaluation on the kernels bench.py's dense_operator block times (k_forward / k_backward<6, 5>: dense 16 x 16 x 4 MFMA tiles, no structure
+    exploited) against the oracle's DENSE products (src/StormerVerlet.jl:461-504 dense step!): objective, infidelity / leak split and
+    gradient at 1e-10.  6 001 steps (odd: several chunks of odd length) in the default suite; the reference's full length (32 386 steps:
+    50 s of CPU oracle) is the slow duplicate."""
     from oracle.oracle import Oracle
     params, info = jq.cases.cnot3_dense()
+    if nsteps:
+        params.T, params.nsteps = params.T * nsteps / params.nsteps, nsteps
     pcof = np.array(json.load(open(os.path.join(ROOT, "tests", "golden", "cnot3.json")))["pcof0"])
     wa = jq.Working_Arrays_HIP(params, pcof.size)
     pi = wa.plan_info()

@@ -114,7 +114,9 @@ def test_full_weights_with_the_jacobi_solver_match_the_oracle(jq, cfg):
     Ntot, N, Nc, nsteps, structure, opts, kernel, replanned = cfg
     rng = np.random.default_rng(6100 + Ntot + N)
     p, pcof = random_problem(jq, rng, Ntot, N, Nc, 1, nsteps, 3, 3, structure)
-    p.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER, max_iter=50, tol=1e-9, nrhs=N)
+    # (N > 16 on the cooperative kernels: convergence is tested per 16-column part -- include/juqbox_hip.h -- so the parts may stop at
+    #  different iterations and the result carries O(tol); a tolerance at rounding level makes that invisible)
+    p.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER, max_iter=80 if N > 16 else 50, tol=1e-13 if N > 16 else 1e-9, nrhs=N)
     set_forbidden(p, rng, 2 + Ntot % 2, complex_states=(Ntot % 3 != 0))
     wa = jq.Working_Arrays_HIP(p, pcof.size, options=opts)
     t = check(jq, p, pcof, wa, rng, ensembles=(2,) if N > 16 else (3, 9))
