@@ -358,9 +358,10 @@ int jq_plan_info(const jq_handle *h, char *buf, int32_t buflen);
 
 /* ---- measurement -----------------------------------------------------------------------------*/
 int jq_last_timing(const jq_handle *h, jq_timing *t);
-/* Library build info: "gfx950 juqbox_hip <version> src:<12 hex digits>" -- the digits are the SHA-256 prefix of the library's
- * sources (the .hip and .h files under csrc/ and include/juqbox_hip.h) at build time, so measurements recorded for one build (profiles/) cannot
- * be paired with another build by accident (bench.py compares it). */
+/* Library build info: "gfx950 juqbox_hip <version> src:<12 hex digits> code:<12 hex digits>" -- src: the SHA-256 prefix of the library's
+ * sources (the .hip and .h files under csrc/ and include/juqbox_hip.h) AND of the flags they were built with, so measurements recorded
+ * for one build (profiles/) cannot be paired with another build by accident (bench.py compares it); code: of the sources alone (the
+ * shipped library and its default-register-form twin of `make check-forms-lib` agree in it). */
 const char *jq_version(void);
 /* JQ_ABI_VERSION of the header the library was built with */
 int jq_abi_version(void);

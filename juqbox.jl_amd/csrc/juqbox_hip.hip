@@ -35,7 +35,10 @@
 #ifndef JQ_SRC_HASH
 #define JQ_SRC_HASH "unknown"      // (the Makefile passes the SHA-256 prefix of the library's sources)
 #endif
-#define JQ_VERSION "gfx950 juqbox_hip 0.4.0 src:" JQ_SRC_HASH
+#ifndef JQ_CODE_HASH
+#define JQ_CODE_HASH "unknown"
+#endif
+#define JQ_VERSION "gfx950 juqbox_hip 0.4.0 src:" JQ_SRC_HASH " code:" JQ_CODE_HASH
 #ifndef JQ_MINW_MAXNT
 #define JQ_MINW_MAXNT 2      // tile counts up to which two workgroups share a CU (slab kernels; jq_kernel_inst.hip)
 #endif

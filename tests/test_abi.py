@@ -180,7 +180,7 @@ def test_abi_version_and_source_hash():
     hdr = open(os.path.join(ROOT, "include", "juqbox_hip.h")).read()
     v = int(re.search(r"#define JQ_ABI_VERSION (\d+)", hdr).group(1))
     assert L.jq_abi_version() == v == _lib.JQ_ABI_VERSION
-    assert re.search(r"src:[0-9a-f]{12}$", L.jq_version().decode()), L.jq_version()
+    assert re.search(r"src:[0-9a-f]{12} code:[0-9a-f]{12}$", L.jq_version().decode()), L.jq_version()
     assert L.jq_handle_device(None) == -1 and L.jq_num_devices(None) == 0
 
 

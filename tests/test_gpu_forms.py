@@ -38,7 +38,11 @@ def test_both_libraries_are_builds_of_the_same_sources():
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, JQ_LIB=lib), capture_output=True, text=True, cwd=ROOT)
         assert r.returncode == 0, r.stderr[-1000:]
         vers.append(r.stdout.strip().splitlines()[-1])
-    assert vers[0] != vers[1] and all(v.startswith("gfx950 juqbox_hip") for v in vers), vers
+    assert all(v.startswith("gfx950 juqbox_hip") for v in vers), vers
+    src = [v.split("src:")[1].split()[0] for v in vers]
+    code = [v.split("code:")[1].split()[0] for v in vers]
+    assert src[0] != src[1], "the twin was built with the same flags: the fence compares a library with itself"
+    assert code[0] == code[1], "the default-form twin was built from OTHER sources (rebuild: make -C juqbox.jl_amd/csrc check-forms-lib): %s" % vers
     man = json.load(open(os.path.join(ROOT, "juqbox.jl_amd", "csrc", "build", "manifest.json"))) if os.path.exists(
         os.path.join(ROOT, "juqbox.jl_amd", "csrc", "build", "manifest.json")) else None
     if man:      # (the build directory does not travel to the GPU box; the CPU suite checks the manifest itself)

@@ -268,3 +268,29 @@ def test_abandoned_rendezvous_falls_back_within_the_call_and_cools_down_briefly(
     f3, g3, *_ = jq.traceobjgrad(pcof, p, wa, False, True)
     assert f3 == f0 and np.array_equal(g3, g0)
     wa.close()
+
+
+# ---- (6) every kernel object with the low-rank weight terms: odd chunk lengths, Neumann terms (advisor, round 5) -----------------------------
+
+@pytest.mark.parametrize("NT", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_full_weight_objects_with_odd_chunk_lengths(jq, NT):
+    """Round 5's miscompiled object (w_6_5 in VGPR form) gave wrong states for chunks with an ODD number of steps and Neumann terms; its
+    siblings are built from the same source.  Every size of the quad-layout objects with the low-rank terms (w_1_7 .. w_8_7: 4 x 4 x n
+    problems, five complex forbidden states so that the cooperative-quad kernels do not take them) and the one-tile-row slab object
+    (w_1_0) runs 7 steps in chunks of 3, 3, 1 and of 2 with three Neumann terms against the oracle; w_6_5 itself: test_gpu_round5.py (7)."""
+    rng = np.random.default_rng(6600 + NT)
+    p, pcof = random_problem(jq, rng, 16 * NT, 4, 2, 1, 7, 3, 3, "t4")
+    set_forbidden(p, rng, 5)
+    for chunk in (3, 2):
+        wa = jq.Working_Arrays_HIP(p, pcof.size, options={"chunk_steps": chunk})
+        t = check(jq, p, pcof, wa, rng, ensembles=(5,))
+        assert (t["kernel_family"], t["kernel_size"], t["kernel_band"]) == (6, NT, 7), t
+        wa.close()
+    if NT == 1:
+        q, qcof = random_problem(jq, rng, 12, 3, 2, 1, 7, 3, 3, False)
+        set_forbidden(q, rng, 3)
+        for chunk in (3, 2):
+            wa = jq.Working_Arrays_HIP(q, qcof.size, options={"chunk_steps": chunk, "lane": 0, "embed": 0})
+            t = check(jq, q, qcof, wa, rng, ensembles=(5,))
+            assert (t["kernel_family"], t["kernel_size"], t["kernel_band"]) == (0, 1, 0), t
+            wa.close()
