@@ -357,8 +357,10 @@ def baseline_configs_block(jq, L, quick=False):
                                            ("%d of the %d quadrature nodes (spread over the interval), one eval_f_g_grad loop on one thread, time "
                                             "scaled by %d / %d" % (ncpu, nq, nq, ncpu))}
         entry["gpu_over_cpu_1core"] = tcpu / (tc["ms_total"] * 1e-3)
-        if nq == 1:      # the same evaluation on both sides: a live parity check of the line's own numbers
-            entry["infidelity_gpu_vs_cpu_rel_diff"] = abs(gpu_infid - cpu_infid) / max(abs(cpu_infid), 1e-300)
+        if nq == 1:      # the same evaluation on both sides: a live parity check of the line's own numbers at the reference's criterion
+            d = abs(gpu_infid - cpu_infid)      # (test/evalGrad.jl:43-67: difference below atol 1e-14, or relative difference below rtol 1e-10)
+            entry["infidelity"] = {"gpu": gpu_infid, "cpu_oracle": cpu_infid, "abs_diff": d,
+                                   "passes_reference_criterion": bool(d < 1e-14 or d / max(abs(cpu_infid), 1e-300) < 1e-10)}
         # ---- bound: latency of the dependent chain --------------------------------------------------------------
         if tc["kernel_family"] == 3 and chain:
             npj = int(tc["kernel_size"])

@@ -282,7 +282,8 @@ def test_full_weight_objects_with_odd_chunk_lengths(jq, NT):
     p, pcof = random_problem(jq, rng, 16 * NT, 4, 2, 1, 7, 3, 3, "t4")
     set_forbidden(p, rng, 5)
     for chunk in (3, 2):
-        wa = jq.Working_Arrays_HIP(p, pcof.size, options={"chunk_steps": chunk})
+        # (one tile row: the row-lane kernels would take it -- lane=0 sends it to the quad-layout object)
+        wa = jq.Working_Arrays_HIP(p, pcof.size, options=dict({"chunk_steps": chunk}, **({"lane": 0} if NT == 1 else {})))
         t = check(jq, p, pcof, wa, rng, ensembles=(5,))
         assert (t["kernel_family"], t["kernel_size"], t["kernel_band"]) == (6, NT, 7), t
         wa.close()
