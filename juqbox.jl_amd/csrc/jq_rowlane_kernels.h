@@ -51,27 +51,89 @@ __device__ __forceinline__ RowMat<NPJ> row_load_lds(const double* img, int row)
     return m;
 }
 
-// y += x[lane J of the row] * m
-template <int J>
-__device__ __forceinline__ void fma_xbcast(double& y, double x, double m)
-{
-    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(y) : "v"(x), "v"(m), "n"(J));
-}
-template <int NPJ, int... J>
-__device__ __forceinline__ void rmv_fold(double& ya, double& yb, double x, const RowMat<NPJ>& M, std::integer_sequence<int, J...>)
-{
-    (fma_xbcast<J>((J & 1) ? yb : ya, x, M.r[J]), ...);
-}
-// y = c + M x : two accumulator chains (even / odd j)
+// y = c + M x : two accumulator chains (even / odd j).
+// x was (almost always) just written by VALU instructions: DPP read-after-write hazard, 2 wait states -- `s_nop 1` opens the product.
+// The whole product is ONE asm block (round 6): with one asm statement per FMA hipcc put an `s_nop 0` of its own between every pair of
+// them (its hazard recognizer cannot see into inline asm) -- four to seven issue slots per product that a wave which is alone on its SIMD
+// pays in full (NPJ = 12: 12 FMAs + 5 s_nop; the time step of cnot2 spent 18 % of its issue slots on them).  Same FMAs, same order,
+// same accumulators: results bit-identical.  scripts/check_dpp_hazard.py verifies the final ISA as before.
 template <int NPJ, bool ZEROC>
 __device__ __forceinline__ double rmv(double c, const RowMat<NPJ>& M, double x)
 {
+    static_assert(NPJ == 2 || NPJ == 4 || NPJ == 6 || NPJ == 8 || NPJ == 12 || NPJ == 16, "row lengths the row-lane kernels are instantiated for");
     double ya = ZEROC ? 0.0 : c, yb = 0.0;
-    // x was (almost always) just written by VALU instructions: DPP read-after-write hazard, 2 wait states
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_nop 1");
-    __builtin_amdgcn_sched_barrier(0);
-    rmv_fold<NPJ>(ya, yb, x, M, std::make_integer_sequence<int, NPJ>{});
+    if constexpr (NPJ == 2)
+        asm("s_nop 1\n\t"
+            "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf"
+            : "+v"(ya), "+v"(yb)
+            : "v"(x), "v"(M.r[0]), "v"(M.r[1]));
+    if constexpr (NPJ == 4)
+        asm("s_nop 1\n\t"
+            "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf"
+            : "+v"(ya), "+v"(yb)
+            : "v"(x), "v"(M.r[0]), "v"(M.r[1]), "v"(M.r[2]), "v"(M.r[3]));
+    if constexpr (NPJ == 6)
+        asm("s_nop 1\n\t"
+            "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf"
+            : "+v"(ya), "+v"(yb)
+            : "v"(x), "v"(M.r[0]), "v"(M.r[1]), "v"(M.r[2]), "v"(M.r[3]), "v"(M.r[4]), "v"(M.r[5]));
+    if constexpr (NPJ == 8)
+        asm("s_nop 1\n\t"
+            "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf"
+            : "+v"(ya), "+v"(yb)
+            : "v"(x), "v"(M.r[0]), "v"(M.r[1]), "v"(M.r[2]), "v"(M.r[3]), "v"(M.r[4]), "v"(M.r[5]), "v"(M.r[6]), "v"(M.r[7]));
+    if constexpr (NPJ == 12)
+        asm("s_nop 1\n\t"
+            "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf"
+            : "+v"(ya), "+v"(yb)
+            : "v"(x), "v"(M.r[0]), "v"(M.r[1]), "v"(M.r[2]), "v"(M.r[3]), "v"(M.r[4]), "v"(M.r[5]), "v"(M.r[6]), "v"(M.r[7]), "v"(M.r[8]), "v"(M.r[9]), "v"(M.r[10]), "v"(M.r[11]));
+    if constexpr (NPJ == 16)
+        asm("s_nop 1\n\t"
+            "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %2, %16 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %0, %2, %17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %2, %18 row_newbcast:15 row_mask:0xf bank_mask:0xf"
+            : "+v"(ya), "+v"(yb)
+            : "v"(x), "v"(M.r[0]), "v"(M.r[1]), "v"(M.r[2]), "v"(M.r[3]), "v"(M.r[4]), "v"(M.r[5]), "v"(M.r[6]), "v"(M.r[7]), "v"(M.r[8]), "v"(M.r[9]), "v"(M.r[10]), "v"(M.r[11]), "v"(M.r[12]), "v"(M.r[13]), "v"(M.r[14]), "v"(M.r[15]));
     return ya + yb;
 }
 // bpa + sum_{j=1..m} S^j A  (Horner form)
@@ -125,9 +187,52 @@ __device__ __forceinline__ void rops_advance(RowOps<NPJ>& o, const RowOps<NPJ>& 
     o.S1 = nxt.S1;
 }
 
-// One Stormer-Verlet state step (forward step!, src/StormerVerlet.jl:461-504), accumulate form; sw = eps*c*ws_i
+// Round 6: the operator rows of a time step WITHOUT register copies between steps.  A step uses the integer point t_n (Kn0, S0), the
+// half point (Kp05, S05) and the integer point t_n+1 (Kn1, S1); the rows of the NEXT half point and of t_n+2 are loaded a whole step
+// ahead (a lone wave cannot hide a global load any other way).  With `o` / `nxt` structs that meant 6 NPJ register-pair moves per step
+// (rops_advance: 72 v_mov_b64 at NPJ = 12, a sixth of the step's issue slots for a wave that is alone on its SIMD).  Instead: three
+// integer-point sets and three half-point sets, the time loop unrolled three times, every step names the sets it reads and the sets its
+// loads go to -- after three steps every value is back in the variable it started in (JQ_RL_ROTATE).  Same loads, same products, same
+// order: bit-identical results.
 template <int NPJ>
-__device__ __forceinline__ void row_state(const PropArgs& a, const RowOps<NPJ>& o, double sw, double u, double v, double& un,
+struct RowTP {
+    RowMat<NPJ> K, S;
+};
+template <int NPJ>
+struct RowOpsV {      // the view a step's code reads its operators through (the member names of RowOps)
+    const RowMat<NPJ>&Kn0, &S0, &Kp05, &S05, &Kn1, &S1;
+};
+// half point of step n -> H, integer point t_n+1 -> I
+template <int NPJ>
+__device__ __forceinline__ void rops_load_tp(RowTP<NPJ>& H, RowTP<NPJ>& I, const PropArgs& a, int n, int row)
+{
+    cmat_t s = as_const(a.stream) + (size_t)(2 * (2 * n + 1)) * a.stride;
+    H.K = row_load<NPJ>(s, row);
+    H.S = row_load<NPJ>(s + a.stride, row);
+    I.K = row_load<NPJ>(s + 2 * a.stride, row);
+    I.S = row_load<NPJ>(s + 3 * a.stride, row);
+}
+template <int NPJ>
+__device__ __forceinline__ void rops_first(RowTP<NPJ>& I0, RowTP<NPJ>& H0, RowTP<NPJ>& I1, const PropArgs& a, int row)
+{
+    I0.K = row_load<NPJ>(as_const(a.stream), row);
+    I0.S = row_load<NPJ>(as_const(a.stream) + a.stride, row);
+    rops_load_tp(H0, I1, a, 0, row);
+}
+// STEP(n, integer point t_n, half point, integer point t_n+1, [load targets:] next half point, integer point t_n+2)
+#define JQ_RL_ROTATE(NSTEPS, STEP)                     \
+    for (int n_ = 0; n_ < (NSTEPS);) {                 \
+        STEP(n_, I0, H0, I1, H1, I2);                  \
+        if (++n_ >= (NSTEPS)) break;                   \
+        STEP(n_, I1, H1, I2, H2, I0);                  \
+        if (++n_ >= (NSTEPS)) break;                   \
+        STEP(n_, I2, H2, I0, H0, I1);                  \
+        ++n_;                                          \
+    }
+
+// One Stormer-Verlet state step (forward step!, src/StormerVerlet.jl:461-504), accumulate form; sw = eps*c*ws_i
+template <int NPJ, typename OPS>
+__device__ __forceinline__ void row_state(const PropArgs& a, const OPS& o, double sw, double u, double v, double& un,
                                           double& v05, double& vnew)
 {
     double A = rmv<NPJ, true>(0.0, o.Kp05, u);
@@ -196,12 +301,11 @@ __global__ __launch_bounds__(64) void k_forward_rowlane(PropArgs a)
     extern __shared__ double lds_w[];
     RowW wl;
     if constexpr (WF) wl.init(a, lds_w, lane, 64);
-    RowOps<NPJ> o, nxt;
-    o.Kn0 = row_load<NPJ>(as_const(a.stream), row);
-    o.S0 = row_load<NPJ>(as_const(a.stream) + a.stride, row);
-    rops_load_half(o, a, 0, row);
-    for (int n = 0; n < a.nsteps_chunk; ++n) {
-        rops_load_half(nxt, a, min(n + 1, a.nsteps_chunk - 1), row);   // lands during this step
+    RowTP<NPJ> I0, I1, I2, H0, H1, H2;
+    rops_first(I0, H0, I1, a, row);
+    auto step = [&](int n, const RowTP<NPJ>& Pa, const RowTP<NPJ>& Ph, const RowTP<NPJ>& Pb, RowTP<NPJ>& Lh, RowTP<NPJ>& Li) {
+        rops_load_tp(Lh, Li, a, min(n + 1, a.nsteps_chunk - 1), row);   // lands during this step
+        const RowOpsV<NPJ> o{Pa.K, Pa.S, Ph.K, Ph.S, Pb.K, Pb.S};
         double un, v05, vnew;
         leak = fma(wd, u * u, leak);
         row_state<NPJ>(a, o, sw, u, v, un, v05, vnew);
@@ -223,8 +327,8 @@ __global__ __launch_bounds__(64) void k_forward_rowlane(PropArgs a)
             a.hist_r[off] = u;
             a.hist_i[off] = -v;
         }
-        rops_advance(o, nxt);
-    }
+    };
+    JQ_RL_ROTATE(a.nsteps_chunk, step)
     st[0] = u;
     st[nw * 64] = v;
     st[(size_t)(JQ_ROWLANE_ARRAYS + JQ_MAXNC) * nw * 64] = leak;
@@ -280,12 +384,11 @@ __global__ __launch_bounds__(64) void k_backward_rowlane(PropArgs a)
     RowW wl;
     if constexpr (WF) wl.init(a, lds_c + (RESIDENT ? 0 : (size_t)2 * Nc * a.stride), lane, 64);
     const double cf0 = a.forced ? 0.5 * a.h * a.tinv : 0.0;
-    RowOps<NPJ> o, nxt;
-    o.Kn0 = row_load<NPJ>(as_const(a.stream), row);
-    o.S0 = row_load<NPJ>(as_const(a.stream) + a.stride, row);
-    rops_load_half(o, a, 0, row);
-    for (int n = 0; n < a.nsteps_chunk; ++n) {
-        rops_load_half(nxt, a, min(n + 1, a.nsteps_chunk - 1), row);   // lands during this step
+    RowTP<NPJ> I0, I1, I2, H0, H1, H2;
+    rops_first(I0, H0, I1, a, row);
+    auto step = [&](int n, const RowTP<NPJ>& Pa, const RowTP<NPJ>& Ph, const RowTP<NPJ>& Pb, RowTP<NPJ>& Lh, RowTP<NPJ>& Li) {
+        rops_load_tp(Lh, Li, a, min(n + 1, a.nsteps_chunk - 1), row);   // lands during this step
+        const RowOpsV<NPJ> o{Pa.K, Pa.S, Ph.K, Ph.S, Pb.K, Pb.S};
         double un, v05, vnew;
         row_state<NPJ>(a, o, sw, u, v, un, v05, vnew);
         // adjoint step! (src/StormerVerlet.jl:255-303) with nb = -lambda_i, see k_backward
@@ -352,8 +455,8 @@ __global__ __launch_bounds__(64) void k_backward_rowlane(PropArgs a)
         v = vnew;
         mu = G;
         nb = nbn;
-        rops_advance(o, nxt);
-    }
+    };
+    JQ_RL_ROTATE(a.nsteps_chunk, step)
     st[0] = u;
     st[nw * 64] = v;
     st[2 * nw * 64] = mu;
@@ -392,16 +495,15 @@ __global__ __launch_bounds__(128) void k_backward_rowlane2(PropArgs a)
         }
     }
     __syncthreads();
-    RowOps<NPJ> o, nxt;
-    o.Kn0 = row_load<NPJ>(as_const(a.stream), row);
-    o.S0 = row_load<NPJ>(as_const(a.stream) + a.stride, row);
-    rops_load_half(o, a, 0, row);
+    RowTP<NPJ> I0, I1, I2, H0, H1, H2;
+    rops_first(I0, H0, I1, a, row);
 
     if (role == 0) {
         // ---- state chain: one step ahead of the adjoint chain at most
         double u = st[0], v = st[nw * 64];
-        for (int n = 0; n < a.nsteps_chunk; ++n) {
-            rops_load_half(nxt, a, min(n + 1, a.nsteps_chunk - 1), row);
+        auto step = [&](int n, const RowTP<NPJ>& Pa, const RowTP<NPJ>& Ph, const RowTP<NPJ>& Pb, RowTP<NPJ>& Lh, RowTP<NPJ>& Li) {
+            rops_load_tp(Lh, Li, a, min(n + 1, a.nsteps_chunk - 1), row);
+            const RowOpsV<NPJ> o{Pa.K, Pa.S, Ph.K, Ph.S, Pb.K, Pb.S};
             double un, v05, vnew;
             row_state<NPJ>(a, o, sw, u, v, un, v05, vnew);
             double* r = rec + (n & 1) * 192;
@@ -410,9 +512,9 @@ __global__ __launch_bounds__(128) void k_backward_rowlane2(PropArgs a)
             r[128] = un;
             u = un;
             v = vnew;
-            rops_advance(o, nxt);
             __syncthreads();      // record n is published (and record n - 1 has been consumed: its slot is the next one written)
-        }
+        };
+        JQ_RL_ROTATE(a.nsteps_chunk, step)
         st[0] = u;
         st[nw * 64] = v;
         return;
@@ -437,8 +539,9 @@ __global__ __launch_bounds__(128) void k_backward_rowlane2(PropArgs a)
         for (int q = 0; q < JQ_MAXNC; ++q)
             if (q < Nc) carry[q] = -u0 * rmv<NPJ, true>(0.0, Hs[q], nb);
     }
-    for (int n = 0; n < a.nsteps_chunk; ++n) {
-        rops_load_half(nxt, a, min(n + 1, a.nsteps_chunk - 1), row);
+    auto step = [&](int n, const RowTP<NPJ>& Pa, const RowTP<NPJ>& Ph, const RowTP<NPJ>& Pb, RowTP<NPJ>& Lh, RowTP<NPJ>& Li) {
+        rops_load_tp(Lh, Li, a, min(n + 1, a.nsteps_chunk - 1), row);
+        const RowOpsV<NPJ> o{Pa.K, Pa.S, Ph.K, Ph.S, Pb.K, Pb.S};
         __syncthreads();          // the state wave has published record n
         const double* r = rec + (n & 1) * 192;
         const double u = r[0], v05 = r[64], un = r[128];
@@ -488,8 +591,8 @@ __global__ __launch_bounds__(128) void k_backward_rowlane2(PropArgs a)
         }
         mu = G;
         nb = nbn;
-        rops_advance(o, nxt);
-    }
+    };
+    JQ_RL_ROTATE(a.nsteps_chunk, step)
     st[2 * nw * 64] = mu;
     st[3 * nw * 64] = nb;
 #pragma unroll

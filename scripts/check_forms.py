@@ -7,8 +7,9 @@ usage: check_forms.py [draws per focus = 2000] [--quick]      (focus modes: gene
 Exit code 1 on the first difference, 2 when a library is missing."""
 import json, os, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-MAIN = os.path.join(ROOT, "juqbox.jl_amd", "libjuqbox_hip.so")
-DF = os.path.join(ROOT, "juqbox.jl_amd", "libjuqbox_hip_df.so")
+# (FORMS_A / FORMS_B: compare two OTHER builds with the same machinery -- A/B checks of kernel changes that must not change a bit)
+MAIN = os.environ.get("FORMS_A") or os.path.join(ROOT, "juqbox.jl_amd", "libjuqbox_hip.so")
+DF = os.environ.get("FORMS_B") or os.path.join(ROOT, "juqbox.jl_amd", "libjuqbox_hip_df.so")
 
 
 def dump(lib, focus, n, seed, path):
