@@ -57,9 +57,30 @@ __device__ __forceinline__ RowMat<NPJ> row_load_lds(const double* img, int row)
 // them (its hazard recognizer cannot see into inline asm) -- four to seven issue slots per product that a wave which is alone on its SIMD
 // pays in full (NPJ = 12: 12 FMAs + 5 s_nop; the time step of cnot2 spent 18 % of its issue slots on them).  Same FMAs, same order,
 // same accumulators: results bit-identical.  scripts/check_dpp_hazard.py verifies the final ISA as before.
-template <int NPJ, bool ZEROC>
+// (BLK = false: one asm statement per FMA behind a scheduling barrier, as before round 6 -- the two-wave backward kernel at NPJ = 16 keeps it:
+//  a block wants all 16 operand pairs of a row in VGPRs at once, and that kernel, which holds the operators of BOTH roles, then spills 175
+//  registers instead of 54: backward sweep 9.9 -> 12.2 ms per 4 000 steps)
+template <int J>
+__device__ __forceinline__ void fma_xbcast(double& y, double x, double m)
+{
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(y) : "v"(x), "v"(m), "n"(J));
+}
+template <int NPJ, int... J>
+__device__ __forceinline__ void rmv_fold(double& ya, double& yb, double x, const RowMat<NPJ>& M, std::integer_sequence<int, J...>)
+{
+    (fma_xbcast<J>((J & 1) ? yb : ya, x, M.r[J]), ...);
+}
+template <int NPJ, bool ZEROC, bool BLK = true>
 __device__ __forceinline__ double rmv(double c, const RowMat<NPJ>& M, double x)
 {
+    if constexpr (!BLK) {
+        double ya = ZEROC ? 0.0 : c, yb = 0.0;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 1");
+        __builtin_amdgcn_sched_barrier(0);
+        rmv_fold<NPJ>(ya, yb, x, M, std::make_integer_sequence<int, NPJ>{});
+        return ya + yb;
+    }
     static_assert(NPJ == 2 || NPJ == 4 || NPJ == 6 || NPJ == 8 || NPJ == 12 || NPJ == 16, "row lengths the row-lane kernels are instantiated for");
     double ya = ZEROC ? 0.0 : c, yb = 0.0;
     if constexpr (NPJ == 2)
@@ -137,7 +158,7 @@ __device__ __forceinline__ double rmv(double c, const RowMat<NPJ>& M, double x)
     return ya + yb;
 }
 // bpa + sum_{j=1..m} S^j A  (Horner form)
-template <int NPJ>
+template <int NPJ, bool BLK = true>
 __device__ __forceinline__ double row_horner(double bpa, double A, const RowMat<NPJ>& S, int m)
 {
     if (m <= 0) return bpa;
@@ -147,20 +168,20 @@ __device__ __forceinline__ double row_horner(double bpa, double A, const RowMat<
         // blocks of four, two and one products (SWAP-02 12.6 -> 12.2 ms; at NPJ = 6 the same lost 3 %: flux 19.5 -> 20.0 ms)
         int j = m - 1;
         for (; j >= 4; j -= 4) {
-            Y = rmv<NPJ, false>(A, S, Y);
-            Y = rmv<NPJ, false>(A, S, Y);
-            Y = rmv<NPJ, false>(A, S, Y);
-            Y = rmv<NPJ, false>(A, S, Y);
+            Y = rmv<NPJ, false, BLK>(A, S, Y);
+            Y = rmv<NPJ, false, BLK>(A, S, Y);
+            Y = rmv<NPJ, false, BLK>(A, S, Y);
+            Y = rmv<NPJ, false, BLK>(A, S, Y);
         }
         if (j & 2) {
-            Y = rmv<NPJ, false>(A, S, Y);
-            Y = rmv<NPJ, false>(A, S, Y);
+            Y = rmv<NPJ, false, BLK>(A, S, Y);
+            Y = rmv<NPJ, false, BLK>(A, S, Y);
         }
-        if (j & 1) Y = rmv<NPJ, false>(A, S, Y);
+        if (j & 1) Y = rmv<NPJ, false, BLK>(A, S, Y);
     } else {
-        for (int j = 1; j < m; ++j) Y = rmv<NPJ, false>(A, S, Y);
+        for (int j = 1; j < m; ++j) Y = rmv<NPJ, false, BLK>(A, S, Y);
     }
-    return rmv<NPJ, false>(bpa, S, Y);
+    return rmv<NPJ, false, BLK>(bpa, S, Y);
 }
 
 template <int NPJ>
@@ -229,25 +250,35 @@ __device__ __forceinline__ void rops_first(RowTP<NPJ>& I0, RowTP<NPJ>& H0, RowTP
         STEP(n_, I2, H2, I0, H0, I1);                  \
         ++n_;                                          \
     }
+// ... the same interface WITH the copies (two integer-point sets + one load target, as before round 6): where the third set costs more than
+// the moves -- the two-wave backward kernel at NPJ = 16 holds both roles' operators and spilled 245 registers with the rotation (measured:
+// backward sweep 9.9 -> 12.2 ms per 4 000 steps; the copy version: 54 spilled registers)
+#define JQ_RL_ADVANCE(NSTEPS, STEP)                    \
+    for (int n_ = 0; n_ < (NSTEPS); ++n_) {            \
+        STEP(n_, I0, H0, I1, H1, I2);                  \
+        I0 = I1;                                       \
+        H0 = H1;                                       \
+        I1 = I2;                                       \
+    }
 
 // One Stormer-Verlet state step (forward step!, src/StormerVerlet.jl:461-504), accumulate form; sw = eps*c*ws_i
-template <int NPJ, typename OPS>
+template <int NPJ, typename OPS, bool BLK = true>
 __device__ __forceinline__ void row_state(const PropArgs& a, const OPS& o, double sw, double u, double v, double& un,
                                           double& v05, double& vnew)
 {
-    double A = rmv<NPJ, true>(0.0, o.Kp05, u);
+    double A = rmv<NPJ, true, BLK>(0.0, o.Kp05, u);
     if (a.use_shift) A = fma(sw, u, A);
-    A = rmv<NPJ, false>(A, o.S05, v);
-    v05 = row_horner<NPJ>(v + A, A, o.S05, a.m);
-    const double vN = rmv<NPJ, false>(v05, o.S05, v05);
-    un = rmv<NPJ, false>(u, o.Kn0, v05);
+    A = rmv<NPJ, false, BLK>(A, o.S05, v);
+    v05 = row_horner<NPJ, BLK>(v + A, A, o.S05, a.m);
+    const double vN = rmv<NPJ, false, BLK>(v05, o.S05, v05);
+    un = rmv<NPJ, false, BLK>(u, o.Kn0, v05);
     if (a.use_shift) un = fma(-sw, v05, un);
-    un = rmv<NPJ, false>(un, o.S0, u);
-    A = rmv<NPJ, true>(0.0, o.Kn1, v05);
+    un = rmv<NPJ, false, BLK>(un, o.S0, u);
+    A = rmv<NPJ, true, BLK>(0.0, o.Kn1, v05);
     if (a.use_shift) A = fma(-sw, v05, A);
-    A = rmv<NPJ, false>(A, o.S1, un);
-    un = row_horner<NPJ>(un + A, A, o.S1, a.m);
-    vnew = rmv<NPJ, false>(vN, o.Kp05, un);
+    A = rmv<NPJ, false, BLK>(A, o.S1, un);
+    un = row_horner<NPJ, BLK>(un + A, A, o.S1, a.m);
+    vnew = rmv<NPJ, false, BLK>(vN, o.Kp05, un);
     if (a.use_shift) vnew = fma(sw, un, vnew);
 }
 
@@ -466,6 +497,9 @@ __global__ __launch_bounds__(64) void k_backward_rowlane(PropArgs a)
         if (q < Nc) st[(size_t)(JQ_ROWLANE_ARRAYS + q) * nw * 64] = carry[q];
 }
 
+// (Round 6: this kernel keeps the `o` / `nxt` operator structs with their copies between steps -- the copy-free rotation of the other
+//  row-lane kernels, JQ_RL_ROTATE, was measured here too: at NPJ = 12 it bought 5 % of the backward sweep, at NPJ = 16, where the kernel
+//  holds the operators of both roles in 512 registers, it tripled the spilled registers (54 -> 168 .. 245) and cost 24 %.)
 // The backward sweep on TWO waves per four columns (round 3): wave 0 re-integrates the state, wave 1 runs the adjoint step and the
 // traces of the same time step -- the adjoint step needs the state step only through u(t_{n+1}), v05 and u(t_n) of its own lanes,
 // which the state wave leaves in a double-buffered LDS record; ONE workgroup barrier per time step keeps the state wave at most
@@ -476,6 +510,7 @@ __global__ __launch_bounds__(64) void k_backward_rowlane(PropArgs a)
 template <int NPJ>
 __global__ __launch_bounds__(128) void k_backward_rowlane2(PropArgs a)
 {
+    constexpr bool BLK = (NPJ <= 12);      // (see rmv)
     const int lane = threadIdx.x & 63;
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // 0: state chain, 1: adjoint chain
     const int row = lane & 15;
@@ -495,26 +530,27 @@ __global__ __launch_bounds__(128) void k_backward_rowlane2(PropArgs a)
         }
     }
     __syncthreads();
-    RowTP<NPJ> I0, I1, I2, H0, H1, H2;
-    rops_first(I0, H0, I1, a, row);
+    RowOps<NPJ> o, nxt;
+    o.Kn0 = row_load<NPJ>(as_const(a.stream), row);
+    o.S0 = row_load<NPJ>(as_const(a.stream) + a.stride, row);
+    rops_load_half(o, a, 0, row);
 
     if (role == 0) {
         // ---- state chain: one step ahead of the adjoint chain at most
         double u = st[0], v = st[nw * 64];
-        auto step = [&](int n, const RowTP<NPJ>& Pa, const RowTP<NPJ>& Ph, const RowTP<NPJ>& Pb, RowTP<NPJ>& Lh, RowTP<NPJ>& Li) {
-            rops_load_tp(Lh, Li, a, min(n + 1, a.nsteps_chunk - 1), row);
-            const RowOpsV<NPJ> o{Pa.K, Pa.S, Ph.K, Ph.S, Pb.K, Pb.S};
+        for (int n = 0; n < a.nsteps_chunk; ++n) {
+            rops_load_half(nxt, a, min(n + 1, a.nsteps_chunk - 1), row);
             double un, v05, vnew;
-            row_state<NPJ>(a, o, sw, u, v, un, v05, vnew);
+            row_state<NPJ, RowOps<NPJ>, BLK>(a, o, sw, u, v, un, v05, vnew);
             double* r = rec + (n & 1) * 192;
             r[0] = u;
             r[64] = v05;
             r[128] = un;
             u = un;
             v = vnew;
+            rops_advance(o, nxt);
             __syncthreads();      // record n is published (and record n - 1 has been consumed: its slot is the next one written)
-        };
-        JQ_RL_ROTATE(a.nsteps_chunk, step)
+        }
         st[0] = u;
         st[nw * 64] = v;
         return;
@@ -537,36 +573,35 @@ __global__ __launch_bounds__(128) void k_backward_rowlane2(PropArgs a)
         const double u0 = st[0];      // (read before the state wave stores: it stores at the end of the chunk only)
 #pragma unroll
         for (int q = 0; q < JQ_MAXNC; ++q)
-            if (q < Nc) carry[q] = -u0 * rmv<NPJ, true>(0.0, Hs[q], nb);
+            if (q < Nc) carry[q] = -u0 * rmv<NPJ, true, BLK>(0.0, Hs[q], nb);
     }
-    auto step = [&](int n, const RowTP<NPJ>& Pa, const RowTP<NPJ>& Ph, const RowTP<NPJ>& Pb, RowTP<NPJ>& Lh, RowTP<NPJ>& Li) {
-        rops_load_tp(Lh, Li, a, min(n + 1, a.nsteps_chunk - 1), row);
-        const RowOpsV<NPJ> o{Pa.K, Pa.S, Ph.K, Ph.S, Pb.K, Pb.S};
+    for (int n = 0; n < a.nsteps_chunk; ++n) {
+        rops_load_half(nxt, a, min(n + 1, a.nsteps_chunk - 1), row);
         __syncthreads();          // the state wave has published record n
         const double* r = rec + (n & 1) * 192;
         const double u = r[0], v05 = r[64], un = r[128];
         // adjoint step! (src/StormerVerlet.jl:255-303) with nb = -lambda_i, see k_backward
-        double R = rmv<NPJ, true>(0.0, o.Kp05, nb);
+        double R = rmv<NPJ, true, BLK>(0.0, o.Kp05, nb);
         if (a.use_shift) R = fma(sw, nb, R);
-        R = rmv<NPJ, false>(R, o.S0, mu);
+        R = rmv<NPJ, false, BLK>(R, o.S0, mu);
         R = fma(cfw, u, R);
-        const double X = row_horner<NPJ>(mu + R, R, o.S0, a.m);
-        double L = rmv<NPJ, true>(0.0, o.Kn0, X);
+        const double X = row_horner<NPJ, BLK>(mu + R, R, o.S0, a.m);
+        double L = rmv<NPJ, true, BLK>(0.0, o.Kn0, X);
         if (a.use_shift) L = fma(-sw, X, L);
-        double Qv = rmv<NPJ, true>(0.0, o.Kn1, X);
+        double Qv = rmv<NPJ, true, BLK>(0.0, o.Kn1, X);
         if (a.use_shift) Qv = fma(-sw, X, Qv);
         {
-            double P = rmv<NPJ, true>(0.0, o.S05, nb);
+            double P = rmv<NPJ, true, BLK>(0.0, o.S05, nb);
             P = fma(-cfw, v05, P);
             L += P;
             Qv += P;
         }
-        Qv = rmv<NPJ, false>(Qv, o.S05, L);
-        const double nbn = row_horner<NPJ>((nb + L) + Qv, Qv, o.S05, a.m);
+        Qv = rmv<NPJ, false, BLK>(Qv, o.S05, L);
+        const double nbn = row_horner<NPJ, BLK>((nb + L) + Qv, Qv, o.S05, a.m);
         const double Bq = nb + nbn;
-        double G = rmv<NPJ, false>(X, o.Kp05, nbn);
+        double G = rmv<NPJ, false, BLK>(X, o.Kp05, nbn);
         if (a.use_shift) G = fma(sw, nbn, G);
-        G = rmv<NPJ, false>(G, o.S1, X);
+        G = rmv<NPJ, false, BLK>(G, o.S1, X);
         G = fma(cfw, un, G);
         double t5p[JQ_MAXNC] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -576,10 +611,10 @@ __global__ __launch_bounds__(128) void k_backward_rowlane2(PropArgs a)
                     Ha[q] = row_load_lds<NPJ>(lds_c + (size_t)(Nc + q) * a.stride, row);
                     Hs[q] = row_load_lds<NPJ>(lds_c + (size_t)q * a.stride, row);
                 }
-                const double HaX = rmv<NPJ, true>(0.0, Ha[q], X);
-                t5p[q] = -v05 * rmv<NPJ, true>(0.0, Ha[q], Bq) * wgt;
-                const double t2 = v05 * rmv<NPJ, true>(0.0, Hs[q], X) * wgt;
-                const double p4 = -un * rmv<NPJ, true>(0.0, Hs[q], nbn);
+                const double HaX = rmv<NPJ, true, BLK>(0.0, Ha[q], X);
+                t5p[q] = -v05 * rmv<NPJ, true, BLK>(0.0, Ha[q], Bq) * wgt;
+                const double t2 = v05 * rmv<NPJ, true, BLK>(0.0, Hs[q], X) * wgt;
+                const double p4 = -un * rmv<NPJ, true, BLK>(0.0, Hs[q], nbn);
                 const double ts = wave_sum4_rows(u * HaX * wgt, t2, un * HaX * wgt, (p4 + carry[q]) * wgt);
                 carry[q] = p4;
                 if (row == 0) trw[(size_t)n * (Nc * JQ_NTR) + q * JQ_NTR + (lane >> 4)] = ts;
@@ -591,8 +626,8 @@ __global__ __launch_bounds__(128) void k_backward_rowlane2(PropArgs a)
         }
         mu = G;
         nb = nbn;
-    };
-    JQ_RL_ROTATE(a.nsteps_chunk, step)
+        rops_advance(o, nxt);
+    }
     st[2 * nw * 64] = mu;
     st[3 * nw * 64] = nb;
 #pragma unroll
