@@ -43,8 +43,8 @@ extern "C" {
  *     the rank of a full weight matrix; full leakage weights with the Jacobi solver. */
 #define JQ_ABI_VERSION 5
 
-#define JQ_MAX_CONTROLS 16 /* control Hamiltonians per problem (Ncoupled or Nunc)                   */
-#define JQ_MAX_WRANK 16    /* largest rank of a full leakage-weight matrix (jq_update_wmat)         */
+#define JQ_MAX_CONTROLS 16 /* control Hamiltonians the fast kernels hold in registers; more: cooperative kernels (no limit)    */
+#define JQ_MAX_WRANK 16    /* rank of a full leakage-weight matrix every kernel family takes; beyond: slab / cooperative kernels */
 
 #define JQ_OK 0
 #define JQ_EINVAL -1      /* bad argument (the reference's @assert / error(...) sites)            */
@@ -232,7 +232,7 @@ int jq_set_linear_solver(jq_handle *h, int32_t solver_id, int32_t max_iter, doub
  * (traceobjgrad for Working_Arrays_M, src/evalobjgrad.jl:1042-1481) with the fixed-point solver
  * lsolver_object(solver=JACOBI_SOLVER_M, max_iter, tol) (src/linear_solvers.jl:52-55, :156-270).  For integrator 2 the
  * leakage weights are params.wmat (pass them with jq_update_wmat_diag).  Kernels: row-lane (Ntot <= 16, N <= 4), cooperative MFMA
- * (any Ntot <= 256 and batch size; both images of a step resident in LDS when they fit, else -- dense 96 x 96, Ntot > 96 -- read from
+ * (any Ntot and batch size -- run-time-size kernels beyond 256 levels; both images of a step resident in LDS when they fit, else -- dense 96 x 96, Ntot > 96 -- read from
  * HBM / L2 per product), quad-layout and cooperative-quad kernels for the 4 x 4 x n structure with N = 1, 2, 4.  N > 16 columns per
  * evaluation (round 4): the solver's per-evaluation stopping rule needs an evaluation's columns in one workgroup, so ONE cooperative
  * workgroup per evaluation walks over its 16-column parts (a correctness-first path: the parts' iterates live in HBM / L2). */
@@ -253,12 +253,13 @@ int jq_update_wmat_diag(jq_handle *h, const double *wmat_real_diag);
  * the objective through penalf2aTrap / penalf2a (full versions, :2183-2223) and penalf2imag (:2226-2228) at :700, :716-718 and the
  * adjoint forcing through the products at :862, :882-888.  wmat_imag may be NULL (= 0).
  * The device exploits the structure: W = wmat_real + i wmat_imag must be Hermitian (wmat_real symmetric, wmat_imag
- * antisymmetric -- what the constructor produces) and is eigen-decomposed on the host into rank <= JQ_MAX_WRANK terms
+ * antisymmetric -- what the constructor produces) and is eigen-decomposed on the host into its rank terms
  * lam_k f_k f_k^H; W x then costs two column dot products and two axpys per term instead of dense products.  A diagonal
  * wmat_real with wmat_imag == 0 is recognised and takes the Diagonal fast path (as jq_update_wmat_diag).
- * Stormer-Verlet integrator with the Neumann solver only (the implicit-midpoint path of the reference reads params.wmat, which is
- * always Diagonal, :90, :1155).  Errors: JQ_EUNSUPPORTED for a non-Hermitian W, rank > JQ_MAX_WRANK, or a handle set to the
- * implicit-midpoint integrator / Jacobi solver; evaluations on kernel families without the low-rank terms are refused, never
+ * Stormer-Verlet integrator (the implicit-midpoint path of the reference reads params.wmat, which is always Diagonal, :90, :1155), with
+ * the Neumann or the Jacobi solver; a rank above JQ_MAX_WRANK or the Jacobi solver route the handle to the slab / cooperative /
+ * run-time-size kernels (ABI 5; before: refused).  Errors: JQ_EUNSUPPORTED for a non-Hermitian W or a handle set to the
+ * implicit-midpoint integrator; evaluations on kernel families without the low-rank terms are refused, never
  * silently evaluated with other weights.  Parity-unpinned in the reference (no test or golden uses the branch): checked against
  * the CPU oracle, whose gradient is checked by finite differences (tests/test_dense_wmat.py).
  * Latency path (4 x 4 x n structure, at most one column quad per compute unit; round 5): a W that fits FOUR SLOTS -- real (wmat_imag
