@@ -93,6 +93,7 @@ template __global__ void k_backward_rowlane_imr2<JQ_NT>(PropArgs);      // (stat
 template __global__ void k_forward_rowlane<JQ_NT>(PropArgs);
 template __global__ void k_backward_rowlane<JQ_NT>(PropArgs);
 template __global__ void k_backward_rowlane2<JQ_NT>(PropArgs);      // (state and adjoint chain on two waves)
+template __global__ void k_backward_rowlane3<JQ_NT>(PropArgs);      // (state chain, adjoint chain and traces on three waves)
 template __global__ void k_forward_rowlane<JQ_NT, true>(PropArgs);      // (low-rank full leakage weights, jq_update_wmat)
 template __global__ void k_backward_rowlane<JQ_NT, true>(PropArgs);
 #elif JQ_VARIANT == 3

@@ -161,6 +161,9 @@ __device__ __forceinline__ double rmv(double c, const RowMat<NPJ>& M, double x)
 template <int NPJ, bool BLK = true>
 __device__ __forceinline__ double row_horner(double bpa, double A, const RowMat<NPJ>& S, int m)
 {
+#ifdef JQ_RL_FIXED_M
+    m = JQ_RL_FIXED_M;
+#endif
     if (m <= 0) return bpa;
     double Y = A;
     if constexpr (NPJ <= 4) {
@@ -232,6 +235,9 @@ __device__ __forceinline__ void rops_load_tp(RowTP<NPJ>& H, RowTP<NPJ>& I, const
     H.S = row_load<NPJ>(s + a.stride, row);
     I.K = row_load<NPJ>(s + 2 * a.stride, row);
     I.S = row_load<NPJ>(s + 3 * a.stride, row);
+    // the loads are ISSUED here, a whole step before their first use: without the barrier the scheduler, which counts registers and not the
+    // ~ 800 clk a lone wave waits for L2, sinks them to their uses whenever a step becomes one basic block (measured: forward sweep x 2)
+    __builtin_amdgcn_sched_barrier(0);
 }
 template <int NPJ>
 __device__ __forceinline__ void rops_first(RowTP<NPJ>& I0, RowTP<NPJ>& H0, RowTP<NPJ>& I1, const PropArgs& a, int row)
@@ -353,7 +359,11 @@ __global__ __launch_bounds__(64) void k_forward_rowlane(PropArgs a)
         u = un;
         v = vnew;
         leak = fma(wd, u * u + 2.0 * v05 * v05, leak);
+#ifdef JQ_RL_NOHIST
+        if (false) {
+#else
         if (a.hist_r && col < a.N && row < a.Ntot) {
+#endif
             const size_t off = (size_t)(a.step0 + n + 1) * a.Ntot * a.N + (size_t)col * a.Ntot + row;
             a.hist_r[off] = u;
             a.hist_i[off] = -v;
@@ -630,6 +640,170 @@ __global__ __launch_bounds__(128) void k_backward_rowlane2(PropArgs a)
     }
     st[2 * nw * 64] = mu;
     st[3 * nw * 64] = nb;
+#pragma unroll
+    for (int q = 0; q < JQ_MAXNC; ++q)
+        if (q < Nc) st[(size_t)(JQ_ROWLANE_ARRAYS + q) * nw * 64] = carry[q];
+}
+
+// The backward sweep on THREE waves per four columns (round 6): wave 0 re-integrates the state, wave 1 runs the adjoint step, wave 2
+// forms the traces of the gradient (adjoint_grad_calc!, src/evalobjgrad.jl:2581-2618).  In the two-wave kernel the adjoint wave carries
+// 10 + 2m products of its own chain AND the 4 Nc trace products with their five wave reductions -- none of which anything waits for.
+// A lone wave pays for every instruction it issues, so the sweep runs at the speed of its longest wave: 10 + 2m products now.
+// The waves form a pipeline one tick (= one workgroup barrier) apart: at tick k the state wave computes step k, the adjoint wave step
+// k - 1, the trace wave step k - 2.  Records in LDS: state wave -> [u(t_n), v05, u(t_n+1)] in THREE slots (read one tick later by the
+// adjoint wave and two ticks later by the trace wave), adjoint wave -> [X, nb(t_n+1)] in two slots.  Every wave passes N + 1 barriers.
+// The trace wave holds the constant images Hsym_q / Hanti_q in registers at every NPJ (it holds nothing else), so the LDS copy of the
+// images is gone.  The arithmetic of each quantity is that of k_backward_rowlane: bit-identical results.
+// Dynamic LDS: (3 x 3 + 2 x 2) x 64 doubles.
+#ifndef JQ_RL3_BLK
+#define JQ_RL3_BLK(NPJ) true
+#define JQ_RL3_ROT(NPJ) ((NPJ) <= 12)
+#endif
+#define JQ_RL3_LDS ((size_t)(3 * 3 + 2 * 2) * 64 * 8)
+#define JQ_RL_LOOP(ROT, NSTEPS, STEP)        \
+    if constexpr (ROT) {                     \
+        JQ_RL_ROTATE(NSTEPS, STEP)           \
+    } else {                                 \
+        JQ_RL_ADVANCE(NSTEPS, STEP)          \
+    }
+template <int NPJ>
+__global__ __launch_bounds__(192) void k_backward_rowlane3(PropArgs a)
+{
+    constexpr bool BLK = JQ_RL3_BLK(NPJ), ROT = JQ_RL3_ROT(NPJ);
+    const int lane = threadIdx.x & 63;
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // 0: state chain, 1: adjoint chain, 2: traces
+    const int row = lane & 15;
+    const long long w = blockIdx.x, nw = a.nslabs;
+    const long long col = 4 * w + (lane >> 4);
+    const int Nc = a.Ncoupled;
+    const int N = a.nsteps_chunk;
+    const double wd = a.tabs[row];
+    double* st = a.state + w * 64 + lane;
+    const double sw = 0.5 * a.h * a.colinfo[col] * a.tabs[16 + row];
+    extern __shared__ double lds_c[];
+    double* recS = lds_c + lane;                // [3 slots][u, v05, un][64]
+    double* recA = lds_c + 3 * 192 + lane;      // [2 slots][X, nbn][64]
+
+    if (role == 0) {
+        // ---- state chain
+        double u = st[0], v = st[nw * 64];
+        RowTP<NPJ> I0, I1, I2, H0, H1, H2;
+        rops_first(I0, H0, I1, a, row);
+        int slot = 0;
+        auto step = [&](int n, const RowTP<NPJ>& Pa, const RowTP<NPJ>& Ph, const RowTP<NPJ>& Pb, RowTP<NPJ>& Lh, RowTP<NPJ>& Li) {
+            rops_load_tp(Lh, Li, a, min(n + 1, N - 1), row);
+            const RowOpsV<NPJ> o{Pa.K, Pa.S, Ph.K, Ph.S, Pb.K, Pb.S};
+            double un, v05, vnew;
+            row_state<NPJ, RowOpsV<NPJ>, BLK>(a, o, sw, u, v, un, v05, vnew);
+            double* r = recS + slot * 192;
+            r[0] = u;
+            r[64] = v05;
+            r[128] = un;
+            slot = (slot == 2) ? 0 : slot + 1;
+            u = un;
+            v = vnew;
+            __syncthreads();      // tick n: record n is published (its slot was last read two ticks ago)
+        };
+        JQ_RL_LOOP(ROT, N, step)
+        __syncthreads();          // tick N (the trace wave's last step)
+        st[0] = u;
+        st[nw * 64] = v;
+        return;
+    }
+    if (role == 1) {
+        // ---- adjoint chain: adjoint step! (src/StormerVerlet.jl:255-303) with nb = -lambda_i, see k_backward
+        double mu = st[2 * nw * 64], nb = st[3 * nw * 64];
+        const double cfw = (a.forced ? 0.5 * a.h * a.tinv : 0.0) * wd;
+        RowTP<NPJ> I0, I1, I2, H0, H1, H2;
+        rops_first(I0, H0, I1, a, row);
+        int slot = 0;
+        auto step = [&](int n, const RowTP<NPJ>& Pa, const RowTP<NPJ>& Ph, const RowTP<NPJ>& Pb, RowTP<NPJ>& Lh, RowTP<NPJ>& Li) {
+            rops_load_tp(Lh, Li, a, min(n + 1, N - 1), row);
+            const RowOpsV<NPJ> o{Pa.K, Pa.S, Ph.K, Ph.S, Pb.K, Pb.S};
+            __syncthreads();      // tick n: the state wave has published record n
+            const double* r = recS + slot * 192;
+            slot = (slot == 2) ? 0 : slot + 1;
+            const double u = r[0], v05 = r[64], un = r[128];
+            double R = rmv<NPJ, true, BLK>(0.0, o.Kp05, nb);
+            if (a.use_shift) R = fma(sw, nb, R);
+            R = rmv<NPJ, false, BLK>(R, o.S0, mu);
+            R = fma(cfw, u, R);
+            const double X = row_horner<NPJ, BLK>(mu + R, R, o.S0, a.m);
+            double* ra = recA + (n & 1) * 128;
+            ra[0] = X;
+            double L = rmv<NPJ, true, BLK>(0.0, o.Kn0, X);
+            if (a.use_shift) L = fma(-sw, X, L);
+            double Qv = rmv<NPJ, true, BLK>(0.0, o.Kn1, X);
+            if (a.use_shift) Qv = fma(-sw, X, Qv);
+            {
+                double P = rmv<NPJ, true, BLK>(0.0, o.S05, nb);
+                P = fma(-cfw, v05, P);
+                L += P;
+                Qv += P;
+            }
+            Qv = rmv<NPJ, false, BLK>(Qv, o.S05, L);
+            const double nbn = row_horner<NPJ, BLK>((nb + L) + Qv, Qv, o.S05, a.m);
+            ra[64] = nbn;
+            double G = rmv<NPJ, false, BLK>(X, o.Kp05, nbn);
+            if (a.use_shift) G = fma(sw, nbn, G);
+            G = rmv<NPJ, false, BLK>(G, o.S1, X);
+            G = fma(cfw, un, G);
+            mu = G;
+            nb = nbn;
+        };
+        JQ_RL_LOOP(ROT, N, step)
+        __syncthreads();          // tick N: record N - 1 of this wave is published
+        st[2 * nw * 64] = mu;
+        st[3 * nw * 64] = nb;
+        return;
+    }
+    // ---- traces, weighted and summed over the wave (one tick behind the adjoint wave)
+    const double wgt = a.colinfo[4 * nw + col];
+    double nb = st[3 * nw * 64];      // (the adjoint wave stores its final nb after tick N)
+    double carry[JQ_MAXNC];
+    RowMat<NPJ> Hs[JQ_MAXNC], Ha[JQ_MAXNC];
+#pragma unroll
+    for (int q = 0; q < JQ_MAXNC; ++q) {
+        const int qq = min(q, Nc - 1);
+        carry[q] = (q < Nc) ? st[(size_t)(JQ_ROWLANE_ARRAYS + q) * nw * 64] : 0.0;
+        Hs[q] = row_load<NPJ>(as_const(a.cimg) + (size_t)qq * a.stride, row);
+        Ha[q] = row_load<NPJ>(as_const(a.cimg) + (size_t)(Nc + qq) * a.stride, row);
+    }
+    double* trw = a.traces + ((size_t)w * N) * (Nc * JQ_NTR);
+    if (a.first_chunk) {
+        const double u0 = st[0];      // (the state wave stores after tick N)
+#pragma unroll
+        for (int q = 0; q < JQ_MAXNC; ++q)
+            if (q < Nc) carry[q] = -u0 * rmv<NPJ, true, BLK>(0.0, Hs[q], nb);
+    }
+    __syncthreads();              // tick 0
+    int slot = 0;
+    for (int n = 0; n < N; ++n) {
+        __syncthreads();          // tick n + 1: the adjoint wave has published record n
+        const double* r = recS + slot * 192;
+        slot = (slot == 2) ? 0 : slot + 1;
+        const double* ra = recA + (n & 1) * 128;
+        const double u = r[0], v05 = r[64], un = r[128], X = ra[0], nbn = ra[64];
+        const double Bq = nb + nbn;
+        double t5p[JQ_MAXNC] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < JQ_MAXNC; ++q) {
+            if (q < Nc) {
+                const double HaX = rmv<NPJ, true, BLK>(0.0, Ha[q], X);
+                t5p[q] = -v05 * rmv<NPJ, true, BLK>(0.0, Ha[q], Bq) * wgt;
+                const double t2 = v05 * rmv<NPJ, true, BLK>(0.0, Hs[q], X) * wgt;
+                const double p4 = -un * rmv<NPJ, true, BLK>(0.0, Hs[q], nbn);
+                const double ts = wave_sum4_rows(u * HaX * wgt, t2, un * HaX * wgt, (p4 + carry[q]) * wgt);
+                carry[q] = p4;
+                if (row == 0) trw[(size_t)n * (Nc * JQ_NTR) + q * JQ_NTR + (lane >> 4)] = ts;
+            }
+        }
+        {
+            const double ts = wave_sum4_rows(t5p[0], t5p[1], t5p[2], t5p[3]);
+            if (row == 0 && (lane >> 4) < Nc) trw[(size_t)n * (Nc * JQ_NTR) + (lane >> 4) * JQ_NTR + 4] = ts;
+        }
+        nb = nbn;
+    }
 #pragma unroll
     for (int q = 0; q < JQ_MAXNC; ++q)
         if (q < Nc) st[(size_t)(JQ_ROWLANE_ARRAYS + q) * nw * 64] = carry[q];

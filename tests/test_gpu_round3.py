@@ -458,26 +458,32 @@ def test_dense_operators_beyond_96_levels_whose_band_equals_a_structure_code(hip
 
 
 @pytest.mark.parametrize("case", ["swap02", "cnot2-leakieq", "flux"])
-def test_rowlane_backward_sweep_on_two_waves_equals_the_one_wave_kernel(hip, case):
-    """k_backward_rowlane2 (state chain and adjoint chain of the backward sweep on two waves, one barrier per time step) against
-    k_backward_rowlane (JQ_RL_SPLIT=0): each chain's arithmetic is the same instruction sequence, so objective and gradients agree
-    to the last bits (1e-14); single evaluations and a ragged ensemble; the golden through the default (two-wave) kernel."""
+def test_rowlane_backward_sweep_on_two_and_three_waves_equals_the_one_wave_kernel(hip, case):
+    """k_backward_rowlane3 (state chain | adjoint chain | traces on three waves: the default for small batches since round 6) and
+    k_backward_rowlane2 (state chain | adjoint chain + traces, option rl_split=2) against k_backward_rowlane (rl_split=0): each
+    quantity's arithmetic is the same instruction sequence, so objective and gradients agree to the last bits; single evaluations
+    and a ragged ensemble; the golden through the default kernel."""
     jq = hip
     params, info, pcof, golden = case_inputs(case)
     res = {}
-    for tag in ("split", "one"):
-        wa = jq.Working_Arrays_HIP(params, pcof.size, options={"rl_split": 0} if tag == "one" else None)
+    for tag, opt, variant in (("three", None, 33), ("two", {"rl_split": 2}, 32), ("one", {"rl_split": 0}, 0)):
+        wa = jq.Working_Arrays_HIP(params, pcof.size, options=opt)
         o = jq.traceobjgrad(pcof, params, wa, False, True)
-        assert wa.last_timing()["kernel_family"] == 3 and wa.last_timing()["kernel_variant"] == (32 if tag == "split" else 0)
+        assert wa.last_timing()["kernel_family"] == 3 and wa.last_timing()["kernel_variant"] == variant
         nodes, weights, shift = _ensemble(params, 7, seed=3)
         jq.eval_f_g_grad(pcof, params, wa, nodes, weights, True, shift=shift)
         res[tag] = (o, params.last_infidelity, params.last_leak, params.last_infidelity_grad.copy(), params.last_leak_grad.copy())
         wa.close()
-    a, b = res["split"], res["one"]
-    assert a[0][0] == b[0][0]                                  # (the forward sweep is the same kernel)
-    for k in (1, 5, 6):
-        assert rel(a[0][k], b[0][k]) < 1e-14 or not np.any(b[0][k])
-    assert a[1] == b[1] and a[2] == b[2] and rel(a[3], b[3]) < 1e-14
+    b = res["one"]
+    for tag in ("three", "two"):
+        a = res[tag]
+        assert a[0][0] == b[0][0]                                  # (the forward sweep is the same kernel)
+        for k in (1, 5, 6):
+            assert rel(a[0][k], b[0][k]) < 1e-14 or not np.any(b[0][k])
+        assert a[1] == b[1] and a[2] == b[2] and rel(a[3], b[3]) < 1e-14
+    for k in (1, 5, 6):                                            # two and three waves: the same sums in the same order -- bit for bit
+        assert np.array_equal(res["three"][0][k], res["two"][0][k])
+    assert np.array_equal(res["three"][3], res["two"][3]) and np.array_equal(res["three"][4], res["two"][4])
 
 
 def test_plan_info_describes_the_handle(hip):
