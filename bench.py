@@ -365,22 +365,23 @@ def baseline_configs_block(jq, L, quick=False):
         if tc["kernel_family"] == 3 and chain:
             npj = int(tc["kernel_size"])
             nwaves = -(-(nq * N) // 4)
-            split = 2 * nwaves <= (4 if npj > 8 else 12) * ncu      # run_eval_impl: the backward sweep's two chains on two waves
+            variant = int(tc["kernel_variant"])                      # 33: state | adjoint | traces on three (four) waves, 32: two waves, 0: one
             prods = 8 + 2 * m                                        # dependent products of one Stormer-Verlet step
+            prods_b = {33: 10 + 2 * m, 32: 10 + 2 * m + 4 * int(pc.Ncoupled)}.get(variant, 18 + 4 * m + 4 * int(pc.Ncoupled))   # longest wave of the backward sweep
             clk_f = tc["ms_forward"] * 1e-3 * 2.4e9 / (nsteps * prods)
-            clk_b = tc["ms_backward"] * 1e-3 * 2.4e9 / (nsteps * prods * (1 if split else 2))
+            clk_b = tc["ms_backward"] * 1e-3 * 2.4e9 / (nsteps * prods_b)
             # two interleaved chains of NPJ / 2 links each (two_chains clk per instruction, NPJ instructions) + the add that joins them
             bound = npj * chain["two_chains"] + chain["one_chain"]
             entry["bound"] = {"kind": "latency of the dependent fp64 FMA chain of a lone wave (no MFMA percentage at Ntot <= 16: SURVEY.md 8(d))",
-                              "dependent_products_per_step_and_chain": prods, "row_length_NPJ": npj,
-                              "backward_chains_on_two_waves": bool(split),
+                              "dependent_products_per_step_forward": prods, "products_per_step_longest_backward_wave": prods_b, "row_length_NPJ": npj,
+                              "backward_kernel_variant": variant,
                               "clk_per_dependent_product_forward": clk_f, "clk_per_dependent_product_backward": clk_b,
                               "chain_latency_bound_clk_per_product": bound,
                               "frac_forward": bound / clk_f, "frac_backward": bound / clk_b,
                               "probe": chain,
                               "note": "bound = NPJ x (clk per link of two interleaved dependent v_fmac_f64 chains) + one dependent add; the "
-                                      "remainder is operand loads, the leak / trace reductions of a step, s_nop hazard slots and loop "
-                                      "branches (a taken branch costs a lone wave 20 .. 120 clk)"}
+                                      "remainder is the operand reads from the LDS ring, register moves in front of the accumulate-form FMAs, the leak "
+                                      "integrand, s_nop hazard slots, and in the backward sweep one workgroup barrier and the LDS hand-off per step"}
         # the same with the implicit-midpoint integrator (the default of the reference's example scripts)
         if cname != "rabi":
             pmc_ = copy.copy(pc)

@@ -108,7 +108,7 @@ struct GateHold {      // exclusive use of a device for the rest of a scope
         if (g) g->release_exclusive();
     }
 };
-#define JQ_RL_ROOM 12          // waves per compute unit the split row-lane kernels may ask for (NPJ <= 8)
+#define JQ_RL_ROOM 12          // waves per compute unit the two-wave implicit-midpoint row-lane kernel may ask for (NPJ <= 8)
 #define JQ_RL_ROOM_WIDE 4      // ... NPJ = 12, 16
 static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamples, const double* eps, const double* wgt,
                          const double* shift, bool adjoint, double* hist_r, double* hist_i, EvalOut* out, double* d_packed);
@@ -389,15 +389,13 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     // option rl_split=0: one wave (tests: the two variants must agree bit for bit)
     // (both integrators; while the doubled wave count still finds idle issue slots: measured in round 3, HISTORY.md --
     //  NPJ <= 8: up to three waves per SIMD, NPJ = 12, 16 (constant images in LDS, 24 .. 32 operand registers per image row): one)
-    // ... Stormer-Verlet since round 6: three waves (state | adjoint | traces, k_backward_rowlane3) or one -- measured over the ensemble
-    // size (scripts/time_rl_split.py, profiles/r06_rowlane3.txt): three waves beat one at every size the row-lane kernels serve when
-    // NPJ <= 8 (162 registers: three workgroups per compute unit and round), and up to two rounds of the chip at NPJ = 12, 16 (304 .. 350
-    // registers: one wave per SIMD); two waves never beat three.  Option rl_split: 0 = one wave, 1 = by these rules, 2 / 3 = two / three
-    // waves at every batch size (tests, measurements)
+    // ... Stormer-Verlet since round 6: three or four waves (state | adjoint | traces, two trace waves for two or more controls:
+    // k_backward_rowlane3) at every batch size the row-lane kernels serve -- measured over the ensemble size (scripts/time_rl_split.py,
+    // profiles/r06_rowlane3.txt): they beat one wave from 1 to 2 048 samples at NPJ = 4, 6 and 12; two waves never beat three.
+    // Option rl_split: 0 = one wave, 1 = by these rules, 2 / 3 = two / three waves at every batch size (tests, measurements)
     const int rl_want = (int)h->opt.get(O_RL_SPLIT);
-    const long long rl_room = (long long)(h->rl_npj > 8 ? JQ_RL_ROOM_WIDE : JQ_RL_ROOM) * h->num_cu;
     const bool rl_sv = rl && !imr_rl;
-    bool rl_split = rl && (rl_want >= 2 || (rl_sv ? (h->rl_npj <= 8 || 3 * nwaves_rl <= 2 * rl_room) : 2 * nwaves_rl <= rl_room));
+    bool rl_split = rl && (rl_want >= 2 || rl_sv || 2 * nwaves_rl <= (long long)(h->rl_npj > 8 ? JQ_RL_ROOM_WIDE : JQ_RL_ROOM) * h->num_cu);
     if (rl_want == 0) rl_split = false;
     if (wfull) rl_split = false;      // (the one-wave backward kernel carries the low-rank terms)
     const bool rl_split3 = rl_split && rl_sv && rl_want != 2;
@@ -408,7 +406,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
              : imr_quad ? select_quad_imr_kernels(h, &kfwd, &kbwd)
              : imr_coop ? (imr_parts ? select_coop_imr_parts_kernels(h, imr_hbm, &kfwd, &kbwd) : select_coop_imr_kernels(h, imr_hbm, &kfwd, &kbwd))
              : imr_rl ? select_rowlane_imr_kernels(h, rl_split, &kfwd, &kbwd)
-             : rl ? select_rowlane_kernels(h, rl_split3 ? 3 : rl_split ? 2 : 1, &kfwd, &kbwd)
+             : rl ? select_rowlane_kernels(h, rl_split3 ? 3 : rl_split ? 2 : 1, hist_r != nullptr, &kfwd, &kbwd)
              : lane ? select_lane_kernels(h, &kfwd, &kbwd, &klinit, &klterm)
                   : cq ? select_cq_kernels(h, cq_fwd2, cq_nr, wfull, &kfwd, &kbwd)
                   : coop ? select_coop_kernels(h, &kfwd, &kbwd) : quad ? (wfull ? select_quad_w_kernels(h, &kfwd, &kbwd) : select_quad_kernels(h, spw, &kfwd, &kbwd)) : select_kernels(h, &kfwd, &kbwd);
@@ -527,9 +525,9 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
                              : batch < 0 ? (size_t)(2 * JQ_WIN_TPS + 2 * h->NcK) * stride * 8
                                          : (size_t)2 * stride * 8;
     const size_t lds_cq = lds_stage + (size_t)32 * h->NT * 8 + (size_t)6 * (h->NT + 2) * 64 * 8 + (size_t)std::max(2, h->NcK + (h->NcK + 1) / 2) * h->NT * 64 * 8;      // tables, x exchange, trace hand-off / wg-sum scratch (one region)
-    const size_t lds_fwd = huge ? 0 : rl ? (wfull ? (size_t)JQ_RL_WTAB * 8 : 0) : lane ? 0 : (cq || imr_cq) ? lds_cq : imr_coop ? coop_imr_lds_bytes(h->NT, imr_hbm ? 0 : stride)
+    const size_t lds_fwd = huge ? 0 : (rl && !imr_rl) ? (wfull ? (size_t)JQ_RL_WTAB * 8 : 0) + JQ_RL_RING_BYTES(h->rl_npj) /* operator ring of the forward sweep */ : rl ? 0 : lane ? 0 : (cq || imr_cq) ? lds_cq : imr_coop ? coop_imr_lds_bytes(h->NT, imr_hbm ? 0 : stride)
                                            : lds_stage + (size_t)32 * h->NT * 8 + (coop ? (size_t)2 * h->KT * 64 * 8 + (size_t)16 * h->NT * 8 + coop_w_bytes : 0);      // (+ the Jacobi solver's column norms [NT][16], the low-rank weights' dot exchange)
-    const size_t lds_bwd = huge ? 0 : qsplit ? qsplit_lds(h, qs_qw) : rl_split3 ? JQ_RL3_LDS : rl ? (h->rl_npj > 8 ? (size_t)2 * h->NcK * h->rl_stride * 8 : 0) + (rl_split ? (size_t)2 * 3 * 64 * 8 : 0) /* records: 3 values per lane and slot, implicit midpoint 2 */ + (wfull ? (size_t)JQ_RL_WTAB * 8 : 0) /* low-rank weight table */ : lane ? 0 : imr_cq2 ? cq_imr2_lds(h, lds_stage) : (coop || cq || imr_cq) ? lds_fwd
+    const size_t lds_bwd = huge ? 0 : qsplit ? qsplit_lds(h, qs_qw) : rl_split3 ? JQ_RL3_LDS(h->rl_npj) : rl ? (h->rl_npj > 8 ? (size_t)2 * h->NcK * h->rl_stride * 8 : 0) + (rl_split ? (size_t)2 * 3 * 64 * 8 : 0) /* records: 3 values per lane and slot, implicit midpoint 2 */ + (wfull ? (size_t)JQ_RL_WTAB * 8 : 0) /* low-rank weight table */ : lane ? 0 : imr_cq2 ? cq_imr2_lds(h, lds_stage) : (coop || cq || imr_cq) ? lds_fwd
                                 : imr_quad ? lds_fwd + (size_t)JQ_MAXNC * nthreads * 8 + (size_t)(nthreads / 64) * h->NT * 64 * 8
                                 : quad ? lds_stage + (size_t)bwd_lds_tail(h->NT, h->NcK, nthreads / 64, (long long)h->NT * 64)   // (a 16-row block per register)
                                 : lds_stage + (size_t)bwd_lds_tail(h->NT, h->NcK, JQ_WAVES, h->park_lds ? (long long)h->KT * 64 : 0);
@@ -713,7 +711,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
                 else if (cq3)
                     hipLaunchKernelGGL(kbwd, dim3((unsigned)(cq_nr * nq_pad)), dim3(nthreads + 128), lds_bwd + (wlr_lds_bwd >= 0 ? wlr_bytes : 0), s, a);      // (three / two workgroups per quad: NT block waves + two staging waves each)
                 else
-                hipLaunchKernelGGL(kbwd, dim3(nblocks), dim3(rl_split3 ? 3 * nthreads : (cq || rl_split) ? 2 * nthreads : imr_cq2 ? 2 * (nthreads + 128) : imr_cq ? nthreads + 128 : nthreads), lds_bwd + (wlr_lds_bwd >= 0 ? wlr_bytes : 0) + (wsc_lds_bwd >= 0 ? wsc_bytes : 0) + jac_bytes, s, a);      // (cooperative quad: state and adjoint chain on separate waves)
+                hipLaunchKernelGGL(kbwd, dim3(nblocks), dim3(rl_split3 ? (a.Ncoupled >= 2 ? 4 : 3) * nthreads /* state | adjoint | traces (two waves for two or more controls) */ : (cq || rl_split) ? 2 * nthreads : imr_cq2 ? 2 * (nthreads + 128) : imr_cq ? nthreads + 128 : nthreads), lds_bwd + (wlr_lds_bwd >= 0 ? wlr_bytes : 0) + (wsc_lds_bwd >= 0 ? wsc_bytes : 0) + jac_bytes, s, a);      // (cooperative quad: state and adjoint chain on separate waves)
                 HIPCHK(h, hipEventRecord(h->ev[evi++], s));
                 if (cq3 && sweep == 0 && n0 == 0) {
                     // the first launch of the split says whether its workgroups were resident together: read the error word now instead

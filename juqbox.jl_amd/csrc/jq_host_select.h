@@ -359,18 +359,19 @@ static int select_lane_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* 
 #define JQ_DECLR(npj)                                                     \
     extern template __global__ void k_forward_rowlane<npj>(PropArgs);     \
     extern template __global__ void k_backward_rowlane<npj>(PropArgs);    \
-    extern template __global__ void k_forward_rowlane<npj, true>(PropArgs);     \
+    extern template __global__ void k_forward_rowlane<npj, false, true>(PropArgs);     \
+    extern template __global__ void k_forward_rowlane<npj, true, true>(PropArgs);     \
     extern template __global__ void k_backward_rowlane<npj, true>(PropArgs);    \
     extern template __global__ void k_backward_rowlane2<npj>(PropArgs);   \
     extern template __global__ void k_backward_rowlane3<npj>(PropArgs);
 JQ_FOR_EACH_ROWLANE(JQ_DECLR)
 #undef JQ_DECLR
 
-static int select_rowlane_kernels(jq_handle* h, int split, prop_kernel_t* fwd, prop_kernel_t* bwd)      // split: waves of the backward sweep (1, 2, 3)
+static int select_rowlane_kernels(jq_handle* h, int split, bool hist, prop_kernel_t* fwd, prop_kernel_t* bwd)      // split: waves of the backward sweep (1, 2, 3)
 {
 #define JQ_PICKR(npj)                                                          \
     if (h->rl_npj == npj) {                                                    \
-        *fwd = h->wrank > 0 ? k_forward_rowlane<npj, true> : k_forward_rowlane<npj>;                                         \
+        *fwd = h->wrank > 0 ? k_forward_rowlane<npj, true, true> : hist ? k_forward_rowlane<npj, false, true> : k_forward_rowlane<npj>;     \
         *bwd = h->wrank > 0 ? k_backward_rowlane<npj, true> : split == 3 ? k_backward_rowlane3<npj> : split == 2 ? k_backward_rowlane2<npj> : k_backward_rowlane<npj>;     \
         return JQ_OK;                                                          \
     }

@@ -91,10 +91,11 @@ template __global__ void k_backward_rowlane_imr2<JQ_NT>(PropArgs);      // (stat
 #elif JQ_VARIANT == 4
 #include "jq_rowlane_kernels.h"
 template __global__ void k_forward_rowlane<JQ_NT>(PropArgs);
+template __global__ void k_forward_rowlane<JQ_NT, false, true>(PropArgs);     // (state history: traceobj_verbose)
 template __global__ void k_backward_rowlane<JQ_NT>(PropArgs);
 template __global__ void k_backward_rowlane2<JQ_NT>(PropArgs);      // (state and adjoint chain on two waves)
 template __global__ void k_backward_rowlane3<JQ_NT>(PropArgs);      // (state chain, adjoint chain and traces on three waves)
-template __global__ void k_forward_rowlane<JQ_NT, true>(PropArgs);      // (low-rank full leakage weights, jq_update_wmat)
+template __global__ void k_forward_rowlane<JQ_NT, true, true>(PropArgs);      // (low-rank full leakage weights, jq_update_wmat; history if asked for)
 template __global__ void k_backward_rowlane<JQ_NT, true>(PropArgs);
 #elif JQ_VARIANT == 3
 #include "jq_lane_kernels.h"

@@ -57,6 +57,9 @@ __device__ __forceinline__ RowMat<NPJ> row_load_lds(const double* img, int row)
 // them (its hazard recognizer cannot see into inline asm) -- four to seven issue slots per product that a wave which is alone on its SIMD
 // pays in full (NPJ = 12: 12 FMAs + 5 s_nop; the time step of cnot2 spent 18 % of its issue slots on them).  Same FMAs, same order,
 // same accumulators: results bit-identical.  scripts/check_dpp_hazard.py verifies the final ISA as before.
+// (The accumulators are early-clobber operands: where c and x are the same value at its last use -- the first term of a two-term Horner
+//  recurrence -- the compiler would otherwise give ya and x ONE register, and the second FMA would broadcast the first one's result;
+//  the hazard check found it.)
 // (BLK = false: one asm statement per FMA behind a scheduling barrier, as before round 6 -- the two-wave backward kernel at NPJ = 16 keeps it:
 //  a block wants all 16 operand pairs of a row in VGPRs at once, and that kernel, which holds the operators of BOTH roles, then spills 175
 //  registers instead of 54: backward sweep 9.9 -> 12.2 ms per 4 000 steps)
@@ -87,7 +90,7 @@ __device__ __forceinline__ double rmv(double c, const RowMat<NPJ>& M, double x)
         asm("s_nop 1\n\t"
             "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
             "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf"
-            : "+v"(ya), "+v"(yb)
+            : "+&v"(ya), "+&v"(yb)
             : "v"(x), "v"(M.r[0]), "v"(M.r[1]));
     if constexpr (NPJ == 4)
         asm("s_nop 1\n\t"
@@ -95,7 +98,7 @@ __device__ __forceinline__ double rmv(double c, const RowMat<NPJ>& M, double x)
             "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
             "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
             "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf"
-            : "+v"(ya), "+v"(yb)
+            : "+&v"(ya), "+&v"(yb)
             : "v"(x), "v"(M.r[0]), "v"(M.r[1]), "v"(M.r[2]), "v"(M.r[3]));
     if constexpr (NPJ == 6)
         asm("s_nop 1\n\t"
@@ -105,7 +108,7 @@ __device__ __forceinline__ double rmv(double c, const RowMat<NPJ>& M, double x)
             "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
             "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
             "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf"
-            : "+v"(ya), "+v"(yb)
+            : "+&v"(ya), "+&v"(yb)
             : "v"(x), "v"(M.r[0]), "v"(M.r[1]), "v"(M.r[2]), "v"(M.r[3]), "v"(M.r[4]), "v"(M.r[5]));
     if constexpr (NPJ == 8)
         asm("s_nop 1\n\t"
@@ -117,7 +120,7 @@ __device__ __forceinline__ double rmv(double c, const RowMat<NPJ>& M, double x)
             "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
             "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
             "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf"
-            : "+v"(ya), "+v"(yb)
+            : "+&v"(ya), "+&v"(yb)
             : "v"(x), "v"(M.r[0]), "v"(M.r[1]), "v"(M.r[2]), "v"(M.r[3]), "v"(M.r[4]), "v"(M.r[5]), "v"(M.r[6]), "v"(M.r[7]));
     if constexpr (NPJ == 12)
         asm("s_nop 1\n\t"
@@ -133,7 +136,7 @@ __device__ __forceinline__ double rmv(double c, const RowMat<NPJ>& M, double x)
             "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
             "v_fmac_f64_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
             "v_fmac_f64_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf"
-            : "+v"(ya), "+v"(yb)
+            : "+&v"(ya), "+&v"(yb)
             : "v"(x), "v"(M.r[0]), "v"(M.r[1]), "v"(M.r[2]), "v"(M.r[3]), "v"(M.r[4]), "v"(M.r[5]), "v"(M.r[6]), "v"(M.r[7]), "v"(M.r[8]), "v"(M.r[9]), "v"(M.r[10]), "v"(M.r[11]));
     if constexpr (NPJ == 16)
         asm("s_nop 1\n\t"
@@ -153,7 +156,7 @@ __device__ __forceinline__ double rmv(double c, const RowMat<NPJ>& M, double x)
             "v_fmac_f64_dpp %1, %2, %16 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
             "v_fmac_f64_dpp %0, %2, %17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
             "v_fmac_f64_dpp %1, %2, %18 row_newbcast:15 row_mask:0xf bank_mask:0xf"
-            : "+v"(ya), "+v"(yb)
+            : "+&v"(ya), "+&v"(yb)
             : "v"(x), "v"(M.r[0]), "v"(M.r[1]), "v"(M.r[2]), "v"(M.r[3]), "v"(M.r[4]), "v"(M.r[5]), "v"(M.r[6]), "v"(M.r[7]), "v"(M.r[8]), "v"(M.r[9]), "v"(M.r[10]), "v"(M.r[11]), "v"(M.r[12]), "v"(M.r[13]), "v"(M.r[14]), "v"(M.r[15]));
     return ya + yb;
 }
@@ -161,9 +164,6 @@ __device__ __forceinline__ double rmv(double c, const RowMat<NPJ>& M, double x)
 template <int NPJ, bool BLK = true>
 __device__ __forceinline__ double row_horner(double bpa, double A, const RowMat<NPJ>& S, int m)
 {
-#ifdef JQ_RL_FIXED_M
-    m = JQ_RL_FIXED_M;
-#endif
     if (m <= 0) return bpa;
     double Y = A;
     if constexpr (NPJ <= 4) {
@@ -186,6 +186,37 @@ __device__ __forceinline__ double row_horner(double bpa, double A, const RowMat<
     }
     return rmv<NPJ, false, BLK>(bpa, S, Y);
 }
+
+// ... with the number of terms known at compile time (MT = m; MT = 0: the run-time loop above): the same products in the same order,
+// no loop branches -- a taken branch costs a lone wave 20 .. 120 clk (probes/lone_wave_probe.hip), and there were 2 (m - 1) + 2 per step
+template <int NPJ, bool BLK, int MT>
+__device__ __forceinline__ double row_horner_m(double bpa, double A, const RowMat<NPJ>& S, int m)
+{
+    if constexpr (MT == 0) {
+        return row_horner<NPJ, BLK>(bpa, A, S, m);
+    } else {
+        double Y = A;
+#pragma unroll
+        for (int j = 1; j < MT; ++j) Y = rmv<NPJ, false, BLK>(A, S, Y);
+        return rmv<NPJ, false, BLK>(bpa, S, Y);
+    }
+}
+template <int MT>
+struct RlTerms {
+    static constexpr int value = MT;
+};
+// RUN(RlTerms<m>{}) for the m the kernels are specialised for, RUN(RlTerms<0>{}) otherwise
+#define JQ_RL_DISPATCH_TERMS(m, RUN)             \
+    switch (m) {                                 \
+    case 2: RUN(RlTerms<2>{}); break;            \
+    case 3: RUN(RlTerms<3>{}); break;            \
+    case 4: RUN(RlTerms<4>{}); break;            \
+    case 5: RUN(RlTerms<5>{}); break;            \
+    case 6: RUN(RlTerms<6>{}); break;            \
+    case 7: RUN(RlTerms<7>{}); break;            \
+    case 8: RUN(RlTerms<8>{}); break;            \
+    default: RUN(RlTerms<0>{}); break;           \
+    }
 
 template <int NPJ>
 struct RowOps {
@@ -268,25 +299,128 @@ __device__ __forceinline__ void rops_first(RowTP<NPJ>& I0, RowTP<NPJ>& H0, RowTP
     }
 
 // One Stormer-Verlet state step (forward step!, src/StormerVerlet.jl:461-504), accumulate form; sw = eps*c*ws_i
-template <int NPJ, typename OPS, bool BLK = true>
+// (MT: Neumann terms at compile time, row_horner_m.  SHF: the caller passes sw = 0 for "no shift" and the shift FMAs are unconditional --
+//  a + 0 x = a: no selects in the step)
+template <int NPJ, typename OPS, bool BLK = true, int MT = 0, bool SHF = false>
 __device__ __forceinline__ void row_state(const PropArgs& a, const OPS& o, double sw, double u, double v, double& un,
                                           double& v05, double& vnew)
 {
     double A = rmv<NPJ, true, BLK>(0.0, o.Kp05, u);
-    if (a.use_shift) A = fma(sw, u, A);
+    if (SHF || a.use_shift) A = fma(sw, u, A);
     A = rmv<NPJ, false, BLK>(A, o.S05, v);
-    v05 = row_horner<NPJ, BLK>(v + A, A, o.S05, a.m);
+    v05 = row_horner_m<NPJ, BLK, MT>(v + A, A, o.S05, a.m);
     const double vN = rmv<NPJ, false, BLK>(v05, o.S05, v05);
     un = rmv<NPJ, false, BLK>(u, o.Kn0, v05);
-    if (a.use_shift) un = fma(-sw, v05, un);
+    if (SHF || a.use_shift) un = fma(-sw, v05, un);
     un = rmv<NPJ, false, BLK>(un, o.S0, u);
     A = rmv<NPJ, true, BLK>(0.0, o.Kn1, v05);
-    if (a.use_shift) A = fma(-sw, v05, A);
+    if (SHF || a.use_shift) A = fma(-sw, v05, A);
     A = rmv<NPJ, false, BLK>(A, o.S1, un);
-    un = row_horner<NPJ, BLK>(un + A, A, o.S1, a.m);
+    un = row_horner_m<NPJ, BLK, MT>(un + A, A, o.S1, a.m);
     vnew = rmv<NPJ, false, BLK>(vN, o.Kp05, un);
-    if (a.use_shift) vnew = fma(sw, un, vnew);
+    if (SHF || a.use_shift) vnew = fma(sw, un, vnew);
 }
+
+// Round 6: the operator rows of the time steps through a RING IN LDS that the wave feeds itself by global->LDS DMA, JQ_RL_AHEAD steps
+// ahead.  Measured (scripts/time_small.py with the stream pointer frozen): the K / S images of a sweep (27 MB at cnot1) come from the
+// Infinity Cache / HBM at ~ 600 ns per access -- more than a time step of a lone wave (~ 400 ns of instructions) -- and the register
+// prefetch of the rotation above reaches one step ahead: every step waited for its rows.  Deeper register prefetch costs 4 NPJ
+// registers per step of distance (no room at NPJ = 12, 16); the DMA costs NPJ / 2 instructions per step, no registers, and the rows
+// a product needs are read from LDS (~ 100 clk) right in the step that uses them.
+//   group g = the four images [K, S](t_g+1/2), [K, S](t_g+1) of the tile stream = NPJ / 2 pieces of 1 KiB; slot = g mod R, R = AHEAD + 2:
+//   step n reads groups n - 1 (images 2, 3: the integer point t_n) and n while groups n + 1 .. n + AHEAD are in flight or landed.
+//   Group -1 is the first time point of the stream (images 0, 1), placed as images 2, 3 of slot R - 1.
+// The DMA instructions are asm statements (the compiler would otherwise wait for ALL of them in front of every LDS read); the wave waits
+// with s_waitcnt vmcnt((AHEAD - 1) P) at the top of a step -- its loads return in order -- and with vmcnt(0) before it ends (a DMA
+// that lands after the workgroup has gone would write into another workgroup's LDS).
+// (NPJ = 12, 16: a step takes longer than the latency and a slot is 6 .. 8 KiB -- two steps ahead)
+#define JQ_RL_AHEAD(npj) ((npj) <= 8 ? 3 : 2)
+#define JQ_RL_RING_BYTES(npj) ((size_t)(JQ_RL_AHEAD(npj) + 2) * 4 * 128 * (npj))
+template <int NPJ, bool ORDERED = true>
+struct RlRing {
+    static constexpr int D = JQ_RL_AHEAD(NPJ), R = D + 2, P = NPJ / 2, IMG = 16 * NPJ, GROUP_B = 4 * 128 * NPJ;
+    static constexpr size_t BYTES = (size_t)R * GROUP_B;
+    const double* lds;      // slot 0
+    unsigned lds0;          // ... as an LDS address (M0 of the DMA)
+    const char* src;        // the stream
+    unsigned lo16;          // 16 x lane
+    int N;
+    int row;
+    int sp, sc;             // slots of groups n - 1 and n
+    int si;                 // slot the next issue goes to
+    int gi;                 // group of the next issue (not clamped)
+
+    __device__ __forceinline__ void dma(unsigned dst, const char* s) const
+    {
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(lo16), "s"(s) : "memory");
+    }
+    __device__ __forceinline__ void issue()
+    {
+        const int g = min(gi, N - 1);      // (past the end: the last group again -- into a slot nobody reads any more)
+        const char* s = src + (size_t)(2 * (2 * g + 1)) * (IMG * 8);
+        const unsigned dst = lds0 + (unsigned)si * GROUP_B;
+#pragma unroll
+        for (int p = 0; p < P; ++p) dma(dst + p * 1024u, s + p * 1024);
+        ++gi;
+        si = (si == R - 1) ? 0 : si + 1;
+    }
+    __device__ __forceinline__ void init(const PropArgs& a, double* ring, int lane, int row_)
+    {
+        lds = ring;
+        lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)ring;
+        src = (const char*)a.stream;
+        lo16 = 16u * lane;
+        N = a.nsteps_chunk;
+        row = row_;
+        // group -1: the two images of t_0 -> images 2, 3 of slot R - 1 (256 NPJ bytes = 16 NPJ lanes of 16 bytes)
+        for (int b = 0; b < 256 * NPJ; b += 1024)
+            if (b + (int)lo16 < 256 * NPJ) dma(lds0 + (unsigned)(R - 1) * GROUP_B + 2u * 128 * NPJ + b, src + b);
+        sp = R - 1;
+        sc = 0;
+        si = 0;
+        gi = 0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) issue();
+    }
+    // top of step n: group n has landed; the DMA of group n + AHEAD goes out
+    __device__ __forceinline__ void begin_step()
+    {
+        if constexpr (ORDERED)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * P) : "memory");
+        else      // (other memory traffic of the wave -- the state history -- completes out of order with the DMA)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        issue();
+    }
+    __device__ __forceinline__ void end_step()
+    {
+        sp = sc;
+        sc = (sc == R - 1) ? 0 : sc + 1;
+    }
+    __device__ __forceinline__ void drain() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    __device__ __forceinline__ RowMat<NPJ> rowmat(int slot, int img) const
+    {
+        typedef double d2_t __attribute__((ext_vector_type(2)));
+        const d2_t* p = (const d2_t*)(lds + (size_t)slot * (4 * IMG) + img * IMG + row * NPJ);
+        RowMat<NPJ> m;
+#pragma unroll
+        for (int k = 0; k < NPJ / 2; ++k) {
+            const d2_t q = p[k];
+            m.r[2 * k] = q[0];
+            m.r[2 * k + 1] = q[1];
+        }
+        return m;
+    }
+};
+// the operators of the current step out of the ring
+template <int NPJ>
+struct RowOpsL {
+    RowMat<NPJ> Kn0, S0, Kp05, S05, Kn1, S1;
+    template <bool O>
+    __device__ __forceinline__ RowOpsL(const RlRing<NPJ, O>& r)
+        : Kn0(r.rowmat(r.sp, 2)), S0(r.rowmat(r.sp, 3)), Kp05(r.rowmat(r.sc, 0)), S05(r.rowmat(r.sc, 1)), Kn1(r.rowmat(r.sc, 2)), S1(r.rowmat(r.sc, 3))
+    {
+    }
+};
 
 // ---------------------------------------------------------------------------------------------
 // Low-rank full leakage weights (PropArgs::wlr; jq_kernels.h WLow) in the row-lane layout: the 16 lanes of a DPP row are the rows
@@ -323,7 +457,7 @@ struct RowW {
 
 // Forward sweep of one chunk; a.nslabs = number of waves (4 columns each), grid = a.nslabs, block = 64.
 // (WF: low-rank full leakage weights compiled in -- separate instantiations, the Diagonal fast path is untouched)
-template <int NPJ, bool WF = false>
+template <int NPJ, bool WF = false, bool HIST = false>
 __global__ __launch_bounds__(64) void k_forward_rowlane(PropArgs a)
 {
     const int lane = threadIdx.x;
@@ -334,18 +468,20 @@ __global__ __launch_bounds__(64) void k_forward_rowlane(PropArgs a)
     double* st = a.state + w * 64 + lane;
     double u = st[0], v = st[nw * 64];
     double leak = st[(size_t)(JQ_ROWLANE_ARRAYS + JQ_MAXNC) * nw * 64];
-    const double sw = 0.5 * a.h * a.colinfo[col] * a.tabs[16 + row];
+    const double sw = a.use_shift ? 0.5 * a.h * a.colinfo[col] * a.tabs[16 + row] : 0.0;
     extern __shared__ double lds_w[];
     RowW wl;
     if constexpr (WF) wl.init(a, lds_w, lane, 64);
-    RowTP<NPJ> I0, I1, I2, H0, H1, H2;
-    rops_first(I0, H0, I1, a, row);
-    auto step = [&](int n, const RowTP<NPJ>& Pa, const RowTP<NPJ>& Ph, const RowTP<NPJ>& Pb, RowTP<NPJ>& Lh, RowTP<NPJ>& Li) {
-        rops_load_tp(Lh, Li, a, min(n + 1, a.nsteps_chunk - 1), row);   // lands during this step
-        const RowOpsV<NPJ> o{Pa.K, Pa.S, Ph.K, Ph.S, Pb.K, Pb.S};
+    RlRing<NPJ, !HIST> ring;
+    ring.init(a, lds_w + (WF ? JQ_RL_WTAB : 0), lane, row);
+    auto sweep = [&](auto terms) {
+    constexpr int MT = decltype(terms)::value;
+    for (int n = 0; n < a.nsteps_chunk; ++n) {
+        ring.begin_step();
+        const RowOpsL<NPJ> o(ring);
         double un, v05, vnew;
         leak = fma(wd, u * u, leak);
-        row_state<NPJ>(a, o, sw, u, v, un, v05, vnew);
+        row_state<NPJ, RowOpsL<NPJ>, true, MT, true>(a, o, sw, u, v, un, v05, vnew);
         if constexpr (WF) {   // full weights: tr(vr' Wr vr) at t_n and t_n+1, 2 tr(vi05' Wr vi05), -2 tr(vi05' Wi vr(t_n)) (:700, :716-718)
             double lk = 0.0;
             for (int k = 0; k < wl.r; ++k) {
@@ -359,17 +495,17 @@ __global__ __launch_bounds__(64) void k_forward_rowlane(PropArgs a)
         u = un;
         v = vnew;
         leak = fma(wd, u * u + 2.0 * v05 * v05, leak);
-#ifdef JQ_RL_NOHIST
-        if (false) {
-#else
-        if (a.hist_r && col < a.N && row < a.Ntot) {
-#endif
-            const size_t off = (size_t)(a.step0 + n + 1) * a.Ntot * a.N + (size_t)col * a.Ntot + row;
-            a.hist_r[off] = u;
-            a.hist_i[off] = -v;
-        }
+        if constexpr (HIST)
+            if (a.hist_r && col < a.N && row < a.Ntot) {
+                const size_t off = (size_t)(a.step0 + n + 1) * a.Ntot * a.N + (size_t)col * a.Ntot + row;
+                a.hist_r[off] = u;
+                a.hist_i[off] = -v;
+            }
+        ring.end_step();
+    }
     };
-    JQ_RL_ROTATE(a.nsteps_chunk, step)
+    JQ_RL_DISPATCH_TERMS(a.m, sweep)
+    ring.drain();
     st[0] = u;
     st[nw * 64] = v;
     st[(size_t)(JQ_ROWLANE_ARRAYS + JQ_MAXNC) * nw * 64] = leak;
@@ -654,22 +790,13 @@ __global__ __launch_bounds__(128) void k_backward_rowlane2(PropArgs a)
 // adjoint wave and two ticks later by the trace wave), adjoint wave -> [X, nb(t_n+1)] in two slots.  Every wave passes N + 1 barriers.
 // The trace wave holds the constant images Hsym_q / Hanti_q in registers at every NPJ (it holds nothing else), so the LDS copy of the
 // images is gone.  The arithmetic of each quantity is that of k_backward_rowlane: bit-identical results.
-// Dynamic LDS: (3 x 3 + 2 x 2) x 64 doubles.
-#ifndef JQ_RL3_BLK
-#define JQ_RL3_BLK(NPJ) true
-#define JQ_RL3_ROT(NPJ) ((NPJ) <= 12)
-#endif
-#define JQ_RL3_LDS ((size_t)(3 * 3 + 2 * 2) * 64 * 8)
-#define JQ_RL_LOOP(ROT, NSTEPS, STEP)        \
-    if constexpr (ROT) {                     \
-        JQ_RL_ROTATE(NSTEPS, STEP)           \
-    } else {                                 \
-        JQ_RL_ADVANCE(NSTEPS, STEP)          \
-    }
+// State and adjoint wave read the operator rows through a ring in LDS each (RlRing: fed by the wave's own DMA, no synchronisation).
+// Dynamic LDS: (3 x 3 + 2 x 2) x 64 doubles of records + two rings.
+#define JQ_RL3_REC_BYTES ((size_t)(3 * 3 + 2 * 2) * 64 * 8)
+#define JQ_RL3_LDS(npj) (JQ_RL3_REC_BYTES + 2 * JQ_RL_RING_BYTES(npj))
 template <int NPJ>
-__global__ __launch_bounds__(192) void k_backward_rowlane3(PropArgs a)
+__global__ __launch_bounds__(256) void k_backward_rowlane3(PropArgs a)
 {
-    constexpr bool BLK = JQ_RL3_BLK(NPJ), ROT = JQ_RL3_ROT(NPJ);
     const int lane = threadIdx.x & 63;
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // 0: state chain, 1: adjoint chain, 2: traces
     const int row = lane & 15;
@@ -679,32 +806,38 @@ __global__ __launch_bounds__(192) void k_backward_rowlane3(PropArgs a)
     const int N = a.nsteps_chunk;
     const double wd = a.tabs[row];
     double* st = a.state + w * 64 + lane;
-    const double sw = 0.5 * a.h * a.colinfo[col] * a.tabs[16 + row];
+    const double sw = a.use_shift ? 0.5 * a.h * a.colinfo[col] * a.tabs[16 + row] : 0.0;
     extern __shared__ double lds_c[];
     double* recS = lds_c + lane;                // [3 slots][u, v05, un][64]
     double* recA = lds_c + 3 * 192 + lane;      // [2 slots][X, nbn][64]
+    double* rings = lds_c + JQ_RL3_REC_BYTES / 8;
 
     if (role == 0) {
         // ---- state chain
         double u = st[0], v = st[nw * 64];
-        RowTP<NPJ> I0, I1, I2, H0, H1, H2;
-        rops_first(I0, H0, I1, a, row);
-        int slot = 0;
-        auto step = [&](int n, const RowTP<NPJ>& Pa, const RowTP<NPJ>& Ph, const RowTP<NPJ>& Pb, RowTP<NPJ>& Lh, RowTP<NPJ>& Li) {
-            rops_load_tp(Lh, Li, a, min(n + 1, N - 1), row);
-            const RowOpsV<NPJ> o{Pa.K, Pa.S, Ph.K, Ph.S, Pb.K, Pb.S};
-            double un, v05, vnew;
-            row_state<NPJ, RowOpsV<NPJ>, BLK>(a, o, sw, u, v, un, v05, vnew);
-            double* r = recS + slot * 192;
-            r[0] = u;
-            r[64] = v05;
-            r[128] = un;
-            slot = (slot == 2) ? 0 : slot + 1;
-            u = un;
-            v = vnew;
-            __syncthreads();      // tick n: record n is published (its slot was last read two ticks ago)
+        RlRing<NPJ> ring;
+        ring.init(a, rings, lane, row);
+        auto sweep = [&](auto terms) {
+            constexpr int MT = decltype(terms)::value;
+            int slot = 0;
+            for (int n = 0; n < N; ++n) {
+                ring.begin_step();
+                const RowOpsL<NPJ> o(ring);
+                double un, v05, vnew;
+                row_state<NPJ, RowOpsL<NPJ>, true, MT, true>(a, o, sw, u, v, un, v05, vnew);
+                double* r = recS + slot * 192;
+                r[0] = u;
+                r[64] = v05;
+                r[128] = un;
+                slot = (slot == 2) ? 0 : slot + 1;
+                u = un;
+                v = vnew;
+                ring.end_step();
+                __syncthreads();      // tick n: record n is published (its slot was last read two ticks ago)
+            }
         };
-        JQ_RL_LOOP(ROT, N, step)
+        JQ_RL_DISPATCH_TERMS(a.m, sweep)
+        ring.drain();
         __syncthreads();          // tick N (the trace wave's last step)
         st[0] = u;
         st[nw * 64] = v;
@@ -714,50 +847,59 @@ __global__ __launch_bounds__(192) void k_backward_rowlane3(PropArgs a)
         // ---- adjoint chain: adjoint step! (src/StormerVerlet.jl:255-303) with nb = -lambda_i, see k_backward
         double mu = st[2 * nw * 64], nb = st[3 * nw * 64];
         const double cfw = (a.forced ? 0.5 * a.h * a.tinv : 0.0) * wd;
-        RowTP<NPJ> I0, I1, I2, H0, H1, H2;
-        rops_first(I0, H0, I1, a, row);
-        int slot = 0;
-        auto step = [&](int n, const RowTP<NPJ>& Pa, const RowTP<NPJ>& Ph, const RowTP<NPJ>& Pb, RowTP<NPJ>& Lh, RowTP<NPJ>& Li) {
-            rops_load_tp(Lh, Li, a, min(n + 1, N - 1), row);
-            const RowOpsV<NPJ> o{Pa.K, Pa.S, Ph.K, Ph.S, Pb.K, Pb.S};
-            __syncthreads();      // tick n: the state wave has published record n
-            const double* r = recS + slot * 192;
-            slot = (slot == 2) ? 0 : slot + 1;
-            const double u = r[0], v05 = r[64], un = r[128];
-            double R = rmv<NPJ, true, BLK>(0.0, o.Kp05, nb);
-            if (a.use_shift) R = fma(sw, nb, R);
-            R = rmv<NPJ, false, BLK>(R, o.S0, mu);
-            R = fma(cfw, u, R);
-            const double X = row_horner<NPJ, BLK>(mu + R, R, o.S0, a.m);
-            double* ra = recA + (n & 1) * 128;
-            ra[0] = X;
-            double L = rmv<NPJ, true, BLK>(0.0, o.Kn0, X);
-            if (a.use_shift) L = fma(-sw, X, L);
-            double Qv = rmv<NPJ, true, BLK>(0.0, o.Kn1, X);
-            if (a.use_shift) Qv = fma(-sw, X, Qv);
-            {
-                double P = rmv<NPJ, true, BLK>(0.0, o.S05, nb);
-                P = fma(-cfw, v05, P);
-                L += P;
-                Qv += P;
+        RlRing<NPJ> ring;
+        ring.init(a, rings + JQ_RL_RING_BYTES(NPJ) / 8, lane, row);
+        auto sweep = [&](auto terms) {
+            constexpr int MT = decltype(terms)::value;
+            int slot = 0;
+            for (int n = 0; n < N; ++n) {
+                ring.begin_step();
+                const RowOpsL<NPJ> o(ring);
+                __syncthreads();      // tick n: the state wave has published record n
+                const double* r = recS + slot * 192;
+                slot = (slot == 2) ? 0 : slot + 1;
+                const double u = r[0], v05 = r[64], un = r[128];
+                double R = rmv<NPJ, true>(0.0, o.Kp05, nb);
+                R = fma(sw, nb, R);
+                R = rmv<NPJ, false>(R, o.S0, mu);
+                R = fma(cfw, u, R);
+                const double X = row_horner_m<NPJ, true, MT>(mu + R, R, o.S0, a.m);
+                double* ra = recA + (n & 1) * 128;
+                ra[0] = X;
+                double L = rmv<NPJ, true>(0.0, o.Kn0, X);
+                L = fma(-sw, X, L);
+                double Qv = rmv<NPJ, true>(0.0, o.Kn1, X);
+                Qv = fma(-sw, X, Qv);
+                {
+                    double P = rmv<NPJ, true>(0.0, o.S05, nb);
+                    P = fma(-cfw, v05, P);
+                    L += P;
+                    Qv += P;
+                }
+                Qv = rmv<NPJ, false>(Qv, o.S05, L);
+                const double nbn = row_horner_m<NPJ, true, MT>((nb + L) + Qv, Qv, o.S05, a.m);
+                ra[64] = nbn;
+                double G = rmv<NPJ, false>(X, o.Kp05, nbn);
+                G = fma(sw, nbn, G);
+                G = rmv<NPJ, false>(G, o.S1, X);
+                G = fma(cfw, un, G);
+                mu = G;
+                nb = nbn;
+                ring.end_step();
             }
-            Qv = rmv<NPJ, false, BLK>(Qv, o.S05, L);
-            const double nbn = row_horner<NPJ, BLK>((nb + L) + Qv, Qv, o.S05, a.m);
-            ra[64] = nbn;
-            double G = rmv<NPJ, false, BLK>(X, o.Kp05, nbn);
-            if (a.use_shift) G = fma(sw, nbn, G);
-            G = rmv<NPJ, false, BLK>(G, o.S1, X);
-            G = fma(cfw, un, G);
-            mu = G;
-            nb = nbn;
         };
-        JQ_RL_LOOP(ROT, N, step)
+        JQ_RL_DISPATCH_TERMS(a.m, sweep)
+        ring.drain();
         __syncthreads();          // tick N: record N - 1 of this wave is published
         st[2 * nw * 64] = mu;
         st[3 * nw * 64] = nb;
         return;
     }
-    // ---- traces, weighted and summed over the wave (one tick behind the adjoint wave)
+    constexpr bool BLK = true;
+    // ---- traces, weighted and summed over the wave (one tick behind the adjoint wave).  With two or more controls the traces are the
+    // longest chain of the three (4 Nc products + Nc + 1 wave reductions per step): a launch with 256 threads gives them TWO waves, wave t
+    // forming the traces of the controls q = t mod 2 (every trace is formed by one wave exactly as before: bit-identical)
+    const int tw = role - 2, tmask = (int)(blockDim.x >> 6) - 3;      // (tmask: 0 = one trace wave, 1 = two)
     const double wgt = a.colinfo[4 * nw + col];
     double nb = st[3 * nw * 64];      // (the adjoint wave stores its final nb after tick N)
     double carry[JQ_MAXNC];
@@ -774,9 +916,11 @@ __global__ __launch_bounds__(192) void k_backward_rowlane3(PropArgs a)
         const double u0 = st[0];      // (the state wave stores after tick N)
 #pragma unroll
         for (int q = 0; q < JQ_MAXNC; ++q)
-            if (q < Nc) carry[q] = -u0 * rmv<NPJ, true, BLK>(0.0, Hs[q], nb);
+            if (q < Nc && (q & tmask) == tw) carry[q] = -u0 * rmv<NPJ, true, BLK>(0.0, Hs[q], nb);
     }
     __syncthreads();              // tick 0
+    auto trace_sweep = [&](auto sel) {
+    constexpr int SEL = decltype(sel)::value;      // 0: every control, 1: the even ones, 2: the odd ones
     int slot = 0;
     for (int n = 0; n < N; ++n) {
         __syncthreads();          // tick n + 1: the adjoint wave has published record n
@@ -788,7 +932,7 @@ __global__ __launch_bounds__(192) void k_backward_rowlane3(PropArgs a)
         double t5p[JQ_MAXNC] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int q = 0; q < JQ_MAXNC; ++q) {
-            if (q < Nc) {
+            if (q < Nc && (SEL == 0 || (q & 1) == SEL - 1)) {
                 const double HaX = rmv<NPJ, true, BLK>(0.0, Ha[q], X);
                 t5p[q] = -v05 * rmv<NPJ, true, BLK>(0.0, Ha[q], Bq) * wgt;
                 const double t2 = v05 * rmv<NPJ, true, BLK>(0.0, Hs[q], X) * wgt;
@@ -800,11 +944,18 @@ __global__ __launch_bounds__(192) void k_backward_rowlane3(PropArgs a)
         }
         {
             const double ts = wave_sum4_rows(t5p[0], t5p[1], t5p[2], t5p[3]);
-            if (row == 0 && (lane >> 4) < Nc) trw[(size_t)n * (Nc * JQ_NTR) + (lane >> 4) * JQ_NTR + 4] = ts;
+            if (row == 0 && (lane >> 4) < Nc && (SEL == 0 || ((lane >> 4) & 1) == SEL - 1)) trw[(size_t)n * (Nc * JQ_NTR) + (lane >> 4) * JQ_NTR + 4] = ts;
         }
         nb = nbn;
     }
+    };
+    if (tmask == 0)
+        trace_sweep(RlTerms<0>{});
+    else if (tw == 0)
+        trace_sweep(RlTerms<1>{});
+    else
+        trace_sweep(RlTerms<2>{});
 #pragma unroll
     for (int q = 0; q < JQ_MAXNC; ++q)
-        if (q < Nc) st[(size_t)(JQ_ROWLANE_ARRAYS + q) * nw * 64] = carry[q];
+        if (q < Nc && (q & tmask) == tw) st[(size_t)(JQ_ROWLANE_ARRAYS + q) * nw * 64] = carry[q];
 }
