@@ -27,6 +27,11 @@ __global__ __launch_bounds__(256 * WPS) void k(double* out, int reps)
                 if (MODE == 3) asm volatile("v_fmac_f64 %0, %1, %2" : "+v"(d[0]) : "v"(a[i & 3]), "v"(a[(i + 1) & 3]));
                 if (MODE == 4) asm volatile("v_fmac_f64 %0, %1, %2" : "+v"(d[i & 1]) : "v"(a[i & 3]), "v"(a[(i + 1) & 3]));
                 if (MODE == 5) asm volatile("v_fmac_f64 %0, %1, %2" : "+v"(d[i & 3]) : "v"(a[i & 3]), "v"(a[(i + 1) & 3]));
+                // the row-lane kernels' product instruction: the broadcast operand through DPP (round 6: is the issue cost of the DPP form higher?)
+                if (MODE == 6) asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(d[0]) : "v"(a[i & 3]), "v"(a[(i + 1) & 3]));
+                if (MODE == 7) asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(d[i & 1]) : "v"(a[i & 3]), "v"(a[(i + 1) & 3]));
+                if (MODE == 8) asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(d[i & 3]) : "v"(a[i & 3]), "v"(a[(i + 1) & 3]));
+                if (MODE == 9) asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(d[i]) : "v"(a[i & 3]), "v"(a[(i + 1) & 3]));
             }
         }
     }
@@ -63,5 +68,9 @@ int main()
     RUN(3, "v_fmac_f64, ONE dependent chain")
     RUN(4, "v_fmac_f64, two chains interleaved")
     RUN(5, "v_fmac_f64, four chains interleaved")
+    RUN(6, "v_fmac_f64_dpp, ONE dependent chain")
+    RUN(7, "v_fmac_f64_dpp, two chains interleaved")
+    RUN(8, "v_fmac_f64_dpp, four chains interleaved")
+    RUN(9, "v_fmac_f64_dpp, independent")
     return 0;
 }

@@ -295,3 +295,21 @@ def test_full_weight_objects_with_odd_chunk_lengths(jq, NT):
             t = check(jq, q, qcof, wa, rng, ensembles=(5,))
             assert (t["kernel_family"], t["kernel_size"], t["kernel_band"]) == (0, 1, 0), t
             wa.close()
+
+
+# ---- (7) row-lane kernels: the LDS ring and the compile-time Neumann terms at their edges --------------------------------------------------
+
+@pytest.mark.parametrize("Ntot,N,Nc,m", [(2, 2, 1, 1), (3, 3, 1, 2), (4, 4, 2, 8), (6, 4, 3, 9), (7, 2, 1, 12), (10, 4, 2, 3), (13, 3, 4, 5), (16, 4, 1, 4)])
+def test_rowlane_ring_with_short_chunks_and_every_term_dispatch(jq, Ntot, N, Nc, m):
+    """The row-lane kernels of round 6 read their operator rows through an LDS ring that the wave's own DMA fills three (two) steps
+    ahead, and run the Neumann recurrences with the number of terms known at compile time for m = 2 .. 8 (the run-time loop otherwise).
+    Edges: chunks SHORTER than the prefetch distance (1, 2, 3 steps -- the DMA re-fetches the last group instead of reading past the
+    stream), a last chunk of one step, every row length (NPJ = 2 .. 16), m inside and outside the dispatch table, one to four controls
+    (one or two trace waves), the one-wave backward kernel (rl_split=0) and the state history -- all against the oracle."""
+    rng = np.random.default_rng(6700 + 17 * Ntot + m)
+    p, pcof = random_problem(jq, rng, Ntot, N, Nc, 1, 7, m, 3 if Nc > 1 else 1, False)
+    for opts in ({"chunk_steps": 1}, {"chunk_steps": 2}, {"chunk_steps": 3}, {"chunk_steps": 5, "rl_split": 0}, {}):
+        wa = jq.Working_Arrays_HIP(p, pcof.size, options=dict(opts, embed=0))
+        t = check(jq, p, pcof, wa, rng, ensembles=(3,), history=(opts == {}))
+        assert t["kernel_family"] == 3 and t["kernel_variant"] == (0 if opts.get("rl_split") == 0 else 33), t
+        wa.close()
