@@ -63,7 +63,7 @@ static const JqOptDesc g_jq_opt[O_COUNT] = {
     {"cq_fwd2", JQ_OPT_UNSET, 0, "cooperative-quad forward sweep with one (0) / two (1) column quads per workgroup (default: two beyond #CU quads; bit-identical)"},
     {"cq3", JQ_OPT_UNSET, 0, "cooperative-quad backward sweep: 0 the one-workgroup kernel, 3 three workgroups per quad or none (default: three / two / one by batch size; bit-identical)"},
     {"qsplit", JQ_OPT_UNSET, 0, "quad-layout backward sweep on two waves per quad: 0 off (one-wave kernel, bit-identical), 2 two quads per workgroup for every batch of the cooperative-quad plan"},
-    {"rl_split", 1, 0, "row-lane backward sweep: 0 = one wave, 2 = two (state | adjoint + traces), 3 = three (state | adjoint | traces) wherever two are allowed, 1 = as many as find idle SIMDs (all bit-identical)"},
+    {"rl_split", 1, 0, "row-lane backward sweep: 0 = one wave, 1 = the library's rule (Stormer-Verlet: three or four waves -- state | adjoint | traces; implicit midpoint: two while idle SIMDs remain), 2 / 3 = two / three at every batch size (all bit-identical)"},
     {"jac_wg", 1, 0, "0: Jacobi solver, N > 16: convergence per 16-column part instead of per sample"},
     {"trace_bytes", JQ_OPT_UNSET, 0, "bytes of the per-step trace records of one backward chunk (default 4 GiB): smaller = more, shorter chunks"},
     {"no_uni", 0, 0, "1: three-slab quad-layout backward sweep on the generic kernel (tests compare)"},

@@ -254,20 +254,20 @@ def test_build_manifest_no_object_falls_back():
 
 
 def test_committed_pmc_record_belongs_to_this_build():
-    """bench.py joins profiles/r05_pmc.json (HBM traffic, MFMA count of the dominant kernel) only when the record was taken with the
+    """bench.py joins profiles/r06_pmc.json (HBM traffic, MFMA count of the dominant kernel) only when the record was taken with the
     build it runs.  A source, Makefile or flag edit after the last profiling round changes the library's source hash; bench.py then
     degrades gracefully (analytic MFMA count, `traffic` null) -- so this is a release check, not a correctness test: it WARNS (advisor,
     round 4: a red CPU suite until someone re-profiles on an MI355X helps nobody).  scripts/profile_round.sh is the fix."""
     import json
     import warnings
     from juqbox_jl_amd import _lib
-    path = os.path.join(ROOT, "profiles", "r05_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r06_pmc.json")
     if not os.path.exists(path):
-        warnings.warn("profiles/r05_pmc.json is missing: run scripts/profile_round.sh on an MI355X and commit it")
+        warnings.warn("profiles/r06_pmc.json is missing: run scripts/profile_round.sh on an MI355X and commit it")
         return
     rec = json.load(open(path))
     if rec["library_version"] != _lib.load().jq_version().decode():
-        warnings.warn("profiles/r05_pmc.json was recorded with %s, the library here is %s: bench.py will not quote it -- re-run "
+        warnings.warn("profiles/r06_pmc.json was recorded with %s, the library here is %s: bench.py will not quote it -- re-run "
                       "scripts/profile_round.sh and commit the record" % (rec["library_version"], _lib.load().jq_version().decode()))
 
 
