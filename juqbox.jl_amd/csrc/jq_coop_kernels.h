@@ -32,6 +32,13 @@ __host__ __device__ constexpr int coop_kb0(int NT, int BW, int mt)
     return k;
 }
 __host__ __device__ constexpr int coop_tiles(int NT, int BW) { return NT * 4 * coop_nb(NT, BW); }
+// Operators straight from HBM / L2 into the MFMA's A registers instead of through LDS slots: more than six tile rows -- and, round 6, the
+// dense 96 x 96 case (NT = 6, band 5), whose two 72 KiB slots never fitted the LDS next to the exchange buffers: its single evaluations
+// and small ensembles ran on the slab kernels, ONE wave per 16 columns doing all six tile rows (259 us per time step; here: six waves)
+__host__ __device__ constexpr bool coop_hbm(int NT, int BW) { return NT > 6 || (NT == 6 && BW == 5); }
+// 1 KiB pieces of an operator image per wave of the workgroup when they divide evenly (else 0: the generic DMA loop)
+__host__ __device__ constexpr int coop_image_pieces(int NT, int BW) { return (NT * coop_row_elems(NT, BW) + 127) / 128; }
+__host__ __device__ constexpr int coop_dma_kper(int NT, int BW) { return coop_image_pieces(NT, BW) % NT == 0 ? coop_image_pieces(NT, BW) / NT : 0; }
 
 // D = C + M[mt, window] * x[window]  (ZEROC: C = 0).  Mrow: my row's tiles in LDS (lane offset applied);
 // x: exchange buffer [4*NT][64] (lane offset applied), kb0 = first k-block of my window.
@@ -134,7 +141,7 @@ __device__ __forceinline__ d4 cmm_od(const d4& C, const double* Mrow, const doub
 }
 
 // per-wave context of a cooperative workgroup (BIG: operators from HBM, see OpCursor)
-template <int NT, int BW, bool BIG = (NT > 6)>
+template <int NT, int BW, bool BIG = coop_hbm(NT, BW)>
 struct Coop {
     typename std::conditional<BIG, OpCursor, Ring>::type ring;
     double* xbuf;       // LDS exchange buffers [2][4*NT][64], lane offset applied
@@ -172,10 +179,15 @@ struct Coop {
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
-        M = ring.next() + row_off;   // (Ring: vmcnt(0) + barrier + prefetch inside)
+        M = next_image() + row_off;   // (Ring: vmcnt(0) + barrier + prefetch inside)
         xcur ^= 1;
     }
-    __device__ __forceinline__ void next_op() { M = ring.next() + row_off; }
+    __device__ __forceinline__ const double* next_image()
+    {
+        if constexpr (BIG) return ring.next();
+        else return ring.template next<coop_dma_kper(NT, BW)>();
+    }
+    __device__ __forceinline__ void next_op() { M = next_image() + row_off; }
     __device__ __forceinline__ const double* x() const { return xbuf + (size_t)xcur * (4 * NT * 64); }
     __device__ __forceinline__ d4 mm_z() const
     {

@@ -418,7 +418,7 @@ static int create_dense(const jq_problem* p, jq_handle* h)
         }
         if (h->NT >= 2 || h->N > 4) {
             const long long ec = (((long long)h->NT * coop_row_elems(h->NT, h->BWc) + 127) / 128) * 128;
-            const long long lds_c = (h->NT > 6 ? 0 : 2 * ec * 8) + lds_fwd_fixed + 2LL * h->KT * 64 * 8 + 16LL * h->NT * 8;      // (operator slots, tables, x exchange, Jacobi column norms)
+            const long long lds_c = (coop_hbm(h->NT, h->BWc) ? 0 : 2 * ec * 8) + lds_fwd_fixed + 2LL * h->KT * 64 * 8 + 16LL * h->NT * 8;      // (operator slots, tables, x exchange, Jacobi column norms)
             h->mat_elems_c = ec;                  // (the images are built whenever the layout exists ...)
             // (... the Stormer-Verlet kernels need two of them in LDS -- or none: NT > 6; the 4 x 4 x 7 / 4 x 4 x 8 structures keep
             //  their JQ_BW_T4 slab kernels as the Stormer-Verlet fallback: the cooperative layout serves their implicit-midpoint path)

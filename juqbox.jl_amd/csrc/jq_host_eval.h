@@ -379,7 +379,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     // (full leakage weights: the cooperative kernels sum their column dot products over the waves through an LDS record of
     //  2 x JQ_COOP_WDOTS x NT x 16 doubles behind the Jacobi norms; where that does not fit next to the operator slots the slab kernels serve)
     const size_t coop_w_bytes = wfull ? (size_t)2 * JQ_COOP_WDOTS * h->NT * 16 * 8 : 0;
-    const bool coop_w_fits = !wfull || h->NT > 6 ||
+    const bool coop_w_fits = !wfull || coop_hbm(h->NT, h->BWc) ||
                              (size_t)2 * h->mat_elems_c * 8 + (size_t)32 * h->NT * 8 + (size_t)2 * h->KT * 64 * 8 + (size_t)16 * h->NT * 8 + coop_w_bytes <= 163840;
     const bool coop = imr_coop || (!cq && !quad && !lane && !rl && h->NT >= 2 && h->coop_ok && coop_w_fits && (h->solver_id == 1 || h->big || wjac) &&
                                    (nslabs <= h->coop_max_slabs || wfull));
@@ -520,7 +520,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     // dynamic LDS layout: [operator staging | tables wd, ws | (backward: carry, parking images)]
     // cooperative kernels: [two operator slots | tables wd, ws | two x exchange buffers]
     const int batch = coop ? 0 : (quad || cq) ? -1 : h->batch;
-    const size_t lds_stage = (coop && (h->NT > 6 || imr_hbm)) ? 0      // operators are read from HBM, no LDS staging
+    const size_t lds_stage = (coop && (h->NT > 6 || imr_hbm || (!imr_coop && coop_hbm(h->NT, h->BWc)))) ? 0      // operators are read from HBM, no LDS staging
                              : batch > 0   ? (size_t)2 * (2 * batch + 1) * 2 * stride * 8 + (size_t)2 * h->NcK * stride * 8
                              : batch < 0 ? (size_t)(2 * JQ_WIN_TPS + 2 * h->NcK) * stride * 8
                                          : (size_t)2 * stride * 8;

@@ -1211,6 +1211,20 @@ struct RingT {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)p * 1024),
                                              (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
     }
+    // the pieces of an image with their number per wave known at compile time (the cooperative kernels: 2 NB pieces per wave): straight-line
+    // code.  The loop above costs a wave a taken branch per piece, 20 .. 120 clk each when the workgroup is alone on its CU -- with the
+    // schedule bookkeeping around it that was more than the 8 MFMAs of a product of a 32-level problem (round 6, profiles/r06_midsize_single.txt)
+    template <int KPER>
+    __device__ __forceinline__ void dma_k(const double* gsrc, char* dst) const
+    {
+        const char* src = (const char*)gsrc + lane_off16() + (size_t)wave * 1024;
+        char* d = dst + wave * 1024;
+        const int step = nwaves * 1024;
+#pragma unroll
+        for (int i = 0; i < KPER; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)i * step),
+                                             (__attribute__((address_space(3))) void*)(d + i * step), 16, 0, 0);
+    }
     // schedule entry of operator use q (cursor position i within the step); scalar loads, no struct copies
     __device__ __forceinline__ void entry_at(int q, int i, int& kind, int& tp) const
     {
@@ -1243,12 +1257,16 @@ struct RingT {
         ++q;
     }
     // ---- per-operator mode -------------------------------------------------------------------
+    template <int KPER = 0>
     __device__ __forceinline__ void issue_prefetch()
     {
         const unsigned e = (unsigned)pword & 63u, kind = e & 3u, tp = e >> 2;
         // image #tp of the constants, or K (kind 0) / S (kind 1) of time point 2 * np + tp of the chunk
         const char* src = (kind == 2) ? (const char*)cimg + tp * stride_b : pbase + (2 * tp + kind) * stride_b;
-        dma((const double*)src, smem + (size_t)(Qp & 1) * slot_bytes, pieces);
+        if constexpr (KPER > 0)
+            dma_k<KPER>((const double*)src, smem + (size_t)(Qp & 1) * slot_bytes);
+        else
+            dma((const double*)src, smem + (size_t)(Qp & 1) * slot_bytes, pieces);
         pword >>= 6;
         if (Qp >= npro) {
             ++ip;
@@ -1364,7 +1382,8 @@ struct RingT {
             issue_prefetch();
         }
     }
-    // LDS image (lane offset applied) of the next operator use
+    // LDS image (lane offset applied) of the next operator use  (KPER > 0: per-operator mode with pieces = KPER x nwaves, see dma_k)
+    template <int KPER = 0>
     __device__ __forceinline__ const double* next()
     {
         const double* M;
@@ -1412,7 +1431,7 @@ struct RingT {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            issue_prefetch();
+            issue_prefetch<KPER>();
         }
         M = (const double*)(smem + (size_t)(Q & 1) * slot_bytes) + lane;
         ++Q;
