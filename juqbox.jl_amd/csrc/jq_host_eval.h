@@ -382,7 +382,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     const bool coop_w_fits = !wfull || coop_hbm(h->NT, h->BWc) ||
                              (size_t)2 * h->mat_elems_c * 8 + (size_t)32 * h->NT * 8 + (size_t)2 * h->KT * 64 * 8 + (size_t)16 * h->NT * 8 + coop_w_bytes <= 163840;
     const bool coop = imr_coop || (!cq && !quad && !lane && !rl && h->NT >= 2 && h->coop_ok && coop_w_fits && (h->solver_id == 1 || h->big || wjac) &&
-                                   (nslabs <= h->coop_max_slabs || wfull));
+                                   (nslabs <= h->coop_max_slabs || (wfull && !(h->NT == 6 && h->BW == 5))));      // (dense 96 x 96: the slab kernels <6, 5> carry the low-rank terms too -- large batches stay there)
     if (wjac && !coop && h->BW == JQ_BW_T4)      // (jq_update_wmat / jq_set_linear_solver re-plan such handles without the structure: cannot happen)
         return fail(h, JQ_EHIP, "internal error: full leakage weights with the Jacobi solver on a 4 x 4 x n plan without cooperative kernels");      // (Ntot > 96: also the Jacobi solver; full weights: every batch size -- the slab kernels have no low-rank terms)
     // row-lane kernels, Stormer-Verlet: the backward sweep's two chains on two waves (jq_rowlane_kernels.h k_backward_rowlane2);

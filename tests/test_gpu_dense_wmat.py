@@ -89,7 +89,8 @@ def test_cnot2(jq, oft, env, family):
     (1, 2, {}, 8, 7), (2, 2, {}, 8, 7),                                   # round 5: complex rank <= 2 on the cooperative-quad kernels (split backward sweep)
     (1, 2, {"JQ_T4": "0"}, 1, 9), (2, 2, {"JQ_T4": "0", "JQ_COOP_MAX": "0"}, 1, 9),      # JQ_BW_OD: cooperative kernels, whatever JQ_COOP_MAX says
     (1, 3, {"JQ_T4": "0", "JQ_OD": "0"}, 1, 1),                           # block-tridiagonal band tiles
-    (3, 2, {"JQ_FORCE_DENSE": "1", "JQ_EMBED": "0"}, 0, 5),               # dense 96 x 96 tiles: no cooperative kernels, slab <6, 5>
+    (3, 2, {"JQ_FORCE_DENSE": "1", "JQ_EMBED": "0"}, 1, 5),               # dense 96 x 96 tiles, small batches: cooperative kernels with HBM operands (round 6)
+    (3, 2, {"JQ_FORCE_DENSE": "1", "JQ_EMBED": "0", "JQ_COOP_MAX": "0"}, 0, 5),      # ... large batches (here: forced): slab <6, 5> with the low-rank terms
 ])
 def test_cnot3_short(jq, oft, nforb, env, family, band):
     p, pcof = forbidden_problem("cnot3", nforb, 23, True, oft, nsteps=300)

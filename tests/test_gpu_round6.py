@@ -106,7 +106,8 @@ def test_implicit_midpoint_beyond_256_levels_is_refused_not_served_by_something_
     (12, 3, 1, 15, False, {}, (0, 1, 0), False),                                # one tile row: slab <1, 0> with both compiled in (x_1_0)
     (16, 4, 2, 11, "t4", {}, (0, 1, 0), True),                                  # 4 x 4 x 1 plan: planned again without the structure
     (112, 4, 2, 6, "t4", {}, (1, 7, 1), True),                                  # 4 x 4 x 7 plan: the general Ntot > 96 cooperative kernels
-    (96, 4, 2, 7, False, {"force_dense": 1, "embed": 0}, (0, 6, 5), False),     # dense 96 x 96: slab <6, 5> (x_6_5)
+    (96, 4, 2, 7, False, {"force_dense": 1, "embed": 0, "coop_max": 0}, (0, 6, 5), False),     # dense 96 x 96, large batches (here: forced): slab <6, 5> (x_6_5)
+    (96, 4, 2, 7, False, {"force_dense": 1, "embed": 0}, (1, 6, 5), False),     # ... small batches: the cooperative kernels with HBM operands (round 6)
     (200, 6, 1, 5, False, {}, (1, 13, 15), False),                              # Ntot > 96, dense
     (40, 24, 2, 6, False, {}, (1, 3, 2), False),                                # N > 16 on the cooperative kernels
 ], ids=lambda c: "Ntot%d_%s" % (c[0], c[4] if isinstance(c[4], str) else ("band" if c[4] else "dense")) if isinstance(c, tuple) and len(c) == 8 else None)
@@ -133,7 +134,7 @@ def test_full_weights_with_the_jacobi_solver_match_the_oracle(jq, cfg):
 
 # ---- (3) ranks beyond 16, more than 16 controls --------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("cfg", [(40, 5, False, 20, {}, 1), (64, 4, "t4", 18, {}, 6), (96, 3, False, 19, {"force_dense": 1, "embed": 0}, 0), (130, 4, True, 24, {}, 1),
+@pytest.mark.parametrize("cfg", [(40, 5, False, 20, {}, 1), (64, 4, "t4", 18, {}, 6), (96, 3, False, 19, {"force_dense": 1, "embed": 0, "coop_max": 0}, 0), (96, 3, False, 19, {"force_dense": 1, "embed": 0}, 1), (130, 4, True, 24, {}, 1),
                                  (33, 6, False, 33, {}, 1)],
                          ids=lambda c: "Ntot%d_rank%d" % (c[0], c[3]) if isinstance(c, tuple) else None)
 def test_full_weights_of_rank_beyond_16(jq, cfg):
