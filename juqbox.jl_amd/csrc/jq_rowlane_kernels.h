@@ -205,7 +205,7 @@ template <int MT>
 struct RlTerms {
     static constexpr int value = MT;
 };
-// RUN(RlTerms<m>{}) for the m the kernels are specialised for, RUN(RlTerms<0>{}) otherwise
+// RUN(RlTerms<m>{}) for the m the kernels are specialised for (2 .. 10: rabi has 10), RUN(RlTerms<0>{}) otherwise
 #define JQ_RL_DISPATCH_TERMS(m, RUN)             \
     switch (m) {                                 \
     case 2: RUN(RlTerms<2>{}); break;            \
@@ -215,6 +215,8 @@ struct RlTerms {
     case 6: RUN(RlTerms<6>{}); break;            \
     case 7: RUN(RlTerms<7>{}); break;            \
     case 8: RUN(RlTerms<8>{}); break;            \
+    case 9: RUN(RlTerms<9>{}); break;            \
+    case 10: RUN(RlTerms<10>{}); break;          \
     default: RUN(RlTerms<0>{}); break;           \
     }
 

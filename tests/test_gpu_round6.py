@@ -303,7 +303,7 @@ def test_full_weight_objects_with_odd_chunk_lengths(jq, NT):
 @pytest.mark.parametrize("Ntot,N,Nc,m", [(2, 2, 1, 1), (3, 3, 1, 2), (4, 4, 2, 8), (6, 4, 3, 9), (7, 2, 1, 12), (10, 4, 2, 3), (13, 3, 4, 5), (16, 4, 1, 4)])
 def test_rowlane_ring_with_short_chunks_and_every_term_dispatch(jq, Ntot, N, Nc, m):
     """The row-lane kernels of round 6 read their operator rows through an LDS ring that the wave's own DMA fills three (two) steps
-    ahead, and run the Neumann recurrences with the number of terms known at compile time for m = 2 .. 8 (the run-time loop otherwise).
+    ahead, and run the Neumann recurrences with the number of terms known at compile time for m = 2 .. 10 (the run-time loop otherwise).
     Edges: chunks SHORTER than the prefetch distance (1, 2, 3 steps -- the DMA re-fetches the last group instead of reading past the
     stream), a last chunk of one step, every row length (NPJ = 2 .. 16), m inside and outside the dispatch table, one to four controls
     (one or two trace waves), the one-wave backward kernel (rl_split=0) and the state history -- all against the oracle."""
