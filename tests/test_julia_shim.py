@@ -137,3 +137,90 @@ def test_sparse_operators_are_passed_in_csc_form():
     assert "sparse ? zeros(1, 1) : Matrix{Float64}(params.Hconst)" in new
     assert "sparse ? pointer(c0) : Ptr{JQCsc}(C_NULL)" in new
     assert ":jq_update_hconst_csc" in txt
+
+
+def _julia_tokens(txt):
+    """hip_backend.jl without comments and string / char literals, as (line, token) pairs: identifiers / keywords and the brackets"""
+    out, i, n, line = [], 0, len(txt), 1
+    while i < n:
+        c = txt[i]
+        if c == "\n":
+            line += 1
+            i += 1
+        elif c == "#":
+            if txt.startswith("#=", i):
+                j = txt.index("=#", i + 2)
+                line += txt.count("\n", i, j)
+                i = j + 2
+            else:
+                while i < n and txt[i] != "\n":
+                    i += 1
+        elif c == '"':
+            q = '"""' if txt.startswith('"""', i) else '"'
+            j = i + len(q)
+            while not txt.startswith(q, j):
+                if txt[j] == "\\":
+                    j += 1
+                if txt[j] == "$" and txt[j + 1] == "(":      # interpolation: skip to its closing parenthesis (no nested strings in this file)
+                    depth, j = 1, j + 2
+                    while depth:
+                        depth += {"(": 1, ")": -1}.get(txt[j], 0)
+                        j += 1
+                    continue
+                j += 1
+            line += txt.count("\n", i, j)
+            i = j + len(q)
+        elif c == "'" and i + 2 < n and (txt[i + 2] == "'" or (txt[i + 1] == "\\" and txt[i + 3] == "'")):      # char literal (not a transpose)
+            i += 3 if txt[i + 2] == "'" else 4
+        elif c.isalpha() or c == "_" or c == "@":
+            j = i + 1
+            while j < n and (txt[j].isalnum() or txt[j] in "_!"):
+                j += 1
+            # (a field access `x.end` or a symbol `:end` is not a keyword)
+            out.append((line, txt[i:j] if not (i and txt[i - 1] in ".:") else "ident"))
+            i = j
+        else:
+            if c in "()[]{}":
+                out.append((line, c))
+            i += 1
+    return out
+
+
+def test_julia_binding_blocks_and_brackets_balance():
+    """No Julia in the image, so the binding is never parsed by the real thing (review: the regex checks above would not notice a
+    syntax slip outside a ccall).  What CAN be checked without an interpreter: every bracket closes in order, and every block opener
+    (function, if, for, while, let, try, begin, do, struct, module, quote, macro -- outside brackets, where `for` / `if` are
+    comprehension / generator syntax) has its `end`, with `end` inside [] being an index.  A missing or extra `end` / bracket -- the
+    usual result of an edit that was never run -- fails here with the line of the opener that is left over."""
+    txt = open(os.path.join(ROOT, "julia", "hip_backend.jl")).read()
+    openers = {"function", "if", "for", "while", "let", "try", "begin", "do", "struct", "module", "quote", "macro", "baremodule"}
+    pairs = {")": "(", "]": "[", "}": "{"}
+    brackets, blocks = [], []
+    toks = _julia_tokens(txt)
+    for k, (line, t) in enumerate(toks):
+        if t in "([{":
+            brackets.append((t, line))
+        elif t in pairs:
+            assert brackets and brackets[-1][0] == pairs[t], "line %d: '%s' closes nothing (open: %s)" % (line, t, brackets[-3:])
+            brackets.pop()
+        elif t == "end":
+            if any(b == "[" for b, _ in brackets):      # a[end]: an index
+                continue
+            assert blocks, "line %d: `end` without an open block" % line
+            blocks.pop()
+        elif t in openers:
+            if t in ("for", "if") and brackets:          # comprehension / generator inside brackets
+                continue
+            if t == "struct" and k and toks[k - 1][1] == "mutable":
+                pass
+            blocks.append((t, line, len(brackets)))
+        elif t == "abstract" or t == "primitive":
+            blocks.append((t, line, len(brackets)))     # `abstract type ... end`
+    assert not brackets, "unclosed brackets: %s" % brackets[:5]
+    assert not blocks, "blocks without `end`: %s" % [(t, ln) for t, ln, _ in blocks[:5]]
+    # ... and the checker itself notices a slip: drop the last `end` of the file
+    broken = txt[:txt.rindex("end")]
+    depth = 0
+    for _, t in _julia_tokens(broken):
+        depth += (t in openers) - (t == "end")
+    assert depth != 0
