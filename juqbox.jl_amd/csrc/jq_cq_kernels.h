@@ -139,8 +139,30 @@ __device__ __forceinline__ D2 fma(double c, D2 x, D2 y) { return D2(fma(c, x.a, 
 // under the latency of the LDS write and moves the shifts and FMAs BEHIND the barrier, where they run while the neighbours'
 // blocks are being read.  (Pinning all of own() in front of the barrier was measured 13 % slower per Neumann publication: an
 // instruction in front of the barrier delays everybody's arrival, one behind it hides in the read latency.)
-template <int NT>
+// DN (round 6): the DENSE policy for NT = 2 -- problems of 17 .. 32 levels WITHOUT the 4 x 4 x n structure, whose single evaluations ran
+// on the cooperative kernels at 26 us per time step (profiles/r06_midsize_single.txt).  Same layout, publications, chains and trace
+// hand-off; only the product differs.  With lane 16 k + 4 b + j <-> (row 4 b + k, column j) a state register IS the B operand of its own
+// four diagonal 4 x 4 blocks; rotated by 4 s lanes inside each 16-lane row (row_ror: lane p reads lane p - 4 s) it gives output block b
+// the rows of block (b - s) mod 4.  A dense 16 x 16 tile is therefore FOUR v_mfma_f64_4x4x4_4b on the register and its three
+// rotations, the A operand of rotation s holding M[16 t + 4 b + i][16 t' + 4 ((b - s) mod 4) + k] on lane 16 k + 4 b + i (host:
+// dq_image): own() = the tile (mt, mt), nbr() = the tile (mt, other block) -- at NT = 2 every wave has exactly one neighbour, the
+// other one is the zero pad block of the exchange image.  16 clk per MFMA against the 64 of a v_mfma_f64_16x16x4 that N = 4 fills to a quarter.
+template <int N>
+__device__ __forceinline__ double row_ror64(double x)
+{
+    union {
+        double d;
+        int i[2];
+    } a, b;
+    a.d = x;
+    b.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], 0x120 + N, 0xf, 0xf, false);
+    b.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], 0x120 + N, 0xf, 0xf, false);
+    return b.d;
+}
+#define JQ_DQ_TILES 8      // 64-lane operand registers per 16-row block of a dense NT = 2 image: [own tile: s = 0 .. 3 | other tile: s = 0 .. 3]
+template <int NT, bool DN = false>
 struct CoopQ {
+    static_assert(!DN || NT == 2, "dense policy: two 16-row blocks");
     static constexpr int CHS = (NT + 2) * 64;       // doubles per channel
     static constexpr int PAR = 3 * CHS;              // doubles per parity
     WinRing ring;
@@ -176,33 +198,66 @@ struct CoopQ {
         asm volatile("" ::: "memory");
     }
     // my block of an operator image (LDS, lane offset applied): A operand of the MFMA + the four coupling coefficients of my row
-    struct Op {
+    struct OpT4 {
         double a;
         d4 c;
     };
+    struct OpDn {
+        double ao[4], an[4];      // A operands of the rotations 0 .. 3: my own tile, the other block's tile
+    };
+    typedef typename std::conditional<DN, OpDn, OpT4>::type Op;
     __device__ __forceinline__ Op load(const double* M) const
     {
         Op o;
-        o.a = M[mt * 64];
-        o.c = t4q_cload(t4q_c<NT>(M, lane), mt);
+        if constexpr (DN) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                o.ao[r] = M[(mt * JQ_DQ_TILES + r) * 64];
+                o.an[r] = M[(mt * JQ_DQ_TILES + 4 + r) * 64];
+            }
+        } else {
+            o.a = M[mt * 64];
+            o.c = t4q_cload(t4q_c<NT>(M, lane), mt);
+        }
         return o;
     }
-    // my block of a vector with its two lane shifts (shared by all products with that vector)
-    struct Sh {
+    // my block of a vector with its two lane shifts (shared by all products with that vector); dense: with its three rotations
+    struct ShT4 {
         double x, dn, up;
     };
+    struct Rot {
+        double x, r1, r2, r3;
+    };
+    typedef typename std::conditional<DN, Rot, ShT4>::type Sh;
+    static __device__ __forceinline__ Rot rot(double x)
+    {
+        Rot r;
+        r.x = x, r.r1 = row_ror64<4>(x), r.r2 = row_ror64<8>(x), r.r3 = row_ror64<12>(x);
+        return r;
+    }
     __device__ __forceinline__ Sh sh(double x) const
     {
-        Sh s;
-        s.x = x, s.dn = row_shift4<0x114>(x), s.up = row_shift4<0x104>(x);
-        return s;
+        if constexpr (DN) {
+            return rot(x);
+        } else {
+            Sh s;
+            s.x = x, s.dn = row_shift4<0x114>(x), s.up = row_shift4<0x104>(x);
+            return s;
+        }
     }
     // C + (my block's own part of M x)
     __device__ __forceinline__ double own(double C, const Op& o, const Sh& s) const
     {
-        double acc = __builtin_amdgcn_mfma_f64_4x4x4f64(o.a, s.x, C, 0, 0, 0);
-        acc = fma(o.c[0], s.dn, acc);
-        return fma(o.c[1], s.up, acc);
+        if constexpr (DN) {
+            double acc = __builtin_amdgcn_mfma_f64_4x4x4f64(o.ao[0], s.x, C, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_4x4x4f64(o.ao[1], s.r1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_4x4x4f64(o.ao[2], s.r2, acc, 0, 0, 0);
+            return __builtin_amdgcn_mfma_f64_4x4x4f64(o.ao[3], s.r3, acc, 0, 0, 0);
+        } else {
+            double acc = __builtin_amdgcn_mfma_f64_4x4x4f64(o.a, s.x, C, 0, 0, 0);
+            acc = fma(o.c[0], s.dn, acc);
+            return fma(o.c[1], s.up, acc);
+        }
     }
     struct Sh2 {
         Sh a, b;
@@ -214,10 +269,12 @@ struct CoopQ {
         return s;
     }
     __device__ __forceinline__ D2 own(D2 C, const Op& o, const Sh2& s) const { return D2(own(C.a, o, s.a), own(C.b, o, s.b)); }
-    // the neighbours' blocks of the vector published in channel C, parity P
-    struct Nb {
+    // the neighbours' blocks of the vector published in channel C, parity P (dense: THE other block -- one of the two is the zero pad --
+    // with its rotations)
+    struct NbT4 {
         double b, a;
     };
+    typedef typename std::conditional<DN, Rot, NbT4>::type Nb;
     struct Nb2 {
         Nb a, b;
     };
@@ -228,6 +285,9 @@ struct CoopQ {
             Nb2 n;
             n.a = nbs<P, C>(), n.b = nbs<P, C + 1>();
             return n;
+        } else if constexpr (DN) {
+            const double below = xb[P * PAR + C * CHS], above = xb[P * PAR + C * CHS + 128];
+            return rot(below + above);
         } else {
             Nb n;
             n.b = xb[P * PAR + C * CHS], n.a = xb[P * PAR + C * CHS + 128];
@@ -236,8 +296,15 @@ struct CoopQ {
     }
     __device__ __forceinline__ double nbr(double acc, const Op& o, const Nb& n) const
     {
-        acc = fma(o.c[2], n.b, acc);      // (the coefficients of a missing neighbour are zero)
-        return fma(o.c[3], n.a, acc);
+        if constexpr (DN) {
+            acc = __builtin_amdgcn_mfma_f64_4x4x4f64(o.an[0], n.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_4x4x4f64(o.an[1], n.r1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_4x4x4f64(o.an[2], n.r2, acc, 0, 0, 0);
+            return __builtin_amdgcn_mfma_f64_4x4x4f64(o.an[3], n.r3, acc, 0, 0, 0);
+        } else {
+            acc = fma(o.c[2], n.b, acc);      // (the coefficients of a missing neighbour are zero)
+            return fma(o.c[3], n.a, acc);
+        }
     }
     __device__ __forceinline__ D2 nbr(D2 acc, const Op& o, const Nb2& n) const { return D2(nbr(acc.a, o, n.a), nbr(acc.b, o, n.b)); }
     // M x for a constant trace image (my block).  ORD: control q acts on subsystem q only -- q = 0: the 4 x 4 diagonal blocks
@@ -246,7 +313,7 @@ struct CoopQ {
     template <bool ORD>
     __device__ __forceinline__ double trace_mm(const double* M, int q, const Sh& s, const Nb& n) const
     {
-        if constexpr (ORD) {
+        if constexpr (ORD && !DN) {
             if (q == 0) return __builtin_amdgcn_mfma_f64_4x4x4f64(M[mt * 64], s.x, 0.0, 0, 0, 0);
             const d4 cc = t4q_cload(t4q_c<NT>(M, lane), mt);
             if (q == 1) return fma(cc[1], s.up, cc[0] * s.dn);
@@ -391,15 +458,15 @@ struct CqW {
 };
 
 // the six operator blocks of a time step (this wave's share of K, S at the time points 2n, 2n+1, 2n+2 of the chunk)
-template <int NT>
+template <int NT, bool DN = false>
 struct CqOps {
-    typename CoopQ<NT>::Op Kp05, S05, Kn0, S0, Kn1, S1;
+    typename CoopQ<NT, DN>::Op Kp05, S05, Kn0, S0, Kn1, S1;
 };
 // step 0: time point 0 sits at the start of the ring
-template <int NT>
-__device__ __forceinline__ CqOps<NT> cq_first_ops(const CoopQ<NT>& c)
+template <int NT, bool DN>
+__device__ __forceinline__ CqOps<NT, DN> cq_first_ops(const CoopQ<NT, DN>& c)
 {
-    CqOps<NT> o;
+    CqOps<NT, DN> o;
     o.Kn0 = c.load(c.ring.template ks<0, 0>());
     o.S0 = c.load(c.ring.template ks<1, 0>());
     o.Kp05 = c.load(c.ring.template ks<0, 1>());
@@ -409,8 +476,8 @@ __device__ __forceinline__ CqOps<NT> cq_first_ops(const CoopQ<NT>& c)
     return o;
 }
 // the next step: K0, S0 are this step's K1, S1; the time points 2n+3, 2n+4 have landed (see WinRing)
-template <int NT>
-__device__ __forceinline__ void cq_next_ops(CoopQ<NT>& c, CqOps<NT>& o)
+template <int NT, bool DN>
+__device__ __forceinline__ void cq_next_ops(CoopQ<NT, DN>& c, CqOps<NT, DN>& o)
 {
     c.ring.advance();
     o.Kn0 = o.Kn1;
@@ -425,8 +492,8 @@ __device__ __forceinline__ void cq_next_ops(CoopQ<NT>& c, CqOps<NT>& o)
 //   I1: P0   I2: P0^1   first Neumann series: from P0   I3: P0^M   I4: P0^M^1   second series: from P0^M   I5: P0      (M = m & 1)
 // State step up to its second-to-last publication: in u, v; out un = u(t+h), v05, vN = v05 + S05 v05 (the caller publishes un
 // once more and adds Kp05 un).
-template <int NT, int P0, bool MODD, typename T>
-__device__ __forceinline__ void cq_state(CoopQ<NT>& c, const PropArgs& a, const CqOps<NT>& o, T cw, T u, T v, T& un, T& v05, T& vN)
+template <int NT, int P0, bool MODD, typename T, bool DN>
+__device__ __forceinline__ void cq_state(CoopQ<NT, DN>& c, const PropArgs& a, const CqOps<NT, DN>& o, T cw, T u, T v, T& un, T& v05, T& vN)
 {
     constexpr int M = MODD ? 1 : 0;
     // x = u: A = c K05 u ; P = u + c S0 u
@@ -530,10 +597,11 @@ __device__ __forceinline__ CqSetup<NT> cq_setup(const PropArgs& a)
 // (b_k . vr(t_n))] on top  (penalf2aTrap, penalf2a, penalf2imag: src/evalobjgrad.jl:700, :716-718, :2170-2233).
 // (First version: partial dots by the propagating waves, 34 instructions per step in lock-step: forward sweep 71 -> 91 ms; behind the
 //  last barrier instead of in front of it 86 ms; this version 71.)
-template <int NT, bool MODD, int NS = 1, bool WLR = false>
+template <int NT, bool MODD, int NS = 1, bool WLR = false, bool DN = false>
 __global__ __launch_bounds__(64 * NT + 128) void k_forward_cq(PropArgs a)
 {
     static_assert(!WLR || NS == 1, "full weights: one column quad per workgroup");
+    static_assert(!DN || (NS == 1 && !WLR), "dense policy: one column quad per workgroup, Diagonal weights");
     typedef typename std::conditional<NS == 2, D2, double>::type T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KT = 4 * NT;
@@ -543,8 +611,8 @@ __global__ __launch_bounds__(64 * NT + 128) void k_forward_cq(PropArgs a)
     const int lane_ = s.lane_, wave = s.wave;
     double* tab = (double*)(smem + a.lds_tab_off);
     for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[(i & ~15) + 4 * (i & 3) + ((i >> 2) & 3)] = a.tabs[i];   // [block][g][r]
-    CoopQ<NT> c;
-    double* scratch = tab + 32 * NT + 2 * CoopQ<NT>::PAR;
+    CoopQ<NT, DN> c;
+    double* scratch = tab + 32 * NT + 2 * CoopQ<NT, DN>::PAR;
     c.setup(tab + 32 * NT, s.chain ? 0 : wave, lane_);
     c.ring.init(smem, a, wave + NT * s.chain, lane_, NT + 2);      // (barrier inside)
     if (s.chain) {      // staging waves
@@ -581,7 +649,7 @@ __global__ __launch_bounds__(64 * NT + 128) void k_forward_cq(PropArgs a)
         // reduction instead of the MFMAs cost 81 ms.)
         double X[NT], acc = 0.0;
         auto wload = [&](int par) {
-            const jq_lds_double* x = c.xb + par * CoopQ<NT>::PAR + 64;
+            const jq_lds_double* x = c.xb + par * CoopQ<NT, DN>::PAR + 64;
 #pragma unroll
             for (int w = 0; w < NT; ++w) X[w] = x[w * 64];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (read before this wave arrives at the next barrier)
@@ -675,7 +743,7 @@ __global__ __launch_bounds__(64 * NT + 128) void k_forward_cq(PropArgs a)
         leak = slot0 ? st[lslot] : 0.0;
         cw = 0.5 * a.h * a.colinfo[(size_t)s.slab * 32 + s.col] * wsr;      // h/2 eps ws[row]
     }
-    CqOps<NT> o = cq_first_ops<NT>(c);
+    CqOps<NT, DN> o = cq_first_ops<NT>(c);
 
     auto hist = [&](int n, int colq, double hu, double hv) {
         const int scol = a.parts > 1 ? 16 * s.slab + colq : colq;
@@ -751,15 +819,16 @@ __global__ __launch_bounds__(64 * NT + 128) void k_forward_cq(PropArgs a)
 // WLR: full (real, rank <= JQ_CQ_WRANK) leakage weights: the forcing terms hr0 = W vr(t_n+1) / T, hi0 = hi1 = W vi05 / T,
 // hr1 = W vr(t_n) / T (src/evalobjgrad.jl:862, :882-888) from the dots the state waves leave with their publications of vi05 and
 // vr(t_n) (CqW); W vr(t_n) is next step's W vr(t_n+1).
-template <int NT, bool MODD, bool ORD, bool WLR = false>
+template <int NT, bool MODD, bool ORD, bool WLR = false, bool DN = false>
 __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
 {
+    static_assert(!DN || (!WLR && !ORD), "dense policy: Diagonal weights, whole trace products");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KT = 4 * NT;
     constexpr int M = MODD ? 1 : 0;
-    typedef typename CoopQ<NT>::Sh Sh;
-    typedef typename CoopQ<NT>::Nb Nb;
-    typedef typename CoopQ<NT>::Op Op;
+    typedef typename CoopQ<NT, DN>::Sh Sh;
+    typedef typename CoopQ<NT, DN>::Nb Nb;
+    typedef typename CoopQ<NT, DN>::Op Op;
     const CqSetup<NT> s = cq_setup<NT>(a);
     const int Nc = a.Ncoupled;
     // trace records: row slab * qps + qd (qps: quads of a full slab); a quad without columns inside that range (last slab)
@@ -773,8 +842,8 @@ __global__ __launch_bounds__(128 * NT) void k_backward_cq(PropArgs a)
     const int lane_ = s.lane_, wave = s.wave, wave_all = s.wave + NT * s.chain;
     double* tab = (double*)(smem + a.lds_tab_off);
     for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[(i & ~15) + 4 * (i & 3) + ((i >> 2) & 3)] = a.tabs[i];   // [block][g][r]
-    CoopQ<NT> c;
-    double* scratch = tab + 32 * NT + 2 * CoopQ<NT>::PAR;      // [2 NT][64]: the workgroup sums after the last time step
+    CoopQ<NT, DN> c;
+    double* scratch = tab + 32 * NT + 2 * CoopQ<NT, DN>::PAR;      // [2 NT][64]: the workgroup sums after the last time step
     const int ntr = Nc * JQ_NTR, ngroups = Nc + (Nc + 1) / 2;
     double* red = scratch;                                      // [ngroups][NT][64]: trace hand-off (dead by then: same LDS)
     c.setup(tab + 32 * NT, wave, lane_);

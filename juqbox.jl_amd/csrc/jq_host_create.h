@@ -89,6 +89,21 @@ static int upload_operators(jq_handle* h)
         }
         HIPCHK(h, hipMemcpy(h->d_cimg_l, cl.data(), cl.size() * sizeof(double), hipMemcpyHostToDevice));
     }
+    if (h->dq_max_quads > 0) {
+        std::vector<double> id((size_t)(1 + 2 * h->Nc) * JQ_DQ_ELEMS, 0.0);
+        dq_image(h->Hconst.data(), h->Ntot, id.data());
+        for (int q = 0; q < h->Nc; ++q) {
+            dq_image(h->Hsym.data() + q * nn, h->Ntot, id.data() + (size_t)(1 + q) * JQ_DQ_ELEMS);
+            dq_image(h->Hanti.data() + q * nn, h->Ntot, id.data() + (size_t)(1 + h->Nc + q) * JQ_DQ_ELEMS);
+        }
+        HIPCHK(h, hipMemcpy(h->d_himg_dq, id.data(), id.size() * sizeof(double), hipMemcpyHostToDevice));
+        std::vector<double> cd((size_t)2 * h->Nc * JQ_DQ_ELEMS);
+        for (int q = 0; q < h->Nc; ++q) {
+            std::copy_n(id.data() + (size_t)(1 + q) * JQ_DQ_ELEMS, JQ_DQ_ELEMS, cd.data() + cslot(q, false) * JQ_DQ_ELEMS);
+            std::copy_n(id.data() + (size_t)(1 + h->Nc + q) * JQ_DQ_ELEMS, JQ_DQ_ELEMS, cd.data() + cslot(q, true) * JQ_DQ_ELEMS);
+        }
+        HIPCHK(h, hipMemcpy(h->d_cimg_dq, cd.data(), cd.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     if (h->rl_npj > 0) {
         std::vector<double> ir((size_t)(1 + 2 * h->Nc) * h->rl_stride, 0.0);
         rowlane_image(h->Hconst.data(), h->Ntot, h->rl_npj, ir.data());
@@ -166,7 +181,7 @@ extern "C" void jq_destroy(jq_handle* h)
     }
     (void)hipSetDevice(h->device);
     if (h->emb) jq_destroy(h->emb);
-    double** bufs[] = {&h->d_cq3, &h->d_qsplit, &h->d_wlr, &h->d_cimg_l, &h->d_cimg_r, &h->d_rfreq, &h->d_wq, &h->d_pk2, &h->d_pack, &h->d_himg_r, &h->d_uinit_r, &h->d_vtr_r, &h->d_vti_r, &h->d_himg_l, &h->d_uinit_l, &h->d_vtr_l, &h->d_vti_l, &h->d_himg_c, &h->d_cimg_c, &h->d_park, &h->d_cimg, &h->d_himg,  &h->d_uimg,       &h->d_vtr,     &h->d_vti,    &h->d_tabs, &h->d_tf,   &h->d_tb,
+    double** bufs[] = {&h->d_himg_dq, &h->d_cimg_dq, &h->d_cq3, &h->d_qsplit, &h->d_wlr, &h->d_cimg_l, &h->d_cimg_r, &h->d_rfreq, &h->d_wq, &h->d_pk2, &h->d_pack, &h->d_himg_r, &h->d_uinit_r, &h->d_vtr_r, &h->d_vti_r, &h->d_himg_l, &h->d_uinit_l, &h->d_vtr_l, &h->d_vti_l, &h->d_himg_c, &h->d_cimg_c, &h->d_park, &h->d_cimg, &h->d_himg,  &h->d_uimg,       &h->d_vtr,     &h->d_vti,    &h->d_tabs, &h->d_tf,   &h->d_tb,
                        &h->d_cfreq, &h->d_pcof,       &h->d_stream,  &h->d_pq,     &h->d_state, &h->d_state_save,
                        &h->d_colinfo, &h->d_traces,   &h->d_R,       &h->d_grad,   &h->d_res};
     for (auto b : bufs)
@@ -470,6 +485,14 @@ static int create_dense(const jq_problem* p, jq_handle* h)
             h->cq_max_quads = (h->BW == JQ_BW_T4 && h->NT >= 2 && h->NT <= 7 && h->quad_max_slabs > 0 && win + tail <= 163840) ? 2 * prop.multiProcessorCount : 0;      // (two rounds of them, 2 x 0.20 s at cnot3, still beat one round of the quad-layout kernels, 0.55 s)
             if (h->opt.has(O_CQ) && h->cq_max_quads > 0) h->cq_max_quads = (int)h->opt.get(O_CQ);
         }
+        // ... with the DENSE policy (round 6, jq_cq_kernels.h CoopQ<2, true>): two 16-row blocks WITHOUT the structure (17 .. 32 levels: two
+        // five-level subsystems, a drift in its eigenbasis, ...), whose small batches otherwise take the cooperative kernels.  Images of
+        // JQ_DQ_ELEMS doubles in the window staging; Neumann solver, Diagonal weights.  option dq=0 disables them.
+        {
+            const long long win = (2LL * JQ_WIN_TPS + 2LL * h->NcK) * JQ_DQ_ELEMS * 8;
+            const long long tail = 32LL * h->NT * 8 + 6LL * (h->NT + 2) * 64 * 8 + (long long)std::max(2, h->NcK + (h->NcK + 1) / 2) * h->NT * 64 * 8;      // (run_eval: lds_cq)
+            h->dq_max_quads = (h->NT == 2 && h->BW != JQ_BW_T4 && !h->big && !h->huge && !h->is_emb && win + tail <= 163840 && h->opt.on(O_DQ)) ? 2 * prop.multiProcessorCount : 0;
+        }
         if (h->opt.has(O_BATCH)) {      // (experiment builds only: jq_options.h)
             const int v = (int)h->opt.get(O_BATCH);
             if (v >= 2 && slot <= 8192) {
@@ -548,6 +571,10 @@ static int create_dense(const jq_problem* p, jq_handle* h)
         column_image(h->Uinit.data(), h->Ntot, h->N, h->lane_np, cl.data());
         HIPCHK(h, hipMemcpy(h->d_uinit_l, cl.data(), cl.size() * sizeof(double), hipMemcpyHostToDevice));
     }
+    if (h->dq_max_quads > 0) {
+        if ((rc = dev_alloc(h, &h->d_himg_dq, (size_t)(1 + 2 * h->Nc) * JQ_DQ_ELEMS))) return rc;
+        if ((rc = dev_alloc(h, &h->d_cimg_dq, (size_t)(2 * h->Nc) * JQ_DQ_ELEMS))) return rc;
+    }
     if (h->rl_npj > 0) {
         if ((rc = dev_alloc(h, &h->d_himg_r, (size_t)(1 + 2 * h->Nc) * h->rl_stride))) return rc;
         if ((rc = dev_alloc(h, &h->d_cimg_r, (size_t)(2 * h->Nc) * h->rl_stride))) return rc;
@@ -584,7 +611,7 @@ static int create_dense(const jq_problem* p, jq_handle* h)
     size_t budget = (size_t)1 << 30;
     if (h->opt.has(O_STREAM_BYTES) && h->opt.get(O_STREAM_BYTES) > 0) budget = (size_t)h->opt.get(O_STREAM_BYTES);
     // largest operator image of any kernel family the handle may use (slab, cooperative, lane, row-lane)
-    const long long img_elems = std::max(std::max(h->mat_elems, h->mat_elems_c), std::max(h->lane_stride, h->rl_stride));
+    const long long img_elems = std::max(std::max(std::max(h->mat_elems, h->mat_elems_c), std::max(h->lane_stride, h->rl_stride)), h->dq_max_quads > 0 ? (long long)JQ_DQ_ELEMS : 0LL);
     const size_t per_tp = 2 * (size_t)img_elems * sizeof(double);
     long long cs = ((long long)(budget / per_tp) - 1) / 2;
     cs = std::max<long long>(1, std::min<long long>(cs, h->nsteps));

@@ -296,13 +296,17 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
                                   (size_t)std::max(2, h->NcK + (h->NcK + 1) / 2) * h->NT * 64 * 8 + (size_t)2 * h->NT * 64 * 8 <= 163840;
     bool cq = !imr && !lane && !rl && (!wfull || wfull_cq) && h->solver_id == 1 && h->cq_max_quads > 0 && nquads_used <= h->cq_max_quads &&
               !h->opt.has(O_QUAD8);      // (quad8 asks for a quad-layout variant explicitly)
+    // ... and their DENSE policy (round 6): 17 .. 32 levels without the structure, Neumann solver, Diagonal weights -- one-workgroup kernels
+    // only (no two-quad forward variant, no split backward sweep)
+    const bool cq_dn = !cq && !imr && !lane && !rl && !wfull && h->solver_id == 1 && h->dq_max_quads > 0 && nquads_used <= h->dq_max_quads;
+    if (cq_dn) cq = true;
     const int qps = h->parts > 1 ? 4 : (h->sps * h->N + 3) / 4;      // column quads of a full slab
     // ... and of the implicit-midpoint integrator (jq_cq_imr_kernels.h): N = 4, one workgroup of NT waves per evaluation
     const bool imr_cq = imr_quad && h->N == 4 && h->parts == 1 && h->cq_max_quads > 0 && nquads_used <= h->cq_max_quads &&
                         h->opt.on(O_IMR_CQ);
     // more column quads than CUs: the forward sweep takes two quads per workgroup (one round of workgroups at ~ 1.5 x the time
     // instead of two rounds; option cq_fwd2=0: one quad per workgroup, =1: always two)
-    const bool cq_fwd2 = cq && !wfull && (h->opt.has(O_CQ_FWD2) ? h->opt.on(O_CQ_FWD2) : nquads_used > h->num_cu);
+    const bool cq_fwd2 = cq && !cq_dn && !wfull && (h->opt.has(O_CQ_FWD2) ? h->opt.on(O_CQ_FWD2) : nquads_used > h->num_cu);
     // single evaluations and small ensembles: the backward sweep on three workgroups (CUs) per column quad -- state re-integration,
     // adjoint step, trace products, pipelined through a ring in global memory (jq_cq_split_kernels.h).  All 3 x quads workgroups must
     // be resident at once (groups of 8 quads: 24 workgroups); option cq3=0: the one-workgroup kernel
@@ -319,7 +323,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     GateHold gate_hold;
     bool cq3 = false;
     int cq_nr = 0;      // workgroups per column quad of the split backward sweep
-    if ((cq || imr_cq) && adjoint) {
+    if ((cq || imr_cq) && !cq_dn && adjoint) {
         const char* why = nullptr;
         cq_nr = 3 * nq_pad <= h->num_cu ? 3 : (cq && 2 * nq_pad <= h->num_cu && !(c3_set && c3_v == 3)) ? 2 : 0;
         // The consumer roles read the state the sweep starts from out of the state file (the carry of the trace products, first chunk
@@ -369,7 +373,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     if (qs_on && quad && !imr && spw == 1 && !wfull && qsplit_lds(h, 4) <= 163840) qs_qw = 4;      // (!imr: the implicit-midpoint quad kernels also run with spw = 1)
     // (option qsplit=2: qw = 2 for every batch of the cooperative-quad plan that does not take the three-workgroup kernels -- tests)
     const bool qs_force2 = qs_set && h->opt.get(O_QSPLIT) == 2;
-    if (qs_on && cq && !cq3 && !wfull && ((nquads_used > h->num_cu && 2 * nslabs <= h->num_cu) || qs_force2) && qsplit_lds(h, 2) <= 163840) qs_qw = 2;
+    if (qs_on && cq && !cq_dn && !cq3 && !wfull && ((nquads_used > h->num_cu && 2 * nslabs <= h->num_cu) || qs_force2) && qsplit_lds(h, 2) <= 163840) qs_qw = 2;
     const bool qsplit = qs_qw > 0;
     const int qs_blocks = qsplit ? (4 * nslabs + qs_qw - 1) / qs_qw : 0;
     if (qsplit) {
@@ -408,7 +412,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
              : imr_rl ? select_rowlane_imr_kernels(h, rl_split, &kfwd, &kbwd)
              : rl ? select_rowlane_kernels(h, rl_split3 ? 3 : rl_split ? 2 : 1, hist_r != nullptr, &kfwd, &kbwd)
              : lane ? select_lane_kernels(h, &kfwd, &kbwd, &klinit, &klterm)
-                  : cq ? select_cq_kernels(h, cq_fwd2, cq_nr, wfull, &kfwd, &kbwd)
+                  : cq ? select_cq_kernels(h, cq_fwd2, cq_nr, wfull, cq_dn, &kfwd, &kbwd)
                   : coop ? select_coop_kernels(h, &kfwd, &kbwd) : quad ? (wfull ? select_quad_w_kernels(h, &kfwd, &kbwd) : select_quad_kernels(h, spw, &kfwd, &kbwd)) : select_kernels(h, &kfwd, &kbwd);
     if (rc) return rc;
     if (qsplit && (rc = select_qsplit_kernel(h, qs_qw, &kbwd))) return rc;
@@ -424,8 +428,8 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     // per-step trace records: one per wave (cooperative, lane, row-lane, implicit-midpoint kernels) or one per workgroup
     // (slab / quad kernels: summed over the workgroup's waves in LDS)
     const int trace_rows = qsplit ? qs_blocks : imr_parts ? nsamples * h->NT : imr_cq ? nslabs * qps * h->NT : cq ? nslabs * qps : (lane || rl) ? nblocks : huge ? nslabs * JQ_HUGE_WAVES : coop ? nslabs * h->NT : imr_quad ? nslabs * JQ_WAVES : nblocks;
-    const long long stride = rl ? h->rl_stride : lane ? h->lane_stride : coop ? h->mat_elems_c : h->mat_elems;
-    const double* himg = rl ? h->d_himg_r : lane ? h->d_himg_l : coop ? h->d_himg_c : h->d_himg;
+    const long long stride = cq_dn ? (long long)JQ_DQ_ELEMS : rl ? h->rl_stride : lane ? h->lane_stride : coop ? h->mat_elems_c : h->mat_elems;
+    const double* himg = cq_dn ? h->d_himg_dq : rl ? h->d_himg_r : lane ? h->d_himg_l : coop ? h->d_himg_c : h->d_himg;
     const size_t state_doubles = rl ? (size_t)JQ_ROWLANE_ROWS * nwaves_rl * 64
                                     : lane ? (size_t)JQ_LANE_ROWS(h->lane_np) * ncols : (size_t)nslabs * h->state_stride;
     const size_t colinfo_doubles = (lane || rl) ? (size_t)2 * ncols : (size_t)nslabs * 32;
@@ -502,7 +506,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     const double dt = h->T / h->nsteps;
     PropArgs a;
     memset(&a, 0, sizeof a);
-    const double* cimg_base = rl ? h->d_cimg_r : lane ? h->d_cimg_l : coop ? h->d_cimg_c : h->d_cimg;      // (control-group order)
+    const double* cimg_base = cq_dn ? h->d_cimg_dq : rl ? h->d_cimg_r : lane ? h->d_cimg_l : coop ? h->d_cimg_c : h->d_cimg;      // (control-group order)
     a.stream = h->d_stream; a.cimg = cimg_base; a.state = h->d_state; a.colinfo = h->d_colinfo;
     a.traces = h->d_traces;
     a.tabs = h->d_tabs; a.stride = stride; a.pieces = (int)(stride * 8 / 1024); a.nslots = h->nslots; a.m = h->m;
@@ -821,7 +825,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     h->timing.svts = (long long)nsamples * h->N * h->nsteps;
     h->timing.kernel_family = imr_cq ? 9 : cq ? 8 : imr_quad ? 7 : imr_coop ? 5 : imr ? 4 : rl ? 3 : lane ? 2 : coop ? 1 : quad ? 6 : 0;
     h->timing.kernel_size = rl ? h->rl_npj : lane ? h->lane_np : h->NT;
-    h->timing.kernel_band = (rl || lane) ? 0 : coop ? h->BWc : (quad || cq) ? JQ_BW_T4Q : h->BW;
+    h->timing.kernel_band = (rl || lane) ? 0 : coop ? h->BWc : cq_dn ? 10 /* dense blocks on the cooperative-quad kernels */ : (quad || cq) ? JQ_BW_T4Q : h->BW;
     h->timing.kernel_variant = cq3 ? cq_nr : qsplit ? 20 + qs_qw : (rl && rl_split3) ? 33 : (rl && rl_split) ? 32 : 0;      // (workgroups per column quad in the backward sweep of the cooperative-quad kernels)
     h->timing.ms_allreduce = 0.0;
     h->timing.ms_shard_min = h->timing.ms_shard_max = h->timing.ms_total;

@@ -186,6 +186,26 @@ static void column_image(const double* A, int Ntot, int N, int NP, double* img)
 }
 
 // [16][NPJ] row-major image of a column-major Ntot x Ntot matrix (row-lane kernels), zero padded
+// Dense policy of the cooperative-quad kernels (jq_cq_kernels.h CoopQ<2, true>; 17 <= Ntot <= 32): per 16-row block mt eight operand
+// registers of 64 lanes -- rotation s = 0 .. 3 of the block's own tile (mt, mt), then of the tile (mt, 1 - mt).  Lane 16 k + 4 b + i of
+// rotation s holds M[16 mt + 4 b + i][16 t' + 4 ((b - s) mod 4) + k]: the A operand of the v_mfma_f64_4x4x4_4b whose B operand is the state
+// register of block t' rotated by 4 s lanes inside each 16-lane row.  Rows / columns beyond Ntot: zero.
+#define JQ_DQ_ELEMS (2 * 8 * 64)
+static void dq_image(const double* M, int Ntot, double* img)
+{
+    std::fill_n(img, JQ_DQ_ELEMS, 0.0);
+    for (int mt = 0; mt < 2; ++mt)
+        for (int half = 0; half < 2; ++half) {
+            const int tp = half == 0 ? mt : 1 - mt;
+            for (int s = 0; s < 4; ++s)
+                for (int k = 0; k < 4; ++k)
+                    for (int b = 0; b < 4; ++b)
+                        for (int i = 0; i < 4; ++i) {
+                            const int row = 16 * mt + 4 * b + i, col = 16 * tp + 4 * ((b - s + 4) % 4) + k;
+                            if (row < Ntot && col < Ntot) img[(size_t)((mt * 8 + half * 4 + s) * 64) + 16 * k + 4 * b + i] = M[row + (size_t)Ntot * col];
+                        }
+        }
+}
 static void rowlane_image(const double* M, int Ntot, int NPJ, double* img)
 {
     for (int i = 0; i < Ntot; ++i)

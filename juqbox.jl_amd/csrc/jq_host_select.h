@@ -68,8 +68,8 @@ static int select_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel_t* bwd)
     extern template __global__ void k_backward<nt, JQ_BW_T4Q, 3, false, false, true, true>(PropArgs);
 JQ_DECLQ(1) JQ_DECLQ(2) JQ_DECLQ(3) JQ_DECLQ(4) JQ_DECLQ(5) JQ_DECLQ(6) JQ_DECLQ(7) JQ_DECLQ(8)
 #undef JQ_DECLQ
-template <int NT, bool MODD, int NS, bool WLR = false> __global__ void k_forward_cq(PropArgs);    // jq_cq_kernels.h (own translation units); NS: column quads per workgroup; WLR: full (real, low-rank) leakage weights
-template <int NT, bool MODD, bool ORD, bool WLR = false> __global__ void k_backward_cq(PropArgs);
+template <int NT, bool MODD, int NS, bool WLR = false, bool DN = false> __global__ void k_forward_cq(PropArgs);    // jq_cq_kernels.h (own translation units); NS: column quads per workgroup; WLR: full (real, low-rank) leakage weights
+template <int NT, bool MODD, bool ORD, bool WLR = false, bool DN = false> __global__ void k_backward_cq(PropArgs);
 template <int NT, bool MODD, bool ORD, int NR = 3, bool WLR = false> __global__ void k_backward_cq3(PropArgs);    // jq_cq_split_kernels.h: three (NR = 2: two) workgroups per column quad
 #define JQ_DECLCQ(nt)                                                      \
     extern template __global__ void k_forward_cq<nt, false, 1>(PropArgs);  \
@@ -104,6 +104,10 @@ template <int NT, bool MODD, bool ORD, int NR = 3, bool WLR = false> __global__ 
     extern template __global__ void k_backward_cq3<nt, true, true, 2>(PropArgs);
 JQ_DECLCQ(1) JQ_DECLCQ(2) JQ_DECLCQ(3) JQ_DECLCQ(4) JQ_DECLCQ(5) JQ_DECLCQ(6) JQ_DECLCQ(7)
 #undef JQ_DECLCQ
+extern template __global__ void k_forward_cq<2, false, 1, false, true>(PropArgs);      // the dense policy (17 .. 32 levels without the structure)
+extern template __global__ void k_forward_cq<2, true, 1, false, true>(PropArgs);
+extern template __global__ void k_backward_cq<2, false, false, false, true>(PropArgs);
+extern template __global__ void k_backward_cq<2, true, false, false, true>(PropArgs);
 // (instantiated for even and odd numbers of Neumann terms: the parities of the LDS exchange are compile-time constants)
 // fwd2: the forward kernel with two column quads per workgroup (grid = 2 * nslabs); bwd3: the backward sweep on three workgroups per
 // quad (k_backward_cq3)
@@ -115,10 +119,16 @@ static bool cq_ord(const jq_handle* h)
     for (int q = 0; q < h->Nc && ord; ++q) ord = (h->bw_trace[q] == (1 << q));
     return ord;
 }
-static int select_cq_kernels(jq_handle* h, bool fwd2, int bwd_nr, bool wlr, prop_kernel_t* fwd, prop_kernel_t* bwd)      // bwd_nr: workgroups per quad in the backward sweep (0 / 1: one); wlr: full (real, low-rank) leakage weights
+static int select_cq_kernels(jq_handle* h, bool fwd2, int bwd_nr, bool wlr, bool dense, prop_kernel_t* fwd, prop_kernel_t* bwd)      // bwd_nr: workgroups per quad in the backward sweep (0 / 1: one); wlr: full (real, low-rank) leakage weights; dense: no structure, NT = 2
 {
     const bool bwd3 = bwd_nr == 3, bwd2 = bwd_nr == 2;
     const bool modd = (h->m > 0 ? h->m : 0) & 1;
+    if (dense) {
+        if (h->NT != 2 || wlr || fwd2 || bwd3 || bwd2) return fail(h, JQ_EHIP, "internal error: dense cooperative-quad kernels selected for a plan they do not exist for");
+        *fwd = modd ? k_forward_cq<2, true, 1, false, true> : k_forward_cq<2, false, 1, false, true>;
+        *bwd = modd ? k_backward_cq<2, true, false, false, true> : k_backward_cq<2, false, false, false, true>;
+        return JQ_OK;
+    }
     const bool ord = cq_ord(h);
 #define JQ_PICKCQ(nt)                                                              \
     if (h->NT == nt && wlr) {                                                      \

@@ -46,6 +46,12 @@ template __global__ void k_backward_cq3<JQ_NT, false, false, 2, true>(PropArgs);
 template __global__ void k_backward_cq3<JQ_NT, false, true, 2, true>(PropArgs);
 template __global__ void k_backward_cq3<JQ_NT, true, false, 2, true>(PropArgs);
 template __global__ void k_backward_cq3<JQ_NT, true, true, 2, true>(PropArgs);
+#if JQ_NT == 2      // the dense policy: 17 .. 32 levels without the 4 x 4 x n structure (jq_cq_kernels.h CoopQ<2, true>)
+template __global__ void k_forward_cq<2, false, 1, false, true>(PropArgs);
+template __global__ void k_forward_cq<2, true, 1, false, true>(PropArgs);
+template __global__ void k_backward_cq<2, false, false, false, true>(PropArgs);
+template __global__ void k_backward_cq<2, true, false, false, true>(PropArgs);
+#endif
 #elif JQ_VARIANT == 12  // quad layout, backward sweep split over two waves per column quad (mid-size ensembles)
 #include "jq_quad_split_kernels.h"
 template __global__ void k_backward_qsplit<JQ_NT, false, 4>(PropArgs);      // (four quads = one slab per workgroup: two waves per SIMD)

@@ -18,7 +18,7 @@ enum JqOpt {
     O_T4, O_OD, O_T4BIG, O_FORCE_DENSE, O_WINDOW, O_LANE, O_LANE_MIN, O_LANE_MAX, O_ROWLANE_MAX, O_COOP_MAX, O_QUAD, O_CQ, O_EMBED,
     O_STREAM_BYTES, O_CHUNK_STEPS, O_BATCH,
     // ---- per evaluation -------------------------------------------------------------------------------------------------
-    O_NOSPLIT, O_QUAD8, O_CQ_W, O_IMR_CQ, O_IMR_CQ2, O_CQ_FWD2, O_CQ3, O_QSPLIT, O_RL_SPLIT, O_JAC_WG, O_TRACE_BYTES, O_NO_UNI, O_NO_ORD,
+    O_DQ, O_NOSPLIT, O_QUAD8, O_CQ_W, O_IMR_CQ, O_IMR_CQ2, O_CQ_FWD2, O_CQ3, O_QSPLIT, O_RL_SPLIT, O_JAC_WG, O_TRACE_BYTES, O_NO_UNI, O_NO_ORD,
     O_QS_RIDE, O_CQ_GENERIC_TRACES, O_WLR_SC, O_RCCL_SELFCHECK, O_MULTI_SAME_DEVICE, O_CQ3_RDV_US, O_CQ3_WAIT_MS,
     // ---- test hooks (results unchanged) ---------------------------------------------------------------------------------
     O_DEBUG, O_CQ3_FAULT,
@@ -55,6 +55,7 @@ static const JqOptDesc g_jq_opt[O_COUNT] = {
     {"stream_bytes", JQ_OPT_UNSET, JQ_OPT_PLAN, "bytes of the operator tile stream of one chunk (default 1 GiB)"},
     {"chunk_steps", JQ_OPT_UNSET, JQ_OPT_PLAN, "time steps per chunk (default: what the tile stream holds)"},
     {"batch", JQ_OPT_UNSET, JQ_OPT_PLAN | JQ_OPT_EXP, "batched staging of B time steps per DMA burst (measured: no gain)"},
+    {"dq", 1, JQ_OPT_PLAN, "0: no dense cooperative-quad kernels (17 .. 32 levels without the 4 x 4 x n structure: small batches on the cooperative kernels)"},
     {"nosplit", 0, 0, "1: evaluate an ensemble as ONE batch even when full rounds + a remainder on other kernels would be faster"},
     {"quad8", JQ_OPT_UNSET, 0, "force 1 / 2 / 3 slabs per quad-layout workgroup (value 0 / 1 / 2)"},
     {"cq_w", 1, 0, "0: full leakage weights that fit four slots on the quad-layout kernels instead of the cooperative-quad ones"},

@@ -95,6 +95,8 @@ struct jq_handle {
     bool in_split = false;      // run_eval is evaluating one part of a split batch
     double* d_pk2 = nullptr;    // packed result of the first part of a split batch
     size_t cap_pk2 = 0;
+    int dq_max_quads = 0;       // no structure, 17 .. 32 levels: batches of at most this many column quads on the DENSE cooperative-quad kernels (round 6)
+    double *d_himg_dq = nullptr, *d_cimg_dq = nullptr;      // their operator images (jq_host_images.h dq_image), JQ_DQ_ELEMS doubles each
     int cq_max_quads = 0;       // JQ_BW_T4 structure: batches of at most this many column quads (4 columns) run on the cooperative-quad
                                 // (latency) kernels, one workgroup of NT waves per quad (0: never)
     int quad_max_slabs = 0;     // JQ_BW_T4 structure: batches of at most this many slabs may use the quad-layout kernels (0: never)

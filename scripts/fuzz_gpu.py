@@ -113,7 +113,7 @@ def run(n_cases=50, seed=1, verbose=True):
         if os.environ.get("FUZZ_FOCUS") == "slab":
             imr = False
             mode = "auto"
-            env.update({"JQ_COOP_MAX": "0", "JQ_QUAD": "0", "JQ_CQ": "0", "JQ_LANE": "0", "JQ_ROWLANE_MAX": "0"})
+            env.update({"JQ_COOP_MAX": "0", "JQ_QUAD": "0", "JQ_CQ": "0", "JQ_DQ": "0", "JQ_LANE": "0", "JQ_ROWLANE_MAX": "0"})
         if imr and mode == "JQ_COOP_MAX=0":
             mode = "auto"           # (the cooperative kernels are the only implicit-midpoint path for Ntot > 16)
         if mode != "auto":

@@ -166,6 +166,7 @@ def test_random_problem_matches_oracle(jq, cfg, mode):
     if mode in ("slab", "slab-od"):
         opts["coop_max"] = 0
         opts["lane"] = 0
+        opts["dq"] = 0      # (round 6: two tile rows without the structure would take the dense cooperative-quad kernels)
     if mode in ("slab", "slab-od", "coop"):
         opts["quad"] = 0
     if mode == "slab-od":

@@ -314,3 +314,28 @@ def test_rowlane_ring_with_short_chunks_and_every_term_dispatch(jq, Ntot, N, Nc,
         t = check(jq, p, pcof, wa, rng, ensembles=(3,), history=(opts == {}))
         assert t["kernel_family"] == 3 and t["kernel_variant"] == (0 if opts.get("rl_split") == 0 else 33), t
         wa.close()
+
+
+# ---- (8) the dense policy of the cooperative-quad kernels: 17 .. 32 levels without the 4 x 4 x n structure ----------------------------------
+
+@pytest.mark.parametrize("Ntot,N,Nc,m,oft,structure", [(17, 4, 1, 3, 1, False), (20, 3, 2, 4, 3, False), (25, 4, 3, 5, 2, False), (32, 4, 2, 6, 1, False),
+                                                       (32, 2, 4, 1, 3, False), (27, 7, 2, 2, 1, True), (24, 16, 1, 3, 3, "od"), (30, 4, 2, 7, 2, False)])
+def test_dense_cooperative_quad_kernels_match_the_oracle(jq, Ntot, N, Nc, m, oft, structure):
+    """Round 6: problems with two 16-row blocks and NO 4 x 4 x n structure (two five-level subsystems, operators in an eigenbasis, ...) ran their
+    single evaluations on the cooperative kernels at 26 us per time step.  The cooperative-quad kernels now take them with a DENSE product
+    (four v_mfma_f64_4x4x4_4b per 16 x 16 tile on the state register and its three lane rotations, jq_cq_kernels.h CoopQ<2, true>): every
+    level count 17 .. 32, one to four controls, even and odd numbers of Neumann terms (the parities of the LDS exchange), all three objective
+    types (two backward passes), N < 4, N = 4 and N > 4 (several column quads per evaluation), chunks of odd length, ensembles with a
+    ragged last slab, the state history -- against the oracle; option dq=0 gives the cooperative kernels back."""
+    rng = np.random.default_rng(6800 + 31 * Ntot + m)
+    p, pcof = random_problem(jq, rng, Ntot, N, Nc, 2, 11, m, oft, structure)
+    for opts in ({}, {"chunk_steps": 3}, {"chunk_steps": 4}):
+        wa = jq.Working_Arrays_HIP(p, pcof.size, options=opts)
+        t = check(jq, p, pcof, wa, rng, ensembles=(3, 9), history=(opts == {}))
+        # (four controls per backward sweep: their eight constant images do not fit the LDS next to the window ring -- cooperative kernels)
+        assert (t["kernel_family"], t["kernel_size"], t["kernel_band"]) == ((8, 2, 10) if Nc <= 3 else (1, 2, 1)), t
+        wa.close()
+    wa = jq.Working_Arrays_HIP(p, pcof.size, options={"dq": 0})
+    t = check(jq, p, pcof, wa, rng)
+    assert t["kernel_family"] == 1, t
+    wa.close()
