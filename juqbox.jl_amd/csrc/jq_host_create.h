@@ -491,7 +491,7 @@ static int create_dense(const jq_problem* p, jq_handle* h)
         {
             const long long win = (2LL * JQ_WIN_TPS + 2LL * h->NcK) * JQ_DQ_ELEMS * 8;
             const long long tail = 32LL * h->NT * 8 + 6LL * (h->NT + 2) * 64 * 8 + (long long)std::max(2, h->NcK + (h->NcK + 1) / 2) * h->NT * 64 * 8;      // (run_eval: lds_cq)
-            h->dq_max_quads = (h->NT == 2 && h->BW != JQ_BW_T4 && !h->big && !h->huge && !h->is_emb && win + tail <= 163840 && h->opt.on(O_DQ)) ? 2 * prop.multiProcessorCount : 0;
+            h->dq_max_quads = (h->NT == 2 && h->BW != JQ_BW_T4 && !h->big && !h->huge && !h->is_emb && win + tail <= 163840 && h->opt.on(O_DQ)) ? 3 * prop.multiProcessorCount : 0;      // (three rounds of them, 3 x 16 ms per 2 000 steps, still beat one round of the cooperative kernels, 52 ms: profiles/r06_midsize_single.txt (g))
         }
         if (h->opt.has(O_BATCH)) {      // (experiment builds only: jq_options.h)
             const int v = (int)h->opt.get(O_BATCH);
