@@ -25,13 +25,14 @@
 #pragma once
 #include "jq_cq_split_kernels.h"
 
-template <int NT>
+// (DN: the dense policy of CoopQ -- two 16-row blocks without the structure, round 6)
+template <int NT, bool DN = false>
 struct CqImr {
-    typedef typename CoopQ<NT>::Op Op;
-    typedef typename CoopQ<NT>::Sh Sh;
-    typedef typename CoopQ<NT>::Nb Nb;
-    static constexpr int CHS = CoopQ<NT>::CHS, PAR = CoopQ<NT>::PAR;
-    CoopQ<NT>* c;
+    typedef typename CoopQ<NT, DN>::Op Op;
+    typedef typename CoopQ<NT, DN>::Sh Sh;
+    typedef typename CoopQ<NT, DN>::Nb Nb;
+    static constexpr int CHS = CoopQ<NT, DN>::CHS, PAR = CoopQ<NT, DN>::PAR;
+    CoopQ<NT, DN>* c;
     jq_lds_double* x0;      // front pad block of channel 0 in parity 0, this lane (block w of a channel: + (w + 1) * 64)
     Op K, S;                // my block of the midpoint operators of this step (pre-scaled by h/2)
     double cw;              // h/2 * eps * ws[row] of this lane
@@ -58,13 +59,15 @@ struct CqImr {
         // (the diagonal shift of K, src/ipopt_interface.jl:41-44, is part of K.a: fold_shift)
         return r;
     }
-    __device__ __forceinline__ void fold_shift() { K.a += cwa; }      // (call after loading K; cwa = 0 without an ensemble shift)
+    __device__ __forceinline__ void fold_shift()      // (call after loading K; cwa = 0 without an ensemble shift)
+    {
+        if constexpr (DN) K.ao[0] += cwa;      // (rotation 0 of the own tile: lane 16 k + 4 b + i holds M[4 b + i][4 b + k] -- the same diagonal lanes)
+        else K.a += cwa;
+    }
     // ... and the (i, i+-16) couplings with the neighbours' blocks of the publication at LDS offset po
     __device__ __forceinline__ void nbr(Acc& r, int po) const
     {
-        Nb nu, nv;
-        nu.b = c->xb[po], nu.a = c->xb[po + 128];
-        nv.b = c->xb[po + CHS], nv.a = c->xb[po + CHS + 128];
+        const Nb nu = c->nbs_at(po), nv = c->nbs_at(po + CHS);
         r.au = c->nbr(r.au, S, nu);
         r.kv = c->nbr(r.kv, K, nv);
         r.av = c->nbr(r.av, K, nu);
@@ -188,13 +191,13 @@ struct CqImr {
     const int lane_ = s.lane_, wave = s.wave;                                                                                    \
     double* tab = (double*)(smem + a.lds_tab_off);                                                                               \
     for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[(i & ~15) + 4 * (i & 3) + ((i >> 2) & 3)] = a.tabs[i];            \
-    CoopQ<NT> c;                                                                                                                 \
+    CoopQ<NT, DN> c;                                                                                                             \
     c.setup(tab + 32 * NT, wave, lane_);        /* (reducer waves: chain 1, wave 0 / 1 -- they only read the exchange image) */  \
     c.ring.init(smem, a, wave + NT * s.chain, lane_, NT + 2);      /* (barrier inside: tables, zeroed exchange image) */         \
     c.ring.wave = wave, c.ring.nwaves = NT;     /* (from here on the block waves stage) */                                       \
     const double wdr = tab[16 * wave + s.g], wsr = tab[16 * NT + 16 * wave + s.g];                                               \
     double* st = a.state + (size_t)s.slab * a.state_stride;                                                                      \
-    CqImr<NT> m;                                                                                                                 \
+    CqImr<NT, DN> m;                                                                                                             \
     m.c = &c;                                                                                                                    \
     m.x0 = (jq_lds_double*)(tab + 32 * NT + lane_);                                                                              \
     m.cw = 0.5 * a.h * a.colinfo[(size_t)s.slab * 32 + s.col] * wsr;                                                             \
@@ -205,7 +208,7 @@ struct CqImr {
 
 // grid = 4 * nslabs (workgroup = column quad qd of slab blockIdx.x / 4 = one evaluation, N = 4), block = 64 * (NT + 2): NT block
 // waves and the two reducer waves
-template <int NT>
+template <int NT, bool DN = false>
 __global__ __launch_bounds__(64 * NT + 128) void k_forward_cq_imr(PropArgs a)
 {
     const CqSetup<NT> s = cq_setup<NT>(a);
@@ -252,11 +255,11 @@ __global__ __launch_bounds__(64 * NT + 128) void k_forward_cq_imr(PropArgs a)
 // Backward sweep (src/evalobjgrad.jl:1290-1336): state re-integration with h < 0, adjoint m_step! with forcing
 // -W (v + v_s) / T and the two gradient scalars of adjoint_grad_calc_m per control (:2660-2702) in the slots of the midpoint weights
 // of k_gradacc (jq_rowlane_imr_kernels.h): tr[3] = -(B + C)/4, tr[4] = (A + D)/4.  One trace record row per wave (its block's share).
-template <int NT>
+template <int NT, bool DN = false>
 __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq_imr(PropArgs a)
 {
-    typedef typename CoopQ<NT>::Sh Sh;
-    typedef typename CoopQ<NT>::Nb Nb;
+    typedef typename CoopQ<NT, DN>::Sh Sh;
+    typedef typename CoopQ<NT, DN>::Nb Nb;
     const CqSetup<NT> s = cq_setup<NT>(a);
     const int Nc = a.Ncoupled, ntr = Nc * JQ_NTR;
     const size_t trow = ((size_t)s.slab * a.qps + s.qd) * NT;      // first of my workgroup's NT record rows
@@ -299,9 +302,7 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq_imr(PropArgs a)
         const Sh shu = c.sh(su), shv = c.sh(sv);
         c.sync();
         m.par ^= 1;
-        Nb nsu, nsv;
-        nsu.b = c.xb[po], nsu.a = c.xb[po + 128];
-        nsv.b = c.xb[po + CHS], nsv.a = c.xb[po + CHS + 128];
+        const Nb nsu = c.nbs_at(po), nsv = c.nbs_at(po + CHS);
         double* tr = trw + (size_t)n * ntr;
         for (int qp = 0; qp < Nc; qp += 2) {
             double P[2] = {0.0, 0.0}, Q[2] = {0.0, 0.0};
@@ -831,6 +832,7 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq_imr3(PropArgs a)
         }
         return;
     }
+    constexpr bool DN = false;      // (the three-workgroup kernel exists for the 4 x 4 x n structure only)
     JQ_CQ_IMR_PROLOGUE
     (void)wsr;
     if (s.chain) {      // reducer waves: one solve and the publication barrier per time step (+ the start barrier of role 1, the last publication)

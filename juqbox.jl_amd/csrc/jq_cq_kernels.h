@@ -294,6 +294,17 @@ struct CoopQ {
             return n;
         }
     }
+    // ... at a run-time offset (doubles from xb to the block below mine) of the exchange image: the implicit-midpoint kernels
+    __device__ __forceinline__ Nb nbs_at(int po) const
+    {
+        if constexpr (DN) {
+            return rot(xb[po] + xb[po + 128]);
+        } else {
+            Nb n;
+            n.b = xb[po], n.a = xb[po + 128];
+            return n;
+        }
+    }
     __device__ __forceinline__ double nbr(double acc, const Op& o, const Nb& n) const
     {
         if constexpr (DN) {

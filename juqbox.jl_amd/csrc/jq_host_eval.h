@@ -229,7 +229,11 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     const bool imr_rl = imr && h->rl_npj > 0 && h->N <= 4;
     // JQ_BW_T4 structure with an evaluation's columns inside one quad: quad-layout kernels (jq_quad_imr_kernels.h)
     // (any batch size: one workgroup per slab, rounds of one workgroup per CU)
-    const bool imr_quad = imr && !imr_rl && h->quad_max_slabs > 0 && (h->N == 1 || h->N == 2 || h->N == 4);
+    // (round 6: two 16-row blocks WITHOUT the structure, N = 4: the dense policy of the cooperative-quad kernels -- routed like the
+    //  JQ_BW_T4 plans' latency path: slab state file, implicit-midpoint terminal kernel, one workgroup per evaluation)
+    const bool imr_dq = imr && !imr_rl && h->quad_max_slabs == 0 && h->dq_max_quads > 0 && h->N == 4 && h->parts == 1 && h->wrank == 0 &&
+                        (ncols_used + 3) / 4 <= h->dq_max_quads && h->opt.on(O_IMR_CQ);
+    const bool imr_quad = imr && !imr_rl && ((h->quad_max_slabs > 0 && (h->N == 1 || h->N == 2 || h->N == 4)) || imr_dq);
     const bool imr_coop = imr && !imr_rl && !imr_quad;
     const bool imr_parts = imr_coop && h->parts > 1;      // N > 16: one workgroup per evaluation, its 16-column parts in turn
     // (both images of a step resident in LDS when they fit; dense 96 x 96 operators: the <6, 5> instantiation that reads them from
@@ -302,8 +306,8 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     if (cq_dn) cq = true;
     const int qps = h->parts > 1 ? 4 : (h->sps * h->N + 3) / 4;      // column quads of a full slab
     // ... and of the implicit-midpoint integrator (jq_cq_imr_kernels.h): N = 4, one workgroup of NT waves per evaluation
-    const bool imr_cq = imr_quad && h->N == 4 && h->parts == 1 && h->cq_max_quads > 0 && nquads_used <= h->cq_max_quads &&
-                        h->opt.on(O_IMR_CQ);
+    const bool imr_cq = imr_dq || (imr_quad && h->N == 4 && h->parts == 1 && h->cq_max_quads > 0 && nquads_used <= h->cq_max_quads &&
+                                   h->opt.on(O_IMR_CQ));
     // more column quads than CUs: the forward sweep takes two quads per workgroup (one round of workgroups at ~ 1.5 x the time
     // instead of two rounds; option cq_fwd2=0: one quad per workgroup, =1: always two)
     const bool cq_fwd2 = cq && !cq_dn && !wfull && (h->opt.has(O_CQ_FWD2) ? h->opt.on(O_CQ_FWD2) : nquads_used > h->num_cu);
@@ -323,7 +327,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     GateHold gate_hold;
     bool cq3 = false;
     int cq_nr = 0;      // workgroups per column quad of the split backward sweep
-    if ((cq || imr_cq) && !cq_dn && adjoint) {
+    if ((cq || imr_cq) && !cq_dn && !imr_dq && adjoint) {
         const char* why = nullptr;
         cq_nr = 3 * nq_pad <= h->num_cu ? 3 : (cq && 2 * nq_pad <= h->num_cu && !(c3_set && c3_v == 3)) ? 2 : 0;
         // The consumer roles read the state the sweep starts from out of the state file (the carry of the trace products, first chunk
@@ -357,7 +361,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
         HIPCHK(h, hipMemsetAsync(h->d_cq3, 0, 64 * sizeof(double), h->stream));      // (the error word of the evaluation)
     }
     const bool imr_cq3 = imr_cq && cq3 && cq_nr == 3;
-    const bool imr_cq2 = imr_cq && !imr_cq3 && h->NT <= 6 && h->opt.on(O_IMR_CQ2) &&
+    const bool imr_cq2 = imr_cq && !imr_dq && !imr_cq3 && h->NT <= 6 && h->opt.on(O_IMR_CQ2) &&
                          cq_imr2_lds(h, (size_t)(2 * JQ_WIN_TPS + 2 * h->NcK) * h->mat_elems * 8) <= 163840;
     if (cq) spw = 0;
     const bool quad = spw > 0;
@@ -406,7 +410,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     prop_kernel_t kfwd, kbwd;
     lane_init_t klinit = nullptr;
     lane_term_t klterm = nullptr;
-    int rc = imr_cq ? select_cq_imr_kernels(h, imr_cq2, imr_cq3, &kfwd, &kbwd)
+    int rc = imr_cq ? select_cq_imr_kernels(h, imr_cq2, imr_cq3, imr_dq, &kfwd, &kbwd)
              : imr_quad ? select_quad_imr_kernels(h, &kfwd, &kbwd)
              : imr_coop ? (imr_parts ? select_coop_imr_parts_kernels(h, imr_hbm, &kfwd, &kbwd) : select_coop_imr_kernels(h, imr_hbm, &kfwd, &kbwd))
              : imr_rl ? select_rowlane_imr_kernels(h, rl_split, &kfwd, &kbwd)
@@ -428,8 +432,8 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     // per-step trace records: one per wave (cooperative, lane, row-lane, implicit-midpoint kernels) or one per workgroup
     // (slab / quad kernels: summed over the workgroup's waves in LDS)
     const int trace_rows = qsplit ? qs_blocks : imr_parts ? nsamples * h->NT : imr_cq ? nslabs * qps * h->NT : cq ? nslabs * qps : (lane || rl) ? nblocks : huge ? nslabs * JQ_HUGE_WAVES : coop ? nslabs * h->NT : imr_quad ? nslabs * JQ_WAVES : nblocks;
-    const long long stride = cq_dn ? (long long)JQ_DQ_ELEMS : rl ? h->rl_stride : lane ? h->lane_stride : coop ? h->mat_elems_c : h->mat_elems;
-    const double* himg = cq_dn ? h->d_himg_dq : rl ? h->d_himg_r : lane ? h->d_himg_l : coop ? h->d_himg_c : h->d_himg;
+    const long long stride = (cq_dn || imr_dq) ? (long long)JQ_DQ_ELEMS : rl ? h->rl_stride : lane ? h->lane_stride : coop ? h->mat_elems_c : h->mat_elems;
+    const double* himg = (cq_dn || imr_dq) ? h->d_himg_dq : rl ? h->d_himg_r : lane ? h->d_himg_l : coop ? h->d_himg_c : h->d_himg;
     const size_t state_doubles = rl ? (size_t)JQ_ROWLANE_ROWS * nwaves_rl * 64
                                     : lane ? (size_t)JQ_LANE_ROWS(h->lane_np) * ncols : (size_t)nslabs * h->state_stride;
     const size_t colinfo_doubles = (lane || rl) ? (size_t)2 * ncols : (size_t)nslabs * 32;
@@ -506,7 +510,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     const double dt = h->T / h->nsteps;
     PropArgs a;
     memset(&a, 0, sizeof a);
-    const double* cimg_base = cq_dn ? h->d_cimg_dq : rl ? h->d_cimg_r : lane ? h->d_cimg_l : coop ? h->d_cimg_c : h->d_cimg;      // (control-group order)
+    const double* cimg_base = (cq_dn || imr_dq) ? h->d_cimg_dq : rl ? h->d_cimg_r : lane ? h->d_cimg_l : coop ? h->d_cimg_c : h->d_cimg;      // (control-group order)
     a.stream = h->d_stream; a.cimg = cimg_base; a.state = h->d_state; a.colinfo = h->d_colinfo;
     a.traces = h->d_traces;
     a.tabs = h->d_tabs; a.stride = stride; a.pieces = (int)(stride * 8 / 1024); a.nslots = h->nslots; a.m = h->m;
@@ -523,7 +527,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     for (int q = 0; q < JQ_MAXNC; ++q) a.bw_trace[q] = q < h->Nc ? h->bw_trace[q] : 0;      // (first control group; the backward sweeps set their own)
     // dynamic LDS layout: [operator staging | tables wd, ws | (backward: carry, parking images)]
     // cooperative kernels: [two operator slots | tables wd, ws | two x exchange buffers]
-    const int batch = coop ? 0 : (quad || cq) ? -1 : h->batch;
+    const int batch = coop ? 0 : (quad || cq || imr_dq) ? -1 : h->batch;
     const size_t lds_stage = (coop && (h->NT > 6 || imr_hbm || (!imr_coop && coop_hbm(h->NT, h->BWc)))) ? 0      // operators are read from HBM, no LDS staging
                              : batch > 0   ? (size_t)2 * (2 * batch + 1) * 2 * stride * 8 + (size_t)2 * h->NcK * stride * 8
                              : batch < 0 ? (size_t)(2 * JQ_WIN_TPS + 2 * h->NcK) * stride * 8
@@ -825,7 +829,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     h->timing.svts = (long long)nsamples * h->N * h->nsteps;
     h->timing.kernel_family = imr_cq ? 9 : cq ? 8 : imr_quad ? 7 : imr_coop ? 5 : imr ? 4 : rl ? 3 : lane ? 2 : coop ? 1 : quad ? 6 : 0;
     h->timing.kernel_size = rl ? h->rl_npj : lane ? h->lane_np : h->NT;
-    h->timing.kernel_band = (rl || lane) ? 0 : coop ? h->BWc : cq_dn ? 10 /* dense blocks on the cooperative-quad kernels */ : (quad || cq) ? JQ_BW_T4Q : h->BW;
+    h->timing.kernel_band = (rl || lane) ? 0 : coop ? h->BWc : (cq_dn || imr_dq) ? 10 /* dense blocks on the cooperative-quad kernels */ : (quad || cq) ? JQ_BW_T4Q : h->BW;
     h->timing.kernel_variant = cq3 ? cq_nr : qsplit ? 20 + qs_qw : (rl && rl_split3) ? 33 : (rl && rl_split) ? 32 : 0;      // (workgroups per column quad in the backward sweep of the cooperative-quad kernels)
     h->timing.ms_allreduce = 0.0;
     h->timing.ms_shard_min = h->timing.ms_shard_max = h->timing.ms_total;

@@ -174,8 +174,8 @@ static int select_quad_imr_kernels(jq_handle* h, prop_kernel_t* fwd, prop_kernel
 #undef JQ_PICKQI
     return fail(h, JQ_EUNSUPPORTED, "unsupported Hilbert dimension");
 }
-template <int NT> __global__ void k_forward_cq_imr(PropArgs);      // jq_cq_imr_kernels.h (own translation units)
-template <int NT> __global__ void k_backward_cq_imr(PropArgs);
+template <int NT, bool DN = false> __global__ void k_forward_cq_imr(PropArgs);      // jq_cq_imr_kernels.h (own translation units)
+template <int NT, bool DN = false> __global__ void k_backward_cq_imr(PropArgs);
 template <int NT> __global__ void k_backward_cq_imr2(PropArgs);    // (state and adjoint chain on two sets of waves, NT <= 6)
 #define JQ_DECLCI(nt)                                                    \
     extern template __global__ void k_forward_cq_imr<nt>(PropArgs);      \
@@ -193,8 +193,16 @@ JQ_DECLCI(1) JQ_DECLCI(2) JQ_DECLCI(3) JQ_DECLCI(4) JQ_DECLCI(5) JQ_DECLCI(6)
 static size_t cq_imr2_lds(const jq_handle* h, size_t lds_stage) { return lds_stage + (size_t)32 * h->NT * 8 + (size_t)12 * (h->NT + 2) * 64 * 8 + 64; }
 // two: the backward sweep with the state and the adjoint chain on two sets of waves (NT <= 6, LDS permitting; option imr_cq2=0: the
 // one-set kernel of round 3)
-static int select_cq_imr_kernels(jq_handle* h, bool two, bool three, prop_kernel_t* fwd, prop_kernel_t* bwd)
+extern template __global__ void k_forward_cq_imr<2, true>(PropArgs);      // the dense policy (17 .. 32 levels without the structure)
+extern template __global__ void k_backward_cq_imr<2, true>(PropArgs);
+static int select_cq_imr_kernels(jq_handle* h, bool two, bool three, bool dense, prop_kernel_t* fwd, prop_kernel_t* bwd)
 {
+    if (dense) {
+        if (h->NT != 2 || two || three) return fail(h, JQ_EHIP, "internal error: dense implicit-midpoint cooperative-quad kernels selected for a plan they do not exist for");
+        *fwd = k_forward_cq_imr<2, true>;
+        *bwd = k_backward_cq_imr<2, true>;
+        return JQ_OK;
+    }
 #define JQ_PICKCI(nt)                            \
     if (h->NT == nt && three) {                  \
         *fwd = k_forward_cq_imr<nt>;             \

@@ -68,6 +68,10 @@ template __global__ void k_backward_cq_imr3<JQ_NT>(PropArgs);      // (three wor
 #if JQ_NT <= 6
 template __global__ void k_backward_cq_imr2<JQ_NT>(PropArgs);      // (state and adjoint chain on two sets of waves)
 #endif
+#if JQ_NT == 2      // the dense policy (17 .. 32 levels without the structure)
+template __global__ void k_forward_cq_imr<2, true>(PropArgs);
+template __global__ void k_backward_cq_imr<2, true>(PropArgs);
+#endif
 #elif JQ_VARIANT == 7
 #include "jq_quad_imr_kernels.h"
 template __global__ void k_forward_quad_imr<JQ_NT, 1>(PropArgs);

@@ -339,3 +339,40 @@ def test_dense_cooperative_quad_kernels_match_the_oracle(jq, Ntot, N, Nc, m, oft
     t = check(jq, p, pcof, wa, rng)
     assert t["kernel_family"] == 1, t
     wa.close()
+
+
+@pytest.mark.parametrize("Ntot,Nc,oft,structure", [(17, 1, 1, False), (25, 2, 3, False), (32, 3, 2, False), (28, 2, 1, True)])
+def test_dense_cooperative_quad_kernels_implicit_midpoint(jq, Ntot, Nc, oft, structure):
+    """... and the implicit-midpoint twins (k_*_cq_imr<2, true>; N = 4: one evaluation per column quad, the solver's stopping rule over the
+    whole evaluation): single evaluations, an ensemble with an ensemble shift (folded into the A operand of the own tile's rotation 0),
+    chunks, against the oracle at the solver's tolerance; option dq=0: the cooperative implicit-midpoint kernels."""
+    from oracle.oracle import Oracle
+    rng = np.random.default_rng(6900 + Ntot)
+    p, pcof = random_problem(jq, rng, Ntot, 4, Nc, 2, 13, 3, oft, structure)
+    p.Integrator_id = jq.Implicit_Midpoint
+    p.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER_M, max_iter=100, tol=1e-13, nrhs=4)
+    p.wmat = p.wmat_real.copy()
+    r = Oracle(p, use_sparse=False).traceobjgrad_imr(pcof, 100, 1e-13)
+    nodes, weights = 0.05 * rng.standard_normal(5), rng.random(5)
+    shift = 0.05 * rng.standard_normal(Ntot)
+    shift[0] = 0.0
+    # (a weighted ensemble with a diagonal perturbation = the weighted sum of the oracle's single evaluations)
+    inf, leak, g = 0.0, 0.0, np.zeros(pcof.size)
+    H0 = p.Hconst.copy()
+    for ep, wq in zip(nodes, weights):
+        p.Hconst = H0 + np.diag(ep * shift)
+        rr = Oracle(p, use_sparse=False).traceobjgrad_imr(pcof, 100, 1e-13)
+        inf, leak, g = inf + wq * rr["primaryobjf"], leak + wq * rr["secondaryobjf"], g + wq * rr["infidelgrad"]
+    p.Hconst = H0
+    for opts, fam in (({}, 9), ({"chunk_steps": 5}, 9), ({"dq": 0}, 5)):
+        wa = jq.Working_Arrays_M_HIP(p, pcof.size, options=opts)
+        objfv, tg, prim, sec, tinf, ig, lg = jq.traceobjgrad(pcof, p, wa, False, True)
+        t = wa.last_timing()
+        assert t["kernel_family"] == fam and (fam != 9 or t["kernel_band"] == 10), t
+        gn = np.linalg.norm(r["totalgrad"])
+        assert abs(prim - r["primaryobjf"]) <= 1e-10 and abs(sec - r["secondaryobjf"]) <= 1e-10 * max(abs(r["secondaryobjf"]), 1e-3)
+        assert np.linalg.norm(tg - r["totalgrad"]) <= 1e-10 * gn and np.linalg.norm(ig - r["infidelgrad"]) <= 1e-10 * gn
+        jq.eval_f_g_grad(pcof, p, wa, nodes, weights, True, shift=shift)
+        assert abs(p.last_infidelity - inf) <= 1e-10 * abs(inf) and abs(p.last_leak - leak) <= max(1e-10 * abs(leak), 1e-14)
+        assert np.linalg.norm(p.last_infidelity_grad - g) <= 1e-10 * np.linalg.norm(g)
+        wa.close()
