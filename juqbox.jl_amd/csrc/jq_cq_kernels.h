@@ -294,6 +294,17 @@ struct CoopQ {
             return n;
         }
     }
+    // ... from the two values themselves (the split kernels read them out of the state file / the hand-off ring; zeros beyond the edge blocks)
+    __device__ __forceinline__ Nb nb_make(double below, double above) const
+    {
+        if constexpr (DN) {
+            return rot(below + above);
+        } else {
+            Nb n;
+            n.b = below, n.a = above;
+            return n;
+        }
+    }
     // ... at a run-time offset (doubles from xb to the block below mine) of the exchange image: the implicit-midpoint kernels
     __device__ __forceinline__ Nb nbs_at(int po) const
     {

@@ -166,16 +166,17 @@ struct Cq3Hand {
 // profiles/r05_cq3_soak_load.txt (d).)  The same operations in the same order as the one-workgroup kernel's (k_backward_cq<.., WLR>):
 // bit-identical results.  (First version: the partial registers themselves through the ring, 12 more loads per step in the adjoint
 // waves: backward sweep 96 ms instead of 81.)
-template <int NT, bool MODD, bool ORD, int NR = 3, bool WLR = false>
+template <int NT, bool MODD, bool ORD, int NR = 3, bool WLR = false, bool DN = false>
 __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
 {
     static_assert(NR == 3 || NR == 2, "workgroups per column quad");
+    static_assert(!DN || (!WLR && !ORD), "dense policy (jq_cq_kernels.h CoopQ<2, true>): Diagonal weights, whole trace products");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KT = 4 * NT;
     constexpr int M = MODD ? 1 : 0;
-    typedef typename CoopQ<NT>::Sh Sh;
-    typedef typename CoopQ<NT>::Nb Nb;
-    typedef typename CoopQ<NT>::Op Op;
+    typedef typename CoopQ<NT, DN>::Sh Sh;
+    typedef typename CoopQ<NT, DN>::Nb Nb;
+    typedef typename CoopQ<NT, DN>::Op Op;
     const int role = ((int)blockIdx.x >> 3) % NR;
     const int quad = 8 * ((int)blockIdx.x / (8 * NR)) + ((int)blockIdx.x & 7);
     const CqSetup<NT> s = cq_setup<NT>(a, quad >> 2, quad & 3);
@@ -192,8 +193,8 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
     double* tab = (double*)(smem + a.lds_tab_off);
     for (int i = threadIdx.x; i < 32 * NT; i += blockDim.x) tab[(i & ~15) + 4 * (i & 3) + ((i >> 2) & 3)] = a.tabs[i];   // [block][g][r]
     if (role == 2 && s.chain) return;      // (the trace workgroup has no staging waves)
-    CoopQ<NT> c;
-    double* scratch = tab + 32 * NT + 2 * CoopQ<NT>::PAR;      // [NT][64] workgroup sums / [ngroups][NT][64] trace hand-off (role 2)
+    CoopQ<NT, DN> c;
+    double* scratch = tab + 32 * NT + 2 * CoopQ<NT, DN>::PAR;      // [NT][64] workgroup sums / [ngroups][NT][64] trace hand-off (role 2)
     Cq3Hand<NT> hd;
     hd.init(a, (size_t)quad, lane_);
     const int nst = a.nsteps_chunk;
@@ -258,9 +259,7 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
         if (a.first_chunk) {
             // carry_q = tr(vr' Hsym_q lambdai) at t = T (see k_backward): vr(T) and -lambda_i(T) from the state file
             const double u0 = st[s.foff], nb0 = st[(size_t)3 * KT * 64 + s.foff];
-            Nb nn;
-            nn.b = wave > 0 ? st[(size_t)3 * KT * 64 + s.foff - 256] : 0.0;
-            nn.a = wave + 1 < NT ? st[(size_t)3 * KT * 64 + s.foff + 256] : 0.0;
+            const Nb nn = c.nb_make(wave > 0 ? st[(size_t)3 * KT * 64 + s.foff - 256] : 0.0, wave + 1 < NT ? st[(size_t)3 * KT * 64 + s.foff + 256] : 0.0);
             const Sh sx = c.sh(nb0);
 #pragma unroll
             for (int q = 0; q < JQ_MAXNC; ++q)
@@ -276,11 +275,12 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
             e.u = hd.load(n, 0, wave), e.v05 = hd.load(n, 1, wave), e.un = hd.load(n, 2, wave);
             e.X = hd.load(n, 3, wave), e.nbn = hd.load(n, 4, wave), e.Bq = hd.load(n, 5, wave);
             const int wb = wave > 0 ? wave - 1 : wave, wa_ = wave + 1 < NT ? wave + 1 : wave;
-            e.nX.b = hd.load(n, 3, wb), e.nX.a = hd.load(n, 3, wa_);
-            e.nN.b = hd.load(n, 4, wb), e.nN.a = hd.load(n, 4, wa_);
-            e.nB.b = hd.load(n, 5, wb), e.nB.a = hd.load(n, 5, wa_);
-            if (wave == 0) e.nX.b = 0.0, e.nN.b = 0.0, e.nB.b = 0.0;
-            if (wave + 1 == NT) e.nX.a = 0.0, e.nN.a = 0.0, e.nB.a = 0.0;
+            const double xb_ = hd.load(n, 3, wb), xa_ = hd.load(n, 3, wa_), nb_ = hd.load(n, 4, wb), na_ = hd.load(n, 4, wa_);
+            const double bb_ = hd.load(n, 5, wb), ba_ = hd.load(n, 5, wa_);
+            const bool lo = wave == 0, hi = wave + 1 == NT;      // (zeros beyond the edge blocks)
+            e.nX = c.nb_make(lo ? 0.0 : xb_, hi ? 0.0 : xa_);
+            e.nN = c.nb_make(lo ? 0.0 : nb_, hi ? 0.0 : na_);
+            e.nB = c.nb_make(lo ? 0.0 : bb_, hi ? 0.0 : ba_);
             return e;
         };
         if (wave == 0) hd.wait(1, 1);
@@ -535,9 +535,7 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq3(PropArgs a)
         if (a.first_chunk) {
             // carry_q = tr(vr' Hsym_q lambdai) at t = T (see k_backward): vr(T) and -lambda_i(T) with its neighbouring blocks from the state file
             const double u0 = st[s.foff];
-            Nb nn;
-            nn.b = wave > 0 ? st[(size_t)3 * KT * 64 + s.foff - 256] : 0.0;
-            nn.a = wave + 1 < NT ? st[(size_t)3 * KT * 64 + s.foff + 256] : 0.0;
+            const Nb nn = c.nb_make(wave > 0 ? st[(size_t)3 * KT * 64 + s.foff - 256] : 0.0, wave + 1 < NT ? st[(size_t)3 * KT * 64 + s.foff + 256] : 0.0);
             const Sh sx = c.sh(nb);
 #pragma unroll
             for (int q = 0; q < JQ_MAXNC; ++q)

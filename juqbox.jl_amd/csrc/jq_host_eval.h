@@ -300,8 +300,8 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
                                   (size_t)std::max(2, h->NcK + (h->NcK + 1) / 2) * h->NT * 64 * 8 + (size_t)2 * h->NT * 64 * 8 <= 163840;
     bool cq = !imr && !lane && !rl && (!wfull || wfull_cq) && h->solver_id == 1 && h->cq_max_quads > 0 && nquads_used <= h->cq_max_quads &&
               !h->opt.has(O_QUAD8);      // (quad8 asks for a quad-layout variant explicitly)
-    // ... and their DENSE policy (round 6): 17 .. 32 levels without the structure, Neumann solver, Diagonal weights -- one-workgroup kernels
-    // only (no two-quad forward variant, no split backward sweep)
+    // ... and their DENSE policy (round 6): 17 .. 32 levels without the structure, Neumann solver, Diagonal weights (no two-quad forward
+    // variant)
     const bool cq_dn = !cq && !imr && !lane && !rl && !wfull && h->solver_id == 1 && h->dq_max_quads > 0 && nquads_used <= h->dq_max_quads;
     if (cq_dn) cq = true;
     const int qps = h->parts > 1 ? 4 : (h->sps * h->N + 3) / 4;      // column quads of a full slab
@@ -327,7 +327,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     GateHold gate_hold;
     bool cq3 = false;
     int cq_nr = 0;      // workgroups per column quad of the split backward sweep
-    if ((cq || imr_cq) && !cq_dn && !imr_dq && adjoint) {
+    if ((cq || imr_cq) && !imr_dq && adjoint) {
         const char* why = nullptr;
         cq_nr = 3 * nq_pad <= h->num_cu ? 3 : (cq && 2 * nq_pad <= h->num_cu && !(c3_set && c3_v == 3)) ? 2 : 0;
         // The consumer roles read the state the sweep starts from out of the state file (the carry of the trace products, first chunk

@@ -70,7 +70,7 @@ JQ_DECLQ(1) JQ_DECLQ(2) JQ_DECLQ(3) JQ_DECLQ(4) JQ_DECLQ(5) JQ_DECLQ(6) JQ_DECLQ
 #undef JQ_DECLQ
 template <int NT, bool MODD, int NS, bool WLR = false, bool DN = false> __global__ void k_forward_cq(PropArgs);    // jq_cq_kernels.h (own translation units); NS: column quads per workgroup; WLR: full (real, low-rank) leakage weights
 template <int NT, bool MODD, bool ORD, bool WLR = false, bool DN = false> __global__ void k_backward_cq(PropArgs);
-template <int NT, bool MODD, bool ORD, int NR = 3, bool WLR = false> __global__ void k_backward_cq3(PropArgs);    // jq_cq_split_kernels.h: three (NR = 2: two) workgroups per column quad
+template <int NT, bool MODD, bool ORD, int NR = 3, bool WLR = false, bool DN = false> __global__ void k_backward_cq3(PropArgs);    // jq_cq_split_kernels.h: three (NR = 2: two) workgroups per column quad
 #define JQ_DECLCQ(nt)                                                      \
     extern template __global__ void k_forward_cq<nt, false, 1>(PropArgs);  \
     extern template __global__ void k_forward_cq<nt, false, 2>(PropArgs);  \
@@ -108,6 +108,10 @@ extern template __global__ void k_forward_cq<2, false, 1, false, true>(PropArgs)
 extern template __global__ void k_forward_cq<2, true, 1, false, true>(PropArgs);
 extern template __global__ void k_backward_cq<2, false, false, false, true>(PropArgs);
 extern template __global__ void k_backward_cq<2, true, false, false, true>(PropArgs);
+extern template __global__ void k_backward_cq3<2, false, false, 3, false, true>(PropArgs);
+extern template __global__ void k_backward_cq3<2, true, false, 3, false, true>(PropArgs);
+extern template __global__ void k_backward_cq3<2, false, false, 2, false, true>(PropArgs);
+extern template __global__ void k_backward_cq3<2, true, false, 2, false, true>(PropArgs);
 // (instantiated for even and odd numbers of Neumann terms: the parities of the LDS exchange are compile-time constants)
 // fwd2: the forward kernel with two column quads per workgroup (grid = 2 * nslabs); bwd3: the backward sweep on three workgroups per
 // quad (k_backward_cq3)
@@ -124,9 +128,11 @@ static int select_cq_kernels(jq_handle* h, bool fwd2, int bwd_nr, bool wlr, bool
     const bool bwd3 = bwd_nr == 3, bwd2 = bwd_nr == 2;
     const bool modd = (h->m > 0 ? h->m : 0) & 1;
     if (dense) {
-        if (h->NT != 2 || wlr || fwd2 || bwd3 || bwd2) return fail(h, JQ_EHIP, "internal error: dense cooperative-quad kernels selected for a plan they do not exist for");
+        if (h->NT != 2 || wlr || fwd2) return fail(h, JQ_EHIP, "internal error: dense cooperative-quad kernels selected for a plan they do not exist for");
         *fwd = modd ? k_forward_cq<2, true, 1, false, true> : k_forward_cq<2, false, 1, false, true>;
-        *bwd = modd ? k_backward_cq<2, true, false, false, true> : k_backward_cq<2, false, false, false, true>;
+        *bwd = bwd3 ? (modd ? k_backward_cq3<2, true, false, 3, false, true> : k_backward_cq3<2, false, false, 3, false, true>)
+             : bwd2 ? (modd ? k_backward_cq3<2, true, false, 2, false, true> : k_backward_cq3<2, false, false, 2, false, true>)
+                    : (modd ? k_backward_cq<2, true, false, false, true> : k_backward_cq<2, false, false, false, true>);
         return JQ_OK;
     }
     const bool ord = cq_ord(h);

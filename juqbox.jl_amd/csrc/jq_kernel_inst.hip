@@ -51,6 +51,10 @@ template __global__ void k_forward_cq<2, false, 1, false, true>(PropArgs);
 template __global__ void k_forward_cq<2, true, 1, false, true>(PropArgs);
 template __global__ void k_backward_cq<2, false, false, false, true>(PropArgs);
 template __global__ void k_backward_cq<2, true, false, false, true>(PropArgs);
+template __global__ void k_backward_cq3<2, false, false, 3, false, true>(PropArgs);     // (... with the backward sweep on three / two workgroups per column quad)
+template __global__ void k_backward_cq3<2, true, false, 3, false, true>(PropArgs);
+template __global__ void k_backward_cq3<2, false, false, 2, false, true>(PropArgs);
+template __global__ void k_backward_cq3<2, true, false, 2, false, true>(PropArgs);
 #endif
 #elif JQ_VARIANT == 12  // quad layout, backward sweep split over two waves per column quad (mid-size ensembles)
 #include "jq_quad_split_kernels.h"

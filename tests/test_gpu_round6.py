@@ -339,6 +339,23 @@ def test_dense_cooperative_quad_kernels_match_the_oracle(jq, Ntot, N, Nc, m, oft
     t = check(jq, p, pcof, wa, rng)
     assert t["kernel_family"] == 1, t
     wa.close()
+    if Nc <= 3 and N <= 4:
+        # the backward sweep on three / one workgroup(s) per column quad: same operations per chain -- bit for bit (first chunks longer than the
+        # hand-off ring of the split kernels: 40 steps)
+        q, qcof = random_problem(jq, rng, Ntot, N, Nc, 2, 40, m, oft, structure)
+        res = {}
+        for tag, opts in (("three", {}), ("one", {"cq3": 0})):
+            wa = jq.Working_Arrays_HIP(q, qcof.size, options=opts)
+            o = jq.traceobjgrad(qcof, q, wa, False, True)
+            t = wa.last_timing()
+            assert (t["kernel_family"], t["kernel_band"], t["kernel_variant"]) == (8, 10, 3 if tag == "three" else 0), (t, wa.plan_info()["latency_split"])
+            res[tag] = o
+            wa.close()
+        for k in (0, 1, 5, 6):
+            assert np.array_equal(res["three"][k], res["one"][k])
+        from oracle.oracle import Oracle
+        r = Oracle(q, use_sparse=False).traceobjgrad(qcof)
+        assert reference_pass(res["three"][1], r["totalgrad"]) and reference_pass(res["three"][0], r["objfv"])
 
 
 @pytest.mark.parametrize("Ntot,Nc,oft,structure", [(17, 1, 1, False), (25, 2, 3, False), (32, 3, 2, False), (28, 2, 1, True)])
