@@ -723,11 +723,11 @@ __global__ __launch_bounds__(128 * NT + 256) void k_backward_cq_imr2(PropArgs a)
 // Roles 0 and 1: NT block waves + two reducer waves, the code of k_forward_cq_imr (one more barrier per step: behind it the stores
 // of the step are acknowledged and the counter is published).  Bit-identical to k_backward_cq_imr / _imr2.
 // grid = 24 * ceil(evaluations / 8), block = 64 * (NT + 2); a.park: the hand-off buffer, zeroed by the host before every launch.
-template <int NT>
+template <int NT, bool DN = false>
 __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq_imr3(PropArgs a)
 {
-    typedef typename CoopQ<NT>::Sh Sh;
-    typedef typename CoopQ<NT>::Nb Nb;
+    typedef typename CoopQ<NT, DN>::Sh Sh;
+    typedef typename CoopQ<NT, DN>::Nb Nb;
     const int role = ((int)blockIdx.x >> 3) % 3;
     const int quad = 8 * ((int)blockIdx.x / 24) + ((int)blockIdx.x & 7);
     const CqSetup<NT> s = cq_setup<NT>(a, quad >> 2, quad & 3);
@@ -759,7 +759,7 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq_imr3(PropArgs a)
         if (s.chain) return;      // (no reducer waves here)
         extern __shared__ __attribute__((aligned(16))) char smem2[];
         const int lane_ = s.lane_, wave = s.wave;
-        CoopQ<NT> c;
+        CoopQ<NT, DN> c;
         c.mt = wave, c.lane = lane_, c.xb = nullptr;
         WinRing& r = c.ring;      // (only the constant images are staged)
         r.smem = smem2, r.wave = wave, r.lane = lane_, r.nwaves = NT;
@@ -778,10 +778,10 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq_imr3(PropArgs a)
             Rec e;
             e.su = hd.load(n, 0, wave), e.sv = hd.load(n, 1, wave), e.smu = hd.load(n, 2, wave), e.snu = hd.load(n, 3, wave);
             const int wb = wave > 0 ? wave - 1 : wave, wa_ = wave + 1 < NT ? wave + 1 : wave;
-            e.nu.b = hd.load(n, 0, wb), e.nu.a = hd.load(n, 0, wa_);
-            e.nv.b = hd.load(n, 1, wb), e.nv.a = hd.load(n, 1, wa_);
-            if (wave == 0) e.nu.b = 0.0, e.nv.b = 0.0;
-            if (wave + 1 == NT) e.nu.a = 0.0, e.nv.a = 0.0;
+            const double ub_ = hd.load(n, 0, wb), ua_ = hd.load(n, 0, wa_), vb_ = hd.load(n, 1, wb), va_ = hd.load(n, 1, wa_);
+            const bool lo = wave == 0, hi = wave + 1 == NT;      // (zeros beyond the edge blocks)
+            e.nu = c.nb_make(lo ? 0.0 : ub_, hi ? 0.0 : ua_);
+            e.nv = c.nb_make(lo ? 0.0 : vb_, hi ? 0.0 : va_);
             return e;
         };
         Rec cur = fetch(0);
@@ -832,7 +832,6 @@ __global__ __launch_bounds__(64 * NT + 128) void k_backward_cq_imr3(PropArgs a)
         }
         return;
     }
-    constexpr bool DN = false;      // (the three-workgroup kernel exists for the 4 x 4 x n structure only)
     JQ_CQ_IMR_PROLOGUE
     (void)wsr;
     if (s.chain) {      // reducer waves: one solve and the publication barrier per time step (+ the start barrier of role 1, the last publication)

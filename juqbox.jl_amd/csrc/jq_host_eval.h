@@ -327,7 +327,7 @@ static int run_eval_impl(jq_handle* h, const double* pcof, int ncoeff, int nsamp
     GateHold gate_hold;
     bool cq3 = false;
     int cq_nr = 0;      // workgroups per column quad of the split backward sweep
-    if ((cq || imr_cq) && !imr_dq && adjoint) {
+    if ((cq || imr_cq) && adjoint) {
         const char* why = nullptr;
         cq_nr = 3 * nq_pad <= h->num_cu ? 3 : (cq && 2 * nq_pad <= h->num_cu && !(c3_set && c3_v == 3)) ? 2 : 0;
         // The consumer roles read the state the sweep starts from out of the state file (the carry of the trace products, first chunk

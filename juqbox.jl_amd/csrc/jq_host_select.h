@@ -188,7 +188,7 @@ template <int NT> __global__ void k_backward_cq_imr2(PropArgs);    // (state and
     extern template __global__ void k_backward_cq_imr<nt>(PropArgs);
 JQ_DECLCI(1) JQ_DECLCI(2) JQ_DECLCI(3) JQ_DECLCI(4) JQ_DECLCI(5) JQ_DECLCI(6) JQ_DECLCI(7)
 #undef JQ_DECLCI
-template <int NT> __global__ void k_backward_cq_imr3(PropArgs);    // (three workgroups per evaluation, as k_backward_cq3)
+template <int NT, bool DN = false> __global__ void k_backward_cq_imr3(PropArgs);    // (three workgroups per evaluation, as k_backward_cq3)
 #define JQ_DECLCI(nt) extern template __global__ void k_backward_cq_imr3<nt>(PropArgs);
 JQ_DECLCI(1) JQ_DECLCI(2) JQ_DECLCI(3) JQ_DECLCI(4) JQ_DECLCI(5) JQ_DECLCI(6) JQ_DECLCI(7)
 #undef JQ_DECLCI
@@ -201,12 +201,13 @@ static size_t cq_imr2_lds(const jq_handle* h, size_t lds_stage) { return lds_sta
 // one-set kernel of round 3)
 extern template __global__ void k_forward_cq_imr<2, true>(PropArgs);      // the dense policy (17 .. 32 levels without the structure)
 extern template __global__ void k_backward_cq_imr<2, true>(PropArgs);
+extern template __global__ void k_backward_cq_imr3<2, true>(PropArgs);
 static int select_cq_imr_kernels(jq_handle* h, bool two, bool three, bool dense, prop_kernel_t* fwd, prop_kernel_t* bwd)
 {
     if (dense) {
-        if (h->NT != 2 || two || three) return fail(h, JQ_EHIP, "internal error: dense implicit-midpoint cooperative-quad kernels selected for a plan they do not exist for");
+        if (h->NT != 2 || two) return fail(h, JQ_EHIP, "internal error: dense implicit-midpoint cooperative-quad kernels selected for a plan they do not exist for");
         *fwd = k_forward_cq_imr<2, true>;
-        *bwd = k_backward_cq_imr<2, true>;
+        *bwd = three ? k_backward_cq_imr3<2, true> : k_backward_cq_imr<2, true>;
         return JQ_OK;
     }
 #define JQ_PICKCI(nt)                            \

@@ -75,6 +75,7 @@ template __global__ void k_backward_cq_imr2<JQ_NT>(PropArgs);      // (state and
 #if JQ_NT == 2      // the dense policy (17 .. 32 levels without the structure)
 template __global__ void k_forward_cq_imr<2, true>(PropArgs);
 template __global__ void k_backward_cq_imr<2, true>(PropArgs);
+template __global__ void k_backward_cq_imr3<2, true>(PropArgs);
 #endif
 #elif JQ_VARIANT == 7
 #include "jq_quad_imr_kernels.h"

@@ -393,3 +393,17 @@ def test_dense_cooperative_quad_kernels_implicit_midpoint(jq, Ntot, Nc, oft, str
         assert abs(p.last_infidelity - inf) <= 1e-10 * abs(inf) and abs(p.last_leak - leak) <= max(1e-10 * abs(leak), 1e-14)
         assert np.linalg.norm(p.last_infidelity_grad - g) <= 1e-10 * np.linalg.norm(g)
         wa.close()
+    # the backward sweep on three workgroups per evaluation / on one: bit for bit (a first chunk longer than the hand-off ring)
+    q, qcof = random_problem(jq, rng, Ntot, 4, Nc, 2, 40, 3, oft, structure)
+    q.Integrator_id = jq.Implicit_Midpoint
+    q.linear_solver = jq.lsolver_object(solver=jq.JACOBI_SOLVER_M, max_iter=100, tol=1e-13, nrhs=4)
+    q.wmat = q.wmat_real.copy()
+    res = {}
+    for tag, opts in (("three", {}), ("one", {"cq3": 0})):
+        wa = jq.Working_Arrays_M_HIP(q, qcof.size, options=opts)
+        res[tag] = jq.traceobjgrad(qcof, q, wa, False, True)
+        t = wa.last_timing()
+        assert (t["kernel_family"], t["kernel_band"], t["kernel_variant"]) == (9, 10, 3 if tag == "three" else 0), (t, wa.plan_info()["latency_split"])
+        wa.close()
+    for k in (0, 1, 5, 6):
+        assert np.array_equal(res["three"][k], res["one"][k])
