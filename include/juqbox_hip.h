@@ -133,13 +133,15 @@ typedef struct jq_timing {
                                9 the same, implicit midpoint (N = 4)                                              */
     int32_t kernel_size;    /* template size parameter: NT (16-row tiles) for 0/1, NP for 2, NPJ for 3       */
     int32_t kernel_band;    /* block band of the MFMA families (9 = JQ_BW_OD: diagonal off-diagonal blocks,
-                               8 = JQ_BW_T4: 4x4 diagonal blocks + diagonal couplings, 7 = the same, quad layout) */
+                               8 = JQ_BW_T4: 4x4 diagonal blocks + diagonal couplings, 7 = the same, quad layout,
+                               10 = dense blocks on the cooperative-quad kernels: 17 .. 32 levels without the structure) */
     int32_t kernel_variant; /* variant of the backward sweep.  Family 8: workgroups (CUs) per column quad -- 3: state re-integration, adjoint
                                step and trace products pipelined over three workgroups (single evaluations, <= 80 cnot3 samples);
                                2: state re-integration | adjoint step + trace products (81 .. 128 samples); 22: more column quads than
                                CUs, backward sweep on k_backward_qsplit with two quads per workgroup.  Family 6: 24 = one slab per
                                workgroup with the state and the adjoint chain of a quad on two waves (k_backward_qsplit).  Family 3: 32 = the backward
-                               sweep's state and adjoint chain on two waves (k_backward_rowlane2).  Else 0 */
+                               sweep's state and adjoint chain on two waves (k_backward_rowlane2), 33 = state chain, adjoint chain and traces on
+                               three or four waves (k_backward_rowlane3).  Else 0 */
     int64_t mfma_backward;  /* the part of mfma_executed issued by the k_backward launches                  */
     double ms_allreduce;    /* multi-device handles: host wall time of the ONE all-reduce (group start .. result on the host);
                                0 for single-device handles (their caller runs the collective)                  */

@@ -86,9 +86,10 @@ extern "C" int jq_plan_info(const jq_handle* hh, char* buf, int32_t buflen)
         fam += std::string("{\"family\": ") + std::to_string(id) + ", \"name\": \"" + name + "\", \"max_" + unit + "\": " + std::to_string(mx) + "}";
     };
     const jq_handle* t = h->emb ? h->emb : h;
-    if (h->rl_npj > 0) add(3, "row-lane (VALU, lane per (row, column); backward sweep on two waves)", "columns", h->rl_max_cols);
+    if (h->rl_npj > 0) add(3, "row-lane (VALU, lane per (row, column); backward sweep on three or four waves, implicit midpoint: two)", "columns", h->rl_max_cols);
     if (h->lane_np > 0) add(2, "lane (VALU, lane per column)", "columns", h->lane_max_cols);
     if (t->cq_max_quads > 0) add(8, "cooperative quad (one 16-row block per wave)", "quads", t->cq_max_quads);
+    if (t->dq_max_quads > 0) add(8, "cooperative quad, dense blocks (17 .. 32 levels without the 4 x 4 x n structure; Neumann, Diagonal weights)", "quads", t->dq_max_quads);
     if (t->quad_max_slabs > 0) add(6, "quad layout (four columns per wave; 1 / 2 / 3 slabs per workgroup by round count)", "slabs", t->quad_max_slabs);
     if (t->coop_ok && t->NT >= 2) add(1, "cooperative (tile row per wave)", "slabs", t->coop_max_slabs);
     if (!t->big) add(0, "slab (wave per 16-column slab)", "slabs", 1LL << 30);
