@@ -319,13 +319,13 @@ def test_rowlane_ring_with_short_chunks_and_every_term_dispatch(jq, Ntot, N, Nc,
 # ---- (8) the dense policy of the cooperative-quad kernels: 17 .. 32 levels without the 4 x 4 x n structure ----------------------------------
 
 @pytest.mark.parametrize("Ntot,N,Nc,m,oft,structure", [(17, 4, 1, 3, 1, False), (20, 3, 2, 4, 3, False), (25, 4, 3, 5, 2, False), (32, 4, 2, 6, 1, False),
-                                                       (32, 2, 4, 1, 3, False), (27, 7, 2, 2, 1, True), (24, 16, 1, 3, 3, "od"), (30, 4, 2, 7, 2, False)])
+                                                       (32, 2, 4, 1, 3, False), (27, 7, 2, 2, 1, True), (24, 16, 1, 3, 3, "od"), (30, 4, 2, 7, 2, False), (24, 20, 2, 3, 1, False)])
 def test_dense_cooperative_quad_kernels_match_the_oracle(jq, Ntot, N, Nc, m, oft, structure):
     """Round 6: problems with two 16-row blocks and NO 4 x 4 x n structure (two five-level subsystems, operators in an eigenbasis, ...) ran their
     single evaluations on the cooperative kernels at 26 us per time step.  The cooperative-quad kernels now take them with a DENSE product
     (four v_mfma_f64_4x4x4_4b per 16 x 16 tile on the state register and its three lane rotations, jq_cq_kernels.h CoopQ<2, true>): every
     level count 17 .. 32, one to four controls, even and odd numbers of Neumann terms (the parities of the LDS exchange), all three objective
-    types (two backward passes), N < 4, N = 4 and N > 4 (several column quads per evaluation), chunks of odd length, ensembles with a
+    types (two backward passes), N < 4, N = 4, N > 4 (several column quads per evaluation) and N > 16 (two slabs per evaluation), chunks of odd length, ensembles with a
     ragged last slab, the state history -- against the oracle; option dq=0 gives the cooperative kernels back."""
     rng = np.random.default_rng(6800 + 31 * Ntot + m)
     p, pcof = random_problem(jq, rng, Ntot, N, Nc, 2, 11, m, oft, structure)
